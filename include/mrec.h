@@ -1,0 +1,208 @@
+/*
+ * mrec.h -- C-ABI of libmrec_hip.so, the MI355X (gfx950) replacement for the MindSpore
+ * primitives that mindspore-lab/mindrec invokes on its embedding hot path.
+ *
+ * The reference's boundary for this path is a *Python operator* boundary (Primitive.__call__ on
+ * framework-owned tensors); there is no FFI in /root/reference to mirror, so every entry point
+ * below cites the reference call site whose MindSpore primitive it replaces.  INTEGRATION.md
+ * shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. a torch tensor's data_ptr())
+ *     unless the name ends in `_host`;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never synchronises,
+ *     never allocates: scratch comes from the caller through (ws, ws_bytes), sized by the
+ *     matching *_workspace_bytes query, so calls are hipGraph-capturable;
+ *   - return value: 0 = MREC_OK, <0 = error code below; nothing throws;
+ *   - ids/keys are int32 (`_i32`) or int64 (`_i64`); rows are fp32; `ld` = row stride in floats;
+ *   - counts that are only known on the device (number of unique ids) live in device int64 words.
+ */
+#ifndef MREC_H_
+#define MREC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MREC_OK 0
+#define MREC_EINVAL (-1)       /* bad argument (null pointer, negative size, misaligned row) */
+#define MREC_EWORKSPACE (-2)   /* workspace too small */
+#define MREC_EUNSUPPORTED (-3) /* shape outside what the kernels cover */
+#define MREC_EHIP (-4)         /* a HIP runtime call failed (see mrec_last_hip_error) */
+#define MREC_ENODEVICE (-5)    /* no gfx950 device / kernel image not loadable */
+
+const char* mrec_strerror(int code);
+int mrec_last_hip_error(void);
+int mrec_version(void);
+/* 0 when a HIP device is visible and the gfx950 code object loads; MREC_ENODEVICE otherwise. */
+int mrec_device_ok(void);
+
+/* ---- table initialisation --------------------------------------------------------------
+ * initializer('normal') of nn.EmbeddingLookup / MapParameter default_value
+ * (models/wide_deep/default_config.yaml:41; mindspore_rec/ops/embedding.py:88,141).
+ * out[r, c] = sigma * N01(seed, row0 + r, c) from the counter-based generator of
+ * csrc/mrec_rng.h (bit-identical to the oracle's), written straight into HBM. */
+int mrec_fill_normal_f32(float* out, int64_t nrows, int32_t D, int64_t ld, uint64_t seed,
+                         int64_t row0, float sigma, void* stream);
+
+/* ---- ops.Unique --------------------------------------------------------------------------
+ * mindspore_rec/ops/embedding.py:153,192; models/wide_deep/src/wide_and_deep.py:212.
+ * uniq keeps first-occurrence order (MindSpore CPU kernel), uniq[inv[i]] == ids[i].
+ * uniq has room for n entries; *n_uniq_dev receives U. */
+int mrec_dedup_workspace_bytes(int64_t n, size_t* out);
+int mrec_dedup_i32(const int32_t* ids, int64_t n, int32_t* uniq, int32_t* inv, int64_t* n_uniq_dev,
+                   void* ws, size_t ws_bytes, void* stream);
+int mrec_dedup_i64(const int64_t* ids, int64_t n, int64_t* uniq, int32_t* inv, int64_t* n_uniq_dev,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* ---- inverted index of a Unique result ---------------------------------------------------
+ * Groups positions 0..n-1 by inv[] (stable: ascending position inside each group).  This is the
+ * index the optimizer-side RowTensor dedup (Unique + UnsortedSegmentSum) needs:
+ * sorted_seg[e] = inv[sorted_pos[e]] non-decreasing; seg_offsets[u] = first e of group u,
+ * seg_offsets[U] = n  (seg_offsets has room for n+1 entries). */
+int mrec_group_workspace_bytes(int64_t n, size_t* out);
+int mrec_group_by_inverse(const int32_t* inv, int64_t n, int32_t* sorted_pos, int32_t* sorted_seg,
+                          int32_t* seg_offsets, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- ops.Gather / SparseGatherV2 / EmbeddingLookup ----------------------------------------
+ * mindspore_rec/ops/embedding.py:150,194; models/deep_and_cross/src/deep_and_cross.py:199;
+ * nn.EmbeddingLookup at models/wide_deep/src/wide_and_deep.py:277-290.
+ * out[i, :] = table[ids[i], :] * (row_scale ? row_scale[i] : 1); ids outside [0,V) give zeros.
+ * row_scale fuses the mask multiply of wide_and_deep.py:303,308 (nullable).  out is [n, D]
+ * contiguous. */
+int mrec_gather_rows_f32_i32(const float* table, int64_t V, int64_t ld, int32_t D, const int32_t* ids,
+                             int64_t n, const float* row_scale, float* out, void* stream);
+int mrec_gather_rows_f32_i64(const float* table, int64_t V, int64_t ld, int32_t D, const int64_t* ids,
+                             int64_t n, const float* row_scale, float* out, void* stream);
+
+/* Wide branch of WideDeepModel.construct (wide_and_deep.py:300,303-306) in one pass:
+ * out[b] = sum_f w[ids[b,f]] * wts[b,f] + *bias_dev   (w is the [V,1] wide table). */
+int mrec_wide_sum_f32_i32(const float* w, int64_t V, const int32_t* ids, const float* wts, int64_t B,
+                          int32_t F, const float* bias_dev, float* out, void* stream);
+int mrec_wide_sum_f32_i64(const float* w, int64_t V, const int64_t* ids, const float* wts, int64_t B,
+                          int32_t F, const float* bias_dev, float* out, void* stream);
+
+/* ---- sparse gradient apply ----------------------------------------------------------------
+ * All three take the inverted index (sorted_pos, sorted_seg, seg_offsets) of the step's ids and
+ * the per-position row gradients g[n, D] (row stride ldg).  Contribution i is
+ * (g[i,:] * row_scale[i]) * grad_scale, summed per unique id in ascending position order for
+ * groups that fit one 16-entry window, and as a fixed-order tree of window partials otherwise
+ * (bitwise reproducible run to run either way).  uniq maps group -> table row. */
+int mrec_sparse_apply_workspace_bytes(int64_t n, int32_t D, size_t* out);
+
+/* ops.UnsortedSegmentSum (bprop of Gather; models/wide_deep/op_precision.ini:2-3):
+ * out[u, :] = sum of contributions of group u, u < U; out is [>=U, D] contiguous. */
+int mrec_segment_sum_f32(const int32_t* sorted_pos, const int32_t* sorted_seg, const int32_t* seg_offsets,
+                         int64_t n, const float* g, int64_t ldg, const float* row_scale, float grad_scale,
+                         int32_t D, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* nn.LazyAdam on a RowTensor gradient (wide_and_deep.py:420-422).  b1_pow/b2_pow are
+ * beta^t AFTER this step's multiply.  Rows outside [0,V) are skipped. */
+int mrec_sparse_lazy_adam_f32_i32(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D,
+                                  const int32_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                  const int32_t* seg_offsets, int64_t n, const float* g, int64_t ldg,
+                                  const float* row_scale, float lr, float b1, float b2, float eps,
+                                  float b1_pow, float b2_pow, float grad_scale, int nesterov, void* ws,
+                                  size_t ws_bytes, void* stream);
+int mrec_sparse_lazy_adam_f32_i64(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D,
+                                  const int64_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                  const int32_t* seg_offsets, int64_t n, const float* g, int64_t ldg,
+                                  const float* row_scale, float lr, float b1, float b2, float eps,
+                                  float b1_pow, float b2_pow, float grad_scale, int nesterov, void* ws,
+                                  size_t ws_bytes, void* stream);
+
+/* nn.FTRL sparse apply (FusedSparseFtrl; wide_and_deep.py:423-430). */
+int mrec_sparse_ftrl_f32_i32(float* var, float* accum, float* linear, int64_t V, int64_t ld, int32_t D,
+                             const int32_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                             const int32_t* seg_offsets, int64_t n, const float* g, int64_t ldg,
+                             const float* row_scale, float lr, float l1, float l2, float lr_power,
+                             float grad_scale, void* ws, size_t ws_bytes, void* stream);
+int mrec_sparse_ftrl_f32_i64(float* var, float* accum, float* linear, int64_t V, int64_t ld, int32_t D,
+                             const int64_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                             const int32_t* seg_offsets, int64_t n, const float* g, int64_t ldg,
+                             const float* row_scale, float lr, float l1, float l2, float lr_power,
+                             float grad_scale, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- dense optimizers (whole tensor) ------------------------------------------------------
+ * nn.Adam / nn.FTRL on dense gradients (wide_and_deep.py:435-445; deep_and_cross.py:342-344). */
+int mrec_dense_adam_f32(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1,
+                        float b2, float eps, float b1_pow, float b2_pow, float grad_scale, int nesterov,
+                        void* stream);
+int mrec_dense_ftrl_f32(float* var, float* accum, float* linear, const float* g, int64_t n, float lr,
+                        float l1, float l2, float lr_power, float grad_scale, void* stream);
+
+/* ---- MapParameter key index ---------------------------------------------------------------
+ * mindspore.experimental.MapParameter as built by HashEmbeddingLookup
+ * (mindspore_rec/ops/embedding.py:136-146) and driven by MapTensorGet/Put/Erase
+ * (embedding.py:149,193,199; README.md:160-205).  The table is split MI355X-style into a key
+ * index (open addressing, this API) and dense row storage owned by the caller: get/put/apply on
+ * the rows reuse the dense gather / sparse-apply kernels above with the row numbers returned here.
+ *
+ * The handle is a host object; its slot arrays live in caller-provided device memory
+ * (`mem`, mrec_map_bytes(capacity) bytes, 256-B aligned).  Keys may be any int64 (int32 keys are
+ * widened by the caller); MindRec reserves -1 and -2 (embedding.py:55-56) and so do we not: no
+ * key value is reserved here.  Rows are handed out in order 0,1,2,... of first insertion
+ * (deterministic: misses are numbered in the order they appear in `keys`); erased rows go to a
+ * free list and are reused in erase order once fresh rows run out. */
+typedef struct mrec_map mrec_map_t;
+int mrec_map_bytes(int64_t capacity_rows, size_t* out);
+int mrec_map_create(mrec_map_t** out, void* mem, size_t mem_bytes, int64_t capacity_rows, void* stream);
+int mrec_map_destroy(mrec_map_t* h);
+/* Device words: [0] = rows handed out so far (high-water mark), [1] = live keys,
+ * [2] = keys dropped because the table was full (sticky error counter). */
+const int64_t* mrec_map_counters_dev(const mrec_map_t* h);
+int mrec_map_workspace_bytes(int64_t n, size_t* out);
+/* keys must be unique within the call (run mrec_dedup first).  rows_out[i] = row of keys[i];
+ * a missing key gets a new row when insert != 0 (is_new_out[i] = 1, caller initialises the row),
+ * else rows_out[i] = -1. */
+int mrec_map_find_or_insert(mrec_map_t* h, const int64_t* keys, int64_t n, int insert, int32_t* rows_out,
+                            uint8_t* is_new_out, void* ws, size_t ws_bytes, void* stream);
+/* Removes keys (unique within the call); missing keys are ignored. */
+int mrec_map_erase(mrec_map_t* h, const int64_t* keys, int64_t n, void* ws, size_t ws_bytes, void* stream);
+/* Writes the live (key,row) pairs in row order; *n_out_dev receives the count. */
+int mrec_map_export(mrec_map_t* h, int64_t* keys_out, int32_t* rows_out, int64_t* n_out_dev, void* ws,
+                    size_t ws_bytes, void* stream);
+/* Default-value rows for newly inserted keys: table[rows[i], :] = sigma * N01(seed, keys[i], c)
+ * where is_new[i] (all i when is_new is null); sigma < 0 selects the constant `fill`. */
+int mrec_init_rows_f32(float* table, int64_t ld, int32_t D, const int32_t* rows, const int64_t* keys,
+                       const uint8_t* is_new, int64_t n, uint64_t seed, float sigma, float fill, void* stream);
+/* MapTensorPut: table[rows[i], :] = vals[i, :] (rows < 0 skipped). */
+int mrec_scatter_rows_f32(float* table, int64_t ld, int32_t D, const int32_t* rows, int64_t n,
+                          const float* vals, void* stream);
+
+/* ---- DCN-v1 cross layers -----------------------------------------------------------------
+ * CrossLayer.construct, models/deep_and_cross/src/deep_and_cross.py:139-149, all L layers of
+ * DeepCrossModel.construct (:300-306) in one HBM pass: y = x0*(x_l . w_l) + b_l + x_l.
+ * w, b are [L, D]; x0, out, dy, dx0 are [B, D] contiguous.  The backward recomputes x_l. */
+int mrec_cross_layers_f32(const float* x0, const float* w, const float* b, int32_t L, int64_t B, int32_t D,
+                          float* out, void* stream);
+int mrec_cross_layers_bwd_workspace_bytes(int32_t L, int64_t B, int32_t D, size_t* out);
+int mrec_cross_layers_bwd_f32(const float* x0, const float* w, const float* b, int32_t L, int64_t B,
+                              int32_t D, const float* dy, float* dx0, float* dw, float* db, void* ws,
+                              size_t ws_bytes, void* stream);
+
+/* ---- row-shard routing (hybrid-parallel embedding, README.md:140-144) --------
+ * owner(id) = id mod n_shards, local row = id div n_shards.  Stable bucketing of ids by owner so
+ * one RCCL all-to-all can ship them: send_local[k] = local row of the k-th id in bucket order,
+ * send_perm[k] = its original position, counts_dev[s] = bucket sizes (int64). */
+int mrec_shard_route_workspace_bytes(int64_t n, int32_t n_shards, size_t* out);
+int mrec_shard_route_i32(const int32_t* ids, int64_t n, int32_t n_shards, int32_t* send_local,
+                         int32_t* send_perm, int64_t* counts_dev, void* ws, size_t ws_bytes, void* stream);
+int mrec_shard_route_i64(const int64_t* ids, int64_t n, int32_t n_shards, int64_t* send_local,
+                         int32_t* send_perm, int64_t* counts_dev, void* ws, size_t ws_bytes, void* stream);
+/* out[send_perm[k], :] = rows[k, :] * (row_scale ? row_scale[send_perm[k]] : 1): undoes the
+ * bucketing on the returned embedding rows. */
+int mrec_shard_unroute_f32(const float* rows, const int32_t* send_perm, int64_t n, int32_t D,
+                           const float* row_scale, float* out, void* stream);
+/* rows_out[k, :] = g[send_perm[k], :] * (row_scale ? row_scale[send_perm[k]] : 1): buckets the
+ * row gradients for the backward all-to-all. */
+int mrec_shard_route_rows_f32(const float* g, int64_t ldg, const int32_t* send_perm, int64_t n, int32_t D,
+                              const float* row_scale, float* rows_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MREC_H_ */

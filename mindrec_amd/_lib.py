@@ -1,0 +1,115 @@
+"""ctypes binding of libmrec_hip.so (C-ABI declared in include/mrec.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails, this module
+raises.  torch is used only as the owner of device memory and streams.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmrec_hip.so")
+
+MREC_OK = 0
+_ERR_NAMES = {-1: "EINVAL", -2: "EWORKSPACE", -3: "EUNSUPPORTED", -4: "EHIP", -5: "ENODEVICE"}
+
+
+class MrecError(RuntimeError):
+    """A libmrec_hip.so entry point returned a non-zero code."""
+
+    def __init__(self, fn, code, detail=""):
+        self.code = code
+        super().__init__(f"{fn} failed: MREC_{_ERR_NAMES.get(code, code)} {detail}".rstrip())
+
+
+_lib = None
+
+_vp, _i64, _i32, _u64, _f32, _int, _sz = (C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_float, C.c_int,
+                                         C.c_size_t)
+_szp = C.POINTER(C.c_size_t)
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+_SIGS = {
+    "mrec_last_hip_error": [],
+    "mrec_version": [],
+    "mrec_device_ok": [],
+    "mrec_fill_normal_f32": [_vp, _i64, _i32, _i64, _u64, _i64, _f32, _vp],
+    "mrec_dedup_workspace_bytes": [_i64, _szp],
+    "mrec_dedup_i32": [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_dedup_i64": [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_group_workspace_bytes": [_i64, _szp],
+    "mrec_group_by_inverse": [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_gather_rows_f32_i32": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
+    "mrec_gather_rows_f32_i64": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
+    "mrec_wide_sum_f32_i32": [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
+    "mrec_wide_sum_f32_i64": [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
+    "mrec_sparse_apply_workspace_bytes": [_i64, _i32, _szp],
+    "mrec_segment_sum_f32": [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _f32, _i32, _vp, _vp, _sz, _vp],
+    "mrec_sparse_lazy_adam_f32_i32": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
+                                      _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _sz, _vp],
+    "mrec_sparse_lazy_adam_f32_i64": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
+                                      _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _sz, _vp],
+    "mrec_sparse_ftrl_f32_i32": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
+                                 _f32, _f32, _f32, _f32, _f32, _vp, _sz, _vp],
+    "mrec_sparse_ftrl_f32_i64": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
+                                 _f32, _f32, _f32, _f32, _f32, _vp, _sz, _vp],
+    "mrec_dense_adam_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp],
+    "mrec_dense_ftrl_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp],
+    "mrec_map_bytes": [_i64, _szp],
+    "mrec_map_create": [C.POINTER(_vp), _vp, _sz, _i64, _vp],
+    "mrec_map_destroy": [_vp],
+    "mrec_map_counters_dev": [_vp],
+    "mrec_map_workspace_bytes": [_i64, _szp],
+    "mrec_map_find_or_insert": [_vp, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp],
+    "mrec_map_erase": [_vp, _vp, _i64, _vp, _sz, _vp],
+    "mrec_map_export": [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_init_rows_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _u64, _f32, _f32, _vp],
+    "mrec_scatter_rows_f32": [_vp, _i64, _i32, _vp, _i64, _vp, _vp],
+    "mrec_cross_layers_f32": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp],
+    "mrec_cross_layers_bwd_workspace_bytes": [_i32, _i64, _i32, _szp],
+    "mrec_cross_layers_bwd_f32": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_shard_route_workspace_bytes": [_i64, _i32, _szp],
+    "mrec_shard_route_i32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_shard_route_i64": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_shard_unroute_f32": [_vp, _vp, _i64, _i32, _vp, _vp, _vp],
+    "mrec_shard_route_rows_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp],
+}
+_RESTYPES = {"mrec_strerror": C.c_char_p, "mrec_map_counters_dev": _vp}
+
+EXPORTED = sorted(list(_SIGS) + ["mrec_strerror"])
+
+
+def lib():
+    """Loads libmrec_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(mindrec_amd has no CPU fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            f = getattr(l, name)
+            f.argtypes = args
+            f.restype = _RESTYPES.get(name, C.c_int)
+        l.mrec_strerror.argtypes = [C.c_int]
+        l.mrec_strerror.restype = C.c_char_p
+        _lib = l
+    return _lib
+
+
+def check(fn, code):
+    if code != MREC_OK:
+        detail = ""
+        if code == -4:
+            detail = f"(hipError {lib().mrec_last_hip_error()})"
+        raise MrecError(fn, code, detail)
+
+
+def call(name, *args):
+    check(name, getattr(lib(), name)(*args))
+
+
+def query_bytes(name, *args):
+    out = C.c_size_t(0)
+    check(name, getattr(lib(), name)(*args, C.byref(out)))
+    return int(out.value)

@@ -1,0 +1,421 @@
+// mrec_apply.hip -- sparse gradient apply: UnsortedSegmentSum fused with the LazyAdam / FTRL row
+// update (or a plain store), for gfx950.
+//
+// Replaces, in one HBM pass, what the reference gets from MindSpore as
+//   RowTensor dedup (Unique + UnsortedSegmentSum)  ->  FusedSparseLazyAdam / FusedSparseFtrl
+// for the optimizers built at models/wide_deep/src/wide_and_deep.py:415-433 and applied at :490-492
+// (formulas: SURVEY.md A.4, A.5).
+//
+// Why no atomics: float atomics run at ~1.3 TB/s chip-wide on MI355X against ~6 TB/s for plain
+// loads/stores, and their sum order is not reproducible.  Instead the step's inverted index
+// (mrec_group_by_inverse) lists, per unique id, the positions that reference it, in ascending
+// order.  The sorted list is cut into windows of AW entries; a lane-group of lpr = D/4 lanes
+// (float4 per lane; D = 80 -> 20 lanes, 3 groups per wave64) walks one window sequentially,
+// accumulating the gathered gradient rows in registers, and at the end of every id's run reads
+// p/m/v (or var/accum/linear) once, updates, and writes them back once.  Loads for AB entries
+// (gradient rows and state rows) are issued together before the first dependent op, so every
+// lane-group keeps up to 4*AB 16-byte loads in flight.
+//
+// Runs that cross a window boundary (duplicate-heavy ids, e.g. Criteo's 13 constant dense-field ids
+// with 16384 copies each) leave per-window partial sums in a carry buffer and their owning window
+// in a work list; a second launch sums each run's partials with a whole 256-thread block in a
+// fixed tree order and applies the update.  Both passes are bitwise reproducible.
+#include "mrec_common.h"
+#include "mrec_optim.h"
+
+namespace {
+
+constexpr int AW = 16;  // sorted entries per window (one lane-group walks one window)
+constexpr int AB = 4;   // entries whose loads are issued together
+
+template <int VEC> struct Vf;
+template <> struct Vf<4> { float4 v; };
+template <> struct Vf<1> { float v; };
+
+__device__ __forceinline__ void vload(Vf<4>& r, const float* p) { r.v = *(const float4*)p; }
+__device__ __forceinline__ void vload(Vf<1>& r, const float* p) { r.v = *p; }
+__device__ __forceinline__ void vstore(float* p, const Vf<4>& x) { *(float4*)p = x.v; }
+__device__ __forceinline__ void vstore(float* p, const Vf<1>& x) { *p = x.v; }
+__device__ __forceinline__ void vzero(Vf<4>& r) { r.v = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void vzero(Vf<1>& r) { r.v = 0.f; }
+__device__ __forceinline__ void vmul(Vf<4>& x, float s) { x.v.x *= s; x.v.y *= s; x.v.z *= s; x.v.w *= s; }
+__device__ __forceinline__ void vmul(Vf<1>& x, float s) { x.v *= s; }
+__device__ __forceinline__ void vadd(Vf<4>& a, const Vf<4>& b) {
+    a.v.x = a.v.x + b.v.x; a.v.y = a.v.y + b.v.y; a.v.z = a.v.z + b.v.z; a.v.w = a.v.w + b.v.w;
+}
+__device__ __forceinline__ void vadd(Vf<1>& a, const Vf<1>& b) { a.v = a.v + b.v; }
+
+// ---- updaters: NS state arrays, each [V, ld]; apply() sees one lane's VEC elements -------------
+struct UpdAdam {
+    static constexpr int NS = 3;
+    static constexpr bool kLoad = true;
+    float* s[3];
+    AdamH h;
+    __device__ __forceinline__ void elem(float* st, float g) const { adam_elem(st[0], st[1], st[2], g, h); }
+};
+struct UpdFtrl {
+    static constexpr int NS = 3;
+    static constexpr bool kLoad = true;
+    float* s[3];
+    FtrlH h;
+    __device__ __forceinline__ void elem(float* st, float g) const { ftrl_elem(st[0], st[1], st[2], g, h); }
+};
+struct UpdStore {  // UnsortedSegmentSum: out[u,:] = sum
+    static constexpr int NS = 1;
+    static constexpr bool kLoad = false;
+    float* s[1];
+    __device__ __forceinline__ void elem(float* st, float g) const { st[0] = g; }
+};
+
+template <class Upd>
+__device__ __forceinline__ void upd_apply(const Upd& u, Vf<4> (&st)[Upd::NS], const Vf<4>& g) {
+    float a[Upd::NS];
+#define MREC_COMP(c)                                              \
+    for (int i = 0; i < Upd::NS; ++i) a[i] = st[i].v.c;           \
+    u.elem(a, g.v.c);                                             \
+    for (int i = 0; i < Upd::NS; ++i) st[i].v.c = a[i];
+    MREC_COMP(x) MREC_COMP(y) MREC_COMP(z) MREC_COMP(w)
+#undef MREC_COMP
+}
+template <class Upd>
+__device__ __forceinline__ void upd_apply(const Upd& u, Vf<1> (&st)[Upd::NS], const Vf<1>& g) {
+    float a[Upd::NS];
+    for (int i = 0; i < Upd::NS; ++i) a[i] = st[i].v;
+    u.elem(a, g.v);
+    for (int i = 0; i < Upd::NS; ++i) st[i].v = a[i];
+}
+
+struct ApplyGeom { int lpr; int G; int D; };
+
+// uniq == nullptr means "row = group number" (segment-sum into a dense [U, D] output).
+template <class K>
+__device__ __forceinline__ int64_t seg_row(const K* uniq, int seg) {
+    return uniq ? (int64_t)uniq[seg] : (int64_t)seg;
+}
+
+template <int VEC, class K, class Upd>
+__global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
+                                                    const int* __restrict__ spos, const int* __restrict__ sseg,
+                                                    int n, const float* __restrict__ g, int64_t ldg,
+                                                    const float* __restrict__ rscale, float gscale, ApplyGeom gm,
+                                                    float* __restrict__ carry_head, float* __restrict__ carry_tail,
+                                                    int* __restrict__ owners, int* __restrict__ n_owners) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
+    if (grp >= gm.G) return;  // spare lanes; this kernel has no barriers
+    const int64_t sw = ((int64_t)blockIdx.x * 4 + wave) * gm.G + grp;
+    const int64_t s64 = sw * AW;
+    if (s64 >= n) return;
+    const int s = (int)s64;
+    const int e_end = (s + AW < n) ? s + AW : n;
+    const int col = sub * VEC;
+
+    const int first_seg = sseg[s];
+    const bool head_open = (s > 0) && (sseg[s - 1] == first_seg);
+    int seg_cur = first_seg;
+    int seg_prev = -3;  // group of the entry before the current batch (unused for the first batch)
+    Vf<VEC> acc;
+    vzero(acc);
+
+    for (int j0 = s; j0 < e_end; j0 += AB) {
+        int seg[AB + 1];
+        bool valid[AB], is_end[AB], is_start[AB], open[AB], upd_ok[AB];
+        int64_t roff[AB];
+        Vf<VEC> gv[AB];
+        Vf<VEC> st[AB][Upd::NS];
+        float rs[AB];
+        seg[0] = seg_cur;
+        // ---- issue all loads of this batch
+#pragma unroll
+        for (int k = 0; k < AB; ++k) {
+            const int e = j0 + k;
+            valid[k] = e < e_end;
+            seg[k + 1] = (e + 1 < n) ? sseg[(e + 1 < n) ? e + 1 : e] : -2;
+            int pos = 0;
+            if (valid[k]) pos = spos[e];
+            rs[k] = 1.0f;
+            vzero(gv[k]);
+            if (valid[k]) {
+                vload(gv[k], g + (int64_t)pos * ldg + col);
+                if (rscale) rs[k] = rscale[pos];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < AB; ++k) {
+            const int e = j0 + k;
+            is_start[k] = (e == s) || (seg[k] != (k > 0 ? seg[k - 1] : seg_prev));
+            is_end[k] = valid[k] && (seg[k + 1] != seg[k]);
+            open[k] = head_open && (seg[k] == first_seg);
+            upd_ok[k] = false;
+            roff[k] = 0;
+            if (is_end[k] && !open[k]) {
+                const int64_t row = seg_row<K>(uniq, seg[k]);
+                if (row >= 0 && row < V) {
+                    upd_ok[k] = true;
+                    roff[k] = row * ld + col;
+                    if (Upd::kLoad) {
+#pragma unroll
+                        for (int i = 0; i < Upd::NS; ++i) vload(st[k][i], upd.s[i] + roff[k]);
+                    }
+                }
+            }
+        }
+        // ---- consume
+#pragma unroll
+        for (int k = 0; k < AB; ++k) {
+            if (!valid[k]) continue;
+            if (rscale) vmul(gv[k], rs[k]);
+            vmul(gv[k], gscale);
+            if (is_start[k]) acc = gv[k]; else vadd(acc, gv[k]);
+            if (is_end[k]) {
+                if (open[k]) {
+                    vstore(carry_head + sw * gm.D + col, acc);
+                } else if (upd_ok[k]) {
+                    upd_apply<Upd>(upd, st[k], acc);
+#pragma unroll
+                    for (int i = 0; i < Upd::NS; ++i) vstore(upd.s[i] + roff[k], st[k][i]);
+                }
+            }
+        }
+        seg_prev = seg[AB - 1];
+        seg_cur = seg[AB];
+    }
+    // run continues past this window?
+    const int last_seg = sseg[e_end - 1];
+    if (e_end < n && sseg[e_end] == last_seg) {
+        if (head_open && last_seg == first_seg) {
+            vstore(carry_head + sw * gm.D + col, acc);  // window lies wholly inside one run
+        } else {
+            vstore(carry_tail + sw * gm.D + col, acc);
+            if (sub == 0) owners[atomicAdd(n_owners, 1)] = (int)sw;
+        }
+    }
+}
+
+// One block per run that crosses windows: partial 0 is the owner's tail, partials 1..k are the
+// heads of the following k windows.  Lane-groups take partials round-robin (fixed assignment),
+// then group 0 adds the per-group sums in group order.
+template <int VEC, class K, class Upd>
+__global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
+                                                    const int* __restrict__ sseg,
+                                                    const int* __restrict__ seg_offsets, int n, ApplyGeom gm,
+                                                    const float* __restrict__ carry_head,
+                                                    const float* __restrict__ carry_tail,
+                                                    const int* __restrict__ owners,
+                                                    const int* __restrict__ n_owners) {
+    __shared__ float red[256 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
+    const bool active = grp < gm.G;
+    const int col = sub * VEC;
+    const int NG = 4 * gm.G;
+    const int gi = wave * gm.G + grp;
+    const int no = *n_owners;
+    for (int o = blockIdx.x; o < no; o += gridDim.x) {
+        const int sw = owners[o];
+        const int last_e = ((sw + 1) * AW < n ? (sw + 1) * AW : n) - 1;
+        const int u = sseg[last_e];
+        const int seg_end = seg_offsets[u + 1];
+        const int k = (seg_end - 1) / AW - sw;  // number of head partials (>= 1)
+        Vf<VEC> acc;
+        vzero(acc);
+        bool has = false;
+        if (active) {
+            for (int t0 = gi; t0 <= k; t0 += NG * AB) {
+                Vf<VEC> x[AB];
+#pragma unroll
+                for (int q = 0; q < AB; ++q) {
+                    const int t = t0 + q * NG;
+                    vzero(x[q]);
+                    if (t <= k) {
+                        const float* src = (t == 0) ? carry_tail + (int64_t)sw * gm.D : carry_head + (int64_t)(sw + t) * gm.D;
+                        vload(x[q], src + col);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < AB; ++q) {
+                    if (t0 + q * NG <= k) {
+                        if (has) vadd(acc, x[q]); else { acc = x[q]; has = true; }
+                    }
+                }
+            }
+            vstore(red + gi * gm.D + col, acc);
+        }
+        __syncthreads();
+        if (active && gi == 0) {
+            const int ng = (k + 1 < NG) ? k + 1 : NG;
+            for (int q = 1; q < ng; ++q) {
+                Vf<VEC> x;
+                vload(x, red + q * gm.D + col);
+                vadd(acc, x);
+            }
+            const int64_t row = seg_row<K>(uniq, u);
+            if (row >= 0 && row < V) {
+                const int64_t roff = row * ld + col;
+                Vf<VEC> st[Upd::NS];
+                if (Upd::kLoad) {
+#pragma unroll
+                    for (int i = 0; i < Upd::NS; ++i) vload(st[i], upd.s[i] + roff);
+                }
+                upd_apply<Upd>(upd, st, acc);
+#pragma unroll
+                for (int i = 0; i < Upd::NS; ++i) vstore(upd.s[i] + roff, st[i]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+struct ApplyWs { float* carry_head; float* carry_tail; int* owners; int* n_owners; };
+
+size_t apply_ws_bytes(int64_t n, int32_t D) {
+    const size_t nsw = (size_t)mrec_cdiv(n ? n : 1, AW);
+    const int Dc = D > 256 ? 256 : D;
+    return mrec_align_up(nsw * Dc * 4, 256) * 2 + mrec_align_up(nsw * 4, 256) + 256;
+}
+
+// One launch pair over columns [c0, c0+Dc) of every array.
+template <class K, class Upd>
+int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, const int* sseg,
+               const int* seg_offsets, int64_t n, const float* g, int64_t ldg, const float* rscale, float gscale,
+               int Dc, bool vec, const ApplyWs& w, hipStream_t st) {
+    ApplyGeom gm;
+    gm.D = Dc;
+    gm.lpr = vec ? Dc / 4 : Dc;
+    gm.G = 64 / gm.lpr;
+    const int64_t nsw = mrec_cdiv(n, AW);
+    const unsigned blocks = (unsigned)mrec_cdiv(nsw, (int64_t)4 * gm.G);
+    MREC_HIP_CHECK(hipMemsetAsync(w.n_owners, 0, sizeof(int), st));
+    unsigned lblocks = (unsigned)(nsw < 2048 ? nsw : 2048);
+    if (vec) {
+        k_apply_main<4, K, Upd><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
+                                                       w.carry_head, w.carry_tail, w.owners, w.n_owners);
+        k_apply_long<4, K, Upd><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
+                                                        w.carry_head, w.carry_tail, w.owners, w.n_owners);
+    } else {
+        k_apply_main<1, K, Upd><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
+                                                       w.carry_head, w.carry_tail, w.owners, w.n_owners);
+        k_apply_long<1, K, Upd><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
+                                                        w.carry_head, w.carry_tail, w.owners, w.n_owners);
+    }
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+template <class K, class Upd>
+int apply_impl(Upd upd, int64_t V, int64_t ld, int32_t D, const K* uniq, const int32_t* spos, const int32_t* sseg,
+               const int32_t* seg_offsets, int64_t n, const float* g, int64_t ldg, const float* rscale,
+               float gscale, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || D <= 0 || V < 0 || ld < D || ldg < D) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!spos || !sseg || !seg_offsets || !g || !ws) return MREC_EINVAL;
+    for (int i = 0; i < Upd::NS; ++i) if (!upd.s[i]) return MREC_EINVAL;
+    if (n > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
+    if (ws_bytes < apply_ws_bytes(n, D)) return MREC_EWORKSPACE;
+    const size_t nsw = (size_t)mrec_cdiv(n, AW);
+    const int Dc_max = D > 256 ? 256 : D;
+    MrecArena a(ws, ws_bytes);
+    ApplyWs w;
+    w.carry_head = a.take<float>(nsw * Dc_max);
+    w.carry_tail = a.take<float>(nsw * Dc_max);
+    w.owners = a.take<int>(nsw);
+    w.n_owners = a.take<int>(1);
+    if (!a.ok) return MREC_EWORKSPACE;
+    bool aligned = (ld % 4 == 0) && (ldg % 4 == 0) && al16(g);
+    for (int i = 0; i < Upd::NS; ++i) aligned = aligned && al16(upd.s[i]);
+    const bool vec = aligned && (D % 4 == 0);
+    const int CB = vec ? 256 : 64;  // columns per launch
+    for (int c0 = 0; c0 < D; c0 += CB) {
+        const int Dc = (D - c0 < CB) ? D - c0 : CB;
+        Upd u2 = upd;
+        for (int i = 0; i < Upd::NS; ++i) u2.s[i] = upd.s[i] + c0;
+        int rc = apply_cols<K, Upd>(u2, V, ld, uniq, spos, sseg, seg_offsets, n, g + c0, ldg, rscale, gscale, Dc, vec, w, st);
+        if (rc != MREC_OK) return rc;
+    }
+    return MREC_OK;
+}
+
+template <class K>
+int lazy_adam_impl(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D, const K* uniq,
+                   const int32_t* spos, const int32_t* sseg, const int32_t* seg_offsets, int64_t n, const float* g,
+                   int64_t ldg, const float* rscale, float lr, float b1, float b2, float eps, float b1_pow,
+                   float b2_pow, float gscale, int nesterov, void* ws, size_t ws_bytes, void* stream) {
+    if (!uniq && n > 0) return MREC_EINVAL;
+    UpdAdam u;
+    u.s[0] = p; u.s[1] = m; u.s[2] = v;
+    u.h.lr_t = lr * sqrtf(1.0f - b2_pow) / (1.0f - b1_pow);
+    u.h.b1 = b1; u.h.b2 = b2; u.h.omb1 = 1.0f - b1; u.h.omb2 = 1.0f - b2; u.h.eps = eps; u.h.gscale = gscale;
+    u.h.nesterov = nesterov;
+    return apply_impl<K, UpdAdam>(u, V, ld, D, uniq, spos, sseg, seg_offsets, n, g, ldg, rscale, gscale, ws, ws_bytes,
+                                  stream);
+}
+
+template <class K>
+int ftrl_impl(float* var, float* accum, float* linear, int64_t V, int64_t ld, int32_t D, const K* uniq,
+              const int32_t* spos, const int32_t* sseg, const int32_t* seg_offsets, int64_t n, const float* g,
+              int64_t ldg, const float* rscale, float lr, float l1, float l2, float lr_power, float gscale, void* ws,
+              size_t ws_bytes, void* stream) {
+    if (!uniq && n > 0) return MREC_EINVAL;
+    UpdFtrl u;
+    u.s[0] = var; u.s[1] = accum; u.s[2] = linear;
+    u.h = FtrlH{lr, l1, l2, lr_power, gscale};
+    return apply_impl<K, UpdFtrl>(u, V, ld, D, uniq, spos, sseg, seg_offsets, n, g, ldg, rscale, gscale, ws, ws_bytes,
+                                  stream);
+}
+
+}  // namespace
+
+MREC_API int mrec_sparse_apply_workspace_bytes(int64_t n, int32_t D, size_t* out) {
+    if (!out || n < 0 || D <= 0) return MREC_EINVAL;
+    *out = apply_ws_bytes(n, D);
+    return MREC_OK;
+}
+
+MREC_API int mrec_segment_sum_f32(const int32_t* sorted_pos, const int32_t* sorted_seg, const int32_t* seg_offsets,
+                                  int64_t n, const float* g, int64_t ldg, const float* row_scale, float grad_scale,
+                                  int32_t D, float* out, void* ws, size_t ws_bytes, void* stream) {
+    UpdStore u;
+    u.s[0] = out;
+    // rows are group numbers; there are at most n groups
+    return apply_impl<int32_t, UpdStore>(u, n, D, D, (const int32_t*)nullptr, sorted_pos, sorted_seg, seg_offsets, n, g,
+                                         ldg, row_scale, grad_scale, ws, ws_bytes, stream);
+}
+
+MREC_API int mrec_sparse_lazy_adam_f32_i32(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D,
+                                           const int32_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                           const int32_t* seg_offsets, int64_t n, const float* g, int64_t ldg,
+                                           const float* row_scale, float lr, float b1, float b2, float eps,
+                                           float b1_pow, float b2_pow, float grad_scale, int nesterov, void* ws,
+                                           size_t ws_bytes, void* stream) {
+    return lazy_adam_impl<int32_t>(p, m, v, V, ld, D, uniq, sorted_pos, sorted_seg, seg_offsets, n, g, ldg, row_scale,
+                                   lr, b1, b2, eps, b1_pow, b2_pow, grad_scale, nesterov, ws, ws_bytes, stream);
+}
+MREC_API int mrec_sparse_lazy_adam_f32_i64(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D,
+                                           const int64_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                           const int32_t* seg_offsets, int64_t n, const float* g, int64_t ldg,
+                                           const float* row_scale, float lr, float b1, float b2, float eps,
+                                           float b1_pow, float b2_pow, float grad_scale, int nesterov, void* ws,
+                                           size_t ws_bytes, void* stream) {
+    return lazy_adam_impl<int64_t>(p, m, v, V, ld, D, uniq, sorted_pos, sorted_seg, seg_offsets, n, g, ldg, row_scale,
+                                   lr, b1, b2, eps, b1_pow, b2_pow, grad_scale, nesterov, ws, ws_bytes, stream);
+}
+
+MREC_API int mrec_sparse_ftrl_f32_i32(float* var, float* accum, float* linear, int64_t V, int64_t ld, int32_t D,
+                                      const int32_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                      const int32_t* seg_offsets, int64_t n, const float* g, int64_t ldg,
+                                      const float* row_scale, float lr, float l1, float l2, float lr_power,
+                                      float grad_scale, void* ws, size_t ws_bytes, void* stream) {
+    return ftrl_impl<int32_t>(var, accum, linear, V, ld, D, uniq, sorted_pos, sorted_seg, seg_offsets, n, g, ldg,
+                              row_scale, lr, l1, l2, lr_power, grad_scale, ws, ws_bytes, stream);
+}
+MREC_API int mrec_sparse_ftrl_f32_i64(float* var, float* accum, float* linear, int64_t V, int64_t ld, int32_t D,
+                                      const int64_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                      const int32_t* seg_offsets, int64_t n, const float* g, int64_t ldg,
+                                      const float* row_scale, float lr, float l1, float l2, float lr_power,
+                                      float grad_scale, void* ws, size_t ws_bytes, void* stream) {
+    return ftrl_impl<int64_t>(var, accum, linear, V, ld, D, uniq, sorted_pos, sorted_seg, seg_offsets, n, g, ldg,
+                              row_scale, lr, l1, l2, lr_power, grad_scale, ws, ws_bytes, stream);
+}

@@ -1,0 +1,220 @@
+// mrec_dedup.hip -- ops.Unique (first-occurrence order) and its inverted index, for gfx950.
+//
+// Replaces the MindSpore `Unique` primitive invoked at mindspore_rec/ops/embedding.py:153,192 and
+// models/wide_deep/src/wide_and_deep.py:212, plus the index half of the optimizer-side RowTensor
+// dedup (Unique + UnsortedSegmentSum).
+//
+// Dedup: a scratch open-addressing table whose slots hold POSITIONS, not keys (slot value j means
+// "key ids[j]"), claimed by CAS and lowered by atomicMin, so that after the insert kernel every
+// slot holds the first occurrence of its key whatever the race order -- the result is a pure
+// function of the input.  No key value needs to be reserved and int64 keys need only 32-bit
+// atomics.  A flag + two-level scan then numbers the first occurrences in position order.
+//
+// Group-by: stable LSD radix sort of positions by their group number (11-bit digits; 2 passes up
+// to 4 M ids).  In-tile ranks come from wave64 ballot matching: ten to eleven __ballot()s give every
+// lane the mask of lanes sharing its digit, popcount of the lower lanes is its rank.
+#include "mrec_common.h"
+#include "mrec_radix.h"
+
+namespace {
+
+constexpr int kEmpty = 0x7f7f7f7f;
+constexpr int DB = 256;        // threads per block
+constexpr int DI = 8;          // ids per thread in the flag/scan kernels
+constexpr int DT = DB * DI;    // ids per tile
+
+template <class K>
+__global__ __launch_bounds__(DB) void k_dedup_insert(const K* __restrict__ ids, int n, int* slots,
+                                                     uint32_t mask, int* __restrict__ sidx) {
+    const int i = blockIdx.x * DB + threadIdx.x;
+    if (i >= n) return;
+    const K key = ids[i];
+    uint32_t s = mrec_hash_key(key) & mask;
+    for (;;) {
+        int cur = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == kEmpty) {
+            const int old = atomicCAS(&slots[s], kEmpty, i);
+            if (old == kEmpty) break;
+            cur = old;
+        }
+        if (ids[cur] == key) {
+            if (cur > i) atomicMin(&slots[s], i);
+            break;
+        }
+        s = (s + 1) & mask;
+    }
+    sidx[i] = (int)s;
+}
+
+__global__ __launch_bounds__(DB) void k_dedup_count(const int* __restrict__ slots,
+                                                    const int* __restrict__ sidx, int n,
+                                                    int* __restrict__ blocksum) {
+    __shared__ int sm[8];
+    const int base = blockIdx.x * DT + threadIdx.x * DI;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < DI; ++k) {
+        const int i = base + k;
+        if (i < n) c += (slots[sidx[i]] == i);
+    }
+    int tot;
+    block_excl_scan_256(c, sm, &tot);
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+
+template <class K>
+__global__ __launch_bounds__(DB) void k_dedup_rank(const K* __restrict__ ids, const int* __restrict__ slots,
+                                                   const int* __restrict__ sidx, int n,
+                                                   const int* __restrict__ blocksum, int nblk,
+                                                   K* __restrict__ uniq, int* __restrict__ srank,
+                                                   int64_t* __restrict__ n_uniq_dev) {
+    __shared__ int sm[8];
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += DB) part += blocksum[b];
+    int tile_base;
+    block_excl_scan_256(part, sm, &tile_base);
+
+    const int base = blockIdx.x * DT + threadIdx.x * DI;
+    bool first[DI];
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < DI; ++k) {
+        const int i = base + k;
+        first[k] = (i < n) && (slots[sidx[i]] == i);
+        c += first[k];
+    }
+    int tot;
+    int r = tile_base + block_excl_scan_256(c, sm, &tot);
+#pragma unroll
+    for (int k = 0; k < DI; ++k) {
+        if (first[k]) {
+            const int i = base + k;
+            uniq[r] = ids[i];
+            srank[sidx[i]] = r;
+            ++r;
+        }
+    }
+    if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 0) *n_uniq_dev = (int64_t)tile_base + tot;
+}
+
+__global__ __launch_bounds__(DB) void k_dedup_inv(const int* __restrict__ srank, const int* __restrict__ sidx,
+                                                  int n, int* __restrict__ inv) {
+    const int i = blockIdx.x * DB + threadIdx.x;
+    if (i < n) inv[i] = srank[sidx[i]];
+}
+
+__global__ void k_set_i64(int64_t* p, int64_t v) { *p = v; }
+
+template <class K>
+int dedup_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_dev, void* ws, size_t ws_bytes,
+               void* stream_v) {
+    hipStream_t st = (hipStream_t)stream_v;
+    if (n < 0 || !n_uniq_dev) return MREC_EINVAL;
+    if (n == 0) {
+        k_set_i64<<<1, 1, 0, st>>>(n_uniq_dev, 0);
+        MREC_LAUNCH_CHECK();
+        return MREC_OK;
+    }
+    if (!ids || !uniq || !inv || !ws) return MREC_EINVAL;
+    if (n > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
+    uint64_t cap = 1024;
+    while (cap < (uint64_t)n * 2) cap <<= 1;
+    const int nblk = (int)mrec_cdiv(n, DT);
+    MrecArena a(ws, ws_bytes);
+    int* slots = a.take<int>(cap);
+    int* srank = a.take<int>(cap);
+    int* sidx = a.take<int>(n);
+    int* blocksum = a.take<int>(nblk);
+    if (!a.ok) return MREC_EWORKSPACE;
+    MREC_HIP_CHECK(hipMemsetAsync(slots, 0x7f, cap * sizeof(int), st));
+    const int g256 = (int)mrec_cdiv(n, DB);
+    k_dedup_insert<K><<<g256, DB, 0, st>>>(ids, (int)n, slots, (uint32_t)(cap - 1), sidx);
+    k_dedup_count<<<nblk, DB, 0, st>>>(slots, sidx, (int)n, blocksum);
+    k_dedup_rank<K><<<nblk, DB, 0, st>>>(ids, slots, sidx, (int)n, blocksum, nblk, uniq, srank, n_uniq_dev);
+    k_dedup_inv<<<g256, DB, 0, st>>>(srank, sidx, (int)n, inv);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+__global__ __launch_bounds__(256) void k_seg_offsets(const int* __restrict__ sseg, int n,
+                                                     int* __restrict__ seg_offsets) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int s = sseg[e];
+    if (e == 0 || sseg[e - 1] != s) seg_offsets[s] = e;
+    if (e == n - 1) seg_offsets[s + 1] = n;
+}
+
+}  // namespace
+
+MREC_API int mrec_dedup_workspace_bytes(int64_t n, size_t* out) {
+    if (!out || n < 0) return MREC_EINVAL;
+    if (n > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
+    uint64_t cap = 1024;
+    while (cap < (uint64_t)n * 2) cap <<= 1;
+    size_t b = 0;
+    b += mrec_align_up(cap * 4, 256) * 2;
+    b += mrec_align_up((size_t)(n ? n : 1) * 4, 256);
+    b += mrec_align_up((size_t)(mrec_cdiv(n ? n : 1, DT)) * 4, 256);
+    *out = b;
+    return MREC_OK;
+}
+
+MREC_API int mrec_dedup_i32(const int32_t* ids, int64_t n, int32_t* uniq, int32_t* inv, int64_t* n_uniq_dev,
+                            void* ws, size_t ws_bytes, void* stream) {
+    return dedup_impl<int32_t>(ids, n, uniq, inv, n_uniq_dev, ws, ws_bytes, stream);
+}
+
+MREC_API int mrec_dedup_i64(const int64_t* ids, int64_t n, int64_t* uniq, int32_t* inv, int64_t* n_uniq_dev,
+                            void* ws, size_t ws_bytes, void* stream) {
+    return dedup_impl<int64_t>(ids, n, uniq, inv, n_uniq_dev, ws, ws_bytes, stream);
+}
+
+MREC_API int mrec_group_workspace_bytes(int64_t n, size_t* out) {
+    if (!out || n < 0) return MREC_EINVAL;
+    if (n > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
+    const size_t nn = (size_t)(n ? n : 1);
+    size_t b = 0;
+    b += mrec_align_up((size_t)mrec_cdiv(nn, RT) * RNB * 4, 256);
+    b += mrec_align_up((size_t)RNB * 4, 256);
+    b += mrec_align_up(nn * 4, 256) * 2;
+    *out = b;
+    return MREC_OK;
+}
+
+MREC_API int mrec_group_by_inverse(const int32_t* inv, int64_t n, int32_t* sorted_pos, int32_t* sorted_seg,
+                                   int32_t* seg_offsets, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || !seg_offsets) return MREC_EINVAL;
+    if (n == 0) {
+        MREC_HIP_CHECK(hipMemsetAsync(seg_offsets, 0, sizeof(int32_t), st));
+        return MREC_OK;
+    }
+    if (!inv || !sorted_pos || !sorted_seg || !ws) return MREC_EINVAL;
+    if (n > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
+    const int nblk = (int)mrec_cdiv(n, RT);
+    MrecArena a(ws, ws_bytes);
+    int* hist = a.take<int>((size_t)nblk * RNB);
+    int* dbase = a.take<int>(RNB);
+    int* tk = a.take<int>(n);
+    int* tv = a.take<int>(n);
+    if (!a.ok) return MREC_EWORKSPACE;
+    int bits = 1;
+    while (((int64_t)1 << bits) < n) ++bits;  // group numbers are < n
+    const int passes = (bits + RMAXB - 1) / RMAXB;
+    const int pbits = (bits + passes - 1) / passes;
+    const int* kin = inv;
+    const int* vin = nullptr;
+    for (int p = 0; p < passes; ++p) {
+        const bool to_user = ((passes - 1 - p) % 2) == 0;
+        int* kout = to_user ? sorted_seg : tk;
+        int* vout = to_user ? sorted_pos : tv;
+        const int shift = p * pbits;
+        radix_pass(kin, vin, (int)n, shift, pbits, hist, dbase, kout, vout, st);
+        kin = kout;
+        vin = vout;
+    }
+    k_seg_offsets<<<(int)mrec_cdiv(n, 256), 256, 0, st>>>(sorted_seg, (int)n, seg_offsets);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}

@@ -1,0 +1,362 @@
+// mrec_gather.hip -- row gather (Gather / SparseGatherV2 / EmbeddingLookup), the fused wide-branch
+// reduction, on-device table initialisation and the dense (whole-tensor) optimizers, for gfx950.
+//
+// Reference call sites: mindspore_rec/ops/embedding.py:150,194; models/wide_deep/src/
+// wide_and_deep.py:277-290,300-309,435-445; models/deep_and_cross/src/deep_and_cross.py:199,342-344.
+//
+// All of these are HBM-bound byte movers.  A row of D floats is covered by lpr = D/4 lanes holding
+// one float4 each (D = 80 -> 20 lanes, three rows per wave64 instruction, 60/64 lanes busy); each
+// lane-group keeps GB independent row loads in flight before the first store.
+#include "mrec_common.h"
+#include "mrec_rng.h"
+#include "mrec_optim.h"
+
+int g_mrec_last_hip_error = 0;
+
+namespace {
+
+template <int VEC> struct Vf;
+template <> struct Vf<4> { float4 v; };
+template <> struct Vf<1> { float v; };
+
+__device__ __forceinline__ Vf<4> vload(const float* p, Vf<4>*) { Vf<4> r; r.v = *(const float4*)p; return r; }
+__device__ __forceinline__ Vf<1> vload(const float* p, Vf<1>*) { Vf<1> r; r.v = *p; return r; }
+__device__ __forceinline__ void vstore(float* p, const Vf<4>& x) { *(float4*)p = x.v; }
+__device__ __forceinline__ void vstore(float* p, const Vf<1>& x) { *p = x.v; }
+__device__ __forceinline__ Vf<4> vscale(Vf<4> x, float s) { x.v.x *= s; x.v.y *= s; x.v.z *= s; x.v.w *= s; return x; }
+__device__ __forceinline__ Vf<1> vscale(Vf<1> x, float s) { x.v *= s; return x; }
+__device__ __forceinline__ Vf<4> vzero(Vf<4>*) { Vf<4> r; r.v = make_float4(0.f, 0.f, 0.f, 0.f); return r; }
+__device__ __forceinline__ Vf<1> vzero(Vf<1>*) { Vf<1> r; r.v = 0.f; return r; }
+
+constexpr int GB = 4;  // rows in flight per lane-group
+
+// Lane-group geometry shared by the row kernels: lpr lanes per row, G = 64/lpr groups per wave.
+struct RowGeom { int lpr; int G; };
+
+template <int VEC, class K>
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ table, int64_t V, int64_t ld,
+                                                     const K* __restrict__ ids, int64_t n,
+                                                     const float* __restrict__ row_scale,
+                                                     float* __restrict__ out, int D, RowGeom gm) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
+    if (grp >= gm.G) return;
+    const int col = sub * VEC;
+    const int64_t wave_row0 = ((int64_t)blockIdx.x * 4 + wave) * (gm.G * GB);
+    Vf<VEC> x[GB];
+    float sc[GB];
+    int64_t row[GB];
+#pragma unroll
+    for (int k = 0; k < GB; ++k) {
+        const int64_t i = wave_row0 + (int64_t)k * gm.G + grp;
+        row[k] = -1;
+        sc[k] = 1.0f;
+        if (i < n) {
+            row[k] = (int64_t)ids[i];
+            if (row_scale) sc[k] = row_scale[i];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < GB; ++k) {
+        x[k] = vzero((Vf<VEC>*)nullptr);
+        if (row[k] >= 0 && row[k] < V) x[k] = vload(table + row[k] * ld + col, (Vf<VEC>*)nullptr);
+    }
+#pragma unroll
+    for (int k = 0; k < GB; ++k) {
+        const int64_t i = wave_row0 + (int64_t)k * gm.G + grp;
+        if (i < n) vstore(out + i * D + col, row_scale ? vscale(x[k], sc[k]) : x[k]);
+    }
+}
+
+// Generic-D fallback (D not a multiple of 4, or misaligned): one wave per GB rows, lanes stride columns.
+template <class K>
+__global__ __launch_bounds__(256) void k_gather_rows_generic(const float* __restrict__ table, int64_t V,
+                                                             int64_t ld, const K* __restrict__ ids, int64_t n,
+                                                             const float* __restrict__ row_scale,
+                                                             float* __restrict__ out, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t r = (int64_t)ids[i];
+    const bool ok = r >= 0 && r < V;
+    const float s = row_scale ? row_scale[i] : 1.0f;
+    for (int c = lane; c < D; c += 64) {
+        float x = ok ? table[r * ld + c] : 0.0f;
+        out[i * D + c] = row_scale ? x * s : x;
+    }
+}
+
+template <class K>
+__global__ __launch_bounds__(256) void k_wide_sum(const float* __restrict__ w, int64_t V,
+                                                  const K* __restrict__ ids, const float* __restrict__ wts,
+                                                  int64_t B, int F, const float* __restrict__ bias,
+                                                  float* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const K* id = ids + b * F;
+    const float* wt = wts + b * F;
+    float acc = 0.0f;
+    int f = 0;
+    for (; f + 4 <= F; f += 4) {
+        float x[4], t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t r = (int64_t)id[f + k];
+            t[k] = wt[f + k];
+            x[k] = (r >= 0 && r < V) ? w[r] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = acc + x[k] * t[k];
+    }
+    for (; f < F; ++f) {
+        const int64_t r = (int64_t)id[f];
+        const float x = (r >= 0 && r < V) ? w[r] : 0.0f;
+        acc = acc + x * wt[f];
+    }
+    out[b] = acc + (bias ? *bias : 0.0f);
+}
+
+__global__ __launch_bounds__(256) void k_fill_normal(float* __restrict__ out, int64_t nrows, int D, int64_t ld,
+                                                     uint64_t seed, int64_t row0, float sigma) {
+    // one thread per (row, 4-column chunk); chunks per row = ceil(D/4)
+    const int cpr = (D + 3) >> 2;
+    const int64_t total = nrows * cpr;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t r = t / cpr;
+        const int c0 = (int)(t - r * cpr) * 4;
+        float* o = out + r * ld + c0;
+        float x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = (c0 + k < D) ? sigma * mrec_det_normal(seed, row0 + r, c0 + k) : 0.0f;
+        if (c0 + 4 <= D && ((ld & 3) == 0) && ((((uintptr_t)out) & 15) == 0)) {
+            *(float4*)o = make_float4(x[0], x[1], x[2], x[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (c0 + k < D) o[k] = x[k];
+        }
+    }
+}
+
+template <class K>
+__global__ __launch_bounds__(256) void k_init_rows(float* __restrict__ table, int64_t ld, int D,
+                                                   const int* __restrict__ rows, const K* __restrict__ keys,
+                                                   const uint8_t* __restrict__ is_new, int64_t n, uint64_t seed,
+                                                   float sigma, float fill) {
+    const int cpr = (D + 3) >> 2;
+    const int64_t total = n * cpr;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t i = t / cpr;
+        if (is_new && !is_new[i]) continue;
+        const int r = rows[i];
+        if (r < 0) continue;
+        const int c0 = (int)(t - i * cpr) * 4;
+        const int64_t key = (int64_t)keys[i];
+        for (int k = 0; k < 4 && c0 + k < D; ++k)
+            table[(int64_t)r * ld + c0 + k] = sigma >= 0.0f ? sigma * mrec_det_normal(seed, key, c0 + k) : fill;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_rows(float* __restrict__ table, int64_t ld, int D,
+                                                      const int* __restrict__ rows, int64_t n,
+                                                      const float* __restrict__ vals) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int r = rows[i];
+    if (r < 0) return;
+    for (int c = lane; c < D; c += 64) table[(int64_t)r * ld + c] = vals[i * D + c];
+}
+
+// ---- dense optimizers ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dense_adam(float* __restrict__ p, float* __restrict__ m,
+                                                    float* __restrict__ v, const float* __restrict__ g, int64_t n,
+                                                    AdamH h) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam_elem(pp, mm, vv, g[i] * h.gscale, h);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dense_adam4(float4* __restrict__ p, float4* __restrict__ m,
+                                                     float4* __restrict__ v, const float4* __restrict__ g,
+                                                     int64_t n4, AdamH h) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pp = p[i], mm = m[i], vv = v[i];
+        const float4 gg = g[i];
+        adam_elem(pp.x, mm.x, vv.x, gg.x * h.gscale, h);
+        adam_elem(pp.y, mm.y, vv.y, gg.y * h.gscale, h);
+        adam_elem(pp.z, mm.z, vv.z, gg.z * h.gscale, h);
+        adam_elem(pp.w, mm.w, vv.w, gg.w * h.gscale, h);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dense_ftrl(float* __restrict__ w, float* __restrict__ a,
+                                                    float* __restrict__ lin, const float* __restrict__ g,
+                                                    int64_t n, FtrlH h) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float ww = w[i], aa = a[i], ll = lin[i];
+        ftrl_elem(ww, aa, ll, g[i] * h.gscale, h);
+        w[i] = ww; a[i] = aa; lin[i] = ll;
+    }
+}
+
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+template <class K>
+int gather_impl(const float* table, int64_t V, int64_t ld, int32_t D, const K* ids, int64_t n,
+                const float* row_scale, float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || D <= 0 || V < 0 || ld < D) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!table || !ids || !out) return MREC_EINVAL;
+    const bool vec = (D % 4 == 0) && (D <= 256) && (ld % 4 == 0) && al16(table) && al16(out);
+    if (vec) {
+        RowGeom gm{D / 4, 64 / (D / 4)};
+        const int64_t rows_per_block = (int64_t)4 * gm.G * GB;
+        k_gather_rows<4, K><<<(unsigned)mrec_cdiv(n, rows_per_block), 256, 0, st>>>(table, V, ld, ids, n, row_scale,
+                                                                                  out, D, gm);
+    } else if (D <= 64) {
+        RowGeom gm{D, 64 / D};
+        const int64_t rows_per_block = (int64_t)4 * gm.G * GB;
+        k_gather_rows<1, K><<<(unsigned)mrec_cdiv(n, rows_per_block), 256, 0, st>>>(table, V, ld, ids, n, row_scale,
+                                                                                  out, D, gm);
+    } else {
+        k_gather_rows_generic<K><<<(unsigned)mrec_cdiv(n, 4), 256, 0, st>>>(table, V, ld, ids, n, row_scale, out, D);
+    }
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+template <class K>
+int wide_sum_impl(const float* w, int64_t V, const K* ids, const float* wts, int64_t B, int32_t F,
+                  const float* bias_dev, float* out, void* stream) {
+    if (B < 0 || F <= 0 || V < 0) return MREC_EINVAL;
+    if (B == 0) return MREC_OK;
+    if (!w || !ids || !wts || !out) return MREC_EINVAL;
+    k_wide_sum<K><<<(unsigned)mrec_cdiv(B, 256), 256, 0, (hipStream_t)stream>>>(w, V, ids, wts, B, F, bias_dev, out);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+inline unsigned stream_grid(int64_t work_items) {
+    int64_t b = mrec_cdiv(work_items, 256);
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+MREC_API const char* mrec_strerror(int code) {
+    switch (code) {
+        case MREC_OK: return "ok";
+        case MREC_EINVAL: return "invalid argument";
+        case MREC_EWORKSPACE: return "workspace too small";
+        case MREC_EUNSUPPORTED: return "unsupported shape";
+        case MREC_EHIP: return "HIP runtime error";
+        case MREC_ENODEVICE: return "no usable gfx950 device";
+        default: return "unknown error";
+    }
+}
+
+MREC_API int mrec_last_hip_error(void) { return g_mrec_last_hip_error; }
+MREC_API int mrec_version(void) { return 100; }
+
+MREC_API int mrec_device_ok(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MREC_ENODEVICE;
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, (const void*)k_fill_normal) != hipSuccess) {
+        (void)hipGetLastError();
+        return MREC_ENODEVICE;
+    }
+    return MREC_OK;
+}
+
+MREC_API int mrec_fill_normal_f32(float* out, int64_t nrows, int32_t D, int64_t ld, uint64_t seed, int64_t row0,
+                                  float sigma, void* stream) {
+    if (nrows < 0 || D <= 0 || ld < D) return MREC_EINVAL;
+    if (nrows == 0) return MREC_OK;
+    if (!out) return MREC_EINVAL;
+    const int64_t total = nrows * ((D + 3) / 4);
+    k_fill_normal<<<stream_grid(total), 256, 0, (hipStream_t)stream>>>(out, nrows, D, ld, seed, row0, sigma);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+MREC_API int mrec_gather_rows_f32_i32(const float* table, int64_t V, int64_t ld, int32_t D, const int32_t* ids,
+                                      int64_t n, const float* row_scale, float* out, void* stream) {
+    return gather_impl<int32_t>(table, V, ld, D, ids, n, row_scale, out, stream);
+}
+MREC_API int mrec_gather_rows_f32_i64(const float* table, int64_t V, int64_t ld, int32_t D, const int64_t* ids,
+                                      int64_t n, const float* row_scale, float* out, void* stream) {
+    return gather_impl<int64_t>(table, V, ld, D, ids, n, row_scale, out, stream);
+}
+
+MREC_API int mrec_wide_sum_f32_i32(const float* w, int64_t V, const int32_t* ids, const float* wts, int64_t B,
+                                   int32_t F, const float* bias_dev, float* out, void* stream) {
+    return wide_sum_impl<int32_t>(w, V, ids, wts, B, F, bias_dev, out, stream);
+}
+MREC_API int mrec_wide_sum_f32_i64(const float* w, int64_t V, const int64_t* ids, const float* wts, int64_t B,
+                                   int32_t F, const float* bias_dev, float* out, void* stream) {
+    return wide_sum_impl<int64_t>(w, V, ids, wts, B, F, bias_dev, out, stream);
+}
+
+MREC_API int mrec_init_rows_f32(float* table, int64_t ld, int32_t D, const int32_t* rows, const int64_t* keys,
+                                const uint8_t* is_new, int64_t n, uint64_t seed, float sigma, float fill,
+                                void* stream) {
+    if (n < 0 || D <= 0 || ld < D) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!table || !rows || !keys) return MREC_EINVAL;
+    const int64_t total = n * ((D + 3) / 4);
+    k_init_rows<int64_t><<<stream_grid(total), 256, 0, (hipStream_t)stream>>>(table, ld, D, rows, keys, is_new, n,
+                                                                           seed, sigma, fill);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+MREC_API int mrec_scatter_rows_f32(float* table, int64_t ld, int32_t D, const int32_t* rows, int64_t n,
+                                   const float* vals, void* stream) {
+    if (n < 0 || D <= 0 || ld < D) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!table || !rows || !vals) return MREC_EINVAL;
+    k_scatter_rows<<<(unsigned)mrec_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(table, ld, D, rows, n, vals);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+MREC_API int mrec_dense_adam_f32(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1,
+                                 float b2, float eps, float b1_pow, float b2_pow, float grad_scale, int nesterov,
+                                 void* stream) {
+    if (n < 0) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!p || !m || !v || !g) return MREC_EINVAL;
+    AdamH h;
+    h.lr_t = lr * sqrtf(1.0f - b2_pow) / (1.0f - b1_pow);
+    h.b1 = b1; h.b2 = b2; h.omb1 = 1.0f - b1; h.omb2 = 1.0f - b2; h.eps = eps; h.gscale = grad_scale;
+    h.nesterov = nesterov;
+    hipStream_t st = (hipStream_t)stream;
+    if (al16(p) && al16(m) && al16(v) && al16(g) && n >= 4) {
+        const int64_t n4 = n / 4;
+        k_dense_adam4<<<stream_grid(n4), 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h);
+        const int64_t rem = n - n4 * 4;
+        if (rem) k_dense_adam<<<1, 256, 0, st>>>(p + n4 * 4, m + n4 * 4, v + n4 * 4, g + n4 * 4, rem, h);
+    } else {
+        k_dense_adam<<<stream_grid(n), 256, 0, st>>>(p, m, v, g, n, h);
+    }
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+MREC_API int mrec_dense_ftrl_f32(float* var, float* accum, float* linear, const float* g, int64_t n, float lr,
+                                 float l1, float l2, float lr_power, float grad_scale, void* stream) {
+    if (n < 0) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!var || !accum || !linear || !g) return MREC_EINVAL;
+    FtrlH h{lr, l1, l2, lr_power, grad_scale};
+    k_dense_ftrl<<<stream_grid(n), 256, 0, (hipStream_t)stream>>>(var, accum, linear, g, n, h);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}

@@ -1,0 +1,405 @@
+"""Host-side wrappers: torch tensors in, libmrec_hip.so kernels on the current HIP stream.
+
+Each function names the MindSpore primitive it stands in for and the reference call site
+(paths relative to the mindspore-lab/mindrec checkout).  torch is the device-memory container
+only: no arithmetic on the hot path is done by torch here.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_WS = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def workspace(tag, nbytes, device):
+    """Stream-ordered scratch, cached per (tag, device, stream) and grown geometrically."""
+    key = (tag, str(device), torch.cuda.current_stream().cuda_stream)
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes * 1.25), 4096), dtype=torch.uint8, device=device)
+        _WS[key] = t
+    return t
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mindrec_amd ops run on the GPU only (no CPU fallback); got a CPU tensor")
+
+
+def _suffix(ids):
+    if ids.dtype == torch.int32:
+        return "i32"
+    if ids.dtype == torch.int64:
+        return "i64"
+    raise TypeError(f"ids must be int32 or int64, got {ids.dtype}")
+
+
+def _table(t):
+    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+        raise TypeError("table must be a float32 [V, D] tensor with unit column stride")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def fill_normal_(table, seed, sigma=0.01, row0=0):
+    """initializer('normal') written on the device (default_config.yaml:41; embedding.py:88)."""
+    _need_cuda(table)
+    V, D, ld = _table(table)
+    _lib.call("mrec_fill_normal_f32", _ptr(table), V, D, ld, C.c_uint64(seed), row0, sigma, _stream())
+    return table
+
+
+class Dedup:
+    """Result of ops.Unique (embedding.py:153,192): uniq[:U] in first-occurrence order, inv[n]."""
+
+    def __init__(self, ids_flat, uniq, inv, n_uniq_dev):
+        self.ids = ids_flat
+        self.uniq_buf = uniq
+        self.inv = inv
+        self.n_uniq_dev = n_uniq_dev
+        self._U = None
+
+    @property
+    def n(self):
+        return self.ids.numel()
+
+    @property
+    def U(self):
+        """Number of unique ids (host sync on first use)."""
+        if self._U is None:
+            self._U = int(self.n_uniq_dev.item())
+        return self._U
+
+    @property
+    def uniq(self):
+        return self.uniq_buf[: self.U]
+
+
+def unique(ids):
+    _need_cuda(ids)
+    sfx = _suffix(ids)
+    flat = ids.reshape(-1).contiguous()
+    n = flat.numel()
+    dev = flat.device
+    uniq = torch.empty(max(n, 1), dtype=flat.dtype, device=dev)
+    inv = torch.empty(max(n, 1), dtype=torch.int32, device=dev)[:n]
+    n_uniq = torch.empty(1, dtype=torch.int64, device=dev)
+    nb = _lib.query_bytes("mrec_dedup_workspace_bytes", n)
+    ws = workspace("dedup", nb, dev)
+    _lib.call(f"mrec_dedup_{sfx}", _ptr(flat), n, _ptr(uniq), _ptr(inv), _ptr(n_uniq), _ptr(ws), ws.numel(), _stream())
+    return Dedup(flat, uniq, inv, n_uniq)
+
+
+class SparsePlan(Dedup):
+    """Dedup + inverted index of one step's ids: what the optimizer-side RowTensor dedup needs."""
+
+    def __init__(self, d, sorted_pos, sorted_seg, seg_offsets):
+        super().__init__(d.ids, d.uniq_buf, d.inv, d.n_uniq_dev)
+        self._U = d._U
+        self.sorted_pos = sorted_pos
+        self.sorted_seg = sorted_seg
+        self.seg_offsets = seg_offsets
+
+
+def group_by_inverse(d):
+    n = d.n
+    dev = d.ids.device
+    sorted_pos = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    sorted_seg = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    seg_offsets = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    nb = _lib.query_bytes("mrec_group_workspace_bytes", n)
+    ws = workspace("group", nb, dev)
+    _lib.call("mrec_group_by_inverse", _ptr(d.inv), n, _ptr(sorted_pos), _ptr(sorted_seg), _ptr(seg_offsets), _ptr(ws),
+              ws.numel(), _stream())
+    return SparsePlan(d, sorted_pos, sorted_seg, seg_offsets)
+
+
+def sparse_plan(ids):
+    return group_by_inverse(unique(ids))
+
+
+def gather_rows(table, ids, row_scale=None, out=None):
+    """ops.Gather / SparseGatherV2 / EmbeddingLookup (embedding.py:150,194; deep_and_cross.py:199),
+    optionally fused with the mask multiply of wide_and_deep.py:303,308."""
+    _need_cuda(table, ids, row_scale)
+    V, D, ld = _table(table)
+    sfx = _suffix(ids)
+    flat = ids.reshape(-1).contiguous()
+    n = flat.numel()
+    if row_scale is not None:
+        row_scale = row_scale.reshape(-1).contiguous()
+        if row_scale.dtype != torch.float32 or row_scale.numel() != n:
+            raise TypeError("row_scale must be float32 with one value per id")
+    if out is None:
+        out = torch.empty((n, D), dtype=torch.float32, device=table.device)
+    _lib.call(f"mrec_gather_rows_f32_{sfx}", _ptr(table), V, ld, D, _ptr(flat), n, _ptr(row_scale), _ptr(out), _stream())
+    return out.view(tuple(ids.shape) + (D,))
+
+
+def wide_sum(w, ids, wts, bias=None):
+    """Wide branch of WideDeepModel.construct (wide_and_deep.py:300,303-306): [B]."""
+    _need_cuda(w, ids, wts, bias)
+    sfx = _suffix(ids)
+    if ids.dim() != 2:
+        raise ValueError("ids must be [B, F]")
+    B, F = ids.shape
+    wf = w.reshape(-1)
+    if wf.dtype != torch.float32 or not wf.is_contiguous():
+        raise TypeError("w must be a contiguous float32 [V,1] table")
+    ids_c = ids.contiguous()
+    wts_c = wts.contiguous()
+    out = torch.empty(B, dtype=torch.float32, device=w.device)
+    _lib.call(f"mrec_wide_sum_f32_{sfx}", _ptr(wf), wf.numel(), _ptr(ids_c), _ptr(wts_c), B, F, _ptr(bias), _ptr(out),
+              _stream())
+    return out
+
+
+def _grads(plan, g, D):
+    if g.dtype != torch.float32:
+        raise TypeError("row gradients must be float32")
+    g2 = g.reshape(plan.n, D)
+    if g2.stride(1) != 1:
+        g2 = g2.contiguous()
+    return g2, (g2.stride(0) if plan.n > 1 else D)
+
+
+def _row_scale(plan, row_scale):
+    if row_scale is None:
+        return None
+    rs = row_scale.reshape(-1).contiguous()
+    if rs.dtype != torch.float32 or rs.numel() != plan.n:
+        raise TypeError("row_scale must be float32 with one value per id")
+    return rs
+
+
+def _apply_ws(plan, D, dev):
+    nb = _lib.query_bytes("mrec_sparse_apply_workspace_bytes", plan.n, D)
+    return workspace("apply", nb, dev)
+
+
+def segment_sum(plan, g, row_scale=None, grad_scale=1.0):
+    """ops.UnsortedSegmentSum over the plan's groups: returns an [n, D] buffer whose first U rows
+    are the per-unique-id sums (rows >= U are unspecified)."""
+    _need_cuda(g, row_scale)
+    D = g.shape[-1]
+    g2, ldg = _grads(plan, g, D)
+    rs = _row_scale(plan, row_scale)
+    out = torch.empty((max(plan.n, 1), D), dtype=torch.float32, device=g.device)
+    ws = _apply_ws(plan, D, g.device)
+    _lib.call("mrec_segment_sum_f32", _ptr(plan.sorted_pos), _ptr(plan.sorted_seg), _ptr(plan.seg_offsets), plan.n,
+              _ptr(g2), ldg, _ptr(rs), grad_scale, D, _ptr(out), _ptr(ws), ws.numel(), _stream())
+    return out
+
+
+def sparse_lazy_adam_(p, m, v, plan, g, row_scale=None, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, beta1_power=0.9,
+                      beta2_power=0.999, grad_scale=1.0, use_nesterov=False):
+    """nn.LazyAdam on a RowTensor gradient (wide_and_deep.py:420-422): in place on p, m, v."""
+    _need_cuda(p, m, v, g, row_scale)
+    V, D, ld = _table(p)
+    for t in (m, v):
+        if _table(t) != (V, D, ld):
+            raise ValueError("p, m, v must share shape and row stride")
+    g2, ldg = _grads(plan, g, D)
+    rs = _row_scale(plan, row_scale)
+    ws = _apply_ws(plan, D, p.device)
+    sfx = _suffix(plan.uniq_buf)
+    _lib.call(f"mrec_sparse_lazy_adam_f32_{sfx}", _ptr(p), _ptr(m), _ptr(v), V, ld, D, _ptr(plan.uniq_buf),
+              _ptr(plan.sorted_pos), _ptr(plan.sorted_seg), _ptr(plan.seg_offsets), plan.n, _ptr(g2), ldg, _ptr(rs), lr,
+              beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _ptr(ws), ws.numel(), _stream())
+
+
+def sparse_ftrl_(var, accum, linear, plan, g, row_scale=None, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):
+    """nn.FTRL sparse apply (wide_and_deep.py:423-430): in place on var, accum, linear."""
+    _need_cuda(var, accum, linear, g, row_scale)
+    V, D, ld = _table(var)
+    for t in (accum, linear):
+        if _table(t) != (V, D, ld):
+            raise ValueError("var, accum, linear must share shape and row stride")
+    g2, ldg = _grads(plan, g, D)
+    rs = _row_scale(plan, row_scale)
+    ws = _apply_ws(plan, D, var.device)
+    sfx = _suffix(plan.uniq_buf)
+    _lib.call(f"mrec_sparse_ftrl_f32_{sfx}", _ptr(var), _ptr(accum), _ptr(linear), V, ld, D, _ptr(plan.uniq_buf),
+              _ptr(plan.sorted_pos), _ptr(plan.sorted_seg), _ptr(plan.seg_offsets), plan.n, _ptr(g2), ldg, _ptr(rs), lr, l1,
+              l2, lr_power, grad_scale, _ptr(ws), ws.numel(), _stream())
+
+
+def _flat_same(*ts):
+    n = ts[0].numel()
+    for t in ts:
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise TypeError("dense optimizer tensors must be contiguous float32 of equal size")
+    return n
+
+
+def dense_adam_(p, m, v, g, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, beta1_power=0.9, beta2_power=0.999,
+                grad_scale=1.0, use_nesterov=False):
+    """nn.Adam over a whole tensor (wide_and_deep.py:435-437; deep_and_cross.py:342-344)."""
+    _need_cuda(p, m, v, g)
+    n = _flat_same(p, m, v, g)
+    _lib.call("mrec_dense_adam_f32", _ptr(p), _ptr(m), _ptr(v), _ptr(g), n, lr, beta1, beta2, eps, beta1_power,
+              beta2_power, grad_scale, int(use_nesterov), _stream())
+
+
+def dense_ftrl_(var, accum, linear, g, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):
+    """nn.FTRL over a whole tensor (wide_and_deep.py:438-445)."""
+    _need_cuda(var, accum, linear, g)
+    n = _flat_same(var, accum, linear, g)
+    _lib.call("mrec_dense_ftrl_f32", _ptr(var), _ptr(accum), _ptr(linear), _ptr(g), n, lr, l1, l2, lr_power, grad_scale,
+              _stream())
+
+
+# ---- MapParameter key index ------------------------------------------------------------------
+class KeyIndex:
+    """Device key -> row-number index behind MapParameter (embedding.py:136-146)."""
+
+    def __init__(self, capacity, device):
+        self.capacity = int(capacity)
+        self.device = torch.device(device)
+        nb = _lib.query_bytes("mrec_map_bytes", self.capacity)
+        self._mem = torch.empty(nb + 256, dtype=torch.uint8, device=self.device)
+        off = (-self._mem.data_ptr()) % 256
+        self._base = self._mem.data_ptr() + off
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.call("mrec_map_create", C.byref(h), C.c_void_p(self._base), nb, self.capacity, _stream())
+        self._h = h
+        cptr = _lib.lib().mrec_map_counters_dev(self._h)
+        self._counters_off = cptr - self._mem.data_ptr()
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().mrec_map_destroy(h)
+            self._h = None
+
+    def counters(self):
+        """(rows handed out, live keys, dropped keys, free rows) -- host sync."""
+        c = self._mem[self._counters_off: self._counters_off + 32].view(torch.int64)
+        return tuple(int(x) for x in c.tolist())
+
+    def __len__(self):
+        return self.counters()[1]
+
+    def _ws(self, n):
+        nb = _lib.query_bytes("mrec_map_workspace_bytes", max(n, 1))
+        return workspace("map", nb, self.device)
+
+    def find_or_insert(self, keys_i64, insert=True):
+        """keys must be unique within the call.  Returns (rows int32[n], is_new uint8[n])."""
+        n = keys_i64.numel()
+        rows = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)[:n]
+        is_new = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)[:n]
+        ws = self._ws(n)
+        _lib.call("mrec_map_find_or_insert", self._h, _ptr(keys_i64), n, int(insert), _ptr(rows), _ptr(is_new), _ptr(ws),
+                  ws.numel(), _stream())
+        return rows, is_new
+
+    def erase(self, keys_i64):
+        n = keys_i64.numel()
+        ws = self._ws(n)
+        _lib.call("mrec_map_erase", self._h, _ptr(keys_i64), n, _ptr(ws), ws.numel(), _stream())
+
+    def export(self):
+        """Live (keys int64, rows int32) in row order (host sync for the count)."""
+        keys = torch.empty(self.capacity, dtype=torch.int64, device=self.device)
+        rows = torch.empty(self.capacity, dtype=torch.int32, device=self.device)
+        n_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        ws = self._ws(self.capacity)
+        _lib.call("mrec_map_export", self._h, _ptr(keys), _ptr(rows), _ptr(n_dev), _ptr(ws), ws.numel(), _stream())
+        n = int(n_dev.item())
+        return keys[:n], rows[:n]
+
+
+def init_rows_(table, rows, keys_i64, is_new=None, seed=0, sigma=0.01, fill=None):
+    """Default-value rows of MapTensorGet(insert_default_value=True) (embedding.py:149)."""
+    V, D, ld = _table(table)
+    n = rows.numel()
+    s = -1.0 if fill is not None else float(sigma)
+    _lib.call("mrec_init_rows_f32", _ptr(table), ld, D, _ptr(rows), _ptr(keys_i64), _ptr(is_new), n, C.c_uint64(seed), s,
+              float(fill or 0.0), _stream())
+
+
+def scatter_rows_(table, rows, vals):
+    """MapTensorPut on the row storage (README.md:188-190)."""
+    V, D, ld = _table(table)
+    n = rows.numel()
+    vals = vals.reshape(n, D).contiguous()
+    _lib.call("mrec_scatter_rows_f32", _ptr(table), ld, D, _ptr(rows), n, _ptr(vals), _stream())
+
+
+# ---- DCN-v1 cross layers ---------------------------------------------------------------------
+def cross_layers(x0, w, b):
+    """CrossLayer x L (deep_and_cross.py:139-149, 300-306).  x0 [B,D], w/b [L,D] -> [B,D]."""
+    _need_cuda(x0, w, b)
+    x0 = x0.contiguous(); w = w.contiguous(); b = b.contiguous()
+    B, D = x0.shape
+    L = w.shape[0]
+    out = torch.empty_like(x0)
+    _lib.call("mrec_cross_layers_f32", _ptr(x0), _ptr(w), _ptr(b), L, B, D, _ptr(out), _stream())
+    return out
+
+
+def cross_layers_bwd(x0, w, b, dy):
+    _need_cuda(x0, w, b, dy)
+    x0 = x0.contiguous(); w = w.contiguous(); b = b.contiguous(); dy = dy.contiguous()
+    B, D = x0.shape
+    L = w.shape[0]
+    dx0 = torch.empty_like(x0)
+    dw = torch.empty_like(w)
+    db = torch.empty_like(b)
+    nb = _lib.query_bytes("mrec_cross_layers_bwd_workspace_bytes", L, B, D)
+    ws = workspace("cross", nb, x0.device)
+    _lib.call("mrec_cross_layers_bwd_f32", _ptr(x0), _ptr(w), _ptr(b), L, B, D, _ptr(dy), _ptr(dx0), _ptr(dw), _ptr(db),
+              _ptr(ws), ws.numel(), _stream())
+    return dx0, dw, db
+
+
+# ---- row-shard routing -----------------------------------------------------------------------
+def shard_route(ids, n_shards):
+    """Buckets ids by owner = id mod n_shards (stable).  Returns (send_local, send_perm, counts_dev)."""
+    _need_cuda(ids)
+    sfx = _suffix(ids)
+    flat = ids.reshape(-1).contiguous()
+    n = flat.numel()
+    dev = flat.device
+    send_local = torch.empty(max(n, 1), dtype=flat.dtype, device=dev)[:n]
+    send_perm = torch.empty(max(n, 1), dtype=torch.int32, device=dev)[:n]
+    counts = torch.empty(n_shards, dtype=torch.int64, device=dev)
+    nb = _lib.query_bytes("mrec_shard_route_workspace_bytes", n, n_shards)
+    ws = workspace("route", nb, dev)
+    _lib.call(f"mrec_shard_route_{sfx}", _ptr(flat), n, n_shards, _ptr(send_local), _ptr(send_perm), _ptr(counts), _ptr(ws),
+              ws.numel(), _stream())
+    return send_local, send_perm, counts
+
+
+def shard_unroute(rows, send_perm, row_scale=None):
+    n, D = rows.shape
+    rows = rows.contiguous()
+    out = torch.empty((n, D), dtype=torch.float32, device=rows.device)
+    rs = row_scale.reshape(-1).contiguous() if row_scale is not None else None
+    _lib.call("mrec_shard_unroute_f32", _ptr(rows), _ptr(send_perm), n, D, _ptr(rs), _ptr(out), _stream())
+    return out
+
+
+def shard_route_rows(g, send_perm, row_scale=None):
+    n = send_perm.numel()
+    D = g.shape[-1]
+    g2 = g.reshape(n, D)
+    if g2.stride(1) != 1:
+        g2 = g2.contiguous()
+    out = torch.empty((n, D), dtype=torch.float32, device=g.device)
+    rs = row_scale.reshape(-1).contiguous() if row_scale is not None else None
+    _lib.call("mrec_shard_route_rows_f32", _ptr(g2), g2.stride(0) if n > 1 else D, _ptr(send_perm), n, D, _ptr(rs),
+              _ptr(out), _stream())
+    return out

@@ -1,0 +1,238 @@
+"""numpy/ctypes front-end of the CPU oracle (oracle/mrec_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+PARITY UNPINNED at the MindSpore boundary -- see the header of mrec_oracle.c.
+
+Every function takes and returns numpy arrays; tables are modified in place where the reference
+primitive mutates its Parameter (optimizers, MapParameter ops).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmrec_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "mrec_oracle.c")
+    if force or not os.path.exists(_SO) or (
+        os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO)
+    ):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libmrec_oracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.mrec_o_unique_i64.restype = C.c_int64
+        _lib.mrec_o_unique_i32.restype = C.c_int64
+        _lib.mrec_o_map_create.restype = C.c_void_p
+        _lib.mrec_o_map_size.restype = C.c_int64
+        _lib.mrec_o_map_export.restype = C.c_int64
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def normal_rows(seed, rows, D, sigma):
+    rows = _i64(rows).ravel()
+    out = np.empty((rows.size, D), np.float32)
+    lib().mrec_o_normal_rows_f32(C.c_uint64(seed), _p(rows), C.c_int64(rows.size), C.c_int32(D),
+                                 C.c_float(sigma), _p(out))
+    return out
+
+
+def fill_normal(seed, nrows, D, sigma, row0=0):
+    out = np.empty((nrows, D), np.float32)
+    lib().mrec_o_fill_normal_f32(C.c_uint64(seed), C.c_int64(row0), C.c_int64(nrows), C.c_int32(D),
+                                 C.c_int64(D), C.c_float(sigma), _p(out))
+    return out
+
+
+def unique(x):
+    """ops.Unique: (y, idx) with first-occurrence order."""
+    x = np.ascontiguousarray(x).ravel()
+    n = x.size
+    inv = np.empty(n, np.int32)
+    if x.dtype == np.int32:
+        uniq = np.empty(n, np.int32)
+        U = lib().mrec_o_unique_i32(_p(x), C.c_int64(n), _p(uniq), _p(inv))
+    else:
+        x = _i64(x)
+        uniq = np.empty(n, np.int64)
+        U = lib().mrec_o_unique_i64(_p(x), C.c_int64(n), _p(uniq), _p(inv))
+    return uniq[:U].copy(), inv
+
+
+def gather_rows(table, ids, row_scale=None):
+    table = np.asarray(table)
+    assert table.dtype == np.float32 and table.ndim == 2 and table.strides[1] == 4
+    V, D = table.shape
+    ld = table.strides[0] // 4
+    ids_f = _i64(ids).ravel()
+    out = np.empty((ids_f.size, D), np.float32)
+    rs = _f32(row_scale).ravel() if row_scale is not None else None
+    lib().mrec_o_gather_rows_f32(_p(table), C.c_int64(V), C.c_int64(ld), C.c_int32(D), _p(ids_f),
+                                 C.c_int64(ids_f.size), _p(rs), _p(out))
+    return out.reshape(tuple(np.shape(ids)) + (D,))
+
+
+def wide_sum(w, ids, wts, bias):
+    w = _f32(w).ravel()
+    ids2 = _i64(ids)
+    B, F = ids2.shape
+    wts = _f32(wts)
+    out = np.empty(B, np.float32)
+    lib().mrec_o_wide_sum_f32(_p(w), C.c_int64(w.size), _p(ids2), _p(wts), C.c_int64(B), C.c_int32(F),
+                              C.c_float(bias), _p(out))
+    return out
+
+
+def segment_sum(vals, seg, U):
+    vals = _f32(vals)
+    n, D = vals.shape
+    seg = np.ascontiguousarray(seg, np.int32)
+    out = np.empty((U, D), np.float32)
+    lib().mrec_o_segment_sum_f32(_p(vals), C.c_int64(D), _p(seg), C.c_int64(n), C.c_int32(D), _p(out),
+                                 C.c_int64(U))
+    return out
+
+
+def _tab(t):
+    assert t.dtype == np.float32 and t.ndim == 2 and t.strides[1] == 4
+    return t.shape[0], t.shape[1], t.strides[0] // 4
+
+
+def sparse_lazy_adam(p, m, v, ids, g, row_scale=None, lr=3.5e-4, b1=0.9, b2=0.999, eps=1e-8,
+                     b1_pow=0.9, b2_pow=0.999, grad_scale=1.0, nesterov=False):
+    V, D, ld = _tab(p)
+    ids_f = _i64(ids).ravel()
+    g = _f32(g).reshape(ids_f.size, D)
+    rs = _f32(row_scale).ravel() if row_scale is not None else None
+    lib().mrec_o_sparse_lazy_adam_f32(
+        _p(p), _p(m), _p(v), C.c_int64(V), C.c_int64(ld), C.c_int32(D), _p(ids_f), C.c_int64(ids_f.size),
+        _p(g), C.c_int64(D), _p(rs), C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps),
+        C.c_float(b1_pow), C.c_float(b2_pow), C.c_float(grad_scale), C.c_int(int(nesterov)))
+
+
+def sparse_ftrl(var, accum, linear, ids, g, row_scale=None, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5,
+                grad_scale=1.0):
+    V, D, ld = _tab(var)
+    ids_f = _i64(ids).ravel()
+    g = _f32(g).reshape(ids_f.size, D)
+    rs = _f32(row_scale).ravel() if row_scale is not None else None
+    lib().mrec_o_sparse_ftrl_f32(
+        _p(var), _p(accum), _p(linear), C.c_int64(V), C.c_int64(ld), C.c_int32(D), _p(ids_f),
+        C.c_int64(ids_f.size), _p(g), C.c_int64(D), _p(rs), C.c_float(lr), C.c_float(l1), C.c_float(l2),
+        C.c_float(lr_power), C.c_float(grad_scale))
+
+
+def dense_adam(p, m, v, g, lr=3.5e-4, b1=0.9, b2=0.999, eps=1e-8, b1_pow=0.9, b2_pow=0.999,
+               grad_scale=1.0, nesterov=False):
+    g = _f32(g)
+    assert p.flags.c_contiguous and m.flags.c_contiguous and v.flags.c_contiguous
+    lib().mrec_o_dense_adam_f32(_p(p), _p(m), _p(v), _p(g), C.c_int64(p.size), C.c_float(lr), C.c_float(b1),
+                                C.c_float(b2), C.c_float(eps), C.c_float(b1_pow), C.c_float(b2_pow),
+                                C.c_float(grad_scale), C.c_int(int(nesterov)))
+
+
+def dense_ftrl(var, accum, linear, g, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):
+    g = _f32(g)
+    lib().mrec_o_dense_ftrl_f32(_p(var), _p(accum), _p(linear), _p(g), C.c_int64(var.size), C.c_float(lr),
+                                C.c_float(l1), C.c_float(l2), C.c_float(lr_power), C.c_float(grad_scale))
+
+
+class Map:
+    """MapParameter restatement (README.md:160-205; embedding.py:136-146)."""
+
+    def __init__(self, D, capacity, seed=0, sigma=0.01, fill=None):
+        self.D = D
+        self.capacity = capacity
+        s = -1.0 if fill is not None else sigma
+        self._h = C.c_void_p(lib().mrec_o_map_create(C.c_int32(D), C.c_int64(capacity), C.c_uint64(seed),
+                                                     C.c_float(s), C.c_float(fill or 0.0)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().mrec_o_map_destroy(self._h)
+            self._h = None
+
+    def find_or_insert(self, keys, insert_default=True):
+        keys = _i64(keys).ravel()
+        rows = np.empty(keys.size, np.int32)
+        lib().mrec_o_map_find_or_insert(self._h, _p(keys), C.c_int64(keys.size), C.c_int(int(insert_default)),
+                                        _p(rows))
+        return rows
+
+    def get(self, keys, insert_default=True):
+        keys = _i64(keys).ravel()
+        out = np.empty((keys.size, self.D), np.float32)
+        lib().mrec_o_map_get(self._h, _p(keys), C.c_int64(keys.size), C.c_int(int(insert_default)), _p(out))
+        return out
+
+    def put(self, keys, vals):
+        keys = _i64(keys).ravel()
+        vals = _f32(vals).reshape(keys.size, self.D)
+        lib().mrec_o_map_put(self._h, _p(keys), C.c_int64(keys.size), _p(vals))
+
+    def erase(self, keys):
+        keys = _i64(keys).ravel()
+        lib().mrec_o_map_erase(self._h, _p(keys), C.c_int64(keys.size))
+
+    def size(self):
+        return int(lib().mrec_o_map_size(self._h))
+
+    def export(self):
+        n = self.size()
+        keys = np.empty(n, np.int64)
+        vals = np.empty((n, self.D), np.float32)
+        lib().mrec_o_map_export(self._h, _p(keys), _p(vals))
+        return keys, vals
+
+
+def cross_layers(x0, w, b):
+    x0 = _f32(x0); w = _f32(w); b = _f32(b)
+    B, D = x0.shape
+    L = w.shape[0]
+    out = np.empty_like(x0)
+    lib().mrec_o_cross_layers_f32(_p(x0), _p(w), _p(b), C.c_int32(L), C.c_int64(B), C.c_int32(D), _p(out), None)
+    return out
+
+
+def cross_layers_bwd(x0, w, b, dy):
+    x0 = _f32(x0); w = _f32(w); b = _f32(b); dy = _f32(dy)
+    B, D = x0.shape
+    L = w.shape[0]
+    dx0 = np.empty_like(x0); dw = np.empty_like(w); db = np.empty_like(b)
+    lib().mrec_o_cross_layers_bwd_f32(_p(x0), _p(w), _p(b), C.c_int32(L), C.c_int64(B), C.c_int32(D), _p(dy),
+                                      _p(dx0), _p(dw), _p(db))
+    return dx0, dw, db
+
+
+def shard_route(ids, n_shards):
+    ids_f = _i64(ids).ravel()
+    n = ids_f.size
+    send_local = np.empty(n, np.int64)
+    perm = np.empty(n, np.int32)
+    counts = np.empty(n_shards, np.int64)
+    lib().mrec_o_shard_route_i64(_p(ids_f), C.c_int64(n), C.c_int32(n_shards), _p(send_local), _p(perm), _p(counts))
+    return send_local, perm, counts

@@ -1,0 +1,414 @@
+"""GPU parity: every HIP kernel, through the C-ABI, against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): bit-exact for ids / dedup / index work; fp32 rows within 1e-5
+relative -- and bit-exact where the summation order provably matches the oracle's.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def ids_case(kind, n, V, rng, dtype):
+    if kind == "uniform":
+        x = rng.integers(0, V, size=n)
+    elif kind == "dups":
+        x = rng.integers(0, max(n // 8, 1), size=n)
+    elif kind == "zipf":
+        x = np.minimum(rng.zipf(1.05, size=n) - 1, V - 1)
+    elif kind == "hot":  # Criteo-like: a few ids repeated thousands of times + uniform rest
+        x = rng.integers(0, V, size=n)
+        hot = rng.random(n) < 0.35
+        x[hot] = rng.integers(0, 13, size=hot.sum())
+    elif kind == "same":
+        x = np.full(n, 7)
+    else:
+        raise ValueError(kind)
+    return x.astype(dtype)
+
+
+AW = 16  # mrec_apply.hip: sorted entries per window; runs inside one window are summed in oracle order
+
+
+def crossing(plan):
+    """Per unique id: does its run of sorted entries cross a 16-entry window boundary?"""
+    offs = plan.seg_offsets[: plan.U + 1].cpu().numpy().astype(np.int64)
+    return (offs[:-1] // AW) != ((offs[1:] - 1) // AW)
+
+
+def row_rel(a, b):
+    """Row-wise relative error, inf-norm: max_r |a_r - b_r|_inf / |b_r|_inf."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    den = np.maximum(np.abs(b).max(axis=1), 1e-30)
+    return float((np.abs(a - b).max(axis=1) / den).max()) if a.size else 0.0
+
+
+def check_rows(got, ref, rows_exact, rows_close, tol=RTOL):
+    """got/ref: tuples of [V, D] arrays, parameter first, then optimizer accumulators.  Rows outside
+    rows_close must match bit for bit (they were summed in oracle order, or never touched).  Rows in
+    rows_close: the parameter within tol row-relative; accumulators (sums of cancelling gradient
+    terms, so an element can be arbitrarily close to 0) within tol of the tensor's magnitude."""
+    V = ref[0].shape[0]
+    other = np.ones(V, bool); other[rows_close] = False
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert np.array_equal(a[other].view(np.uint32), b[other].view(np.uint32))
+        if len(rows_close) and k == 0:
+            assert row_rel(a[rows_close], b[rows_close]) <= tol, row_rel(a[rows_close], b[rows_close])
+        elif len(rows_close):
+            err = np.abs(a[rows_close].astype(np.float64) - b[rows_close]).max()
+            assert err <= tol * np.abs(b).max(), (err, np.abs(b).max())
+    assert len(rows_exact) > 0 or len(rows_close) > 0
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-6))) if a.size else 0.0
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("kind,n", [("uniform", 1), ("uniform", 63), ("uniform", 5000), ("dups", 70001), ("zipf", 40000),
+                                    ("hot", 100000), ("same", 3000)])
+def test_unique_and_group(dev, oracle, dtype, kind, n):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(n + (1 if dtype == np.int64 else 0))
+    V = 2_000_000 if dtype == np.int32 else 2**40
+    x = ids_case(kind, n, V, rng, dtype)
+    if dtype == np.int64 and kind == "uniform":
+        x = x - 2**39  # negative keys too
+    u_ref, inv_ref = oracle.unique(x)
+    plan = ops.sparse_plan(T(x, dev))
+    assert plan.U == u_ref.size
+    assert np.array_equal(plan.uniq.cpu().numpy(), u_ref)          # first-occurrence order, bit-exact
+    assert np.array_equal(plan.inv.cpu().numpy(), inv_ref)
+    # inverted index: stable sort of positions by group
+    order = np.argsort(inv_ref, kind="stable").astype(np.int32)
+    assert np.array_equal(plan.sorted_pos[:n].cpu().numpy(), order)
+    assert np.array_equal(plan.sorted_seg[:n].cpu().numpy(), inv_ref[order])
+    offs = np.concatenate([[0], np.cumsum(np.bincount(inv_ref, minlength=u_ref.size))]).astype(np.int32)
+    assert np.array_equal(plan.seg_offsets[: u_ref.size + 1].cpu().numpy(), offs)
+
+
+def test_unique_empty(dev):
+    from mindrec_amd import ops
+    d = ops.unique(torch.empty(0, dtype=torch.int32, device=dev))
+    assert d.U == 0
+    p = ops.group_by_inverse(d)
+    assert int(p.seg_offsets[0].item()) == 0
+
+
+def test_unique_large_bitexact(dev, oracle):
+    """BASELINE cfg2 size: 16384 x 39 ids (13 constant dense-field ids + Zipf categorical)."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(1000)
+    B, F = 16384, 39
+    x = np.minimum(rng.zipf(1.05, size=(B, F)) + 13, 200_000_000 - 1).astype(np.int32)
+    x[:, :13] = np.arange(13, dtype=np.int32)
+    u_ref, inv_ref = oracle.unique(x)
+    plan = ops.sparse_plan(T(x, dev))
+    assert plan.U == u_ref.size
+    assert np.array_equal(plan.uniq.cpu().numpy(), u_ref)
+    assert np.array_equal(plan.inv.cpu().numpy(), inv_ref)
+    order = np.argsort(inv_ref, kind="stable").astype(np.int32)
+    assert np.array_equal(plan.sorted_pos.cpu().numpy(), order)
+
+
+def test_fill_normal_bitexact(dev, oracle):
+    from mindrec_amd import ops
+    for (V, D) in [(1000, 80), (257, 16), (100, 1), (64, 30)]:
+        t = torch.empty((V, D), dtype=torch.float32, device=dev)
+        ops.fill_normal_(t, seed=1000, sigma=0.01)
+        ref = oracle.fill_normal(1000, V, D, 0.01)
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # row offset + padded rows
+    t = torch.zeros((50, 96), dtype=torch.float32, device=dev)
+    ops.fill_normal_(t[:, :80], seed=3, sigma=1.0, row0=12345678901)
+    ref = oracle.fill_normal(3, 50, 80, 1.0, row0=12345678901)
+    assert np.array_equal(t[:, :80].cpu().numpy(), ref)
+    assert float(t[:, 80:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("D", [80, 16, 128, 1, 30, 4, 260, 512])
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+def test_gather_rows(dev, oracle, D, dtype):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(D)
+    V = 5000
+    table = rng.standard_normal((V, D)).astype(np.float32)
+    ids = rng.integers(-3, V + 3, size=(37, 11)).astype(dtype)     # includes out-of-range both sides
+    wts = rng.random((37, 11)).astype(np.float32)
+    tt, ti, tw = T(table, dev), T(ids, dev), T(wts, dev)
+    out = ops.gather_rows(tt, ti).cpu().numpy()
+    assert np.array_equal(out, oracle.gather_rows(table, ids))
+    out = ops.gather_rows(tt, ti, row_scale=tw).cpu().numpy()
+    assert np.array_equal(out, oracle.gather_rows(table, ids, wts))   # one fp32 multiply: bit-exact
+
+
+def test_gather_strided_table(dev, oracle):
+    """Rows embedded in a wider allocation (ld > D)."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(5)
+    big = rng.standard_normal((300, 96)).astype(np.float32)
+    ids = rng.integers(0, 300, size=1000).astype(np.int32)
+    out = ops.gather_rows(T(big, dev)[:, :80], T(ids, dev)).cpu().numpy()
+    assert np.array_equal(out, big[ids, :80])
+
+
+@pytest.mark.parametrize("F", [26, 39, 3])
+def test_wide_sum(dev, oracle, F):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(F)
+    V, B = 10000, 777
+    w = (rng.standard_normal((V, 1)) * 0.01).astype(np.float32)
+    ids = rng.integers(0, V, size=(B, F)).astype(np.int32)
+    wts = rng.random((B, F)).astype(np.float32)
+    bias = np.array([0.125], np.float32)
+    out = ops.wide_sum(T(w, dev), T(ids, dev), T(wts, dev), T(bias, dev)).cpu().numpy()
+    ref = oracle.wide_sum(w, ids, wts, float(bias[0]))
+    assert np.array_equal(out, ref)   # same sequential order over fields -> bit-exact
+
+
+def _adam_case(dev, oracle, kind, n, D, V, dtype, use_scale, nesterov=False, steps=2):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(n * 7 + D)
+    p = (rng.standard_normal((V, D)) * 0.01).astype(np.float32)
+    m = np.zeros((V, D), np.float32); v = np.zeros((V, D), np.float32)
+    tp, tm, tv = T(p, dev), T(m, dev), T(v, dev)
+    b1p, b2p = np.float32(1.0), np.float32(1.0)
+    cross_rows = set()
+    for step in range(steps):
+        ids = ids_case(kind, n, V, rng, dtype)
+        g = (rng.standard_normal((n, D)) * 1024).astype(np.float32)
+        sc = rng.random(n).astype(np.float32) if use_scale else None
+        b1p = np.float32(b1p * np.float32(0.9)); b2p = np.float32(b2p * np.float32(0.999))
+        oracle.sparse_lazy_adam(p, m, v, ids, g, sc, lr=3.5e-4, eps=1e-8, b1_pow=float(b1p), b2_pow=float(b2p),
+                                grad_scale=1.0 / 1024, nesterov=nesterov)
+        plan = ops.sparse_plan(T(ids, dev))
+        ops.sparse_lazy_adam_(tp, tm, tv, plan, T(g, dev), T(sc, dev) if use_scale else None, lr=3.5e-4, eps=1e-8,
+                              beta1_power=float(b1p), beta2_power=float(b2p), grad_scale=1.0 / 1024,
+                              use_nesterov=nesterov)
+        cross_rows.update(plan.uniq.cpu().numpy()[crossing(plan)].tolist())
+    cross_rows = np.array(sorted(r for r in cross_rows if 0 <= r < V), dtype=np.int64)
+    return (tp.cpu().numpy(), tm.cpu().numpy(), tv.cpu().numpy()), (p, m, v), cross_rows
+
+
+@pytest.mark.parametrize("D", [80, 16, 128, 1, 30])
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+def test_lazy_adam_unique_ids_bitexact(dev, oracle, D, dtype):
+    """No duplicate spans a window -> summation order equals the oracle's -> bit-exact."""
+    got, ref, cross = _adam_case(dev, oracle, "uniform", 3000, D, 1_000_000, dtype, use_scale=True)
+    assert cross.size == 0
+    for a, b in zip(got, ref):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("kind", ["dups", "zipf", "hot", "same"])
+@pytest.mark.parametrize("D", [80, 16, 1, 30])
+def test_lazy_adam_duplicates(dev, oracle, kind, D):
+    got, ref, cross = _adam_case(dev, oracle, kind, 20000, D, 50000, np.int32, use_scale=True)
+    # ids whose run stays inside one window: bit-exact.  ids whose run crosses windows are summed as
+    # a fixed tree of window partials: rows within 1e-5 relative of the sequential oracle (1e-4 for
+    # the 20000-copies-of-one-id case, where the oracle's own fp32 chain is ~1e-5 from exact).
+    check_rows(got, ref, rows_exact=[0], rows_close=cross, tol=1e-4 if kind == "same" else RTOL)
+
+
+def test_lazy_adam_nesterov_and_noscale(dev, oracle):
+    got, ref, cross = _adam_case(dev, oracle, "dups", 5000, 80, 20000, np.int32, use_scale=False, nesterov=True)
+    check_rows(got, ref, rows_exact=[0], rows_close=cross)
+
+
+def test_lazy_adam_out_of_range_ids_skipped(dev, oracle):
+    from mindrec_amd import ops
+    V, D = 100, 16
+    p = np.ones((V, D), np.float32); m = np.zeros_like(p); v = np.zeros_like(p)
+    ids = np.array([5, 100, -1, 5, 99], np.int32)
+    g = np.ones((5, D), np.float32)
+    tp, tm, tv = T(p, dev), T(m, dev), T(v, dev)
+    ops.sparse_lazy_adam_(tp, tm, tv, ops.sparse_plan(T(ids, dev)), T(g, dev))
+    oracle.sparse_lazy_adam(p, m, v, ids, g)
+    assert np.array_equal(tp.cpu().numpy(), p)
+    assert (p[[5, 99]] != 1).all() and (np.delete(p, [5, 99], 0) == 1).all()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "hot", "same"])
+@pytest.mark.parametrize("D", [1, 16])
+def test_sparse_ftrl(dev, oracle, kind, D):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(11 + D)
+    V, n = 30000, 20000
+    var = (rng.standard_normal((V, D)) * 0.01).astype(np.float32)
+    acc = np.ones((V, D), np.float32); lin = np.zeros((V, D), np.float32)
+    tv, ta, tl = T(var, dev), T(acc, dev), T(lin, dev)
+    cross = set()
+    for step in range(3):
+        ids = ids_case(kind, n, V, rng, np.int32)
+        g = (rng.standard_normal((n, D)) * 1024).astype(np.float32)
+        oracle.sparse_ftrl(var, acc, lin, ids, g, None, lr=5e-2, l1=1e-8, l2=1e-8, grad_scale=1.0 / 1024)
+        plan = ops.sparse_plan(T(ids, dev))
+        ops.sparse_ftrl_(tv, ta, tl, plan, T(g, dev), None, lr=5e-2, l1=1e-8, l2=1e-8, grad_scale=1.0 / 1024)
+        cross.update(plan.uniq.cpu().numpy()[crossing(plan)].tolist())
+    cross = np.array(sorted(cross), dtype=np.int64)
+    got = (tv.cpu().numpy(), ta.cpu().numpy(), tl.cpu().numpy())
+    # FTRL's weight is a ratio of cancelling sums; for ids with thousands of copies per step the
+    # sequential fp32 oracle is itself ~1e-4 from exact, so those rows get the looser bound.
+    check_rows(got, (var, acc, lin), rows_exact=[0], rows_close=cross, tol=RTOL if kind == "uniform" else 2e-3)
+
+
+def test_ftrl_general_lr_power(dev, oracle):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(2)
+    V, n, D = 1000, 500, 8
+    var = (rng.standard_normal((V, D)) * 0.01).astype(np.float32)
+    acc = np.full((V, D), 0.1, np.float32); lin = np.zeros((V, D), np.float32)
+    tv, ta, tl = T(var, dev), T(acc, dev), T(lin, dev)
+    ids = rng.integers(0, V, n).astype(np.int32); g = rng.standard_normal((n, D)).astype(np.float32)
+    oracle.sparse_ftrl(var, acc, lin, ids, g, None, lr=0.01, l1=1e-3, l2=1e-3, lr_power=-0.3)
+    ops.sparse_ftrl_(tv, ta, tl, ops.sparse_plan(T(ids, dev)), T(g, dev), None, lr=0.01, l1=1e-3, l2=1e-3, lr_power=-0.3)
+    assert np.allclose(tv.cpu().numpy(), var, rtol=1e-4, atol=1e-6)   # powf differs host/device by ulps
+
+
+@pytest.mark.parametrize("kind", ["uniform", "zipf", "hot"])
+@pytest.mark.parametrize("D", [80, 1, 30, 300])
+def test_segment_sum(dev, oracle, kind, D):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(3 + D)
+    n = 9000
+    ids = ids_case(kind, n, 100000, rng, np.int32)
+    g = rng.standard_normal((n, D)).astype(np.float32)
+    u_ref, inv_ref = oracle.unique(ids)
+    ref = oracle.segment_sum(g, inv_ref, u_ref.size)
+    plan = ops.sparse_plan(T(ids, dev))
+    out = ops.segment_sum(plan, T(g, dev))[: plan.U].cpu().numpy()
+    cr = crossing(plan)
+    assert (~cr).sum() > 0
+    assert np.array_equal(out[~cr].view(np.uint32), ref[~cr].view(np.uint32))     # oracle order: bit-exact
+    # any-order fp32 summation bound against the exact (float64) sum: |err| <= (count-1) * eps * sum|x|
+    exact = np.zeros((u_ref.size, D)); absum = np.zeros((u_ref.size, D))
+    np.add.at(exact, inv_ref, g.astype(np.float64)); np.add.at(absum, inv_ref, np.abs(g).astype(np.float64))
+    cnt = np.bincount(inv_ref, minlength=u_ref.size)[:, None]
+    bound = np.maximum(cnt - 1, 1) * 2.0 ** -23 * absum
+    assert (np.abs(out - exact) <= bound).all()
+    assert (np.abs(ref - exact) <= bound).all()        # the oracle obeys the same bound
+
+
+def test_dense_optimizers(dev, oracle):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(4)
+    for n in (1, 7, 4096, 100003):
+        p = rng.standard_normal(n).astype(np.float32); m = rng.standard_normal(n).astype(np.float32) * 0.1
+        v = rng.random(n).astype(np.float32) * 0.01; g = rng.standard_normal(n).astype(np.float32) * 1000
+        tp, tm, tv = T(p, dev), T(m, dev), T(v, dev)
+        ops.dense_adam_(tp, tm, tv, T(g, dev), lr=1e-4, beta1_power=0.81, beta2_power=0.998, grad_scale=1e-3)
+        oracle.dense_adam(p, m, v, g, lr=1e-4, b1_pow=0.81, b2_pow=0.998, grad_scale=1e-3)
+        assert np.array_equal(tp.cpu().numpy(), p) and np.array_equal(tm.cpu().numpy(), m) and np.array_equal(tv.cpu().numpy(), v)
+        w = rng.standard_normal(n).astype(np.float32) * 0.01; a = np.ones(n, np.float32); l = np.zeros(n, np.float32)
+        tw, ta, tl = T(w, dev), T(a, dev), T(l, dev)
+        ops.dense_ftrl_(tw, ta, tl, T(g, dev), grad_scale=1e-3)
+        oracle.dense_ftrl(w, a, l, g, grad_scale=1e-3)
+        assert np.array_equal(tw.cpu().numpy(), w) and np.array_equal(ta.cpu().numpy(), a) and np.array_equal(tl.cpu().numpy(), l)
+
+
+def test_key_index_matches_oracle_map(dev, oracle):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(9)
+    D, cap = 16, 5000
+    om = oracle.Map(D, cap, seed=77, sigma=0.01)
+    ki = ops.KeyIndex(cap, dev)
+    table = torch.zeros((cap, D), dtype=torch.float32, device=dev)
+    for step in range(6):
+        keys = rng.integers(-2**40, 2**40, size=700)
+        keys[:100] = rng.integers(0, 50, size=100)          # recurring keys
+        ukeys, _ = oracle.unique(keys.astype(np.int64))
+        tk = T(ukeys, dev)
+        rows, is_new = ki.find_or_insert(tk, insert=True)
+        ops.init_rows_(table, rows, tk, is_new, seed=77, sigma=0.01)
+        ref_rows = om.find_or_insert(ukeys, True)
+        assert np.array_equal(rows.cpu().numpy(), ref_rows)             # same deterministic row numbering
+        got = ops.gather_rows(table, rows).cpu().numpy()
+        assert np.array_equal(got, om.get(ukeys, True))
+        if step == 2:                                                    # erase some, then keep going
+            er = ukeys[::3].copy()
+            ki.erase(T(er, dev)); om.erase(er)
+            assert len(ki) == om.size()
+    # lookups without insertion
+    probe = np.concatenate([ukeys[:10], np.array([2**50 + 1, 2**50 + 2])]).astype(np.int64)
+    rows, _ = ki.find_or_insert(T(probe, dev), insert=False)
+    assert np.array_equal(rows.cpu().numpy(), om.find_or_insert(probe, False))
+    assert len(ki) == om.size()
+    k, r = ki.export()
+    ok, ov = om.export()
+    assert np.array_equal(np.sort(k.cpu().numpy()), np.sort(ok))
+    vals = ops.gather_rows(table, r).cpu().numpy()
+    order_g, order_o = np.argsort(k.cpu().numpy()), np.argsort(ok)
+    assert np.array_equal(vals[order_g], ov[order_o])
+
+
+def test_key_index_full_and_reuse(dev):
+    from mindrec_amd import ops
+    ki = ops.KeyIndex(100, dev)
+    k1 = torch.arange(0, 100, dtype=torch.int64, device=dev)
+    rows, new = ki.find_or_insert(k1)
+    assert rows.tolist() == list(range(100)) and int(new.sum()) == 100
+    rows, new = ki.find_or_insert(torch.arange(100, 110, dtype=torch.int64, device=dev))
+    assert (rows == -1).all() and int(new.sum()) == 0
+    hwm, live, dropped, free = ki.counters()
+    assert (hwm, live, dropped, free) == (100, 100, 10, 0)
+    ki.erase(torch.tensor([3, 5, 7], dtype=torch.int64, device=dev))
+    rows, new = ki.find_or_insert(torch.tensor([200, 201], dtype=torch.int64, device=dev))
+    assert rows.tolist() == [7, 5]          # free list is LIFO in erase order
+    assert ki.counters()[1] == 99
+
+
+@pytest.mark.parametrize("B,D,L", [(1000, 1170, 6), (77, 64, 3), (33, 30, 1), (500, 1500, 8)])
+def test_cross_layers(dev, oracle, B, D, L):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(B)
+    x0 = rng.standard_normal((B, D)).astype(np.float32) * 0.5
+    w = (rng.standard_normal((L, D)) / np.sqrt(D)).astype(np.float32)
+    b = (rng.standard_normal((L, D)) * 0.1).astype(np.float32)
+    out = ops.cross_layers(T(x0, dev), T(w, dev), T(b, dev)).cpu().numpy()
+    ref = oracle.cross_layers(x0, w, b)
+    assert np.allclose(out, ref, rtol=1e-5, atol=1e-5)
+    dy = rng.standard_normal((B, D)).astype(np.float32)
+    dx0, dw, db = ops.cross_layers_bwd(T(x0, dev), T(w, dev), T(b, dev), T(dy, dev))
+    rdx0, rdw, rdb = oracle.cross_layers_bwd(x0, w, b, dy)
+    assert np.allclose(dx0.cpu().numpy(), rdx0, rtol=1e-4, atol=1e-4)
+    scale = np.abs(rdw).max()
+    assert np.abs(dw.cpu().numpy() - rdw).max() <= 2e-5 * max(scale, 1) * np.sqrt(B)
+    assert np.abs(db.cpu().numpy() - rdb).max() <= 2e-5 * max(np.abs(rdb).max(), 1) * np.sqrt(B)
+
+
+@pytest.mark.parametrize("S", [2, 8, 3])
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+def test_shard_route_roundtrip(dev, oracle, S, dtype):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(S)
+    n, D = 10007, 80
+    ids = rng.integers(0, 10**6, size=n).astype(dtype)
+    if dtype == np.int64:
+        ids[:50] = -ids[:50]
+    loc, perm, counts = ops.shard_route(T(ids, dev), S)
+    rloc, rperm, rcounts = oracle.shard_route(ids, S)
+    assert np.array_equal(loc.cpu().numpy(), rloc.astype(dtype))
+    assert np.array_equal(perm.cpu().numpy(), rperm)
+    assert np.array_equal(counts.cpu().numpy(), rcounts)
+    rows = rng.standard_normal((n, D)).astype(np.float32)
+    sc = rng.random(n).astype(np.float32)
+    back = ops.shard_unroute(T(rows, dev), perm, T(sc, dev)).cpu().numpy()
+    exp = np.empty_like(rows); exp[rperm] = rows * sc[rperm][:, None]
+    assert np.array_equal(back, exp)
+    fwd = ops.shard_route_rows(T(rows, dev), perm, T(sc, dev)).cpu().numpy()
+    assert np.array_equal(fwd, rows[rperm] * sc[rperm][:, None])
+
+
+def test_cpu_tensor_is_refused():
+    """No silent CPU fallback: the product path refuses host tensors."""
+    from mindrec_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.gather_rows(torch.zeros(4, 4), torch.zeros(2, dtype=torch.int32))
