@@ -43,10 +43,11 @@ int mrec_device_ok(void);
 /* ---- table initialisation --------------------------------------------------------------
  * initializer('normal') of nn.EmbeddingLookup / MapParameter default_value
  * (models/wide_deep/default_config.yaml:41; mindspore_rec/ops/embedding.py:88,141).
- * out[r, c] = sigma * N01(seed, row0 + r, c) from the counter-based generator of
- * csrc/mrec_rng.h (bit-identical to the oracle's), written straight into HBM. */
+ * out[r, c] = sigma * N01(seed, row0 + r * row_stride, c) from the counter-based generator of
+ * csrc/mrec_rng.h (bit-identical to the oracle's), written straight into HBM.  A row shard
+ * (owner = id mod n) passes row0 = rank, row_stride = n so values depend on the GLOBAL row only. */
 int mrec_fill_normal_f32(float* out, int64_t nrows, int32_t D, int64_t ld, uint64_t seed,
-                         int64_t row0, float sigma, void* stream);
+                         int64_t row0, int64_t row_stride, float sigma, void* stream);
 
 /* ---- ops.Unique --------------------------------------------------------------------------
  * mindspore_rec/ops/embedding.py:153,192; models/wide_deep/src/wide_and_deep.py:212.
@@ -79,19 +80,25 @@ int mrec_gather_rows_f32_i64(const float* table, int64_t V, int64_t ld, int32_t 
                              int64_t n, const float* row_scale, float* out, void* stream);
 
 /* Wide branch of WideDeepModel.construct (wide_and_deep.py:300,303-306) in one pass:
- * out[b] = sum_f w[ids[b,f]] * wts[b,f] + *bias_dev   (w is the [V,1] wide table). */
-int mrec_wide_sum_f32_i32(const float* w, int64_t V, const int32_t* ids, const float* wts, int64_t B,
+ * out[b] = sum_f w[ids[b,f] * ldw] * wts[b,f] + *bias_dev   (w is the [V,1] wide table, row
+ * stride ldw floats: 1 for a dense column, 4 when it lives in a fused w|accum|linear|pad record). */
+int mrec_wide_sum_f32_i32(const float* w, int64_t V, int64_t ldw, const int32_t* ids, const float* wts, int64_t B,
                           int32_t F, const float* bias_dev, float* out, void* stream);
-int mrec_wide_sum_f32_i64(const float* w, int64_t V, const int64_t* ids, const float* wts, int64_t B,
+int mrec_wide_sum_f32_i64(const float* w, int64_t V, int64_t ldw, const int64_t* ids, const float* wts, int64_t B,
                           int32_t F, const float* bias_dev, float* out, void* stream);
 
 /* ---- sparse gradient apply ----------------------------------------------------------------
  * All three take the inverted index (sorted_pos, sorted_seg, seg_offsets) of the step's ids and
  * the per-position row gradients g[n, D] (row stride ldg).  Contribution i is
  * (g[i,:] * row_scale[i]) * grad_scale, summed per unique id in ascending position order for
- * groups that fit one 16-entry window, and as a fixed-order tree of window partials otherwise
+ * groups that fit one window (mrec_sparse_apply_window), and as a fixed-order tree of window partials otherwise
  * (bitwise reproducible run to run either way).  uniq maps group -> table row. */
 int mrec_sparse_apply_workspace_bytes(int64_t n, int32_t D, size_t* out);
+/* Entries per window of the sorted index for a table of width D: 16 on the float4 path (D % 4 == 0,
+ * rows and row strides 16-byte aligned: aligned16 != 0), 8 on the scalar path.  A group whose run
+ * of sorted entries stays inside one window is summed in ascending position order (= the CPU
+ * reference order); longer runs are a fixed tree of window partials. */
+int mrec_sparse_apply_window(int32_t D, int aligned16);
 
 /* ops.UnsortedSegmentSum (bprop of Gather; models/wide_deep/op_precision.ini:2-3):
  * out[u, :] = sum of contributions of group u, u < U; out is [>=U, D] contiguous. */

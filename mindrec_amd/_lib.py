@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmrec_hip.so")
+# MREC_HIP_LIB selects an alternative build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("MREC_HIP_LIB") or os.path.join(_HERE, "csrc", "libmrec_hip.so")
 
 MREC_OK = 0
 _ERR_NAMES = {-1: "EINVAL", -2: "EWORKSPACE", -3: "EUNSUPPORTED", -4: "EHIP", -5: "ENODEVICE"}
@@ -32,7 +33,7 @@ _SIGS = {
     "mrec_last_hip_error": [],
     "mrec_version": [],
     "mrec_device_ok": [],
-    "mrec_fill_normal_f32": [_vp, _i64, _i32, _i64, _u64, _i64, _f32, _vp],
+    "mrec_fill_normal_f32": [_vp, _i64, _i32, _i64, _u64, _i64, _i64, _f32, _vp],
     "mrec_dedup_workspace_bytes": [_i64, _szp],
     "mrec_dedup_i32": [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_dedup_i64": [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp],
@@ -40,9 +41,10 @@ _SIGS = {
     "mrec_group_by_inverse": [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_gather_rows_f32_i32": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_gather_rows_f32_i64": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
-    "mrec_wide_sum_f32_i32": [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
-    "mrec_wide_sum_f32_i64": [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
+    "mrec_wide_sum_f32_i32": [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
+    "mrec_wide_sum_f32_i64": [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_sparse_apply_workspace_bytes": [_i64, _i32, _szp],
+    "mrec_sparse_apply_window": [_i32, _int],
     "mrec_segment_sum_f32": [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _f32, _i32, _vp, _vp, _sz, _vp],
     "mrec_sparse_lazy_adam_f32_i32": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
                                       _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _sz, _vp],

@@ -6,4 +6,4 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 SRCS=$(ls mrec_*.hip)
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fvisibility=hidden \
-    -Wall -Wno-unused-function $EXTRA_FLAGS -o libmrec_hip.so $SRCS
+    -Wall -Wno-unused-function $EXTRA_FLAGS -o ${OUT:-libmrec_hip.so} $SRCS

@@ -25,17 +25,62 @@
 
 namespace {
 
-constexpr int AW = 16;  // sorted entries per window (one lane-group walks one window)
-constexpr int AB = 4;   // entries whose loads are issued together
+// Per-path tuning (measured on MI355X, V = 200 M, D = 80, batch 16384 x 26, uniform ids):
+//   float4 path : nontemporal loads/stores +10 % (rows are touched once per step: keep them out of
+//                 L2/MALL), 2 entries per batch +4 % over 4 (8 is 15 % slower: past saturation more
+//                 requests in flight only lengthen the queues), 16-entry windows.
+//   scalar path (D = 1 wide table, odd D): cached accesses (the three 4-byte state words of a
+//                 fused w|accum|linear record share one 64-B sector), 8-entry windows.
+#ifndef MREC_AW4
+#define MREC_AW4 16
+#endif
+#ifndef MREC_AB4
+#define MREC_AB4 2
+#endif
+#ifndef MREC_NT4
+#define MREC_NT4 1
+#endif
+#ifndef MREC_AW1
+#define MREC_AW1 8
+#endif
+#ifndef MREC_AB1
+#define MREC_AB1 4
+#endif
+#ifndef MREC_NT1
+#define MREC_NT1 0
+#endif
+template <int VEC> struct ACfg;
+template <> struct ACfg<4> { static constexpr int AW = MREC_AW4, AB = MREC_AB4; static constexpr bool NT = MREC_NT4; };
+template <> struct ACfg<1> { static constexpr int AW = MREC_AW1, AB = MREC_AB1; static constexpr bool NT = MREC_NT1; };
+constexpr int AW_MIN = (MREC_AW4 < MREC_AW1) ? MREC_AW4 : MREC_AW1;
 
 template <int VEC> struct Vf;
 template <> struct Vf<4> { float4 v; };
 template <> struct Vf<1> { float v; };
 
-__device__ __forceinline__ void vload(Vf<4>& r, const float* p) { r.v = *(const float4*)p; }
-__device__ __forceinline__ void vload(Vf<1>& r, const float* p) { r.v = *p; }
-__device__ __forceinline__ void vstore(float* p, const Vf<4>& x) { *(float4*)p = x.v; }
-__device__ __forceinline__ void vstore(float* p, const Vf<1>& x) { *p = x.v; }
+typedef float mrec_f4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ void vload(Vf<4>& r, const float* p) {
+    if (NT) {
+        mrec_f4 t = __builtin_nontemporal_load((const mrec_f4*)p);
+        r.v = make_float4(t.x, t.y, t.z, t.w);
+    } else {
+        r.v = *(const float4*)p;
+    }
+}
+template <bool NT> __device__ __forceinline__ void vload(Vf<1>& r, const float* p) {
+    r.v = NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT> __device__ __forceinline__ void vstore(float* p, const Vf<4>& x) {
+    if (NT) {
+        mrec_f4 t = {x.v.x, x.v.y, x.v.z, x.v.w};
+        __builtin_nontemporal_store(t, (mrec_f4*)p);
+    } else {
+        *(float4*)p = x.v;
+    }
+}
+template <bool NT> __device__ __forceinline__ void vstore(float* p, const Vf<1>& x) {
+    if (NT) __builtin_nontemporal_store(x.v, p); else *p = x.v;
+}
 __device__ __forceinline__ void vzero(Vf<4>& r) { r.v = make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void vzero(Vf<1>& r) { r.v = 0.f; }
 __device__ __forceinline__ void vmul(Vf<4>& x, float s) { x.v.x *= s; x.v.y *= s; x.v.z *= s; x.v.w *= s; }
@@ -100,6 +145,8 @@ __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t 
                                                     const float* __restrict__ rscale, float gscale, ApplyGeom gm,
                                                     float* __restrict__ carry_head, float* __restrict__ carry_tail,
                                                     int* __restrict__ owners, int* __restrict__ n_owners) {
+    constexpr int AW = ACfg<VEC>::AW, AB = ACfg<VEC>::AB;
+    constexpr bool NT = ACfg<VEC>::NT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
     if (grp >= gm.G) return;  // spare lanes; this kernel has no barriers
@@ -136,7 +183,7 @@ __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t 
             rs[k] = 1.0f;
             vzero(gv[k]);
             if (valid[k]) {
-                vload(gv[k], g + (int64_t)pos * ldg + col);
+                vload<NT>(gv[k], g + (int64_t)pos * ldg + col);
                 if (rscale) rs[k] = rscale[pos];
             }
         }
@@ -155,7 +202,7 @@ __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t 
                     roff[k] = row * ld + col;
                     if (Upd::kLoad) {
 #pragma unroll
-                        for (int i = 0; i < Upd::NS; ++i) vload(st[k][i], upd.s[i] + roff[k]);
+                        for (int i = 0; i < Upd::NS; ++i) vload<NT>(st[k][i], upd.s[i] + roff[k]);
                     }
                 }
             }
@@ -169,11 +216,11 @@ __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t 
             if (is_start[k]) acc = gv[k]; else vadd(acc, gv[k]);
             if (is_end[k]) {
                 if (open[k]) {
-                    vstore(carry_head + sw * gm.D + col, acc);
+                    vstore<false>(carry_head + sw * gm.D + col, acc);
                 } else if (upd_ok[k]) {
                     upd_apply<Upd>(upd, st[k], acc);
 #pragma unroll
-                    for (int i = 0; i < Upd::NS; ++i) vstore(upd.s[i] + roff[k], st[k][i]);
+                    for (int i = 0; i < Upd::NS; ++i) vstore<NT>(upd.s[i] + roff[k], st[k][i]);
                 }
             }
         }
@@ -184,9 +231,9 @@ __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t 
     const int last_seg = sseg[e_end - 1];
     if (e_end < n && sseg[e_end] == last_seg) {
         if (head_open && last_seg == first_seg) {
-            vstore(carry_head + sw * gm.D + col, acc);  // window lies wholly inside one run
+            vstore<false>(carry_head + sw * gm.D + col, acc);  // window lies wholly inside one run
         } else {
-            vstore(carry_tail + sw * gm.D + col, acc);
+            vstore<false>(carry_tail + sw * gm.D + col, acc);
             if (sub == 0) owners[atomicAdd(n_owners, 1)] = (int)sw;
         }
     }
@@ -203,6 +250,7 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
                                                     const float* __restrict__ carry_tail,
                                                     const int* __restrict__ owners,
                                                     const int* __restrict__ n_owners) {
+    constexpr int AW = ACfg<VEC>::AW, AB = 4;
     __shared__ float red[256 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
@@ -229,7 +277,7 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
                     vzero(x[q]);
                     if (t <= k) {
                         const float* src = (t == 0) ? carry_tail + (int64_t)sw * gm.D : carry_head + (int64_t)(sw + t) * gm.D;
-                        vload(x[q], src + col);
+                        vload<false>(x[q], src + col);
                     }
                 }
 #pragma unroll
@@ -239,14 +287,14 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
                     }
                 }
             }
-            vstore(red + gi * gm.D + col, acc);
+            vstore<false>(red + gi * gm.D + col, acc);
         }
         __syncthreads();
         if (active && gi == 0) {
             const int ng = (k + 1 < NG) ? k + 1 : NG;
             for (int q = 1; q < ng; ++q) {
                 Vf<VEC> x;
-                vload(x, red + q * gm.D + col);
+                vload<false>(x, red + q * gm.D + col);
                 vadd(acc, x);
             }
             const int64_t row = seg_row<K>(uniq, u);
@@ -255,11 +303,11 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
                 Vf<VEC> st[Upd::NS];
                 if (Upd::kLoad) {
 #pragma unroll
-                    for (int i = 0; i < Upd::NS; ++i) vload(st[i], upd.s[i] + roff);
+                    for (int i = 0; i < Upd::NS; ++i) vload<false>(st[i], upd.s[i] + roff);
                 }
                 upd_apply<Upd>(upd, st, acc);
 #pragma unroll
-                for (int i = 0; i < Upd::NS; ++i) vstore(upd.s[i] + roff, st[i]);
+                for (int i = 0; i < Upd::NS; ++i) vstore<false>(upd.s[i] + roff, st[i]);
             }
         }
         __syncthreads();
@@ -271,7 +319,7 @@ inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 struct ApplyWs { float* carry_head; float* carry_tail; int* owners; int* n_owners; };
 
 size_t apply_ws_bytes(int64_t n, int32_t D) {
-    const size_t nsw = (size_t)mrec_cdiv(n ? n : 1, AW);
+    const size_t nsw = (size_t)mrec_cdiv(n ? n : 1, AW_MIN);
     const int Dc = D > 256 ? 256 : D;
     return mrec_align_up(nsw * Dc * 4, 256) * 2 + mrec_align_up(nsw * 4, 256) + 256;
 }
@@ -285,7 +333,7 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
     gm.D = Dc;
     gm.lpr = vec ? Dc / 4 : Dc;
     gm.G = 64 / gm.lpr;
-    const int64_t nsw = mrec_cdiv(n, AW);
+    const int64_t nsw = mrec_cdiv(n, vec ? ACfg<4>::AW : ACfg<1>::AW);
     const unsigned blocks = (unsigned)mrec_cdiv(nsw, (int64_t)4 * gm.G);
     MREC_HIP_CHECK(hipMemsetAsync(w.n_owners, 0, sizeof(int), st));
     unsigned lblocks = (unsigned)(nsw < 2048 ? nsw : 2048);
@@ -315,7 +363,7 @@ int apply_impl(Upd upd, int64_t V, int64_t ld, int32_t D, const K* uniq, const i
     for (int i = 0; i < Upd::NS; ++i) if (!upd.s[i]) return MREC_EINVAL;
     if (n > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
     if (ws_bytes < apply_ws_bytes(n, D)) return MREC_EWORKSPACE;
-    const size_t nsw = (size_t)mrec_cdiv(n, AW);
+    const size_t nsw = (size_t)mrec_cdiv(n, AW_MIN);
     const int Dc_max = D > 256 ? 256 : D;
     MrecArena a(ws, ws_bytes);
     ApplyWs w;
@@ -367,6 +415,10 @@ int ftrl_impl(float* var, float* accum, float* linear, int64_t V, int64_t ld, in
 }
 
 }  // namespace
+
+MREC_API int mrec_sparse_apply_window(int32_t D, int aligned16) {
+    return (aligned16 && D % 4 == 0) ? ACfg<4>::AW : ACfg<1>::AW;
+}
 
 MREC_API int mrec_sparse_apply_workspace_bytes(int64_t n, int32_t D, size_t* out) {
     if (!out || n < 0 || D <= 0) return MREC_EINVAL;

@@ -175,7 +175,7 @@ MREC_API int mrec_group_workspace_bytes(int64_t n, size_t* out) {
     if (n > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
     const size_t nn = (size_t)(n ? n : 1);
     size_t b = 0;
-    b += mrec_align_up((size_t)mrec_cdiv(nn, RT) * RNB * 4, 256);
+    b += mrec_align_up((size_t)mrec_cdiv(nn, RT) * RNB * 4, 256) * 2;
     b += mrec_align_up((size_t)RNB * 4, 256);
     b += mrec_align_up(nn * 4, 256) * 2;
     *out = b;
@@ -195,7 +195,8 @@ MREC_API int mrec_group_by_inverse(const int32_t* inv, int64_t n, int32_t* sorte
     const int nblk = (int)mrec_cdiv(n, RT);
     MrecArena a(ws, ws_bytes);
     int* hist = a.take<int>((size_t)nblk * RNB);
-    int* dbase = a.take<int>(RNB);
+    int* hscan = a.take<int>((size_t)nblk * RNB);
+    int* totals = a.take<int>(RNB);
     int* tk = a.take<int>(n);
     int* tv = a.take<int>(n);
     if (!a.ok) return MREC_EWORKSPACE;
@@ -210,7 +211,7 @@ MREC_API int mrec_group_by_inverse(const int32_t* inv, int64_t n, int32_t* sorte
         int* kout = to_user ? sorted_seg : tk;
         int* vout = to_user ? sorted_pos : tv;
         const int shift = p * pbits;
-        radix_pass(kin, vin, (int)n, shift, pbits, hist, dbase, kout, vout, st);
+        radix_pass(kin, vin, (int)n, shift, pbits, hist, hscan, totals, nullptr, kout, vout, st);
         kin = kout;
         vin = vout;
     }

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_gather_rows_generic(const float* __rest
 }
 
 template <class K>
-__global__ __launch_bounds__(256) void k_wide_sum(const float* __restrict__ w, int64_t V,
+__global__ __launch_bounds__(256) void k_wide_sum(const float* __restrict__ w, int64_t V, int64_t ldw,
                                                   const K* __restrict__ ids, const float* __restrict__ wts,
                                                   int64_t B, int F, const float* __restrict__ bias,
                                                   float* __restrict__ out) {
@@ -103,21 +103,21 @@ __global__ __launch_bounds__(256) void k_wide_sum(const float* __restrict__ w, i
         for (int k = 0; k < 4; ++k) {
             const int64_t r = (int64_t)id[f + k];
             t[k] = wt[f + k];
-            x[k] = (r >= 0 && r < V) ? w[r] : 0.0f;
+            x[k] = (r >= 0 && r < V) ? w[r * ldw] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc = acc + x[k] * t[k];
     }
     for (; f < F; ++f) {
         const int64_t r = (int64_t)id[f];
-        const float x = (r >= 0 && r < V) ? w[r] : 0.0f;
+        const float x = (r >= 0 && r < V) ? w[r * ldw] : 0.0f;
         acc = acc + x * wt[f];
     }
     out[b] = acc + (bias ? *bias : 0.0f);
 }
 
 __global__ __launch_bounds__(256) void k_fill_normal(float* __restrict__ out, int64_t nrows, int D, int64_t ld,
-                                                     uint64_t seed, int64_t row0, float sigma) {
+                                                     uint64_t seed, int64_t row0, int64_t row_stride, float sigma) {
     // one thread per (row, 4-column chunk); chunks per row = ceil(D/4)
     const int cpr = (D + 3) >> 2;
     const int64_t total = nrows * cpr;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_fill_normal(float* __restrict__ out, in
         float* o = out + r * ld + c0;
         float x[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = (c0 + k < D) ? sigma * mrec_det_normal(seed, row0 + r, c0 + k) : 0.0f;
+        for (int k = 0; k < 4; ++k) x[k] = (c0 + k < D) ? sigma * mrec_det_normal(seed, row0 + r * row_stride, c0 + k) : 0.0f;
         if (c0 + 4 <= D && ((ld & 3) == 0) && ((((uintptr_t)out) & 15) == 0)) {
             *(float4*)o = make_float4(x[0], x[1], x[2], x[3]);
         } else {
@@ -230,12 +230,12 @@ int gather_impl(const float* table, int64_t V, int64_t ld, int32_t D, const K* i
 }
 
 template <class K>
-int wide_sum_impl(const float* w, int64_t V, const K* ids, const float* wts, int64_t B, int32_t F,
+int wide_sum_impl(const float* w, int64_t V, int64_t ldw, const K* ids, const float* wts, int64_t B, int32_t F,
                   const float* bias_dev, float* out, void* stream) {
-    if (B < 0 || F <= 0 || V < 0) return MREC_EINVAL;
+    if (B < 0 || F <= 0 || V < 0 || ldw < 1) return MREC_EINVAL;
     if (B == 0) return MREC_OK;
     if (!w || !ids || !wts || !out) return MREC_EINVAL;
-    k_wide_sum<K><<<(unsigned)mrec_cdiv(B, 256), 256, 0, (hipStream_t)stream>>>(w, V, ids, wts, B, F, bias_dev, out);
+    k_wide_sum<K><<<(unsigned)mrec_cdiv(B, 256), 256, 0, (hipStream_t)stream>>>(w, V, ldw, ids, wts, B, F, bias_dev, out);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -276,12 +276,12 @@ MREC_API int mrec_device_ok(void) {
 }
 
 MREC_API int mrec_fill_normal_f32(float* out, int64_t nrows, int32_t D, int64_t ld, uint64_t seed, int64_t row0,
-                                  float sigma, void* stream) {
+                                  int64_t row_stride, float sigma, void* stream) {
     if (nrows < 0 || D <= 0 || ld < D) return MREC_EINVAL;
     if (nrows == 0) return MREC_OK;
     if (!out) return MREC_EINVAL;
     const int64_t total = nrows * ((D + 3) / 4);
-    k_fill_normal<<<stream_grid(total), 256, 0, (hipStream_t)stream>>>(out, nrows, D, ld, seed, row0, sigma);
+    k_fill_normal<<<stream_grid(total), 256, 0, (hipStream_t)stream>>>(out, nrows, D, ld, seed, row0, row_stride, sigma);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -295,13 +295,13 @@ MREC_API int mrec_gather_rows_f32_i64(const float* table, int64_t V, int64_t ld,
     return gather_impl<int64_t>(table, V, ld, D, ids, n, row_scale, out, stream);
 }
 
-MREC_API int mrec_wide_sum_f32_i32(const float* w, int64_t V, const int32_t* ids, const float* wts, int64_t B,
-                                   int32_t F, const float* bias_dev, float* out, void* stream) {
-    return wide_sum_impl<int32_t>(w, V, ids, wts, B, F, bias_dev, out, stream);
+MREC_API int mrec_wide_sum_f32_i32(const float* w, int64_t V, int64_t ldw, const int32_t* ids, const float* wts,
+                                   int64_t B, int32_t F, const float* bias_dev, float* out, void* stream) {
+    return wide_sum_impl<int32_t>(w, V, ldw, ids, wts, B, F, bias_dev, out, stream);
 }
-MREC_API int mrec_wide_sum_f32_i64(const float* w, int64_t V, const int64_t* ids, const float* wts, int64_t B,
-                                   int32_t F, const float* bias_dev, float* out, void* stream) {
-    return wide_sum_impl<int64_t>(w, V, ids, wts, B, F, bias_dev, out, stream);
+MREC_API int mrec_wide_sum_f32_i64(const float* w, int64_t V, int64_t ldw, const int64_t* ids, const float* wts,
+                                   int64_t B, int32_t F, const float* bias_dev, float* out, void* stream) {
+    return wide_sum_impl<int64_t>(w, V, ldw, ids, wts, B, F, bias_dev, out, stream);
 }
 
 MREC_API int mrec_init_rows_f32(float* table, int64_t ld, int32_t D, const int32_t* rows, const int64_t* keys,

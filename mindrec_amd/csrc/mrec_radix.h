@@ -31,53 +31,65 @@ __global__ __launch_bounds__(256) void k_radix_hist(const int* __restrict__ keys
     for (int d = threadIdx.x; d < NB; d += 256) hist[(int64_t)blockIdx.x * NB + d] = h[d];
 }
 
-// One block of 1024 threads: per digit, exclusive prefix over tiles (in place), then exclusive
-// prefix of digit totals into dbase.
-__global__ __launch_bounds__(1024) void k_radix_scan(int* __restrict__ hist, int nblk, int nbits,
-                                                     int* __restrict__ dbase) {
-    __shared__ int wsum[16];
+// Per digit column: exclusive prefix over tiles (hist -> hscan) and the column total.  One thread
+// per digit, 256 threads per block, loads unrolled 8 deep (input and output do not alias, so the
+// loads of a chunk are all in flight before the first add).
+__global__ __launch_bounds__(256) void k_radix_colscan(const int* __restrict__ hist, int nblk, int nbits,
+                                                       int* __restrict__ hscan, int* __restrict__ totals) {
     const int NB = 1 << nbits;
-    const int per = (NB + 1023) / 1024;  // 1 or 2 digits per thread
-    const int d0 = threadIdx.x * per;
-    int run0 = 0, run1 = 0;
-    if (d0 < NB) {
-        if (per == 1) {
-            for (int b = 0; b < nblk; ++b) {
-                int* p = hist + (int64_t)b * NB + d0;
-                const int t = *p; *p = run0; run0 += t;
-            }
-        } else {
-            for (int b = 0; b < nblk; ++b) {
-                int2* p = (int2*)(hist + (int64_t)b * NB + d0);
-                const int2 t = *p;
-                *p = make_int2(run0, run1);
-                run0 += t.x; run1 += t.y;
-            }
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= NB) return;
+    int run = 0;
+    int b = 0;
+    for (; b + 8 <= nblk; b += 8) {
+        int t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = hist[(int64_t)(b + k) * NB + d];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            hscan[(int64_t)(b + k) * NB + d] = run;
+            run += t[k];
         }
     }
-    const int mine = run0 + run1;
-    int incl = wave_incl_scan(mine);
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if (l == 63) wsum[w] = incl;
-    __syncthreads();
-    int base = 0;
-    for (int i = 0; i < w; ++i) base += wsum[i];
-    const int excl = base + incl - mine;
-    if (d0 < NB) {
-        dbase[d0] = excl;
-        if (per == 2) dbase[d0 + 1] = excl + run0;
+    for (; b < nblk; ++b) {
+        const int t = hist[(int64_t)b * NB + d];
+        hscan[(int64_t)b * NB + d] = run;
+        run += t;
     }
+    totals[d] = run;
 }
 
 __global__ __launch_bounds__(256) void k_radix_scatter(const int* __restrict__ keys_in,
                                                        const int* __restrict__ vals_in, int n, int shift,
                                                        int nbits, const int* __restrict__ hist,
-                                                       const int* __restrict__ dbase, int* __restrict__ keys_out,
-                                                       int* __restrict__ vals_out) {
+                                                       const int* __restrict__ totals, int* __restrict__ keys_out,
+                                                       int* __restrict__ vals_out, int* __restrict__ dbase_out) {
     __shared__ int cnt[4][RNB];
+    __shared__ int dbase[RNB];
+    __shared__ int sm[8];
     const int NB = 1 << nbits;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     for (int d = threadIdx.x; d < 4 * RNB; d += 256) (&cnt[0][0])[d] = 0;
+    {   // exclusive scan of the digit totals (every block recomputes it: NB <= 2048 ints from L2)
+        const int per = (NB + 255) / 256;      // <= 8 consecutive digits per thread
+        const int d0 = threadIdx.x * per;
+        int t[8], s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            t[k] = (k < per && d0 + k < NB) ? totals[d0 + k] : 0;
+            s += t[k];
+        }
+        int tot;
+        int run = block_excl_scan_256(s, sm, &tot);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < per && d0 + k < NB) {
+                dbase[d0 + k] = run;
+                if (dbase_out && blockIdx.x == 0) dbase_out[d0 + k] = run;
+                run += t[k];
+            }
+        }
+    }
     __syncthreads();
     volatile int* my = cnt[w];
     const int base = blockIdx.x * RT + w * (RROUNDS * 64);
@@ -131,14 +143,15 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const int* __restrict__ k
 
 
 // Runs pass (shift, nbits) of the sort: keys_in/vals_in -> keys_out/vals_out (vals_in == nullptr
-// means "identity").  hist: [nblk * 2^nbits] ints, dbase: [2^nbits] ints (exclusive digit offsets
-// on return).
-inline void radix_pass(const int* kin, const int* vin, int n, int shift, int nbits, int* hist, int* dbase, int* kout,
-                       int* vout, hipStream_t st) {
+// means "identity").  hist, hscan: [nblk * 2^nbits] ints each; totals: [2^nbits]; dbase (nullable):
+// [2^nbits] ints, receives the exclusive digit offsets.
+inline void radix_pass(const int* kin, const int* vin, int n, int shift, int nbits, int* hist, int* hscan, int* totals,
+                       int* dbase, int* kout, int* vout, hipStream_t st) {
     const int nblk = (int)mrec_cdiv(n, RT);
+    const int NB = 1 << nbits;
     k_radix_hist<<<nblk, 256, 0, st>>>(kin, n, shift, nbits, hist);
-    k_radix_scan<<<1, 1024, 0, st>>>(hist, nblk, nbits, dbase);
-    k_radix_scatter<<<nblk, 256, 0, st>>>(kin, vin, n, shift, nbits, hist, dbase, kout, vout);
+    k_radix_colscan<<<(NB + 255) / 256, 256, 0, st>>>(hist, nblk, nbits, hscan, totals);
+    k_radix_scatter<<<nblk, 256, 0, st>>>(kin, vin, n, shift, nbits, hscan, totals, kout, vout, dbase);
 }
 
 }  // namespace

@@ -69,6 +69,8 @@ int route_impl(const K* ids, int64_t n, int32_t S, K* send_local, int32_t* send_
     const int nblk = (int)mrec_cdiv(n, RT);
     MrecArena a(ws, ws_bytes);
     int* hist = a.take<int>((size_t)nblk * RNB);
+    int* hscan = a.take<int>((size_t)nblk * RNB);
+    int* totals = a.take<int>(RNB);
     int* dbase = a.take<int>(RNB);
     int* owner = a.take<int>(n);
     int* okeys = a.take<int>(n);
@@ -76,7 +78,7 @@ int route_impl(const K* ids, int64_t n, int32_t S, K* send_local, int32_t* send_
     int nbits = 1;
     while ((1 << nbits) < S) ++nbits;
     k_owner<K><<<(unsigned)mrec_cdiv(n, 256), 256, 0, st>>>(ids, n, S, owner);
-    radix_pass(owner, nullptr, (int)n, 0, nbits, hist, dbase, okeys, send_perm, st);
+    radix_pass(owner, nullptr, (int)n, 0, nbits, hist, hscan, totals, dbase, okeys, send_perm, st);
     const int64_t m = n > S ? n : S;
     k_route_finish<K><<<(unsigned)mrec_cdiv(m, 256), 256, 0, st>>>(ids, n, S, send_perm, dbase, send_local, counts_dev);
     MREC_LAUNCH_CHECK();
@@ -88,7 +90,7 @@ int route_impl(const K* ids, int64_t n, int32_t S, K* send_local, int32_t* send_
 MREC_API int mrec_shard_route_workspace_bytes(int64_t n, int32_t n_shards, size_t* out) {
     if (!out || n < 0 || n_shards <= 0) return MREC_EINVAL;
     const size_t nn = (size_t)(n ? n : 1);
-    *out = mrec_align_up((size_t)mrec_cdiv(nn, RT) * RNB * 4, 256) + mrec_align_up((size_t)RNB * 4, 256) +
+    *out = mrec_align_up((size_t)mrec_cdiv(nn, RT) * RNB * 4, 256) * 2 + mrec_align_up((size_t)RNB * 4, 256) * 2 +
            mrec_align_up(nn * 4, 256) * 2;
     return MREC_OK;
 }

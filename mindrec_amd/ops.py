@@ -51,11 +51,12 @@ def _table(t):
     return t.shape[0], t.shape[1], t.stride(0)
 
 
-def fill_normal_(table, seed, sigma=0.01, row0=0):
-    """initializer('normal') written on the device (default_config.yaml:41; embedding.py:88)."""
+def fill_normal_(table, seed, sigma=0.01, row0=0, row_stride=1):
+    """initializer('normal') written on the device (default_config.yaml:41; embedding.py:88).
+    Row r of `table` gets the values of global row row0 + r*row_stride."""
     _need_cuda(table)
     V, D, ld = _table(table)
-    _lib.call("mrec_fill_normal_f32", _ptr(table), V, D, ld, C.c_uint64(seed), row0, sigma, _stream())
+    _lib.call("mrec_fill_normal_f32", _ptr(table), V, D, ld, C.c_uint64(seed), row0, row_stride, sigma, _stream())
     return table
 
 
@@ -153,13 +154,13 @@ def wide_sum(w, ids, wts, bias=None):
     if ids.dim() != 2:
         raise ValueError("ids must be [B, F]")
     B, F = ids.shape
-    wf = w.reshape(-1)
-    if wf.dtype != torch.float32 or not wf.is_contiguous():
-        raise TypeError("w must be a contiguous float32 [V,1] table")
+    if w.dtype != torch.float32 or w.dim() != 2 or w.shape[1] != 1:
+        raise TypeError("w must be a float32 [V,1] table (any row stride)")
+    V, ldw = w.shape[0], (w.stride(0) if w.shape[0] > 1 else 1)
     ids_c = ids.contiguous()
     wts_c = wts.contiguous()
     out = torch.empty(B, dtype=torch.float32, device=w.device)
-    _lib.call(f"mrec_wide_sum_f32_{sfx}", _ptr(wf), wf.numel(), _ptr(ids_c), _ptr(wts_c), B, F, _ptr(bias), _ptr(out),
+    _lib.call(f"mrec_wide_sum_f32_{sfx}", _ptr(w), V, ldw, _ptr(ids_c), _ptr(wts_c), B, F, _ptr(bias), _ptr(out),
               _stream())
     return out
 
@@ -185,6 +186,11 @@ def _row_scale(plan, row_scale):
 def _apply_ws(plan, D, dev):
     nb = _lib.query_bytes("mrec_sparse_apply_workspace_bytes", plan.n, D)
     return workspace("apply", nb, dev)
+
+
+def apply_window(D, aligned=True):
+    """Sorted-index window of the sparse-apply kernels for width D (see include/mrec.h)."""
+    return int(_lib.lib().mrec_sparse_apply_window(D, int(aligned)))
 
 
 def segment_sum(plan, g, row_scale=None, grad_scale=1.0):

@@ -1,0 +1,348 @@
+"""Wide&Deep training step on the MI355X embedding path.
+
+Mirrors, op for op, what one call of TrainStepWrap.construct does in the reference
+(models/wide_deep/src/wide_and_deep.py:472-492) in its sparse configuration -- the one BASELINE
+config 2/4 names (SURVEY.md 8(a) "Which mode is the W&D hot path"):
+
+  WideDeepModel.construct      :293-316  two lookups sharing one id tensor, mask multiply, wide
+                                         reduce-sum + bias, 5-layer MLP, wide + deep
+  NetWithLossClass.construct   :349-362  sigmoid cross-entropy, mean; no L2 term when sparse
+  TrainStepWrap.__init__       :415-433  LazyAdam(lr 3.5e-4, eps 1e-8) on non-"wide" params,
+                                         FTRL(lr 5e-2, l1 = l2 = 1e-8, initial_accum 1.0) on "wide" params,
+                                         both with loss_scale = sens = 1024
+  TrainStepWrap.construct      :472-492  backward seeded with sens, optional grad reducer, two applies
+
+The reference writes the forward three times and lets MindSpore's graph compiler merge them; here
+it simply runs once.  Embedding lookups, the id dedup and both sparse applies are libmrec_hip.so
+kernels; the MLP (true GEMMs) goes to hipBLASLt through torch, with fp32 master weights kept in one
+flat buffer so the dense LazyAdam (= Adam on dense gradients) is a single kernel launch.
+
+Multi-GPU ("hybrid parallel", README.md:140-144): both tables are row-sharded, owner = id mod n,
+local row = id div n.  Per step: bucket ids by owner -> RCCL all-to-all ids -> local gather ->
+all-to-all rows back; backward: all-to-all row-gradients to the owners -> local dedup + sparse
+apply (optimizer state is shard-local, the table gradient is never all-reduced).  The MLP stays
+data-parallel with one flat all-reduce(mean) (gradients_mean=True,
+train_and_eval_distribute.py:135-138).
+"""
+import contextlib
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import ops
+
+
+@dataclass
+class WideDeepConfig:
+    """Field names follow models/wide_deep/default_config.yaml:14-44."""
+    vocab_size: int = 200_000_000
+    emb_dim: int = 80
+    field_size: int = 39
+    batch_size: int = 16384
+    deep_layer_dim: List[int] = field(default_factory=lambda: [1024, 512, 256, 128])
+    sens: float = 1024.0                 # TrainStepWrap(sens=1024.0), wide_and_deep.py:390
+    adam_lr: float = 3.5e-4              # :420
+    adam_eps: float = 1e-8
+    ftrl_lr: float = 5e-2                # :423-430
+    ftrl_l1: float = 1e-8
+    ftrl_l2: float = 1e-8
+    ftrl_initial_accum: float = 1.0
+    init_sigma: float = 0.01             # emb_init / weight_bias_init 'normal' [EXT: N(0, 0.01)]
+    seed: int = 1000                     # set_seed(1000), train_and_eval_distribute.py:72
+    mlp_dtype: str = "bf16"              # reference casts the MLP to fp16 (use_mixed_precision); bf16 on MI355X
+    id_dtype: str = "int32"              # dataset contract, process_data.py:204-206
+    # HBM layout: one allocation per table with the optimizer state beside the weights --
+    # deep rows are [p(D) | m(D) | v(D)] (960 B contiguous at D = 80), wide rows [w | accum | linear | pad]
+    # (16 B).  The sparse apply then touches one contiguous run per row instead of three rows 64 GB
+    # apart (fewer DRAM activations and TLB walks per byte: +6-8 % on MI355X); the API still sees
+    # p, m, v, w, ... as separate (strided) [V, D] / [V, 1] tensors.  False = three separate arrays.
+    fused_state: bool = True
+
+
+def _flat_views(shapes, device):
+    n = sum(int(np.prod(s)) for s in shapes)
+    flat = torch.zeros(n, dtype=torch.float32, device=device)
+    views, off = [], 0
+    for s in shapes:
+        k = int(np.prod(s))
+        views.append(flat[off:off + k].view(s))
+        off += k
+    return flat, views
+
+
+class WideDeepEngine:
+    """State + one training step.  rank/world describe the row sharding; world == 1 is one GPU."""
+
+    def __init__(self, cfg: WideDeepConfig, device, rank=0, world=1, group=None, kernels=None):
+        """kernels: module providing the op set of mindrec_amd.ops.  The product always uses the HIP
+        one (default); tests/ inject a CPU stand-in to exercise the multi-rank host logic under gloo."""
+        self.cfg, self.device, self.rank, self.world, self.group = cfg, torch.device(device), rank, world, group
+        self.k = kernels if kernels is not None else ops
+        self._gpu = self.device.type == "cuda"
+        if kernels is None and not self._gpu:
+            raise RuntimeError("WideDeepEngine runs on an MI355X (no CPU fallback)")
+        V, D = cfg.vocab_size, cfg.emb_dim
+        self.local_rows = (V - rank + world - 1) // world          # rows r with r*world + rank < V
+        dev = self.device
+        with (torch.cuda.device(dev) if self._gpu else contextlib.nullcontext()):
+            # deep table + Adam moments, wide table + FTRL accumulators: plain row-major fp32 in HBM
+            R = self.local_rows
+            if cfg.fused_state:
+                self.deep_state = torch.empty((R, 3 * D), dtype=torch.float32, device=dev)
+                self.deep, self.deep_m, self.deep_v = (self.deep_state[:, :D], self.deep_state[:, D:2 * D],
+                                                       self.deep_state[:, 2 * D:])
+                self.wide_state = torch.zeros((R, 4), dtype=torch.float32, device=dev)
+                self.wide, self.wide_accum, self.wide_linear = (self.wide_state[:, 0:1], self.wide_state[:, 1:2],
+                                                                self.wide_state[:, 2:3])
+            else:
+                self.deep = torch.empty((R, D), dtype=torch.float32, device=dev)
+                self.deep_m, self.deep_v = torch.empty_like(self.deep), torch.empty_like(self.deep)
+                self.wide = torch.empty((R, 1), dtype=torch.float32, device=dev)
+                self.wide_accum, self.wide_linear = torch.empty_like(self.wide), torch.empty_like(self.wide)
+            self.k.fill_normal_(self.deep, cfg.seed, cfg.init_sigma, row0=rank, row_stride=world)
+            self.deep_m.zero_()
+            self.deep_v.zero_()
+            self.k.fill_normal_(self.wide, cfg.seed + 1, cfg.init_sigma, row0=rank, row_stride=world)
+            self.wide_accum.fill_(cfg.ftrl_initial_accum)
+            self.wide_linear.zero_()
+            # MLP: fp32 master weights in one flat buffer (views below), same for grads / m / v
+            dims = [cfg.field_size * D] + list(cfg.deep_layer_dim) + [1]
+            shapes = []
+            for i in range(len(dims) - 1):
+                shapes += [(dims[i], dims[i + 1]), (dims[i + 1],)]
+            self.dims = dims
+            self.dense_flat, self.dense = _flat_views(shapes, dev)
+            self.dense_grad_flat, self.dense_grad = _flat_views(shapes, dev)
+            self.dense_m = torch.zeros_like(self.dense_flat)
+            self.dense_v = torch.zeros_like(self.dense_flat)
+            # identical on every rank: global row 0.. of a [n,1] "table" keyed by a private seed
+            self.k.fill_normal_(self.dense_flat.view(-1, 1), cfg.seed + 2, cfg.init_sigma)
+            for p, g in zip(self.dense, self.dense_grad):
+                p.requires_grad_(True)
+                p.grad = g
+            self.wide_b = torch.zeros(1, dtype=torch.float32, device=dev)   # "Wide_b", FTRL side
+            self.k.fill_normal_(self.wide_b.view(1, 1), cfg.seed + 3, cfg.init_sigma)
+            self.wide_b_accum = torch.full_like(self.wide_b, cfg.ftrl_initial_accum)
+            self.wide_b_linear = torch.zeros_like(self.wide_b)
+        self.beta1, self.beta2 = np.float32(0.9), np.float32(0.999)
+        self.beta1_power, self.beta2_power = np.float32(1.0), np.float32(1.0)
+        self.step_count = 0
+        self._amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[cfg.mlp_dtype]
+        self.timers = None            # optional dict name -> list[(start_event, stop_event)]
+
+    # ---- helpers -----------------------------------------------------------------------------
+    def _tick(self, name):
+        if self.timers is None:
+            return None
+        if not self._gpu:
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        self.timers.setdefault(name, []).append(ev)
+        return ev
+
+    @staticmethod
+    def _tock(ev):
+        if ev is not None:
+            ev[1].record()
+
+    def mlp(self, x):
+        """DenseLayer x5 (wide_and_deep.py:113-133): act(x W + b), ReLU on all but the last.
+        Hidden layers run in cfg.mlp_dtype on MFMA (hipBLASLt); the last layer (128 -> 1, a GEMV)
+        stays fp32: it is bandwidth-trivial, and its bf16 weight-gradient product
+        [128,B] x [B,1] takes a ~11 ms host-side path in the GEMM library on this image."""
+        n = len(self.dims) - 1
+        amp = self._amp
+        h = x.to(amp) if amp is not None else x
+        for i in range(n):
+            W, b = self.dense[2 * i], self.dense[2 * i + 1]
+            if amp is not None and i < n - 1:
+                h = torch.addmm(b.to(amp), h, W.to(amp))
+            else:
+                h = torch.addmm(b, h.float(), W)
+            if i < n - 1:
+                h = torch.relu(h)
+        return h.float()
+
+    # ---- forward (eval path: PredictWithSigmoid, wide_and_deep.py:495-518) ---------------------
+    def lookup(self, ids, wts):
+        """Returns (deep_in [B, F*D] already mask-multiplied, wide_out [B] incl. bias) and the
+        routing state needed by the backward (None on one GPU)."""
+        cfg = self.cfg
+        B, Fd = ids.shape
+        if self.world == 1:
+            ev = self._tick("gather_deep")
+            emb = self.k.gather_rows(self.deep, ids, wts).view(B, Fd * cfg.emb_dim)
+            self._tock(ev)
+            ev = self._tick("wide_sum")
+            wide = self.k.wide_sum(self.wide, ids, wts, self.wide_b)
+            self._tock(ev)
+            return emb, wide, None
+        # --- row-sharded: bucket by owner, exchange ids, gather locally, exchange rows back
+        ev = self._tick("route")
+        send_local, perm, counts = self.k.shard_route(ids, self.world)
+        send_counts = counts.tolist()                                    # host sync: n_shards ints
+        recv_counts_t = torch.empty_like(counts)
+        dist.all_to_all_single(recv_counts_t, counts, group=self.group)
+        recv_counts = recv_counts_t.tolist()
+        n_recv = int(sum(recv_counts))
+        recv_local = torch.empty(n_recv, dtype=ids.dtype, device=self.device)
+        dist.all_to_all_single(recv_local, send_local, recv_counts, send_counts, group=self.group)
+        self._tock(ev)
+        ev = self._tick("gather_deep")
+        rows = self.k.gather_rows(self.deep, recv_local)                    # [n_recv, D]
+        wrows = self.k.gather_rows(self.wide, recv_local)                   # [n_recv, 1]
+        self._tock(ev)
+        ev = self._tick("a2a_rows")
+        n = ids.numel()
+        back = torch.empty((n, cfg.emb_dim), dtype=torch.float32, device=self.device)
+        wback = torch.empty((n, 1), dtype=torch.float32, device=self.device)
+        dist.all_to_all_single(back, rows, [c * 1 for c in send_counts], recv_counts, group=self.group)
+        dist.all_to_all_single(wback, wrows, send_counts, recv_counts, group=self.group)
+        self._tock(ev)
+        ev = self._tick("unroute")
+        emb = self.k.shard_unroute(back, perm, wts.reshape(-1)).view(B, Fd * cfg.emb_dim)
+        wvals = self.k.shard_unroute(wback, perm, wts.reshape(-1)).view(B, Fd)
+        wide = wvals.sum(dim=1) + self.wide_b
+        self._tock(ev)
+        return emb, wide, (perm, send_counts, recv_counts, recv_local)
+
+    def predict(self, ids, wts):
+        emb, wide, _ = self.lookup(ids, wts)
+        with torch.no_grad():
+            logit = wide.view(-1, 1) + self.mlp(emb)
+        return logit, torch.sigmoid(logit)
+
+    # ---- one training step -------------------------------------------------------------------
+    def train_step(self, ids, wts, label):
+        cfg = self.cfg
+        B, Fd = ids.shape
+        D = cfg.emb_dim
+        inv_sens = 1.0 / cfg.sens
+        self.step_count += 1
+        self.beta1_power = np.float32(self.beta1_power * self.beta1)
+        self.beta2_power = np.float32(self.beta2_power * self.beta2)
+
+        emb, wide, route = self.lookup(ids, wts)
+        emb.requires_grad_(True)
+        wide.requires_grad_(True)
+
+        ev = self._tick("mlp_fwd_bwd")
+        self.dense_grad_flat.zero_()
+        logit = wide.view(-1, 1) + self.mlp(emb)
+        loss = F.binary_cross_entropy_with_logits(logit, label)          # SigmoidCrossEntropyWithLogits + ReduceMean
+        (loss * cfg.sens).backward()                                      # sens_param seeding, :479-486
+        g_emb, g_wide = emb.grad, wide.grad                               # [B, F*D], [B]
+        self._tock(ev)
+
+        if self.world > 1:
+            ev = self._tick("allreduce_dense")
+            dist.all_reduce(self.dense_grad_flat, group=self.group)
+            self.dense_grad_flat.div_(self.world)
+            gb = g_wide.sum().view(1)
+            dist.all_reduce(gb, group=self.group)
+            gb.div_(self.world)
+            self._tock(ev)
+        else:
+            gb = g_wide.sum().view(1)
+
+        if route is None:
+            ev = self._tick("plan")
+            plan = self.k.sparse_plan(ids)
+            self._tock(ev)
+            ev = self._tick("apply_deep")
+            self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, lr=cfg.adam_lr,
+                                  beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
+                                  beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
+                                  grad_scale=inv_sens)
+            self._tock(ev)
+            ev = self._tick("apply_wide")
+            gw = (g_wide.view(B, 1) * wts).view(B * Fd, 1)               # Mul bprop of wide_mul, :304
+            self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, gw, None, lr=cfg.ftrl_lr, l1=cfg.ftrl_l1,
+                             l2=cfg.ftrl_l2, grad_scale=inv_sens)
+            self._tock(ev)
+        else:
+            perm, send_counts, recv_counts, recv_local = route
+            ev = self._tick("a2a_grads")
+            wflat = wts.reshape(-1)
+            send_g = self.k.shard_route_rows(g_emb.view(B * Fd, D), perm, wflat)
+            gw = (g_wide.view(B, 1) * wts).view(B * Fd, 1)
+            send_gw = self.k.shard_route_rows(gw, perm, None)
+            n_recv = recv_local.numel()
+            recv_g = torch.empty((n_recv, D), dtype=torch.float32, device=self.device)
+            recv_gw = torch.empty((n_recv, 1), dtype=torch.float32, device=self.device)
+            dist.all_to_all_single(recv_g, send_g, recv_counts, send_counts, group=self.group)
+            dist.all_to_all_single(recv_gw, send_gw, recv_counts, send_counts, group=self.group)
+            self._tock(ev)
+            ev = self._tick("plan")
+            plan = self.k.sparse_plan(recv_local)
+            self._tock(ev)
+            # RowTensor gradients of all ranks are summed at the owner; gradients_mean divides by world
+            scale = inv_sens / self.world
+            ev = self._tick("apply_deep")
+            self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, recv_g, None, lr=cfg.adam_lr,
+                                  beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
+                                  beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
+                                  grad_scale=scale)
+            self._tock(ev)
+            ev = self._tick("apply_wide")
+            self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, recv_gw, None, lr=cfg.ftrl_lr,
+                             l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=scale)
+            self._tock(ev)
+
+        ev = self._tick("apply_dense")
+        self.k.dense_adam_(self.dense_flat, self.dense_m, self.dense_v, self.dense_grad_flat, lr=cfg.adam_lr,
+                        beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
+                        beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=inv_sens)
+        self.k.dense_ftrl_(self.wide_b, self.wide_b_accum, self.wide_b_linear, gb, lr=cfg.ftrl_lr, l1=cfg.ftrl_l1,
+                        l2=cfg.ftrl_l2, grad_scale=inv_sens)
+        self._tock(ev)
+        self.last_plan = plan
+        return loss.detach()
+
+
+# ---- synthetic Criteo-shaped batches ------------------------------------------
+def synthetic_batch(cfg: WideDeepConfig, device, dist_kind="uniform", seed=1000, rank=0):
+    """ids int32 [B,F], wts f32 [B,F], label f32 [B,1] -- the dataset contract of
+    models/wide_deep/src/datasets.py:212-216.  F = 39 puts the 13 dense fields on the constant ids
+    0..12 with weights in [0,1) (process_data.py:138-147); categorical weights are 1.0 (:149-162).
+      uniform : ids uniform over [0, V)            (worst case for HBM: ~no duplicates)
+      zipf    : Zipf(1.05) per slot over V/n_cat-sized sub-ranges  (realistic duplicate rate)
+    """
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed * 1000003 + rank)
+    B, Fd, V = cfg.batch_size, cfg.field_size, cfg.vocab_size
+    n_dense = 13 if Fd == 39 else 0
+    n_cat = Fd - n_dense
+    idt = torch.int32 if cfg.id_dtype == "int32" else torch.int64
+    if dist_kind == "uniform":
+        cat = torch.randint(n_dense, V, (B, n_cat), generator=g, dtype=torch.int64)
+    elif dist_kind == "zipf":
+        rng = np.random.default_rng(seed * 1000003 + rank)
+        slot = max((V - n_dense) // n_cat, 1)
+        z = np.minimum(rng.zipf(1.05, size=(B, n_cat)) - 1, slot - 1)
+        cat = torch.from_numpy(z + n_dense + slot * np.arange(n_cat)[None, :])
+    else:
+        raise ValueError(dist_kind)
+    wts = torch.ones((B, Fd), dtype=torch.float32)
+    if n_dense:
+        ids = torch.cat([torch.arange(n_dense, dtype=torch.int64).expand(B, n_dense), cat], dim=1)
+        wts[:, :n_dense] = torch.rand((B, n_dense), generator=g)
+    else:
+        ids = cat
+    label = (torch.rand((B, 1), generator=g) < 0.25).float()
+    return ids.to(idt).to(device), wts.to(device), label.to(device)
+
+
+def embedding_bytes(N, U, D, s=4):
+    """Algorithmic bytes of the embedding path per step."""
+    return {
+        "lookup": N * s + U * D * 4 + N * D * 4,
+        "apply_deep": N * s + N * D * 4 + U * 6 * D * 4,
+        "wide_lookup": N * (s + 8),
+        "apply_wide": N * s + N * 4 + U * 24,
+    }

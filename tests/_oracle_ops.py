@@ -1,0 +1,80 @@
+"""CPU stand-in for mindrec_amd.ops built on the oracle.  TEST INFRASTRUCTURE ONLY: it exists so
+the multi-rank host logic of WideDeepEngine (routing, all-to-all protocol, gradient averaging) can
+run under gloo on a machine without a GPU, and so the GPU engine can be checked step for step.
+The product never imports this module."""
+import numpy as np
+import torch
+
+from oracle import oracle as O
+
+
+def _np(t):
+    return t.detach().numpy()
+
+
+def fill_normal_(table, seed, sigma=0.01, row0=0, row_stride=1):
+    V, D = table.shape
+    rows = row0 + row_stride * np.arange(V, dtype=np.int64)
+    _np(table)[...] = O.normal_rows(seed, rows, D, sigma)
+    return table
+
+
+class Plan:
+    def __init__(self, ids):
+        self.ids = _np(ids).reshape(-1).copy()
+        self.n = self.ids.size
+
+
+def sparse_plan(ids):
+    return Plan(ids)
+
+
+def gather_rows(table, ids, row_scale=None):
+    out = O.gather_rows(_np(table), _np(ids), _np(row_scale) if row_scale is not None else None)
+    return torch.from_numpy(out)
+
+
+def wide_sum(w, ids, wts, bias=None):
+    return torch.from_numpy(O.wide_sum(_np(w), _np(ids), _np(wts), float(bias[0]) if bias is not None else 0.0))
+
+
+def sparse_lazy_adam_(p, m, v, plan, g, row_scale=None, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, beta1_power=0.9,
+                      beta2_power=0.999, grad_scale=1.0, use_nesterov=False):
+    O.sparse_lazy_adam(_np(p), _np(m), _np(v), plan.ids, _np(g).reshape(plan.n, -1),
+                       _np(row_scale).reshape(-1) if row_scale is not None else None, lr=lr, b1=beta1, b2=beta2, eps=eps,
+                       b1_pow=beta1_power, b2_pow=beta2_power, grad_scale=grad_scale, nesterov=use_nesterov)
+
+
+def sparse_ftrl_(var, accum, linear, plan, g, row_scale=None, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):
+    O.sparse_ftrl(_np(var), _np(accum), _np(linear), plan.ids, _np(g).reshape(plan.n, -1),
+                  _np(row_scale).reshape(-1) if row_scale is not None else None, lr=lr, l1=l1, l2=l2, lr_power=lr_power,
+                  grad_scale=grad_scale)
+
+
+def dense_adam_(p, m, v, g, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, beta1_power=0.9, beta2_power=0.999,
+                grad_scale=1.0, use_nesterov=False):
+    O.dense_adam(_np(p), _np(m), _np(v), _np(g), lr=lr, b1=beta1, b2=beta2, eps=eps, b1_pow=beta1_power,
+                 b2_pow=beta2_power, grad_scale=grad_scale, nesterov=use_nesterov)
+
+
+def dense_ftrl_(var, accum, linear, g, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):
+    O.dense_ftrl(_np(var), _np(accum), _np(linear), _np(g), lr=lr, l1=l1, l2=l2, lr_power=lr_power, grad_scale=grad_scale)
+
+
+def shard_route(ids, n_shards):
+    loc, perm, counts = O.shard_route(_np(ids), n_shards)
+    return torch.from_numpy(loc.astype(_np(ids).dtype)), torch.from_numpy(perm), torch.from_numpy(counts)
+
+
+def shard_unroute(rows, send_perm, row_scale=None):
+    r, p = _np(rows), _np(send_perm)
+    out = np.empty_like(r)
+    out[p] = r * (_np(row_scale)[p][:, None] if row_scale is not None else 1.0)
+    return torch.from_numpy(out.astype(np.float32))
+
+
+def shard_route_rows(g, send_perm, row_scale=None):
+    p = _np(send_perm)
+    gg = _np(g).reshape(p.size, -1)
+    out = gg[p] * (_np(row_scale)[p][:, None] if row_scale is not None else 1.0)
+    return torch.from_numpy(np.ascontiguousarray(out, dtype=np.float32))
