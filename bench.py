@@ -120,8 +120,11 @@ def main():
         eng.train_step(*batches[i % len(batches)])
     barrier()
     eng.timers = {}
+    from mindrec_amd import ops
+    ktimers = [ops.KernelTimer() for _ in range(args.steps)]     # HIP events around k_apply_main only
     t0 = time.perf_counter()
     for i in range(args.steps):
+        ktimers[i].arm()              # the step's first sparse apply is the deep-table LazyAdam
         eng.train_step(*batches[i % len(batches)])
     barrier()
     dt = time.perf_counter() - t0
@@ -138,9 +141,19 @@ def main():
     U = plan.U                                  # unique ids of the last step's (local) apply
     n_apply = plan.n
     by = embedding_bytes(n_apply, U, args.emb_dim)
-    apply_ms = sum(kern_ms["apply_deep"]) / len(kern_ms["apply_deep"])
+    kmain = [t.ms() for t in ktimers]
+    apply_ms = sum(kmain) / len(kmain)
     achieved = by["apply_deep"] / (apply_ms * 1e-3) / 1e9
     peak = 8000.0
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, collected
+    # with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command and corrected
+    # per MI355X_MICROARCH.md); only quoted when this run is the workload that was profiled.
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    default_cfg = (args.vocab == 200_000_000 and args.emb_dim == 80 and args.batch == 16384 and args.fields == 26
+                   and args.dist == "uniform" and not args.split_state and world == 1)
+    if default_cfg and os.path.exists(pmc_path):
+        traffic = json.load(open(pmc_path)).get("apply_main_adam", {}).get("total_bytes")
     out = {
         "metric": "samples/sec Wide&Deep Criteo batch16384",
         "value": round(args.batch * world * args.steps / dt, 1),
@@ -160,9 +173,11 @@ def main():
                                f"MLP {cfg.field_size * cfg.emb_dim}-1024-512-256-128-1 in {args.mlp_dtype}",
                    "global_batch": args.batch * world, "id_dist": args.dist, "unique_frac": round(U / max(n_apply, 1), 4),
                    "parallelism": "1 GPU" if world == 1 else f"tables row-sharded x{world} (RCCL all-to-all), MLP dp{world}"},
-        "roofline": {"bound": "hbm", "kernel": "k_apply_main<4,int,UpdAdam> (fused segment-sum + LazyAdam) + carry pass",
+        "roofline": {"bound": "hbm", "kernel": "k_apply_main<4,int,UpdAdam> (fused segment-sum + LazyAdam row update)",
                      "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
-                     "traffic": None, "algorithmic_bytes": by["apply_deep"], "avg_ms": round(apply_ms, 5)},
+                     "traffic": traffic, "algorithmic_bytes": by["apply_deep"], "avg_ms": round(apply_ms, 5),
+                     "timing": "HIP events around k_apply_main on its launch stream (mrec_profile_next_apply), "
+                               "averaged over the timed steps"},
         "kernels_ms": {k: round(sum(v) / len(v), 5) for k, v in sorted(kern_ms.items())},
         "embed_gbps": {
             "lookup": round(by["lookup"] / (median(kern_ms["gather_deep"]) * 1e-3) / 1e9, 1) if world == 1 else None,

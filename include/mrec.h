@@ -209,6 +209,16 @@ int mrec_shard_unroute_f32(const float* rows, const int32_t* send_perm, int64_t 
 int mrec_shard_route_rows_f32(const float* g, int64_t ldg, const int32_t* send_perm, int64_t n, int32_t D,
                               const float* row_scale, float* rows_out, void* stream);
 
+/* ---- measurement hooks (used by bench.py; no effect on results) --------------------------
+ * HIP events owned by the library, and a one-shot hook: the NEXT sparse-apply call (segment_sum /
+ * lazy_adam / ftrl) on this host thread records `start` immediately before its main kernel
+ * (k_apply_main) and `stop` immediately after it, on the stream the kernel is launched on, so the
+ * pair times exactly the kernel rocprofv3 lists under that name. */
+int mrec_event_create(void** ev_out);
+int mrec_event_destroy(void* ev);
+int mrec_event_elapsed_ms(void* start, void* stop, float* ms_out); /* waits for `stop` */
+int mrec_profile_next_apply(void* start, void* stop);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,10 @@ _SIGS = {
     "mrec_shard_route_i64": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_shard_unroute_f32": [_vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_shard_route_rows_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp],
+    "mrec_event_create": [C.POINTER(_vp)],
+    "mrec_event_destroy": [_vp],
+    "mrec_event_elapsed_ms": [_vp, _vp, C.POINTER(C.c_float)],
+    "mrec_profile_next_apply": [_vp, _vp],
 }
 _RESTYPES = {"mrec_strerror": C.c_char_p, "mrec_map_counters_dev": _vp}
 

@@ -316,6 +316,8 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+thread_local hipEvent_t t_prof_start = nullptr, t_prof_stop = nullptr;
+
 struct ApplyWs { float* carry_head; float* carry_tail; int* owners; int* n_owners; };
 
 size_t apply_ws_bytes(int64_t n, int32_t D) {
@@ -337,14 +339,19 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
     const unsigned blocks = (unsigned)mrec_cdiv(nsw, (int64_t)4 * gm.G);
     MREC_HIP_CHECK(hipMemsetAsync(w.n_owners, 0, sizeof(int), st));
     unsigned lblocks = (unsigned)(nsw < 2048 ? nsw : 2048);
+    const hipEvent_t ev0 = t_prof_start, ev1 = t_prof_stop;
+    t_prof_start = t_prof_stop = nullptr;
+    if (ev0) MREC_HIP_CHECK(hipEventRecord(ev0, st));
     if (vec) {
         k_apply_main<4, K, Upd><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
                                                        w.carry_head, w.carry_tail, w.owners, w.n_owners);
+        if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         k_apply_long<4, K, Upd><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
                                                         w.carry_head, w.carry_tail, w.owners, w.n_owners);
     } else {
         k_apply_main<1, K, Upd><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
                                                        w.carry_head, w.carry_tail, w.owners, w.n_owners);
+        if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         k_apply_long<1, K, Upd><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
                                                         w.carry_head, w.carry_tail, w.owners, w.n_owners);
     }
@@ -415,6 +422,30 @@ int ftrl_impl(float* var, float* accum, float* linear, int64_t V, int64_t ld, in
 }
 
 }  // namespace
+
+MREC_API int mrec_event_create(void** ev_out) {
+    if (!ev_out) return MREC_EINVAL;
+    hipEvent_t e;
+    MREC_HIP_CHECK(hipEventCreate(&e));
+    *ev_out = (void*)e;
+    return MREC_OK;
+}
+MREC_API int mrec_event_destroy(void* ev) {
+    if (!ev) return MREC_EINVAL;
+    MREC_HIP_CHECK(hipEventDestroy((hipEvent_t)ev));
+    return MREC_OK;
+}
+MREC_API int mrec_event_elapsed_ms(void* start, void* stop, float* ms_out) {
+    if (!start || !stop || !ms_out) return MREC_EINVAL;
+    MREC_HIP_CHECK(hipEventSynchronize((hipEvent_t)stop));
+    MREC_HIP_CHECK(hipEventElapsedTime(ms_out, (hipEvent_t)start, (hipEvent_t)stop));
+    return MREC_OK;
+}
+MREC_API int mrec_profile_next_apply(void* start, void* stop) {
+    t_prof_start = (hipEvent_t)start;
+    t_prof_stop = (hipEvent_t)stop;
+    return MREC_OK;
+}
 
 MREC_API int mrec_sparse_apply_window(int32_t D, int aligned16) {
     return (aligned16 && D % 4 == 0) ? ACfg<4>::AW : ACfg<1>::AW;

@@ -409,3 +409,27 @@ def shard_route_rows(g, send_perm, row_scale=None):
     _lib.call("mrec_shard_route_rows_f32", _ptr(g2), g2.stride(0) if n > 1 else D, _ptr(send_perm), n, D, _ptr(rs),
               _ptr(out), _stream())
     return out
+
+
+# ---- measurement hook ------------------------------------------------------------------------
+class KernelTimer:
+    """Times exactly the main kernel of the next sparse-apply call (see include/mrec.h,
+    mrec_profile_next_apply): arm() before the call, ms() afterwards (waits for the stop event)."""
+
+    def __init__(self):
+        self._a, self._b = C.c_void_p(), C.c_void_p()
+        _lib.call("mrec_event_create", C.byref(self._a))
+        _lib.call("mrec_event_create", C.byref(self._b))
+
+    def arm(self):
+        _lib.call("mrec_profile_next_apply", self._a, self._b)
+
+    def ms(self):
+        out = C.c_float()
+        _lib.call("mrec_event_elapsed_ms", self._a, self._b, C.byref(out))
+        return float(out.value)
+
+    def __del__(self):
+        for e in (getattr(self, "_a", None), getattr(self, "_b", None)):
+            if e:
+                _lib.lib().mrec_event_destroy(e)
