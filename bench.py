@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--n-batches", type=int, default=4, help="distinct resident batches cycled through")
     ap.add_argument("--split-state", action="store_true", help="p, m, v as three separate arrays (default: fused rows)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product path); gloo stages collectives through the host and lets "
+                         "several ranks share one GPU (debugging only)")
     return ap.parse_args()
 
 
@@ -95,6 +98,8 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (mindrec_amd has no CPU fallback)")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rc = _lib.lib().mrec_device_ok()
@@ -103,7 +108,10 @@ def main():
     group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cfg = WideDeepConfig(vocab_size=args.vocab, emb_dim=args.emb_dim, field_size=args.fields, batch_size=args.batch,
                          mlp_dtype=args.mlp_dtype, fused_state=not args.split_state)
@@ -129,7 +137,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

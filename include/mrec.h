@@ -164,9 +164,11 @@ const int64_t* mrec_map_counters_dev(const mrec_map_t* h);
 int mrec_map_workspace_bytes(int64_t n, size_t* out);
 /* keys must be unique within the call (run mrec_dedup first).  rows_out[i] = row of keys[i];
  * a missing key gets a new row when insert != 0 (is_new_out[i] = 1, caller initialises the row),
- * else rows_out[i] = -1. */
-int mrec_map_find_or_insert(mrec_map_t* h, const int64_t* keys, int64_t n, int insert, int32_t* rows_out,
-                            uint8_t* is_new_out, void* ws, size_t ws_bytes, void* stream);
+ * else rows_out[i] = -1.  n_dev (nullable, device int64): only the first min(n, *n_dev) keys are
+ * processed -- pass mrec_dedup's n_uniq_dev so the Unique -> MapTensorGet chain of
+ * HashEmbeddingLookup.construct (embedding.py:192-193) needs no host synchronisation. */
+int mrec_map_find_or_insert(mrec_map_t* h, const int64_t* keys, int64_t n, const int64_t* n_dev, int insert,
+                            int32_t* rows_out, uint8_t* is_new_out, void* ws, size_t ws_bytes, void* stream);
 /* Removes keys (unique within the call); missing keys are ignored. */
 int mrec_map_erase(mrec_map_t* h, const int64_t* keys, int64_t n, void* ws, size_t ws_bytes, void* stream);
 /* Writes the live (key,row) pairs in row order; *n_out_dev receives the count. */
@@ -175,7 +177,12 @@ int mrec_map_export(mrec_map_t* h, int64_t* keys_out, int32_t* rows_out, int64_t
 /* Default-value rows for newly inserted keys: table[rows[i], :] = sigma * N01(seed, keys[i], c)
  * where is_new[i] (all i when is_new is null); sigma < 0 selects the constant `fill`. */
 int mrec_init_rows_f32(float* table, int64_t ld, int32_t D, const int32_t* rows, const int64_t* keys,
-                       const uint8_t* is_new, int64_t n, uint64_t seed, float sigma, float fill, void* stream);
+                       const uint8_t* is_new, int64_t n, const int64_t* n_dev, uint64_t seed, float sigma,
+                       float fill, void* stream);
+/* out[i] = table[idx[i]] for int32 arrays (idx[i] < 0 gives -1): rows_of_position = rows_of_unique[inv]. */
+int mrec_compose_i32(const int32_t* table, const int32_t* idx, int64_t n, int32_t* out, void* stream);
+/* int32 -> int64 widening of key arrays (MapParameter key_dtype int32). */
+int mrec_widen_i32_i64(const int32_t* in, int64_t n, int64_t* out, void* stream);
 /* MapTensorPut: table[rows[i], :] = vals[i, :] (rows < 0 skipped). */
 int mrec_scatter_rows_f32(float* table, int64_t ld, int32_t D, const int32_t* rows, int64_t n,
                           const float* vals, void* stream);

@@ -61,10 +61,12 @@ _SIGS = {
     "mrec_map_destroy": [_vp],
     "mrec_map_counters_dev": [_vp],
     "mrec_map_workspace_bytes": [_i64, _szp],
-    "mrec_map_find_or_insert": [_vp, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp],
+    "mrec_map_find_or_insert": [_vp, _vp, _i64, _vp, _int, _vp, _vp, _vp, _sz, _vp],
     "mrec_map_erase": [_vp, _vp, _i64, _vp, _sz, _vp],
     "mrec_map_export": [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
-    "mrec_init_rows_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _u64, _f32, _f32, _vp],
+    "mrec_init_rows_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _u64, _f32, _f32, _vp],
+    "mrec_compose_i32": [_vp, _vp, _i64, _vp, _vp],
+    "mrec_widen_i32_i64": [_vp, _i64, _vp, _vp],
     "mrec_scatter_rows_f32": [_vp, _i64, _i32, _vp, _i64, _vp, _vp],
     "mrec_cross_layers_f32": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp],
     "mrec_cross_layers_bwd_workspace_bytes": [_i32, _i64, _i32, _szp],

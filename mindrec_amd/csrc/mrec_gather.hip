@@ -140,9 +140,12 @@ __global__ __launch_bounds__(256) void k_fill_normal(float* __restrict__ out, in
 template <class K>
 __global__ __launch_bounds__(256) void k_init_rows(float* __restrict__ table, int64_t ld, int D,
                                                    const int* __restrict__ rows, const K* __restrict__ keys,
-                                                   const uint8_t* __restrict__ is_new, int64_t n, uint64_t seed,
-                                                   float sigma, float fill) {
+                                                   const uint8_t* __restrict__ is_new, int64_t n_max,
+                                                   const int64_t* __restrict__ n_dev, uint64_t seed, float sigma,
+                                                   float fill) {
     const int cpr = (D + 3) >> 2;
+    int64_t n = n_max;
+    if (n_dev) { const int64_t nd = *n_dev; n = nd < n ? nd : n; }
     const int64_t total = n * cpr;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int64_t i = t / cpr;
@@ -304,15 +307,42 @@ MREC_API int mrec_wide_sum_f32_i64(const float* w, int64_t V, int64_t ldw, const
     return wide_sum_impl<int64_t>(w, V, ldw, ids, wts, B, F, bias_dev, out, stream);
 }
 
+__global__ __launch_bounds__(256) void k_compose_i32(const int* __restrict__ table, const int* __restrict__ idx,
+                                                     int64_t n, int* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const int j = idx[i]; out[i] = j >= 0 ? table[j] : -1; }
+}
+__global__ __launch_bounds__(256) void k_widen(const int* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (int64_t)in[i];
+}
+
+MREC_API int mrec_compose_i32(const int32_t* table, const int32_t* idx, int64_t n, int32_t* out, void* stream) {
+    if (n < 0) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!table || !idx || !out) return MREC_EINVAL;
+    k_compose_i32<<<(unsigned)mrec_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(table, idx, n, out);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+MREC_API int mrec_widen_i32_i64(const int32_t* in, int64_t n, int64_t* out, void* stream) {
+    if (n < 0) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!in || !out) return MREC_EINVAL;
+    k_widen<<<(unsigned)mrec_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(in, n, out);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
 MREC_API int mrec_init_rows_f32(float* table, int64_t ld, int32_t D, const int32_t* rows, const int64_t* keys,
-                                const uint8_t* is_new, int64_t n, uint64_t seed, float sigma, float fill,
-                                void* stream) {
+                                const uint8_t* is_new, int64_t n, const int64_t* n_dev, uint64_t seed, float sigma,
+                                float fill, void* stream) {
     if (n < 0 || D <= 0 || ld < D) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
     if (!table || !rows || !keys) return MREC_EINVAL;
     const int64_t total = n * ((D + 3) / 4);
     k_init_rows<int64_t><<<stream_grid(total), 256, 0, (hipStream_t)stream>>>(table, ld, D, rows, keys, is_new, n,
-                                                                           seed, sigma, fill);
+                                                                           n_dev, seed, sigma, fill);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }

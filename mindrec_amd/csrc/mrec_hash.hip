@@ -36,11 +36,18 @@ struct MapDev {
     uint32_t mask;
 };
 
-__global__ __launch_bounds__(HB) void k_map_find(MapDev m, const int64_t* __restrict__ keys, int64_t n,
-                                                 int* __restrict__ rows_out, int* __restrict__ slot_out,
-                                                 uint8_t* __restrict__ miss) {
+__device__ __forceinline__ int64_t eff_n(int64_t n, const int64_t* n_dev) {
+    if (!n_dev) return n;
+    const int64_t nd = *n_dev;
+    return nd < n ? (nd < 0 ? 0 : nd) : n;
+}
+
+__global__ __launch_bounds__(HB) void k_map_find(MapDev m, const int64_t* __restrict__ keys, int64_t n_max,
+                                                 const int64_t* __restrict__ n_dev, int* __restrict__ rows_out,
+                                                 int* __restrict__ slot_out, uint8_t* __restrict__ miss) {
     const int64_t i = (int64_t)blockIdx.x * HB + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n_max) return;
+    if (i >= eff_n(n_max, n_dev)) { miss[i] = 0; rows_out[i] = -1; return; }
     const int64_t key = keys[i];
     uint32_t s = mrec_hash_key(key) & m.mask;
     int row = -1, slot = -1;
@@ -245,8 +252,8 @@ MREC_API int mrec_map_workspace_bytes(int64_t n, size_t* out) {
     return MREC_OK;
 }
 
-MREC_API int mrec_map_find_or_insert(mrec_map_t* h, const int64_t* keys, int64_t n, int insert, int32_t* rows_out,
-                                     uint8_t* is_new_out, void* ws, size_t ws_bytes, void* stream) {
+MREC_API int mrec_map_find_or_insert(mrec_map_t* h, const int64_t* keys, int64_t n, const int64_t* n_dev, int insert,
+                                     int32_t* rows_out, uint8_t* is_new_out, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!h || n < 0) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
@@ -262,7 +269,7 @@ MREC_API int mrec_map_find_or_insert(mrec_map_t* h, const int64_t* keys, int64_t
     if (!a.ok) return MREC_EWORKSPACE;
     (void)slots;
     const unsigned g = (unsigned)mrec_cdiv(n, HB);
-    k_map_find<<<g, HB, 0, st>>>(h->d, keys, n, rows_out, nullptr, miss);
+    k_map_find<<<g, HB, 0, st>>>(h->d, keys, n, n_dev, rows_out, nullptr, miss);
     if (insert) {
         MREC_HIP_CHECK(hipMemsetAsync(words, 0, 16, st));
         k_flag_count<<<nblk, HB, 0, st>>>(miss, n, 0, blocksum);
@@ -292,7 +299,7 @@ MREC_API int mrec_map_erase(mrec_map_t* h, const int64_t* keys, int64_t n, void*
     int* rows = a.take<int>(n);
     if (!a.ok) return MREC_EWORKSPACE;
     const unsigned g = (unsigned)mrec_cdiv(n, HB);
-    k_map_find<<<g, HB, 0, st>>>(h->d, keys, n, rows, slots, miss);
+    k_map_find<<<g, HB, 0, st>>>(h->d, keys, n, nullptr, rows, slots, miss);
     k_flag_count<<<nblk, HB, 0, st>>>(miss, n, 1, blocksum);
     k_flag_rank<<<nblk, HB, 0, st>>>(miss, n, 1, blocksum, nblk, rank, words);
     k_map_erase<<<g, HB, 0, st>>>(h->d, n, rows, slots, miss, rank);

@@ -39,11 +39,66 @@ __global__ void k_zero_counts(int64_t* counts, int S) {
     if (k < S) counts[k] = 0;
 }
 
-// One wave per row: dst[dst_row(k), :] = src[src_row(k), :] * scale.
-template <bool SCATTER>
+// dst[dst_row(k), :] = src[src_row(k), :] * scale[perm[k]]  (SCATTER: dst_row = perm[k], src_row = k;
+// otherwise dst_row = k, src_row = perm[k]).  Lane-group of D/VEC lanes per row (float4 when aligned),
+// PB rows per lane-group loaded before the first store.
+constexpr int PB = 4;
+template <bool SCATTER, int VEC>
 __global__ __launch_bounds__(256) void k_perm_rows(const float* __restrict__ src, int64_t lds,
-                                                   const int* __restrict__ perm, int64_t n, int D,
+                                                   const int* __restrict__ perm, int64_t n, int D, int lpr, int G,
                                                    const float* __restrict__ row_scale, float* __restrict__ dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / lpr, sub = lane - grp * lpr;
+    if (grp >= G) return;
+    const int64_t k0 = ((int64_t)blockIdx.x * 4 + wave) * (G * PB);
+    float x[PB][VEC];
+    int64_t p[PB];
+    float s[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int64_t k = k0 + (int64_t)q * G + grp;
+        p[q] = -1;
+        s[q] = 1.0f;
+        if (k < n) {
+            p[q] = perm[k];
+            if (row_scale) s[q] = row_scale[p[q]];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int64_t k = k0 + (int64_t)q * G + grp;
+        if (p[q] >= 0) {
+            const float* a = (SCATTER ? src + k * lds : src + p[q] * lds) + sub * VEC;
+            if (VEC == 4) {
+                const float4 v = *(const float4*)a;
+                x[q][0] = v.x; x[q][1 % VEC] = v.y; x[q][2 % VEC] = v.z; x[q][3 % VEC] = v.w;
+            } else {
+                x[q][0] = *a;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int64_t k = k0 + (int64_t)q * G + grp;
+        if (p[q] >= 0) {
+            float* o = (SCATTER ? dst + p[q] * (int64_t)D : dst + k * (int64_t)D) + sub * VEC;
+            if (VEC == 4) {
+                float4 v = make_float4(x[q][0], x[q][1 % VEC], x[q][2 % VEC], x[q][3 % VEC]);
+                if (row_scale) { v.x *= s[q]; v.y *= s[q]; v.z *= s[q]; v.w *= s[q]; }
+                *(float4*)o = v;
+            } else {
+                *o = row_scale ? x[q][0] * s[q] : x[q][0];
+            }
+        }
+    }
+}
+
+// generic fallback: one wave per row, lanes stride the columns
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_perm_rows_generic(const float* __restrict__ src, int64_t lds,
+                                                           const int* __restrict__ perm, int64_t n, int D,
+                                                           const float* __restrict__ row_scale,
+                                                           float* __restrict__ dst) {
     const int lane = threadIdx.x & 63;
     const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= n) return;
@@ -52,6 +107,25 @@ __global__ __launch_bounds__(256) void k_perm_rows(const float* __restrict__ src
     const float* a = SCATTER ? src + k * lds : src + p * lds;
     float* o = SCATTER ? dst + p * (int64_t)D : dst + k * (int64_t)D;
     for (int c = lane; c < D; c += 64) o[c] = row_scale ? a[c] * s : a[c];
+}
+
+template <bool SCATTER>
+int perm_rows_launch(const float* src, int64_t lds, const int* perm, int64_t n, int D, const float* row_scale,
+                     float* dst, hipStream_t st) {
+    const bool al = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0 && (lds % 4 == 0);
+    if (D % 4 == 0 && D <= 256 && al) {
+        const int lpr = D / 4, G = 64 / lpr;
+        k_perm_rows<SCATTER, 4><<<(unsigned)mrec_cdiv(n, (int64_t)4 * G * PB), 256, 0, st>>>(src, lds, perm, n, D, lpr, G,
+                                                                                           row_scale, dst);
+    } else if (D <= 64) {
+        const int lpr = D, G = 64 / lpr;
+        k_perm_rows<SCATTER, 1><<<(unsigned)mrec_cdiv(n, (int64_t)4 * G * PB), 256, 0, st>>>(src, lds, perm, n, D, lpr, G,
+                                                                                           row_scale, dst);
+    } else {
+        k_perm_rows_generic<SCATTER><<<(unsigned)mrec_cdiv(n, 4), 256, 0, st>>>(src, lds, perm, n, D, row_scale, dst);
+    }
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
 }
 
 template <class K>
@@ -110,9 +184,7 @@ MREC_API int mrec_shard_unroute_f32(const float* rows, const int32_t* send_perm,
     if (n < 0 || D <= 0) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
     if (!rows || !send_perm || !out) return MREC_EINVAL;
-    k_perm_rows<true><<<(unsigned)mrec_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(rows, D, send_perm, n, D, row_scale, out);
-    MREC_LAUNCH_CHECK();
-    return MREC_OK;
+    return perm_rows_launch<true>(rows, D, send_perm, n, D, row_scale, out, (hipStream_t)stream);
 }
 
 MREC_API int mrec_shard_route_rows_f32(const float* g, int64_t ldg, const int32_t* send_perm, int64_t n, int32_t D,
@@ -120,8 +192,5 @@ MREC_API int mrec_shard_route_rows_f32(const float* g, int64_t ldg, const int32_
     if (n < 0 || D <= 0 || ldg < D) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
     if (!g || !send_perm || !rows_out) return MREC_EINVAL;
-    k_perm_rows<false><<<(unsigned)mrec_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(g, ldg, send_perm, n, D, row_scale,
-                                                                                 rows_out);
-    MREC_LAUNCH_CHECK();
-    return MREC_OK;
+    return perm_rows_launch<false>(g, ldg, send_perm, n, D, row_scale, rows_out, (hipStream_t)stream);
 }

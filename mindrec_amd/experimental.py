@@ -1,0 +1,207 @@
+"""`mindspore.experimental.MapParameter` on MI355X.
+
+Reference surface: built by HashEmbeddingLookup at mindspore_rec/ops/embedding.py:136-146, read by
+MapTensorGet(insert_default_value=True) at :149,193,199, API by example at README.md:160-205
+(`m[key] = val`, `m[key]`, `m.erase(key)`), semantics SURVEY.md Appendix A.6 [EXT].
+
+Storage is MI355X-style: a device key -> row-number index (`ops.KeyIndex`, csrc/mrec_hash.hip) over
+a dense fp32 row table [capacity, D]; optimizer slots (Adam m/v, FTRL accum/linear) are further
+[capacity, D] tables with the same row numbering, allocated by the optimizer.  All lookups and
+updates therefore run through the dense gather / sparse-apply kernels.
+"""
+import sys
+import zlib
+
+import torch
+
+from . import ops
+
+MAX_SIZE = sys.maxsize
+
+
+def _seed_from_name(name):
+    return zlib.crc32((name or "map_parameter").encode()) & 0x7FFFFFFF
+
+
+class RowGrad:
+    """RowTensor analogue: what SparseGatherV2 / MapTensorGet bprop hands the optimizer --
+    (row indices, per-position value gradients), not yet deduplicated."""
+
+    def __init__(self, plan, values, row_scale=None):
+        self.plan = plan            # ops.SparsePlan whose uniq_buf holds TABLE ROW numbers
+        self.values = values        # [n, D] fp32
+        self.row_scale = row_scale  # optional [n] mask fused into the apply
+
+
+class MapParameter:
+    """Hash-table parameter: int keys -> fp32 rows of shape value_shape.
+
+    Extra (MI355X) arguments: `capacity` rows are reserved in HBM up front (default 1 Mi rows);
+    `device`.  Keys -1 and -2 are reserved by MindRec (embedding.py:55-56); this implementation
+    reserves none.
+    """
+
+    def __init__(self, key_dtype=torch.int32, value_dtype=torch.float32, value_shape=1, key_tensor=None,
+                 value_tensor=None, default_value="normal", permit_filter_value=1, evict_filter_value=MAX_SIZE,
+                 name=None, requires_grad=True, capacity=1 << 20, device="cuda:0", seed=None):
+        if key_dtype not in (torch.int32, torch.int64):
+            raise TypeError(f"For 'MapParameter', the 'key_dtype' must be int32 or int64, but got {key_dtype}.")
+        if value_dtype != torch.float32:
+            raise TypeError(f"For 'MapParameter', the 'value_dtype' must be float32, but got {value_dtype}.")
+        if isinstance(value_shape, int):
+            value_shape = (value_shape,)
+        value_shape = tuple(int(x) for x in value_shape)
+        if len(value_shape) != 1 or value_shape[0] <= 0:
+            raise ValueError(f"For 'MapParameter', 'value_shape' must be one positive dimension, but got {value_shape}.")
+        if not isinstance(permit_filter_value, int) or permit_filter_value < 1:
+            raise ValueError("For 'MapParameter', 'permit_filter_value' must be a positive int.")
+        if not isinstance(evict_filter_value, int) or evict_filter_value < 1:
+            raise ValueError("For 'MapParameter', 'evict_filter_value' must be a positive int.")
+        self.key_dtype, self.value_dtype, self.value_shape = key_dtype, value_dtype, value_shape
+        self.default_value = default_value
+        self.permit_filter_value, self.evict_filter_value = permit_filter_value, evict_filter_value
+        self.name = name or "map_parameter"
+        self.requires_grad = requires_grad
+        self.device = torch.device(device)
+        self.capacity = int(capacity)
+        self.seed = _seed_from_name(self.name) if seed is None else int(seed)
+        if isinstance(default_value, str):
+            if default_value not in ("normal", "zeros", "ones"):
+                raise ValueError(f"For 'MapParameter', unsupported 'default_value' {default_value!r}.")
+            self._sigma, self._fill = (0.01, None) if default_value == "normal" else (None, 0.0 if default_value == "zeros" else 1.0)
+        else:
+            self._sigma, self._fill = None, float(default_value)
+        D = value_shape[0]
+        self.index = ops.KeyIndex(self.capacity, self.device)
+        self.values = torch.zeros((self.capacity, D), dtype=torch.float32, device=self.device)
+        self.slots = {}              # optimizer state tables keyed by name, same row numbering
+        self.sparse_grads = []       # RowGrad list filled by the lookup's backward
+        self.unique = True           # set by HashEmbeddingLookup (embedding.py:146)
+        self.cache_enable = False
+        # admission / eviction bookkeeping (only maintained when a filter is active)
+        self._track = permit_filter_value > 1 or evict_filter_value < MAX_SIZE
+        if self._track:
+            self.hits = torch.zeros(self.capacity, dtype=torch.int32, device=self.device)
+            self.last_step = torch.zeros(self.capacity, dtype=torch.int64, device=self.device)
+        self.step = 0
+        if key_tensor is not None:
+            self.put(key_tensor, value_tensor)
+
+    # ---- helpers --------------------------------------------------------------------------
+    def _keys(self, keys):
+        if not torch.is_tensor(keys):
+            keys = torch.as_tensor(keys, dtype=self.key_dtype)
+        if keys.dtype != self.key_dtype:
+            raise TypeError(f"For 'MapParameter', the key dtype must be {self.key_dtype}, but got {keys.dtype}.")
+        return keys.to(self.device).reshape(-1).contiguous()
+
+    def _init_kwargs(self):
+        return dict(seed=self.seed, sigma=self._sigma if self._sigma is not None else 0.0, fill=self._fill)
+
+    def lookup_rows(self, keys_flat, insert=True):
+        """(dedup, rows_uniq int32 [n], rows_pos int32 [n]) for flat device keys, without host sync:
+        Unique -> index probe / insert (misses numbered in first-occurrence order) -> default rows."""
+        d = ops.unique(keys_flat)
+        k64 = ops.widen_keys(d.uniq_buf)
+        rows_u, is_new = self.index.find_or_insert(k64, insert=insert, n_dev=d.n_uniq_dev)
+        if insert:
+            ops.init_rows_(self.values, rows_u, k64, is_new, n_dev=d.n_uniq_dev, **self._init_kwargs())
+            for t in self.slots.values():
+                ops.init_rows_(t["table"], rows_u, k64, is_new, n_dev=d.n_uniq_dev, seed=0, sigma=None, fill=t["init"])
+        rows_pos = ops.compose_i32(rows_u, d.inv)
+        if self._track and insert:
+            ok = rows_u >= 0                                   # entries past U read -1
+            idx = rows_u.clamp_min(0).long()
+            self.hits.index_add_(0, idx, ok.to(torch.int32))
+            stamp = torch.full_like(idx, self.step)
+            self.last_step.scatter_(0, idx, torch.where(ok, stamp, self.last_step[idx]))
+        return d, rows_u, rows_pos
+
+    def admitted_rows(self, rows_u):
+        """Row numbers with un-admitted keys (seen fewer than permit_filter_value times) replaced by
+        -1, which the sparse-apply kernels skip: such keys read their default row and are not
+        updated."""
+        if self.permit_filter_value <= 1:
+            return rows_u
+        ok = (rows_u >= 0) & (self.hits[rows_u.clamp_min(0).long()] >= self.permit_filter_value)
+        return torch.where(ok, rows_u, torch.full_like(rows_u, -1))
+
+    # ---- MapTensorGet / Put / Erase -----------------------------------------------------------
+    def get(self, key_tensor, insert_default_value=True):
+        keys = self._keys(key_tensor)
+        d, rows_u, rows_pos = self.lookup_rows(keys, insert=insert_default_value)
+        out = ops.gather_rows(self.values, rows_pos)
+        if not insert_default_value:
+            # missing keys read as their default row, without being inserted
+            miss = rows_pos < 0
+            if bool(miss.any()):
+                tmp = torch.empty_like(out)
+                seq = torch.arange(keys.numel(), dtype=torch.int32, device=self.device)
+                ops.init_rows_(tmp, seq, ops.widen_keys(keys), None, **self._init_kwargs())
+                out = torch.where(miss.view(-1, 1), tmp, out)
+        return out
+
+    def put(self, key_tensor, value_tensor):
+        keys = self._keys(key_tensor)
+        vals = value_tensor.to(self.device, torch.float32).reshape(keys.numel(), self.value_shape[0])
+        d, rows_u, rows_pos = self.lookup_rows(keys, insert=True)
+        # keys of one put should be unique; with duplicates one of the rows wins (a sequential
+        # upsert would keep the last)
+        ops.scatter_rows_(self.values, rows_pos, vals)
+        return self
+
+    def erase(self, key_tensor):
+        keys = self._keys(key_tensor)
+        d = ops.unique(keys)
+        self.index.erase(ops.widen_keys(d.uniq))
+        return self
+
+    def __getitem__(self, key_tensor):
+        return self.get(key_tensor, True)
+
+    def __setitem__(self, key_tensor, value_tensor):
+        self.put(key_tensor, value_tensor)
+
+    def __len__(self):
+        return len(self.index)
+
+    # ---- export / import ------------------------------------------------------------------
+    def get_keys(self):
+        k, _ = self.index.export()
+        return k.to(self.key_dtype)
+
+    def get_values(self):
+        _, r = self.index.export()
+        return ops.gather_rows(self.values, r)
+
+    def get_data(self):
+        k, r = self.index.export()
+        return k.to(self.key_dtype), ops.gather_rows(self.values, r)
+
+    def export_data(self, incremental=False):
+        k, v = self.get_data()
+        status = torch.zeros(k.numel(), dtype=torch.int32, device=self.device)
+        return k, v, status
+
+    def import_data(self, data):
+        keys, values = data[0], data[1]
+        self.put(keys, values)
+
+    def add_slot(self, name, init=0.0):
+        """Optimizer state table with this map's row numbering (Adam m/v, FTRL accum/linear)."""
+        if name not in self.slots:
+            t = torch.full((self.capacity, self.value_shape[0]), float(init), dtype=torch.float32, device=self.device)
+            self.slots[name] = {"table": t, "init": float(init)}
+        return self.slots[name]["table"]
+
+    # ---- eviction (README.md:182-183: thresholds in training steps) -----------------------------
+    def evict(self):
+        """Removes keys not seen for more than evict_filter_value steps (SURVEY A.6 definition)."""
+        if not self._track or self.evict_filter_value >= MAX_SIZE:
+            return 0
+        k, r = self.index.export()
+        stale = (self.step - self.last_step[r.long()]) > self.evict_filter_value
+        dead = k[stale]
+        if dead.numel():
+            self.index.erase(dead.contiguous())
+        return int(dead.numel())

@@ -301,14 +301,15 @@ class KeyIndex:
         nb = _lib.query_bytes("mrec_map_workspace_bytes", max(n, 1))
         return workspace("map", nb, self.device)
 
-    def find_or_insert(self, keys_i64, insert=True):
-        """keys must be unique within the call.  Returns (rows int32[n], is_new uint8[n])."""
+    def find_or_insert(self, keys_i64, insert=True, n_dev=None):
+        """keys must be unique within the call.  Returns (rows int32[n], is_new uint8[n]).
+        n_dev: optional device int64 word; only the first min(n, n_dev) keys are processed."""
         n = keys_i64.numel()
         rows = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)[:n]
         is_new = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)[:n]
         ws = self._ws(n)
-        _lib.call("mrec_map_find_or_insert", self._h, _ptr(keys_i64), n, int(insert), _ptr(rows), _ptr(is_new), _ptr(ws),
-                  ws.numel(), _stream())
+        _lib.call("mrec_map_find_or_insert", self._h, _ptr(keys_i64), n, _ptr(n_dev), int(insert), _ptr(rows), _ptr(is_new),
+                  _ptr(ws), ws.numel(), _stream())
         return rows, is_new
 
     def erase(self, keys_i64):
@@ -327,13 +328,33 @@ class KeyIndex:
         return keys[:n], rows[:n]
 
 
-def init_rows_(table, rows, keys_i64, is_new=None, seed=0, sigma=0.01, fill=None):
+def init_rows_(table, rows, keys_i64, is_new=None, seed=0, sigma=0.01, fill=None, n_dev=None):
     """Default-value rows of MapTensorGet(insert_default_value=True) (embedding.py:149)."""
     V, D, ld = _table(table)
     n = rows.numel()
     s = -1.0 if fill is not None else float(sigma)
-    _lib.call("mrec_init_rows_f32", _ptr(table), ld, D, _ptr(rows), _ptr(keys_i64), _ptr(is_new), n, C.c_uint64(seed), s,
-              float(fill or 0.0), _stream())
+    _lib.call("mrec_init_rows_f32", _ptr(table), ld, D, _ptr(rows), _ptr(keys_i64), _ptr(is_new), n, _ptr(n_dev),
+              C.c_uint64(seed), s, float(fill or 0.0), _stream())
+
+
+def compose_i32(table, idx):
+    """out[i] = table[idx[i]] on int32 arrays: rows per position from rows per unique key."""
+    n = idx.numel()
+    out = torch.empty(max(n, 1), dtype=torch.int32, device=idx.device)[:n]
+    _lib.call("mrec_compose_i32", _ptr(table), _ptr(idx), n, _ptr(out), _stream())
+    return out
+
+
+def widen_keys(keys):
+    """int32 -> int64 key widening (no-op for int64)."""
+    if keys.dtype == torch.int64:
+        return keys.contiguous()
+    if keys.dtype != torch.int32:
+        raise TypeError(f"keys must be int32 or int64, got {keys.dtype}")
+    k = keys.contiguous()
+    out = torch.empty(k.shape, dtype=torch.int64, device=k.device)
+    _lib.call("mrec_widen_i32_i64", _ptr(k), k.numel(), _ptr(out), _stream())
+    return out
 
 
 def scatter_rows_(table, rows, vals):

@@ -134,6 +134,28 @@ class WideDeepEngine:
         self._amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[cfg.mlp_dtype]
         self.timers = None            # optional dict name -> list[(start_event, stop_event)]
 
+    # ---- collectives -------------------------------------------------------------------------
+    # RCCL (backend "nccl") takes device tensors directly.  Under a gloo group with device tensors
+    # (debugging several ranks on one GPU, or CPU tests) the payload is staged through host memory.
+    def _staged(self):
+        return self._gpu and dist.get_backend(self.group) == "gloo"
+
+    def _all_to_all(self, out, inp, out_splits=None, in_splits=None):
+        if self._staged():
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
+    def _all_reduce(self, t):
+        if self._staged():
+            c = t.cpu()
+            dist.all_reduce(c, group=self.group)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, group=self.group)
+
     # ---- helpers -----------------------------------------------------------------------------
     def _tick(self, name):
         if self.timers is None:
@@ -187,11 +209,11 @@ class WideDeepEngine:
         send_local, perm, counts = self.k.shard_route(ids, self.world)
         send_counts = counts.tolist()                                    # host sync: n_shards ints
         recv_counts_t = torch.empty_like(counts)
-        dist.all_to_all_single(recv_counts_t, counts, group=self.group)
+        self._all_to_all(recv_counts_t, counts)
         recv_counts = recv_counts_t.tolist()
         n_recv = int(sum(recv_counts))
         recv_local = torch.empty(n_recv, dtype=ids.dtype, device=self.device)
-        dist.all_to_all_single(recv_local, send_local, recv_counts, send_counts, group=self.group)
+        self._all_to_all(recv_local, send_local, recv_counts, send_counts)
         self._tock(ev)
         ev = self._tick("gather_deep")
         rows = self.k.gather_rows(self.deep, recv_local)                    # [n_recv, D]
@@ -201,8 +223,8 @@ class WideDeepEngine:
         n = ids.numel()
         back = torch.empty((n, cfg.emb_dim), dtype=torch.float32, device=self.device)
         wback = torch.empty((n, 1), dtype=torch.float32, device=self.device)
-        dist.all_to_all_single(back, rows, [c * 1 for c in send_counts], recv_counts, group=self.group)
-        dist.all_to_all_single(wback, wrows, send_counts, recv_counts, group=self.group)
+        self._all_to_all(back, rows, send_counts, recv_counts)
+        self._all_to_all(wback, wrows, send_counts, recv_counts)
         self._tock(ev)
         ev = self._tick("unroute")
         emb = self.k.shard_unroute(back, perm, wts.reshape(-1)).view(B, Fd * cfg.emb_dim)
@@ -241,10 +263,10 @@ class WideDeepEngine:
 
         if self.world > 1:
             ev = self._tick("allreduce_dense")
-            dist.all_reduce(self.dense_grad_flat, group=self.group)
+            self._all_reduce(self.dense_grad_flat)
             self.dense_grad_flat.div_(self.world)
             gb = g_wide.sum().view(1)
-            dist.all_reduce(gb, group=self.group)
+            self._all_reduce(gb)
             gb.div_(self.world)
             self._tock(ev)
         else:
@@ -275,8 +297,8 @@ class WideDeepEngine:
             n_recv = recv_local.numel()
             recv_g = torch.empty((n_recv, D), dtype=torch.float32, device=self.device)
             recv_gw = torch.empty((n_recv, 1), dtype=torch.float32, device=self.device)
-            dist.all_to_all_single(recv_g, send_g, recv_counts, send_counts, group=self.group)
-            dist.all_to_all_single(recv_gw, send_gw, recv_counts, send_counts, group=self.group)
+            self._all_to_all(recv_g, send_g, recv_counts, send_counts)
+            self._all_to_all(recv_gw, send_gw, recv_counts, send_counts)
             self._tock(ev)
             ev = self._tick("plan")
             plan = self.k.sparse_plan(recv_local)
