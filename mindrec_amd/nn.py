@@ -214,12 +214,7 @@ class Adam(LazyAdam):
 def _densify(rg, like):
     sums = ops.segment_sum(rg.plan, rg.values, rg.row_scale)
     dense = torch.zeros_like(like)
-    rows = rg.plan.uniq_buf if rg.plan.uniq_buf.dtype == torch.int32 else rg.plan.uniq_buf.to(torch.int32)
-    # rows past U are garbage: mask them with the device-side count
-    n = rows.numel()
-    valid = torch.arange(n, device=rows.device) < rg.plan.n_uniq_dev
-    rows = torch.where(valid, rows, torch.full_like(rows, -1))
-    ops.scatter_rows_(dense, rows, sums)
+    ops.scatter_unique_rows_(dense, rg.plan, sums)
     return dense
 
 

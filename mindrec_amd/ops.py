@@ -357,6 +357,16 @@ def widen_keys(keys):
     return out
 
 
+def scatter_unique_rows_(table, plan, vals):
+    """table[plan.uniq[u], :] = vals[u, :] for u < U (device-side U: rows past it are masked off).
+    Densifies a segment-sum into the [V, D] gradient of a Gather (deep_and_cross.py:199 bprop)."""
+    rows = plan.uniq_buf if plan.uniq_buf.dtype == torch.int32 else plan.uniq_buf.to(torch.int32)
+    n = rows.numel()
+    valid = torch.arange(n, device=rows.device) < plan.n_uniq_dev
+    rows = torch.where(valid, rows, torch.full_like(rows, -1))
+    scatter_rows_(table, rows, vals[:n])
+
+
 def scatter_rows_(table, rows, vals):
     """MapTensorPut on the row storage (README.md:188-190)."""
     V, D, ld = _table(table)

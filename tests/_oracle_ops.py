@@ -78,3 +78,29 @@ def shard_route_rows(g, send_perm, row_scale=None):
     gg = _np(g).reshape(p.size, -1)
     out = gg[p] * (_np(row_scale)[p][:, None] if row_scale is not None else 1.0)
     return torch.from_numpy(np.ascontiguousarray(out, dtype=np.float32))
+
+
+def segment_sum(plan, g, row_scale=None, grad_scale=1.0):
+    u, inv = O.unique(plan.ids)
+    vals = _np(g).reshape(plan.n, -1)
+    if row_scale is not None:
+        vals = vals * _np(row_scale).reshape(-1, 1)
+    vals = (vals * np.float32(grad_scale)).astype(np.float32)
+    plan._uniq = u
+    out = np.zeros((plan.n, vals.shape[1]), np.float32)
+    out[: u.size] = O.segment_sum(vals, inv, u.size)
+    return torch.from_numpy(out)
+
+
+def scatter_unique_rows_(table, plan, vals):
+    u = plan._uniq
+    ok = (u >= 0) & (u < table.shape[0])
+    _np(table)[u[ok]] = _np(vals)[: u.size][ok]
+
+
+def cross_layers(x0, w, b):
+    return torch.from_numpy(O.cross_layers(_np(x0), _np(w), _np(b)))
+
+
+def cross_layers_bwd(x0, w, b, dy):
+    return tuple(torch.from_numpy(a) for a in O.cross_layers_bwd(_np(x0), _np(w), _np(b), _np(dy)))
