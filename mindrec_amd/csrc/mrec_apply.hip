@@ -40,6 +40,12 @@ namespace {
 #ifndef MREC_NT4
 #define MREC_NT4 1
 #endif
+#ifndef MREC_GP4
+#define MREC_GP4 2
+#endif
+#ifndef MREC_GP1
+#define MREC_GP1 4
+#endif
 #ifndef MREC_AW1
 #define MREC_AW1 8
 #endif
@@ -50,8 +56,9 @@ namespace {
 #define MREC_NT1 0
 #endif
 template <int VEC> struct ACfg;
-template <> struct ACfg<4> { static constexpr int AW = MREC_AW4, AB = MREC_AB4; static constexpr bool NT = MREC_NT4; };
-template <> struct ACfg<1> { static constexpr int AW = MREC_AW1, AB = MREC_AB1; static constexpr bool NT = MREC_NT1; };
+template <> struct ACfg<4> { static constexpr int AW = MREC_AW4, AB = MREC_AB4, GP = MREC_GP4; static constexpr bool NT = MREC_NT4; };
+template <> struct ACfg<1> { static constexpr int AW = MREC_AW1, AB = MREC_AB1, GP = MREC_GP1; static constexpr bool NT = MREC_NT1; };
+static_assert(MREC_GP4 % MREC_AB4 == 0 && MREC_GP1 % MREC_AB1 == 0, "gradient prefetch depth must be a multiple of the state batch depth");
 constexpr int AW_MIN = (MREC_AW4 < MREC_AW1) ? MREC_AW4 : MREC_AW1;
 
 template <int VEC> struct Vf;
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t 
                                                     const float* __restrict__ rscale, float gscale, ApplyGeom gm,
                                                     float* __restrict__ carry_head, float* __restrict__ carry_tail,
                                                     int* __restrict__ owners, int* __restrict__ n_owners) {
-    constexpr int AW = ACfg<VEC>::AW, AB = ACfg<VEC>::AB;
+    constexpr int AW = ACfg<VEC>::AW, AB = ACfg<VEC>::AB, GP = ACfg<VEC>::GP;
     constexpr bool NT = ACfg<VEC>::NT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
@@ -164,68 +171,77 @@ __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t 
     Vf<VEC> acc;
     vzero(acc);
 
-    for (int j0 = s; j0 < e_end; j0 += AB) {
-        int seg[AB + 1];
-        bool valid[AB], is_end[AB], is_start[AB], open[AB], upd_ok[AB];
-        int64_t roff[AB];
-        Vf<VEC> gv[AB];
-        Vf<VEC> st[AB][Upd::NS];
-        float rs[AB];
-        seg[0] = seg_cur;
-        // ---- issue all loads of this batch
+    // Gradient rows are prefetched GP entries at a time (one load each, always needed); state rows are
+    // loaded AB entries at a time just before their update (only run ends need them).
+    for (int jg = s; jg < e_end; jg += GP) {
+        Vf<VEC> gvv[GP];
+        float rsv[GP];
 #pragma unroll
-        for (int k = 0; k < AB; ++k) {
-            const int e = j0 + k;
-            valid[k] = e < e_end;
-            seg[k + 1] = (e + 1 < n) ? sseg[(e + 1 < n) ? e + 1 : e] : -2;
-            int pos = 0;
-            if (valid[k]) pos = spos[e];
-            rs[k] = 1.0f;
-            vzero(gv[k]);
-            if (valid[k]) {
-                vload<NT>(gv[k], g + (int64_t)pos * ldg + col);
-                if (rscale) rs[k] = rscale[pos];
+        for (int q = 0; q < GP; ++q) {
+            const int e = jg + q;
+            rsv[q] = 1.0f;
+            vzero(gvv[q]);
+            if (e < e_end) {
+                const int pos = spos[e];
+                vload<NT>(gvv[q], g + (int64_t)pos * ldg + col);
+                if (rscale) rsv[q] = rscale[pos];
             }
         }
 #pragma unroll
-        for (int k = 0; k < AB; ++k) {
-            const int e = j0 + k;
-            is_start[k] = (e == s) || (seg[k] != (k > 0 ? seg[k - 1] : seg_prev));
-            is_end[k] = valid[k] && (seg[k + 1] != seg[k]);
-            open[k] = head_open && (seg[k] == first_seg);
-            upd_ok[k] = false;
-            roff[k] = 0;
-            if (is_end[k] && !open[k]) {
-                const int64_t row = seg_row<K>(uniq, seg[k]);
-                if (row >= 0 && row < V) {
-                    upd_ok[k] = true;
-                    roff[k] = row * ld + col;
-                    if (Upd::kLoad) {
+        for (int sb = 0; sb < GP / AB; ++sb) {
+            const int j0 = jg + sb * AB;
+            if (j0 >= e_end) break;
+            int seg[AB + 1];
+            bool valid[AB], is_end[AB], is_start[AB], open[AB], upd_ok[AB];
+            int64_t roff[AB];
+            Vf<VEC> st[AB][Upd::NS];
+            seg[0] = seg_cur;
 #pragma unroll
-                        for (int i = 0; i < Upd::NS; ++i) vload<NT>(st[k][i], upd.s[i] + roff[k]);
+            for (int k = 0; k < AB; ++k) {
+                const int e = j0 + k;
+                valid[k] = e < e_end;
+                seg[k + 1] = (e + 1 < n) ? sseg[e + 1] : -2;
+            }
+#pragma unroll
+            for (int k = 0; k < AB; ++k) {
+                const int e = j0 + k;
+                is_start[k] = (e == s) || (seg[k] != (k > 0 ? seg[k - 1] : seg_prev));
+                is_end[k] = valid[k] && (seg[k + 1] != seg[k]);
+                open[k] = head_open && (seg[k] == first_seg);
+                upd_ok[k] = false;
+                roff[k] = 0;
+                if (is_end[k] && !open[k]) {
+                    const int64_t row = seg_row<K>(uniq, seg[k]);
+                    if (row >= 0 && row < V) {
+                        upd_ok[k] = true;
+                        roff[k] = row * ld + col;
+                        if (Upd::kLoad) {
+#pragma unroll
+                            for (int i = 0; i < Upd::NS; ++i) vload<NT>(st[k][i], upd.s[i] + roff[k]);
+                        }
                     }
                 }
             }
-        }
-        // ---- consume
 #pragma unroll
-        for (int k = 0; k < AB; ++k) {
-            if (!valid[k]) continue;
-            if (rscale) vmul(gv[k], rs[k]);
-            vmul(gv[k], gscale);
-            if (is_start[k]) acc = gv[k]; else vadd(acc, gv[k]);
-            if (is_end[k]) {
-                if (open[k]) {
-                    vstore<false>(carry_head + sw * gm.D + col, acc);
-                } else if (upd_ok[k]) {
-                    upd_apply<Upd>(upd, st[k], acc);
+            for (int k = 0; k < AB; ++k) {
+                if (!valid[k]) continue;
+                Vf<VEC> x = gvv[sb * AB + k];
+                if (rscale) vmul(x, rsv[sb * AB + k]);
+                vmul(x, gscale);
+                if (is_start[k]) acc = x; else vadd(acc, x);
+                if (is_end[k]) {
+                    if (open[k]) {
+                        vstore<false>(carry_head + sw * gm.D + col, acc);
+                    } else if (upd_ok[k]) {
+                        upd_apply<Upd>(upd, st[k], acc);
 #pragma unroll
-                    for (int i = 0; i < Upd::NS; ++i) vstore<NT>(upd.s[i] + roff[k], st[k][i]);
+                        for (int i = 0; i < Upd::NS; ++i) vstore<NT>(upd.s[i] + roff[k], st[k][i]);
+                    }
                 }
             }
+            seg_prev = seg[AB - 1];
+            seg_cur = seg[AB];
         }
-        seg_prev = seg[AB - 1];
-        seg_cur = seg[AB];
     }
     // run continues past this window?
     const int last_seg = sseg[e_end - 1];
@@ -250,7 +266,8 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
                                                     const float* __restrict__ carry_tail,
                                                     const int* __restrict__ owners,
                                                     const int* __restrict__ n_owners) {
-    constexpr int AW = ACfg<VEC>::AW, AB = 4;
+    // the partials of a run are consecutive carry rows: stream them 16 deep per lane-group
+    constexpr int AW = ACfg<VEC>::AW, AB = 16;
     __shared__ float red[256 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
