@@ -25,6 +25,7 @@ data-parallel with one flat all-reduce(mean) (gradients_mean=True,
 train_and_eval_distribute.py:135-138).
 """
 import contextlib
+import os
 from dataclasses import dataclass, field
 from typing import List
 
@@ -63,6 +64,26 @@ class WideDeepConfig:
     fused_state: bool = True
 
 
+_TUNED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "tunableop_gfx950.csv")
+
+
+def enable_tuned_gemms():
+    """Loads the shipped TunableOp table (tools/tune_gemms.py) with tuning disabled: the MLP GEMMs
+    use the hipBLASLt / rocBLAS solutions measured fastest on MI355X for these shapes (0.56 ms vs
+    0.83 ms of GEMM time per Wide&Deep step); unknown shapes fall back to the library default."""
+    if os.environ.get("MREC_NO_TUNED_GEMMS") or not os.path.exists(_TUNED):
+        return False
+    try:
+        import torch.cuda.tunable as tn
+        tn.enable(True)
+        tn.tuning_enable(False)
+        tn.set_filename(_TUNED, insert_device_ordinal=False)
+        tn.read_file(_TUNED)
+        return True
+    except Exception:      # table from another library version: run on defaults
+        return False
+
+
 def _flat_views(shapes, device):
     n = sum(int(np.prod(s)) for s in shapes)
     flat = torch.zeros(n, dtype=torch.float32, device=device)
@@ -77,7 +98,7 @@ def _flat_views(shapes, device):
 class WideDeepEngine:
     """State + one training step.  rank/world describe the row sharding; world == 1 is one GPU."""
 
-    def __init__(self, cfg: WideDeepConfig, device, rank=0, world=1, group=None, kernels=None):
+    def __init__(self, cfg: WideDeepConfig, device, rank=0, world=1, group=None, kernels=None, tuned_gemms=True):
         """kernels: module providing the op set of mindrec_amd.ops.  The product always uses the HIP
         one (default); tests/ inject a CPU stand-in to exercise the multi-rank host logic under gloo."""
         self.cfg, self.device, self.rank, self.world, self.group = cfg, torch.device(device), rank, world, group
@@ -85,6 +106,7 @@ class WideDeepEngine:
         self._gpu = self.device.type == "cuda"
         if kernels is None and not self._gpu:
             raise RuntimeError("WideDeepEngine runs on an MI355X (no CPU fallback)")
+        self.tuned_gemms = bool(tuned_gemms and self._gpu and enable_tuned_gemms())
         V, D = cfg.vocab_size, cfg.emb_dim
         self.local_rows = (V - rank + world - 1) // world          # rows r with r*world + rank < V
         dev = self.device
