@@ -148,7 +148,8 @@ def main():
     plan = eng.last_plan
     U = plan.U                                  # unique ids of the last step's (local) apply
     n_apply = plan.n
-    by = embedding_bytes(n_apply, U, args.emb_dim)
+    bf16_io = eng._fused_bf16() and world == 1        # gather writes / apply reads bf16 rows
+    by = embedding_bytes(n_apply, U, args.emb_dim, act_bytes=2 if bf16_io else 4)
     kmain = [t.ms() for t in ktimers]
     apply_ms = sum(kmain) / len(kmain)
     achieved = by["apply_deep"] / (apply_ms * 1e-3) / 1e9
@@ -157,9 +158,9 @@ def main():
     # with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command and corrected
     # per MI355X_MICROARCH.md); only quoted when this run is the workload that was profiled.
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")      # collected on the bf16-gradient variant
     default_cfg = (args.vocab == 200_000_000 and args.emb_dim == 80 and args.batch == 16384 and args.fields == 26
-                   and args.dist == "uniform" and not args.split_state and world == 1)
+                   and args.dist == "uniform" and not args.split_state and world == 1 and args.mlp_dtype == "bf16")
     if default_cfg and os.path.exists(pmc_path):
         traffic = json.load(open(pmc_path)).get("apply_main_adam", {}).get("total_bytes")
     out = {
@@ -181,7 +182,8 @@ def main():
                                f"MLP {cfg.field_size * cfg.emb_dim}-1024-512-256-128-1 in {args.mlp_dtype}",
                    "global_batch": args.batch * world, "id_dist": args.dist, "unique_frac": round(U / max(n_apply, 1), 4),
                    "parallelism": "1 GPU" if world == 1 else f"tables row-sharded x{world} (RCCL all-to-all), MLP dp{world}"},
-        "roofline": {"bound": "hbm", "kernel": "k_apply_main<4,int,UpdAdam> (fused segment-sum + LazyAdam row update)",
+        "roofline": {"bound": "hbm", "kernel": "k_apply_main<4,int,UpdAdam,%s> (fused segment-sum + LazyAdam row update)" % ("bf16_t" if bf16_io else "float"),
+                     "row_gradient_dtype": "bf16" if bf16_io else "f32",
                      "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "algorithmic_bytes": by["apply_deep"], "avg_ms": round(apply_ms, 5),
                      "timing": "HIP events around k_apply_main on its launch stream (mrec_profile_next_apply), "

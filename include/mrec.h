@@ -79,6 +79,14 @@ int mrec_gather_rows_f32_i32(const float* table, int64_t V, int64_t ld, int32_t 
 int mrec_gather_rows_f32_i64(const float* table, int64_t V, int64_t ld, int32_t D, const int64_t* ids,
                              int64_t n, const float* row_scale, float* out, void* stream);
 
+/* Same gather with bf16 output rows (round-to-nearest-even): fuses the Cast(x, float16) that
+ * DenseLayer.construct applies to the masked embeddings (wide_and_deep.py:122) -- bf16 on MI355X.
+ * D % 4 == 0 and D <= 256, or D <= 64. */
+int mrec_gather_rows_bf16_i32(const float* table, int64_t V, int64_t ld, int32_t D, const int32_t* ids,
+                              int64_t n, const float* row_scale, uint16_t* out, void* stream);
+int mrec_gather_rows_bf16_i64(const float* table, int64_t V, int64_t ld, int32_t D, const int64_t* ids,
+                              int64_t n, const float* row_scale, uint16_t* out, void* stream);
+
 /* Wide branch of WideDeepModel.construct (wide_and_deep.py:300,303-306) in one pass:
  * out[b] = sum_f w[ids[b,f] * ldw] * wts[b,f] + *bias_dev   (w is the [V,1] wide table, row
  * stride ldw floats: 1 for a dense column, 4 when it lives in a fused w|accum|linear|pad record). */
@@ -120,6 +128,21 @@ int mrec_sparse_lazy_adam_f32_i64(float* p, float* m, float* v, int64_t V, int64
                                   const float* row_scale, float lr, float b1, float b2, float eps,
                                   float b1_pow, float b2_pow, float grad_scale, int nesterov, void* ws,
                                   size_t ws_bytes, void* stream);
+
+/* LazyAdam with bf16 row gradients g[n, D] (what the mixed-precision MLP's backward hands back;
+ * the Cast bprop would widen them to fp32 first -- the kernel widens on load, bit-identically). */
+int mrec_sparse_lazy_adam_bf16g_i32(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D,
+                                    const int32_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                    const int32_t* seg_offsets, int64_t n, const uint16_t* g, int64_t ldg,
+                                    const float* row_scale, float lr, float b1, float b2, float eps,
+                                    float b1_pow, float b2_pow, float grad_scale, int nesterov, void* ws,
+                                    size_t ws_bytes, void* stream);
+int mrec_sparse_lazy_adam_bf16g_i64(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D,
+                                    const int64_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                    const int32_t* seg_offsets, int64_t n, const uint16_t* g, int64_t ldg,
+                                    const float* row_scale, float lr, float b1, float b2, float eps,
+                                    float b1_pow, float b2_pow, float grad_scale, int nesterov, void* ws,
+                                    size_t ws_bytes, void* stream);
 
 /* nn.FTRL sparse apply (FusedSparseFtrl; wide_and_deep.py:423-430). */
 int mrec_sparse_ftrl_f32_i32(float* var, float* accum, float* linear, int64_t V, int64_t ld, int32_t D,

@@ -41,6 +41,8 @@ _SIGS = {
     "mrec_group_by_inverse": [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_gather_rows_f32_i32": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_gather_rows_f32_i64": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
+    "mrec_gather_rows_bf16_i32": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
+    "mrec_gather_rows_bf16_i64": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_wide_sum_f32_i32": [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_wide_sum_f32_i64": [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_sparse_apply_workspace_bytes": [_i64, _i32, _szp],
@@ -50,6 +52,10 @@ _SIGS = {
                                       _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _sz, _vp],
     "mrec_sparse_lazy_adam_f32_i64": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
                                       _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _sz, _vp],
+    "mrec_sparse_lazy_adam_bf16g_i32": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
+                                        _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _sz, _vp],
+    "mrec_sparse_lazy_adam_bf16g_i64": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
+                                        _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _sz, _vp],
     "mrec_sparse_ftrl_f32_i32": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
                                  _f32, _f32, _f32, _f32, _f32, _vp, _sz, _vp],
     "mrec_sparse_ftrl_f32_i64": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,

@@ -77,6 +77,24 @@ template <bool NT> __device__ __forceinline__ void vload(Vf<4>& r, const float* 
 template <bool NT> __device__ __forceinline__ void vload(Vf<1>& r, const float* p) {
     r.v = NT ? __builtin_nontemporal_load(p) : *p;
 }
+// bf16 row gradients (what a mixed-precision MLP backward produces): widened exactly (bits << 16),
+// so summing them is bit-identical to casting the gradient tensor to fp32 first -- at half the bytes.
+struct bf16_t { uint16_t v; };
+template <bool NT> __device__ __forceinline__ void vload(Vf<4>& r, const bf16_t* p) {
+    uint2 u;
+    if (NT) {
+        typedef unsigned int mrec_u2 __attribute__((ext_vector_type(2)));
+        mrec_u2 t = __builtin_nontemporal_load((const mrec_u2*)p);
+        u = make_uint2(t.x, t.y);
+    } else {
+        u = *(const uint2*)p;
+    }
+    r.v = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                      __uint_as_float(u.y & 0xFFFF0000u));
+}
+template <bool NT> __device__ __forceinline__ void vload(Vf<1>& r, const bf16_t* p) {
+    r.v = __uint_as_float(((unsigned int)p->v) << 16);
+}
 template <bool NT> __device__ __forceinline__ void vstore(float* p, const Vf<4>& x) {
     if (NT) {
         mrec_f4 t = {x.v.x, x.v.y, x.v.z, x.v.w};
@@ -145,10 +163,10 @@ __device__ __forceinline__ int64_t seg_row(const K* uniq, int seg) {
     return uniq ? (int64_t)uniq[seg] : (int64_t)seg;
 }
 
-template <int VEC, class K, class Upd>
+template <int VEC, class K, class Upd, class GT>
 __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
                                                     const int* __restrict__ spos, const int* __restrict__ sseg,
-                                                    int n, const float* __restrict__ g, int64_t ldg,
+                                                    int n, const GT* __restrict__ g, int64_t ldg,
                                                     const float* __restrict__ rscale, float gscale, ApplyGeom gm,
                                                     float* __restrict__ carry_head, float* __restrict__ carry_tail,
                                                     int* __restrict__ owners, int* __restrict__ n_owners) {
@@ -344,9 +362,9 @@ size_t apply_ws_bytes(int64_t n, int32_t D) {
 }
 
 // One launch pair over columns [c0, c0+Dc) of every array.
-template <class K, class Upd>
+template <class K, class Upd, class GT>
 int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, const int* sseg,
-               const int* seg_offsets, int64_t n, const float* g, int64_t ldg, const float* rscale, float gscale,
+               const int* seg_offsets, int64_t n, const GT* g, int64_t ldg, const float* rscale, float gscale,
                int Dc, bool vec, const ApplyWs& w, hipStream_t st) {
     ApplyGeom gm;
     gm.D = Dc;
@@ -360,13 +378,13 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
     t_prof_start = t_prof_stop = nullptr;
     if (ev0) MREC_HIP_CHECK(hipEventRecord(ev0, st));
     if (vec) {
-        k_apply_main<4, K, Upd><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
+        k_apply_main<4, K, Upd, GT><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
                                                        w.carry_head, w.carry_tail, w.owners, w.n_owners);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         k_apply_long<4, K, Upd><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
                                                         w.carry_head, w.carry_tail, w.owners, w.n_owners);
     } else {
-        k_apply_main<1, K, Upd><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
+        k_apply_main<1, K, Upd, GT><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
                                                        w.carry_head, w.carry_tail, w.owners, w.n_owners);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         k_apply_long<1, K, Upd><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
@@ -376,9 +394,9 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
     return MREC_OK;
 }
 
-template <class K, class Upd>
+template <class K, class Upd, class GT = float>
 int apply_impl(Upd upd, int64_t V, int64_t ld, int32_t D, const K* uniq, const int32_t* spos, const int32_t* sseg,
-               const int32_t* seg_offsets, int64_t n, const float* g, int64_t ldg, const float* rscale,
+               const int32_t* seg_offsets, int64_t n, const GT* g, int64_t ldg, const float* rscale,
                float gscale, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || D <= 0 || V < 0 || ld < D || ldg < D) return MREC_EINVAL;
@@ -396,7 +414,7 @@ int apply_impl(Upd upd, int64_t V, int64_t ld, int32_t D, const K* uniq, const i
     w.owners = a.take<int>(nsw);
     w.n_owners = a.take<int>(1);
     if (!a.ok) return MREC_EWORKSPACE;
-    bool aligned = (ld % 4 == 0) && (ldg % 4 == 0) && al16(g);
+    bool aligned = (ld % 4 == 0) && (ldg % 4 == 0) && ((((uintptr_t)g) & (4 * sizeof(GT) - 1)) == 0);
     for (int i = 0; i < Upd::NS; ++i) aligned = aligned && al16(upd.s[i]);
     const bool vec = aligned && (D % 4 == 0);
     const int CB = vec ? 256 : 64;  // columns per launch
@@ -404,15 +422,15 @@ int apply_impl(Upd upd, int64_t V, int64_t ld, int32_t D, const K* uniq, const i
         const int Dc = (D - c0 < CB) ? D - c0 : CB;
         Upd u2 = upd;
         for (int i = 0; i < Upd::NS; ++i) u2.s[i] = upd.s[i] + c0;
-        int rc = apply_cols<K, Upd>(u2, V, ld, uniq, spos, sseg, seg_offsets, n, g + c0, ldg, rscale, gscale, Dc, vec, w, st);
+        int rc = apply_cols<K, Upd, GT>(u2, V, ld, uniq, spos, sseg, seg_offsets, n, g + c0, ldg, rscale, gscale, Dc, vec, w, st);
         if (rc != MREC_OK) return rc;
     }
     return MREC_OK;
 }
 
-template <class K>
+template <class K, class GT = float>
 int lazy_adam_impl(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D, const K* uniq,
-                   const int32_t* spos, const int32_t* sseg, const int32_t* seg_offsets, int64_t n, const float* g,
+                   const int32_t* spos, const int32_t* sseg, const int32_t* seg_offsets, int64_t n, const GT* g,
                    int64_t ldg, const float* rscale, float lr, float b1, float b2, float eps, float b1_pow,
                    float b2_pow, float gscale, int nesterov, void* ws, size_t ws_bytes, void* stream) {
     if (!uniq && n > 0) return MREC_EINVAL;
@@ -421,7 +439,7 @@ int lazy_adam_impl(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t 
     u.h.lr_t = lr * sqrtf(1.0f - b2_pow) / (1.0f - b1_pow);
     u.h.b1 = b1; u.h.b2 = b2; u.h.omb1 = 1.0f - b1; u.h.omb2 = 1.0f - b2; u.h.eps = eps; u.h.gscale = gscale;
     u.h.nesterov = nesterov;
-    return apply_impl<K, UpdAdam>(u, V, ld, D, uniq, spos, sseg, seg_offsets, n, g, ldg, rscale, gscale, ws, ws_bytes,
+    return apply_impl<K, UpdAdam, GT>(u, V, ld, D, uniq, spos, sseg, seg_offsets, n, g, ldg, rscale, gscale, ws, ws_bytes,
                                   stream);
 }
 
@@ -501,6 +519,27 @@ MREC_API int mrec_sparse_lazy_adam_f32_i64(float* p, float* m, float* v, int64_t
                                            size_t ws_bytes, void* stream) {
     return lazy_adam_impl<int64_t>(p, m, v, V, ld, D, uniq, sorted_pos, sorted_seg, seg_offsets, n, g, ldg, row_scale,
                                    lr, b1, b2, eps, b1_pow, b2_pow, grad_scale, nesterov, ws, ws_bytes, stream);
+}
+
+MREC_API int mrec_sparse_lazy_adam_bf16g_i32(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D,
+                                             const int32_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                             const int32_t* seg_offsets, int64_t n, const uint16_t* g, int64_t ldg,
+                                             const float* row_scale, float lr, float b1, float b2, float eps,
+                                             float b1_pow, float b2_pow, float grad_scale, int nesterov, void* ws,
+                                             size_t ws_bytes, void* stream) {
+    return lazy_adam_impl<int32_t, bf16_t>(p, m, v, V, ld, D, uniq, sorted_pos, sorted_seg, seg_offsets, n,
+                                           (const bf16_t*)g, ldg, row_scale, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale,
+                                           nesterov, ws, ws_bytes, stream);
+}
+MREC_API int mrec_sparse_lazy_adam_bf16g_i64(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D,
+                                             const int64_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                             const int32_t* seg_offsets, int64_t n, const uint16_t* g, int64_t ldg,
+                                             const float* row_scale, float lr, float b1, float b2, float eps,
+                                             float b1_pow, float b2_pow, float grad_scale, int nesterov, void* ws,
+                                             size_t ws_bytes, void* stream) {
+    return lazy_adam_impl<int64_t, bf16_t>(p, m, v, V, ld, D, uniq, sorted_pos, sorted_seg, seg_offsets, n,
+                                           (const bf16_t*)g, ldg, row_scale, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale,
+                                           nesterov, ws, ws_bytes, stream);
 }
 
 MREC_API int mrec_sparse_ftrl_f32_i32(float* var, float* accum, float* linear, int64_t V, int64_t ld, int32_t D,

@@ -28,16 +28,28 @@ __device__ __forceinline__ Vf<1> vscale(Vf<1> x, float s) { x.v *= s; return x; 
 __device__ __forceinline__ Vf<4> vzero(Vf<4>*) { Vf<4> r; r.v = make_float4(0.f, 0.f, 0.f, 0.f); return r; }
 __device__ __forceinline__ Vf<1> vzero(Vf<1>*) { Vf<1> r; r.v = 0.f; return r; }
 
+// bf16 output rows (round-to-nearest-even, the cast the reference applies to the masked embeddings
+// before its mixed-precision MLP, wide_and_deep.py:113-133): halves the gather's write stream.
+struct bf16o_t { uint16_t v; };
+__device__ __forceinline__ uint16_t f2bf(float x) { __bf16 b = (__bf16)x; return __builtin_bit_cast(uint16_t, b); }
+__device__ __forceinline__ void vstore(bf16o_t* p, const Vf<4>& x) {
+    uint2 u;
+    u.x = (unsigned)f2bf(x.v.x) | ((unsigned)f2bf(x.v.y) << 16);
+    u.y = (unsigned)f2bf(x.v.z) | ((unsigned)f2bf(x.v.w) << 16);
+    *(uint2*)p = u;
+}
+__device__ __forceinline__ void vstore(bf16o_t* p, const Vf<1>& x) { p->v = f2bf(x.v); }
+
 constexpr int GB = 4;  // rows in flight per lane-group
 
 // Lane-group geometry shared by the row kernels: lpr lanes per row, G = 64/lpr groups per wave.
 struct RowGeom { int lpr; int G; };
 
-template <int VEC, class K>
+template <int VEC, class K, class OT = float>
 __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ table, int64_t V, int64_t ld,
                                                      const K* __restrict__ ids, int64_t n,
                                                      const float* __restrict__ row_scale,
-                                                     float* __restrict__ out, int D, RowGeom gm) {
+                                                     OT* __restrict__ out, int D, RowGeom gm) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
     if (grp >= gm.G) return;
@@ -208,6 +220,29 @@ __global__ __launch_bounds__(256) void k_dense_ftrl(float* __restrict__ w, float
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 template <class K>
+int gather_bf16_impl(const float* table, int64_t V, int64_t ld, int32_t D, const K* ids, int64_t n,
+                     const float* row_scale, uint16_t* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || D <= 0 || V < 0 || ld < D) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!table || !ids || !out) return MREC_EINVAL;
+    const bool vec = (D % 4 == 0) && (D <= 256) && (ld % 4 == 0) && al16(table) && ((((uintptr_t)out) & 7) == 0);
+    if (vec) {
+        RowGeom gm{D / 4, 64 / (D / 4)};
+        k_gather_rows<4, K, bf16o_t><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
+            table, V, ld, ids, n, row_scale, (bf16o_t*)out, D, gm);
+    } else if (D <= 64) {
+        RowGeom gm{D, 64 / D};
+        k_gather_rows<1, K, bf16o_t><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
+            table, V, ld, ids, n, row_scale, (bf16o_t*)out, D, gm);
+    } else {
+        return MREC_EUNSUPPORTED;
+    }
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+template <class K>
 int gather_impl(const float* table, int64_t V, int64_t ld, int32_t D, const K* ids, int64_t n,
                 const float* row_scale, float* out, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -296,6 +331,15 @@ MREC_API int mrec_gather_rows_f32_i32(const float* table, int64_t V, int64_t ld,
 MREC_API int mrec_gather_rows_f32_i64(const float* table, int64_t V, int64_t ld, int32_t D, const int64_t* ids,
                                       int64_t n, const float* row_scale, float* out, void* stream) {
     return gather_impl<int64_t>(table, V, ld, D, ids, n, row_scale, out, stream);
+}
+
+MREC_API int mrec_gather_rows_bf16_i32(const float* table, int64_t V, int64_t ld, int32_t D, const int32_t* ids,
+                                       int64_t n, const float* row_scale, uint16_t* out, void* stream) {
+    return gather_bf16_impl<int32_t>(table, V, ld, D, ids, n, row_scale, out, stream);
+}
+MREC_API int mrec_gather_rows_bf16_i64(const float* table, int64_t V, int64_t ld, int32_t D, const int64_t* ids,
+                                       int64_t n, const float* row_scale, uint16_t* out, void* stream) {
+    return gather_bf16_impl<int64_t>(table, V, ld, D, ids, n, row_scale, out, stream);
 }
 
 MREC_API int mrec_wide_sum_f32_i32(const float* w, int64_t V, int64_t ldw, const int32_t* ids, const float* wts,

@@ -129,9 +129,10 @@ def sparse_plan(ids):
     return group_by_inverse(unique(ids))
 
 
-def gather_rows(table, ids, row_scale=None, out=None):
+def gather_rows(table, ids, row_scale=None, out=None, out_dtype=torch.float32):
     """ops.Gather / SparseGatherV2 / EmbeddingLookup (embedding.py:150,194; deep_and_cross.py:199),
-    optionally fused with the mask multiply of wide_and_deep.py:303,308."""
+    optionally fused with the mask multiply of wide_and_deep.py:303,308.  out_dtype=torch.bfloat16
+    also fuses the half-precision cast in front of the MLP (wide_and_deep.py:122)."""
     _need_cuda(table, ids, row_scale)
     V, D, ld = _table(table)
     sfx = _suffix(ids)
@@ -141,9 +142,12 @@ def gather_rows(table, ids, row_scale=None, out=None):
         row_scale = row_scale.reshape(-1).contiguous()
         if row_scale.dtype != torch.float32 or row_scale.numel() != n:
             raise TypeError("row_scale must be float32 with one value per id")
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("gather_rows out_dtype must be float32 or bfloat16")
     if out is None:
-        out = torch.empty((n, D), dtype=torch.float32, device=table.device)
-    _lib.call(f"mrec_gather_rows_f32_{sfx}", _ptr(table), V, ld, D, _ptr(flat), n, _ptr(row_scale), _ptr(out), _stream())
+        out = torch.empty((n, D), dtype=out_dtype, device=table.device)
+    fn = "mrec_gather_rows_f32_" if out.dtype == torch.float32 else "mrec_gather_rows_bf16_"
+    _lib.call(fn + sfx, _ptr(table), V, ld, D, _ptr(flat), n, _ptr(row_scale), _ptr(out), _stream())
     return out.view(tuple(ids.shape) + (D,))
 
 
@@ -165,9 +169,9 @@ def wide_sum(w, ids, wts, bias=None):
     return out
 
 
-def _grads(plan, g, D):
-    if g.dtype != torch.float32:
-        raise TypeError("row gradients must be float32")
+def _grads(plan, g, D, allow_bf16=False):
+    if g.dtype != torch.float32 and not (allow_bf16 and g.dtype == torch.bfloat16):
+        raise TypeError("row gradients must be float32" + (" or bfloat16" if allow_bf16 else ""))
     g2 = g.reshape(plan.n, D)
     if g2.stride(1) != 1:
         g2 = g2.contiguous()
@@ -215,11 +219,12 @@ def sparse_lazy_adam_(p, m, v, plan, g, row_scale=None, lr=3.5e-4, beta1=0.9, be
     for t in (m, v):
         if _table(t) != (V, D, ld):
             raise ValueError("p, m, v must share shape and row stride")
-    g2, ldg = _grads(plan, g, D)
+    g2, ldg = _grads(plan, g, D, allow_bf16=True)
     rs = _row_scale(plan, row_scale)
     ws = _apply_ws(plan, D, p.device)
     sfx = _suffix(plan.uniq_buf)
-    _lib.call(f"mrec_sparse_lazy_adam_f32_{sfx}", _ptr(p), _ptr(m), _ptr(v), V, ld, D, _ptr(plan.uniq_buf),
+    fn = "mrec_sparse_lazy_adam_f32_" if g2.dtype == torch.float32 else "mrec_sparse_lazy_adam_bf16g_"
+    _lib.call(fn + sfx, _ptr(p), _ptr(m), _ptr(v), V, ld, D, _ptr(plan.uniq_buf),
               _ptr(plan.sorted_pos), _ptr(plan.sorted_seg), _ptr(plan.seg_offsets), plan.n, _ptr(g2), ldg, _ptr(rs), lr,
               beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _ptr(ws), ws.numel(), _stream())
 

@@ -62,6 +62,7 @@ class WideDeepConfig:
     # apart (fewer DRAM activations and TLB walks per byte: +6-8 % on MI355X); the API still sees
     # p, m, v, w, ... as separate (strided) [V, D] / [V, 1] tensors.  False = three separate arrays.
     fused_state: bool = True
+    fused_mlp: bool = True               # hand-written fwd/bwd of the mixed-precision MLP (else autograd)
 
 
 _TUNED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "tunableop_gfx950.csv")
@@ -212,6 +213,39 @@ class WideDeepEngine:
                 h = torch.relu(h)
         return h.float()
 
+    @torch.no_grad()
+    def _mlp_step_fused(self, emb, wide, label):
+        """Forward + backward of the bf16 MLP written out by hand (no autograd graph).  `emb` arrives
+        in bf16 straight from the gather kernel, and the gradient of the MLP input is returned in bf16
+        for the sparse apply to widen on load -- the two [B, F*D] fp32<->bf16 cast passes of the
+        autograd path disappear, as do autograd's per-parameter cast and accumulate kernels.  Every
+        GEMM stays a plain addmm / mm so the shipped TunableOp table applies.  Same math as the
+        autograd path (ReLU mask = activation > 0).
+        Returns (loss, g_emb [B, F*D] bf16, g_wide [B] fp32); dense gradients land in dense_grad."""
+        amp, n = self._amp, len(self.dims) - 1
+        B = emb.shape[0]
+        Wb = [self.dense[2 * i].to(amp) for i in range(n - 1)]
+        hs = [emb if emb.dtype == amp else emb.to(amp)]
+        for i in range(n - 1):
+            hs.append(torch.addmm(self.dense[2 * i + 1].to(amp), hs[i], Wb[i]).relu_())
+        W5, b5 = self.dense[2 * (n - 1)], self.dense[2 * (n - 1) + 1]
+        h4 = hs[-1].float()
+        logit = torch.addmm(b5, h4, W5) + wide.view(-1, 1)
+        loss = F.binary_cross_entropy_with_logits(logit, label)
+        dlogit = (torch.sigmoid(logit) - label) * (self.cfg.sens / B)              # d(sens * mean BCE)/d logit
+        torch.mm(h4.t(), dlogit, out=self.dense_grad[2 * (n - 1)])
+        torch.sum(dlogit, dim=0, out=self.dense_grad[2 * (n - 1) + 1])
+        dh = torch.ops.aten.threshold_backward(torch.mm(dlogit, W5.t()).to(amp), hs[-1], 0)
+        g_emb = None
+        for i in range(n - 2, -1, -1):
+            self.dense_grad[2 * i].copy_(torch.mm(hs[i].t(), dh))                  # bf16 GEMM, widened into the flat fp32 grads
+            torch.sum(dh, dim=0, dtype=torch.float32, out=self.dense_grad[2 * i + 1])
+            if i > 0:
+                dh = torch.ops.aten.threshold_backward(torch.mm(dh, Wb[i].t()), hs[i], 0)
+            else:
+                g_emb = torch.mm(dh, Wb[0].t())
+        return loss, g_emb, dlogit.view(-1)
+
     # ---- forward (eval path: PredictWithSigmoid, wide_and_deep.py:495-518) ---------------------
     def lookup(self, ids, wts):
         """Returns (deep_in [B, F*D] already mask-multiplied, wide_out [B] incl. bias) and the
@@ -220,7 +254,10 @@ class WideDeepEngine:
         B, Fd = ids.shape
         if self.world == 1:
             ev = self._tick("gather_deep")
-            emb = self.k.gather_rows(self.deep, ids, wts).view(B, Fd * cfg.emb_dim)
+            if self._fused_bf16() and torch.is_grad_enabled():
+                emb = self.k.gather_rows(self.deep, ids, wts, out_dtype=torch.bfloat16).view(B, Fd * cfg.emb_dim)
+            else:
+                emb = self.k.gather_rows(self.deep, ids, wts).view(B, Fd * cfg.emb_dim)
             self._tock(ev)
             ev = self._tick("wide_sum")
             wide = self.k.wide_sum(self.wide, ids, wts, self.wide_b)
@@ -255,9 +292,12 @@ class WideDeepEngine:
         self._tock(ev)
         return emb, wide, (perm, send_counts, recv_counts, recv_local)
 
+    def _fused_bf16(self):
+        return self._gpu and self.cfg.fused_mlp and self._amp == torch.bfloat16 and self.k is ops
+
     def predict(self, ids, wts):
-        emb, wide, _ = self.lookup(ids, wts)
         with torch.no_grad():
+            emb, wide, _ = self.lookup(ids, wts)
             logit = wide.view(-1, 1) + self.mlp(emb)
         return logit, torch.sigmoid(logit)
 
@@ -272,15 +312,20 @@ class WideDeepEngine:
         self.beta2_power = np.float32(self.beta2_power * self.beta2)
 
         emb, wide, route = self.lookup(ids, wts)
-        emb.requires_grad_(True)
-        wide.requires_grad_(True)
 
         ev = self._tick("mlp_fwd_bwd")
-        self.dense_grad_flat.zero_()
-        logit = wide.view(-1, 1) + self.mlp(emb)
-        loss = F.binary_cross_entropy_with_logits(logit, label)          # SigmoidCrossEntropyWithLogits + ReduceMean
-        (loss * cfg.sens).backward()                                      # sens_param seeding, :479-486
-        g_emb, g_wide = emb.grad, wide.grad                               # [B, F*D], [B]
+        if self._fused_bf16():
+            loss, g_emb, g_wide = self._mlp_step_fused(emb, wide, label)
+            if route is not None:
+                g_emb = g_emb.float()          # the routed exchange ships fp32 rows
+        else:
+            emb.requires_grad_(True)
+            wide.requires_grad_(True)
+            self.dense_grad_flat.zero_()
+            logit = wide.view(-1, 1) + self.mlp(emb)
+            loss = F.binary_cross_entropy_with_logits(logit, label)      # SigmoidCrossEntropyWithLogits + ReduceMean
+            (loss * cfg.sens).backward()                                  # sens_param seeding, :479-486
+            g_emb, g_wide = emb.grad, wide.grad                           # [B, F*D], [B]
         self._tock(ev)
 
         if self.world > 1:
@@ -350,12 +395,14 @@ class WideDeepEngine:
 
 
 # ---- synthetic Criteo-shaped batches ------------------------------------------
-def synthetic_batch(cfg: WideDeepConfig, device, dist_kind="uniform", seed=1000, rank=0):
+def synthetic_batch(cfg: WideDeepConfig, device, dist_kind="uniform", seed=1000, rank=0, signal=False):
     """ids int32 [B,F], wts f32 [B,F], label f32 [B,1] -- the dataset contract of
     models/wide_deep/src/datasets.py:212-216.  F = 39 puts the 13 dense fields on the constant ids
     0..12 with weights in [0,1) (process_data.py:138-147); categorical weights are 1.0 (:149-162).
       uniform : ids uniform over [0, V)            (worst case for HBM: ~no duplicates)
       zipf    : Zipf(1.05) per slot over V/n_cat-sized sub-ranges  (realistic duplicate rate)
+    signal=True plants a hidden linear model over the ids (label ~ Bernoulli(sigmoid(sum_f a[id]))) so
+    that AUC is meaningful; otherwise labels are Bernoulli(0.25) noise.
     """
     g = torch.Generator(device="cpu")
     g.manual_seed(seed * 1000003 + rank)
@@ -378,15 +425,24 @@ def synthetic_batch(cfg: WideDeepConfig, device, dist_kind="uniform", seed=1000,
         wts[:, :n_dense] = torch.rand((B, n_dense), generator=g)
     else:
         ids = cat
-    label = (torch.rand((B, 1), generator=g) < 0.25).float()
+    if signal:
+        h = (ids * 2654435761 + 12345) % 1000003                       # fixed pseudo-random weight per id
+        a = (h.double() / 1000003.0 - 0.5) * 1.6
+        logit = (a * wts.double()).sum(dim=1, keepdim=True) - 0.8
+        label = (torch.rand((B, 1), generator=g).double() < torch.sigmoid(logit)).float()
+    else:
+        label = (torch.rand((B, 1), generator=g) < 0.25).float()
     return ids.to(idt).to(device), wts.to(device), label.to(device)
 
 
-def embedding_bytes(N, U, D, s=4):
-    """Algorithmic bytes of the embedding path per step."""
+def embedding_bytes(N, U, D, s=4, act_bytes=4):
+    """Algorithmic bytes of the embedding path per step.
+    act_bytes: bytes per element of the looked-up rows written by the gather and of the row gradients
+    read by the apply -- 4 for fp32 (the formulas of SURVEY 8(d)), 2 when the bf16 MLP path has the
+    gather emit bf16 and the apply read bf16 gradients."""
     return {
-        "lookup": N * s + U * D * 4 + N * D * 4,
-        "apply_deep": N * s + N * D * 4 + U * 6 * D * 4,
+        "lookup": N * s + U * D * 4 + N * D * act_bytes,
+        "apply_deep": N * s + N * D * act_bytes + U * 6 * D * 4,
         "wide_lookup": N * (s + 8),
         "apply_wide": N * s + N * 4 + U * 24,
     }

@@ -418,3 +418,38 @@ def test_cpu_tensor_is_refused():
     from mindrec_amd import ops
     with pytest.raises(RuntimeError):
         ops.gather_rows(torch.zeros(4, 4), torch.zeros(2, dtype=torch.int32))
+
+
+@pytest.mark.parametrize("D", [80, 16, 30])
+def test_gather_bf16_out_matches_cast(dev, oracle, D):
+    """bf16-output gather == fp32 gather followed by a round-to-nearest-even cast, bit for bit."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(D)
+    V = 4000
+    table = (rng.standard_normal((V, D)) * 0.01).astype(np.float32)
+    ids = rng.integers(-2, V + 2, size=(50, 13)).astype(np.int32)
+    wts = rng.random((50, 13)).astype(np.float32)
+    tt, ti, tw = T(table, dev), T(ids, dev), T(wts, dev)
+    got = ops.gather_rows(tt, ti, tw, out_dtype=torch.bfloat16)
+    ref = torch.from_numpy(oracle.gather_rows(table, ids, wts)).to(torch.bfloat16)
+    assert got.dtype == torch.bfloat16 and torch.equal(got.cpu().view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("kind", ["uniform", "hot"])
+@pytest.mark.parametrize("D", [80, 30])
+def test_lazy_adam_bf16_gradients_equal_widened_fp32(dev, oracle, kind, D):
+    """Feeding bf16 row gradients gives exactly the result of feeding the same values widened to fp32."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(17 + D)
+    V, n = 20000, 12000
+    ids = ids_case(kind, n, V, rng, np.int32)
+    g16 = torch.from_numpy((rng.standard_normal((n, D)) * 100).astype(np.float32)).to(torch.bfloat16).to(dev)
+    sc = T(rng.random(n).astype(np.float32), dev)
+    res = []
+    for g in (g16, g16.float()):
+        p = T((np.random.default_rng(1).standard_normal((V, D)) * 0.01).astype(np.float32), dev)
+        m = torch.zeros_like(p); v = torch.zeros_like(p)
+        ops.sparse_lazy_adam_(p, m, v, ops.sparse_plan(T(ids, dev)), g, sc, grad_scale=1 / 1024)
+        res.append((p, m, v))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

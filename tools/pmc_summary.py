@@ -21,8 +21,8 @@ def load(d):
 
 def main(fetch_dir, write_dir, out_json=None):
     fe, wr = load(fetch_dir), load(write_dir)
-    names = {"apply_main_adam": "k_apply_main<4, int, UpdAdam>", "gather_rows": "k_gather_rows<4, int>",
-             "apply_main_ftrl": "k_apply_main<1, int, UpdFtrl>", "wide_sum": "k_wide_sum<int>",
+    names = {"apply_main_adam": "k_apply_main<4, int, UpdAdam", "gather_rows": "k_gather_rows<4, int",
+             "apply_main_ftrl": "k_apply_main<1, int, UpdFtrl", "wide_sum": "k_wide_sum<int>",
              "dense_adam4": "k_dense_adam4", "dedup_insert": "k_dedup_insert<int>"}
     res = {}
     print(f"{'kernel':18s} {'launches':>8s} {'read MB (2*FETCH)':>18s} {'write MB':>10s} {'total MB':>10s}")
