@@ -161,6 +161,13 @@ int mrec_sparse_ftrl_f32_i64(float* var, float* accum, float* linear, int64_t V,
 int mrec_dense_adam_f32(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1,
                         float b2, float eps, float b1_pow, float b2_pow, float grad_scale, int nesterov,
                         void* stream);
+/* Same update for the parameters of a mixed-precision MLP: g may be bf16 (g_is_bf16 != 0: the weight
+ * gradient as the bf16 GEMM wrote it; widened on load, exactly), and shadow_bf16 (nullable) receives
+ * the updated parameters rounded to bf16 (round-to-nearest-even) -- the operand copy the next forward
+ * reads, replacing the Cast(weight, float16) of DenseLayer.construct (wide_and_deep.py:123-124). */
+int mrec_dense_adam_ex_f32(float* p, float* m, float* v, const void* g, int g_is_bf16, uint16_t* shadow_bf16,
+                           int64_t n, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
+                           float grad_scale, int nesterov, void* stream);
 int mrec_dense_ftrl_f32(float* var, float* accum, float* linear, const float* g, int64_t n, float lr,
                         float l1, float l2, float lr_power, float grad_scale, void* stream);
 

@@ -61,6 +61,7 @@ _SIGS = {
     "mrec_sparse_ftrl_f32_i64": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
                                  _f32, _f32, _f32, _f32, _f32, _vp, _sz, _vp],
     "mrec_dense_adam_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp],
+    "mrec_dense_adam_ex_f32": [_vp, _vp, _vp, _vp, _int, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp],
     "mrec_dense_ftrl_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp],
     "mrec_map_bytes": [_i64, _szp],
     "mrec_map_create": [C.POINTER(_vp), _vp, _sz, _i64, _vp],

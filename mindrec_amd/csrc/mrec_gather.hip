@@ -98,32 +98,62 @@ __global__ __launch_bounds__(256) void k_gather_rows_generic(const float* __rest
     }
 }
 
+// Wide branch: out[b] = sum_f w[ids[b,f]] * wts[b,f] + bias.  A block takes S whole samples
+// (S*F <= WS_TILE entries): every thread gathers WS_PER entries (coalesced id / weight reads, all the
+// 4-byte random gathers of the tile in flight at once), products go to LDS, then one thread per sample
+// adds its F products in field order -- the same order, multiply and add as the CPU reference, so the
+// result is bit-identical; only the memory-level parallelism changed (one thread per sample left the
+// chip at one wave per CU: 36 us; this form ~3x faster).
+constexpr int WS_PER = 8;
+constexpr int WS_TILE = 256 * WS_PER;
 template <class K>
 __global__ __launch_bounds__(256) void k_wide_sum(const float* __restrict__ w, int64_t V, int64_t ldw,
                                                   const K* __restrict__ ids, const float* __restrict__ wts,
-                                                  int64_t B, int F, const float* __restrict__ bias,
+                                                  int64_t B, int F, int S, const float* __restrict__ bias,
                                                   float* __restrict__ out) {
+    __shared__ float prod[WS_TILE];
+    const int64_t b0 = (int64_t)blockIdx.x * S;
+    const int64_t e0 = b0 * F;
+    const int64_t nb = (B - b0 < S) ? B - b0 : S;       // samples in this block
+    const int ne = (int)(nb * F);                         // entries in this block
+    float x[WS_PER], t[WS_PER];
+#pragma unroll
+    for (int k = 0; k < WS_PER; ++k) {
+        const int j = k * 256 + threadIdx.x;
+        x[k] = 0.0f; t[k] = 0.0f;
+        if (j < ne) {
+            const int64_t r = (int64_t)ids[e0 + j];
+            t[k] = wts[e0 + j];
+            if (r >= 0 && r < V) x[k] = w[r * ldw];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < WS_PER; ++k) {
+        const int j = k * 256 + threadIdx.x;
+        if (j < ne) prod[j] = x[k] * t[k];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nb) {
+        float acc = 0.0f;
+        const float* p = prod + threadIdx.x * F;
+        for (int f = 0; f < F; ++f) acc = acc + p[f];
+        out[b0 + threadIdx.x] = acc + (bias ? *bias : 0.0f);
+    }
+}
+
+// fallback for F > WS_TILE: one thread per sample
+template <class K>
+__global__ __launch_bounds__(256) void k_wide_sum_wideF(const float* __restrict__ w, int64_t V, int64_t ldw,
+                                                        const K* __restrict__ ids, const float* __restrict__ wts,
+                                                        int64_t B, int F, const float* __restrict__ bias,
+                                                        float* __restrict__ out) {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
-    const K* id = ids + b * F;
-    const float* wt = wts + b * F;
     float acc = 0.0f;
-    int f = 0;
-    for (; f + 4 <= F; f += 4) {
-        float x[4], t[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t r = (int64_t)id[f + k];
-            t[k] = wt[f + k];
-            x[k] = (r >= 0 && r < V) ? w[r * ldw] : 0.0f;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc = acc + x[k] * t[k];
-    }
-    for (; f < F; ++f) {
-        const int64_t r = (int64_t)id[f];
+    for (int f = 0; f < F; ++f) {
+        const int64_t r = (int64_t)ids[b * F + f];
         const float x = (r >= 0 && r < V) ? w[r * ldw] : 0.0f;
-        acc = acc + x * wt[f];
+        acc = acc + x * wts[b * F + f];
     }
     out[b] = acc + (bias ? *bias : 0.0f);
 }
@@ -183,19 +213,29 @@ __global__ __launch_bounds__(256) void k_scatter_rows(float* __restrict__ table,
 }
 
 // ---- dense optimizers ------------------------------------------------------------------------
+// Dense Adam over n elements.  GT = float or bf16 gradients (the GEMM that produced a weight gradient
+// in a bf16 MLP writes bf16; widening on load is exact).  SH: also write the updated parameter, rounded
+// to bf16, into a shadow buffer -- the operand copy the next forward's bf16 GEMMs read, so no separate
+// cast pass over the weights is needed.
+__device__ __forceinline__ float g_widen(float x) { return x; }
+__device__ __forceinline__ float g_widen(uint16_t x) { return __uint_as_float(((unsigned)x) << 16); }
+
+template <class GT, bool SH>
 __global__ __launch_bounds__(256) void k_dense_adam(float* __restrict__ p, float* __restrict__ m,
-                                                    float* __restrict__ v, const float* __restrict__ g, int64_t n,
-                                                    AdamH h) {
+                                                    float* __restrict__ v, const GT* __restrict__ g, int64_t n,
+                                                    AdamH h, uint16_t* __restrict__ shadow) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float pp = p[i], mm = m[i], vv = v[i];
-        adam_elem(pp, mm, vv, g[i] * h.gscale, h);
+        adam_elem(pp, mm, vv, g_widen(g[i]) * h.gscale, h);
         p[i] = pp; m[i] = mm; v[i] = vv;
+        if (SH) shadow[i] = f2bf(pp);
     }
 }
 
+template <bool SH>
 __global__ __launch_bounds__(256) void k_dense_adam4(float4* __restrict__ p, float4* __restrict__ m,
                                                      float4* __restrict__ v, const float4* __restrict__ g,
-                                                     int64_t n4, AdamH h) {
+                                                     int64_t n4, AdamH h, uint2* __restrict__ shadow) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 pp = p[i], mm = m[i], vv = v[i];
         const float4 gg = g[i];
@@ -204,6 +244,25 @@ __global__ __launch_bounds__(256) void k_dense_adam4(float4* __restrict__ p, flo
         adam_elem(pp.z, mm.z, vv.z, gg.z * h.gscale, h);
         adam_elem(pp.w, mm.w, vv.w, gg.w * h.gscale, h);
         p[i] = pp; m[i] = mm; v[i] = vv;
+        if (SH) shadow[i] = make_uint2((unsigned)f2bf(pp.x) | ((unsigned)f2bf(pp.y) << 16),
+                                       (unsigned)f2bf(pp.z) | ((unsigned)f2bf(pp.w) << 16));
+    }
+}
+
+template <bool SH>
+__global__ __launch_bounds__(256) void k_dense_adam4_g16(float4* __restrict__ p, float4* __restrict__ m,
+                                                         float4* __restrict__ v, const uint2* __restrict__ g,
+                                                         int64_t n4, AdamH h, uint2* __restrict__ shadow) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pp = p[i], mm = m[i], vv = v[i];
+        const uint2 u = g[i];
+        adam_elem(pp.x, mm.x, vv.x, __uint_as_float(u.x << 16) * h.gscale, h);
+        adam_elem(pp.y, mm.y, vv.y, __uint_as_float(u.x & 0xFFFF0000u) * h.gscale, h);
+        adam_elem(pp.z, mm.z, vv.z, __uint_as_float(u.y << 16) * h.gscale, h);
+        adam_elem(pp.w, mm.w, vv.w, __uint_as_float(u.y & 0xFFFF0000u) * h.gscale, h);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (SH) shadow[i] = make_uint2((unsigned)f2bf(pp.x) | ((unsigned)f2bf(pp.y) << 16),
+                                       (unsigned)f2bf(pp.z) | ((unsigned)f2bf(pp.w) << 16));
     }
 }
 
@@ -273,7 +332,14 @@ int wide_sum_impl(const float* w, int64_t V, int64_t ldw, const K* ids, const fl
     if (B < 0 || F <= 0 || V < 0 || ldw < 1) return MREC_EINVAL;
     if (B == 0) return MREC_OK;
     if (!w || !ids || !wts || !out) return MREC_EINVAL;
-    k_wide_sum<K><<<(unsigned)mrec_cdiv(B, 256), 256, 0, (hipStream_t)stream>>>(w, V, ldw, ids, wts, B, F, bias_dev, out);
+    if (F <= WS_TILE) {
+        int S = WS_TILE / F;
+        if (S > 256) S = 256;
+        k_wide_sum<K><<<(unsigned)mrec_cdiv(B, S), 256, 0, (hipStream_t)stream>>>(w, V, ldw, ids, wts, B, F, S, bias_dev, out);
+    } else {
+        k_wide_sum_wideF<K><<<(unsigned)mrec_cdiv(B, 256), 256, 0, (hipStream_t)stream>>>(w, V, ldw, ids, wts, B, F,
+                                                                                          bias_dev, out);
+    }
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -401,9 +467,9 @@ MREC_API int mrec_scatter_rows_f32(float* table, int64_t ld, int32_t D, const in
     return MREC_OK;
 }
 
-MREC_API int mrec_dense_adam_f32(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1,
-                                 float b2, float eps, float b1_pow, float b2_pow, float grad_scale, int nesterov,
-                                 void* stream) {
+static int dense_adam_launch(float* p, float* m, float* v, const void* g, int g_bf16, uint16_t* shadow, int64_t n,
+                             float lr, float b1, float b2, float eps, float b1_pow, float b2_pow, float grad_scale,
+                             int nesterov, void* stream) {
     if (n < 0) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
     if (!p || !m || !v || !g) return MREC_EINVAL;
@@ -412,16 +478,48 @@ MREC_API int mrec_dense_adam_f32(float* p, float* m, float* v, const float* g, i
     h.b1 = b1; h.b2 = b2; h.omb1 = 1.0f - b1; h.omb2 = 1.0f - b2; h.eps = eps; h.gscale = grad_scale;
     h.nesterov = nesterov;
     hipStream_t st = (hipStream_t)stream;
-    if (al16(p) && al16(m) && al16(v) && al16(g) && n >= 4) {
-        const int64_t n4 = n / 4;
-        k_dense_adam4<<<stream_grid(n4), 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h);
-        const int64_t rem = n - n4 * 4;
-        if (rem) k_dense_adam<<<1, 256, 0, st>>>(p + n4 * 4, m + n4 * 4, v + n4 * 4, g + n4 * 4, rem, h);
-    } else {
-        k_dense_adam<<<stream_grid(n), 256, 0, st>>>(p, m, v, g, n, h);
+    const bool al = al16(p) && al16(m) && al16(v) && ((((uintptr_t)g) & (g_bf16 ? 7 : 15)) == 0) &&
+                    (!shadow || ((((uintptr_t)shadow) & 7) == 0));
+    const int64_t n4 = al ? n / 4 : 0;
+    if (n4 > 0) {
+        const unsigned gr = stream_grid(n4);
+        if (g_bf16) {
+            if (shadow) k_dense_adam4_g16<true><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const uint2*)g, n4, h, (uint2*)shadow);
+            else k_dense_adam4_g16<false><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const uint2*)g, n4, h, nullptr);
+        } else {
+            if (shadow) k_dense_adam4<true><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow);
+            else k_dense_adam4<false><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, nullptr);
+        }
+    }
+    const int64_t done = n4 * 4, rem = n - done;
+    if (rem > 0) {
+        const unsigned gr = stream_grid(rem);
+        uint16_t* sh = shadow ? shadow + done : nullptr;
+        if (g_bf16) {
+            const uint16_t* gg = (const uint16_t*)g + done;
+            if (sh) k_dense_adam<uint16_t, true><<<gr, 256, 0, st>>>(p + done, m + done, v + done, gg, rem, h, sh);
+            else k_dense_adam<uint16_t, false><<<gr, 256, 0, st>>>(p + done, m + done, v + done, gg, rem, h, nullptr);
+        } else {
+            const float* gg = (const float*)g + done;
+            if (sh) k_dense_adam<float, true><<<gr, 256, 0, st>>>(p + done, m + done, v + done, gg, rem, h, sh);
+            else k_dense_adam<float, false><<<gr, 256, 0, st>>>(p + done, m + done, v + done, gg, rem, h, nullptr);
+        }
     }
     MREC_LAUNCH_CHECK();
     return MREC_OK;
+}
+
+MREC_API int mrec_dense_adam_f32(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1,
+                                 float b2, float eps, float b1_pow, float b2_pow, float grad_scale, int nesterov,
+                                 void* stream) {
+    return dense_adam_launch(p, m, v, g, 0, nullptr, n, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale, nesterov, stream);
+}
+
+MREC_API int mrec_dense_adam_ex_f32(float* p, float* m, float* v, const void* g, int g_is_bf16, uint16_t* shadow_bf16,
+                                    int64_t n, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
+                                    float grad_scale, int nesterov, void* stream) {
+    return dense_adam_launch(p, m, v, g, g_is_bf16, shadow_bf16, n, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale, nesterov,
+                             stream);
 }
 
 MREC_API int mrec_dense_ftrl_f32(float* var, float* accum, float* linear, const float* g, int64_t n, float lr,

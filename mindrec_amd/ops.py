@@ -254,12 +254,20 @@ def _flat_same(*ts):
 
 
 def dense_adam_(p, m, v, g, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, beta1_power=0.9, beta2_power=0.999,
-                grad_scale=1.0, use_nesterov=False):
-    """nn.Adam over a whole tensor (wide_and_deep.py:435-437; deep_and_cross.py:342-344)."""
-    _need_cuda(p, m, v, g)
-    n = _flat_same(p, m, v, g)
-    _lib.call("mrec_dense_adam_f32", _ptr(p), _ptr(m), _ptr(v), _ptr(g), n, lr, beta1, beta2, eps, beta1_power,
-              beta2_power, grad_scale, int(use_nesterov), _stream())
+                grad_scale=1.0, use_nesterov=False, shadow_bf16=None):
+    """nn.Adam over a whole tensor (wide_and_deep.py:435-437; deep_and_cross.py:342-344).  g may be
+    bfloat16 (widened on load); shadow_bf16 (optional bf16 tensor of the same size) receives the updated
+    parameters rounded to bf16, ready to be the next forward's GEMM operand."""
+    _need_cuda(p, m, v, g, shadow_bf16)
+    n = _flat_same(p, m, v)
+    if g.numel() != n or not g.is_contiguous() or g.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("dense gradient must be contiguous float32 or bfloat16 of the parameter's size")
+    if shadow_bf16 is not None and (shadow_bf16.dtype != torch.bfloat16 or shadow_bf16.numel() != n
+                                    or not shadow_bf16.is_contiguous()):
+        raise TypeError("shadow_bf16 must be a contiguous bfloat16 tensor of the parameter's size")
+    _lib.call("mrec_dense_adam_ex_f32", _ptr(p), _ptr(m), _ptr(v), _ptr(g), int(g.dtype == torch.bfloat16),
+              _ptr(shadow_bf16), n, lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov),
+              _stream())
 
 
 def dense_ftrl_(var, accum, linear, g, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):

@@ -85,9 +85,9 @@ def enable_tuned_gemms():
         return False
 
 
-def _flat_views(shapes, device):
+def _flat_views(shapes, device, dtype=torch.float32):
     n = sum(int(np.prod(s)) for s in shapes)
-    flat = torch.zeros(n, dtype=torch.float32, device=device)
+    flat = torch.zeros(n, dtype=dtype, device=device)
     views, off = [], 0
     for s in shapes:
         k = int(np.prod(s))
@@ -132,14 +132,26 @@ class WideDeepEngine:
             self.k.fill_normal_(self.wide, cfg.seed + 1, cfg.init_sigma, row0=rank, row_stride=world)
             self.wide_accum.fill_(cfg.ftrl_initial_accum)
             self.wide_linear.zero_()
-            # MLP: fp32 master weights in one flat buffer (views below), same for grads / m / v
+            # MLP: fp32 master weights in one flat buffer, same for grads / m / v.  Flat order: the hidden
+            # layers' weight matrices first (group H: bf16 GEMM operands, bf16 gradients), then the biases
+            # and the fp32 last layer (group S); `self.dense` lists them in layer order W0, b0, W1, b1, ...
             dims = [cfg.field_size * D] + list(cfg.deep_layer_dim) + [1]
-            shapes = []
-            for i in range(len(dims) - 1):
-                shapes += [(dims[i], dims[i + 1]), (dims[i + 1],)]
+            nl = len(dims) - 1
+            shapes_h = [(dims[i], dims[i + 1]) for i in range(nl - 1)]
+            shapes_s = [(dims[i + 1],) for i in range(nl - 1)] + [(dims[nl - 1], dims[nl]), (dims[nl],)]
             self.dims = dims
-            self.dense_flat, self.dense = _flat_views(shapes, dev)
-            self.dense_grad_flat, self.dense_grad = _flat_views(shapes, dev)
+            self.n_h = sum(int(np.prod(x)) for x in shapes_h)
+
+            def interleave(vh, vs):
+                out = []
+                for i in range(nl - 1):
+                    out += [vh[i], vs[i]]
+                return out + [vs[nl - 1], vs[nl]]
+
+            self.dense_flat, views = _flat_views(shapes_h + shapes_s, dev)
+            self.dense = interleave(views[:nl - 1], views[nl - 1:])
+            self.dense_grad_flat, gviews = _flat_views(shapes_h + shapes_s, dev)
+            self.dense_grad = interleave(gviews[:nl - 1], gviews[nl - 1:])
             self.dense_m = torch.zeros_like(self.dense_flat)
             self.dense_v = torch.zeros_like(self.dense_flat)
             # identical on every rank: global row 0.. of a [n,1] "table" keyed by a private seed
@@ -147,6 +159,14 @@ class WideDeepEngine:
             for p, g in zip(self.dense, self.dense_grad):
                 p.requires_grad_(True)
                 p.grad = g
+            self.dense16 = self.grad_h16 = None
+            if self._gpu and cfg.mlp_dtype == "bf16" and cfg.fused_mlp and kernels is None:
+                # bf16 shadow of every dense parameter (kept current by the dense-Adam kernel) and a flat bf16
+                # buffer the weight-gradient GEMMs write into
+                flat16, v16 = _flat_views(shapes_h + shapes_s, dev, torch.bfloat16)
+                flat16.copy_(self.dense_flat.detach())
+                self.dense16_flat, self.dense16 = flat16, interleave(v16[:nl - 1], v16[nl - 1:])
+                self.grad_h16_flat, self.grad_h16 = _flat_views(shapes_h, dev, torch.bfloat16)
             self.wide_b = torch.zeros(1, dtype=torch.float32, device=dev)   # "Wide_b", FTRL side
             self.k.fill_normal_(self.wide_b.view(1, 1), cfg.seed + 3, cfg.init_sigma)
             self.wide_b_accum = torch.full_like(self.wide_b, cfg.ftrl_initial_accum)
@@ -220,14 +240,16 @@ class WideDeepEngine:
         for the sparse apply to widen on load -- the two [B, F*D] fp32<->bf16 cast passes of the
         autograd path disappear, as do autograd's per-parameter cast and accumulate kernels.  Every
         GEMM stays a plain addmm / mm so the shipped TunableOp table applies.  Same math as the
-        autograd path (ReLU mask = activation > 0).
-        Returns (loss, g_emb [B, F*D] bf16, g_wide [B] fp32); dense gradients land in dense_grad."""
+        autograd path (ReLU mask = activation > 0).  Weights and biases are read from their bf16 shadows
+        (no per-step cast kernels); hidden-layer weight gradients stay bf16 in grad_h16 for the dense Adam
+        to widen on load; bias and last-layer gradients are fp32 in dense_grad.
+        Returns (loss, g_emb [B, F*D] bf16, g_wide [B] fp32)."""
         amp, n = self._amp, len(self.dims) - 1
         B = emb.shape[0]
-        Wb = [self.dense[2 * i].to(amp) for i in range(n - 1)]
+        Wb = [self.dense16[2 * i] for i in range(n - 1)]              # bf16 shadows written by the dense Adam
         hs = [emb if emb.dtype == amp else emb.to(amp)]
         for i in range(n - 1):
-            hs.append(torch.addmm(self.dense[2 * i + 1].to(amp), hs[i], Wb[i]).relu_())
+            hs.append(torch.addmm(self.dense16[2 * i + 1], hs[i], Wb[i]).relu_())
         W5, b5 = self.dense[2 * (n - 1)], self.dense[2 * (n - 1) + 1]
         h4 = hs[-1].float()
         logit = torch.addmm(b5, h4, W5) + wide.view(-1, 1)
@@ -238,7 +260,7 @@ class WideDeepEngine:
         dh = torch.ops.aten.threshold_backward(torch.mm(dlogit, W5.t()).to(amp), hs[-1], 0)
         g_emb = None
         for i in range(n - 2, -1, -1):
-            self.dense_grad[2 * i].copy_(torch.mm(hs[i].t(), dh))                  # bf16 GEMM, widened into the flat fp32 grads
+            torch.mm(hs[i].t(), dh, out=self.grad_h16[i])                         # bf16 GEMM straight into the flat bf16 grads
             torch.sum(dh, dim=0, dtype=torch.float32, out=self.dense_grad[2 * i + 1])
             if i > 0:
                 dh = torch.ops.aten.threshold_backward(torch.mm(dh, Wb[i].t()), hs[i], 0)
@@ -293,7 +315,7 @@ class WideDeepEngine:
         return emb, wide, (perm, send_counts, recv_counts, recv_local)
 
     def _fused_bf16(self):
-        return self._gpu and self.cfg.fused_mlp and self._amp == torch.bfloat16 and self.k is ops
+        return self.dense16 is not None
 
     def predict(self, ids, wts):
         with torch.no_grad():
@@ -314,10 +336,12 @@ class WideDeepEngine:
         emb, wide, route = self.lookup(ids, wts)
 
         ev = self._tick("mlp_fwd_bwd")
-        if self._fused_bf16():
+        fused = self._fused_bf16()
+        if fused:
             loss, g_emb, g_wide = self._mlp_step_fused(emb, wide, label)
             if route is not None:
                 g_emb = g_emb.float()          # the routed exchange ships fp32 rows
+                self.dense_grad_flat[: self.n_h].copy_(self.grad_h16_flat)     # all-reduce the dense grads in fp32
         else:
             emb.requires_grad_(True)
             wide.requires_grad_(True)
@@ -384,9 +408,19 @@ class WideDeepEngine:
             self._tock(ev)
 
         ev = self._tick("apply_dense")
-        self.k.dense_adam_(self.dense_flat, self.dense_m, self.dense_v, self.dense_grad_flat, lr=cfg.adam_lr,
-                        beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
-                        beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=inv_sens)
+        akw = dict(lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
+                   beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=inv_sens)
+        flat = self.dense_flat.detach()
+        if fused and route is None:
+            nh = self.n_h       # group H reads the bf16 GEMM outputs, group S fp32; both refresh the bf16 shadow
+            self.k.dense_adam_(flat[:nh], self.dense_m[:nh], self.dense_v[:nh], self.grad_h16_flat,
+                               shadow_bf16=self.dense16_flat[:nh], **akw)
+            self.k.dense_adam_(flat[nh:], self.dense_m[nh:], self.dense_v[nh:], self.dense_grad_flat[nh:],
+                               shadow_bf16=self.dense16_flat[nh:], **akw)
+        elif self.dense16 is not None:
+            self.k.dense_adam_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, shadow_bf16=self.dense16_flat, **akw)
+        else:
+            self.k.dense_adam_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, **akw)
         self.k.dense_ftrl_(self.wide_b, self.wide_b_accum, self.wide_b_linear, gb, lr=cfg.ftrl_lr, l1=cfg.ftrl_l1,
                         l2=cfg.ftrl_l2, grad_scale=inv_sens)
         self._tock(ev)

@@ -166,7 +166,7 @@ def test_gather_strided_table(dev, oracle):
     assert np.array_equal(out, big[ids, :80])
 
 
-@pytest.mark.parametrize("F", [26, 39, 3])
+@pytest.mark.parametrize("F", [26, 39, 3, 1, 300, 2500])
 def test_wide_sum(dev, oracle, F):
     from mindrec_amd import ops
     rng = np.random.default_rng(F)
@@ -453,3 +453,18 @@ def test_lazy_adam_bf16_gradients_equal_widened_fp32(dev, oracle, kind, D):
         res.append((p, m, v))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+def test_dense_adam_bf16_grad_and_shadow(dev, oracle):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(8)
+    for n in (5, 4096, 100003):
+        p = rng.standard_normal(n).astype(np.float32) * 0.01
+        g16 = torch.from_numpy(rng.standard_normal(n).astype(np.float32) * 50).to(torch.bfloat16)
+        m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+        tp, tm, tv = T(p, dev), T(m, dev), T(v, dev)
+        sh = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        ops.dense_adam_(tp, tm, tv, g16.to(dev), grad_scale=1 / 1024, shadow_bf16=sh)
+        oracle.dense_adam(p, m, v, g16.float().numpy(), grad_scale=1 / 1024)
+        assert np.array_equal(tp.cpu().numpy(), p) and np.array_equal(tm.cpu().numpy(), m) and np.array_equal(tv.cpu().numpy(), v)
+        assert torch.equal(sh.cpu().view(torch.int16), torch.from_numpy(p).to(torch.bfloat16).view(torch.int16))
