@@ -68,6 +68,17 @@ int mrec_group_workspace_bytes(int64_t n, size_t* out);
 int mrec_group_by_inverse(const int32_t* inv, int64_t n, int32_t* sorted_pos, int32_t* sorted_seg,
                           int32_t* seg_offsets, void* ws, size_t ws_bytes, void* stream);
 
+/* Unique + inverted index in one call -- what one training step needs from its id tensor (the forward's
+ * Unique, embedding.py:192, and the optimizer-side RowTensor dedup share it).  Same outputs as
+ * mrec_dedup_* followed by mrec_group_by_inverse, one pass and one launch fewer. */
+int mrec_sparse_plan_workspace_bytes(int64_t n, size_t* out);
+int mrec_sparse_plan_i32(const int32_t* ids, int64_t n, int32_t* uniq, int32_t* inv, int64_t* n_uniq_dev,
+                         int32_t* sorted_pos, int32_t* sorted_seg, int32_t* seg_offsets, void* ws,
+                         size_t ws_bytes, void* stream);
+int mrec_sparse_plan_i64(const int64_t* ids, int64_t n, int64_t* uniq, int32_t* inv, int64_t* n_uniq_dev,
+                         int32_t* sorted_pos, int32_t* sorted_seg, int32_t* seg_offsets, void* ws,
+                         size_t ws_bytes, void* stream);
+
 /* ---- ops.Gather / SparseGatherV2 / EmbeddingLookup ----------------------------------------
  * mindspore_rec/ops/embedding.py:150,194; models/deep_and_cross/src/deep_and_cross.py:199;
  * nn.EmbeddingLookup at models/wide_deep/src/wide_and_deep.py:277-290.

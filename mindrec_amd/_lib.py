@@ -39,6 +39,9 @@ _SIGS = {
     "mrec_dedup_i64": [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_group_workspace_bytes": [_i64, _szp],
     "mrec_group_by_inverse": [_vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_sparse_plan_workspace_bytes": [_i64, _szp],
+    "mrec_sparse_plan_i32": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_sparse_plan_i64": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_gather_rows_f32_i32": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_gather_rows_f32_i64": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_gather_rows_bf16_i32": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],

@@ -86,14 +86,11 @@ __global__ __launch_bounds__(DB) void k_dedup_insert(const K* __restrict__ ids, 
         const int i = base + k * DB + threadIdx.x;
         uint32_t s = hsh[k] & mask;
         for (;;) {
-            // plain (cached) load: a slot only moves EMPTY -> position -> smaller position of the SAME
-            // key, so a stale value is still a valid answer (at worst one redundant atomic)
-            int cur = slots[s];
-            if (cur == kEmpty) {
-                const int old = atomicCAS(&slots[s], kEmpty, i);
-                if (old == kEmpty) break;
-                cur = old;
-            }
+            // CAS first, no read-before-claim: tile leaders are mostly distinct keys, so the common case
+            // is an empty slot and one memory operation.  A slot only moves EMPTY -> position -> smaller
+            // position of the SAME key, so the returned value is always a valid position to compare.
+            const int cur = atomicCAS(&slots[s], kEmpty, i);
+            if (cur == kEmpty) break;
             if (ids[cur] == key[k]) {
                 if (cur > i) atomicMin(&slots[s], i);
                 break;
@@ -169,9 +166,13 @@ __global__ __launch_bounds__(DB) void k_dedup_inv(const int* __restrict__ srank,
 
 __global__ void k_set_i64(int64_t* p, int64_t v) { *p = v; }
 
+struct DedupScratch { int* srank; int* sidx; };
+
+// fuse_inv_out != nullptr: skip the inverse kernel and hand back (srank, sidx) so the caller's first
+// radix histogram can produce inv on the fly.
 template <class K>
 int dedup_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_dev, void* ws, size_t ws_bytes,
-               void* stream_v) {
+               void* stream_v, DedupScratch* fuse_inv_out = nullptr) {
     hipStream_t st = (hipStream_t)stream_v;
     if (n < 0 || !n_uniq_dev) return MREC_EINVAL;
     if (n == 0) {
@@ -195,7 +196,8 @@ int dedup_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_d
     k_dedup_insert<K><<<(int)mrec_cdiv(n, IT), DB, 0, st>>>(ids, (int)n, slots, (uint32_t)(cap - 1), sidx);
     k_dedup_count<<<nblk, DB, 0, st>>>(slots, sidx, (int)n, blocksum);
     k_dedup_rank<K><<<nblk, DB, 0, st>>>(ids, slots, sidx, (int)n, blocksum, nblk, uniq, srank, n_uniq_dev);
-    k_dedup_inv<<<g256, DB, 0, st>>>(srank, sidx, (int)n, inv);
+    if (fuse_inv_out) { fuse_inv_out->srank = srank; fuse_inv_out->sidx = sidx; }
+    else k_dedup_inv<<<g256, DB, 0, st>>>(srank, sidx, (int)n, inv);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -246,15 +248,15 @@ MREC_API int mrec_group_workspace_bytes(int64_t n, size_t* out) {
     return MREC_OK;
 }
 
-MREC_API int mrec_group_by_inverse(const int32_t* inv, int64_t n, int32_t* sorted_pos, int32_t* sorted_seg,
-                                   int32_t* seg_offsets, void* ws, size_t ws_bytes, void* stream) {
+static int group_impl(const int32_t* inv, int64_t n, int32_t* sorted_pos, int32_t* sorted_seg, int32_t* seg_offsets,
+                      void* ws, size_t ws_bytes, void* stream, const DedupScratch* fuse, int32_t* inv_out) {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || !seg_offsets) return MREC_EINVAL;
     if (n == 0) {
         MREC_HIP_CHECK(hipMemsetAsync(seg_offsets, 0, sizeof(int32_t), st));
         return MREC_OK;
     }
-    if (!inv || !sorted_pos || !sorted_seg || !ws) return MREC_EINVAL;
+    if ((!inv && !fuse) || !sorted_pos || !sorted_seg || !ws) return MREC_EINVAL;
     if (n > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
     const int nblk = (int)mrec_cdiv(n, RT);
     MrecArena a(ws, ws_bytes);
@@ -268,18 +270,65 @@ MREC_API int mrec_group_by_inverse(const int32_t* inv, int64_t n, int32_t* sorte
     while (((int64_t)1 << bits) < n) ++bits;  // group numbers are < n
     const int passes = (bits + RMAXB - 1) / RMAXB;
     const int pbits = (bits + passes - 1) / passes;
-    const int* kin = inv;
+    const int* kin = fuse ? inv_out : inv;
     const int* vin = nullptr;
     for (int p = 0; p < passes; ++p) {
         const bool to_user = ((passes - 1 - p) % 2) == 0;
         int* kout = to_user ? sorted_seg : tk;
         int* vout = to_user ? sorted_pos : tv;
         const int shift = p * pbits;
-        radix_pass(kin, vin, (int)n, shift, pbits, hist, hscan, totals, nullptr, kout, vout, st);
+        if (p == 0 && fuse)      // pass 0 computes inv = srank[sidx[i]] while it builds its histogram
+            radix_pass(inv_out, vin, (int)n, shift, pbits, hist, hscan, totals, nullptr, kout, vout, st, fuse->srank,
+                       fuse->sidx, inv_out);
+        else
+            radix_pass(kin, vin, (int)n, shift, pbits, hist, hscan, totals, nullptr, kout, vout, st);
         kin = kout;
         vin = vout;
     }
     k_seg_offsets<<<(int)mrec_cdiv(n, 256), 256, 0, st>>>(sorted_seg, (int)n, seg_offsets);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
+}
+
+MREC_API int mrec_group_by_inverse(const int32_t* inv, int64_t n, int32_t* sorted_pos, int32_t* sorted_seg,
+                                   int32_t* seg_offsets, void* ws, size_t ws_bytes, void* stream) {
+    return group_impl(inv, n, sorted_pos, sorted_seg, seg_offsets, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+// Unique + inverted index in one call (what a training step needs): the inverse rides on the first
+// radix histogram, saving a pass and a launch over mrec_dedup_* followed by mrec_group_by_inverse.
+template <class K>
+static int plan_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_dev, int32_t* sorted_pos,
+                     int32_t* sorted_seg, int32_t* seg_offsets, void* ws, size_t ws_bytes, void* stream) {
+    if (n < 0 || !n_uniq_dev || !seg_offsets) return MREC_EINVAL;
+    size_t db = 0, gb = 0;
+    int rc = mrec_dedup_workspace_bytes(n, &db);
+    if (rc != MREC_OK) return rc;
+    rc = mrec_group_workspace_bytes(n, &gb);
+    if (rc != MREC_OK) return rc;
+    if (n > 0 && (!ws || ws_bytes < db + gb)) return MREC_EWORKSPACE;
+    DedupScratch sc{nullptr, nullptr};
+    rc = dedup_impl<K>(ids, n, uniq, inv, n_uniq_dev, ws, db, stream, n > 0 ? &sc : nullptr);
+    if (rc != MREC_OK) return rc;
+    return group_impl(nullptr, n, sorted_pos, sorted_seg, seg_offsets, (char*)ws + db, gb, stream, n > 0 ? &sc : nullptr, inv);
+}
+
+MREC_API int mrec_sparse_plan_workspace_bytes(int64_t n, size_t* out) {
+    size_t db = 0, gb = 0;
+    int rc = mrec_dedup_workspace_bytes(n, &db);
+    if (rc != MREC_OK) return rc;
+    rc = mrec_group_workspace_bytes(n, &gb);
+    if (rc != MREC_OK) return rc;
+    *out = db + gb;
+    return MREC_OK;
+}
+MREC_API int mrec_sparse_plan_i32(const int32_t* ids, int64_t n, int32_t* uniq, int32_t* inv, int64_t* n_uniq_dev,
+                                  int32_t* sorted_pos, int32_t* sorted_seg, int32_t* seg_offsets, void* ws,
+                                  size_t ws_bytes, void* stream) {
+    return plan_impl<int32_t>(ids, n, uniq, inv, n_uniq_dev, sorted_pos, sorted_seg, seg_offsets, ws, ws_bytes, stream);
+}
+MREC_API int mrec_sparse_plan_i64(const int64_t* ids, int64_t n, int64_t* uniq, int32_t* inv, int64_t* n_uniq_dev,
+                                  int32_t* sorted_pos, int32_t* sorted_seg, int32_t* seg_offsets, void* ws,
+                                  size_t ws_bytes, void* stream) {
+    return plan_impl<int64_t>(ids, n, uniq, inv, n_uniq_dev, sorted_pos, sorted_seg, seg_offsets, ws, ws_bytes, stream);
 }

@@ -126,7 +126,23 @@ def group_by_inverse(d):
 
 
 def sparse_plan(ids):
-    return group_by_inverse(unique(ids))
+    """Unique + inverted index of a step's ids in one library call (mrec_sparse_plan_*)."""
+    _need_cuda(ids)
+    sfx = _suffix(ids)
+    flat = ids.reshape(-1).contiguous()
+    n = flat.numel()
+    dev = flat.device
+    uniq = torch.empty(max(n, 1), dtype=flat.dtype, device=dev)
+    inv = torch.empty(max(n, 1), dtype=torch.int32, device=dev)[:n]
+    n_uniq = torch.empty(1, dtype=torch.int64, device=dev)
+    sorted_pos = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    sorted_seg = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    seg_offsets = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    nb = _lib.query_bytes("mrec_sparse_plan_workspace_bytes", n)
+    ws = workspace("plan", nb, dev)
+    _lib.call(f"mrec_sparse_plan_{sfx}", _ptr(flat), n, _ptr(uniq), _ptr(inv), _ptr(n_uniq), _ptr(sorted_pos),
+              _ptr(sorted_seg), _ptr(seg_offsets), _ptr(ws), ws.numel(), _stream())
+    return SparsePlan(Dedup(flat, uniq, inv, n_uniq), sorted_pos, sorted_seg, seg_offsets)
 
 
 def gather_rows(table, ids, row_scale=None, out=None, out_dtype=torch.float32):

@@ -85,7 +85,7 @@ def test_unique_and_group(dev, oracle, dtype, kind, n):
     if dtype == np.int64 and kind == "uniform":
         x = x - 2**39  # negative keys too
     u_ref, inv_ref = oracle.unique(x)
-    plan = ops.sparse_plan(T(x, dev))
+    plan = ops.sparse_plan(T(x, dev)) if n % 2 else ops.group_by_inverse(ops.unique(T(x, dev)))   # fused and two-call forms
     assert plan.U == u_ref.size
     assert np.array_equal(plan.uniq.cpu().numpy(), u_ref)          # first-occurrence order, bit-exact
     assert np.array_equal(plan.inv.cpu().numpy(), inv_ref)
@@ -103,6 +103,8 @@ def test_unique_empty(dev):
     assert d.U == 0
     p = ops.group_by_inverse(d)
     assert int(p.seg_offsets[0].item()) == 0
+    p = ops.sparse_plan(torch.empty(0, dtype=torch.int64, device=dev))
+    assert p.U == 0 and int(p.seg_offsets[0].item()) == 0
 
 
 def test_unique_large_bitexact(dev, oracle):
