@@ -182,6 +182,26 @@ int mrec_dense_adam_ex_f32(float* p, float* m, float* v, const void* g, int g_is
 int mrec_dense_ftrl_f32(float* var, float* accum, float* linear, const float* g, int64_t n, float lr,
                         float l1, float l2, float lr_power, float grad_scale, void* stream);
 
+/* ---- elementwise ends of the dense net (bf16 training step) ---------------------------------
+ * ReLU bprop + BiasAdd bprop of one DenseLayer (wide_and_deep.py:113-133) in one pass:
+ *   dh[b, c] = h[b, c] > 0 ? g[b, c] : 0      db[c] = sum_b dh[b, c]
+ * g, h, dh are [B, N] bf16 (16-byte aligned), db is [N] fp32.  N / 8 must be a power of two <= 256. */
+int mrec_relu_bwd_colsum_workspace_bytes(int64_t B, int32_t N, size_t* out);
+int mrec_relu_bwd_colsum_bf16(const uint16_t* g, const uint16_t* h, int64_t B, int32_t N, uint16_t* dh,
+                              float* db, void* ws, size_t ws_bytes, void* stream);
+/* Output head of Wide&Deep, forward and backward in one pass over the last hidden activations h4
+ * [B, K5] bf16: dense_layer_5 (K5 -> 1, fp32 weights w5[K5], b5), out = wide + deep (:315),
+ * SigmoidCrossEntropyWithLogits + ReduceMean (:352-354), and their bprops seeded with dscale
+ * (= sens / B):   logit[b] = h4[b,:].w5 + b5 + wide[b];  loss = mean_b BCE(logit, label);
+ *   dlogit[b] = (sigmoid(logit[b]) - label[b]) * dscale;   dh4[b,k] = h4[b,k] > 0 ? dlogit[b] * w5[k] : 0;
+ *   dw5[k] = sum_b h4[b,k] * dlogit[b];  db5 = sum_b dlogit[b];  db4[k] = sum_b dh4[b,k].
+ * K5 / 8 must be a power of two <= 64. */
+int mrec_head_workspace_bytes(int64_t B, int32_t K5, size_t* out);
+int mrec_head_fwd_bwd_bf16(const uint16_t* h4, const float* w5, const float* b5, const float* wide,
+                           const float* label, int64_t B, int32_t K5, float dscale, float* logit, float* dlogit,
+                           uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss, void* ws,
+                           size_t ws_bytes, void* stream);
+
 /* ---- MapParameter key index ---------------------------------------------------------------
  * mindspore.experimental.MapParameter as built by HashEmbeddingLookup
  * (mindspore_rec/ops/embedding.py:136-146) and driven by MapTensorGet/Put/Erase

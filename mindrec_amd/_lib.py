@@ -66,6 +66,10 @@ _SIGS = {
     "mrec_dense_adam_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp],
     "mrec_dense_adam_ex_f32": [_vp, _vp, _vp, _vp, _int, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp],
     "mrec_dense_ftrl_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp],
+    "mrec_relu_bwd_colsum_workspace_bytes": [_i64, _i32, _szp],
+    "mrec_relu_bwd_colsum_bf16": [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp],
+    "mrec_head_workspace_bytes": [_i64, _i32, _szp],
+    "mrec_head_fwd_bwd_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_map_bytes": [_i64, _szp],
     "mrec_map_create": [C.POINTER(_vp), _vp, _sz, _i64, _vp],
     "mrec_map_destroy": [_vp],

@@ -1,0 +1,302 @@
+// mrec_mlp.hip -- the elementwise / reduction ends of the Wide&Deep dense net, fused, for gfx950.
+//
+// The GEMMs of DenseLayer (models/wide_deep/src/wide_and_deep.py:113-133) go to hipBLASLt; what is left
+// around them in a bf16 training step is HBM-bound byte work that MindSpore runs as separate
+// primitives (ReLU bprop, BiasAdd bprop = ReduceSum over the batch, the 128 -> 1 output layer,
+// wide + deep add :315, SigmoidCrossEntropyWithLogits + ReduceMean :352-354 and their bprops).
+// Two kernels cover it:
+//
+//  k_relu_bwd_colsum : dh = g * (h > 0)  and  db[c] = sum_b dh[b, c]   in one pass over [B, N] bf16
+//                      (ReLU bprop + BiasAdd bprop; the column sum alone cost ~20 us per layer as a
+//                      generic reduce kernel whatever N was).
+//  k_head_fwd_bwd    : logit = h4 . W5 + b5 + wide;  loss terms;  dlogit = (sigmoid(logit) - y) * scale;
+//                      dh4 = dlogit * W5 masked by h4 > 0;  dW5 += h4 * dlogit;  db5 += dlogit
+//                      -- forward AND backward of the output layer and the loss in one pass over h4.
+//
+// Both reduce over the batch with per-block partials written to a workspace and a second tiny kernel
+// that adds the partials in block order: bitwise reproducible, no float atomics.
+#include "mrec_common.h"
+
+namespace {
+
+__device__ __forceinline__ float bf2f(uint16_t x) { return __uint_as_float(((unsigned)x) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float x) { __bf16 b = (__bf16)x; return __builtin_bit_cast(uint16_t, b); }
+
+struct bf8 { uint4 u; };   // 8 bf16
+
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xFFFF0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xFFFF0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xFFFF0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xFFFF0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    uint4 u;
+    u.x = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
+    u.y = (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
+    u.z = (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
+    u.w = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
+    return u;
+}
+
+constexpr int MB = 256;   // threads per block
+
+// A block walks its stripe of rows; thread t owns column group cg = t % CG (8 adjacent columns) and rows
+// r0 + t / CG + k * RP.  CG = N / 8 must divide 256 (N in {8, 16, ..., 2048} with N/8 a power of two <= 256)
+// -- other widths take the torch path.
+__global__ __launch_bounds__(MB) void k_relu_bwd_colsum(const uint4* __restrict__ g, const uint4* __restrict__ h,
+                                                        int64_t B, int CG, int rows_per_block, uint4* __restrict__ dh,
+                                                        float* __restrict__ partial /*[nblk][N]*/) {
+    __shared__ float red[MB][8];
+    const int cg = threadIdx.x % CG, rl = threadIdx.x / CG, RP = MB / CG;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r_end = (r_begin + rows_per_block < B) ? r_begin + rows_per_block : B;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = r_begin + rl; r < r_end; r += 2 * RP) {
+        // two rows in flight per thread
+        const int64_t ra = r, rb = r + RP;
+        const bool vb = rb < r_end;
+        const uint4 ga = g[ra * CG + cg], ha = h[ra * CG + cg];
+        uint4 gb = make_uint4(0, 0, 0, 0), hb = make_uint4(0, 0, 0, 0);
+        if (vb) { gb = g[rb * CG + cg]; hb = h[rb * CG + cg]; }
+        float fg[8], fh[8], o[8];
+        unpack8(ga, fg); unpack8(ha, fh);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { o[k] = fh[k] > 0.0f ? fg[k] : 0.0f; acc[k] += o[k]; }
+        dh[ra * CG + cg] = pack8(o);
+        if (vb) {
+            unpack8(gb, fg); unpack8(hb, fh);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { o[k] = fh[k] > 0.0f ? fg[k] : 0.0f; acc[k] += o[k]; }
+            dh[rb * CG + cg] = pack8(o);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    if (rl == 0) {   // threads 0..CG-1: add the RP row-lanes of their column group in lane order
+        float s[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] = red[cg][k];
+        for (int q = 1; q < RP; ++q) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += red[q * CG + cg][k];
+        }
+        float* p = partial + (int64_t)blockIdx.x * (CG * 8) + cg * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] = s[k];
+    }
+}
+
+// out[c] = sum over blocks of partial[blk][c] in a fixed order.  A block owns 32 adjacent columns and
+// splits the partial rows over 8 row-groups; every thread keeps 8 independent loads in flight (a single
+// thread walking 512 partials serially paid a memory round trip per partial: 117 us for this "tiny" step).
+__device__ __forceinline__ float finish_column(const float* __restrict__ partial, int nblk, int W, int c,
+                                               float (*sm)[32]) {
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int chunk = (nblk + 7) / 8;
+    const int b0 = ry * chunk, b1 = (b0 + chunk < nblk) ? b0 + chunk : nblk;
+    float s = 0.0f;
+    if (c < W) {
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = partial[(int64_t)(b + k) * W + c];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += t[k];
+        }
+        for (; b < b1; ++b) s += partial[(int64_t)b * W + c];
+    }
+    sm[ry][cx] = s;
+    __syncthreads();
+    float tot = 0.0f;
+    if (ry == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += sm[k][cx];
+    }
+    return tot;   // valid for ry == 0
+}
+
+__global__ __launch_bounds__(MB) void k_colsum_finish(const float* __restrict__ partial, int nblk, int N,
+                                                      float* __restrict__ out) {
+    __shared__ float sm[8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const float tot = finish_column(partial, nblk, N, c, sm);
+    if ((threadIdx.x >> 5) == 0 && c < N) out[c] = tot;
+}
+
+// Output head.  K5 = width of the last hidden layer (multiple of 8, K5/8 a power of two <= 64).
+// partial layout per block: [K5] dW5 partials, [K5] column sums of dh4 (= bias gradient of the last
+// hidden layer), then db5 partial, then loss partial.
+__global__ __launch_bounds__(MB) void k_head_fwd_bwd(const uint4* __restrict__ h4, const float* __restrict__ w5,
+                                                     const float* __restrict__ b5, const float* __restrict__ wide,
+                                                     const float* __restrict__ label, int64_t B, int CG,
+                                                     int rows_per_block, float dscale, float* __restrict__ logit_out,
+                                                     float* __restrict__ dlogit_out, uint4* __restrict__ dh4,
+                                                     float* __restrict__ partial) {
+    __shared__ float red[MB][8];
+    __shared__ float red2[MB][2];
+    const int cg = threadIdx.x % CG, rl = threadIdx.x / CG, RP = MB / CG;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r_end = (r_begin + rows_per_block < B) ? r_begin + rows_per_block : B;
+    float w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = w5[cg * 8 + k];
+    const float bias = *b5;
+    float accw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float accd[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float accb = 0.0f, accl = 0.0f;
+    // all threads of a row-group iterate together (the shuffles below need the CG lanes of a row converged)
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += RP) {
+        const int64_t r = r0 + rl;
+        const bool valid = r < r_end;
+        float fh[8];
+        if (valid) unpack8(h4[r * CG + cg], fh);
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) fh[k] = 0.0f;
+        }
+        float part = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) part += fh[k] * w[k];
+        // reduce over the CG lanes of this row (CG is a power of two <= 64, lanes of a row are adjacent)
+        for (int d = CG >> 1; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        float dl = 0.0f;
+        if (valid) {
+            const float z = part + bias + wide[r];
+            const float y = label[r];
+            // SigmoidCrossEntropyWithLogits: max(z,0) - z*y + log(1 + exp(-|z|))
+            const float loss = fmaxf(z, 0.0f) - z * y + log1pf(expf(-fabsf(z)));
+            const float sg = 1.0f / (1.0f + expf(-z));
+            dl = (sg - y) * dscale;
+            if (cg == 0) {
+                logit_out[r] = z;
+                dlogit_out[r] = dl;
+                accl += loss;
+                accb += dl;
+            }
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                o[k] = fh[k] > 0.0f ? dl * w[k] : 0.0f;      // d h4 through the last layer, masked by its ReLU
+                accw[k] += fh[k] * dl;
+                accd[k] += o[k];
+            }
+            dh4[r * CG + cg] = pack8(o);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = accw[k];
+    red2[threadIdx.x][0] = accb;
+    red2[threadIdx.x][1] = accl;
+    __syncthreads();
+    const int K5 = CG * 8;
+    float* p = partial + (int64_t)blockIdx.x * (2 * K5 + 2);
+    if (rl == 0) {
+        float s[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] = red[cg][k];
+        for (int q = 1; q < RP; ++q) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += red[q * CG + cg][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[cg * 8 + k] = s[k];
+    }
+    if (threadIdx.x == 0) {
+        float sb = 0.0f, sl = 0.0f;
+        for (int q = 0; q < RP; ++q) { sb += red2[q * CG][0]; sl += red2[q * CG][1]; }
+        p[2 * K5] = sb;
+        p[2 * K5 + 1] = sl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = accd[k];
+    __syncthreads();
+    if (rl == 0) {
+        float s[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] = red[cg][k];
+        for (int q = 1; q < RP; ++q) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += red[q * CG + cg][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[K5 + cg * 8 + k] = s[k];
+    }
+}
+
+__global__ __launch_bounds__(MB) void k_head_finish(const float* __restrict__ partial, int nblk, int K5, float inv_B,
+                                                    float* __restrict__ dw5, float* __restrict__ db4,
+                                                    float* __restrict__ db5, float* __restrict__ loss) {
+    __shared__ float sm[8][32];
+    const int W = 2 * K5 + 2;
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const float s = finish_column(partial, nblk, W, c, sm);
+    if ((threadIdx.x >> 5) != 0 || c >= W) return;
+    if (c < K5) dw5[c] = s;
+    else if (c < 2 * K5) db4[c - K5] = s;
+    else if (c == 2 * K5) *db5 = s;
+    else *loss = s * inv_B;
+}
+
+inline bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+inline int pick_blocks(int64_t B, int RP) {
+    int64_t nb = 256;
+    while (nb > 1 && B / nb < 4 * RP) nb >>= 1;   // at least a few passes per block
+    return (int)nb;
+}
+
+}  // namespace
+
+MREC_API int mrec_relu_bwd_colsum_workspace_bytes(int64_t B, int32_t N, size_t* out) {
+    if (!out || B < 0 || N <= 0) return MREC_EINVAL;
+    *out = (size_t)512 * N * sizeof(float) + 256;
+    return MREC_OK;
+}
+
+MREC_API int mrec_relu_bwd_colsum_bf16(const uint16_t* g, const uint16_t* h, int64_t B, int32_t N, uint16_t* dh,
+                                       float* db, void* ws, size_t ws_bytes, void* stream) {
+    if (B <= 0 || N <= 0) return MREC_EINVAL;
+    if (!g || !h || !dh || !db || !ws) return MREC_EINVAL;
+    if (N % 8 || !pow2(N / 8) || N / 8 > MB) return MREC_EUNSUPPORTED;
+    if ((((uintptr_t)g | (uintptr_t)h | (uintptr_t)dh) & 15) != 0) return MREC_EINVAL;
+    const int CG = N / 8, RP = MB / CG;
+    const int nblk = pick_blocks(B, RP);
+    if (ws_bytes < (size_t)nblk * N * sizeof(float)) return MREC_EWORKSPACE;
+    const int rows_per_block = (int)mrec_cdiv(mrec_cdiv(B, nblk), 2 * RP) * 2 * RP;
+    const int nb = (int)mrec_cdiv(B, rows_per_block);
+    hipStream_t st = (hipStream_t)stream;
+    k_relu_bwd_colsum<<<nb, MB, 0, st>>>((const uint4*)g, (const uint4*)h, B, CG, rows_per_block, (uint4*)dh, (float*)ws);
+    k_colsum_finish<<<(unsigned)mrec_cdiv(N, 32), MB, 0, st>>>((const float*)ws, nb, N, db);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+MREC_API int mrec_head_workspace_bytes(int64_t B, int32_t K5, size_t* out) {
+    if (!out || B < 0 || K5 <= 0) return MREC_EINVAL;
+    *out = (size_t)512 * (2 * K5 + 2) * sizeof(float) + 256;
+    return MREC_OK;
+}
+
+MREC_API int mrec_head_fwd_bwd_bf16(const uint16_t* h4, const float* w5, const float* b5, const float* wide,
+                                    const float* label, int64_t B, int32_t K5, float dscale, float* logit,
+                                    float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    if (B <= 0 || K5 <= 0) return MREC_EINVAL;
+    if (!h4 || !w5 || !b5 || !wide || !label || !logit || !dlogit || !dh4 || !dw5 || !db4 || !db5 || !loss || !ws) return MREC_EINVAL;
+    if (K5 % 8 || !pow2(K5 / 8) || K5 / 8 > 64) return MREC_EUNSUPPORTED;
+    if ((((uintptr_t)h4 | (uintptr_t)dh4) & 15) != 0) return MREC_EINVAL;
+    const int CG = K5 / 8, RP = MB / CG;
+    const int nblk = pick_blocks(B, RP);
+    if (ws_bytes < (size_t)nblk * (2 * K5 + 2) * sizeof(float)) return MREC_EWORKSPACE;
+    const int rows_per_block = (int)mrec_cdiv(mrec_cdiv(B, nblk), RP) * RP;
+    const int nb = (int)mrec_cdiv(B, rows_per_block);
+    hipStream_t st = (hipStream_t)stream;
+    k_head_fwd_bwd<<<nb, MB, 0, st>>>((const uint4*)h4, w5, b5, wide, label, B, CG, rows_per_block, dscale, logit, dlogit,
+                                      (uint4*)dh4, (float*)ws);
+    k_head_finish<<<(unsigned)mrec_cdiv(2 * K5 + 2, 32), MB, 0, st>>>((const float*)ws, nb, K5, 1.0f / (float)B, dw5, db4, db5, loss);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}

@@ -493,3 +493,42 @@ class KernelTimer:
         for e in (getattr(self, "_a", None), getattr(self, "_b", None)):
             if e:
                 _lib.lib().mrec_event_destroy(e)
+
+
+# ---- elementwise ends of the bf16 dense net ----------------------------------------------------
+def relu_bwd_colsum_supported(N):
+    return N % 8 == 0 and (N // 8) & (N // 8 - 1) == 0 and N // 8 <= 256
+
+
+def relu_bwd_colsum(g, h, db_out):
+    """dh = g * (h > 0), db_out[:] = dh.sum(0) in one pass (ReLU bprop + BiasAdd bprop).  g, h bf16 [B, N]."""
+    _need_cuda(g, h, db_out)
+    B, N = h.shape
+    g = g.contiguous(); h = h.contiguous()
+    dh = torch.empty_like(h)
+    nb = _lib.query_bytes("mrec_relu_bwd_colsum_workspace_bytes", B, N)
+    ws = workspace("colsum", nb, h.device)
+    _lib.call("mrec_relu_bwd_colsum_bf16", _ptr(g), _ptr(h), B, N, _ptr(dh), _ptr(db_out), _ptr(ws), ws.numel(), _stream())
+    return dh
+
+
+def head_supported(K5):
+    return K5 % 8 == 0 and (K5 // 8) & (K5 // 8 - 1) == 0 and K5 // 8 <= 64
+
+
+def head_fwd_bwd(h4, w5, b5, wide, label, dscale, dw5_out, db4_out, db5_out):
+    """Output layer + wide/deep add + sigmoid cross-entropy, forward and backward, one pass over h4.
+    Returns (loss [1], logit [B], dlogit [B], dh4 [B, K5] bf16)."""
+    _need_cuda(h4, w5, b5, wide, label)
+    B, K5 = h4.shape
+    dev = h4.device
+    logit = torch.empty(B, dtype=torch.float32, device=dev)
+    dlogit = torch.empty(B, dtype=torch.float32, device=dev)
+    dh4 = torch.empty_like(h4)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    nb = _lib.query_bytes("mrec_head_workspace_bytes", B, K5)
+    ws = workspace("head", nb, dev)
+    _lib.call("mrec_head_fwd_bwd_bf16", _ptr(h4.contiguous()), _ptr(w5), _ptr(b5), _ptr(wide.contiguous()),
+              _ptr(label.contiguous()), B, K5, float(dscale), _ptr(logit), _ptr(dlogit), _ptr(dh4), _ptr(dw5_out),
+              _ptr(db4_out), _ptr(db5_out), _ptr(loss), _ptr(ws), ws.numel(), _stream())
+    return loss, logit, dlogit, dh4

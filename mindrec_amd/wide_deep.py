@@ -257,13 +257,22 @@ class WideDeepEngine:
         for i in range(n - 1):
             hs.append(torch.addmm(self.dense16[2 * i + 1], hs[i], Wb[i]).relu_())
         W5, b5 = self.dense[2 * (n - 1)], self.dense[2 * (n - 1) + 1]
-        h4 = hs[-1].float()
-        logit = torch.addmm(b5, h4, W5) + wide.view(-1, 1)
-        loss = F.binary_cross_entropy_with_logits(logit, label)
-        dlogit = (torch.sigmoid(logit) - label) * (self.cfg.sens / B)              # d(sens * mean BCE)/d logit
-        torch.mm(h4.t(), dlogit, out=self.dense_grad[2 * (n - 1)])
-        torch.sum(dlogit, dim=0, out=self.dense_grad[2 * (n - 1) + 1])
-        dh = torch.ops.aten.threshold_backward(torch.mm(dlogit, W5.t()).to(amp), hs[-1], 0)
+        K5 = self.dims[n - 1]
+        if self.k.head_supported(K5):
+            # output layer + wide/deep add + sigmoid cross-entropy, forward AND backward, one pass over h4
+            loss, _, dlogit, dh = self.k.head_fwd_bwd(hs[-1], W5.detach().view(-1), b5.detach(), wide, label.view(-1),
+                                                       self.cfg.sens / B, self.dense_grad[2 * (n - 1)].view(-1),
+                                                       self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1])
+            loss = loss.view(())
+        else:
+            h4 = hs[-1].float()
+            logit = torch.addmm(b5, h4, W5) + wide.view(-1, 1)
+            loss = F.binary_cross_entropy_with_logits(logit, label)
+            dlogit = (torch.sigmoid(logit) - label) * (self.cfg.sens / B)          # d(sens * mean BCE)/d logit
+            torch.mm(h4.t(), dlogit, out=self.dense_grad[2 * (n - 1)])
+            torch.sum(dlogit, dim=0, out=self.dense_grad[2 * (n - 1) + 1])
+            dh = torch.ops.aten.threshold_backward(torch.mm(dlogit, W5.t()).to(amp), hs[-1], 0)
+            torch.sum(dh, dim=0, dtype=torch.float32, out=self.dense_grad[2 * (n - 2) + 1])
         g_emb = None
         for i in range(n - 2, -1, -1):
             # dW = h^T dh has only (K/256)*(N/256) output tiles but a 16384-deep reduction: split the batch
@@ -275,9 +284,14 @@ class WideDeepEngine:
                 torch.sum(part, dim=0, dtype=torch.float32, out=self.dense_grad[2 * i])
             else:
                 self.dense_grad[2 * i].copy_(torch.mm(hs[i].t(), dh))
-            torch.sum(dh, dim=0, dtype=torch.float32, out=self.dense_grad[2 * i + 1])
             if i > 0:
-                dh = torch.ops.aten.threshold_backward(torch.mm(dh, Wb[i].t()), hs[i], 0)
+                # ReLU bprop of layer i-1's activation + its bias gradient (column sum) in one pass
+                gpre = torch.mm(dh, Wb[i].t())
+                if self.k.relu_bwd_colsum_supported(self.dims[i]):
+                    dh = self.k.relu_bwd_colsum(gpre, hs[i], self.dense_grad[2 * (i - 1) + 1])
+                else:
+                    dh = torch.ops.aten.threshold_backward(gpre, hs[i], 0)
+                    torch.sum(dh, dim=0, dtype=torch.float32, out=self.dense_grad[2 * (i - 1) + 1])
             else:
                 g_emb = torch.mm(dh, Wb[0].t())
         return loss, g_emb, dlogit.view(-1)

@@ -236,3 +236,23 @@ def shard_route(ids, n_shards):
     counts = np.empty(n_shards, np.int64)
     lib().mrec_o_shard_route_i64(_p(ids_f), C.c_int64(n), C.c_int32(n_shards), _p(send_local), _p(perm), _p(counts))
     return send_local, perm, counts
+
+
+# ---- elementwise ends of the dense net (numpy restatements; reference: wide_and_deep.py:113-133,315,352-354)
+def relu_bwd_colsum(g, h):
+    """ReLU bprop + BiasAdd bprop: dh = g where h > 0 else 0; db = dh.sum(0) (float64 accumulate)."""
+    g = np.asarray(g, np.float32); h = np.asarray(h, np.float32)
+    dh = np.where(h > 0, g, np.float32(0))
+    return dh, dh.astype(np.float64).sum(axis=0)
+
+
+def head_fwd_bwd(h4, w5, b5, wide, label, dscale):
+    """dense_layer_5 (K5 -> 1) + wide/deep add + SigmoidCrossEntropyWithLogits/ReduceMean, forward and
+    backward.  Returns dict(loss, logit, dlogit, dh4, dw5, db4, db5) in float64 where reduced."""
+    h4 = np.asarray(h4, np.float64); w5 = np.asarray(w5, np.float64).ravel()
+    z = h4 @ w5 + float(b5) + np.asarray(wide, np.float64)
+    y = np.asarray(label, np.float64).ravel()
+    loss = np.maximum(z, 0) - z * y + np.log1p(np.exp(-np.abs(z)))
+    dl = (1.0 / (1.0 + np.exp(-z)) - y) * dscale
+    dh4 = np.where(h4 > 0, dl[:, None] * w5[None, :], 0.0)
+    return dict(loss=loss.mean(), logit=z, dlogit=dl, dh4=dh4, dw5=h4.T @ dl, db4=dh4.sum(axis=0), db5=dl.sum())

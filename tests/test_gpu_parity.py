@@ -470,3 +470,40 @@ def test_dense_adam_bf16_grad_and_shadow(dev, oracle):
         oracle.dense_adam(p, m, v, g16.float().numpy(), grad_scale=1 / 1024)
         assert np.array_equal(tp.cpu().numpy(), p) and np.array_equal(tm.cpu().numpy(), m) and np.array_equal(tv.cpu().numpy(), v)
         assert torch.equal(sh.cpu().view(torch.int16), torch.from_numpy(p).to(torch.bfloat16).view(torch.int16))
+
+
+@pytest.mark.parametrize("B,N", [(16384, 1024), (16384, 256), (1000, 128), (37, 8), (5000, 2048)])
+def test_relu_bwd_colsum(dev, oracle, B, N):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(N + B)
+    g = torch.from_numpy(rng.standard_normal((B, N)).astype(np.float32)).to(torch.bfloat16)
+    h = torch.from_numpy(np.maximum(rng.standard_normal((B, N)), 0).astype(np.float32)).to(torch.bfloat16)
+    db = torch.empty(N, dtype=torch.float32, device=dev)
+    dh = ops.relu_bwd_colsum(g.to(dev), h.to(dev), db)
+    rdh, rdb = oracle.relu_bwd_colsum(g.float().numpy(), h.float().numpy())
+    assert torch.equal(dh.cpu().float(), torch.from_numpy(rdh))                 # masking is exact
+    assert np.allclose(db.cpu().numpy(), rdb, rtol=1e-5, atol=1e-3 * np.sqrt(B) * 6e-3 + 1e-4)
+
+
+@pytest.mark.parametrize("B,K5", [(16384, 128), (1000, 64), (77, 8), (4096, 512)])
+def test_head_fwd_bwd(dev, oracle, B, K5):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(K5 + B)
+    h4 = torch.from_numpy(np.maximum(rng.standard_normal((B, K5)), 0).astype(np.float32)).to(torch.bfloat16)
+    w5 = (rng.standard_normal(K5) * 0.1).astype(np.float32); b5 = np.array([0.05], np.float32)
+    wide = rng.standard_normal(B).astype(np.float32) * 0.3
+    label = (rng.random(B) < 0.3).astype(np.float32)
+    dscale = 1024.0 / B
+    dw5 = torch.empty(K5, device=dev); db4 = torch.empty(K5, device=dev); db5 = torch.empty(1, device=dev)
+    loss, logit, dlogit, dh4 = ops.head_fwd_bwd(h4.to(dev), T(w5, dev), T(b5, dev), T(wide, dev), T(label, dev), dscale,
+                                                dw5, db4, db5)
+    r = oracle.head_fwd_bwd(h4.float().numpy(), w5, b5[0], wide, label, dscale)
+    assert abs(float(loss) - r["loss"]) <= 1e-5 * abs(r["loss"])
+    assert np.allclose(logit.cpu().numpy(), r["logit"], rtol=1e-5, atol=1e-5)
+    assert np.allclose(dlogit.cpu().numpy(), r["dlogit"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(dh4.cpu().float().numpy(), r["dh4"], rtol=1e-2, atol=1e-6)          # bf16 output
+    assert np.array_equal(dh4.cpu().float().numpy() == 0, r["dh4"] == 0)
+    s = np.abs(r["dw5"]).max()
+    assert np.abs(dw5.cpu().numpy() - r["dw5"]).max() <= 1e-4 * s
+    assert np.abs(db4.cpu().numpy() - r["db4"]).max() <= 1e-2 * np.abs(r["db4"]).max()      # sums of bf16-rounded dh4
+    assert abs(float(db5) - r["db5"]) <= 1e-4 * max(abs(r["db5"]), 1e-3)
