@@ -259,6 +259,18 @@ int mrec_cross_layers_bwd_f32(const float* x0, const float* w, const float* b, i
                               int32_t D, const float* dy, float* dx0, float* dw, float* db, void* ws,
                               size_t ws_bytes, void* stream);
 
+/* ---- DeepFM second-order term ----------------------------------------------------------------
+ * models/deepfm/src/deepfm.py:221-228 on the gathered, masked embeddings vx [B, F, D] (fp32):
+ *   fm_out[b] = 0.5 * sum_d ( (sum_f vx[b,f,d])^2 - sum_f vx[b,f,d]^2 ),   colsum[b,d] = sum_f vx[b,f,d]
+ * (colsum is what the backward needs).  Backward: g[b,f,d] += dout[b] * (colsum[b,d] - vx[b,f,d]).  D <= 256. */
+int mrec_fm_fwd_f32(const float* vx, int64_t B, int32_t F, int32_t D, float* fm_out, float* colsum, void* stream);
+int mrec_fm_bwd_f32(const float* vx, const float* colsum, const float* dout, int64_t B, int32_t F, int32_t D,
+                    float* g, void* stream);
+/* table[rows[i], :] += vals[i, :] for distinct rows (rows < 0 skipped): adds a segment-sum into a dense
+ * [V, D] gradient that already holds the L2 term (deepfm.py:252-259). */
+int mrec_scatter_add_rows_f32(float* table, int64_t ld, int32_t D, const int32_t* rows, int64_t n,
+                              const float* vals, void* stream);
+
 /* ---- row-shard routing (hybrid-parallel embedding, README.md:140-144) --------
  * owner(id) = id mod n_shards, local row = id div n_shards.  Stable bucketing of ids by owner so
  * one RCCL all-to-all can ship them: send_local[k] = local row of the k-th id in bucket order,

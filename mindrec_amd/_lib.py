@@ -85,6 +85,9 @@ _SIGS = {
     "mrec_cross_layers_f32": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp],
     "mrec_cross_layers_bwd_workspace_bytes": [_i32, _i64, _i32, _szp],
     "mrec_cross_layers_bwd_f32": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_fm_fwd_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp],
+    "mrec_fm_bwd_f32": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
+    "mrec_scatter_add_rows_f32": [_vp, _i64, _i32, _vp, _i64, _vp, _vp],
     "mrec_shard_route_workspace_bytes": [_i64, _i32, _szp],
     "mrec_shard_route_i32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_shard_route_i64": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp],

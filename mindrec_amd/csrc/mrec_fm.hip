@@ -1,0 +1,114 @@
+// mrec_fm.hip -- DeepFM second-order (FM) term over the gathered, masked embeddings, for gfx950.
+//
+// Reference: DeepFMModel.construct, models/deepfm/src/deepfm.py:221-228
+//     vx = V[ids] * mask;  fm_out = 0.5 * ReduceSum( Square(ReduceSum(vx, 1)) - ReduceSum(Square(vx), 1), 1 )
+// MindSpore runs two Squares, three ReduceSums and a Sub over the [B, F, D] tensor; here one wave64
+// owns a sample, keeps the D column sums in registers while it streams the sample's F rows once, and
+// writes fm_out[b] plus the column sums (the only thing the backward needs besides vx):
+//     d fm / d vx[b, f, d] = sum_f' vx[b, f', d] - vx[b, f, d].
+// HBM-bound: B*F*D*4 bytes read forward; backward reads vx, adds into the MLP's input gradient.
+#include "mrec_common.h"
+
+namespace {
+
+constexpr int FM_MAXC = 4;   // columns per lane: D <= 256
+
+__device__ __forceinline__ float wave_sum_f(float x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_fm_fwd(const float* __restrict__ vx, int64_t B, int F, int D,
+                                                float* __restrict__ fm_out, float* __restrict__ colsum) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += nw) {
+        float s[FM_MAXC], q[FM_MAXC];
+#pragma unroll
+        for (int j = 0; j < FM_MAXC; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
+        const float* row = vx + b * (int64_t)F * D;
+        for (int f = 0; f < F; ++f) {
+#pragma unroll
+            for (int j = 0; j < FM_MAXC; ++j) {
+                const int c = lane + 64 * j;
+                if (c < D) {
+                    const float x = row[(int64_t)f * D + c];
+                    s[j] = s[j] + x;          // ReduceSum(vx, 1), field order
+                    q[j] = q[j] + x * x;      // ReduceSum(Square(vx), 1)
+                }
+            }
+        }
+        float part = 0.0f;
+#pragma unroll
+        for (int j = 0; j < FM_MAXC; ++j) {
+            const int c = lane + 64 * j;
+            if (c < D) {
+                part += s[j] * s[j] - q[j];
+                colsum[b * D + c] = s[j];
+            }
+        }
+        const float tot = wave_sum_f(part);
+        if (lane == 0) fm_out[b] = 0.5f * tot;
+    }
+}
+
+// g[b, f, d] += dout[b] * (colsum[b, d] - vx[b, f, d])
+__global__ __launch_bounds__(256) void k_fm_bwd(const float* __restrict__ vx, const float* __restrict__ colsum,
+                                                const float* __restrict__ dout, int64_t B, int F, int D,
+                                                float* __restrict__ g) {
+    const int64_t total = B * (int64_t)F * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / ((int64_t)F * D);
+        const int d = (int)(i % D);
+        g[i] = g[i] + dout[b] * (colsum[b * D + d] - vx[i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_add_rows(float* __restrict__ table, int64_t ld, int D,
+                                                          const int* __restrict__ rows, int64_t n,
+                                                          const float* __restrict__ vals) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int r = rows[i];
+    if (r < 0) return;
+    for (int c = lane; c < D; c += 64) table[(int64_t)r * ld + c] += vals[i * D + c];
+}
+
+}  // namespace
+
+MREC_API int mrec_fm_fwd_f32(const float* vx, int64_t B, int32_t F, int32_t D, float* fm_out, float* colsum,
+                             void* stream) {
+    if (B < 0 || F <= 0 || D <= 0) return MREC_EINVAL;
+    if (D > 64 * FM_MAXC) return MREC_EUNSUPPORTED;
+    if (B == 0) return MREC_OK;
+    if (!vx || !fm_out || !colsum) return MREC_EINVAL;
+    int64_t blocks = mrec_cdiv(B, 4);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    k_fm_fwd<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(vx, B, F, D, fm_out, colsum);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+MREC_API int mrec_fm_bwd_f32(const float* vx, const float* colsum, const float* dout, int64_t B, int32_t F, int32_t D,
+                             float* g, void* stream) {
+    if (B < 0 || F <= 0 || D <= 0) return MREC_EINVAL;
+    if (B == 0) return MREC_OK;
+    if (!vx || !colsum || !dout || !g) return MREC_EINVAL;
+    int64_t blocks = mrec_cdiv(B * (int64_t)F * D, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    k_fm_bwd<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(vx, colsum, dout, B, F, D, g);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+MREC_API int mrec_scatter_add_rows_f32(float* table, int64_t ld, int32_t D, const int32_t* rows, int64_t n,
+                                       const float* vals, void* stream) {
+    if (n < 0 || D <= 0 || ld < D) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!table || !rows || !vals) return MREC_EINVAL;
+    k_scatter_add_rows<<<(unsigned)mrec_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(table, ld, D, rows, n, vals);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}

@@ -1,0 +1,154 @@
+"""DeepFM training step on the MI355X kernels.
+
+Mirrors models/deepfm/src/deepfm.py of the reference:
+  DeepFMModel.construct      :206-237  linear term  sum_f W_l2[id] * wt,  FM term over vx = V_l2[id] * wt,
+                                       5-layer MLP on vx,  out = linear + fm + deep
+  NetWithLossClass.construct :252-259  mean sigmoid-CE + l2_coef * 0.5 * (sum V_l2^2 + sum W_l2^2)  (whole tables)
+  TrainStepWrap              :263-295  dense Adam(lr 5e-4, eps 5e-8, loss_scale 1024) over ALL parameters
+
+Both tables carry an L2 term over every row, so their gradients are dense: sens * l2_coef * table, plus
+the segment-sum of the row gradients scattered onto the touched rows; Adam then sweeps the whole tables
+(vocab 184 965: 59 MB, trivial next to the batch).  Lookups, the FM term (one pass, mrec_fm.hip), the
+segment-sums and the Adam sweeps are libmrec_hip.so kernels; the MLP GEMMs go to hipBLASLt through torch.
+"""
+import contextlib
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+@dataclass
+class DeepFMConfig:
+    """models/deepfm/default_config.yaml:14-33."""
+    data_vocab_size: int = 184965
+    data_emb_dim: int = 80
+    data_field_size: int = 39
+    batch_size: int = 16000
+    deep_layer_dims: List[int] = field(default_factory=lambda: [1024, 512, 256, 128])
+    l2_coef: float = 8e-5
+    learning_rate: float = 5e-4
+    epsilon: float = 5e-8
+    loss_scale: float = 1024.0
+    seed: int = 1000
+    init_sigma: float = 0.01
+    mlp_dtype: str = "fp32"
+
+
+class _FMTerm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vx, k):
+        fm, cs = k.fm_forward(vx)
+        ctx.k = k
+        ctx.save_for_backward(vx, cs)
+        return fm
+
+    @staticmethod
+    def backward(ctx, dout):
+        vx, cs = ctx.saved_tensors
+        g = torch.zeros_like(vx)
+        ctx.k.fm_backward_(g, vx, cs, dout.contiguous())
+        return g, None
+
+
+class DeepFMEngine:
+    def __init__(self, cfg: DeepFMConfig, device, kernels=None):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.k = kernels if kernels is not None else ops
+        self._gpu = self.device.type == "cuda"
+        if kernels is None and not self._gpu:
+            raise RuntimeError("DeepFMEngine runs on an MI355X (no CPU fallback)")
+        V, D, dev = cfg.data_vocab_size, cfg.data_emb_dim, self.device
+        with (torch.cuda.device(dev) if self._gpu else contextlib.nullcontext()):
+            self.V_l2 = torch.empty((V, D), dtype=torch.float32, device=dev)
+            self.k.fill_normal_(self.V_l2, cfg.seed, cfg.init_sigma)
+            self.W_l2 = torch.empty((V, 1), dtype=torch.float32, device=dev)
+            self.k.fill_normal_(self.W_l2, cfg.seed + 1, cfg.init_sigma)
+            self.state = {n: (torch.zeros_like(t), torch.zeros_like(t)) for n, t in (("V", self.V_l2), ("W", self.W_l2))}
+            dims = [cfg.data_field_size * D] + list(cfg.deep_layer_dims) + [1]
+            self.dims = dims
+            shapes = []
+            for i in range(len(dims) - 1):
+                shapes += [(dims[i], dims[i + 1]), (dims[i + 1],)]
+            n = sum(int(np.prod(s)) for s in shapes)
+            self.dense_flat = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.dense_grad_flat = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.k.fill_normal_(self.dense_flat.view(-1, 1), cfg.seed + 2, cfg.init_sigma)
+            self.dense, off = [], 0
+            for s in shapes:
+                k = int(np.prod(s))
+                p = self.dense_flat[off:off + k].view(s)
+                p.requires_grad_(True)
+                p.grad = self.dense_grad_flat[off:off + k].view(s)
+                self.dense.append(p)
+                off += k
+            self.dense_m = torch.zeros_like(self.dense_flat)
+            self.dense_v = torch.zeros_like(self.dense_flat)
+        self.beta1, self.beta2 = np.float32(0.9), np.float32(0.999)
+        self.beta1_power, self.beta2_power = np.float32(1.0), np.float32(1.0)
+        self._amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[cfg.mlp_dtype]
+
+    def _mlp(self, x):
+        n = len(self.dims) - 1
+        amp = self._amp
+        h = x.to(amp) if amp is not None else x
+        for i in range(n):
+            W, b = self.dense[2 * i], self.dense[2 * i + 1]
+            if amp is not None and i < n - 1:
+                h = torch.addmm(b.to(amp), h, W.to(amp))
+            else:
+                h = torch.addmm(b, h.float(), W)
+            if i < n - 1:
+                h = torch.relu(h)
+        return h.float()
+
+    def _forward(self, ids, wts):
+        cfg = self.cfg
+        B, Fd = ids.shape
+        D = cfg.data_emb_dim
+        vx = self.k.gather_rows(self.V_l2, ids, wts)                     # [B, F, D], mask fused
+        linear = self.k.wide_sum(self.W_l2, ids, wts)                    # [B]
+        return vx, linear
+
+    def predict(self, ids, wts):
+        with torch.no_grad():
+            vx, linear = self._forward(ids, wts)
+            fm, _ = self.k.fm_forward(vx)
+            logit = (linear + fm).view(-1, 1) + self._mlp(vx.view(vx.shape[0], -1))
+        return logit, torch.sigmoid(logit)
+
+    def train_step(self, ids, wts, label):
+        cfg = self.cfg
+        B, Fd = ids.shape
+        D = cfg.data_emb_dim
+        self.beta1_power = np.float32(self.beta1_power * self.beta1)
+        self.beta2_power = np.float32(self.beta2_power * self.beta2)
+        vx, linear = self._forward(ids, wts)
+        vx.requires_grad_(True)
+        linear.requires_grad_(True)
+        self.dense_grad_flat.zero_()
+        fm = _FMTerm.apply(vx, self.k)
+        logit = (linear + fm).view(-1, 1) + self._mlp(vx.view(B, Fd * D))
+        log_loss = F.binary_cross_entropy_with_logits(logit, label)
+        with torch.no_grad():
+            l2 = cfg.l2_coef * 0.5 * ((self.V_l2 * self.V_l2).sum() + (self.W_l2 * self.W_l2).sum())
+        (log_loss * cfg.loss_scale).backward()
+        loss = log_loss.detach() + l2
+        # dense table gradients: sens * l2_coef * table everywhere, plus the segment-sums on the touched rows
+        plan = self.k.sparse_plan(ids)
+        sens = cfg.loss_scale
+        kw = dict(lr=cfg.learning_rate, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.epsilon,
+                  beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=1.0 / sens)
+        for name, table, g, scale in (("V", self.V_l2, vx.grad.view(B * Fd, D), wts),
+                                      ("W", self.W_l2, (linear.grad.view(B, 1) * wts).view(B * Fd, 1), None)):
+            gtab = table * (cfg.l2_coef * sens)
+            sums = self.k.segment_sum(plan, g, scale)
+            self.k.scatter_unique_rows_add_(gtab, plan, sums)
+            m, v = self.state[name]
+            self.k.dense_adam_(table.view(-1), m.view(-1), v.view(-1), gtab.view(-1), **kw)
+        self.k.dense_adam_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, **kw)
+        return loss

@@ -396,6 +396,17 @@ def scatter_unique_rows_(table, plan, vals):
     scatter_rows_(table, rows, vals[:n])
 
 
+def scatter_unique_rows_add_(table, plan, vals):
+    """table[plan.uniq[u], :] += vals[u, :] for u < U (rows are distinct)."""
+    rows = plan.uniq_buf if plan.uniq_buf.dtype == torch.int32 else plan.uniq_buf.to(torch.int32)
+    n = rows.numel()
+    valid = torch.arange(n, device=rows.device) < plan.n_uniq_dev
+    rows = torch.where(valid, rows, torch.full_like(rows, -1))
+    V, D, ld = _table(table)
+    v = vals[:n].reshape(n, D).contiguous()
+    _lib.call("mrec_scatter_add_rows_f32", _ptr(table), ld, D, _ptr(rows), n, _ptr(v), _stream())
+
+
 def scatter_rows_(table, rows, vals):
     """MapTensorPut on the row storage (README.md:188-190)."""
     V, D, ld = _table(table)
@@ -532,3 +543,23 @@ def head_fwd_bwd(h4, w5, b5, wide, label, dscale, dw5_out, db4_out, db5_out):
               _ptr(label.contiguous()), B, K5, float(dscale), _ptr(logit), _ptr(dlogit), _ptr(dh4), _ptr(dw5_out),
               _ptr(db4_out), _ptr(db5_out), _ptr(loss), _ptr(ws), ws.numel(), _stream())
     return loss, logit, dlogit, dh4
+
+
+# ---- DeepFM second-order term ------------------------------------------------------------------
+def fm_forward(vx):
+    """vx [B, F, D] fp32 -> (fm_out [B], colsum [B, D]) (deepfm.py:221-228)."""
+    _need_cuda(vx)
+    B, F_, D = vx.shape
+    vx = vx.contiguous()
+    fm = torch.empty(B, dtype=torch.float32, device=vx.device)
+    cs = torch.empty((B, D), dtype=torch.float32, device=vx.device)
+    _lib.call("mrec_fm_fwd_f32", _ptr(vx), B, F_, D, _ptr(fm), _ptr(cs), _stream())
+    return fm, cs
+
+
+def fm_backward_(g, vx, colsum, dout):
+    """g[b,f,d] += dout[b] * (colsum[b,d] - vx[b,f,d]) in place."""
+    _need_cuda(g, vx, colsum, dout)
+    B, F_, D = vx.shape
+    _lib.call("mrec_fm_bwd_f32", _ptr(vx.contiguous()), _ptr(colsum), _ptr(dout.contiguous()), B, F_, D, _ptr(g), _stream())
+    return g

@@ -256,3 +256,18 @@ def head_fwd_bwd(h4, w5, b5, wide, label, dscale):
     dl = (1.0 / (1.0 + np.exp(-z)) - y) * dscale
     dh4 = np.where(h4 > 0, dl[:, None] * w5[None, :], 0.0)
     return dict(loss=loss.mean(), logit=z, dlogit=dl, dh4=dh4, dw5=h4.T @ dl, db4=dh4.sum(axis=0), db5=dl.sum())
+
+
+def fm_forward(vx):
+    """DeepFM second-order term (deepfm.py:221-228), sequential float32 sums over the field axis."""
+    vx = np.asarray(vx, np.float32)
+    B, F, D = vx.shape
+    s = np.zeros((B, D), np.float32); q = np.zeros((B, D), np.float32)
+    for f in range(F):
+        s = s + vx[:, f, :]
+        q = q + vx[:, f, :] * vx[:, f, :]
+    return (0.5 * (s.astype(np.float64) ** 2 - q).sum(axis=1)), s
+
+
+def fm_backward(vx, colsum, dout):
+    return np.asarray(dout, np.float64)[:, None, None] * (np.asarray(colsum, np.float64)[:, None, :] - np.asarray(vx, np.float64))

@@ -104,3 +104,19 @@ def cross_layers(x0, w, b):
 
 def cross_layers_bwd(x0, w, b, dy):
     return tuple(torch.from_numpy(a) for a in O.cross_layers_bwd(_np(x0), _np(w), _np(b), _np(dy)))
+
+
+def fm_forward(vx):
+    fm, cs = O.fm_forward(_np(vx))
+    return torch.from_numpy(fm.astype(np.float32)), torch.from_numpy(cs)
+
+
+def fm_backward_(g, vx, colsum, dout):
+    _np(g)[...] = _np(g) + O.fm_backward(_np(vx), _np(colsum), _np(dout)).astype(np.float32)
+    return g
+
+
+def scatter_unique_rows_add_(table, plan, vals):
+    u = plan._uniq
+    ok = (u >= 0) & (u < table.shape[0])
+    _np(table)[u[ok]] += _np(vals)[: u.size][ok]

@@ -507,3 +507,19 @@ def test_head_fwd_bwd(dev, oracle, B, K5):
     assert np.abs(dw5.cpu().numpy() - r["dw5"]).max() <= 1e-4 * s
     assert np.abs(db4.cpu().numpy() - r["db4"]).max() <= 1e-2 * np.abs(r["db4"]).max()      # sums of bf16-rounded dh4
     assert abs(float(db5) - r["db5"]) <= 1e-4 * max(abs(r["db5"]), 1e-3)
+
+
+@pytest.mark.parametrize("B,F,D", [(300, 39, 80), (64, 26, 16), (5, 3, 200)])
+def test_fm_term(dev, oracle, B, F, D):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(B + D)
+    vx = rng.standard_normal((B, F, D)).astype(np.float32) * 0.1
+    fm, cs = ops.fm_forward(T(vx, dev))
+    rfm, rcs = oracle.fm_forward(vx)
+    assert np.array_equal(cs.cpu().numpy(), rcs)                          # same sequential field order
+    assert np.allclose(fm.cpu().numpy(), rfm, rtol=1e-5, atol=1e-6)
+    dout = rng.standard_normal(B).astype(np.float32)
+    g0 = rng.standard_normal((B, F, D)).astype(np.float32)
+    g = T(g0, dev)
+    ops.fm_backward_(g, T(vx, dev), cs, T(dout, dev))
+    assert np.allclose(g.cpu().numpy(), g0 + oracle.fm_backward(vx, rcs, dout), rtol=1e-5, atol=1e-6)

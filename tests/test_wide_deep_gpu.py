@@ -129,3 +129,26 @@ def test_fused_mlp_step_matches_autograd(dev):
     # bf16 GEMMs: compare against the gradient scale
     assert np.abs(ge1 - ge2).max() <= 3e-2 * np.abs(ge2).max()
     assert np.abs(gd1 - gd2).max() <= 3e-2 * np.abs(gd2).max()
+
+
+def test_deepfm_engine_matches_oracle_engine(dev, oracle):
+    """DeepFM step (two gathers, FM term, MLP, L2 over both whole tables, dense Adam) vs the oracle-driven engine."""
+    import _oracle_ops
+    from mindrec_amd.deepfm import DeepFMConfig, DeepFMEngine
+    from mindrec_amd.wide_deep import WideDeepConfig, synthetic_batch
+    cfg = DeepFMConfig(data_vocab_size=4000, data_emb_dim=16, data_field_size=39, batch_size=128, deep_layer_dims=[64, 32])
+    g = DeepFMEngine(cfg, dev)
+    c = DeepFMEngine(cfg, "cpu", kernels=_oracle_ops)
+    assert np.array_equal(g.V_l2.cpu().numpy(), c.V_l2.numpy())
+    bcfg = WideDeepConfig(vocab_size=4000, emb_dim=16, field_size=39, batch_size=128)
+    for s in range(3):
+        ids, wts, label = synthetic_batch(bcfg, "cpu", "zipf", seed=40 + s)
+        lc = float(c.train_step(ids, wts, label))
+        lg = float(g.train_step(ids.to(dev), wts.to(dev), label.to(dev)))
+        assert abs(lc - lg) <= 2e-5 * max(abs(lc), 1e-3)
+    assert row_rel(g.V_l2.cpu().numpy(), c.V_l2.numpy()) <= 5e-5
+    assert np.abs(g.W_l2.cpu().numpy() - c.W_l2.numpy()).max() <= 1e-4 * np.abs(c.W_l2.numpy()).max()
+    assert np.allclose(g.dense_flat.detach().cpu().numpy(), c.dense_flat.detach().numpy(), rtol=2e-4, atol=2e-6)
+    logit, prob = g.predict(ids.to(dev), wts.to(dev))
+    lc2, _ = c.predict(ids, wts)
+    assert np.allclose(logit.cpu().numpy(), lc2.numpy(), rtol=1e-3, atol=1e-4)
