@@ -63,6 +63,7 @@ class WideDeepConfig:
     # p, m, v, w, ... as separate (strided) [V, D] / [V, 1] tensors.  False = three separate arrays.
     fused_state: bool = True
     fused_mlp: bool = True               # hand-written fwd/bwd of the mixed-precision MLP (else autograd)
+    overlap_plan: bool = True            # dedup + inverted index on a side HIP stream, under the MLP
 
 
 _TUNED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "tunableop_gfx950.csv")
@@ -175,6 +176,7 @@ class WideDeepEngine:
         self.step_count = 0
         self._amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[cfg.mlp_dtype]
         self.timers = None            # optional dict name -> list[(start_event, stop_event)]
+        self._side = torch.cuda.Stream(device=self.device) if (self._gpu and cfg.overlap_plan) else None
 
     # ---- collectives -------------------------------------------------------------------------
     # RCCL (backend "nccl") takes device tensors directly.  Under a gloo group with device tensors
@@ -361,6 +363,19 @@ class WideDeepEngine:
         self.beta1_power = np.float32(self.beta1_power * self.beta1)
         self.beta2_power = np.float32(self.beta2_power * self.beta2)
 
+        plan_early = None
+        if self._side is not None and self.world == 1:
+            # The step's Unique + inverted index needs only the ids: run it on a side stream so its dozen
+            # small latency-bound kernels hide under the gathers and the MLP instead of sitting on the
+            # critical path in front of the sparse applies.
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                plan_early = self.k.sparse_plan(ids)
+            for t in (plan_early.uniq_buf, plan_early.inv, plan_early.n_uniq_dev, plan_early.sorted_pos,
+                      plan_early.sorted_seg, plan_early.seg_offsets):
+                t.record_stream(main)
+
         emb, wide, route = self.lookup(ids, wts)
 
         ev = self._tick("mlp_fwd_bwd")
@@ -392,7 +407,11 @@ class WideDeepEngine:
 
         if route is None:
             ev = self._tick("plan")
-            plan = self.k.sparse_plan(ids)
+            if plan_early is not None:
+                torch.cuda.current_stream().wait_stream(self._side)
+                plan = plan_early
+            else:
+                plan = self.k.sparse_plan(ids)
             self._tock(ev)
             ev = self._tick("apply_deep")
             self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, lr=cfg.adam_lr,
@@ -447,6 +466,68 @@ class WideDeepEngine:
         self._tock(ev)
         self.last_plan = plan
         return loss.detach()
+
+
+# ---- checkpoint / resume ---------------------------------------------------
+# The reference saves through ModelCheckpoint (train_and_eval.py:96-97) and, for sliced tables, merges
+# the per-rank slices at load time (eval.py:86-107: build_searched_strategy + merge_sliced_parameter).
+# Here every rank saves its own row shard; merge_shards() interleaves them back (owner = id mod n).
+def _engine_state(eng):
+    return {
+        "meta": {"rank": eng.rank, "world": eng.world, "vocab_size": eng.cfg.vocab_size, "emb_dim": eng.cfg.emb_dim,
+                 "field_size": eng.cfg.field_size, "step_count": eng.step_count,
+                 "beta1_power": float(eng.beta1_power), "beta2_power": float(eng.beta2_power)},
+        "tables": {"deep": eng.deep, "deep_m": eng.deep_m, "deep_v": eng.deep_v, "wide": eng.wide,
+                   "wide_accum": eng.wide_accum, "wide_linear": eng.wide_linear},
+        "dense": {"dense": eng.dense_flat.detach(), "dense_m": eng.dense_m, "dense_v": eng.dense_v, "wide_b": eng.wide_b,
+                  "wide_b_accum": eng.wide_b_accum, "wide_b_linear": eng.wide_b_linear},
+    }
+
+
+def save_checkpoint(eng, path):
+    """Writes this rank's shard (tables + optimizer state + dense parameters) to `path` (torch.save)."""
+    st = _engine_state(eng)
+    out = {"meta": st["meta"], "tables": {k: v.detach().cpu().contiguous() for k, v in st["tables"].items()},
+           "dense": {k: v.detach().cpu().contiguous() for k, v in st["dense"].items()}}
+    torch.save(out, path)
+
+
+def load_checkpoint(eng, path):
+    """Restores a shard saved by save_checkpoint into an engine of the same geometry."""
+    ck = torch.load(path, map_location="cpu")
+    m = ck["meta"]
+    for k in ("rank", "world", "vocab_size", "emb_dim", "field_size"):
+        have = {"rank": eng.rank, "world": eng.world}.get(k, getattr(eng.cfg, k, None))
+        if m[k] != have:
+            raise ValueError(f"checkpoint {path}: {k} = {m[k]} but the engine has {have}")
+    st = _engine_state(eng)
+    with torch.no_grad():
+        for grp in ("tables", "dense"):
+            for k, dst in st[grp].items():
+                dst.copy_(ck[grp][k].to(dst.device))
+        if eng.dense16 is not None:
+            eng.dense16_flat.copy_(eng.dense_flat.detach())
+    eng.step_count = m["step_count"]
+    eng.beta1_power, eng.beta2_power = np.float32(m["beta1_power"]), np.float32(m["beta2_power"])
+
+
+def merge_shards(paths):
+    """Interleaves the row shards of all ranks back into whole tables (row id = local * world + rank):
+    the analogue of merge_sliced_parameter (eval.py:101-105).  Returns {name: [V, D] tensor} + the dense part
+    of rank 0 (replicated by data parallelism)."""
+    cks = sorted((torch.load(p, map_location="cpu") for p in paths), key=lambda c: c["meta"]["rank"])
+    world = cks[0]["meta"]["world"]
+    if [c["meta"]["rank"] for c in cks] != list(range(world)):
+        raise ValueError("merge_shards needs exactly one checkpoint per rank")
+    V = cks[0]["meta"]["vocab_size"]
+    out = {}
+    for name, t0 in cks[0]["tables"].items():
+        full = torch.empty((V, t0.shape[1]), dtype=t0.dtype)
+        for c in cks:
+            full[c["meta"]["rank"]::world] = c["tables"][name]
+        out[name] = full
+    out.update(cks[0]["dense"])
+    return out
 
 
 # ---- synthetic Criteo-shaped batches (SURVEY.md 8(d)) ------------------------------------------

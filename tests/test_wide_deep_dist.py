@@ -90,3 +90,33 @@ def test_engine_refuses_cpu_without_kernels():
     from mindrec_amd.wide_deep import WideDeepEngine
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         WideDeepEngine(_cfg(4), "cpu")
+
+
+def test_checkpoint_roundtrip_and_shard_merge(tmp_path):
+    """save -> train on -> load restores the exact state and training continues identically; two rank
+    shards merge back into the single-process tables (eval.py:86-107 analogue)."""
+    import _oracle_ops
+    from mindrec_amd.wide_deep import WideDeepEngine, load_checkpoint, merge_shards, save_checkpoint
+    cfg = _cfg(24)
+    a = WideDeepEngine(cfg, "cpu", kernels=_oracle_ops)
+    for s in range(2):
+        a.train_step(*_batch(cfg, seed=s))
+    save_checkpoint(a, tmp_path / "a.pt")
+    ref = [float(a.train_step(*_batch(cfg, seed=10 + s))) for s in range(2)]
+    b = WideDeepEngine(cfg, "cpu", kernels=_oracle_ops)
+    load_checkpoint(b, tmp_path / "a.pt")
+    got = [float(b.train_step(*_batch(cfg, seed=10 + s))) for s in range(2)]
+    assert got == ref
+    assert torch.equal(a.deep, b.deep) and torch.equal(a.deep_v, b.deep_v) and torch.equal(a.wide_linear, b.wide_linear)
+    assert torch.equal(a.dense_flat, b.dense_flat) and b.step_count == a.step_count
+    # shards of a 2-rank layout interleave back to the full table
+    shards = []
+    for r in range(2):
+        e = WideDeepEngine(cfg, "cpu", rank=r, world=2, kernels=_oracle_ops)
+        save_checkpoint(e, tmp_path / f"r{r}.pt")
+        shards.append(tmp_path / f"r{r}.pt")
+    full = merge_shards(shards)
+    fresh = WideDeepEngine(cfg, "cpu", kernels=_oracle_ops)
+    assert torch.equal(full["deep"], fresh.deep) and torch.equal(full["wide"], fresh.wide)
+    with pytest.raises(ValueError):
+        load_checkpoint(WideDeepEngine(cfg, "cpu", rank=1, world=2, kernels=_oracle_ops), tmp_path / "a.pt")
