@@ -186,6 +186,11 @@ class WideDeepEngine:
 
     def _all_to_all(self, out, inp, out_splits=None, in_splits=None):
         if self._staged():
+            if out.dtype == torch.bfloat16:                 # gloo has no bf16: ship the bytes (row splits unchanged)
+                o8 = torch.empty(out.shape[:-1] + (out.shape[-1] * 2,), dtype=torch.uint8)
+                dist.all_to_all_single(o8, inp.cpu().contiguous().view(torch.uint8), out_splits, in_splits, group=self.group)
+                out.copy_(o8.view(torch.bfloat16))
+                return
             o = torch.empty(out.shape, dtype=out.dtype)
             dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
             out.copy_(o)
@@ -317,6 +322,8 @@ class WideDeepEngine:
             return emb, wide, None
         # --- row-sharded: bucket by owner, exchange ids, gather locally, exchange rows back
         ev = self._tick("route")
+        n = ids.numel()
+        D = cfg.emb_dim
         send_local, perm, counts = self.k.shard_route(ids, self.world)
         send_counts = counts.tolist()                                    # host sync: n_shards ints
         recv_counts_t = torch.empty_like(counts)
@@ -325,24 +332,41 @@ class WideDeepEngine:
         n_recv = int(sum(recv_counts))
         recv_local = torch.empty(n_recv, dtype=ids.dtype, device=self.device)
         self._all_to_all(recv_local, send_local, recv_counts, send_counts)
+        wire16 = self._fused_bf16() and torch.is_grad_enabled() and D % 2 == 0
+        recv_wts = None
+        if wire16:
+            # bf16 on the wire: the per-position weights travel with the ids so the OWNER applies the mask in
+            # fp32 and rounds once to bf16 -- bit-identical to the one-GPU gather -- and rows / row-gradients
+            # cross xGMI at half the bytes.  A row of D bf16 is moved as D/2 fp32 words (pure permutation).
+            send_w = self.k.shard_route_rows(wts.reshape(n, 1), perm, None)
+            recv_wts = torch.empty((n_recv, 1), dtype=torch.float32, device=self.device)
+            self._all_to_all(recv_wts, send_w, recv_counts, send_counts)
+            recv_wts = recv_wts.view(-1)
         self._tock(ev)
         ev = self._tick("gather_deep")
-        rows = self.k.gather_rows(self.deep, recv_local)                    # [n_recv, D]
-        wrows = self.k.gather_rows(self.wide, recv_local)                   # [n_recv, 1]
+        if wire16:
+            rows = self.k.gather_rows(self.deep, recv_local, recv_wts, out_dtype=torch.bfloat16)     # [n_recv, D] bf16
+            wrows = self.k.gather_rows(self.wide, recv_local, recv_wts)                               # [n_recv, 1], masked
+        else:
+            rows = self.k.gather_rows(self.deep, recv_local)                # [n_recv, D]
+            wrows = self.k.gather_rows(self.wide, recv_local)               # [n_recv, 1]
         self._tock(ev)
         ev = self._tick("a2a_rows")
-        n = ids.numel()
-        back = torch.empty((n, cfg.emb_dim), dtype=torch.float32, device=self.device)
+        back = torch.empty((n, D), dtype=rows.dtype, device=self.device)
         wback = torch.empty((n, 1), dtype=torch.float32, device=self.device)
         self._all_to_all(back, rows, send_counts, recv_counts)
         self._all_to_all(wback, wrows, send_counts, recv_counts)
         self._tock(ev)
         ev = self._tick("unroute")
-        emb = self.k.shard_unroute(back, perm, wts.reshape(-1)).view(B, Fd * cfg.emb_dim)
-        wvals = self.k.shard_unroute(wback, perm, wts.reshape(-1)).view(B, Fd)
+        if wire16:
+            emb = self.k.shard_unroute(back.view(torch.float32), perm, None).view(torch.bfloat16).view(B, Fd * D)
+            wvals = self.k.shard_unroute(wback, perm, None).view(B, Fd)
+        else:
+            emb = self.k.shard_unroute(back, perm, wts.reshape(-1)).view(B, Fd * D)
+            wvals = self.k.shard_unroute(wback, perm, wts.reshape(-1)).view(B, Fd)
         wide = wvals.sum(dim=1) + self.wide_b
         self._tock(ev)
-        return emb, wide, (perm, send_counts, recv_counts, recv_local)
+        return emb, wide, (perm, send_counts, recv_counts, recv_local, recv_wts)
 
     def _fused_bf16(self):
         return self.dense16 is not None
@@ -382,8 +406,8 @@ class WideDeepEngine:
         fused = self._fused_bf16()
         if fused:
             loss, g_emb, g_wide = self._mlp_step_fused(emb, wide, label)
-            if route is not None:
-                g_emb = g_emb.float()          # the routed exchange ships fp32 rows
+            if route is not None and route[4] is None:
+                g_emb = g_emb.float()          # fp32 wire format
         else:
             emb.requires_grad_(True)
             wide.requires_grad_(True)
@@ -425,16 +449,28 @@ class WideDeepEngine:
                              l2=cfg.ftrl_l2, grad_scale=inv_sens)
             self._tock(ev)
         else:
-            perm, send_counts, recv_counts, recv_local = route
+            perm, send_counts, recv_counts, recv_local, recv_wts = route
             ev = self._tick("a2a_grads")
-            wflat = wts.reshape(-1)
-            send_g = self.k.shard_route_rows(g_emb.view(B * Fd, D), perm, wflat)
-            gw = (g_wide.view(B, 1) * wts).view(B * Fd, 1)
-            send_gw = self.k.shard_route_rows(gw, perm, None)
             n_recv = recv_local.numel()
-            recv_g = torch.empty((n_recv, D), dtype=torch.float32, device=self.device)
+            if recv_wts is not None:
+                # bf16 wire: raw bf16 row-gradients travel (as D/2 fp32 words); the owner multiplies by the
+                # weights it received in the forward, inside the apply kernel, exactly as on one GPU
+                send_g = self.k.shard_route_rows(g_emb.view(B * Fd, D).view(torch.float32), perm, None)
+                recv_g32 = torch.empty((n_recv, D // 2), dtype=torch.float32, device=self.device)
+                self._all_to_all(recv_g32, send_g, recv_counts, send_counts)
+                recv_g = recv_g32.view(torch.bfloat16)
+                gw = g_wide.view(B, 1).expand(B, Fd).reshape(B * Fd, 1).contiguous()
+                send_gw = self.k.shard_route_rows(gw, perm, None)
+                row_scale = recv_wts
+            else:
+                wflat = wts.reshape(-1)
+                send_g = self.k.shard_route_rows(g_emb.view(B * Fd, D), perm, wflat)
+                gw = (g_wide.view(B, 1) * wts).view(B * Fd, 1)
+                send_gw = self.k.shard_route_rows(gw, perm, None)
+                recv_g = torch.empty((n_recv, D), dtype=torch.float32, device=self.device)
+                self._all_to_all(recv_g, send_g, recv_counts, send_counts)
+                row_scale = None
             recv_gw = torch.empty((n_recv, 1), dtype=torch.float32, device=self.device)
-            self._all_to_all(recv_g, send_g, recv_counts, send_counts)
             self._all_to_all(recv_gw, send_gw, recv_counts, send_counts)
             self._tock(ev)
             ev = self._tick("plan")
@@ -443,13 +479,13 @@ class WideDeepEngine:
             # RowTensor gradients of all ranks are summed at the owner; gradients_mean divides by world
             scale = inv_sens / self.world
             ev = self._tick("apply_deep")
-            self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, recv_g, None, lr=cfg.adam_lr,
+            self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, recv_g, row_scale, lr=cfg.adam_lr,
                                   beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
                                   beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
                                   grad_scale=scale)
             self._tock(ev)
             ev = self._tick("apply_wide")
-            self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, recv_gw, None, lr=cfg.ftrl_lr,
+            self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, recv_gw, row_scale, lr=cfg.ftrl_lr,
                              l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=scale)
             self._tock(ev)
 

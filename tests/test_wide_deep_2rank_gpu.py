@@ -15,13 +15,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _cfg(B, fields=39):
+MLP_DTYPE = "fp32"
+
+
+def _cfg(B, fields=39, mlp_dtype=None):
     from mindrec_amd.wide_deep import WideDeepConfig
     return WideDeepConfig(vocab_size=30_011, emb_dim=80, field_size=fields, batch_size=B, deep_layer_dim=[64, 32],
-                          mlp_dtype="fp32")
+                          mlp_dtype=mlp_dtype or MLP_DTYPE)
 
 
-def _worker(rank, world, port, steps, out_dir):
+def _worker(rank, world, port, steps, out_dir, mlp_dtype="fp32"):
+    global MLP_DTYPE
+    MLP_DTYPE = mlp_dtype
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -46,10 +51,15 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_one_gpu_match_single_process(dev, tmp_path):
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16"])
+def test_two_ranks_one_gpu_match_single_process(dev, tmp_path, mlp_dtype):
+    """fp32: fp32 rows on the wire.  bf16: the production path -- weights travel with the ids, bf16 rows and
+    bf16 row-gradients on the wire, hand-written MLP step."""
+    global MLP_DTYPE
     from mindrec_amd.wide_deep import WideDeepEngine, synthetic_batch
+    MLP_DTYPE = mlp_dtype
     world, steps = 2, 3
-    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), mlp_dtype), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
     eng = WideDeepEngine(_cfg(256), dev)
     losses = []
@@ -63,7 +73,11 @@ def test_two_ranks_one_gpu_match_single_process(dev, tmp_path):
         for k in range(world):
             merged[k::world] = r[k][name]
         scale = np.abs(full).max()
-        assert np.abs(merged - full).max() <= 2e-5 * scale, name
+        # bf16: the two layouts run different GEMM shapes (batch 128 vs 256), so bf16 rounding differs
+        tol = 2e-5 if mlp_dtype == "fp32" else 2e-2
+        assert np.abs(merged - full).max() <= tol * scale, name
+        assert np.array_equal((merged != 0).any(axis=1), (full != 0).any(axis=1)) or name == "wide"   # same rows touched
     assert np.array_equal(r[0]["dense"], r[1]["dense"])
-    assert np.allclose(r[0]["dense"], eng.dense_flat.detach().cpu().numpy(), rtol=1e-4, atol=1e-7)
-    assert np.allclose((r[0]["losses"] + r[1]["losses"]) / 2, losses, rtol=1e-5)
+    rt = 1e-4 if mlp_dtype == "fp32" else 5e-2
+    assert np.allclose(r[0]["dense"], eng.dense_flat.detach().cpu().numpy(), rtol=rt, atol=1e-5 if mlp_dtype == "bf16" else 1e-7)
+    assert np.allclose((r[0]["losses"] + r[1]["losses"]) / 2, losses, rtol=1e-5 if mlp_dtype == "fp32" else 2e-3)
