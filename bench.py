@@ -148,7 +148,7 @@ def main():
     plan = eng.last_plan
     U = plan.U                                  # unique ids of the last step's (local) apply
     n_apply = plan.n
-    bf16_io = eng._fused_bf16() and world == 1        # gather writes / apply reads bf16 rows
+    bf16_io = eng._fused_bf16()                       # gather writes / apply reads bf16 rows (also on the wire)
     by = embedding_bytes(n_apply, U, args.emb_dim, act_bytes=2 if bf16_io else 4)
     kmain = [t.ms() for t in ktimers]
     apply_ms = sum(kmain) / len(kmain)
