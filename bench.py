@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--n-batches", type=int, default=4, help="distinct resident batches cycled through")
     ap.add_argument("--split-state", action="store_true", help="p, m, v as three separate arrays (default: fused rows)")
+    ap.add_argument("--no-overlap-plan", action="store_true", help="run dedup + inverted index on the main stream")
+    ap.add_argument("--overlap-wide", action="store_true", help="also run wide_sum on the side stream (measured slower)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo stages collectives through the host and lets "
                          "several ranks share one GPU (debugging only)")
@@ -114,7 +116,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cfg = WideDeepConfig(vocab_size=args.vocab, emb_dim=args.emb_dim, field_size=args.fields, batch_size=args.batch,
-                         mlp_dtype=args.mlp_dtype, fused_state=not args.split_state)
+                         mlp_dtype=args.mlp_dtype, fused_state=not args.split_state,
+                         overlap_plan=not args.no_overlap_plan, overlap_wide=args.overlap_wide)
     eng = WideDeepEngine(cfg, dev, rank=rank, world=world, group=group)
     batches = [synthetic_batch(cfg, dev, args.dist, seed=1000 + i, rank=rank) for i in range(args.n_batches)]
     torch.cuda.synchronize()

@@ -64,6 +64,7 @@ class WideDeepConfig:
     fused_state: bool = True
     fused_mlp: bool = True               # hand-written fwd/bwd of the mixed-precision MLP (else autograd)
     overlap_plan: bool = True            # dedup + inverted index on a side HIP stream, under the MLP
+    overlap_wide: bool = False           # wide_sum on the side stream beside the deep gather (measured: slightly slower)
 
 
 _TUNED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "tunableop_gfx950.csv")
@@ -317,7 +318,16 @@ class WideDeepEngine:
                 emb = self.k.gather_rows(self.deep, ids, wts).view(B, Fd * cfg.emb_dim)
             self._tock(ev)
             ev = self._tick("wide_sum")
-            wide = self.k.wide_sum(self.wide, ids, wts, self.wide_b)
+            if self._side is not None and self.cfg.overlap_wide and torch.is_grad_enabled():
+                # latency-bound 4-byte gathers: let them run beside the deep gather on the side stream
+                main = torch.cuda.current_stream()
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    wide = self.k.wide_sum(self.wide, ids, wts, self.wide_b)
+                    self._wide_event = self._side.record_event()
+                wide.record_stream(main)
+            else:
+                wide = self.k.wide_sum(self.wide, ids, wts, self.wide_b)
             self._tock(ev)
             return emb, wide, None
         # --- row-sharded: bucket by owner, exchange ids, gather locally, exchange rows back
@@ -387,20 +397,23 @@ class WideDeepEngine:
         self.beta1_power = np.float32(self.beta1_power * self.beta1)
         self.beta2_power = np.float32(self.beta2_power * self.beta2)
 
+        self._wide_event = None
+        emb, wide, route = self.lookup(ids, wts)        # deep gather on the main stream, wide_sum on the side stream
         plan_early = None
         if self._side is not None and self.world == 1:
-            # The step's Unique + inverted index needs only the ids: run it on a side stream so its dozen
-            # small latency-bound kernels hide under the gathers and the MLP instead of sitting on the
+            # The step's Unique + inverted index needs only the ids: queue it on the side stream (behind the
+            # wide_sum) so its dozen small latency-bound kernels hide under the MLP instead of sitting on the
             # critical path in front of the sparse applies.
             main = torch.cuda.current_stream()
-            self._side.wait_stream(main)
+            if self._wide_event is None:
+                self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 plan_early = self.k.sparse_plan(ids)
             for t in (plan_early.uniq_buf, plan_early.inv, plan_early.n_uniq_dev, plan_early.sorted_pos,
                       plan_early.sorted_seg, plan_early.seg_offsets):
                 t.record_stream(main)
-
-        emb, wide, route = self.lookup(ids, wts)
+        if self._wide_event is not None:
+            torch.cuda.current_stream().wait_event(self._wide_event)   # the head needs `wide`; the plan may still run
 
         ev = self._tick("mlp_fwd_bwd")
         fused = self._fused_bf16()
@@ -437,6 +450,8 @@ class WideDeepEngine:
             else:
                 plan = self.k.sparse_plan(ids)
             self._tock(ev)
+            # (Running the wide FTRL apply on the side stream beside the deep apply was tried and rejected:
+            # sharing CUs drops the deep kernel from 5.0 to 4.0 TB/s and the step gets 0.11 ms longer.)
             ev = self._tick("apply_deep")
             self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, lr=cfg.adam_lr,
                                   beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
@@ -444,9 +459,9 @@ class WideDeepEngine:
                                   grad_scale=inv_sens)
             self._tock(ev)
             ev = self._tick("apply_wide")
-            gw = (g_wide.view(B, 1) * wts).view(B * Fd, 1)               # Mul bprop of wide_mul, :304
-            self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, gw, None, lr=cfg.ftrl_lr, l1=cfg.ftrl_l1,
-                             l2=cfg.ftrl_l2, grad_scale=inv_sens)
+            gw = g_wide.view(B, 1).expand(B, Fd).reshape(B * Fd, 1)      # Mul bprop of wide_mul (:304): the mask is
+            self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, gw, wts, lr=cfg.ftrl_lr,   # applied as row_scale
+                                l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=inv_sens)
             self._tock(ev)
         else:
             perm, send_counts, recv_counts, recv_local, recv_wts = route
@@ -500,6 +515,8 @@ class WideDeepEngine:
         self.k.dense_ftrl_(self.wide_b, self.wide_b_accum, self.wide_b_linear, gb, lr=cfg.ftrl_lr, l1=cfg.ftrl_l1,
                         l2=cfg.ftrl_l2, grad_scale=inv_sens)
         self._tock(ev)
+        if self._side is not None and route is None:
+            torch.cuda.current_stream().wait_stream(self._side)
         self.last_plan = plan
         return loss.detach()
 
