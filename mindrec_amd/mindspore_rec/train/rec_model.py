@@ -80,53 +80,42 @@ class RecModel:
                 self._online_train_dataset_sink(train_dataset, list_callback, cb_params, sink_size)
 
     def _online_train_dataset_not_sink(self, train_dataset, callbacks=None, cb_params=None):
-        cb_params.cur_epoch_num = 0
-        cb_params.cur_step_num = 0
-        cb_params.dataset_sink_mode = False
-        run_context = RunContext(cb_params)
-        callbacks.on_train_begin(run_context)
-        for epoch_iter in range(sys.maxsize):
-            cb_params.cur_epoch_num = epoch_iter + 1
-            callbacks.on_train_epoch_begin(run_context)
-            for next_element in train_dataset:
-                cb_params.cur_step_num += 1
-                callbacks.on_train_step_begin(run_context)
-                self._check_network_mode(self._train_network, True)
-                outputs = self._train_network(*next_element)
-                cb_params.net_outputs = outputs
-                callbacks.on_train_step_end(run_context)
-                if run_context.get_stop_requested():
-                    break
-            if hasattr(train_dataset, "reset"):
-                train_dataset.reset()
-            callbacks.on_train_epoch_end(run_context)
-            if run_context.get_stop_requested():
-                break
-        callbacks.on_train_end(run_context)
+        """Feed mode (rec_model.py:192-249): batches go straight to the network; the dataset is reset each epoch."""
+        self._stream_epochs(train_dataset, callbacks, cb_params, sink=False, step_inc=1)
 
     def _online_train_dataset_sink(self, train_dataset, callbacks=None, cb_params=None, sink_size=1):
+        """Sink mode (rec_model.py:251-309): sink_size must be a positive int and, for now, exactly 1."""
         sink_size = Validator.check_positive_int(sink_size)                             # :267
         if sink_size != 1:                                                              # :268-271
             raise ValueError(f"The sink_size parameter only support value of 1 currently, but got: {sink_size}")
-        cb_params.cur_step_num = 0
-        cb_params.dataset_sink_mode = True
-        run_context = RunContext(cb_params)
-        callbacks.on_train_begin(run_context)
         train_dataset.__model_hash__ = hash(self)            # sink mode binds the dataset to this model
-        for epoch_iter in range(sys.maxsize):
-            cb_params.cur_epoch_num = epoch_iter + 1
-            callbacks.on_train_epoch_begin(run_context)
-            cb_params.train_network = self._train_network
-            for inputs in train_dataset:
-                cb_params.cur_step_num += sink_size
-                callbacks.on_train_step_begin(run_context)
-                train_network = self._check_network_mode(self._train_network, True)
-                outputs = train_network(*inputs)
-                cb_params.net_outputs = outputs
-                callbacks.on_train_step_end(run_context)
-                if run_context.get_stop_requested():
+        self._stream_epochs(train_dataset, callbacks, cb_params, sink=True, step_inc=sink_size)
+
+    def _stream_epochs(self, dataset, cbs, p, sink, step_inc):
+        """The unbounded epoch/step loop both modes share.  Callback order and counter updates follow the
+        reference: train_begin; per epoch: epoch_begin, per batch (cur_step_num += step_inc; step_begin; run;
+        net_outputs; step_end), [feed mode: dataset.reset()], epoch_end; train_end."""
+        p.cur_epoch_num = 0 if not sink else p.get("cur_epoch_num", 0)
+        p.cur_step_num = 0
+        p.dataset_sink_mode = sink
+        ctx = RunContext(p)
+        cbs.on_train_begin(ctx)
+        epoch = 0
+        while epoch < sys.maxsize and not ctx.get_stop_requested():
+            epoch += 1
+            p.cur_epoch_num = epoch
+            cbs.on_train_epoch_begin(ctx)
+            if sink:
+                p.train_network = self._train_network
+            for batch in dataset:
+                p.cur_step_num += step_inc
+                cbs.on_train_step_begin(ctx)
+                net = self._check_network_mode(self._train_network, True)
+                p.net_outputs = net(*batch)
+                cbs.on_train_step_end(ctx)
+                if ctx.get_stop_requested():
                     break
-            callbacks.on_train_epoch_end(run_context)
-            if run_context.get_stop_requested():
-                break
-        callbacks.on_train_end(run_context)
+            if not sink and hasattr(dataset, "reset"):
+                dataset.reset()
+            cbs.on_train_epoch_end(ctx)
+        cbs.on_train_end(ctx)
