@@ -1,0 +1,49 @@
+"""The host-DRAM feature-cache tier is transparent: a table driven through a small device cache (with
+evictions, write-backs, re-fetches and first-touch initialisation) ends bit-identical to a fully
+device-resident table, and every lookup along the way returns the same rows."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dist_kind", ["uniform", "zipf"])
+def test_cache_tier_is_transparent(dev, dist_kind):
+    from mindrec_amd import ops
+    from mindrec_amd.feature_cache import HostBackedTable
+    V, D, C, B, F = 6000, 16, 900, 64, 13
+    rng = np.random.default_rng(0)
+    full = torch.zeros((V, 3 * D), device=dev)
+    fp, fm, fv = full[:, :D], full[:, D:2 * D], full[:, 2 * D:]
+    ops.fill_normal_(fp, 1000, 0.01)
+    hb = HostBackedTable(V, D, C, dev, seed=1000, sigma=0.01)
+    b1p = b2p = 1.0
+    for step in range(25):
+        if dist_kind == "uniform":
+            ids = rng.integers(0, V, size=(B, F))
+        else:
+            ids = np.minimum(rng.zipf(1.2, size=(B, F)) - 1 + (step % 5) * 400, V - 1)
+        tid = torch.from_numpy(ids.astype(np.int64)).to(dev)
+        wts = torch.from_numpy(rng.random((B, F)).astype(np.float32)).to(dev)
+        g = torch.from_numpy(rng.standard_normal((B * F, D)).astype(np.float32)).to(dev)
+        b1p *= 0.9; b2p *= 0.999
+        # fully resident
+        plan_f = ops.sparse_plan(tid)
+        emb_f = ops.gather_rows(fp, tid, wts)
+        ops.sparse_lazy_adam_(fp, fm, fv, plan_f, g, wts, beta1_power=b1p, beta2_power=b2p)
+        # through the cache tier
+        plan_c, rows_pos = hb.prepare(tid)
+        emb_c = hb.gather(rows_pos, wts.reshape(-1)).view(B, F, D)
+        assert torch.equal(emb_c, emb_f), step
+        ops.sparse_lazy_adam_(hb.p, hb.slots[0], hb.slots[1], plan_c, g, wts, beta1_power=b1p, beta2_power=b2p)
+    assert hb.stats["evictions"] > 0 and hb.stats["first_touch"] > C       # the cache really cycled
+    assert torch.equal(hb.full_table(), full.cpu())                          # weights AND both Adam moments
+    assert hb.stats["hits"] > 0 and hb.stats["hits"] + hb.stats["misses"] > 0
+
+
+def test_cache_too_small_is_reported(dev):
+    from mindrec_amd.feature_cache import HostBackedTable
+    hb = HostBackedTable(1000, 8, 16, dev)
+    with pytest.raises(RuntimeError, match="unique ids"):
+        hb.prepare(torch.arange(0, 100, dtype=torch.int64, device=dev))
