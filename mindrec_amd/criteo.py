@@ -1,0 +1,110 @@
+"""Criteo TSV -> (ids, wts, label) batches: the id / weight encoding that defines the engine's input
+contract.
+
+Reference: datasets/criteo_1tb/process_data.py -- `StatsDict` (:43-163) and the record writer (:203-283):
+  * 13 integer columns: id = column index 0..12, weight = value / column max; missing -> weight 0   (:138-147)
+  * 26 categorical columns: id from a dictionary built over the data, keeping categories seen MORE than
+    CAT_COUNT_THRESHOLD = 6 times (:120-123); anything else maps to the column's OOV id 13 + column   (:149-162);
+    weight 1.0
+  * dictionary ids start after the 13 + 26 reserved ones, assigned column by column (:120-123)
+  * output dtypes int32 / float32 / float32 (:204-206); the reference packs 1000 samples per MindRecord row,
+    here batches are yielded directly.
+This is host-side data plumbing (numpy), not a kernel; it exists so real Criteo data can be fed to the
+engine with the reference's encoding.
+"""
+import collections
+
+import numpy as np
+
+NUM_INTEGER_COLUMNS = 13
+NUM_CATEGORICAL_COLUMNS = 26
+CAT_COUNT_THRESHOLD = 6
+
+
+def _parse_line(line):
+    parts = line.rstrip("\n").split("\t")
+    if len(parts) != 1 + NUM_INTEGER_COLUMNS + NUM_CATEGORICAL_COLUMNS:
+        raise ValueError(f"expected 40 tab-separated fields, got {len(parts)}")
+    return parts[0], parts[1:1 + NUM_INTEGER_COLUMNS], parts[1 + NUM_INTEGER_COLUMNS:]
+
+
+class StatsDict:
+    """Column statistics and the category -> id dictionary (process_data.py:43-131)."""
+
+    def __init__(self, dense_dim=NUM_INTEGER_COLUMNS, slot_dim=NUM_CATEGORICAL_COLUMNS, threshold=CAT_COUNT_THRESHOLD):
+        self.dense_dim, self.slot_dim, self.threshold = dense_dim, slot_dim, threshold
+        self.field_size = dense_dim + slot_dim
+        self.val_max = np.zeros(dense_dim, np.float64)
+        self.val_min = np.zeros(dense_dim, np.float64)
+        self.cat_counts = [collections.Counter() for _ in range(slot_dim)]
+        self.cat2id = None
+
+    def update(self, lines):
+        """First pass over (a chunk of) the data: min / max of the integer columns, category counts."""
+        for line in lines:
+            _, vals, cats = _parse_line(line)
+            for i, v in enumerate(vals):
+                if v != "":
+                    x = float(v)
+                    self.val_max[i] = max(self.val_max[i], x)
+                    self.val_min[i] = min(self.val_min[i], x)
+            for j, c in enumerate(cats):
+                self.cat_counts[j][c] += 1
+
+    def finalize(self):
+        """Builds the dictionary: ids 0..12 dense columns, 13..38 per-column OOV, then one id per category
+        seen more than `threshold` times, column by column in first-seen order."""
+        self.cat2id = [dict() for _ in range(self.slot_dim)]
+        nxt = self.field_size
+        for j in range(self.slot_dim):
+            for cat, cnt in self.cat_counts[j].items():
+                if cnt > self.threshold:
+                    self.cat2id[j][cat] = nxt
+                    nxt += 1
+        self.vocab_size = nxt
+        return self
+
+    def encode(self, lines):
+        """Second pass: lines -> (ids int32 [n, 39], wts float32 [n, 39], label float32 [n, 1])."""
+        if self.cat2id is None:
+            raise RuntimeError("call finalize() before encode()")
+        n = len(lines)
+        ids = np.empty((n, self.field_size), np.int32)
+        wts = np.empty((n, self.field_size), np.float32)
+        label = np.empty((n, 1), np.float32)
+        ids[:, : self.dense_dim] = np.arange(self.dense_dim, dtype=np.int32)
+        vmax = np.where(self.val_max != 0, self.val_max, 1.0)
+        for r, line in enumerate(lines):
+            lab, vals, cats = _parse_line(line)
+            label[r, 0] = float(lab)
+            for i, v in enumerate(vals):
+                wts[r, i] = 0.0 if v == "" else float(v) / vmax[i]
+            for j, c in enumerate(cats):
+                ids[r, self.dense_dim + j] = self.cat2id[j].get(c, self.dense_dim + j)
+                wts[r, self.dense_dim + j] = 1.0
+        return ids, wts, label
+
+
+class CriteoDataset:
+    """Iterable of (ids, wts, label) batches over TSV lines, usable by RecModel.online_train:
+    `get_dataset_size()`, `reset()`, optional `to_device` hook (e.g. lambda t: torch.from_numpy(t).cuda())."""
+
+    def __init__(self, lines, stats, batch_size, drop_remainder=True, to_device=None):
+        self.lines, self.stats, self.batch_size = list(lines), stats, int(batch_size)
+        self.drop_remainder, self.to_device = drop_remainder, to_device
+
+    def get_dataset_size(self):
+        n = len(self.lines)
+        return n // self.batch_size if self.drop_remainder else -(-n // self.batch_size)
+
+    def reset(self):
+        pass
+
+    def __iter__(self):
+        B = self.batch_size
+        for s in range(0, len(self.lines), B):
+            chunk = self.lines[s:s + B]
+            if len(chunk) < B and self.drop_remainder:
+                return
+            out = self.stats.encode(chunk)
+            yield tuple(self.to_device(a) for a in out) if self.to_device else out

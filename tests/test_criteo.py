@@ -1,0 +1,63 @@
+"""The Criteo encoder against a line-by-line restatement of the reference's map_cat2id
+(datasets/criteo_1tb/process_data.py:132-163) on a synthetic TSV."""
+import numpy as np
+
+from mindrec_amd.criteo import CAT_COUNT_THRESHOLD, CriteoDataset, StatsDict
+
+
+def _tsv(n, seed=0):
+    rng = np.random.default_rng(seed)
+    lines = []
+    for _ in range(n):
+        dense = ["" if rng.random() < 0.1 else str(int(rng.integers(0, 50))) for _ in range(13)]
+        cats = ["%08x" % int(rng.zipf(1.5)) if rng.random() > 0.05 else "" for _ in range(26)]
+        lines.append("\t".join([str(int(rng.random() < 0.25))] + dense + cats))
+    return lines
+
+
+def _restate(lines, stats):
+    """map_cat2id semantics written as the reference writes them: one value at a time."""
+    ids, wts = [], []
+    for line in lines:
+        parts = line.split("\t")
+        vals, cats = parts[1:14], parts[14:]
+        row_i, row_w = [], []
+        for i, v in enumerate(vals):
+            if v == "":
+                row_i.append(i); row_w.append(0.0)
+            else:
+                row_i.append(i); row_w.append(float(v) / float(stats.val_max[i] or 1.0))
+        for j, c in enumerate(cats):
+            row_i.append(stats.cat2id[j][c] if c in stats.cat2id[j] else 13 + j)
+            row_w.append(1.0)
+        ids.append(row_i); wts.append(row_w)
+    return np.array(ids, np.int32), np.array(wts, np.float32)
+
+
+def test_encoder_matches_restatement_and_contract():
+    lines = _tsv(600)
+    st = StatsDict()
+    st.update(lines[:300]); st.update(lines[300:])          # chunked first pass
+    st.finalize()
+    ids, wts, label = st.encode(lines)
+    rid, rw = _restate(lines, st)
+    assert ids.dtype == np.int32 and wts.dtype == np.float32 and label.dtype == np.float32      # process_data.py:204-206
+    assert ids.shape == (600, 39) and label.shape == (600, 1)
+    assert np.array_equal(ids, rid) and np.array_equal(wts, rw)
+    assert (ids[:, :13] == np.arange(13)).all() and (wts[:, 13:] == 1.0).all() and wts[:, :13].max() <= 1.0
+    # vocabulary: only categories seen more than the threshold get their own id; the rest are per-column OOV
+    for j in range(26):
+        for cat, cnt in st.cat_counts[j].items():
+            assert (cat in st.cat2id[j]) == (cnt > CAT_COUNT_THRESHOLD)
+    assert ids.max() < st.vocab_size and len({v for d in st.cat2id for v in d.values()}) == st.vocab_size - 39
+    unseen = st.encode(["0\t" + "\t".join(["7"] * 13) + "\t" + "\t".join(["zzzzzzzz"] * 26)])[0]
+    assert (unseen[0, 13:] == 13 + np.arange(26)).all()
+
+
+def test_dataset_batches():
+    lines = _tsv(250, seed=3)
+    st = StatsDict(); st.update(lines); st.finalize()
+    ds = CriteoDataset(lines, st, batch_size=100)
+    batches = list(ds)
+    assert ds.get_dataset_size() == 2 and len(batches) == 2 and batches[0][0].shape == (100, 39)
+    assert len(list(CriteoDataset(lines, st, 100, drop_remainder=False))) == 3
