@@ -28,58 +28,176 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
-template <int NPL>
-__global__ __launch_bounds__(256) void k_cross_fwd(const float* __restrict__ x0, const float* __restrict__ w,
-                                                   const float* __restrict__ b, int L, int64_t B, int D,
-                                                   float* __restrict__ out) {
+// One activation row as a buffer resource of D*4 bytes (0 bytes = a row that does not exist): the hardware
+// range check returns 0 for the padded columns c >= D and drops stores to them, so the row loops carry no
+// guards, and every access is base + lane*4 + an immediate (one address register, not one per load).
+// The descriptor must be provably wave-uniform, hence the readfirstlane of the row pointer.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* p, int bytes) {
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+// voff = the lane's byte offset (one VGPR for the whole row), soff = the wave-uniform part (scalar operand)
+__device__ __forceinline__ float row_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t r, int voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
+// w and b of all layers ([L, D] each) are staged once per block in LDS, each layer padded with zeros to
+// DP = 64 * NPL columns (2*L*DP*4 bytes: 60 KB for the reference's L = 6, D = 1170).  Two reasons:
+// re-reading them from L2 for every row made the kernel L2-bound at 9 % of the HBM roofline (56 KB of
+// weights per 9 KB row), and with the padding the inner loops need no `c < D` guards -- a guard per LDS
+// read compiled to a branch per read and serialised the reads (~1100 branches in the backward kernel).
+// WLDS = false reads w / b from global memory through a per-layer buffer resource (also guard-free) for stacks
+// too large for LDS.
+template <bool WLDS>
+__device__ __forceinline__ float wload(const float* __restrict__ g, const float* s, int l, int lane, int j, int D, int DP) {
+    if (WLDS) return s[l * DP + lane + 64 * j];
+    return row_load(row_rsrc(g + (int64_t)l * D, D * 4), lane * 4, j * 256);
+}
+
+template <int NT, int DP, bool WITH_B = true>
+__device__ __forceinline__ void stage_wb(const float* __restrict__ w, const float* __restrict__ b, int L, int D,
+                                         float* sw, float* sb) {
+    const int total = L * DP;
+    for (int base = 0; base < total; base += NT * 4) {
+        float tw[4], tb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * NT + (int)threadIdx.x;
+            const int l = i / DP, cc = i - l * DP;
+            const bool ok = i < total && cc < D;
+            const int src = ok ? l * D + cc : 0;
+            const float a = w[src], bb = WITH_B ? b[src] : 0.0f;
+            tw[u] = ok ? a : 0.0f;
+            tb[u] = ok ? bb : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * NT + (int)threadIdx.x;
+            if (i < total) {
+                sw[i] = tw[u];
+                if (WITH_B) sb[i] = tb[u];
+            }
+        }
+    }
+    __syncthreads();
+}
+
+constexpr int FWD_NT = 1024;   // 16 waves: one block per CU, w / b staged once per CU
+constexpr int BWD_NT = 256;
+
+template <int NPL, bool WLDS>
+__global__ __launch_bounds__(FWD_NT) void k_cross_fwd(const float* __restrict__ x0, const float* __restrict__ w,
+                                                      const float* __restrict__ b, int L, int64_t B, int D,
+                                                      float* __restrict__ out) {
+    constexpr int DP = NPL * 64;
+    extern __shared__ float smem[];
+    float* sw = smem;
+    float* sb = smem + (WLDS ? L * DP : 0);
+    if (WLDS) stage_wb<FWD_NT, DP>(w, b, L, D, sw, sb);
     const int lane = threadIdx.x & 63;
-    const int64_t nw = (int64_t)gridDim.x * 4;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < B; row += nw) {
-        float x[NPL], xl[NPL];
+    const int voff = lane * 4;
+    constexpr int WPB = FWD_NT / 64;
+    const int64_t nw = (int64_t)gridDim.x * WPB;
+    // two rows per wave per iteration: one LDS read of w / b serves both
+    for (int64_t rowA = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); rowA < B; rowA += 2 * nw) {
+        const int64_t rowB = rowA + nw;
+        const bool vB = rowB < B;
+        float xA[NPL], lA[NPL], xB[NPL], lB[NPL];
+        const __amdgpu_buffer_rsrc_t rA = row_rsrc(x0 + rowA * D, D * 4);
+        const __amdgpu_buffer_rsrc_t rB = row_rsrc(x0 + (vB ? rowB : rowA) * D, vB ? D * 4 : 0);
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
-            const int c = lane + 64 * j;
-            x[j] = c < D ? x0[row * D + c] : 0.0f;
-            xl[j] = x[j];
+            xA[j] = row_load(rA, voff, 256 * j);
+            xB[j] = row_load(rB, voff, 256 * j);
+            lA[j] = xA[j];
+            lB[j] = xB[j];
         }
         for (int l = 0; l < L; ++l) {
-            float part = 0.0f;
+            float pA = 0.0f, pB = 0.0f;
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
-                const int c = lane + 64 * j;
-                if (c < D) part += xl[j] * w[l * D + c];
+                const float wv = wload<WLDS>(w, sw, l, lane, j, D, DP);
+                pA += lA[j] * wv;
+                pB += lB[j] * wv;
             }
-            const float s = wave_sum(part);
+            const float sA = wave_sum(pA), sB = wave_sum(pB);
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
-                const int c = lane + 64 * j;
-                if (c < D) xl[j] = (x[j] * s + b[l * D + c]) + xl[j];
+                const float bv = wload<WLDS>(b, sb, l, lane, j, D, DP);
+                lA[j] = (xA[j] * sA + bv) + lA[j];
+                lB[j] = (xB[j] * sB + bv) + lB[j];
             }
         }
+        const __amdgpu_buffer_rsrc_t oA = row_rsrc(out + rowA * D, D * 4);
+        const __amdgpu_buffer_rsrc_t oB = row_rsrc(out + (vB ? rowB : rowA) * D, vB ? D * 4 : 0);
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
-            const int c = lane + 64 * j;
-            if (c < D) out[row * D + c] = xl[j];
+            row_store(oA, voff, 256 * j, lA[j]);
+            row_store(oB, voff, 256 * j, lB[j]);
         }
     }
 }
 
-// slab layout per wave: [LMAX][D] sums of u_l*x0, then [D] colsum(dy), then [LMAX] sums of t_l.
+// slab layout per block: [LMAX][D] sums of u_l*x0, then [D] colsum(dy), then [LMAX] sums of t_l.
 __host__ __device__ inline int64_t slab_floats(int D) { return (int64_t)(LMAX + 1) * D + LMAX; }
 
-template <int NPL>
-__global__ __launch_bounds__(256) void k_cross_bwd(const float* __restrict__ x0, const float* __restrict__ w,
-                                                   const float* __restrict__ b, int L, int64_t B, int D,
-                                                   const float* __restrict__ dy, float* __restrict__ dx0,
-                                                   float* __restrict__ slabs) {
+// pd[l' * L + l] = b_l' . w_l for l' < l (0 otherwise): the row-independent part of s_l = x_l . w_l is
+// c_l = beta_l . w_l = sum_{l' < l} pd[l', l] (k_cross_bwd adds the pairs in l' order).  One block per pair.
+__global__ __launch_bounds__(256) void k_cross_beta_dot(const float* __restrict__ w, const float* __restrict__ b,
+                                                        int L, int D, float* __restrict__ pd) {
+    __shared__ float part[4];
+    const int lp = blockIdx.x / L, l = blockIdx.x - lp * L;
+    float s = 0.0f;
+    if (lp < l)
+        for (int c = threadIdx.x; c < D; c += 256) s = fmaf(b[lp * D + c], w[l * D + c], s);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) pd[blockIdx.x] = ((part[0] + part[1]) + part[2]) + part[3];
+}
+
+// two waves per SIMD where the [LT][NPL] accumulators + x, dy, colsum rows leave room under 256 registers
+constexpr int bwd_occ(int npl, int lt) { return (lt + 3) * npl <= 180 ? 2 : 1; }
+
+// LT = compile-time bound on the layer count (2, 4, 6 or 8): the [LT][NPL] batch-sum accumulators live in
+// registers, so they must be sized statically.
+//
+// Per row the kernel needs only the L dots P_l = x0 . w_l (independent of each other, so their wave
+// reductions overlap): with x_l = a_l x0 + beta_l,  s_l = x_l . w_l = a_l P_l + c_l,  a_{l+1} = a_l + s_l.
+// x_l itself is never rebuilt, b is not read at all; fmaf is used freely -- this kernel is checked against
+// the oracle's double-precision backward to a tolerance, not bit for bit (the forward is bit-exact).
+template <int NPL, int LT, bool WLDS>
+__global__ __launch_bounds__(BWD_NT) __attribute__((amdgpu_waves_per_eu(bwd_occ(NPL, LT), bwd_occ(NPL, LT)))) void k_cross_bwd(const float* __restrict__ x0, const float* __restrict__ w,
+                                                      const float* __restrict__ cvec, int L, int64_t B, int D,
+                                                      const float* __restrict__ dy, float* __restrict__ dx0,
+                                                      float* __restrict__ slabs) {
+    constexpr int DP = NPL * 64;
+    extern __shared__ float smem[];
+    float* sw = smem;
+    if (WLDS) stage_wb<BWD_NT, DP, false>(w, nullptr, L, D, sw, nullptr);
     const int lane = threadIdx.x & 63;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nw = (int64_t)gridDim.x * 4;
-    float accw[LMAX][NPL];
-    float accd[NPL];
-    float accT[LMAX];
+    const int voff = lane * 4;
+    constexpr int WPB = BWD_NT / 64;
+    const int64_t wid = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * WPB;
+    float cl[LT];
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l) {
+    for (int l = 0; l < LT; ++l) {
+        float s = 0.0f;
+        for (int lp = 0; lp < l && l < L; ++lp) s += cvec[lp * L + l];
+        cl[l] = s;
+    }
+    float accw[LT][NPL];
+    float accd[NPL];
+    float accT[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
         accT[l] = 0.0f;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) accw[l][j] = 0.0f;
@@ -88,124 +206,144 @@ __global__ __launch_bounds__(256) void k_cross_bwd(const float* __restrict__ x0,
     for (int j = 0; j < NPL; ++j) accd[j] = 0.0f;
 
     for (int64_t row = wid; row < B; row += nw) {
-        float x[NPL], xl[NPL], g[NPL];
+        float x[NPL], g[NPL];
+        const __amdgpu_buffer_rsrc_t rx = row_rsrc(x0 + row * D, D * 4);
+        const __amdgpu_buffer_rsrc_t rg = row_rsrc(dy + row * D, D * 4);
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
-            const int c = lane + 64 * j;
-            x[j] = c < D ? x0[row * D + c] : 0.0f;
-            g[j] = c < D ? dy[row * D + c] : 0.0f;
-            xl[j] = x[j];
+            x[j] = row_load(rx, voff, 256 * j);
+            g[j] = row_load(rg, voff, 256 * j);
         }
-        float a[LMAX + 1], P[LMAX], t[LMAX];
-        a[0] = 1.0f;
-        float qp = 0.0f;
+        float P[LT], qp = 0.0f;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) qp += g[j] * x[j];
+        for (int j = 0; j < NPL; ++j) qp = fmaf(g[j], x[j], qp);
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            float p = 0.0f;
+            if (l < L) {
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) p = fmaf(x[j], wload<WLDS>(w, sw, l, lane, j, D, DP), p);
+            }
+            P[l] = p;
+            __builtin_amdgcn_sched_barrier(0);   // keep one layer's LDS reads in flight, not all L*NPL (registers)
+        }
         const float q = wave_sum(qp);
 #pragma unroll
-        for (int l = 0; l < LMAX; ++l) {
-            if (l < L) {
-                float ps = 0.0f, pp = 0.0f;
+        for (int l = 0; l < LT; ++l) P[l] = wave_sum(P[l]);      // P[l] == 0 for l >= L
+        float a[LT + 1], t[LT];
+        a[0] = 1.0f;
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) {
-                    const int c = lane + 64 * j;
-                    if (c < D) {
-                        const float wv = w[l * D + c];
-                        ps += xl[j] * wv;
-                        pp += x[j] * wv;
-                    }
-                }
-                const float s = wave_sum(ps);
-                P[l] = wave_sum(pp);
-                a[l + 1] = a[l] + s;
-#pragma unroll
-                for (int j = 0; j < NPL; ++j) {
-                    const int c = lane + 64 * j;
-                    if (c < D) xl[j] = (x[j] * s + b[l * D + c]) + xl[j];
-                }
-            } else {
-                P[l] = 0.0f;
-                a[l + 1] = a[l];
-            }
-        }
+        for (int l = 0; l < LT; ++l) a[l + 1] = l < L ? a[l] + fmaf(a[l], P[l], cl[l]) : a[l];
         // t_l = q + sum_{l' > l} t_l' P_l'
         float run = 0.0f;
 #pragma unroll
-        for (int l = LMAX - 1; l >= 0; --l) {
-            if (l < L) {
-                t[l] = q + run;
-                run += t[l] * P[l];
-            } else {
-                t[l] = 0.0f;
-            }
+        for (int l = LT - 1; l >= 0; --l) {
+            t[l] = l < L ? q + run : 0.0f;
+            run = fmaf(t[l], P[l], run);
         }
         // dx0 = a_L * dy + sum_l u_l w_l ; accumulate batch sums
         float o[NPL];
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
-            o[j] = a[LMAX] * g[j];  // a[LMAX] == a[L]: layers past L add nothing
+            o[j] = a[LT] * g[j];  // a[LT] == a[L]: layers past L add nothing
             accd[j] += g[j];
         }
 #pragma unroll
-        for (int l = 0; l < LMAX; ++l) {
+        for (int l = 0; l < LT; ++l) {
             if (l < L) {
                 const float u = t[l] * a[l];
                 accT[l] += t[l];
 #pragma unroll
                 for (int j = 0; j < NPL; ++j) {
-                    const int c = lane + 64 * j;
-                    if (c < D) {
-                        o[j] += u * w[l * D + c];
-                        accw[l][j] += u * x[j];
-                    }
+                    o[j] = fmaf(u, wload<WLDS>(w, sw, l, lane, j, D, DP), o[j]);
+                    accw[l][j] = fmaf(u, x[j], accw[l][j]);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        const __amdgpu_buffer_rsrc_t ro = row_rsrc(dx0 + row * D, D * 4);
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const int c = lane + 64 * j;
-            if (c < D) dx0[row * D + c] = o[j];
-        }
+        for (int j = 0; j < NPL; ++j) row_store(ro, voff, 256 * j, o[j]);
     }
-    float* sl = slabs + wid * slab_floats(D);
+    // Block slab: the waves add their sums in wave order into LDS (the w staging area is dead by now;
+    // rows padded to DP, so no guards), one slab per block goes to HBM, same fixed order every run.
+    __syncthreads();
+    float* bs = smem;
+    const int wv_id = threadIdx.x >> 6;
+    for (int turn = 0; turn < WPB; ++turn) {
+        if (wv_id == turn) {
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l) {
+            for (int l = 0; l < LT; ++l) {
+                if (l < L) {
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const int c = lane + 64 * j;
-            if (c < D) sl[(int64_t)l * D + c] = accw[l][j];
+                    for (int j = 0; j < NPL; ++j) {
+                        const int c = lane + 64 * j;
+                        bs[l * DP + c] = (turn ? bs[l * DP + c] : 0.0f) + accw[l][j];
+                    }
+                    if (lane == 0) bs[(L + 1) * DP + l] = (turn ? bs[(L + 1) * DP + l] : 0.0f) + accT[l];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const int c = lane + 64 * j;
+                bs[L * DP + c] = (turn ? bs[L * DP + c] : 0.0f) + accd[j];
+            }
         }
-        if (lane == 0) sl[(int64_t)(LMAX + 1) * D + l] = accT[l];
+        __syncthreads();
     }
+    float* sl = slabs + (int64_t)blockIdx.x * slab_floats(D);
+    for (int l = 0; l < L; ++l)
+        for (int i = threadIdx.x; i < D; i += BWD_NT) sl[(int64_t)l * D + i] = bs[l * DP + i];
+    for (int i = threadIdx.x; i < D; i += BWD_NT) sl[(int64_t)LMAX * D + i] = bs[L * DP + i];
+    if ((int)threadIdx.x < L) sl[(int64_t)(LMAX + 1) * D + threadIdx.x] = bs[(L + 1) * DP + threadIdx.x];
+}
+
+// Stage 1 of the slab reduction.  blockIdx.y = quantity q (q < L: sum u_l x0 of layer q; q == L: colsum(dy);
+// q == L + 1: the L scalars sum t_l).  A block owns 32 columns; its 32 thread groups each add a strided
+// subset of the slabs, then the 32 partial sums are added in group order: a fixed order, independent of timing.
+__global__ __launch_bounds__(1024) void k_cross_bwd_sum(const float* __restrict__ slabs, int nslabs, int L, int D,
+                                                        float* __restrict__ R) {
+    __shared__ float part[32][33];
+    const int q = blockIdx.y;
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int64_t sf = slab_floats(D);
+    int64_t off;
+    bool live;
+    if (q <= L) {
+        const int c = blockIdx.x * 32 + cl;
+        live = c < D;
+        off = (int64_t)(q < L ? q : LMAX) * D + c;
+    } else {
+        if (blockIdx.x != 0) return;
+        live = cl < L;
+        off = (int64_t)(LMAX + 1) * D + cl;
+    }
+    float s = 0.0f;
+    if (live) {
+#pragma unroll 4
+        for (int k = grp; k < nslabs; k += 32) s += slabs[k * sf + off];
+    }
+    part[grp][cl] = s;
+    __syncthreads();
+    if (grp == 0 && live) {
+        float t = part[0][cl];
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-        const int c = lane + 64 * j;
-        if (c < D) sl[(int64_t)LMAX * D + c] = accd[j];
+        for (int g2 = 1; g2 < 32; ++g2) t += part[g2][cl];
+        if (q <= L) R[(int64_t)(q < L ? q : LMAX) * D + blockIdx.x * 32 + cl] = t;
+        else R[(int64_t)(LMAX + 1) * D + cl] = t;
     }
 }
 
-// One thread per column: adds the per-wave slabs in wave order, then composes dw and db.
-__global__ __launch_bounds__(256) void k_cross_bwd_reduce(const float* __restrict__ slabs, int64_t nslabs,
-                                                          const float* __restrict__ w, const float* __restrict__ b,
-                                                          int L, int D, float* __restrict__ dw,
-                                                          float* __restrict__ db) {
+// Stage 2: one thread per column composes dw and db from the reduced slab R.
+__global__ __launch_bounds__(256) void k_cross_bwd_compose(const float* __restrict__ R, const float* __restrict__ w,
+                                                           const float* __restrict__ b, int L, int D,
+                                                           float* __restrict__ dw, float* __restrict__ db) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= D) return;
-    const int64_t sf = slab_floats(D);
-    float sw[LMAX], T[LMAX], cs = 0.0f;
+    float T[LMAX];
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l) { sw[l] = 0.0f; T[l] = 0.0f; }
-    for (int64_t k = 0; k < nslabs; ++k) {
-        const float* sl = slabs + k * sf;
-#pragma unroll
-        for (int l = 0; l < LMAX; ++l) {
-            if (l < L) {
-                sw[l] += sl[(int64_t)l * D + c];
-                T[l] += sl[(int64_t)(LMAX + 1) * D + l];
-            }
-        }
-        cs += sl[(int64_t)LMAX * D + c];
-    }
+    for (int l = 0; l < LMAX; ++l) T[l] = l < L ? R[(int64_t)(LMAX + 1) * D + l] : 0.0f;
+    const float cs = R[(int64_t)LMAX * D + c];
     float beta = 0.0f;  // beta_l[c]
     float tail = 0.0f;  // sum_{l' > l} w_l'[c] * T_l'
     float dbv[LMAX];
@@ -219,7 +357,7 @@ __global__ __launch_bounds__(256) void k_cross_bwd_reduce(const float* __restric
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
         if (l < L) {
-            dw[l * D + c] = sw[l] + beta * T[l];
+            dw[l * D + c] = R[(int64_t)l * D + c] + beta * T[l];
             db[l * D + c] = dbv[l];
             beta += b[l * D + c];
         }
@@ -235,7 +373,7 @@ inline int npl_bucket(int D) {
 
 inline unsigned bwd_blocks(int64_t B) {
     int64_t blocks = mrec_cdiv(B, 4 * 8);  // >= 8 rows per wave
-    if (blocks > 512) blocks = 512;
+    if (blocks > 512) blocks = 512;       // two blocks per CU (256 VGPRs, <= 80 KB of LDS each)
     if (blocks < 1) blocks = 1;
     return (unsigned)blocks;
 }
@@ -255,6 +393,62 @@ inline unsigned bwd_blocks(int64_t B) {
         default: { constexpr int N_ = 32; CALL; } break;                                           \
     }
 
+namespace {
+constexpr size_t kMaxLds = 160 * 1024;
+
+template <class Kern>
+int set_lds(Kern kern, size_t bytes) {
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { g_mrec_last_hip_error = (int)e; return MREC_EHIP; }
+    }
+    return MREC_OK;
+}
+
+template <int NPL>
+int launch_fwd(const float* x0, const float* w, const float* b, int L, int64_t B, int D, float* out, hipStream_t st) {
+    const size_t lds = (size_t)2 * L * NPL * 64 * sizeof(float);
+    int64_t blocks = mrec_cdiv(B, 2 * (FWD_NT / 64));            // 16 waves x 2 rows per pass
+    if (blocks > 256) blocks = 256;
+    if (lds > 0 && lds <= kMaxLds) {
+        int rc = set_lds(k_cross_fwd<NPL, true>, lds);
+        if (rc != MREC_OK) return rc;
+        k_cross_fwd<NPL, true><<<(unsigned)blocks, FWD_NT, lds, st>>>(x0, w, b, L, B, D, out);
+    } else {
+        k_cross_fwd<NPL, false><<<(unsigned)blocks, FWD_NT, 0, st>>>(x0, w, b, L, B, D, out);
+    }
+    return MREC_OK;
+}
+
+template <int NPL, int LT>
+int launch_bwd_lt(const float* x0, const float* w, const float* cvec, int L, int64_t B, int D, const float* dy, float* dx0,
+                  float* slabs, unsigned blocks, hipStream_t st) {
+    constexpr int DP = NPL * 64;
+    const size_t slab = ((size_t)(L + 1) * DP + L) * sizeof(float);   // block slab, <= 74 KB (D <= 2048, L <= 8)
+    const size_t wlds = (size_t)L * DP * sizeof(float);
+    if (wlds > 0 && wlds <= kMaxLds) {
+        const size_t lds = wlds > slab ? wlds : slab;
+        int rc = set_lds(k_cross_bwd<NPL, LT, true>, lds);
+        if (rc != MREC_OK) return rc;
+        k_cross_bwd<NPL, LT, true><<<blocks, BWD_NT, lds, st>>>(x0, w, cvec, L, B, D, dy, dx0, slabs);
+    } else {
+        int rc = set_lds(k_cross_bwd<NPL, LT, false>, slab);
+        if (rc != MREC_OK) return rc;
+        k_cross_bwd<NPL, LT, false><<<blocks, BWD_NT, slab, st>>>(x0, w, cvec, L, B, D, dy, dx0, slabs);
+    }
+    return MREC_OK;
+}
+
+template <int NPL>
+int launch_bwd(const float* x0, const float* w, const float* cvec, int L, int64_t B, int D, const float* dy, float* dx0,
+               float* slabs, unsigned blocks, hipStream_t st) {
+    if (L <= 2) return launch_bwd_lt<NPL, 2>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st);
+    if (L <= 4) return launch_bwd_lt<NPL, 4>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st);
+    if (L <= 6) return launch_bwd_lt<NPL, 6>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st);
+    return launch_bwd_lt<NPL, 8>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st);
+}
+}  // namespace
+
 MREC_API int mrec_cross_layers_f32(const float* x0, const float* w, const float* b, int32_t L, int64_t B, int32_t D,
                                    float* out, void* stream) {
     if (B < 0 || D <= 0 || L < 0) return MREC_EINVAL;
@@ -263,16 +457,16 @@ MREC_API int mrec_cross_layers_f32(const float* x0, const float* w, const float*
     const int npl = npl_bucket(D);
     if (npl < 0) return MREC_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    int64_t blocks = mrec_cdiv(B, 4);
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    MREC_NPL_DISPATCH(npl, (k_cross_fwd<N_><<<(unsigned)blocks, 256, 0, st>>>(x0, w, b, L, B, D, out)));
+    int rc = MREC_OK;
+    MREC_NPL_DISPATCH(npl, (rc = launch_fwd<N_>(x0, w, b, L, B, D, out, st)));
+    if (rc != MREC_OK) return rc;
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
 
 MREC_API int mrec_cross_layers_bwd_workspace_bytes(int32_t L, int64_t B, int32_t D, size_t* out) {
     if (!out || B < 0 || D <= 0 || L < 0) return MREC_EINVAL;
-    *out = (size_t)bwd_blocks(B) * 4 * slab_floats(D) * sizeof(float) + 256;
+    *out = ((size_t)bwd_blocks(B) + 1) * slab_floats(D) * sizeof(float) + 512;   // block slabs + the reduced slab + pair dots
     return MREC_OK;
 }
 
@@ -285,13 +479,20 @@ MREC_API int mrec_cross_layers_bwd_f32(const float* x0, const float* w, const fl
     const int npl = npl_bucket(D);
     if (npl < 0) return MREC_EUNSUPPORTED;
     const unsigned blocks = bwd_blocks(B);
-    const int64_t nslabs = (int64_t)blocks * 4;
-    if (ws_bytes < (size_t)nslabs * slab_floats(D) * sizeof(float)) return MREC_EWORKSPACE;
+    const int nslabs = (int)blocks;
+    if (ws_bytes < (((size_t)nslabs + 1) * slab_floats(D) + LMAX * LMAX) * sizeof(float)) return MREC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* slabs = (float*)ws;
-    MREC_NPL_DISPATCH(npl, (k_cross_bwd<N_><<<blocks, 256, 0, st>>>(x0, w, b, L, B, D, dy, dx0, slabs)));
-    if (L > 0)
-        k_cross_bwd_reduce<<<(unsigned)mrec_cdiv(D, 256), 256, 0, st>>>(slabs, nslabs, w, b, L, D, dw, db);
+    float* R = slabs + (int64_t)nslabs * slab_floats(D);
+    float* cvec = R + slab_floats(D);                       // LMAX*LMAX pair dots in the workspace's 256-byte tail
+    if (L > 0) k_cross_beta_dot<<<(unsigned)(L * L), 256, 0, st>>>(w, b, L, D, cvec);
+    int rc = MREC_OK;
+    MREC_NPL_DISPATCH(npl, (rc = launch_bwd<N_>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st)));
+    if (rc != MREC_OK) return rc;
+    if (L > 0) {
+        k_cross_bwd_sum<<<dim3((unsigned)mrec_cdiv(D, 32), (unsigned)(L + 2)), 1024, 0, st>>>(slabs, nslabs, L, D, R);
+        k_cross_bwd_compose<<<(unsigned)mrec_cdiv(D, 256), 256, 0, st>>>(R, w, b, L, D, dw, db);
+    }
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }

@@ -179,25 +179,43 @@ __global__ __launch_bounds__(256) void k_fill_normal(float* __restrict__ out, in
     }
 }
 
+// Each wave takes 64 entries at a time: one coalesced read of the new-flags / rows / keys, a ballot of the
+// entries that need a row, then the wave fills those rows together (coalesced stores).  When nothing is new
+// -- every lookup of resident keys -- the kernel is a single pass over the flags.  Rows of <= 16 columns
+// (the wide table's 1-4 floats) are filled by their own lane instead.
 template <class K>
 __global__ __launch_bounds__(256) void k_init_rows(float* __restrict__ table, int64_t ld, int D,
                                                    const int* __restrict__ rows, const K* __restrict__ keys,
                                                    const uint8_t* __restrict__ is_new, int64_t n_max,
                                                    const int64_t* __restrict__ n_dev, uint64_t seed, float sigma,
                                                    float fill) {
-    const int cpr = (D + 3) >> 2;
     int64_t n = n_max;
     if (n_dev) { const int64_t nd = *n_dev; n = nd < n ? nd : n; }
-    const int64_t total = n * cpr;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-        const int64_t i = t / cpr;
-        if (is_new && !is_new[i]) continue;
-        const int r = rows[i];
-        if (r < 0) continue;
-        const int c0 = (int)(t - i * cpr) * 4;
-        const int64_t key = (int64_t)keys[i];
-        for (int k = 0; k < 4 && c0 + k < D; ++k)
-            table[(int64_t)r * ld + c0 + k] = sigma >= 0.0f ? sigma * mrec_det_normal(seed, key, c0 + k) : fill;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t base = wave * 64; base < n; base += nwaves * 64) {
+        const int64_t i = base + lane;
+        int r = -1;
+        int64_t key = 0;
+        if (i < n && (!is_new || is_new[i])) {
+            r = rows[i];
+            if (r >= 0) key = (int64_t)keys[i];
+        }
+        if (D <= 16) {
+            if (r >= 0)
+                for (int c = 0; c < D; ++c)
+                    table[(int64_t)r * ld + c] = sigma >= 0.0f ? sigma * mrec_det_normal(seed, key, c) : fill;
+            continue;
+        }
+        uint64_t mask = __ballot(r >= 0);
+        while (mask) {
+            const int src = __ffsll((unsigned long long)mask) - 1;
+            mask &= mask - 1;
+            const int rr = __shfl(r, src, 64);
+            const int64_t kk = ((int64_t)__shfl((int)(key >> 32), src, 64) << 32) | (uint32_t)__shfl((int)key, src, 64);
+            for (int c = lane; c < D; c += 64)
+                table[(int64_t)rr * ld + c] = sigma >= 0.0f ? sigma * mrec_det_normal(seed, kk, c) : fill;
+        }
     }
 }
 
@@ -450,8 +468,7 @@ MREC_API int mrec_init_rows_f32(float* table, int64_t ld, int32_t D, const int32
     if (n < 0 || D <= 0 || ld < D) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
     if (!table || !rows || !keys) return MREC_EINVAL;
-    const int64_t total = n * ((D + 3) / 4);
-    k_init_rows<int64_t><<<stream_grid(total), 256, 0, (hipStream_t)stream>>>(table, ld, D, rows, keys, is_new, n,
+    k_init_rows<int64_t><<<stream_grid(n), 256, 0, (hipStream_t)stream>>>(table, ld, D, rows, keys, is_new, n,
                                                                            n_dev, seed, sigma, fill);
     MREC_LAUNCH_CHECK();
     return MREC_OK;

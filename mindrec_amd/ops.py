@@ -314,8 +314,11 @@ class KeyIndex:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
-            _lib.lib().mrec_map_destroy(h)
+        if h and _lib is not None:          # _lib is None during interpreter shutdown
+            try:
+                _lib.lib().mrec_map_destroy(h)
+            except Exception:
+                pass
             self._h = None
 
     def counters(self):
