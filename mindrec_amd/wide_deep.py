@@ -152,7 +152,10 @@ class WideDeepEngine:
 
             self.dense_flat, views = _flat_views(shapes_h + shapes_s, dev)
             self.dense = interleave(views[:nl - 1], views[nl - 1:])
-            self.dense_grad_flat, gviews = _flat_views(shapes_h + shapes_s, dev)
+            # one extra slot at the end carries the wide-bias gradient through the same all-reduce
+            self.dense_grad_ext, gviews = _flat_views(shapes_h + shapes_s + [(1,)], dev)
+            self.dense_grad_flat = self.dense_grad_ext[:-1]
+            gviews = gviews[:-1]
             self.dense_grad = interleave(gviews[:nl - 1], gviews[nl - 1:])
             self.dense_m = torch.zeros_like(self.dense_flat)
             self.dense_v = torch.zeros_like(self.dense_flat)
@@ -198,13 +201,18 @@ class WideDeepEngine:
         else:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
-    def _all_reduce(self, t):
+    def _all_reduce(self, t, async_op=False):
+        """Sum over ranks.  async_op=True returns a work handle (None when the collective is staged through the
+        host): the reduction proceeds on RCCL's stream while this stream keeps issuing kernels."""
         if self._staged():
             c = t.cpu()
             dist.all_reduce(c, group=self.group)
             t.copy_(c)
-        else:
-            dist.all_reduce(t, group=self.group)
+            return None
+        if async_op and self._gpu:
+            return dist.all_reduce(t, group=self.group, async_op=True)
+        dist.all_reduce(t, group=self.group)
+        return None
 
     # ---- helpers -----------------------------------------------------------------------------
     def _tick(self, name):
@@ -400,15 +408,15 @@ class WideDeepEngine:
         self._wide_event = None
         emb, wide, route = self.lookup(ids, wts)        # deep gather on the main stream, wide_sum on the side stream
         plan_early = None
-        if self._side is not None and self.world == 1:
-            # The step's Unique + inverted index needs only the ids: queue it on the side stream (behind the
-            # wide_sum) so its dozen small latency-bound kernels hide under the MLP instead of sitting on the
-            # critical path in front of the sparse applies.
+        if self._side is not None:
+            # The step's Unique + inverted index needs only the ids (on a shard: the ids received from the
+            # other ranks): queue it on the side stream (behind the wide_sum) so its dozen small latency-bound
+            # kernels hide under the MLP instead of sitting on the critical path in front of the sparse applies.
             main = torch.cuda.current_stream()
             if self._wide_event is None:
                 self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
-                plan_early = self.k.sparse_plan(ids)
+                plan_early = self.k.sparse_plan(ids if route is None else route[3])
             for t in (plan_early.uniq_buf, plan_early.inv, plan_early.n_uniq_dev, plan_early.sorted_pos,
                       plan_early.sorted_seg, plan_early.seg_offsets):
                 t.record_stream(main)
@@ -431,16 +439,8 @@ class WideDeepEngine:
             g_emb, g_wide = emb.grad, wide.grad                           # [B, F*D], [B]
         self._tock(ev)
 
-        if self.world > 1:
-            ev = self._tick("allreduce_dense")
-            self._all_reduce(self.dense_grad_flat)
-            self.dense_grad_flat.div_(self.world)
-            gb = g_wide.sum().view(1)
-            self._all_reduce(gb)
-            gb.div_(self.world)
-            self._tock(ev)
-        else:
-            gb = g_wide.sum().view(1)
+        gb = g_wide.sum().view(1)
+        dense_work = None
 
         if route is None:
             ev = self._tick("plan")
@@ -488,8 +488,18 @@ class WideDeepEngine:
             recv_gw = torch.empty((n_recv, 1), dtype=torch.float32, device=self.device)
             self._all_to_all(recv_gw, send_gw, recv_counts, send_counts)
             self._tock(ev)
+            # Dense gradients (+ the wide bias gradient riding in the same buffer): all-reduce queued behind the
+            # row-gradient exchange and left running while the sparse applies execute -- they do not need it.
+            ev = self._tick("allreduce_dense")
+            self.dense_grad_ext[-1:].copy_(gb)
+            dense_work = self._all_reduce(self.dense_grad_ext, async_op=True)
+            self._tock(ev)
             ev = self._tick("plan")
-            plan = self.k.sparse_plan(recv_local)
+            if plan_early is not None:
+                torch.cuda.current_stream().wait_stream(self._side)
+                plan = plan_early
+            else:
+                plan = self.k.sparse_plan(recv_local)
             self._tock(ev)
             # RowTensor gradients of all ranks are summed at the owner; gradients_mean divides by world
             scale = inv_sens / self.world
@@ -504,6 +514,11 @@ class WideDeepEngine:
                              l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=scale)
             self._tock(ev)
 
+        if self.world > 1:
+            if dense_work is not None:
+                dense_work.wait()                     # the current stream waits for RCCL's stream; no host block
+            self.dense_grad_ext.div_(self.world)      # gradients_mean=True (train_and_eval_distribute.py:137)
+            gb = self.dense_grad_ext[-1:]
         ev = self._tick("apply_dense")
         akw = dict(lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
                    beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=inv_sens)
@@ -515,7 +530,7 @@ class WideDeepEngine:
         self.k.dense_ftrl_(self.wide_b, self.wide_b_accum, self.wide_b_linear, gb, lr=cfg.ftrl_lr, l1=cfg.ftrl_l1,
                         l2=cfg.ftrl_l2, grad_scale=inv_sens)
         self._tock(ev)
-        if self._side is not None and route is None:
+        if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         self.last_plan = plan
         return loss.detach()
