@@ -57,12 +57,14 @@ namespace {
 #endif
 template <int VEC> struct ACfg;
 template <> struct ACfg<4> { static constexpr int AW = MREC_AW4, AB = MREC_AB4, GP = MREC_GP4; static constexpr bool NT = MREC_NT4; };
+template <> struct ACfg<2> { static constexpr int AW = MREC_AW1, AB = MREC_AB1, GP = MREC_GP1; static constexpr bool NT = MREC_NT1; };  // 8-byte path: same window as scalar
 template <> struct ACfg<1> { static constexpr int AW = MREC_AW1, AB = MREC_AB1, GP = MREC_GP1; static constexpr bool NT = MREC_NT1; };
 static_assert(MREC_GP4 % MREC_AB4 == 0 && MREC_GP1 % MREC_AB1 == 0, "gradient prefetch depth must be a multiple of the state batch depth");
 constexpr int AW_MIN = (MREC_AW4 < MREC_AW1) ? MREC_AW4 : MREC_AW1;
 
 template <int VEC> struct Vf;
 template <> struct Vf<4> { float4 v; };
+template <> struct Vf<2> { float2 v; };
 template <> struct Vf<1> { float v; };
 
 typedef float mrec_f4 __attribute__((ext_vector_type(4)));
@@ -72,6 +74,15 @@ template <bool NT> __device__ __forceinline__ void vload(Vf<4>& r, const float* 
         r.v = make_float4(t.x, t.y, t.z, t.w);
     } else {
         r.v = *(const float4*)p;
+    }
+}
+typedef float mrec_f2 __attribute__((ext_vector_type(2)));
+template <bool NT> __device__ __forceinline__ void vload(Vf<2>& r, const float* p) {
+    if (NT) {
+        mrec_f2 t = __builtin_nontemporal_load((const mrec_f2*)p);
+        r.v = make_float2(t.x, t.y);
+    } else {
+        r.v = *(const float2*)p;
     }
 }
 template <bool NT> __device__ __forceinline__ void vload(Vf<1>& r, const float* p) {
@@ -92,6 +103,10 @@ template <bool NT> __device__ __forceinline__ void vload(Vf<4>& r, const bf16_t*
     r.v = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
                       __uint_as_float(u.y & 0xFFFF0000u));
 }
+template <bool NT> __device__ __forceinline__ void vload(Vf<2>& r, const bf16_t* p) {
+    const unsigned int u = NT ? __builtin_nontemporal_load((const unsigned int*)p) : *(const unsigned int*)p;
+    r.v = make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u));
+}
 template <bool NT> __device__ __forceinline__ void vload(Vf<1>& r, const bf16_t* p) {
     r.v = __uint_as_float(((unsigned int)p->v) << 16);
 }
@@ -103,16 +118,27 @@ template <bool NT> __device__ __forceinline__ void vstore(float* p, const Vf<4>&
         *(float4*)p = x.v;
     }
 }
+template <bool NT> __device__ __forceinline__ void vstore(float* p, const Vf<2>& x) {
+    if (NT) {
+        mrec_f2 t = {x.v.x, x.v.y};
+        __builtin_nontemporal_store(t, (mrec_f2*)p);
+    } else {
+        *(float2*)p = x.v;
+    }
+}
 template <bool NT> __device__ __forceinline__ void vstore(float* p, const Vf<1>& x) {
     if (NT) __builtin_nontemporal_store(x.v, p); else *p = x.v;
 }
 __device__ __forceinline__ void vzero(Vf<4>& r) { r.v = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void vzero(Vf<2>& r) { r.v = make_float2(0.f, 0.f); }
 __device__ __forceinline__ void vzero(Vf<1>& r) { r.v = 0.f; }
 __device__ __forceinline__ void vmul(Vf<4>& x, float s) { x.v.x *= s; x.v.y *= s; x.v.z *= s; x.v.w *= s; }
+__device__ __forceinline__ void vmul(Vf<2>& x, float s) { x.v.x *= s; x.v.y *= s; }
 __device__ __forceinline__ void vmul(Vf<1>& x, float s) { x.v *= s; }
 __device__ __forceinline__ void vadd(Vf<4>& a, const Vf<4>& b) {
     a.v.x = a.v.x + b.v.x; a.v.y = a.v.y + b.v.y; a.v.z = a.v.z + b.v.z; a.v.w = a.v.w + b.v.w;
 }
+__device__ __forceinline__ void vadd(Vf<2>& a, const Vf<2>& b) { a.v.x = a.v.x + b.v.x; a.v.y = a.v.y + b.v.y; }
 __device__ __forceinline__ void vadd(Vf<1>& a, const Vf<1>& b) { a.v = a.v + b.v; }
 
 // ---- updaters: NS state arrays, each [V, ld]; apply() sees one lane's VEC elements -------------
@@ -148,6 +174,16 @@ __device__ __forceinline__ void upd_apply(const Upd& u, Vf<4> (&st)[Upd::NS], co
 #undef MREC_COMP
 }
 template <class Upd>
+__device__ __forceinline__ void upd_apply(const Upd& u, Vf<2> (&st)[Upd::NS], const Vf<2>& g) {
+    float a[Upd::NS];
+    for (int i = 0; i < Upd::NS; ++i) a[i] = st[i].v.x;
+    u.elem(a, g.v.x);
+    for (int i = 0; i < Upd::NS; ++i) st[i].v.x = a[i];
+    for (int i = 0; i < Upd::NS; ++i) a[i] = st[i].v.y;
+    u.elem(a, g.v.y);
+    for (int i = 0; i < Upd::NS; ++i) st[i].v.y = a[i];
+}
+template <class Upd>
 __device__ __forceinline__ void upd_apply(const Upd& u, Vf<1> (&st)[Upd::NS], const Vf<1>& g) {
     float a[Upd::NS];
     for (int i = 0; i < Upd::NS; ++i) a[i] = st[i].v;
@@ -169,7 +205,7 @@ __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t 
                                                     int n, const GT* __restrict__ g, int64_t ldg,
                                                     const float* __restrict__ rscale, float gscale, ApplyGeom gm,
                                                     float* __restrict__ carry_head, float* __restrict__ carry_tail,
-                                                    int* __restrict__ owners, int* __restrict__ n_owners) {
+                                                    int* __restrict__ owners, const int* __restrict__ seg_offsets) {
     constexpr int AW = ACfg<VEC>::AW, AB = ACfg<VEC>::AB, GP = ACfg<VEC>::GP;
     constexpr bool NT = ACfg<VEC>::NT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -261,75 +297,62 @@ __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t 
             seg_cur = seg[AB];
         }
     }
-    // run continues past this window?
+    // run continues past this window?  owners[sw]: 0 = no run of this window continues, 1 = this window owns
+    // a run with few partials (finished by one lane-group of k_apply_long), 2 = a long run (a block's job).
+    // Every window writes its flag, so the list needs neither clearing nor an atomic counter.
     const int last_seg = sseg[e_end - 1];
+    int flag = 0;
     if (e_end < n && sseg[e_end] == last_seg) {
         if (head_open && last_seg == first_seg) {
             vstore<false>(carry_head + sw * gm.D + col, acc);  // window lies wholly inside one run
         } else {
             vstore<false>(carry_tail + sw * gm.D + col, acc);
-            if (sub == 0) owners[atomicAdd(n_owners, 1)] = (int)sw;
+            const int k = (seg_offsets[last_seg + 1] - 1) / AW - (int)sw;   // head partials that follow
+            flag = (k + 1 <= 4 * gm.G) ? 1 : 2;
         }
     }
+    if (sub == 0) owners[sw] = flag;
 }
 
-// One block per run that crosses windows: partial 0 is the owner's tail, partials 1..k are the
-// heads of the following k windows.  Lane-groups take partials round-robin (fixed assignment),
-// then group 0 adds the per-group sums in group order.
+// Finishes the runs that cross windows.  Partial 0 is the owner's tail, partials 1..k the heads of the
+// following k windows.
+//   pass A: runs with at most NG = 4*G partials -- one lane-group each, partials added in order, no barriers
+//           (with heavy duplication, e.g. 640 K ids over a 200 K-row table, most windows own such a run);
+//   pass B: longer runs -- one block each: lane-groups take partials round-robin (fixed assignment), then
+//           group 0 adds the per-group sums in group order.
+// For k + 1 <= NG both orders coincide (each group holds one partial), so the split does not change results.
 template <int VEC, class K, class Upd>
 __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
                                                     const int* __restrict__ sseg,
                                                     const int* __restrict__ seg_offsets, int n, ApplyGeom gm,
                                                     const float* __restrict__ carry_head,
                                                     const float* __restrict__ carry_tail,
-                                                    const int* __restrict__ owners,
-                                                    const int* __restrict__ n_owners) {
+                                                    const int* __restrict__ owners, int nsw) {
     // the partials of a run are consecutive carry rows: stream them 16 deep per lane-group
     constexpr int AW = ACfg<VEC>::AW, AB = 16;
     __shared__ float red[256 * 4];
+    __shared__ int list[256];
+    __shared__ int nlist;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
     const bool active = grp < gm.G;
     const int col = sub * VEC;
     const int NG = 4 * gm.G;
     const int gi = wave * gm.G + grp;
-    const int no = *n_owners;
-    for (int o = blockIdx.x; o < no; o += gridDim.x) {
-        const int sw = owners[o];
-        const int last_e = ((sw + 1) * AW < n ? (sw + 1) * AW : n) - 1;
-        const int u = sseg[last_e];
-        const int seg_end = seg_offsets[u + 1];
-        const int k = (seg_end - 1) / AW - sw;  // number of head partials (>= 1)
-        Vf<VEC> acc;
-        vzero(acc);
-        bool has = false;
-        if (active) {
-            for (int t0 = gi; t0 <= k; t0 += NG * AB) {
-                Vf<VEC> x[AB];
-#pragma unroll
-                for (int q = 0; q < AB; ++q) {
-                    const int t = t0 + q * NG;
-                    vzero(x[q]);
-                    if (t <= k) {
-                        const float* src = (t == 0) ? carry_tail + (int64_t)sw * gm.D : carry_head + (int64_t)(sw + t) * gm.D;
-                        vload<false>(x[q], src + col);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < AB; ++q) {
-                    if (t0 + q * NG <= k) {
-                        if (has) vadd(acc, x[q]); else { acc = x[q]; has = true; }
-                    }
-                }
-            }
-            vstore<false>(red + gi * gm.D + col, acc);
-        }
-        __syncthreads();
-        if (active && gi == 0) {
-            const int ng = (k + 1 < NG) ? k + 1 : NG;
-            for (int q = 1; q < ng; ++q) {
+
+    // ---- pass A
+    if (active) {
+        for (int64_t w = (int64_t)blockIdx.x * NG + gi; w < nsw; w += (int64_t)gridDim.x * NG) {
+            if (owners[w] != 1) continue;
+            const int sw = (int)w;
+            const int last_e = ((sw + 1) * AW < n ? (sw + 1) * AW : n) - 1;
+            const int u = sseg[last_e];
+            const int k = (seg_offsets[u + 1] - 1) / AW - sw;
+            Vf<VEC> acc;
+            vload<false>(acc, carry_tail + (int64_t)sw * gm.D + col);
+            for (int t = 1; t <= k; ++t) {
                 Vf<VEC> x;
-                vload<false>(x, red + q * gm.D + col);
+                vload<false>(x, carry_head + (int64_t)(sw + t) * gm.D + col);
                 vadd(acc, x);
             }
             const int64_t row = seg_row<K>(uniq, u);
@@ -344,6 +367,72 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
 #pragma unroll
                 for (int i = 0; i < Upd::NS; ++i) vstore<false>(upd.s[i] + roff, st[i]);
             }
+        }
+    }
+
+    // ---- pass B: each block scans its slice of the flags, 256 at a time, and works through the long runs
+    const int64_t chunk = (nsw + gridDim.x - 1) / gridDim.x;
+    const int64_t w0 = (int64_t)blockIdx.x * chunk;
+    const int64_t w1 = (w0 + chunk < nsw) ? w0 + chunk : nsw;
+    for (int64_t base = w0; base < w1; base += 256) {
+        if (threadIdx.x == 0) nlist = 0;
+        __syncthreads();
+        const int64_t wq = base + threadIdx.x;
+        if (wq < w1 && owners[wq] == 2) list[atomicAdd(&nlist, 1)] = (int)wq;
+        __syncthreads();
+        const int cnt = nlist;
+        for (int o = 0; o < cnt; ++o) {
+            const int sw = list[o];
+            const int last_e = ((sw + 1) * AW < n ? (sw + 1) * AW : n) - 1;
+            const int u = sseg[last_e];
+            const int seg_end = seg_offsets[u + 1];
+            const int k = (seg_end - 1) / AW - sw;  // number of head partials (>= 1)
+            Vf<VEC> acc;
+            vzero(acc);
+            bool has = false;
+            if (active) {
+                for (int t0 = gi; t0 <= k; t0 += NG * AB) {
+                    Vf<VEC> x[AB];
+#pragma unroll
+                    for (int q = 0; q < AB; ++q) {
+                        const int t = t0 + q * NG;
+                        vzero(x[q]);
+                        if (t <= k) {
+                            const float* src = (t == 0) ? carry_tail + (int64_t)sw * gm.D : carry_head + (int64_t)(sw + t) * gm.D;
+                            vload<false>(x[q], src + col);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < AB; ++q) {
+                        if (t0 + q * NG <= k) {
+                            if (has) vadd(acc, x[q]); else { acc = x[q]; has = true; }
+                        }
+                    }
+                }
+                vstore<false>(red + gi * gm.D + col, acc);
+            }
+            __syncthreads();
+            if (active && gi == 0) {
+                const int ng = (k + 1 < NG) ? k + 1 : NG;
+                for (int q = 1; q < ng; ++q) {
+                    Vf<VEC> x;
+                    vload<false>(x, red + q * gm.D + col);
+                    vadd(acc, x);
+                }
+                const int64_t row = seg_row<K>(uniq, u);
+                if (row >= 0 && row < V) {
+                    const int64_t roff = row * ld + col;
+                    Vf<VEC> st[Upd::NS];
+                    if (Upd::kLoad) {
+#pragma unroll
+                        for (int i = 0; i < Upd::NS; ++i) vload<false>(st[i], upd.s[i] + roff);
+                    }
+                    upd_apply<Upd>(upd, st, acc);
+#pragma unroll
+                    for (int i = 0; i < Upd::NS; ++i) vstore<false>(upd.s[i] + roff, st[i]);
+                }
+            }
+            __syncthreads();
         }
         __syncthreads();
     }
@@ -365,30 +454,36 @@ size_t apply_ws_bytes(int64_t n, int32_t D) {
 template <class K, class Upd, class GT>
 int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, const int* sseg,
                const int* seg_offsets, int64_t n, const GT* g, int64_t ldg, const float* rscale, float gscale,
-               int Dc, bool vec, const ApplyWs& w, hipStream_t st) {
+               int Dc, int vec, const ApplyWs& w, hipStream_t st) {
     ApplyGeom gm;
     gm.D = Dc;
-    gm.lpr = vec ? Dc / 4 : Dc;
+    gm.lpr = Dc / vec;
     gm.G = 64 / gm.lpr;
-    const int64_t nsw = mrec_cdiv(n, vec ? ACfg<4>::AW : ACfg<1>::AW);
+    const int64_t nsw = mrec_cdiv(n, vec == 4 ? ACfg<4>::AW : ACfg<1>::AW);
     const unsigned blocks = (unsigned)mrec_cdiv(nsw, (int64_t)4 * gm.G);
-    MREC_HIP_CHECK(hipMemsetAsync(w.n_owners, 0, sizeof(int), st));
-    unsigned lblocks = (unsigned)(nsw < 2048 ? nsw : 2048);
+    const int64_t lneed = mrec_cdiv(nsw, (int64_t)4 * gm.G);
+    const unsigned lblocks = (unsigned)(lneed < 2048 ? lneed : 2048);
     const hipEvent_t ev0 = t_prof_start, ev1 = t_prof_stop;
     t_prof_start = t_prof_stop = nullptr;
     if (ev0) MREC_HIP_CHECK(hipEventRecord(ev0, st));
-    if (vec) {
+    if (vec == 4) {
         k_apply_main<4, K, Upd, GT><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
-                                                       w.carry_head, w.carry_tail, w.owners, w.n_owners);
+                                                       w.carry_head, w.carry_tail, w.owners, seg_offsets);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         k_apply_long<4, K, Upd><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
-                                                        w.carry_head, w.carry_tail, w.owners, w.n_owners);
+                                                        w.carry_head, w.carry_tail, w.owners, (int)nsw);
+    } else if (vec == 2) {
+        k_apply_main<2, K, Upd, GT><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
+                                                       w.carry_head, w.carry_tail, w.owners, seg_offsets);
+        if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
+        k_apply_long<2, K, Upd><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
+                                                        w.carry_head, w.carry_tail, w.owners, (int)nsw);
     } else {
         k_apply_main<1, K, Upd, GT><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
-                                                       w.carry_head, w.carry_tail, w.owners, w.n_owners);
+                                                       w.carry_head, w.carry_tail, w.owners, seg_offsets);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         k_apply_long<1, K, Upd><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
-                                                        w.carry_head, w.carry_tail, w.owners, w.n_owners);
+                                                        w.carry_head, w.carry_tail, w.owners, (int)nsw);
     }
     MREC_LAUNCH_CHECK();
     return MREC_OK;
@@ -416,8 +511,11 @@ int apply_impl(Upd upd, int64_t V, int64_t ld, int32_t D, const K* uniq, const i
     if (!a.ok) return MREC_EWORKSPACE;
     bool aligned = (ld % 4 == 0) && (ldg % 4 == 0) && ((((uintptr_t)g) & (4 * sizeof(GT) - 1)) == 0);
     for (int i = 0; i < Upd::NS; ++i) aligned = aligned && al16(upd.s[i]);
-    const bool vec = aligned && (D % 4 == 0);
-    const int CB = vec ? 256 : 64;  // columns per launch
+    bool aligned8 = (ld % 2 == 0) && (ldg % 2 == 0) && ((((uintptr_t)g) & (2 * sizeof(GT) - 1)) == 0);
+    for (int i = 0; i < Upd::NS; ++i) aligned8 = aligned8 && ((((uintptr_t)upd.s[i]) & 7) == 0);
+    // 16-byte lanes when rows allow it, else 8-byte lanes (D = 30 of the DCN table), else scalar
+    const int vec = (aligned && D % 4 == 0) ? 4 : ((aligned8 && D % 2 == 0) ? 2 : 1);
+    const int CB = 64 * vec;  // columns per launch
     for (int c0 = 0; c0 < D; c0 += CB) {
         const int Dc = (D - c0 < CB) ? D - c0 : CB;
         Upd u2 = upd;

@@ -282,7 +282,7 @@ def test_ftrl_general_lr_power(dev, oracle):
 
 
 @pytest.mark.parametrize("kind", ["uniform", "zipf", "hot"])
-@pytest.mark.parametrize("D", [80, 1, 30, 300])
+@pytest.mark.parametrize("D", [80, 1, 30, 300, 7, 130])
 def test_segment_sum(dev, oracle, kind, D):
     from mindrec_amd import ops
     rng = np.random.default_rng(3 + D)
