@@ -97,7 +97,10 @@ class DeepCrossEngine:
         d1 = torch.relu(torch.addmm(b1, emb, W1))
         d2 = torch.relu(torch.addmm(b2, d1, W2))
         c = _CrossStack.apply(emb, cw, cb, self.k)
-        return torch.addmm(b3, torch.cat((d2, c), dim=1), W3)
+        # concat([deep, cross]) . W3 (deep_and_cross.py:306-308) as two products on the halves of W3: same sum,
+        # without materialising the [B, 2194] concat and its backward slices
+        h2 = d2.shape[1]
+        return torch.addmm(b3, d2, W3[:h2]) + c @ W3[h2:]
 
     def predict(self, ids, wts):
         B, Fd = ids.shape
