@@ -463,10 +463,13 @@ def shard_route(ids, n_shards):
     return send_local, send_perm, counts
 
 
-def shard_unroute(rows, send_perm, row_scale=None):
+def shard_unroute(rows, send_perm, row_scale=None, out=None):
     n, D = rows.shape
     rows = rows.contiguous()
-    out = torch.empty((n, D), dtype=torch.float32, device=rows.device)
+    if out is None:
+        out = torch.empty((n, D), dtype=torch.float32, device=rows.device)
+    elif out.dtype != torch.float32 or tuple(out.shape) != (n, D) or not out.is_contiguous():
+        raise TypeError("shard_unroute: out must be a contiguous float32 [n, D] tensor")
     rs = row_scale.reshape(-1).contiguous() if row_scale is not None else None
     _lib.call("mrec_shard_unroute_f32", _ptr(rows), _ptr(send_perm), n, D, _ptr(rs), _ptr(out), _stream())
     return out

@@ -267,7 +267,14 @@ class WideDeepEngine:
             return self._mlp_step_fused(emb, wide, label)
         g = self._mlp_graph
         if g is None or g["emb"].shape != emb.shape or g["emb"].dtype != emb.dtype:
-            g = self._capture_mlp(emb, wide, label)
+            try:
+                g = self._capture_mlp(emb, wide, label)
+            except RuntimeError as e:          # capture refused (e.g. a library call not capturable): stay eager
+                import warnings
+                warnings.warn(f"HIP-graph capture of the MLP step failed, running it eagerly: {e}")
+                self.cfg.graph_mlp = False
+                self._mlp_graph = None
+                return self._mlp_step_fused(emb, wide, label)
         if emb.data_ptr() != g["emb"].data_ptr():
             g["emb"].copy_(emb)
         g["wide"].copy_(wide)
@@ -282,7 +289,8 @@ class WideDeepEngine:
         g["label"].copy_(label)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: RCCL's watchdog thread may query events while this thread captures
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             g["loss"], g["g_emb"], g["g_wide"] = self._mlp_step_fused(g["emb"], g["wide"], g["label"])
         g["graph"] = graph
         self._mlp_graph = g
@@ -418,7 +426,10 @@ class WideDeepEngine:
         self._tock(ev)
         ev = self._tick("unroute")
         if wire16:
-            emb = self.k.shard_unroute(back.view(torch.float32), perm, None).view(torch.bfloat16).view(B, Fd * D)
+            eo = self._emb_out(n, D, torch.bfloat16)            # static graph input, when the MLP graph exists
+            if eo is not None:
+                eo = eo.view(torch.float32)
+            emb = self.k.shard_unroute(back.view(torch.float32), perm, None, out=eo).view(torch.bfloat16).view(B, Fd * D)
             wvals = self.k.shard_unroute(wback, perm, None).view(B, Fd)
         else:
             emb = self.k.shard_unroute(back, perm, wts.reshape(-1)).view(B, Fd * D)
