@@ -129,6 +129,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Priming (setup, whatever --warmup says): workspaces, GEMM library handles and the HIP graph of the MLP
+    # step come into being in the engine's first three steps.
+    for i in range(3):
+        eng.train_step(*batches[i % len(batches)])
+    barrier()
     for i in range(args.warmup):
         eng.train_step(*batches[i % len(batches)])
     barrier()
