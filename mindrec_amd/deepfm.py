@@ -152,3 +152,112 @@ class DeepFMEngine:
             self.k.dense_adam_(table.view(-1), m.view(-1), v.view(-1), gtab.view(-1), **kw)
         self.k.dense_adam_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, **kw)
         return loss
+
+
+class DeepFMHashEngine:
+    """BASELINE configs[4]: the DeepFM model over MapParameter hash embeddings (int64 keys, dim 128,
+    admission / eviction filters on).  The reference contains the two halves but not this composition
+    (only models/wide_deep builds a HashEmbeddingLookup, wide_and_deep.py:271-274), so it is assembled
+    the way the reference assembles Wide&Deep over hash tables:
+
+      * V (dim D) and W (dim 1) are MapParameters; a step's keys are looked up with
+        MapTensorGet(insert_default_value=True) semantics: Unique -> probe/insert -> default rows
+        (embedding.py:184-206);
+      * model math is DeepFMModel.construct (deepfm.py:206-237): linear + FM + MLP;
+      * dynamic tables have no whole-table L2 term and no dense sweep: both tables take the sparse
+        LazyAdam the reference pairs with hash tables (wide_and_deep.py:415-422), applied to admitted
+        rows only (permit_filter_value); evict() drops keys not seen for evict_filter_value steps.
+    One Unique serves both tables (same keys, as wide_and_deep.py:300-302)."""
+
+    def __init__(self, cfg: DeepFMConfig, device, key_dtype=torch.int64, capacity=1 << 22, permit_filter_value=1,
+                 evict_filter_value=None):
+        from .experimental import MAX_SIZE, MapParameter
+        self.cfg, self.device = cfg, torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DeepFMHashEngine runs on an MI355X (no CPU fallback)")
+        D, dev = cfg.data_emb_dim, self.device
+        ev = MAX_SIZE if evict_filter_value is None else evict_filter_value
+        mk = dict(key_dtype=key_dtype, default_value="normal", permit_filter_value=permit_filter_value,
+                  evict_filter_value=ev, capacity=capacity, device=dev)
+        self.V = MapParameter(value_shape=(D,), name="V_l2", seed=cfg.seed, **mk)
+        self.W = MapParameter(value_shape=(1,), name="W_l2", seed=cfg.seed + 1, **mk)
+        for t in (self.V, self.W):
+            t.add_slot("moment1", 0.0)
+            t.add_slot("moment2", 0.0)
+        dims = [cfg.data_field_size * D] + list(cfg.deep_layer_dims) + [1]
+        self.dims = dims
+        shapes = []
+        for i in range(len(dims) - 1):
+            shapes += [(dims[i], dims[i + 1]), (dims[i + 1],)]
+        n = sum(int(np.prod(s)) for s in shapes)
+        with torch.cuda.device(dev):
+            self.dense_flat = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.dense_grad_flat = torch.zeros(n, dtype=torch.float32, device=dev)
+            ops.fill_normal_(self.dense_flat.view(-1, 1), cfg.seed + 2, cfg.init_sigma)
+            self.dense, off = [], 0
+            for s in shapes:
+                k = int(np.prod(s))
+                p = self.dense_flat[off:off + k].view(s)
+                p.requires_grad_(True)
+                p.grad = self.dense_grad_flat[off:off + k].view(s)
+                self.dense.append(p)
+                off += k
+            self.dense_m = torch.zeros_like(self.dense_flat)
+            self.dense_v = torch.zeros_like(self.dense_flat)
+        self.beta1, self.beta2 = np.float32(0.9), np.float32(0.999)
+        self.beta1_power, self.beta2_power = np.float32(1.0), np.float32(1.0)
+
+    def _mlp(self, x):
+        n = len(self.dims) - 1
+        h = x
+        for i in range(n):
+            h = torch.addmm(self.dense[2 * i + 1], h, self.dense[2 * i])
+            if i < n - 1:
+                h = torch.relu(h)
+        return h
+
+    def _lookup(self, keys, insert):
+        flat = self.V._keys(keys)
+        d = ops.unique(flat)
+        _, rows_v, pos_v = self.V.lookup_rows(flat, insert=insert, dedup=d)
+        _, rows_w, pos_w = self.W.lookup_rows(flat, insert=insert, dedup=d)
+        return d, rows_v, pos_v, rows_w, pos_w
+
+    def predict(self, keys, wts):
+        B, Fd = keys.shape
+        with torch.no_grad():
+            _, _, pos_v, _, pos_w = self._lookup(keys, insert=True)
+            vx = ops.gather_rows(self.V.values, pos_v.view(B, Fd), wts)
+            linear = ops.wide_sum(self.W.values, pos_w.view(B, Fd), wts)
+            fm, _ = ops.fm_forward(vx)
+            logit = (linear + fm).view(-1, 1) + self._mlp(vx.view(B, -1))
+        return logit, torch.sigmoid(logit)
+
+    def train_step(self, keys, wts, label):
+        cfg = self.cfg
+        B, Fd = keys.shape
+        D = cfg.data_emb_dim
+        self.beta1_power = np.float32(self.beta1_power * self.beta1)
+        self.beta2_power = np.float32(self.beta2_power * self.beta2)
+        d, rows_v, pos_v, rows_w, pos_w = self._lookup(keys, insert=True)
+        vx = ops.gather_rows(self.V.values, pos_v.view(B, Fd), wts)             # [B, F, D], mask fused
+        linear = ops.wide_sum(self.W.values, pos_w.view(B, Fd), wts)             # [B]
+        vx.requires_grad_(True)
+        linear.requires_grad_(True)
+        self.dense_grad_flat.zero_()
+        fm = _FMTerm.apply(vx, ops)
+        logit = (linear + fm).view(-1, 1) + self._mlp(vx.view(B, Fd * D))
+        loss = F.binary_cross_entropy_with_logits(logit, label)
+        (loss * cfg.loss_scale).backward()
+        kw = dict(lr=cfg.learning_rate, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.epsilon,
+                  beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=1.0 / cfg.loss_scale)
+        plan = ops.group_by_inverse(d)
+        for t, rows_u, g, scale in ((self.V, rows_v, vx.grad.view(B * Fd, D), wts),
+                                    (self.W, rows_w, (linear.grad.view(B, 1) * wts).view(B * Fd, 1), None)):
+            plan.uniq_buf = t.admitted_rows(rows_u)               # groups -> table rows, un-admitted keys -> -1 (skipped)
+            ops.sparse_lazy_adam_(t.values, t.slots["moment1"]["table"], t.slots["moment2"]["table"], plan, g, scale, **kw)
+        ops.dense_adam_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, **kw)
+        return loss.detach()
+
+    def evict(self):
+        return self.V.evict(), self.W.evict()

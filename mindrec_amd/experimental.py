@@ -81,8 +81,9 @@ class MapParameter:
         # admission / eviction bookkeeping (only maintained when a filter is active)
         self._track = permit_filter_value > 1 or evict_filter_value < MAX_SIZE
         if self._track:
-            self.hits = torch.zeros(self.capacity, dtype=torch.int32, device=self.device)
-            self.last_step = torch.zeros(self.capacity, dtype=torch.int64, device=self.device)
+            # one extra slot at the end absorbs the writes of a lookup's padding entries (rows_u == -1)
+            self.hits = torch.zeros(self.capacity + 1, dtype=torch.int32, device=self.device)
+            self.last_step = torch.zeros(self.capacity + 1, dtype=torch.int64, device=self.device)
         self.step = 0
         if key_tensor is not None:
             self.put(key_tensor, value_tensor)
@@ -98,10 +99,13 @@ class MapParameter:
     def _init_kwargs(self):
         return dict(seed=self.seed, sigma=self._sigma if self._sigma is not None else 0.0, fill=self._fill)
 
-    def lookup_rows(self, keys_flat, insert=True):
+    def lookup_rows(self, keys_flat, insert=True, dedup=None):
         """(dedup, rows_uniq int32 [n], rows_pos int32 [n]) for flat device keys, without host sync:
-        Unique -> index probe / insert (misses numbered in first-occurrence order) -> default rows."""
-        d = ops.unique(keys_flat)
+        Unique -> index probe / insert (misses numbered in first-occurrence order) -> default rows.
+        `dedup`: an ops.unique(keys_flat) result to reuse when several maps are read with the same keys."""
+        d = dedup if dedup is not None else ops.unique(keys_flat)
+        if self._track and insert:
+            self.step += 1            # one inserting lookup = one training step of this table (evict threshold unit)
         k64 = ops.widen_keys(d.uniq_buf)
         rows_u, is_new = self.index.find_or_insert(k64, insert=insert, n_dev=d.n_uniq_dev)
         if insert:
@@ -111,10 +115,12 @@ class MapParameter:
         rows_pos = ops.compose_i32(rows_u, d.inv)
         if self._track and insert:
             ok = rows_u >= 0                                   # entries past U read -1
-            idx = rows_u.clamp_min(0).long()
-            self.hits.index_add_(0, idx, ok.to(torch.int32))
-            stamp = torch.full_like(idx, self.step)
-            self.last_step.scatter_(0, idx, torch.where(ok, stamp, self.last_step[idx]))
+            idx = torch.where(ok, rows_u, torch.full_like(rows_u, self.capacity)).long()
+            # a row handed to a new key (first sighting, or a row freed by an eviction) starts counting from zero
+            fresh = ok & is_new.view(-1)[: rows_u.numel()].bool()
+            cur = self.hits[idx]
+            self.hits.scatter_(0, idx, torch.where(fresh, torch.zeros_like(cur), cur) + ok.to(torch.int32))
+            self.last_step.scatter_(0, idx, torch.full_like(idx, self.step))
         return d, rows_u, rows_pos
 
     def admitted_rows(self, rows_u):

@@ -1,0 +1,113 @@
+"""BASELINE configs[4] at test size: DeepFM over MapParameter hash embeddings -- int64 keys, dim 128,
+permit_filter_value = 2, evict_filter_value = 2 -- against a reference assembled from the oracle's map,
+gather, wide-sum and sparse LazyAdam plus a torch-CPU fp32 restatement of the dense part (FM term and MLP,
+models/deepfm/src/deepfm.py:206-237).  The reference has no script for this composition (SURVEY 8(a) notes);
+the pieces follow embedding.py:184-206 and wide_and_deep.py:415-422."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _rows_view(oracle, m, cap, D):
+    pr = oracle.lib().mrec_o_map_rows_ptr
+    pr.restype = C.POINTER(C.c_float)
+    return np.ctypeslib.as_array(pr(m._h), shape=(cap, D))
+
+
+def test_deepfm_over_hash_tables_with_admission_and_eviction(dev, oracle):
+    from mindrec_amd.deepfm import DeepFMConfig, DeepFMHashEngine
+    D, Fd, B, cap = 128, 6, 48, 4096
+    cfg = DeepFMConfig(data_emb_dim=D, data_field_size=Fd, batch_size=B, deep_layer_dims=[64, 32], learning_rate=1e-2)
+    eng = DeepFMHashEngine(cfg, dev, key_dtype=torch.int64, capacity=cap, permit_filter_value=2, evict_filter_value=2)
+    # ---- reference state
+    oV, oW = oracle.Map(D, cap, seed=cfg.seed, sigma=0.01), oracle.Map(1, cap, seed=cfg.seed + 1, sigma=0.01)
+    vV, vW = _rows_view(oracle, oV, cap, D), _rows_view(oracle, oW, cap, 1)
+    st = {"V": (np.zeros((cap, D), np.float32), np.zeros((cap, D), np.float32)),
+          "W": (np.zeros((cap, 1), np.float32), np.zeros((cap, 1), np.float32))}
+    hits, last = {}, {}
+    dense = eng.dense_flat.detach().cpu().clone().requires_grad_(True)
+    dm, dv = np.zeros(dense.numel(), np.float32), np.zeros(dense.numel(), np.float32)
+    dims = eng.dims
+    b1p = b2p = np.float32(1.0)
+    rng = np.random.default_rng(5)
+    pools = [rng.integers(1, 2 ** 40, size=40), rng.integers(2 ** 41, 2 ** 42, size=40)]    # two disjoint key sets
+
+    def ref_mlp(x):
+        off, h = 0, x
+        for i in range(len(dims) - 1):
+            W = dense[off:off + dims[i] * dims[i + 1]].view(dims[i], dims[i + 1]); off += dims[i] * dims[i + 1]
+            b = dense[off:off + dims[i + 1]]; off += dims[i + 1]
+            h = torch.addmm(b, h, W)
+            if i < len(dims) - 2:
+                h = torch.relu(h)
+        return h
+
+    step = 0
+    for phase, nsteps in ((0, 3), (1, 4), (0, 2)):          # pool 0, then only pool 1 (pool 0 goes stale), then pool 0 again
+        for _ in range(nsteps):
+            step += 1
+            keys = rng.choice(pools[phase], size=(B, Fd)).astype(np.int64)
+            wts = rng.random((B, Fd)).astype(np.float32)
+            label = (rng.random((B, 1)) < 0.4).astype(np.float32)
+            lg = float(eng.train_step(T(keys, dev), T(wts, dev), T(label, dev)))
+            # ---- reference step
+            flat = keys.reshape(-1)
+            live_before = set(last)
+            rows_v = oV.find_or_insert(flat, True)
+            rows_w = oW.find_or_insert(flat, True)
+            for k in np.unique(flat):
+                k = int(k)
+                if k not in live_before:            # new (or re-inserted after eviction): fresh optimizer state and hit count
+                    hits[k] = 0
+                    for nm, rr in (("V", rows_v), ("W", rows_w)):
+                        r = int(rr[np.nonzero(flat == k)[0][0]])
+                        st[nm][0][r] = 0
+                        st[nm][1][r] = 0
+                hits[k] += 1
+                last[k] = step
+            vx = torch.from_numpy(oracle.gather_rows(vV, rows_v, wts.reshape(-1)).reshape(B, Fd, D)).requires_grad_(True)
+            lin = torch.from_numpy(oracle.wide_sum(vW, rows_w.reshape(B, Fd), wts, 0.0)).requires_grad_(True)
+            s = vx.sum(dim=1)
+            fm = 0.5 * (s * s - (vx * vx).sum(dim=1)).sum(dim=1)
+            logit = (lin + fm).view(-1, 1) + ref_mlp(vx.view(B, Fd * D))
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, torch.from_numpy(label))
+            dense.grad = None
+            (loss * cfg.loss_scale).backward()
+            lr_ = float(loss.detach())
+            assert abs(lr_ - lg) <= 2e-5 * max(abs(lr_), 1e-3), (step, lr_, lg)
+            b1p = np.float32(b1p * np.float32(0.9)); b2p = np.float32(b2p * np.float32(0.999))
+            kw = dict(lr=cfg.learning_rate, eps=cfg.epsilon, b1_pow=float(b1p), b2_pow=float(b2p), grad_scale=1.0 / cfg.loss_scale)
+            admitted = np.array([hits[int(k)] >= 2 for k in flat])
+            oracle.sparse_lazy_adam(vV, st["V"][0], st["V"][1], np.where(admitted, rows_v, -1), vx.grad.numpy().reshape(-1, D),
+                                    wts.reshape(-1), **kw)
+            gw = (lin.grad.numpy().reshape(B, 1) * wts).reshape(-1, 1)
+            oracle.sparse_lazy_adam(vW, st["W"][0], st["W"][1], np.where(admitted, rows_w, -1), gw, None, **kw)
+            p = dense.detach().numpy()
+            oracle.dense_adam(p, dm, dv, dense.grad.numpy(), **kw)
+        # ---- eviction between phases: keys unseen for more than 2 steps go
+        n_ev = eng.evict()
+        dead = [k for k, s0 in last.items() if step - s0 > 2]
+        if dead:
+            oV.erase(np.array(dead, np.int64)); oW.erase(np.array(dead, np.int64))
+            for k in dead:
+                del last[k], hits[k]
+        assert n_ev == (len(dead), len(dead)), (phase, n_ev, len(dead))
+        assert len(eng.V) == oV.size() == len(last)
+    assert any(True for _ in last)
+    # ---- final tables by key
+    keys = np.array(sorted(last), np.int64)
+    got = eng.V.get(T(keys, dev), False).cpu().numpy()
+    ref = oV.get(keys, False)
+    den = np.maximum(np.abs(ref).max(axis=1), 1e-30)
+    assert (np.abs(got - ref).max(axis=1) / den).max() <= 5e-5
+    gw_, rw_ = eng.W.get(T(keys, dev), False).cpu().numpy(), oW.get(keys, False)
+    assert np.abs(gw_ - rw_).max() <= 1e-4 * np.abs(rw_).max()
+    assert np.allclose(eng.dense_flat.detach().cpu().numpy(), dense.detach().numpy(), rtol=2e-4, atol=2e-6)
