@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--n-batches", type=int, default=4, help="distinct resident batches cycled through")
     ap.add_argument("--split-state", action="store_true", help="p, m, v as three separate arrays (default: fused rows)")
     ap.add_argument("--no-overlap-plan", action="store_true", help="run dedup + inverted index on the main stream")
+    ap.add_argument("--no-overlap-wide-apply", action="store_true", help="wide FTRL after the deep apply on the main stream")
+    ap.add_argument("--overlap-dw0", action="store_true", help="first-layer weight-gradient GEMM beside the sparse apply (side stream)")
     ap.add_argument("--no-graph-mlp", action="store_true", help="issue the fused MLP step kernel by kernel instead of replaying its HIP graph")
     ap.add_argument("--overlap-wide", action="store_true", help="also run wide_sum on the side stream (measured slower)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -119,7 +121,8 @@ def main():
     cfg = WideDeepConfig(vocab_size=args.vocab, emb_dim=args.emb_dim, field_size=args.fields, batch_size=args.batch,
                          mlp_dtype=args.mlp_dtype, fused_state=not args.split_state,
                          overlap_plan=not args.no_overlap_plan, overlap_wide=args.overlap_wide,
-                         graph_mlp=not args.no_graph_mlp)
+                         graph_mlp=not args.no_graph_mlp, overlap_dw0=args.overlap_dw0,
+                         overlap_wide_apply=not args.no_overlap_wide_apply)
     eng = WideDeepEngine(cfg, dev, rank=rank, world=world, group=group)
     batches = [synthetic_batch(cfg, dev, args.dist, seed=1000 + i, rank=rank) for i in range(args.n_batches)]
     torch.cuda.synchronize()
@@ -141,7 +144,7 @@ def main():
     ktimers = [ops.KernelTimer() for _ in range(args.steps)]     # HIP events around k_apply_main only
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ktimers[i].arm()              # the step's first sparse apply is the deep-table LazyAdam
+        eng.deep_apply_timer = ktimers[i]      # armed by the engine right before the deep-table LazyAdam launch
         eng.train_step(*batches[i % len(batches)])
     barrier()
     dt = time.perf_counter() - t0

@@ -65,6 +65,10 @@ class WideDeepConfig:
     fused_mlp: bool = True               # hand-written fwd/bwd of the mixed-precision MLP (else autograd)
     overlap_plan: bool = True            # dedup + inverted index on a side HIP stream, under the MLP
     overlap_wide: bool = False           # wide_sum on the side stream beside the deep gather (measured: slightly slower)
+    overlap_wide_apply: bool = True  # wide-table FTRL on the side stream as soon as the head's backward has produced its gradient:
+                                     # a latency-bound kernel hidden under the backward GEMMs (one GPU)
+    overlap_dw0: bool = False      # first-layer weight-gradient GEMM on the side stream beside the sparse apply: step -1 %, but the
+                                   # apply kernel shares the chip and runs 7 % longer (0.179 -> 0.192 ms), so off by default
     graph_mlp: bool = True         # replay the fused MLP forward+backward as one captured HIP graph (one host launch, not ~35)
 
 
@@ -183,6 +187,8 @@ class WideDeepEngine:
         self.timers = None            # optional dict name -> list[(start_event, stop_event)]
         self._side = torch.cuda.Stream(device=self.device) if (self._gpu and cfg.overlap_plan) else None
         self._mlp_graph = None        # dict: captured fused-MLP step + its static input / output tensors
+        self._dw0_pending = None      # graph of the deferred first-layer weight gradient, to replay this step
+        self.deep_apply_timer = None  # optional ops.KernelTimer armed right before the deep table's sparse apply
 
     # ---- collectives -------------------------------------------------------------------------
     # RCCL (backend "nccl") takes device tensors directly.  Under a gloo group with device tensors
@@ -257,14 +263,17 @@ class WideDeepEngine:
             S //= 2
         return S
 
-    def _mlp_step(self, emb, wide, label):
-        """The fused MLP step, replayed from a HIP graph once the engine has run two eager steps (library
+    def _mlp_step(self, emb, wide, label, after_head=None):
+        """The fused MLP step, replayed from HIP graphs once the engine has run two eager steps (library
         handles and workspaces exist by then).  The step was host-bound: issuing its ~35 launches took 0.8 ms of
-        Python for 1.0 ms of device time.  The graph holds exactly the kernels of the eager path, in the same
+        Python for 1.0 ms of device time.  The graphs hold exactly the kernels of the eager path, in the same
         order, on the same buffers (weights / gradients are updated in place, so their addresses are stable);
-        inputs are staged in three static tensors -- the gather writes the embeddings there directly."""
+        inputs are staged in three static tensors -- the gather writes the embeddings there directly.
+        Two graphs, cut where the wide branch's gradient appears: forward + head, then the backward; after_head
+        runs between them."""
+        self._dw0_pending = None
         if not (self.cfg.graph_mlp and self._gpu and self.step_count > 2):
-            return self._mlp_step_fused(emb, wide, label)
+            return self._mlp_step_fused(emb, wide, label, after_head=after_head)
         g = self._mlp_graph
         if g is None or g["emb"].shape != emb.shape or g["emb"].dtype != emb.dtype:
             try:
@@ -274,13 +283,17 @@ class WideDeepEngine:
                 warnings.warn(f"HIP-graph capture of the MLP step failed, running it eagerly: {e}")
                 self.cfg.graph_mlp = False
                 self._mlp_graph = None
-                return self._mlp_step_fused(emb, wide, label)
+                return self._mlp_step_fused(emb, wide, label, after_head=after_head)
         if emb.data_ptr() != g["emb"].data_ptr():
             g["emb"].copy_(emb)
         g["wide"].copy_(wide)
         g["label"].copy_(label)
-        g["graph"].replay()
-        return g["loss"], g["g_emb"], g["g_wide"]
+        g["graph_fwd"].replay()
+        if after_head is not None:
+            after_head(g["ctx"]["g_wide"])
+        g["graph_bwd"].replay()
+        self._dw0_pending = g["graph_dw0"]
+        return g["ctx"]["loss"], g["g_emb"], g["ctx"]["g_wide"]
 
     def _capture_mlp(self, emb, wide, label):
         g = {"emb": torch.empty_like(emb), "wide": torch.empty_like(wide), "label": torch.empty_like(label)}
@@ -288,11 +301,23 @@ class WideDeepEngine:
         g["wide"].copy_(wide)
         g["label"].copy_(label)
         torch.cuda.synchronize(self.device)
-        graph = torch.cuda.CUDAGraph()
+        defer = self._side is not None and self.cfg.overlap_dw0
         # thread_local: RCCL's watchdog thread may query events while this thread captures
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            g["loss"], g["g_emb"], g["g_wide"] = self._mlp_step_fused(g["emb"], g["wide"], g["label"])
-        g["graph"] = graph
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+            g["ctx"] = self._mlp_fwd_head(g["emb"], g["wide"], g["label"])
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+            g["g_emb"] = self._mlp_bwd(g["ctx"], defer_dw0=defer)
+        g["graph_fwd"], g["graph_bwd"], g["graph_dw0"] = g1, g2, None
+        if defer:
+            # third graph: the first layer's weight gradient alone (reads the static input and layer 0's dh,
+            # both kept alive here); train_step replays it on the side stream beside the sparse apply
+            g["dw0_args"] = self._dw0_args
+            g3 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g3, capture_error_mode="thread_local"):
+                self._mlp_dw(0, *g["dw0_args"])
+            g["graph_dw0"] = g3
         self._mlp_graph = g
         return g
 
@@ -304,16 +329,22 @@ class WideDeepEngine:
         return None
 
     @torch.no_grad()
-    def _mlp_step_fused(self, emb, wide, label):
-        """Forward + backward of the bf16 MLP written out by hand (no autograd graph).  `emb` arrives
-        in bf16 straight from the gather kernel, and the gradient of the MLP input is returned in bf16
-        for the sparse apply to widen on load -- the two [B, F*D] fp32<->bf16 cast passes of the
-        autograd path disappear, as do autograd's per-parameter cast and accumulate kernels.  Every
-        GEMM stays a plain addmm / mm so the shipped TunableOp table applies.  Same math as the
-        autograd path (ReLU mask = activation > 0).  Weights and biases are read from their bf16 shadows
-        (no per-step cast kernels); weight gradients are split-K batched GEMMs whose fp32 partial sums
-        land in dense_grad, like the bias and last-layer gradients.
-        Returns (loss, g_emb [B, F*D] bf16, g_wide [B] fp32)."""
+    def _mlp_dw(self, i, h, dh):
+        """Weight gradient of hidden layer i: dW = h^T dh has only (K/256)*(N/256) output tiles but a 16384-deep
+        reduction: split the batch dimension into S chunks (one batched GEMM fills the chip), sum the partials
+        in fp32 straight into the flat gradient buffer (measured: 139/78/46/36 us -> 107/30/25/25 us)."""
+        B = h.shape[0]
+        S = self._splitk(B)
+        if S > 1:
+            part = torch.bmm(h.view(S, B // S, -1).transpose(1, 2), dh.view(S, B // S, -1))
+            torch.sum(part, dim=0, dtype=torch.float32, out=self.dense_grad[2 * i])
+        else:
+            self.dense_grad[2 * i].copy_(torch.mm(h.t(), dh))
+
+    @torch.no_grad()
+    def _mlp_fwd_head(self, emb, wide, label):
+        """Hidden layers forward, then output layer + wide/deep add + sigmoid cross-entropy forward AND backward.
+        Returns the context the backward needs: hs (activations), loss, dlogit (= the wide branch's gradient), dh."""
         amp, n = self._amp, len(self.dims) - 1
         B = emb.shape[0]
         Wb = [self.dense16[2 * i] for i in range(n - 1)]              # bf16 shadows written by the dense Adam
@@ -337,17 +368,20 @@ class WideDeepEngine:
             torch.sum(dlogit, dim=0, out=self.dense_grad[2 * (n - 1) + 1])
             dh = torch.ops.aten.threshold_backward(torch.mm(dlogit, W5.t()).to(amp), hs[-1], 0)
             torch.sum(dh, dim=0, dtype=torch.float32, out=self.dense_grad[2 * (n - 2) + 1])
+        return {"hs": hs, "loss": loss, "g_wide": dlogit.view(-1), "dh": dh}
+
+    @torch.no_grad()
+    def _mlp_bwd(self, ctx, defer_dw0=False):
+        """Backward through the hidden layers; returns g_emb [B, F*D] (bf16)."""
+        n = len(self.dims) - 1
+        Wb = [self.dense16[2 * i] for i in range(n - 1)]
+        hs, dh = ctx["hs"], ctx["dh"]
         g_emb = None
         for i in range(n - 2, -1, -1):
-            # dW = h^T dh has only (K/256)*(N/256) output tiles but a 16384-deep reduction: split the batch
-            # dimension into S chunks (one batched GEMM fills the chip), sum the partials in fp32 straight
-            # into the flat gradient buffer (measured: 139/78/46/36 us -> 107/30/25/25 us for the four layers)
-            S = self._splitk(B)
-            if S > 1:
-                part = torch.bmm(hs[i].view(S, B // S, -1).transpose(1, 2), dh.view(S, B // S, -1))
-                torch.sum(part, dim=0, dtype=torch.float32, out=self.dense_grad[2 * i])
+            if i == 0 and defer_dw0:
+                self._dw0_args = (hs[0], dh)
             else:
-                self.dense_grad[2 * i].copy_(torch.mm(hs[i].t(), dh))
+                self._mlp_dw(i, hs[i], dh)
             if i > 0:
                 # ReLU bprop of layer i-1's activation + its bias gradient (column sum) in one pass
                 gpre = torch.mm(dh, Wb[i].t())
@@ -358,7 +392,25 @@ class WideDeepEngine:
                     torch.sum(dh, dim=0, dtype=torch.float32, out=self.dense_grad[2 * (i - 1) + 1])
             else:
                 g_emb = torch.mm(dh, Wb[0].t())
-        return loss, g_emb, dlogit.view(-1)
+        return g_emb
+
+    def _mlp_step_fused(self, emb, wide, label, defer_dw0=False, after_head=None):
+        """Forward + backward of the bf16 MLP written out by hand (no autograd graph).  `emb` arrives
+        in bf16 straight from the gather kernel, and the gradient of the MLP input is returned in bf16
+        for the sparse apply to widen on load -- the two [B, F*D] fp32<->bf16 cast passes of the
+        autograd path disappear, as do autograd's per-parameter cast and accumulate kernels.  Every
+        GEMM stays a plain addmm / mm so the shipped TunableOp table applies.  Same math as the
+        autograd path (ReLU mask = activation > 0).  Weights and biases are read from their bf16 shadows
+        (no per-step cast kernels); weight gradients are split-K batched GEMMs whose fp32 partial sums
+        land in dense_grad, like the bias and last-layer gradients.
+        Returns (loss, g_emb [B, F*D] bf16, g_wide [B] fp32).  after_head(g_wide) is called as soon as the wide
+        branch's gradient exists (the caller may start the wide table's update beside the backward GEMMs).
+        defer_dw0=True leaves the first layer's weight gradient to the caller (self._mlp_dw(0, *self._dw0_args))."""
+        ctx = self._mlp_fwd_head(emb, wide, label)
+        if after_head is not None:
+            after_head(ctx["g_wide"])
+        g_emb = self._mlp_bwd(ctx, defer_dw0)
+        return ctx["loss"], g_emb, ctx["g_wide"]
 
     # ---- forward (eval path: PredictWithSigmoid, wide_and_deep.py:495-518) ---------------------
     def lookup(self, ids, wts):
@@ -477,8 +529,22 @@ class WideDeepEngine:
 
         ev = self._tick("mlp_fwd_bwd")
         fused = self._fused_bf16()
+        wide_done = False
         if fused:
-            loss, g_emb, g_wide = self._mlp_step(emb, wide, label)
+            after_head = None
+            if plan_early is not None and route is None and cfg.overlap_wide_apply:
+                def after_head(gw_b):
+                    # wide FTRL beside the backward GEMMs: needs only the plan (already on the side stream, in order)
+                    # and the head's dlogit.  The Mul bprop of wide_mul (:304) is applied as row_scale.
+                    main = torch.cuda.current_stream()
+                    self._side.wait_event(main.record_event())
+                    gw_b.record_stream(self._side)
+                    with torch.cuda.stream(self._side):
+                        gw = gw_b.view(B, 1).expand(B, Fd).reshape(B * Fd, 1)
+                        self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan_early, gw, wts, lr=cfg.ftrl_lr,
+                                            l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=inv_sens)
+                wide_done = True
+            loss, g_emb, g_wide = self._mlp_step(emb, wide, label, after_head=after_head)
             if route is not None and route[4] is None:
                 g_emb = g_emb.float()          # fp32 wire format
         else:
@@ -493,28 +559,37 @@ class WideDeepEngine:
 
         gb = g_wide.sum().view(1)
         dense_work = None
+        if plan_early is not None:
+            torch.cuda.current_stream().wait_stream(self._side)          # the plan (queued long ago) is done
+        if self._dw0_pending is not None:
+            # first layer's weight gradient: a compute-bound GEMM nobody needs before the dense Adam -- on the
+            # side stream, beside the HBM-bound sparse applies (one GPU) / the row-gradient exchange (shards)
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                self._dw0_pending.replay()
+            self._dw0_pending = None
 
         if route is None:
             ev = self._tick("plan")
-            if plan_early is not None:
-                torch.cuda.current_stream().wait_stream(self._side)
-                plan = plan_early
-            else:
-                plan = self.k.sparse_plan(ids)
+            plan = plan_early if plan_early is not None else self.k.sparse_plan(ids)
             self._tock(ev)
             # (Running the wide FTRL apply on the side stream beside the deep apply was tried and rejected:
             # sharing CUs drops the deep kernel from 5.0 to 4.0 TB/s and the step gets 0.11 ms longer.)
             ev = self._tick("apply_deep")
+            if self.deep_apply_timer is not None:
+                self.deep_apply_timer.arm()
+                self.deep_apply_timer = None
             self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, lr=cfg.adam_lr,
                                   beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
                                   beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
                                   grad_scale=inv_sens)
             self._tock(ev)
-            ev = self._tick("apply_wide")
-            gw = g_wide.view(B, 1).expand(B, Fd).reshape(B * Fd, 1)      # Mul bprop of wide_mul (:304): the mask is
-            self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, gw, wts, lr=cfg.ftrl_lr,   # applied as row_scale
-                                l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=inv_sens)
-            self._tock(ev)
+            if not wide_done:
+                ev = self._tick("apply_wide")
+                gw = g_wide.view(B, 1).expand(B, Fd).reshape(B * Fd, 1)      # Mul bprop of wide_mul (:304): the mask is
+                self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, gw, wts, lr=cfg.ftrl_lr,   # applied as row_scale
+                                    l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=inv_sens)
+                self._tock(ev)
         else:
             perm, send_counts, recv_counts, recv_local, recv_wts = route
             ev = self._tick("a2a_grads")
@@ -543,19 +618,20 @@ class WideDeepEngine:
             # Dense gradients (+ the wide bias gradient riding in the same buffer): all-reduce queued behind the
             # row-gradient exchange and left running while the sparse applies execute -- they do not need it.
             ev = self._tick("allreduce_dense")
+            if self._side is not None:
+                torch.cuda.current_stream().wait_stream(self._side)      # deferred dW0 has landed in dense_grad
             self.dense_grad_ext[-1:].copy_(gb)
             dense_work = self._all_reduce(self.dense_grad_ext, async_op=True)
             self._tock(ev)
             ev = self._tick("plan")
-            if plan_early is not None:
-                torch.cuda.current_stream().wait_stream(self._side)
-                plan = plan_early
-            else:
-                plan = self.k.sparse_plan(recv_local)
+            plan = plan_early if plan_early is not None else self.k.sparse_plan(recv_local)
             self._tock(ev)
             # RowTensor gradients of all ranks are summed at the owner; gradients_mean divides by world
             scale = inv_sens / self.world
             ev = self._tick("apply_deep")
+            if self.deep_apply_timer is not None:
+                self.deep_apply_timer.arm()
+                self.deep_apply_timer = None
             self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, recv_g, row_scale, lr=cfg.adam_lr,
                                   beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
                                   beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
@@ -571,6 +647,8 @@ class WideDeepEngine:
                 dense_work.wait()                     # the current stream waits for RCCL's stream; no host block
             self.dense_grad_ext.div_(self.world)      # gradients_mean=True (train_and_eval_distribute.py:137)
             gb = self.dense_grad_ext[-1:]
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)          # deferred dW0
         ev = self._tick("apply_dense")
         akw = dict(lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
                    beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=inv_sens)

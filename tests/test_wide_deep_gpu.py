@@ -154,14 +154,15 @@ def test_deepfm_engine_matches_oracle_engine(dev, oracle):
     assert np.allclose(logit.cpu().numpy(), lc2.numpy(), rtol=1e-3, atol=1e-4)
 
 
-def test_graph_replay_is_bit_identical_to_eager(dev):
+@pytest.mark.parametrize("overlap_dw0", [False, True])
+def test_graph_replay_is_bit_identical_to_eager(dev, overlap_dw0):
     """The captured MLP step holds the same kernels in the same order on the same buffers as the eager
     path: losses, tables and dense parameters must agree bit for bit over several steps (the graph is
     captured on step 3 and replayed from then on, with a different batch every step)."""
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     kw = dict(vocab_size=50000, emb_dim=16, field_size=26, batch_size=2048, deep_layer_dim=[256, 128, 64, 32],
               mlp_dtype="bf16")
-    a = WideDeepEngine(WideDeepConfig(graph_mlp=True, **kw), dev)
+    a = WideDeepEngine(WideDeepConfig(graph_mlp=True, overlap_dw0=overlap_dw0, **kw), dev)
     b = WideDeepEngine(WideDeepConfig(graph_mlp=False, **kw), dev)
     assert a.dense16 is not None, "fused bf16 MLP path expected"
     for s in range(7):
