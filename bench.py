@@ -182,6 +182,20 @@ def main():
                    and args.dist == "uniform" and not args.split_state and world == 1 and args.mlp_dtype == "bf16")
     if default_cfg and os.path.exists(pmc_path):
         traffic = json.load(open(pmc_path)).get("apply_main_adam", {}).get("total_bytes")
+    # streaming-copy ceiling of this box, measured in this run (outside the timed region): 1 GiB device-to-device
+    copy_gbps = None
+    if rank == 0:
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = round(5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del src, dst
     out = {
         "metric": "samples/sec Wide&Deep Criteo batch16384",
         "value": round(args.batch * world * args.steps / dt, 1),
@@ -205,6 +219,7 @@ def main():
                      "row_gradient_dtype": "bf16" if bf16_io else "f32",
                      "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "algorithmic_bytes": by["apply_deep"], "avg_ms": round(apply_ms, 5),
+                     "measured_copy_gbps": copy_gbps,
                      "timing": "HIP events around k_apply_main on its launch stream (mrec_profile_next_apply), "
                                "averaged over the timed steps"},
         "kernels_ms": {k: round(sum(v) / len(v), 5) for k, v in sorted(kern_ms.items())},

@@ -424,18 +424,13 @@ template <int NPL, int LT>
 int launch_bwd_lt(const float* x0, const float* w, const float* cvec, int L, int64_t B, int D, const float* dy, float* dx0,
                   float* slabs, unsigned blocks, hipStream_t st) {
     constexpr int DP = NPL * 64;
-    const size_t slab = ((size_t)(L + 1) * DP + L) * sizeof(float);   // block slab, <= 74 KB (D <= 2048, L <= 8)
+    // w of all layers (<= 8 x 2048 floats = 64 KB) always fits in LDS; the block slab reuses the same area
+    const size_t slab = ((size_t)(L + 1) * DP + L) * sizeof(float);   // <= 74 KB (D <= 2048, L <= 8)
     const size_t wlds = (size_t)L * DP * sizeof(float);
-    if (wlds > 0 && wlds <= kMaxLds) {
-        const size_t lds = wlds > slab ? wlds : slab;
-        int rc = set_lds(k_cross_bwd<NPL, LT, true>, lds);
-        if (rc != MREC_OK) return rc;
-        k_cross_bwd<NPL, LT, true><<<blocks, BWD_NT, lds, st>>>(x0, w, cvec, L, B, D, dy, dx0, slabs);
-    } else {
-        int rc = set_lds(k_cross_bwd<NPL, LT, false>, slab);
-        if (rc != MREC_OK) return rc;
-        k_cross_bwd<NPL, LT, false><<<blocks, BWD_NT, slab, st>>>(x0, w, cvec, L, B, D, dy, dx0, slabs);
-    }
+    const size_t lds = wlds > slab ? wlds : slab;
+    int rc = set_lds(k_cross_bwd<NPL, LT, true>, lds);
+    if (rc != MREC_OK) return rc;
+    k_cross_bwd<NPL, LT, true><<<blocks, BWD_NT, lds, st>>>(x0, w, cvec, L, B, D, dy, dx0, slabs);
     return MREC_OK;
 }
 
@@ -487,7 +482,15 @@ MREC_API int mrec_cross_layers_bwd_f32(const float* x0, const float* w, const fl
     float* cvec = R + slab_floats(D);                       // LMAX*LMAX pair dots in the workspace's 256-byte tail
     if (L > 0) k_cross_beta_dot<<<(unsigned)(L * L), 256, 0, st>>>(w, b, L, D, cvec);
     int rc = MREC_OK;
-    MREC_NPL_DISPATCH(npl, (rc = launch_bwd<N_>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st)));
+    // the backward's register-heavy instantiations use coarser column buckets (compile time)
+    const int nb = npl <= 4 ? 4 : (npl <= 8 ? 8 : (npl <= 16 ? 16 : (npl <= 20 ? 20 : 32)));
+    switch (nb) {
+        case 4: rc = launch_bwd<4>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st); break;
+        case 8: rc = launch_bwd<8>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st); break;
+        case 16: rc = launch_bwd<16>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st); break;
+        case 20: rc = launch_bwd<20>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st); break;
+        default: rc = launch_bwd<32>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st); break;
+    }
     if (rc != MREC_OK) return rc;
     if (L > 0) {
         k_cross_bwd_sum<<<dim3((unsigned)mrec_cdiv(D, 32), (unsigned)(L + 2)), 1024, 0, st>>>(slabs, nslabs, L, D, R);
