@@ -51,17 +51,17 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16"])
-def test_two_ranks_one_gpu_match_single_process(dev, tmp_path, mlp_dtype):
+@pytest.mark.parametrize("mlp_dtype,world", [("fp32", 2), ("bf16", 2), ("bf16", 4)])
+def test_ranks_on_one_gpu_match_single_process(dev, tmp_path, mlp_dtype, world):
     """fp32: fp32 rows on the wire.  bf16: the production path -- weights travel with the ids, bf16 rows and
     bf16 row-gradients on the wire, hand-written MLP step."""
     global MLP_DTYPE
     from mindrec_amd.wide_deep import WideDeepEngine, synthetic_batch
     MLP_DTYPE = mlp_dtype
-    world, steps = 2, 3
+    steps = 4          # the MLP graphs are captured on step 3 and replayed on step 4
     mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), mlp_dtype), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
-    eng = WideDeepEngine(_cfg(256), dev)
+    eng = WideDeepEngine(_cfg(128 * world), dev)
     losses = []
     for s in range(steps):
         parts = [synthetic_batch(_cfg(128), dev, "zipf", seed=50 + s, rank=k) for k in range(world)]
@@ -77,7 +77,16 @@ def test_two_ranks_one_gpu_match_single_process(dev, tmp_path, mlp_dtype):
         tol = 2e-5 if mlp_dtype == "fp32" else 2e-2
         assert np.abs(merged - full).max() <= tol * scale, name
         assert np.array_equal((merged != 0).any(axis=1), (full != 0).any(axis=1)) or name == "wide"   # same rows touched
-    assert np.array_equal(r[0]["dense"], r[1]["dense"])
-    rt = 1e-4 if mlp_dtype == "fp32" else 5e-2
-    assert np.allclose(r[0]["dense"], eng.dense_flat.detach().cpu().numpy(), rtol=rt, atol=1e-5 if mlp_dtype == "bf16" else 1e-7)
-    assert np.allclose((r[0]["losses"] + r[1]["losses"]) / 2, losses, rtol=1e-5 if mlp_dtype == "fp32" else 2e-3)
+    for k in range(1, world):
+        assert np.array_equal(r[0]["dense"], r[k]["dense"])
+    ref_dense = eng.dense_flat.detach().cpu().numpy()
+    if mlp_dtype == "fp32":
+        assert np.allclose(r[0]["dense"], ref_dense, rtol=1e-4, atol=1e-7)
+    else:
+        # bf16 GEMMs of different shapes (batch 128 per rank vs 128 * world) round differently; Adam turns a flipped
+        # sign of a near-zero gradient element into a full +-lr step, so bound the difference by the steps taken
+        # and ask the bulk of the parameters to agree closely
+        diff = np.abs(r[0]["dense"] - ref_dense)
+        assert diff.max() <= 2.0 * eng.cfg.adam_lr * steps
+        assert np.mean(diff <= 5e-2 * np.abs(ref_dense) + 1e-5) >= 0.99
+    assert np.allclose(sum(r[k]["losses"] for k in range(world)) / world, losses, rtol=1e-5 if mlp_dtype == "fp32" else 2e-3)

@@ -1,4 +1,4 @@
-"""world_size-2 gloo test (CPU) of the row-sharded Wide&Deep step: two ranks, each with its own
+"""world_size-2 and -4 gloo tests (CPU) of the row-sharded Wide&Deep step: two ranks, each with its own
 batch and half of both tables, must reproduce the single-process step on the concatenated batch.
 The kernels are stood in by the oracle (tests/_oracle_ops.py); what is under test is the engine's
 host logic: routing, the all-to-all protocol, row-gradient exchange and gradient averaging."""
@@ -52,15 +52,17 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_sharded_step_matches_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_step_matches_single_process(tmp_path, world):
+    """world = 4 with V = 997 also covers shards of unequal length (250, 249, 249, 249 rows)."""
     import _oracle_ops
     from mindrec_amd.wide_deep import WideDeepEngine
-    world, steps = 2, 3
+    steps = 3
     mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path)), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
 
-    # single process, concatenated batch of 2 x 24
-    cfg1 = _cfg(48)
+    # single process, concatenated batch of world x 24
+    cfg1 = _cfg(24 * world)
     eng = WideDeepEngine(cfg1, "cpu", kernels=_oracle_ops)
     losses = []
     for s in range(steps):
@@ -81,9 +83,10 @@ def test_two_rank_sharded_step_matches_single_process(tmp_path):
     for k in range(world):
         assert np.allclose(r[k]["dense"], eng.dense_flat.detach().numpy(), rtol=2e-5, atol=1e-7)   # DP: replicas agree
         assert np.allclose(r[k]["wide_b"], eng.wide_b.numpy(), rtol=2e-5, atol=1e-8)
-    assert np.array_equal(r[0]["dense"], r[1]["dense"])
+    for k in range(1, world):
+        assert np.array_equal(r[0]["dense"], r[k]["dense"])
     # mean of the per-rank mean losses == loss of the concatenated batch
-    assert np.allclose((r[0]["losses"] + r[1]["losses"]) / 2, losses, rtol=1e-5)
+    assert np.allclose(sum(r[k]["losses"] for k in range(world)) / world, losses, rtol=1e-5)
 
 
 def test_engine_refuses_cpu_without_kernels():
