@@ -67,6 +67,8 @@ class WideDeepConfig:
     overlap_wide: bool = False           # wide_sum on the side stream beside the deep gather (measured: slightly slower)
     overlap_wide_apply: bool = True  # wide-table FTRL on the side stream as soon as the head's backward has produced its gradient:
                                      # a latency-bound kernel hidden under the backward GEMMs (one GPU)
+    parallel_dw: bool = False      # weight-gradient GEMMs on a parallel branch of the backward (their own stream / graph branch):
+                                   # measured slower (0.93 -> 0.98 ms/step): two GEMMs sharing the CUs lose more than the gaps they fill
     overlap_dw0: bool = False      # first-layer weight-gradient GEMM on the side stream beside the sparse apply: step -1 %, but the
                                    # apply kernel shares the chip and runs 7 % longer (0.179 -> 0.192 ms), so off by default
     graph_mlp: bool = True         # replay the fused MLP forward+backward as one captured HIP graph (one host launch, not ~35)
@@ -186,6 +188,7 @@ class WideDeepEngine:
         self._amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[cfg.mlp_dtype]
         self.timers = None            # optional dict name -> list[(start_event, stop_event)]
         self._side = torch.cuda.Stream(device=self.device) if (self._gpu and cfg.overlap_plan) else None
+        self._dw_stream = torch.cuda.Stream(device=self.device) if (self._gpu and cfg.parallel_dw) else None
         self._mlp_graph = None        # dict: captured fused-MLP step + its static input / output tensors
         self._dw0_pending = None      # graph of the deferred first-layer weight gradient, to replay this step
         self.deep_apply_timer = None  # optional ops.KernelTimer armed right before the deep table's sparse apply
@@ -377,9 +380,19 @@ class WideDeepEngine:
         Wb = [self.dense16[2 * i] for i in range(n - 1)]
         hs, dh = ctx["hs"], ctx["dh"]
         g_emb = None
+        # The weight gradients hang off the dh chain as leaves: issue them on a second stream (a parallel branch
+        # when captured into the graph) so their GEMMs and split-K reductions fill the gaps the chain's small
+        # kernels (ReLU bprop + column sums) and GEMM tails leave on the chip.
+        main, br = torch.cuda.current_stream(), self._dw_stream
         for i in range(n - 2, -1, -1):
             if i == 0 and defer_dw0:
                 self._dw0_args = (hs[0], dh)
+            elif br is not None:
+                br.wait_stream(main)
+                hs[i].record_stream(br)
+                dh.record_stream(br)
+                with torch.cuda.stream(br):
+                    self._mlp_dw(i, hs[i], dh)
             else:
                 self._mlp_dw(i, hs[i], dh)
             if i > 0:
@@ -392,6 +405,8 @@ class WideDeepEngine:
                     torch.sum(dh, dim=0, dtype=torch.float32, out=self.dense_grad[2 * (i - 1) + 1])
             else:
                 g_emb = torch.mm(dh, Wb[0].t())
+        if br is not None:
+            main.wait_stream(br)
         return g_emb
 
     def _mlp_step_fused(self, emb, wide, label, defer_dw0=False, after_head=None):
