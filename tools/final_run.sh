@@ -16,4 +16,10 @@ python tools/dcn_bench.py > gpurun_out/final/dcn_bench.txt 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/crossprof -- python3 tools/cross_probe.py > /dev/null 2>&1
 python tools/prof_summary.py $(find gpurun_out/final/crossprof -name "*kernel_stats.csv") > gpurun_out/final/cross_kernel_summary.txt
 cat gpurun_out/final/paths_bench.txt gpurun_out/final/dcn_bench.txt
-rm -rf gpurun_out/final/prof gpurun_out/final/crossprof gpurun_out/final/pmc_fetch/*/*.db
+
+# id-distribution sweep: uniform / Zipf(1.05), 26 / 39 fields
+for d in uniform zipf; do for f in 26 39; do
+  python bench.py --no-cpu-baseline --dist $d --fields $f 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$d', $f, 'fields:', d['value'], 'samples/s', d['ms_per_step'], 'ms/step, U/N', d['config']['unique_frac'], ', apply', d['roofline']['avg_ms'], 'ms', d['roofline']['achieved'], 'GB/s')"
+done; done > gpurun_out/final/dist_sweep.txt
+cat gpurun_out/final/dist_sweep.txt
+rm -rf gpurun_out/final/prof gpurun_out/final/crossprof
