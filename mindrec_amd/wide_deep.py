@@ -67,6 +67,11 @@ class WideDeepConfig:
     overlap_wide: bool = False           # wide_sum on the side stream beside the deep gather (measured: slightly slower)
     overlap_wide_apply: bool = True  # wide-table FTRL on the side stream as soon as the head's backward has produced its gradient:
                                      # a latency-bound kernel hidden under the backward GEMMs (one GPU)
+    early_route: bool = False      # shards: bucket the ids and run the request exchange (sizes, ids, weights) on the side stream
+                                   # WITHOUT waiting for the previous step's tail on the main stream -- it hides three small
+                                   # collectives, the routing kernels and the bucket-size host sync under the previous step's
+                                   # applies.  Requires ids / wts to be complete in HBM when train_step is called (bench.py: yes)
+    early_wide_grad: bool = True   # shards: the wide branch's row-gradient exchange starts at the head's backward, under the backward GEMMs
     parallel_dw: bool = False      # weight-gradient GEMMs on a parallel branch of the backward (their own stream / graph branch):
                                    # measured slower (0.93 -> 0.98 ms/step): two GEMMs sharing the CUs lose more than the gaps they fill
     overlap_dw0: bool = False      # first-layer weight-gradient GEMM on the side stream beside the sparse apply: step -1 %, but the
@@ -198,6 +203,11 @@ class WideDeepEngine:
     # (debugging several ranks on one GPU, or CPU tests) the payload is staged through host memory.
     def _staged(self):
         return self._gpu and dist.get_backend(self.group) == "gloo"
+
+    def _staged_blocking(self):
+        """Collectives issued from a hook in the middle of the step need a backend that runs them on the device
+        timeline (RCCL).  The gloo-staged debug path works too (it simply blocks the host), so nothing is excluded."""
+        return False
 
     def _all_to_all(self, out, inp, out_splits=None, in_splits=None):
         if self._staged():
@@ -458,24 +468,35 @@ class WideDeepEngine:
         ev = self._tick("route")
         n = ids.numel()
         D = cfg.emb_dim
-        send_local, perm, counts = self.k.shard_route(ids, self.world)
-        send_counts = counts.tolist()                                    # host sync: n_shards ints
-        recv_counts_t = torch.empty_like(counts)
-        self._all_to_all(recv_counts_t, counts)
-        recv_counts = recv_counts_t.tolist()
-        n_recv = int(sum(recv_counts))
-        recv_local = torch.empty(n_recv, dtype=ids.dtype, device=self.device)
-        self._all_to_all(recv_local, send_local, recv_counts, send_counts)
         wire16 = self._fused_bf16() and torch.is_grad_enabled() and D % 2 == 0
-        recv_wts = None
-        if wire16:
-            # bf16 on the wire: the per-position weights travel with the ids so the OWNER applies the mask in
-            # fp32 and rounds once to bf16 -- bit-identical to the one-GPU gather -- and rows / row-gradients
-            # cross xGMI at half the bytes.  A row of D bf16 is moved as D/2 fp32 words (pure permutation).
-            send_w = self.k.shard_route_rows(wts.reshape(n, 1), perm, None)
-            recv_wts = torch.empty((n_recv, 1), dtype=torch.float32, device=self.device)
-            self._all_to_all(recv_wts, send_w, recv_counts, send_counts)
-            recv_wts = recv_wts.view(-1)
+        early = self._side is not None and cfg.early_route and torch.is_grad_enabled()
+        main = torch.cuda.current_stream() if self._gpu else None
+        with (torch.cuda.stream(self._side) if early else contextlib.nullcontext()):
+            # early: issued on the side stream, so neither the routing kernels, nor the host sync for the bucket
+            # sizes, nor the collectives (RCCL orders them after the *current* stream) wait for the main stream,
+            # where the previous step's sparse applies may still be running.
+            send_local, perm, counts = self.k.shard_route(ids, self.world)
+            send_counts = counts.tolist()                                    # host sync: n_shards ints
+            recv_counts_t = torch.empty_like(counts)
+            self._all_to_all(recv_counts_t, counts)
+            recv_counts = recv_counts_t.tolist()
+            n_recv = int(sum(recv_counts))
+            recv_local = torch.empty(n_recv, dtype=ids.dtype, device=self.device)
+            self._all_to_all(recv_local, send_local, recv_counts, send_counts)
+            recv_wts = None
+            if wire16:
+                # bf16 on the wire: the per-position weights travel with the ids so the OWNER applies the mask in
+                # fp32 and rounds once to bf16 -- bit-identical to the one-GPU gather -- and rows / row-gradients
+                # cross xGMI at half the bytes.  A row of D bf16 is moved as D/2 fp32 words (pure permutation).
+                send_w = self.k.shard_route_rows(wts.reshape(n, 1), perm, None)
+                recv_wts = torch.empty((n_recv, 1), dtype=torch.float32, device=self.device)
+                self._all_to_all(recv_wts, send_w, recv_counts, send_counts)
+                recv_wts = recv_wts.view(-1)
+        if early:
+            main.wait_stream(self._side)
+            for t in (send_local, perm, recv_local, recv_wts):
+                if t is not None:
+                    t.record_stream(main)
         self._tock(ev)
         ev = self._tick("gather_deep")
         if wire16:
@@ -559,6 +580,28 @@ class WideDeepEngine:
                         self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan_early, gw, wts, lr=cfg.ftrl_lr,
                                             l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=inv_sens)
                 wide_done = True
+            early_gw = None
+            if (after_head is None and route is not None and self._side is not None and cfg.early_wide_grad
+                    and not self._staged_blocking()):
+                holder = {}
+
+                def after_head(gw_b):
+                    # shards: the wide branch's row-gradients need only the head's dlogit -- bucket them and start
+                    # their all-to-all now, on the side stream, while the backward GEMMs run on the main stream
+                    perm_, send_counts_, recv_counts_, recv_local_, recv_wts_ = route
+                    main = torch.cuda.current_stream()
+                    self._side.wait_event(main.record_event())
+                    gw_b.record_stream(self._side)
+                    with torch.cuda.stream(self._side):
+                        if recv_wts_ is not None:
+                            gw = gw_b.view(B, 1).expand(B, Fd).reshape(B * Fd, 1).contiguous()
+                        else:
+                            gw = (gw_b.view(B, 1) * wts).view(B * Fd, 1)
+                        send_gw = self.k.shard_route_rows(gw, perm_, None)
+                        recv_gw = torch.empty((recv_local_.numel(), 1), dtype=torch.float32, device=self.device)
+                        self._all_to_all(recv_gw, send_gw, recv_counts_, send_counts_)
+                    holder["recv_gw"] = recv_gw
+                early_gw = holder
             loss, g_emb, g_wide = self._mlp_step(emb, wide, label, after_head=after_head)
             if route is not None and route[4] is None:
                 g_emb = g_emb.float()          # fp32 wire format
@@ -609,6 +652,7 @@ class WideDeepEngine:
             perm, send_counts, recv_counts, recv_local, recv_wts = route
             ev = self._tick("a2a_grads")
             n_recv = recv_local.numel()
+            have_gw = fused and early_gw is not None and "recv_gw" in early_gw
             if recv_wts is not None:
                 # bf16 wire: raw bf16 row-gradients travel (as D/2 fp32 words); the owner multiplies by the
                 # weights it received in the forward, inside the apply kernel, exactly as on one GPU
@@ -616,19 +660,25 @@ class WideDeepEngine:
                 recv_g32 = torch.empty((n_recv, D // 2), dtype=torch.float32, device=self.device)
                 self._all_to_all(recv_g32, send_g, recv_counts, send_counts)
                 recv_g = recv_g32.view(torch.bfloat16)
-                gw = g_wide.view(B, 1).expand(B, Fd).reshape(B * Fd, 1).contiguous()
-                send_gw = self.k.shard_route_rows(gw, perm, None)
+                if not have_gw:
+                    gw = g_wide.view(B, 1).expand(B, Fd).reshape(B * Fd, 1).contiguous()
+                    send_gw = self.k.shard_route_rows(gw, perm, None)
                 row_scale = recv_wts
             else:
                 wflat = wts.reshape(-1)
                 send_g = self.k.shard_route_rows(g_emb.view(B * Fd, D), perm, wflat)
-                gw = (g_wide.view(B, 1) * wts).view(B * Fd, 1)
-                send_gw = self.k.shard_route_rows(gw, perm, None)
+                if not have_gw:
+                    gw = (g_wide.view(B, 1) * wts).view(B * Fd, 1)
+                    send_gw = self.k.shard_route_rows(gw, perm, None)
                 recv_g = torch.empty((n_recv, D), dtype=torch.float32, device=self.device)
                 self._all_to_all(recv_g, send_g, recv_counts, send_counts)
                 row_scale = None
-            recv_gw = torch.empty((n_recv, 1), dtype=torch.float32, device=self.device)
-            self._all_to_all(recv_gw, send_gw, recv_counts, send_counts)
+            if have_gw:
+                recv_gw = early_gw["recv_gw"]          # exchanged on the side stream during the backward; joined below
+                recv_gw.record_stream(torch.cuda.current_stream())
+            else:
+                recv_gw = torch.empty((n_recv, 1), dtype=torch.float32, device=self.device)
+                self._all_to_all(recv_gw, send_gw, recv_counts, send_counts)
             self._tock(ev)
             # Dense gradients (+ the wide bias gradient riding in the same buffer): all-reduce queued behind the
             # row-gradient exchange and left running while the sparse applies execute -- they do not need it.

@@ -18,15 +18,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MLP_DTYPE = "fp32"
 
 
+EARLY_ROUTE = False
+
+
 def _cfg(B, fields=39, mlp_dtype=None):
     from mindrec_amd.wide_deep import WideDeepConfig
     return WideDeepConfig(vocab_size=30_011, emb_dim=80, field_size=fields, batch_size=B, deep_layer_dim=[64, 32],
-                          mlp_dtype=mlp_dtype or MLP_DTYPE)
+                          mlp_dtype=mlp_dtype or MLP_DTYPE, early_route=EARLY_ROUTE)
 
 
-def _worker(rank, world, port, steps, out_dir, mlp_dtype="fp32"):
-    global MLP_DTYPE
+def _worker(rank, world, port, steps, out_dir, mlp_dtype="fp32", early_route=False):
+    global MLP_DTYPE, EARLY_ROUTE
     MLP_DTYPE = mlp_dtype
+    EARLY_ROUTE = early_route
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -51,15 +55,17 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mlp_dtype,world", [("fp32", 2), ("bf16", 2), ("bf16", 4)])
-def test_ranks_on_one_gpu_match_single_process(dev, tmp_path, mlp_dtype, world):
+@pytest.mark.parametrize("mlp_dtype,world,early_route", [("fp32", 2, False), ("bf16", 2, False), ("bf16", 2, True), ("bf16", 4, True)])
+def test_ranks_on_one_gpu_match_single_process(dev, tmp_path, mlp_dtype, world, early_route):
     """fp32: fp32 rows on the wire.  bf16: the production path -- weights travel with the ids, bf16 rows and
-    bf16 row-gradients on the wire, hand-written MLP step."""
+    bf16 row-gradients on the wire, hand-written MLP step.  early_route: the request exchange runs on the side stream
+    without waiting for the previous step's tail (the batches here are complete in HBM before each step: the
+    workers synchronise through float(loss))."""
     global MLP_DTYPE
     from mindrec_amd.wide_deep import WideDeepEngine, synthetic_batch
     MLP_DTYPE = mlp_dtype
     steps = 4          # the MLP graphs are captured on step 3 and replayed on step 4
-    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), mlp_dtype), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), mlp_dtype, early_route), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
     eng = WideDeepEngine(_cfg(128 * world), dev)
     losses = []
