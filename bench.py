@@ -38,9 +38,11 @@ def parse():
     ap.add_argument("--split-state", action="store_true", help="p, m, v as three separate arrays (default: fused rows)")
     ap.add_argument("--no-overlap-plan", action="store_true", help="run dedup + inverted index on the main stream")
     ap.add_argument("--no-overlap-wide-apply", action="store_true", help="wide FTRL after the deep apply on the main stream")
+    ap.add_argument("--late-wide", choices=["auto", "on", "off"], default="auto", help="wide branch on the side stream under the hidden-layer GEMMs (auto: when sharded)")
     ap.add_argument("--no-early-route", action="store_true", help="shards: request exchange on the main stream (waits for the previous step)")
     ap.add_argument("--parallel-dw", action="store_true", help="weight-gradient GEMMs on a parallel branch of the backward (measured slower)")
     ap.add_argument("--overlap-dw0", action="store_true", help="first-layer weight-gradient GEMM beside the sparse apply (side stream)")
+    ap.add_argument("--no-graph-front", action="store_true", help="one GPU: only the MLP as HIP graphs, lookups / plan issued kernel by kernel")
     ap.add_argument("--no-graph-mlp", action="store_true", help="issue the fused MLP step kernel by kernel instead of replaying its HIP graph")
     ap.add_argument("--overlap-wide", action="store_true", help="also run wide_sum on the side stream (measured slower)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -123,7 +125,7 @@ def main():
     cfg = WideDeepConfig(vocab_size=args.vocab, emb_dim=args.emb_dim, field_size=args.fields, batch_size=args.batch,
                          mlp_dtype=args.mlp_dtype, fused_state=not args.split_state,
                          overlap_plan=not args.no_overlap_plan, overlap_wide=args.overlap_wide,
-                         graph_mlp=not args.no_graph_mlp, overlap_dw0=args.overlap_dw0, parallel_dw=args.parallel_dw, early_route=not args.no_early_route,
+                         graph_mlp=not args.no_graph_mlp, graph_front=not args.no_graph_front, overlap_dw0=args.overlap_dw0, parallel_dw=args.parallel_dw, early_route=not args.no_early_route, late_wide={'auto': None, 'on': True, 'off': False}[args.late_wide],
                          overlap_wide_apply=not args.no_overlap_wide_apply)
     eng = WideDeepEngine(cfg, dev, rank=rank, world=world, group=group)
     batches = [synthetic_batch(cfg, dev, args.dist, seed=1000 + i, rank=rank) for i in range(args.n_batches)]
@@ -226,7 +228,7 @@ def main():
                                "averaged over the timed steps"},
         "kernels_ms": {k: round(sum(v) / len(v), 5) for k, v in sorted(kern_ms.items())},
         "embed_gbps": {
-            "lookup": round(by["lookup"] / (median(kern_ms["gather_deep"]) * 1e-3) / 1e9, 1) if world == 1 else None,
+            "lookup": round(by["lookup"] / (median(kern_ms["gather_deep"]) * 1e-3) / 1e9, 1) if (world == 1 and "gather_deep" in kern_ms) else None,
             "apply_deep": round(achieved, 1),
         },
     }

@@ -67,6 +67,11 @@ class WideDeepConfig:
     overlap_wide: bool = False           # wide_sum on the side stream beside the deep gather (measured: slightly slower)
     overlap_wide_apply: bool = True  # wide-table FTRL on the side stream as soon as the head's backward has produced its gradient:
                                      # a latency-bound kernel hidden under the backward GEMMs (one GPU)
+    late_wide: object = None       # the wide branch (one GPU: wide_sum; shards: wide-row exchange + unroute + sum) runs on the side
+                                   # stream while the hidden-layer GEMMs run; the main stream joins it right before the output head.
+                                   # It needs one more cut in the MLP graph, and a graph boundary costs ~25 us on the device: on one
+                                   # GPU that is more than the 16-us wide_sum it hides (0.928 -> 0.945 ms/step), on shards it hides a
+                                   # collective.  None = on when sharded, off on one GPU
     early_route: bool = False      # shards: bucket the ids and run the request exchange (sizes, ids, weights) on the side stream
                                    # WITHOUT waiting for the previous step's tail on the main stream -- it hides three small
                                    # collectives, the routing kernels and the bucket-size host sync under the previous step's
@@ -76,6 +81,7 @@ class WideDeepConfig:
                                    # measured slower (0.93 -> 0.98 ms/step): two GEMMs sharing the CUs lose more than the gaps they fill
     overlap_dw0: bool = False      # first-layer weight-gradient GEMM on the side stream beside the sparse apply: step -1 %, but the
                                    # apply kernel shares the chip and runs 7 % longer (0.179 -> 0.192 ms), so off by default
+    graph_front: bool = True       # one GPU: lookups + plan + MLP + wide FTRL replayed as ONE graph (needs graph_mlp)
     graph_mlp: bool = True         # replay the fused MLP forward+backward as one captured HIP graph (one host launch, not ~35)
 
 
@@ -197,6 +203,7 @@ class WideDeepEngine:
         self._mlp_graph = None        # dict: captured fused-MLP step + its static input / output tensors
         self._dw0_pending = None      # graph of the deferred first-layer weight gradient, to replay this step
         self.deep_apply_timer = None  # optional ops.KernelTimer armed right before the deep table's sparse apply
+        self._front_graph = None      # one-GPU: the whole front of the step (lookups .. MLP backward) as one captured graph
 
     # ---- collectives -------------------------------------------------------------------------
     # RCCL (backend "nccl") takes device tensors directly.  Under a gloo group with device tensors
@@ -282,13 +289,14 @@ class WideDeepEngine:
         Python for 1.0 ms of device time.  The graphs hold exactly the kernels of the eager path, in the same
         order, on the same buffers (weights / gradients are updated in place, so their addresses are stable);
         inputs are staged in three static tensors -- the gather writes the embeddings there directly.
-        Two graphs, cut where the wide branch's gradient appears: forward + head, then the backward; after_head
-        runs between them."""
+        Three graphs, cut around the output head: hidden-layer forward | head | backward.  `wide` may be a function:
+        it is called between the first two (the wide branch is computed on the side stream meanwhile); after_head
+        runs between the last two (the wide branch's gradient exists from there on)."""
         self._dw0_pending = None
         if not (self.cfg.graph_mlp and self._gpu and self.step_count > 2):
             return self._mlp_step_fused(emb, wide, label, after_head=after_head)
         g = self._mlp_graph
-        if g is None or g["emb"].shape != emb.shape or g["emb"].dtype != emb.dtype:
+        if g is None or g["emb"].shape != emb.shape or g["emb"].dtype != emb.dtype or (g["graph_head"] is None) == callable(wide):
             try:
                 g = self._capture_mlp(emb, wide, label)
             except RuntimeError as e:          # capture refused (e.g. a library call not capturable): stay eager
@@ -299,9 +307,14 @@ class WideDeepEngine:
                 return self._mlp_step_fused(emb, wide, label, after_head=after_head)
         if emb.data_ptr() != g["emb"].data_ptr():
             g["emb"].copy_(emb)
-        g["wide"].copy_(wide)
         g["label"].copy_(label)
-        g["graph_fwd"].replay()
+        if g["graph_head"] is None:
+            g["wide"].copy_(wide() if callable(wide) else wide)
+            g["graph_fwd"].replay()                # hidden layers + head in one graph
+        else:
+            g["graph_fwd"].replay()
+            g["wide"].copy_(wide() if callable(wide) else wide)
+            g["graph_head"].replay()
         if after_head is not None:
             after_head(g["ctx"]["g_wide"])
         g["graph_bwd"].replay()
@@ -309,6 +322,9 @@ class WideDeepEngine:
         return g["ctx"]["loss"], g["g_emb"], g["ctx"]["g_wide"]
 
     def _capture_mlp(self, emb, wide, label):
+        late = callable(wide)
+        if late:
+            wide = wide()
         g = {"emb": torch.empty_like(emb), "wide": torch.empty_like(wide), "label": torch.empty_like(label)}
         g["emb"].copy_(emb)
         g["wide"].copy_(wide)
@@ -317,8 +333,19 @@ class WideDeepEngine:
         defer = self._side is not None and self.cfg.overlap_dw0
         # thread_local: RCCL's watchdog thread may query events while this thread captures
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-            g["ctx"] = self._mlp_fwd_head(g["emb"], g["wide"], g["label"])
+        if late:
+            # cut between the hidden layers and the head: the wide branch arrives in between
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                g["hs"] = self._mlp_fwd(g["emb"])
+            gh = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gh, capture_error_mode="thread_local"):
+                g["ctx"] = self._mlp_head(g["hs"], g["wide"], g["label"])
+            g["graph_head"] = gh
+        else:
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                g["hs"] = self._mlp_fwd(g["emb"])
+                g["ctx"] = self._mlp_head(g["hs"], g["wide"], g["label"])
+            g["graph_head"] = None
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, capture_error_mode="thread_local"):
             g["g_emb"] = self._mlp_bwd(g["ctx"], defer_dw0=defer)
@@ -355,15 +382,21 @@ class WideDeepEngine:
             self.dense_grad[2 * i].copy_(torch.mm(h.t(), dh))
 
     @torch.no_grad()
-    def _mlp_fwd_head(self, emb, wide, label):
-        """Hidden layers forward, then output layer + wide/deep add + sigmoid cross-entropy forward AND backward.
-        Returns the context the backward needs: hs (activations), loss, dlogit (= the wide branch's gradient), dh."""
+    def _mlp_fwd(self, emb):
+        """Hidden layers forward: the activations hs[0..n-1] (hs[0] = the MLP input)."""
         amp, n = self._amp, len(self.dims) - 1
-        B = emb.shape[0]
         Wb = [self.dense16[2 * i] for i in range(n - 1)]              # bf16 shadows written by the dense Adam
         hs = [emb if emb.dtype == amp else emb.to(amp)]
         for i in range(n - 1):
             hs.append(torch.addmm(self.dense16[2 * i + 1], hs[i], Wb[i]).relu_())
+        return hs
+
+    @torch.no_grad()
+    def _mlp_head(self, hs, wide, label):
+        """Output layer + wide/deep add + sigmoid cross-entropy, forward AND backward.  Returns the context the
+        backward needs: hs, loss, dlogit (= the wide branch's gradient), dh."""
+        amp, n = self._amp, len(self.dims) - 1
+        B = hs[0].shape[0]
         W5, b5 = self.dense[2 * (n - 1)], self.dense[2 * (n - 1) + 1]
         K5 = self.dims[n - 1]
         if self.k.head_supported(K5):
@@ -431,16 +464,20 @@ class WideDeepEngine:
         Returns (loss, g_emb [B, F*D] bf16, g_wide [B] fp32).  after_head(g_wide) is called as soon as the wide
         branch's gradient exists (the caller may start the wide table's update beside the backward GEMMs).
         defer_dw0=True leaves the first layer's weight gradient to the caller (self._mlp_dw(0, *self._dw0_args))."""
-        ctx = self._mlp_fwd_head(emb, wide, label)
+        hs = self._mlp_fwd(emb)
+        if callable(wide):
+            wide = wide()                  # joins whatever stream computed the wide branch; returns the tensor
+        ctx = self._mlp_head(hs, wide, label)
         if after_head is not None:
             after_head(ctx["g_wide"])
         g_emb = self._mlp_bwd(ctx, defer_dw0)
         return ctx["loss"], g_emb, ctx["g_wide"]
 
     # ---- forward (eval path: PredictWithSigmoid, wide_and_deep.py:495-518) ---------------------
-    def lookup(self, ids, wts):
+    def lookup(self, ids, wts, defer_wide=False):
         """Returns (deep_in [B, F*D] already mask-multiplied, wide_out [B] incl. bias) and the
-        routing state needed by the backward (None on one GPU)."""
+        routing state needed by the backward (None on one GPU).  defer_wide=True: wide_out is returned as a
+        function to call (on whatever stream should do the work) instead of a tensor."""
         cfg = self.cfg
         B, Fd = ids.shape
         if self.world == 1:
@@ -451,6 +488,8 @@ class WideDeepEngine:
             else:
                 emb = self.k.gather_rows(self.deep, ids, wts).view(B, Fd * cfg.emb_dim)
             self._tock(ev)
+            if defer_wide:
+                return emb, (lambda: self.k.wide_sum(self.wide, ids, wts, self.wide_b)), None
             ev = self._tick("wide_sum")
             if self._side is not None and self.cfg.overlap_wide and torch.is_grad_enabled():
                 # latency-bound 4-byte gathers: let them run beside the deep gather on the side stream
@@ -508,9 +547,16 @@ class WideDeepEngine:
         self._tock(ev)
         ev = self._tick("a2a_rows")
         back = torch.empty((n, D), dtype=rows.dtype, device=self.device)
-        wback = torch.empty((n, 1), dtype=torch.float32, device=self.device)
         self._all_to_all(back, rows, send_counts, recv_counts)
-        self._all_to_all(wback, wrows, send_counts, recv_counts)
+
+        def wide_branch():
+            # wide rows back from their owners, un-permuted, summed over the fields (+ bias)
+            wback = torch.empty((n, 1), dtype=torch.float32, device=self.device)
+            self._all_to_all(wback, wrows, send_counts, recv_counts)
+            wv = self.k.shard_unroute(wback, perm, None if wire16 else wts.reshape(-1)).view(B, Fd)
+            return wv.sum(dim=1) + self.wide_b
+
+        wide = wide_branch if defer_wide else wide_branch()
         self._tock(ev)
         ev = self._tick("unroute")
         if wire16:
@@ -518,12 +564,11 @@ class WideDeepEngine:
             if eo is not None:
                 eo = eo.view(torch.float32)
             emb = self.k.shard_unroute(back.view(torch.float32), perm, None, out=eo).view(torch.bfloat16).view(B, Fd * D)
-            wvals = self.k.shard_unroute(wback, perm, None).view(B, Fd)
         else:
             emb = self.k.shard_unroute(back, perm, wts.reshape(-1)).view(B, Fd * D)
-            wvals = self.k.shard_unroute(wback, perm, wts.reshape(-1)).view(B, Fd)
-        wide = wvals.sum(dim=1) + self.wide_b
         self._tock(ev)
+        if defer_wide:
+            wrows.record_stream(self._side)
         return emb, wide, (perm, send_counts, recv_counts, recv_local, recv_wts)
 
     def _fused_bf16(self):
@@ -535,31 +580,47 @@ class WideDeepEngine:
             logit = wide.view(-1, 1) + self.mlp(emb)
         return logit, torch.sigmoid(logit)
 
-    # ---- one training step -------------------------------------------------------------------
-    def train_step(self, ids, wts, label):
+    @staticmethod
+    def _rs(t, stream):
+        """record_stream outside graph capture (inside a capture every tensor lives in the graph's own pool)."""
+        if not torch.cuda.is_current_stream_capturing():
+            t.record_stream(stream)
+
+    def _front(self, ids, wts, label, capturing=False):
+        """Everything of a step in front of the sparse applies: lookups, the step's Unique + inverted index (side
+        stream), the MLP forward/backward with the wide branch's work hooked in.  Returns
+        (loss, g_emb, g_wide, plan_early, wide_done, route, early_gw, fused); the side stream is joined on return.
+        capturing=True: called under HIP-graph capture (one GPU) -- the MLP is issued kernel by kernel."""
         cfg = self.cfg
         B, Fd = ids.shape
         D = cfg.emb_dim
         inv_sens = 1.0 / cfg.sens
-        self.step_count += 1
-        self.beta1_power = np.float32(self.beta1_power * self.beta1)
-        self.beta2_power = np.float32(self.beta2_power * self.beta2)
-
         self._wide_event = None
-        emb, wide, route = self.lookup(ids, wts)        # deep gather on the main stream, wide_sum on the side stream
+        late_cfg = cfg.late_wide if cfg.late_wide is not None else self.world > 1
+        late = bool(self._side is not None and late_cfg and self._fused_bf16())
+        emb, wide, route = self.lookup(ids, wts, defer_wide=late)
         plan_early = None
         if self._side is not None:
-            # The step's Unique + inverted index needs only the ids (on a shard: the ids received from the
-            # other ranks): queue it on the side stream (behind the wide_sum) so its dozen small latency-bound
-            # kernels hide under the MLP instead of sitting on the critical path in front of the sparse applies.
+            # Side stream, in this order: (1) the wide branch, which the main stream joins only right before the
+            # output head -- it runs while the hidden-layer GEMMs do; (2) the step's Unique + inverted index, which
+            # needs only the ids (on a shard: the ids received from the other ranks) and is joined before the sparse
+            # applies: its dozen small latency-bound kernels hide under the MLP.
             main = torch.cuda.current_stream()
             if self._wide_event is None:
-                self._side.wait_stream(main)
+                self._side.wait_stream(main)          # the gathers are queued on main: the wide branch starts behind them
             with torch.cuda.stream(self._side):
+                if late:
+                    wide_t = wide()
+                    ev_wide = self._side.record_event()
+
+                    def wide():
+                        torch.cuda.current_stream().wait_event(ev_wide)
+                        self._rs(wide_t, torch.cuda.current_stream())
+                        return wide_t
                 plan_early = self.k.sparse_plan(ids if route is None else route[3])
             for t in (plan_early.uniq_buf, plan_early.inv, plan_early.n_uniq_dev, plan_early.sorted_pos,
                       plan_early.sorted_seg, plan_early.seg_offsets):
-                t.record_stream(main)
+                self._rs(t, main)
         if self._wide_event is not None:
             torch.cuda.current_stream().wait_event(self._wide_event)   # the head needs `wide`; the plan may still run
 
@@ -574,7 +635,7 @@ class WideDeepEngine:
                     # and the head's dlogit.  The Mul bprop of wide_mul (:304) is applied as row_scale.
                     main = torch.cuda.current_stream()
                     self._side.wait_event(main.record_event())
-                    gw_b.record_stream(self._side)
+                    self._rs(gw_b, self._side)
                     with torch.cuda.stream(self._side):
                         gw = gw_b.view(B, 1).expand(B, Fd).reshape(B * Fd, 1)
                         self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan_early, gw, wts, lr=cfg.ftrl_lr,
@@ -591,7 +652,7 @@ class WideDeepEngine:
                     perm_, send_counts_, recv_counts_, recv_local_, recv_wts_ = route
                     main = torch.cuda.current_stream()
                     self._side.wait_event(main.record_event())
-                    gw_b.record_stream(self._side)
+                    self._rs(gw_b, self._side)
                     with torch.cuda.stream(self._side):
                         if recv_wts_ is not None:
                             gw = gw_b.view(B, 1).expand(B, Fd).reshape(B * Fd, 1).contiguous()
@@ -602,7 +663,10 @@ class WideDeepEngine:
                         self._all_to_all(recv_gw, send_gw, recv_counts_, send_counts_)
                     holder["recv_gw"] = recv_gw
                 early_gw = holder
-            loss, g_emb, g_wide = self._mlp_step(emb, wide, label, after_head=after_head)
+            if capturing:
+                loss, g_emb, g_wide = self._mlp_step_fused(emb, wide, label, after_head=after_head)
+            else:
+                loss, g_emb, g_wide = self._mlp_step(emb, wide, label, after_head=after_head)
             if route is not None and route[4] is None:
                 g_emb = g_emb.float()          # fp32 wire format
         else:
@@ -615,10 +679,63 @@ class WideDeepEngine:
             g_emb, g_wide = emb.grad, wide.grad                           # [B, F*D], [B]
         self._tock(ev)
 
-        gb = g_wide.sum().view(1)
-        dense_work = None
         if plan_early is not None:
             torch.cuda.current_stream().wait_stream(self._side)          # the plan (queued long ago) is done
+        return loss, g_emb, g_wide, plan_early, wide_done, route, (early_gw if fused else None), fused
+
+    # ---- the whole front of a one-GPU step as ONE HIP graph ------------------------------------------
+    def _front_graph_ok(self):
+        return bool(self.cfg.graph_front and self.cfg.graph_mlp and self._gpu and self.world == 1 and self._side is not None
+                    and self._fused_bf16() and self.step_count > 2 and torch.is_grad_enabled() and self.timers is None
+                    and not self.cfg.overlap_dw0)
+
+    def _front_replay(self, ids, wts, label):
+        """ids / wts / label are copied into static buffers (3.5 MB) and the captured front is replayed: the deep
+        gather, wide_sum, the plan on its side branch, the MLP and the wide table's FTRL apply (constant hyper-
+        parameters) on another side branch -- one launch, no graph boundaries inside (each costs ~25 us of device
+        time on this stack).  The deep LazyAdam apply and the dense Adam stay outside: their step size changes
+        every step (bias correction) and is a kernel argument."""
+        g = self._front_graph
+        if g is None or g["ids"].shape != ids.shape or g["ids"].dtype != ids.dtype:
+            try:
+                g = {"ids": ids.clone(), "wts": wts.clone(), "label": label.clone()}
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    g["out"] = self._front(g["ids"], g["wts"], g["label"], capturing=True)
+                g["graph"] = graph
+                self._front_graph = g
+            except RuntimeError as e:
+                import warnings
+                warnings.warn(f"HIP-graph capture of the step front failed, falling back to the MLP graphs: {e}")
+                self.cfg.graph_front = False
+                self._front_graph = None
+                return None
+        g["ids"].copy_(ids)
+        g["wts"].copy_(wts)
+        g["label"].copy_(label)
+        g["graph"].replay()
+        return g["out"]
+
+    # ---- one training step -------------------------------------------------------------------
+    def train_step(self, ids, wts, label):
+        cfg = self.cfg
+        B, Fd = ids.shape
+        D = cfg.emb_dim
+        inv_sens = 1.0 / cfg.sens
+        self.step_count += 1
+        self.beta1_power = np.float32(self.beta1_power * self.beta1)
+        self.beta2_power = np.float32(self.beta2_power * self.beta2)
+
+        front = None
+        if self._front_graph_ok():
+            front = self._front_replay(ids, wts, label)
+        if front is None:
+            front = self._front(ids, wts, label)
+        loss, g_emb, g_wide, plan_early, wide_done, route, early_gw, fused = front
+
+        gb = g_wide.sum().view(1)
+        dense_work = None
         if self._dw0_pending is not None:
             # first layer's weight gradient: a compute-bound GEMM nobody needs before the dense Adam -- on the
             # side stream, beside the HBM-bound sparse applies (one GPU) / the row-gradient exchange (shards)

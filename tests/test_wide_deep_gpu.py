@@ -154,21 +154,22 @@ def test_deepfm_engine_matches_oracle_engine(dev, oracle):
     assert np.allclose(logit.cpu().numpy(), lc2.numpy(), rtol=1e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("overlap_dw0", [False, True])
-def test_graph_replay_is_bit_identical_to_eager(dev, overlap_dw0):
-    """The captured MLP step holds the same kernels in the same order on the same buffers as the eager
-    path: losses, tables and dense parameters must agree bit for bit over several steps (the graph is
-    captured on step 3 and replayed from then on, with a different batch every step)."""
+@pytest.mark.parametrize("overlap_dw0,graph_front", [(False, True), (False, False), (True, False)])
+def test_graph_replay_is_bit_identical_to_eager(dev, overlap_dw0, graph_front):
+    """The captured graphs (the whole front of the step, or the MLP alone) hold the same kernels in the same
+    order on the same buffers as the eager path: losses, tables and dense parameters must agree bit for bit
+    over several steps (capture on step 3, replay from then on, a different batch every step)."""
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     kw = dict(vocab_size=50000, emb_dim=16, field_size=26, batch_size=2048, deep_layer_dim=[256, 128, 64, 32],
               mlp_dtype="bf16")
-    a = WideDeepEngine(WideDeepConfig(graph_mlp=True, overlap_dw0=overlap_dw0, **kw), dev)
+    a = WideDeepEngine(WideDeepConfig(graph_mlp=True, graph_front=graph_front, overlap_dw0=overlap_dw0, **kw), dev)
     b = WideDeepEngine(WideDeepConfig(graph_mlp=False, **kw), dev)
     assert a.dense16 is not None, "fused bf16 MLP path expected"
     for s in range(7):
         ids, wts, label = synthetic_batch(a.cfg, dev, "zipf", seed=70 + s)
         la, lb = float(a.train_step(ids, wts, label)), float(b.train_step(ids, wts, label))
         assert la == lb, (s, la, lb)
-    assert a._mlp_graph is not None and b._mlp_graph is None
+    assert (a._front_graph is not None) if graph_front else (a._mlp_graph is not None)
+    assert b._mlp_graph is None and b._front_graph is None
     assert torch.equal(a.deep, b.deep) and torch.equal(a.wide, b.wide)
     assert torch.equal(a.dense_flat.detach(), b.dense_flat.detach())
