@@ -57,6 +57,32 @@ __global__ __launch_bounds__(256) void k_rmw(float* __restrict__ table, const in
     }
 }
 
+// The lookup's pattern: random 320-byte rows (80 floats) read, rounded to bf16, written as a dense [n, 80] bf16
+// stream.  20 lanes per row, 4 rows per lane-group in flight.
+__global__ __launch_bounds__(256) void k_gather_pat(const float* __restrict__ table, const int* __restrict__ rows, int n,
+                                                    uint16_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / 20, sub = lane - grp * 20;
+    if (grp >= 3) return;
+    const int64_t g = ((int64_t)blockIdx.x * 4 + wave) * 3 + grp;
+    f4 v[4];
+    int64_t e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        e[k] = g * 4 + k;
+        if (e[k] < n) v[k] = *(const f4*)(table + (int64_t)rows[e[k]] * 80 + sub * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (e[k] < n) {
+            u2 o;
+            o.x = (__float_as_uint(v[k].x) >> 16) | (__float_as_uint(v[k].y) & 0xFFFF0000u);
+            o.y = (__float_as_uint(v[k].z) >> 16) | (__float_as_uint(v[k].w) & 0xFFFF0000u);
+            *(u2*)(out + e[k] * 80 + sub * 4) = o;
+        }
+    }
+}
+
 template <int BATCH, bool NT, bool GRAD>
 float run(float* table, const int* rows, int n, int W, const uint16_t* grad, int iters) {
     const int64_t groups = (n + W - 1) / W;
@@ -103,6 +129,25 @@ int main(int argc, char** argv) {
         t = run<4, true, false>(table, rows, n, W, grad, 20);  printf("W=%2d batch 4 nontemporal          : %7.1f us  %6.0f GB/s\n", W, t * 1e3, rmw / t / 1e6);
         t = run<2, false, false>(table, rows, n, W, grad, 20); printf("W=%2d batch 2 cached               : %7.1f us  %6.0f GB/s\n", W, t * 1e3, rmw / t / 1e6);
         t = run<2, true, true>(table, rows, n, W, grad, 20);   printf("W=%2d batch 2 nontemporal + gradient: %7.1f us  %6.0f GB/s (of %.1f MB)\n", W, t * 1e3, withg / t / 1e6, withg / 1e6);
+    }
+    {
+        // lookup pattern over a [3*V, 80] view of the same memory (rows drawn from [0, V))
+        const unsigned blocks = (unsigned)(((n + 3) / 4 + 11) / 12);
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        for (int i = 0; i < 3; ++i) k_gather_pat<<<blocks, 256>>>(table, rows, n, grad);
+        CK(hipDeviceSynchronize());
+        float tot = 0;
+        for (int i = 0; i < 20; ++i) {
+            CK(hipEventRecord(a));
+            k_gather_pat<<<blocks, 256>>>(table, rows + (size_t)(i % 4) * n, n, grad);
+            CK(hipEventRecord(b));
+            CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b));
+            tot += ms;
+        }
+        const double by = (double)n * (4 + 320 + 160);
+        printf("lookup pattern: random 320-B rows -> bf16 stream: %7.1f us  %6.0f GB/s (of %.1f MB)\n", tot / 20 * 1e3, by / (tot / 20) / 1e6, by / 1e6);
     }
     return 0;
 }
