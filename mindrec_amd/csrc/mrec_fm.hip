@@ -53,6 +53,48 @@ __global__ __launch_bounds__(256) void k_fm_fwd(const float* __restrict__ vx, in
     }
 }
 
+// 16-byte-lane variant (D % 4 == 0, 16-byte aligned rows): a lane-group of lpr = D/4 lanes owns a sample (three
+// samples per wave64 at D = 80), four fields' loads are issued before they are consumed, no per-column guards.
+// Column sums are accumulated in field order exactly as above (colsum stays bit-identical); the sum over the
+// columns is a fixed shuffle tree inside the lane-group.
+__global__ __launch_bounds__(256) void k_fm_fwd4(const float4* __restrict__ vx, int64_t B, int F, int lpr, int G,
+                                                 float* __restrict__ fm_out, float4* __restrict__ colsum) {
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / lpr, sub = lane - grp * lpr;
+    const bool act = grp < G;
+    const int64_t ng = (int64_t)gridDim.x * 4 * G;
+    for (int64_t b0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G; b0 < B; b0 += ng) {
+        const int64_t b = b0 + grp;
+        const bool live = act && b < B;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+        const float4* row = vx + (live ? b : 0) * (int64_t)F * lpr + sub;
+        int f = 0;
+        for (; f + 4 <= F; f += 4) {
+            float4 x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = live ? row[(int64_t)(f + k) * lpr] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s.x = s.x + x[k].x; s.y = s.y + x[k].y; s.z = s.z + x[k].z; s.w = s.w + x[k].w;
+                q.x = q.x + x[k].x * x[k].x; q.y = q.y + x[k].y * x[k].y; q.z = q.z + x[k].z * x[k].z; q.w = q.w + x[k].w * x[k].w;
+            }
+        }
+        for (; f < F; ++f) {
+            const float4 x = live ? row[(int64_t)f * lpr] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s.x = s.x + x.x; s.y = s.y + x.y; s.z = s.z + x.z; s.w = s.w + x.w;
+            q.x = q.x + x.x * x.x; q.y = q.y + x.y * x.y; q.z = q.z + x.z * x.z; q.w = q.w + x.w * x.w;
+        }
+        float part = ((s.x * s.x - q.x) + (s.y * s.y - q.y)) + ((s.z * s.z - q.z) + (s.w * s.w - q.w));
+        if (live) colsum[b * lpr + sub] = s;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float o = __shfl_down(part, off, 64);
+            if (sub + off < lpr) part += o;
+        }
+        if (live && sub == 0) fm_out[b] = 0.5f * part;
+    }
+}
+
 // g[b, f, d] += dout[b] * (colsum[b, d] - vx[b, f, d])
 __global__ __launch_bounds__(256) void k_fm_bwd(const float* __restrict__ vx, const float* __restrict__ colsum,
                                                 const float* __restrict__ dout, int64_t B, int F, int D,
@@ -62,6 +104,21 @@ __global__ __launch_bounds__(256) void k_fm_bwd(const float* __restrict__ vx, co
         const int64_t b = i / ((int64_t)F * D);
         const int d = (int)(i % D);
         g[i] = g[i] + dout[b] * (colsum[b * D + d] - vx[i]);
+    }
+}
+
+// float4 variant with 32-bit index arithmetic (B*F*D/4 < 2^31)
+__global__ __launch_bounds__(256) void k_fm_bwd4(const float4* __restrict__ vx, const float4* __restrict__ colsum,
+                                                 const float* __restrict__ dout, unsigned total4, unsigned FD4, unsigned D4,
+                                                 float4* __restrict__ g) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += gridDim.x * 256u) {
+        const unsigned b = i / FD4;
+        const unsigned d4 = i % D4;
+        const float w = dout[b];
+        const float4 c = colsum[b * D4 + d4], x = vx[i];
+        float4 y = g[i];
+        y.x = y.x + w * (c.x - x.x); y.y = y.y + w * (c.y - x.y); y.z = y.z + w * (c.z - x.z); y.w = y.w + w * (c.w - x.w);
+        g[i] = y;
     }
 }
 
@@ -84,9 +141,17 @@ MREC_API int mrec_fm_fwd_f32(const float* vx, int64_t B, int32_t F, int32_t D, f
     if (D > 64 * FM_MAXC) return MREC_EUNSUPPORTED;
     if (B == 0) return MREC_OK;
     if (!vx || !fm_out || !colsum) return MREC_EINVAL;
-    int64_t blocks = mrec_cdiv(B, 4);
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    k_fm_fwd<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(vx, B, F, D, fm_out, colsum);
+    const bool al = ((((uintptr_t)vx) | ((uintptr_t)colsum)) & 15) == 0;
+    if (D % 4 == 0 && al) {
+        const int lpr = D / 4, G = 64 / lpr;
+        int64_t blocks = mrec_cdiv(B, (int64_t)4 * G);
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        k_fm_fwd4<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const float4*)vx, B, F, lpr, G, fm_out, (float4*)colsum);
+    } else {
+        int64_t blocks = mrec_cdiv(B, 4);
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        k_fm_fwd<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(vx, B, F, D, fm_out, colsum);
+    }
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -96,9 +161,19 @@ MREC_API int mrec_fm_bwd_f32(const float* vx, const float* colsum, const float* 
     if (B < 0 || F <= 0 || D <= 0) return MREC_EINVAL;
     if (B == 0) return MREC_OK;
     if (!vx || !colsum || !dout || !g) return MREC_EINVAL;
-    int64_t blocks = mrec_cdiv(B * (int64_t)F * D, 256);
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    k_fm_bwd<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(vx, colsum, dout, B, F, D, g);
+    const int64_t total = B * (int64_t)F * D;
+    const bool al = ((((uintptr_t)vx) | ((uintptr_t)colsum) | ((uintptr_t)g)) & 15) == 0;
+    if (D % 4 == 0 && al && total / 4 < (int64_t(1) << 31)) {
+        int64_t blocks = mrec_cdiv(total / 4, 256);
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        k_fm_bwd4<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const float4*)vx, (const float4*)colsum, dout,
+                                                                     (unsigned)(total / 4), (unsigned)(F * (D / 4)),
+                                                                     (unsigned)(D / 4), (float4*)g);
+    } else {
+        int64_t blocks = mrec_cdiv(total, 256);
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        k_fm_bwd<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(vx, colsum, dout, B, F, D, g);
+    }
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }

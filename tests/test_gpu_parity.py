@@ -509,7 +509,7 @@ def test_head_fwd_bwd(dev, oracle, B, K5):
     assert abs(float(db5) - r["db5"]) <= 1e-4 * max(abs(r["db5"]), 1e-3)
 
 
-@pytest.mark.parametrize("B,F,D", [(300, 39, 80), (64, 26, 16), (5, 3, 200)])
+@pytest.mark.parametrize("B,F,D", [(300, 39, 80), (64, 26, 16), (5, 3, 200), (7, 5, 30), (1000, 39, 128)])
 def test_fm_term(dev, oracle, B, F, D):
     from mindrec_amd import ops
     rng = np.random.default_rng(B + D)
