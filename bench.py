@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-early-route", action="store_true", help="shards: request exchange on the main stream (waits for the previous step)")
     ap.add_argument("--parallel-dw", action="store_true", help="weight-gradient GEMMs on a parallel branch of the backward (measured slower)")
     ap.add_argument("--overlap-dw0", action="store_true", help="first-layer weight-gradient GEMM beside the sparse apply (side stream)")
+    ap.add_argument("--dynamic-embedding", action="store_true", help="hash tables keyed by the raw ids (reference --dynamic_embedding=True); "
+                    "use a --vocab small enough for --hash-capacity, e.g. --vocab 3000000")
+    ap.add_argument("--hash-capacity", type=int, default=1 << 22)
     ap.add_argument("--no-graph-front", action="store_true", help="one GPU: only the MLP as HIP graphs, lookups / plan issued kernel by kernel")
     ap.add_argument("--no-graph-mlp", action="store_true", help="issue the fused MLP step kernel by kernel instead of replaying its HIP graph")
     ap.add_argument("--overlap-wide", action="store_true", help="also run wide_sum on the side stream (measured slower)")
@@ -125,7 +128,8 @@ def main():
     cfg = WideDeepConfig(vocab_size=args.vocab, emb_dim=args.emb_dim, field_size=args.fields, batch_size=args.batch,
                          mlp_dtype=args.mlp_dtype, fused_state=not args.split_state,
                          overlap_plan=not args.no_overlap_plan, overlap_wide=args.overlap_wide,
-                         graph_mlp=not args.no_graph_mlp, graph_front=not args.no_graph_front, overlap_dw0=args.overlap_dw0, parallel_dw=args.parallel_dw, early_route=not args.no_early_route, late_wide={'auto': None, 'on': True, 'off': False}[args.late_wide],
+                         graph_mlp=not args.no_graph_mlp, graph_front=not args.no_graph_front,
+                         dynamic_embedding=args.dynamic_embedding, hash_capacity=args.hash_capacity, overlap_dw0=args.overlap_dw0, parallel_dw=args.parallel_dw, early_route=not args.no_early_route, late_wide={'auto': None, 'on': True, 'off': False}[args.late_wide],
                          overlap_wide_apply=not args.no_overlap_wide_apply)
     eng = WideDeepEngine(cfg, dev, rank=rank, world=world, group=group)
     batches = [synthetic_batch(cfg, dev, args.dist, seed=1000 + i, rank=rank) for i in range(args.n_batches)]
@@ -217,7 +221,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"Wide&Deep Criteo (BASELINE configs[1]): vocab {args.vocab}, dim {args.emb_dim}, "
                                f"batch {args.batch}/GPU, {args.fields} fields, fp32 tables ({'split' if args.split_state else 'fused-row'} "
-                               f"state layout), {args.dist} ids, "
+                               f"state layout), {args.dist} ids{', hash tables keyed by id (dynamic_embedding)' if args.dynamic_embedding else ''}, "
                                f"MLP {cfg.field_size * cfg.emb_dim}-1024-512-256-128-1 in {args.mlp_dtype}",
                    "global_batch": args.batch * world, "id_dist": args.dist, "unique_frac": round(U / max(n_apply, 1), 4),
                    "parallelism": "1 GPU" if world == 1 else f"tables row-sharded x{world} (RCCL all-to-all), MLP dp{world}"},

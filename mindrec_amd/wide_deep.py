@@ -81,6 +81,9 @@ class WideDeepConfig:
                                    # measured slower (0.93 -> 0.98 ms/step): two GEMMs sharing the CUs lose more than the gaps they fill
     overlap_dw0: bool = False      # first-layer weight-gradient GEMM on the side stream beside the sparse apply: step -1 %, but the
                                    # apply kernel shares the chip and runs 7 % longer (0.179 -> 0.192 ms), so off by default
+    dynamic_embedding: bool = False  # both tables are hash tables keyed by the raw ids (train_and_eval.py --dynamic_embedding=True,
+                                     # wide_and_deep.py:271-274): rows are created on first sight with their default values
+    hash_capacity: int = 1 << 22     # rows reserved in HBM for each hash table (dynamic_embedding)
     graph_front: bool = True       # one GPU: lookups + plan + MLP + wide FTRL replayed as ONE graph (needs graph_mlp)
     graph_mlp: bool = True         # replay the fused MLP forward+backward as one captured HIP graph (one host launch, not ~35)
 
@@ -130,6 +133,17 @@ class WideDeepEngine:
         self.tuned_gemms = bool(tuned_gemms and self._gpu and enable_tuned_gemms())
         V, D = cfg.vocab_size, cfg.emb_dim
         self.local_rows = (V - rank + world - 1) // world          # rows r with r*world + rank < V
+        self.index = None
+        if cfg.dynamic_embedding:
+            # HashEmbeddingLookup x2 with all defaults (wide_and_deep.py:271-274; embedding.py:88-93): a device
+            # key -> row index over `hash_capacity` rows; the row tables below are addressed by row number, so
+            # every kernel downstream of the index probe is the one the dense-table mode uses.
+            if world != 1:
+                raise ValueError("dynamic_embedding runs on one GPU (the reference's dynamic-embedding mode is standalone)")
+            if kernels is not None:
+                raise ValueError("dynamic_embedding needs the device key index (no CPU stand-in)")
+            self.local_rows = int(cfg.hash_capacity)
+            self.index = ops.KeyIndex(self.local_rows, self.device)
         dev = self.device
         with (torch.cuda.device(dev) if self._gpu else contextlib.nullcontext()):
             # deep table + Adam moments, wide table + FTRL accumulators: plain row-major fp32 in HBM
@@ -146,12 +160,14 @@ class WideDeepEngine:
                 self.deep_m, self.deep_v = torch.empty_like(self.deep), torch.empty_like(self.deep)
                 self.wide = torch.empty((R, 1), dtype=torch.float32, device=dev)
                 self.wide_accum, self.wide_linear = torch.empty_like(self.wide), torch.empty_like(self.wide)
-            self.k.fill_normal_(self.deep, cfg.seed, cfg.init_sigma, row0=rank, row_stride=world)
-            self.deep_m.zero_()
-            self.deep_v.zero_()
-            self.k.fill_normal_(self.wide, cfg.seed + 1, cfg.init_sigma, row0=rank, row_stride=world)
-            self.wide_accum.fill_(cfg.ftrl_initial_accum)
-            self.wide_linear.zero_()
+            if not cfg.dynamic_embedding:
+                self.k.fill_normal_(self.deep, cfg.seed, cfg.init_sigma, row0=rank, row_stride=world)
+                self.deep_m.zero_()
+                self.deep_v.zero_()
+                self.k.fill_normal_(self.wide, cfg.seed + 1, cfg.init_sigma, row0=rank, row_stride=world)
+                self.wide_accum.fill_(cfg.ftrl_initial_accum)
+                self.wide_linear.zero_()
+            # (dynamic_embedding: rows get exactly these values when their key is first seen, _translate_keys)
             # MLP: fp32 master weights in one flat buffer, same for grads / m / v.  Flat order: the hidden
             # layers' weight matrices first (group H: bf16 GEMM operands, bf16 gradients), then the biases
             # and the fp32 last layer (group S); `self.dense` lists them in layer order W0, b0, W1, b1, ...
@@ -576,9 +592,30 @@ class WideDeepEngine:
 
     def predict(self, ids, wts):
         with torch.no_grad():
+            if self.index is not None:
+                ids, _ = self._translate_keys(ids)      # MapTensorGet inserts default rows in eval too (embedding.py:193)
             emb, wide, _ = self.lookup(ids, wts)
             logit = wide.view(-1, 1) + self.mlp(emb)
         return logit, torch.sigmoid(logit)
+
+    def _translate_keys(self, ids):
+        """dynamic_embedding: Unique -> key-index probe / insert -> default rows for new keys (MapTensorGet with
+        insert_default_value=True, embedding.py:149,192-195).  Returns (row numbers [B, F] int32, the step's
+        SparsePlan with groups mapped to table rows).  The Unique is the one the optimizer side needs anyway."""
+        cfg = self.cfg
+        plan = self.k.sparse_plan(ids)
+        k64 = ops.widen_keys(plan.uniq_buf)
+        rows_u, is_new = self.index.find_or_insert(k64, insert=True, n_dev=plan.n_uniq_dev)
+        nd = plan.n_uniq_dev
+        ops.init_rows_(self.deep, rows_u, k64, is_new, n_dev=nd, seed=cfg.seed, sigma=cfg.init_sigma)
+        ops.init_rows_(self.deep_m, rows_u, k64, is_new, n_dev=nd, seed=0, sigma=None, fill=0.0)
+        ops.init_rows_(self.deep_v, rows_u, k64, is_new, n_dev=nd, seed=0, sigma=None, fill=0.0)
+        ops.init_rows_(self.wide, rows_u, k64, is_new, n_dev=nd, seed=cfg.seed + 1, sigma=cfg.init_sigma)
+        ops.init_rows_(self.wide_accum, rows_u, k64, is_new, n_dev=nd, seed=0, sigma=None, fill=cfg.ftrl_initial_accum)
+        ops.init_rows_(self.wide_linear, rows_u, k64, is_new, n_dev=nd, seed=0, sigma=None, fill=0.0)
+        rows_pos = ops.compose_i32(rows_u, plan.inv).view(ids.shape)
+        plan.uniq_buf = rows_u
+        return rows_pos, plan
 
     @staticmethod
     def _rs(t, stream):
@@ -598,9 +635,11 @@ class WideDeepEngine:
         self._wide_event = None
         late_cfg = cfg.late_wide if cfg.late_wide is not None else self.world > 1
         late = bool(self._side is not None and late_cfg and self._fused_bf16())
-        emb, wide, route = self.lookup(ids, wts, defer_wide=late)
         plan_early = None
-        if self._side is not None:
+        if self.index is not None:
+            ids, plan_early = self._translate_keys(ids)        # from here on `ids` are table row numbers
+        emb, wide, route = self.lookup(ids, wts, defer_wide=late)
+        if self._side is not None and self.index is None:
             # Side stream, in this order: (1) the wide branch, which the main stream joins only right before the
             # output head -- it runs while the hidden-layer GEMMs do; (2) the step's Unique + inverted index, which
             # needs only the ids (on a shard: the ids received from the other ranks) and is joined before the sparse
@@ -866,6 +905,9 @@ def _engine_state(eng):
 
 def save_checkpoint(eng, path):
     """Writes this rank's shard (tables + optimizer state + dense parameters) to `path` (torch.save)."""
+    if eng.index is not None:
+        raise NotImplementedError("checkpointing a dynamic_embedding engine: export the key index with MapParameter-style "
+                                  "export (ops.KeyIndex.export) -- not wired into save_checkpoint yet")
     st = _engine_state(eng)
     out = {"meta": st["meta"], "tables": {k: v.detach().cpu().contiguous() for k, v in st["tables"].items()},
            "dense": {k: v.detach().cpu().contiguous() for k, v in st["dense"].items()}}

@@ -173,3 +173,34 @@ def test_graph_replay_is_bit_identical_to_eager(dev, overlap_dw0, graph_front):
     assert b._mlp_graph is None and b._front_graph is None
     assert torch.equal(a.deep, b.deep) and torch.equal(a.wide, b.wide)
     assert torch.equal(a.dense_flat.detach(), b.dense_flat.detach())
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_dynamic_embedding_engine_equals_dense_table_engine(dev, graph):
+    """--dynamic_embedding=True (hash tables keyed by the raw ids, rows created on first sight with their default
+    values) must train exactly like the dense-table engine when the keys happen to be valid row numbers: default
+    rows are the same counter-based N(0, 0.01) values keyed by (seed, id, column), every kernel downstream of the
+    index probe is shared, and the segment sums are grouped in the same first-occurrence order."""
+    from mindrec_amd import ops
+    from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
+    kw = dict(vocab_size=50000, emb_dim=16, field_size=39, batch_size=1024, deep_layer_dim=[128, 64, 32],
+              mlp_dtype="bf16", graph_mlp=graph)
+    a = WideDeepEngine(WideDeepConfig(**kw), dev)
+    b = WideDeepEngine(WideDeepConfig(dynamic_embedding=True, hash_capacity=1 << 16, **kw), dev)
+    seen = []
+    for s in range(6):
+        ids, wts, label = synthetic_batch(a.cfg, dev, "zipf", seed=90 + s)
+        la, lb = float(a.train_step(ids, wts, label)), float(b.train_step(ids, wts, label))
+        assert la == lb, (s, la, lb)
+        seen.append(ids.reshape(-1))
+    keys = torch.unique(torch.cat(seen)).to(torch.int64)
+    assert len(b.index) == keys.numel()
+    rows, _ = b.index.find_or_insert(keys.contiguous(), insert=False)
+    assert bool((rows >= 0).all())
+    r = rows.long()
+    for name in ("deep", "deep_m", "deep_v", "wide", "wide_accum", "wide_linear"):
+        assert torch.equal(getattr(a, name)[keys], getattr(b, name)[r]), name
+    assert torch.equal(a.dense_flat.detach(), b.dense_flat.detach())
+    la, _ = a.predict(ids, wts)
+    lb, _ = b.predict(ids, wts)
+    assert torch.equal(la, lb)
