@@ -88,10 +88,39 @@ def cpu_baseline(args, seconds):
             break
         _ = ts
     dt = time.perf_counter() - t0
-    return {"value": round(B * steps / dt, 1), "unit": "samples/s", "cores": 1, "kind": "port",
-            "sample": f"embedding path only (lookup+wide_sum+sparse LazyAdam+sparse FTRL, no MLP), {steps} steps of "
-                      f"batch {B}x{Fd}, dim {D}, table scaled to V={V}, uniform ids, oracle/mrec_oracle.c 1 thread; "
-                      f"MindSpore CPU not installable here"}
+    t_embed = dt / steps
+    # the dense net of the same step (fwd + bwd, fp32) on the host's cores through torch's CPU GEMMs
+    import torch
+    import torch.nn.functional as F
+    threads = max(1, min(os.cpu_count() or 1, 16))
+    torch.set_num_threads(threads)
+    dims = [Fd * D, 1024, 512, 256, 128, 1]
+    Ws = [(torch.randn(dims[i], dims[i + 1]) * 0.01).requires_grad_(True) for i in range(5)]
+    bs = [torch.zeros(dims[i + 1], requires_grad=True) for i in range(5)]
+    x = torch.randn(B, Fd * D, requires_grad=True)
+    y = (torch.rand(B, 1) < 0.25).float()
+    t_mlp, reps = 0.0, 0
+    for it in range(4):
+        t1 = time.perf_counter()
+        h = x
+        for i in range(5):
+            h = torch.addmm(bs[i], h, Ws[i])
+            if i < 4:
+                h = torch.relu(h)
+        F.binary_cross_entropy_with_logits(h, y).backward()
+        if it:                      # first pass warms the thread pool
+            t_mlp += time.perf_counter() - t1
+            reps += 1
+        if time.perf_counter() - t0 > 2.5 * seconds:
+            break
+    t_mlp = t_mlp / max(reps, 1)
+    whole = B / (t_embed + t_mlp) if reps else None
+    return {"value": round(whole, 1) if whole else round(B / t_embed, 1), "unit": "samples/s", "cores": threads if reps else 1,
+            "kind": "port", "embedding_path_only": round(B / t_embed, 1), "embedding_ms": round(t_embed * 1e3, 1),
+            "mlp_ms": round(t_mlp * 1e3, 1) if reps else None,
+            "sample": f"whole step = embedding path (lookup+wide_sum+sparse LazyAdam+sparse FTRL: oracle/mrec_oracle.c, 1 thread, "
+                      f"{steps} steps) + MLP {dims[0]}-1024-512-256-128-1 fwd+bwd (torch CPU fp32, {threads} threads, {reps} steps); "
+                      f"batch {B}x{Fd}, dim {D}, table scaled to V={V}, uniform ids; MindSpore CPU not installable here"}
 
 
 def main():
