@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--mlp-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--n-batches", type=int, default=4, help="distinct resident batches cycled through")
     ap.add_argument("--split-state", action="store_true", help="p, m, v as three separate arrays (default: fused rows)")
     ap.add_argument("--no-overlap-plan", action="store_true", help="run dedup + inverted index on the main stream")
