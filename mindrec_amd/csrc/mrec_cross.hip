@@ -171,7 +171,7 @@ constexpr int bwd_occ(int npl, int lt) { return (lt + 3) * npl <= 180 ? 2 : 1; }
 // Per row the kernel needs only the L dots P_l = x0 . w_l (independent of each other, so their wave
 // reductions overlap): with x_l = a_l x0 + beta_l,  s_l = x_l . w_l = a_l P_l + c_l,  a_{l+1} = a_l + s_l.
 // x_l itself is never rebuilt, b is not read at all; fmaf is used freely -- this kernel is checked against
-// the oracle's double-precision backward to a tolerance, not bit for bit (the forward is bit-exact).
+// the oracle's double-precision backward to a tolerance, not bit for bit.
 template <int NPL, int LT, bool WLDS>
 __global__ __launch_bounds__(BWD_NT) __attribute__((amdgpu_waves_per_eu(bwd_occ(NPL, LT), bwd_occ(NPL, LT)))) void k_cross_bwd(const float* __restrict__ x0, const float* __restrict__ w,
                                                       const float* __restrict__ cvec, int L, int64_t B, int D,

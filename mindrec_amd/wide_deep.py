@@ -227,11 +227,6 @@ class WideDeepEngine:
     def _staged(self):
         return self._gpu and dist.get_backend(self.group) == "gloo"
 
-    def _staged_blocking(self):
-        """Collectives issued from a hook in the middle of the step need a backend that runs them on the device
-        timeline (RCCL).  The gloo-staged debug path works too (it simply blocks the host), so nothing is excluded."""
-        return False
-
     def _all_to_all(self, out, inp, out_splits=None, in_splits=None):
         if self._staged():
             if out.dtype == torch.bfloat16:                 # gloo has no bf16: ship the bytes (row splits unchanged)
@@ -681,8 +676,7 @@ class WideDeepEngine:
                                             l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=inv_sens)
                 wide_done = True
             early_gw = None
-            if (after_head is None and route is not None and self._side is not None and cfg.early_wide_grad
-                    and not self._staged_blocking()):
+            if after_head is None and route is not None and self._side is not None and cfg.early_wide_grad:
                 holder = {}
 
                 def after_head(gw_b):
