@@ -598,17 +598,27 @@ class WideDeepEngine:
         insert_default_value=True, embedding.py:149,192-195).  Returns (row numbers [B, F] int32, the step's
         SparsePlan with groups mapped to table rows).  The Unique is the one the optimizer side needs anyway."""
         cfg = self.cfg
-        plan = self.k.sparse_plan(ids)
-        k64 = ops.widen_keys(plan.uniq_buf)
-        rows_u, is_new = self.index.find_or_insert(k64, insert=True, n_dev=plan.n_uniq_dev)
-        nd = plan.n_uniq_dev
+        d = self.k.unique(ids)                                   # critical path: the gather needs the row numbers
+        k64 = ops.widen_keys(d.uniq_buf)
+        rows_u, is_new = self.index.find_or_insert(k64, insert=True, n_dev=d.n_uniq_dev)
+        nd = d.n_uniq_dev
         ops.init_rows_(self.deep, rows_u, k64, is_new, n_dev=nd, seed=cfg.seed, sigma=cfg.init_sigma)
         ops.init_rows_(self.deep_m, rows_u, k64, is_new, n_dev=nd, seed=0, sigma=None, fill=0.0)
         ops.init_rows_(self.deep_v, rows_u, k64, is_new, n_dev=nd, seed=0, sigma=None, fill=0.0)
         ops.init_rows_(self.wide, rows_u, k64, is_new, n_dev=nd, seed=cfg.seed + 1, sigma=cfg.init_sigma)
         ops.init_rows_(self.wide_accum, rows_u, k64, is_new, n_dev=nd, seed=0, sigma=None, fill=cfg.ftrl_initial_accum)
         ops.init_rows_(self.wide_linear, rows_u, k64, is_new, n_dev=nd, seed=0, sigma=None, fill=0.0)
-        rows_pos = ops.compose_i32(rows_u, plan.inv).view(ids.shape)
+        rows_pos = ops.compose_i32(rows_u, d.inv).view(ids.shape)
+        # the inverted index (two radix passes) is needed only by the sparse applies: side stream, under the MLP
+        if self._side is not None:
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                plan = ops.group_by_inverse(d)
+            for t in (plan.sorted_pos, plan.sorted_seg, plan.seg_offsets):
+                self._rs(t, main)
+        else:
+            plan = ops.group_by_inverse(d)
         plan.uniq_buf = rows_u
         return rows_pos, plan
 
