@@ -84,6 +84,7 @@ class WideDeepConfig:
     dynamic_embedding: bool = False  # both tables are hash tables keyed by the raw ids (train_and_eval.py --dynamic_embedding=True,
                                      # wide_and_deep.py:271-274): rows are created on first sight with their default values
     hash_capacity: int = 1 << 22     # rows reserved in HBM for each hash table (dynamic_embedding)
+    relu_epilogue: bool = True     # hidden layers: bias + ReLU in the GEMM epilogue instead of a separate ReLU pass
     graph_front: bool = True       # one GPU: lookups + plan + MLP + wide FTRL replayed as ONE graph (needs graph_mlp)
     graph_mlp: bool = True         # replay the fused MLP forward+backward as one captured HIP graph (one host launch, not ~35)
 
@@ -399,7 +400,11 @@ class WideDeepEngine:
         Wb = [self.dense16[2 * i] for i in range(n - 1)]              # bf16 shadows written by the dense Adam
         hs = [emb if emb.dtype == amp else emb.to(amp)]
         for i in range(n - 1):
-            hs.append(torch.addmm(self.dense16[2 * i + 1], hs[i], Wb[i]).relu_())
+            if self.cfg.relu_epilogue:
+                # bias + ReLU in the GEMM's epilogue (hipBLASLt): bit-identical to addmm + relu_, one pass less
+                hs.append(torch._addmm_activation(self.dense16[2 * i + 1], hs[i], Wb[i], use_gelu=False))
+            else:
+                hs.append(torch.addmm(self.dense16[2 * i + 1], hs[i], Wb[i]).relu_())
         return hs
 
     @torch.no_grad()
