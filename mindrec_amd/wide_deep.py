@@ -782,7 +782,12 @@ class WideDeepEngine:
             front = self._front(ids, wts, label)
         loss, g_emb, g_wide, plan_early, wide_done, route, early_gw, fused = front
 
-        gb = g_wide.sum().view(1)
+        if fused:
+            # d loss / d Wide_b = sum of dlogit = the output layer's bias gradient, which the head kernel has
+            # already reduced into the flat gradient buffer
+            gb = self.dense_grad[2 * (len(self.dims) - 2) + 1].view(1)
+        else:
+            gb = g_wide.sum().view(1)
         dense_work = None
         if self._dw0_pending is not None:
             # first layer's weight gradient: a compute-bound GEMM nobody needs before the dense Adam -- on the
