@@ -919,10 +919,17 @@ def _engine_state(eng):
 
 def save_checkpoint(eng, path):
     """Writes this rank's shard (tables + optimizer state + dense parameters) to `path` (torch.save)."""
-    if eng.index is not None:
-        raise NotImplementedError("checkpointing a dynamic_embedding engine: export the key index with MapParameter-style "
-                                  "export (ops.KeyIndex.export) -- not wired into save_checkpoint yet")
     st = _engine_state(eng)
+    if eng.index is not None:
+        # hash tables: the live keys and, per table, the rows of those keys in key-export order (the analogue of
+        # MapParameter.export_data: keys + values; row numbers are not part of the state)
+        keys, rows = eng.index.export()
+        r = rows.long()
+        tables = {k: v.detach()[r].cpu().contiguous() for k, v in st["tables"].items()}
+        out = {"meta": dict(st["meta"], dynamic_embedding=True), "keys": keys.cpu(), "tables": tables,
+               "dense": {k: v.detach().cpu().contiguous() for k, v in st["dense"].items()}}
+        torch.save(out, path)
+        return
     out = {"meta": st["meta"], "tables": {k: v.detach().cpu().contiguous() for k, v in st["tables"].items()},
            "dense": {k: v.detach().cpu().contiguous() for k, v in st["dense"].items()}}
     torch.save(out, path)
@@ -937,10 +944,23 @@ def load_checkpoint(eng, path):
         if m[k] != have:
             raise ValueError(f"checkpoint {path}: {k} = {m[k]} but the engine has {have}")
     st = _engine_state(eng)
+    if bool(m.get("dynamic_embedding", False)) != (eng.index is not None):
+        raise ValueError(f"checkpoint {path}: dynamic_embedding does not match the engine")
     with torch.no_grad():
-        for grp in ("tables", "dense"):
-            for k, dst in st[grp].items():
-                dst.copy_(ck[grp][k].to(dst.device))
+        if eng.index is not None:
+            # re-insert the keys (this engine numbers the rows its own way), then put each key's rows in place
+            if len(eng.index):
+                raise ValueError("load_checkpoint needs a fresh dynamic_embedding engine (its key index is not empty)")
+            keys = ck["keys"].to(eng.device).contiguous()
+            rows, _ = eng.index.find_or_insert(keys, insert=True)
+            for k, dst in st["tables"].items():
+                ops.scatter_rows_(dst, rows, ck["tables"][k].to(eng.device).contiguous())
+            for k, dst in st["dense"].items():
+                dst.copy_(ck["dense"][k].to(dst.device))
+        else:
+            for grp in ("tables", "dense"):
+                for k, dst in st[grp].items():
+                    dst.copy_(ck[grp][k].to(dst.device))
         if eng.dense16 is not None:
             eng.dense16_flat.copy_(eng.dense_flat.detach())
     eng.step_count = m["step_count"]
