@@ -125,6 +125,8 @@ def cpu_baseline(args, seconds):
 
 
 def main():
+    # RCCL / cross-process tensor sharing on this pool needs dmabuf IPC (the driver image exports this already)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse()
     import torch
     import torch.distributed as dist
