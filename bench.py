@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-overlap-wide-apply", action="store_true", help="wide FTRL after the deep apply on the main stream")
     ap.add_argument("--late-wide", choices=["auto", "on", "off"], default="auto", help="wide branch on the side stream under the hidden-layer GEMMs (auto: when sharded)")
     ap.add_argument("--no-early-route", action="store_true", help="shards: request exchange on the main stream (waits for the previous step)")
+    ap.add_argument("--parallel-dw-from", type=int, default=0)
     ap.add_argument("--parallel-dw", action="store_true", help="weight-gradient GEMMs on a parallel branch of the backward (measured slower)")
     ap.add_argument("--overlap-dw0", action="store_true", help="first-layer weight-gradient GEMM beside the sparse apply (side stream)")
     ap.add_argument("--dynamic-embedding", action="store_true", help="hash tables keyed by the raw ids (reference --dynamic_embedding=True); "
@@ -161,7 +162,7 @@ def main():
                          mlp_dtype=args.mlp_dtype, fused_state=not args.split_state,
                          overlap_plan=not args.no_overlap_plan, overlap_wide=args.overlap_wide,
                          graph_mlp=not args.no_graph_mlp, graph_front=not args.no_graph_front, relu_epilogue=not args.no_relu_epilogue,
-                         dynamic_embedding=args.dynamic_embedding, hash_capacity=args.hash_capacity, overlap_dw0=args.overlap_dw0, parallel_dw=args.parallel_dw, early_route=not args.no_early_route, late_wide={'auto': None, 'on': True, 'off': False}[args.late_wide],
+                         dynamic_embedding=args.dynamic_embedding, hash_capacity=args.hash_capacity, overlap_dw0=args.overlap_dw0, parallel_dw=args.parallel_dw, parallel_dw_from=args.parallel_dw_from, early_route=not args.no_early_route, late_wide={'auto': None, 'on': True, 'off': False}[args.late_wide],
                          overlap_wide_apply=not args.no_overlap_wide_apply)
     eng = WideDeepEngine(cfg, dev, rank=rank, world=world, group=group)
     batches = [synthetic_batch(cfg, dev, args.dist, seed=1000 + i, rank=rank) for i in range(args.n_batches)]

@@ -77,6 +77,7 @@ class WideDeepConfig:
                                    # collectives, the routing kernels and the bucket-size host sync under the previous step's
                                    # applies.  Requires ids / wts to be complete in HBM when train_step is called (bench.py: yes)
     early_wide_grad: bool = True   # shards: the wide branch's row-gradient exchange starts at the head's backward, under the backward GEMMs
+    parallel_dw_from: int = 0      # with parallel_dw: only layers >= this index take the side branch (small GEMMs leave CUs idle)
     parallel_dw: bool = False      # weight-gradient GEMMs on a parallel branch of the backward (their own stream / graph branch):
                                    # measured slower (0.93 -> 0.98 ms/step): two GEMMs sharing the CUs lose more than the gaps they fill
     overlap_dw0: bool = False      # first-layer weight-gradient GEMM on the side stream beside the sparse apply: step -1 %, but the
@@ -446,7 +447,7 @@ class WideDeepEngine:
         for i in range(n - 2, -1, -1):
             if i == 0 and defer_dw0:
                 self._dw0_args = (hs[0], dh)
-            elif br is not None:
+            elif br is not None and i >= self.cfg.parallel_dw_from:
                 br.wait_stream(main)
                 hs[i].record_stream(br)
                 dh.record_stream(br)
