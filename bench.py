@@ -47,6 +47,7 @@ def parse():
                     "use a --vocab small enough for --hash-capacity, e.g. --vocab 3000000")
     ap.add_argument("--hash-capacity", type=int, default=1 << 22)
     ap.add_argument("--no-relu-epilogue", action="store_true", help="hidden layers as addmm + a separate ReLU pass")
+    ap.add_argument("--no-plan-first", action="store_true", help="plan queued behind the gathers")
     ap.add_argument("--no-graph-front", action="store_true", help="one GPU: only the MLP as HIP graphs, lookups / plan issued kernel by kernel")
     ap.add_argument("--no-graph-mlp", action="store_true", help="issue the fused MLP step kernel by kernel instead of replaying its HIP graph")
     ap.add_argument("--overlap-wide", action="store_true", help="also run wide_sum on the side stream (measured slower)")
@@ -161,7 +162,7 @@ def main():
     cfg = WideDeepConfig(vocab_size=args.vocab, emb_dim=args.emb_dim, field_size=args.fields, batch_size=args.batch,
                          mlp_dtype=args.mlp_dtype, fused_state=not args.split_state,
                          overlap_plan=not args.no_overlap_plan, overlap_wide=args.overlap_wide,
-                         graph_mlp=not args.no_graph_mlp, graph_front=not args.no_graph_front, relu_epilogue=not args.no_relu_epilogue,
+                         graph_mlp=not args.no_graph_mlp, graph_front=not args.no_graph_front, plan_first=not args.no_plan_first, relu_epilogue=not args.no_relu_epilogue,
                          dynamic_embedding=args.dynamic_embedding, hash_capacity=args.hash_capacity, overlap_dw0=args.overlap_dw0, parallel_dw=args.parallel_dw, parallel_dw_from=args.parallel_dw_from, early_route=not args.no_early_route, late_wide={'auto': None, 'on': True, 'off': False}[args.late_wide],
                          overlap_wide_apply=not args.no_overlap_wide_apply)
     eng = WideDeepEngine(cfg, dev, rank=rank, world=world, group=group)

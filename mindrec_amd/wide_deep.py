@@ -86,6 +86,7 @@ class WideDeepConfig:
                                      # wide_and_deep.py:271-274): rows are created on first sight with their default values
     hash_capacity: int = 1 << 22     # rows reserved in HBM for each hash table (dynamic_embedding)
     relu_epilogue: bool = True     # hidden layers: bias + ReLU in the GEMM epilogue instead of a separate ReLU pass
+    plan_first: bool = True        # one GPU: queue the plan on the side stream before the gathers rather than behind them
     graph_front: bool = True       # one GPU: lookups + plan + MLP + wide FTRL replayed as ONE graph (needs graph_mlp)
     graph_mlp: bool = True         # replay the fused MLP forward+backward as one captured HIP graph (one host launch, not ~35)
 
@@ -649,8 +650,18 @@ class WideDeepEngine:
         plan_early = None
         if self.index is not None:
             ids, plan_early = self._translate_keys(ids)        # from here on `ids` are table row numbers
+        elif self._side is not None and self.world == 1 and not late and cfg.plan_first:
+            # one GPU: the plan needs nothing but the ids -- start it on the side stream BEFORE the gathers are
+            # queued, so that it runs beside them (HBM-bound) and eats less into the first GEMM
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                plan_early = self.k.sparse_plan(ids)
+            for t in (plan_early.uniq_buf, plan_early.inv, plan_early.n_uniq_dev, plan_early.sorted_pos,
+                      plan_early.sorted_seg, plan_early.seg_offsets):
+                self._rs(t, main)
         emb, wide, route = self.lookup(ids, wts, defer_wide=late)
-        if self._side is not None and self.index is None:
+        if self._side is not None and self.index is None and plan_early is None:
             # Side stream, in this order: (1) the wide branch, which the main stream joins only right before the
             # output head -- it runs while the hidden-layer GEMMs do; (2) the step's Unique + inverted index, which
             # needs only the ids (on a shard: the ids received from the other ranks) and is joined before the sparse
