@@ -176,7 +176,8 @@ def main():
 
     # Priming (setup, whatever --warmup says): workspaces, GEMM library handles and the HIP graph of the MLP
     # step come into being in the engine's first three steps.
-    for i in range(3):
+    # (2 x n_batches more steps let a one-GPU engine bind a front graph to each of the rotating input batches.)
+    for i in range(3 + 2 * len(batches)):
         eng.train_step(*batches[i % len(batches)])
     barrier()
     for i in range(args.warmup):

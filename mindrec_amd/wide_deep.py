@@ -86,6 +86,8 @@ class WideDeepConfig:
                                      # wide_and_deep.py:271-274): rows are created on first sight with their default values
     hash_capacity: int = 1 << 22     # rows reserved in HBM for each hash table (dynamic_embedding)
     relu_epilogue: bool = True     # hidden layers: bias + ReLU in the GEMM epilogue instead of a separate ReLU pass
+    graph_bound_inputs: int = 0    # how many recurring (ids, wts, label) buffer triples get a front graph of their own (no staging
+                                   # copies); measured gain 2 us/step for ~0.5 GB of graph pool each, so off
     plan_first: bool = True        # one GPU: queue the plan on the side stream before the gathers rather than behind them
     graph_front: bool = True       # one GPU: lookups + plan + MLP + wide FTRL replayed as ONE graph (needs graph_mlp)
     graph_mlp: bool = True         # replay the fused MLP forward+backward as one captured HIP graph (one host launch, not ~35)
@@ -223,6 +225,8 @@ class WideDeepEngine:
         self._dw0_pending = None      # graph of the deferred first-layer weight gradient, to replay this step
         self.deep_apply_timer = None  # optional ops.KernelTimer armed right before the deep table's sparse apply
         self._front_graph = None      # one-GPU: the whole front of the step (lookups .. MLP backward) as one captured graph
+        self._front_bound = {}        # ... and graphs bound to recurring input buffers (no staging copies)
+        self._front_seen = {}
 
     # ---- collectives -------------------------------------------------------------------------
     # RCCL (backend "nccl") takes device tensors directly.  Under a gloo group with device tensors
@@ -755,27 +759,53 @@ class WideDeepEngine:
         parameters) on another side branch -- one launch, no graph boundaries inside (each costs ~25 us of device
         time on this stack).  The deep LazyAdam apply and the dense Adam stay outside: their step size changes
         every step (bias correction) and is a kernel argument."""
+        # Input buffers that keep coming back (a loader's double buffer, bench.py's rotating batches) get a graph bound
+        # to their addresses: no staging copies at all.  Everything else goes through the staging graph.
+        key = (ids.data_ptr(), wts.data_ptr(), label.data_ptr(), tuple(ids.shape), ids.dtype)
+        bound = self._front_bound.get(key)
+        if bound is not None:
+            bound["graph"].replay()
+            return bound["out"]
+        if self.cfg.graph_bound_inputs > 0:
+            if len(self._front_seen) > 64:
+                self._front_seen.clear()
+            seen = self._front_seen.get(key, 0) + 1
+            self._front_seen[key] = seen
+            if seen >= 2 and len(self._front_bound) < self.cfg.graph_bound_inputs:
+                bound = self._capture_front(ids, wts, label)
+                if bound is not None:
+                    self._front_bound[key] = bound
+                    bound["graph"].replay()
+                    return bound["out"]
         g = self._front_graph
         if g is None or g["ids"].shape != ids.shape or g["ids"].dtype != ids.dtype:
-            try:
-                g = {"ids": ids.clone(), "wts": wts.clone(), "label": label.clone()}
-                torch.cuda.synchronize(self.device)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    g["out"] = self._front(g["ids"], g["wts"], g["label"], capturing=True)
-                g["graph"] = graph
-                self._front_graph = g
-            except RuntimeError as e:
-                import warnings
-                warnings.warn(f"HIP-graph capture of the step front failed, falling back to the MLP graphs: {e}")
-                self.cfg.graph_front = False
-                self._front_graph = None
+            g = self._capture_front(ids.clone(), wts.clone(), label.clone())
+            if g is None:
                 return None
+            self._front_graph = g
         g["ids"].copy_(ids)
         g["wts"].copy_(wts)
         g["label"].copy_(label)
         g["graph"].replay()
         return g["out"]
+
+    def _capture_front(self, ids, wts, label):
+        """Captures the front on exactly these input tensors (kept alive by the returned dict)."""
+        try:
+            g = {"ids": ids, "wts": wts, "label": label}
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                g["out"] = self._front(ids, wts, label, capturing=True)
+            g["graph"] = graph
+            return g
+        except RuntimeError as e:
+            import warnings
+            warnings.warn(f"HIP-graph capture of the step front failed, falling back to the MLP graphs: {e}")
+            self.cfg.graph_front = False
+            self._front_graph = None
+            self._front_bound.clear()
+            return None
 
     # ---- one training step -------------------------------------------------------------------
     def train_step(self, ids, wts, label):
