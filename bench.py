@@ -191,6 +191,7 @@ def main():
         eng.train_step(*batches[i % len(batches)])
     barrier()
     dt = time.perf_counter() - t0
+    graphs_used = {"front": eng._front_graph is not None or bool(eng._front_bound), "mlp": eng._mlp_graph is not None}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -258,7 +259,7 @@ def main():
                                f"batch {args.batch}/GPU, {args.fields} fields, fp32 tables ({'split' if args.split_state else 'fused-row'} "
                                f"state layout), {args.dist} ids{', hash tables keyed by id (dynamic_embedding)' if args.dynamic_embedding else ''}, "
                                f"MLP {cfg.field_size * cfg.emb_dim}-1024-512-256-128-1 in {args.mlp_dtype}",
-                   "global_batch": args.batch * world, "id_dist": args.dist, "unique_frac": round(U / max(n_apply, 1), 4),
+                   "global_batch": args.batch * world, "id_dist": args.dist, "hip_graphs": graphs_used, "unique_frac": round(U / max(n_apply, 1), 4),
                    "parallelism": "1 GPU" if world == 1 else f"tables row-sharded x{world} (RCCL all-to-all), MLP dp{world}"},
         "roofline": {"bound": "hbm", "kernel": "k_apply_main<4,int,UpdAdam,%s> (fused segment-sum + LazyAdam row update)" % ("bf16_t" if bf16_io else "float"),
                      "row_gradient_dtype": "bf16" if bf16_io else "f32",

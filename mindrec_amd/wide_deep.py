@@ -219,6 +219,7 @@ class WideDeepEngine:
         self.step_count = 0
         self._amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[cfg.mlp_dtype]
         self.timers = None            # optional dict name -> list[(start_event, stop_event)]
+        # (default priority: a high-priority side stream was measured at 1.52 ms/step instead of 0.88)
         self._side = torch.cuda.Stream(device=self.device) if (self._gpu and cfg.overlap_plan) else None
         self._dw_stream = torch.cuda.Stream(device=self.device) if (self._gpu and cfg.parallel_dw) else None
         self._mlp_graph = None        # dict: captured fused-MLP step + its static input / output tensors
