@@ -12,13 +12,17 @@ host DRAM instead of a parameter server:
   * prepare(ids) makes every id of the batch resident: Unique -> probe -> if the misses do not fit, the
     least-recently-used rows that are not in this batch are written back to the host and their keys erased
     -> misses get cache rows; a row never seen before is initialised on the device by the same
-    counter-based generator as a fully resident table (keyed by the global id), otherwise it is copied
+    counter-based generator as a fully resident table (keyed by the global id), otherwise it is fetched
     from the host;
   * gather / sparse apply then run unchanged on cache rows (the plan's `uniq` holds cache rows).
 
+All bookkeeping (residency flags, LRU stamps, victim selection, the miss list) lives on the device, and rows move
+between the pinned host array and the cache by the ordinary gather / scatter kernels addressing host memory over
+PCIe -- no host-side indexing, no staging buffers.  The host takes part twice per step: it reads the number of
+unique ids and the number of misses (two scalar syncs).
+
 The tier is transparent: a table driven through it ends bit-identical to a fully device-resident table
-(tests/test_feature_cache_gpu.py).  It trades host round trips (two small syncs per step for the miss
-count and the victim list) for capacity; the all-resident engine needs none of this at V = 200 M.
+(tests/test_feature_cache_gpu.py).
 """
 import torch
 
@@ -35,79 +39,93 @@ class HostBackedTable:
         self.device = torch.device(device)
         self.seed, self.sigma, self.state_init = seed, sigma, tuple(state_init)
         self.host = torch.zeros((self.V, self.W), dtype=torch.float32).pin_memory()
-        self.materialised = torch.zeros(self.V, dtype=torch.bool)             # host row holds real data
-        self.cache = torch.zeros((self.C, self.W), dtype=torch.float32, device=self.device)
-        self.index = ops.KeyIndex(self.C, self.device)
-        self.row_key = torch.full((self.C,), -1, dtype=torch.int64, device=self.device)
-        self.stamp = torch.zeros(self.C, dtype=torch.int64, device=self.device)   # last step a row was used
+        C, dev = self.C, self.device
+        # slot V / C of the flag arrays is a dummy that absorbs the writes of masked-out entries
+        self.materialised = torch.zeros(self.V + 1, dtype=torch.bool, device=dev)      # host row holds real data
+        self.cache = torch.zeros((C, self.W), dtype=torch.float32, device=dev)
+        self.index = ops.KeyIndex(C, dev)
+        self.row_key = torch.full((C + 1,), -1, dtype=torch.int64, device=dev)
+        self.stamp = torch.zeros(C + 1, dtype=torch.int64, device=dev)               # last step a row was used
         self.step = 0
-        self.stats = {"hits": 0, "misses": 0, "evictions": 0, "first_touch": 0}
-        # views of the cache in the layout the kernels expect
+        self.resident = 0                                                            # keys in the index (host copy)
+        self._hits = self._misses = self._evictions = 0
+        self._first_touch = torch.zeros(1, dtype=torch.int64, device=dev)
         D = self.D
         self.p = self.cache[:, :D]
         self.slots = [self.cache[:, (i + 1) * D:(i + 2) * D] for i in range(state_slots)]
+
+    @property
+    def stats(self):
+        return {"hits": self._hits, "misses": self._misses, "evictions": self._evictions,
+                "first_touch": int(self._first_touch.item())}
+
+    @stats.setter
+    def stats(self, d):
+        self._hits, self._misses, self._evictions = int(d.get("hits", 0)), int(d.get("misses", 0)), int(d.get("evictions", 0))
+        self._first_touch.fill_(int(d.get("first_touch", 0)))
 
     # ------------------------------------------------------------------------------------------
     def prepare(self, ids):
         """Makes all ids resident; returns a SparsePlan whose groups map to CACHE rows (plan.uniq_buf) and
         the per-position cache rows (int32 [n]) for the gather."""
         self.step += 1
+        C, dev = self.C, self.device
         plan = ops.sparse_plan(ids)
         U = plan.U                                                    # host sync #1
-        if U > self.C:
-            raise RuntimeError(f"batch has {U} unique ids but the device cache holds {self.C} rows")
+        if U > C:
+            raise RuntimeError(f"batch has {U} unique ids but the device cache holds {C} rows")
         keys = ops.widen_keys(plan.uniq_buf)[:U].contiguous()
         rows, _ = self.index.find_or_insert(keys, insert=False)
         hit = rows >= 0
-        self.stamp[rows[hit].long()] = self.step                      # rows of this batch are not eviction candidates
-        n_miss = int((~hit).sum())                                    # host sync #2
-        self.stats["hits"] += U - n_miss
-        self.stats["misses"] += n_miss
+        slot = torch.where(hit, rows, torch.full_like(rows, C)).long()
+        self.stamp.scatter_(0, slot, torch.full_like(slot, self.step))   # rows of this batch are not eviction candidates
+        n_miss = U - int(hit.sum())                                   # host sync #2
+        self._hits += U - n_miss
+        self._misses += n_miss
         if n_miss:
-            free = self.C - len(self.index)
+            free = C - self.resident
             if n_miss > free:
-                self._evict(n_miss - free)
+                self._evict(n_miss - free, n_hits=U - n_miss)
             rows, is_new = self.index.find_or_insert(keys, insert=True)
-            new = is_new.bool()
-            nrows, nkeys = rows[new], keys[new]
-            self.row_key[nrows.long()] = nkeys
-            self.stamp[nrows.long()] = self.step
-            seen = self.materialised[nkeys.cpu()]
-            # rows with a home on the host: copy them in; first-touch rows: initialise on the device
-            if bool(seen.any()):
-                sel = seen.to(self.device)
-                back = self.host[nkeys[sel].cpu()].to(self.device, non_blocking=True)
-                ops.scatter_rows_(self.cache, nrows[sel].contiguous(), back)
-            fresh = ~seen
-            if bool(fresh.any()):
-                sel = fresh.to(self.device)
-                fr, fk = nrows[sel].contiguous(), nkeys[sel].contiguous()
-                self.stats["first_touch"] += int(fr.numel())
-                ops.init_rows_(self.p, fr, fk, None, seed=self.seed, sigma=self.sigma)
-                for slot, init in zip(self.slots, self.state_init):
-                    ops.init_rows_(slot, fr, fk, None, seed=0, sigma=None, fill=float(init))
+            self.resident += n_miss
+            new = is_new.view(-1)[:U].bool()
+            # the miss list, compacted on the device (its length is known on the host, so no sync)
+            mpos = torch.argsort(new.to(torch.int8), descending=True, stable=True)[:n_miss]
+            mkeys, mrows = keys[mpos].contiguous(), rows[mpos].contiguous()
+            self.row_key[mrows.long()] = mkeys
+            self.stamp[mrows.long()] = self.step
+            seen = self.materialised[mkeys]
+            # rows with a home on the host: fetched over PCIe by the gather kernel; first-touch rows: initialised here
+            fetched = ops.gather_rows_pinned(self.host, torch.where(seen, mkeys, torch.full_like(mkeys, -1)))
+            ops.scatter_rows_(self.cache, torch.where(seen, mrows, torch.full_like(mrows, -1)), fetched)
+            fresh = (~seen).to(torch.uint8)
+            self._first_touch += fresh.sum()
+            ops.init_rows_(self.p, mrows, mkeys, fresh, seed=self.seed, sigma=self.sigma)
+            for s, init in zip(self.slots, self.state_init):
+                ops.init_rows_(s, mrows, mkeys, fresh, seed=0, sigma=None, fill=float(init))
         if plan.n > U:      # groups >= U do not exist; keep the buffer's length (n) with skipped rows
-            rows = torch.cat([rows, torch.full((plan.n - U,), -1, dtype=torch.int32, device=self.device)])
+            rows = torch.cat([rows, torch.full((plan.n - U,), -1, dtype=torch.int32, device=dev)])
         plan.uniq_buf = rows
         rows_pos = ops.compose_i32(plan.uniq_buf, plan.inv)
         return plan, rows_pos
 
-    def _evict(self, k):
+    def _evict(self, k, n_hits=0):
         """Writes the k least-recently-used rows (never rows stamped this step) back to the host and frees them."""
-        live = self.row_key >= 0
-        cand = live & (self.stamp < self.step)
-        if int(cand.sum()) < k:
+        C = self.C
+        if self.resident - n_hits < k:
             raise RuntimeError("device cache too small for this batch's working set")
-        score = torch.where(cand, self.stamp, torch.full_like(self.stamp, torch.iinfo(torch.int64).max))
+        live = self.row_key[:C] >= 0
+        cand = live & (self.stamp[:C] < self.step)
+        score = torch.where(cand, self.stamp[:C], torch.full_like(self.stamp[:C], torch.iinfo(torch.int64).max))
         victims = torch.topk(score, k, largest=False).indices                       # cache rows
-        vkeys = self.row_key[victims]
-        data = self.cache[victims].cpu()
-        hk = vkeys.cpu()
-        self.host[hk] = data
-        self.materialised[hk] = True
-        self.index.erase(vkeys.contiguous())
+        vkeys = self.row_key[victims].contiguous()
+        data = ops.gather_rows(self.cache, victims.to(torch.int32))
+        ops.scatter_rows_pinned_(self.host, vkeys, data)                             # device writes host memory (PCIe)
+        self.materialised[vkeys] = True
+        self.index.erase(vkeys)
         self.row_key[victims] = -1
-        self.stats["evictions"] += int(k)
+        self.resident -= k
+        self._evictions += int(k)
 
     # ------------------------------------------------------------------------------------------
     def gather(self, rows_pos, row_scale=None, out_dtype=torch.float32):
@@ -115,22 +133,24 @@ class HostBackedTable:
 
     def flush(self):
         """Writes every resident row back to the host (checkpoint / end of training)."""
-        live = (self.row_key >= 0).nonzero().view(-1)
-        if live.numel():
-            hk = self.row_key[live].cpu()
-            self.host[hk] = self.cache[live].cpu()
-            self.materialised[hk] = True
+        C = self.C
+        keys = self.row_key[:C]
+        ops.scatter_rows_pinned_(self.host, keys, self.cache)                        # free rows carry key -1: skipped
+        self.materialised.scatter_(0, torch.where(keys >= 0, keys, torch.full_like(keys, self.V)),
+                                   torch.ones(C, dtype=torch.bool, device=self.device))
+        self.materialised[self.V] = False
+        torch.cuda.synchronize(self.device)
 
     def full_table(self):
         """The whole table as a host tensor [V, W] (never-touched rows are generated on demand)."""
         self.flush()
         out = self.host.clone()
-        missing = (~self.materialised).nonzero().view(-1)
+        missing = (~self.materialised[: self.V]).nonzero().view(-1)
         if missing.numel():
             tmp = torch.zeros((missing.numel(), self.W), dtype=torch.float32, device=self.device)
             seq = torch.arange(missing.numel(), dtype=torch.int32, device=self.device)
-            ops.init_rows_(tmp[:, : self.D], seq, missing.to(self.device), None, seed=self.seed, sigma=self.sigma)
+            ops.init_rows_(tmp[:, : self.D], seq, missing, None, seed=self.seed, sigma=self.sigma)
             for i, init in enumerate(self.state_init):
                 tmp[:, (i + 1) * self.D:(i + 2) * self.D] = float(init)
-            out[missing] = tmp.cpu()
+            out[missing.cpu()] = tmp.cpu()
         return out

@@ -167,6 +167,33 @@ def gather_rows(table, ids, row_scale=None, out=None, out_dtype=torch.float32):
     return out.view(tuple(ids.shape) + (D,))
 
 
+def gather_rows_pinned(host_table, ids):
+    """Rows of a PINNED HOST table straight into HBM: the same gather kernel reads host memory over PCIe (pinned
+    allocations are device-addressable; ~45 GB/s measured).  ids < 0 give zero rows without touching the host."""
+    if host_table.is_cuda or not host_table.is_pinned():
+        raise TypeError("gather_rows_pinned needs a pinned host table")
+    _need_cuda(ids)
+    V, D, ld = _table(host_table)
+    sfx = _suffix(ids)
+    flat = ids.reshape(-1).contiguous()
+    out = torch.empty((flat.numel(), D), dtype=torch.float32, device=ids.device)
+    _lib.call("mrec_gather_rows_f32_" + sfx, _ptr(host_table), V, ld, D, _ptr(flat), flat.numel(), None, _ptr(out), _stream())
+    return out
+
+
+def scatter_rows_pinned_(host_table, rows, vals):
+    """host_table[rows[i], :] = vals[i, :] written by the device over PCIe (rows < 0 skipped); the host may read the
+    table after the stream has been synchronised."""
+    if host_table.is_cuda or not host_table.is_pinned():
+        raise TypeError("scatter_rows_pinned_ needs a pinned host table")
+    _need_cuda(rows, vals)
+    V, D, ld = _table(host_table)
+    n = rows.numel()
+    vals = vals.reshape(n, D).contiguous()
+    r32 = rows.to(torch.int32).contiguous()
+    _lib.call("mrec_scatter_rows_f32", _ptr(host_table), ld, D, _ptr(r32), n, _ptr(vals), _stream())
+
+
 def wide_sum(w, ids, wts, bias=None):
     """Wide branch of WideDeepModel.construct (wide_and_deep.py:300,303-306): [B]."""
     _need_cuda(w, ids, wts, bias)
