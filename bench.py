@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--dynamic-embedding", action="store_true", help="hash tables keyed by the raw ids (reference --dynamic_embedding=True); "
                     "use a --vocab small enough for --hash-capacity, e.g. --vocab 3000000")
     ap.add_argument("--hash-capacity", type=int, default=1 << 22)
+    ap.add_argument("--host-cache-rows", type=int, default=0, help="tables in pinned host DRAM behind a device cache of this many rows "
+                    "(the reference's vocab_cache_size); keep --vocab x 976 B within the host's RAM")
     ap.add_argument("--no-relu-epilogue", action="store_true", help="hidden layers as addmm + a separate ReLU pass")
     ap.add_argument("--no-plan-first", action="store_true", help="plan queued behind the gathers")
     ap.add_argument("--no-graph-front", action="store_true", help="one GPU: only the MLP as HIP graphs, lookups / plan issued kernel by kernel")
@@ -163,7 +165,8 @@ def main():
                          mlp_dtype=args.mlp_dtype, fused_state=not args.split_state,
                          overlap_plan=not args.no_overlap_plan, overlap_wide=args.overlap_wide,
                          graph_mlp=not args.no_graph_mlp, graph_front=not args.no_graph_front, plan_first=not args.no_plan_first, relu_epilogue=not args.no_relu_epilogue,
-                         dynamic_embedding=args.dynamic_embedding, hash_capacity=args.hash_capacity, overlap_dw0=args.overlap_dw0, parallel_dw=args.parallel_dw, parallel_dw_from=args.parallel_dw_from, early_route=not args.no_early_route, late_wide={'auto': None, 'on': True, 'off': False}[args.late_wide],
+                         dynamic_embedding=args.dynamic_embedding, hash_capacity=args.hash_capacity,
+                         host_cache_rows=args.host_cache_rows, overlap_dw0=args.overlap_dw0, parallel_dw=args.parallel_dw, parallel_dw_from=args.parallel_dw_from, early_route=not args.no_early_route, late_wide={'auto': None, 'on': True, 'off': False}[args.late_wide],
                          overlap_wide_apply=not args.no_overlap_wide_apply)
     eng = WideDeepEngine(cfg, dev, rank=rank, world=world, group=group)
     batches = [synthetic_batch(cfg, dev, args.dist, seed=1000 + i, rank=rank) for i in range(args.n_batches)]
@@ -257,7 +260,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"Wide&Deep Criteo (BASELINE configs[1]): vocab {args.vocab}, dim {args.emb_dim}, "
                                f"batch {args.batch}/GPU, {args.fields} fields, fp32 tables ({'split' if args.split_state else 'fused-row'} "
-                               f"state layout), {args.dist} ids{', hash tables keyed by id (dynamic_embedding)' if args.dynamic_embedding else ''}, "
+                               f"state layout), {args.dist} ids{', hash tables keyed by id (dynamic_embedding)' if args.dynamic_embedding else ''}"
+                               f"{f', tables in host DRAM behind a {args.host_cache_rows}-row device cache' if args.host_cache_rows else ''}, "
                                f"MLP {cfg.field_size * cfg.emb_dim}-1024-512-256-128-1 in {args.mlp_dtype}",
                    "global_batch": args.batch * world, "id_dist": args.dist, "hip_graphs": graphs_used, "unique_frac": round(U / max(n_apply, 1), 4),
                    "parallelism": "1 GPU" if world == 1 else f"tables row-sharded x{world} (RCCL all-to-all), MLP dp{world}"},

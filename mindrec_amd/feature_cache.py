@@ -30,12 +30,20 @@ from . import ops
 
 
 class HostBackedTable:
+    """columns: optional list of (name, width, init) describing a row's column groups, init = ("normal", seed, sigma)
+    or ("fill", value); default: the fused LazyAdam row [p(D) normal | m(D) 0 | v(D) 0] (state_slots / state_init).
+    `self.cols[name]` is the [cache_rows, width] view of a group."""
+
     def __init__(self, vocab_size, emb_dim, cache_rows, device, seed=1000, sigma=0.01, state_slots=2,
-                 state_init=(0.0, 0.0)):
+                 state_init=(0.0, 0.0), columns=None):
         if cache_rows <= 0 or vocab_size <= 0:
             raise ValueError("vocab_size and cache_rows must be positive")
         self.V, self.D, self.C = int(vocab_size), int(emb_dim), int(cache_rows)
-        self.W = self.D * (1 + state_slots)
+        if columns is None:
+            columns = [("p", self.D, ("normal", seed, sigma))] + [(f"slot{i}", self.D, ("fill", float(state_init[i])))
+                                                                   for i in range(state_slots)]
+        self.columns = [(str(n), int(w), tuple(i)) for n, w, i in columns]
+        self.W = sum(w for _, w, _ in self.columns)
         self.device = torch.device(device)
         self.seed, self.sigma, self.state_init = seed, sigma, tuple(state_init)
         self.host = torch.zeros((self.V, self.W), dtype=torch.float32).pin_memory()
@@ -50,9 +58,13 @@ class HostBackedTable:
         self.resident = 0                                                            # keys in the index (host copy)
         self._hits = self._misses = self._evictions = 0
         self._first_touch = torch.zeros(1, dtype=torch.int64, device=dev)
-        D = self.D
-        self.p = self.cache[:, :D]
-        self.slots = [self.cache[:, (i + 1) * D:(i + 2) * D] for i in range(state_slots)]
+        self.cols, off = {}, 0
+        for name, w, _ in self.columns:
+            self.cols[name] = self.cache[:, off:off + w]
+            off += w
+        first = self.columns[0][0]
+        self.p = self.cols[first]
+        self.slots = [self.cols[n] for n, _, _ in self.columns[1:]]
 
     @property
     def stats(self):
@@ -100,14 +112,20 @@ class HostBackedTable:
             ops.scatter_rows_(self.cache, torch.where(seen, mrows, torch.full_like(mrows, -1)), fetched)
             fresh = (~seen).to(torch.uint8)
             self._first_touch += fresh.sum()
-            ops.init_rows_(self.p, mrows, mkeys, fresh, seed=self.seed, sigma=self.sigma)
-            for s, init in zip(self.slots, self.state_init):
-                ops.init_rows_(s, mrows, mkeys, fresh, seed=0, sigma=None, fill=float(init))
+            self._init_groups(self.cols, mrows, mkeys, fresh)
         if plan.n > U:      # groups >= U do not exist; keep the buffer's length (n) with skipped rows
             rows = torch.cat([rows, torch.full((plan.n - U,), -1, dtype=torch.int32, device=dev)])
         plan.uniq_buf = rows
         rows_pos = ops.compose_i32(plan.uniq_buf, plan.inv)
         return plan, rows_pos
+
+    def _init_groups(self, views, rows, keys, mask):
+        """Default values of first-touch rows, column group by column group (the generator is keyed by the GLOBAL id)."""
+        for name, _, init in self.columns:
+            if init[0] == "normal":
+                ops.init_rows_(views[name], rows, keys, mask, seed=int(init[1]), sigma=float(init[2]))
+            else:
+                ops.init_rows_(views[name], rows, keys, mask, seed=0, sigma=None, fill=float(init[1]))
 
     def _evict(self, k, n_hits=0):
         """Writes the k least-recently-used rows (never rows stamped this step) back to the host and frees them."""
@@ -149,8 +167,10 @@ class HostBackedTable:
         if missing.numel():
             tmp = torch.zeros((missing.numel(), self.W), dtype=torch.float32, device=self.device)
             seq = torch.arange(missing.numel(), dtype=torch.int32, device=self.device)
-            ops.init_rows_(tmp[:, : self.D], seq, missing, None, seed=self.seed, sigma=self.sigma)
-            for i, init in enumerate(self.state_init):
-                tmp[:, (i + 1) * self.D:(i + 2) * self.D] = float(init)
+            views, off = {}, 0
+            for name, w, _ in self.columns:
+                views[name] = tmp[:, off:off + w]
+                off += w
+            self._init_groups(views, seq, missing, None)
             out[missing.cpu()] = tmp.cpu()
         return out

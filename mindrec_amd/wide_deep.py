@@ -89,6 +89,8 @@ class WideDeepConfig:
     graph_bound_inputs: int = 0    # how many recurring (ids, wts, label) buffer triples get a front graph of their own (no staging
                                    # copies); measured gain 2 us/step for ~0.5 GB of graph pool each, so off
     plan_first: bool = True        # one GPU: queue the plan on the side stream before the gathers rather than behind them
+    host_cache_rows: int = 0         # > 0: both tables live in pinned host DRAM behind a device cache of this many rows (the
+                                     # reference's vocab_cache_size, wide_and_deep.py:215-265); one GPU
     graph_front: bool = True       # one GPU: lookups + plan + MLP + wide FTRL replayed as ONE graph (needs graph_mlp)
     graph_mlp: bool = True         # replay the fused MLP forward+backward as one captured HIP graph (one host launch, not ~35)
 
@@ -139,6 +141,11 @@ class WideDeepEngine:
         V, D = cfg.vocab_size, cfg.emb_dim
         self.local_rows = (V - rank + world - 1) // world          # rows r with r*world + rank < V
         self.index = None
+        self.hb = None
+        if cfg.host_cache_rows > 0:
+            if world != 1 or kernels is not None or cfg.dynamic_embedding:
+                raise ValueError("host_cache_rows needs one GPU, the HIP kernels and dense (non-hash) tables")
+            self.local_rows = int(cfg.host_cache_rows)
         if cfg.dynamic_embedding:
             # HashEmbeddingLookup x2 with all defaults (wide_and_deep.py:271-274; embedding.py:88-93): a device
             # key -> row index over `hash_capacity` rows; the row tables below are addressed by row number, so
@@ -153,7 +160,17 @@ class WideDeepEngine:
         with (torch.cuda.device(dev) if self._gpu else contextlib.nullcontext()):
             # deep table + Adam moments, wide table + FTRL accumulators: plain row-major fp32 in HBM
             R = self.local_rows
-            if cfg.fused_state:
+            if cfg.host_cache_rows > 0:
+                # one row = [p | m | v | w, accum, linear, pad]: the deep LazyAdam row and the wide FTRL record of an id
+                # travel between the host and the cache together
+                from .feature_cache import HostBackedTable
+                self.hb = HostBackedTable(V, D, R, dev, columns=[
+                    ("deep", D, ("normal", cfg.seed, cfg.init_sigma)), ("deep_m", D, ("fill", 0.0)), ("deep_v", D, ("fill", 0.0)),
+                    ("wide", 1, ("normal", cfg.seed + 1, cfg.init_sigma)), ("wide_accum", 1, ("fill", cfg.ftrl_initial_accum)),
+                    ("wide_linear", 1, ("fill", 0.0)), ("pad", 1, ("fill", 0.0))])
+                for name in ("deep", "deep_m", "deep_v", "wide", "wide_accum", "wide_linear"):
+                    setattr(self, name, self.hb.cols[name])
+            elif cfg.fused_state:
                 self.deep_state = torch.empty((R, 3 * D), dtype=torch.float32, device=dev)
                 self.deep, self.deep_m, self.deep_v = (self.deep_state[:, :D], self.deep_state[:, D:2 * D],
                                                        self.deep_state[:, 2 * D:])
@@ -165,7 +182,7 @@ class WideDeepEngine:
                 self.deep_m, self.deep_v = torch.empty_like(self.deep), torch.empty_like(self.deep)
                 self.wide = torch.empty((R, 1), dtype=torch.float32, device=dev)
                 self.wide_accum, self.wide_linear = torch.empty_like(self.wide), torch.empty_like(self.wide)
-            if not cfg.dynamic_embedding:
+            if not cfg.dynamic_embedding and self.hb is None:
                 self.k.fill_normal_(self.deep, cfg.seed, cfg.init_sigma, row0=rank, row_stride=world)
                 self.deep_m.zero_()
                 self.deep_v.zero_()
@@ -599,7 +616,7 @@ class WideDeepEngine:
 
     def predict(self, ids, wts):
         with torch.no_grad():
-            if self.index is not None:
+            if self.index is not None or self.hb is not None:
                 ids, _ = self._translate_keys(ids)      # MapTensorGet inserts default rows in eval too (embedding.py:193)
             emb, wide, _ = self.lookup(ids, wts)
             logit = wide.view(-1, 1) + self.mlp(emb)
@@ -610,6 +627,10 @@ class WideDeepEngine:
         insert_default_value=True, embedding.py:149,192-195).  Returns (row numbers [B, F] int32, the step's
         SparsePlan with groups mapped to table rows).  The Unique is the one the optimizer side needs anyway."""
         cfg = self.cfg
+        if self.hb is not None:
+            # host-backed tables: make the batch resident in the device cache (two scalar host syncs), rows = cache rows
+            plan, rows_pos = self.hb.prepare(ids)
+            return rows_pos.view(ids.shape), plan
         d = self.k.unique(ids)                                   # critical path: the gather needs the row numbers
         k64 = ops.widen_keys(d.uniq_buf)
         rows_u, is_new = self.index.find_or_insert(k64, insert=True, n_dev=d.n_uniq_dev)
@@ -653,7 +674,7 @@ class WideDeepEngine:
         late_cfg = cfg.late_wide if cfg.late_wide is not None else self.world > 1
         late = bool(self._side is not None and late_cfg and self._fused_bf16())
         plan_early = None
-        if self.index is not None:
+        if self.index is not None or self.hb is not None:
             ids, plan_early = self._translate_keys(ids)        # from here on `ids` are table row numbers
         elif self._side is not None and self.world == 1 and not late and cfg.plan_first:
             # one GPU: the plan needs nothing but the ids -- start it on the side stream BEFORE the gathers are
@@ -666,7 +687,7 @@ class WideDeepEngine:
                       plan_early.sorted_seg, plan_early.seg_offsets):
                 self._rs(t, main)
         emb, wide, route = self.lookup(ids, wts, defer_wide=late)
-        if self._side is not None and self.index is None and plan_early is None:
+        if self._side is not None and self.index is None and self.hb is None and plan_early is None:
             # Side stream, in this order: (1) the wide branch, which the main stream joins only right before the
             # output head -- it runs while the hidden-layer GEMMs do; (2) the step's Unique + inverted index, which
             # needs only the ids (on a shard: the ids received from the other ranks) and is joined before the sparse
@@ -752,7 +773,7 @@ class WideDeepEngine:
     def _front_graph_ok(self):
         return bool(self.cfg.graph_front and self.cfg.graph_mlp and self._gpu and self.world == 1 and self._side is not None
                     and self._fused_bf16() and self.step_count > 2 and torch.is_grad_enabled() and self.timers is None
-                    and not self.cfg.overlap_dw0)
+                    and not self.cfg.overlap_dw0 and self.hb is None)
 
     def _front_replay(self, ids, wts, label):
         """ids / wts / label are copied into static buffers (3.5 MB) and the captured front is replayed: the deep
@@ -962,6 +983,9 @@ def _engine_state(eng):
 
 def save_checkpoint(eng, path):
     """Writes this rank's shard (tables + optimizer state + dense parameters) to `path` (torch.save)."""
+    if eng.hb is not None:
+        raise NotImplementedError("host-cached tables: flush the cache (eng.hb.flush()) and save eng.hb.host; not wired "
+                                  "into save_checkpoint")
     st = _engine_state(eng)
     if eng.index is not None:
         # hash tables: the live keys and, per table, the rows of those keys in key-export order (the analogue of
