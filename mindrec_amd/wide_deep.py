@@ -206,12 +206,17 @@ class WideDeepEngine:
                     out += [vh[i], vs[i]]
                 return out + [vs[nl - 1], vs[nl]]
 
-            self.dense_flat, views = _flat_views(shapes_h + shapes_s, dev)
+            # pad the flat buffers to a multiple of 4 floats: the dense Adam then is one float4 launch (a 1-element tail
+            # launch cost 5 us + a gap every step); the pad element is a parameter nobody reads (gradient always 0)
+            n_real = sum(int(np.prod(x)) for x in shapes_h + shapes_s)
+            pad = [((-n_real) % 4,)] if n_real % 4 else []
+            self.dense_flat, views = _flat_views(shapes_h + shapes_s + pad, dev)
+            views = views[:len(shapes_h + shapes_s)]
             self.dense = interleave(views[:nl - 1], views[nl - 1:])
             # one extra slot at the end carries the wide-bias gradient through the same all-reduce
-            self.dense_grad_ext, gviews = _flat_views(shapes_h + shapes_s + [(1,)], dev)
+            self.dense_grad_ext, gviews = _flat_views(shapes_h + shapes_s + pad + [(1,)], dev)
             self.dense_grad_flat = self.dense_grad_ext[:-1]
-            gviews = gviews[:-1]
+            gviews = gviews[:len(shapes_h + shapes_s)]
             self.dense_grad = interleave(gviews[:nl - 1], gviews[nl - 1:])
             self.dense_m = torch.zeros_like(self.dense_flat)
             self.dense_v = torch.zeros_like(self.dense_flat)
@@ -224,7 +229,8 @@ class WideDeepEngine:
             if self._gpu and cfg.mlp_dtype == "bf16" and cfg.fused_mlp and kernels is None:
                 # bf16 shadow of every dense parameter (kept current by the dense-Adam kernel) and a flat bf16
                 # buffer the weight-gradient GEMMs write into
-                flat16, v16 = _flat_views(shapes_h + shapes_s, dev, torch.bfloat16)
+                flat16, v16 = _flat_views(shapes_h + shapes_s + pad, dev, torch.bfloat16)
+                v16 = v16[:len(shapes_h + shapes_s)]
                 flat16.copy_(self.dense_flat.detach())
                 self.dense16_flat, self.dense16 = flat16, interleave(v16[:nl - 1], v16[nl - 1:])
             self.wide_b = torch.zeros(1, dtype=torch.float32, device=dev)   # "Wide_b", FTRL side
