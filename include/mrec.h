@@ -179,6 +179,15 @@ int mrec_dense_adam_f32(float* p, float* m, float* v, const float* g, int64_t n,
 int mrec_dense_adam_ex_f32(float* p, float* m, float* v, const void* g, int g_is_bf16, uint16_t* shadow_bf16,
                            int64_t n, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
                            float grad_scale, int nesterov, void* stream);
+/* Dense Adam over a flat buffer whose gradient is, for up to 8 segments, still in split-K form: segment q covers
+ * elements [starts[q], starts[q]+lens[q]) and its gradient is the sum over s < splits[q] of the bf16 arrays
+ * parts[q][s*lens[q] + e] (what the weight-gradient batched GEMMs of the MLP backward leave behind, wide_and_deep.py:
+ * 113-133 bprop); every other element reads the fp32 gradient g.  Saves the separate reduction passes.  n, starts,
+ * lens multiples of 4; parts / starts / lens / splits are HOST arrays of nseg entries. */
+int mrec_dense_adam_splitk_f32(float* p, float* m, float* v, const float* g, uint16_t* shadow_bf16, int64_t n,
+                               int32_t nseg, const void* const* parts, const int64_t* starts, const int64_t* lens,
+                               const int32_t* splits, float lr, float b1, float b2, float eps, float b1_pow,
+                               float b2_pow, float grad_scale, int nesterov, void* stream);
 int mrec_dense_ftrl_f32(float* var, float* accum, float* linear, const float* g, int64_t n, float lr,
                         float l1, float l2, float lr_power, float grad_scale, void* stream);
 

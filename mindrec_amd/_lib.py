@@ -65,6 +65,8 @@ _SIGS = {
                                  _f32, _f32, _f32, _f32, _f32, _vp, _sz, _vp],
     "mrec_dense_adam_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp],
     "mrec_dense_adam_ex_f32": [_vp, _vp, _vp, _vp, _int, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp],
+    "mrec_dense_adam_splitk_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32,
+                                   _f32, _int, _vp],
     "mrec_dense_ftrl_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp],
     "mrec_relu_bwd_colsum_workspace_bytes": [_i64, _i32, _szp],
     "mrec_relu_bwd_colsum_bf16": [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp],

@@ -85,6 +85,7 @@ class WideDeepConfig:
     dynamic_embedding: bool = False  # both tables are hash tables keyed by the raw ids (train_and_eval.py --dynamic_embedding=True,
                                      # wide_and_deep.py:271-274): rows are created on first sight with their default values
     hash_capacity: int = 1 << 22     # rows reserved in HBM for each hash table (dynamic_embedding)
+    fold_splitk: bool = True       # one GPU: split-K partial sums of the weight gradients are added inside the dense-Adam kernel
     relu_epilogue: bool = True     # hidden layers: bias + ReLU in the GEMM epilogue instead of a separate ReLU pass
     graph_bound_inputs: int = 0    # how many recurring (ids, wts, label) buffer triples get a front graph of their own (no staging
                                    # copies); measured gain 2 us/step for ~0.5 GB of graph pool each, so off
@@ -247,6 +248,9 @@ class WideDeepEngine:
         self._dw_stream = torch.cuda.Stream(device=self.device) if (self._gpu and cfg.parallel_dw) else None
         self._mlp_graph = None        # dict: captured fused-MLP step + its static input / output tensors
         self._dw0_pending = None      # graph of the deferred first-layer weight gradient, to replay this step
+        # one GPU: leave the weight gradients as split-K partials and let the dense-Adam kernel add them up
+        self._fold_splitk = bool(self._gpu and world == 1 and cfg.fold_splitk and kernels is None)
+        self._dw_parts = {}
         self.deep_apply_timer = None  # optional ops.KernelTimer armed right before the deep table's sparse apply
         self._front_graph = None      # one-GPU: the whole front of the step (lookups .. MLP backward) as one captured graph
         self._front_bound = {}        # ... and graphs bound to recurring input buffers (no staging copies)
@@ -419,7 +423,10 @@ class WideDeepEngine:
         S = self._splitk(B)
         if S > 1:
             part = torch.bmm(h.view(S, B // S, -1).transpose(1, 2), dh.view(S, B // S, -1))
-            torch.sum(part, dim=0, dtype=torch.float32, out=self.dense_grad[2 * i])
+            if self._fold_splitk:
+                self._dw_parts[i] = part          # summed inside the dense-Adam kernel (one GPU: nobody else needs the sum)
+            else:
+                torch.sum(part, dim=0, dtype=torch.float32, out=self.dense_grad[2 * i])
         else:
             self.dense_grad[2 * i].copy_(torch.mm(h.t(), dh))
 
@@ -958,7 +965,11 @@ class WideDeepEngine:
         akw = dict(lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
                    beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=inv_sens)
         flat = self.dense_flat.detach()
-        if self.dense16 is not None:      # also refreshes the bf16 operand shadow
+        if self.dense16 is not None and self._fold_splitk and fused and self._dw_parts:
+            parts = [(self.dense_grad[2 * i].storage_offset(), p_) for i, p_ in sorted(self._dw_parts.items())]
+            self.k.dense_adam_splitk_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, parts,
+                                      shadow_bf16=self.dense16_flat, **akw)
+        elif self.dense16 is not None:      # also refreshes the bf16 operand shadow
             self.k.dense_adam_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, shadow_bf16=self.dense16_flat, **akw)
         else:
             self.k.dense_adam_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, **akw)

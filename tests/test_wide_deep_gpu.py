@@ -109,7 +109,7 @@ def test_fused_mlp_step_matches_autograd(dev):
     outs = []
     for fused in (True, False):
         cfg = WideDeepConfig(vocab_size=20_000, emb_dim=80, field_size=26, batch_size=2048, mlp_dtype="bf16",
-                             fused_mlp=fused)
+                             fused_mlp=fused, fold_splitk=False)      # gradients are compared in their summed form
         e = WideDeepEngine(cfg, dev)
         ids, wts, label = synthetic_batch(cfg, dev, "zipf", seed=5)
         emb, wide, _ = e.lookup(ids, wts)
@@ -246,3 +246,22 @@ def test_host_cached_tables_engine_equals_resident_engine(dev):
     ref = torch.cat([a.deep, a.deep_m, a.deep_v, a.wide, a.wide_accum, a.wide_linear], dim=1).cpu()
     assert torch.equal(full[:, : 3 * D + 3], ref)
     assert torch.equal(a.dense_flat.detach(), b.dense_flat.detach())
+
+
+def test_splitk_partials_folded_into_dense_adam(dev):
+    """fold_splitk (one GPU): the weight gradients stay split-K partials and the dense-Adam kernel adds them up.
+    Same parameters as summing them first, up to the order of the fp32 additions."""
+    from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
+    kw = dict(vocab_size=50000, emb_dim=80, field_size=26, batch_size=16384, mlp_dtype="bf16", graph_mlp=False)
+    a = WideDeepEngine(WideDeepConfig(fold_splitk=True, **kw), dev)
+    b = WideDeepEngine(WideDeepConfig(fold_splitk=False, **kw), dev)
+    assert a._fold_splitk and not b._fold_splitk
+    for s in range(3):
+        batch = synthetic_batch(a.cfg, dev, "zipf", seed=700 + s)
+        la, lb = float(a.train_step(*batch)), float(b.train_step(*batch))
+        assert abs(la - lb) <= 1e-5 * abs(lb)
+    assert len(a._dw_parts) == 4 and a._dw_parts[0].shape[0] == 8          # four hidden layers, split 8 ways at B = 16384
+    pa, pb = a.dense_flat.detach(), b.dense_flat.detach()
+    # Adam turns a gradient into a step of about lr whatever its size, so bound the difference by a fraction of lr
+    assert float((pa - pb).abs().max()) <= 0.5 * a.cfg.adam_lr
+    assert float(((pa - pb).abs() <= 1e-6 + 1e-3 * pb.abs()).float().mean()) >= 0.995
