@@ -89,6 +89,7 @@ class WideDeepConfig:
     relu_epilogue: bool = True     # hidden layers: bias + ReLU in the GEMM epilogue instead of a separate ReLU pass
     graph_bound_inputs: int = 0    # how many recurring (ids, wts, label) buffer triples get a front graph of their own (no staging
                                    # copies); measured gain 2 us/step for ~0.5 GB of graph pool each, so off
+    graph_tail_on_side: bool = True  # whole-front graph: the last layer's two GEMMs are captured on the plan's branch (-5 us/step)
     plan_first: bool = True        # one GPU: queue the plan on the side stream before the gathers rather than behind them
     host_cache_rows: int = 0         # > 0: both tables live in pinned host DRAM behind a device cache of this many rows (the
                                      # reference's vocab_cache_size, wide_and_deep.py:215-265); one GPU
@@ -505,7 +506,28 @@ class WideDeepEngine:
             main.wait_stream(br)
         return g_emb
 
-    def _mlp_step_fused(self, emb, wide, label, defer_dw0=False, after_head=None):
+    def _mlp_bwd_tail_on(self, stream, ctx):
+        """Variant used under whole-front capture: the last layer's two GEMMs are issued on `stream` (the branch the
+        runtime keeps on the launching stream's hardware queue), so the graph ends where the next eager kernel starts."""
+        n = len(self.dims) - 1
+        Wb = [self.dense16[2 * i] for i in range(n - 1)]
+        hs, dh = ctx["hs"], ctx["dh"]
+        main = torch.cuda.current_stream()
+        for i in range(n - 2, 0, -1):
+            self._mlp_dw(i, hs[i], dh)
+            gpre = torch.mm(dh, Wb[i].t())
+            if self.k.relu_bwd_colsum_supported(self.dims[i]):
+                dh = self.k.relu_bwd_colsum(gpre, hs[i], self.dense_grad[2 * (i - 1) + 1])
+            else:
+                dh = torch.ops.aten.threshold_backward(gpre, hs[i], 0)
+                torch.sum(dh, dim=0, dtype=torch.float32, out=self.dense_grad[2 * (i - 1) + 1])
+        stream.wait_stream(main)
+        with torch.cuda.stream(stream):
+            g_emb = torch.mm(dh, Wb[0].t())
+            self._mlp_dw(0, hs[0], dh)
+        return g_emb
+
+    def _mlp_step_fused(self, emb, wide, label, defer_dw0=False, after_head=None, tail_stream=None):
         """Forward + backward of the bf16 MLP written out by hand (no autograd graph).  `emb` arrives
         in bf16 straight from the gather kernel, and the gradient of the MLP input is returned in bf16
         for the sparse apply to widen on load -- the two [B, F*D] fp32<->bf16 cast passes of the
@@ -523,7 +545,10 @@ class WideDeepEngine:
         ctx = self._mlp_head(hs, wide, label)
         if after_head is not None:
             after_head(ctx["g_wide"])
-        g_emb = self._mlp_bwd(ctx, defer_dw0)
+        if tail_stream is not None:
+            g_emb = self._mlp_bwd_tail_on(tail_stream, ctx)
+        else:
+            g_emb = self._mlp_bwd(ctx, defer_dw0)
         return ctx["loss"], g_emb, ctx["g_wide"]
 
     # ---- forward (eval path: PredictWithSigmoid, wide_and_deep.py:495-518) ---------------------
@@ -763,7 +788,11 @@ class WideDeepEngine:
                     holder["recv_gw"] = recv_gw
                 early_gw = holder
             if capturing:
-                loss, g_emb, g_wide = self._mlp_step_fused(emb, wide, label, after_head=after_head)
+                # the runtime keeps the branch whose nodes were captured first -- the plan's -- on the launching stream's
+                # hardware queue; ending the graph there saves most of the cross-queue hand-over to the eager apply
+                tail = self._side if (cfg.graph_tail_on_side and route is None and plan_early is not None
+                                      and self.index is None) else None
+                loss, g_emb, g_wide = self._mlp_step_fused(emb, wide, label, after_head=after_head, tail_stream=tail)
             else:
                 loss, g_emb, g_wide = self._mlp_step(emb, wide, label, after_head=after_head)
             if route is not None and route[4] is None:
