@@ -709,7 +709,9 @@ class WideDeepEngine:
         D = cfg.emb_dim
         inv_sens = 1.0 / cfg.sens
         self._wide_event = None
-        late_cfg = cfg.late_wide if cfg.late_wide is not None else self.world > 1
+        # the wide branch on the side stream: on when sharded (hides a collective) and inside the whole-front graph (no
+        # graph cut to pay for there); off for the one-GPU MLP-graph path, where it costs an extra graph boundary
+        late_cfg = cfg.late_wide if cfg.late_wide is not None else (self.world > 1 or capturing)
         late = bool(self._side is not None and late_cfg and self._fused_bf16())
         plan_early = None
         if self.index is not None or self.hb is not None:
