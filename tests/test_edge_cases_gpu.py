@@ -102,3 +102,36 @@ def test_all_duplicates_and_max_run(dev, oracle):
     assert plan.U == 1
     out = ops.segment_sum(plan, g)[:1]
     assert torch.equal(out, torch.full((1, D), float(n), device=dev))           # integers: exact in any order
+
+
+def test_cross_and_fm_degenerate_shapes(dev, oracle):
+    """Cross stack with no layers / one row / D not a multiple of 64 at the buffer-resource boundary; FM term with one
+    sample and one field."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(4)
+    # L = 0: identity forward, dx0 = dy backward
+    x0 = torch.from_numpy(rng.standard_normal((5, 70)).astype(np.float32)).to(dev)
+    w = torch.zeros((0, 70), device=dev); b = torch.zeros((0, 70), device=dev)
+    assert torch.equal(ops.cross_layers(x0, w, b), x0)
+    dy = torch.from_numpy(rng.standard_normal((5, 70)).astype(np.float32)).to(dev)
+    dx0, dw, db = ops.cross_layers_bwd(x0, w, b, dy)
+    assert torch.equal(dx0, dy) and dw.numel() == 0 and db.numel() == 0
+    # one row, D = 65 (one full 64-lane pass + a single column in the second), 2 layers
+    for B, D, L in ((1, 65, 2), (3, 2048, 1), (2, 1, 3)):
+        x = rng.standard_normal((B, D)).astype(np.float32)
+        ww = (rng.standard_normal((L, D)) / np.sqrt(D)).astype(np.float32)
+        bb = (rng.standard_normal((L, D)) * 0.1).astype(np.float32)
+        out = ops.cross_layers(torch.from_numpy(x).to(dev), torch.from_numpy(ww).to(dev), torch.from_numpy(bb).to(dev))
+        assert np.allclose(out.cpu().numpy(), oracle.cross_layers(x, ww, bb), rtol=1e-5, atol=1e-5), (B, D, L)
+        g = rng.standard_normal((B, D)).astype(np.float32)
+        dx, dww, dbb = ops.cross_layers_bwd(torch.from_numpy(x).to(dev), torch.from_numpy(ww).to(dev),
+                                            torch.from_numpy(bb).to(dev), torch.from_numpy(g).to(dev))
+        rdx, rdw, rdb = oracle.cross_layers_bwd(x, ww, bb, g)
+        assert np.allclose(dx.cpu().numpy(), rdx, rtol=1e-4, atol=1e-4), (B, D, L)
+        assert np.allclose(dww.cpu().numpy(), rdw, rtol=1e-4, atol=1e-4) and np.allclose(dbb.cpu().numpy(), rdb, rtol=1e-4, atol=1e-4)
+    with pytest.raises(Exception):
+        ops.cross_layers(torch.zeros((2, 4096), device=dev), torch.zeros((1, 4096), device=dev), torch.zeros((1, 4096), device=dev))
+    # FM: one sample, one field -> (x^2 - x^2) / 2 = 0 and colsum = x
+    vx = torch.from_numpy(rng.standard_normal((1, 1, 16)).astype(np.float32)).to(dev)
+    fm, cs = ops.fm_forward(vx)
+    assert float(fm.abs().max()) == 0.0 and torch.equal(cs.view(-1), vx.view(-1))
