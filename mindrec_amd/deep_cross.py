@@ -91,6 +91,9 @@ class DeepCrossEngine:
                 p.grad = g
         self.beta1, self.beta2 = np.float32(0.9), np.float32(0.999)
         self.beta1_power, self.beta2_power = np.float32(1.0), np.float32(1.0)
+        if self._gpu:
+            from .wide_deep import enable_tuned_gemms
+            enable_tuned_gemms()                     # shipped GEMM selections (tools/tune_gemms.py), tuning off
 
     def forward(self, emb):
         W1, b1, W2, b2, W3, b3, cw, cb = self.dense

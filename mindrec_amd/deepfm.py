@@ -91,6 +91,9 @@ class DeepFMEngine:
         self.beta1, self.beta2 = np.float32(0.9), np.float32(0.999)
         self.beta1_power, self.beta2_power = np.float32(1.0), np.float32(1.0)
         self._amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[cfg.mlp_dtype]
+        if self._gpu:
+            from .wide_deep import enable_tuned_gemms
+            enable_tuned_gemms()                     # shipped GEMM selections (tools/tune_gemms*.py), tuning off
 
     def _mlp(self, x):
         n = len(self.dims) - 1
@@ -206,15 +209,24 @@ class DeepFMHashEngine:
             self.dense_v = torch.zeros_like(self.dense_flat)
         self.beta1, self.beta2 = np.float32(0.9), np.float32(0.999)
         self.beta1_power, self.beta2_power = np.float32(1.0), np.float32(1.0)
+        self._amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[cfg.mlp_dtype]
+        from .wide_deep import enable_tuned_gemms
+        enable_tuned_gemms()
 
     def _mlp(self, x):
+        """Hidden layers in cfg.mlp_dtype (bf16: MFMA GEMMs, fp32 master weights cast per step), last layer fp32."""
         n = len(self.dims) - 1
-        h = x
+        amp = self._amp
+        h = x.to(amp) if amp is not None else x
         for i in range(n):
-            h = torch.addmm(self.dense[2 * i + 1], h, self.dense[2 * i])
+            W, b = self.dense[2 * i], self.dense[2 * i + 1]
+            if amp is not None and i < n - 1:
+                h = torch.addmm(b.to(amp), h, W.to(amp))
+            else:
+                h = torch.addmm(b, h.float(), W)
             if i < n - 1:
                 h = torch.relu(h)
-        return h
+        return h.float()
 
     def _lookup(self, keys, insert):
         flat = self.V._keys(keys)

@@ -12,7 +12,8 @@ from mindrec_amd.deepfm import DeepFMConfig, DeepFMHashEngine  # noqa: E402
 
 dev = torch.device("cuda:0")
 B, F, D = 16384, 26, 128
-cfg = DeepFMConfig(data_emb_dim=D, data_field_size=F, batch_size=B, mlp_dtype="fp32")
+mlp_dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+cfg = DeepFMConfig(data_emb_dim=D, data_field_size=F, batch_size=B, mlp_dtype=mlp_dtype)
 eng = DeepFMHashEngine(cfg, dev, key_dtype=torch.int64, capacity=1 << 23, permit_filter_value=2, evict_filter_value=100)
 rng = np.random.default_rng(7)
 
@@ -37,5 +38,5 @@ for i in range(steps):
 b.record()
 torch.cuda.synchronize()
 ms = a.elapsed_time(b) / steps
-print(f"configs[4] step (DeepFM + hash tables, int64 keys, D=128, permit 2): {ms:.3f} ms = {B / ms * 1e3 / 1e6:.2f} M samples/s; "
+print(f"configs[4] step (DeepFM + hash tables, int64 keys, D=128, permit 2, MLP {mlp_dtype}): {ms:.3f} ms = {B / ms * 1e3 / 1e6:.2f} M samples/s; "
       f"{len(eng.V)} keys resident; loss {float(loss):.5f}")
