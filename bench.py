@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- Wide&Deep training throughput on the MI355X embedding path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: spawns N ranks itself, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one synthetic Criteo-shaped batch that is already resident
-in HBM: id dedup + inverted index, deep/wide lookups, the 5-layer MLP forward/backward, the fused
-segment-sum + LazyAdam apply on the deep table, the FTRL apply on the wide table and the dense
-optimizer (mindrec_amd/wide_deep.py; reference models/wide_deep/src/wide_and_deep.py:472-492).
+in HBM: id dedup + inverted index, deep/wide lookups, the 5-layer MLP forward/backward (hand-written MFMA
+kernels), the fused segment-sum + LazyAdam apply on the deep table, the FTRL apply on the wide table and the
+dense optimizer (mindrec_amd/wide_deep.py; reference models/wide_deep/src/wide_and_deep.py:472-492).
 Workload = BASELINE.json configs[1]: vocab 200 M, dim 80, batch 16384 per GPU, 26 categorical slots,
 fp32 tables.  Rank 0 prints ONE JSON line.
+
+Timing: W untimed warmup steps, then R (--repeats, default 5) blocks of EXACTLY K steps, each bracketed by a
+barrier + synchronize on both sides and reduced with MAX over the ranks; `ms_per_step` / `value` are the MEDIAN
+block, min / max are reported beside it.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,6 +31,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; the median block is reported")
     ap.add_argument("--vocab", type=int, default=200_000_000)
     ap.add_argument("--emb-dim", type=int, default=80)
     ap.add_argument("--batch", type=int, default=16384, help="per-GPU batch (reference passes batch_size per worker)")
@@ -33,29 +39,21 @@ def parse():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--mlp-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of each cpu_baseline leg")
     ap.add_argument("--n-batches", type=int, default=4, help="distinct resident batches cycled through")
     ap.add_argument("--split-state", action="store_true", help="p, m, v as three separate arrays (default: fused rows)")
     ap.add_argument("--no-overlap-plan", action="store_true", help="run dedup + inverted index on the main stream")
     ap.add_argument("--no-overlap-wide-apply", action="store_true", help="wide FTRL after the deep apply on the main stream")
-    ap.add_argument("--late-wide", choices=["auto", "on", "off"], default="auto", help="wide branch on the side stream under the hidden-layer GEMMs (auto: when sharded)")
+    ap.add_argument("--late-wide", choices=["auto", "on", "off"], default="auto",
+                    help="wide branch on the side stream under the hidden-layer GEMMs (auto: when sharded / in the front graph)")
     ap.add_argument("--no-early-route", action="store_true", help="shards: request exchange on the main stream (waits for the previous step)")
-    ap.add_argument("--parallel-dw-from", type=int, default=0)
-    ap.add_argument("--parallel-dw", action="store_true", help="weight-gradient GEMMs on a parallel branch of the backward (measured slower)")
-    ap.add_argument("--overlap-dw0", action="store_true", help="first-layer weight-gradient GEMM beside the sparse apply (side stream)")
     ap.add_argument("--dynamic-embedding", action="store_true", help="hash tables keyed by the raw ids (reference --dynamic_embedding=True); "
                     "use a --vocab small enough for --hash-capacity, e.g. --vocab 3000000")
     ap.add_argument("--hash-capacity", type=int, default=1 << 22)
     ap.add_argument("--host-cache-rows", type=int, default=0, help="tables in pinned host DRAM behind a device cache of this many rows "
                     "(the reference's vocab_cache_size); keep --vocab x 976 B within the host's RAM")
-    ap.add_argument("--no-relu-epilogue", action="store_true", help="hidden layers as addmm + a separate ReLU pass")
-    ap.add_argument("--no-plan-first", action="store_true", help="plan queued behind the gathers")
     ap.add_argument("--no-graph-front", action="store_true", help="one GPU: only the MLP as HIP graphs, lookups / plan issued kernel by kernel")
-    ap.add_argument("--no-graph-mlp", action="store_true", help="issue the fused MLP step kernel by kernel instead of replaying its HIP graph")
-    ap.add_argument("--overlap-wide", action="store_true", help="also run wide_sum on the side stream (measured slower)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (the product path); gloo stages collectives through the host and lets "
-                         "several ranks share one GPU (debugging only)")
+    ap.add_argument("--no-graph-mlp", action="store_true", help="issue the MLP step kernel by kernel instead of replaying its HIP graph")
     return ap.parse_args()
 
 
@@ -64,13 +62,37 @@ def median(xs):
     return xs[len(xs) // 2] if xs else float("nan")
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start N ranks (one per GPU) with
+    torch.distributed.run as a CHILD process -- this process has made no GPU call yet and makes none -- relay the
+    ranks' output (rank 0 prints the JSON line) and exit with the child's code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
+
+
 def cpu_baseline(args, seconds):
-    """The oracle (CPU restatement, scalar C, 1 thread) on a bounded sample of the same workload:
-    the embedding path only (lookup + wide sum + sparse LazyAdam + sparse FTRL) at the same batch
-    shape, with the table scaled down to fit host RAM (random-row bandwidth is insensitive to V once
-    V*D*4 >> LLC).  MindSpore's own CPU path cannot be timed: it is not installable here."""
+    """CPU legs on the GPU box's host cores, each on a bounded sample of the same workload (same batch shape, table
+    scaled down to fit host RAM: random-row bandwidth is insensitive to V once V*D*4 >> LLC):
+      port_1t   the oracle (oracle/mrec_oracle.c, scalar C) on ONE thread: lookup + wide sum + sparse LazyAdam + sparse FTRL
+      port_mt   the same restatement on all host threads (the *_mt entries; bit-identical results)
+      torch_cpu an independent second opinion: torch.unique + index_select + index_add_ + vectorised Adam/FTRL row updates
+      mlp       the dense net of the same step (fwd + bwd, fp32) through torch's CPU GEMMs
+    `value` = whole step = port_mt embedding path + mlp.  MindSpore's own CPU path cannot be timed: not installable here."""
     import numpy as np
+    import torch
+    import torch.nn.functional as F
     from oracle import oracle as O
+    ncpu = max(1, os.cpu_count() or 1)
+    threads = min(ncpu, 64)
     V = min(args.vocab, 2_000_000)
     D, B, Fd = args.emb_dim, args.batch, args.fields
     rng = np.random.default_rng(1000)
@@ -80,31 +102,57 @@ def cpu_baseline(args, seconds):
     g = rng.standard_normal((B * Fd, D)).astype(np.float32)
     gw = rng.standard_normal((B * Fd, 1)).astype(np.float32)
     wts = np.ones((B, Fd), np.float32)
+
+    def oracle_leg(th, budget):
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            ids = rng.integers(0, V, size=(B, Fd)).astype(np.int32)
+            O.gather_rows(p, ids, wts, threads=th)
+            O.wide_sum(w, ids, wts, 0.0, threads=th)
+            O.sparse_lazy_adam(p, m, v, ids, g, wts, grad_scale=1 / 1024, threads=th)
+            O.sparse_ftrl(w, wa, wl, ids, gw, None, grad_scale=1 / 1024, threads=th)
+            steps += 1
+            if time.perf_counter() - t0 > budget or steps >= 200:
+                break
+        return (time.perf_counter() - t0) / steps, steps
+
+    t_1t, n_1t = oracle_leg(0, seconds)
+    t_mt, n_mt = oracle_leg(threads, seconds)
+
+    # second opinion: PyTorch-CPU restatement of the same embedding path
+    torch.set_num_threads(threads)
+    tp, tm, tv = torch.from_numpy(p), torch.from_numpy(m), torch.from_numpy(v)
+    tw, twa, twl = torch.from_numpy(w), torch.from_numpy(wa), torch.from_numpy(wl)
+    tg, tgw = torch.from_numpy(g), torch.from_numpy(gw)
     steps, t0 = 0, time.perf_counter()
     while True:
-        ids = rng.integers(0, V, size=(B, Fd)).astype(np.int32)
-        ts = time.perf_counter()
-        O.gather_rows(p, ids, wts)
-        O.wide_sum(w, ids, wts, 0.0)
-        O.sparse_lazy_adam(p, m, v, ids, g, wts, grad_scale=1 / 1024)
-        O.sparse_ftrl(w, wa, wl, ids, gw, None, grad_scale=1 / 1024)
+        ids = torch.from_numpy(rng.integers(0, V, size=(B * Fd,)).astype(np.int64))
+        emb = tp.index_select(0, ids)                                           # lookup
+        _ = tw.index_select(0, ids).view(B, Fd).sum(dim=1)                      # wide sum
+        uq, inv = torch.unique(ids, return_inverse=True)
+        gs = torch.zeros((uq.numel(), D)).index_add_(0, inv, tg).mul_(1 / 1024)  # RowTensor dedup
+        mm = tm.index_select(0, uq).mul_(0.9).add_(gs, alpha=0.1)
+        vv = tv.index_select(0, uq).mul_(0.999).addcmul_(gs, gs, value=0.001)
+        tp.index_copy_(0, uq, tp.index_select(0, uq) - 3.5e-4 * mm / (vv.sqrt() + 1e-8))
+        tm.index_copy_(0, uq, mm); tv.index_copy_(0, uq, vv)
+        gws = torch.zeros((uq.numel(), 1)).index_add_(0, inv, tgw).mul_(1 / 1024)
+        a0 = twa.index_select(0, uq); a1 = a0 + gws * gws
+        ln = twl.index_select(0, uq) + gws - (a1.sqrt() - a0.sqrt()) / 5e-2 * tw.index_select(0, uq)
+        tw.index_copy_(0, uq, (ln.clamp(-1e-8, 1e-8) - ln) / (a1.sqrt() / 5e-2 + 2e-8))
+        twa.index_copy_(0, uq, a1); twl.index_copy_(0, uq, ln)
         steps += 1
+        del emb
         if time.perf_counter() - t0 > seconds or steps >= 200:
             break
-        _ = ts
-    dt = time.perf_counter() - t0
-    t_embed = dt / steps
+    t_torch, n_torch = (time.perf_counter() - t0) / steps, steps
+
     # the dense net of the same step (fwd + bwd, fp32) on the host's cores through torch's CPU GEMMs
-    import torch
-    import torch.nn.functional as F
-    threads = max(1, min(os.cpu_count() or 1, 16))
-    torch.set_num_threads(threads)
     dims = [Fd * D, 1024, 512, 256, 128, 1]
     Ws = [(torch.randn(dims[i], dims[i + 1]) * 0.01).requires_grad_(True) for i in range(5)]
     bs = [torch.zeros(dims[i + 1], requires_grad=True) for i in range(5)]
     x = torch.randn(B, Fd * D, requires_grad=True)
     y = (torch.rand(B, 1) < 0.25).float()
-    t_mlp, reps = 0.0, 0
+    t_mlp, reps, t0 = 0.0, 0, time.perf_counter()
     for it in range(4):
         t1 = time.perf_counter()
         h = x
@@ -116,59 +164,64 @@ def cpu_baseline(args, seconds):
         if it:                      # first pass warms the thread pool
             t_mlp += time.perf_counter() - t1
             reps += 1
-        if time.perf_counter() - t0 > 2.5 * seconds:
+        if time.perf_counter() - t0 > 1.5 * seconds:
             break
     t_mlp = t_mlp / max(reps, 1)
-    whole = B / (t_embed + t_mlp) if reps else None
-    return {"value": round(whole, 1) if whole else round(B / t_embed, 1), "unit": "samples/s", "cores": threads if reps else 1,
-            "kind": "port", "embedding_path_only": round(B / t_embed, 1), "embedding_ms": round(t_embed * 1e3, 1),
-            "mlp_ms": round(t_mlp * 1e3, 1) if reps else None,
-            "sample": f"whole step = embedding path (lookup+wide_sum+sparse LazyAdam+sparse FTRL: oracle/mrec_oracle.c, 1 thread, "
-                      f"{steps} steps) + MLP {dims[0]}-1024-512-256-128-1 fwd+bwd (torch CPU fp32, {threads} threads, {reps} steps); "
-                      f"batch {B}x{Fd}, dim {D}, table scaled to V={V}, uniform ids; MindSpore CPU not installable here"}
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    by = (B * Fd) * 4 + 2 * (B * Fd) * D * 4 + (B * Fd) * 4 + (B * Fd) * D * 4 + 6 * (B * Fd) * D * 4      # lookup + apply, U = N
+    return {"value": round(B / (t_mt + t_mlp), 1) if reps else round(B / t_mt, 1), "unit": "samples/s", "cores": threads,
+            "kind": "port", "host_cpu": model, "host_threads_available": ncpu,
+            "legs": {
+                "port_1t": {"samples_per_s": round(B / t_1t, 1), "ms": round(t_1t * 1e3, 1), "cores": 1, "steps": n_1t,
+                            "embed_gbps": round(by / t_1t / 1e9, 2)},
+                "port_mt": {"samples_per_s": round(B / t_mt, 1), "ms": round(t_mt * 1e3, 1), "cores": threads, "steps": n_mt,
+                            "embed_gbps": round(by / t_mt / 1e9, 2)},
+                "torch_cpu": {"samples_per_s": round(B / t_torch, 1), "ms": round(t_torch * 1e3, 1), "cores": threads, "steps": n_torch,
+                              "embed_gbps": round(by / t_torch / 1e9, 2)},
+                "mlp_torch_cpu_fp32": {"ms": round(t_mlp * 1e3, 1) if reps else None, "cores": threads, "steps": reps}},
+            "sample": f"embedding path (lookup + wide_sum + sparse LazyAdam + sparse FTRL) at batch {B}x{Fd}, dim {D}, table scaled to "
+                      f"V={V}, uniform ids, a fresh batch per step; value = all-core oracle leg + torch-CPU MLP {dims[0]}-1024-512-256-128-1 "
+                      f"fwd+bwd; MindSpore CPU not installable here"}
 
 
 def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                   # never returns
     # RCCL / cross-process tensor sharing on this pool needs dmabuf IPC (the driver image exports this already)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    args = parse()
     import torch
     import torch.distributed as dist
-    from mindrec_amd import _lib
+    from mindrec_amd import _lib, ops
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, embedding_bytes, synthetic_batch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (mindrec_amd has no CPU fallback)")
-    if args.backend == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rc = _lib.lib().mrec_device_ok()
     if rc != 0:
         raise SystemExit(f"libmrec_hip.so cannot run on this device: {_lib.lib().mrec_strerror(rc).decode()}")
-    group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)          # "nccl" IS RCCL on ROCm
 
     cfg = WideDeepConfig(vocab_size=args.vocab, emb_dim=args.emb_dim, field_size=args.fields, batch_size=args.batch,
                          mlp_dtype=args.mlp_dtype, fused_state=not args.split_state,
-                         overlap_plan=not args.no_overlap_plan, overlap_wide=args.overlap_wide,
-                         graph_mlp=not args.no_graph_mlp, graph_front=not args.no_graph_front, plan_first=not args.no_plan_first, relu_epilogue=not args.no_relu_epilogue,
+                         overlap_plan=not args.no_overlap_plan, graph_mlp=not args.no_graph_mlp, graph_front=not args.no_graph_front,
                          dynamic_embedding=args.dynamic_embedding, hash_capacity=args.hash_capacity,
-                         host_cache_rows=args.host_cache_rows, overlap_dw0=args.overlap_dw0, parallel_dw=args.parallel_dw, parallel_dw_from=args.parallel_dw_from, early_route=not args.no_early_route, late_wide={'auto': None, 'on': True, 'off': False}[args.late_wide],
+                         host_cache_rows=args.host_cache_rows, early_route=not args.no_early_route,
+                         late_wide={'auto': None, 'on': True, 'off': False}[args.late_wide],
                          overlap_wide_apply=not args.no_overlap_wide_apply)
-    eng = WideDeepEngine(cfg, dev, rank=rank, world=world, group=group)
+    eng = WideDeepEngine(cfg, dev, rank=rank, world=world)
     batches = [synthetic_batch(cfg, dev, args.dist, seed=1000 + i, rank=rank) for i in range(args.n_batches)]
     torch.cuda.synchronize()
 
@@ -177,28 +230,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Priming (setup, whatever --warmup says): workspaces, GEMM library handles and the HIP graph of the MLP
-    # step come into being in the engine's first three steps.
-    # (2 x n_batches more steps let a one-GPU engine bind a front graph to each of the rotating input batches.)
-    for i in range(3 + 2 * len(batches)):
+    # Priming (setup, whatever --warmup says): workspaces and the HIP graphs come into being in the engine's first steps.
+    for i in range(5):
         eng.train_step(*batches[i % len(batches)])
     barrier()
     for i in range(args.warmup):
         eng.train_step(*batches[i % len(batches)])
     barrier()
-    from mindrec_amd import ops
-    ktimers = [ops.KernelTimer() for _ in range(args.steps)]     # HIP events around k_apply_main only
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        eng.deep_apply_timer = ktimers[i]      # armed by the engine right before the deep-table LazyAdam launch
-        eng.train_step(*batches[i % len(batches)])
-    barrier()
-    dt = time.perf_counter() - t0
-    graphs_used = {"front": eng._front_graph is not None or bool(eng._front_bound), "mlp": eng._mlp_graph is not None}
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    block_s, kmain = [], []
+    for r in range(max(1, args.repeats)):
+        ktimers = [ops.KernelTimer() for _ in range(args.steps)]     # HIP events around k_apply_main only
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            eng.deep_apply_timer = ktimers[i]      # armed by the engine right before the deep-table LazyAdam launch
+            eng.train_step(*batches[i % len(batches)])
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        block_s.append(dt)
+        kmain += [t.ms() for t in ktimers]
+    dt = median(block_s)
+    graphs_used = {"front": eng._front_graph is not None, "mlp": eng._mlp_graph is not None}
 
     # Per-phase device times (informational "kernels_ms"): HIP events around every phase, recorded in a few
     # EXTRA steps after the timed region -- two dozen timing events per step serialise the queue and cost
@@ -212,25 +268,26 @@ def main():
     # and captures the MLP graphs instead, which happens here
     kern_ms = {k: [a.elapsed_time(b) for a, b in evs][2:] for k, evs in eng.timers.items()}
     eng.timers = None
-    N = args.batch * args.fields
     plan = eng.last_plan
     U = plan.U                                  # unique ids of the last step's (local) apply
     n_apply = plan.n
-    bf16_io = eng._fused_bf16()                       # gather writes / apply reads bf16 rows (also on the wire)
-    by = embedding_bytes(n_apply, U, args.emb_dim, act_bytes=2 if bf16_io else 4)
-    kmain = [t.ms() for t in ktimers]
+    io16 = eng._mfma                            # gather writes / apply reads 16-bit rows (also on the wire)
+    by = embedding_bytes(n_apply, U, args.emb_dim, act_bytes=2 if io16 else 4)
     apply_ms = sum(kmain) / len(kmain)
     achieved = by["apply_deep"] / (apply_ms * 1e-3) / 1e9
     peak = 8000.0
-    # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, collected
-    # with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command and corrected
-    # per MI355X_MICROARCH.md); only quoted when this run is the workload that was profiled.
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")      # collected on the bf16-gradient variant
+    # HBM bytes per launch of the dominant kernel come from the committed PMC passes (profiles/: rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate runs of this same command, corrected per MI355X_MICROARCH.md) -- NOT measured in this run;
+    # quoted only when this run is the workload that was profiled, and labelled with their source.
+    traffic, traffic_source = None, None
     default_cfg = (args.vocab == 200_000_000 and args.emb_dim == 80 and args.batch == 16384 and args.fields == 26
                    and args.dist == "uniform" and not args.split_state and world == 1 and args.mlp_dtype == "bf16")
-    if default_cfg and os.path.exists(pmc_path):
-        traffic = json.load(open(pmc_path)).get("apply_main_adam", {}).get("total_bytes")
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        pmc_path = os.path.join(ROOT, "profiles", name)
+        if default_cfg and os.path.exists(pmc_path):
+            traffic = json.load(open(pmc_path)).get("apply_main_adam", {}).get("total_bytes")
+            traffic_source = f"profiles/{name} (separate rocprofv3 --pmc passes of this command; not measured in this run)"
+            break
     # streaming-copy ceiling of this box, measured in this run (outside the timed region): 1 GiB device-to-device
     copy_gbps = None
     if rank == 0:
@@ -245,6 +302,12 @@ def main():
         torch.cuda.synchronize()
         copy_gbps = round(5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
         del src, dst
+
+    def med_ms(name):
+        return median(kern_ms[name]) if name in kern_ms and kern_ms[name] else None
+
+    lookup_ms, wide_ms, wapply_ms = med_ms("gather_deep"), med_ms("wide_sum"), med_ms("apply_wide")
+    dt_name = {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.mlp_dtype]
     out = {
         "metric": "samples/sec Wide&Deep Criteo batch16384",
         "value": round(args.batch * world * args.steps / dt, 1),
@@ -253,31 +316,43 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "repeats": len(block_s),
+        "ms_per_step_min": round(min(block_s) / args.steps * 1e3, 4),
+        "ms_per_step_max": round(max(block_s) / args.steps * 1e3, 4),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": dt_name,
         "data": "synthetic",
         "config": {"workload": f"Wide&Deep Criteo (BASELINE configs[1]): vocab {args.vocab}, dim {args.emb_dim}, "
-                               f"batch {args.batch}/GPU, {args.fields} fields, fp32 tables ({'split' if args.split_state else 'fused-row'} "
-                               f"state layout), {args.dist} ids{', hash tables keyed by id (dynamic_embedding)' if args.dynamic_embedding else ''}"
+                               f"batch {args.batch}/GPU, {args.fields} fields, fp32 tables and fp32 optimizer state ({'split' if args.split_state else 'fused-row'} "
+                               f"layout), {args.dist} ids{', hash tables keyed by id (dynamic_embedding)' if args.dynamic_embedding else ''}"
                                f"{f', tables in host DRAM behind a {args.host_cache_rows}-row device cache' if args.host_cache_rows else ''}, "
-                               f"MLP {cfg.field_size * cfg.emb_dim}-1024-512-256-128-1 in {args.mlp_dtype}",
+                               f"MLP {cfg.field_size * cfg.emb_dim}-1024-512-256-128-1 in {args.mlp_dtype} "
+                               f"({'hand-written MFMA kernels' if eng._mfma else 'torch GEMMs'}; looked-up rows and row gradients in {dt_name})",
                    "global_batch": args.batch * world, "id_dist": args.dist, "hip_graphs": graphs_used, "unique_frac": round(U / max(n_apply, 1), 4),
                    "parallelism": "1 GPU" if world == 1 else f"tables row-sharded x{world} (RCCL all-to-all), MLP dp{world}"},
-        "roofline": {"bound": "hbm", "kernel": "k_apply_main<4,int,UpdAdam,%s> (fused segment-sum + LazyAdam row update)" % ("bf16_t" if bf16_io else "float"),
-                     "row_gradient_dtype": "bf16" if bf16_io else "f32",
+        "roofline": {"bound": "hbm", "kernel": "k_apply_main<4,int,UpdAdam,%s> (fused segment-sum + LazyAdam row update)" % (dt_name + "_t" if io16 else "float"),
+                     "row_gradient_dtype": dt_name if io16 else "f32",
                      "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
-                     "traffic": traffic, "algorithmic_bytes": by["apply_deep"], "avg_ms": round(apply_ms, 5),
+                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": by["apply_deep"], "avg_ms": round(apply_ms, 5),
                      "measured_copy_gbps": copy_gbps,
                      "timing": "HIP events around k_apply_main on its launch stream (mrec_profile_next_apply), "
-                               "averaged over the timed steps"},
-        "kernels_ms": {k: round(sum(v) / len(v), 5) for k, v in sorted(kern_ms.items())},
-        "embed_gbps": {
-            "lookup": round(by["lookup"] / (median(kern_ms["gather_deep"]) * 1e-3) / 1e9, 1) if (world == 1 and "gather_deep" in kern_ms) else None,
-            "apply_deep": round(achieved, 1),
-        },
+                               f"averaged over the {len(kmain)} timed steps"},
+        "kernels_ms": {k: round(sum(v) / len(v), 5) for k, v in sorted(kern_ms.items()) if v},
     }
+    if world == 1 and lookup_ms:
+        out["roofline_lookup"] = {"bound": "hbm", "kernel": "k_gather_rows (EmbeddingLookup, mask fused)", "achieved": round(by["lookup"] / (lookup_ms * 1e-3) / 1e9, 1),
+                                  "peak": peak, "unit": "GB/s", "frac": round(by["lookup"] / (lookup_ms * 1e-3) / 1e9 / peak, 4),
+                                  "algorithmic_bytes": by["lookup"], "avg_ms": round(lookup_ms, 5),
+                                  "timing": "torch events around the gather in extra steps after the timed region"}
+        if wide_ms and wapply_ms:
+            tot_b = by["lookup"] + by["apply_deep"] + by["wide_lookup"] + by["apply_wide"]
+            tot_ms = lookup_ms + apply_ms + wide_ms + wapply_ms
+            out["roofline_embedding_path"] = {"what": "EmbeddingLookup + sparse apply, deep AND wide tables (north-star quantity)",
+                                              "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 1), "peak": peak, "unit": "GB/s",
+                                              "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / peak, 4), "algorithmic_bytes": tot_b,
+                                              "sum_ms": round(tot_ms, 5)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

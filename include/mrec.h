@@ -98,6 +98,12 @@ int mrec_gather_rows_bf16_i32(const float* table, int64_t V, int64_t ld, int32_t
 int mrec_gather_rows_bf16_i64(const float* table, int64_t V, int64_t ld, int32_t D, const int64_t* ids,
                               int64_t n, const float* row_scale, uint16_t* out, void* stream);
 
+/* ... and with IEEE half output rows: exactly the Cast(x, float16) of wide_and_deep.py:122. */
+int mrec_gather_rows_f16_i32(const float* table, int64_t V, int64_t ld, int32_t D, const int32_t* ids,
+                             int64_t n, const float* row_scale, uint16_t* out, void* stream);
+int mrec_gather_rows_f16_i64(const float* table, int64_t V, int64_t ld, int32_t D, const int64_t* ids,
+                             int64_t n, const float* row_scale, uint16_t* out, void* stream);
+
 /* Wide branch of WideDeepModel.construct (wide_and_deep.py:300,303-306) in one pass:
  * out[b] = sum_f w[ids[b,f] * ldw] * wts[b,f] + *bias_dev   (w is the [V,1] wide table, row
  * stride ldw floats: 1 for a dense column, 4 when it lives in a fused w|accum|linear|pad record). */
@@ -155,6 +161,20 @@ int mrec_sparse_lazy_adam_bf16g_i64(float* p, float* m, float* v, int64_t V, int
                                     float b1_pow, float b2_pow, float grad_scale, int nesterov, void* ws,
                                     size_t ws_bytes, void* stream);
 
+/* LazyAdam with IEEE half row gradients (widened exactly on load). */
+int mrec_sparse_lazy_adam_f16g_i32(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D,
+                                   const int32_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                   const int32_t* seg_offsets, int64_t n, const uint16_t* g, int64_t ldg,
+                                   const float* row_scale, float lr, float b1, float b2, float eps,
+                                   float b1_pow, float b2_pow, float grad_scale, int nesterov, void* ws,
+                                   size_t ws_bytes, void* stream);
+int mrec_sparse_lazy_adam_f16g_i64(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D,
+                                   const int64_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                   const int32_t* seg_offsets, int64_t n, const uint16_t* g, int64_t ldg,
+                                   const float* row_scale, float lr, float b1, float b2, float eps,
+                                   float b1_pow, float b2_pow, float grad_scale, int nesterov, void* ws,
+                                   size_t ws_bytes, void* stream);
+
 /* nn.FTRL sparse apply (FusedSparseFtrl; wide_and_deep.py:423-430). */
 int mrec_sparse_ftrl_f32_i32(float* var, float* accum, float* linear, int64_t V, int64_t ld, int32_t D,
                              const int32_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
@@ -188,8 +208,51 @@ int mrec_dense_adam_splitk_f32(float* p, float* m, float* v, const float* g, uin
                                int32_t nseg, const void* const* parts, const int64_t* starts, const int64_t* lens,
                                const int32_t* splits, float lr, float b1, float b2, float eps, float b1_pow,
                                float b2_pow, float grad_scale, int nesterov, void* stream);
+/* Dense Adam over a flat buffer whose gradient is, for up to 8 segments, the sum of S fp32 slabs
+ * slabs[q][s*lens[q] + e], s < splits[q] (what mrec_dense_bwd_weight_* leaves behind), added in slab order; every other
+ * element reads g.  shadow_kind: 0 none, 1 bf16, 2 fp16 -- the 16-bit operand copy of the updated parameters
+ * (Cast(weight, float16) of DenseLayer.construct, wide_and_deep.py:123-124).  slabs / starts / lens / splits are HOST arrays. */
+int mrec_dense_adam_slabs_f32(float* p, float* m, float* v, const float* g, void* shadow16, int shadow_kind, int64_t n,
+                              int32_t nseg, const float* const* slabs, const int64_t* starts, const int64_t* lens,
+                              const int32_t* splits, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
+                              float grad_scale, int nesterov, void* stream);
 int mrec_dense_ftrl_f32(float* var, float* accum, float* linear, const float* g, int64_t n, float lr,
                         float l1, float l2, float lr_power, float grad_scale, void* stream);
+
+/* ---- DenseLayer on the matrix cores (hand-written MFMA GEMM, csrc/mrec_gemm.h) ------------------------
+ * DenseLayer.construct, models/wide_deep/src/wide_and_deep.py:113-133 (MatMul + BiasAdd + ReLU with fp16 casts under
+ * use_mixed_precision; deep_and_cross.py:94-114 is the same cell) and its bprops.  16-bit operands (`_bf16`: bfloat16,
+ * `_f16`: IEEE half, the reference's dtype), fp32 accumulation, one rounding of the result.  All matrices row-major with
+ * row strides in elements; x / dy / w 16-byte aligned, strides multiples of 8.
+ *
+ * forward:  y[M, N] = act(x[M, K] . w[K, N] + bias[N])   bias fp32 (nullable), relu != 0 applies max(., 0);
+ *           K % 8 == 0, N % 8 == 0.  w is the weight as the reference stores it ([in, out], :100-103). */
+int mrec_dense_fwd_bf16(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bias, int64_t M, int32_t K,
+                        int32_t N, int relu, uint16_t* y, int64_t ldy, void* stream);
+int mrec_dense_fwd_f16(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bias, int64_t M, int32_t K,
+                       int32_t N, int relu, uint16_t* y, int64_t ldy, void* stream);
+/* bprop with respect to the layer's input, fused with the ReLU and BiasAdd bprops of the layer BELOW:
+ *   dx[m, k] = h[m, k] > 0 ? sum_n dy[m, n] * w[k, n] : 0      (h nullable: no mask -- the first layer's input)
+ *   db[k]    = sum_m dx[m, k]                                  (db nullable; sums of the rounded dx, fp32, fixed order)
+ * N % 8 == 0, K % 4 == 0.  ws: mrec_dense_bwd_input_workspace_bytes(M, K) bytes when db != NULL. */
+int mrec_dense_bwd_input_workspace_bytes(int64_t M, int32_t K, size_t* out);
+int mrec_dense_bwd_input_bf16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M, int32_t K,
+                              int32_t N, uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, void* stream);
+int mrec_dense_bwd_input_f16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M, int32_t K,
+                             int32_t N, uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, void* stream);
+/* bprop with respect to the weight: dw[K, N] = x[M, K]^T . dy[M, N], the batch cut in S slabs whose fp32 partial sums
+ * are written to dw_slabs[S, K, N] (slab s = rows [s*c, (s+1)*c) of the batch, c = 64*ceil(ceil(M/64)/S)); the
+ * optimizer adds them up (mrec_dense_adam_slabs_f32).  mrec_dense_bwd_weight_slabs proposes S for this device.
+ * K % 8 == 0, N % 8 == 0 (any M). */
+int mrec_dense_bwd_weight_slabs(int64_t M, int32_t K, int32_t N, int32_t* S_out);
+int mrec_dense_bwd_weight_bf16(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t lddy, int64_t M, int32_t K,
+                               int32_t N, int32_t S, float* dw_slabs, void* stream);
+int mrec_dense_bwd_weight_f16(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t lddy, int64_t M, int32_t K,
+                              int32_t N, int32_t S, float* dw_slabs, void* stream);
+
+/* out[e] = sum over s < S of slabs[s*len + e], in slab order: the weight gradient as one tensor, for consumers other than
+ * mrec_dense_adam_slabs_f32 (the data-parallel all-reduce).  len % 4 == 0, 16-byte aligned. */
+int mrec_dense_sum_slabs_f32(const float* slabs, int32_t S, int64_t len, float* out, void* stream);
 
 /* ---- elementwise ends of the dense net (bf16 training step) ---------------------------------
  * ReLU bprop + BiasAdd bprop of one DenseLayer (wide_and_deep.py:113-133) in one pass:
@@ -210,6 +273,11 @@ int mrec_head_fwd_bwd_bf16(const uint16_t* h4, const float* w5, const float* b5,
                            const float* label, int64_t B, int32_t K5, float dscale, float* logit, float* dlogit,
                            uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss, void* ws,
                            size_t ws_bytes, void* stream);
+/* the same with IEEE half activations (the reference's mixed-precision dtype, wide_and_deep.py:119-128) */
+int mrec_head_fwd_bwd_f16(const uint16_t* h4, const float* w5, const float* b5, const float* wide,
+                          const float* label, int64_t B, int32_t K5, float dscale, float* logit, float* dlogit,
+                          uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss, void* ws,
+                          size_t ws_bytes, void* stream);
 
 /* ---- MapParameter key index ---------------------------------------------------------------
  * mindspore.experimental.MapParameter as built by HashEmbeddingLookup
@@ -229,7 +297,10 @@ int mrec_map_bytes(int64_t capacity_rows, size_t* out);
 int mrec_map_create(mrec_map_t** out, void* mem, size_t mem_bytes, int64_t capacity_rows, void* stream);
 int mrec_map_destroy(mrec_map_t* h);
 /* Device words: [0] = rows handed out so far (high-water mark), [1] = live keys,
- * [2] = keys dropped because the table was full (sticky error counter). */
+ * [2] = keys dropped because the table was full (sticky error counter), [3] = rows on the free list,
+ * [4] = tombstones in the slot array, [6] = slot-array rebuilds so far.  Erase leaves tombstones; once they
+ * exceed a fifth of the slots the erase call rebuilds the slot array from the row side, so a probe for a
+ * missing key always meets an empty slot (every probe loop is bounded by the slot count besides). */
 const int64_t* mrec_map_counters_dev(const mrec_map_t* h);
 int mrec_map_workspace_bytes(int64_t n, size_t* out);
 /* keys must be unique within the call (run mrec_dedup first).  rows_out[i] = row of keys[i];

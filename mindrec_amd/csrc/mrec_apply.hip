@@ -111,6 +111,32 @@ template <bool NT> __device__ __forceinline__ void vload(Vf<2>& r, const bf16_t*
 template <bool NT> __device__ __forceinline__ void vload(Vf<1>& r, const bf16_t* p) {
     r.v = __uint_as_float(((unsigned int)p->v) << 16);
 }
+// IEEE half row gradients (the reference's mixed-precision dtype): widened exactly by v_cvt_f32_f16.
+struct f16_t { uint16_t v; };
+__device__ __forceinline__ float2 mrec_h2f2(unsigned int u) {
+    typedef _Float16 mrec_h2 __attribute__((ext_vector_type(2)));
+    const mrec_h2 h = __builtin_bit_cast(mrec_h2, u);
+    return make_float2((float)h[0], (float)h[1]);
+}
+template <bool NT> __device__ __forceinline__ void vload(Vf<4>& r, const f16_t* p) {
+    uint2 u;
+    if (NT) {
+        typedef unsigned int mrec_u2 __attribute__((ext_vector_type(2)));
+        mrec_u2 t = __builtin_nontemporal_load((const mrec_u2*)p);
+        u = make_uint2(t.x, t.y);
+    } else {
+        u = *(const uint2*)p;
+    }
+    const float2 a = mrec_h2f2(u.x), b = mrec_h2f2(u.y);
+    r.v = make_float4(a.x, a.y, b.x, b.y);
+}
+template <bool NT> __device__ __forceinline__ void vload(Vf<2>& r, const f16_t* p) {
+    const unsigned int u = NT ? __builtin_nontemporal_load((const unsigned int*)p) : *(const unsigned int*)p;
+    r.v = mrec_h2f2(u);
+}
+template <bool NT> __device__ __forceinline__ void vload(Vf<1>& r, const f16_t* p) {
+    r.v = (float)__builtin_bit_cast(_Float16, p->v);
+}
 template <bool NT> __device__ __forceinline__ void vstore(float* p, const Vf<4>& x) {
     if (NT) {
         mrec_f4 t = {x.v.x, x.v.y, x.v.z, x.v.w};
@@ -639,6 +665,27 @@ MREC_API int mrec_sparse_lazy_adam_bf16g_i64(float* p, float* m, float* v, int64
     return lazy_adam_impl<int64_t, bf16_t>(p, m, v, V, ld, D, uniq, sorted_pos, sorted_seg, seg_offsets, n,
                                            (const bf16_t*)g, ldg, row_scale, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale,
                                            nesterov, ws, ws_bytes, stream);
+}
+
+MREC_API int mrec_sparse_lazy_adam_f16g_i32(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D,
+                                            const int32_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                            const int32_t* seg_offsets, int64_t n, const uint16_t* g, int64_t ldg,
+                                            const float* row_scale, float lr, float b1, float b2, float eps,
+                                            float b1_pow, float b2_pow, float grad_scale, int nesterov, void* ws,
+                                            size_t ws_bytes, void* stream) {
+    return lazy_adam_impl<int32_t, f16_t>(p, m, v, V, ld, D, uniq, sorted_pos, sorted_seg, seg_offsets, n,
+                                          (const f16_t*)g, ldg, row_scale, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale,
+                                          nesterov, ws, ws_bytes, stream);
+}
+MREC_API int mrec_sparse_lazy_adam_f16g_i64(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D,
+                                            const int64_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                            const int32_t* seg_offsets, int64_t n, const uint16_t* g, int64_t ldg,
+                                            const float* row_scale, float lr, float b1, float b2, float eps,
+                                            float b1_pow, float b2_pow, float grad_scale, int nesterov, void* ws,
+                                            size_t ws_bytes, void* stream) {
+    return lazy_adam_impl<int64_t, f16_t>(p, m, v, V, ld, D, uniq, sorted_pos, sorted_seg, seg_offsets, n,
+                                          (const f16_t*)g, ldg, row_scale, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale,
+                                          nesterov, ws, ws_bytes, stream);
 }
 
 MREC_API int mrec_sparse_ftrl_f32_i32(float* var, float* accum, float* linear, int64_t V, int64_t ld, int32_t D,

@@ -1,0 +1,190 @@
+// mrec_dense.hip -- DenseLayer (models/wide_deep/src/wide_and_deep.py:113-133; models/deep_and_cross/src/
+// deep_and_cross.py:94-114) on the gfx950 matrix cores: the C ABI over the MFMA GEMM body of mrec_gemm.h.
+//
+//   forward     y  = act(x . W + b)                     MatMul + BiasAdd + ReLU, 16-bit operands, fp32 accumulate
+//   bprop/input dx = (dy . W^T) [masked by h > 0]       MatMul bprop + the ReLU bprop of the layer below, and
+//               db[k] = sum_m dx[m, k]                  that layer's BiasAdd bprop (column sums, fixed order)
+//   bprop/weight dW = x^T . dy                          reduction over the batch, split in S slabs of fp32
+//                                                       partial sums (never rounded to 16 bits)
+// Everything is reproducible run to run: no atomics, fixed summation orders.
+#include "mrec_common.h"
+#include "mrec_gemm.h"
+
+namespace {
+
+using mgemm::Args;
+
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+int g_cu_count = 0;
+int cu_count() {
+    if (g_cu_count == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            g_cu_count = n;
+        else
+            g_cu_count = 256;
+    }
+    return g_cu_count;
+}
+
+// db[k] = sum over tile rows of the per-tile column sums, in tile order
+__global__ __launch_bounds__(256) void k_colsum_tiles(const float* __restrict__ ws, int nT, int K, float* __restrict__ db) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int t = 0; t < nT; ++t) s += ws[(int64_t)t * K + k];
+    db[k] = s;
+}
+
+// out[e] = sum_s slabs[s * len + e] in slab order (float4 lanes)
+__global__ __launch_bounds__(256) void k_sum_slabs(const float4* __restrict__ slabs, int S, int64_t len4, float4* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len4; i += (int64_t)gridDim.x * 256) {
+        float4 a = slabs[i];
+        for (int s = 1; s < S; ++s) {
+            const float4 u = slabs[(int64_t)s * len4 + i];
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        }
+        out[i] = a;
+    }
+}
+
+template <bool F16>
+int fwd_impl(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bias, int64_t M, int32_t K, int32_t N, int relu,
+             uint16_t* y, int64_t ldy, void* stream) {
+    if (M < 0 || K <= 0 || N <= 0 || ldx < K || ldy < N) return MREC_EINVAL;
+    if (M == 0) return MREC_OK;
+    if (!x || !w || !y) return MREC_EINVAL;
+    if (K % 8 || N % 8 || ldx % 8 || ldy % 4 || !al16(x) || !al16(w) || (((uintptr_t)y) & 7)) return MREC_EUNSUPPORTED;
+    if (M * ldx * 2 >= (int64_t(1) << 31) || (int64_t)K * N * 2 >= (int64_t(1) << 31) || M > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
+    Args a{};
+    a.P = x; a.Q = w; a.C = y; a.bias = bias;
+    a.ldp = ldx; a.ldq = N; a.ldc = ldy;
+    a.Pext = (int)M; a.Qext = N; a.K = K;
+    a.nTp = (int)mrec_cdiv(M, 256); a.nTq = (int)mrec_cdiv(N, 256);
+    a.kt_per_slab = (K + 63) / 64;
+    a.relu = relu;
+    mgemm::k_gemm256<false, true, mgemm::EPI_FWD, F16><<<a.nTp * a.nTq, mgemm::kThreads, 0, (hipStream_t)stream>>>(a);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+template <bool F16>
+int bwd_input_impl(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M, int32_t K, int32_t N,
+                   uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, void* stream) {
+    if (M < 0 || K <= 0 || N <= 0 || lddy < N || lddx < K) return MREC_EINVAL;
+    if (M == 0) {
+        if (db) MREC_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)K * 4, (hipStream_t)stream));
+        return MREC_OK;
+    }
+    if (!dy || !w || !dx) return MREC_EINVAL;
+    if (N % 8 || K % 4 || lddy % 8 || lddx % 4 || !al16(dy) || !al16(w) || (((uintptr_t)dx) & 7) || (h && (((uintptr_t)h) & 7)))
+        return MREC_EUNSUPPORTED;
+    if (M * lddy * 2 >= (int64_t(1) << 31) || (int64_t)K * N * 2 >= (int64_t(1) << 31) || M > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
+    const int nTp = (int)mrec_cdiv(M, 256);
+    float* part = nullptr;
+    if (db) {
+        if (!ws || ws_bytes < (size_t)nTp * K * 4) return MREC_EWORKSPACE;
+        part = (float*)ws;
+    }
+    Args a{};
+    a.P = dy; a.Q = w; a.C = dx; a.H = h; a.colsum_ws = part;
+    a.ldp = lddy; a.ldq = N; a.ldc = lddx;
+    a.Pext = (int)M; a.Qext = K; a.K = N;
+    a.nTp = nTp; a.nTq = (int)mrec_cdiv(K, 256);
+    a.kt_per_slab = (N + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    mgemm::k_gemm256<false, false, mgemm::EPI_DGRAD, F16><<<a.nTp * a.nTq, mgemm::kThreads, 0, st>>>(a);
+    if (db) k_colsum_tiles<<<(unsigned)mrec_cdiv(K, 256), 256, 0, st>>>(part, nTp, K, db);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+int weight_slabs(int64_t M, int32_t K, int32_t N) {
+    const int64_t tiles = mrec_cdiv(K, 256) * mrec_cdiv(N, 256);
+    const int64_t Ttot = mrec_cdiv(M, 64);
+    int64_t S = cu_count() / tiles;
+    if (S > 16) S = 16;             // each slab is K*N fp32 written once and read once by the optimizer
+    if (S > Ttot) S = Ttot;
+    if (S < 1) S = 1;
+    return (int)S;
+}
+
+template <bool F16>
+int bwd_weight_impl(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t lddy, int64_t M, int32_t K, int32_t N, int32_t S,
+                    float* dw, void* stream) {
+    if (M < 0 || K <= 0 || N <= 0 || S <= 0 || ldx < K || lddy < N) return MREC_EINVAL;
+    if (!dw) return MREC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 0) {
+        MREC_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)S * K * N * 4, st));
+        return MREC_OK;
+    }
+    if (!x || !dy) return MREC_EINVAL;
+    if (K % 8 || N % 8 || ldx % 8 || lddy % 8 || !al16(x) || !al16(dy) || !al16(dw)) return MREC_EUNSUPPORTED;
+    if (M * ldx * 2 >= (int64_t(1) << 31) || M * lddy * 2 >= (int64_t(1) << 31)) return MREC_EUNSUPPORTED;
+    Args a{};
+    a.P = x; a.Q = dy; a.C = dw;
+    a.ldp = ldx; a.ldq = lddy; a.ldc = N;
+    a.Pext = K; a.Qext = N; a.K = (int)M;
+    a.nTp = (int)mrec_cdiv(K, 256); a.nTq = (int)mrec_cdiv(N, 256);
+    const int Ttot = (int)mrec_cdiv(M, 64);
+    a.kt_per_slab = (Ttot + S - 1) / S;
+    a.slab_stride = (int64_t)K * N;
+    mgemm::k_gemm256<true, true, mgemm::EPI_F32, F16><<<a.nTp * a.nTq * S, mgemm::kThreads, 0, st>>>(a);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+}  // namespace
+
+MREC_API int mrec_dense_fwd_bf16(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bias, int64_t M, int32_t K,
+                                 int32_t N, int relu, uint16_t* y, int64_t ldy, void* stream) {
+    return fwd_impl<false>(x, ldx, w, bias, M, K, N, relu, y, ldy, stream);
+}
+MREC_API int mrec_dense_fwd_f16(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bias, int64_t M, int32_t K,
+                                int32_t N, int relu, uint16_t* y, int64_t ldy, void* stream) {
+    return fwd_impl<true>(x, ldx, w, bias, M, K, N, relu, y, ldy, stream);
+}
+
+MREC_API int mrec_dense_bwd_input_workspace_bytes(int64_t M, int32_t K, size_t* out) {
+    if (!out || M < 0 || K <= 0) return MREC_EINVAL;
+    *out = mrec_align_up((size_t)mrec_cdiv(M > 0 ? M : 1, 256) * K * 4, 256);
+    return MREC_OK;
+}
+MREC_API int mrec_dense_bwd_input_bf16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M,
+                                       int32_t K, int32_t N, uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes,
+                                       void* stream) {
+    return bwd_input_impl<false>(dy, lddy, w, h, M, K, N, dx, lddx, db, ws, ws_bytes, stream);
+}
+MREC_API int mrec_dense_bwd_input_f16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M,
+                                      int32_t K, int32_t N, uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    return bwd_input_impl<true>(dy, lddy, w, h, M, K, N, dx, lddx, db, ws, ws_bytes, stream);
+}
+
+MREC_API int mrec_dense_bwd_weight_slabs(int64_t M, int32_t K, int32_t N, int32_t* S_out) {
+    if (!S_out || M < 0 || K <= 0 || N <= 0) return MREC_EINVAL;
+    *S_out = weight_slabs(M, K, N);
+    return MREC_OK;
+}
+MREC_API int mrec_dense_bwd_weight_bf16(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t lddy, int64_t M, int32_t K,
+                                        int32_t N, int32_t S, float* dw_slabs, void* stream) {
+    return bwd_weight_impl<false>(x, ldx, dy, lddy, M, K, N, S, dw_slabs, stream);
+}
+MREC_API int mrec_dense_bwd_weight_f16(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t lddy, int64_t M, int32_t K,
+                                       int32_t N, int32_t S, float* dw_slabs, void* stream) {
+    return bwd_weight_impl<true>(x, ldx, dy, lddy, M, K, N, S, dw_slabs, stream);
+}
+
+MREC_API int mrec_dense_sum_slabs_f32(const float* slabs, int32_t S, int64_t len, float* out, void* stream) {
+    if (S <= 0 || len < 0) return MREC_EINVAL;
+    if (len == 0) return MREC_OK;
+    if (!slabs || !out) return MREC_EINVAL;
+    if (len % 4 || !al16(slabs) || !al16(out)) return MREC_EUNSUPPORTED;
+    const int64_t len4 = len / 4;
+    const unsigned g = (unsigned)(mrec_cdiv(len4, 256) < 2048 ? mrec_cdiv(len4, 256) : 2048);
+    k_sum_slabs<<<g, 256, 0, (hipStream_t)stream>>>((const float4*)slabs, S, len4, (float4*)out);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}

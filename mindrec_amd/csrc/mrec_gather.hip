@@ -40,6 +40,16 @@ __device__ __forceinline__ void vstore(bf16o_t* p, const Vf<4>& x) {
 }
 __device__ __forceinline__ void vstore(bf16o_t* p, const Vf<1>& x) { p->v = f2bf(x.v); }
 
+// ... and IEEE half output rows (the reference's own mixed-precision dtype)
+struct f16o_t { uint16_t v; };
+__device__ __forceinline__ unsigned f2h2(float lo, float hi) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void vstore(f16o_t* p, const Vf<4>& x) { *(uint2*)p = make_uint2(f2h2(x.v.x, x.v.y), f2h2(x.v.z, x.v.w)); }
+__device__ __forceinline__ void vstore(f16o_t* p, const Vf<1>& x) { p->v = __builtin_bit_cast(uint16_t, (_Float16)x.v); }
+
 constexpr int GB = 4;  // rows in flight per lane-group
 
 // Lane-group geometry shared by the row kernels: lpr lanes per row, G = 64/lpr groups per wave.
@@ -328,6 +338,53 @@ __global__ __launch_bounds__(256) void k_dense_adam4_splitk(float4* __restrict__
     }
 }
 
+// The same, for the hand-written MFMA weight-gradient kernel (mrec_dense.hip): its split slabs are fp32 partial
+// sums (never rounded), added here in slab order.  SHK: 0 = no shadow, 1 = bf16 shadow, 2 = fp16 shadow.
+struct SlabSegs {
+    const float4* part[8];
+    int64_t start4[8], len4[8];
+    int S[8];
+    int n;
+};
+
+__device__ __forceinline__ unsigned pack_shadow2(float lo, float hi, int shk) {
+    if (shk == 2) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 v = {(_Float16)lo, (_Float16)hi};
+        return __builtin_bit_cast(unsigned, v);
+    }
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+template <int SHK>
+__global__ __launch_bounds__(256) void k_dense_adam4_slabs(float4* __restrict__ p, float4* __restrict__ m,
+                                                           float4* __restrict__ v, const float4* __restrict__ g,
+                                                           int64_t n4, AdamH h, uint2* __restrict__ shadow, SlabSegs sg) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pp = p[i], mm = m[i], vv = v[i];
+        float4 gg;
+        int k = -1;
+        for (int q = 0; q < sg.n; ++q)
+            if (i >= sg.start4[q] && i < sg.start4[q] + sg.len4[q]) k = q;
+        if (k >= 0) {
+            const float4* src = sg.part[k] + (i - sg.start4[k]);
+            gg = src[0];
+            for (int s = 1; s < sg.S[k]; ++s) {
+                const float4 u = src[(int64_t)s * sg.len4[k]];
+                gg.x += u.x; gg.y += u.y; gg.z += u.z; gg.w += u.w;
+            }
+        } else {
+            gg = g[i];
+        }
+        adam_elem(pp.x, mm.x, vv.x, gg.x * h.gscale, h);
+        adam_elem(pp.y, mm.y, vv.y, gg.y * h.gscale, h);
+        adam_elem(pp.z, mm.z, vv.z, gg.z * h.gscale, h);
+        adam_elem(pp.w, mm.w, vv.w, gg.w * h.gscale, h);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (SHK) shadow[i] = make_uint2(pack_shadow2(pp.x, pp.y, SHK), pack_shadow2(pp.z, pp.w, SHK));
+    }
+}
+
 __global__ __launch_bounds__(256) void k_dense_ftrl(float* __restrict__ w, float* __restrict__ a,
                                                     float* __restrict__ lin, const float* __restrict__ g,
                                                     int64_t n, FtrlH h) {
@@ -340,7 +397,7 @@ __global__ __launch_bounds__(256) void k_dense_ftrl(float* __restrict__ w, float
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-template <class K>
+template <class K, class OT = bf16o_t>
 int gather_bf16_impl(const float* table, int64_t V, int64_t ld, int32_t D, const K* ids, int64_t n,
                      const float* row_scale, uint16_t* out, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -350,12 +407,12 @@ int gather_bf16_impl(const float* table, int64_t V, int64_t ld, int32_t D, const
     const bool vec = (D % 4 == 0) && (D <= 256) && (ld % 4 == 0) && al16(table) && ((((uintptr_t)out) & 7) == 0);
     if (vec) {
         RowGeom gm{D / 4, 64 / (D / 4)};
-        k_gather_rows<4, K, bf16o_t><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
-            table, V, ld, ids, n, row_scale, (bf16o_t*)out, D, gm);
+        k_gather_rows<4, K, OT><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
+            table, V, ld, ids, n, row_scale, (OT*)out, D, gm);
     } else if (D <= 64) {
         RowGeom gm{D, 64 / D};
-        k_gather_rows<1, K, bf16o_t><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
-            table, V, ld, ids, n, row_scale, (bf16o_t*)out, D, gm);
+        k_gather_rows<1, K, OT><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
+            table, V, ld, ids, n, row_scale, (OT*)out, D, gm);
     } else {
         return MREC_EUNSUPPORTED;
     }
@@ -468,6 +525,15 @@ MREC_API int mrec_gather_rows_bf16_i32(const float* table, int64_t V, int64_t ld
 MREC_API int mrec_gather_rows_bf16_i64(const float* table, int64_t V, int64_t ld, int32_t D, const int64_t* ids,
                                        int64_t n, const float* row_scale, uint16_t* out, void* stream) {
     return gather_bf16_impl<int64_t>(table, V, ld, D, ids, n, row_scale, out, stream);
+}
+
+MREC_API int mrec_gather_rows_f16_i32(const float* table, int64_t V, int64_t ld, int32_t D, const int32_t* ids,
+                                      int64_t n, const float* row_scale, uint16_t* out, void* stream) {
+    return gather_bf16_impl<int32_t, f16o_t>(table, V, ld, D, ids, n, row_scale, out, stream);
+}
+MREC_API int mrec_gather_rows_f16_i64(const float* table, int64_t V, int64_t ld, int32_t D, const int64_t* ids,
+                                      int64_t n, const float* row_scale, uint16_t* out, void* stream) {
+    return gather_bf16_impl<int64_t, f16o_t>(table, V, ld, D, ids, n, row_scale, out, stream);
 }
 
 MREC_API int mrec_wide_sum_f32_i32(const float* w, int64_t V, int64_t ldw, const int32_t* ids, const float* wts,
@@ -611,6 +677,41 @@ MREC_API int mrec_dense_adam_splitk_f32(float* p, float* m, float* v, const floa
     hipStream_t st = (hipStream_t)stream;
     if (shadow_bf16) k_dense_adam4_splitk<true><<<stream_grid(n4), 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow_bf16, sg);
     else k_dense_adam4_splitk<false><<<stream_grid(n4), 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, nullptr, sg);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+MREC_API int mrec_dense_adam_slabs_f32(float* p, float* m, float* v, const float* g, void* shadow16, int shadow_kind,
+                                       int64_t n, int32_t nseg, const float* const* slabs, const int64_t* starts,
+                                       const int64_t* lens, const int32_t* splits, float lr, float b1, float b2, float eps,
+                                       float b1_pow, float b2_pow, float grad_scale, int nesterov, void* stream) {
+    if (n < 0 || nseg < 0 || nseg > 8 || shadow_kind < 0 || shadow_kind > 2) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!p || !m || !v || !g || (nseg > 0 && (!slabs || !starts || !lens || !splits)) || (shadow_kind && !shadow16))
+        return MREC_EINVAL;
+    if (n % 4 || !al16(p) || !al16(m) || !al16(v) || !al16(g) || (shadow16 && (((uintptr_t)shadow16) & 7)))
+        return MREC_EUNSUPPORTED;
+    SlabSegs sg;
+    sg.n = nseg;
+    for (int q = 0; q < nseg; ++q) {
+        if (!slabs[q] || starts[q] < 0 || lens[q] <= 0 || starts[q] % 4 || lens[q] % 4 || starts[q] + lens[q] > n ||
+            splits[q] <= 0 || !al16(slabs[q]))
+            return MREC_EINVAL;
+        sg.part[q] = (const float4*)slabs[q];
+        sg.start4[q] = starts[q] / 4;
+        sg.len4[q] = lens[q] / 4;
+        sg.S[q] = splits[q];
+    }
+    AdamH h;
+    h.lr_t = lr * sqrtf(1.0f - b2_pow) / (1.0f - b1_pow);
+    h.b1 = b1; h.b2 = b2; h.omb1 = 1.0f - b1; h.omb2 = 1.0f - b2; h.eps = eps; h.gscale = grad_scale;
+    h.nesterov = nesterov;
+    const int64_t n4 = n / 4;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned gr = stream_grid(n4);
+    if (shadow_kind == 1) k_dense_adam4_slabs<1><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow16, sg);
+    else if (shadow_kind == 2) k_dense_adam4_slabs<2><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow16, sg);
+    else k_dense_adam4_slabs<0><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, nullptr, sg);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }

@@ -1,0 +1,400 @@
+// mrec_gemm.h -- the MFMA GEMM body behind DenseLayer (models/wide_deep/src/wide_and_deep.py:113-133:
+// MatMul + BiasAdd + ReLU in fp16/bf16) and its two bprops, hand-written for gfx950.
+//
+// One workgroup = 8 waves (512 threads) owns a 256 x 256 output tile; wave (wr, wc) = (w >> 2, w & 3) owns
+// 128 (P side) x 64 (Q side) of it as 8 x 4 accumulators of v_mfma_f32_16x16x32_{bf16,f16}.  The reduction
+// dimension is cut in K-tiles of 64; a K-tile is staged global -> LDS by LDS-DMA (buffer_load ... lds, 16 B per
+// lane) in four 16-KB pieces (P rows 0-63 / 64-127 of every wave row, Q columns 0-31 / 32-63 of every wave
+// column), two LDS buffers = 128 KB.  A K-tile is computed in four phases, one 64 x 32 quadrant of the wave's
+// tile each (16 MFMAs); every phase issues the LDS reads of the fragments it needs, stages ONE piece that will
+// be needed five phases later, waits with a COUNTED vmcnt (4 pieces stay in flight across the barriers) and
+// runs its MFMAs between two raw s_barriers.  The two wave rows run staggered by one barrier, so that on every
+// SIMD one wave issues MFMAs while its partner issues LDS reads and DMA (MI355X guide, "256^2 8-phase").
+//
+// LDS image: 1-KB subtiles of 16 rows x 64 B, byte ^= ((byte >> 9) & 1) << 5 (conflict-free for ds_read_b128
+// fragments and for ds_read_b64_tr_b16 blocks alike).  LDS-DMA writes lane-linear, so the swizzle is applied to
+// the per-lane SOURCE address and again on the read.
+//
+// Each operand is either K-contiguous (P[p, k] / Q[q, k]: fragments by ds_read_b128) or reduction-strided
+// (P[k, p] / Q[k, q]: fragments through ds_read_b64_tr_b16), chosen per operand by PT / QT:
+//   forward   y  = x . W      P = x  [M, K]  (PT = 0)   Q = W  [K, N] (QT = 1)   -- W is used as stored
+//   dgrad     dx = dy . W^T   P = dy [M, N]  (PT = 0)   Q = W  [K, N] (QT = 0: its rows ARE the outputs)
+//   wgrad     dW = x^T . dy   P = x  [M, K]  (PT = 1)   Q = dy [M, N] (QT = 1), reduction over M, split in slabs
+// A trailing partial K-tile is zero-filled by dropping the staging loads of k >= K (buffer range check); when it
+// holds at most 32 k its second k-step is skipped altogether.  K-contiguous operands need K % 8 == 0.
+// Accumulators hold C transposed (MFMA "A" = Q fragment, "B" = P fragment), so a lane owns 4 consecutive q of
+// one p: 8-byte (16-bit output) / 16-byte (fp32 output) stores.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mgemm {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+#define MGEMM_LDS __attribute__((address_space(3)))
+
+enum { EPI_FWD = 0,     // out = relu?(acc + bias[q])                      -> 16-bit
+       EPI_DGRAD = 1,   // out = H[p, q] > 0 ? acc : 0 (H nullable), optional column sums over p -> 16-bit
+       EPI_F32 = 2 };   // out = acc                                        -> fp32 (split slabs)
+
+struct Args {
+    const void* P;
+    const void* Q;
+    void* C;
+    const float* bias;      // EPI_FWD: [Qext] fp32 (nullable)
+    const void* H;          // EPI_DGRAD: [Pext, ldc] 16-bit activations of the layer below (nullable: no mask)
+    float* colsum_ws;       // EPI_DGRAD: [nTp, Qext] per-tile-row column sums (nullable)
+    int64_t ldp, ldq, ldc;  // row strides in elements
+    int Pext, Qext, K;      // output extents (P side, Q side) and the reduction extent
+    int nTp, nTq;           // 256-tiles per side
+    int kt_per_slab;        // K-tiles per split slab (grid has nTp * nTq * S workgroups; no split: all of them)
+    int64_t slab_stride;    // elements between consecutive slabs of C
+    int relu;               // EPI_FWD
+};
+
+template <bool F16> struct Elem;
+template <> struct Elem<false> {
+    typedef bf16x8_t v8;
+    static __device__ __forceinline__ f32x4_t mfma(u32x4_t a, u32x4_t b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+        return __builtin_bit_cast(uint32_t, v);
+    }
+    static __device__ __forceinline__ float widen(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+};
+template <> struct Elem<true> {
+    typedef f16x8_t v8;
+    static __device__ __forceinline__ f32x4_t mfma(u32x4_t a, u32x4_t b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+        f16x2_t v = {(_Float16)lo, (_Float16)hi};
+        return __builtin_bit_cast(uint32_t, v);
+    }
+    static __device__ __forceinline__ float widen(uint32_t bits16) {
+        return (float)__builtin_bit_cast(_Float16, (uint16_t)bits16);
+    }
+};
+
+constexpr int kThreads = 512;
+constexpr int kLdsBytes = 131072;
+constexpr uint32_t kOob = 0x80000000u;      // voffset beyond any buffer: the load is dropped (zero fill), nothing is fetched
+
+__device__ __forceinline__ constexpr int slot_off(int buf, int type) { return (buf * 4 + type) * 16384; }
+
+template <bool PT, bool QT, int EPI, bool F16, int VAR = 0>
+__global__ __launch_bounds__(kThreads, 2) void k_gemm256(const Args a) {
+    typedef Elem<F16> E;
+    __shared__ __attribute__((aligned(1024))) char smem[kLdsBytes];
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;
+
+    // ---- workgroup -> (tq, tp, z): neighbours in the remapped order share an XCD (its L2 then serves the shared
+    // operand panel); the remap is bijective for any grid size.
+    int tq, tp, z;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+        const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+        tq = swz % a.nTq;
+        const int rest = swz / a.nTq;
+        tp = rest % a.nTp;
+        z = rest / a.nTp;
+    }
+    const int Ttot = (a.K + 63) >> 6;
+    const int kt0 = z * a.kt_per_slab;
+    int T = min(a.kt_per_slab, Ttot - kt0);
+    if (T < 0) T = 0;
+    const int krem = a.K & 63;                        // k in the trailing partial K-tile (0: none)
+    const bool ktail = krem != 0;
+
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.P), 0, (int)((PT ? (int64_t)a.K : (int64_t)a.Pext) * a.ldp * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.Q), 0, (int)((QT ? (int64_t)a.K : (int64_t)a.Qext) * a.ldq * 2), 0x00020000);
+
+    // ---- per-lane source offsets of the staging loads (bytes); [half][e]
+    uint32_t voffP[2][2], voffQ[2][2];        // ... and for the trailing partial K-tile (loads of k >= K dropped)
+    uint32_t voffPt[2][2], voffQt[2][2];
+    {
+        const int srow = l >> 2, chunk = (l & 3) ^ ((l >> 5) << 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (!PT) {
+                    const int rowp = tp * 256 + (w >> 2) * 128 + h * 64 + (w & 3) * 16 + srow;
+                    voffP[h][e] = rowp < a.Pext ? (uint32_t)(((int64_t)rowp * a.ldp + e * 32 + chunk * 8) * 2) : kOob;
+                    voffPt[h][e] = (e * 32 + chunk * 8 < krem) ? voffP[h][e] : kOob;
+                } else {
+                    const int ip = tp * 256 + (w >> 2) * 128 + h * 64 + e * 32 + chunk * 8;
+                    const int mp = (w & 3) * 16 + srow;
+                    voffP[h][e] = ip < a.Pext ? (uint32_t)(((int64_t)mp * a.ldp + ip) * 2) : kOob;
+                    voffPt[h][e] = mp < krem ? voffP[h][e] : kOob;
+                }
+                if (!QT) {
+                    const int rowq = tq * 256 + (w >> 1) * 64 + h * 32 + (w & 1) * 16 + srow;
+                    voffQ[h][e] = rowq < a.Qext ? (uint32_t)(((int64_t)rowq * a.ldq + e * 32 + chunk * 8) * 2) : kOob;
+                    voffQt[h][e] = (e * 32 + chunk * 8 < krem) ? voffQ[h][e] : kOob;
+                } else {
+                    const int jq = tq * 256 + (w >> 1) * 64 + h * 32 + chunk * 8;
+                    const int mq = (2 * (w & 1) + e) * 16 + srow;
+                    voffQ[h][e] = jq < a.Qext ? (uint32_t)(((int64_t)mq * a.ldq + jq) * 2) : kOob;
+                    voffQt[h][e] = mq < krem ? voffQ[h][e] : kOob;
+                }
+            }
+    }
+    const uint32_t ktP = PT ? (uint32_t)(64 * a.ldp * 2) : 128u;     // soffset step per K-tile
+    const uint32_t ktQ = QT ? (uint32_t)(64 * a.ldq * 2) : 128u;
+    // piece types: 0 = P rows 0-63 of each wave row, 1 = Q cols 0-31 of each wave column, 2 = Q cols 32-63, 3 = P rows 64-127
+#define MG_STAGE(TYPE, BUF, tt)                                                                                   \
+    do {                                                                                                          \
+        const int tt_ = (tt);                                                                                     \
+        const bool live_ = tt_ < T;                                                                               \
+        constexpr bool isP_ = (TYPE) == 0 || (TYPE) == 3;                                                         \
+        constexpr int h_ = ((TYPE) >= 2) ? 1 : 0;                                                                 \
+        const uint32_t soff_ = (uint32_t)(kt0 + tt_) * (isP_ ? ktP : ktQ);                                        \
+        MGEMM_LDS char* dst_ = (MGEMM_LDS char*)smem + slot_off(BUF, TYPE) + w * 2048;                           \
+        const bool last_ = ktail && (kt0 + tt_ == Ttot - 1);                                                      \
+        const uint32_t v0_ = !live_ ? kOob : last_ ? (isP_ ? voffPt[h_][0] : voffQt[h_][0]) : (isP_ ? voffP[h_][0] : voffQ[h_][0]); \
+        const uint32_t v1_ = !live_ ? kOob : last_ ? (isP_ ? voffPt[h_][1] : voffQt[h_][1]) : (isP_ ? voffP[h_][1] : voffQ[h_][1]); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(isP_ ? rP : rQ, (MGEMM_LDS void*)dst_, 16, v0_, soff_, 0, 0);    \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(isP_ ? rP : rQ, (MGEMM_LDS void*)(dst_ + 1024), 16, v1_, soff_, 0, 0); \
+    } while (0)
+
+    // ---- per-lane LDS read offsets
+    uint32_t rdP0, rdP1, rdQ0, rdQ1;      // K-contiguous operands use *0 only; strided: index = 16-column half of the subtile row
+    {
+        const int r = l & 15, c = l >> 4;
+        const uint32_t lane = (uint32_t)((64 * r + 16 * c) ^ ((r >> 3) << 5));
+        const int lg = l >> 4, rr = 8 * (lg & 1) + ((l & 15) >> 2), pp = l & 3;
+        const uint32_t b = (uint32_t)(64 * rr + 8 * pp);
+        const uint32_t x0 = rr >= 8 ? 32u : 0u, x1 = rr >= 8 ? 0u : 32u;
+        if (!PT) {
+            rdP0 = lane + wr * 8192;          // subtile ((wr*4 + mi)*2 + ks)
+            rdP1 = 0;
+        } else {
+            rdP0 = b + x0 + (lg >> 1) * 2048 + wr * 8192;     // subtile (wr*4 + 2ks + (lg>>1))*2 + (mi>>1)
+            rdP1 = b + x1 + (lg >> 1) * 2048 + wr * 8192;
+        }
+        if (!QT) {
+            rdQ0 = lane + wc * 4096;          // subtile ((wc*2 + nj)*2 + ks)
+            rdQ1 = 0;
+        } else {
+            rdQ0 = b + x0 + (lg >> 1) * 1024 + wc * 4096;     // subtile wc*4 + 2ks + (lg>>1)
+            rdQ1 = b + x1 + (lg >> 1) * 1024 + wc * 4096;
+        }
+    }
+
+    u32x4_t fP[4][2], fQ0[2][2], fQ1[2][2];       // fragments [rep][ks]
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto ld128 = [&](uint32_t off) -> u32x4_t { return *(const MGEMM_LDS u32x4_t*)((MGEMM_LDS char*)smem + off); };
+    auto ldtr = [&](uint32_t off) -> u32x4_t {
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((MGEMM_LDS s16x4_t*)((MGEMM_LDS char*)smem + off));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((MGEMM_LDS s16x4_t*)((MGEMM_LDS char*)smem + off + 256));
+        u32x2_t a2 = __builtin_bit_cast(u32x2_t, lo), b2 = __builtin_bit_cast(u32x2_t, hi);
+        return u32x4_t{a2[0], a2[1], b2[0], b2[1]};
+    };
+
+#define MG_READ_P(BUF, H)                                                                              \
+    do {                                                                                               \
+        _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) { \
+            if (!PT) fP[mi_][ks_] = ld128(slot_off(BUF, (H) ? 3 : 0) + (mi_ * 2 + ks_) * 1024 + rdP0); \
+            else fP[mi_][ks_] = ldtr(slot_off(BUF, (H) ? 3 : 0) + (4 * ks_ + (mi_ >> 1)) * 1024 + ((mi_ & 1) ? rdP1 : rdP0)); \
+        }                                                                                              \
+    } while (0)
+#define MG_READ_Q(BUF, H, F)                                                                           \
+    do {                                                                                               \
+        _Pragma("unroll") for (int nj_ = 0; nj_ < 2; ++nj_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) { \
+            if (!QT) F[nj_][ks_] = ld128(slot_off(BUF, (H) ? 2 : 1) + (nj_ * 2 + ks_) * 1024 + rdQ0);  \
+            else F[nj_][ks_] = ldtr(slot_off(BUF, (H) ? 2 : 1) + (2 * ks_) * 1024 + (nj_ ? rdQ1 : rdQ0)); \
+        }                                                                                              \
+    } while (0)
+    // one quadrant: 4 P reps x 2 Q reps x 2 k-steps (the second k-step is skipped in a half tail tile)
+#define MG_MFMA(MH, NH, F, HALF)                                                                       \
+    do {                                                                                               \
+        if (!(VAR & 2)) __builtin_amdgcn_s_setprio(1);                                                 \
+        _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_) _Pragma("unroll") for (int nj_ = 0; nj_ < 2; ++nj_) \
+            acc[(MH) * 4 + mi_][(NH) * 2 + nj_] = E::mfma(F[nj_][0], fP[mi_][0], acc[(MH) * 4 + mi_][(NH) * 2 + nj_]); \
+        if (!(HALF)) {                                                                                 \
+            _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_) _Pragma("unroll") for (int nj_ = 0; nj_ < 2; ++nj_) \
+                acc[(MH) * 4 + mi_][(NH) * 2 + nj_] = E::mfma(F[nj_][1], fP[mi_][1], acc[(MH) * 4 + mi_][(NH) * 2 + nj_]); \
+        }                                                                                              \
+        if (!(VAR & 2)) __builtin_amdgcn_s_setprio(0);                                                 \
+    } while (0)
+#define MG_SYNC_PRE()                                     \
+    do {                                                  \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                \
+        __builtin_amdgcn_s_barrier();                     \
+        __builtin_amdgcn_sched_barrier(0);                \
+    } while (0)
+#define MG_SYNC_POST()                     \
+    do {                                   \
+        __builtin_amdgcn_sched_barrier(0); \
+        __builtin_amdgcn_s_barrier();      \
+        __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+    // the four phases of K-tile t living in LDS buffer BUF
+#define MG_KTILE(BUF, t)                             \
+    do {                                             \
+        const bool half_ = ktail && krem <= 32 && (kt0 + (t)) == Ttot - 1;    \
+        MG_READ_Q(BUF, 0, fQ0);                      \
+        MG_READ_P(BUF, 0);                           \
+        MG_STAGE(2, (BUF) ^ 1, (t) + 1);             \
+        MG_SYNC_PRE();                               \
+        MG_MFMA(0, 0, fQ0, half_);                   \
+        MG_SYNC_POST();                              \
+        MG_READ_Q(BUF, 1, fQ1);                      \
+        MG_STAGE(3, (BUF) ^ 1, (t) + 1);             \
+        MG_SYNC_PRE();                               \
+        MG_MFMA(0, 1, fQ1, half_);                   \
+        MG_SYNC_POST();                              \
+        MG_READ_P(BUF, 1);                           \
+        MG_STAGE(0, BUF, (t) + 2);                   \
+        MG_SYNC_PRE();                               \
+        MG_MFMA(1, 1, fQ1, half_);                   \
+        MG_SYNC_POST();                              \
+        MG_STAGE(1, BUF, (t) + 2);                   \
+        MG_SYNC_PRE();                               \
+        MG_MFMA(1, 0, fQ0, half_);                   \
+        MG_SYNC_POST();                              \
+    } while (0)
+
+    // ---- prologue: six pieces in flight, the first two landed
+    MG_STAGE(0, 0, 0);
+    MG_STAGE(1, 0, 0);
+    MG_STAGE(2, 0, 0);
+    MG_STAGE(3, 0, 0);
+    MG_STAGE(0, 1, 1);
+    MG_STAGE(1, 1, 1);
+    MG_SYNC_PRE();
+    if (!(VAR & 1) && wr == 1) __builtin_amdgcn_s_barrier();       // stagger: wave row 1 runs one barrier behind wave row 0
+
+    for (int t = 0; t < T; t += 2) {
+        MG_KTILE(0, t);
+        if (t + 1 < T) MG_KTILE(1, t + 1);
+    }
+    if (!(VAR & 1) && wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: lane owns p = p0 + mi*16 + (l & 15), q = q0 + ni*16 + 4*(l >> 4) + {0..3}
+    const int p0 = tp * 256 + wr * 128 + (l & 15);
+    const int q0 = tq * 256 + wc * 64 + 4 * (l >> 4);
+    if (EPI == EPI_F32) {
+        float* C = (float*)a.C + (int64_t)z * a.slab_stride;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int p = p0 + mi * 16;
+            if (p < a.Pext) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int q = q0 + ni * 16;
+                    if (q < a.Qext) *(f32x4_t*)(C + (int64_t)p * a.ldc + q) = acc[mi][ni];
+                }
+            }
+        }
+    } else {
+        uint16_t* C = (uint16_t*)a.C;
+        float bq[4][4];
+        if (EPI == EPI_FWD) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = q0 + ni * 16 + r;
+                    bq[ni][r] = (a.bias != nullptr && q < a.Qext) ? a.bias[q] : 0.f;
+                }
+        }
+        float cs[4][4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[ni][r] = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int p = p0 + mi * 16;
+            const bool pv = p < a.Pext;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int q = q0 + ni * 16;
+                const bool ok = pv && q < a.Qext;
+                f32x4_t v = acc[mi][ni];
+                if (EPI == EPI_FWD) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] += bq[ni][r];
+                        if (a.relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
+                    }
+                }
+                u32x2_t o = {E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
+                if (EPI == EPI_DGRAD) {
+                    if (a.H != nullptr) {
+                        u32x2_t hb = {0u, 0u};
+                        if (ok) hb = *(const u32x2_t*)((const uint16_t*)a.H + (int64_t)p * a.ldc + q);
+                        // activation > 0 <=> its 16-bit pattern is a positive number (sign clear, not zero)
+                        if (!((hb[0] & 0xFFFFu) - 1u < 0x7FFFu)) o[0] &= 0xFFFF0000u;
+                        if (!((hb[0] >> 16) - 1u < 0x7FFFu)) o[0] &= 0x0000FFFFu;
+                        if (!((hb[1] & 0xFFFFu) - 1u < 0x7FFFu)) o[1] &= 0xFFFF0000u;
+                        if (!((hb[1] >> 16) - 1u < 0x7FFFu)) o[1] &= 0x0000FFFFu;
+                    }
+                    if (a.colsum_ws != nullptr && ok) {      // sums of the ROUNDED gradients, fp32
+                        cs[ni][0] += E::widen(o[0] & 0xFFFFu);
+                        cs[ni][1] += E::widen(o[0] >> 16);
+                        cs[ni][2] += E::widen(o[1] & 0xFFFFu);
+                        cs[ni][3] += E::widen(o[1] >> 16);
+                    }
+                }
+                if (ok) *(u32x2_t*)(C + (int64_t)p * a.ldc + q) = o;
+            }
+        }
+        if (EPI == EPI_DGRAD && a.colsum_ws != nullptr) {
+            // over the 16 lanes that share l >> 4 (fixed xor tree), then over the two wave rows through LDS
+            float* red = (float*)smem;      // [2][256]
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s = cs[ni][r];
+                    s += __shfl_xor(s, 1, 64);
+                    s += __shfl_xor(s, 2, 64);
+                    s += __shfl_xor(s, 4, 64);
+                    s += __shfl_xor(s, 8, 64);
+                    if ((l & 15) == 0) red[wr * 256 + wc * 64 + ni * 16 + 4 * (l >> 4) + r] = s;
+                }
+            __syncthreads();
+            if (tid < 256) {
+                const int q = tq * 256 + tid;
+                if (q < a.Qext) a.colsum_ws[(int64_t)tp * a.Qext + q] = red[tid] + red[256 + tid];
+            }
+        }
+    }
+#undef MG_STAGE
+#undef MG_READ_P
+#undef MG_READ_Q
+#undef MG_MFMA
+#undef MG_SYNC_PRE
+#undef MG_SYNC_POST
+#undef MG_KTILE
+}
+
+}  // namespace mgemm

@@ -23,7 +23,9 @@ constexpr int HB = 256;
 constexpr int HI = 8;
 constexpr int HT = HB * HI;
 
-enum { C_HWM = 0, C_LIVE = 1, C_DROPPED = 2, C_FREE = 3, C_NCOUNTERS = 8 };
+// counters: [C_TOMB] = tombstones in the slot array, [C_REBUILD] = "rebuild the slot array now" (set by the erase
+// commit, read by the two rebuild kernels behind it), [C_NREBUILD] = rebuilds so far
+enum { C_HWM = 0, C_LIVE = 1, C_DROPPED = 2, C_FREE = 3, C_TOMB = 4, C_REBUILD = 5, C_NREBUILD = 6, C_NCOUNTERS = 8 };
 
 struct MapDev {
     int64_t* skey;      // [S]
@@ -51,7 +53,9 @@ __global__ __launch_bounds__(HB) void k_map_find(MapDev m, const int64_t* __rest
     const int64_t key = keys[i];
     uint32_t s = mrec_hash_key(key) & m.mask;
     int row = -1, slot = -1;
-    for (;;) {
+    // bounded: a slot array without an empty slot (it cannot arise while the rebuild below keeps
+    // live + tombstones <= 0.7 S, but a probe must never depend on that) ends as a miss, not a hang
+    for (uint32_t it = 0; it <= m.mask; ++it) {
         const int r = m.srow[s];
         if (r == -1) break;
         if (r >= 0 && m.skey[s] == key) { row = r; slot = (int)s; break; }
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(HB) void k_flag_rank(const uint8_t* __restrict__ fl
 __global__ __launch_bounds__(HB) void k_map_insert(MapDev m, const int64_t* __restrict__ keys, int64_t n,
                                                    const uint8_t* __restrict__ miss, const int* __restrict__ rank,
                                                    int* __restrict__ rows_out, uint8_t* __restrict__ is_new,
-                                                   int64_t* __restrict__ n_dropped_call) {
+                                                   int64_t* __restrict__ n_dropped_call, int64_t* __restrict__ n_tomb_reused) {
     const int64_t i = (int64_t)blockIdx.x * HB + threadIdx.x;
     if (i >= n) return;
     if (!miss[i]) { if (is_new) is_new[i] = 0; return; }
@@ -126,13 +130,25 @@ __global__ __launch_bounds__(HB) void k_map_insert(MapDev m, const int64_t* __re
     }
     const int64_t key = keys[i];
     uint32_t s = mrec_hash_key(key) & m.mask;
-    for (;;) {
+    bool placed = false;
+    // live keys <= C <= S / 2, so a negative slot exists; bounded all the same
+    for (uint32_t it = 0; it <= m.mask; ++it) {
         const int cur = __hip_atomic_load(&m.srow[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur < 0) {
             const int old = atomicCAS(&m.srow[s], cur, row);
-            if (old == cur) break;
+            if (old == cur) {
+                if (cur == -2) atomicAdd((unsigned long long*)n_tomb_reused, 1ull);
+                placed = true;
+                break;
+            }
         }
         s = (s + 1) & m.mask;
+    }
+    if (!placed) {
+        rows_out[i] = -1;
+        if (is_new) is_new[i] = 0;
+        atomicAdd((unsigned long long*)n_dropped_call, 1ull);
+        return;
     }
     m.skey[s] = key;
     m.row_key[row] = key;
@@ -141,8 +157,10 @@ __global__ __launch_bounds__(HB) void k_map_insert(MapDev m, const int64_t* __re
     if (is_new) is_new[i] = 1;
 }
 
-__global__ void k_map_commit_insert(MapDev m, const int64_t* n_miss, const int64_t* n_dropped_call) {
+__global__ void k_map_commit_insert(MapDev m, const int64_t* n_miss, const int64_t* n_dropped_call,
+                                    const int64_t* n_tomb_reused) {
     const int64_t M = *n_miss, dropped = *n_dropped_call;
+    m.counters[C_TOMB] -= *n_tomb_reused;
     const int64_t hwm = m.counters[C_HWM], nfree = m.counters[C_FREE];
     const int64_t fresh = m.C - hwm;
     const int64_t use_fresh = M < fresh ? M : fresh;
@@ -165,9 +183,37 @@ __global__ __launch_bounds__(HB) void k_map_erase(MapDev m, int64_t n, const int
     m.free_list[nfree + rank[i]] = rows[i];
 }
 
-__global__ void k_map_commit_erase(MapDev m, const int64_t* n_found) {
+// Erase leaves tombstones, and an insert only takes one back when its probe happens to pass it: under
+// insert / erase churn the EMPTY slots (the only thing that ends a miss probe) would run out.  Once
+// tombstones exceed S / 5 (live <= S / 2, so live + tombstones <= 0.7 S always holds) the slot array is
+// rebuilt from the row side (row_key / row_live), which empties every tombstone.
+__global__ void k_map_commit_erase(MapDev m, const int64_t* n_found, int64_t S) {
     m.counters[C_FREE] += *n_found;
     m.counters[C_LIVE] -= *n_found;
+    const int64_t tomb = m.counters[C_TOMB] + *n_found;
+    const bool rebuild = tomb * 5 > S;
+    m.counters[C_REBUILD] = rebuild ? 1 : 0;
+    m.counters[C_TOMB] = rebuild ? 0 : tomb;
+    if (rebuild) m.counters[C_NREBUILD] += 1;
+}
+
+__global__ __launch_bounds__(HB) void k_map_rebuild_clear(MapDev m, int64_t S) {
+    if (!m.counters[C_REBUILD]) return;
+    for (int64_t s = (int64_t)blockIdx.x * HB + threadIdx.x; s < S; s += (int64_t)gridDim.x * HB) m.srow[s] = -1;
+}
+
+__global__ __launch_bounds__(HB) void k_map_rebuild_insert(MapDev m) {
+    if (!m.counters[C_REBUILD]) return;
+    const int64_t hwm = m.counters[C_HWM];
+    for (int64_t r = (int64_t)blockIdx.x * HB + threadIdx.x; r < hwm; r += (int64_t)gridDim.x * HB) {
+        if (!m.row_live[r]) continue;
+        const int64_t key = m.row_key[r];
+        uint32_t s = mrec_hash_key(key) & m.mask;
+        for (uint32_t it = 0; it <= m.mask; ++it) {
+            if (atomicCAS(&m.srow[s], -1, (int)r) == -1) { m.skey[s] = key; break; }
+            s = (s + 1) & m.mask;
+        }
+    }
 }
 
 __global__ __launch_bounds__(HB) void k_map_export(MapDev m, const int* __restrict__ rank,
@@ -182,7 +228,7 @@ __global__ __launch_bounds__(HB) void k_map_export(MapDev m, const int* __restri
 size_t map_ws_bytes(int64_t n) {
     const size_t nn = (size_t)(n ? n : 1);
     return mrec_align_up(nn * 4, 256) * 3 + mrec_align_up(nn, 256) + mrec_align_up((size_t)mrec_cdiv(nn, HT) * 4, 256) +
-           256;
+           512;
 }
 
 }  // namespace
@@ -265,17 +311,17 @@ MREC_API int mrec_map_find_or_insert(mrec_map_t* h, const int64_t* keys, int64_t
     uint8_t* miss = a.take<uint8_t>(n);
     const int nblk = (int)mrec_cdiv(n, HT);
     int* blocksum = a.take<int>(nblk);
-    int64_t* words = a.take<int64_t>(2);  // [0] = misses, [1] = dropped in this call
+    int64_t* words = a.take<int64_t>(3);  // [0] = misses, [1] = dropped in this call, [2] = tombstones taken back
     if (!a.ok) return MREC_EWORKSPACE;
     (void)slots;
     const unsigned g = (unsigned)mrec_cdiv(n, HB);
     k_map_find<<<g, HB, 0, st>>>(h->d, keys, n, n_dev, rows_out, nullptr, miss);
     if (insert) {
-        MREC_HIP_CHECK(hipMemsetAsync(words, 0, 16, st));
+        MREC_HIP_CHECK(hipMemsetAsync(words, 0, 24, st));
         k_flag_count<<<nblk, HB, 0, st>>>(miss, n, 0, blocksum);
         k_flag_rank<<<nblk, HB, 0, st>>>(miss, n, 0, blocksum, nblk, rank, words);
-        k_map_insert<<<g, HB, 0, st>>>(h->d, keys, n, miss, rank, rows_out, is_new_out, words + 1);
-        k_map_commit_insert<<<1, 1, 0, st>>>(h->d, words, words + 1);
+        k_map_insert<<<g, HB, 0, st>>>(h->d, keys, n, miss, rank, rows_out, is_new_out, words + 1, words + 2);
+        k_map_commit_insert<<<1, 1, 0, st>>>(h->d, words, words + 1, words + 2);
     } else if (is_new_out) {
         MREC_HIP_CHECK(hipMemsetAsync(is_new_out, 0, (size_t)n, st));
     }
@@ -303,7 +349,11 @@ MREC_API int mrec_map_erase(mrec_map_t* h, const int64_t* keys, int64_t n, void*
     k_flag_count<<<nblk, HB, 0, st>>>(miss, n, 1, blocksum);
     k_flag_rank<<<nblk, HB, 0, st>>>(miss, n, 1, blocksum, nblk, rank, words);
     k_map_erase<<<g, HB, 0, st>>>(h->d, n, rows, slots, miss, rank);
-    k_map_commit_erase<<<1, 1, 0, st>>>(h->d, words);
+    k_map_commit_erase<<<1, 1, 0, st>>>(h->d, words, (int64_t)h->S);
+    // both return at once unless the commit asked for a rebuild (grid-stride, so the idle launch is small)
+    const unsigned gr = (unsigned)(mrec_cdiv((int64_t)h->S, HB) < 2048 ? mrec_cdiv((int64_t)h->S, HB) : 2048);
+    k_map_rebuild_clear<<<gr, HB, 0, st>>>(h->d, (int64_t)h->S);
+    k_map_rebuild_insert<<<gr, HB, 0, st>>>(h->d);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }

@@ -39,6 +39,23 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     return u;
 }
 
+// fp16 forms (the reference's mixed-precision dtype, wide_and_deep.py:119-128) for the output head
+template <bool F16> __device__ __forceinline__ void unpack8t(const uint4& u, float (&f)[8]) {
+    if (!F16) { unpack8(u, f); return; }
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const h2 v = __builtin_bit_cast(h2, w[k]); f[2 * k] = (float)v[0]; f[2 * k + 1] = (float)v[1]; }
+}
+template <bool F16> __device__ __forceinline__ uint4 pack8t(const float (&f)[8]) {
+    if (!F16) return pack8(f);
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    unsigned w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const h2 v = {(_Float16)f[2 * k], (_Float16)f[2 * k + 1]}; w[k] = __builtin_bit_cast(unsigned, v); }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 constexpr int MB = 256;   // threads per block
 
 // A block walks its stripe of rows; thread t owns column group cg = t % CG (8 adjacent columns) and rows
@@ -129,6 +146,7 @@ __global__ __launch_bounds__(MB) void k_colsum_finish(const float* __restrict__ 
 // Output head.  K5 = width of the last hidden layer (multiple of 8, K5/8 a power of two <= 64).
 // partial layout per block: [K5] dW5 partials, [K5] column sums of dh4 (= bias gradient of the last
 // hidden layer), then db5 partial, then loss partial.
+template <bool F16>
 __global__ __launch_bounds__(MB) void k_head_fwd_bwd(const uint4* __restrict__ h4, const float* __restrict__ w5,
                                                      const float* __restrict__ b5, const float* __restrict__ wide,
                                                      const float* __restrict__ label, int64_t B, int CG,
@@ -152,7 +170,7 @@ __global__ __launch_bounds__(MB) void k_head_fwd_bwd(const uint4* __restrict__ h
         const int64_t r = r0 + rl;
         const bool valid = r < r_end;
         float fh[8];
-        if (valid) unpack8(h4[r * CG + cg], fh);
+        if (valid) unpack8t<F16>(h4[r * CG + cg], fh);
         else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) fh[k] = 0.0f;
@@ -183,7 +201,7 @@ __global__ __launch_bounds__(MB) void k_head_fwd_bwd(const uint4* __restrict__ h
                 accw[k] += fh[k] * dl;
                 accd[k] += o[k];
             }
-            dh4[r * CG + cg] = pack8(o);
+            dh4[r * CG + cg] = pack8t<F16>(o);
         }
     }
 #pragma unroll
@@ -280,10 +298,10 @@ MREC_API int mrec_head_workspace_bytes(int64_t B, int32_t K5, size_t* out) {
     return MREC_OK;
 }
 
-MREC_API int mrec_head_fwd_bwd_bf16(const uint16_t* h4, const float* w5, const float* b5, const float* wide,
-                                    const float* label, int64_t B, int32_t K5, float dscale, float* logit,
-                                    float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
-                                    void* ws, size_t ws_bytes, void* stream) {
+static int head_impl(bool f16, const uint16_t* h4, const float* w5, const float* b5, const float* wide,
+                     const float* label, int64_t B, int32_t K5, float dscale, float* logit,
+                     float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
+                     void* ws, size_t ws_bytes, void* stream) {
     if (B <= 0 || K5 <= 0) return MREC_EINVAL;
     if (!h4 || !w5 || !b5 || !wide || !label || !logit || !dlogit || !dh4 || !dw5 || !db4 || !db5 || !loss || !ws) return MREC_EINVAL;
     if (K5 % 8 || !pow2(K5 / 8) || K5 / 8 > 64) return MREC_EUNSUPPORTED;
@@ -294,9 +312,27 @@ MREC_API int mrec_head_fwd_bwd_bf16(const uint16_t* h4, const float* w5, const f
     const int rows_per_block = (int)mrec_cdiv(mrec_cdiv(B, nblk), RP) * RP;
     const int nb = (int)mrec_cdiv(B, rows_per_block);
     hipStream_t st = (hipStream_t)stream;
-    k_head_fwd_bwd<<<nb, MB, 0, st>>>((const uint4*)h4, w5, b5, wide, label, B, CG, rows_per_block, dscale, logit, dlogit,
-                                      (uint4*)dh4, (float*)ws);
+    if (f16)
+        k_head_fwd_bwd<true><<<nb, MB, 0, st>>>((const uint4*)h4, w5, b5, wide, label, B, CG, rows_per_block, dscale, logit, dlogit,
+                                                (uint4*)dh4, (float*)ws);
+    else
+        k_head_fwd_bwd<false><<<nb, MB, 0, st>>>((const uint4*)h4, w5, b5, wide, label, B, CG, rows_per_block, dscale, logit, dlogit,
+                                                 (uint4*)dh4, (float*)ws);
     k_head_finish<<<(unsigned)mrec_cdiv(2 * K5 + 2, 32), MB, 0, st>>>((const float*)ws, nb, K5, 1.0f / (float)B, dw5, db4, db5, loss);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
+}
+
+MREC_API int mrec_head_fwd_bwd_bf16(const uint16_t* h4, const float* w5, const float* b5, const float* wide,
+                                    const float* label, int64_t B, int32_t K5, float dscale, float* logit,
+                                    float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    return head_impl(false, h4, w5, b5, wide, label, B, K5, dscale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes, stream);
+}
+
+MREC_API int mrec_head_fwd_bwd_f16(const uint16_t* h4, const float* w5, const float* b5, const float* wide,
+                                   const float* label, int64_t B, int32_t K5, float dscale, float* logit,
+                                   float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
+                                   void* ws, size_t ws_bytes, void* stream) {
+    return head_impl(true, h4, w5, b5, wide, label, B, K5, dscale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes, stream);
 }

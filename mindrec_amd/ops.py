@@ -11,6 +11,8 @@ import torch
 from . import _lib
 
 _WS = {}
+_DT16 = {torch.bfloat16: "bf16", torch.float16: "f16"}
+_WS_RETIRED = []      # outgrown workspaces stay referenced: a captured HIP graph may still hold their addresses
 
 
 def _stream():
@@ -26,6 +28,8 @@ def workspace(tag, nbytes, device):
     key = (tag, str(device), torch.cuda.current_stream().cuda_stream)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
+        if t is not None:
+            _WS_RETIRED.append(t)
         t = torch.empty(max(int(nbytes * 1.25), 4096), dtype=torch.uint8, device=device)
         _WS[key] = t
     return t
@@ -158,11 +162,12 @@ def gather_rows(table, ids, row_scale=None, out=None, out_dtype=torch.float32):
         row_scale = row_scale.reshape(-1).contiguous()
         if row_scale.dtype != torch.float32 or row_scale.numel() != n:
             raise TypeError("row_scale must be float32 with one value per id")
-    if out_dtype not in (torch.float32, torch.bfloat16):
-        raise TypeError("gather_rows out_dtype must be float32 or bfloat16")
+    if out_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise TypeError("gather_rows out_dtype must be float32, bfloat16 or float16")
     if out is None:
         out = torch.empty((n, D), dtype=out_dtype, device=table.device)
-    fn = "mrec_gather_rows_f32_" if out.dtype == torch.float32 else "mrec_gather_rows_bf16_"
+    fn = {torch.float32: "mrec_gather_rows_f32_", torch.bfloat16: "mrec_gather_rows_bf16_",
+          torch.float16: "mrec_gather_rows_f16_"}[out.dtype]
     _lib.call(fn + sfx, _ptr(table), V, ld, D, _ptr(flat), n, _ptr(row_scale), _ptr(out), _stream())
     return out.view(tuple(ids.shape) + (D,))
 
@@ -213,8 +218,8 @@ def wide_sum(w, ids, wts, bias=None):
 
 
 def _grads(plan, g, D, allow_bf16=False):
-    if g.dtype != torch.float32 and not (allow_bf16 and g.dtype == torch.bfloat16):
-        raise TypeError("row gradients must be float32" + (" or bfloat16" if allow_bf16 else ""))
+    if g.dtype != torch.float32 and not (allow_bf16 and g.dtype in (torch.bfloat16, torch.float16)):
+        raise TypeError("row gradients must be float32" + (", bfloat16 or float16" if allow_bf16 else ""))
     g2 = g.reshape(plan.n, D)
     if g2.stride(1) != 1:
         g2 = g2.contiguous()
@@ -266,7 +271,8 @@ def sparse_lazy_adam_(p, m, v, plan, g, row_scale=None, lr=3.5e-4, beta1=0.9, be
     rs = _row_scale(plan, row_scale)
     ws = _apply_ws(plan, D, p.device)
     sfx = _suffix(plan.uniq_buf)
-    fn = "mrec_sparse_lazy_adam_f32_" if g2.dtype == torch.float32 else "mrec_sparse_lazy_adam_bf16g_"
+    fn = {torch.float32: "mrec_sparse_lazy_adam_f32_", torch.bfloat16: "mrec_sparse_lazy_adam_bf16g_",
+          torch.float16: "mrec_sparse_lazy_adam_f16g_"}[g2.dtype]
     _lib.call(fn + sfx, _ptr(p), _ptr(m), _ptr(v), V, ld, D, _ptr(plan.uniq_buf),
               _ptr(plan.sorted_pos), _ptr(plan.sorted_seg), _ptr(plan.seg_offsets), plan.n, _ptr(g2), ldg, _ptr(rs), lr,
               beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _ptr(ws), ws.numel(), _stream())
@@ -377,6 +383,11 @@ class KeyIndex:
     def counters(self):
         """(rows handed out, live keys, dropped keys, free rows) -- host sync."""
         c = self._mem[self._counters_off: self._counters_off + 32].view(torch.int64)
+        return tuple(int(x) for x in c.tolist())
+
+    def counters_all(self):
+        """All eight device counter words ([4] = tombstones, [6] = slot-array rebuilds) -- host sync."""
+        c = self._mem[self._counters_off: self._counters_off + 64].view(torch.int64)
         return tuple(int(x) for x in c.tolist())
 
     def __len__(self):
@@ -598,10 +609,128 @@ def head_fwd_bwd(h4, w5, b5, wide, label, dscale, dw5_out, db4_out, db5_out):
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     nb = _lib.query_bytes("mrec_head_workspace_bytes", B, K5)
     ws = workspace("head", nb, dev)
-    _lib.call("mrec_head_fwd_bwd_bf16", _ptr(h4.contiguous()), _ptr(w5), _ptr(b5), _ptr(wide.contiguous()),
+    if h4.dtype not in _DT16:
+        raise TypeError("h4 must be bfloat16 or float16")
+    _lib.call("mrec_head_fwd_bwd_" + _DT16[h4.dtype], _ptr(h4.contiguous()), _ptr(w5), _ptr(b5), _ptr(wide.contiguous()),
               _ptr(label.contiguous()), B, K5, float(dscale), _ptr(logit), _ptr(dlogit), _ptr(dh4), _ptr(dw5_out),
               _ptr(db4_out), _ptr(db5_out), _ptr(loss), _ptr(ws), ws.numel(), _stream())
     return loss, logit, dlogit, dh4
+
+
+# ---- DenseLayer on the matrix cores (csrc/mrec_dense.hip) --------------------------------------------
+def _mat16(t, name):
+    if t.dtype not in _DT16 or t.dim() != 2 or t.stride(1) != 1:
+        raise TypeError(f"{name} must be a bfloat16 / float16 [rows, cols] tensor with unit column stride")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def dense_supported(M, K, N):
+    """Shapes the MFMA DenseLayer kernels cover (forward and both bprops): widths multiples of 8 (16-byte rows)."""
+    return K % 8 == 0 and N % 8 == 0
+
+
+def dense_fwd(x, w, bias, relu=True, out=None):
+    """DenseLayer.construct (wide_and_deep.py:113-133): act(x . w + bias).  x [M, K], w [K, N] 16-bit (same dtype),
+    bias fp32 [N] or None.  Returns y [M, N] in x's dtype (fp32 accumulation, one rounding)."""
+    _need_cuda(x, w, bias, out)
+    M, K, ldx = _mat16(x, "x")
+    K2, N, ldw = _mat16(w, "w")
+    if K2 != K or ldw != N or w.dtype != x.dtype:
+        raise TypeError("w must be a contiguous [K, N] tensor of x's dtype")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N or not bias.is_contiguous()):
+        raise TypeError("bias must be contiguous float32 [N]")
+    y = out if out is not None else torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _, _, ldy = _mat16(y, "out")
+    if y.shape != (M, N) or y.dtype != x.dtype:
+        raise TypeError("out must be [M, N] of x's dtype")
+    _lib.call("mrec_dense_fwd_" + _DT16[x.dtype], _ptr(x), ldx, _ptr(w), _ptr(bias), M, K, N, int(bool(relu)), _ptr(y), ldy,
+              _stream())
+    return y
+
+
+def dense_bwd_input(dy, w, h=None, db_out=None, out=None):
+    """MatMul bprop with respect to the input, fused with the ReLU + BiasAdd bprops of the layer below:
+    dx = (dy . w^T) * (h > 0); db_out[:] = dx.sum(0).  dy [M, N], w [K, N], h [M, K] or None, db_out fp32 [K] or None."""
+    _need_cuda(dy, w, h, db_out, out)
+    M, N, lddy = _mat16(dy, "dy")
+    K, N2, ldw = _mat16(w, "w")
+    if N2 != N or ldw != N or w.dtype != dy.dtype:
+        raise TypeError("w must be a contiguous [K, N] tensor of dy's dtype")
+    dx = out if out is not None else torch.empty((M, K), dtype=dy.dtype, device=dy.device)
+    _, _, lddx = _mat16(dx, "out")
+    if h is not None and (h.shape != (M, K) or h.dtype != dy.dtype or h.stride(1) != 1 or h.stride(0) != lddx):
+        raise TypeError("h must be [M, K] of dy's dtype with the row stride of the output")
+    if db_out is not None and (db_out.dtype != torch.float32 or db_out.numel() != K or not db_out.is_contiguous()):
+        raise TypeError("db_out must be contiguous float32 [K]")
+    ws, nb = None, 0
+    if db_out is not None:
+        nb = _lib.query_bytes("mrec_dense_bwd_input_workspace_bytes", M, K)
+        ws = workspace("dense_bwd_input", nb, dy.device)
+    _lib.call("mrec_dense_bwd_input_" + _DT16[dy.dtype], _ptr(dy), lddy, _ptr(w), _ptr(h), M, K, N, _ptr(dx), lddx,
+              _ptr(db_out), _ptr(ws), ws.numel() if ws is not None else 0, _stream())
+    return dx
+
+
+def dense_bwd_weight_slabs(M, K, N):
+    """Number of batch slabs mrec_dense_bwd_weight_* should use for this shape on this device."""
+    s = C.c_int32(0)
+    _lib.call("mrec_dense_bwd_weight_slabs", M, K, N, C.byref(s))
+    return int(s.value)
+
+
+def dense_bwd_weight(x, dy, out_slabs):
+    """MatMul bprop with respect to the weight: out_slabs[s] = x[slab s]^T . dy[slab s], fp32 [S, K, N]."""
+    _need_cuda(x, dy, out_slabs)
+    M, K, ldx = _mat16(x, "x")
+    M2, N, lddy = _mat16(dy, "dy")
+    if M2 != M or dy.dtype != x.dtype:
+        raise TypeError("x and dy must share the batch dimension and the dtype")
+    if out_slabs.dtype != torch.float32 or out_slabs.dim() != 3 or out_slabs.shape[1:] != (K, N) or not out_slabs.is_contiguous():
+        raise TypeError("out_slabs must be contiguous float32 [S, K, N]")
+    _lib.call("mrec_dense_bwd_weight_" + _DT16[x.dtype], _ptr(x), ldx, _ptr(dy), lddy, M, K, N, out_slabs.shape[0],
+              _ptr(out_slabs), _stream())
+    return out_slabs
+
+
+def sum_slabs(slabs, out):
+    """out[...] = slabs.sum(0) in slab order (fp32): the weight gradient of dense_bwd_weight as one tensor."""
+    _need_cuda(slabs, out)
+    if slabs.dtype != torch.float32 or out.dtype != torch.float32 or not slabs.is_contiguous() or not out.is_contiguous():
+        raise TypeError("sum_slabs needs contiguous float32 tensors")
+    if out.numel() != slabs[0].numel():
+        raise ValueError("out must have the size of one slab")
+    _lib.call("mrec_dense_sum_slabs_f32", _ptr(slabs), slabs.shape[0], out.numel(), _ptr(out), _stream())
+    return out
+
+
+def dense_adam_slabs_(p, m, v, g, slabs, shadow16=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, beta1_power=0.9,
+                      beta2_power=0.999, grad_scale=1.0, use_nesterov=False):
+    """dense_adam_ whose gradient is, for some segments, still the fp32 batch slabs of dense_bwd_weight:
+    slabs = [(start, tensor [S, ...] fp32)], start = element offset of the segment in the flat buffers; the slabs
+    are added in slab order inside the Adam kernel.  shadow16 (bf16 / fp16, optional) receives the updated parameters."""
+    _need_cuda(p, m, v, g, shadow16)
+    n = p.numel()
+    if n % 4:
+        raise ValueError("dense_adam_slabs_ needs flat buffers padded to a multiple of 4 elements")
+    k = len(slabs)
+    if k > 8:
+        raise ValueError("at most 8 slab segments")
+    kind = 0
+    if shadow16 is not None:
+        if shadow16.dtype not in _DT16 or shadow16.numel() != n or not shadow16.is_contiguous():
+            raise TypeError("shadow16 must be a contiguous bfloat16 / float16 tensor of the parameter's size")
+        kind = 1 if shadow16.dtype == torch.bfloat16 else 2
+    ptrs = (C.c_void_p * max(k, 1))()
+    starts = (C.c_int64 * max(k, 1))()
+    lens = (C.c_int64 * max(k, 1))()
+    splits = (C.c_int32 * max(k, 1))()
+    for q, (start, part) in enumerate(slabs):
+        if part.dtype != torch.float32 or not part.is_contiguous():
+            raise TypeError("slabs must be contiguous float32 [S, ...]")
+        ptrs[q], starts[q], lens[q], splits[q] = part.data_ptr(), int(start), part[0].numel(), part.shape[0]
+    _lib.call("mrec_dense_adam_slabs_f32", _ptr(p), _ptr(m), _ptr(v), _ptr(g), _ptr(shadow16), kind, n, k,
+              C.cast(ptrs, C.c_void_p), C.cast(starts, C.c_void_p), C.cast(lens, C.c_void_p), C.cast(splits, C.c_void_p),
+              lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _stream())
 
 
 # ---- DeepFM second-order term ------------------------------------------------------------------

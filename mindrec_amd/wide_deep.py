@@ -13,9 +13,9 @@ config 2/4 names (SURVEY.md 8(a) "Which mode is the W&D hot path"):
   TrainStepWrap.construct      :472-492  backward seeded with sens, optional grad reducer, two applies
 
 The reference writes the forward three times and lets MindSpore's graph compiler merge them; here
-it simply runs once.  Embedding lookups, the id dedup and both sparse applies are libmrec_hip.so
-kernels; the MLP (true GEMMs) goes to hipBLASLt through torch, with fp32 master weights kept in one
-flat buffer so the dense LazyAdam (= Adam on dense gradients) is a single kernel launch.
+it simply runs once.  Embedding lookups, the id dedup, both sparse applies AND the mixed-precision
+MLP (hand-written MFMA GEMMs, csrc/mrec_dense.hip) are libmrec_hip.so kernels; fp32 master weights are
+kept in one flat buffer so the dense LazyAdam (= Adam on dense gradients) is a single kernel launch.
 
 Multi-GPU ("hybrid parallel", README.md:140-144): both tables are row-sharded, owner = id mod n,
 local row = id div n.  Per step: bucket ids by owner -> RCCL all-to-all ids -> local gather ->
@@ -62,39 +62,24 @@ class WideDeepConfig:
     # apart (fewer DRAM activations and TLB walks per byte: +6-8 % on MI355X); the API still sees
     # p, m, v, w, ... as separate (strided) [V, D] / [V, 1] tensors.  False = three separate arrays.
     fused_state: bool = True
-    fused_mlp: bool = True               # hand-written fwd/bwd of the mixed-precision MLP (else autograd)
-    overlap_plan: bool = True            # dedup + inverted index on a side HIP stream, under the MLP
-    overlap_wide: bool = False           # wide_sum on the side stream beside the deep gather (measured: slightly slower)
+    overlap_plan: bool = True            # dedup + inverted index (and the wide branch) on a side HIP stream, under the MLP
     overlap_wide_apply: bool = True  # wide-table FTRL on the side stream as soon as the head's backward has produced its gradient:
                                      # a latency-bound kernel hidden under the backward GEMMs (one GPU)
     late_wide: object = None       # the wide branch (one GPU: wide_sum; shards: wide-row exchange + unroute + sum) runs on the side
                                    # stream while the hidden-layer GEMMs run; the main stream joins it right before the output head.
-                                   # It needs one more cut in the MLP graph, and a graph boundary costs ~25 us on the device: on one
-                                   # GPU that is more than the 16-us wide_sum it hides (0.928 -> 0.945 ms/step), on shards it hides a
-                                   # collective.  None = on when sharded, off on one GPU
+                                   # None = on when sharded (it hides a collective) and inside the one-GPU whole-front graph
     early_route: bool = False      # shards: bucket the ids and run the request exchange (sizes, ids, weights) on the side stream
                                    # WITHOUT waiting for the previous step's tail on the main stream -- it hides three small
                                    # collectives, the routing kernels and the bucket-size host sync under the previous step's
                                    # applies.  Requires ids / wts to be complete in HBM when train_step is called (bench.py: yes)
     early_wide_grad: bool = True   # shards: the wide branch's row-gradient exchange starts at the head's backward, under the backward GEMMs
-    parallel_dw_from: int = 0      # with parallel_dw: only layers >= this index take the side branch (small GEMMs leave CUs idle)
-    parallel_dw: bool = False      # weight-gradient GEMMs on a parallel branch of the backward (their own stream / graph branch):
-                                   # measured slower (0.93 -> 0.98 ms/step): two GEMMs sharing the CUs lose more than the gaps they fill
-    overlap_dw0: bool = False      # first-layer weight-gradient GEMM on the side stream beside the sparse apply: step -1 %, but the
-                                   # apply kernel shares the chip and runs 7 % longer (0.179 -> 0.192 ms), so off by default
     dynamic_embedding: bool = False  # both tables are hash tables keyed by the raw ids (train_and_eval.py --dynamic_embedding=True,
                                      # wide_and_deep.py:271-274): rows are created on first sight with their default values
     hash_capacity: int = 1 << 22     # rows reserved in HBM for each hash table (dynamic_embedding)
-    fold_splitk: bool = True       # one GPU: split-K partial sums of the weight gradients are added inside the dense-Adam kernel
-    relu_epilogue: bool = True     # hidden layers: bias + ReLU in the GEMM epilogue instead of a separate ReLU pass
-    graph_bound_inputs: int = 0    # how many recurring (ids, wts, label) buffer triples get a front graph of their own (no staging
-                                   # copies); measured gain 2 us/step for ~0.5 GB of graph pool each, so off
-    graph_tail_on_side: bool = True  # whole-front graph: the last layer's two GEMMs are captured on the plan's branch (-5 us/step)
-    plan_first: bool = True        # one GPU: queue the plan on the side stream before the gathers rather than behind them
     host_cache_rows: int = 0         # > 0: both tables live in pinned host DRAM behind a device cache of this many rows (the
                                      # reference's vocab_cache_size, wide_and_deep.py:215-265); one GPU
     graph_front: bool = True       # one GPU: lookups + plan + MLP + wide FTRL replayed as ONE graph (needs graph_mlp)
-    graph_mlp: bool = True         # replay the fused MLP forward+backward as one captured HIP graph (one host launch, not ~35)
+    graph_mlp: bool = True         # replay the MLP forward+backward as captured HIP graphs (one host launch, not ~25)
 
 
 _TUNED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "tunableop_gfx950.csv")
@@ -128,37 +113,71 @@ def _flat_views(shapes, device, dtype=torch.float32):
     return flat, views
 
 
+class _DirectComm:
+    """The engine's collectives: torch.distributed on the tensors as they are -- device tensors under backend "nccl"
+    (= RCCL over xGMI, the product path), host tensors under gloo (the CPU logic tests).  Test harnesses that put
+    several ranks on ONE GPU inject a comm that stages device tensors through the host (tests/_staged_comm.py)."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def all_to_all(self, out, inp, out_splits=None, in_splits=None):
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
+    def all_reduce(self, t, async_op=False):
+        """Sum over ranks.  async_op=True returns a work handle (device tensors only): the reduction proceeds on RCCL's
+        stream while the calling stream keeps issuing kernels."""
+        if async_op and t.is_cuda:
+            return dist.all_reduce(t, group=self.group, async_op=True)
+        dist.all_reduce(t, group=self.group)
+        return None
+
+
 class WideDeepEngine:
     """State + one training step.  rank/world describe the row sharding; world == 1 is one GPU."""
 
-    def __init__(self, cfg: WideDeepConfig, device, rank=0, world=1, group=None, kernels=None, tuned_gemms=True):
+    def __init__(self, cfg: WideDeepConfig, device, rank=0, world=1, group=None, kernels=None, tuned_gemms=True, comm=None,
+                 shard_protocol=False):
         """kernels: module providing the op set of mindrec_amd.ops.  The product always uses the HIP
-        one (default); tests/ inject a CPU stand-in to exercise the multi-rank host logic under gloo."""
+        one (default); tests/ inject a CPU stand-in to exercise the multi-rank host logic under gloo.
+        comm: collectives provider (default: torch.distributed as is, see _DirectComm).
+        shard_protocol: run the row-shard protocol (routing kernels + collectives) even when world == 1 -- every
+        collective then talks to itself, which executes the RCCL code path on a single GPU."""
         self.cfg, self.device, self.rank, self.world, self.group = cfg, torch.device(device), rank, world, group
+        self._sharded = bool(world > 1 or shard_protocol)
         self.k = kernels if kernels is not None else ops
+        self.comm = comm if comm is not None else _DirectComm(group)
         self._gpu = self.device.type == "cuda"
         if kernels is None and not self._gpu:
             raise RuntimeError("WideDeepEngine runs on an MI355X (no CPU fallback)")
-        self.tuned_gemms = bool(tuned_gemms and self._gpu and enable_tuned_gemms())
         V, D = cfg.vocab_size, cfg.emb_dim
         self.local_rows = (V - rank + world - 1) // world          # rows r with r*world + rank < V
         self.index = None
         self.hb = None
         if cfg.host_cache_rows > 0:
-            if world != 1 or kernels is not None or cfg.dynamic_embedding:
+            if self._sharded or kernels is not None or cfg.dynamic_embedding:
                 raise ValueError("host_cache_rows needs one GPU, the HIP kernels and dense (non-hash) tables")
             self.local_rows = int(cfg.host_cache_rows)
         if cfg.dynamic_embedding:
             # HashEmbeddingLookup x2 with all defaults (wide_and_deep.py:271-274; embedding.py:88-93): a device
             # key -> row index over `hash_capacity` rows; the row tables below are addressed by row number, so
             # every kernel downstream of the index probe is the one the dense-table mode uses.
-            if world != 1:
+            if self._sharded:
                 raise ValueError("dynamic_embedding runs on one GPU (the reference's dynamic-embedding mode is standalone)")
             if kernels is not None:
                 raise ValueError("dynamic_embedding needs the device key index (no CPU stand-in)")
             self.local_rows = int(cfg.hash_capacity)
             self.index = ops.KeyIndex(self.local_rows, self.device)
         dev = self.device
+        self._amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[cfg.mlp_dtype]
+        dims = [cfg.field_size * D] + list(cfg.deep_layer_dim) + [1]
+        nl = len(dims) - 1
+        self.dims = dims
+        # The mixed-precision dense net runs on the hand-written MFMA kernels (csrc/mrec_dense.hip); widths that are not
+        # multiples of 8 (rows not 16-byte aligned), an fp32 net and the CPU stand-in take the autograd path below.
+        self._mfma = bool(self._gpu and kernels is None and self._amp is not None and nl >= 2 and D % 4 == 0 and D <= 256
+                          and all(d % 8 == 0 for d in dims[:-1]))
+        self.tuned_gemms = bool(tuned_gemms and self._gpu and not self._mfma and enable_tuned_gemms())
         with (torch.cuda.device(dev) if self._gpu else contextlib.nullcontext()):
             # deep table + Adam moments, wide table + FTRL accumulators: plain row-major fp32 in HBM
             R = self.local_rows
@@ -193,13 +212,10 @@ class WideDeepEngine:
                 self.wide_linear.zero_()
             # (dynamic_embedding: rows get exactly these values when their key is first seen, _translate_keys)
             # MLP: fp32 master weights in one flat buffer, same for grads / m / v.  Flat order: the hidden
-            # layers' weight matrices first (group H: bf16 GEMM operands, bf16 gradients), then the biases
+            # layers' weight matrices first (group H: the 16-bit GEMM operands), then the biases
             # and the fp32 last layer (group S); `self.dense` lists them in layer order W0, b0, W1, b1, ...
-            dims = [cfg.field_size * D] + list(cfg.deep_layer_dim) + [1]
-            nl = len(dims) - 1
             shapes_h = [(dims[i], dims[i + 1]) for i in range(nl - 1)]
             shapes_s = [(dims[i + 1],) for i in range(nl - 1)] + [(dims[nl - 1], dims[nl]), (dims[nl],)]
-            self.dims = dims
             self.n_h = sum(int(np.prod(x)) for x in shapes_h)
 
             def interleave(vh, vs):
@@ -228,10 +244,10 @@ class WideDeepEngine:
                 p.requires_grad_(True)
                 p.grad = g
             self.dense16 = None
-            if self._gpu and cfg.mlp_dtype == "bf16" and cfg.fused_mlp and kernels is None:
-                # bf16 shadow of every dense parameter (kept current by the dense-Adam kernel) and a flat bf16
-                # buffer the weight-gradient GEMMs write into
-                flat16, v16 = _flat_views(shapes_h + shapes_s + pad, dev, torch.bfloat16)
+            if self._mfma:
+                # 16-bit shadow of every dense parameter, kept current by the dense-Adam kernel: the hidden layers'
+                # [in, out] weight matrices in it are the GEMM operands of the forward AND of the input-gradient kernel
+                flat16, v16 = _flat_views(shapes_h + shapes_s + pad, dev, self._amp)
                 v16 = v16[:len(shapes_h + shapes_s)]
                 flat16.copy_(self.dense_flat.detach())
                 self.dense16_flat, self.dense16 = flat16, interleave(v16[:nl - 1], v16[nl - 1:])
@@ -242,52 +258,15 @@ class WideDeepEngine:
         self.beta1, self.beta2 = np.float32(0.9), np.float32(0.999)
         self.beta1_power, self.beta2_power = np.float32(1.0), np.float32(1.0)
         self.step_count = 0
-        self._amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[cfg.mlp_dtype]
         self.timers = None            # optional dict name -> list[(start_event, stop_event)]
         # (default priority: a high-priority side stream was measured at 1.52 ms/step instead of 0.88)
         self._side = torch.cuda.Stream(device=self.device) if (self._gpu and cfg.overlap_plan) else None
-        self._dw_stream = torch.cuda.Stream(device=self.device) if (self._gpu and cfg.parallel_dw) else None
-        self._mlp_graph = None        # dict: captured fused-MLP step + its static input / output tensors
-        self._dw0_pending = None      # graph of the deferred first-layer weight gradient, to replay this step
-        # one GPU: leave the weight gradients as split-K partials and let the dense-Adam kernel add them up
-        self._fold_splitk = bool(self._gpu and world == 1 and cfg.fold_splitk and kernels is None)
-        self._dw_parts = {}
+        self._mlp_graph = None        # dict: captured MLP step + its static input / output tensors
+        self._dw = {}                 # hidden layer -> fp32 batch slabs [S, in, out] of its weight gradient (persistent:
+                                      # graph replays and eager steps write the same buffers, the dense Adam reads them)
+        self._dw_batch = None
         self.deep_apply_timer = None  # optional ops.KernelTimer armed right before the deep table's sparse apply
         self._front_graph = None      # one-GPU: the whole front of the step (lookups .. MLP backward) as one captured graph
-        self._front_bound = {}        # ... and graphs bound to recurring input buffers (no staging copies)
-        self._front_seen = {}
-
-    # ---- collectives -------------------------------------------------------------------------
-    # RCCL (backend "nccl") takes device tensors directly.  Under a gloo group with device tensors
-    # (debugging several ranks on one GPU, or CPU tests) the payload is staged through host memory.
-    def _staged(self):
-        return self._gpu and dist.get_backend(self.group) == "gloo"
-
-    def _all_to_all(self, out, inp, out_splits=None, in_splits=None):
-        if self._staged():
-            if out.dtype == torch.bfloat16:                 # gloo has no bf16: ship the bytes (row splits unchanged)
-                o8 = torch.empty(out.shape[:-1] + (out.shape[-1] * 2,), dtype=torch.uint8)
-                dist.all_to_all_single(o8, inp.cpu().contiguous().view(torch.uint8), out_splits, in_splits, group=self.group)
-                out.copy_(o8.view(torch.bfloat16))
-                return
-            o = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
-            out.copy_(o)
-        else:
-            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
-
-    def _all_reduce(self, t, async_op=False):
-        """Sum over ranks.  async_op=True returns a work handle (None when the collective is staged through the
-        host): the reduction proceeds on RCCL's stream while this stream keeps issuing kernels."""
-        if self._staged():
-            c = t.cpu()
-            dist.all_reduce(c, group=self.group)
-            t.copy_(c)
-            return None
-        if async_op and self._gpu:
-            return dist.all_reduce(t, group=self.group, async_op=True)
-        dist.all_reduce(t, group=self.group)
-        return None
 
     # ---- helpers -----------------------------------------------------------------------------
     def _tick(self, name):
@@ -306,12 +285,16 @@ class WideDeepEngine:
             ev[1].record()
 
     def mlp(self, x):
-        """DenseLayer x5 (wide_and_deep.py:113-133): act(x W + b), ReLU on all but the last.
-        Hidden layers run in cfg.mlp_dtype on MFMA (hipBLASLt); the last layer (128 -> 1, a GEMV)
-        stays fp32: it is bandwidth-trivial, and its bf16 weight-gradient product
-        [128,B] x [B,1] takes a ~11 ms host-side path in the GEMM library on this image."""
+        """DenseLayer x5 (wide_and_deep.py:113-133): act(x W + b), ReLU on all but the last; returns the fp32 logit.
+        On the GPU in 16-bit mode the hidden layers are the MFMA kernels of csrc/mrec_dense.hip (inference path,
+        no autograd); the last layer (128 -> 1, a GEMV) is fp32.  Otherwise (fp32 net, CPU stand-in) plain autograd."""
         n = len(self.dims) - 1
         amp = self._amp
+        if self._mfma and not torch.is_grad_enabled():
+            h = x if x.dtype == amp else x.to(amp)
+            for i in range(n - 1):
+                h = self.k.dense_fwd(h, self.dense16[2 * i], self.dense[2 * i + 1].detach(), relu=True)
+            return torch.addmm(self.dense[2 * (n - 1) + 1].detach(), h.float(), self.dense[2 * (n - 1)].detach())
         h = x.to(amp) if amp is not None else x
         for i in range(n):
             W, b = self.dense[2 * i], self.dense[2 * i + 1]
@@ -323,126 +306,26 @@ class WideDeepEngine:
                 h = torch.relu(h)
         return h.float()
 
-    @staticmethod
-    def _splitk(B):
-        S = 16
-        while S > 1 and (B % S or B // S < 2048):
-            S //= 2
-        return S
-
-    def _mlp_step(self, emb, wide, label, after_head=None):
-        """The fused MLP step, replayed from HIP graphs once the engine has run two eager steps (library
-        handles and workspaces exist by then).  The step was host-bound: issuing its ~35 launches took 0.8 ms of
-        Python for 1.0 ms of device time.  The graphs hold exactly the kernels of the eager path, in the same
-        order, on the same buffers (weights / gradients are updated in place, so their addresses are stable);
-        inputs are staged in three static tensors -- the gather writes the embeddings there directly.
-        Three graphs, cut around the output head: hidden-layer forward | head | backward.  `wide` may be a function:
-        it is called between the first two (the wide branch is computed on the side stream meanwhile); after_head
-        runs between the last two (the wide branch's gradient exists from there on)."""
-        self._dw0_pending = None
-        if not (self.cfg.graph_mlp and self._gpu and self.step_count > 2):
-            return self._mlp_step_fused(emb, wide, label, after_head=after_head)
-        g = self._mlp_graph
-        if g is None or g["emb"].shape != emb.shape or g["emb"].dtype != emb.dtype or (g["graph_head"] is None) == callable(wide):
-            try:
-                g = self._capture_mlp(emb, wide, label)
-            except RuntimeError as e:          # capture refused (e.g. a library call not capturable): stay eager
-                import warnings
-                warnings.warn(f"HIP-graph capture of the MLP step failed, running it eagerly: {e}")
-                self.cfg.graph_mlp = False
-                self._mlp_graph = None
-                return self._mlp_step_fused(emb, wide, label, after_head=after_head)
-        if emb.data_ptr() != g["emb"].data_ptr():
-            g["emb"].copy_(emb)
-        g["label"].copy_(label)
-        if g["graph_head"] is None:
-            g["wide"].copy_(wide() if callable(wide) else wide)
-            g["graph_fwd"].replay()                # hidden layers + head in one graph
-        else:
-            g["graph_fwd"].replay()
-            g["wide"].copy_(wide() if callable(wide) else wide)
-            g["graph_head"].replay()
-        if after_head is not None:
-            after_head(g["ctx"]["g_wide"])
-        g["graph_bwd"].replay()
-        self._dw0_pending = g["graph_dw0"]
-        return g["ctx"]["loss"], g["g_emb"], g["ctx"]["g_wide"]
-
-    def _capture_mlp(self, emb, wide, label):
-        late = callable(wide)
-        if late:
-            wide = wide()
-        g = {"emb": torch.empty_like(emb), "wide": torch.empty_like(wide), "label": torch.empty_like(label)}
-        g["emb"].copy_(emb)
-        g["wide"].copy_(wide)
-        g["label"].copy_(label)
-        torch.cuda.synchronize(self.device)
-        defer = self._side is not None and self.cfg.overlap_dw0
-        # thread_local: RCCL's watchdog thread may query events while this thread captures
-        g1 = torch.cuda.CUDAGraph()
-        if late:
-            # cut between the hidden layers and the head: the wide branch arrives in between
-            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-                g["hs"] = self._mlp_fwd(g["emb"])
-            gh = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gh, capture_error_mode="thread_local"):
-                g["ctx"] = self._mlp_head(g["hs"], g["wide"], g["label"])
-            g["graph_head"] = gh
-        else:
-            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-                g["hs"] = self._mlp_fwd(g["emb"])
-                g["ctx"] = self._mlp_head(g["hs"], g["wide"], g["label"])
-            g["graph_head"] = None
-        g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2, capture_error_mode="thread_local"):
-            g["g_emb"] = self._mlp_bwd(g["ctx"], defer_dw0=defer)
-        g["graph_fwd"], g["graph_bwd"], g["graph_dw0"] = g1, g2, None
-        if defer:
-            # third graph: the first layer's weight gradient alone (reads the static input and layer 0's dh,
-            # both kept alive here); train_step replays it on the side stream beside the sparse apply
-            g["dw0_args"] = self._dw0_args
-            g3 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g3, capture_error_mode="thread_local"):
-                self._mlp_dw(0, *g["dw0_args"])
-            g["graph_dw0"] = g3
-        self._mlp_graph = g
-        return g
-
-    def _emb_out(self, n, D, dtype):
-        """Static graph input to gather into (None while the step still runs eagerly)."""
-        g = self._mlp_graph
-        if g is not None and g["emb"].dtype == dtype and g["emb"].numel() == n * D and torch.is_grad_enabled():
-            return g["emb"].view(n, D)
-        return None
-
-    @torch.no_grad()
-    def _mlp_dw(self, i, h, dh):
-        """Weight gradient of hidden layer i: dW = h^T dh has only (K/256)*(N/256) output tiles but a 16384-deep
-        reduction: split the batch dimension into S chunks (one batched GEMM fills the chip), sum the partials
-        in fp32 straight into the flat gradient buffer (measured: 139/78/46/36 us -> 107/30/25/25 us)."""
-        B = h.shape[0]
-        S = self._splitk(B)
-        if S > 1:
-            part = torch.bmm(h.view(S, B // S, -1).transpose(1, 2), dh.view(S, B // S, -1))
-            if self._fold_splitk:
-                self._dw_parts[i] = part          # summed inside the dense-Adam kernel (one GPU: nobody else needs the sum)
-            else:
-                torch.sum(part, dim=0, dtype=torch.float32, out=self.dense_grad[2 * i])
-        else:
-            self.dense_grad[2 * i].copy_(torch.mm(h.t(), dh))
+    # ---- the mixed-precision dense net, forward + backward by hand on the MFMA kernels -----------------
+    def _dw_slabs(self, i, B):
+        """fp32 batch slabs [S, in, out] the weight-gradient kernel of hidden layer i writes (allocated once per batch size)."""
+        if self._dw_batch != B:
+            self._dw, self._dw_batch = {}, B
+        t = self._dw.get(i)
+        if t is None:
+            K, N = self.dims[i], self.dims[i + 1]
+            S = self.k.dense_bwd_weight_slabs(B, K, N)
+            t = torch.empty((S, K, N), dtype=torch.float32, device=self.device)
+            self._dw[i] = t
+        return t
 
     @torch.no_grad()
     def _mlp_fwd(self, emb):
-        """Hidden layers forward: the activations hs[0..n-1] (hs[0] = the MLP input)."""
-        amp, n = self._amp, len(self.dims) - 1
-        Wb = [self.dense16[2 * i] for i in range(n - 1)]              # bf16 shadows written by the dense Adam
-        hs = [emb if emb.dtype == amp else emb.to(amp)]
+        """Hidden layers forward: the activations hs[0..n-1] (hs[0] = the MLP input), bias + ReLU in the GEMM epilogue."""
+        n = len(self.dims) - 1
+        hs = [emb if emb.dtype == self._amp else emb.to(self._amp)]
         for i in range(n - 1):
-            if self.cfg.relu_epilogue:
-                # bias + ReLU in the GEMM's epilogue (hipBLASLt): bit-identical to addmm + relu_, one pass less
-                hs.append(torch._addmm_activation(self.dense16[2 * i + 1], hs[i], Wb[i], use_gelu=False))
-            else:
-                hs.append(torch.addmm(self.dense16[2 * i + 1], hs[i], Wb[i]).relu_())
+            hs.append(self.k.dense_fwd(hs[i], self.dense16[2 * i], self.dense[2 * i + 1].detach(), relu=True))
         return hs
 
     @torch.no_grad()
@@ -471,85 +354,111 @@ class WideDeepEngine:
         return {"hs": hs, "loss": loss, "g_wide": dlogit.view(-1), "dh": dh}
 
     @torch.no_grad()
-    def _mlp_bwd(self, ctx, defer_dw0=False):
-        """Backward through the hidden layers; returns g_emb [B, F*D] (bf16)."""
+    def _mlp_bwd(self, ctx, tail_stream=None):
+        """Backward through the hidden layers; returns g_emb [B, F*D] (16-bit).  Per layer, from the top: the input
+        gradient (MatMul bprop fused with the ReLU and BiasAdd bprops of the layer below: that layer's bias gradient
+        lands in dense_grad) and the weight gradient (fp32 batch slabs, summed later inside the dense Adam).
+        tail_stream (whole-front capture): the first layer's two kernels are issued on that stream -- the branch the
+        runtime keeps on the launching stream's hardware queue -- so the graph ends where the next eager kernel starts."""
         n = len(self.dims) - 1
-        Wb = [self.dense16[2 * i] for i in range(n - 1)]
         hs, dh = ctx["hs"], ctx["dh"]
-        g_emb = None
-        # The weight gradients hang off the dh chain as leaves: issue them on a second stream (a parallel branch
-        # when captured into the graph) so their GEMMs and split-K reductions fill the gaps the chain's small
-        # kernels (ReLU bprop + column sums) and GEMM tails leave on the chip.
-        main, br = torch.cuda.current_stream(), self._dw_stream
-        for i in range(n - 2, -1, -1):
-            if i == 0 and defer_dw0:
-                self._dw0_args = (hs[0], dh)
-            elif br is not None and i >= self.cfg.parallel_dw_from:
-                br.wait_stream(main)
-                hs[i].record_stream(br)
-                dh.record_stream(br)
-                with torch.cuda.stream(br):
-                    self._mlp_dw(i, hs[i], dh)
-            else:
-                self._mlp_dw(i, hs[i], dh)
-            if i > 0:
-                # ReLU bprop of layer i-1's activation + its bias gradient (column sum) in one pass
-                gpre = torch.mm(dh, Wb[i].t())
-                if self.k.relu_bwd_colsum_supported(self.dims[i]):
-                    dh = self.k.relu_bwd_colsum(gpre, hs[i], self.dense_grad[2 * (i - 1) + 1])
-                else:
-                    dh = torch.ops.aten.threshold_backward(gpre, hs[i], 0)
-                    torch.sum(dh, dim=0, dtype=torch.float32, out=self.dense_grad[2 * (i - 1) + 1])
-            else:
-                g_emb = torch.mm(dh, Wb[0].t())
-        if br is not None:
-            main.wait_stream(br)
-        return g_emb
-
-    def _mlp_bwd_tail_on(self, stream, ctx):
-        """Variant used under whole-front capture: the last layer's two GEMMs are issued on `stream` (the branch the
-        runtime keeps on the launching stream's hardware queue), so the graph ends where the next eager kernel starts."""
-        n = len(self.dims) - 1
-        Wb = [self.dense16[2 * i] for i in range(n - 1)]
-        hs, dh = ctx["hs"], ctx["dh"]
-        main = torch.cuda.current_stream()
+        B = hs[0].shape[0]
         for i in range(n - 2, 0, -1):
-            self._mlp_dw(i, hs[i], dh)
-            gpre = torch.mm(dh, Wb[i].t())
-            if self.k.relu_bwd_colsum_supported(self.dims[i]):
-                dh = self.k.relu_bwd_colsum(gpre, hs[i], self.dense_grad[2 * (i - 1) + 1])
-            else:
-                dh = torch.ops.aten.threshold_backward(gpre, hs[i], 0)
-                torch.sum(dh, dim=0, dtype=torch.float32, out=self.dense_grad[2 * (i - 1) + 1])
-        stream.wait_stream(main)
-        with torch.cuda.stream(stream):
-            g_emb = torch.mm(dh, Wb[0].t())
-            self._mlp_dw(0, hs[0], dh)
+            self.k.dense_bwd_weight(hs[i], dh, self._dw_slabs(i, B))
+            dh = self.k.dense_bwd_input(dh, self.dense16[2 * i], h=hs[i], db_out=self.dense_grad[2 * (i - 1) + 1])
+        if tail_stream is not None:
+            tail_stream.wait_stream(torch.cuda.current_stream())
+        with (torch.cuda.stream(tail_stream) if tail_stream is not None else contextlib.nullcontext()):
+            g_emb = self.k.dense_bwd_input(dh, self.dense16[0], h=None, db_out=None)
+            self.k.dense_bwd_weight(hs[0], dh, self._dw_slabs(0, B))
         return g_emb
 
-    def _mlp_step_fused(self, emb, wide, label, defer_dw0=False, after_head=None, tail_stream=None):
-        """Forward + backward of the bf16 MLP written out by hand (no autograd graph).  `emb` arrives
-        in bf16 straight from the gather kernel, and the gradient of the MLP input is returned in bf16
-        for the sparse apply to widen on load -- the two [B, F*D] fp32<->bf16 cast passes of the
-        autograd path disappear, as do autograd's per-parameter cast and accumulate kernels.  Every
-        GEMM stays a plain addmm / mm so the shipped TunableOp table applies.  Same math as the
-        autograd path (ReLU mask = activation > 0).  Weights and biases are read from their bf16 shadows
-        (no per-step cast kernels); weight gradients are split-K batched GEMMs whose fp32 partial sums
-        land in dense_grad, like the bias and last-layer gradients.
-        Returns (loss, g_emb [B, F*D] bf16, g_wide [B] fp32).  after_head(g_wide) is called as soon as the wide
-        branch's gradient exists (the caller may start the wide table's update beside the backward GEMMs).
-        defer_dw0=True leaves the first layer's weight gradient to the caller (self._mlp_dw(0, *self._dw0_args))."""
+    def _mlp_step_eager(self, emb, wide, label, after_head=None, tail_stream=None):
+        """Forward + backward of the mixed-precision MLP written out by hand (no autograd graph).  `emb` arrives
+        in 16 bits straight from the gather kernel, and the gradient of the MLP input is returned in 16 bits
+        for the sparse apply to widen on load.  Weights are read from their 16-bit shadows (no per-step cast kernels).
+        Returns (loss, g_emb [B, F*D] 16-bit, g_wide [B] fp32).  after_head(g_wide) is called as soon as the wide
+        branch's gradient exists (the caller may start the wide table's update beside the backward GEMMs)."""
         hs = self._mlp_fwd(emb)
         if callable(wide):
             wide = wide()                  # joins whatever stream computed the wide branch; returns the tensor
         ctx = self._mlp_head(hs, wide, label)
         if after_head is not None:
             after_head(ctx["g_wide"])
-        if tail_stream is not None:
-            g_emb = self._mlp_bwd_tail_on(tail_stream, ctx)
-        else:
-            g_emb = self._mlp_bwd(ctx, defer_dw0)
+        g_emb = self._mlp_bwd(ctx, tail_stream)
         return ctx["loss"], g_emb, ctx["g_wide"]
+
+    def _mlp_step(self, emb, wide, label, after_head=None):
+        """The MLP step, replayed from HIP graphs once the engine has run two eager steps (workspaces exist by then).
+        The graphs hold exactly the kernels of the eager path, in the same order, on the same buffers (weights /
+        gradients are updated in place, so their addresses are stable); inputs are staged in three static tensors --
+        the gather writes the embeddings there directly.  Graphs: hidden-layer forward [| head] | backward.  `wide` may
+        be a function: it is called between the first two (the wide branch is computed on the side stream meanwhile);
+        after_head runs before the backward graph (the wide branch's gradient exists from there on)."""
+        if not (self.cfg.graph_mlp and self._gpu and self.step_count > 2):
+            return self._mlp_step_eager(emb, wide, label, after_head=after_head)
+        g = self._mlp_graph
+        if g is None or g["emb"].shape != emb.shape or g["emb"].dtype != emb.dtype or (g["graph_head"] is None) == callable(wide):
+            try:
+                g = self._capture_mlp(emb, wide, label)
+            except RuntimeError as e:          # capture refused: stay eager
+                import warnings
+                warnings.warn(f"HIP-graph capture of the MLP step failed, running it eagerly: {e}")
+                self.cfg.graph_mlp = False
+                self._mlp_graph = None
+                return self._mlp_step_eager(emb, wide, label, after_head=after_head)
+        if emb.data_ptr() != g["emb"].data_ptr():
+            g["emb"].copy_(emb)
+        g["label"].copy_(label)
+        if g["graph_head"] is None:
+            g["wide"].copy_(wide() if callable(wide) else wide)
+            g["graph_fwd"].replay()                # hidden layers + head in one graph
+        else:
+            g["graph_fwd"].replay()
+            g["wide"].copy_(wide() if callable(wide) else wide)
+            g["graph_head"].replay()
+        if after_head is not None:
+            after_head(g["ctx"]["g_wide"])
+        g["graph_bwd"].replay()
+        return g["ctx"]["loss"], g["g_emb"], g["ctx"]["g_wide"]
+
+    def _capture_mlp(self, emb, wide, label):
+        late = callable(wide)
+        if late:
+            wide = wide()
+        g = {"emb": torch.empty_like(emb), "wide": torch.empty_like(wide), "label": torch.empty_like(label)}
+        g["emb"].copy_(emb)
+        g["wide"].copy_(wide)
+        g["label"].copy_(label)
+        torch.cuda.synchronize(self.device)
+        # thread_local: RCCL's watchdog thread may query events while this thread captures
+        g1 = torch.cuda.CUDAGraph()
+        if late:
+            # cut between the hidden layers and the head: the wide branch arrives in between
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                g["hs"] = self._mlp_fwd(g["emb"])
+            gh = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gh, capture_error_mode="thread_local"):
+                g["ctx"] = self._mlp_head(g["hs"], g["wide"], g["label"])
+            g["graph_head"] = gh
+        else:
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                g["hs"] = self._mlp_fwd(g["emb"])
+                g["ctx"] = self._mlp_head(g["hs"], g["wide"], g["label"])
+            g["graph_head"] = None
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+            g["g_emb"] = self._mlp_bwd(g["ctx"])
+        g["graph_fwd"], g["graph_bwd"] = g1, g2
+        self._mlp_graph = g
+        return g
+
+    def _emb_out(self, n, D, dtype):
+        """Static graph input to gather into (None while the step still runs eagerly)."""
+        g = self._mlp_graph
+        if g is not None and g["emb"].dtype == dtype and g["emb"].numel() == n * D and torch.is_grad_enabled():
+            return g["emb"].view(n, D)
+        return None
 
     # ---- forward (eval path: PredictWithSigmoid, wide_and_deep.py:495-518) ---------------------
     def lookup(self, ids, wts, defer_wide=False):
@@ -558,34 +467,25 @@ class WideDeepEngine:
         function to call (on whatever stream should do the work) instead of a tensor."""
         cfg = self.cfg
         B, Fd = ids.shape
-        if self.world == 1:
+        if not self._sharded:
             ev = self._tick("gather_deep")
-            if self._fused_bf16() and torch.is_grad_enabled():
-                emb = self.k.gather_rows(self.deep, ids, wts, out=self._emb_out(B * Fd, cfg.emb_dim, torch.bfloat16),
-                                         out_dtype=torch.bfloat16).view(B, Fd * cfg.emb_dim)
+            if self._mfma and torch.is_grad_enabled():
+                emb = self.k.gather_rows(self.deep, ids, wts, out=self._emb_out(B * Fd, cfg.emb_dim, self._amp),
+                                         out_dtype=self._amp).view(B, Fd * cfg.emb_dim)
             else:
                 emb = self.k.gather_rows(self.deep, ids, wts).view(B, Fd * cfg.emb_dim)
             self._tock(ev)
             if defer_wide:
                 return emb, (lambda: self.k.wide_sum(self.wide, ids, wts, self.wide_b)), None
             ev = self._tick("wide_sum")
-            if self._side is not None and self.cfg.overlap_wide and torch.is_grad_enabled():
-                # latency-bound 4-byte gathers: let them run beside the deep gather on the side stream
-                main = torch.cuda.current_stream()
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
-                    wide = self.k.wide_sum(self.wide, ids, wts, self.wide_b)
-                    self._wide_event = self._side.record_event()
-                wide.record_stream(main)
-            else:
-                wide = self.k.wide_sum(self.wide, ids, wts, self.wide_b)
+            wide = self.k.wide_sum(self.wide, ids, wts, self.wide_b)
             self._tock(ev)
             return emb, wide, None
         # --- row-sharded: bucket by owner, exchange ids, gather locally, exchange rows back
         ev = self._tick("route")
         n = ids.numel()
         D = cfg.emb_dim
-        wire16 = self._fused_bf16() and torch.is_grad_enabled() and D % 2 == 0
+        wire16 = self._mfma and torch.is_grad_enabled() and D % 2 == 0
         early = self._side is not None and cfg.early_route and torch.is_grad_enabled()
         main = torch.cuda.current_stream() if self._gpu else None
         with (torch.cuda.stream(self._side) if early else contextlib.nullcontext()):
@@ -595,19 +495,19 @@ class WideDeepEngine:
             send_local, perm, counts = self.k.shard_route(ids, self.world)
             send_counts = counts.tolist()                                    # host sync: n_shards ints
             recv_counts_t = torch.empty_like(counts)
-            self._all_to_all(recv_counts_t, counts)
+            self.comm.all_to_all(recv_counts_t, counts)
             recv_counts = recv_counts_t.tolist()
             n_recv = int(sum(recv_counts))
             recv_local = torch.empty(n_recv, dtype=ids.dtype, device=self.device)
-            self._all_to_all(recv_local, send_local, recv_counts, send_counts)
+            self.comm.all_to_all(recv_local, send_local, recv_counts, send_counts)
             recv_wts = None
             if wire16:
-                # bf16 on the wire: the per-position weights travel with the ids so the OWNER applies the mask in
-                # fp32 and rounds once to bf16 -- bit-identical to the one-GPU gather -- and rows / row-gradients
-                # cross xGMI at half the bytes.  A row of D bf16 is moved as D/2 fp32 words (pure permutation).
+                # 16 bits on the wire: the per-position weights travel with the ids so the OWNER applies the mask in
+                # fp32 and rounds once -- bit-identical to the one-GPU gather -- and rows / row-gradients
+                # cross xGMI at half the bytes.  A row of D 16-bit values is moved as D/2 fp32 words (pure permutation).
                 send_w = self.k.shard_route_rows(wts.reshape(n, 1), perm, None)
                 recv_wts = torch.empty((n_recv, 1), dtype=torch.float32, device=self.device)
-                self._all_to_all(recv_wts, send_w, recv_counts, send_counts)
+                self.comm.all_to_all(recv_wts, send_w, recv_counts, send_counts)
                 recv_wts = recv_wts.view(-1)
         if early:
             main.wait_stream(self._side)
@@ -617,7 +517,7 @@ class WideDeepEngine:
         self._tock(ev)
         ev = self._tick("gather_deep")
         if wire16:
-            rows = self.k.gather_rows(self.deep, recv_local, recv_wts, out_dtype=torch.bfloat16)     # [n_recv, D] bf16
+            rows = self.k.gather_rows(self.deep, recv_local, recv_wts, out_dtype=self._amp)          # [n_recv, D] 16-bit
             wrows = self.k.gather_rows(self.wide, recv_local, recv_wts)                               # [n_recv, 1], masked
         else:
             rows = self.k.gather_rows(self.deep, recv_local)                # [n_recv, D]
@@ -625,12 +525,12 @@ class WideDeepEngine:
         self._tock(ev)
         ev = self._tick("a2a_rows")
         back = torch.empty((n, D), dtype=rows.dtype, device=self.device)
-        self._all_to_all(back, rows, send_counts, recv_counts)
+        self.comm.all_to_all(back, rows, send_counts, recv_counts)
 
         def wide_branch():
             # wide rows back from their owners, un-permuted, summed over the fields (+ bias)
             wback = torch.empty((n, 1), dtype=torch.float32, device=self.device)
-            self._all_to_all(wback, wrows, send_counts, recv_counts)
+            self.comm.all_to_all(wback, wrows, send_counts, recv_counts)
             wv = self.k.shard_unroute(wback, perm, None if wire16 else wts.reshape(-1)).view(B, Fd)
             return wv.sum(dim=1) + self.wide_b
 
@@ -638,19 +538,16 @@ class WideDeepEngine:
         self._tock(ev)
         ev = self._tick("unroute")
         if wire16:
-            eo = self._emb_out(n, D, torch.bfloat16)            # static graph input, when the MLP graph exists
+            eo = self._emb_out(n, D, self._amp)            # static graph input, when the MLP graph exists
             if eo is not None:
                 eo = eo.view(torch.float32)
-            emb = self.k.shard_unroute(back.view(torch.float32), perm, None, out=eo).view(torch.bfloat16).view(B, Fd * D)
+            emb = self.k.shard_unroute(back.view(torch.float32), perm, None, out=eo).view(self._amp).view(B, Fd * D)
         else:
             emb = self.k.shard_unroute(back, perm, wts.reshape(-1)).view(B, Fd * D)
         self._tock(ev)
         if defer_wide:
             wrows.record_stream(self._side)
         return emb, wide, (perm, send_counts, recv_counts, recv_local, recv_wts)
-
-    def _fused_bf16(self):
-        return self.dense16 is not None
 
     def predict(self, ids, wts):
         with torch.no_grad():
@@ -708,15 +605,14 @@ class WideDeepEngine:
         B, Fd = ids.shape
         D = cfg.emb_dim
         inv_sens = 1.0 / cfg.sens
-        self._wide_event = None
         # the wide branch on the side stream: on when sharded (hides a collective) and inside the whole-front graph (no
         # graph cut to pay for there); off for the one-GPU MLP-graph path, where it costs an extra graph boundary
-        late_cfg = cfg.late_wide if cfg.late_wide is not None else (self.world > 1 or capturing)
-        late = bool(self._side is not None and late_cfg and self._fused_bf16())
+        late_cfg = cfg.late_wide if cfg.late_wide is not None else (self._sharded or capturing)
+        late = bool(self._side is not None and late_cfg and self._mfma)
         plan_early = None
         if self.index is not None or self.hb is not None:
             ids, plan_early = self._translate_keys(ids)        # from here on `ids` are table row numbers
-        elif self._side is not None and self.world == 1 and not late and cfg.plan_first:
+        elif self._side is not None and not self._sharded and not late:
             # one GPU: the plan needs nothing but the ids -- start it on the side stream BEFORE the gathers are
             # queued, so that it runs beside them (HBM-bound) and eats less into the first GEMM
             main = torch.cuda.current_stream()
@@ -733,8 +629,7 @@ class WideDeepEngine:
             # needs only the ids (on a shard: the ids received from the other ranks) and is joined before the sparse
             # applies: its dozen small latency-bound kernels hide under the MLP.
             main = torch.cuda.current_stream()
-            if self._wide_event is None:
-                self._side.wait_stream(main)          # the gathers are queued on main: the wide branch starts behind them
+            self._side.wait_stream(main)          # the gathers are queued on main: the wide branch starts behind them
             with torch.cuda.stream(self._side):
                 if late:
                     wide_t = wide()
@@ -748,11 +643,9 @@ class WideDeepEngine:
             for t in (plan_early.uniq_buf, plan_early.inv, plan_early.n_uniq_dev, plan_early.sorted_pos,
                       plan_early.sorted_seg, plan_early.seg_offsets):
                 self._rs(t, main)
-        if self._wide_event is not None:
-            torch.cuda.current_stream().wait_event(self._wide_event)   # the head needs `wide`; the plan may still run
 
         ev = self._tick("mlp_fwd_bwd")
-        fused = self._fused_bf16()
+        fused = self._mfma
         wide_done = False
         if fused:
             after_head = None
@@ -786,15 +679,14 @@ class WideDeepEngine:
                             gw = (gw_b.view(B, 1) * wts).view(B * Fd, 1)
                         send_gw = self.k.shard_route_rows(gw, perm_, None)
                         recv_gw = torch.empty((recv_local_.numel(), 1), dtype=torch.float32, device=self.device)
-                        self._all_to_all(recv_gw, send_gw, recv_counts_, send_counts_)
+                        self.comm.all_to_all(recv_gw, send_gw, recv_counts_, send_counts_)
                     holder["recv_gw"] = recv_gw
                 early_gw = holder
             if capturing:
                 # the runtime keeps the branch whose nodes were captured first -- the plan's -- on the launching stream's
                 # hardware queue; ending the graph there saves most of the cross-queue hand-over to the eager apply
-                tail = self._side if (cfg.graph_tail_on_side and route is None and plan_early is not None
-                                      and self.index is None) else None
-                loss, g_emb, g_wide = self._mlp_step_fused(emb, wide, label, after_head=after_head, tail_stream=tail)
+                tail = self._side if (route is None and plan_early is not None and self.index is None) else None
+                loss, g_emb, g_wide = self._mlp_step_eager(emb, wide, label, after_head=after_head, tail_stream=tail)
             else:
                 loss, g_emb, g_wide = self._mlp_step(emb, wide, label, after_head=after_head)
             if route is not None and route[4] is None:
@@ -807,17 +699,18 @@ class WideDeepEngine:
             loss = F.binary_cross_entropy_with_logits(logit, label)      # SigmoidCrossEntropyWithLogits + ReduceMean
             (loss * cfg.sens).backward()                                  # sens_param seeding, :479-486
             g_emb, g_wide = emb.grad, wide.grad                           # [B, F*D], [B]
+            early_gw = None
         self._tock(ev)
 
-        if plan_early is not None:
+        if plan_early is not None and self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)          # the plan (queued long ago) is done
-        return loss, g_emb, g_wide, plan_early, wide_done, route, (early_gw if fused else None), fused
+        return loss, g_emb, g_wide, plan_early, wide_done, route, early_gw, fused
 
     # ---- the whole front of a one-GPU step as ONE HIP graph ------------------------------------------
     def _front_graph_ok(self):
-        return bool(self.cfg.graph_front and self.cfg.graph_mlp and self._gpu and self.world == 1 and self._side is not None
-                    and self._fused_bf16() and self.step_count > 2 and torch.is_grad_enabled() and self.timers is None
-                    and not self.cfg.overlap_dw0 and self.hb is None)
+        return bool(self.cfg.graph_front and self.cfg.graph_mlp and self._gpu and not self._sharded and self._side is not None
+                    and self._mfma and self.step_count > 2 and torch.is_grad_enabled() and self.timers is None
+                    and self.hb is None)
 
     def _front_replay(self, ids, wts, label):
         """ids / wts / label are copied into static buffers (3.5 MB) and the captured front is replayed: the deep
@@ -825,24 +718,6 @@ class WideDeepEngine:
         parameters) on another side branch -- one launch, no graph boundaries inside (each costs ~25 us of device
         time on this stack).  The deep LazyAdam apply and the dense Adam stay outside: their step size changes
         every step (bias correction) and is a kernel argument."""
-        # Input buffers that keep coming back (a loader's double buffer, bench.py's rotating batches) get a graph bound
-        # to their addresses: no staging copies at all.  Everything else goes through the staging graph.
-        key = (ids.data_ptr(), wts.data_ptr(), label.data_ptr(), tuple(ids.shape), ids.dtype)
-        bound = self._front_bound.get(key)
-        if bound is not None:
-            bound["graph"].replay()
-            return bound["out"]
-        if self.cfg.graph_bound_inputs > 0:
-            if len(self._front_seen) > 64:
-                self._front_seen.clear()
-            seen = self._front_seen.get(key, 0) + 1
-            self._front_seen[key] = seen
-            if seen >= 2 and len(self._front_bound) < self.cfg.graph_bound_inputs:
-                bound = self._capture_front(ids, wts, label)
-                if bound is not None:
-                    self._front_bound[key] = bound
-                    bound["graph"].replay()
-                    return bound["out"]
         g = self._front_graph
         if g is None or g["ids"].shape != ids.shape or g["ids"].dtype != ids.dtype:
             g = self._capture_front(ids.clone(), wts.clone(), label.clone())
@@ -870,8 +745,13 @@ class WideDeepEngine:
             warnings.warn(f"HIP-graph capture of the step front failed, falling back to the MLP graphs: {e}")
             self.cfg.graph_front = False
             self._front_graph = None
-            self._front_bound.clear()
             return None
+
+    def _sum_dw_slabs(self):
+        """Weight-gradient slabs -> the flat gradient buffer (needed only where somebody other than the dense Adam
+        reads the summed gradient: the data-parallel all-reduce)."""
+        for i, t in self._dw.items():
+            self.k.sum_slabs(t, self.dense_grad[2 * i])
 
     # ---- one training step -------------------------------------------------------------------
     def train_step(self, ids, wts, label):
@@ -897,13 +777,6 @@ class WideDeepEngine:
         else:
             gb = g_wide.sum().view(1)
         dense_work = None
-        if self._dw0_pending is not None:
-            # first layer's weight gradient: a compute-bound GEMM nobody needs before the dense Adam -- on the
-            # side stream, beside the HBM-bound sparse applies (one GPU) / the row-gradient exchange (shards)
-            self._side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._side):
-                self._dw0_pending.replay()
-            self._dw0_pending = None
 
         if route is None:
             ev = self._tick("plan")
@@ -932,12 +805,12 @@ class WideDeepEngine:
             n_recv = recv_local.numel()
             have_gw = fused and early_gw is not None and "recv_gw" in early_gw
             if recv_wts is not None:
-                # bf16 wire: raw bf16 row-gradients travel (as D/2 fp32 words); the owner multiplies by the
+                # 16-bit wire: raw 16-bit row-gradients travel (as D/2 fp32 words); the owner multiplies by the
                 # weights it received in the forward, inside the apply kernel, exactly as on one GPU
                 send_g = self.k.shard_route_rows(g_emb.view(B * Fd, D).view(torch.float32), perm, None)
                 recv_g32 = torch.empty((n_recv, D // 2), dtype=torch.float32, device=self.device)
-                self._all_to_all(recv_g32, send_g, recv_counts, send_counts)
-                recv_g = recv_g32.view(torch.bfloat16)
+                self.comm.all_to_all(recv_g32, send_g, recv_counts, send_counts)
+                recv_g = recv_g32.view(self._amp)
                 if not have_gw:
                     gw = g_wide.view(B, 1).expand(B, Fd).reshape(B * Fd, 1).contiguous()
                     send_gw = self.k.shard_route_rows(gw, perm, None)
@@ -949,22 +822,24 @@ class WideDeepEngine:
                     gw = (g_wide.view(B, 1) * wts).view(B * Fd, 1)
                     send_gw = self.k.shard_route_rows(gw, perm, None)
                 recv_g = torch.empty((n_recv, D), dtype=torch.float32, device=self.device)
-                self._all_to_all(recv_g, send_g, recv_counts, send_counts)
+                self.comm.all_to_all(recv_g, send_g, recv_counts, send_counts)
                 row_scale = None
             if have_gw:
                 recv_gw = early_gw["recv_gw"]          # exchanged on the side stream during the backward; joined below
                 recv_gw.record_stream(torch.cuda.current_stream())
             else:
                 recv_gw = torch.empty((n_recv, 1), dtype=torch.float32, device=self.device)
-                self._all_to_all(recv_gw, send_gw, recv_counts, send_counts)
+                self.comm.all_to_all(recv_gw, send_gw, recv_counts, send_counts)
             self._tock(ev)
             # Dense gradients (+ the wide bias gradient riding in the same buffer): all-reduce queued behind the
             # row-gradient exchange and left running while the sparse applies execute -- they do not need it.
             ev = self._tick("allreduce_dense")
             if self._side is not None:
-                torch.cuda.current_stream().wait_stream(self._side)      # deferred dW0 has landed in dense_grad
+                torch.cuda.current_stream().wait_stream(self._side)
+            if fused:
+                self._sum_dw_slabs()
             self.dense_grad_ext[-1:].copy_(gb)
-            dense_work = self._all_reduce(self.dense_grad_ext, async_op=True)
+            dense_work = self.comm.all_reduce(self.dense_grad_ext, async_op=True)
             self._tock(ev)
             ev = self._tick("plan")
             plan = plan_early if plan_early is not None else self.k.sparse_plan(recv_local)
@@ -985,23 +860,25 @@ class WideDeepEngine:
                              l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=scale)
             self._tock(ev)
 
-        if self.world > 1:
+        if self._sharded:
             if dense_work is not None:
                 dense_work.wait()                     # the current stream waits for RCCL's stream; no host block
-            self.dense_grad_ext.div_(self.world)      # gradients_mean=True (train_and_eval_distribute.py:137)
+            if self.world > 1:
+                self.dense_grad_ext.div_(self.world)  # gradients_mean=True (train_and_eval_distribute.py:137)
             gb = self.dense_grad_ext[-1:]
         if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)          # deferred dW0
+            torch.cuda.current_stream().wait_stream(self._side)
         ev = self._tick("apply_dense")
         akw = dict(lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
                    beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=inv_sens)
         flat = self.dense_flat.detach()
-        if self.dense16 is not None and self._fold_splitk and fused and self._dw_parts:
-            parts = [(self.dense_grad[2 * i].storage_offset(), p_) for i, p_ in sorted(self._dw_parts.items())]
-            self.k.dense_adam_splitk_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, parts,
-                                      shadow_bf16=self.dense16_flat, **akw)
-        elif self.dense16 is not None:      # also refreshes the bf16 operand shadow
-            self.k.dense_adam_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, shadow_bf16=self.dense16_flat, **akw)
+        if fused:
+            # one GPU: the weight gradients stay fp32 batch slabs and are added up inside the Adam kernel (nobody else
+            # needs the sums); shards: they were summed for the all-reduce above.  Either way the kernel also refreshes
+            # the 16-bit operand shadow.
+            slabs = [] if self._sharded else [(self.dense_grad[2 * i].storage_offset(), t) for i, t in sorted(self._dw.items())]
+            self.k.dense_adam_slabs_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, slabs,
+                                     shadow16=self.dense16_flat, **akw)
         else:
             self.k.dense_adam_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, **akw)
         self.k.dense_ftrl_(self.wide_b, self.wide_b_accum, self.wide_b_linear, gb, lr=cfg.ftrl_lr, l1=cfg.ftrl_l1,

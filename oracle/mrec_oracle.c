@@ -19,6 +19,7 @@
  * HIP build, which is compiled with the same flag.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -313,6 +314,131 @@ MREC_O_API void mrec_o_sparse_ftrl_f32(float* var, float* accum, float* linear, 
                       l1, l2, lr_power);
     }
     free(uniq); free(sum);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * *_mt entries: the same restatements run on T host threads (bench.py's all-core cpu_baseline leg).
+ * Results are bit-identical to the single-thread entries: rows of the output (gather, wide sum) or
+ * unique ids (sparse applies) are partitioned over the threads, and every unique id's contributions
+ * are still added in ascending position order (a stable counting sort of the positions by group).
+ * The Unique itself stays sequential (first-occurrence numbering is inherently ordered).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int kind; int64_t lo, hi;
+    /* gather / wide */
+    const float* table; int64_t V, ld; int32_t D; const int64_t* ids; const float* rs; float* out; int32_t F; float bias;
+    /* apply */
+    float *p, *m, *v; const int64_t* uniq; const int32_t *order, *start; const float* g; int64_t ldg;
+    float gscale, lr, b1, b2, eps, lr_t, l1, l2, lr_power; int nesterov;
+} mt_job_t;
+
+static void* mt_worker(void* arg) {
+    mt_job_t* j = (mt_job_t*)arg;
+    if (j->kind == 0) {
+        mrec_o_gather_rows_f32(j->table, j->V, j->ld, j->D, j->ids + j->lo, j->hi - j->lo, j->rs ? j->rs + j->lo : NULL,
+                               j->out + j->lo * j->D);
+    } else if (j->kind == 1) {
+        mrec_o_wide_sum_f32(j->table, j->V, j->ids + j->lo * j->F, j->rs + j->lo * j->F, j->hi - j->lo, j->F, j->bias,
+                            j->out + j->lo);
+    } else {
+        const int32_t D = j->D;
+        float* sum = (float*)malloc(sizeof(float) * (size_t)D);
+        float omb1 = 1.0f - j->b1, omb2 = 1.0f - j->b2;
+        for (int64_t u = j->lo; u < j->hi; ++u) {
+            for (int32_t e = j->start[u]; e < j->start[u + 1]; ++e) {          /* ascending position order */
+                const int64_t i = j->order[e];
+                const float* gi = j->g + i * j->ldg;
+                const float s = j->rs ? j->rs[i] : 1.0f;
+                for (int32_t c = 0; c < D; ++c) {
+                    float x = j->rs ? gi[c] * s : gi[c];
+                    if (e == j->start[u]) sum[c] = x * j->gscale; else sum[c] = sum[c] + x * j->gscale;
+                }
+            }
+            const int64_t r = j->uniq[u];
+            if (r < 0 || r >= j->V) continue;
+            if (j->kind == 2) {
+                float *pp = j->p + r * j->ld, *mm = j->m + r * j->ld, *vv = j->v + r * j->ld;
+                for (int32_t c = 0; c < D; ++c) {
+                    float gc = sum[c];
+                    float mn = j->b1 * mm[c] + omb1 * gc;
+                    float vn = j->b2 * vv[c] + omb2 * (gc * gc);
+                    float num = j->nesterov ? (j->b1 * mn + omb1 * gc) : mn;
+                    pp[c] = pp[c] - (j->lr_t * num) / (sqrtf(vn) + j->eps);
+                    mm[c] = mn; vv[c] = vn;
+                }
+            } else {
+                for (int32_t c = 0; c < D; ++c)
+                    ftrl_elem(j->p + r * j->ld + c, j->m + r * j->ld + c, j->v + r * j->ld + c, sum[c], j->lr, j->l1, j->l2,
+                              j->lr_power);
+            }
+        }
+        free(sum);
+    }
+    return NULL;
+}
+
+static void mt_run(mt_job_t* proto, int64_t n, int T) {
+    if (T < 1) T = 1;
+    if (T > 256) T = 256;
+    pthread_t th[256]; mt_job_t jobs[256];
+    for (int t = 0; t < T; ++t) {
+        jobs[t] = *proto;
+        jobs[t].lo = n * t / T; jobs[t].hi = n * (t + 1) / T;
+        pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+    }
+    for (int t = 0; t < T; ++t) pthread_join(th[t], NULL);
+}
+
+MREC_O_API void mrec_o_gather_rows_f32_mt(const float* table, int64_t V, int64_t ld, int32_t D, const int64_t* ids,
+                                          int64_t n, const float* row_scale, float* out, int threads) {
+    mt_job_t j; memset(&j, 0, sizeof j);
+    j.kind = 0; j.table = table; j.V = V; j.ld = ld; j.D = D; j.ids = ids; j.rs = row_scale; j.out = out;
+    mt_run(&j, n, threads);
+}
+
+MREC_O_API void mrec_o_wide_sum_f32_mt(const float* w, int64_t V, const int64_t* ids, const float* wts, int64_t B,
+                                       int32_t F, float bias, float* out, int threads) {
+    mt_job_t j; memset(&j, 0, sizeof j);
+    j.kind = 1; j.table = w; j.V = V; j.ids = ids; j.rs = wts; j.F = F; j.bias = bias; j.out = out;
+    mt_run(&j, B, threads);
+}
+
+static void mt_apply(int kind, float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D, const int64_t* ids,
+                     int64_t n, const float* g, int64_t ldg, const float* row_scale, mt_job_t* hp, int threads) {
+    int64_t* uniq = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n ? n : 1));
+    int32_t* inv = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n ? n : 1));
+    int64_t U = unique_i64_impl(ids, n, uniq, inv);
+    int32_t* start = (int32_t*)calloc((size_t)(U + 2), sizeof(int32_t));
+    int32_t* order = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n ? n : 1));
+    for (int64_t i = 0; i < n; ++i) start[inv[i] + 1]++;
+    for (int64_t u = 0; u < U; ++u) start[u + 1] += start[u];
+    int32_t* fill = (int32_t*)malloc(sizeof(int32_t) * (size_t)(U ? U : 1));
+    for (int64_t u = 0; u < U; ++u) fill[u] = start[u];
+    for (int64_t i = 0; i < n; ++i) order[fill[inv[i]]++] = (int32_t)i;       /* stable: ascending i per group */
+    mt_job_t j = *hp;
+    j.kind = kind; j.p = p; j.m = m; j.v = v; j.V = V; j.ld = ld; j.D = D; j.uniq = uniq; j.order = order; j.start = start;
+    j.g = g; j.ldg = ldg; j.rs = row_scale;
+    mt_run(&j, U, threads);
+    free(uniq); free(inv); free(start); free(order); free(fill);
+}
+
+MREC_O_API void mrec_o_sparse_lazy_adam_f32_mt(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D,
+                                               const int64_t* ids, int64_t n, const float* g, int64_t ldg,
+                                               const float* row_scale, float lr, float b1, float b2, float eps,
+                                               float b1_pow, float b2_pow, float grad_scale, int nesterov, int threads) {
+    mt_job_t h; memset(&h, 0, sizeof h);
+    h.gscale = grad_scale; h.b1 = b1; h.b2 = b2; h.eps = eps; h.nesterov = nesterov;
+    h.lr_t = lr * sqrtf(1.0f - b2_pow) / (1.0f - b1_pow);
+    mt_apply(2, p, m, v, V, ld, D, ids, n, g, ldg, row_scale, &h, threads);
+}
+
+MREC_O_API void mrec_o_sparse_ftrl_f32_mt(float* var, float* accum, float* linear, int64_t V, int64_t ld, int32_t D,
+                                          const int64_t* ids, int64_t n, const float* g, int64_t ldg,
+                                          const float* row_scale, float lr, float l1, float l2, float lr_power,
+                                          float grad_scale, int threads) {
+    mt_job_t h; memset(&h, 0, sizeof h);
+    h.gscale = grad_scale; h.lr = lr; h.l1 = l1; h.l2 = l2; h.lr_power = lr_power;
+    mt_apply(3, var, accum, linear, V, ld, D, ids, n, g, ldg, row_scale, &h, threads);
 }
 
 /* Dense nn.Adam / nn.FTRL over a whole tensor [EXT A.4/A.5]; wide_and_deep.py:435-445,

@@ -83,7 +83,7 @@ def unique(x):
     return uniq[:U].copy(), inv
 
 
-def gather_rows(table, ids, row_scale=None):
+def gather_rows(table, ids, row_scale=None, threads=0):
     table = np.asarray(table)
     assert table.dtype == np.float32 and table.ndim == 2 and table.strides[1] == 4
     V, D = table.shape
@@ -91,19 +91,25 @@ def gather_rows(table, ids, row_scale=None):
     ids_f = _i64(ids).ravel()
     out = np.empty((ids_f.size, D), np.float32)
     rs = _f32(row_scale).ravel() if row_scale is not None else None
-    lib().mrec_o_gather_rows_f32(_p(table), C.c_int64(V), C.c_int64(ld), C.c_int32(D), _p(ids_f),
-                                 C.c_int64(ids_f.size), _p(rs), _p(out))
+    args = (_p(table), C.c_int64(V), C.c_int64(ld), C.c_int32(D), _p(ids_f), C.c_int64(ids_f.size), _p(rs), _p(out))
+    if threads > 0:
+        lib().mrec_o_gather_rows_f32_mt(*args, C.c_int(threads))
+    else:
+        lib().mrec_o_gather_rows_f32(*args)
     return out.reshape(tuple(np.shape(ids)) + (D,))
 
 
-def wide_sum(w, ids, wts, bias):
+def wide_sum(w, ids, wts, bias, threads=0):
     w = _f32(w).ravel()
     ids2 = _i64(ids)
     B, F = ids2.shape
     wts = _f32(wts)
     out = np.empty(B, np.float32)
-    lib().mrec_o_wide_sum_f32(_p(w), C.c_int64(w.size), _p(ids2), _p(wts), C.c_int64(B), C.c_int32(F),
-                              C.c_float(bias), _p(out))
+    args = (_p(w), C.c_int64(w.size), _p(ids2), _p(wts), C.c_int64(B), C.c_int32(F), C.c_float(bias), _p(out))
+    if threads > 0:
+        lib().mrec_o_wide_sum_f32_mt(*args, C.c_int(threads))
+    else:
+        lib().mrec_o_wide_sum_f32(*args)
     return out
 
 
@@ -123,27 +129,34 @@ def _tab(t):
 
 
 def sparse_lazy_adam(p, m, v, ids, g, row_scale=None, lr=3.5e-4, b1=0.9, b2=0.999, eps=1e-8,
-                     b1_pow=0.9, b2_pow=0.999, grad_scale=1.0, nesterov=False):
+                     b1_pow=0.9, b2_pow=0.999, grad_scale=1.0, nesterov=False, threads=0):
+    """threads > 0 runs the *_mt entry (same bits, unique ids partitioned over host threads)."""
     V, D, ld = _tab(p)
     ids_f = _i64(ids).ravel()
     g = _f32(g).reshape(ids_f.size, D)
     rs = _f32(row_scale).ravel() if row_scale is not None else None
-    lib().mrec_o_sparse_lazy_adam_f32(
-        _p(p), _p(m), _p(v), C.c_int64(V), C.c_int64(ld), C.c_int32(D), _p(ids_f), C.c_int64(ids_f.size),
-        _p(g), C.c_int64(D), _p(rs), C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps),
-        C.c_float(b1_pow), C.c_float(b2_pow), C.c_float(grad_scale), C.c_int(int(nesterov)))
+    args = (_p(p), _p(m), _p(v), C.c_int64(V), C.c_int64(ld), C.c_int32(D), _p(ids_f), C.c_int64(ids_f.size),
+            _p(g), C.c_int64(D), _p(rs), C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps),
+            C.c_float(b1_pow), C.c_float(b2_pow), C.c_float(grad_scale), C.c_int(int(nesterov)))
+    if threads > 0:
+        lib().mrec_o_sparse_lazy_adam_f32_mt(*args, C.c_int(threads))
+    else:
+        lib().mrec_o_sparse_lazy_adam_f32(*args)
 
 
 def sparse_ftrl(var, accum, linear, ids, g, row_scale=None, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5,
-                grad_scale=1.0):
+                grad_scale=1.0, threads=0):
     V, D, ld = _tab(var)
     ids_f = _i64(ids).ravel()
     g = _f32(g).reshape(ids_f.size, D)
     rs = _f32(row_scale).ravel() if row_scale is not None else None
-    lib().mrec_o_sparse_ftrl_f32(
-        _p(var), _p(accum), _p(linear), C.c_int64(V), C.c_int64(ld), C.c_int32(D), _p(ids_f),
-        C.c_int64(ids_f.size), _p(g), C.c_int64(D), _p(rs), C.c_float(lr), C.c_float(l1), C.c_float(l2),
-        C.c_float(lr_power), C.c_float(grad_scale))
+    args = (_p(var), _p(accum), _p(linear), C.c_int64(V), C.c_int64(ld), C.c_int32(D), _p(ids_f),
+            C.c_int64(ids_f.size), _p(g), C.c_int64(D), _p(rs), C.c_float(lr), C.c_float(l1), C.c_float(l2),
+            C.c_float(lr_power), C.c_float(grad_scale))
+    if threads > 0:
+        lib().mrec_o_sparse_ftrl_f32_mt(*args, C.c_int(threads))
+    else:
+        lib().mrec_o_sparse_ftrl_f32(*args)
 
 
 def dense_adam(p, m, v, g, lr=3.5e-4, b1=0.9, b2=0.999, eps=1e-8, b1_pow=0.9, b2_pow=0.999,
@@ -271,3 +284,45 @@ def fm_forward(vx):
 
 def fm_backward(vx, colsum, dout):
     return np.asarray(dout, np.float64)[:, None, None] * (np.asarray(colsum, np.float64)[:, None, :] - np.asarray(vx, np.float64))
+
+
+# ---- DenseLayer in mixed precision (numpy restatements) ---------------------------------------------------
+# Reference: DenseLayer.construct, models/wide_deep/src/wide_and_deep.py:113-133 -- with use_mixed_precision the input
+# and the weight are cast to float16, MatMul runs on them, BiasAdd and ReLU follow.  Restated here with the rounding
+# points of the MI355X path: 16-bit operands (float16 as in the reference, or bfloat16), products summed exactly
+# (float64 here; fp32 on the matrix cores), fp32 bias added, ONE rounding of the result to 16 bits.
+def round16(x, dtype):
+    """Round float32 values to dtype ('bf16' or 'f16'), round-to-nearest-even; returns float32 holding those values."""
+    x = np.ascontiguousarray(x, np.float32)
+    if dtype == "f16":
+        return x.astype(np.float16).astype(np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    out = (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32).copy()
+    nan = np.isnan(x)
+    out[nan] = np.float32("nan")
+    return out.reshape(x.shape)
+
+
+def dense_layer(x16, w16, bias, relu, dtype):
+    """y = round16(act(x . w + b)); x16 [M, K], w16 [K, N] hold 16-bit values (as float32), bias float32 [N]."""
+    acc = np.asarray(x16, np.float64) @ np.asarray(w16, np.float64)
+    if bias is not None:
+        acc = acc + np.asarray(bias, np.float64)[None, :]
+    if relu:
+        acc = np.maximum(acc, 0.0)
+    return round16(acc.astype(np.float32), dtype)
+
+
+def dense_bwd_input(dy16, w16, h16, dtype):
+    """MatMul bprop wrt the input, then the ReLU bprop of the layer below and its BiasAdd bprop:
+    dx = round16(dy . w^T) where h > 0 else 0;  db = sum over the batch of the rounded dx (float64)."""
+    g = round16((np.asarray(dy16, np.float64) @ np.asarray(w16, np.float64).T).astype(np.float32), dtype)
+    if h16 is not None:
+        g = np.where(np.asarray(h16) > 0, g, np.float32(0))
+    return g, g.astype(np.float64).sum(axis=0)
+
+
+def dense_bwd_weight(x16, dy16):
+    """MatMul bprop wrt the weight: dw = x^T . dy, exact products summed in float64 (the GPU sums in fp32)."""
+    return np.asarray(x16, np.float64).T @ np.asarray(dy16, np.float64)

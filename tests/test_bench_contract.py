@@ -26,3 +26,23 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+
+
+def test_bench_gpus_n_self_launches_ranks_before_any_gpu_call():
+    """`python bench.py --gpus 2` typed as is (no launcher environment) must start two ranks itself, through
+    torch.distributed.run as a child process, and propagate their failure -- on this GPU-less machine each rank ends
+    with "needs an MI355X", which proves both were started and that the parent reports a non-zero code."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    try:
+        import torch
+        if torch.cuda.is_available():
+            import pytest
+            pytest.skip("GPU present: covered by the driver's multi-GPU bench")
+    except ImportError:
+        pass
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--repeats", "1",
+                        "--vocab", "1000", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert (r.stdout + r.stderr).count("needs an MI355X") >= 2, (r.stdout + r.stderr)[-2000:]

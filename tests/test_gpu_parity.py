@@ -373,6 +373,40 @@ def test_key_index_full_and_reuse(dev):
     assert ki.counters()[1] == 99
 
 
+def test_key_index_long_churn_keeps_empty_slots(dev, oracle):
+    """Insert / erase churn with a key space far larger than the slot array (the pattern of the feature-cache
+    tier's evict + prepare and of MapParameter.evict): without tombstone reclamation the empty slots run out
+    after ~20 steps and a probe for a missing key never ends.  300 steps here; row numbering must keep
+    matching the oracle's map, tombstones must stay under a fifth of the slots, rebuilds must have happened."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(21)
+    cap = 900                                   # 2048 slots
+    om = oracle.Map(1, cap, seed=1, sigma=0.01)
+    ki = ops.KeyIndex(cap, dev)
+    resident = np.zeros(0, np.int64)
+    for step in range(300):
+        fresh = rng.integers(0, 2**45, size=660).astype(np.int64)
+        fresh = np.unique(fresh)
+        fresh = fresh[~np.isin(fresh, resident)]
+        room = cap - resident.size
+        if fresh.size > room:                   # evict the oldest residents to make room
+            k = fresh.size - room
+            out, resident = resident[:k], resident[k:]
+            ki.erase(T(out, dev)); om.erase(out)
+        rows, is_new = ki.find_or_insert(T(fresh, dev), insert=True)
+        assert np.array_equal(rows.cpu().numpy(), om.find_or_insert(fresh, True))
+        assert int(is_new.sum()) == fresh.size
+        resident = np.concatenate([resident, fresh])
+        if step % 50 == 49:
+            c = ki.counters_all()
+            assert c[1] == resident.size == om.size()
+            assert 0 <= c[4] * 5 <= 2048 + 5 * 660, c       # tombstones bounded by the rebuild threshold (+ one call)
+            probe = np.concatenate([resident[:50], rng.integers(2**46, 2**47, size=200)]).astype(np.int64)
+            r, _ = ki.find_or_insert(T(probe, dev), insert=False)       # misses must terminate
+            assert np.array_equal(r.cpu().numpy(), om.find_or_insert(probe, False))
+    assert ki.counters_all()[6] >= 10           # the slot array was rebuilt many times
+
+
 @pytest.mark.parametrize("B,D,L", [(1000, 1170, 6), (77, 64, 3), (33, 30, 1), (500, 1500, 8)])
 def test_cross_layers(dev, oracle, B, D, L):
     from mindrec_amd import ops

@@ -203,3 +203,44 @@ def test_golden_step_fixture(oracle):
                             grad_scale=1 / 1024)
     touched = np.unique(z["ids"])
     assert np.array_equal(p[touched], z["p_touched"]) and np.array_equal(m[touched], z["m_touched"])
+
+
+def test_round16_and_dense_layer_known_answers(oracle):
+    """The mixed-precision DenseLayer restatement (wide_and_deep.py:113-133): rounding to bf16 / f16 is round-to-nearest-
+    even, the layer is act(x . w + b) on 16-bit operands with ONE rounding of the result."""
+    r = oracle.round16(np.array([1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8, 1.0 + 2.0 ** -8 + 2.0 ** -20, -2.5], np.float32), "bf16")
+    assert r.tolist() == [1.0, 1.0 + 2.0 ** -6, 1.0 + 2.0 ** -7, -2.5]          # ties to even, above a tie rounds up
+    with np.errstate(over="ignore"):
+        assert oracle.round16(np.array([1.0 + 2.0 ** -11, 65520.0], np.float32), "f16").tolist() == [1.0, float("inf")]
+    x = np.array([[1.0, 2.0, -1.0], [0.5, 0.0, 4.0]], np.float32)
+    w = np.array([[1.0, -1.0], [0.5, 0.25], [2.0, 1.0]], np.float32)
+    b = np.array([0.125, -3.0], np.float32)
+    y = oracle.dense_layer(x, w, b, True, "bf16")
+    assert y.tolist() == [[0.125, 0.0], [8.625, 0.5]]
+    g, db = oracle.dense_bwd_input(np.array([[1.0, 2.0]], np.float32), w, np.array([[1.0, 0.0, 3.0]], np.float32), "f16")
+    assert g.tolist() == [[-1.0, 0.0, 4.0]] and db.tolist() == [-1.0, 0.0, 4.0]
+    assert oracle.dense_bwd_weight(x, np.array([[1.0], [2.0]], np.float32)).tolist() == [[2.0], [2.0], [7.0]]
+
+
+def test_mt_entries_are_bit_identical_to_single_thread(oracle):
+    """The *_mt oracle entries (bench.py's all-core CPU baseline) partition rows / unique ids over threads and keep
+    every per-id sum in ascending position order: same bits as the scalar entries."""
+    rng = np.random.default_rng(5)
+    V, D, B, F = 5000, 16, 300, 13
+    ids = np.minimum(rng.zipf(1.2, size=(B, F)), V - 1).astype(np.int64)
+    ids[0, 0] = V + 5                                          # out of range: skipped
+    wts = rng.random((B, F)).astype(np.float32)
+    p0 = (rng.standard_normal((V, D)) * 0.01).astype(np.float32)
+    g = rng.standard_normal((B * F, D)).astype(np.float32)
+    assert np.array_equal(oracle.gather_rows(p0, ids, wts), oracle.gather_rows(p0, ids, wts, threads=5))
+    w0 = (rng.standard_normal((V, 1)) * 0.01).astype(np.float32)
+    assert np.array_equal(oracle.wide_sum(w0, ids, wts, 0.25), oracle.wide_sum(w0, ids, wts, 0.25, threads=3))
+    out = []
+    for th in (0, 4):
+        p, m, v = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+        oracle.sparse_lazy_adam(p, m, v, ids, g, wts, grad_scale=1 / 1024, threads=th)
+        w, a, l = w0.copy(), np.ones_like(w0), np.zeros_like(w0)
+        oracle.sparse_ftrl(w, a, l, ids, g[:, :1].copy(), wts, grad_scale=1 / 1024, threads=th)
+        out.append((p, m, v, w, a, l))
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)

@@ -1,4 +1,5 @@
-"""Two ranks sharing the one GPU of the test box (gloo group, collectives staged through the host):
+"""Two / four ranks sharing the one GPU of the test box (gloo group, collectives staged through the host by the test
+harness, tests/_staged_comm.py):
 the row-sharded step with the real HIP kernels must reproduce the single-process GPU step on the
 concatenated batch.  (RCCL itself needs one GPU per rank; the driver's multi-GPU bench covers it.)"""
 import os
@@ -32,14 +33,16 @@ def _worker(rank, world, port, steps, out_dir, mlp_dtype="fp32", early_route=Fal
     MLP_DTYPE = mlp_dtype
     EARLY_ROUTE = early_route
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from _staged_comm import StagedGlooComm
     from mindrec_amd.wide_deep import WideDeepEngine, synthetic_batch
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     cfg = _cfg(128)
-    eng = WideDeepEngine(cfg, dev, rank=rank, world=world)
+    eng = WideDeepEngine(cfg, dev, rank=rank, world=world, comm=StagedGlooComm())
     losses = []
     for s in range(steps):
         ids, wts, label = synthetic_batch(cfg, dev, "zipf", seed=50 + s, rank=rank)
@@ -55,7 +58,7 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mlp_dtype,world,early_route", [("fp32", 2, False), ("bf16", 2, False), ("bf16", 2, True), ("bf16", 4, True)])
+@pytest.mark.parametrize("mlp_dtype,world,early_route", [("fp32", 2, False), ("bf16", 2, False), ("bf16", 2, True), ("bf16", 4, True), ("fp16", 2, True), ("bf16", 5, True)])
 def test_ranks_on_one_gpu_match_single_process(dev, tmp_path, mlp_dtype, world, early_route):
     """fp32: fp32 rows on the wire.  bf16: the production path -- weights travel with the ids, bf16 rows and
     bf16 row-gradients on the wire, hand-written MLP step.  early_route: the request exchange runs on the side stream

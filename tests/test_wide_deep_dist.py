@@ -1,4 +1,4 @@
-"""world_size-2 and -4 gloo tests (CPU) of the row-sharded Wide&Deep step: two ranks, each with its own
+"""world_size-2, -4 and -8 gloo tests (CPU) of the row-sharded Wide&Deep step: two ranks, each with its own
 batch and half of both tables, must reproduce the single-process step on the concatenated batch.
 The kernels are stood in by the oracle (tests/_oracle_ops.py); what is under test is the engine's
 host logic: routing, the all-to-all protocol, row-gradient exchange and gradient averaging."""
@@ -52,9 +52,10 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_step_matches_single_process(tmp_path, world):
-    """world = 4 with V = 997 also covers shards of unequal length (250, 249, 249, 249 rows)."""
+    """world = 4 / 8 with V = 997 also cover shards of unequal length (250, 249, ... / 125, 125, ..., 124 rows);
+    world = 8 is the driver's scaling-bench geometry (BASELINE configs[3])."""
     import _oracle_ops
     from mindrec_amd.wide_deep import WideDeepEngine
     steps = 3
