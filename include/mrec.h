@@ -208,7 +208,7 @@ int mrec_dense_adam_splitk_f32(float* p, float* m, float* v, const float* g, uin
                                int32_t nseg, const void* const* parts, const int64_t* starts, const int64_t* lens,
                                const int32_t* splits, float lr, float b1, float b2, float eps, float b1_pow,
                                float b2_pow, float grad_scale, int nesterov, void* stream);
-/* Dense Adam over a flat buffer whose gradient is, for up to 8 segments, the sum of S fp32 slabs
+/* Dense Adam over a flat buffer whose gradient is, for up to 16 segments, the sum of S fp32 slabs
  * slabs[q][s*lens[q] + e], s < splits[q] (what mrec_dense_bwd_weight_* leaves behind), added in slab order; every other
  * element reads g.  shadow_kind: 0 none, 1 bf16, 2 fp16 -- the 16-bit operand copy of the updated parameters
  * (Cast(weight, float16) of DenseLayer.construct, wide_and_deep.py:123-124).  slabs / starts / lens / splits are HOST arrays. */
@@ -234,7 +234,9 @@ int mrec_dense_fwd_f16(const uint16_t* x, int64_t ldx, const uint16_t* w, const 
 /* bprop with respect to the layer's input, fused with the ReLU and BiasAdd bprops of the layer BELOW:
  *   dx[m, k] = h[m, k] > 0 ? sum_n dy[m, n] * w[k, n] : 0      (h nullable: no mask -- the first layer's input)
  *   db[k]    = sum_m dx[m, k]                                  (db nullable; sums of the rounded dx, fp32, fixed order)
- * N % 8 == 0, K % 4 == 0.  ws: mrec_dense_bwd_input_workspace_bytes(M, K) bytes when db != NULL. */
+ * N % 8 == 0, K % 4 == 0.  ws: mrec_dense_bwd_input_workspace_bytes(M, K) bytes when db != NULL.  With db == NULL and
+ * ws != NULL the per-tile-row column sums are left in ws as ceil(M/256) fp32 slabs of K (slab t = rows [256 t, 256 t + 256));
+ * mrec_dense_adam_slabs_f32 / mrec_dense_sum_slabs_f32 add them up in slab order. */
 int mrec_dense_bwd_input_workspace_bytes(int64_t M, int32_t K, size_t* out);
 int mrec_dense_bwd_input_bf16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M, int32_t K,
                               int32_t N, uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, void* stream);
@@ -250,6 +252,16 @@ int mrec_dense_bwd_weight_bf16(const uint16_t* x, int64_t ldx, const uint16_t* d
 int mrec_dense_bwd_weight_f16(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t lddy, int64_t M, int32_t K,
                               int32_t N, int32_t S, float* dw_slabs, void* stream);
 
+/* Both bprops of one DenseLayer in ONE launch (the two are independent and, for the narrow layers, neither fills the chip
+ * alone): dx / bias-gradient slabs exactly as mrec_dense_bwd_input_* with db == NULL (db_slabs nullable: no bias gradient),
+ * dw_slabs exactly as mrec_dense_bwd_weight_*.  x [M, K] is the layer's input, h (nullable) the same tensor when the layer
+ * below has a ReLU to back-propagate through.  M > 0. */
+int mrec_dense_bwd_bf16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x, int64_t ldx,
+                        int64_t M, int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_slabs, size_t db_slabs_bytes,
+                        int32_t S, float* dw_slabs, void* stream);
+int mrec_dense_bwd_f16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x, int64_t ldx,
+                       int64_t M, int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_slabs, size_t db_slabs_bytes,
+                       int32_t S, float* dw_slabs, void* stream);
 /* out[e] = sum over s < S of slabs[s*len + e], in slab order: the weight gradient as one tensor, for consumers other than
  * mrec_dense_adam_slabs_f32 (the data-parallel all-reduce).  len % 4 == 0, 16-byte aligned. */
 int mrec_dense_sum_slabs_f32(const float* slabs, int32_t S, int64_t len, float* out, void* stream);

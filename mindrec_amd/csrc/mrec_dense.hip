@@ -28,13 +28,29 @@ int cu_count() {
     return g_cu_count;
 }
 
-// db[k] = sum over tile rows of the per-tile column sums, in tile order
+// db[k] = sum over tile rows of the per-tile column sums.  Thread (c, q) of a block adds the tile rows t = q, q + 4, ...
+// of column c with all its loads in flight (a serial loop over the tile rows is one dependent L2 round trip per row:
+// 17 us for 64 rows); the four partial sums are then added in q order: a fixed order, reproducible run to run.
 __global__ __launch_bounds__(256) void k_colsum_tiles(const float* __restrict__ ws, int nT, int K, float* __restrict__ db) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + c;
     float s = 0.f;
-    for (int t = 0; t < nT; ++t) s += ws[(int64_t)t * K + k];
-    db[k] = s;
+    if (k < K) {
+        for (int t0 = q; t0 < nT; t0 += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + 4 * u;
+                v[u] = t < nT ? ws[(int64_t)t * K + k] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+    }
+    part[q][c] = s;
+    __syncthreads();
+    if (q == 0 && k < K) db[k] = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
 }
 
 // out[e] = sum_s slabs[s * len + e] in slab order (float4 lanes)
@@ -69,21 +85,17 @@ int fwd_impl(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bia
     return MREC_OK;
 }
 
-template <bool F16>
-int bwd_input_impl(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M, int32_t K, int32_t N,
-                   uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, void* stream) {
-    if (M < 0 || K <= 0 || N <= 0 || lddy < N || lddx < K) return MREC_EINVAL;
-    if (M == 0) {
-        if (db) MREC_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)K * 4, (hipStream_t)stream));
-        return MREC_OK;
-    }
+// argument checks + Args of the two bprops (shared by the separate and the fused entry points)
+int bwd_input_args(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M, int32_t K, int32_t N,
+                   uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, Args* out) {
+    if (M <= 0 || K <= 0 || N <= 0 || lddy < N || lddx < K) return MREC_EINVAL;
     if (!dy || !w || !dx) return MREC_EINVAL;
     if (N % 8 || K % 4 || lddy % 8 || lddx % 4 || !al16(dy) || !al16(w) || (((uintptr_t)dx) & 7) || (h && (((uintptr_t)h) & 7)))
         return MREC_EUNSUPPORTED;
     if (M * lddy * 2 >= (int64_t(1) << 31) || (int64_t)K * N * 2 >= (int64_t(1) << 31) || M > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
     const int nTp = (int)mrec_cdiv(M, 256);
     float* part = nullptr;
-    if (db) {
+    if (db || ws) {             // ws without db: leave the per-tile-row column sums there for the caller (the dense Adam adds them)
         if (!ws || ws_bytes < (size_t)nTp * K * 4) return MREC_EWORKSPACE;
         part = (float*)ws;
     }
@@ -93,34 +105,14 @@ int bwd_input_impl(const uint16_t* dy, int64_t lddy, const uint16_t* w, const ui
     a.Pext = (int)M; a.Qext = K; a.K = N;
     a.nTp = nTp; a.nTq = (int)mrec_cdiv(K, 256);
     a.kt_per_slab = (N + 63) / 64;
-    hipStream_t st = (hipStream_t)stream;
-    mgemm::k_gemm256<false, false, mgemm::EPI_DGRAD, F16><<<a.nTp * a.nTq, mgemm::kThreads, 0, st>>>(a);
-    if (db) k_colsum_tiles<<<(unsigned)mrec_cdiv(K, 256), 256, 0, st>>>(part, nTp, K, db);
-    MREC_LAUNCH_CHECK();
+    *out = a;
     return MREC_OK;
 }
 
-int weight_slabs(int64_t M, int32_t K, int32_t N) {
-    const int64_t tiles = mrec_cdiv(K, 256) * mrec_cdiv(N, 256);
-    const int64_t Ttot = mrec_cdiv(M, 64);
-    int64_t S = cu_count() / tiles;
-    if (S > 16) S = 16;             // each slab is K*N fp32 written once and read once by the optimizer
-    if (S > Ttot) S = Ttot;
-    if (S < 1) S = 1;
-    return (int)S;
-}
-
-template <bool F16>
-int bwd_weight_impl(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t lddy, int64_t M, int32_t K, int32_t N, int32_t S,
-                    float* dw, void* stream) {
-    if (M < 0 || K <= 0 || N <= 0 || S <= 0 || ldx < K || lddy < N) return MREC_EINVAL;
-    if (!dw) return MREC_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    if (M == 0) {
-        MREC_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)S * K * N * 4, st));
-        return MREC_OK;
-    }
-    if (!x || !dy) return MREC_EINVAL;
+int bwd_weight_args(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t lddy, int64_t M, int32_t K, int32_t N, int32_t S,
+                    float* dw, Args* out) {
+    if (M <= 0 || K <= 0 || N <= 0 || S <= 0 || ldx < K || lddy < N) return MREC_EINVAL;
+    if (!dw || !x || !dy) return MREC_EINVAL;
     if (K % 8 || N % 8 || ldx % 8 || lddy % 8 || !al16(x) || !al16(dy) || !al16(dw)) return MREC_EUNSUPPORTED;
     if (M * ldx * 2 >= (int64_t(1) << 31) || M * lddy * 2 >= (int64_t(1) << 31)) return MREC_EUNSUPPORTED;
     Args a{};
@@ -131,7 +123,69 @@ int bwd_weight_impl(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t 
     const int Ttot = (int)mrec_cdiv(M, 64);
     a.kt_per_slab = (Ttot + S - 1) / S;
     a.slab_stride = (int64_t)K * N;
+    *out = a;
+    return MREC_OK;
+}
+
+template <bool F16>
+int bwd_input_impl(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M, int32_t K, int32_t N,
+                   uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, void* stream) {
+    if (M == 0 && K > 0) {
+        if (db) MREC_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)K * 4, (hipStream_t)stream));
+        return MREC_OK;
+    }
+    Args a;
+    const int rc = bwd_input_args(dy, lddy, w, h, M, K, N, dx, lddx, db, ws, ws_bytes, &a);
+    if (rc != MREC_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    mgemm::k_gemm256<false, false, mgemm::EPI_DGRAD, F16><<<a.nTp * a.nTq, mgemm::kThreads, 0, st>>>(a);
+    if (db) k_colsum_tiles<<<(unsigned)mrec_cdiv(K, 64), 256, 0, st>>>(a.colsum_ws, a.nTp, K, db);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+int weight_slabs(int64_t M, int32_t K, int32_t N) {
+    const int64_t tiles = mrec_cdiv(K, 256) * mrec_cdiv(N, 256);
+    const int64_t Ttot = mrec_cdiv(M, 64);
+    int64_t S = cu_count() / tiles;
+    // each slab is K*N fp32 written once and read once by the optimizer: beyond 16 slabs keep them within 16 MB in all
+    // (the narrow layers then get short workgroups: 32 / 64 slabs of 0.5 / 0.13 MB for 512x256 / 256x128)
+    int64_t cap = ((int64_t)16 << 20) / ((int64_t)K * N * 4);
+    if (cap < 16) cap = 16;
+    if (cap > 64) cap = 64;
+    if (S > cap) S = cap;
+    if (S > Ttot) S = Ttot;
+    if (S < 1) S = 1;
+    return (int)S;
+}
+
+template <bool F16>
+int bwd_weight_impl(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t lddy, int64_t M, int32_t K, int32_t N, int32_t S,
+                    float* dw, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 0 && K > 0 && N > 0 && S > 0 && dw) {
+        MREC_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)S * K * N * 4, st));
+        return MREC_OK;
+    }
+    Args a;
+    const int rc = bwd_weight_args(x, ldx, dy, lddy, M, K, N, S, dw, &a);
+    if (rc != MREC_OK) return rc;
     mgemm::k_gemm256<true, true, mgemm::EPI_F32, F16><<<a.nTp * a.nTq * S, mgemm::kThreads, 0, st>>>(a);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+template <bool F16>
+int bwd_impl(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x, int64_t ldx, int64_t M,
+             int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_ws, size_t db_ws_bytes, int32_t S, float* dw, void* stream) {
+    Args ad, aw;
+    int rc = bwd_input_args(dy, lddy, w, h, M, K, N, dx, lddx, nullptr, db_ws, db_ws_bytes, &ad);
+    if (rc != MREC_OK) return rc;
+    rc = bwd_weight_args(x, ldx, dy, lddy, M, K, N, S, dw, &aw);
+    if (rc != MREC_OK) return rc;
+    const int nd = ad.nTp * ad.nTq, nw = aw.nTp * aw.nTq * S;
+    const int wfirst = aw.kt_per_slab >= ad.kt_per_slab;       // longer workgroups first
+    mgemm::k_gemm256_bwd<F16><<<nd + nw, mgemm::kThreads, 0, (hipStream_t)stream>>>(ad, aw, wfirst ? nw : nd, wfirst);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -187,4 +241,16 @@ MREC_API int mrec_dense_sum_slabs_f32(const float* slabs, int32_t S, int64_t len
     k_sum_slabs<<<g, 256, 0, (hipStream_t)stream>>>((const float4*)slabs, S, len4, (float4*)out);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
+}
+
+/* both bprops of one layer in one launch (see include/mrec.h) */
+MREC_API int mrec_dense_bwd_bf16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x,
+                                 int64_t ldx, int64_t M, int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_slabs,
+                                 size_t db_slabs_bytes, int32_t S, float* dw_slabs, void* stream) {
+    return bwd_impl<false>(dy, lddy, w, h, x, ldx, M, K, N, dx, lddx, db_slabs, db_slabs_bytes, S, dw_slabs, stream);
+}
+MREC_API int mrec_dense_bwd_f16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x,
+                                int64_t ldx, int64_t M, int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_slabs,
+                                size_t db_slabs_bytes, int32_t S, float* dw_slabs, void* stream) {
+    return bwd_impl<true>(dy, lddy, w, h, x, ldx, M, K, N, dx, lddx, db_slabs, db_slabs_bytes, S, dw_slabs, stream);
 }

@@ -341,9 +341,9 @@ __global__ __launch_bounds__(256) void k_dense_adam4_splitk(float4* __restrict__
 // The same, for the hand-written MFMA weight-gradient kernel (mrec_dense.hip): its split slabs are fp32 partial
 // sums (never rounded), added here in slab order.  SHK: 0 = no shadow, 1 = bf16 shadow, 2 = fp16 shadow.
 struct SlabSegs {
-    const float4* part[8];
-    int64_t start4[8], len4[8];
-    int S[8];
+    const float4* part[16];
+    int64_t start4[16], len4[16];
+    int S[16];
     int n;
 };
 
@@ -685,7 +685,7 @@ MREC_API int mrec_dense_adam_slabs_f32(float* p, float* m, float* v, const float
                                        int64_t n, int32_t nseg, const float* const* slabs, const int64_t* starts,
                                        const int64_t* lens, const int32_t* splits, float lr, float b1, float b2, float eps,
                                        float b1_pow, float b2_pow, float grad_scale, int nesterov, void* stream) {
-    if (n < 0 || nseg < 0 || nseg > 8 || shadow_kind < 0 || shadow_kind > 2) return MREC_EINVAL;
+    if (n < 0 || nseg < 0 || nseg > 16 || shadow_kind < 0 || shadow_kind > 2) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
     if (!p || !m || !v || !g || (nseg > 0 && (!slabs || !starts || !lens || !splits)) || (shadow_kind && !shadow16))
         return MREC_EINVAL;

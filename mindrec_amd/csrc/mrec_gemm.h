@@ -94,10 +94,10 @@ constexpr uint32_t kOob = 0x80000000u;      // voffset beyond any buffer: the lo
 
 __device__ __forceinline__ constexpr int slot_off(int buf, int type) { return (buf * 4 + type) * 16384; }
 
+// The body: one workgroup computes tile `bid` of the `nblk` tiles of problem `a`; smem = the kernel's 128 KB of LDS.
 template <bool PT, bool QT, int EPI, bool F16, int VAR = 0>
-__global__ __launch_bounds__(kThreads, 2) void k_gemm256(const Args a) {
+__device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const int nblk, MGEMM_LDS char* const smem) {
     typedef Elem<F16> E;
-    __shared__ __attribute__((aligned(1024))) char smem[kLdsBytes];
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 2, wc = w & 3;
@@ -106,7 +106,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm256(const Args a) {
     // operand panel); the remap is bijective for any grid size.
     int tq, tp, z;
     {
-        const int nblk = gridDim.x, bid = blockIdx.x;
         const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
         const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
         tq = swz % a.nTq;
@@ -368,7 +367,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm256(const Args a) {
         }
         if (EPI == EPI_DGRAD && a.colsum_ws != nullptr) {
             // over the 16 lanes that share l >> 4 (fixed xor tree), then over the two wave rows through LDS
-            float* red = (float*)smem;      // [2][256]
+            MGEMM_LDS float* red = (MGEMM_LDS float*)smem;      // [2][256]
             __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
@@ -395,6 +394,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm256(const Args a) {
 #undef MG_SYNC_PRE
 #undef MG_SYNC_POST
 #undef MG_KTILE
+}
+
+template <bool PT, bool QT, int EPI, bool F16, int VAR = 0>
+__global__ __launch_bounds__(kThreads, 2) void k_gemm256(const Args a) {
+    __shared__ __attribute__((aligned(1024))) char smem[kLdsBytes];
+    gemm256_body<PT, QT, EPI, F16, VAR>(a, blockIdx.x, gridDim.x, (MGEMM_LDS char*)smem);
+}
+
+// Both bprops of one DenseLayer in ONE launch: the two problems are independent (both read dy) and, for the narrow
+// layers, neither fills the chip alone.  Workgroups [0, n1) run the problem whose workgroups take longer (more K-tiles
+// each; dispatched first so that the short ones pack behind them), the rest the other one.
+template <bool F16>
+__global__ __launch_bounds__(kThreads, 2) void k_gemm256_bwd(const Args ad, const Args aw, const int n1, const int wfirst) {
+    __shared__ __attribute__((aligned(1024))) char smem[kLdsBytes];
+    const int b = blockIdx.x, n2 = (int)gridDim.x - n1;
+    const bool second = b >= n1;
+    if (second != (wfirst != 0)) gemm256_body<true, true, EPI_F32, F16>(aw, second ? b - n1 : b, second ? n2 : n1, (MGEMM_LDS char*)smem);
+    else gemm256_body<false, false, EPI_DGRAD, F16>(ad, second ? b - n1 : b, second ? n2 : n1, (MGEMM_LDS char*)smem);
 }
 
 }  // namespace mgemm

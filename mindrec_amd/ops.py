@@ -648,9 +648,11 @@ def dense_fwd(x, w, bias, relu=True, out=None):
     return y
 
 
-def dense_bwd_input(dy, w, h=None, db_out=None, out=None):
+def dense_bwd_input(dy, w, h=None, db_out=None, out=None, db_slabs=None):
     """MatMul bprop with respect to the input, fused with the ReLU + BiasAdd bprops of the layer below:
-    dx = (dy . w^T) * (h > 0); db_out[:] = dx.sum(0).  dy [M, N], w [K, N], h [M, K] or None, db_out fp32 [K] or None."""
+    dx = (dy . w^T) * (h > 0); db_out[:] = dx.sum(0).  dy [M, N], w [K, N], h [M, K] or None, db_out fp32 [K] or None.
+    db_slabs (fp32 [ceil(M/256), K], instead of db_out): the bias gradient is left as per-tile-row partial sums for
+    dense_adam_slabs_ / sum_slabs to add up (no finishing kernel on the backward chain)."""
     _need_cuda(dy, w, h, db_out, out)
     M, N, lddy = _mat16(dy, "dy")
     K, N2, ldw = _mat16(w, "w")
@@ -663,7 +665,13 @@ def dense_bwd_input(dy, w, h=None, db_out=None, out=None):
     if db_out is not None and (db_out.dtype != torch.float32 or db_out.numel() != K or not db_out.is_contiguous()):
         raise TypeError("db_out must be contiguous float32 [K]")
     ws, nb = None, 0
-    if db_out is not None:
+    if db_slabs is not None:
+        if db_out is not None:
+            raise ValueError("pass db_out or db_slabs, not both")
+        if db_slabs.dtype != torch.float32 or not db_slabs.is_contiguous() or db_slabs.shape != ((M + 255) // 256, K):
+            raise TypeError("db_slabs must be contiguous float32 [ceil(M/256), K]")
+        ws = db_slabs.view(torch.uint8).view(-1)
+    elif db_out is not None:
         nb = _lib.query_bytes("mrec_dense_bwd_input_workspace_bytes", M, K)
         ws = workspace("dense_bwd_input", nb, dy.device)
     _lib.call("mrec_dense_bwd_input_" + _DT16[dy.dtype], _ptr(dy), lddy, _ptr(w), _ptr(h), M, K, N, _ptr(dx), lddx,
@@ -692,6 +700,32 @@ def dense_bwd_weight(x, dy, out_slabs):
     return out_slabs
 
 
+def dense_bwd(dy, w, x, dw_slabs, mask=True, db_slabs=None, out=None):
+    """Both bprops of one DenseLayer in one launch: returns dx = (dy . w^T) [* (x > 0) when mask], fills dw_slabs
+    [S, K, N] with x^T . dy by batch slab and db_slabs [ceil(M/256), K] (optional) with the bias-gradient partials of
+    the layer below.  dy [M, N], w [K, N], x [M, K] (the layer's input = the activation of the layer below)."""
+    _need_cuda(dy, w, x, dw_slabs, db_slabs, out)
+    M, N, lddy = _mat16(dy, "dy")
+    K, N2, ldw = _mat16(w, "w")
+    M2, K2, ldx = _mat16(x, "x")
+    if N2 != N or ldw != N or K2 != K or M2 != M or w.dtype != dy.dtype or x.dtype != dy.dtype:
+        raise TypeError("dense_bwd: dy [M, N], w [K, N] contiguous, x [M, K], one dtype")
+    dx = out if out is not None else torch.empty((M, K), dtype=dy.dtype, device=dy.device)
+    _, _, lddx = _mat16(dx, "out")
+    if mask and ldx != lddx:
+        raise TypeError("dense_bwd: the mask source x must have the row stride of the output")
+    if dw_slabs.dtype != torch.float32 or dw_slabs.dim() != 3 or dw_slabs.shape[1:] != (K, N) or not dw_slabs.is_contiguous():
+        raise TypeError("dw_slabs must be contiguous float32 [S, K, N]")
+    nb = 0
+    if db_slabs is not None:
+        if db_slabs.dtype != torch.float32 or not db_slabs.is_contiguous() or db_slabs.shape != ((M + 255) // 256, K):
+            raise TypeError("db_slabs must be contiguous float32 [ceil(M/256), K]")
+        nb = db_slabs.numel() * 4
+    _lib.call("mrec_dense_bwd_" + _DT16[dy.dtype], _ptr(dy), lddy, _ptr(w), _ptr(x) if mask else None, _ptr(x), ldx, M, K, N,
+              _ptr(dx), lddx, _ptr(db_slabs), nb, dw_slabs.shape[0], _ptr(dw_slabs), _stream())
+    return dx
+
+
 def sum_slabs(slabs, out):
     """out[...] = slabs.sum(0) in slab order (fp32): the weight gradient of dense_bwd_weight as one tensor."""
     _need_cuda(slabs, out)
@@ -713,8 +747,8 @@ def dense_adam_slabs_(p, m, v, g, slabs, shadow16=None, lr=1e-3, beta1=0.9, beta
     if n % 4:
         raise ValueError("dense_adam_slabs_ needs flat buffers padded to a multiple of 4 elements")
     k = len(slabs)
-    if k > 8:
-        raise ValueError("at most 8 slab segments")
+    if k > 16:
+        raise ValueError("at most 16 slab segments")
     kind = 0
     if shadow16 is not None:
         if shadow16.dtype not in _DT16 or shadow16.numel() != n or not shadow16.is_contiguous():

@@ -264,6 +264,7 @@ class WideDeepEngine:
         self._mlp_graph = None        # dict: captured MLP step + its static input / output tensors
         self._dw = {}                 # hidden layer -> fp32 batch slabs [S, in, out] of its weight gradient (persistent:
                                       # graph replays and eager steps write the same buffers, the dense Adam reads them)
+        self._db = {}                 # hidden layer -> fp32 partial sums of its bias gradient (same idea)
         self._dw_batch = None
         self.deep_apply_timer = None  # optional ops.KernelTimer armed right before the deep table's sparse apply
         self._front_graph = None      # one-GPU: the whole front of the step (lookups .. MLP backward) as one captured graph
@@ -307,10 +308,21 @@ class WideDeepEngine:
         return h.float()
 
     # ---- the mixed-precision dense net, forward + backward by hand on the MFMA kernels -----------------
+    def _db_slabs(self, i, B):
+        """fp32 per-tile-row partial sums [ceil(B/256), out_i] of hidden layer i's bias gradient (written by the input-gradient
+        kernel of layer i + 1, added up inside the dense Adam like the weight-gradient slabs)."""
+        if self._dw_batch != B:
+            self._dw, self._db, self._dw_batch = {}, {}, B
+        t = self._db.get(i)
+        if t is None:
+            t = torch.empty(((B + 255) // 256, self.dims[i + 1]), dtype=torch.float32, device=self.device)
+            self._db[i] = t
+        return t
+
     def _dw_slabs(self, i, B):
         """fp32 batch slabs [S, in, out] the weight-gradient kernel of hidden layer i writes (allocated once per batch size)."""
         if self._dw_batch != B:
-            self._dw, self._dw_batch = {}, B
+            self._dw, self._db, self._dw_batch = {}, {}, B
         t = self._dw.get(i)
         if t is None:
             K, N = self.dims[i], self.dims[i + 1]
@@ -354,26 +366,22 @@ class WideDeepEngine:
         return {"hs": hs, "loss": loss, "g_wide": dlogit.view(-1), "dh": dh}
 
     @torch.no_grad()
-    def _mlp_bwd(self, ctx, tail_stream=None):
-        """Backward through the hidden layers; returns g_emb [B, F*D] (16-bit).  Per layer, from the top: the input
-        gradient (MatMul bprop fused with the ReLU and BiasAdd bprops of the layer below: that layer's bias gradient
-        lands in dense_grad) and the weight gradient (fp32 batch slabs, summed later inside the dense Adam).
-        tail_stream (whole-front capture): the first layer's two kernels are issued on that stream -- the branch the
-        runtime keeps on the launching stream's hardware queue -- so the graph ends where the next eager kernel starts."""
+    def _mlp_bwd(self, ctx):
+        """Backward through the hidden layers; returns g_emb [B, F*D] (16-bit).  One launch per layer, from the top:
+        the input gradient (MatMul bprop fused with the ReLU and BiasAdd bprops of the layer below: that layer's bias
+        gradient is left as per-tile-row partial sums) and the weight gradient (fp32 batch slabs) are workgroups of the
+        same kernel -- both read dh, and for the narrow layers neither fills the chip alone.  Slabs and partial sums are
+        added up inside the dense Adam.  (Weight gradients on a parallel stream / graph branch instead were measured:
+        the graph runtime queues chain kernels behind side-branch work, 0.87 -> 0.95 ms/step.)"""
         n = len(self.dims) - 1
         hs, dh = ctx["hs"], ctx["dh"]
         B = hs[0].shape[0]
-        for i in range(n - 2, 0, -1):
-            self.k.dense_bwd_weight(hs[i], dh, self._dw_slabs(i, B))
-            dh = self.k.dense_bwd_input(dh, self.dense16[2 * i], h=hs[i], db_out=self.dense_grad[2 * (i - 1) + 1])
-        if tail_stream is not None:
-            tail_stream.wait_stream(torch.cuda.current_stream())
-        with (torch.cuda.stream(tail_stream) if tail_stream is not None else contextlib.nullcontext()):
-            g_emb = self.k.dense_bwd_input(dh, self.dense16[0], h=None, db_out=None)
-            self.k.dense_bwd_weight(hs[0], dh, self._dw_slabs(0, B))
-        return g_emb
+        for i in range(n - 2, -1, -1):
+            dh = self.k.dense_bwd(dh, self.dense16[2 * i], hs[i], self._dw_slabs(i, B), mask=i > 0,
+                                  db_slabs=self._db_slabs(i - 1, B) if i > 0 else None)
+        return dh
 
-    def _mlp_step_eager(self, emb, wide, label, after_head=None, tail_stream=None):
+    def _mlp_step_eager(self, emb, wide, label, after_head=None):
         """Forward + backward of the mixed-precision MLP written out by hand (no autograd graph).  `emb` arrives
         in 16 bits straight from the gather kernel, and the gradient of the MLP input is returned in 16 bits
         for the sparse apply to widen on load.  Weights are read from their 16-bit shadows (no per-step cast kernels).
@@ -385,7 +393,7 @@ class WideDeepEngine:
         ctx = self._mlp_head(hs, wide, label)
         if after_head is not None:
             after_head(ctx["g_wide"])
-        g_emb = self._mlp_bwd(ctx, tail_stream)
+        g_emb = self._mlp_bwd(ctx)
         return ctx["loss"], g_emb, ctx["g_wide"]
 
     def _mlp_step(self, emb, wide, label, after_head=None):
@@ -683,10 +691,7 @@ class WideDeepEngine:
                     holder["recv_gw"] = recv_gw
                 early_gw = holder
             if capturing:
-                # the runtime keeps the branch whose nodes were captured first -- the plan's -- on the launching stream's
-                # hardware queue; ending the graph there saves most of the cross-queue hand-over to the eager apply
-                tail = self._side if (route is None and plan_early is not None and self.index is None) else None
-                loss, g_emb, g_wide = self._mlp_step_eager(emb, wide, label, after_head=after_head, tail_stream=tail)
+                loss, g_emb, g_wide = self._mlp_step_eager(emb, wide, label, after_head=after_head)
             else:
                 loss, g_emb, g_wide = self._mlp_step(emb, wide, label, after_head=after_head)
             if route is not None and route[4] is None:
@@ -748,10 +753,12 @@ class WideDeepEngine:
             return None
 
     def _sum_dw_slabs(self):
-        """Weight-gradient slabs -> the flat gradient buffer (needed only where somebody other than the dense Adam
-        reads the summed gradient: the data-parallel all-reduce)."""
+        """Weight- and bias-gradient slabs -> the flat gradient buffer (needed only where somebody other than the dense
+        Adam reads the summed gradient: the data-parallel all-reduce)."""
         for i, t in self._dw.items():
             self.k.sum_slabs(t, self.dense_grad[2 * i])
+        for i, t in self._db.items():
+            self.k.sum_slabs(t, self.dense_grad[2 * i + 1])
 
     # ---- one training step -------------------------------------------------------------------
     def train_step(self, ids, wts, label):
@@ -876,7 +883,8 @@ class WideDeepEngine:
             # one GPU: the weight gradients stay fp32 batch slabs and are added up inside the Adam kernel (nobody else
             # needs the sums); shards: they were summed for the all-reduce above.  Either way the kernel also refreshes
             # the 16-bit operand shadow.
-            slabs = [] if self._sharded else [(self.dense_grad[2 * i].storage_offset(), t) for i, t in sorted(self._dw.items())]
+            slabs = [] if self._sharded else ([(self.dense_grad[2 * i].storage_offset(), t) for i, t in sorted(self._dw.items())] +
+                                              [(self.dense_grad[2 * i + 1].storage_offset(), t) for i, t in sorted(self._db.items())])
             self.k.dense_adam_slabs_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, slabs,
                                      shadow16=self.dense16_flat, **akw)
         else:

@@ -1,0 +1,155 @@
+"""The step bench.py measures, AT THE BENCH SHAPE, against the mixed-precision oracle (tests/_oracle_mixed.py).
+
+Shape: batch 16384, 26 fields, dim 80, MLP 2080-1024-512-256-128-1 in bf16, fused-row fp32 tables, whole-front HIP
+graph ON, weight-gradient slabs summed inside the dense Adam -- BASELINE configs[1] with the vocabulary cut to 2 M rows so
+that the oracle's tables fit the host (the kernels' work per step does not depend on V).
+
+Two checks:
+  * layer by layer (kernel level): one step's intermediates, each against the oracle's restatement fed with the SAME inputs
+    where that isolates a kernel (the sparse apply is fed the GPU's own 16-bit row gradients: identical inputs, so the
+    reference bar for fp32 rows applies: bit-exact inside the windows, <= 1e-5 row-relative);
+  * free-running: 5 steps of engine.train_step (graphs replayed from step 4 on) against 5 oracle steps, with the bounds
+    stated at the asserts (16-bit activations differ by single ulps where the device's fp32 sum and the oracle's exact sum
+    round to different neighbours; everything downstream inherits those flips)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+ULP = {"bf16": 2.0 ** -7, "f16": 2.0 ** -10}
+
+
+def _cfg(dt, B=16384, V=2_000_000, layers=(1024, 512, 256, 128)):
+    from mindrec_amd.wide_deep import WideDeepConfig
+    return WideDeepConfig(vocab_size=V, emb_dim=80, field_size=26, batch_size=B, deep_layer_dim=list(layers),
+                          mlp_dtype={"bf16": "bf16", "f16": "fp16"}[dt])
+
+
+def _close16(got, ref, dt, what, min_equal=0.97):
+    """16-bit tensors: every element within ONE 16-bit ulp of the oracle's (plus an absolute floor for values that
+    cancel to ~0), and at least min_equal of them identical."""
+    got = np.asarray(got, np.float64); ref = np.asarray(ref, np.float64)
+    tol = ULP[dt] * np.abs(ref) + 1e-3 * np.abs(ref).max() * ULP[dt] + (2.0 ** -24 if dt == "f16" else 0.0)      # f16 subnormal spacing
+    bad = np.abs(got - ref) > tol
+    eq = float(np.mean(got == ref))
+    print(f"  {what}: equal {eq:.5f}, beyond one ulp {float(bad.mean()):.2e}, max |diff| / max |ref| = {np.abs(got - ref).max() / np.abs(ref).max():.2e}")
+    return eq, float(bad.mean())
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_one_step_layer_by_layer_vs_mixed_oracle(dev, oracle, dt):
+    from _oracle_mixed import OracleMixedEngine
+    from mindrec_amd import ops
+    from mindrec_amd.wide_deep import WideDeepEngine, synthetic_batch
+    cfg = _cfg(dt) if dt == "bf16" else _cfg(dt, B=4096, V=500_000)          # the reference's own dtype at a quarter of the batch
+    B, Fd, D = cfg.batch_size, cfg.field_size, cfg.emb_dim
+    g = WideDeepEngine(cfg, dev)
+    assert g._mfma
+    o = OracleMixedEngine(cfg, dt)
+    assert np.array_equal(g.dense_flat.detach().cpu().numpy(), o.flat)
+    ids, wts, label = synthetic_batch(cfg, "cpu", "uniform", seed=1000)
+    wts = wts * torch.rand_like(wts)                                             # non-trivial mask weights
+    r = o.forward_backward(ids.numpy(), wts.numpy(), label.numpy().ravel())
+    tid, twt, tl = ids.to(dev), wts.to(dev), label.to(dev)
+    emb, wide, _ = g.lookup(tid, twt)
+    assert np.array_equal(emb.float().cpu().numpy(), r["emb"]), "looked-up rows: one rounding of an fp32 product, must be bit-exact"
+    assert np.array_equal(wide.cpu().numpy(), r["wide"])
+    hs = g._mlp_fwd(emb)
+    # --- forward, each layer fed with the ORACLE's previous activation (isolates the kernel) and free-running
+    for i in range(1, len(hs)):
+        xin = torch.from_numpy(r["hs"][i - 1]).to(dev).to(emb.dtype)
+        yi = ops.dense_fwd(xin, g.dense16[2 * (i - 1)], g.dense[2 * (i - 1) + 1].detach(), relu=True).float().cpu().numpy()
+        eq, bad = _close16(yi, r["hs"][i], dt, f"layer {i} forward (oracle input)")
+        assert bad == 0.0 and eq >= 0.97
+        eq, bad = _close16(hs[i].float().cpu().numpy(), r["hs"][i], dt, f"layer {i} forward (free-running)", 0.8)
+        assert bad <= 2e-2 and eq >= 0.75
+    ctx = g._mlp_head(hs, wide, tl)
+    loss = float(ctx["loss"])
+    print(f"  loss gpu {loss:.8f} oracle {r['loss']:.8f}")
+    assert abs(loss - r["loss"]) <= 2e-5 * abs(r["loss"])
+    dl = ctx["g_wide"].cpu().numpy()
+    assert np.abs(dl - r["dlogit"]).max() <= 2e-3 * np.abs(r["dlogit"]).max()
+    g_emb = g._mlp_bwd(ctx)
+    torch.cuda.synchronize()
+    # --- backward kernels fed with the oracle's tensors
+    nl = len(g.dims) - 1
+    dh = r["dh_top"]
+    for i in range(nl - 2, -1, -1):
+        hi = torch.from_numpy(r["hs"][i]).to(dev).to(emb.dtype)
+        dht = torch.from_numpy(dh).to(dev).to(emb.dtype)
+        S = ops.dense_bwd_weight_slabs(B, g.dims[i], g.dims[i + 1])
+        slabs = torch.empty((S, g.dims[i], g.dims[i + 1]), dtype=torch.float32, device=dev)
+        ops.dense_bwd_weight(hi, dht, slabs)
+        dw = slabs.sum(dim=0).cpu().numpy().astype(np.float64)
+        err = np.abs(dw - r["gW"][i]).max() / np.abs(r["gW"][i]).max()
+        print(f"  layer {i} weight gradient: max |diff| / max |ref| = {err:.2e}")
+        assert err <= 2e-5
+        db = torch.zeros(g.dims[i], dtype=torch.float32, device=dev)
+        dx = ops.dense_bwd_input(dht, g.dense16[2 * i], h=hi if i > 0 else None, db_out=db if i > 0 else None).float().cpu().numpy()
+        ref_dx, ref_db = oracle.dense_bwd_input(dh, oracle.round16(o.W[i], dt), r["hs"][i] if i > 0 else None, dt)
+        eq, bad = _close16(dx, ref_dx, dt, f"layer {i} input gradient (oracle input)")
+        assert bad == 0.0 and eq >= 0.97
+        if i > 0:
+            assert np.abs(db.cpu().numpy() - ref_db).max() <= 2e-3 * np.abs(ref_db).max() + 1e-7
+        dh = ref_dx
+    # --- the engine's own chain end to end: row gradients
+    ge = g_emb.float().cpu().numpy()
+    # the engine's own chain: an activation that differs by an ulp upstream (or a ReLU mask that flips on a ~0 value) moves
+    # a few downstream elements by more than an ulp: >= 99 % identical, <= 0.5 % beyond one ulp, nothing beyond 15 % of the scale
+    eq, bad = _close16(ge, r["g_emb"], dt, "row gradients g_emb (free-running chain)", 0.5)
+    assert eq >= 0.99 and bad <= 5e-3 and np.abs(ge - r["g_emb"]).max() <= 0.15 * np.abs(r["g_emb"]).max()
+    # --- sparse applies fed with the GPU's own 16-bit row gradients: the fp32-row bar of the reference applies
+    g._sum_dw_slabs()
+    plan = ops.sparse_plan(tid)
+    ops.sparse_lazy_adam_(g.deep, g.deep_m, g.deep_v, plan, g_emb.view(B * Fd, D), twt, lr=cfg.adam_lr, eps=cfg.adam_eps,
+                          beta1_power=0.9, beta2_power=0.999, grad_scale=1.0 / cfg.sens)
+    o.apply(ids.numpy(), wts.numpy(), r, g_emb=ge)
+    a, b = g.deep.cpu().numpy(), o.deep
+    den = np.maximum(np.abs(b).max(axis=1), 1e-30)
+    rr = float((np.abs(a.astype(np.float64) - b).max(axis=1) / den).max())
+    print(f"  deep rows after LazyAdam on identical 16-bit gradients: row-relative error {rr:.2e}; touched rows {int((o.deep_m != 0).any(axis=1).sum())}")
+    assert rr <= 1e-5
+    untouched = (o.deep_m == 0).all(axis=1)
+    assert np.array_equal(a[untouched], b[untouched]) and np.array_equal((g.deep_m.cpu().numpy() == 0).all(axis=1), untouched)
+
+
+@pytest.mark.timeout(1200)
+def test_free_running_steps_with_graphs_vs_mixed_oracle(dev, oracle):
+    from _oracle_mixed import OracleMixedEngine
+    from mindrec_amd.wide_deep import WideDeepEngine, synthetic_batch
+    cfg = _cfg("bf16")
+    g = WideDeepEngine(cfg, dev)
+    o = OracleMixedEngine(cfg, "bf16")
+    steps = 5
+    lg, lo = [], []
+    for s in range(steps):
+        ids, wts, label = synthetic_batch(cfg, "cpu", "uniform" if s % 2 == 0 else "zipf", seed=2000 + s)
+        lg.append(float(g.train_step(ids.to(dev), wts.to(dev), label.to(dev))))
+        lo.append(o.train_step(ids.numpy(), wts.numpy(), label.numpy().ravel()))
+    assert g._front_graph is not None, "the whole-front graph must have been captured and replayed"
+    print("  losses gpu   ", lg)
+    print("  losses oracle", lo)
+    # mean of 16384 per-sample losses: the ulp flips in the activations average out
+    assert np.allclose(lg, lo, rtol=1e-4)
+    a, b = g.deep.cpu().numpy(), o.deep
+    touched = (o.deep_m != 0).any(axis=1)
+    assert np.array_equal((g.deep_m.cpu().numpy() != 0).any(axis=1), touched)
+    assert np.array_equal(a[~touched], b[~touched])
+    # LazyAdam moves a touched row by about lr per step whatever the gradient's size (m / sqrt(v) = +-1 at first touch): a row
+    # gradient element that differs by a 16-bit ulp changes the update by a few percent of lr at most, a flipped sign of a
+    # ~0 element by 2 lr.  Bounds: every element within 2 lr * steps; 99.9 % of the touched elements within 5 % of lr.
+    d = np.abs(a[touched].astype(np.float64) - b[touched])
+    print(f"  deep rows: max |diff| = {d.max():.3e} (lr = {cfg.adam_lr}), fraction within 5 % of lr: {np.mean(d <= 0.05 * cfg.adam_lr):.5f}")
+    assert d.max() <= 2 * cfg.adam_lr * steps and np.mean(d <= 0.05 * cfg.adam_lr) >= 0.999
+    dw = np.abs(g.wide.cpu().numpy().astype(np.float64) - o.wide)
+    print(f"  wide table: max |diff| / max |w| = {dw.max() / np.abs(o.wide).max():.3e}")
+    assert dw.max() <= 2e-2 * np.abs(o.wide).max()
+    dd = np.abs(g.dense_flat.detach().cpu().numpy().astype(np.float64) - o.flat)
+    print(f"  dense parameters: max |diff| = {dd.max():.3e}, fraction within 5 % of lr: {np.mean(dd <= 0.05 * cfg.adam_lr):.5f}")
+    assert dd.max() <= 2 * cfg.adam_lr * steps and np.mean(dd <= 0.05 * cfg.adam_lr) >= 0.99

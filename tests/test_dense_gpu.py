@@ -4,8 +4,8 @@ models/wide_deep/src/wide_and_deep.py:113-133).
 
 Bars, written out: the kernels accumulate in fp32 on the MFMA units, the oracle in float64.  With 16-bit operands the
 products are exact in fp32, so the two sums differ by at most K * 2^-24 * sum|x||w| (any-order fp32 summation bound);
-the final rounding to 16 bits adds half a 16-bit ulp of the result.  Outputs: |gpu - oracle| <= 0.5 ulp16(|oracle|)
-+ 2 K 2^-24 (|x| . |w|), elementwise.  Weight gradients (fp32 out): |gpu - oracle| <= 2 M 2^-24 (|x|^T . |dy|)."""
+both results are then rounded to 16 bits, so they can land on the two sides of a rounding boundary: one 16-bit ulp.
+Outputs: |gpu - oracle| <= ulp16(|oracle|) + 2 K 2^-24 (|x| . |w|), elementwise, and > 98 % of the elements are equal.  Weight gradients (fp32 out): |gpu - oracle| <= 2 M 2^-24 (|x|^T . |dy|)."""
 import numpy as np
 import pytest
 import torch
@@ -13,8 +13,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 DT = {"bf16": torch.bfloat16, "f16": torch.float16}
-EPS16 = {"bf16": 2.0 ** -8, "f16": 2.0 ** -11}      # half an ulp relative to the value: 2^-(mantissa bits + 1)
-TINY = {"bf16": 1e-38, "f16": 2.0 ** -25}           # f16 subnormal spacing / 2
+EPS16 = {"bf16": 2.0 ** -7, "f16": 2.0 ** -10}      # one ulp relative to the value (upper bound): 2^-(mantissa bits)
+TINY = {"bf16": 1e-38, "f16": 2.0 ** -24}           # f16 subnormal spacing
 
 
 def _vals(rng, shape, scale, dtype, oracle):
@@ -99,8 +99,12 @@ def test_dense_bwd_weight_matches_oracle(dev, oracle, dtype, M, K, N):
     bound = 2 * M * 2.0 ** -24 * (np.abs(x).astype(np.float64).T @ np.abs(dy)) + 1e-30
     assert np.all(np.abs(got - ref) <= bound), float((np.abs(got - ref) / bound).max())
     assert np.allclose(got, ref, rtol=1e-4, atol=1e-6 * np.abs(ref).max())
-    # slabs sum in slab order: the same bits as torch's sequential fp32 sum over dim 0
-    assert torch.equal(out, slabs.cpu().sum(dim=0, dtype=torch.float32).to(dev)) or np.allclose(got, slabs.sum(0).cpu().numpy(), rtol=1e-6)
+    # slabs are added in slab order: the same bits as a sequential fp32 sum on the host
+    sl = slabs.cpu().numpy()
+    acc = sl[0].copy()
+    for s_ in range(1, S):
+        acc = acc + sl[s_]
+    assert np.array_equal(out.cpu().numpy(), acc)
 
 
 def test_dense_adam_slabs_equals_plain_adam_on_summed_gradient(dev, oracle):
@@ -140,3 +144,28 @@ def test_dense_rejects_unsupported_shapes(dev):
         ops.dense_fwd(x, w, None)
     with pytest.raises(RuntimeError):
         ops.dense_fwd(x.cpu(), w.cpu(), None)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("M,K,N,mask", [(1024, 512, 256, True), (300, 3120, 136, False), (2048, 256, 128, True)])
+def test_dense_bwd_fused_launch_equals_separate_kernels(dev, oracle, dtype, M, K, N, mask):
+    """Both bprops of a layer in one launch (what the engine runs) == the two separate kernels, bit for bit: the same
+    workgroup bodies, only dispatched together."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(M + K)
+    dy = _dev(_vals(rng, (M, N), 1e-2, dtype, oracle), dtype, dev)
+    w = _dev(_vals(rng, (K, N), 0.05, dtype, oracle), dtype, dev)
+    x = _dev(np.maximum(_vals(rng, (M, K), 1.0, dtype, oracle), 0), dtype, dev)
+    S = ops.dense_bwd_weight_slabs(M, K, N)
+    dw1 = torch.empty((S, K, N), dtype=torch.float32, device=dev); dw2 = torch.empty_like(dw1)
+    db1 = torch.empty(((M + 255) // 256, K), dtype=torch.float32, device=dev); db2 = torch.empty_like(db1)
+    dx1 = ops.dense_bwd(dy, w, x, dw1, mask=mask, db_slabs=db1 if mask else None)
+    dx2 = ops.dense_bwd_input(dy, w, h=x if mask else None, db_slabs=db2 if mask else None)
+    ops.dense_bwd_weight(x, dy, dw2)
+    assert torch.equal(dx1, dx2) and torch.equal(dw1, dw2)
+    if mask:
+        assert torch.equal(db1, db2)
+        ref, ref_db = oracle.dense_bwd_input(dy.float().cpu().numpy(), w.float().cpu().numpy(), x.float().cpu().numpy(), dtype)
+        tot = torch.empty(K, dtype=torch.float32, device=dev)
+        ops.sum_slabs(db1, tot)
+        assert np.allclose(tot.cpu().numpy(), ref_db, rtol=1e-2, atol=1e-3 * np.abs(ref_db).max())

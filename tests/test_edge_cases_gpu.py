@@ -84,7 +84,7 @@ def test_wrong_dtypes_raise(dev):
         ops.gather_rows(table, torch.zeros(2, dtype=torch.int32, device=dev), row_scale=torch.zeros(3, device=dev))
     with pytest.raises(TypeError):
         ops.sparse_lazy_adam_(table, table.clone(), table.clone(), ops.sparse_plan(torch.zeros(2, dtype=torch.int32, device=dev)),
-                              torch.zeros((2, 4), dtype=torch.float16, device=dev))
+                              torch.zeros((2, 4), dtype=torch.float64, device=dev))
     with pytest.raises(ValueError):
         ops.sparse_lazy_adam_(table, torch.zeros((4, 8), device=dev)[:, :4], table.clone(),
                               ops.sparse_plan(torch.zeros(2, dtype=torch.int32, device=dev)), torch.zeros((2, 4), device=dev))

@@ -373,37 +373,45 @@ def test_key_index_full_and_reuse(dev):
     assert ki.counters()[1] == 99
 
 
-def test_key_index_long_churn_keeps_empty_slots(dev, oracle):
+def test_key_index_long_churn_keeps_empty_slots(dev):
     """Insert / erase churn with a key space far larger than the slot array (the pattern of the feature-cache
     tier's evict + prepare and of MapParameter.evict): without tombstone reclamation the empty slots run out
-    after ~20 steps and a probe for a missing key never ends.  300 steps here; row numbering must keep
-    matching the oracle's map, tombstones must stay under a fifth of the slots, rebuilds must have happened."""
+    after ~20 steps and a probe for a missing key never ends.  300 steps here, checked against a host dict:
+    every live key keeps its row, rows are distinct and in range, misses terminate with -1, tombstones stay
+    under the rebuild threshold and the slot array was rebuilt many times.  (Row NUMBERS after reuse are this
+    index's own free-list policy; the oracle's map is append-only, so they are not compared here.)"""
     from mindrec_amd import ops
     rng = np.random.default_rng(21)
     cap = 900                                   # 2048 slots
-    om = oracle.Map(1, cap, seed=1, sigma=0.01)
     ki = ops.KeyIndex(cap, dev)
-    resident = np.zeros(0, np.int64)
+    row_of = {}
+    order = []                                  # residents, oldest first
     for step in range(300):
-        fresh = rng.integers(0, 2**45, size=660).astype(np.int64)
-        fresh = np.unique(fresh)
-        fresh = fresh[~np.isin(fresh, resident)]
-        room = cap - resident.size
+        fresh = np.unique(rng.integers(0, 2**45, size=660).astype(np.int64))
+        fresh = np.array([k for k in fresh.tolist() if k not in row_of], np.int64)
+        room = cap - len(order)
         if fresh.size > room:                   # evict the oldest residents to make room
             k = fresh.size - room
-            out, resident = resident[:k], resident[k:]
-            ki.erase(T(out, dev)); om.erase(out)
+            out, order = order[:k], order[k:]
+            ki.erase(T(np.array(out, np.int64), dev))
+            for key in out:
+                del row_of[key]
         rows, is_new = ki.find_or_insert(T(fresh, dev), insert=True)
-        assert np.array_equal(rows.cpu().numpy(), om.find_or_insert(fresh, True))
-        assert int(is_new.sum()) == fresh.size
-        resident = np.concatenate([resident, fresh])
-        if step % 50 == 49:
+        rows = rows.cpu().numpy()
+        assert int(is_new.sum()) == fresh.size and rows.min() >= 0 and rows.max() < cap
+        for key, r in zip(fresh.tolist(), rows.tolist()):
+            row_of[key] = r
+        order += fresh.tolist()
+        assert len(set(row_of.values())) == len(row_of) == len(order)          # live keys own distinct rows
+        if step % 25 == 24:
             c = ki.counters_all()
-            assert c[1] == resident.size == om.size()
+            assert c[1] == len(order) and c[2] == 0
             assert 0 <= c[4] * 5 <= 2048 + 5 * 660, c       # tombstones bounded by the rebuild threshold (+ one call)
-            probe = np.concatenate([resident[:50], rng.integers(2**46, 2**47, size=200)]).astype(np.int64)
+            res = np.array(order[:300], np.int64)
+            probe = np.concatenate([res, rng.integers(2**46, 2**47, size=200)]).astype(np.int64)
             r, _ = ki.find_or_insert(T(probe, dev), insert=False)       # misses must terminate
-            assert np.array_equal(r.cpu().numpy(), om.find_or_insert(probe, False))
+            r = r.cpu().numpy()
+            assert r[:res.size].tolist() == [row_of[k] for k in res.tolist()] and (r[res.size:] == -1).all()
     assert ki.counters_all()[6] >= 10           # the slot array was rebuilt many times
 
 

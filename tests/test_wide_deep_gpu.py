@@ -103,33 +103,44 @@ def test_auc_parity_on_planted_signal(dev, oracle):
     assert abs(auc_c - auc_g) < 2e-3, (auc_c, auc_g)
 
 
-def test_mfma_mlp_step_matches_autograd(dev):
-    """The hand-written mixed-precision MLP step (MFMA kernels, csrc/mrec_dense.hip) gives the same loss and gradients
-    as autograd over torch's GEMMs on the same 16-bit operands (a second opinion; the oracle check is
-    tests/test_dense_gpu.py and tests/test_bench_shape_gpu.py)."""
+def test_mfma_mlp_step_matches_torch_fp32_reference(dev):
+    """Second opinion for the hand-written mixed-precision MLP step (the oracle checks are tests/test_dense_gpu.py and
+    tests/test_bench_shape_gpu.py): a plain PyTorch fp32 restatement with the SAME rounding points -- 16-bit operands
+    widened to fp32, fp32 matmul + fp32 bias, one cast of every activation to 16 bits (whose autograd casts the gradient
+    back at the same point) -- run through autograd on the same GPU."""
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     for dt in ("bf16", "fp16"):
         cfg = WideDeepConfig(vocab_size=20_000, emb_dim=80, field_size=26, batch_size=2048, mlp_dtype=dt)
         e = WideDeepEngine(cfg, dev)
         assert e._mfma
+        amp = e._amp
         ids, wts, label = synthetic_batch(cfg, dev, "zipf", seed=5)
         emb, wide, _ = e.lookup(ids, wts)
         loss, g_emb, g_wide = e._mlp_step_eager(emb, wide, label)
         e._sum_dw_slabs()
-        gd1 = e.dense_grad_flat.detach().clone().cpu().numpy()
-        l1, ge1, gw1 = float(loss), g_emb.float().cpu().numpy(), g_wide.cpu().numpy()
-        emb2 = emb.float().requires_grad_(True); wide2 = wide.clone().requires_grad_(True); e.dense_grad_flat.zero_()
+        gd1 = e.dense_grad_flat.detach().clone()
+        n = len(e.dims) - 1
+        params = [p.detach().clone().requires_grad_(True) for p in e.dense]
+        x = emb.detach().clone().requires_grad_(True)
+        wd = wide.detach().clone().requires_grad_(True)
         with torch.enable_grad():
-            logit = wide2.view(-1, 1) + e.mlp(emb2)
+            h = x
+            for i in range(n - 1):
+                W16 = params[2 * i].to(amp)                         # the operand shadow: one rounding of the fp32 master weight
+                h = torch.relu(h.float() @ W16.float() + params[2 * i + 1]).to(amp)
+            logit = h.float() @ params[2 * (n - 1)] + params[2 * (n - 1) + 1] + wd.view(-1, 1)
             loss2 = torch.nn.functional.binary_cross_entropy_with_logits(logit, label)
             (loss2 * cfg.sens).backward()
-        gd2 = e.dense_grad_flat.detach().cpu().numpy()
-        ge2, gw2, l2 = emb2.grad.cpu().numpy(), wide2.grad.cpu().numpy(), float(loss2.detach())
-        assert abs(l1 - l2) <= 1e-3 * abs(l2), dt
-        assert np.allclose(gw1, gw2, rtol=2e-2, atol=1e-5), dt
-        # 16-bit GEMMs: compare against the gradient scale
-        assert np.abs(ge1 - ge2).max() <= 3e-2 * np.abs(ge2).max(), dt
-        assert np.abs(gd1 - gd2).max() <= 3e-2 * np.abs(gd2).max(), dt
+        assert abs(float(loss) - float(loss2.detach())) <= 2e-5 * abs(float(loss2.detach())), dt
+        assert torch.allclose(g_wide, wd.grad, rtol=2e-3, atol=1e-6 * float(wd.grad.abs().max())), dt
+        ge1, ge2 = g_emb.float(), x.grad.float()
+        # row gradients: 16-bit values, a few differ by an ulp (and what that does downstream)
+        assert float((ge1 - ge2).abs().max()) <= 0.1 * float(ge2.abs().max()), dt
+        assert float((ge1 == ge2).float().mean()) >= 0.9, dt
+        for i, p in enumerate(params):
+            ref = p.grad
+            got = gd1[e.dense_grad[i].storage_offset(): e.dense_grad[i].storage_offset() + ref.numel()].view_as(ref)
+            assert float((got - ref).abs().max()) <= 5e-3 * float(ref.abs().max()) + 1e-12, (dt, i)
 
 
 def test_deepfm_engine_matches_oracle_engine(dev, oracle):
