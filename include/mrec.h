@@ -104,6 +104,16 @@ int mrec_gather_rows_f16_i32(const float* table, int64_t V, int64_t ld, int32_t 
 int mrec_gather_rows_f16_i64(const float* table, int64_t V, int64_t ld, int32_t D, const int64_t* ids,
                              int64_t n, const float* row_scale, uint16_t* out, void* stream);
 
+/* Deep lookup + the wide branch's products in one pass over FUSED rows [p(D) | w accum linear pad | ...] (both lookups of
+ * WideDeepModel.construct read the same id tensor, wide_and_deep.py:300-302): out as mrec_gather_rows_{bf16,f16} (out_kind 1 /
+ * 2), and wide_prod[2 i] = table[ids[i], wide_col] * row_scale[i] (0 for ids outside [0, V); wide_prod[2 i + 1] = 0: the
+ * products are stored as 8-byte pairs).  wide_col must equal D (the wide word right behind the deep columns), D % 4 == 0,
+ * D <= 252.  The per-sample sum over the fields + bias is taken by mrec_head_fwd_bwd_wide in field order: same adds, same
+ * order as mrec_wide_sum. */
+int mrec_gather_rows_wide(const float* table, int64_t V, int64_t ld, int32_t D, const void* ids, int32_t id_bytes, int64_t n,
+                          const float* row_scale, void* out, int32_t out_kind, int32_t wide_col, float* wide_prod,
+                          void* stream);
+
 /* Wide branch of WideDeepModel.construct (wide_and_deep.py:300,303-306) in one pass:
  * out[b] = sum_f w[ids[b,f] * ldw] * wts[b,f] + *bias_dev   (w is the [V,1] wide table, row
  * stride ldw floats: 1 for a dense column, 4 when it lives in a fused w|accum|linear|pad record). */
@@ -119,8 +129,8 @@ int mrec_wide_sum_f32_i64(const float* w, int64_t V, int64_t ldw, const int64_t*
  * groups that fit one window (mrec_sparse_apply_window), and as a fixed-order tree of window partials otherwise
  * (bitwise reproducible run to run either way).  uniq maps group -> table row. */
 int mrec_sparse_apply_workspace_bytes(int64_t n, int32_t D, size_t* out);
-/* Entries per window of the sorted index for a table of width D: 16 on the float4 path (D % 4 == 0,
- * rows and row strides 16-byte aligned: aligned16 != 0), 8 on the scalar path.  A group whose run
+/* Entries per window of the sorted index for a table of width D (8 on every path in this build: the float4 path --
+ * D % 4 == 0, rows and row strides 16-byte aligned: aligned16 != 0 -- and the 8-byte / scalar paths).  A group whose run
  * of sorted entries stays inside one window is summed in ascending position order (= the CPU
  * reference order); longer runs are a fixed tree of window partials. */
 int mrec_sparse_apply_window(int32_t D, int aligned16);
@@ -174,6 +184,22 @@ int mrec_sparse_lazy_adam_f16g_i64(float* p, float* m, float* v, int64_t V, int6
                                    const float* row_scale, float lr, float b1, float b2, float eps,
                                    float b1_pow, float b2_pow, float grad_scale, int nesterov, void* ws,
                                    size_t ws_bytes, void* stream);
+
+/* LazyAdam on the deep columns AND FTRL on the wide record of the same fused rows, one pass: the wide table's
+ * Unique + UnsortedSegmentSum + FusedSparseFtrl (wide_and_deep.py:423-430) ride the deep table's row visit.  Row layout:
+ * p at column 0 (pointer p), the wide record [w, accum, linear, pad] as one float4 at column wide_col of the same rows
+ * (relative to p), m and v wherever their pointers say; all with row stride ld.  The wide gradient of position i is
+ * gw[i / F] (the head's dlogit of sample i / F: Mul bprop of wide_and_deep.py:304), scaled by row_scale[i] * grad_scale and
+ * summed per id in the same window / tree order as the deep columns.  uniq_bytes 4 / 8; g_kind 0 f32, 1 bf16, 2 f16;
+ * D % 4 == 0, D <= 252, wide_col == D (the record right behind p: it is loaded and stored by the instruction that moves p),
+ * 16-byte aligned rows (128-byte aligned rows avoid a second line per record), n * F < 2^32.
+ * ws: mrec_sparse_apply_workspace_bytes(n, D + 4). */
+int mrec_sparse_lazy_adam_wide(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D, const void* uniq,
+                               int32_t uniq_bytes, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                               const int32_t* seg_offsets, int64_t n, const void* g, int32_t g_kind, int64_t ldg,
+                               const float* row_scale, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
+                               float grad_scale, int nesterov, const float* gw, int32_t F, int32_t wide_col, float ftrl_lr,
+                               float l1, float l2, float lr_power, void* ws, size_t ws_bytes, void* stream);
 
 /* nn.FTRL sparse apply (FusedSparseFtrl; wide_and_deep.py:423-430). */
 int mrec_sparse_ftrl_f32_i32(float* var, float* accum, float* linear, int64_t V, int64_t ld, int32_t D,
@@ -290,6 +316,13 @@ int mrec_head_fwd_bwd_f16(const uint16_t* h4, const float* w5, const float* b5, 
                           const float* label, int64_t B, int32_t K5, float dscale, float* logit, float* dlogit,
                           uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss, void* ws,
                           size_t ws_bytes, void* stream);
+
+/* The same head (f16 != 0: IEEE half activations) with the wide branch given as the per-field products of
+ * mrec_gather_rows_wide ([B, F, 2] floats: product, pad): wide[b] = (((0 + prod[b,0]) + prod[b,1]) + ...) + *wide_bias. */
+int mrec_head_fwd_bwd_wide(int32_t f16, const uint16_t* h4, const float* w5, const float* b5, const float* wide_prod, int32_t F,
+                           const float* wide_bias, const float* label, int64_t B, int32_t K5, float dscale, float* logit,
+                           float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss, void* ws,
+                           size_t ws_bytes, void* stream);
 
 /* ---- MapParameter key index ---------------------------------------------------------------
  * mindspore.experimental.MapParameter as built by HashEmbeddingLookup

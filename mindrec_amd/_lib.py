@@ -48,6 +48,10 @@ _SIGS = {
     "mrec_gather_rows_bf16_i64": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_gather_rows_f16_i32": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_gather_rows_f16_i64": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
+    "mrec_gather_rows_wide": [_vp, _i64, _i64, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp],
+    "mrec_sparse_lazy_adam_wide": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i64, _vp,
+                                   _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _sz, _vp],
+    "mrec_head_fwd_bwd_wide": [_i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_wide_sum_f32_i32": [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_wide_sum_f32_i64": [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_sparse_apply_workspace_bytes": [_i64, _i32, _szp],

@@ -17,9 +17,11 @@
 // lane-group keeps up to 4*AB 16-byte loads in flight.
 //
 // Runs that cross a window boundary (duplicate-heavy ids, e.g. Criteo's 13 constant dense-field ids
-// with 16384 copies each) leave per-window partial sums in a carry buffer and their owning window
-// in a work list; a second launch sums each run's partials with a whole 256-thread block in a
-// fixed tree order and applies the update.  Both passes are bitwise reproducible.
+// with 16384 copies each) leave per-window partial sums in a carry buffer, and every window writes a
+// flag (0 = no run continues past it, 1 = it owns a run with few partials, 2 = a long run): no list,
+// no counter, no atomic.  A second launch (k_apply_long) finishes the short runs with one lane-group
+// each, partials in order, and the long ones with a whole 256-thread block in a fixed tree order.
+// Both passes are bitwise reproducible.
 #include "mrec_common.h"
 #include "mrec_optim.h"
 
@@ -137,6 +139,23 @@ template <bool NT> __device__ __forceinline__ void vload(Vf<2>& r, const f16_t* 
 template <bool NT> __device__ __forceinline__ void vload(Vf<1>& r, const f16_t* p) {
     r.v = (float)__builtin_bit_cast(_Float16, p->v);
 }
+// Gradient load of the float4 path with a wide lane in the group: ONE load instruction for all lanes (the wide lane's
+// address points into gw); the wide lane keeps the first dword as the fp32 it is, the others widen their 16-bit values.
+template <bool NT> __device__ __forceinline__ void vload_w(Vf<4>& r, const float* p, bool) { vload<NT>(r, p); }
+template <bool NT> __device__ __forceinline__ void vload_w(Vf<4>& r, const bf16_t* p, bool wl) {
+    typedef unsigned int mrec_u2 __attribute__((ext_vector_type(2)));
+    const mrec_u2 t = NT ? __builtin_nontemporal_load((const mrec_u2*)p) : *(const mrec_u2*)p;
+    r.v = make_float4(__uint_as_float(wl ? t.x : (t.x << 16)), __uint_as_float(t.x & 0xFFFF0000u), __uint_as_float(t.y << 16),
+                      __uint_as_float(t.y & 0xFFFF0000u));
+}
+template <bool NT> __device__ __forceinline__ void vload_w(Vf<4>& r, const f16_t* p, bool wl) {
+    typedef unsigned int mrec_u2 __attribute__((ext_vector_type(2)));
+    const mrec_u2 t = NT ? __builtin_nontemporal_load((const mrec_u2*)p) : *(const mrec_u2*)p;
+    const float2 a = mrec_h2f2(t.x), b = mrec_h2f2(t.y);
+    r.v = make_float4(wl ? __uint_as_float(t.x) : a.x, a.y, b.x, b.y);
+}
+template <bool NT, class G> __device__ __forceinline__ void vload_w(Vf<2>&, const G*, bool) {}
+template <bool NT, class G> __device__ __forceinline__ void vload_w(Vf<1>&, const G*, bool) {}
 template <bool NT> __device__ __forceinline__ void vstore(float* p, const Vf<4>& x) {
     if (NT) {
         mrec_f4 t = {x.v.x, x.v.y, x.v.z, x.v.w};
@@ -218,7 +237,30 @@ __device__ __forceinline__ void upd_apply(const Upd& u, Vf<1> (&st)[Upd::NS], co
     for (int i = 0; i < Upd::NS; ++i) st[i].v = a[i];
 }
 
+__device__ __forceinline__ void vset_x(Vf<4>& r, float x) { r.v.x = x; }
+__device__ __forceinline__ void vset_x(Vf<2>& r, float x) { r.v.x = x; }
+__device__ __forceinline__ void vset_x(Vf<1>& r, float x) { r.v = x; }
+// FTRL on the wide record held as one float4 [w, accum, linear, pad]; g = the summed gradient in .x
+template <int VEC> __device__ __forceinline__ void wide_apply(Vf<VEC>&, const Vf<VEC>&, const FtrlH&) {}
+template <> __device__ __forceinline__ void wide_apply<4>(Vf<4>& st, const Vf<4>& g, const FtrlH& h) {
+    ftrl_elem(st.v.x, st.v.y, st.v.z, g.v.x, h);
+}
+
 struct ApplyGeom { int lpr; int G; int D; };
+
+// The "wide lane": with WIDE the lane-group gets one lane more (sub == lpr - 1), which owns the wide table's FTRL record
+// [w | accum | linear | pad] (one float4 at column wcol of the SAME fused row, s[0] + row * ld + wcol) instead of four
+// columns of p / m / v.  Its gradient per position is gw[pos / F] (the head's dlogit of the sample, wide_and_deep.py:304-306
+// bprop), scaled and summed exactly like the other lanes' columns -- so Unique + UnsortedSegmentSum + FusedSparseFtrl of
+// the wide table (wide_and_deep.py:423-430) ride the deep table's pass: one row visit instead of two kernels.
+// Cost model (measured): the kernel is bound by the cache-line requests it makes per row, not by bytes or instructions.
+//   * the wide record is loaded / stored by the instruction that loads / stores p: wcol == D puts it right behind p's last
+//     lane (contiguous 16 bytes more, the same 128-byte line when rows are 128-byte aligned) -- no extra request;
+//   * for m and v the wide lane is simply masked off;
+//   * the per-sample gradient gw[pos / F] is one group-uniform, cached load (pos / F by multiply-high with `magic`).
+// Two earlier forms cost +35 % (separate nontemporal load + store of the record: the line is fetched again) and +55 %
+// (the wide lane pointed at dummy lines for m / v: two more line requests per load and store).
+struct WideArgs { const float* gw; int F; int wcol; FtrlH h; unsigned magic; float* dummy; };
 
 // uniq == nullptr means "row = group number" (segment-sum into a dense [U, D] output).
 template <class K>
@@ -226,13 +268,17 @@ __device__ __forceinline__ int64_t seg_row(const K* uniq, int seg) {
     return uniq ? (int64_t)uniq[seg] : (int64_t)seg;
 }
 
-template <int VEC, class K, class Upd, class GT>
-__global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
+// (WIDE: 5 waves per SIMD asked of the register allocator -- the wide lane's FTRL path took the kernel from 74 to 97
+// VGPRs, i.e. from 6 to 4 waves per SIMD, and the lost latency hiding cost more than everything else the wide lane does;
+// 96 registers fit without spilling, 80 do not)
+template <int VEC, class K, class Upd, class GT, bool WIDE = false>
+__global__ __launch_bounds__(256, WIDE ? 5 : 1) void k_apply_main(Upd upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
                                                     const int* __restrict__ spos, const int* __restrict__ sseg,
                                                     int n, const GT* __restrict__ g, int64_t ldg,
                                                     const float* __restrict__ rscale, float gscale, ApplyGeom gm,
                                                     float* __restrict__ carry_head, float* __restrict__ carry_tail,
-                                                    int* __restrict__ owners, const int* __restrict__ seg_offsets) {
+                                                    int* __restrict__ owners, const int* __restrict__ seg_offsets,
+                                                    WideArgs wa) {
     constexpr int AW = ACfg<VEC>::AW, AB = ACfg<VEC>::AB, GP = ACfg<VEC>::GP;
     constexpr bool NT = ACfg<VEC>::NT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -243,7 +289,9 @@ __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t 
     if (s64 >= n) return;
     const int s = (int)s64;
     const int e_end = (s + AW < n) ? s + AW : n;
-    const int col = sub * VEC;
+    const bool wl = WIDE && sub == gm.lpr - 1;          // this lane owns the wide record
+    const int ccol = sub * VEC;                         // column in the carry rows
+    const int col = wl ? wa.wcol : ccol;                // column in the table rows
 
     const int first_seg = sseg[s];
     const bool head_open = (s > 0) && (sseg[s - 1] == first_seg);
@@ -264,7 +312,13 @@ __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t 
             vzero(gvv[q]);
             if (e < e_end) {
                 const int pos = spos[e];
-                vload<NT>(gvv[q], g + (int64_t)pos * ldg + col);
+                if (WIDE) {
+                    const float gwv = wa.gw[__umulhi((unsigned)pos, wa.magic)];      // same address for the whole lane-group
+                    if (!wl) vload<NT>(gvv[q], g + (int64_t)pos * ldg + col);
+                    else vset_x(gvv[q], gwv);
+                } else {
+                    vload<NT>(gvv[q], g + (int64_t)pos * ldg + col);
+                }
                 if (rscale) rsv[q] = rscale[pos];
             }
         }
@@ -298,7 +352,8 @@ __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t 
                         roff[k] = row * ld + col;
                         if (Upd::kLoad) {
 #pragma unroll
-                            for (int i = 0; i < Upd::NS; ++i) vload<NT>(st[k][i], upd.s[i] + roff[k]);
+                            for (int i = 0; i < Upd::NS; ++i)
+                                if (!(WIDE && wl && i > 0)) vload<NT>(st[k][i], upd.s[i] + roff[k]);
                         }
                     }
                 }
@@ -312,11 +367,13 @@ __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t 
                 if (is_start[k]) acc = x; else vadd(acc, x);
                 if (is_end[k]) {
                     if (open[k]) {
-                        vstore<false>(carry_head + sw * gm.D + col, acc);
+                        vstore<false>(carry_head + sw * gm.D + ccol, acc);
                     } else if (upd_ok[k]) {
-                        upd_apply<Upd>(upd, st[k], acc);
+                        if (WIDE && wl) wide_apply(st[k][0], acc, wa.h);
+                        else upd_apply<Upd>(upd, st[k], acc);
 #pragma unroll
-                        for (int i = 0; i < Upd::NS; ++i) vstore<NT>(upd.s[i] + roff[k], st[k][i]);
+                        for (int i = 0; i < Upd::NS; ++i)
+                            if (!(WIDE && wl && i > 0)) vstore<NT>(upd.s[i] + roff[k], st[k][i]);
                     }
                 }
             }
@@ -331,9 +388,9 @@ __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t 
     int flag = 0;
     if (e_end < n && sseg[e_end] == last_seg) {
         if (head_open && last_seg == first_seg) {
-            vstore<false>(carry_head + sw * gm.D + col, acc);  // window lies wholly inside one run
+            vstore<false>(carry_head + sw * gm.D + ccol, acc);  // window lies wholly inside one run
         } else {
-            vstore<false>(carry_tail + sw * gm.D + col, acc);
+            vstore<false>(carry_tail + sw * gm.D + ccol, acc);
             const int k = (seg_offsets[last_seg + 1] - 1) / AW - (int)sw;   // head partials that follow
             flag = (k + 1 <= 4 * gm.G) ? 1 : 2;
         }
@@ -348,13 +405,13 @@ __global__ __launch_bounds__(256) void k_apply_main(Upd upd, int64_t V, int64_t 
 //   pass B: longer runs -- one block each: lane-groups take partials round-robin (fixed assignment), then
 //           group 0 adds the per-group sums in group order.
 // For k + 1 <= NG both orders coincide (each group holds one partial), so the split does not change results.
-template <int VEC, class K, class Upd>
+template <int VEC, class K, class Upd, bool WIDE = false>
 __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
                                                     const int* __restrict__ sseg,
                                                     const int* __restrict__ seg_offsets, int n, ApplyGeom gm,
                                                     const float* __restrict__ carry_head,
                                                     const float* __restrict__ carry_tail,
-                                                    const int* __restrict__ owners, int nsw) {
+                                                    const int* __restrict__ owners, int nsw, WideArgs wa) {
     // the partials of a run are consecutive carry rows: stream them 16 deep per lane-group
     constexpr int AW = ACfg<VEC>::AW, AB = 16;
     __shared__ float red[256 * 4];
@@ -363,7 +420,9 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
     const bool active = grp < gm.G;
-    const int col = sub * VEC;
+    const bool wl = WIDE && sub == gm.lpr - 1;
+    const int col = sub * VEC;                          // column in the carry rows
+    const int tcol = wl ? wa.wcol : col;                // column in the table rows
     const int NG = 4 * gm.G;
     const int gi = wave * gm.G + grp;
 
@@ -384,15 +443,21 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
             }
             const int64_t row = seg_row<K>(uniq, u);
             if (row >= 0 && row < V) {
-                const int64_t roff = row * ld + col;
+                const int64_t roff = row * ld + tcol;
                 Vf<VEC> st[Upd::NS];
-                if (Upd::kLoad) {
+                if (WIDE && wl) {
+                    vload<false>(st[0], upd.s[0] + roff);
+                    wide_apply(st[0], acc, wa.h);
+                    vstore<false>(upd.s[0] + roff, st[0]);
+                } else {
+                    if (Upd::kLoad) {
 #pragma unroll
-                    for (int i = 0; i < Upd::NS; ++i) vload<false>(st[i], upd.s[i] + roff);
+                        for (int i = 0; i < Upd::NS; ++i) vload<false>(st[i], upd.s[i] + roff);
+                    }
+                    upd_apply<Upd>(upd, st, acc);
+#pragma unroll
+                    for (int i = 0; i < Upd::NS; ++i) vstore<false>(upd.s[i] + roff, st[i]);
                 }
-                upd_apply<Upd>(upd, st, acc);
-#pragma unroll
-                for (int i = 0; i < Upd::NS; ++i) vstore<false>(upd.s[i] + roff, st[i]);
             }
         }
     }
@@ -448,15 +513,21 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
                 }
                 const int64_t row = seg_row<K>(uniq, u);
                 if (row >= 0 && row < V) {
-                    const int64_t roff = row * ld + col;
+                    const int64_t roff = row * ld + tcol;
                     Vf<VEC> st[Upd::NS];
-                    if (Upd::kLoad) {
+                    if (WIDE && wl) {
+                        vload<false>(st[0], upd.s[0] + roff);
+                        wide_apply(st[0], acc, wa.h);
+                        vstore<false>(upd.s[0] + roff, st[0]);
+                    } else {
+                        if (Upd::kLoad) {
 #pragma unroll
-                        for (int i = 0; i < Upd::NS; ++i) vload<false>(st[i], upd.s[i] + roff);
+                            for (int i = 0; i < Upd::NS; ++i) vload<false>(st[i], upd.s[i] + roff);
+                        }
+                        upd_apply<Upd>(upd, st, acc);
+#pragma unroll
+                        for (int i = 0; i < Upd::NS; ++i) vstore<false>(upd.s[i] + roff, st[i]);
                     }
-                    upd_apply<Upd>(upd, st, acc);
-#pragma unroll
-                    for (int i = 0; i < Upd::NS; ++i) vstore<false>(upd.s[i] + roff, st[i]);
                 }
             }
             __syncthreads();
@@ -469,23 +540,30 @@ inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 thread_local hipEvent_t t_prof_start = nullptr, t_prof_stop = nullptr;
 
-struct ApplyWs { float* carry_head; float* carry_tail; int* owners; int* n_owners; };
+struct ApplyWs { float* carry_head; float* carry_tail; int* owners; int* n_owners; float* dummy; };
 
 size_t apply_ws_bytes(int64_t n, int32_t D) {
     const size_t nsw = (size_t)mrec_cdiv(n ? n : 1, AW_MIN);
     const int Dc = D > 256 ? 256 : D;
-    return mrec_align_up(nsw * Dc * 4, 256) * 2 + mrec_align_up(nsw * 4, 256) + 256;
+    return mrec_align_up(nsw * Dc * 4, 256) * 2 + mrec_align_up(nsw * 4, 256) + 256 + 2048 * 64;
 }
 
 // One launch pair over columns [c0, c0+Dc) of every array.
 template <class K, class Upd, class GT>
 int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, const int* sseg,
                const int* seg_offsets, int64_t n, const GT* g, int64_t ldg, const float* rscale, float gscale,
-               int Dc, int vec, const ApplyWs& w, hipStream_t st) {
+               int Dc, int vec, const ApplyWs& w, hipStream_t st, const WideArgs* wide = nullptr) {
     ApplyGeom gm;
-    gm.D = Dc;
-    gm.lpr = Dc / vec;
+    gm.D = Dc + (wide ? 4 : 0);
+    gm.lpr = Dc / vec + (wide ? 1 : 0);
     gm.G = 64 / gm.lpr;
+    WideArgs wa{};
+    if (wide) {
+        wa = *wide;
+        wa.magic = (unsigned)(((uint64_t)1 << 32) / (uint64_t)wa.F + 1);       // pos / F = umulhi(pos, magic) while pos * F < 2^32
+        wa.dummy = w.dummy;
+        if ((uint64_t)n * (uint64_t)wa.F >= ((uint64_t)1 << 32)) return MREC_EUNSUPPORTED;
+    }
     const int64_t nsw = mrec_cdiv(n, vec == 4 ? ACfg<4>::AW : ACfg<1>::AW);
     const unsigned blocks = (unsigned)mrec_cdiv(nsw, (int64_t)4 * gm.G);
     const int64_t lneed = mrec_cdiv(nsw, (int64_t)4 * gm.G);
@@ -493,24 +571,30 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
     const hipEvent_t ev0 = t_prof_start, ev1 = t_prof_stop;
     t_prof_start = t_prof_stop = nullptr;
     if (ev0) MREC_HIP_CHECK(hipEventRecord(ev0, st));
-    if (vec == 4) {
+    if (vec == 4 && wide) {
+        k_apply_main<4, K, Upd, GT, true><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
+                                                             w.carry_head, w.carry_tail, w.owners, seg_offsets, wa);
+        if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
+        k_apply_long<4, K, Upd, true><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
+                                                              w.carry_head, w.carry_tail, w.owners, (int)nsw, wa);
+    } else if (vec == 4) {
         k_apply_main<4, K, Upd, GT><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
-                                                       w.carry_head, w.carry_tail, w.owners, seg_offsets);
+                                                       w.carry_head, w.carry_tail, w.owners, seg_offsets, wa);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         k_apply_long<4, K, Upd><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
-                                                        w.carry_head, w.carry_tail, w.owners, (int)nsw);
+                                                        w.carry_head, w.carry_tail, w.owners, (int)nsw, wa);
     } else if (vec == 2) {
         k_apply_main<2, K, Upd, GT><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
-                                                       w.carry_head, w.carry_tail, w.owners, seg_offsets);
+                                                       w.carry_head, w.carry_tail, w.owners, seg_offsets, wa);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         k_apply_long<2, K, Upd><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
-                                                        w.carry_head, w.carry_tail, w.owners, (int)nsw);
+                                                        w.carry_head, w.carry_tail, w.owners, (int)nsw, wa);
     } else {
         k_apply_main<1, K, Upd, GT><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
-                                                       w.carry_head, w.carry_tail, w.owners, seg_offsets);
+                                                       w.carry_head, w.carry_tail, w.owners, seg_offsets, wa);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         k_apply_long<1, K, Upd><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
-                                                        w.carry_head, w.carry_tail, w.owners, (int)nsw);
+                                                        w.carry_head, w.carry_tail, w.owners, (int)nsw, wa);
     }
     MREC_LAUNCH_CHECK();
     return MREC_OK;
@@ -519,22 +603,23 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
 template <class K, class Upd, class GT = float>
 int apply_impl(Upd upd, int64_t V, int64_t ld, int32_t D, const K* uniq, const int32_t* spos, const int32_t* sseg,
                const int32_t* seg_offsets, int64_t n, const GT* g, int64_t ldg, const float* rscale,
-               float gscale, void* ws, size_t ws_bytes, void* stream) {
+               float gscale, void* ws, size_t ws_bytes, void* stream, const WideArgs* wide = nullptr) {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || D <= 0 || V < 0 || ld < D || ldg < D) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
     if (!spos || !sseg || !seg_offsets || !g || !ws) return MREC_EINVAL;
     for (int i = 0; i < Upd::NS; ++i) if (!upd.s[i]) return MREC_EINVAL;
     if (n > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
-    if (ws_bytes < apply_ws_bytes(n, D)) return MREC_EWORKSPACE;
+    if (ws_bytes < apply_ws_bytes(n, D + (wide ? 4 : 0))) return MREC_EWORKSPACE;
     const size_t nsw = (size_t)mrec_cdiv(n, AW_MIN);
-    const int Dc_max = D > 256 ? 256 : D;
+    const int Dc_max = (D > 256 ? 256 : D) + (wide ? 4 : 0);
     MrecArena a(ws, ws_bytes);
     ApplyWs w;
     w.carry_head = a.take<float>(nsw * Dc_max);
     w.carry_tail = a.take<float>(nsw * Dc_max);
     w.owners = a.take<int>(nsw);
     w.n_owners = a.take<int>(1);
+    w.dummy = a.take<float>(2048 * 16);
     if (!a.ok) return MREC_EWORKSPACE;
     bool aligned = (ld % 4 == 0) && (ldg % 4 == 0) && ((((uintptr_t)g) & (4 * sizeof(GT) - 1)) == 0);
     for (int i = 0; i < Upd::NS; ++i) aligned = aligned && al16(upd.s[i]);
@@ -542,12 +627,13 @@ int apply_impl(Upd upd, int64_t V, int64_t ld, int32_t D, const K* uniq, const i
     for (int i = 0; i < Upd::NS; ++i) aligned8 = aligned8 && ((((uintptr_t)upd.s[i]) & 7) == 0);
     // 16-byte lanes when rows allow it, else 8-byte lanes (D = 30 of the DCN table), else scalar
     const int vec = (aligned && D % 4 == 0) ? 4 : ((aligned8 && D % 2 == 0) ? 2 : 1);
+    if (wide && (vec != 4 || D > 252 || wide->wcol != D || D + 4 > ld || wide->F <= 0 || !wide->gw)) return MREC_EUNSUPPORTED;
     const int CB = 64 * vec;  // columns per launch
     for (int c0 = 0; c0 < D; c0 += CB) {
         const int Dc = (D - c0 < CB) ? D - c0 : CB;
         Upd u2 = upd;
         for (int i = 0; i < Upd::NS; ++i) u2.s[i] = upd.s[i] + c0;
-        int rc = apply_cols<K, Upd, GT>(u2, V, ld, uniq, spos, sseg, seg_offsets, n, g + c0, ldg, rscale, gscale, Dc, vec, w, st);
+        int rc = apply_cols<K, Upd, GT>(u2, V, ld, uniq, spos, sseg, seg_offsets, n, g + c0, ldg, rscale, gscale, Dc, vec, w, st, wide);
         if (rc != MREC_OK) return rc;
     }
     return MREC_OK;
@@ -557,7 +643,8 @@ template <class K, class GT = float>
 int lazy_adam_impl(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D, const K* uniq,
                    const int32_t* spos, const int32_t* sseg, const int32_t* seg_offsets, int64_t n, const GT* g,
                    int64_t ldg, const float* rscale, float lr, float b1, float b2, float eps, float b1_pow,
-                   float b2_pow, float gscale, int nesterov, void* ws, size_t ws_bytes, void* stream) {
+                   float b2_pow, float gscale, int nesterov, void* ws, size_t ws_bytes, void* stream,
+                   const WideArgs* wide = nullptr) {
     if (!uniq && n > 0) return MREC_EINVAL;
     UpdAdam u;
     u.s[0] = p; u.s[1] = m; u.s[2] = v;
@@ -565,7 +652,7 @@ int lazy_adam_impl(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t 
     u.h.b1 = b1; u.h.b2 = b2; u.h.omb1 = 1.0f - b1; u.h.omb2 = 1.0f - b2; u.h.eps = eps; u.h.gscale = gscale;
     u.h.nesterov = nesterov;
     return apply_impl<K, UpdAdam, GT>(u, V, ld, D, uniq, spos, sseg, seg_offsets, n, g, ldg, rscale, gscale, ws, ws_bytes,
-                                  stream);
+                                  stream, wide);
 }
 
 template <class K>
@@ -686,6 +773,32 @@ MREC_API int mrec_sparse_lazy_adam_f16g_i64(float* p, float* m, float* v, int64_
     return lazy_adam_impl<int64_t, f16_t>(p, m, v, V, ld, D, uniq, sorted_pos, sorted_seg, seg_offsets, n,
                                           (const f16_t*)g, ldg, row_scale, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale,
                                           nesterov, ws, ws_bytes, stream);
+}
+
+/* LazyAdam on the deep columns + FTRL on the wide record of the same fused rows, one pass (see include/mrec.h) */
+MREC_API int mrec_sparse_lazy_adam_wide(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D, const void* uniq,
+                                        int32_t uniq_bytes, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                        const int32_t* seg_offsets, int64_t n, const void* g, int32_t g_kind, int64_t ldg,
+                                        const float* row_scale, float lr, float b1, float b2, float eps, float b1_pow,
+                                        float b2_pow, float grad_scale, int nesterov, const float* gw, int32_t F,
+                                        int32_t wide_col, float ftrl_lr, float l1, float l2, float lr_power, void* ws,
+                                        size_t ws_bytes, void* stream) {
+    if ((uniq_bytes != 4 && uniq_bytes != 8) || g_kind < 0 || g_kind > 2) return MREC_EINVAL;
+    WideArgs wa;
+    wa.gw = gw; wa.F = F; wa.wcol = wide_col; wa.magic = 0; wa.dummy = nullptr;
+    wa.h = FtrlH{ftrl_lr, l1, l2, lr_power, grad_scale};
+#define MREC_WIDE_CALL(KT, GT)                                                                                          \
+    return lazy_adam_impl<KT, GT>(p, m, v, V, ld, D, (const KT*)uniq, sorted_pos, sorted_seg, seg_offsets, n, (const GT*)g, ldg, \
+                                  row_scale, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale, nesterov, ws, ws_bytes, stream, &wa)
+    if (uniq_bytes == 4) {
+        if (g_kind == 0) { MREC_WIDE_CALL(int32_t, float); }
+        if (g_kind == 1) { MREC_WIDE_CALL(int32_t, bf16_t); }
+        MREC_WIDE_CALL(int32_t, f16_t);
+    }
+    if (g_kind == 0) { MREC_WIDE_CALL(int64_t, float); }
+    if (g_kind == 1) { MREC_WIDE_CALL(int64_t, bf16_t); }
+    MREC_WIDE_CALL(int64_t, f16_t);
+#undef MREC_WIDE_CALL
 }
 
 MREC_API int mrec_sparse_ftrl_f32_i32(float* var, float* accum, float* linear, int64_t V, int64_t ld, int32_t D,

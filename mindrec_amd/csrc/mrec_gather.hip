@@ -55,15 +55,29 @@ constexpr int GB = 4;  // rows in flight per lane-group
 // Lane-group geometry shared by the row kernels: lpr lanes per row, G = 64/lpr groups per wave.
 struct RowGeom { int lpr; int G; };
 
+// wprod (nullable; float4 path with 16-bit output only): the wide branch's products ride along.  The lane-group gets one
+// lane more (sub == lpr - 1, column D): it loads the float4 [w accum linear pad] that sits right behind the D deep columns of
+// a fused row with the instruction its neighbours load deep columns with, and stores (w * scale, 0) as 8 bytes to
+// wprod[2 i] with the instruction they store four 16-bit values with -- no extra memory instructions (a lane-masked scalar
+// load + store for it cost +13 us).  The output head adds the products up per sample in field order
+// (mrec_head_fwd_bwd_wide), which replaces mrec_wide_sum.
+__device__ __forceinline__ uint2 pack16(const bf16o_t*, const float4& v) {
+    return make_uint2((unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16), (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16));
+}
+__device__ __forceinline__ uint2 pack16(const f16o_t*, const float4& v) { return make_uint2(f2h2(v.x, v.y), f2h2(v.z, v.w)); }
+__device__ __forceinline__ uint2 pack16(const float*, const float4&) { return make_uint2(0u, 0u); }
+
 template <int VEC, class K, class OT = float>
 __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ table, int64_t V, int64_t ld,
                                                      const K* __restrict__ ids, int64_t n,
                                                      const float* __restrict__ row_scale,
-                                                     OT* __restrict__ out, int D, RowGeom gm) {
+                                                     OT* __restrict__ out, int D, RowGeom gm,
+                                                     float* __restrict__ wprod = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
     if (grp >= gm.G) return;
     const int col = sub * VEC;
+    const bool wl = VEC == 4 && sizeof(OT) == 2 && wprod != nullptr && col >= D;      // the wide lane (column D)
     const int64_t wave_row0 = ((int64_t)blockIdx.x * 4 + wave) * (gm.G * GB);
     Vf<VEC> x[GB];
     float sc[GB];
@@ -86,7 +100,22 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
 #pragma unroll
     for (int k = 0; k < GB; ++k) {
         const int64_t i = wave_row0 + (int64_t)k * gm.G + grp;
-        if (i < n) vstore(out + i * D + col, row_scale ? vscale(x[k], sc[k]) : x[k]);
+        if (i < n) {
+            const Vf<VEC> y = row_scale ? vscale(x[k], sc[k]) : x[k];
+            if constexpr (VEC == 4 && sizeof(OT) == 2) {
+              if (wprod != nullptr) {
+                const float4 yv = y.v;
+                uint2 u = pack16((const OT*)nullptr, yv);
+                if (wl) u = make_uint2(__float_as_uint(yv.x), 0u);
+                uint2* dst = wl ? (uint2*)(wprod + 2 * i) : (uint2*)(out + i * D + col);
+                *dst = u;
+              } else {
+                vstore(out + i * D + col, y);
+              }
+            } else {
+                vstore(out + i * D + col, y);
+            }
+        }
     }
 }
 
@@ -367,11 +396,19 @@ __global__ __launch_bounds__(256) void k_dense_adam4_slabs(float4* __restrict__ 
         for (int q = 0; q < sg.n; ++q)
             if (i >= sg.start4[q] && i < sg.start4[q] + sg.len4[q]) k = q;
         if (k >= 0) {
+            // slabs added in slab order, eight loads in flight at a time (a serial loop over 64 bias-gradient slabs is 64
+            // dependent L2 round trips for the threads that own bias elements: it doubled the kernel's time)
             const float4* src = sg.part[k] + (i - sg.start4[k]);
+            const int S = sg.S[k];
+            const int64_t L = sg.len4[k];
             gg = src[0];
-            for (int s = 1; s < sg.S[k]; ++s) {
-                const float4 u = src[(int64_t)s * sg.len4[k]];
-                gg.x += u.x; gg.y += u.y; gg.z += u.z; gg.w += u.w;
+            for (int s0 = 1; s0 < S; s0 += 8) {
+                float4 u[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) u[q] = (s0 + q < S) ? src[(int64_t)(s0 + q) * L] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (s0 + q < S) { gg.x += u[q].x; gg.y += u[q].y; gg.z += u[q].z; gg.w += u[q].w; }
             }
         } else {
             gg = g[i];
@@ -399,17 +436,20 @@ inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 template <class K, class OT = bf16o_t>
 int gather_bf16_impl(const float* table, int64_t V, int64_t ld, int32_t D, const K* ids, int64_t n,
-                     const float* row_scale, uint16_t* out, void* stream) {
+                     const float* row_scale, uint16_t* out, void* stream, int wcol = 0, float* wprod = nullptr) {
+    if (wprod && (wcol != D || D % 4 || D > 252 || ld % 4 || ld < D + 4 || !al16(table) || (((uintptr_t)out) & 7) || (((uintptr_t)wprod) & 7)))
+        return MREC_EUNSUPPORTED;       // the wide word must sit right behind the deep columns of 16-byte aligned rows
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || D <= 0 || V < 0 || ld < D) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
     if (!table || !ids || !out) return MREC_EINVAL;
     const bool vec = (D % 4 == 0) && (D <= 256) && (ld % 4 == 0) && al16(table) && ((((uintptr_t)out) & 7) == 0);
     if (vec) {
-        RowGeom gm{D / 4, 64 / (D / 4)};
+        const int lpr = D / 4 + (wprod ? 1 : 0);
+        RowGeom gm{lpr, 64 / lpr};
         k_gather_rows<4, K, OT><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
-            table, V, ld, ids, n, row_scale, (OT*)out, D, gm);
-    } else if (D <= 64) {
+            table, V, ld, ids, n, row_scale, (OT*)out, D, gm, wprod);
+    } else if (D <= 64 && !wprod) {
         RowGeom gm{D, 64 / D};
         k_gather_rows<1, K, OT><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
             table, V, ld, ids, n, row_scale, (OT*)out, D, gm);
@@ -534,6 +574,20 @@ MREC_API int mrec_gather_rows_f16_i32(const float* table, int64_t V, int64_t ld,
 MREC_API int mrec_gather_rows_f16_i64(const float* table, int64_t V, int64_t ld, int32_t D, const int64_t* ids,
                                       int64_t n, const float* row_scale, uint16_t* out, void* stream) {
     return gather_bf16_impl<int64_t, f16o_t>(table, V, ld, D, ids, n, row_scale, out, stream);
+}
+
+/* Gather + the wide branch's products in one pass (see include/mrec.h): out_kind 1 = bf16, 2 = f16 rows. */
+MREC_API int mrec_gather_rows_wide(const float* table, int64_t V, int64_t ld, int32_t D, const void* ids, int32_t id_bytes,
+                                   int64_t n, const float* row_scale, void* out, int32_t out_kind, int32_t wide_col,
+                                   float* wide_prod, void* stream) {
+    if ((id_bytes != 4 && id_bytes != 8) || (out_kind != 1 && out_kind != 2)) return MREC_EINVAL;
+    if (!wide_prod || wide_col < 0 || wide_col >= ld) return MREC_EINVAL;
+    if (id_bytes == 4) {
+        if (out_kind == 1) return gather_bf16_impl<int32_t, bf16o_t>(table, V, ld, D, (const int32_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod);
+        return gather_bf16_impl<int32_t, f16o_t>(table, V, ld, D, (const int32_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod);
+    }
+    if (out_kind == 1) return gather_bf16_impl<int64_t, bf16o_t>(table, V, ld, D, (const int64_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod);
+    return gather_bf16_impl<int64_t, f16o_t>(table, V, ld, D, (const int64_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod);
 }
 
 MREC_API int mrec_wide_sum_f32_i32(const float* w, int64_t V, int64_t ldw, const int32_t* ids, const float* wts,

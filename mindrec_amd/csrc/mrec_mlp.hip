@@ -152,7 +152,8 @@ __global__ __launch_bounds__(MB) void k_head_fwd_bwd(const uint4* __restrict__ h
                                                      const float* __restrict__ label, int64_t B, int CG,
                                                      int rows_per_block, float dscale, float* __restrict__ logit_out,
                                                      float* __restrict__ dlogit_out, uint4* __restrict__ dh4,
-                                                     float* __restrict__ partial) {
+                                                     float* __restrict__ partial, const float* __restrict__ wprod, int F,
+                                                     const float* __restrict__ wide_bias) {
     __shared__ float red[MB][8];
     __shared__ float red2[MB][2];
     const int cg = threadIdx.x % CG, rl = threadIdx.x / CG, RP = MB / CG;
@@ -182,7 +183,17 @@ __global__ __launch_bounds__(MB) void k_head_fwd_bwd(const uint4* __restrict__ h
         for (int d = CG >> 1; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
         float dl = 0.0f;
         if (valid) {
-            const float z = part + bias + wide[r];
+            float wsum;
+            if (wprod) {
+                // the wide branch from its per-field products (written by the gather): ReduceSum over the fields in field
+                // order, then + Wide_b -- the same adds in the same order as mrec_wide_sum / the CPU restatement
+                float acc_w = 0.0f;
+                for (int f = 0; f < F; ++f) acc_w = acc_w + wprod[2 * (r * F + f)];      // [B, F, 2]: product, pad
+                wsum = acc_w + *wide_bias;
+            } else {
+                wsum = wide[r];
+            }
+            const float z = part + bias + wsum;
             const float y = label[r];
             // SigmoidCrossEntropyWithLogits: max(z,0) - z*y + log(1 + exp(-|z|))
             const float loss = fmaxf(z, 0.0f) - z * y + log1pf(expf(-fabsf(z)));
@@ -301,9 +312,11 @@ MREC_API int mrec_head_workspace_bytes(int64_t B, int32_t K5, size_t* out) {
 static int head_impl(bool f16, const uint16_t* h4, const float* w5, const float* b5, const float* wide,
                      const float* label, int64_t B, int32_t K5, float dscale, float* logit,
                      float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
-                     void* ws, size_t ws_bytes, void* stream) {
+                     void* ws, size_t ws_bytes, void* stream, const float* wprod = nullptr, int F = 0,
+                     const float* wide_bias = nullptr) {
     if (B <= 0 || K5 <= 0) return MREC_EINVAL;
-    if (!h4 || !w5 || !b5 || !wide || !label || !logit || !dlogit || !dh4 || !dw5 || !db4 || !db5 || !loss || !ws) return MREC_EINVAL;
+    if (wprod && (F <= 0 || !wide_bias)) return MREC_EINVAL;
+    if (!h4 || !w5 || !b5 || (!wide && !wprod) || !label || !logit || !dlogit || !dh4 || !dw5 || !db4 || !db5 || !loss || !ws) return MREC_EINVAL;
     if (K5 % 8 || !pow2(K5 / 8) || K5 / 8 > 64) return MREC_EUNSUPPORTED;
     if ((((uintptr_t)h4 | (uintptr_t)dh4) & 15) != 0) return MREC_EINVAL;
     const int CG = K5 / 8, RP = MB / CG;
@@ -314,10 +327,10 @@ static int head_impl(bool f16, const uint16_t* h4, const float* w5, const float*
     hipStream_t st = (hipStream_t)stream;
     if (f16)
         k_head_fwd_bwd<true><<<nb, MB, 0, st>>>((const uint4*)h4, w5, b5, wide, label, B, CG, rows_per_block, dscale, logit, dlogit,
-                                                (uint4*)dh4, (float*)ws);
+                                                (uint4*)dh4, (float*)ws, wprod, F, wide_bias);
     else
         k_head_fwd_bwd<false><<<nb, MB, 0, st>>>((const uint4*)h4, w5, b5, wide, label, B, CG, rows_per_block, dscale, logit, dlogit,
-                                                 (uint4*)dh4, (float*)ws);
+                                                 (uint4*)dh4, (float*)ws, wprod, F, wide_bias);
     k_head_finish<<<(unsigned)mrec_cdiv(2 * K5 + 2, 32), MB, 0, st>>>((const float*)ws, nb, K5, 1.0f / (float)B, dw5, db4, db5, loss);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
@@ -335,4 +348,13 @@ MREC_API int mrec_head_fwd_bwd_f16(const uint16_t* h4, const float* w5, const fl
                                    float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
                                    void* ws, size_t ws_bytes, void* stream) {
     return head_impl(true, h4, w5, b5, wide, label, B, K5, dscale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes, stream);
+}
+
+/* The same head with the wide branch given as per-field products [B, F] + the wide bias (see include/mrec.h). */
+MREC_API int mrec_head_fwd_bwd_wide(int32_t f16, const uint16_t* h4, const float* w5, const float* b5, const float* wide_prod,
+                                    int32_t F, const float* wide_bias, const float* label, int64_t B, int32_t K5, float dscale,
+                                    float* logit, float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    return head_impl(f16 != 0, h4, w5, b5, nullptr, label, B, K5, dscale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes,
+                     stream, wide_prod, F, wide_bias);
 }

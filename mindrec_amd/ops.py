@@ -172,6 +172,28 @@ def gather_rows(table, ids, row_scale=None, out=None, out_dtype=torch.float32):
     return out.view(tuple(ids.shape) + (D,))
 
 
+def gather_rows_wide(table, ids, row_scale, wide_col, out=None, out_dtype=torch.bfloat16):
+    """Both lookups of WideDeepModel.construct (wide_and_deep.py:300-302) in one pass over fused rows: returns
+    (rows [.., D] in out_dtype, wide_prod [.., 2] with [.., 0] = table_row[wide_col] * row_scale and [.., 1] = 0).  `table` is the [V, D] view of the deep
+    columns; wide_col is the column (relative to it, >= D) of the wide weight in the same rows."""
+    _need_cuda(table, ids, row_scale, out)
+    V, D, ld = _table(table)
+    flat = ids.reshape(-1).contiguous()
+    n = flat.numel()
+    if row_scale is not None:
+        row_scale = row_scale.reshape(-1).contiguous()
+        if row_scale.dtype != torch.float32 or row_scale.numel() != n:
+            raise TypeError("row_scale must be float32 with one value per id")
+    if out_dtype not in _DT16:
+        raise TypeError("gather_rows_wide writes bfloat16 or float16 rows")
+    if out is None:
+        out = torch.empty((n, D), dtype=out_dtype, device=table.device)
+    wprod = torch.empty((max(n, 1), 2), dtype=torch.float32, device=table.device)[:n]      # (product, pad) pairs
+    _lib.call("mrec_gather_rows_wide", _ptr(table), V, ld, D, _ptr(flat), flat.element_size(), n, _ptr(row_scale), _ptr(out),
+              1 if out.dtype == torch.bfloat16 else 2, int(wide_col), _ptr(wprod), _stream())
+    return out.view(tuple(ids.shape) + (D,)), wprod.view(tuple(ids.shape) + (2,))
+
+
 def gather_rows_pinned(host_table, ids):
     """Rows of a PINNED HOST table straight into HBM: the same gather kernel reads host memory over PCIe (pinned
     allocations are device-addressable; ~45 GB/s measured).  ids < 0 give zero rows without touching the host."""
@@ -276,6 +298,29 @@ def sparse_lazy_adam_(p, m, v, plan, g, row_scale=None, lr=3.5e-4, beta1=0.9, be
     _lib.call(fn + sfx, _ptr(p), _ptr(m), _ptr(v), V, ld, D, _ptr(plan.uniq_buf),
               _ptr(plan.sorted_pos), _ptr(plan.sorted_seg), _ptr(plan.seg_offsets), plan.n, _ptr(g2), ldg, _ptr(rs), lr,
               beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _ptr(ws), ws.numel(), _stream())
+
+
+def sparse_lazy_adam_wide_(p, m, v, plan, g, row_scale, gw, F, wide_col, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8,
+                           beta1_power=0.9, beta2_power=0.999, grad_scale=1.0, use_nesterov=False, ftrl_lr=5e-2, l1=1e-8, l2=1e-8,
+                           lr_power=-0.5):
+    """LazyAdam on the deep columns and FTRL on the wide record of the same fused rows in ONE pass (wide_and_deep.py:420-430):
+    gw [n / F] is the wide branch's gradient per sample (the head's dlogit); position i contributes gw[i // F] * row_scale[i]."""
+    _need_cuda(p, m, v, g, row_scale, gw)
+    V, D, ld = _table(p)
+    for t in (m, v):
+        if _table(t) != (V, D, ld):
+            raise ValueError("p, m, v must share shape and row stride")
+    g2, ldg = _grads(plan, g, D, allow_bf16=True)
+    rs = _row_scale(plan, row_scale)
+    if gw.dtype != torch.float32 or not gw.is_contiguous() or gw.numel() * F != plan.n:
+        raise TypeError("gw must be contiguous float32 with one value per sample (n / F)")
+    nb = _lib.query_bytes("mrec_sparse_apply_workspace_bytes", max(plan.n, 1), D + 4)
+    ws = workspace("apply", nb, p.device)
+    kind = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[g2.dtype]
+    _lib.call("mrec_sparse_lazy_adam_wide", _ptr(p), _ptr(m), _ptr(v), V, ld, D, _ptr(plan.uniq_buf), plan.uniq_buf.element_size(),
+              _ptr(plan.sorted_pos), _ptr(plan.sorted_seg), _ptr(plan.seg_offsets), plan.n, _ptr(g2), kind, ldg, _ptr(rs), lr,
+              beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _ptr(gw), int(F), int(wide_col),
+              ftrl_lr, l1, l2, lr_power, _ptr(ws), ws.numel(), _stream())
 
 
 def sparse_ftrl_(var, accum, linear, plan, g, row_scale=None, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):
@@ -614,6 +659,29 @@ def head_fwd_bwd(h4, w5, b5, wide, label, dscale, dw5_out, db4_out, db5_out):
     _lib.call("mrec_head_fwd_bwd_" + _DT16[h4.dtype], _ptr(h4.contiguous()), _ptr(w5), _ptr(b5), _ptr(wide.contiguous()),
               _ptr(label.contiguous()), B, K5, float(dscale), _ptr(logit), _ptr(dlogit), _ptr(dh4), _ptr(dw5_out),
               _ptr(db4_out), _ptr(db5_out), _ptr(loss), _ptr(ws), ws.numel(), _stream())
+    return loss, logit, dlogit, dh4
+
+
+def head_fwd_bwd_wide(h4, w5, b5, wide_prod, wide_bias, label, dscale, dw5_out, db4_out, db5_out):
+    """head_fwd_bwd with the wide branch given as the per-field products of gather_rows_wide ([B, F]) + the wide bias:
+    the ReduceSum over the fields (wide_and_deep.py:305-306) happens inside the head, in field order."""
+    _need_cuda(h4, w5, b5, wide_prod, wide_bias, label)
+    B, K5 = h4.shape
+    dev = h4.device
+    if (wide_prod.dtype != torch.float32 or wide_prod.dim() != 3 or wide_prod.shape[0] != B or wide_prod.shape[2] != 2
+            or not wide_prod.is_contiguous()):
+        raise TypeError("wide_prod must be the contiguous float32 [B, F, 2] tensor of gather_rows_wide")
+    if h4.dtype not in _DT16:
+        raise TypeError("h4 must be bfloat16 or float16")
+    logit = torch.empty(B, dtype=torch.float32, device=dev)
+    dlogit = torch.empty(B, dtype=torch.float32, device=dev)
+    dh4 = torch.empty_like(h4)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    nb = _lib.query_bytes("mrec_head_workspace_bytes", B, K5)
+    ws = workspace("head", nb, dev)
+    _lib.call("mrec_head_fwd_bwd_wide", int(h4.dtype == torch.float16), _ptr(h4.contiguous()), _ptr(w5), _ptr(b5), _ptr(wide_prod),
+              wide_prod.shape[1], _ptr(wide_bias), _ptr(label.contiguous()), B, K5, float(dscale), _ptr(logit), _ptr(dlogit),
+              _ptr(dh4), _ptr(dw5_out), _ptr(db4_out), _ptr(db5_out), _ptr(loss), _ptr(ws), ws.numel(), _stream())
     return loss, logit, dlogit, dh4
 
 

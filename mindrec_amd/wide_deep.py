@@ -62,6 +62,8 @@ class WideDeepConfig:
     # apart (fewer DRAM activations and TLB walks per byte: +6-8 % on MI355X); the API still sees
     # p, m, v, w, ... as separate (strided) [V, D] / [V, 1] tensors.  False = three separate arrays.
     fused_state: bool = True
+    fold_wide: bool = True               # one GPU, fused rows, 16-bit MLP: the wide lookup rides the deep gather and the wide FTRL
+                                         # the deep LazyAdam apply (one row visit each); False keeps the separate wide kernels
     overlap_plan: bool = True            # dedup + inverted index (and the wide branch) on a side HIP stream, under the MLP
     overlap_wide_apply: bool = True  # wide-table FTRL on the side stream as soon as the head's backward has produced its gradient:
                                      # a latency-bound kernel hidden under the backward GEMMs (one GPU)
@@ -113,6 +115,13 @@ def _flat_views(shapes, device, dtype=torch.float32):
     return flat, views
 
 
+class _WideProd:
+    """The wide branch as its per-field products [B, F] (written by the fused lookup, summed inside the output head)."""
+
+    def __init__(self, prod):
+        self.prod = prod
+
+
 class _DirectComm:
     """The engine's collectives: torch.distributed on the tensors as they are -- device tensors under backend "nccl"
     (= RCCL over xGMI, the product path), host tensors under gloo (the CPU logic tests).  Test harnesses that put
@@ -145,6 +154,7 @@ class WideDeepEngine:
         collective then talks to itself, which executes the RCCL code path on a single GPU."""
         self.cfg, self.device, self.rank, self.world, self.group = cfg, torch.device(device), rank, world, group
         self._sharded = bool(world > 1 or shard_protocol)
+        self._fold_wide = False       # set below: one GPU, fused rows, 16-bit MLP -> the wide branch rides the deep kernels
         self.k = kernels if kernels is not None else ops
         self.comm = comm if comm is not None else _DirectComm(group)
         self._gpu = self.device.type == "cuda"
@@ -178,6 +188,8 @@ class WideDeepEngine:
         self._mfma = bool(self._gpu and kernels is None and self._amp is not None and nl >= 2 and D % 4 == 0 and D <= 256
                           and all(d % 8 == 0 for d in dims[:-1]))
         self.tuned_gemms = bool(tuned_gemms and self._gpu and not self._mfma and enable_tuned_gemms())
+        self._fold_wide = bool(cfg.fold_wide and self._mfma and not self._sharded and cfg.fused_state and cfg.host_cache_rows == 0 and D <= 252
+                               and self.k.head_supported(dims[nl - 1]))
         with (torch.cuda.device(dev) if self._gpu else contextlib.nullcontext()):
             # deep table + Adam moments, wide table + FTRL accumulators: plain row-major fp32 in HBM
             R = self.local_rows
@@ -192,12 +204,18 @@ class WideDeepEngine:
                 for name in ("deep", "deep_m", "deep_v", "wide", "wide_accum", "wide_linear"):
                     setattr(self, name, self.hb.cols[name])
             elif cfg.fused_state:
-                self.deep_state = torch.empty((R, 3 * D), dtype=torch.float32, device=dev)
-                self.deep, self.deep_m, self.deep_v = (self.deep_state[:, :D], self.deep_state[:, D:2 * D],
-                                                       self.deep_state[:, 2 * D:])
-                self.wide_state = torch.zeros((R, 4), dtype=torch.float32, device=dev)
-                self.wide, self.wide_accum, self.wide_linear = (self.wide_state[:, 0:1], self.wide_state[:, 1:2],
-                                                                self.wide_state[:, 2:3])
+                # ONE row per id: [p(D) | w accum linear pad | m(D) | v(D) | pad], padded to a multiple of 128 bytes (3D + 4 = 244
+                # floats -> 256 floats = 1 KB at D = 80: every row is exactly 8 lines, p + w exactly 3; with 976-byte rows a row
+                # straddles 8.5 lines on average and the lookup 3.5).  The wide weight sits right behind the deep weights (the
+                # line the deep lookup fetches anyway) and its FTRL words inside the run the deep LazyAdam reads and writes anyway:
+                # both lookups and both sparse applies visit a row once.  The API still sees p, m, v [V, D] and w, accum,
+                # linear [V, 1] as (strided) tensors.
+                ldrow = -(-(3 * D + 4) // 32) * 32
+                self.deep_state = torch.zeros((R, ldrow), dtype=torch.float32, device=dev)
+                self.deep, self.deep_m, self.deep_v = (self.deep_state[:, :D], self.deep_state[:, D + 4:2 * D + 4],
+                                                       self.deep_state[:, 2 * D + 4:3 * D + 4])
+                self.wide, self.wide_accum, self.wide_linear = (self.deep_state[:, D:D + 1], self.deep_state[:, D + 1:D + 2],
+                                                                self.deep_state[:, D + 2:D + 3])
             else:
                 self.deep = torch.empty((R, D), dtype=torch.float32, device=dev)
                 self.deep_m, self.deep_v = torch.empty_like(self.deep), torch.empty_like(self.deep)
@@ -348,7 +366,12 @@ class WideDeepEngine:
         B = hs[0].shape[0]
         W5, b5 = self.dense[2 * (n - 1)], self.dense[2 * (n - 1) + 1]
         K5 = self.dims[n - 1]
-        if self.k.head_supported(K5):
+        if isinstance(wide, _WideProd):
+            loss, _, dlogit, dh = self.k.head_fwd_bwd_wide(hs[-1], W5.detach().view(-1), b5.detach(), wide.prod, self.wide_b,
+                                                            label.view(-1), self.cfg.sens / B, self.dense_grad[2 * (n - 1)].view(-1),
+                                                            self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1])
+            loss = loss.view(())
+        elif self.k.head_supported(K5):
             # output layer + wide/deep add + sigmoid cross-entropy, forward AND backward, one pass over h4
             loss, _, dlogit, dh = self.k.head_fwd_bwd(hs[-1], W5.detach().view(-1), b5.detach(), wide, label.view(-1),
                                                        self.cfg.sens / B, self.dense_grad[2 * (n - 1)].view(-1),
@@ -406,7 +429,8 @@ class WideDeepEngine:
         if not (self.cfg.graph_mlp and self._gpu and self.step_count > 2):
             return self._mlp_step_eager(emb, wide, label, after_head=after_head)
         g = self._mlp_graph
-        if g is None or g["emb"].shape != emb.shape or g["emb"].dtype != emb.dtype or (g["graph_head"] is None) == callable(wide):
+        if (g is None or g["emb"].shape != emb.shape or g["emb"].dtype != emb.dtype or (g["graph_head"] is None) == callable(wide)
+                or isinstance(g["wide"], _WideProd) != isinstance(wide, _WideProd)):
             try:
                 g = self._capture_mlp(emb, wide, label)
             except RuntimeError as e:          # capture refused: stay eager
@@ -418,12 +442,20 @@ class WideDeepEngine:
         if emb.data_ptr() != g["emb"].data_ptr():
             g["emb"].copy_(emb)
         g["label"].copy_(label)
+
+        def stage_wide():
+            w_ = wide() if callable(wide) else wide
+            if isinstance(w_, _WideProd):
+                g["wide"].prod.copy_(w_.prod)
+            else:
+                g["wide"].copy_(w_)
+
         if g["graph_head"] is None:
-            g["wide"].copy_(wide() if callable(wide) else wide)
+            stage_wide()
             g["graph_fwd"].replay()                # hidden layers + head in one graph
         else:
             g["graph_fwd"].replay()
-            g["wide"].copy_(wide() if callable(wide) else wide)
+            stage_wide()
             g["graph_head"].replay()
         if after_head is not None:
             after_head(g["ctx"]["g_wide"])
@@ -434,9 +466,9 @@ class WideDeepEngine:
         late = callable(wide)
         if late:
             wide = wide()
-        g = {"emb": torch.empty_like(emb), "wide": torch.empty_like(wide), "label": torch.empty_like(label)}
+        g = {"emb": torch.empty_like(emb), "label": torch.empty_like(label)}
+        g["wide"] = _WideProd(wide.prod.clone()) if isinstance(wide, _WideProd) else wide.clone()
         g["emb"].copy_(emb)
-        g["wide"].copy_(wide)
         g["label"].copy_(label)
         torch.cuda.synchronize(self.device)
         # thread_local: RCCL's watchdog thread may query events while this thread captures
@@ -477,6 +509,12 @@ class WideDeepEngine:
         B, Fd = ids.shape
         if not self._sharded:
             ev = self._tick("gather_deep")
+            if self._fold_wide and torch.is_grad_enabled():
+                # both lookups in one pass over the fused rows; the per-sample sum of the wide products is taken by the head
+                emb, wprod = self.k.gather_rows_wide(self.deep, ids, wts, cfg.emb_dim, out=self._emb_out(B * Fd, cfg.emb_dim, self._amp),
+                                                     out_dtype=self._amp)
+                self._tock(ev)
+                return emb.view(B, Fd * cfg.emb_dim), _WideProd(wprod), None
             if self._mfma and torch.is_grad_enabled():
                 emb = self.k.gather_rows(self.deep, ids, wts, out=self._emb_out(B * Fd, cfg.emb_dim, self._amp),
                                          out_dtype=self._amp).view(B, Fd * cfg.emb_dim)
@@ -616,7 +654,7 @@ class WideDeepEngine:
         # the wide branch on the side stream: on when sharded (hides a collective) and inside the whole-front graph (no
         # graph cut to pay for there); off for the one-GPU MLP-graph path, where it costs an extra graph boundary
         late_cfg = cfg.late_wide if cfg.late_wide is not None else (self._sharded or capturing)
-        late = bool(self._side is not None and late_cfg and self._mfma)
+        late = bool(self._side is not None and late_cfg and self._mfma and not self._fold_wide)
         plan_early = None
         if self.index is not None or self.hb is not None:
             ids, plan_early = self._translate_keys(ids)        # from here on `ids` are table row numbers
@@ -657,7 +695,9 @@ class WideDeepEngine:
         wide_done = False
         if fused:
             after_head = None
-            if plan_early is not None and route is None and cfg.overlap_wide_apply:
+            if self._fold_wide and route is None:
+                wide_done = True             # the wide table's FTRL rides the deep table's apply (train_step)
+            elif plan_early is not None and route is None and cfg.overlap_wide_apply:
                 def after_head(gw_b):
                     # wide FTRL beside the backward GEMMs: needs only the plan (already on the side stream, in order)
                     # and the head's dlogit.  The Mul bprop of wide_mul (:304) is applied as row_scale.
@@ -795,10 +835,17 @@ class WideDeepEngine:
             if self.deep_apply_timer is not None:
                 self.deep_apply_timer.arm()
                 self.deep_apply_timer = None
-            self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, lr=cfg.adam_lr,
-                                  beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
-                                  beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
-                                  grad_scale=inv_sens)
+            if self._fold_wide and fused:
+                # LazyAdam on the deep columns + FTRL on the wide record of the same rows: one visit per touched row
+                self.k.sparse_lazy_adam_wide_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, g_wide, Fd, D,
+                                              lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
+                                              beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
+                                              grad_scale=inv_sens, ftrl_lr=cfg.ftrl_lr, l1=cfg.ftrl_l1, l2=cfg.ftrl_l2)
+            else:
+                self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, lr=cfg.adam_lr,
+                                         beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
+                                         beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
+                                         grad_scale=inv_sens)
             self._tock(ev)
             if not wide_done:
                 ev = self._tick("apply_wide")

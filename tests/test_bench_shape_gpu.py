@@ -59,7 +59,12 @@ def test_one_step_layer_by_layer_vs_mixed_oracle(dev, oracle, dt):
     tid, twt, tl = ids.to(dev), wts.to(dev), label.to(dev)
     emb, wide, _ = g.lookup(tid, twt)
     assert np.array_equal(emb.float().cpu().numpy(), r["emb"]), "looked-up rows: one rounding of an fp32 product, must be bit-exact"
-    assert np.array_equal(wide.cpu().numpy(), r["wide"])
+    # the wide branch arrives as per-field products (fused lookup); their sum in field order + bias is the oracle's wide_sum
+    wp = wide.prod.cpu().numpy()[..., 0]
+    acc = np.zeros(B, np.float32)
+    for f in range(Fd):
+        acc = acc + wp[:, f]
+    assert np.array_equal(acc + g.wide_b.cpu().numpy()[0], r["wide"])
     hs = g._mlp_fwd(emb)
     # --- forward, each layer fed with the ORACLE's previous activation (isolates the kernel) and free-running
     for i in range(1, len(hs)):

@@ -36,11 +36,11 @@ def ids_case(kind, n, V, rng, dtype):
 
 def crossing(plan, D):
     """Per unique id: does its run of sorted entries cross a window boundary of the apply kernel?
-    (runs inside one window are summed in oracle order; window = 16 entries on the float4 path, 8
-    on the scalar path -- mrec_sparse_apply_window)."""
+    (runs inside one window are summed in oracle order; the window -- 8 entries on every path today -- is
+    whatever mrec_sparse_apply_window reports)."""
     from mindrec_amd import ops
     AW = ops.apply_window(D)
-    assert AW in (8, 16)
+    assert AW == 8
     offs = plan.seg_offsets[: plan.U + 1].cpu().numpy().astype(np.int64)
     return (offs[:-1] // AW) != ((offs[1:] - 1) // AW)
 
@@ -599,3 +599,66 @@ def test_fm_term(dev, oracle, B, F, D):
     g = T(g0, dev)
     ops.fm_backward_(g, T(vx, dev), cs, T(dout, dev))
     assert np.allclose(g.cpu().numpy(), g0 + oracle.fm_backward(vx, rcs, dout), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kind,D,F", [("uniform", 80, 26), ("zipf", 80, 39), ("same", 16, 4), ("hot", 16, 13)])
+def test_fused_row_kernels_wide_branch(dev, oracle, dtype, kind, D, F):
+    """The wide branch riding the deep kernels over fused rows [p | w accum linear pad | m | v]:
+    gather_rows_wide (rows + per-field products), head_fwd_bwd_wide (sum of the products in field order) and
+    sparse_lazy_adam_wide_ (LazyAdam + FTRL in one pass) against the oracle's separate restatements."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(D * 100 + F)
+    V, B = 3000, 512
+    ld = -(-(3 * D + 4) // 32) * 32 if kind != "hot" else 3 * D + 4       # 128-byte aligned rows (the engine's), and tight ones
+    state = torch.zeros((V, ld), dtype=torch.float32, device=dev)
+    p, m, v = state[:, :D], state[:, D + 4:2 * D + 4], state[:, 2 * D + 4:3 * D + 4]
+    w, wa, wl = state[:, D:D + 1], state[:, D + 1:D + 2], state[:, D + 2:D + 3]
+    ops.fill_normal_(p, seed=5, sigma=0.01); ops.fill_normal_(w, seed=6, sigma=0.01); wa.fill_(1.0)
+    rp, rm, rv = oracle.fill_normal(5, V, D, 0.01), np.zeros((V, D), np.float32), np.zeros((V, D), np.float32)
+    rw, rwa, rwl = oracle.fill_normal(6, V, 1, 0.01), np.ones((V, 1), np.float32), np.zeros((V, 1), np.float32)
+    ids = ids_case(kind, B * F, V, rng, np.int32).reshape(B, F)
+    ids[0, 0] = V + 3                                                   # out of range: zero row, zero product, no update
+    wts = rng.random((B, F)).astype(np.float32)
+    tid, twt = T(ids, dev), T(wts, dev)
+    dname = "bf16" if dtype == torch.bfloat16 else "f16"
+    emb, wprod = ops.gather_rows_wide(p, tid, twt, D, out_dtype=dtype)
+    assert np.array_equal(emb.float().cpu().numpy(), oracle.round16(oracle.gather_rows(rp, ids, wts), dname))
+    ref_prod = oracle.gather_rows(rw, ids, wts).reshape(B, F)
+    assert np.array_equal(wprod.cpu().numpy()[..., 0], ref_prod) and (wprod[..., 1] == 0).all()
+    # head: the sum of the products inside the head == the head on the oracle's wide sum, bit for bit
+    K5 = 128
+    h4 = T(np.maximum(rng.standard_normal((B, K5)), 0).astype(np.float32), dev).to(dtype)
+    w5 = T((rng.standard_normal(K5) * 0.1).astype(np.float32), dev); b5 = T(np.array([0.3], np.float32), dev)
+    wb = T(np.array([-0.2], np.float32), dev)
+    label = T((rng.random(B) < 0.3).astype(np.float32), dev)
+    outs = []
+    for mode in ("prod", "sum"):
+        dw5 = torch.zeros(K5, device=dev); db4 = torch.zeros(K5, device=dev); db5 = torch.zeros(1, device=dev)
+        if mode == "prod":
+            r = ops.head_fwd_bwd_wide(h4, w5, b5, wprod.contiguous(), wb, label, 2.0, dw5, db4, db5)
+        else:
+            wide = T(oracle.wide_sum(rw, ids, wts, -0.2), dev)
+            r = ops.head_fwd_bwd(h4, w5, b5, wide, label, 2.0, dw5, db4, db5)
+        outs.append([t.clone() for t in r] + [dw5, db4, db5])
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    # apply: deep LazyAdam + wide FTRL in one pass vs the oracle's two applies
+    g = (rng.standard_normal((B * F, D)) * 1.024).astype(np.float32)
+    g16 = oracle.round16(g, dname)
+    gw = (rng.standard_normal(B) * 1.024).astype(np.float32)
+    plan = ops.sparse_plan(tid)
+    ops.sparse_lazy_adam_wide_(p, m, v, plan, T(g16, dev).to(dtype), twt, T(gw, dev), F, D, grad_scale=1 / 1024)
+    oracle.sparse_lazy_adam(rp, rm, rv, ids, g16, wts, grad_scale=1 / 1024)
+    oracle.sparse_ftrl(rw, rwa, rwl, ids, np.repeat(gw, F).reshape(B * F, 1), wts, grad_scale=1 / 1024)
+    cross = plan.uniq.cpu().numpy()[crossing(plan, D)]
+    inwin = np.ones(V, bool)
+    inwin[cross[(cross >= 0) & (cross < V)]] = False                    # rows whose run stays inside one window: bit-exact
+    gp, gw_, gwa, gwl = p.cpu().numpy(), w.cpu().numpy(), wa.cpu().numpy(), wl.cpu().numpy()
+    assert np.array_equal(gp[inwin], rp[inwin]) and np.array_equal(m.cpu().numpy()[inwin], rm[inwin])
+    assert np.array_equal(gw_[inwin], rw[inwin]) and np.array_equal(gwa[inwin], rwa[inwin]) and np.array_equal(gwl[inwin], rwl[inwin])
+    assert inwin.sum() > V // 2
+    den = np.maximum(np.abs(rp).max(axis=1), 1e-30)
+    assert float((np.abs(gp - rp).max(axis=1) / den).max()) <= 1e-5
+    assert np.abs(gw_ - rw).max() <= 1e-4 * np.abs(rw).max() and np.allclose(gwa, rwa, rtol=1e-5)
+    assert (state[:, D + 3] == 0).all() and (state[:, 3 * D + 4:] == 0).all()        # the pad words are never written

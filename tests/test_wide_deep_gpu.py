@@ -122,7 +122,7 @@ def test_mfma_mlp_step_matches_torch_fp32_reference(dev):
         n = len(e.dims) - 1
         params = [p.detach().clone().requires_grad_(True) for p in e.dense]
         x = emb.detach().clone().requires_grad_(True)
-        wd = wide.detach().clone().requires_grad_(True)
+        wd = (wide.prod[..., 0].sum(dim=1) + e.wide_b).detach().clone().requires_grad_(True)      # the fused lookup's per-field products
         with torch.enable_grad():
             h = x
             for i in range(n - 1):
@@ -245,7 +245,7 @@ def test_host_cached_tables_engine_equals_resident_engine(dev):
     and the engine trains bit-identically to the fully resident one; the flushed host table equals the resident tables."""
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     kw = dict(vocab_size=30000, emb_dim=16, field_size=26, batch_size=256, deep_layer_dim=[64, 32], mlp_dtype="bf16")
-    a = WideDeepEngine(WideDeepConfig(**kw), dev)
+    a = WideDeepEngine(WideDeepConfig(fold_wide=False, **kw), dev)      # the cache tier runs the separate wide kernels: same sum trees
     b = WideDeepEngine(WideDeepConfig(host_cache_rows=8000, **kw), dev)
     for s in range(12):
         ids, wts, label = synthetic_batch(a.cfg, dev, "uniform" if s % 3 == 0 else "zipf", seed=500 + s)
@@ -253,7 +253,7 @@ def test_host_cached_tables_engine_equals_resident_engine(dev):
         assert la == lb, (s, la, lb)
     st = b.hb.stats
     assert st["evictions"] > 0 and st["misses"] > 8000 and st["hits"] > 0
-    full = b.hb.full_table()                                       # [V, 3D + 4] on the host
+    full = b.hb.full_table()                                       # [V, 3D + 4] on the host: p | m | v | w accum linear pad
     D = 16
     ref = torch.cat([a.deep, a.deep_m, a.deep_v, a.wide, a.wide_accum, a.wide_linear], dim=1).cpu()
     assert torch.equal(full[:, : 3 * D + 3], ref)
@@ -281,3 +281,29 @@ def test_weight_gradient_slabs_and_graph_switching(dev):
     assert len(a._dw) == 4 and a._dw[0].dtype == torch.float32          # four hidden layers, fp32 slabs
     assert torch.equal(a.dense_flat.detach(), b.dense_flat.detach())
     assert torch.equal(a.deep, b.deep)
+
+
+def test_folded_wide_branch_equals_separate_wide_kernels(dev):
+    """fold_wide (default on one GPU): the wide lookup rides the deep gather, the per-sample sum is taken inside the head and
+    the wide FTRL rides the deep LazyAdam apply.  Same adds in the same order as the separate kernels wherever an id's run
+    of duplicates fits the short-run path, a different (fixed) tree above it: losses and deep tables bit-identical on uniform
+    ids, wide table within 1e-6 of its scale on Zipf ids with hot rows."""
+    from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
+    kw = dict(vocab_size=40000, emb_dim=80, field_size=26, batch_size=2048, deep_layer_dim=[128, 64], mlp_dtype="bf16")
+    for dist_kind in ("uniform", "zipf"):
+        a = WideDeepEngine(WideDeepConfig(fold_wide=True, **kw), dev)
+        b = WideDeepEngine(WideDeepConfig(fold_wide=False, **kw), dev)
+        assert a._fold_wide and not b._fold_wide
+        for s in range(6):
+            batch = synthetic_batch(a.cfg, dev, dist_kind, seed=40 + s)
+            la, lb = float(a.train_step(*batch)), float(b.train_step(*batch))
+            if dist_kind == "uniform":
+                assert la == lb, (s, la, lb)
+            else:
+                assert abs(la - lb) <= 1e-6 * abs(lb)
+        if dist_kind == "uniform":
+            assert torch.equal(a.deep, b.deep) and torch.equal(a.wide, b.wide) and torch.equal(a.wide_accum, b.wide_accum)
+            assert torch.equal(a.dense_flat.detach(), b.dense_flat.detach())
+        else:
+            assert float((a.wide - b.wide).abs().max()) <= 1e-5 * float(b.wide.abs().max())
+            assert float((a.deep - b.deep).abs().max()) <= 1e-5 * float(b.deep.abs().max())
