@@ -261,9 +261,13 @@ int mrec_dense_fwd_f16(const uint16_t* x, int64_t ldx, const uint16_t* w, const 
  *   dx[m, k] = h[m, k] > 0 ? sum_n dy[m, n] * w[k, n] : 0      (h nullable: no mask -- the first layer's input)
  *   db[k]    = sum_m dx[m, k]                                  (db nullable; sums of the rounded dx, fp32, fixed order)
  * N % 8 == 0, K % 4 == 0.  ws: mrec_dense_bwd_input_workspace_bytes(M, K) bytes when db != NULL.  With db == NULL and
- * ws != NULL the per-tile-row column sums are left in ws as ceil(M/256) fp32 slabs of K (slab t = rows [256 t, 256 t + 256));
+ * ws != NULL the per-tile-row column sums are left in ws as T fp32 slabs of K (T from mrec_dense_bwd_bias_slabs);
  * mrec_dense_adam_slabs_f32 / mrec_dense_sum_slabs_f32 add them up in slab order. */
 int mrec_dense_bwd_input_workspace_bytes(int64_t M, int32_t K, size_t* out);
+/* Rows T of the bias-gradient slabs [T, K] that mrec_dense_bwd_* (fused != 0) or mrec_dense_bwd_input_* (fused == 0) with
+ * db == NULL leave in ws for this shape on this device: one per row tile of the configuration the library picks
+ * (256 or 128 batch rows per tile). */
+int mrec_dense_bwd_bias_slabs(int64_t M, int32_t K, int32_t N, int fused, int32_t* rows_out);
 int mrec_dense_bwd_input_bf16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M, int32_t K,
                               int32_t N, uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, void* stream);
 int mrec_dense_bwd_input_f16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M, int32_t K,
@@ -365,6 +369,11 @@ int mrec_map_export(mrec_map_t* h, int64_t* keys_out, int32_t* rows_out, int64_t
 int mrec_init_rows_f32(float* table, int64_t ld, int32_t D, const int32_t* rows, const int64_t* keys,
                        const uint8_t* is_new, int64_t n, const int64_t* n_dev, uint64_t seed, float sigma,
                        float fill, void* stream);
+/* Three device-to-device copies in ONE launch: a step's ids / weights / labels (the dataset contract of
+ * models/wide_deep/src/datasets.py:212-216) into the static input buffers of the step's HIP graph.  Sizes are multiples
+ * of 16 bytes, pointers 16-byte aligned. */
+int mrec_copy3(void* dst0, const void* src0, int64_t bytes0, void* dst1, const void* src1, int64_t bytes1, void* dst2,
+               const void* src2, int64_t bytes2, void* stream);
 /* out[i] = table[idx[i]] for int32 arrays (idx[i] < 0 gives -1): rows_of_position = rows_of_unique[inv]. */
 int mrec_compose_i32(const int32_t* table, const int32_t* idx, int64_t n, int32_t* out, void* stream);
 /* int32 -> int64 widening of key arrays (MapParameter key_dtype int32). */

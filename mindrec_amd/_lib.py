@@ -82,6 +82,7 @@ _SIGS = {
     "mrec_dense_fwd_bf16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp],
     "mrec_dense_fwd_f16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp],
     "mrec_dense_bwd_input_workspace_bytes": [_i64, _i32, _szp],
+    "mrec_dense_bwd_bias_slabs": [_i64, _i32, _i32, _int, C.POINTER(C.c_int32)],
     "mrec_dense_bwd_input_bf16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp],
     "mrec_dense_bwd_input_f16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp],
     "mrec_dense_bwd_weight_slabs": [_i64, _i32, _i32, C.POINTER(C.c_int32)],
@@ -105,6 +106,7 @@ _SIGS = {
     "mrec_map_erase": [_vp, _vp, _i64, _vp, _sz, _vp],
     "mrec_map_export": [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_init_rows_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _u64, _f32, _f32, _vp],
+    "mrec_copy3": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp],
     "mrec_compose_i32": [_vp, _vp, _i64, _vp, _vp],
     "mrec_widen_i32_i64": [_vp, _i64, _vp, _vp],
     "mrec_scatter_rows_f32": [_vp, _i64, _i32, _vp, _i64, _vp, _vp],

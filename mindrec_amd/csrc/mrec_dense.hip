@@ -28,6 +28,12 @@ int cu_count() {
     return g_cu_count;
 }
 
+// Tile configuration: the 256 x 256 tile when its workgroups fill the chip, else the 128 x 256 one (twice the
+// workgroups, half the time per K-tile: the narrow layers are bound by the latency of one workgroup's K loop).
+inline int pick_mr(int64_t blocks_256) { return blocks_256 * 4 >= (int64_t)cu_count() * 3 ? 8 : 4; }
+int bwd_input_mr(int64_t M, int32_t K);
+int bwd_mr(int64_t M, int32_t K, int32_t N);
+
 // db[k] = sum over tile rows of the per-tile column sums.  Thread (c, q) of a block adds the tile rows t = q, q + 4, ...
 // of column c with all its loads in flight (a serial loop over the tile rows is one dependent L2 round trip per row:
 // 17 us for 64 rows); the four partial sums are then added in q order: a fixed order, reproducible run to run.
@@ -73,27 +79,29 @@ int fwd_impl(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bia
     if (!x || !w || !y) return MREC_EINVAL;
     if (K % 8 || N % 8 || ldx % 8 || ldy % 4 || !al16(x) || !al16(w) || (((uintptr_t)y) & 7)) return MREC_EUNSUPPORTED;
     if (M * ldx * 2 >= (int64_t(1) << 31) || (int64_t)K * N * 2 >= (int64_t(1) << 31) || M > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
+    const int mr = pick_mr(mrec_cdiv(M, 256) * mrec_cdiv(N, 256));
     Args a{};
     a.P = x; a.Q = w; a.C = y; a.bias = bias;
     a.ldp = ldx; a.ldq = N; a.ldc = ldy;
     a.Pext = (int)M; a.Qext = N; a.K = K;
-    a.nTp = (int)mrec_cdiv(M, 256); a.nTq = (int)mrec_cdiv(N, 256);
+    a.nTp = (int)mrec_cdiv(M, mr * 32); a.nTq = (int)mrec_cdiv(N, 256);
     a.kt_per_slab = (K + 63) / 64;
     a.relu = relu;
-    mgemm::k_gemm256<false, true, mgemm::EPI_FWD, F16><<<a.nTp * a.nTq, mgemm::kThreads, 0, (hipStream_t)stream>>>(a);
+    if (mr == 8) mgemm::k_gemm256<false, true, mgemm::EPI_FWD, F16, 0, 8><<<a.nTp * a.nTq, mgemm::kThreads, 0, (hipStream_t)stream>>>(a);
+    else mgemm::k_gemm256<false, true, mgemm::EPI_FWD, F16, 0, 4><<<a.nTp * a.nTq, mgemm::kThreads, 0, (hipStream_t)stream>>>(a);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
 
 // argument checks + Args of the two bprops (shared by the separate and the fused entry points)
 int bwd_input_args(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M, int32_t K, int32_t N,
-                   uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, Args* out) {
+                   uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, int mr, Args* out) {
     if (M <= 0 || K <= 0 || N <= 0 || lddy < N || lddx < K) return MREC_EINVAL;
     if (!dy || !w || !dx) return MREC_EINVAL;
     if (N % 8 || K % 4 || lddy % 8 || lddx % 4 || !al16(dy) || !al16(w) || (((uintptr_t)dx) & 7) || (h && (((uintptr_t)h) & 7)))
         return MREC_EUNSUPPORTED;
     if (M * lddy * 2 >= (int64_t(1) << 31) || (int64_t)K * N * 2 >= (int64_t(1) << 31) || M > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
-    const int nTp = (int)mrec_cdiv(M, 256);
+    const int nTp = (int)mrec_cdiv(M, mr * 32);
     float* part = nullptr;
     if (db || ws) {             // ws without db: leave the per-tile-row column sums there for the caller (the dense Adam adds them)
         if (!ws || ws_bytes < (size_t)nTp * K * 4) return MREC_EWORKSPACE;
@@ -110,7 +118,7 @@ int bwd_input_args(const uint16_t* dy, int64_t lddy, const uint16_t* w, const ui
 }
 
 int bwd_weight_args(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t lddy, int64_t M, int32_t K, int32_t N, int32_t S,
-                    float* dw, Args* out) {
+                    float* dw, int mr, Args* out) {
     if (M <= 0 || K <= 0 || N <= 0 || S <= 0 || ldx < K || lddy < N) return MREC_EINVAL;
     if (!dw || !x || !dy) return MREC_EINVAL;
     if (K % 8 || N % 8 || ldx % 8 || lddy % 8 || !al16(x) || !al16(dy) || !al16(dw)) return MREC_EUNSUPPORTED;
@@ -119,7 +127,7 @@ int bwd_weight_args(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t 
     a.P = x; a.Q = dy; a.C = dw;
     a.ldp = ldx; a.ldq = lddy; a.ldc = N;
     a.Pext = K; a.Qext = N; a.K = (int)M;
-    a.nTp = (int)mrec_cdiv(K, 256); a.nTq = (int)mrec_cdiv(N, 256);
+    a.nTp = (int)mrec_cdiv(K, mr * 32); a.nTq = (int)mrec_cdiv(N, 256);
     const int Ttot = (int)mrec_cdiv(M, 64);
     a.kt_per_slab = (Ttot + S - 1) / S;
     a.slab_stride = (int64_t)K * N;
@@ -135,17 +143,26 @@ int bwd_input_impl(const uint16_t* dy, int64_t lddy, const uint16_t* w, const ui
         return MREC_OK;
     }
     Args a;
-    const int rc = bwd_input_args(dy, lddy, w, h, M, K, N, dx, lddx, db, ws, ws_bytes, &a);
+    const int mr = bwd_input_mr(M, K);
+    const int rc = bwd_input_args(dy, lddy, w, h, M, K, N, dx, lddx, db, ws, ws_bytes, mr, &a);
     if (rc != MREC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    mgemm::k_gemm256<false, false, mgemm::EPI_DGRAD, F16><<<a.nTp * a.nTq, mgemm::kThreads, 0, st>>>(a);
+    if (mr == 8) mgemm::k_gemm256<false, false, mgemm::EPI_DGRAD, F16, 0, 8><<<a.nTp * a.nTq, mgemm::kThreads, 0, st>>>(a);
+    else mgemm::k_gemm256<false, false, mgemm::EPI_DGRAD, F16, 0, 4><<<a.nTp * a.nTq, mgemm::kThreads, 0, st>>>(a);
     if (db) k_colsum_tiles<<<(unsigned)mrec_cdiv(K, 64), 256, 0, st>>>(a.colsum_ws, a.nTp, K, db);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
 
-int weight_slabs(int64_t M, int32_t K, int32_t N) {
-    const int64_t tiles = mrec_cdiv(K, 256) * mrec_cdiv(N, 256);
+// the configurations of a layer's two bprops, each by the workgroups it would have with 256 x 256 tiles
+int weight_slabs_mr(int64_t M, int32_t K, int32_t N, int mr);
+int bwd_mr(int64_t M, int32_t K, int32_t N) {            // weight gradient
+    return pick_mr(mrec_cdiv(K, 256) * mrec_cdiv(N, 256) * weight_slabs_mr(M, K, N, 8));
+}
+int bwd_input_mr(int64_t M, int32_t K) { return pick_mr(mrec_cdiv(M, 256) * mrec_cdiv(K, 256)); }
+
+int weight_slabs_mr(int64_t M, int32_t K, int32_t N, int mr) {
+    const int64_t tiles = mrec_cdiv(K, mr * 32) * mrec_cdiv(N, 256);
     const int64_t Ttot = mrec_cdiv(M, 64);
     int64_t S = cu_count() / tiles;
     // each slab is K*N fp32 written once and read once by the optimizer: beyond 16 slabs keep them within 16 MB in all
@@ -158,6 +175,7 @@ int weight_slabs(int64_t M, int32_t K, int32_t N) {
     if (S < 1) S = 1;
     return (int)S;
 }
+int weight_slabs(int64_t M, int32_t K, int32_t N) { return weight_slabs_mr(M, K, N, bwd_mr(M, K, N)); }
 
 template <bool F16>
 int bwd_weight_impl(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t lddy, int64_t M, int32_t K, int32_t N, int32_t S,
@@ -168,9 +186,11 @@ int bwd_weight_impl(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t 
         return MREC_OK;
     }
     Args a;
-    const int rc = bwd_weight_args(x, ldx, dy, lddy, M, K, N, S, dw, &a);
+    const int mr = bwd_mr(M, K, N);
+    const int rc = bwd_weight_args(x, ldx, dy, lddy, M, K, N, S, dw, mr, &a);
     if (rc != MREC_OK) return rc;
-    mgemm::k_gemm256<true, true, mgemm::EPI_F32, F16><<<a.nTp * a.nTq * S, mgemm::kThreads, 0, st>>>(a);
+    if (mr == 8) mgemm::k_gemm256<true, true, mgemm::EPI_F32, F16, 0, 8><<<a.nTp * a.nTq * S, mgemm::kThreads, 0, st>>>(a);
+    else mgemm::k_gemm256<true, true, mgemm::EPI_F32, F16, 0, 4><<<a.nTp * a.nTq * S, mgemm::kThreads, 0, st>>>(a);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -179,13 +199,20 @@ template <bool F16>
 int bwd_impl(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x, int64_t ldx, int64_t M,
              int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_ws, size_t db_ws_bytes, int32_t S, float* dw, void* stream) {
     Args ad, aw;
-    int rc = bwd_input_args(dy, lddy, w, h, M, K, N, dx, lddx, nullptr, db_ws, db_ws_bytes, &ad);
+    const int mrd = bwd_input_mr(M, K), mrw = bwd_mr(M, K, N);
+    int rc = bwd_input_args(dy, lddy, w, h, M, K, N, dx, lddx, nullptr, db_ws, db_ws_bytes, mrd, &ad);
     if (rc != MREC_OK) return rc;
-    rc = bwd_weight_args(x, ldx, dy, lddy, M, K, N, S, dw, &aw);
+    rc = bwd_weight_args(x, ldx, dy, lddy, M, K, N, S, dw, mrw, &aw);
     if (rc != MREC_OK) return rc;
     const int nd = ad.nTp * ad.nTq, nw = aw.nTp * aw.nTq * S;
-    const int wfirst = aw.kt_per_slab >= ad.kt_per_slab;       // longer workgroups first
-    mgemm::k_gemm256_bwd<F16><<<nd + nw, mgemm::kThreads, 0, (hipStream_t)stream>>>(ad, aw, wfirst ? nw : nd, wfirst);
+    // longer workgroups first (time per K-tile goes with the tile height)
+    const int wfirst = (int64_t)aw.kt_per_slab * mrw >= (int64_t)ad.kt_per_slab * mrd;
+    hipStream_t st = (hipStream_t)stream;
+    const int n1 = wfirst ? nw : nd;
+    if (mrd == 8 && mrw == 8) mgemm::k_gemm256_bwd<F16, 8, 8><<<nd + nw, mgemm::kThreads, 0, st>>>(ad, aw, n1, wfirst);
+    else if (mrd == 8) mgemm::k_gemm256_bwd<F16, 8, 4><<<nd + nw, mgemm::kThreads, 0, st>>>(ad, aw, n1, wfirst);
+    else if (mrw == 8) mgemm::k_gemm256_bwd<F16, 4, 8><<<nd + nw, mgemm::kThreads, 0, st>>>(ad, aw, n1, wfirst);
+    else mgemm::k_gemm256_bwd<F16, 4, 4><<<nd + nw, mgemm::kThreads, 0, st>>>(ad, aw, n1, wfirst);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -203,7 +230,15 @@ MREC_API int mrec_dense_fwd_f16(const uint16_t* x, int64_t ldx, const uint16_t* 
 
 MREC_API int mrec_dense_bwd_input_workspace_bytes(int64_t M, int32_t K, size_t* out) {
     if (!out || M < 0 || K <= 0) return MREC_EINVAL;
-    *out = mrec_align_up((size_t)mrec_cdiv(M > 0 ? M : 1, 256) * K * 4, 256);
+    *out = mrec_align_up((size_t)mrec_cdiv(M > 0 ? M : 1, 128) * K * 4, 256);        // enough for either tile configuration
+    return MREC_OK;
+}
+/* rows of the bias-gradient slabs mrec_dense_bwd_* (fused = 1) / mrec_dense_bwd_input_* (fused = 0) leave in ws */
+MREC_API int mrec_dense_bwd_bias_slabs(int64_t M, int32_t K, int32_t N, int fused, int32_t* rows_out) {
+    if (!rows_out || M < 0 || K <= 0 || N <= 0) return MREC_EINVAL;
+    (void)fused; (void)N;                      // both entry points tile the input gradient the same way
+    const int mr = bwd_input_mr(M, K);
+    *rows_out = (int32_t)mrec_cdiv(M > 0 ? M : 1, mr * 32);
     return MREC_OK;
 }
 MREC_API int mrec_dense_bwd_input_bf16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M,

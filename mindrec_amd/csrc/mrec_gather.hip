@@ -609,6 +609,35 @@ __global__ __launch_bounds__(256) void k_widen(const int* __restrict__ in, int64
     if (i < n) out[i] = (int64_t)in[i];
 }
 
+// three device-to-device copies in one launch (a step's ids / weights / labels into the static inputs of its HIP graph)
+struct Copy3 { uint4* dst[3]; const uint4* src[3]; int64_t n16[3]; };
+__global__ __launch_bounds__(256) void k_copy3(Copy3 c) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < c.n16[k]; i += stride) c.dst[k][i] = c.src[k][i];
+}
+
+MREC_API int mrec_copy3(void* dst0, const void* src0, int64_t bytes0, void* dst1, const void* src1, int64_t bytes1, void* dst2,
+                        const void* src2, int64_t bytes2, void* stream) {
+    void* d[3] = {dst0, dst1, dst2};
+    const void* sp[3] = {src0, src1, src2};
+    const int64_t b[3] = {bytes0, bytes1, bytes2};
+    Copy3 c;
+    int64_t most = 0;
+    for (int k = 0; k < 3; ++k) {
+        if (b[k] < 0 || (b[k] > 0 && (!d[k] || !sp[k]))) return MREC_EINVAL;
+        if (b[k] % 16 || (((uintptr_t)d[k] | (uintptr_t)sp[k]) & 15)) return MREC_EUNSUPPORTED;
+        c.dst[k] = (uint4*)d[k]; c.src[k] = (const uint4*)sp[k]; c.n16[k] = b[k] / 16;
+        if (c.n16[k] > most) most = c.n16[k];
+    }
+    if (most == 0) return MREC_OK;
+    const unsigned g = (unsigned)(mrec_cdiv(most, 256) < 1024 ? mrec_cdiv(most, 256) : 1024);
+    k_copy3<<<g, 256, 0, (hipStream_t)stream>>>(c);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
 MREC_API int mrec_compose_i32(const int32_t* table, const int32_t* idx, int64_t n, int32_t* out, void* stream) {
     if (n < 0) return MREC_EINVAL;
     if (n == 0) return MREC_OK;

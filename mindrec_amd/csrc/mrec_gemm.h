@@ -24,6 +24,11 @@
 // holds at most 32 k its second k-step is skipped altogether.  K-contiguous operands need K % 8 == 0.
 // Accumulators hold C transposed (MFMA "A" = Q fragment, "B" = P fragment), so a lane owns 4 consecutive q of
 // one p: 8-byte (16-bit output) / 16-byte (fp32 output) stores.
+//
+// Tile configurations (MR = 16-row repeats of the P side per wave; 8 waves as 2 x 4, Q tile always 256):
+//   MR = 8   256 x 256 tile, 2 LDS buffers (128 KB), 4 phases per K-tile         -- the layers that fill the chip with it
+//   MR = 4   128 x 256 tile, 3 LDS buffers (144 KB), 2 phases per K-tile         -- the narrow layers: twice the workgroups,
+//            half the time per K-tile; a phase is again 4 P reps x 2 Q reps x 2 k-steps = 16 MFMAs
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -89,15 +94,18 @@ template <> struct Elem<true> {
 };
 
 constexpr int kThreads = 512;
-constexpr int kLdsBytes = 131072;
+template <int MR> struct Lds { static constexpr int bytes = MR == 8 ? 131072 : 147456; };
 constexpr uint32_t kOob = 0x80000000u;      // voffset beyond any buffer: the load is dropped (zero fill), nothing is fetched
 
 __device__ __forceinline__ constexpr int slot_off(int buf, int type) { return (buf * 4 + type) * 16384; }
 
-// The body: one workgroup computes tile `bid` of the `nblk` tiles of problem `a`; smem = the kernel's 128 KB of LDS.
-template <bool PT, bool QT, int EPI, bool F16, int VAR = 0>
+// The body: one workgroup computes tile `bid` of the `nblk` tiles of problem `a`; smem = the kernel's LDS (Lds<MR>::bytes).
+template <int MR, bool PT, bool QT, int EPI, bool F16, int VAR = 0>
 __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const int nblk, MGEMM_LDS char* const smem) {
     typedef Elem<F16> E;
+    static_assert(MR == 8 || MR == 4, "tile configurations: MR = 8 (256 x 256) or MR = 4 (128 x 256)");
+    constexpr int WP = MR * 16;          // P rows per wave
+    constexpr int BP = 2 * WP;           // P rows per workgroup
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 2, wc = w & 3;
@@ -135,11 +143,11 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 if (!PT) {
-                    const int rowp = tp * 256 + (w >> 2) * 128 + h * 64 + (w & 3) * 16 + srow;
+                    const int rowp = tp * BP + (w >> 2) * WP + h * 64 + (w & 3) * 16 + srow;
                     voffP[h][e] = rowp < a.Pext ? (uint32_t)(((int64_t)rowp * a.ldp + e * 32 + chunk * 8) * 2) : kOob;
                     voffPt[h][e] = (e * 32 + chunk * 8 < krem) ? voffP[h][e] : kOob;
                 } else {
-                    const int ip = tp * 256 + (w >> 2) * 128 + h * 64 + e * 32 + chunk * 8;
+                    const int ip = tp * BP + (w >> 2) * WP + h * 64 + e * 32 + chunk * 8;
                     const int mp = (w & 3) * 16 + srow;
                     voffP[h][e] = ip < a.Pext ? (uint32_t)(((int64_t)mp * a.ldp + ip) * 2) : kOob;
                     voffPt[h][e] = mp < krem ? voffP[h][e] : kOob;
@@ -199,9 +207,9 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
     }
 
     u32x4_t fP[4][2], fQ0[2][2], fQ1[2][2];       // fragments [rep][ks]
-    f32x4_t acc[8][4];
+    f32x4_t acc[MR][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -278,30 +286,103 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
         MG_SYNC_POST();                              \
     } while (0)
 
-    // ---- prologue: six pieces in flight, the first two landed
-    MG_STAGE(0, 0, 0);
-    MG_STAGE(1, 0, 0);
-    MG_STAGE(2, 0, 0);
-    MG_STAGE(3, 0, 0);
-    MG_STAGE(0, 1, 1);
-    MG_STAGE(1, 1, 1);
-    MG_SYNC_PRE();
-    if (!(VAR & 1) && wr == 1) __builtin_amdgcn_s_barrier();       // stagger: wave row 1 runs one barrier behind wave row 0
+    if constexpr (MR == 8) {
+        // ---- prologue: six pieces in flight, the first two landed
+        MG_STAGE(0, 0, 0);
+        MG_STAGE(1, 0, 0);
+        MG_STAGE(2, 0, 0);
+        MG_STAGE(3, 0, 0);
+        MG_STAGE(0, 1, 1);
+        MG_STAGE(1, 1, 1);
+        MG_SYNC_PRE();
+        if (!(VAR & 1) && wr == 1) __builtin_amdgcn_s_barrier();       // stagger: wave row 1 runs one barrier behind wave row 0
 
-    for (int t = 0; t < T; t += 2) {
-        MG_KTILE(0, t);
-        if (t + 1 < T) MG_KTILE(1, t + 1);
+        for (int t = 0; t < T; t += 2) {
+            MG_KTILE(0, t);
+            if (t + 1 < T) MG_KTILE(1, t + 1);
+        }
+    } else {
+        // ---- 128 x 256 tile: a K-tile is three 16-KB pieces (P, Q cols 0-31, Q cols 32-63 of every wave column) in one of
+        // three LDS buffers, and two phases: phase 0 reads P and Q_n0 and stages P, Q_n0 of K-tile t + 2 (into the buffer
+        // K-tile t - 1 was read from two phases ago), phase 1 reads Q_n1 and stages Q_n1 of K-tile t + 2.  Loads issued
+        // after the piece the NEXT phase needs: 10 at the wait of phase 0, 8 at the wait of phase 1.
+        constexpr uint32_t KTB = 49152;
+#define MG4_STAGE(TYPE, bo_, tt)                                                                                  \
+    do {                                                                                                          \
+        const int tt_ = (tt);                                                                                     \
+        const bool live_ = tt_ < T;                                                                               \
+        constexpr bool isP_ = (TYPE) == 0;                                                                        \
+        constexpr int h_ = (TYPE) == 2 ? 1 : 0;                                                                   \
+        const uint32_t soff_ = (uint32_t)(kt0 + tt_) * (isP_ ? ktP : ktQ);                                        \
+        MGEMM_LDS char* dst_ = smem + (bo_) + (TYPE) * 16384 + w * 2048;                                         \
+        const bool last_ = ktail && (kt0 + tt_ == Ttot - 1);                                                      \
+        const uint32_t v0_ = !live_ ? kOob : last_ ? (isP_ ? voffPt[0][0] : voffQt[h_][0]) : (isP_ ? voffP[0][0] : voffQ[h_][0]); \
+        const uint32_t v1_ = !live_ ? kOob : last_ ? (isP_ ? voffPt[0][1] : voffQt[h_][1]) : (isP_ ? voffP[0][1] : voffQ[h_][1]); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(isP_ ? rP : rQ, (MGEMM_LDS void*)dst_, 16, v0_, soff_, 0, 0);    \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(isP_ ? rP : rQ, (MGEMM_LDS void*)(dst_ + 1024), 16, v1_, soff_, 0, 0); \
+    } while (0)
+#define MG4_READ_P(bo_)                                                                                \
+    do {                                                                                               \
+        _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) { \
+            if (!PT) fP[mi_][ks_] = ld128((bo_) + (mi_ * 2 + ks_) * 1024 + rdP0);                      \
+            else fP[mi_][ks_] = ldtr((bo_) + (4 * ks_ + (mi_ >> 1)) * 1024 + ((mi_ & 1) ? rdP1 : rdP0)); \
+        }                                                                                              \
+    } while (0)
+#define MG4_READ_Q(bo_, H, F)                                                                          \
+    do {                                                                                               \
+        _Pragma("unroll") for (int nj_ = 0; nj_ < 2; ++nj_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) { \
+            if (!QT) F[nj_][ks_] = ld128((bo_) + ((H) ? 2 : 1) * 16384 + (nj_ * 2 + ks_) * 1024 + rdQ0); \
+            else F[nj_][ks_] = ldtr((bo_) + ((H) ? 2 : 1) * 16384 + (2 * ks_) * 1024 + (nj_ ? rdQ1 : rdQ0)); \
+        }                                                                                              \
+    } while (0)
+#define MG4_SYNC_PRE(N)                                          \
+    do {                                                         \
+        asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_barrier();                            \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
+        MG4_STAGE(0, 0u, 0);
+        MG4_STAGE(1, 0u, 0);
+        MG4_STAGE(2, 0u, 0);
+        MG4_STAGE(0, KTB, 1);
+        MG4_STAGE(1, KTB, 1);
+        MG4_STAGE(2, KTB, 1);
+        MG4_SYNC_PRE(8);                                               // P, Q_n0 of K-tile 0 have landed
+        if (!(VAR & 1) && wr == 1) __builtin_amdgcn_s_barrier();       // stagger
+        uint32_t bo = 0, bs = 2 * KTB;                                 // buffer of K-tile t / of K-tile t + 2
+        for (int t = 0; t < T; ++t) {
+            const bool half_ = ktail && krem <= 32 && (kt0 + t) == Ttot - 1;
+            MG4_READ_Q(bo, 0, fQ0);
+            MG4_READ_P(bo);
+            MG4_STAGE(0, bs, t + 2);
+            MG4_STAGE(1, bs, t + 2);
+            MG4_SYNC_PRE(10);
+            MG_MFMA(0, 0, fQ0, half_);
+            MG_SYNC_POST();
+            MG4_READ_Q(bo, 1, fQ1);
+            MG4_STAGE(2, bs, t + 2);
+            MG4_SYNC_PRE(8);
+            MG_MFMA(0, 1, fQ1, half_);
+            MG_SYNC_POST();
+            bo = bo == 2 * KTB ? 0u : bo + KTB;
+            bs = bs == 2 * KTB ? 0u : bs + KTB;
+        }
+#undef MG4_STAGE
+#undef MG4_READ_P
+#undef MG4_READ_Q
+#undef MG4_SYNC_PRE
     }
     if (!(VAR & 1) && wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue: lane owns p = p0 + mi*16 + (l & 15), q = q0 + ni*16 + 4*(l >> 4) + {0..3}
-    const int p0 = tp * 256 + wr * 128 + (l & 15);
+    const int p0 = tp * BP + wr * WP + (l & 15);
     const int q0 = tq * 256 + wc * 64 + 4 * (l >> 4);
     if (EPI == EPI_F32) {
         float* C = (float*)a.C + (int64_t)z * a.slab_stride;
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
+        for (int mi = 0; mi < MR; ++mi) {
             const int p = p0 + mi * 16;
             if (p < a.Pext) {
 #pragma unroll
@@ -329,7 +410,7 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
 #pragma unroll
             for (int r = 0; r < 4; ++r) cs[ni][r] = 0.f;
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
+        for (int mi = 0; mi < MR; ++mi) {
             const int p = p0 + mi * 16;
             const bool pv = p < a.Pext;
 #pragma unroll
@@ -396,22 +477,22 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
 #undef MG_KTILE
 }
 
-template <bool PT, bool QT, int EPI, bool F16, int VAR = 0>
+template <bool PT, bool QT, int EPI, bool F16, int VAR = 0, int MR = 8>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm256(const Args a) {
-    __shared__ __attribute__((aligned(1024))) char smem[kLdsBytes];
-    gemm256_body<PT, QT, EPI, F16, VAR>(a, blockIdx.x, gridDim.x, (MGEMM_LDS char*)smem);
+    __shared__ __attribute__((aligned(1024))) char smem[Lds<MR>::bytes];
+    gemm256_body<MR, PT, QT, EPI, F16, VAR>(a, blockIdx.x, gridDim.x, (MGEMM_LDS char*)smem);
 }
 
 // Both bprops of one DenseLayer in ONE launch: the two problems are independent (both read dy) and, for the narrow
 // layers, neither fills the chip alone.  Workgroups [0, n1) run the problem whose workgroups take longer (more K-tiles
 // each; dispatched first so that the short ones pack behind them), the rest the other one.
-template <bool F16>
+template <bool F16, int MRD = 8, int MRW = 8>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm256_bwd(const Args ad, const Args aw, const int n1, const int wfirst) {
-    __shared__ __attribute__((aligned(1024))) char smem[kLdsBytes];
+    __shared__ __attribute__((aligned(1024))) char smem[Lds<(MRD < MRW ? MRD : MRW)>::bytes];      // the 128 x 256 config needs more
     const int b = blockIdx.x, n2 = (int)gridDim.x - n1;
     const bool second = b >= n1;
-    if (second != (wfirst != 0)) gemm256_body<true, true, EPI_F32, F16>(aw, second ? b - n1 : b, second ? n2 : n1, (MGEMM_LDS char*)smem);
-    else gemm256_body<false, false, EPI_DGRAD, F16>(ad, second ? b - n1 : b, second ? n2 : n1, (MGEMM_LDS char*)smem);
+    if (second != (wfirst != 0)) gemm256_body<MRW, true, true, EPI_F32, F16>(aw, second ? b - n1 : b, second ? n2 : n1, (MGEMM_LDS char*)smem);
+    else gemm256_body<MRD, false, false, EPI_DGRAD, F16>(ad, second ? b - n1 : b, second ? n2 : n1, (MGEMM_LDS char*)smem);
 }
 
 }  // namespace mgemm

@@ -181,18 +181,27 @@ __global__ __launch_bounds__(MB) void k_head_fwd_bwd(const uint4* __restrict__ h
         for (int k = 0; k < 8; ++k) part += fh[k] * w[k];
         // reduce over the CG lanes of this row (CG is a power of two <= 64, lanes of a row are adjacent)
         for (int d = CG >> 1; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        // the wide branch: either given per sample, or as the per-field products the fused lookup wrote ([B, F, 2]: product,
+        // pad).  The CG lanes of the row load the products side by side (one pass of loads, not F dependent ones), then every
+        // lane adds them up in FIELD ORDER through shuffles -- ReduceSum over the fields, then + Wide_b: the same adds in the
+        // same order as mrec_wide_sum / the CPU restatement.
+        float wv = 0.0f;
+        if (wprod) {
+            const int lane_row0 = (threadIdx.x & 63) - cg;           // first lane of this row's group
+            float acc_w = 0.0f;
+            for (int f0 = 0; f0 < F; f0 += CG) {
+                const int f = f0 + cg;
+                const float mine = (valid && f < F) ? wprod[2 * (r * F + f)] : 0.0f;
+                const int nf = (F - f0 < CG) ? F - f0 : CG;
+                for (int c = 0; c < nf; ++c) acc_w = acc_w + __shfl(mine, lane_row0 + c, 64);
+            }
+            wv = acc_w + *wide_bias;
+        } else if (valid) {
+            wv = wide[r];
+        }
         float dl = 0.0f;
         if (valid) {
-            float wsum;
-            if (wprod) {
-                // the wide branch from its per-field products (written by the gather): ReduceSum over the fields in field
-                // order, then + Wide_b -- the same adds in the same order as mrec_wide_sum / the CPU restatement
-                float acc_w = 0.0f;
-                for (int f = 0; f < F; ++f) acc_w = acc_w + wprod[2 * (r * F + f)];      // [B, F, 2]: product, pad
-                wsum = acc_w + *wide_bias;
-            } else {
-                wsum = wide[r];
-            }
+            float wsum = wv;
             const float z = part + bias + wsum;
             const float y = label[r];
             // SigmoidCrossEntropyWithLogits: max(z,0) - z*y + log(1 + exp(-|z|))

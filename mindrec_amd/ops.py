@@ -478,6 +478,21 @@ def init_rows_(table, rows, keys_i64, is_new=None, seed=0, sigma=0.01, fill=None
               C.c_uint64(seed), s, float(fill or 0.0), _stream())
 
 
+def copy3_(dsts, srcs):
+    """Three contiguous device tensors copied in one launch (a step's inputs into its graph's static buffers); falls back to
+    tensor.copy_ when a size is not a multiple of 16 bytes."""
+    _need_cuda(*dsts, *srcs)
+    nb = [d.numel() * d.element_size() for d in dsts]
+    ok = all(d.is_contiguous() and s_.is_contiguous() and d.dtype == s_.dtype and d.numel() == s_.numel() and n % 16 == 0
+             and d.data_ptr() % 16 == 0 and s_.data_ptr() % 16 == 0 for d, s_, n in zip(dsts, srcs, nb))
+    if not ok:
+        for d, s_ in zip(dsts, srcs):
+            d.copy_(s_)
+        return
+    _lib.call("mrec_copy3", _ptr(dsts[0]), _ptr(srcs[0]), nb[0], _ptr(dsts[1]), _ptr(srcs[1]), nb[1], _ptr(dsts[2]), _ptr(srcs[2]),
+              nb[2], _stream())
+
+
 def compose_i32(table, idx):
     """out[i] = table[idx[i]] on int32 arrays: rows per position from rows per unique key."""
     n = idx.numel()
@@ -736,8 +751,8 @@ def dense_bwd_input(dy, w, h=None, db_out=None, out=None, db_slabs=None):
     if db_slabs is not None:
         if db_out is not None:
             raise ValueError("pass db_out or db_slabs, not both")
-        if db_slabs.dtype != torch.float32 or not db_slabs.is_contiguous() or db_slabs.shape != ((M + 255) // 256, K):
-            raise TypeError("db_slabs must be contiguous float32 [ceil(M/256), K]")
+        if db_slabs.dtype != torch.float32 or not db_slabs.is_contiguous() or db_slabs.shape != (dense_bwd_bias_slabs(M, K, N, False), K):
+            raise TypeError("db_slabs must be contiguous float32 [dense_bwd_bias_slabs(M, K, N, fused=False), K]")
         ws = db_slabs.view(torch.uint8).view(-1)
     elif db_out is not None:
         nb = _lib.query_bytes("mrec_dense_bwd_input_workspace_bytes", M, K)
@@ -745,6 +760,13 @@ def dense_bwd_input(dy, w, h=None, db_out=None, out=None, db_slabs=None):
     _lib.call("mrec_dense_bwd_input_" + _DT16[dy.dtype], _ptr(dy), lddy, _ptr(w), _ptr(h), M, K, N, _ptr(dx), lddx,
               _ptr(db_out), _ptr(ws), ws.numel() if ws is not None else 0, _stream())
     return dx
+
+
+def dense_bwd_bias_slabs(M, K, N, fused=True):
+    """Rows of the bias-gradient slabs [T, K] dense_bwd (fused) / dense_bwd_input leave behind for this shape."""
+    t = C.c_int32(0)
+    _lib.call("mrec_dense_bwd_bias_slabs", M, K, N, int(bool(fused)), C.byref(t))
+    return int(t.value)
 
 
 def dense_bwd_weight_slabs(M, K, N):
@@ -786,8 +808,8 @@ def dense_bwd(dy, w, x, dw_slabs, mask=True, db_slabs=None, out=None):
         raise TypeError("dw_slabs must be contiguous float32 [S, K, N]")
     nb = 0
     if db_slabs is not None:
-        if db_slabs.dtype != torch.float32 or not db_slabs.is_contiguous() or db_slabs.shape != ((M + 255) // 256, K):
-            raise TypeError("db_slabs must be contiguous float32 [ceil(M/256), K]")
+        if db_slabs.dtype != torch.float32 or not db_slabs.is_contiguous() or db_slabs.shape != (dense_bwd_bias_slabs(M, K, N, True), K):
+            raise TypeError("db_slabs must be contiguous float32 [dense_bwd_bias_slabs(M, K, N), K]")
         nb = db_slabs.numel() * 4
     _lib.call("mrec_dense_bwd_" + _DT16[dy.dtype], _ptr(dy), lddy, _ptr(w), _ptr(x) if mask else None, _ptr(x), ldx, M, K, N,
               _ptr(dx), lddx, _ptr(db_slabs), nb, dw_slabs.shape[0], _ptr(dw_slabs), _stream())

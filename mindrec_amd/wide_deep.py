@@ -333,7 +333,9 @@ class WideDeepEngine:
             self._dw, self._db, self._dw_batch = {}, {}, B
         t = self._db.get(i)
         if t is None:
-            t = torch.empty(((B + 255) // 256, self.dims[i + 1]), dtype=torch.float32, device=self.device)
+            # written by the backward launch of layer i + 1, whose reduction width is dims[i + 2]
+            rows = self.k.dense_bwd_bias_slabs(B, self.dims[i + 1], self.dims[i + 2])
+            t = torch.empty((rows, self.dims[i + 1]), dtype=torch.float32, device=self.device)
             self._db[i] = t
         return t
 
@@ -769,9 +771,7 @@ class WideDeepEngine:
             if g is None:
                 return None
             self._front_graph = g
-        g["ids"].copy_(ids)
-        g["wts"].copy_(wts)
-        g["label"].copy_(label)
+        self.k.copy3_((g["ids"], g["wts"], g["label"]), (ids, wts, label))        # one launch, not three
         g["graph"].replay()
         return g["out"]
 

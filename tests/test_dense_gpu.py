@@ -158,7 +158,8 @@ def test_dense_bwd_fused_launch_equals_separate_kernels(dev, oracle, dtype, M, K
     x = _dev(np.maximum(_vals(rng, (M, K), 1.0, dtype, oracle), 0), dtype, dev)
     S = ops.dense_bwd_weight_slabs(M, K, N)
     dw1 = torch.empty((S, K, N), dtype=torch.float32, device=dev); dw2 = torch.empty_like(dw1)
-    db1 = torch.empty(((M + 255) // 256, K), dtype=torch.float32, device=dev); db2 = torch.empty_like(db1)
+    db1 = torch.empty((ops.dense_bwd_bias_slabs(M, K, N, True), K), dtype=torch.float32, device=dev)
+    db2 = torch.empty((ops.dense_bwd_bias_slabs(M, K, N, False), K), dtype=torch.float32, device=dev)
     dx1 = ops.dense_bwd(dy, w, x, dw1, mask=mask, db_slabs=db1 if mask else None)
     dx2 = ops.dense_bwd_input(dy, w, h=x if mask else None, db_slabs=db2 if mask else None)
     ops.dense_bwd_weight(x, dy, dw2)

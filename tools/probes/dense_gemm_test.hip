@@ -33,7 +33,7 @@ struct Timer {
 };
 
 // forward: C[M,N] = relu(X[M,K] . W[K,N] + b)
-template <int VAR = 0>
+template <int VAR = 0, int MR = 8>
 static void test_fwd(int M, int N, int K) {
     std::vector<uint16_t> hX((size_t)M * K), hW((size_t)K * N), hC((size_t)M * N);
     std::vector<float> hb(N);
@@ -48,9 +48,9 @@ static void test_fwd(int M, int N, int K) {
     CK(hipMemset(dC, 0xFF, hC.size() * 2));
     Args a{};
     a.P = dX; a.Q = dW; a.C = dC; a.bias = db; a.ldp = K; a.ldq = N; a.ldc = N; a.Pext = M; a.Qext = N; a.K = K;
-    a.nTp = (M + 255) / 256; a.nTq = (N + 255) / 256; a.relu = 1; a.kt_per_slab = (K + 63) / 64;
+    a.nTp = (M + MR * 32 - 1) / (MR * 32); a.nTq = (N + 255) / 256; a.relu = 1; a.kt_per_slab = (K + 63) / 64;
     const int grid = a.nTp * a.nTq;
-    auto run = [&] { k_gemm256<false, true, EPI_FWD, false, VAR><<<grid, kThreads>>>(a); };
+    auto run = [&] { k_gemm256<false, true, EPI_FWD, false, VAR, MR><<<grid, kThreads>>>(a); };
     run();
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost));
@@ -69,19 +69,20 @@ static void test_fwd(int M, int N, int K) {
     }
     Timer tm;
     const double us = tm.us(run);
-    printf("fwd%d  M=%d N=%d K=%d grid %d: %7.1f us %6.3f PF/s  worst rel err %.2e  %s\n", VAR, M, N, K, grid, us, 2.0 * M * N * K / us / 1e9, worst,
+    printf("fwd%d mr%d M=%d N=%d K=%d grid %d: %7.1f us %6.3f PF/s  worst rel err %.2e  %s\n", VAR, MR, M, N, K, grid, us, 2.0 * M * N * K / us / 1e9, worst,
            bad ? "FAIL" : "ok");
     CK(hipFree(dX)); CK(hipFree(dW)); CK(hipFree(dC)); CK(hipFree(db));
 }
 
 // dgrad: dX[M,Kin] = (dY[M,N] . W[Kin,N]^T) masked by H[M,Kin] > 0, + column sums
+template <int MR = 8>
 static void test_dgrad(int M, int Kin, int N, bool mask) {
     std::vector<uint16_t> hdY((size_t)M * N), hW((size_t)Kin * N), hH((size_t)M * Kin), hC((size_t)M * Kin);
     for (auto& x : hdY) x = h_f2bf(frand());
     for (auto& x : hW) x = h_f2bf(frand() * 0.05f);
     for (auto& x : hH) { float v = frand(); x = h_f2bf(v > 0.2f ? v : 0.f); }
     uint16_t *ddY, *dW, *dH, *dC; float* dws;
-    const int nTp = (M + 255) / 256, nTq = (Kin + 255) / 256;
+    const int nTp = (M + MR * 32 - 1) / (MR * 32), nTq = (Kin + 255) / 256;
     CK(hipMalloc(&ddY, hdY.size() * 2)); CK(hipMalloc(&dW, hW.size() * 2)); CK(hipMalloc(&dH, hH.size() * 2)); CK(hipMalloc(&dC, hC.size() * 2));
     CK(hipMalloc(&dws, (size_t)nTp * Kin * 4));
     CK(hipMemcpy(ddY, hdY.data(), hdY.size() * 2, hipMemcpyHostToDevice));
@@ -92,7 +93,7 @@ static void test_dgrad(int M, int Kin, int N, bool mask) {
     a.P = ddY; a.Q = dW; a.C = dC; a.H = mask ? dH : nullptr; a.colsum_ws = mask ? dws : nullptr;
     a.ldp = N; a.ldq = N; a.ldc = Kin; a.Pext = M; a.Qext = Kin; a.K = N; a.nTp = nTp; a.nTq = nTq; a.kt_per_slab = (N + 63) / 64;
     const int grid = nTp * nTq;
-    auto run = [&] { k_gemm256<false, false, EPI_DGRAD, false><<<grid, kThreads>>>(a); };
+    auto run = [&] { k_gemm256<false, false, EPI_DGRAD, false, 0, MR><<<grid, kThreads>>>(a); };
     run();
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost));
@@ -124,18 +125,19 @@ static void test_dgrad(int M, int Kin, int N, bool mask) {
     }
     Timer tm;
     const double us = tm.us(run);
-    printf("dgrad M=%d Kin=%d N=%d mask=%d grid %d: %7.1f us %6.3f PF/s  worst rel err %.2e colsum %.2e  %s\n", M, Kin, N, (int)mask, grid, us,
+    printf("dgrad mr%d M=%d Kin=%d N=%d mask=%d grid %d: %7.1f us %6.3f PF/s  worst rel err %.2e colsum %.2e  %s\n", MR, M, Kin, N, (int)mask, grid, us,
            2.0 * M * N * Kin / us / 1e9, worst, cworst, bad ? "FAIL" : "ok");
     CK(hipFree(ddY)); CK(hipFree(dW)); CK(hipFree(dH)); CK(hipFree(dC)); CK(hipFree(dws));
 }
 
 // wgrad: dW[Kin,N] = X[M,Kin]^T . dY[M,N], split over M in S slabs (fp32)
+template <int MR = 8>
 static void test_wgrad(int M, int Kin, int N, int S) {
     std::vector<uint16_t> hX((size_t)M * Kin), hdY((size_t)M * N);
     for (auto& x : hX) x = h_f2bf(frand());
     for (auto& x : hdY) x = h_f2bf(frand() * 0.05f);
     uint16_t *dX, *ddY; float* dC;
-    const int nTp = (Kin + 255) / 256, nTq = (N + 255) / 256;
+    const int nTp = (Kin + MR * 32 - 1) / (MR * 32), nTq = (N + 255) / 256;
     CK(hipMalloc(&dX, hX.size() * 2)); CK(hipMalloc(&ddY, hdY.size() * 2)); CK(hipMalloc(&dC, (size_t)S * Kin * N * 4));
     CK(hipMemcpy(dX, hX.data(), hX.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(ddY, hdY.data(), hdY.size() * 2, hipMemcpyHostToDevice));
@@ -145,7 +147,7 @@ static void test_wgrad(int M, int Kin, int N, int S) {
     const int Ttot = (M + 63) / 64;
     a.kt_per_slab = (Ttot + S - 1) / S; a.slab_stride = (int64_t)Kin * N;
     const int grid = nTp * nTq * S;
-    auto run = [&] { k_gemm256<true, true, EPI_F32, false><<<grid, kThreads>>>(a); };
+    auto run = [&] { k_gemm256<true, true, EPI_F32, false, 0, MR><<<grid, kThreads>>>(a); };
     run();
     CK(hipDeviceSynchronize());
     std::vector<float> hC((size_t)S * Kin * N);
@@ -164,7 +166,7 @@ static void test_wgrad(int M, int Kin, int N, int S) {
     }
     Timer tm;
     const double us = tm.us(run);
-    printf("wgrad M=%d Kin=%d N=%d S=%d grid %d: %7.1f us %6.3f PF/s  worst rel err %.2e  %s\n", M, Kin, N, S, grid, us, 2.0 * M * N * Kin / us / 1e9,
+    printf("wgrad mr%d M=%d Kin=%d N=%d S=%d grid %d: %7.1f us %6.3f PF/s  worst rel err %.2e  %s\n", MR, M, Kin, N, S, grid, us, 2.0 * M * N * Kin / us / 1e9,
            worst, bad ? "FAIL" : "ok");
     CK(hipFree(dX)); CK(hipFree(ddY)); CK(hipFree(dC));
 }
@@ -173,7 +175,8 @@ int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 16384;
     if (argc > 2 && !strcmp(argv[2], "prof")) {        // one long dispatch for counter passes (clock, LDS conflicts)
         test_fwd(B, 1024, 33280);
-        test_dgrad(B, 1024, 33280, false);
+        test_dgrad<8>(B, 1024, 33280, false);
+        test_dgrad<4>(B, 1024, 33280, false);
         return 0;
     }
     // small odd shapes first (tails, masks), then the Wide&Deep MLP shapes (2080-1024-512-256-128)
@@ -192,6 +195,28 @@ int main(int argc, char** argv) {
     test_dgrad(300, 200, 72, true);
     test_wgrad(1000, 3120, 264, 3);
     test_wgrad(50, 264, 72, 1);
+    // the 128 x 256 configuration: odd shapes, tails, then the narrow layers
+    test_fwd<0, 4>(300, 200, 96);
+    test_fwd<0, 4>(130, 520, 160);
+    test_fwd<0, 4>(700, 264, 3120);
+    test_fwd<0, 4>(512, 256, 72);
+    test_fwd<0, 4>(128, 256, 64);
+    test_dgrad<4>(300, 200, 128, true);
+    test_dgrad<4>(300, 3120, 136, false);
+    test_dgrad<4>(1000, 200, 72, true);
+    test_wgrad<4>(256, 200, 136, 2);
+    test_wgrad<4>(1000, 3120, 264, 3);
+    test_wgrad<4>(50, 264, 72, 1);
+    test_wgrad<4>(96, 136, 72, 1);
+    test_fwd<0, 4>(B, 512, 1024);
+    test_fwd<0, 4>(B, 256, 512);
+    test_fwd<0, 4>(B, 128, 256);
+    test_dgrad<4>(B, 1024, 512, true);
+    test_dgrad<4>(B, 512, 256, true);
+    test_dgrad<4>(B, 256, 128, true);
+    test_wgrad<4>(B, 1024, 512, 16);
+    test_wgrad<4>(B, 512, 256, 32);
+    test_wgrad<4>(B, 256, 128, 64);
     test_fwd(B, 1024, 2080);
     test_fwd(B, 512, 1024);
     test_fwd(B, 256, 512);
