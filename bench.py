@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--host-cache-rows", type=int, default=0, help="tables in pinned host DRAM behind a device cache of this many rows "
                     "(the reference's vocab_cache_size); keep --vocab x 976 B within the host's RAM")
     ap.add_argument("--no-graph-front", action="store_true", help="one GPU: only the MLP as HIP graphs, lookups / plan issued kernel by kernel")
+    ap.add_argument("--no-graph-step", action="store_true", help="one GPU: the front of the step as one HIP graph, the sparse apply and the dense "
+                    "optimizers issued kernel by kernel behind it (instead of the whole step as one graph)")
     ap.add_argument("--no-graph-mlp", action="store_true", help="issue the MLP step kernel by kernel instead of replaying its HIP graph")
     return ap.parse_args()
 
@@ -216,7 +218,7 @@ def main():
 
     cfg = WideDeepConfig(vocab_size=args.vocab, emb_dim=args.emb_dim, field_size=args.fields, batch_size=args.batch,
                          mlp_dtype=args.mlp_dtype, fused_state=not args.split_state,
-                         overlap_plan=not args.no_overlap_plan, graph_mlp=not args.no_graph_mlp, graph_front=not args.no_graph_front,
+                         overlap_plan=not args.no_overlap_plan, graph_mlp=not args.no_graph_mlp, graph_front=not args.no_graph_front, graph_step=not args.no_graph_step,
                          dynamic_embedding=args.dynamic_embedding, hash_capacity=args.hash_capacity,
                          host_cache_rows=args.host_cache_rows, early_route=not args.no_early_route,
                          late_wide={'auto': None, 'on': True, 'off': False}[args.late_wide],
@@ -252,9 +254,21 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         block_s.append(dt)
-        kmain += [t.ms() for t in ktimers]
+        if eng._step_graph is None:
+            kmain += [t.ms() for t in ktimers]
+    apply_timing = ("HIP events around k_apply_main on its launch stream (mrec_profile_next_apply), "
+                    "averaged over the {n} timed steps")
+    if eng._step_graph is not None:
+        # The whole step is one HIP graph: events recorded inside a captured graph cannot be timed on this stack (hipError 400,
+        # tools/probes/graph_event_probe.py), so the kernel stamps the device wall clock itself -- first workgroup in, last wave
+        # out -- into a ring in the device-side step state, read here after the timed region.
+        last = eng.step_count
+        n_timed = min(len(block_s) * args.steps, ops.StepState.RING - 1)
+        kmain = eng._step_state.apply_ms(range(last - n_timed + 1, last + 1))
+        apply_timing = ("device wall-clock stamps written by k_apply_main itself (first workgroup begin -> last wave end; the step "
+                        "is one HIP graph, whose event nodes cannot be timed), averaged over the last {n} timed steps")
     dt = median(block_s)
-    graphs_used = {"front": eng._front_graph is not None, "mlp": eng._mlp_graph is not None}
+    graphs_used = {"step": eng._step_graph is not None, "front": eng._front_graph is not None, "mlp": eng._mlp_graph is not None}
 
     # Per-phase device times (informational "kernels_ms"): HIP events around every phase, recorded in a few
     # EXTRA steps after the timed region -- two dozen timing events per step serialise the queue and cost
@@ -267,14 +281,33 @@ def main():
     # the first two of these steps are dropped: with phase timers on, a one-GPU engine leaves its whole-front graph
     # and captures the MLP graphs instead, which happens here
     kern_ms = {k: [a.elapsed_time(b) for a, b in evs][2:] for k, evs in eng.timers.items()}
+    # the same kernel between two HIP events, in four more eager steps (a cross-check of the stamps; phase timers still on, so
+    # the step runs kernel by kernel)
+    ev_ms = []
+    for i in range(4):
+        t = ops.KernelTimer()
+        eng.deep_apply_timer = t
+        eng.train_step(*batches[i % len(batches)])
+        torch.cuda.synchronize()
+        try:
+            ev_ms.append(t.ms())
+        except RuntimeError:
+            pass
     eng.timers = None
     plan = eng.last_plan
     U = plan.U                                  # unique ids of the last step's (local) apply
     n_apply = plan.n
     io16 = eng._mfma                            # gather writes / apply reads 16-bit rows (also on the wire)
     by = embedding_bytes(n_apply, U, args.emb_dim, act_bytes=2 if io16 else 4)
+    # Folded wide branch (one-GPU fused rows [p | w accum linear | m | v]): the wide FTRL runs inside the deep apply and the
+    # wide lookup inside the deep gather.  Their algorithmic bytes join those kernels' figures: the apply reads and writes the
+    # 12-byte record of each touched row (U * 24) and reads one logit gradient per sample (B * 4); the gather reads the
+    # wide word of each row once (U * 4) and writes one product per position (N * 4; ids and weights are already counted).
+    fold = bool(eng._fold_wide and world == 1)
+    apply_bytes = by["apply_deep"] + (U * 24 + args.batch * 4 if fold else 0)
+    lookup_bytes = by["lookup"] + (U * 4 + n_apply * 4 if fold else 0)
     apply_ms = sum(kmain) / len(kmain)
-    achieved = by["apply_deep"] / (apply_ms * 1e-3) / 1e9
+    achieved = apply_bytes / (apply_ms * 1e-3) / 1e9
     peak = 8000.0
     # HBM bytes per launch of the dominant kernel come from the committed PMC passes (profiles/: rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate runs of this same command, corrected per MI355X_MICROARCH.md) -- NOT measured in this run;
@@ -332,27 +365,41 @@ def main():
                                f"({'hand-written MFMA kernels' if eng._mfma else 'torch GEMMs'}; looked-up rows and row gradients in {dt_name})",
                    "global_batch": args.batch * world, "id_dist": args.dist, "hip_graphs": graphs_used, "unique_frac": round(U / max(n_apply, 1), 4),
                    "parallelism": "1 GPU" if world == 1 else f"tables row-sharded x{world} (RCCL all-to-all), MLP dp{world}"},
-        "roofline": {"bound": "hbm", "kernel": "k_apply_main<4,int,UpdAdam,%s> (fused segment-sum + LazyAdam row update)" % (dt_name + "_t" if io16 else "float"),
-                     "row_gradient_dtype": dt_name if io16 else "f32",
+        "roofline": {"bound": "hbm",
+                     "kernel": ("k_apply_main<4,int,UpdAdam,%s,WIDE> (segment-sum + LazyAdam row update + FTRL on the row's wide record)" if fold else
+                                "k_apply_main<4,int,UpdAdam,%s> (fused segment-sum + LazyAdam row update)") % (dt_name + "_t" if io16 else "float"),
+                     "row_gradient_dtype": dt_name if io16 else "f32", "wide_folded": fold,
                      "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
-                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": by["apply_deep"], "avg_ms": round(apply_ms, 5),
+                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": apply_bytes, "avg_ms": round(apply_ms, 5),
+                     "avg_ms_hip_events_eager": round(sum(ev_ms) / len(ev_ms), 5) if ev_ms else None,
                      "measured_copy_gbps": copy_gbps,
-                     "timing": "HIP events around k_apply_main on its launch stream (mrec_profile_next_apply), "
-                               f"averaged over the {len(kmain)} timed steps"},
+                     "timing": apply_timing.format(n=len(kmain))},
         "kernels_ms": {k: round(sum(v) / len(v), 5) for k, v in sorted(kern_ms.items()) if v},
     }
     if world == 1 and lookup_ms:
-        out["roofline_lookup"] = {"bound": "hbm", "kernel": "k_gather_rows (EmbeddingLookup, mask fused)", "achieved": round(by["lookup"] / (lookup_ms * 1e-3) / 1e9, 1),
-                                  "peak": peak, "unit": "GB/s", "frac": round(by["lookup"] / (lookup_ms * 1e-3) / 1e9 / peak, 4),
-                                  "algorithmic_bytes": by["lookup"], "avg_ms": round(lookup_ms, 5),
+        out["roofline_lookup"] = {"bound": "hbm", "kernel": "k_gather_rows (EmbeddingLookup, mask fused%s)" % (" + the row's wide word" if fold else ""),
+                                  "achieved": round(lookup_bytes / (lookup_ms * 1e-3) / 1e9, 1),
+                                  "peak": peak, "unit": "GB/s", "frac": round(lookup_bytes / (lookup_ms * 1e-3) / 1e9 / peak, 4),
+                                  "algorithmic_bytes": lookup_bytes, "avg_ms": round(lookup_ms, 5),
                                   "timing": "torch events around the gather in extra steps after the timed region"}
-        if wide_ms and wapply_ms:
+        tot_b = tot_ms = None
+        if fold:
+            # both tables' lookup and apply are these two kernels (the per-sample sum of the wide products is in the head kernel)
+            tot_b, tot_ms = lookup_bytes + apply_bytes, lookup_ms + apply_ms
+        elif wide_ms and wapply_ms:
             tot_b = by["lookup"] + by["apply_deep"] + by["wide_lookup"] + by["apply_wide"]
             tot_ms = lookup_ms + apply_ms + wide_ms + wapply_ms
+        if tot_b:
             out["roofline_embedding_path"] = {"what": "EmbeddingLookup + sparse apply, deep AND wide tables (north-star quantity)",
                                               "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 1), "peak": peak, "unit": "GB/s",
                                               "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / peak, 4), "algorithmic_bytes": tot_b,
                                               "sum_ms": round(tot_ms, 5)}
+    if world == 1 and eng._mfma:
+        # exact HBM bytes of one k_dense_adam4_slabs launch (tools/pmc_summary.py checks its counter correction on these)
+        n_el = eng.dense_flat.numel()
+        slab_el = sum(t.numel() for t in list(eng._dw.values()) + list(eng._db.values()))
+        covered = sum(t[0].numel() for t in list(eng._dw.values()) + list(eng._db.values()))
+        out["dense_adam_bytes"] = {"read": 4 * (3 * n_el + slab_el + (n_el - covered)), "write": 4 * 3 * n_el + 2 * n_el}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

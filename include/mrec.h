@@ -78,6 +78,17 @@ int mrec_sparse_plan_i32(const int32_t* ids, int64_t n, int32_t* uniq, int32_t* 
 int mrec_sparse_plan_i64(const int64_t* ids, int64_t n, int64_t* uniq, int32_t* inv, int64_t* n_uniq_dev,
                          int32_t* sorted_pos, int32_t* sorted_seg, int32_t* seg_offsets, void* ws,
                          size_t ws_bytes, void* stream);
+/* Same with flags.  MREC_PLAN_WS_PRIMED: the caller vouches that the last thing that wrote `ws` was a COMPLETED
+ * mrec_sparse_plan_* call with the same n (any flags) and the same ws pointer: the scratch hash table and the scan's
+ * look-back words are then already clean -- every call hands them back the way it found them -- and the two memsets at the
+ * head of the chain are skipped.  (A training step replays the same plan on the same workspace every step.) */
+#define MREC_PLAN_WS_PRIMED 1u
+int mrec_sparse_plan_ex_i32(const int32_t* ids, int64_t n, int32_t* uniq, int32_t* inv, int64_t* n_uniq_dev,
+                            int32_t* sorted_pos, int32_t* sorted_seg, int32_t* seg_offsets, void* ws, size_t ws_bytes,
+                            uint32_t flags, void* stream);
+int mrec_sparse_plan_ex_i64(const int64_t* ids, int64_t n, int64_t* uniq, int32_t* inv, int64_t* n_uniq_dev,
+                            int32_t* sorted_pos, int32_t* sorted_seg, int32_t* seg_offsets, void* ws, size_t ws_bytes,
+                            uint32_t flags, void* stream);
 
 /* ---- ops.Gather / SparseGatherV2 / EmbeddingLookup ----------------------------------------
  * mindspore_rec/ops/embedding.py:150,194; models/deep_and_cross/src/deep_and_cross.py:199;
@@ -193,13 +204,36 @@ int mrec_sparse_lazy_adam_f16g_i64(float* p, float* m, float* v, int64_t V, int6
  * summed per id in the same window / tree order as the deep columns.  uniq_bytes 4 / 8; g_kind 0 f32, 1 bf16, 2 f16;
  * D % 4 == 0, D <= 252, wide_col == D (the record right behind p: it is loaded and stored by the instruction that moves p),
  * 16-byte aligned rows (128-byte aligned rows avoid a second line per record), n * F < 2^32.
- * ws: mrec_sparse_apply_workspace_bytes(n, D + 4). */
+ * ws: mrec_sparse_apply_workspace_bytes(n, D + 4).
+ * step_state (nullable): an mrec_step_state_t in device memory; when given, the Adam step size comes from it instead of
+ * b1_pow / b2_pow, and the main kernel leaves its begin / end wall clock stamps there. */
 int mrec_sparse_lazy_adam_wide(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D, const void* uniq,
                                int32_t uniq_bytes, const int32_t* sorted_pos, const int32_t* sorted_seg,
                                const int32_t* seg_offsets, int64_t n, const void* g, int32_t g_kind, int64_t ldg,
                                const float* row_scale, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
                                float grad_scale, int nesterov, const float* gw, int32_t F, int32_t wide_col, float ftrl_lr,
-                               float l1, float l2, float lr_power, void* ws, size_t ws_bytes, void* stream);
+                               float l1, float l2, float lr_power, void* ws, size_t ws_bytes, void* step_state, void* stream);
+
+/* ---- step scalars in device memory ------------------------------------------------------------------------------
+ * nn.Adam / nn.LazyAdam keep beta1_power and beta2_power as Parameters that the optimizer's own graph multiplies by
+ * beta1 / beta2 every step (mindspore.nn.Adam: beta1_power = beta1_power * beta1; wide_and_deep.py:420-422 builds the
+ * optimizers).  The same here: the powers live in device memory and a one-thread kernel advances them, so every kernel
+ * argument of a training step is constant and the whole step replays as one HIP graph.  Layout (little endian): */
+#define MREC_STAMP_RING 256
+typedef struct mrec_step_state {
+    float beta1_power, beta2_power;   /* after `step` advances */
+    float lr_t;                       /* lr * sqrt(1 - beta2_power) / (1 - beta1_power), fp32 operations in this order */
+    float reserved0;
+    int64_t step;
+    uint64_t reserved1;
+    /* [step % MREC_STAMP_RING] = {begin of the first workgroup, end of the last wave} of the main sparse-apply kernel that
+     * ran with this state, in ticks of the device wall clock (mrec_wall_clock_khz) */
+    uint64_t stamps[MREC_STAMP_RING][2];
+} mrec_step_state_t;
+int mrec_step_state_init(void* state, float beta1_power, float beta2_power, int64_t step, void* stream);
+/* powers *= betas, step += 1, lr_t recomputed, the stamp slot of the new step reset */
+int mrec_step_advance(void* state, float lr, float beta1, float beta2, void* stream);
+int mrec_wall_clock_khz(int32_t* out);
 
 /* nn.FTRL sparse apply (FusedSparseFtrl; wide_and_deep.py:423-430). */
 int mrec_sparse_ftrl_f32_i32(float* var, float* accum, float* linear, int64_t V, int64_t ld, int32_t D,
@@ -241,7 +275,8 @@ int mrec_dense_adam_splitk_f32(float* p, float* m, float* v, const float* g, uin
 int mrec_dense_adam_slabs_f32(float* p, float* m, float* v, const float* g, void* shadow16, int shadow_kind, int64_t n,
                               int32_t nseg, const float* const* slabs, const int64_t* starts, const int64_t* lens,
                               const int32_t* splits, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
-                              float grad_scale, int nesterov, void* stream);
+                              float grad_scale, int nesterov, void* step_state /* nullable mrec_step_state_t: lr_t */,
+                              void* stream);
 int mrec_dense_ftrl_f32(float* var, float* accum, float* linear, const float* g, int64_t n, float lr,
                         float l1, float l2, float lr_power, float grad_scale, void* stream);
 

@@ -42,6 +42,8 @@ _SIGS = {
     "mrec_sparse_plan_workspace_bytes": [_i64, _szp],
     "mrec_sparse_plan_i32": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_sparse_plan_i64": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_sparse_plan_ex_i32": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, C.c_uint32, _vp],
+    "mrec_sparse_plan_ex_i64": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, C.c_uint32, _vp],
     "mrec_gather_rows_f32_i32": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_gather_rows_f32_i64": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_gather_rows_bf16_i32": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
@@ -50,7 +52,10 @@ _SIGS = {
     "mrec_gather_rows_f16_i64": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_gather_rows_wide": [_vp, _i64, _i64, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp],
     "mrec_sparse_lazy_adam_wide": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i64, _vp,
-                                   _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _sz, _vp],
+                                   _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _sz, _vp, _vp],
+    "mrec_step_state_init": [_vp, _f32, _f32, _i64, _vp],
+    "mrec_step_advance": [_vp, _f32, _f32, _f32, _vp],
+    "mrec_wall_clock_khz": [_vp],
     "mrec_head_fwd_bwd_wide": [_i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_wide_sum_f32_i32": [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_wide_sum_f32_i64": [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
@@ -78,7 +83,7 @@ _SIGS = {
     "mrec_dense_adam_splitk_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32,
                                    _f32, _int, _vp],
     "mrec_dense_adam_slabs_f32": [_vp, _vp, _vp, _vp, _vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32,
-                                  _f32, _int, _vp],
+                                  _f32, _int, _vp, _vp],
     "mrec_dense_fwd_bf16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp],
     "mrec_dense_fwd_f16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp],
     "mrec_dense_bwd_input_workspace_bytes": [_i64, _i32, _szp],

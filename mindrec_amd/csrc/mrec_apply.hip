@@ -272,13 +272,13 @@ __device__ __forceinline__ int64_t seg_row(const K* uniq, int seg) {
 // VGPRs, i.e. from 6 to 4 waves per SIMD, and the lost latency hiding cost more than everything else the wide lane does;
 // 96 registers fit without spilling, 80 do not)
 template <int VEC, class K, class Upd, class GT, bool WIDE = false>
-__global__ __launch_bounds__(256, WIDE ? 5 : 1) void k_apply_main(Upd upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
+__device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
                                                     const int* __restrict__ spos, const int* __restrict__ sseg,
                                                     int n, const GT* __restrict__ g, int64_t ldg,
                                                     const float* __restrict__ rscale, float gscale, ApplyGeom gm,
                                                     float* __restrict__ carry_head, float* __restrict__ carry_tail,
                                                     int* __restrict__ owners, const int* __restrict__ seg_offsets,
-                                                    WideArgs wa) {
+                                                    const WideArgs& wa) {
     constexpr int AW = ACfg<VEC>::AW, AB = ACfg<VEC>::AB, GP = ACfg<VEC>::GP;
     constexpr bool NT = ACfg<VEC>::NT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -398,6 +398,39 @@ __global__ __launch_bounds__(256, WIDE ? 5 : 1) void k_apply_main(Upd upd, int64
     if (sub == 0) owners[sw] = flag;
 }
 
+// Step scalars from device memory (ss != nullptr): the Adam step size of this step, and the kernel's own begin / end wall
+// clock stamps (events recorded inside a captured graph cannot be timed on this stack; these can).
+template <class Upd>
+__device__ __forceinline__ void resolve_step(Upd&, const StepState*) {}
+__device__ __forceinline__ void resolve_step(UpdAdam& u, const StepState* ss) { if (ss) u.h.lr_t = ss->lr_t; }
+
+template <int VEC, class K, class Upd, class GT, bool WIDE = false>
+__global__ __launch_bounds__(256, WIDE ? 5 : 1) void k_apply_main(Upd upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
+                                                    const int* __restrict__ spos, const int* __restrict__ sseg,
+                                                    int n, const GT* __restrict__ g, int64_t ldg,
+                                                    const float* __restrict__ rscale, float gscale, ApplyGeom gm,
+                                                    float* __restrict__ carry_head, float* __restrict__ carry_tail,
+                                                    int* __restrict__ owners, const int* __restrict__ seg_offsets,
+                                                    WideArgs wa, StepState* ss) {
+    resolve_step(upd, ss);
+    // Stamps: workgroup 0 (dispatched first) stores the begin; the last wave of every workgroup raises the end -- ONE global
+    // atomic per workgroup (an atomic per wave on the one address serialised at ~6 ns each and made the kernel 140 us longer).
+    __shared__ int waves_done;
+    unsigned long long* stamp = ss ? ss->stamps[(unsigned)ss->step % kStampRing] : nullptr;
+    if (stamp) {
+        if (threadIdx.x == 0) {
+            waves_done = 0;
+            if (blockIdx.x == 0) stamp[0] = (unsigned long long)wall_clock64();
+        }
+        __syncthreads();
+    }
+    apply_main_body<VEC, K, Upd, GT, WIDE>(upd, V, ld, uniq, spos, sseg, n, g, ldg, rscale, gscale, gm, carry_head, carry_tail, owners,
+                                           seg_offsets, wa);
+    if (stamp && (threadIdx.x & 63) == 0 && atomicAdd(&waves_done, 1) == 3)
+        atomicMax(&stamp[1], (unsigned long long)wall_clock64());
+}
+
+
 // Finishes the runs that cross windows.  Partial 0 is the owner's tail, partials 1..k the heads of the
 // following k windows.
 //   pass A: runs with at most NG = 4*G partials -- one lane-group each, partials added in order, no barriers
@@ -411,7 +444,9 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
                                                     const int* __restrict__ seg_offsets, int n, ApplyGeom gm,
                                                     const float* __restrict__ carry_head,
                                                     const float* __restrict__ carry_tail,
-                                                    const int* __restrict__ owners, int nsw, WideArgs wa) {
+                                                    const int* __restrict__ owners, int nsw, WideArgs wa,
+                                                    const StepState* ss) {
+    resolve_step(upd, ss);
     // the partials of a run are consecutive carry rows: stream them 16 deep per lane-group
     constexpr int AW = ACfg<VEC>::AW, AB = 16;
     __shared__ float red[256 * 4];
@@ -552,7 +587,7 @@ size_t apply_ws_bytes(int64_t n, int32_t D) {
 template <class K, class Upd, class GT>
 int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, const int* sseg,
                const int* seg_offsets, int64_t n, const GT* g, int64_t ldg, const float* rscale, float gscale,
-               int Dc, int vec, const ApplyWs& w, hipStream_t st, const WideArgs* wide = nullptr) {
+               int Dc, int vec, const ApplyWs& w, hipStream_t st, const WideArgs* wide = nullptr, StepState* ss = nullptr) {
     ApplyGeom gm;
     gm.D = Dc + (wide ? 4 : 0);
     gm.lpr = Dc / vec + (wide ? 1 : 0);
@@ -573,28 +608,28 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
     if (ev0) MREC_HIP_CHECK(hipEventRecord(ev0, st));
     if (vec == 4 && wide) {
         k_apply_main<4, K, Upd, GT, true><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
-                                                             w.carry_head, w.carry_tail, w.owners, seg_offsets, wa);
+                                                             w.carry_head, w.carry_tail, w.owners, seg_offsets, wa, ss);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         k_apply_long<4, K, Upd, true><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
-                                                              w.carry_head, w.carry_tail, w.owners, (int)nsw, wa);
+                                                              w.carry_head, w.carry_tail, w.owners, (int)nsw, wa, ss);
     } else if (vec == 4) {
         k_apply_main<4, K, Upd, GT><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
-                                                       w.carry_head, w.carry_tail, w.owners, seg_offsets, wa);
+                                                       w.carry_head, w.carry_tail, w.owners, seg_offsets, wa, ss);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         k_apply_long<4, K, Upd><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
-                                                        w.carry_head, w.carry_tail, w.owners, (int)nsw, wa);
+                                                        w.carry_head, w.carry_tail, w.owners, (int)nsw, wa, ss);
     } else if (vec == 2) {
         k_apply_main<2, K, Upd, GT><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
-                                                       w.carry_head, w.carry_tail, w.owners, seg_offsets, wa);
+                                                       w.carry_head, w.carry_tail, w.owners, seg_offsets, wa, ss);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         k_apply_long<2, K, Upd><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
-                                                        w.carry_head, w.carry_tail, w.owners, (int)nsw, wa);
+                                                        w.carry_head, w.carry_tail, w.owners, (int)nsw, wa, ss);
     } else {
         k_apply_main<1, K, Upd, GT><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
-                                                       w.carry_head, w.carry_tail, w.owners, seg_offsets, wa);
+                                                       w.carry_head, w.carry_tail, w.owners, seg_offsets, wa, ss);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         k_apply_long<1, K, Upd><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
-                                                        w.carry_head, w.carry_tail, w.owners, (int)nsw, wa);
+                                                        w.carry_head, w.carry_tail, w.owners, (int)nsw, wa, ss);
     }
     MREC_LAUNCH_CHECK();
     return MREC_OK;
@@ -603,7 +638,7 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
 template <class K, class Upd, class GT = float>
 int apply_impl(Upd upd, int64_t V, int64_t ld, int32_t D, const K* uniq, const int32_t* spos, const int32_t* sseg,
                const int32_t* seg_offsets, int64_t n, const GT* g, int64_t ldg, const float* rscale,
-               float gscale, void* ws, size_t ws_bytes, void* stream, const WideArgs* wide = nullptr) {
+               float gscale, void* ws, size_t ws_bytes, void* stream, const WideArgs* wide = nullptr, StepState* ss = nullptr) {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || D <= 0 || V < 0 || ld < D || ldg < D) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
@@ -633,7 +668,7 @@ int apply_impl(Upd upd, int64_t V, int64_t ld, int32_t D, const K* uniq, const i
         const int Dc = (D - c0 < CB) ? D - c0 : CB;
         Upd u2 = upd;
         for (int i = 0; i < Upd::NS; ++i) u2.s[i] = upd.s[i] + c0;
-        int rc = apply_cols<K, Upd, GT>(u2, V, ld, uniq, spos, sseg, seg_offsets, n, g + c0, ldg, rscale, gscale, Dc, vec, w, st, wide);
+        int rc = apply_cols<K, Upd, GT>(u2, V, ld, uniq, spos, sseg, seg_offsets, n, g + c0, ldg, rscale, gscale, Dc, vec, w, st, wide, ss);
         if (rc != MREC_OK) return rc;
     }
     return MREC_OK;
@@ -644,7 +679,7 @@ int lazy_adam_impl(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t 
                    const int32_t* spos, const int32_t* sseg, const int32_t* seg_offsets, int64_t n, const GT* g,
                    int64_t ldg, const float* rscale, float lr, float b1, float b2, float eps, float b1_pow,
                    float b2_pow, float gscale, int nesterov, void* ws, size_t ws_bytes, void* stream,
-                   const WideArgs* wide = nullptr) {
+                   const WideArgs* wide = nullptr, StepState* ss = nullptr) {
     if (!uniq && n > 0) return MREC_EINVAL;
     UpdAdam u;
     u.s[0] = p; u.s[1] = m; u.s[2] = v;
@@ -652,7 +687,7 @@ int lazy_adam_impl(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t 
     u.h.b1 = b1; u.h.b2 = b2; u.h.omb1 = 1.0f - b1; u.h.omb2 = 1.0f - b2; u.h.eps = eps; u.h.gscale = gscale;
     u.h.nesterov = nesterov;
     return apply_impl<K, UpdAdam, GT>(u, V, ld, D, uniq, spos, sseg, seg_offsets, n, g, ldg, rscale, gscale, ws, ws_bytes,
-                                  stream, wide);
+                                  stream, wide, ss);
 }
 
 template <class K>
@@ -669,6 +704,43 @@ int ftrl_impl(float* var, float* accum, float* linear, int64_t V, int64_t ld, in
 }
 
 }  // namespace
+
+namespace {
+__global__ void k_step_init(StepState* s, float b1p, float b2p, long long step) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { s->b1p = b1p; s->b2p = b2p; s->lr_t = 0.f; s->pad0 = 0.f; s->step = step; s->pad1 = 0; }
+    if (i < kStampRing) { s->stamps[i][0] = ~0ull; s->stamps[i][1] = 0ull; }
+}
+__global__ void k_step_advance(StepState* s, float lr, float b1, float b2) {
+    const float b1p = s->b1p * b1, b2p = s->b2p * b2;
+    const long long step = s->step + 1;
+    s->b1p = b1p; s->b2p = b2p; s->step = step;
+    s->lr_t = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);      // same fp32 operations as the host-side entries
+    s->stamps[(unsigned)step % kStampRing][0] = ~0ull;
+    s->stamps[(unsigned)step % kStampRing][1] = 0ull;
+}
+}  // namespace
+
+MREC_API int mrec_step_state_init(void* state, float beta1_power, float beta2_power, int64_t step, void* stream) {
+    if (!state || step < 0) return MREC_EINVAL;
+    k_step_init<<<1, 256, 0, (hipStream_t)stream>>>((StepState*)state, beta1_power, beta2_power, (long long)step);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+MREC_API int mrec_step_advance(void* state, float lr, float beta1, float beta2, void* stream) {
+    if (!state) return MREC_EINVAL;
+    k_step_advance<<<1, 1, 0, (hipStream_t)stream>>>((StepState*)state, lr, beta1, beta2);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+MREC_API int mrec_wall_clock_khz(int32_t* out) {
+    if (!out) return MREC_EINVAL;
+    int dev = 0, khz = 0;
+    MREC_HIP_CHECK(hipGetDevice(&dev));
+    MREC_HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+    *out = khz;
+    return MREC_OK;
+}
 
 MREC_API int mrec_event_create(void** ev_out) {
     if (!ev_out) return MREC_EINVAL;
@@ -782,14 +854,15 @@ MREC_API int mrec_sparse_lazy_adam_wide(float* p, float* m, float* v, int64_t V,
                                         const float* row_scale, float lr, float b1, float b2, float eps, float b1_pow,
                                         float b2_pow, float grad_scale, int nesterov, const float* gw, int32_t F,
                                         int32_t wide_col, float ftrl_lr, float l1, float l2, float lr_power, void* ws,
-                                        size_t ws_bytes, void* stream) {
+                                        size_t ws_bytes, void* step_state, void* stream) {
     if ((uniq_bytes != 4 && uniq_bytes != 8) || g_kind < 0 || g_kind > 2) return MREC_EINVAL;
     WideArgs wa;
     wa.gw = gw; wa.F = F; wa.wcol = wide_col; wa.magic = 0; wa.dummy = nullptr;
     wa.h = FtrlH{ftrl_lr, l1, l2, lr_power, grad_scale};
 #define MREC_WIDE_CALL(KT, GT)                                                                                          \
     return lazy_adam_impl<KT, GT>(p, m, v, V, ld, D, (const KT*)uniq, sorted_pos, sorted_seg, seg_offsets, n, (const GT*)g, ldg, \
-                                  row_scale, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale, nesterov, ws, ws_bytes, stream, &wa)
+                                  row_scale, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale, nesterov, ws, ws_bytes, stream, &wa,      \
+                                  (StepState*)step_state)
     if (uniq_bytes == 4) {
         if (g_kind == 0) { MREC_WIDE_CALL(int32_t, float); }
         if (g_kind == 1) { MREC_WIDE_CALL(int32_t, bf16_t); }

@@ -107,51 +107,82 @@ __global__ __launch_bounds__(DB) void k_dedup_insert(const K* __restrict__ ids, 
     }
 }
 
-__global__ __launch_bounds__(DB) void k_dedup_count(const int* __restrict__ slots,
-                                                    const int* __restrict__ sidx, int n,
-                                                    int* __restrict__ blocksum) {
-    __shared__ int sm[8];
-    const int base = blockIdx.x * DT + threadIdx.x * DI;
-    int c = 0;
+// Decoupled look-back over the tiles' first-occurrence counts (one status word per tile: flag << 30 | value; flag 1 = the
+// tile's own count, 2 = inclusive prefix).  Tiles are dispatched in index order and only ever wait for lower-numbered
+// tiles, so the wait always ends.  The words are zero when the kernel starts: the NEXT kernel of the chain clears them again
+// (k_radix_hist / k_dedup_inv), which is what keeps a primed workspace primed.
+constexpr unsigned kFlagA = 1u << 30, kFlagP = 2u << 30, kFlagMask = 3u << 30;
+
+__device__ __forceinline__ int lookback_excl(unsigned* status, int tile) {
+    const int l = lane_id();
+    int excl = 0;
+    for (int base = tile - 1;; base -= 64) {
+        const int idx = base - l;
+        unsigned st;
+        do {
+            st = (idx >= 0) ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kFlagP;
+        } while (__any((st & kFlagMask) == 0));
+        const uint64_t pm = __ballot((st & kFlagMask) == kFlagP);
+        const int firstp = pm ? __ffsll((long long)pm) - 1 : 63; // nearest predecessor with an inclusive prefix (the virtual
+        int c = (l <= firstp) ? (int)(st & ~kFlagMask) : 0;      // tiles below 0 carry one); none in this round: add all 64
 #pragma unroll
-    for (int k = 0; k < DI; ++k) {
-        const int i = base + k;
-        if (i < n) c += (slots[sidx[i]] == i);
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+        excl += c;
+        if (pm) break;
     }
-    int tot;
-    block_excl_scan_256(c, sm, &tot);
-    if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+    return excl;
 }
 
+// Numbers the first occurrences in position order in ONE pass (flag + count + scan + rank), and hands every claimed slot
+// back to EMPTY on the way: a slot's only reader that needs its value is the thread of the first occurrence itself (every
+// other position of the key sees "not me" before and after), so the scratch table leaves the call as it entered it and the
+// next call on the same workspace needs no memset.
 template <class K>
-__global__ __launch_bounds__(DB) void k_dedup_rank(const K* __restrict__ ids, const int* __restrict__ slots,
-                                                   const int* __restrict__ sidx, int n,
-                                                   const int* __restrict__ blocksum, int nblk,
-                                                   K* __restrict__ uniq, int* __restrict__ srank,
+__global__ __launch_bounds__(DB) void k_dedup_rank(const K* __restrict__ ids, int* __restrict__ slots,
+                                                   const int* __restrict__ sidx, int n, unsigned* __restrict__ status,
+                                                   int nblk, K* __restrict__ uniq, int* __restrict__ srank,
                                                    int64_t* __restrict__ n_uniq_dev) {
     __shared__ int sm[8];
-    int part = 0;
-    for (int b = threadIdx.x; b < (int)blockIdx.x; b += DB) part += blocksum[b];
-    int tile_base;
-    block_excl_scan_256(part, sm, &tile_base);
-
+    __shared__ int s_excl;
     const int base = blockIdx.x * DT + threadIdx.x * DI;
     bool first[DI];
+    int slot[DI];
     int c = 0;
 #pragma unroll
     for (int k = 0; k < DI; ++k) {
         const int i = base + k;
-        first[k] = (i < n) && (slots[sidx[i]] == i);
+        slot[k] = (i < n) ? sidx[i] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < DI; ++k) {
+        const int i = base + k;
+        first[k] = (i < n) && (slots[slot[k]] == i);
         c += first[k];
     }
     int tot;
-    int r = tile_base + block_excl_scan_256(c, sm, &tot);
+    const int pre = block_excl_scan_256(c, sm, &tot);
+    if (threadIdx.x < 64) {
+        const int t = blockIdx.x;
+        int excl = 0;
+        if (t == 0) {
+            if (threadIdx.x == 0) __hip_atomic_store(&status[0], kFlagP | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (threadIdx.x == 0) __hip_atomic_store(&status[t], kFlagA | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            excl = lookback_excl(status, t);
+            if (threadIdx.x == 0) __hip_atomic_store(&status[t], kFlagP | (unsigned)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (threadIdx.x == 0) s_excl = excl;
+    }
+    __syncthreads();
+    const int tile_base = s_excl;
+    int r = tile_base + pre;
 #pragma unroll
     for (int k = 0; k < DI; ++k) {
         if (first[k]) {
             const int i = base + k;
             uniq[r] = ids[i];
-            srank[sidx[i]] = r;
+            srank[slot[k]] = r;
+            slots[slot[k]] = kEmpty;
             ++r;
         }
     }
@@ -159,20 +190,23 @@ __global__ __launch_bounds__(DB) void k_dedup_rank(const K* __restrict__ ids, co
 }
 
 __global__ __launch_bounds__(DB) void k_dedup_inv(const int* __restrict__ srank, const int* __restrict__ sidx,
-                                                  int n, int* __restrict__ inv) {
+                                                  int n, int* __restrict__ inv, unsigned* __restrict__ status, int nstatus) {
     const int i = blockIdx.x * DB + threadIdx.x;
+    if (i < nstatus) status[i] = 0;                   // the look-back words of k_dedup_rank, for the next call
     if (i < n) inv[i] = srank[sidx[i]];
 }
 
 __global__ void k_set_i64(int64_t* p, int64_t v) { *p = v; }
 
-struct DedupScratch { int* srank; int* sidx; };
+struct DedupScratch { int* srank; int* sidx; unsigned* status; int nstatus; };
 
 // fuse_inv_out != nullptr: skip the inverse kernel and hand back (srank, sidx) so the caller's first
 // radix histogram can produce inv on the fly.
+// primed: the caller vouches that the last thing that wrote this workspace was a completed call of this function with the
+// same n (see MREC_PLAN_WS_PRIMED in include/mrec.h) -- the scratch table and the look-back words are then already clean.
 template <class K>
 int dedup_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_dev, void* ws, size_t ws_bytes,
-               void* stream_v, DedupScratch* fuse_inv_out = nullptr) {
+               void* stream_v, DedupScratch* fuse_inv_out = nullptr, bool primed = false) {
     hipStream_t st = (hipStream_t)stream_v;
     if (n < 0 || !n_uniq_dev) return MREC_EINVAL;
     if (n == 0) {
@@ -181,7 +215,7 @@ int dedup_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_d
         return MREC_OK;
     }
     if (!ids || !uniq || !inv || !ws) return MREC_EINVAL;
-    if (n > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
+    if (n >= (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
     uint64_t cap = 1024;
     while (cap < (uint64_t)n * 2) cap <<= 1;
     const int nblk = (int)mrec_cdiv(n, DT);
@@ -189,15 +223,17 @@ int dedup_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_d
     int* slots = a.take<int>(cap);
     int* srank = a.take<int>(cap);
     int* sidx = a.take<int>(n);
-    int* blocksum = a.take<int>(nblk);
+    unsigned* status = (unsigned*)a.take<int>(nblk);
     if (!a.ok) return MREC_EWORKSPACE;
-    MREC_HIP_CHECK(hipMemsetAsync(slots, 0x7f, cap * sizeof(int), st));
+    if (!primed) {
+        MREC_HIP_CHECK(hipMemsetAsync(slots, 0x7f, cap * sizeof(int), st));
+        MREC_HIP_CHECK(hipMemsetAsync(status, 0, (size_t)nblk * sizeof(int), st));
+    }
     const int g256 = (int)mrec_cdiv(n, DB);
     k_dedup_insert<K><<<(int)mrec_cdiv(n, IT), DB, 0, st>>>(ids, (int)n, slots, (uint32_t)(cap - 1), sidx);
-    k_dedup_count<<<nblk, DB, 0, st>>>(slots, sidx, (int)n, blocksum);
-    k_dedup_rank<K><<<nblk, DB, 0, st>>>(ids, slots, sidx, (int)n, blocksum, nblk, uniq, srank, n_uniq_dev);
-    if (fuse_inv_out) { fuse_inv_out->srank = srank; fuse_inv_out->sidx = sidx; }
-    else k_dedup_inv<<<g256, DB, 0, st>>>(srank, sidx, (int)n, inv);
+    k_dedup_rank<K><<<nblk, DB, 0, st>>>(ids, slots, sidx, (int)n, status, nblk, uniq, srank, n_uniq_dev);
+    if (fuse_inv_out) { fuse_inv_out->srank = srank; fuse_inv_out->sidx = sidx; fuse_inv_out->status = status; fuse_inv_out->nstatus = nblk; }
+    else k_dedup_inv<<<g256, DB, 0, st>>>(srank, sidx, (int)n, inv, status, nblk);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -215,7 +251,7 @@ __global__ __launch_bounds__(256) void k_seg_offsets(const int* __restrict__ sse
 
 MREC_API int mrec_dedup_workspace_bytes(int64_t n, size_t* out) {
     if (!out || n < 0) return MREC_EINVAL;
-    if (n > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
+    if (n >= (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
     uint64_t cap = 1024;
     while (cap < (uint64_t)n * 2) cap <<= 1;
     size_t b = 0;
@@ -279,7 +315,7 @@ static int group_impl(const int32_t* inv, int64_t n, int32_t* sorted_pos, int32_
         const int shift = p * pbits;
         if (p == 0 && fuse)      // pass 0 computes inv = srank[sidx[i]] while it builds its histogram
             radix_pass(inv_out, vin, (int)n, shift, pbits, hist, hscan, totals, nullptr, kout, vout, st, fuse->srank,
-                       fuse->sidx, inv_out);
+                       fuse->sidx, inv_out, fuse->status, fuse->nstatus);
         else
             radix_pass(kin, vin, (int)n, shift, pbits, hist, hscan, totals, nullptr, kout, vout, st);
         kin = kout;
@@ -299,7 +335,7 @@ MREC_API int mrec_group_by_inverse(const int32_t* inv, int64_t n, int32_t* sorte
 // radix histogram, saving a pass and a launch over mrec_dedup_* followed by mrec_group_by_inverse.
 template <class K>
 static int plan_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_dev, int32_t* sorted_pos,
-                     int32_t* sorted_seg, int32_t* seg_offsets, void* ws, size_t ws_bytes, void* stream) {
+                     int32_t* sorted_seg, int32_t* seg_offsets, void* ws, size_t ws_bytes, void* stream, bool primed = false) {
     if (n < 0 || !n_uniq_dev || !seg_offsets) return MREC_EINVAL;
     size_t db = 0, gb = 0;
     int rc = mrec_dedup_workspace_bytes(n, &db);
@@ -307,8 +343,8 @@ static int plan_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_
     rc = mrec_group_workspace_bytes(n, &gb);
     if (rc != MREC_OK) return rc;
     if (n > 0 && (!ws || ws_bytes < db + gb)) return MREC_EWORKSPACE;
-    DedupScratch sc{nullptr, nullptr};
-    rc = dedup_impl<K>(ids, n, uniq, inv, n_uniq_dev, ws, db, stream, n > 0 ? &sc : nullptr);
+    DedupScratch sc{nullptr, nullptr, nullptr, 0};
+    rc = dedup_impl<K>(ids, n, uniq, inv, n_uniq_dev, ws, db, stream, n > 0 ? &sc : nullptr, primed);
     if (rc != MREC_OK) return rc;
     return group_impl(nullptr, n, sorted_pos, sorted_seg, seg_offsets, (char*)ws + db, gb, stream, n > 0 ? &sc : nullptr, inv);
 }
@@ -331,4 +367,18 @@ MREC_API int mrec_sparse_plan_i64(const int64_t* ids, int64_t n, int64_t* uniq, 
                                   int32_t* sorted_pos, int32_t* sorted_seg, int32_t* seg_offsets, void* ws,
                                   size_t ws_bytes, void* stream) {
     return plan_impl<int64_t>(ids, n, uniq, inv, n_uniq_dev, sorted_pos, sorted_seg, seg_offsets, ws, ws_bytes, stream);
+}
+
+// flags & MREC_PLAN_WS_PRIMED: skip the two memsets (see include/mrec.h)
+MREC_API int mrec_sparse_plan_ex_i32(const int32_t* ids, int64_t n, int32_t* uniq, int32_t* inv, int64_t* n_uniq_dev,
+                                     int32_t* sorted_pos, int32_t* sorted_seg, int32_t* seg_offsets, void* ws,
+                                     size_t ws_bytes, uint32_t flags, void* stream) {
+    return plan_impl<int32_t>(ids, n, uniq, inv, n_uniq_dev, sorted_pos, sorted_seg, seg_offsets, ws, ws_bytes, stream,
+                              (flags & MREC_PLAN_WS_PRIMED) != 0);
+}
+MREC_API int mrec_sparse_plan_ex_i64(const int64_t* ids, int64_t n, int64_t* uniq, int32_t* inv, int64_t* n_uniq_dev,
+                                     int32_t* sorted_pos, int32_t* sorted_seg, int32_t* seg_offsets, void* ws,
+                                     size_t ws_bytes, uint32_t flags, void* stream) {
+    return plan_impl<int64_t>(ids, n, uniq, inv, n_uniq_dev, sorted_pos, sorted_seg, seg_offsets, ws, ws_bytes, stream,
+                              (flags & MREC_PLAN_WS_PRIMED) != 0);
 }

@@ -388,7 +388,9 @@ __device__ __forceinline__ unsigned pack_shadow2(float lo, float hi, int shk) {
 template <int SHK>
 __global__ __launch_bounds__(256) void k_dense_adam4_slabs(float4* __restrict__ p, float4* __restrict__ m,
                                                            float4* __restrict__ v, const float4* __restrict__ g,
-                                                           int64_t n4, AdamH h, uint2* __restrict__ shadow, SlabSegs sg) {
+                                                           int64_t n4, AdamH h, uint2* __restrict__ shadow, SlabSegs sg,
+                                                           const StepState* ss) {
+    if (ss) h.lr_t = ss->lr_t;             // this step's bias-corrected step size from device memory (mrec_step_advance)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 pp = p[i], mm = m[i], vv = v[i];
         float4 gg;
@@ -767,8 +769,10 @@ MREC_API int mrec_dense_adam_splitk_f32(float* p, float* m, float* v, const floa
 MREC_API int mrec_dense_adam_slabs_f32(float* p, float* m, float* v, const float* g, void* shadow16, int shadow_kind,
                                        int64_t n, int32_t nseg, const float* const* slabs, const int64_t* starts,
                                        const int64_t* lens, const int32_t* splits, float lr, float b1, float b2, float eps,
-                                       float b1_pow, float b2_pow, float grad_scale, int nesterov, void* stream) {
+                                       float b1_pow, float b2_pow, float grad_scale, int nesterov, void* step_state,
+                                       void* stream) {
     if (n < 0 || nseg < 0 || nseg > 16 || shadow_kind < 0 || shadow_kind > 2) return MREC_EINVAL;
+    const StepState* ss = (const StepState*)step_state;
     if (n == 0) return MREC_OK;
     if (!p || !m || !v || !g || (nseg > 0 && (!slabs || !starts || !lens || !splits)) || (shadow_kind && !shadow16))
         return MREC_EINVAL;
@@ -792,9 +796,9 @@ MREC_API int mrec_dense_adam_slabs_f32(float* p, float* m, float* v, const float
     const int64_t n4 = n / 4;
     hipStream_t st = (hipStream_t)stream;
     const unsigned gr = stream_grid(n4);
-    if (shadow_kind == 1) k_dense_adam4_slabs<1><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow16, sg);
-    else if (shadow_kind == 2) k_dense_adam4_slabs<2><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow16, sg);
-    else k_dense_adam4_slabs<0><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, nullptr, sg);
+    if (shadow_kind == 1) k_dense_adam4_slabs<1><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow16, sg, ss);
+    else if (shadow_kind == 2) k_dense_adam4_slabs<2><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow16, sg, ss);
+    else k_dense_adam4_slabs<0><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, nullptr, sg, ss);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }

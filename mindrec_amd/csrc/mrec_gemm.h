@@ -106,6 +106,9 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
     static_assert(MR == 8 || MR == 4, "tile configurations: MR = 8 (256 x 256) or MR = 4 (128 x 256)");
     constexpr int WP = MR * 16;          // P rows per wave
     constexpr int BP = 2 * WP;           // P rows per workgroup
+    // These waves outrank whatever shares the CU with them (the step's plan kernels on the side branch): base priority 2,
+    // 3 inside the MFMA clusters.
+    if (!(VAR & 2)) __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 2, wc = w & 3;
@@ -238,14 +241,14 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
     // one quadrant: 4 P reps x 2 Q reps x 2 k-steps (the second k-step is skipped in a half tail tile)
 #define MG_MFMA(MH, NH, F, HALF)                                                                       \
     do {                                                                                               \
-        if (!(VAR & 2)) __builtin_amdgcn_s_setprio(1);                                                 \
+        if (!(VAR & 2)) __builtin_amdgcn_s_setprio(3);                                                 \
         _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_) _Pragma("unroll") for (int nj_ = 0; nj_ < 2; ++nj_) \
             acc[(MH) * 4 + mi_][(NH) * 2 + nj_] = E::mfma(F[nj_][0], fP[mi_][0], acc[(MH) * 4 + mi_][(NH) * 2 + nj_]); \
         if (!(HALF)) {                                                                                 \
             _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_) _Pragma("unroll") for (int nj_ = 0; nj_ < 2; ++nj_) \
                 acc[(MH) * 4 + mi_][(NH) * 2 + nj_] = E::mfma(F[nj_][1], fP[mi_][1], acc[(MH) * 4 + mi_][(NH) * 2 + nj_]); \
         }                                                                                              \
-        if (!(VAR & 2)) __builtin_amdgcn_s_setprio(0);                                                 \
+        if (!(VAR & 2)) __builtin_amdgcn_s_setprio(2);                                                 \
     } while (0)
 #define MG_SYNC_PRE()                                     \
     do {                                                  \

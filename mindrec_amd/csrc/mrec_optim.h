@@ -15,6 +15,16 @@ __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g,
     v = vn;
 }
 
+// Step scalars in device memory (mrec_step_state_t of include/mrec.h): the Adam bias-correction powers advance by a kernel
+// (mrec_step_advance), so a whole training step -- optimizer included -- replays as one HIP graph with constant arguments.
+constexpr int kStampRing = 256;
+struct StepState {
+    float b1p, b2p, lr_t, pad0;
+    long long step;
+    unsigned long long pad1;
+    unsigned long long stamps[kStampRing][2];   // [step % ring] = {first workgroup start, last wave end} of k_apply_main, wall clock ticks
+};
+
 struct FtrlH { float lr, l1, l2, lr_power, gscale; };
 
 __device__ __forceinline__ void ftrl_elem(float& w, float& a, float& lin, float g, const FtrlH& h) {

@@ -19,8 +19,11 @@ constexpr int RROUNDS = 8;
 // inverse of the dedup -- instead of being read: the Unique's last pass rides on the first histogram.
 __global__ __launch_bounds__(256) void k_radix_hist(const int* __restrict__ keys, int n, int shift, int nbits,
                                                     int* __restrict__ hist, const int* __restrict__ srank,
-                                                    const int* __restrict__ sidx, int* __restrict__ keys_out) {
+                                                    const int* __restrict__ sidx, int* __restrict__ keys_out,
+                                                    unsigned* __restrict__ clear, int nclear) {
     __shared__ int h[RNB];
+    // (the look-back words the Unique's rank kernel left behind: zeroed here for the next call, no launch of their own)
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < nclear; j += gridDim.x * 256) clear[j] = 0;
     const int NB = 1 << nbits;
     for (int d = threadIdx.x; d < NB; d += 256) h[d] = 0;
     __syncthreads();
@@ -176,10 +179,10 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const int* __restrict__ k
 // [2^nbits] ints, receives the exclusive digit offsets.
 inline void radix_pass(const int* kin, const int* vin, int n, int shift, int nbits, int* hist, int* hscan, int* totals,
                        int* dbase, int* kout, int* vout, hipStream_t st, const int* srank = nullptr,
-                       const int* sidx = nullptr, int* keys_gen = nullptr) {
+                       const int* sidx = nullptr, int* keys_gen = nullptr, unsigned* clear = nullptr, int nclear = 0) {
     const int nblk = (int)mrec_cdiv(n, RT);
     const int NB = 1 << nbits;
-    k_radix_hist<<<nblk, 256, 0, st>>>(kin, n, shift, nbits, hist, srank, sidx, keys_gen);
+    k_radix_hist<<<nblk, 256, 0, st>>>(kin, n, shift, nbits, hist, srank, sidx, keys_gen, clear, nclear);
     k_radix_colscan<<<(NB + 31) / 32, 256, 0, st>>>(hist, nblk, nbits, hscan, totals);
     k_radix_scatter<<<nblk, 256, 0, st>>>(kin, vin, n, shift, nbits, hscan, totals, kout, vout, dbase);
 }

@@ -6,6 +6,7 @@ only: no arithmetic on the hot path is done by torch here.
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -21,6 +22,9 @@ def _stream():
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+_PLAN_PRIMED = {}
 
 
 def workspace(tag, nbytes, device):
@@ -143,9 +147,14 @@ def sparse_plan(ids):
     sorted_seg = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     seg_offsets = torch.empty(n + 1, dtype=torch.int32, device=dev)
     nb = _lib.query_bytes("mrec_sparse_plan_workspace_bytes", n)
-    ws = workspace("plan", nb, dev)
-    _lib.call(f"mrec_sparse_plan_{sfx}", _ptr(flat), n, _ptr(uniq), _ptr(inv), _ptr(n_uniq), _ptr(sorted_pos),
-              _ptr(sorted_seg), _ptr(seg_offsets), _ptr(ws), ws.numel(), _stream())
+    # a workspace of its own per problem size: only plans of this n ever write it, and each of them hands the scratch table
+    # and the scan's look-back words back clean -- so every call after the first skips the memsets (MREC_PLAN_WS_PRIMED)
+    ws = workspace(f"plan:{n}:{sfx}", nb, dev)
+    key = (ws.data_ptr(), n, sfx)
+    primed = _PLAN_PRIMED.pop(key, False)          # (dropped while the call is in flight: an exception leaves it unprimed)
+    _lib.call(f"mrec_sparse_plan_ex_{sfx}", _ptr(flat), n, _ptr(uniq), _ptr(inv), _ptr(n_uniq), _ptr(sorted_pos),
+              _ptr(sorted_seg), _ptr(seg_offsets), _ptr(ws), ws.numel(), 1 if primed else 0, _stream())
+    _PLAN_PRIMED[key] = True
     return SparsePlan(Dedup(flat, uniq, inv, n_uniq), sorted_pos, sorted_seg, seg_offsets)
 
 
@@ -302,9 +311,11 @@ def sparse_lazy_adam_(p, m, v, plan, g, row_scale=None, lr=3.5e-4, beta1=0.9, be
 
 def sparse_lazy_adam_wide_(p, m, v, plan, g, row_scale, gw, F, wide_col, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8,
                            beta1_power=0.9, beta2_power=0.999, grad_scale=1.0, use_nesterov=False, ftrl_lr=5e-2, l1=1e-8, l2=1e-8,
-                           lr_power=-0.5):
+                           lr_power=-0.5, step_state=None):
     """LazyAdam on the deep columns and FTRL on the wide record of the same fused rows in ONE pass (wide_and_deep.py:420-430):
-    gw [n / F] is the wide branch's gradient per sample (the head's dlogit); position i contributes gw[i // F] * row_scale[i]."""
+    gw [n / F] is the wide branch's gradient per sample (the head's dlogit); position i contributes gw[i // F] * row_scale[i].
+    step_state (StepState): the Adam step size comes from device memory (beta powers ignored) and the main kernel stamps its
+    begin / end there."""
     _need_cuda(p, m, v, g, row_scale, gw)
     V, D, ld = _table(p)
     for t in (m, v):
@@ -320,7 +331,7 @@ def sparse_lazy_adam_wide_(p, m, v, plan, g, row_scale, gw, F, wide_col, lr=3.5e
     _lib.call("mrec_sparse_lazy_adam_wide", _ptr(p), _ptr(m), _ptr(v), V, ld, D, _ptr(plan.uniq_buf), plan.uniq_buf.element_size(),
               _ptr(plan.sorted_pos), _ptr(plan.sorted_seg), _ptr(plan.seg_offsets), plan.n, _ptr(g2), kind, ldg, _ptr(rs), lr,
               beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _ptr(gw), int(F), int(wide_col),
-              ftrl_lr, l1, l2, lr_power, _ptr(ws), ws.numel(), _stream())
+              ftrl_lr, l1, l2, lr_power, _ptr(ws), ws.numel(), _ptr(step_state.buf) if step_state is not None else None, _stream())
 
 
 def sparse_ftrl_(var, accum, linear, plan, g, row_scale=None, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):
@@ -613,6 +624,42 @@ def shard_route_rows(g, send_perm, row_scale=None):
 
 
 # ---- measurement hook ------------------------------------------------------------------------
+class StepState:
+    """mrec_step_state_t in device memory (include/mrec.h): the Adam bias-correction powers as the reference keeps them -- as
+    state the optimizer's own graph advances (nn.Adam: beta1_power *= beta1) -- so that a captured step has constant arguments."""
+    RING = 256
+    _DT = np.dtype([("beta1_power", "<f4"), ("beta2_power", "<f4"), ("lr_t", "<f4"), ("r0", "<f4"), ("step", "<i8"), ("r1", "<u8"),
+                    ("stamps", "<u8", (256, 2))])
+
+    def __init__(self, device, beta1_power=1.0, beta2_power=1.0, step=0):
+        self.buf = torch.empty(self._DT.itemsize, dtype=torch.uint8, device=device)
+        _need_cuda(self.buf)
+        self.reset(beta1_power, beta2_power, step)
+        khz = C.c_int32()
+        _lib.call("mrec_wall_clock_khz", C.byref(khz))
+        self.clock_khz = int(khz.value)
+
+    def reset(self, beta1_power, beta2_power, step):
+        _lib.call("mrec_step_state_init", _ptr(self.buf), float(beta1_power), float(beta2_power), int(step), _stream())
+
+    def advance(self, lr, beta1, beta2):
+        _lib.call("mrec_step_advance", _ptr(self.buf), float(lr), float(beta1), float(beta2), _stream())
+
+    def read(self):
+        """Host copy (synchronises): a numpy record with beta1_power, beta2_power, lr_t, step, stamps[256, 2]."""
+        return self.buf.cpu().numpy().view(self._DT)[0]
+
+    def apply_ms(self, steps):
+        """Durations (ms) of the main sparse-apply kernel in the given step numbers, from the kernel's own stamps."""
+        st = self.read()["stamps"]
+        out = []
+        for k in steps:
+            a, b = int(st[k % self.RING][0]), int(st[k % self.RING][1])
+            if b > a and a != 0xFFFFFFFFFFFFFFFF:
+                out.append((b - a) / self.clock_khz)
+        return out
+
+
 class KernelTimer:
     """Times exactly the main kernel of the next sparse-apply call (see include/mrec.h,
     mrec_profile_next_apply): arm() before the call, ms() afterwards (waits for the stop event)."""
@@ -828,7 +875,7 @@ def sum_slabs(slabs, out):
 
 
 def dense_adam_slabs_(p, m, v, g, slabs, shadow16=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, beta1_power=0.9,
-                      beta2_power=0.999, grad_scale=1.0, use_nesterov=False):
+                      beta2_power=0.999, grad_scale=1.0, use_nesterov=False, step_state=None):
     """dense_adam_ whose gradient is, for some segments, still the fp32 batch slabs of dense_bwd_weight:
     slabs = [(start, tensor [S, ...] fp32)], start = element offset of the segment in the flat buffers; the slabs
     are added in slab order inside the Adam kernel.  shadow16 (bf16 / fp16, optional) receives the updated parameters."""
@@ -854,7 +901,8 @@ def dense_adam_slabs_(p, m, v, g, slabs, shadow16=None, lr=1e-3, beta1=0.9, beta
         ptrs[q], starts[q], lens[q], splits[q] = part.data_ptr(), int(start), part[0].numel(), part.shape[0]
     _lib.call("mrec_dense_adam_slabs_f32", _ptr(p), _ptr(m), _ptr(v), _ptr(g), _ptr(shadow16), kind, n, k,
               C.cast(ptrs, C.c_void_p), C.cast(starts, C.c_void_p), C.cast(lens, C.c_void_p), C.cast(splits, C.c_void_p),
-              lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _stream())
+              lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov),
+              _ptr(step_state.buf) if step_state is not None else None, _stream())
 
 
 # ---- DeepFM second-order term ------------------------------------------------------------------

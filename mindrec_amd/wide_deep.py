@@ -81,6 +81,8 @@ class WideDeepConfig:
     host_cache_rows: int = 0         # > 0: both tables live in pinned host DRAM behind a device cache of this many rows (the
                                      # reference's vocab_cache_size, wide_and_deep.py:215-265); one GPU
     graph_front: bool = True       # one GPU: lookups + plan + MLP + wide FTRL replayed as ONE graph (needs graph_mlp)
+    graph_step: bool = True        # one GPU, folded wide branch: the sparse apply and the dense optimizers join that graph too (the
+                                   # Adam bias-correction powers live in device memory and advance by a kernel: ops.StepState)
     graph_mlp: bool = True         # replay the MLP forward+backward as captured HIP graphs (one host launch, not ~25)
 
 
@@ -285,7 +287,11 @@ class WideDeepEngine:
         self._db = {}                 # hidden layer -> fp32 partial sums of its bias gradient (same idea)
         self._dw_batch = None
         self.deep_apply_timer = None  # optional ops.KernelTimer armed right before the deep table's sparse apply
+        self._dyn = False             # step scalars (Adam powers / step size) in device memory: set per step
         self._front_graph = None      # one-GPU: the whole front of the step (lookups .. MLP backward) as one captured graph
+        self._step_graph = None       # ... and, with the wide branch folded, the whole step
+        self._step_state = None       # ops.StepState (device-side beta powers / step size), created on first use
+        self._state_step = -1         # the step count the device-side state stands at
 
     # ---- helpers -----------------------------------------------------------------------------
     def _tick(self, name):
@@ -657,21 +663,34 @@ class WideDeepEngine:
         # graph cut to pay for there); off for the one-GPU MLP-graph path, where it costs an extra graph boundary
         late_cfg = cfg.late_wide if cfg.late_wide is not None else (self._sharded or capturing)
         late = bool(self._side is not None and late_cfg and self._mfma and not self._fold_wide)
-        plan_early = None
+        plan_early, fork_ev = None, None
         if self.index is not None or self.hb is not None:
             ids, plan_early = self._translate_keys(ids)        # from here on `ids` are table row numbers
         elif self._side is not None and not self._sharded and not late:
             # one GPU: the plan needs nothing but the ids -- start it on the side stream BEFORE the gathers are
             # queued, so that it runs beside them (HBM-bound) and eats less into the first GEMM
             main = torch.cuda.current_stream()
-            self._side.wait_stream(main)
+            if capturing:
+                # Under capture the ORDER of issue decides nothing about concurrency but it decides which branch the graph
+                # runtime keeps on the launch queue: the branch whose first node is created first.  That must be the
+                # critical chain (gather -> GEMMs -> apply), or every step pays two cross-queue hops of ~10 us on it; so the
+                # fork point is only marked here and the plan is issued behind the lookups.
+                fork_ev = torch.cuda.Event()
+                fork_ev.record(main)
+            else:
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    plan_early = self.k.sparse_plan(ids)
+                for t in (plan_early.uniq_buf, plan_early.inv, plan_early.n_uniq_dev, plan_early.sorted_pos,
+                          plan_early.sorted_seg, plan_early.seg_offsets):
+                    self._rs(t, main)
+        emb, wide, route = self.lookup(ids, wts, defer_wide=late)
+        if fork_ev is not None:
+            # (forking it behind the output head instead -- beside the backward GEMMs -- was measured: 0.786 vs 0.764 ms)
+            self._side.wait_event(fork_ev)
             with torch.cuda.stream(self._side):
                 plan_early = self.k.sparse_plan(ids)
-            for t in (plan_early.uniq_buf, plan_early.inv, plan_early.n_uniq_dev, plan_early.sorted_pos,
-                      plan_early.sorted_seg, plan_early.seg_offsets):
-                self._rs(t, main)
-        emb, wide, route = self.lookup(ids, wts, defer_wide=late)
-        if self._side is not None and self.index is None and self.hb is None and plan_early is None:
+        if self._side is not None and self.index is None and self.hb is None and plan_early is None and fork_ev is None:
             # Side stream, in this order: (1) the wide branch, which the main stream joins only right before the
             # output head -- it runs while the hidden-layer GEMMs do; (2) the step's Unique + inverted index, which
             # needs only the ids (on a shard: the ids received from the other ranks) and is joined before the sparse
@@ -792,6 +811,36 @@ class WideDeepEngine:
             self._front_graph = None
             return None
 
+    # ---- ... and the whole step, optimizers included (wide branch folded: every kernel argument is constant) --------
+    def _step_replay(self, ids, wts, label):
+        g = self._step_graph
+        if g is None or g["ids"].shape != ids.shape or g["ids"].dtype != ids.dtype:
+            g = self._capture_step(ids.clone(), wts.clone(), label.clone())
+            if g is None:
+                return None
+            self._step_graph = g
+        self.k.copy3_((g["ids"], g["wts"], g["label"]), (ids, wts, label))
+        g["graph"].replay()
+        self.last_plan = g["plan"]
+        return g["loss"]
+
+    def _capture_step(self, ids, wts, label):
+        try:
+            g = {"ids": ids, "wts": wts, "label": label}
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                front = self._front(ids, wts, label, capturing=True)
+                g["loss"] = self._tail(front, ids, wts)
+            g["graph"], g["plan"] = graph, self.last_plan
+            return g
+        except RuntimeError as e:
+            import warnings
+            warnings.warn(f"HIP-graph capture of the whole step failed, falling back to the front graph: {e}")
+            self.cfg.graph_step = False
+            self._step_graph = None
+            return None
+
     def _sum_dw_slabs(self):
         """Weight- and bias-gradient slabs -> the flat gradient buffer (needed only where somebody other than the dense
         Adam reads the summed gradient: the data-parallel all-reduce)."""
@@ -806,16 +855,42 @@ class WideDeepEngine:
         B, Fd = ids.shape
         D = cfg.emb_dim
         inv_sens = 1.0 / cfg.sens
+        self._dyn = bool(self._fold_wide and self._mfma and not self._sharded and self._gpu)
+        if self._dyn:
+            # device-side step scalars (ops.StepState): brought in line with the host mirrors whenever somebody else moved
+            # those (first step, load_checkpoint)
+            if self._step_state is None:
+                self._step_state = self.k.StepState(self.device)
+            if self._state_step != self.step_count:
+                self._step_state.reset(self.beta1_power, self.beta2_power, self.step_count)
         self.step_count += 1
         self.beta1_power = np.float32(self.beta1_power * self.beta1)
         self.beta2_power = np.float32(self.beta2_power * self.beta2)
+        self._state_step = self.step_count
 
+        if self._dyn and cfg.graph_step and self._front_graph_ok():
+            self.deep_apply_timer = None              # (HIP events cannot be timed from inside a graph; the kernel stamps
+            loss = self._step_replay(ids, wts, label)  # its own begin / end in the step state instead)
+            if loss is not None:
+                return loss
         front = None
         if self._front_graph_ok():
             front = self._front_replay(ids, wts, label)
         if front is None:
             front = self._front(ids, wts, label)
+        return self._tail(front, ids, wts)
+
+    def _tail(self, front, ids, wts):
+        """The optimizer half of a step: sparse applies, (shards) gradient exchange, dense Adam / FTRL."""
+        cfg = self.cfg
+        B, Fd = ids.shape
+        D = cfg.emb_dim
+        inv_sens = 1.0 / cfg.sens
         loss, g_emb, g_wide, plan_early, wide_done, route, early_gw, fused = front
+        state = None
+        if self._dyn:
+            state = self._step_state
+            state.advance(cfg.adam_lr, float(self.beta1), float(self.beta2))       # one thread: powers *= betas, lr_t
 
         if fused:
             # d loss / d Wide_b = sum of dlogit = the output layer's bias gradient, which the head kernel has
@@ -840,7 +915,8 @@ class WideDeepEngine:
                 self.k.sparse_lazy_adam_wide_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, g_wide, Fd, D,
                                               lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
                                               beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
-                                              grad_scale=inv_sens, ftrl_lr=cfg.ftrl_lr, l1=cfg.ftrl_l1, l2=cfg.ftrl_l2)
+                                              grad_scale=inv_sens, ftrl_lr=cfg.ftrl_lr, l1=cfg.ftrl_l1, l2=cfg.ftrl_l2,
+                                              step_state=state)
             else:
                 self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, lr=cfg.adam_lr,
                                          beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
@@ -920,8 +996,8 @@ class WideDeepEngine:
             if self.world > 1:
                 self.dense_grad_ext.div_(self.world)  # gradients_mean=True (train_and_eval_distribute.py:137)
             gb = self.dense_grad_ext[-1:]
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+        if self._side is not None and not self._dyn:          # (folded one-GPU step: nothing was queued on the side stream since
+            torch.cuda.current_stream().wait_stream(self._side)   # the front joined it, and a join costs ~6 us inside a graph)
         ev = self._tick("apply_dense")
         akw = dict(lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
                    beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=inv_sens)
@@ -933,13 +1009,13 @@ class WideDeepEngine:
             slabs = [] if self._sharded else ([(self.dense_grad[2 * i].storage_offset(), t) for i, t in sorted(self._dw.items())] +
                                               [(self.dense_grad[2 * i + 1].storage_offset(), t) for i, t in sorted(self._db.items())])
             self.k.dense_adam_slabs_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, slabs,
-                                     shadow16=self.dense16_flat, **akw)
+                                     shadow16=self.dense16_flat, step_state=state, **akw)
         else:
             self.k.dense_adam_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, **akw)
         self.k.dense_ftrl_(self.wide_b, self.wide_b_accum, self.wide_b_linear, gb, lr=cfg.ftrl_lr, l1=cfg.ftrl_l1,
                         l2=cfg.ftrl_l2, grad_scale=inv_sens)
         self._tock(ev)
-        if self._side is not None:
+        if self._side is not None and not self._dyn:
             torch.cuda.current_stream().wait_stream(self._side)
         self.last_plan = plan
         return loss.detach()

@@ -137,7 +137,7 @@ def test_free_running_steps_with_graphs_vs_mixed_oracle(dev, oracle):
         ids, wts, label = synthetic_batch(cfg, "cpu", "uniform" if s % 2 == 0 else "zipf", seed=2000 + s)
         lg.append(float(g.train_step(ids.to(dev), wts.to(dev), label.to(dev))))
         lo.append(o.train_step(ids.numpy(), wts.numpy(), label.numpy().ravel()))
-    assert g._front_graph is not None, "the whole-front graph must have been captured and replayed"
+    assert g._step_graph is not None, "the whole-step graph must have been captured and replayed"
     print("  losses gpu   ", lg)
     print("  losses oracle", lo)
     # mean of 16384 per-sample losses: the ulp flips in the activations average out

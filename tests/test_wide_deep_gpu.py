@@ -166,25 +166,57 @@ def test_deepfm_engine_matches_oracle_engine(dev, oracle):
     assert np.allclose(logit.cpu().numpy(), lc2.numpy(), rtol=1e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("graph_front", [True, False])
-def test_graph_replay_is_bit_identical_to_eager(dev, graph_front):
-    """The captured graphs (the whole front of the step, or the MLP alone) hold the same kernels in the same
-    order on the same buffers as the eager path: losses, tables and dense parameters must agree bit for bit
-    over several steps (capture on step 3, replay from then on, a different batch every step)."""
+@pytest.mark.parametrize("level", ["step", "front", "mlp"])
+def test_graph_replay_is_bit_identical_to_eager(dev, level):
+    """The captured graphs (the whole step with the optimizers, the front of the step, or the MLP alone) hold the same
+    kernels in the same order on the same buffers as the eager path: losses, tables and dense parameters must agree bit
+    for bit over several steps (capture on step 3, replay from then on, a different batch every step).  In the whole-step
+    graph the Adam step size comes from the device-side step state, advanced by a kernel inside the graph."""
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     kw = dict(vocab_size=50000, emb_dim=16, field_size=26, batch_size=2048, deep_layer_dim=[256, 128, 64, 32],
               mlp_dtype="bf16")
-    a = WideDeepEngine(WideDeepConfig(graph_mlp=True, graph_front=graph_front, **kw), dev)
+    a = WideDeepEngine(WideDeepConfig(graph_mlp=True, graph_front=level != "mlp", graph_step=level == "step", **kw), dev)
     b = WideDeepEngine(WideDeepConfig(graph_mlp=False, **kw), dev)
-    assert a._mfma, "MFMA MLP path expected"
-    for s in range(7):
+    assert a._mfma and a._fold_wide, "MFMA MLP path with the folded wide branch expected"
+    for s in range(9):
         ids, wts, label = synthetic_batch(a.cfg, dev, "zipf", seed=70 + s)
         la, lb = float(a.train_step(ids, wts, label)), float(b.train_step(ids, wts, label))
         assert la == lb, (s, la, lb)
-    assert (a._front_graph is not None) if graph_front else (a._mlp_graph is not None)
-    assert b._mlp_graph is None and b._front_graph is None
+    got = {"step": a._step_graph, "front": a._front_graph, "mlp": a._mlp_graph}
+    assert got[level] is not None and all(v is None for k, v in got.items() if k != level), {k: v is not None for k, v in got.items()}
+    assert b._mlp_graph is None and b._front_graph is None and b._step_graph is None
     assert torch.equal(a.deep, b.deep) and torch.equal(a.wide, b.wide)
     assert torch.equal(a.dense_flat.detach(), b.dense_flat.detach())
+    # device-side step scalars == the host mirrors (same fp32 products in the same order)
+    st = a._step_state.read()
+    assert int(st["step"]) == a.step_count == 9
+    assert np.float32(st["beta1_power"]) == a.beta1_power and np.float32(st["beta2_power"]) == a.beta2_power
+    lr_t = np.float32(a.cfg.adam_lr) * np.sqrt(np.float32(1) - a.beta2_power) / (np.float32(1) - a.beta1_power)
+    assert np.float32(st["lr_t"]) == np.float32(lr_t)
+    if level == "step":
+        ms = a._step_state.apply_ms(range(4, 10))
+        assert len(ms) == 6 and all(0.0 < x < 50.0 for x in ms), ms
+
+
+def test_step_graph_survives_checkpoint_restore(dev, tmp_path):
+    """load_checkpoint moves the host-side step count and beta powers; the device-side step state follows on the next step
+    (graph replay included): a restored engine continues bit-identically to the one that never stopped."""
+    from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, load_checkpoint, save_checkpoint, synthetic_batch
+    kw = dict(vocab_size=20000, emb_dim=16, field_size=26, batch_size=1024, deep_layer_dim=[64, 32], mlp_dtype="bf16")
+    a = WideDeepEngine(WideDeepConfig(**kw), dev)
+    batches = [synthetic_batch(a.cfg, dev, "uniform", seed=5 + s) for s in range(10)]
+    for s in range(5):
+        a.train_step(*batches[s])
+    save_checkpoint(a, str(tmp_path / "ck.pt"))
+    b = WideDeepEngine(WideDeepConfig(**kw), dev)
+    for s in range(4):                    # b has its own history (and its step graph) before the restore
+        b.train_step(*batches[9 - s])
+    load_checkpoint(b, str(tmp_path / "ck.pt"))
+    for s in range(5, 9):
+        la, lb = float(a.train_step(*batches[s])), float(b.train_step(*batches[s]))
+        assert la == lb, (s, la, lb)
+    assert a._step_graph is not None and b._step_graph is not None
+    assert torch.equal(a.deep, b.deep) and torch.equal(a.dense_flat.detach(), b.dense_flat.detach())
 
 
 @pytest.mark.parametrize("graph", [False, True])
@@ -262,7 +294,7 @@ def test_host_cached_tables_engine_equals_resident_engine(dev):
 
 def test_weight_gradient_slabs_and_graph_switching(dev):
     """One GPU: the weight gradients stay fp32 batch slabs and the dense-Adam kernel adds them up.  The slabs are
-    persistent engine buffers, so switching between the whole-front graph, the MLP graphs (phase timers on) and
+    persistent engine buffers, so switching between the whole-step graph, the MLP graphs (phase timers on) and
     eager steps must not change which buffers the Adam reads (round-1 ADVICE: stale split-K partials after a switch):
     an engine that toggles its timers mid-run trains bit-identically to an eager one."""
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
@@ -271,13 +303,13 @@ def test_weight_gradient_slabs_and_graph_switching(dev):
     b = WideDeepEngine(WideDeepConfig(graph_mlp=False, **kw), dev)
     for s in range(12):
         if s == 5:
-            a.timers = {}              # leaves the front graph: MLP graphs get captured
+            a.timers = {}              # leaves the step graph: MLP graphs get captured
         if s == 8:
-            a.timers = None            # back to the front graph
+            a.timers = None            # back to the step graph
         batch = synthetic_batch(a.cfg, dev, "zipf", seed=700 + s)
         la, lb = float(a.train_step(*batch)), float(b.train_step(*batch))
         assert la == lb, (s, la, lb)
-    assert a._front_graph is not None and a._mlp_graph is not None
+    assert a._step_graph is not None and a._mlp_graph is not None
     assert len(a._dw) == 4 and a._dw[0].dtype == torch.float32          # four hidden layers, fp32 slabs
     assert torch.equal(a.dense_flat.detach(), b.dense_flat.detach())
     assert torch.equal(a.deep, b.deep)

@@ -1,25 +1,32 @@
+# Produces every measurement the profiles/ directory holds for a round (run on the GPU box from the repo root):
+#   bash tools/final_run.sh  &&  python tools/collect_profiles.py rNN
 set -e
-mkdir -p gpurun_out/final
-python bench.py > gpurun_out/final/bench_line.json 2> gpurun_out/final/bench.err
-echo "bench done"; cut -c1-200 gpurun_out/final/bench_line.json
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/final/bench_line_under_rocprof.json 2> gpurun_out/final/prof.err
-cp $(find gpurun_out/final/prof -name "*kernel_stats.csv") gpurun_out/final/kernel_stats.csv
-python tools/prof_summary.py gpurun_out/final/kernel_stats.csv > gpurun_out/final/kernel_summary.txt
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/final
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/bench_line.json 2> $O/bench.err
+echo "bench done"; cut -c1-200 $O/bench_line.json
+python3 $R/bench.py --mlp-dtype fp16 --no-cpu-baseline > $O/bench_line_fp16.json 2>> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_line_under_rocprof.json 2> $O/prof.err
+cp $(find $O/prof -name "*kernel_stats.csv") $O/bench_kernel_stats.csv
+python3 $R/tools/prof_summary.py $O/bench_kernel_stats.csv > $O/bench_kernel_summary.txt
+python3 $R/tools/step_timeline.py $O/prof > $O/step_timeline_under_rocprof.txt 2>&1 || true
 echo "prof done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/final/pmc_fetch -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2> gpurun_out/final/pmc1.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/final/pmc_write -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2> gpurun_out/final/pmc2.err
-python tools/pmc_summary.py gpurun_out/final/pmc_fetch gpurun_out/final/pmc_write gpurun_out/final/pmc_traffic.json > gpurun_out/final/pmc_traffic.txt
-echo "pmc done"; cat gpurun_out/final/pmc_traffic.txt
-python bench.py --no-cpu-baseline --dist zipf --fields 39 > gpurun_out/final/bench_line_zipf39.json 2>/dev/null
-python tools/paths_bench.py > gpurun_out/final/paths_bench.txt 2>/dev/null
-python tools/dcn_bench.py > gpurun_out/final/dcn_bench.txt 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/crossprof -- python3 tools/cross_probe.py > /dev/null 2>&1
-python tools/prof_summary.py $(find gpurun_out/final/crossprof -name "*kernel_stats.csv") > gpurun_out/final/cross_kernel_summary.txt
-cat gpurun_out/final/paths_bench.txt gpurun_out/final/dcn_bench.txt
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline > $O/pmc_bench_line.json 2> $O/pmc1.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline > /dev/null 2> $O/pmc2.err
+python3 $R/tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json $O/pmc_bench_line.json > $O/pmc_traffic.txt
+echo "pmc done"; cat $O/pmc_traffic.txt
+cd $R
+python bench.py --no-cpu-baseline --dist zipf --fields 39 > $O/bench_line_zipf39.json 2>/dev/null
+python tools/paths_bench.py > $O/paths_bench.txt 2>/dev/null
+python tools/dcn_bench.py > $O/dcn_bench.txt 2>/dev/null
+cat $O/paths_bench.txt $O/dcn_bench.txt
+timeout -k 10 200 ./tools/probes/dense_gemm_test > $O/dense_gemm_probe.txt 2>&1 || true
 
 # id-distribution sweep: uniform / Zipf(1.05), 26 / 39 fields
 for d in uniform zipf; do for f in 26 39; do
   python bench.py --no-cpu-baseline --dist $d --fields $f 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$d', $f, 'fields:', d['value'], 'samples/s', d['ms_per_step'], 'ms/step, U/N', d['config']['unique_frac'], ', apply', d['roofline']['avg_ms'], 'ms', d['roofline']['achieved'], 'GB/s')"
-done; done > gpurun_out/final/dist_sweep.txt
-cat gpurun_out/final/dist_sweep.txt
-rm -rf gpurun_out/final/prof gpurun_out/final/crossprof
+done; done > $O/dist_sweep.txt
+cat $O/dist_sweep.txt
+rm -rf $O/prof $O/pmc_fetch $O/pmc_write

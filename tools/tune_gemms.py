@@ -25,14 +25,14 @@ from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batc
 
 dev = torch.device("cuda:0")
 for fields in (26, 39):
-    for fused in (True, False):          # hand-written MLP step and the autograd path use different GEMM ops
-        cfg = WideDeepConfig(vocab_size=1_000_000, field_size=fields, fused_mlp=fused)
-        eng = WideDeepEngine(cfg, dev, tuned_gemms=False)
-        b = synthetic_batch(cfg, dev, "uniform")
-        for _ in range(3):
-            eng.train_step(*b)
-        torch.cuda.synchronize()
-        del eng
+    # the fp32 MLP is the one that still runs on library GEMMs (the 16-bit MLPs run on mrec_dense_*)
+    cfg = WideDeepConfig(vocab_size=1_000_000, field_size=fields, mlp_dtype="fp32")
+    eng = WideDeepEngine(cfg, dev, tuned_gemms=False)
+    b = synthetic_batch(cfg, dev, "uniform")
+    for _ in range(3):
+        eng.train_step(*b)
+    torch.cuda.synchronize()
+    del eng
 cfg = DeepCrossConfig()
 eng = DeepCrossEngine(cfg, dev)
 wcfg = WideDeepConfig(vocab_size=cfg.vocab_size, emb_dim=cfg.emb_dim, field_size=cfg.field_size, batch_size=cfg.batch_size)
