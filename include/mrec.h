@@ -386,6 +386,10 @@ int mrec_map_destroy(mrec_map_t* h);
  * exceed a fifth of the slots the erase call rebuilds the slot array from the row side, so a probe for a
  * missing key always meets an empty slot (every probe loop is bounded by the slot count besides). */
 const int64_t* mrec_map_counters_dev(const mrec_map_t* h);
+/* Device arrays inside `mem`, one entry per row: the key a row holds (valid while the row is live); training-lookup hits,
+ * last training step, dirty mark (see mrec_map_lookup). */
+const int64_t* mrec_map_row_keys_dev(const mrec_map_t* h);
+int mrec_map_tracking_dev(const mrec_map_t* h, int32_t** hits, int32_t** last_step, uint8_t** dirty);
 int mrec_map_workspace_bytes(int64_t n, size_t* out);
 /* keys must be unique within the call (run mrec_dedup first).  rows_out[i] = row of keys[i];
  * a missing key gets a new row when insert != 0 (is_new_out[i] = 1, caller initialises the row),
@@ -399,6 +403,59 @@ int mrec_map_erase(mrec_map_t* h, const int64_t* keys, int64_t n, void* ws, size
 /* Writes the live (key,row) pairs in row order; *n_out_dev receives the count. */
 int mrec_map_export(mrec_map_t* h, int64_t* keys_out, int32_t* rows_out, int64_t* n_out_dev, void* ws,
                     size_t ws_bytes, void* stream);
+/* ---- MapTensorGet as one short chain (embedding.py:149,193,199: MapTensorGet(insert_default_value=True); README.md:160-205) ----
+ * mrec_map_lookup resolves n key positions to table rows in 3 launches (probe; rank + place the missing keys; default
+ * rows + admission), 1 launch when not inserting:
+ *   - keys need NOT be unique (MREC_MAP_UNIQUE says they are and skips the in-call dedup of the missing ones); int32 or
+ *     int64 (key_bytes); n_dev as in mrec_map_find_or_insert;
+ *   - a missing key gets the next row in order of first appearance in `keys` (MREC_MAP_INSERT), and the default value
+ *     of every table in `tables` (values first, then the optimizer slots that share the row numbering) is written to it;
+ *     without MREC_MAP_INSERT rows_out[i] = -1 (mrec_map_fill_missing then gives such positions their default value);
+ *   - MREC_MAP_TRAIN marks a training lookup at step `step` (1, 2, ...): every distinct key found counts one hit and has
+ *     its last-seen step stamped (the permit / evict filters of embedding.py:141-146, README.md:176-183: thresholds are
+ *     counted in training steps), touched rows are marked for the next incremental export;
+ *   - rows_admitted_out (nullable): rows_out with the rows of keys seen in fewer than `permit` training lookups replaced
+ *     by -1 -- the row list the sparse-apply kernels take, which skip negative rows (an un-admitted key reads its
+ *     default row and is not updated);
+ *   - ws: mrec_map_lookup_workspace_bytes(n).  MREC_MAP_WS_PRIMED: as MREC_PLAN_WS_PRIMED -- the last writer of ws was a
+ *     completed mrec_map_lookup with the same n and pointer.
+ * At most 8 tables. */
+typedef struct mrec_map_table {
+    float* rows;      /* [capacity, D] row-major, row stride ld */
+    int64_t ld;
+    int32_t D;
+    float sigma;      /* >= 0: default value sigma * N(0,1) keyed by (seed, key, column); < 0: the constant `fill` */
+    float fill;
+    uint64_t seed;
+} mrec_map_table_t;
+#define MREC_MAP_INSERT 1u
+#define MREC_MAP_UNIQUE 2u
+#define MREC_MAP_TRAIN 4u
+#define MREC_MAP_WS_PRIMED 8u
+int mrec_map_lookup_workspace_bytes(int64_t n, size_t* out);
+int mrec_map_lookup(mrec_map_t* h, const void* keys, int32_t key_bytes, int64_t n, const int64_t* n_dev, uint32_t flags,
+                    int64_t step, int32_t permit, const mrec_map_table_t* tables, int32_t n_tables, int32_t* rows_out,
+                    int32_t* rows_admitted_out, void* ws, size_t ws_bytes, void* stream);
+/* out[i, :] = default value of keys[i] wherever rows[i] < 0 (insert_default_value=False: a missing key reads as its
+ * default without entering the table); only D / sigma / fill / seed of `table` are used. */
+int mrec_map_fill_missing(const void* keys, int32_t key_bytes, const int32_t* rows, int64_t n, float* out, int64_t ldo,
+                          const mrec_map_table_t* table, void* stream);
+/* Eviction on the device: every live key whose last training lookup is more than `threshold` steps before `step` leaves
+ * the table (rows to the free list in row order, keys to the erased-keys log); *n_evicted_dev receives the count.
+ * ws: 4 * ceil(capacity / 2048) bytes. */
+int mrec_map_evict(mrec_map_t* h, int64_t step, int64_t threshold, int64_t* n_evicted_dev, void* ws, size_t ws_bytes,
+                   void* stream);
+/* Incremental export (RELEASE.md:18 "MapParameter supports incremental export"): the live rows inserted, trained on or
+ * put since the last call with clear != 0 as (key, row, status 1 = modified), in row order, followed by the keys erased or
+ * evicted since then that are not live now as (key, -1, status 2 = erased).  Outputs sized for 2 * capacity entries;
+ * ws: mrec_map_workspace_bytes(capacity) + capacity bytes. */
+int mrec_map_export_dirty(mrec_map_t* h, int64_t* keys_out, int32_t* rows_out, int32_t* status_out, int64_t* n_out_dev,
+                          int clear, void* ws, size_t ws_bytes, void* stream);
+int mrec_map_mark_dirty(mrec_map_t* h, const int32_t* rows, int64_t n, void* stream);
+/* MapTensorPut with duplicate keys in one call: table[rows[i], :] = vals[i, :] for the LAST position i of every row (what a
+ * sequential upsert loop leaves, README.md:188-190).  winner: one int32 per table row, all -1 on entry and on return. */
+int mrec_put_rows_last_f32(float* table, int64_t ld, int32_t D, const int32_t* rows, int64_t n, const float* vals,
+                           int32_t* winner, void* stream);
 /* Default-value rows for newly inserted keys: table[rows[i], :] = sigma * N01(seed, keys[i], c)
  * where is_new[i] (all i when is_new is null); sigma < 0 selects the constant `fill`. */
 int mrec_init_rows_f32(float* table, int64_t ld, int32_t D, const int32_t* rows, const int64_t* keys,
@@ -453,6 +510,13 @@ int mrec_shard_route_i32(const int32_t* ids, int64_t n, int32_t n_shards, int32_
                          int32_t* send_perm, int64_t* counts_dev, void* ws, size_t ws_bytes, void* stream);
 int mrec_shard_route_i64(const int64_t* ids, int64_t n, int32_t n_shards, int64_t* send_local,
                          int32_t* send_perm, int64_t* counts_dev, void* ws, size_t ws_bytes, void* stream);
+/* Same for hash tables keyed by the raw id (MapParameter under row sharding, BASELINE configs[4]): owner =
+ * (mix64(key) >> 33) mod n_shards and send_keys carries the raw keys, which the owner translates to rows of its own
+ * key index (mrec_map_lookup). */
+int mrec_shard_route_hash_i32(const int32_t* keys, int64_t n, int32_t n_shards, int32_t* send_keys, int32_t* send_perm,
+                              int64_t* counts_dev, void* ws, size_t ws_bytes, void* stream);
+int mrec_shard_route_hash_i64(const int64_t* keys, int64_t n, int32_t n_shards, int64_t* send_keys, int32_t* send_perm,
+                              int64_t* counts_dev, void* ws, size_t ws_bytes, void* stream);
 /* out[send_perm[k], :] = rows[k, :] * (row_scale ? row_scale[send_perm[k]] : 1): undoes the
  * bucketing on the returned embedding rows. */
 int mrec_shard_unroute_f32(const float* rows, const int32_t* send_perm, int64_t n, int32_t D,

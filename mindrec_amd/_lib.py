@@ -106,7 +106,16 @@ _SIGS = {
     "mrec_map_create": [C.POINTER(_vp), _vp, _sz, _i64, _vp],
     "mrec_map_destroy": [_vp],
     "mrec_map_counters_dev": [_vp],
+    "mrec_map_row_keys_dev": [_vp],
     "mrec_map_workspace_bytes": [_i64, _szp],
+    "mrec_map_tracking_dev": [_vp, _vp, _vp, _vp],
+    "mrec_map_lookup_workspace_bytes": [_i64, _szp],
+    "mrec_map_lookup": [_vp, _vp, _i32, _i64, _vp, C.c_uint32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp],
+    "mrec_map_fill_missing": [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp],
+    "mrec_map_evict": [_vp, _i64, _i64, _vp, _vp, _sz, _vp],
+    "mrec_map_export_dirty": [_vp, _vp, _vp, _vp, _vp, _int, _vp, _sz, _vp],
+    "mrec_map_mark_dirty": [_vp, _vp, _i64, _vp],
+    "mrec_put_rows_last_f32": [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_map_find_or_insert": [_vp, _vp, _i64, _vp, _int, _vp, _vp, _vp, _sz, _vp],
     "mrec_map_erase": [_vp, _vp, _i64, _vp, _sz, _vp],
     "mrec_map_export": [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
@@ -124,6 +133,8 @@ _SIGS = {
     "mrec_shard_route_workspace_bytes": [_i64, _i32, _szp],
     "mrec_shard_route_i32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_shard_route_i64": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_shard_route_hash_i32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_shard_route_hash_i64": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_shard_unroute_f32": [_vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_shard_route_rows_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_event_create": [C.POINTER(_vp)],
@@ -131,7 +142,7 @@ _SIGS = {
     "mrec_event_elapsed_ms": [_vp, _vp, C.POINTER(C.c_float)],
     "mrec_profile_next_apply": [_vp, _vp],
 }
-_RESTYPES = {"mrec_strerror": C.c_char_p, "mrec_map_counters_dev": _vp}
+_RESTYPES = {"mrec_strerror": C.c_char_p, "mrec_map_counters_dev": _vp, "mrec_map_row_keys_dev": _vp}
 
 EXPORTED = sorted(list(_SIGS) + ["mrec_strerror"])
 

@@ -12,25 +12,34 @@
 
 namespace {
 
+// HASH: the table is a hash table keyed by the raw id (MapParameter): owner = hash(key) mod n_shards, taken from the HIGH
+// bits of the 64-bit mix -- the owner's key index probes from the low bits of the same mix, and keys that share their low
+// bits must not all land on one owner -- and the raw key travels (the owner translates it to a row of its own index).
 template <class K>
-__global__ __launch_bounds__(256) void k_owner(const K* __restrict__ ids, int64_t n, int S, int* __restrict__ owner) {
+__device__ __forceinline__ int owner_of(K id, int S, bool hash) {
+    if (hash) return (int)((mrec_mix64((uint64_t)(int64_t)id) >> 33) % (uint64_t)S);
+    K o = id % (K)S;
+    if (o < 0) o += (K)S;
+    return (int)o;
+}
+
+template <class K>
+__global__ __launch_bounds__(256) void k_owner(const K* __restrict__ ids, int64_t n, int S, int* __restrict__ owner, bool hash) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    K o = ids[i] % (K)S;
-    if (o < 0) o += (K)S;
-    owner[i] = (int)o;
+    owner[i] = owner_of(ids[i], S, hash);
 }
 
 template <class K>
 __global__ __launch_bounds__(256) void k_route_finish(const K* __restrict__ ids, int64_t n, int S,
                                                       const int* __restrict__ perm, const int* __restrict__ dbase,
-                                                      K* __restrict__ send_local, int64_t* __restrict__ counts) {
+                                                      K* __restrict__ send_local, int64_t* __restrict__ counts, bool hash) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k < S) counts[k] = (int64_t)((k + 1 < S) ? dbase[k + 1] : (int)n) - dbase[k];
     if (k >= n) return;
     const K id = ids[perm[k]];
-    K o = id % (K)S;
-    if (o < 0) o += (K)S;
+    if (hash) { send_local[k] = id; return; }
+    const K o = (K)owner_of(id, S, false);
     send_local[k] = (id - o) / (K)S;
 }
 
@@ -130,7 +139,7 @@ int perm_rows_launch(const float* src, int64_t lds, const int* perm, int64_t n, 
 
 template <class K>
 int route_impl(const K* ids, int64_t n, int32_t S, K* send_local, int32_t* send_perm, int64_t* counts_dev, void* ws,
-               size_t ws_bytes, void* stream) {
+               size_t ws_bytes, void* stream, bool hash = false) {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || S <= 0 || S > RNB || !counts_dev) return MREC_EINVAL;
     if (n == 0) {
@@ -151,10 +160,10 @@ int route_impl(const K* ids, int64_t n, int32_t S, K* send_local, int32_t* send_
     if (!a.ok) return MREC_EWORKSPACE;
     int nbits = 1;
     while ((1 << nbits) < S) ++nbits;
-    k_owner<K><<<(unsigned)mrec_cdiv(n, 256), 256, 0, st>>>(ids, n, S, owner);
+    k_owner<K><<<(unsigned)mrec_cdiv(n, 256), 256, 0, st>>>(ids, n, S, owner, hash);
     radix_pass(owner, nullptr, (int)n, 0, nbits, hist, hscan, totals, dbase, okeys, send_perm, st);
     const int64_t m = n > S ? n : S;
-    k_route_finish<K><<<(unsigned)mrec_cdiv(m, 256), 256, 0, st>>>(ids, n, S, send_perm, dbase, send_local, counts_dev);
+    k_route_finish<K><<<(unsigned)mrec_cdiv(m, 256), 256, 0, st>>>(ids, n, S, send_perm, dbase, send_local, counts_dev, hash);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -167,6 +176,15 @@ MREC_API int mrec_shard_route_workspace_bytes(int64_t n, int32_t n_shards, size_
     *out = mrec_align_up((size_t)mrec_cdiv(nn, RT) * RNB * 4, 256) * 2 + mrec_align_up((size_t)RNB * 4, 256) * 2 +
            mrec_align_up(nn * 4, 256) * 2;
     return MREC_OK;
+}
+
+MREC_API int mrec_shard_route_hash_i32(const int32_t* keys, int64_t n, int32_t n_shards, int32_t* send_keys,
+                                       int32_t* send_perm, int64_t* counts_dev, void* ws, size_t ws_bytes, void* stream) {
+    return route_impl<int32_t>(keys, n, n_shards, send_keys, send_perm, counts_dev, ws, ws_bytes, stream, true);
+}
+MREC_API int mrec_shard_route_hash_i64(const int64_t* keys, int64_t n, int32_t n_shards, int64_t* send_keys,
+                                       int32_t* send_perm, int64_t* counts_dev, void* ws, size_t ws_bytes, void* stream) {
+    return route_impl<int64_t>(keys, n, n_shards, send_keys, send_perm, counts_dev, ws, ws_bytes, stream, true);
 }
 
 MREC_API int mrec_shard_route_i32(const int32_t* ids, int64_t n, int32_t n_shards, int32_t* send_local,

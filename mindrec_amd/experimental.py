@@ -78,13 +78,10 @@ class MapParameter:
         self.sparse_grads = []       # RowGrad list filled by the lookup's backward
         self.unique = True           # set by HashEmbeddingLookup (embedding.py:146)
         self.cache_enable = False
-        # admission / eviction bookkeeping (only maintained when a filter is active)
+        # admission / eviction counters (hits, last-seen step) live inside the index and are kept by the lookup kernels
         self._track = permit_filter_value > 1 or evict_filter_value < MAX_SIZE
-        if self._track:
-            # one extra slot at the end absorbs the writes of a lookup's padding entries (rows_u == -1)
-            self.hits = torch.zeros(self.capacity + 1, dtype=torch.int32, device=self.device)
-            self.last_step = torch.zeros(self.capacity + 1, dtype=torch.int64, device=self.device)
         self.step = 0
+        self._winner = None          # put(): one int32 per row, all -1 between calls
         if key_tensor is not None:
             self.put(key_tensor, value_tensor)
 
@@ -99,61 +96,66 @@ class MapParameter:
     def _init_kwargs(self):
         return dict(seed=self.seed, sigma=self._sigma if self._sigma is not None else 0.0, fill=self._fill)
 
-    def lookup_rows(self, keys_flat, insert=True, dedup=None):
-        """(dedup, rows_uniq int32 [n], rows_pos int32 [n]) for flat device keys, without host sync:
-        Unique -> index probe / insert (misses numbered in first-occurrence order) -> default rows.
-        `dedup`: an ops.unique(keys_flat) result to reuse when several maps are read with the same keys."""
-        d = dedup if dedup is not None else ops.unique(keys_flat)
-        if self._track and insert:
-            self.step += 1            # one inserting lookup = one training step of this table (evict threshold unit)
-        k64 = ops.widen_keys(d.uniq_buf)
-        rows_u, is_new = self.index.find_or_insert(k64, insert=insert, n_dev=d.n_uniq_dev)
-        if insert:
-            ops.init_rows_(self.values, rows_u, k64, is_new, n_dev=d.n_uniq_dev, **self._init_kwargs())
-            for t in self.slots.values():
-                ops.init_rows_(t["table"], rows_u, k64, is_new, n_dev=d.n_uniq_dev, seed=0, sigma=None, fill=t["init"])
-        rows_pos = ops.compose_i32(rows_u, d.inv)
-        if self._track and insert:
-            ok = rows_u >= 0                                   # entries past U read -1
-            idx = torch.where(ok, rows_u, torch.full_like(rows_u, self.capacity)).long()
-            # a row handed to a new key (first sighting, or a row freed by an eviction) starts counting from zero
-            fresh = ok & is_new.view(-1)[: rows_u.numel()].bool()
-            cur = self.hits[idx]
-            self.hits.scatter_(0, idx, torch.where(fresh, torch.zeros_like(cur), cur) + ok.to(torch.int32))
-            self.last_step.scatter_(0, idx, torch.full_like(idx, self.step))
-        return d, rows_u, rows_pos
+    def _tables(self):
+        """(tensor, sigma, fill, seed) of every table that shares this map's row numbering: the values, then the slots."""
+        tabs = [(self.values, self._sigma, self._fill, self.seed)]
+        tabs += [(t["table"], None, t["init"], 0) for t in self.slots.values()]
+        return tabs
 
-    def admitted_rows(self, rows_u):
-        """Row numbers with un-admitted keys (seen fewer than permit_filter_value times) replaced by
-        -1, which the sparse-apply kernels skip: such keys read their default row and are not
-        updated."""
+    def lookup_rows(self, keys_flat, insert=True, dedup=None, train=None):
+        """(dedup, rows_uniq int32, rows_pos int32 [n]) for flat device keys, without host sync.  One chain of three launches
+        (mrec_map_lookup): probe, rank + place the missing keys in first-occurrence order, default rows of the values and of
+        every optimizer slot.  `dedup`: an ops.unique(keys_flat) result when the caller needs the Unique anyway (a training
+        step: the optimizer's inverted index is built from it) -- the index is then probed per unique key and rows_pos is
+        composed through the inverse; without it every position probes the index itself.
+        train (default: insert and a filter is active): this lookup counts as one training step of the table."""
+        train = (self._track and insert) if train is None else bool(train)
+        if train:
+            self.step += 1            # one inserting lookup = one training step of this table (evict threshold unit)
+        kw = dict(insert=insert, train=train, step=self.step, permit=self.permit_filter_value, tables=self._tables())
+        if dedup is not None:
+            rows_u = self.index.lookup(dedup.uniq_buf, unique=True, n_dev=dedup.n_uniq_dev, **kw)
+            return dedup, rows_u, ops.compose_i32(rows_u, dedup.inv)
+        rows_pos = self.index.lookup(keys_flat, **kw)
+        return None, None, rows_pos
+
+    def admitted_rows(self, rows):
+        """Row numbers with un-admitted keys (seen in fewer than permit_filter_value training lookups) replaced by -1,
+        which the sparse-apply kernels skip: such keys read their default row and are not updated."""
         if self.permit_filter_value <= 1:
-            return rows_u
-        ok = (rows_u >= 0) & (self.hits[rows_u.clamp_min(0).long()] >= self.permit_filter_value)
-        return torch.where(ok, rows_u, torch.full_like(rows_u, -1))
+            return rows
+        ok = (rows >= 0) & (self.hits[rows.clamp_min(0).long()] >= self.permit_filter_value)
+        return torch.where(ok, rows, torch.full_like(rows, -1))
+
+    @property
+    def hits(self):
+        return self.index.tracking()[0]
+
+    @property
+    def last_step(self):
+        return self.index.tracking()[1]
 
     # ---- MapTensorGet / Put / Erase -----------------------------------------------------------
     def get(self, key_tensor, insert_default_value=True):
+        """MapTensorGet: 4 launches (the lookup chain + the row gather), 3 without insertion (probe, gather, defaults)."""
         keys = self._keys(key_tensor)
-        d, rows_u, rows_pos = self.lookup_rows(keys, insert=insert_default_value)
+        _, _, rows_pos = self.lookup_rows(keys, insert=insert_default_value)
         out = ops.gather_rows(self.values, rows_pos)
         if not insert_default_value:
-            # missing keys read as their default row, without being inserted
-            miss = rows_pos < 0
-            if bool(miss.any()):
-                tmp = torch.empty_like(out)
-                seq = torch.arange(keys.numel(), dtype=torch.int32, device=self.device)
-                ops.init_rows_(tmp, seq, ops.widen_keys(keys), None, **self._init_kwargs())
-                out = torch.where(miss.view(-1, 1), tmp, out)
+            # missing keys read as their default row, without being inserted (no host round trip: a kernel overlays them)
+            self.index.fill_missing(keys, rows_pos, out, self._sigma, self._fill, self.seed)
         return out
 
     def put(self, key_tensor, value_tensor):
+        """MapTensorPut (README.md:188-190): upsert; with duplicate keys in one call the LAST one wins, as in a sequential
+        loop over the pairs."""
         keys = self._keys(key_tensor)
         vals = value_tensor.to(self.device, torch.float32).reshape(keys.numel(), self.value_shape[0])
-        d, rows_u, rows_pos = self.lookup_rows(keys, insert=True)
-        # keys of one put should be unique; with duplicates one of the rows wins (a sequential
-        # upsert would keep the last)
-        ops.scatter_rows_(self.values, rows_pos, vals)
+        _, _, rows_pos = self.lookup_rows(keys, insert=True, train=False)
+        if self._winner is None:
+            self._winner = torch.full((self.capacity,), -1, dtype=torch.int32, device=self.device)
+        ops.put_rows_last_(self.values, rows_pos, vals, self._winner)
+        self.index.mark_dirty(rows_pos)                     # for the next incremental export
         return self
 
     def erase(self, key_tensor):
@@ -185,13 +187,27 @@ class MapParameter:
         return k.to(self.key_dtype), ops.gather_rows(self.values, r)
 
     def export_data(self, incremental=False):
-        k, v = self.get_data()
-        status = torch.zeros(k.numel(), dtype=torch.int32, device=self.device)
-        return k, v, status
+        """(keys, values, statuses).  incremental=False: every live pair, status 0.  incremental=True (RELEASE.md:18): only
+        what changed since the previous incremental export -- rows inserted, trained on or put since then (status 1, with
+        their values) and keys erased or evicted since then (status 2, values zero); the marks are cleared."""
+        if not incremental:
+            k, v = self.get_data()
+            return k, v, torch.zeros(k.numel(), dtype=torch.int32, device=self.device)
+        k, r, status = self.index.export_dirty(clear=True)
+        v = ops.gather_rows(self.values, r)               # negative rows (erased keys) read as zeros
+        return k.to(self.key_dtype), v, status
 
     def import_data(self, data):
+        """Full or incremental: pairs with status 2 are erased, the others upserted."""
         keys, values = data[0], data[1]
-        self.put(keys, values)
+        status = data[2] if len(data) > 2 and data[2] is not None else None
+        if status is not None and bool((status == 2).any()):
+            gone = status.to(self.device) == 2
+            keys, values = keys.to(self.device), values.to(self.device)
+            self.erase(keys[gone])
+            keys, values = keys[~gone], values[~gone]
+        if keys.numel():
+            self.put(keys, values)
 
     def add_slot(self, name, init=0.0):
         """Optimizer state table with this map's row numbering (Adam m/v, FTRL accum/linear)."""
@@ -202,12 +218,8 @@ class MapParameter:
 
     # ---- eviction (README.md:182-183: thresholds in training steps) -----------------------------
     def evict(self):
-        """Removes keys not seen for more than evict_filter_value steps (SURVEY A.6 definition)."""
+        """Removes keys not seen in a training lookup for more than evict_filter_value steps (SURVEY A.6 definition), on the
+        device (mrec_map_evict: one pass over the rows); returns how many went (one host read of the count)."""
         if not self._track or self.evict_filter_value >= MAX_SIZE:
             return 0
-        k, r = self.index.export()
-        stale = (self.step - self.last_step[r.long()]) > self.evict_filter_value
-        dead = k[stale]
-        if dead.numel():
-            self.index.erase(dead.contiguous())
-        return int(dead.numel())
+        return int(self.index.evict(self.step, self.evict_filter_value).item())

@@ -35,7 +35,12 @@ class HostBackedTable:
     `self.cols[name]` is the [cache_rows, width] view of a group."""
 
     def __init__(self, vocab_size, emb_dim, cache_rows, device, seed=1000, sigma=0.01, state_slots=2,
-                 state_init=(0.0, 0.0), columns=None):
+                 state_init=(0.0, 0.0), columns=None, hashed=False, key_scale=1, key_offset=0):
+        """hashed=True: the table is a hash table keyed by arbitrary int keys (MapParameter under the cache tier, BASELINE
+        configs[4]): a second device key index `home` gives every key a host row (0 .. vocab_size-1, in order of first
+        appearance), the tier below runs unchanged on host-row numbers, and default values stay keyed by the KEY.
+        key_scale / key_offset: a row shard of a dense table -- local row r is global id r * key_scale + key_offset, which is
+        what its default values are keyed by."""
         if cache_rows <= 0 or vocab_size <= 0:
             raise ValueError("vocab_size and cache_rows must be positive")
         self.V, self.D, self.C = int(vocab_size), int(emb_dim), int(cache_rows)
@@ -52,6 +57,9 @@ class HostBackedTable:
         self.materialised = torch.zeros(self.V + 1, dtype=torch.bool, device=dev)      # host row holds real data
         self.cache = torch.zeros((C, self.W), dtype=torch.float32, device=dev)
         self.index = ops.KeyIndex(C, dev)
+        self.hashed = bool(hashed)
+        self.key_scale, self.key_offset = int(key_scale), int(key_offset)
+        self.home = ops.KeyIndex(self.V, dev) if self.hashed else None        # key -> host row
         self.row_key = torch.full((C + 1,), -1, dtype=torch.int64, device=dev)
         self.stamp = torch.zeros(C + 1, dtype=torch.int64, device=dev)               # last step a row was used
         self.step = 0
@@ -82,6 +90,10 @@ class HostBackedTable:
         the per-position cache rows (int32 [n]) for the gather."""
         self.step += 1
         C, dev = self.C, self.device
+        if self.hashed:
+            # keys -> host rows (every position probes `home`; new keys take the next host row): from here on `ids` are
+            # host-row numbers and the tier is the dense-table one
+            ids = self.home.lookup(ids, insert=True).view(ids.shape)
         plan = ops.sparse_plan(ids)
         U = plan.U                                                    # host sync #1
         if U > C:
@@ -121,6 +133,10 @@ class HostBackedTable:
 
     def _init_groups(self, views, rows, keys, mask):
         """Default values of first-touch rows, column group by column group (the generator is keyed by the GLOBAL id)."""
+        if self.hashed:
+            keys = self.home.row_keys()[keys]                   # host row -> the key it belongs to
+        elif self.key_scale != 1 or self.key_offset != 0:
+            keys = keys * self.key_scale + self.key_offset
         for name, _, init in self.columns:
             if init[0] == "normal":
                 ops.init_rows_(views[name], rows, keys, mask, seed=int(init[1]), sigma=float(init[2]))
@@ -159,8 +175,16 @@ class HostBackedTable:
         self.materialised[self.V] = False
         torch.cuda.synchronize(self.device)
 
+    def export_hashed(self):
+        """hashed tables: (keys int64 [n], rows float32 [n, W]) of every key seen so far (host tensors)."""
+        self.flush()
+        k, r = self.home.export()
+        return k.cpu(), self.host[r.cpu().long()]
+
     def full_table(self):
         """The whole table as a host tensor [V, W] (never-touched rows are generated on demand)."""
+        if self.hashed:
+            raise RuntimeError("a hashed table has no dense image; use export_hashed()")
         self.flush()
         out = self.host.clone()
         missing = (~self.materialised[: self.V]).nonzero().view(-1)

@@ -55,9 +55,12 @@ class HashEmbeddingLookup(nn.Cell):
         t = self.embedding_table
         shape = tuple(indices.shape) + (self.embedding_size,)
         flat = t._keys(indices)
-        d, rows_u, rows_pos = t.lookup_rows(flat, insert=True)
+        training = torch.is_grad_enabled() and t.requires_grad
+        # a training lookup needs the Unique anyway (the optimizer's inverted index is built from it): the index is then
+        # probed once per unique key; otherwise every position probes the index itself and no Unique is run
+        d, rows_u, rows_pos = t.lookup_rows(flat, insert=True, dedup=ops.unique(flat) if training else None)
         out = ops.gather_rows(t.values, rows_pos).view(shape)
-        if torch.is_grad_enabled() and t.requires_grad:
+        if training:
             def plan_fn():
                 plan = ops.group_by_inverse(d)
                 plan.uniq_buf = t.admitted_rows(rows_u)     # groups -> table rows (un-admitted keys -> -1)

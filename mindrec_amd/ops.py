@@ -25,6 +25,7 @@ def _ptr(t):
 
 
 _PLAN_PRIMED = {}
+_MAP_PRIMED = {}
 
 
 def workspace(tag, nbytes, device):
@@ -449,6 +450,21 @@ class KeyIndex:
     def __len__(self):
         return self.counters()[1]
 
+    def _view(self, ptr, nbytes, dtype):
+        off = int(ptr) - self._mem.data_ptr()
+        return self._mem[off: off + nbytes].view(dtype)
+
+    def tracking(self):
+        """(hits int32 [C], last_step int32 [C], dirty uint8 [C]) views of the index's per-row counters."""
+        h, l, d = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.call("mrec_map_tracking_dev", self._h, C.byref(h), C.byref(l), C.byref(d))
+        n = self.capacity
+        return self._view(h.value, 4 * n, torch.int32), self._view(l.value, 4 * n, torch.int32), self._view(d.value, n, torch.uint8)
+
+    def row_keys(self):
+        """int64 [C] view: the key each row holds (valid for live rows)."""
+        return self._view(_lib.lib().mrec_map_row_keys_dev(self._h), 8 * self.capacity, torch.int64)
+
     def _ws(self, n):
         nb = _lib.query_bytes("mrec_map_workspace_bytes", max(n, 1))
         return workspace("map", nb, self.device)
@@ -463,6 +479,73 @@ class KeyIndex:
         _lib.call("mrec_map_find_or_insert", self._h, _ptr(keys_i64), n, _ptr(n_dev), int(insert), _ptr(rows), _ptr(is_new),
                   _ptr(ws), ws.numel(), _stream())
         return rows, is_new
+
+    # ---- MapTensorGet as one chain (mrec_map_lookup) -----------------------------------------------------------
+    class _MapTable(C.Structure):
+        _fields_ = [("rows", C.c_void_p), ("ld", C.c_int64), ("D", C.c_int32), ("sigma", C.c_float), ("fill", C.c_float),
+                    ("seed", C.c_uint64)]
+
+    @classmethod
+    def _tables(cls, tables):
+        arr = (cls._MapTable * max(len(tables), 1))()
+        for q, (t, sigma, fill, seed) in enumerate(tables):
+            _need_cuda(t)
+            V, D, ld = _table(t)
+            arr[q] = cls._MapTable(t.data_ptr(), ld, D, -1.0 if sigma is None else float(sigma), float(fill or 0.0), int(seed))
+        return arr
+
+    def lookup(self, keys, insert=True, unique=False, train=False, step=0, permit=1, tables=(), n_dev=None, want_admitted=False):
+        """Rows of `keys` (int32 / int64, any shape, duplicates allowed) in 3 launches (1 when not inserting): probe, rank and
+        place the missing keys in order of first appearance, default rows of `tables` = [(tensor [C, D], sigma or None, fill,
+        seed)] + admission.  Returns rows int32 [n] (and the admitted rows when want_admitted)."""
+        _need_cuda(keys)
+        flat = keys.reshape(-1).contiguous()
+        n = flat.numel()
+        rows = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)[:n]
+        adm = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)[:n] if want_admitted else None
+        nb = _lib.query_bytes("mrec_map_lookup_workspace_bytes", max(n, 1))
+        ws = workspace(f"maplookup:{n}", nb, self.device)           # one per problem size, so it stays primed
+        key = (ws.data_ptr(), n)
+        primed = _MAP_PRIMED.pop(key, False)
+        flags = (1 if insert else 0) | (2 if unique else 0) | (4 if train else 0) | (8 if primed else 0)
+        tabs = self._tables(tables)
+        _lib.call("mrec_map_lookup", self._h, _ptr(flat), flat.element_size(), n, _ptr(n_dev), flags, int(step), int(permit),
+                  C.cast(tabs, C.c_void_p), len(tables), _ptr(rows), _ptr(adm), _ptr(ws), ws.numel(), _stream())
+        if insert:
+            _MAP_PRIMED[key] = True
+        elif primed:
+            _MAP_PRIMED[key] = True        # a probe-only call leaves the workspace untouched
+        return (rows, adm) if want_admitted else rows
+
+    def fill_missing(self, keys, rows, out, sigma, fill, seed):
+        flat = keys.reshape(-1).contiguous()
+        tab = self._MapTable(0, out.stride(0), out.shape[1], -1.0 if sigma is None else float(sigma), float(fill or 0.0), int(seed))
+        _lib.call("mrec_map_fill_missing", _ptr(flat), flat.element_size(), _ptr(rows), flat.numel(), _ptr(out), out.stride(0),
+                  C.byref(tab), _stream())
+
+    def evict(self, step, threshold):
+        """Device-side eviction; returns the device word holding the count (no host sync)."""
+        n_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        ws = workspace("mapevict", 4 * ((self.capacity + 2047) // 2048) + 256, self.device)
+        _lib.call("mrec_map_evict", self._h, int(step), int(threshold), _ptr(n_dev), _ptr(ws), ws.numel(), _stream())
+        return n_dev
+
+    def export_dirty(self, clear=True):
+        """(keys int64, rows int32, status int32) of the rows modified and the keys erased since the last clearing call."""
+        cap2 = 2 * self.capacity
+        keys = torch.empty(cap2, dtype=torch.int64, device=self.device)
+        rows = torch.empty(cap2, dtype=torch.int32, device=self.device)
+        status = torch.empty(cap2, dtype=torch.int32, device=self.device)
+        n_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        nb = _lib.query_bytes("mrec_map_workspace_bytes", self.capacity) + self.capacity + 512
+        ws = workspace("mapexport", nb, self.device)
+        _lib.call("mrec_map_export_dirty", self._h, _ptr(keys), _ptr(rows), _ptr(status), _ptr(n_dev), int(bool(clear)), _ptr(ws),
+                  ws.numel(), _stream())
+        n = int(n_dev.item())
+        return keys[:n], rows[:n], status[:n]
+
+    def mark_dirty(self, rows):
+        _lib.call("mrec_map_mark_dirty", self._h, _ptr(rows), rows.numel(), _stream())
 
     def erase(self, keys_i64):
         n = keys_i64.numel()
@@ -502,6 +585,15 @@ def copy3_(dsts, srcs):
         return
     _lib.call("mrec_copy3", _ptr(dsts[0]), _ptr(srcs[0]), nb[0], _ptr(dsts[1]), _ptr(srcs[1]), nb[1], _ptr(dsts[2]), _ptr(srcs[2]),
               nb[2], _stream())
+
+
+def put_rows_last_(table, rows, vals, winner):
+    """table[rows[i]] = vals[i] for the LAST position of every row (duplicates: a sequential upsert); winner: int32 [rows of
+    table] scratch, all -1 before and after."""
+    _need_cuda(table, rows, vals, winner)
+    V, D, ld = _table(table)
+    vals = vals.contiguous()
+    _lib.call("mrec_put_rows_last_f32", _ptr(table), ld, D, _ptr(rows), rows.numel(), _ptr(vals), _ptr(winner), _stream())
 
 
 def compose_i32(table, idx):
@@ -581,8 +673,9 @@ def cross_layers_bwd(x0, w, b, dy):
 
 
 # ---- row-shard routing -----------------------------------------------------------------------
-def shard_route(ids, n_shards):
-    """Buckets ids by owner = id mod n_shards (stable).  Returns (send_local, send_perm, counts_dev)."""
+def shard_route(ids, n_shards, hashed=False):
+    """Buckets ids by owner = id mod n_shards (stable).  Returns (send_local, send_perm, counts_dev).
+    hashed=True: hash tables keyed by the raw id -- owner = hash(key) mod n_shards and send_local holds the raw keys."""
     _need_cuda(ids)
     sfx = _suffix(ids)
     flat = ids.reshape(-1).contiguous()
@@ -593,7 +686,7 @@ def shard_route(ids, n_shards):
     counts = torch.empty(n_shards, dtype=torch.int64, device=dev)
     nb = _lib.query_bytes("mrec_shard_route_workspace_bytes", n, n_shards)
     ws = workspace("route", nb, dev)
-    _lib.call(f"mrec_shard_route_{sfx}", _ptr(flat), n, n_shards, _ptr(send_local), _ptr(send_perm), _ptr(counts), _ptr(ws),
+    _lib.call(f"mrec_shard_route_{'hash_' if hashed else ''}{sfx}", _ptr(flat), n, n_shards, _ptr(send_local), _ptr(send_perm), _ptr(counts), _ptr(ws),
               ws.numel(), _stream())
     return send_local, send_perm, counts
 

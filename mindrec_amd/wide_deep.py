@@ -167,19 +167,19 @@ class WideDeepEngine:
         self.index = None
         self.hb = None
         if cfg.host_cache_rows > 0:
-            if self._sharded or kernels is not None or cfg.dynamic_embedding:
-                raise ValueError("host_cache_rows needs one GPU, the HIP kernels and dense (non-hash) tables")
+            if kernels is not None:
+                raise ValueError("host_cache_rows needs the HIP kernels (no CPU stand-in)")
             self.local_rows = int(cfg.host_cache_rows)
         if cfg.dynamic_embedding:
             # HashEmbeddingLookup x2 with all defaults (wide_and_deep.py:271-274; embedding.py:88-93): a device
             # key -> row index over `hash_capacity` rows; the row tables below are addressed by row number, so
-            # every kernel downstream of the index probe is the one the dense-table mode uses.
-            if self._sharded:
-                raise ValueError("dynamic_embedding runs on one GPU (the reference's dynamic-embedding mode is standalone)")
+            # every kernel downstream of the index probe is the one the dense-table mode uses.  Row-sharded: the raw keys
+            # travel to owner = hash(key) mod n, whose own index translates them (BASELINE configs[4]).
             if kernels is not None:
                 raise ValueError("dynamic_embedding needs the device key index (no CPU stand-in)")
-            self.local_rows = int(cfg.hash_capacity)
-            self.index = ops.KeyIndex(self.local_rows, self.device)
+            if cfg.host_cache_rows == 0:
+                self.local_rows = int(cfg.hash_capacity)
+                self.index = ops.KeyIndex(self.local_rows, self.device)
         dev = self.device
         self._amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[cfg.mlp_dtype]
         dims = [cfg.field_size * D] + list(cfg.deep_layer_dim) + [1]
@@ -198,8 +198,11 @@ class WideDeepEngine:
             if cfg.host_cache_rows > 0:
                 # one row = [p | m | v | w, accum, linear, pad]: the deep LazyAdam row and the wide FTRL record of an id
                 # travel between the host and the cache together
+                # (hash tables: `hash_capacity` host rows behind a second key index; a row shard of a dense table: this
+                # rank's rows, default values keyed by the global id r * world + rank)
                 from .feature_cache import HostBackedTable
-                self.hb = HostBackedTable(V, D, R, dev, columns=[
+                host_rows = int(cfg.hash_capacity) if cfg.dynamic_embedding else (V - rank + world - 1) // world
+                self.hb = HostBackedTable(host_rows, D, R, dev, hashed=cfg.dynamic_embedding, key_scale=world, key_offset=rank, columns=[
                     ("deep", D, ("normal", cfg.seed, cfg.init_sigma)), ("deep_m", D, ("fill", 0.0)), ("deep_v", D, ("fill", 0.0)),
                     ("wide", 1, ("normal", cfg.seed + 1, cfg.init_sigma)), ("wide_accum", 1, ("fill", cfg.ftrl_initial_accum)),
                     ("wide_linear", 1, ("fill", 0.0)), ("pad", 1, ("fill", 0.0))])
@@ -275,6 +278,8 @@ class WideDeepEngine:
             self.k.fill_normal_(self.wide_b.view(1, 1), cfg.seed + 3, cfg.init_sigma)
             self.wide_b_accum = torch.full_like(self.wide_b, cfg.ftrl_initial_accum)
             self.wide_b_linear = torch.zeros_like(self.wide_b)
+        self._hashed = bool(cfg.dynamic_embedding)
+        self._recv_plan = None        # shards with a host-backed table: the plan of the received keys (made by the cache tier)
         self.beta1, self.beta2 = np.float32(0.9), np.float32(0.999)
         self.beta1_power, self.beta2_power = np.float32(1.0), np.float32(1.0)
         self.step_count = 0
@@ -546,7 +551,8 @@ class WideDeepEngine:
             # early: issued on the side stream, so neither the routing kernels, nor the host sync for the bucket
             # sizes, nor the collectives (RCCL orders them after the *current* stream) wait for the main stream,
             # where the previous step's sparse applies may still be running.
-            send_local, perm, counts = self.k.shard_route(ids, self.world)
+            send_local, perm, counts = (self.k.shard_route(ids, self.world, hashed=True) if self._hashed
+                                        else self.k.shard_route(ids, self.world))
             send_counts = counts.tolist()                                    # host sync: n_shards ints
             recv_counts_t = torch.empty_like(counts)
             self.comm.all_to_all(recv_counts_t, counts)
@@ -568,6 +574,12 @@ class WideDeepEngine:
             for t in (send_local, perm, recv_local, recv_wts):
                 if t is not None:
                     t.record_stream(main)
+        if self.index is not None:
+            # hash tables: what arrived are raw keys; this owner's index gives them rows (new keys: the next rows, default
+            # values keyed by the key) -- one chain of three launches, duplicates welcome
+            recv_local = self.index.lookup(recv_local, insert=True, tables=self._map_tables())
+        elif self.hb is not None:
+            self._recv_plan, recv_local = self.hb.prepare(recv_local)          # rows of the device cache
         self._tock(ev)
         ev = self._tick("gather_deep")
         if wire16:
@@ -605,11 +617,19 @@ class WideDeepEngine:
 
     def predict(self, ids, wts):
         with torch.no_grad():
-            if self.index is not None or self.hb is not None:
+            if (self.index is not None or self.hb is not None) and not self._sharded:
                 ids, _ = self._translate_keys(ids)      # MapTensorGet inserts default rows in eval too (embedding.py:193)
             emb, wide, _ = self.lookup(ids, wts)
             logit = wide.view(-1, 1) + self.mlp(emb)
         return logit, torch.sigmoid(logit)
+
+    def _map_tables(self):
+        """(tensor, sigma, fill, seed) of the six tables that share the key index's row numbering, with the values a row gets
+        when its key is first seen (the same as a dense table's initial contents, keyed by the key)."""
+        cfg = self.cfg
+        return [(self.deep, cfg.init_sigma, None, cfg.seed), (self.deep_m, None, 0.0, 0), (self.deep_v, None, 0.0, 0),
+                (self.wide, cfg.init_sigma, None, cfg.seed + 1), (self.wide_accum, None, cfg.ftrl_initial_accum, 0),
+                (self.wide_linear, None, 0.0, 0)]
 
     def _translate_keys(self, ids):
         """dynamic_embedding: Unique -> key-index probe / insert -> default rows for new keys (MapTensorGet with
@@ -621,15 +641,7 @@ class WideDeepEngine:
             plan, rows_pos = self.hb.prepare(ids)
             return rows_pos.view(ids.shape), plan
         d = self.k.unique(ids)                                   # critical path: the gather needs the row numbers
-        k64 = ops.widen_keys(d.uniq_buf)
-        rows_u, is_new = self.index.find_or_insert(k64, insert=True, n_dev=d.n_uniq_dev)
-        nd = d.n_uniq_dev
-        ops.init_rows_(self.deep, rows_u, k64, is_new, n_dev=nd, seed=cfg.seed, sigma=cfg.init_sigma)
-        ops.init_rows_(self.deep_m, rows_u, k64, is_new, n_dev=nd, seed=0, sigma=None, fill=0.0)
-        ops.init_rows_(self.deep_v, rows_u, k64, is_new, n_dev=nd, seed=0, sigma=None, fill=0.0)
-        ops.init_rows_(self.wide, rows_u, k64, is_new, n_dev=nd, seed=cfg.seed + 1, sigma=cfg.init_sigma)
-        ops.init_rows_(self.wide_accum, rows_u, k64, is_new, n_dev=nd, seed=0, sigma=None, fill=cfg.ftrl_initial_accum)
-        ops.init_rows_(self.wide_linear, rows_u, k64, is_new, n_dev=nd, seed=0, sigma=None, fill=0.0)
+        rows_u = self.index.lookup(d.uniq_buf, insert=True, unique=True, n_dev=d.n_uniq_dev, tables=self._map_tables())
         rows_pos = ops.compose_i32(rows_u, d.inv).view(ids.shape)
         # the inverted index (two radix passes) is needed only by the sparse applies: side stream, under the MLP
         if self._side is not None:
@@ -664,7 +676,7 @@ class WideDeepEngine:
         late_cfg = cfg.late_wide if cfg.late_wide is not None else (self._sharded or capturing)
         late = bool(self._side is not None and late_cfg and self._mfma and not self._fold_wide)
         plan_early, fork_ev = None, None
-        if self.index is not None or self.hb is not None:
+        if (self.index is not None or self.hb is not None) and not self._sharded:
             ids, plan_early = self._translate_keys(ids)        # from here on `ids` are table row numbers
         elif self._side is not None and not self._sharded and not late:
             # one GPU: the plan needs nothing but the ids -- start it on the side stream BEFORE the gathers are
@@ -690,7 +702,10 @@ class WideDeepEngine:
             self._side.wait_event(fork_ev)
             with torch.cuda.stream(self._side):
                 plan_early = self.k.sparse_plan(ids)
-        if self._side is not None and self.index is None and self.hb is None and plan_early is None and fork_ev is None:
+        if route is not None and self.hb is not None:
+            plan_early = self._recv_plan       # the cache tier planned the received keys while making them resident
+        if (self._side is not None and plan_early is None and fork_ev is None
+                and ((self.index is None and self.hb is None) or route is not None)):
             # Side stream, in this order: (1) the wide branch, which the main stream joins only right before the
             # output head -- it runs while the hidden-layer GEMMs do; (2) the step's Unique + inverted index, which
             # needs only the ids (on a shard: the ids received from the other ranks) and is joined before the sparse

@@ -22,9 +22,13 @@ def _rows_view(oracle, m, cap, D):
     return np.ctypeslib.as_array(pr(m._h), shape=(cap, D))
 
 
-def test_deepfm_over_hash_tables_with_admission_and_eviction(dev, oracle):
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("B,Fd,cap,pool,phases", [(48, 6, 4096, 40, ((0, 3), (1, 4), (0, 2))),
+                                                   (16384, 26, 1 << 20, 300_000, ((0, 2), (1, 3), (0, 1)))])
+def test_deepfm_over_hash_tables_with_admission_and_eviction(dev, oracle, B, Fd, cap, pool, phases):
+    """The second case is the configuration's own shape: batch 16384, 26 fields, dim 128 (BASELINE configs[4])."""
     from mindrec_amd.deepfm import DeepFMConfig, DeepFMHashEngine
-    D, Fd, B, cap = 128, 6, 48, 4096
+    D = 128
     cfg = DeepFMConfig(data_emb_dim=D, data_field_size=Fd, batch_size=B, deep_layer_dims=[64, 32], learning_rate=1e-2)
     eng = DeepFMHashEngine(cfg, dev, key_dtype=torch.int64, capacity=cap, permit_filter_value=2, evict_filter_value=2)
     # ---- reference state
@@ -38,7 +42,7 @@ def test_deepfm_over_hash_tables_with_admission_and_eviction(dev, oracle):
     dims = eng.dims
     b1p = b2p = np.float32(1.0)
     rng = np.random.default_rng(5)
-    pools = [rng.integers(1, 2 ** 40, size=40), rng.integers(2 ** 41, 2 ** 42, size=40)]    # two disjoint key sets
+    pools = [rng.integers(1, 2 ** 40, size=pool), rng.integers(2 ** 41, 2 ** 42, size=pool)]    # two disjoint key sets
 
     def ref_mlp(x):
         off, h = 0, x
@@ -51,7 +55,7 @@ def test_deepfm_over_hash_tables_with_admission_and_eviction(dev, oracle):
         return h
 
     step = 0
-    for phase, nsteps in ((0, 3), (1, 4), (0, 2)):          # pool 0, then only pool 1 (pool 0 goes stale), then pool 0 again
+    for phase, nsteps in phases:          # pool 0, then only pool 1 (pool 0 goes stale), then pool 0 again
         for _ in range(nsteps):
             step += 1
             keys = rng.choice(pools[phase], size=(B, Fd)).astype(np.int64)
@@ -63,15 +67,14 @@ def test_deepfm_over_hash_tables_with_admission_and_eviction(dev, oracle):
             live_before = set(last)
             rows_v = oV.find_or_insert(flat, True)
             rows_w = oW.find_or_insert(flat, True)
-            for k in np.unique(flat):
-                k = int(k)
-                if k not in live_before:            # new (or re-inserted after eviction): fresh optimizer state and hit count
-                    hits[k] = 0
-                    for nm, rr in (("V", rows_v), ("W", rows_w)):
-                        r = int(rr[np.nonzero(flat == k)[0][0]])
-                        st[nm][0][r] = 0
-                        st[nm][1][r] = 0
-                hits[k] += 1
+            uk, first = np.unique(flat, return_index=True)
+            is_new = np.fromiter((int(k) not in live_before for k in uk), bool, uk.size)
+            for nm, rr in (("V", rows_v), ("W", rows_w)):      # new (or re-inserted after eviction): fresh optimizer state
+                r = rr[first[is_new]]
+                st[nm][0][r] = 0
+                st[nm][1][r] = 0
+            for k, fresh in zip(uk.tolist(), is_new.tolist()):
+                hits[k] = 1 if fresh else hits[k] + 1
                 last[k] = step
             vx = torch.from_numpy(oracle.gather_rows(vV, rows_v, wts.reshape(-1)).reshape(B, Fd, D)).requires_grad_(True)
             lin = torch.from_numpy(oracle.wide_sum(vW, rows_w.reshape(B, Fd), wts, 0.0)).requires_grad_(True)
@@ -85,7 +88,8 @@ def test_deepfm_over_hash_tables_with_admission_and_eviction(dev, oracle):
             assert abs(lr_ - lg) <= 2e-5 * max(abs(lr_), 1e-3), (step, lr_, lg)
             b1p = np.float32(b1p * np.float32(0.9)); b2p = np.float32(b2p * np.float32(0.999))
             kw = dict(lr=cfg.learning_rate, eps=cfg.epsilon, b1_pow=float(b1p), b2_pow=float(b2p), grad_scale=1.0 / cfg.loss_scale)
-            admitted = np.array([hits[int(k)] >= 2 for k in flat])
+            adm_u = np.fromiter((hits[k] >= 2 for k in uk.tolist()), bool, uk.size)
+            admitted = adm_u[np.searchsorted(uk, flat)]
             oracle.sparse_lazy_adam(vV, st["V"][0], st["V"][1], np.where(admitted, rows_v, -1), vx.grad.numpy().reshape(-1, D),
                                     wts.reshape(-1), **kw)
             gw = (lin.grad.numpy().reshape(B, 1) * wts).reshape(-1, 1)

@@ -99,3 +99,82 @@ def test_ranks_on_one_gpu_match_single_process(dev, tmp_path, mlp_dtype, world, 
         assert diff.max() <= 2.0 * eng.cfg.adam_lr * steps
         assert np.mean(diff <= 5e-2 * np.abs(ref_dense) + 1e-5) >= 0.99
     assert np.allclose(sum(r[k]["losses"] for k in range(world)) / world, losses, rtol=1e-5 if mlp_dtype == "fp32" else 2e-3)
+
+
+# ---- BASELINE configs[4] composition: hash tables keyed by the raw id x row sharding (owner = hash(key) mod n) x the
+# ---- host-DRAM cache tier under them ---------------------------------------------------------------------------------
+def _hash_cfg(B, host_cache_rows=0):
+    from mindrec_amd.wide_deep import WideDeepConfig
+    return WideDeepConfig(vocab_size=1, emb_dim=16, field_size=13, batch_size=B, deep_layer_dim=[64, 32], mlp_dtype="fp32",
+                          dynamic_embedding=True, hash_capacity=1 << 15, host_cache_rows=host_cache_rows, early_route=False)
+
+
+def _hash_batch(B, F, seed, dev):
+    """int64 keys far outside any dense vocabulary, with repeats inside and across batches."""
+    g = torch.Generator().manual_seed(seed)
+    pool = torch.randint(-2 ** 60, 2 ** 60, (3000,), generator=torch.Generator().manual_seed(7), dtype=torch.int64)
+    ids = pool[torch.randint(0, 3000, (B, F), generator=g)]
+    wts = (torch.rand(B, F, generator=g) > 0.1).float()
+    label = (torch.rand(B, 1, generator=g) < 0.3).float()
+    return ids.to(dev), wts.to(dev), label.to(dev)
+
+
+def _hash_worker(rank, world, port, steps, out_dir, host_cache_rows):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from _staged_comm import StagedGlooComm
+    from mindrec_amd.wide_deep import WideDeepEngine
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    cfg = _hash_cfg(64, host_cache_rows)
+    eng = WideDeepEngine(cfg, dev, rank=rank, world=world, comm=StagedGlooComm())
+    losses = []
+    for s in range(steps):
+        ids, wts, label = _hash_batch(64 * world, cfg.field_size, 100 + s, dev)
+        sl = slice(64 * rank, 64 * (rank + 1))
+        losses.append(float(eng.train_step(ids[sl].contiguous(), wts[sl].contiguous(), label[sl].contiguous())))
+    if eng.hb is not None:
+        keys, rows = eng.hb.export_hashed()
+        keys, deep, wide = keys.numpy(), rows[:, :16].numpy(), rows[:, 48:49].numpy()
+        stats = eng.hb.stats
+        assert stats["evictions"] > 0, stats                    # the cache is smaller than the shard's working set
+    else:
+        k, r = eng.index.export()
+        keys, deep, wide = k.cpu().numpy(), eng.deep[r.long()].cpu().numpy(), eng.wide[r.long()].cpu().numpy()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keys=keys, deep=deep, wide=wide, dense=eng.dense_flat.detach().cpu().numpy(),
+             losses=np.array(losses))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,host_cache_rows", [(2, 0), (3, 0), (2, 1000)])
+def test_sharded_hash_tables_match_single_process(dev, tmp_path, world, host_cache_rows):
+    """Keys travel to owner = hash(key) mod n, whose own key index (or, with host_cache_rows, the cache tier over a
+    host-DRAM hash table) gives them rows; the sharded step must reproduce the one-GPU hash-table engine on the whole
+    batch: same losses, the same value for every key, every key on exactly one rank."""
+    from mindrec_amd.wide_deep import WideDeepEngine
+    steps = 5
+    mp.spawn(_hash_worker, args=(world, _free_port(), steps, str(tmp_path), host_cache_rows), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
+    eng = WideDeepEngine(_hash_cfg(64 * world), dev)
+    losses = []
+    for s in range(steps):
+        losses.append(float(eng.train_step(*_hash_batch(64 * world, eng.cfg.field_size, 100 + s, dev))))
+    k1, r1 = eng.index.export()
+    ref = {int(k): (eng.deep[int(x)].cpu().numpy(), float(eng.wide[int(x)])) for k, x in zip(k1.cpu().numpy(), r1.cpu().numpy())}
+    seen = set()
+    for k in range(world):
+        assert len(r[k]["keys"]) > 0.5 * len(ref) / world                       # the hash spreads the keys
+        for key, d, w in zip(r[k]["keys"], r[k]["deep"], r[k]["wide"]):
+            key = int(key)
+            assert key not in seen and key in ref
+            seen.add(key)
+            assert np.allclose(d, ref[key][0], rtol=2e-4, atol=2e-6) and abs(float(w[0]) - ref[key][1]) <= 2e-4 * abs(ref[key][1]) + 1e-6
+    assert seen == set(ref)
+    assert np.allclose(sum(r[k]["losses"] for k in range(world)) / world, losses, rtol=1e-5)
+    for k in range(1, world):
+        assert np.array_equal(r[0]["dense"], r[k]["dense"])
+    assert np.allclose(r[0]["dense"], eng.dense_flat.detach().cpu().numpy(), rtol=1e-4, atol=1e-7)

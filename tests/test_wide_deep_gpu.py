@@ -292,6 +292,34 @@ def test_host_cached_tables_engine_equals_resident_engine(dev):
     assert torch.equal(a.dense_flat.detach(), b.dense_flat.detach())
 
 
+def test_hash_tables_behind_the_host_cache_equal_resident_hash_tables(dev):
+    """dynamic_embedding + host_cache_rows (BASELINE configs[4]: MapParameter tables larger than HBM): keys -> host rows by
+    a second device key index, the cache tier below unchanged; trains bit-identically to the resident hash-table engine and
+    ends with the same value for every key."""
+    from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine
+    kw = dict(vocab_size=1, emb_dim=16, field_size=26, batch_size=256, deep_layer_dim=[64, 32], mlp_dtype="bf16",
+              dynamic_embedding=True, hash_capacity=1 << 16)
+    a = WideDeepEngine(WideDeepConfig(fold_wide=False, **kw), dev)
+    b = WideDeepEngine(WideDeepConfig(host_cache_rows=7000, **kw), dev)
+    pool = torch.randint(-2 ** 62, 2 ** 62, (30000,), dtype=torch.int64, generator=torch.Generator().manual_seed(1))
+    for s in range(10):
+        g = torch.Generator().manual_seed(900 + s)
+        ids = pool[(torch.rand(256, 26, generator=g) ** (3 if s % 3 else 1) * 30000).long().clamp_(0, 29999)].to(dev)
+        wts = (torch.rand(256, 26, generator=g) > 0.1).float().to(dev)
+        label = (torch.rand(256, 1, generator=g) < 0.3).float().to(dev)
+        la, lb = float(a.train_step(ids, wts, label)), float(b.train_step(ids, wts, label))
+        assert la == lb, (s, la, lb)
+    st = b.hb.stats
+    assert st["evictions"] > 0 and st["hits"] > 0
+    keys, rows = b.hb.export_hashed()
+    ka, ra = a.index.export()
+    assert set(keys.tolist()) == set(ka.cpu().tolist())
+    order_b, order_a = torch.argsort(keys), torch.argsort(ka.cpu())
+    ref = torch.cat([a.deep, a.deep_m, a.deep_v, a.wide, a.wide_accum, a.wide_linear], dim=1)[ra.long()].cpu()[order_a]
+    assert torch.equal(rows[order_b][:, : 3 * 16 + 3], ref)
+    assert torch.equal(a.dense_flat.detach(), b.dense_flat.detach())
+
+
 def test_weight_gradient_slabs_and_graph_switching(dev):
     """One GPU: the weight gradients stay fp32 batch slabs and the dense-Adam kernel adds them up.  The slabs are
     persistent engine buffers, so switching between the whole-step graph, the MLP graphs (phase timers on) and
