@@ -89,7 +89,7 @@ __device__ __forceinline__ void stage_wb(const float* __restrict__ w, const floa
 }
 
 constexpr int FWD_NT = 1024;   // 16 waves: one block per CU, w / b staged once per CU
-constexpr int BWD_NT = 256;
+constexpr int BWD_NT = 512;   // 8 waves: one block per CU at two waves per SIMD -> one slab per CU for the reduction kernel
 
 template <int NPL, bool WLDS>
 __global__ __launch_bounds__(FWD_NT) void k_cross_fwd(const float* __restrict__ x0, const float* __restrict__ w,
@@ -147,21 +147,6 @@ __global__ __launch_bounds__(FWD_NT) void k_cross_fwd(const float* __restrict__ 
 // slab layout per block: [LMAX][D] sums of u_l*x0, then [D] colsum(dy), then [LMAX] sums of t_l.
 __host__ __device__ inline int64_t slab_floats(int D) { return (int64_t)(LMAX + 1) * D + LMAX; }
 
-// pd[l' * L + l] = b_l' . w_l for l' < l (0 otherwise): the row-independent part of s_l = x_l . w_l is
-// c_l = beta_l . w_l = sum_{l' < l} pd[l', l] (k_cross_bwd adds the pairs in l' order).  One block per pair.
-__global__ __launch_bounds__(256) void k_cross_beta_dot(const float* __restrict__ w, const float* __restrict__ b,
-                                                        int L, int D, float* __restrict__ pd) {
-    __shared__ float part[4];
-    const int lp = blockIdx.x / L, l = blockIdx.x - lp * L;
-    float s = 0.0f;
-    if (lp < l)
-        for (int c = threadIdx.x; c < D; c += 256) s = fmaf(b[lp * D + c], w[l * D + c], s);
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) pd[blockIdx.x] = ((part[0] + part[1]) + part[2]) + part[3];
-}
-
 // two waves per SIMD where the [LT][NPL] accumulators + x, dy, colsum rows leave room under 256 registers
 constexpr int bwd_occ(int npl, int lt) { return (lt + 3) * npl <= 180 ? 2 : 1; }
 
@@ -172,62 +157,108 @@ constexpr int bwd_occ(int npl, int lt) { return (lt + 3) * npl <= 180 ? 2 : 1; }
 // reductions overlap): with x_l = a_l x0 + beta_l,  s_l = x_l . w_l = a_l P_l + c_l,  a_{l+1} = a_l + s_l.
 // x_l itself is never rebuilt, b is not read at all; fmaf is used freely -- this kernel is checked against
 // the oracle's double-precision backward to a tolerance, not bit for bit.
+// A lane owns FOUR consecutive columns per 256-column block (columns 256 q + 4 lane + {0..3}): x0, dy and dx0 move as
+// 16-byte buffer accesses (the range check zero-fills / drops the dwords past column D one by one), w comes out of LDS as
+// ds_read_b128, and the arithmetic runs on 2-wide packed fp32 (v_pk_fma_f32) -- a quarter of the memory and LDS instructions
+// and half of the FMAs of a one-column-per-lane layout, which was what bound this kernel (issue slots, two waves per SIMD).
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 row_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void row_store4(__amdgpu_buffer_rsrc_t r, int voff, int soff, f4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ f4 fma4(f4 a, f4 b, f4 c) {
+    const f2 lo = __builtin_elementwise_fma(a.lo, b.lo, c.lo), hi = __builtin_elementwise_fma(a.hi, b.hi, c.hi);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f4 bc4(float u) { return f4{u, u, u, u}; }
+__device__ __forceinline__ float hsum4(f4 v) { return (v.x + v.y) + (v.z + v.w); }
+
 template <int NPL, int LT, bool WLDS>
 __global__ __launch_bounds__(BWD_NT) __attribute__((amdgpu_waves_per_eu(bwd_occ(NPL, LT), bwd_occ(NPL, LT)))) void k_cross_bwd(const float* __restrict__ x0, const float* __restrict__ w,
-                                                      const float* __restrict__ cvec, int L, int64_t B, int D,
+                                                      const float* __restrict__ b, int L, int64_t B, int D,
                                                       const float* __restrict__ dy, float* __restrict__ dx0,
-                                                      float* __restrict__ slabs) {
+                                                      float* __restrict__ slabs, int* __restrict__ tile_counters, int ntiles) {
+    static_assert(NPL % 4 == 0 && WLDS, "the backward is instantiated for 256-column blocks with w staged in LDS");
     constexpr int DP = NPL * 64;
+    constexpr int NQ = NPL / 4;             // 256-column blocks
     extern __shared__ float smem[];
+    __shared__ float s_pd[LMAX * LMAX];
     float* sw = smem;
-    if (WLDS) stage_wb<BWD_NT, DP, false>(w, nullptr, L, D, sw, nullptr);
+    stage_wb<BWD_NT, DP, false>(w, nullptr, L, D, sw, nullptr);
     const int lane = threadIdx.x & 63;
-    const int voff = lane * 4;
+    const int voff = lane * 16;
     constexpr int WPB = BWD_NT / 64;
     const int64_t wid = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * WPB;
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < ntiles; i += BWD_NT) tile_counters[i] = 0;      // for the reduction kernel behind this one
+    // pair dots b_l' . w_l (l' < l), the row-independent part of s_l = x_l . w_l: every block computes them itself (15 dots of
+    // D terms against 60 KB of rows per wave: nothing); fixed order
+    for (int pr = threadIdx.x >> 6; pr < L * L; pr += WPB) {
+        const int lp = pr / L, l = pr - lp * L;
+        float sdot = 0.0f;
+        if (lp < l) {
+            const __amdgpu_buffer_rsrc_t rb = row_rsrc(b + (int64_t)lp * D, D * 4);
+            f4 bv[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) bv[q] = row_load4(rb, voff, 1024 * q);
+            f4 acc = bc4(0.0f);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc = fma4(bv[q], *(const f4*)(sw + l * DP + 256 * q + 4 * lane), acc);
+            sdot = wave_sum(hsum4(acc));
+        }
+        if (lane == 0) s_pd[pr] = sdot;
+    }
+    __syncthreads();
     float cl[LT];
 #pragma unroll
     for (int l = 0; l < LT; ++l) {
         float s = 0.0f;
-        for (int lp = 0; lp < l && l < L; ++lp) s += cvec[lp * L + l];
+        for (int lp = 0; lp < l && l < L; ++lp) s += s_pd[lp * L + l];
         cl[l] = s;
     }
-    float accw[LT][NPL];
-    float accd[NPL];
+    f4 accw[LT][NQ];
+    f4 accd[NQ];
     float accT[LT];
 #pragma unroll
     for (int l = 0; l < LT; ++l) {
         accT[l] = 0.0f;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) accw[l][j] = 0.0f;
+        for (int q = 0; q < NQ; ++q) accw[l][q] = bc4(0.0f);
     }
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) accd[j] = 0.0f;
+    for (int q = 0; q < NQ; ++q) accd[q] = bc4(0.0f);
 
+    // (Requesting the next row ahead of time -- into LDS with buffer_load ... lds, the registers being full -- was built and
+    // measured: no faster; the loop is bound by instruction issue at two waves per SIMD, not by the load latency.)
     for (int64_t row = wid; row < B; row += nw) {
-        float x[NPL], g[NPL];
+        f4 x[NQ], g[NQ];
         const __amdgpu_buffer_rsrc_t rx = row_rsrc(x0 + row * D, D * 4);
         const __amdgpu_buffer_rsrc_t rg = row_rsrc(dy + row * D, D * 4);
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            x[j] = row_load(rx, voff, 256 * j);
-            g[j] = row_load(rg, voff, 256 * j);
+        for (int q = 0; q < NQ; ++q) {
+            x[q] = row_load4(rx, voff, 1024 * q);
+            g[q] = row_load4(rg, voff, 1024 * q);
         }
-        float P[LT], qp = 0.0f;
+        float P[LT];
+        f4 qa = bc4(0.0f);
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) qp = fmaf(g[j], x[j], qp);
+        for (int q = 0; q < NQ; ++q) qa = fma4(g[q], x[q], qa);
 #pragma unroll
         for (int l = 0; l < LT; ++l) {
-            float p = 0.0f;
+            f4 pa = bc4(0.0f);
             if (l < L) {
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) p = fmaf(x[j], wload<WLDS>(w, sw, l, lane, j, D, DP), p);
+                for (int q = 0; q < NQ; ++q) pa = fma4(x[q], *(const f4*)(sw + l * DP + 256 * q + 4 * lane), pa);
             }
-            P[l] = p;
-            __builtin_amdgcn_sched_barrier(0);   // keep one layer's LDS reads in flight, not all L*NPL (registers)
+            P[l] = hsum4(pa);
+            __builtin_amdgcn_sched_barrier(0);   // keep one layer's LDS reads in flight, not all of them (registers)
         }
-        const float q = wave_sum(qp);
+        const float qd = wave_sum(hsum4(qa));
 #pragma unroll
         for (int l = 0; l < LT; ++l) P[l] = wave_sum(P[l]);      // P[l] == 0 for l >= L
         float a[LT + 1], t[LT];
@@ -238,32 +269,32 @@ __global__ __launch_bounds__(BWD_NT) __attribute__((amdgpu_waves_per_eu(bwd_occ(
         float run = 0.0f;
 #pragma unroll
         for (int l = LT - 1; l >= 0; --l) {
-            t[l] = l < L ? q + run : 0.0f;
+            t[l] = l < L ? qd + run : 0.0f;
             run = fmaf(t[l], P[l], run);
         }
-        // dx0 = a_L * dy + sum_l u_l w_l ; accumulate batch sums
-        float o[NPL];
+        // dx0 = a_L * dy + sum_l u_l w_l, built in dy's registers; batch sums accumulate
+        const f4 aL = bc4(a[LT]);                // a[LT] == a[L]: layers past L add nothing
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            o[j] = a[LT] * g[j];  // a[LT] == a[L]: layers past L add nothing
-            accd[j] += g[j];
+        for (int q = 0; q < NQ; ++q) {
+            accd[q] += g[q];
+            g[q] = aL * g[q];
         }
 #pragma unroll
         for (int l = 0; l < LT; ++l) {
             if (l < L) {
-                const float u = t[l] * a[l];
+                const f4 u = bc4(t[l] * a[l]);
                 accT[l] += t[l];
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) {
-                    o[j] = fmaf(u, wload<WLDS>(w, sw, l, lane, j, D, DP), o[j]);
-                    accw[l][j] = fmaf(u, x[j], accw[l][j]);
+                for (int q = 0; q < NQ; ++q) {
+                    g[q] = fma4(u, *(const f4*)(sw + l * DP + 256 * q + 4 * lane), g[q]);
+                    accw[l][q] = fma4(u, x[q], accw[l][q]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         const __amdgpu_buffer_rsrc_t ro = row_rsrc(dx0 + row * D, D * 4);
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) row_store(ro, voff, 256 * j, o[j]);
+        for (int q = 0; q < NQ; ++q) row_store4(ro, voff, 1024 * q, g[q]);
     }
     // Block slab: the waves add their sums in wave order into LDS (the w staging area is dead by now;
     // rows padded to DP, so no guards), one slab per block goes to HBM, same fixed order every run.
@@ -276,17 +307,17 @@ __global__ __launch_bounds__(BWD_NT) __attribute__((amdgpu_waves_per_eu(bwd_occ(
             for (int l = 0; l < LT; ++l) {
                 if (l < L) {
 #pragma unroll
-                    for (int j = 0; j < NPL; ++j) {
-                        const int c = lane + 64 * j;
-                        bs[l * DP + c] = (turn ? bs[l * DP + c] : 0.0f) + accw[l][j];
+                    for (int q = 0; q < NQ; ++q) {
+                        f4* dst = (f4*)(bs + l * DP + 256 * q + 4 * lane);
+                        *dst = (turn ? *dst : bc4(0.0f)) + accw[l][q];
                     }
                     if (lane == 0) bs[(L + 1) * DP + l] = (turn ? bs[(L + 1) * DP + l] : 0.0f) + accT[l];
                 }
             }
 #pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-                const int c = lane + 64 * j;
-                bs[L * DP + c] = (turn ? bs[L * DP + c] : 0.0f) + accd[j];
+            for (int q = 0; q < NQ; ++q) {
+                f4* dst = (f4*)(bs + L * DP + 256 * q + 4 * lane);
+                *dst = (turn ? *dst : bc4(0.0f)) + accd[q];
             }
         }
         __syncthreads();
@@ -298,23 +329,27 @@ __global__ __launch_bounds__(BWD_NT) __attribute__((amdgpu_waves_per_eu(bwd_occ(
     if ((int)threadIdx.x < L) sl[(int64_t)(LMAX + 1) * D + threadIdx.x] = bs[(L + 1) * DP + threadIdx.x];
 }
 
-// Stage 1 of the slab reduction.  blockIdx.y = quantity q (q < L: sum u_l x0 of layer q; q == L: colsum(dy);
-// q == L + 1: the L scalars sum t_l).  A block owns 32 columns; its 32 thread groups each add a strided
-// subset of the slabs, then the 32 partial sums are added in group order: a fixed order, independent of timing.
-__global__ __launch_bounds__(1024) void k_cross_bwd_sum(const float* __restrict__ slabs, int nslabs, int L, int D,
-                                                        float* __restrict__ R) {
+// Slab reduction and the composition of dw / db in ONE launch.  blockIdx.y = quantity q (q < L: sum u_l x0 of layer q;
+// q == L: colsum(dy); q == L + 1: the L scalars sum t_l, computed by that block of EVERY column tile -- same slabs, same
+// order, same bits).  A block owns 32 columns; its 32 thread groups each add a strided subset of the slabs, then the 32
+// partial sums are added in group order: a fixed order, independent of timing.  The block that finishes a column tile LAST
+// (a counter per tile, zeroed by k_cross_bwd) composes dw and db of its 32 columns from the reduced sums.
+__global__ __launch_bounds__(1024) void k_cross_bwd_finish(const float* __restrict__ slabs, int nslabs, int L, int D,
+                                                           float* __restrict__ R, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ dw,
+                                                           float* __restrict__ db, int* __restrict__ tile_counters) {
     __shared__ float part[32][33];
+    __shared__ int s_last;
     const int q = blockIdx.y;
     const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int64_t sf = slab_floats(D);
+    const int c = blockIdx.x * 32 + cl;
     int64_t off;
     bool live;
     if (q <= L) {
-        const int c = blockIdx.x * 32 + cl;
         live = c < D;
         off = (int64_t)(q < L ? q : LMAX) * D + c;
     } else {
-        if (blockIdx.x != 0) return;
         live = cl < L;
         off = (int64_t)(LMAX + 1) * D + cl;
     }
@@ -329,21 +364,20 @@ __global__ __launch_bounds__(1024) void k_cross_bwd_sum(const float* __restrict_
         float t = part[0][cl];
 #pragma unroll
         for (int g2 = 1; g2 < 32; ++g2) t += part[g2][cl];
-        if (q <= L) R[(int64_t)(q < L ? q : LMAX) * D + blockIdx.x * 32 + cl] = t;
-        else R[(int64_t)(LMAX + 1) * D + cl] = t;
+        R[off] = t;
+        __threadfence();          // (only the 32 writers: a release fence per thread of the block cost 70 us)
     }
-}
-
-// Stage 2: one thread per column composes dw and db from the reduced slab R.
-__global__ __launch_bounds__(256) void k_cross_bwd_compose(const float* __restrict__ R, const float* __restrict__ w,
-                                                           const float* __restrict__ b, int L, int D,
-                                                           float* __restrict__ dw, float* __restrict__ db) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= D) return;
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&tile_counters[blockIdx.x], 1) == L + 1);
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 32 || c >= D) return;
+    __threadfence();
+    // compose (what the other blocks of this tile wrote is read past the caches)
+    auto rd = [&](int64_t i) { return __hip_atomic_load(&R[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     float T[LMAX];
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l) T[l] = l < L ? R[(int64_t)(LMAX + 1) * D + l] : 0.0f;
-    const float cs = R[(int64_t)LMAX * D + c];
+    for (int l = 0; l < LMAX; ++l) T[l] = l < L ? rd((int64_t)(LMAX + 1) * D + l) : 0.0f;
+    const float cs = rd((int64_t)LMAX * D + c);
     float beta = 0.0f;  // beta_l[c]
     float tail = 0.0f;  // sum_{l' > l} w_l'[c] * T_l'
     float dbv[LMAX];
@@ -357,7 +391,7 @@ __global__ __launch_bounds__(256) void k_cross_bwd_compose(const float* __restri
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
         if (l < L) {
-            dw[l * D + c] = R[(int64_t)l * D + c] + beta * T[l];
+            dw[l * D + c] = rd((int64_t)l * D + c) + beta * T[l];
             db[l * D + c] = dbv[l];
             beta += b[l * D + c];
         }
@@ -372,8 +406,8 @@ inline int npl_bucket(int D) {
 }
 
 inline unsigned bwd_blocks(int64_t B) {
-    int64_t blocks = mrec_cdiv(B, 4 * 8);  // >= 8 rows per wave
-    if (blocks > 512) blocks = 512;       // two blocks per CU (256 VGPRs, <= 80 KB of LDS each)
+    int64_t blocks = mrec_cdiv(B, (BWD_NT / 64) * 8);  // >= 8 rows per wave
+    if (blocks > 256) blocks = 256;       // one block per CU (8 waves x 256 VGPRs)
     if (blocks < 1) blocks = 1;
     return (unsigned)blocks;
 }
@@ -421,8 +455,8 @@ int launch_fwd(const float* x0, const float* w, const float* b, int L, int64_t B
 }
 
 template <int NPL, int LT>
-int launch_bwd_lt(const float* x0, const float* w, const float* cvec, int L, int64_t B, int D, const float* dy, float* dx0,
-                  float* slabs, unsigned blocks, hipStream_t st) {
+int launch_bwd_lt(const float* x0, const float* w, const float* b, int L, int64_t B, int D, const float* dy, float* dx0,
+                  float* slabs, unsigned blocks, int* counters, int ntiles, hipStream_t st) {
     constexpr int DP = NPL * 64;
     // w of all layers (<= 8 x 2048 floats = 64 KB) always fits in LDS; the block slab reuses the same area
     const size_t slab = ((size_t)(L + 1) * DP + L) * sizeof(float);   // <= 74 KB (D <= 2048, L <= 8)
@@ -430,17 +464,17 @@ int launch_bwd_lt(const float* x0, const float* w, const float* cvec, int L, int
     const size_t lds = wlds > slab ? wlds : slab;
     int rc = set_lds(k_cross_bwd<NPL, LT, true>, lds);
     if (rc != MREC_OK) return rc;
-    k_cross_bwd<NPL, LT, true><<<blocks, BWD_NT, lds, st>>>(x0, w, cvec, L, B, D, dy, dx0, slabs);
+    k_cross_bwd<NPL, LT, true><<<blocks, BWD_NT, lds, st>>>(x0, w, b, L, B, D, dy, dx0, slabs, counters, ntiles);
     return MREC_OK;
 }
 
 template <int NPL>
-int launch_bwd(const float* x0, const float* w, const float* cvec, int L, int64_t B, int D, const float* dy, float* dx0,
-               float* slabs, unsigned blocks, hipStream_t st) {
-    if (L <= 2) return launch_bwd_lt<NPL, 2>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st);
-    if (L <= 4) return launch_bwd_lt<NPL, 4>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st);
-    if (L <= 6) return launch_bwd_lt<NPL, 6>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st);
-    return launch_bwd_lt<NPL, 8>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st);
+int launch_bwd(const float* x0, const float* w, const float* b, int L, int64_t B, int D, const float* dy, float* dx0,
+               float* slabs, unsigned blocks, int* counters, int ntiles, hipStream_t st) {
+    if (L <= 2) return launch_bwd_lt<NPL, 2>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st);
+    if (L <= 4) return launch_bwd_lt<NPL, 4>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st);
+    if (L <= 6) return launch_bwd_lt<NPL, 6>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st);
+    return launch_bwd_lt<NPL, 8>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st);
 }
 }  // namespace
 
@@ -461,7 +495,8 @@ MREC_API int mrec_cross_layers_f32(const float* x0, const float* w, const float*
 
 MREC_API int mrec_cross_layers_bwd_workspace_bytes(int32_t L, int64_t B, int32_t D, size_t* out) {
     if (!out || B < 0 || D <= 0 || L < 0) return MREC_EINVAL;
-    *out = ((size_t)bwd_blocks(B) + 1) * slab_floats(D) * sizeof(float) + 512;   // block slabs + the reduced slab + pair dots
+    // block slabs + the reduced slab + a completion counter per 32-column tile
+    *out = ((size_t)bwd_blocks(B) + 1) * slab_floats(D) * sizeof(float) + (size_t)mrec_cdiv(D, 32) * sizeof(int) + 256;
     return MREC_OK;
 }
 
@@ -475,27 +510,25 @@ MREC_API int mrec_cross_layers_bwd_f32(const float* x0, const float* w, const fl
     if (npl < 0) return MREC_EUNSUPPORTED;
     const unsigned blocks = bwd_blocks(B);
     const int nslabs = (int)blocks;
-    if (ws_bytes < (((size_t)nslabs + 1) * slab_floats(D) + LMAX * LMAX) * sizeof(float)) return MREC_EWORKSPACE;
+    const int ntiles = (int)mrec_cdiv(D, 32);
+    if (ws_bytes < ((size_t)nslabs + 1) * slab_floats(D) * sizeof(float) + (size_t)ntiles * sizeof(int)) return MREC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* slabs = (float*)ws;
     float* R = slabs + (int64_t)nslabs * slab_floats(D);
-    float* cvec = R + slab_floats(D);                       // LMAX*LMAX pair dots in the workspace's 256-byte tail
-    if (L > 0) k_cross_beta_dot<<<(unsigned)(L * L), 256, 0, st>>>(w, b, L, D, cvec);
+    int* counters = (int*)(R + slab_floats(D));
     int rc = MREC_OK;
     // the backward's register-heavy instantiations use coarser column buckets (compile time)
     const int nb = npl <= 4 ? 4 : (npl <= 8 ? 8 : (npl <= 16 ? 16 : (npl <= 20 ? 20 : 32)));
     switch (nb) {
-        case 4: rc = launch_bwd<4>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st); break;
-        case 8: rc = launch_bwd<8>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st); break;
-        case 16: rc = launch_bwd<16>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st); break;
-        case 20: rc = launch_bwd<20>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st); break;
-        default: rc = launch_bwd<32>(x0, w, cvec, L, B, D, dy, dx0, slabs, blocks, st); break;
+        case 4: rc = launch_bwd<4>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st); break;
+        case 8: rc = launch_bwd<8>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st); break;
+        case 16: rc = launch_bwd<16>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st); break;
+        case 20: rc = launch_bwd<20>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st); break;
+        default: rc = launch_bwd<32>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st); break;
     }
     if (rc != MREC_OK) return rc;
-    if (L > 0) {
-        k_cross_bwd_sum<<<dim3((unsigned)mrec_cdiv(D, 32), (unsigned)(L + 2)), 1024, 0, st>>>(slabs, nslabs, L, D, R);
-        k_cross_bwd_compose<<<(unsigned)mrec_cdiv(D, 256), 256, 0, st>>>(R, w, b, L, D, dw, db);
-    }
+    if (L > 0)
+        k_cross_bwd_finish<<<dim3((unsigned)ntiles, (unsigned)(L + 2)), 1024, 0, st>>>(slabs, nslabs, L, D, R, w, b, dw, db, counters);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
