@@ -75,6 +75,10 @@ class WideDeepConfig:
                                    # collectives, the routing kernels and the bucket-size host sync under the previous step's
                                    # applies.  Requires ids / wts to be complete in HBM when train_step is called (bench.py: yes)
     early_wide_grad: bool = True   # shards: the wide branch's row-gradient exchange starts at the head's backward, under the backward GEMMs
+    sparse: bool = True              # False: the reference's DEFAULT mode (default_config.yaml:36, the CPU-runnable configs[0]): the
+                                     # embedding gradients are dense [V, D] tensors, nn.Adam / nn.FTRL visit every row every step
+                                     # and the deep loss carries l2_coef * sum(E^2) / 2 (wide_and_deep.py:337-339,356-360,434-445)
+    l2_coef: float = 8e-5            # default_config.yaml:43
     dynamic_embedding: bool = False  # both tables are hash tables keyed by the raw ids (train_and_eval.py --dynamic_embedding=True,
                                      # wide_and_deep.py:271-274): rows are created on first sight with their default values
     hash_capacity: int = 1 << 22     # rows reserved in HBM for each hash table (dynamic_embedding)
@@ -190,7 +194,9 @@ class WideDeepEngine:
         self._mfma = bool(self._gpu and kernels is None and self._amp is not None and nl >= 2 and D % 4 == 0 and D <= 256
                           and all(d % 8 == 0 for d in dims[:-1]))
         self.tuned_gemms = bool(tuned_gemms and self._gpu and not self._mfma and enable_tuned_gemms())
-        self._fold_wide = bool(cfg.fold_wide and self._mfma and not self._sharded and cfg.fused_state and cfg.host_cache_rows == 0 and D <= 252
+        if not cfg.sparse and (self._sharded or cfg.dynamic_embedding or cfg.host_cache_rows > 0):
+            raise ValueError("sparse=False (dense gradients over the whole table) runs on one GPU with resident dense tables")
+        self._fold_wide = bool(cfg.sparse and cfg.fold_wide and self._mfma and not self._sharded and cfg.fused_state and cfg.host_cache_rows == 0 and D <= 252
                                and self.k.head_supported(dims[nl - 1]))
         with (torch.cuda.device(dev) if self._gpu else contextlib.nullcontext()):
             # deep table + Adam moments, wide table + FTRL accumulators: plain row-major fp32 in HBM
@@ -208,7 +214,7 @@ class WideDeepEngine:
                     ("wide_linear", 1, ("fill", 0.0)), ("pad", 1, ("fill", 0.0))])
                 for name in ("deep", "deep_m", "deep_v", "wide", "wide_accum", "wide_linear"):
                     setattr(self, name, self.hb.cols[name])
-            elif cfg.fused_state:
+            elif cfg.fused_state and cfg.sparse:
                 # ONE row per id: [p(D) | w accum linear pad | m(D) | v(D) | pad], padded to a multiple of 128 bytes (3D + 4 = 244
                 # floats -> 256 floats = 1 KB at D = 80: every row is exactly 8 lines, p + w exactly 3; with 976-byte rows a row
                 # straddles 8.5 lines on average and the lookup 3.5).  The wide weight sits right behind the deep weights (the
@@ -733,7 +739,7 @@ class WideDeepEngine:
             after_head = None
             if self._fold_wide and route is None:
                 wide_done = True             # the wide table's FTRL rides the deep table's apply (train_step)
-            elif plan_early is not None and route is None and cfg.overlap_wide_apply:
+            elif plan_early is not None and route is None and cfg.overlap_wide_apply and cfg.sparse:
                 def after_head(gw_b):
                     # wide FTRL beside the backward GEMMs: needs only the plan (already on the side stream, in order)
                     # and the head's dlogit.  The Mul bprop of wide_mul (:304) is applied as row_scale.
@@ -856,6 +862,63 @@ class WideDeepEngine:
             self._step_graph = None
             return None
 
+    def _tail_dense(self, front, ids, wts):
+        """sparse=False (the reference's default): the gradient of an embedding table is a DENSE [V, D] tensor -- the
+        scatter-add of the row gradients (Gather bprop) plus, for the deep table, l2_coef * E from the L2 term of the deep
+        loss (NetWithLossClass.construct, wide_and_deep.py:356-360) -- and nn.Adam / nn.FTRL (:434-445) update EVERY row
+        every step: moments decay, the L2 pull acts on rows the batch never touched, and FTRL re-derives every wide weight
+        from its accumulators.  O(V * D) per step: the small-vocabulary configuration."""
+        cfg = self.cfg
+        B, Fd = ids.shape
+        D = cfg.emb_dim
+        inv_sens = 1.0 / cfg.sens
+        loss, g_emb, g_wide, plan_early, wide_done, route, early_gw, fused = front
+        ev = self._tick("plan")
+        plan = plan_early if plan_early is not None else self.k.sparse_plan(ids)
+        self._tock(ev)
+        if getattr(self, "_gdeep", None) is None:
+            self._gdeep, self._gwide = torch.empty_like(self.deep), torch.empty_like(self.wide)
+        akw = dict(lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
+                   beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=inv_sens)
+        ev = self._tick("apply_deep")
+        sums = self.k.segment_sum(plan, g_emb.view(B * Fd, D).float(), wts)           # UnsortedSegmentSum of the row gradients
+        self._gdeep.zero_()
+        self.k.scatter_unique_rows_(self._gdeep, plan, sums)
+        # d/dE [l2_coef * sum(E^2) / 2] = l2_coef * E, carried at the loss scale like every other gradient
+        self._gdeep.add_(self.deep * np.float32(cfg.l2_coef * cfg.sens))     # (product rounded, then added: no fused multiply-add)
+        self.k.dense_adam_(self.deep.view(-1), self.deep_m.view(-1), self.deep_v.view(-1), self._gdeep.view(-1), **akw)
+        self._tock(ev)
+        ev = self._tick("apply_wide")
+        gw = (g_wide.view(B, 1) * wts).view(B * Fd, 1)                                # Mul bprop of wide_mul (:304)
+        self._gwide.zero_()
+        self.k.scatter_unique_rows_(self._gwide, plan, self.k.segment_sum(plan, gw, None))
+        self.k.dense_ftrl_(self.wide.view(-1), self.wide_accum.view(-1), self.wide_linear.view(-1), self._gwide.view(-1),
+                           lr=cfg.ftrl_lr, l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=inv_sens)
+        self._tock(ev)
+        ev = self._tick("apply_dense")
+        if fused:
+            self._sum_dw_slabs()
+            self.k.dense_adam_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, **akw)
+            self.dense16_flat.copy_(self.dense_flat.detach())
+            gb = self.dense_grad[2 * (len(self.dims) - 2) + 1].view(1)
+        else:
+            self.k.dense_adam_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, **akw)
+            gb = g_wide.sum().view(1)
+        self.k.dense_ftrl_(self.wide_b, self.wide_b_accum, self.wide_b_linear, gb, lr=cfg.ftrl_lr, l1=cfg.ftrl_l1,
+                           l2=cfg.ftrl_l2, grad_scale=inv_sens)
+        self._tock(ev)
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self.last_plan = plan
+        return loss.detach()
+
+    def deep_loss(self, loss):
+        """The deep optimizer's loss of NetWithLossClass.construct (:356-360): log loss + l2_coef * sum(E^2) / 2 in dense mode,
+        the log loss itself in sparse mode."""
+        if self.cfg.sparse:
+            return loss
+        return loss + self.cfg.l2_coef * 0.5 * float((self.deep.double() ** 2).sum())
+
     def _sum_dw_slabs(self):
         """Weight- and bias-gradient slabs -> the flat gradient buffer (needed only where somebody other than the dense
         Adam reads the summed gradient: the data-parallel all-reduce)."""
@@ -902,6 +965,8 @@ class WideDeepEngine:
         D = cfg.emb_dim
         inv_sens = 1.0 / cfg.sens
         loss, g_emb, g_wide, plan_early, wide_done, route, early_gw, fused = front
+        if not cfg.sparse:
+            return self._tail_dense(front, ids, wts)
         state = None
         if self._dyn:
             state = self._step_state

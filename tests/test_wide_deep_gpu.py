@@ -46,6 +46,38 @@ def test_engine_matches_oracle_engine(dev, oracle, fields, dist_kind):
     assert np.allclose(g.dense_flat.detach().cpu().numpy(), c.dense_flat.detach().numpy(), rtol=1e-4, atol=1e-6)
 
 
+def test_dense_gradient_mode_matches_oracle_engine(dev, oracle):
+    """sparse=False, the reference's default and its CPU-runnable configuration (BASELINE configs[0]: vocab 2 M, dim 16,
+    batch 1024, 39 fields): dense [V, D] embedding gradients with the L2 term, nn.Adam / nn.FTRL over every row.  The engine on
+    the GPU against the same engine driven by the oracle on the CPU: every row moves every step (Adam on l2_coef * E), the
+    untouched wide weights collapse onto FTRL's fixed point, and both sides must agree on all of it."""
+    import _oracle_ops
+    from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
+    cfg = WideDeepConfig(vocab_size=2_000_000, emb_dim=16, field_size=39, batch_size=1024, mlp_dtype="fp32", sparse=False)
+    g = WideDeepEngine(cfg, dev)
+    c = WideDeepEngine(cfg, "cpu", kernels=_oracle_ops)
+    d0 = c.deep.numpy().copy()
+    w0 = c.wide.numpy().copy()
+    untouched = np.ones(cfg.vocab_size, bool)
+    for s in range(3):
+        ids, wts, label = synthetic_batch(cfg, "cpu", "zipf", seed=17 + s)
+        untouched[ids.numpy().reshape(-1)] = False
+        lc = float(c.train_step(ids, wts, label))
+        lg = float(g.train_step(ids.to(dev), wts.to(dev), label.to(dev)))
+        assert abs(lc - lg) <= 1e-5 * max(abs(lc), 1e-3)
+    a, b = g.deep.cpu().numpy(), c.deep.numpy()
+    assert row_rel(a, b) <= 2e-5, row_rel(a, b)
+    assert (np.abs(b - d0).max(axis=1) > 0).all()                    # dense Adam: no row stays where it was
+    assert untouched.sum() > 1_000_000                               # rows that saw only the L2 pull
+    assert np.array_equal(a[untouched], b[untouched])                 # ... and those agree bit for bit
+    aw, bw = g.wide.cpu().numpy(), c.wide.numpy()
+    assert np.abs(aw - bw).max() <= 1e-4 * np.abs(w0).max()
+    assert (bw[untouched] == 0).all() and (w0[untouched] != 0).any()   # dense FTRL re-derives w from linear = 0
+    assert np.allclose(g.dense_flat.detach().cpu().numpy(), c.dense_flat.detach().numpy(), rtol=1e-4, atol=1e-6)
+    dl = g.deep_loss(lg)
+    assert dl > lg and abs((dl - lg) - cfg.l2_coef * 0.5 * float((b.astype(np.float64) ** 2).sum())) <= 1e-6 * dl
+
+
 def test_predict_and_lookup(dev, oracle):
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     cfg = WideDeepConfig(vocab_size=10_000, emb_dim=16, field_size=39, batch_size=64, deep_layer_dim=[32], mlp_dtype="fp32")
