@@ -255,8 +255,12 @@ class WideDeepEngine:
 
             # pad the flat buffers to a multiple of 4 floats: the dense Adam then is one float4 launch (a 1-element tail
             # launch cost 5 us + a gap every step); the pad element is a parameter nobody reads (gradient always 0)
+            # ... plus "Wide_b" in the first element behind them: TrainStepWrap sorts parameters by the case-sensitive test
+            # `"wide" in params.name` (wide_and_deep.py:407-411) and the bias is named "Wide_b" (:161-163), so it belongs to the
+            # DEEP optimizer (Adam), not to FTRL; living in this buffer it is updated by the same dense-Adam launch.
             n_real = sum(int(np.prod(x)) for x in shapes_h + shapes_s)
-            pad = [((-n_real) % 4,)] if n_real % 4 else []
+            pad = [(((-n_real - 1) % 4) + 1,)]
+            self._wb_off = n_real
             self.dense_flat, views = _flat_views(shapes_h + shapes_s + pad, dev)
             views = views[:len(shapes_h + shapes_s)]
             self.dense = interleave(views[:nl - 1], views[nl - 1:])
@@ -280,10 +284,11 @@ class WideDeepEngine:
                 v16 = v16[:len(shapes_h + shapes_s)]
                 flat16.copy_(self.dense_flat.detach())
                 self.dense16_flat, self.dense16 = flat16, interleave(v16[:nl - 1], v16[nl - 1:])
-            self.wide_b = torch.zeros(1, dtype=torch.float32, device=dev)   # "Wide_b", FTRL side
+            self.wide_b = self.dense_flat.detach()[self._wb_off:self._wb_off + 1]       # "Wide_b": a view into the dense buffer
+            self.wide_b_grad = self.dense_grad_flat[self._wb_off:self._wb_off + 1]
             self.k.fill_normal_(self.wide_b.view(1, 1), cfg.seed + 3, cfg.init_sigma)
-            self.wide_b_accum = torch.full_like(self.wide_b, cfg.ftrl_initial_accum)
-            self.wide_b_linear = torch.zeros_like(self.wide_b)
+            if self.dense16 is not None:
+                self.dense16_flat.copy_(self.dense_flat.detach())
         self._hashed = bool(cfg.dynamic_embedding)
         self._recv_plan = None        # shards with a host-backed table: the plan of the received keys (made by the cache tier)
         self.beta1, self.beta2 = np.float32(0.9), np.float32(0.999)
@@ -896,16 +901,15 @@ class WideDeepEngine:
                            lr=cfg.ftrl_lr, l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=inv_sens)
         self._tock(ev)
         ev = self._tick("apply_dense")
+        # d loss / d Wide_b = sum of dlogit (= the output layer's bias gradient), into Wide_b's slot of the dense gradient
         if fused:
             self._sum_dw_slabs()
-            self.k.dense_adam_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, **akw)
-            self.dense16_flat.copy_(self.dense_flat.detach())
-            gb = self.dense_grad[2 * (len(self.dims) - 2) + 1].view(1)
+            self.wide_b_grad.copy_(self.dense_grad[2 * (len(self.dims) - 2) + 1].view(1))
         else:
-            self.k.dense_adam_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, **akw)
-            gb = g_wide.sum().view(1)
-        self.k.dense_ftrl_(self.wide_b, self.wide_b_accum, self.wide_b_linear, gb, lr=cfg.ftrl_lr, l1=cfg.ftrl_l1,
-                           l2=cfg.ftrl_l2, grad_scale=inv_sens)
+            self.wide_b_grad.copy_(g_wide.sum().view(1))
+        self.k.dense_adam_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, **akw)
+        if fused:
+            self.dense16_flat.copy_(self.dense_flat.detach())
         self._tock(ev)
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
@@ -1048,8 +1052,8 @@ class WideDeepEngine:
                 torch.cuda.current_stream().wait_stream(self._side)
             if fused:
                 self._sum_dw_slabs()
-            self.dense_grad_ext[-1:].copy_(gb)
-            dense_work = self.comm.all_reduce(self.dense_grad_ext, async_op=True)
+            self.wide_b_grad.copy_(gb)                 # rides the same all-reduce, in Wide_b's slot of the dense gradient
+            dense_work = self.comm.all_reduce(self.dense_grad_flat, async_op=True)
             self._tock(ev)
             ev = self._tick("plan")
             plan = plan_early if plan_early is not None else self.k.sparse_plan(recv_local)
@@ -1074,14 +1078,15 @@ class WideDeepEngine:
             if dense_work is not None:
                 dense_work.wait()                     # the current stream waits for RCCL's stream; no host block
             if self.world > 1:
-                self.dense_grad_ext.div_(self.world)  # gradients_mean=True (train_and_eval_distribute.py:137)
-            gb = self.dense_grad_ext[-1:]
+                self.dense_grad_flat.div_(self.world)  # gradients_mean=True (train_and_eval_distribute.py:137)
         if self._side is not None and not self._dyn:          # (folded one-GPU step: nothing was queued on the side stream since
             torch.cuda.current_stream().wait_stream(self._side)   # the front joined it, and a join costs ~6 us inside a graph)
         ev = self._tick("apply_dense")
         akw = dict(lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
                    beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=inv_sens)
         flat = self.dense_flat.detach()
+        if not self._sharded:
+            self.wide_b_grad.copy_(gb)                     # Wide_b's slot of the dense gradient (updated by the Adam below)
         if fused:
             # one GPU: the weight gradients stay fp32 batch slabs and are added up inside the Adam kernel (nobody else
             # needs the sums); shards: they were summed for the all-reduce above.  Either way the kernel also refreshes
@@ -1092,8 +1097,6 @@ class WideDeepEngine:
                                      shadow16=self.dense16_flat, step_state=state, **akw)
         else:
             self.k.dense_adam_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, **akw)
-        self.k.dense_ftrl_(self.wide_b, self.wide_b_accum, self.wide_b_linear, gb, lr=cfg.ftrl_lr, l1=cfg.ftrl_l1,
-                        l2=cfg.ftrl_l2, grad_scale=inv_sens)
         self._tock(ev)
         if self._side is not None and not self._dyn:
             torch.cuda.current_stream().wait_stream(self._side)
@@ -1112,8 +1115,7 @@ def _engine_state(eng):
                  "beta1_power": float(eng.beta1_power), "beta2_power": float(eng.beta2_power)},
         "tables": {"deep": eng.deep, "deep_m": eng.deep_m, "deep_v": eng.deep_v, "wide": eng.wide,
                    "wide_accum": eng.wide_accum, "wide_linear": eng.wide_linear},
-        "dense": {"dense": eng.dense_flat.detach(), "dense_m": eng.dense_m, "dense_v": eng.dense_v, "wide_b": eng.wide_b,
-                  "wide_b_accum": eng.wide_b_accum, "wide_b_linear": eng.wide_b_linear},
+        "dense": {"dense": eng.dense_flat.detach(), "dense_m": eng.dense_m, "dense_v": eng.dense_v, "wide_b": eng.wide_b},
     }
 
 

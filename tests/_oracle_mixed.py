@@ -33,7 +33,8 @@ class OracleMixedEngine:
         shapes_h = [(dims[i], dims[i + 1]) for i in range(nl - 1)]
         shapes_s = [(dims[i + 1],) for i in range(nl - 1)] + [(dims[nl - 1], dims[nl]), (dims[nl],)]
         n_real = sum(int(np.prod(s)) for s in shapes_h + shapes_s)
-        n = n_real + ((-n_real) % 4)
+        n = n_real + ((-n_real - 1) % 4) + 1          # + "Wide_b" right behind the net's parameters, then padding to 4
+        self._wb_off = n_real
         self.flat = np.zeros(n, np.float32)
         self.flat[:] = O.fill_normal(cfg.seed + 2, n, 1, cfg.init_sigma).ravel()          # same keyed init as the engine
         self.m = np.zeros(n, np.float32); self.v = np.zeros(n, np.float32)
@@ -46,8 +47,9 @@ class OracleMixedEngine:
         self.w5 = self.flat[o5[0]: o5[0] + dims[nl - 1]]
         self.b5 = self.flat[offs[2 * (nl - 1) + 1][0]: offs[2 * (nl - 1) + 1][0] + 1]
         self._offs = offs
-        self.wide_b = O.fill_normal(cfg.seed + 3, 1, 1, cfg.init_sigma).ravel().copy()
-        self.wide_b_accum = np.full(1, cfg.ftrl_initial_accum, np.float32); self.wide_b_linear = np.zeros(1, np.float32)
+        # "wide" in "Wide_b" is False (wide_and_deep.py:407-411 is case-sensitive): the bias belongs to the deep optimizer
+        self.wide_b = self.flat[n_real: n_real + 1]
+        self.wide_b[:] = O.fill_normal(cfg.seed + 3, 1, 1, cfg.init_sigma).ravel()
         self.b1p = np.float32(1.0); self.b2p = np.float32(1.0)
 
     def forward_backward(self, ids, wts, label):
@@ -99,11 +101,11 @@ class OracleMixedEngine:
         grad[o: o + s[0]] = r["gw5"].astype(np.float32)
         o, s = self._offs[2 * (nl - 1) + 1]
         grad[o] = np.float32(r["gb5"])
+        grad[self._wb_off] = np.float32(r["gb5"])           # d loss / d Wide_b = sum of dlogit
         self.last_dense_grad = grad
         O.dense_adam(self.flat, self.m, self.v, grad, lr=cfg.adam_lr, eps=cfg.adam_eps, b1_pow=float(self.b1p), b2_pow=float(self.b2p),
                      grad_scale=inv)
-        O.dense_ftrl(self.wide_b, self.wide_b_accum, self.wide_b_linear, np.array([r["gb5"]], np.float32), lr=cfg.ftrl_lr, l1=cfg.ftrl_l1,
-                     l2=cfg.ftrl_l2, grad_scale=inv)
+
 
     def train_step(self, ids, wts, label):
         r = self.forward_backward(ids, wts, label)
