@@ -357,11 +357,13 @@ int mrec_head_fwd_bwd_f16(const uint16_t* h4, const float* w5, const float* b5, 
                           size_t ws_bytes, void* stream);
 
 /* The same head (f16 != 0: IEEE half activations) with the wide branch given as the per-field products of
- * mrec_gather_rows_wide ([B, F, 2] floats: product, pad): wide[b] = (((0 + prod[b,0]) + prod[b,1]) + ...) + *wide_bias. */
+ * mrec_gather_rows_wide ([B, F, 2] floats: product, pad): wide[b] = (((0 + prod[b,0]) + prod[b,1]) + ...) + *wide_bias.
+ * dwide_bias (nullable): receives d loss / d wide_bias = sum of dlogit (the value db5 gets), so that "Wide_b", which the
+ * reference's deep optimizer owns (wide_and_deep.py:407-411), has its gradient in place without a copy. */
 int mrec_head_fwd_bwd_wide(int32_t f16, const uint16_t* h4, const float* w5, const float* b5, const float* wide_prod, int32_t F,
                            const float* wide_bias, const float* label, int64_t B, int32_t K5, float dscale, float* logit,
-                           float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss, void* ws,
-                           size_t ws_bytes, void* stream);
+                           float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* dwide_bias, float* loss,
+                           void* ws, size_t ws_bytes, void* stream);
 
 /* ---- MapParameter key index ---------------------------------------------------------------
  * mindspore.experimental.MapParameter as built by HashEmbeddingLookup

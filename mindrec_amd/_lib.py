@@ -56,7 +56,7 @@ _SIGS = {
     "mrec_step_state_init": [_vp, _f32, _f32, _i64, _vp],
     "mrec_step_advance": [_vp, _f32, _f32, _f32, _vp],
     "mrec_wall_clock_khz": [_vp],
-    "mrec_head_fwd_bwd_wide": [_i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_head_fwd_bwd_wide": [_i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_wide_sum_f32_i32": [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_wide_sum_f32_i64": [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_sparse_apply_workspace_bytes": [_i64, _i32, _szp],

@@ -267,7 +267,8 @@ __global__ __launch_bounds__(MB) void k_head_fwd_bwd(const uint4* __restrict__ h
 
 __global__ __launch_bounds__(MB) void k_head_finish(const float* __restrict__ partial, int nblk, int K5, float inv_B,
                                                     float* __restrict__ dw5, float* __restrict__ db4,
-                                                    float* __restrict__ db5, float* __restrict__ loss) {
+                                                    float* __restrict__ db5, float* __restrict__ loss,
+                                                    float* __restrict__ dwide_b) {
     __shared__ float sm[8][32];
     const int W = 2 * K5 + 2;
     const int c = blockIdx.x * 32 + (threadIdx.x & 31);
@@ -275,8 +276,10 @@ __global__ __launch_bounds__(MB) void k_head_finish(const float* __restrict__ pa
     if ((threadIdx.x >> 5) != 0 || c >= W) return;
     if (c < K5) dw5[c] = s;
     else if (c < 2 * K5) db4[c - K5] = s;
-    else if (c == 2 * K5) *db5 = s;
-    else *loss = s * inv_B;
+    else if (c == 2 * K5) {
+        *db5 = s;
+        if (dwide_b) *dwide_b = s;       // d loss / d Wide_b is the same sum of dlogit
+    } else *loss = s * inv_B;
 }
 
 inline bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
@@ -322,7 +325,7 @@ static int head_impl(bool f16, const uint16_t* h4, const float* w5, const float*
                      const float* label, int64_t B, int32_t K5, float dscale, float* logit,
                      float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
                      void* ws, size_t ws_bytes, void* stream, const float* wprod = nullptr, int F = 0,
-                     const float* wide_bias = nullptr) {
+                     const float* wide_bias = nullptr, float* dwide_b = nullptr) {
     if (B <= 0 || K5 <= 0) return MREC_EINVAL;
     if (wprod && (F <= 0 || !wide_bias)) return MREC_EINVAL;
     if (!h4 || !w5 || !b5 || (!wide && !wprod) || !label || !logit || !dlogit || !dh4 || !dw5 || !db4 || !db5 || !loss || !ws) return MREC_EINVAL;
@@ -340,7 +343,7 @@ static int head_impl(bool f16, const uint16_t* h4, const float* w5, const float*
     else
         k_head_fwd_bwd<false><<<nb, MB, 0, st>>>((const uint4*)h4, w5, b5, wide, label, B, CG, rows_per_block, dscale, logit, dlogit,
                                                  (uint4*)dh4, (float*)ws, wprod, F, wide_bias);
-    k_head_finish<<<(unsigned)mrec_cdiv(2 * K5 + 2, 32), MB, 0, st>>>((const float*)ws, nb, K5, 1.0f / (float)B, dw5, db4, db5, loss);
+    k_head_finish<<<(unsigned)mrec_cdiv(2 * K5 + 2, 32), MB, 0, st>>>((const float*)ws, nb, K5, 1.0f / (float)B, dw5, db4, db5, loss, dwide_b);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -362,8 +365,8 @@ MREC_API int mrec_head_fwd_bwd_f16(const uint16_t* h4, const float* w5, const fl
 /* The same head with the wide branch given as per-field products [B, F] + the wide bias (see include/mrec.h). */
 MREC_API int mrec_head_fwd_bwd_wide(int32_t f16, const uint16_t* h4, const float* w5, const float* b5, const float* wide_prod,
                                     int32_t F, const float* wide_bias, const float* label, int64_t B, int32_t K5, float dscale,
-                                    float* logit, float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
-                                    void* ws, size_t ws_bytes, void* stream) {
+                                    float* logit, float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* dwide_bias,
+                                    float* loss, void* ws, size_t ws_bytes, void* stream) {
     return head_impl(f16 != 0, h4, w5, b5, nullptr, label, B, K5, dscale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes,
-                     stream, wide_prod, F, wide_bias);
+                     stream, wide_prod, F, wide_bias, dwide_bias);
 }

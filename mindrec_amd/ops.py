@@ -817,7 +817,7 @@ def head_fwd_bwd(h4, w5, b5, wide, label, dscale, dw5_out, db4_out, db5_out):
     return loss, logit, dlogit, dh4
 
 
-def head_fwd_bwd_wide(h4, w5, b5, wide_prod, wide_bias, label, dscale, dw5_out, db4_out, db5_out):
+def head_fwd_bwd_wide(h4, w5, b5, wide_prod, wide_bias, label, dscale, dw5_out, db4_out, db5_out, dwide_bias_out=None):
     """head_fwd_bwd with the wide branch given as the per-field products of gather_rows_wide ([B, F]) + the wide bias:
     the ReduceSum over the fields (wide_and_deep.py:305-306) happens inside the head, in field order."""
     _need_cuda(h4, w5, b5, wide_prod, wide_bias, label)
@@ -836,7 +836,7 @@ def head_fwd_bwd_wide(h4, w5, b5, wide_prod, wide_bias, label, dscale, dw5_out, 
     ws = workspace("head", nb, dev)
     _lib.call("mrec_head_fwd_bwd_wide", int(h4.dtype == torch.float16), _ptr(h4.contiguous()), _ptr(w5), _ptr(b5), _ptr(wide_prod),
               wide_prod.shape[1], _ptr(wide_bias), _ptr(label.contiguous()), B, K5, float(dscale), _ptr(logit), _ptr(dlogit),
-              _ptr(dh4), _ptr(dw5_out), _ptr(db4_out), _ptr(db5_out), _ptr(loss), _ptr(ws), ws.numel(), _stream())
+              _ptr(dh4), _ptr(dw5_out), _ptr(db4_out), _ptr(db5_out), _ptr(dwide_bias_out), _ptr(loss), _ptr(ws), ws.numel(), _stream())
     return loss, logit, dlogit, dh4
 
 

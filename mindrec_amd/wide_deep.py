@@ -393,7 +393,8 @@ class WideDeepEngine:
         if isinstance(wide, _WideProd):
             loss, _, dlogit, dh = self.k.head_fwd_bwd_wide(hs[-1], W5.detach().view(-1), b5.detach(), wide.prod, self.wide_b,
                                                             label.view(-1), self.cfg.sens / B, self.dense_grad[2 * (n - 1)].view(-1),
-                                                            self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1])
+                                                            self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1],
+                                                            dwide_bias_out=self.wide_b_grad)
             loss = loss.view(())
         elif self.k.head_supported(K5):
             # output layer + wide/deep add + sigmoid cross-entropy, forward AND backward, one pass over h4
@@ -1085,8 +1086,9 @@ class WideDeepEngine:
         akw = dict(lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
                    beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=inv_sens)
         flat = self.dense_flat.detach()
-        if not self._sharded:
-            self.wide_b_grad.copy_(gb)                     # Wide_b's slot of the dense gradient (updated by the Adam below)
+        if not self._sharded and not (self._fold_wide and fused):
+            self.wide_b_grad.copy_(gb)                     # Wide_b's slot of the dense gradient (updated by the Adam below;
+                                                           # the folded path's head kernel has already written it)
         if fused:
             # one GPU: the weight gradients stay fp32 batch slabs and are added up inside the Adam kernel (nobody else
             # needs the sums); shards: they were summed for the all-reduce above.  Either way the kernel also refreshes

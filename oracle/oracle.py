@@ -13,7 +13,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libmrec_oracle.so")
+# MREC_ORACLE_SANITIZE=1 (tools/sanitize_oracle.sh): the AddressSanitizer + UBSan build of the same source
+_SAN = os.environ.get("MREC_ORACLE_SANITIZE", "") not in ("", "0")
+_TARGET = "libmrec_oracle_san.so" if _SAN else "libmrec_oracle.so"
+_SO = os.path.join(_HERE, _TARGET)
 
 
 def build(force=False):
@@ -21,7 +24,7 @@ def build(force=False):
     if force or not os.path.exists(_SO) or (
         os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO)
     ):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libmrec_oracle.so"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", _TARGET])
     return _SO
 
 
