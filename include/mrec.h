@@ -259,15 +259,6 @@ int mrec_dense_adam_f32(float* p, float* m, float* v, const float* g, int64_t n,
 int mrec_dense_adam_ex_f32(float* p, float* m, float* v, const void* g, int g_is_bf16, uint16_t* shadow_bf16,
                            int64_t n, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
                            float grad_scale, int nesterov, void* stream);
-/* Dense Adam over a flat buffer whose gradient is, for up to 8 segments, still in split-K form: segment q covers
- * elements [starts[q], starts[q]+lens[q]) and its gradient is the sum over s < splits[q] of the bf16 arrays
- * parts[q][s*lens[q] + e] (what the weight-gradient batched GEMMs of the MLP backward leave behind, wide_and_deep.py:
- * 113-133 bprop); every other element reads the fp32 gradient g.  Saves the separate reduction passes.  n, starts,
- * lens multiples of 4; parts / starts / lens / splits are HOST arrays of nseg entries. */
-int mrec_dense_adam_splitk_f32(float* p, float* m, float* v, const float* g, uint16_t* shadow_bf16, int64_t n,
-                               int32_t nseg, const void* const* parts, const int64_t* starts, const int64_t* lens,
-                               const int32_t* splits, float lr, float b1, float b2, float eps, float b1_pow,
-                               float b2_pow, float grad_scale, int nesterov, void* stream);
 /* Dense Adam over a flat buffer whose gradient is, for up to 16 segments, the sum of S fp32 slabs
  * slabs[q][s*lens[q] + e], s < splits[q] (what mrec_dense_bwd_weight_* leaves behind), added in slab order; every other
  * element reads g.  shadow_kind: 0 none, 1 bf16, 2 fp16 -- the 16-bit operand copy of the updated parameters
@@ -331,13 +322,6 @@ int mrec_dense_bwd_f16(const uint16_t* dy, int64_t lddy, const uint16_t* w, cons
  * mrec_dense_adam_slabs_f32 (the data-parallel all-reduce).  len % 4 == 0, 16-byte aligned. */
 int mrec_dense_sum_slabs_f32(const float* slabs, int32_t S, int64_t len, float* out, void* stream);
 
-/* ---- elementwise ends of the dense net (bf16 training step) ---------------------------------
- * ReLU bprop + BiasAdd bprop of one DenseLayer (wide_and_deep.py:113-133) in one pass:
- *   dh[b, c] = h[b, c] > 0 ? g[b, c] : 0      db[c] = sum_b dh[b, c]
- * g, h, dh are [B, N] bf16 (16-byte aligned), db is [N] fp32.  N / 8 must be a power of two <= 256. */
-int mrec_relu_bwd_colsum_workspace_bytes(int64_t B, int32_t N, size_t* out);
-int mrec_relu_bwd_colsum_bf16(const uint16_t* g, const uint16_t* h, int64_t B, int32_t N, uint16_t* dh,
-                              float* db, void* ws, size_t ws_bytes, void* stream);
 /* Output head of Wide&Deep, forward and backward in one pass over the last hidden activations h4
  * [B, K5] bf16: dense_layer_5 (K5 -> 1, fp32 weights w5[K5], b5), out = wide + deep (:315),
  * SigmoidCrossEntropyWithLogits + ReduceMean (:352-354), and their bprops seeded with dscale

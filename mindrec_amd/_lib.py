@@ -80,8 +80,6 @@ _SIGS = {
                                  _f32, _f32, _f32, _f32, _f32, _vp, _sz, _vp],
     "mrec_dense_adam_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp],
     "mrec_dense_adam_ex_f32": [_vp, _vp, _vp, _vp, _int, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp],
-    "mrec_dense_adam_splitk_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32,
-                                   _f32, _int, _vp],
     "mrec_dense_adam_slabs_f32": [_vp, _vp, _vp, _vp, _vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32,
                                   _f32, _int, _vp, _vp],
     "mrec_dense_fwd_bf16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp],
@@ -97,8 +95,6 @@ _SIGS = {
     "mrec_dense_sum_slabs_f32": [_vp, _i32, _i64, _vp, _vp],
     "mrec_dense_bwd_weight_f16": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp],
     "mrec_dense_ftrl_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp],
-    "mrec_relu_bwd_colsum_workspace_bytes": [_i64, _i32, _szp],
-    "mrec_relu_bwd_colsum_bf16": [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp],
     "mrec_head_workspace_bytes": [_i64, _i32, _szp],
     "mrec_head_fwd_bwd_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_head_fwd_bwd_f16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],

@@ -323,50 +323,6 @@ __global__ __launch_bounds__(256) void k_dense_adam4_g16(float4* __restrict__ p,
     }
 }
 
-// Dense Adam whose gradient is, for up to 8 segments of the flat buffer, still in split-K form: S bf16 partial
-// products [S, len] per segment (what the weight-gradient batched GEMMs leave behind).  The partials are widened and
-// added in s order here, so the separate reduction passes over them disappear; elements outside the segments read
-// the fp32 gradient buffer as usual.  All offsets in float4 units.
-struct SplitSegs {
-    const uint2* part[8];
-    int64_t start4[8], len4[8];
-    int S[8];
-    int n;
-};
-
-template <bool SH>
-__global__ __launch_bounds__(256) void k_dense_adam4_splitk(float4* __restrict__ p, float4* __restrict__ m,
-                                                            float4* __restrict__ v, const float4* __restrict__ g,
-                                                            int64_t n4, AdamH h, uint2* __restrict__ shadow, SplitSegs sg) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 pp = p[i], mm = m[i], vv = v[i];
-        float4 gg;
-        int k = -1;
-        for (int q = 0; q < sg.n; ++q)
-            if (i >= sg.start4[q] && i < sg.start4[q] + sg.len4[q]) k = q;
-        if (k >= 0) {
-            const uint2* src = sg.part[k] + (i - sg.start4[k]);
-            gg = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int s = 0; s < sg.S[k]; ++s) {
-                const uint2 u = src[(int64_t)s * sg.len4[k]];
-                gg.x += __uint_as_float(u.x << 16);
-                gg.y += __uint_as_float(u.x & 0xFFFF0000u);
-                gg.z += __uint_as_float(u.y << 16);
-                gg.w += __uint_as_float(u.y & 0xFFFF0000u);
-            }
-        } else {
-            gg = g[i];
-        }
-        adam_elem(pp.x, mm.x, vv.x, gg.x * h.gscale, h);
-        adam_elem(pp.y, mm.y, vv.y, gg.y * h.gscale, h);
-        adam_elem(pp.z, mm.z, vv.z, gg.z * h.gscale, h);
-        adam_elem(pp.w, mm.w, vv.w, gg.w * h.gscale, h);
-        p[i] = pp; m[i] = mm; v[i] = vv;
-        if (SH) shadow[i] = make_uint2((unsigned)f2bf(pp.x) | ((unsigned)f2bf(pp.y) << 16),
-                                       (unsigned)f2bf(pp.z) | ((unsigned)f2bf(pp.w) << 16));
-    }
-}
-
 // The same, for the hand-written MFMA weight-gradient kernel (mrec_dense.hip): its split slabs are fp32 partial
 // sums (never rounded), added here in slab order.  SHK: 0 = no shadow, 1 = bf16 shadow, 2 = fp16 shadow.
 struct SlabSegs {
@@ -732,38 +688,6 @@ MREC_API int mrec_dense_adam_ex_f32(float* p, float* m, float* v, const void* g,
                                     float grad_scale, int nesterov, void* stream) {
     return dense_adam_launch(p, m, v, g, g_is_bf16, shadow_bf16, n, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale, nesterov,
                              stream);
-}
-
-MREC_API int mrec_dense_adam_splitk_f32(float* p, float* m, float* v, const float* g, uint16_t* shadow_bf16, int64_t n,
-                                        int32_t nseg, const void* const* parts, const int64_t* starts, const int64_t* lens,
-                                        const int32_t* splits, float lr, float b1, float b2, float eps, float b1_pow,
-                                        float b2_pow, float grad_scale, int nesterov, void* stream) {
-    if (n < 0 || nseg < 0 || nseg > 8) return MREC_EINVAL;
-    if (n == 0) return MREC_OK;
-    if (!p || !m || !v || !g || (nseg > 0 && (!parts || !starts || !lens || !splits))) return MREC_EINVAL;
-    if (n % 4 || !al16(p) || !al16(m) || !al16(v) || !al16(g) || (shadow_bf16 && (((uintptr_t)shadow_bf16) & 7)))
-        return MREC_EUNSUPPORTED;                       // the flat buffers are float4-padded by construction
-    SplitSegs sg;
-    sg.n = nseg;
-    for (int q = 0; q < nseg; ++q) {
-        if (!parts[q] || starts[q] < 0 || lens[q] <= 0 || starts[q] % 4 || lens[q] % 4 || starts[q] + lens[q] > n ||
-            splits[q] <= 0 || (((uintptr_t)parts[q]) & 7))
-            return MREC_EINVAL;
-        sg.part[q] = (const uint2*)parts[q];
-        sg.start4[q] = starts[q] / 4;
-        sg.len4[q] = lens[q] / 4;
-        sg.S[q] = splits[q];
-    }
-    AdamH h;
-    h.lr_t = lr * sqrtf(1.0f - b2_pow) / (1.0f - b1_pow);
-    h.b1 = b1; h.b2 = b2; h.omb1 = 1.0f - b1; h.omb2 = 1.0f - b2; h.eps = eps; h.gscale = grad_scale;
-    h.nesterov = nesterov;
-    const int64_t n4 = n / 4;
-    hipStream_t st = (hipStream_t)stream;
-    if (shadow_bf16) k_dense_adam4_splitk<true><<<stream_grid(n4), 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow_bf16, sg);
-    else k_dense_adam4_splitk<false><<<stream_grid(n4), 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, nullptr, sg);
-    MREC_LAUNCH_CHECK();
-    return MREC_OK;
 }
 
 MREC_API int mrec_dense_adam_slabs_f32(float* p, float* m, float* v, const float* g, void* shadow16, int shadow_kind,

@@ -1,19 +1,15 @@
 // mrec_mlp.hip -- the elementwise / reduction ends of the Wide&Deep dense net, fused, for gfx950.
 //
-// The GEMMs of DenseLayer (models/wide_deep/src/wide_and_deep.py:113-133) go to hipBLASLt; what is left
-// around them in a bf16 training step is HBM-bound byte work that MindSpore runs as separate
-// primitives (ReLU bprop, BiasAdd bprop = ReduceSum over the batch, the 128 -> 1 output layer,
-// wide + deep add :315, SigmoidCrossEntropyWithLogits + ReduceMean :352-354 and their bprops).
-// Two kernels cover it:
+// The hidden DenseLayers (models/wide_deep/src/wide_and_deep.py:113-133) run on the matrix cores (mrec_dense.hip; their
+// ReLU / BiasAdd bprops are GEMM epilogues there); what is left is the output end of the net, HBM-bound byte work that
+// MindSpore runs as separate primitives (the 128 -> 1 output layer, wide + deep add :315,
+// SigmoidCrossEntropyWithLogits + ReduceMean :352-354 and their bprops).  One kernel covers it:
 //
-//  k_relu_bwd_colsum : dh = g * (h > 0)  and  db[c] = sum_b dh[b, c]   in one pass over [B, N] bf16
-//                      (ReLU bprop + BiasAdd bprop; the column sum alone cost ~20 us per layer as a
-//                      generic reduce kernel whatever N was).
 //  k_head_fwd_bwd    : logit = h4 . W5 + b5 + wide;  loss terms;  dlogit = (sigmoid(logit) - y) * scale;
 //                      dh4 = dlogit * W5 masked by h4 > 0;  dW5 += h4 * dlogit;  db5 += dlogit
 //                      -- forward AND backward of the output layer and the loss in one pass over h4.
 //
-// Both reduce over the batch with per-block partials written to a workspace and a second tiny kernel
+// It reduces over the batch with per-block partials written to a workspace and a second tiny kernel
 // that adds the partials in block order: bitwise reproducible, no float atomics.
 #include "mrec_common.h"
 
@@ -58,53 +54,6 @@ template <bool F16> __device__ __forceinline__ uint4 pack8t(const float (&f)[8])
 
 constexpr int MB = 256;   // threads per block
 
-// A block walks its stripe of rows; thread t owns column group cg = t % CG (8 adjacent columns) and rows
-// r0 + t / CG + k * RP.  CG = N / 8 must divide 256 (N in {8, 16, ..., 2048} with N/8 a power of two <= 256)
-// -- other widths take the torch path.
-__global__ __launch_bounds__(MB) void k_relu_bwd_colsum(const uint4* __restrict__ g, const uint4* __restrict__ h,
-                                                        int64_t B, int CG, int rows_per_block, uint4* __restrict__ dh,
-                                                        float* __restrict__ partial /*[nblk][N]*/) {
-    __shared__ float red[MB][8];
-    const int cg = threadIdx.x % CG, rl = threadIdx.x / CG, RP = MB / CG;
-    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r_end = (r_begin + rows_per_block < B) ? r_begin + rows_per_block : B;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int64_t r = r_begin + rl; r < r_end; r += 2 * RP) {
-        // two rows in flight per thread
-        const int64_t ra = r, rb = r + RP;
-        const bool vb = rb < r_end;
-        const uint4 ga = g[ra * CG + cg], ha = h[ra * CG + cg];
-        uint4 gb = make_uint4(0, 0, 0, 0), hb = make_uint4(0, 0, 0, 0);
-        if (vb) { gb = g[rb * CG + cg]; hb = h[rb * CG + cg]; }
-        float fg[8], fh[8], o[8];
-        unpack8(ga, fg); unpack8(ha, fh);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { o[k] = fh[k] > 0.0f ? fg[k] : 0.0f; acc[k] += o[k]; }
-        dh[ra * CG + cg] = pack8(o);
-        if (vb) {
-            unpack8(gb, fg); unpack8(hb, fh);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { o[k] = fh[k] > 0.0f ? fg[k] : 0.0f; acc[k] += o[k]; }
-            dh[rb * CG + cg] = pack8(o);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = acc[k];
-    __syncthreads();
-    if (rl == 0) {   // threads 0..CG-1: add the RP row-lanes of their column group in lane order
-        float s[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s[k] = red[cg][k];
-        for (int q = 1; q < RP; ++q) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s[k] += red[q * CG + cg][k];
-        }
-        float* p = partial + (int64_t)blockIdx.x * (CG * 8) + cg * 8;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) p[k] = s[k];
-    }
-}
-
 // out[c] = sum over blocks of partial[blk][c] in a fixed order.  A block owns 32 adjacent columns and
 // splits the partial rows over 8 row-groups; every thread keeps 8 independent loads in flight (a single
 // thread walking 512 partials serially paid a memory round trip per partial: 117 us for this "tiny" step).
@@ -133,14 +82,6 @@ __device__ __forceinline__ float finish_column(const float* __restrict__ partial
         for (int k = 0; k < 8; ++k) tot += sm[k][cx];
     }
     return tot;   // valid for ry == 0
-}
-
-__global__ __launch_bounds__(MB) void k_colsum_finish(const float* __restrict__ partial, int nblk, int N,
-                                                      float* __restrict__ out) {
-    __shared__ float sm[8][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    const float tot = finish_column(partial, nblk, N, c, sm);
-    if ((threadIdx.x >> 5) == 0 && c < N) out[c] = tot;
 }
 
 // Output head.  K5 = width of the last hidden layer (multiple of 8, K5/8 a power of two <= 64).
@@ -290,30 +231,6 @@ inline int pick_blocks(int64_t B, int RP) {
 }
 
 }  // namespace
-
-MREC_API int mrec_relu_bwd_colsum_workspace_bytes(int64_t B, int32_t N, size_t* out) {
-    if (!out || B < 0 || N <= 0) return MREC_EINVAL;
-    *out = (size_t)512 * N * sizeof(float) + 256;
-    return MREC_OK;
-}
-
-MREC_API int mrec_relu_bwd_colsum_bf16(const uint16_t* g, const uint16_t* h, int64_t B, int32_t N, uint16_t* dh,
-                                       float* db, void* ws, size_t ws_bytes, void* stream) {
-    if (B <= 0 || N <= 0) return MREC_EINVAL;
-    if (!g || !h || !dh || !db || !ws) return MREC_EINVAL;
-    if (N % 8 || !pow2(N / 8) || N / 8 > MB) return MREC_EUNSUPPORTED;
-    if ((((uintptr_t)g | (uintptr_t)h | (uintptr_t)dh) & 15) != 0) return MREC_EINVAL;
-    const int CG = N / 8, RP = MB / CG;
-    const int nblk = pick_blocks(B, RP);
-    if (ws_bytes < (size_t)nblk * N * sizeof(float)) return MREC_EWORKSPACE;
-    const int rows_per_block = (int)mrec_cdiv(mrec_cdiv(B, nblk), 2 * RP) * 2 * RP;
-    const int nb = (int)mrec_cdiv(B, rows_per_block);
-    hipStream_t st = (hipStream_t)stream;
-    k_relu_bwd_colsum<<<nb, MB, 0, st>>>((const uint4*)g, (const uint4*)h, B, CG, rows_per_block, (uint4*)dh, (float*)ws);
-    k_colsum_finish<<<(unsigned)mrec_cdiv(N, 32), MB, 0, st>>>((const float*)ws, nb, N, db);
-    MREC_LAUNCH_CHECK();
-    return MREC_OK;
-}
 
 MREC_API int mrec_head_workspace_bytes(int64_t B, int32_t K5, size_t* out) {
     if (!out || B < 0 || K5 <= 0) return MREC_EINVAL;

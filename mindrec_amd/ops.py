@@ -376,32 +376,6 @@ def dense_adam_(p, m, v, g, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, beta1_p
               _stream())
 
 
-def dense_adam_splitk_(p, m, v, g, parts, shadow_bf16=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, beta1_power=0.9,
-                       beta2_power=0.999, grad_scale=1.0, use_nesterov=False):
-    """dense_adam_ whose gradient is still in split-K form for some segments: parts = [(start, partials [S, len] bf16)],
-    start = element offset of the segment in the flat buffers.  The partials are summed inside the Adam kernel."""
-    _need_cuda(p, m, v, g)
-    n = p.numel()
-    if n % 4:
-        raise ValueError("dense_adam_splitk_ needs flat buffers padded to a multiple of 4 elements")
-    k = len(parts)
-    if k > 8:
-        raise ValueError("at most 8 split-K segments")
-    ptrs = (C.c_void_p * max(k, 1))()
-    starts = (C.c_int64 * max(k, 1))()
-    lens = (C.c_int64 * max(k, 1))()
-    splits = (C.c_int32 * max(k, 1))()
-    keep = []
-    for q, (start, part) in enumerate(parts):
-        if part.dtype != torch.bfloat16 or not part.is_contiguous():
-            raise TypeError("split-K partials must be contiguous bfloat16 [S, ...]")
-        keep.append(part)
-        ptrs[q], starts[q], lens[q], splits[q] = part.data_ptr(), int(start), part[0].numel(), part.shape[0]
-    _lib.call("mrec_dense_adam_splitk_f32", _ptr(p), _ptr(m), _ptr(v), _ptr(g), _ptr(shadow_bf16), n, k,
-              C.cast(ptrs, C.c_void_p), C.cast(starts, C.c_void_p), C.cast(lens, C.c_void_p), C.cast(splits, C.c_void_p),
-              lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _stream())
-
-
 def dense_ftrl_(var, accum, linear, g, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):
     """nn.FTRL over a whole tensor (wide_and_deep.py:438-445)."""
     _need_cuda(var, accum, linear, g)
@@ -777,22 +751,6 @@ class KernelTimer:
 
 
 # ---- elementwise ends of the bf16 dense net ----------------------------------------------------
-def relu_bwd_colsum_supported(N):
-    return N % 8 == 0 and (N // 8) & (N // 8 - 1) == 0 and N // 8 <= 256
-
-
-def relu_bwd_colsum(g, h, db_out):
-    """dh = g * (h > 0), db_out[:] = dh.sum(0) in one pass (ReLU bprop + BiasAdd bprop).  g, h bf16 [B, N]."""
-    _need_cuda(g, h, db_out)
-    B, N = h.shape
-    g = g.contiguous(); h = h.contiguous()
-    dh = torch.empty_like(h)
-    nb = _lib.query_bytes("mrec_relu_bwd_colsum_workspace_bytes", B, N)
-    ws = workspace("colsum", nb, h.device)
-    _lib.call("mrec_relu_bwd_colsum_bf16", _ptr(g), _ptr(h), B, N, _ptr(dh), _ptr(db_out), _ptr(ws), ws.numel(), _stream())
-    return dh
-
-
 def head_supported(K5):
     return K5 % 8 == 0 and (K5 // 8) & (K5 // 8 - 1) == 0 and K5 // 8 <= 64
 

@@ -514,52 +514,6 @@ def test_dense_adam_bf16_grad_and_shadow(dev, oracle):
         assert torch.equal(sh.cpu().view(torch.int16), torch.from_numpy(p).to(torch.bfloat16).view(torch.int16))
 
 
-def test_dense_adam_splitk_segments(dev, oracle):
-    """Dense Adam whose gradient is partly still split-K partials: bit-exact against the oracle's dense Adam fed the
-    partials added in s order in fp32 (that is the order the kernel uses), other elements from the fp32 gradient."""
-    from mindrec_amd import ops
-    rng = np.random.default_rng(11)
-    n = 4096 + 8192 + 400                      # two segments and a plain fp32 tail; all multiples of 4
-    p = (rng.standard_normal(n) * 0.01).astype(np.float32)
-    m = (rng.standard_normal(n) * 0.001).astype(np.float32)
-    v = (rng.random(n) * 1e-4).astype(np.float32)
-    g = rng.standard_normal(n).astype(np.float32)
-    segs = [(0, 8, 4096), (4096 + 400, 3, 8192 - 400)]      # (start, S, len); the gap in between reads g
-    parts, gref = [], g.copy()
-    for start, S, ln in segs:
-        pt = torch.from_numpy(rng.standard_normal((S, ln)).astype(np.float32)).to(torch.bfloat16)
-        parts.append((start, pt.to(dev)))
-        acc = np.zeros(ln, np.float32)
-        for s in range(S):
-            acc = acc + pt[s].float().numpy()
-        gref[start:start + ln] = acc
-    tp, tm, tv = T(p, dev), T(m, dev), T(v, dev)
-    sh = torch.zeros(n, dtype=torch.bfloat16, device=dev)
-    kw = dict(lr=3.5e-4, beta1_power=0.9 ** 3, beta2_power=0.999 ** 3, grad_scale=1 / 1024)
-    ops.dense_adam_splitk_(tp, tm, tv, T(g, dev), parts, shadow_bf16=sh, **kw)
-    oracle.dense_adam(p, m, v, gref, lr=3.5e-4, b1_pow=0.9 ** 3, b2_pow=0.999 ** 3, grad_scale=1 / 1024)
-    assert np.array_equal(tp.cpu().numpy(), p) and np.array_equal(tm.cpu().numpy(), m) and np.array_equal(tv.cpu().numpy(), v)
-    assert torch.equal(sh.cpu().view(torch.int16), torch.from_numpy(p).to(torch.bfloat16).view(torch.int16))
-    # no segments at all = plain dense Adam; a length that is not a multiple of 4 is refused
-    ops.dense_adam_splitk_(tp, tm, tv, T(g, dev), [], **kw)
-    oracle.dense_adam(p, m, v, g, lr=3.5e-4, b1_pow=0.9 ** 3, b2_pow=0.999 ** 3, grad_scale=1 / 1024)
-    assert np.array_equal(tp.cpu().numpy(), p)
-    with pytest.raises(ValueError):
-        ops.dense_adam_splitk_(tp[:-1], tm[:-1], tv[:-1], T(g, dev)[:-1], [])
-
-
-@pytest.mark.parametrize("B,N", [(16384, 1024), (16384, 256), (1000, 128), (37, 8), (5000, 2048)])
-def test_relu_bwd_colsum(dev, oracle, B, N):
-    from mindrec_amd import ops
-    rng = np.random.default_rng(N + B)
-    g = torch.from_numpy(rng.standard_normal((B, N)).astype(np.float32)).to(torch.bfloat16)
-    h = torch.from_numpy(np.maximum(rng.standard_normal((B, N)), 0).astype(np.float32)).to(torch.bfloat16)
-    db = torch.empty(N, dtype=torch.float32, device=dev)
-    dh = ops.relu_bwd_colsum(g.to(dev), h.to(dev), db)
-    rdh, rdb = oracle.relu_bwd_colsum(g.float().numpy(), h.float().numpy())
-    assert torch.equal(dh.cpu().float(), torch.from_numpy(rdh))                 # masking is exact
-    assert np.allclose(db.cpu().numpy(), rdb, rtol=1e-5, atol=1e-3 * np.sqrt(B) * 6e-3 + 1e-4)
-
 
 @pytest.mark.parametrize("B,K5", [(16384, 128), (1000, 64), (77, 8), (4096, 512)])
 def test_head_fwd_bwd(dev, oracle, B, K5):
