@@ -88,6 +88,34 @@ __device__ __forceinline__ void stage_wb(const float* __restrict__ w, const floa
     __syncthreads();
 }
 
+// A lane owns FOUR consecutive columns per 256-column block (columns 256 q + 4 lane + {0..3}): x0, dy and dx0 move as
+// 16-byte buffer accesses (the range check zero-fills / drops the dwords past column D one by one), w comes out of LDS as
+// ds_read_b128, and the arithmetic runs on 2-wide packed fp32 (v_pk_fma_f32) -- a quarter of the memory and LDS instructions
+// and half of the FMAs of a one-column-per-lane layout, which was what bound this kernel (issue slots, two waves per SIMD).
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 row_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void row_store4(__amdgpu_buffer_rsrc_t r, int voff, int soff, f4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ f4 fma4(f4 a, f4 b, f4 c) {
+    const f2 lo = __builtin_elementwise_fma(a.lo, b.lo, c.lo), hi = __builtin_elementwise_fma(a.hi, b.hi, c.hi);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f4 bc4(float u) { return f4{u, u, u, u}; }
+__device__ __forceinline__ float hsum4(f4 v) { return (v.x + v.y) + (v.z + v.w); }
+
+
+// forward, 4 columns per lane (NPL a multiple of 4: every D > 128): 16-byte row accesses, ds_read_b128 for w and b, packed
+// fp32 arithmetic; the update keeps the oracle's operation order (x * s + b, then + x_l; no fused multiply-add)
+template <bool WLDS>
+__device__ __forceinline__ f4 wload4(const float* __restrict__ g, const float* s, int l, int lane, int q, int D, int DP) {
+    if (WLDS) return *(const f4*)(s + l * DP + 256 * q + 4 * lane);
+    return row_load4(row_rsrc(g + (int64_t)l * D, D * 4), lane * 16, q * 1024);
+}
 constexpr int FWD_NT = 1024;   // 16 waves: one block per CU, w / b staged once per CU
 constexpr int BWD_NT = 512;   // 8 waves: one block per CU at two waves per SIMD -> one slab per CU for the reduction kernel
 
@@ -144,6 +172,60 @@ __global__ __launch_bounds__(FWD_NT) void k_cross_fwd(const float* __restrict__ 
     }
 }
 
+template <int NPL, bool WLDS>
+__global__ __launch_bounds__(FWD_NT) void k_cross_fwd4(const float* __restrict__ x0, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int L, int64_t B, int D,
+                                                       float* __restrict__ out) {
+    static_assert(NPL % 4 == 0, "256-column blocks");
+    constexpr int DP = NPL * 64, NQ = NPL / 4;
+    extern __shared__ float smem[];
+    float* sw = smem;
+    float* sb = smem + (WLDS ? L * DP : 0);
+    if (WLDS) stage_wb<FWD_NT, DP>(w, b, L, D, sw, sb);
+    const int lane = threadIdx.x & 63;
+    const int voff = lane * 16;
+    constexpr int WPB = FWD_NT / 64;
+    const int64_t nw = (int64_t)gridDim.x * WPB;
+    // two rows per wave per iteration: one LDS read of w / b serves both
+    for (int64_t rowA = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); rowA < B; rowA += 2 * nw) {
+        const int64_t rowB = rowA + nw;
+        const bool vB = rowB < B;
+        f4 xA[NQ], lA[NQ], xB[NQ], lB[NQ];
+        const __amdgpu_buffer_rsrc_t rA = row_rsrc(x0 + rowA * D, D * 4);
+        const __amdgpu_buffer_rsrc_t rB = row_rsrc(x0 + (vB ? rowB : rowA) * D, vB ? D * 4 : 0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            xA[q] = row_load4(rA, voff, 1024 * q);
+            xB[q] = row_load4(rB, voff, 1024 * q);
+            lA[q] = xA[q];
+            lB[q] = xB[q];
+        }
+        for (int l = 0; l < L; ++l) {
+            f4 pA = bc4(0.0f), pB = bc4(0.0f);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const f4 wv = wload4<WLDS>(w, sw, l, lane, q, D, DP);
+                pA += lA[q] * wv;
+                pB += lB[q] * wv;
+            }
+            const f4 sA = bc4(wave_sum(hsum4(pA))), sB = bc4(wave_sum(hsum4(pB)));
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const f4 bv = wload4<WLDS>(b, sb, l, lane, q, D, DP);
+                lA[q] = (xA[q] * sA + bv) + lA[q];
+                lB[q] = (xB[q] * sB + bv) + lB[q];
+            }
+        }
+        const __amdgpu_buffer_rsrc_t oA = row_rsrc(out + rowA * D, D * 4);
+        const __amdgpu_buffer_rsrc_t oB = row_rsrc(out + (vB ? rowB : rowA) * D, vB ? D * 4 : 0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            row_store4(oA, voff, 1024 * q, lA[q]);
+            row_store4(oB, voff, 1024 * q, lB[q]);
+        }
+    }
+}
+
 // slab layout per block: [LMAX][D] sums of u_l*x0, then [D] colsum(dy), then [LMAX] sums of t_l.
 __host__ __device__ inline int64_t slab_floats(int D) { return (int64_t)(LMAX + 1) * D + LMAX; }
 
@@ -157,26 +239,6 @@ constexpr int bwd_occ(int npl, int lt) { return (lt + 3) * npl <= 180 ? 2 : 1; }
 // reductions overlap): with x_l = a_l x0 + beta_l,  s_l = x_l . w_l = a_l P_l + c_l,  a_{l+1} = a_l + s_l.
 // x_l itself is never rebuilt, b is not read at all; fmaf is used freely -- this kernel is checked against
 // the oracle's double-precision backward to a tolerance, not bit for bit.
-// A lane owns FOUR consecutive columns per 256-column block (columns 256 q + 4 lane + {0..3}): x0, dy and dx0 move as
-// 16-byte buffer accesses (the range check zero-fills / drops the dwords past column D one by one), w comes out of LDS as
-// ds_read_b128, and the arithmetic runs on 2-wide packed fp32 (v_pk_fma_f32) -- a quarter of the memory and LDS instructions
-// and half of the FMAs of a one-column-per-lane layout, which was what bound this kernel (issue slots, two waves per SIMD).
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef unsigned u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f4 row_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ void row_store4(__amdgpu_buffer_rsrc_t r, int voff, int soff, f4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff, soff, 0);
-}
-__device__ __forceinline__ f4 fma4(f4 a, f4 b, f4 c) {
-    const f2 lo = __builtin_elementwise_fma(a.lo, b.lo, c.lo), hi = __builtin_elementwise_fma(a.hi, b.hi, c.hi);
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
-}
-__device__ __forceinline__ f4 bc4(float u) { return f4{u, u, u, u}; }
-__device__ __forceinline__ float hsum4(f4 v) { return (v.x + v.y) + (v.z + v.w); }
-
 template <int NPL, int LT, bool WLDS>
 __global__ __launch_bounds__(BWD_NT) __attribute__((amdgpu_waves_per_eu(bwd_occ(NPL, LT), bwd_occ(NPL, LT)))) void k_cross_bwd(const float* __restrict__ x0, const float* __restrict__ w,
                                                       const float* __restrict__ b, int L, int64_t B, int D,
@@ -444,6 +506,16 @@ int launch_fwd(const float* x0, const float* w, const float* b, int L, int64_t B
     const size_t lds = (size_t)2 * L * NPL * 64 * sizeof(float);
     int64_t blocks = mrec_cdiv(B, 2 * (FWD_NT / 64));            // 16 waves x 2 rows per pass
     if (blocks > 256) blocks = 256;
+    if constexpr (NPL % 4 == 0) {
+        if (lds > 0 && lds <= kMaxLds) {
+            int rc = set_lds(k_cross_fwd4<NPL, true>, lds);
+            if (rc != MREC_OK) return rc;
+            k_cross_fwd4<NPL, true><<<(unsigned)blocks, FWD_NT, lds, st>>>(x0, w, b, L, B, D, out);
+        } else {
+            k_cross_fwd4<NPL, false><<<(unsigned)blocks, FWD_NT, 0, st>>>(x0, w, b, L, B, D, out);
+        }
+        return MREC_OK;
+    }
     if (lds > 0 && lds <= kMaxLds) {
         int rc = set_lds(k_cross_fwd<NPL, true>, lds);
         if (rc != MREC_OK) return rc;
