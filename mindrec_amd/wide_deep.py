@@ -710,7 +710,9 @@ class WideDeepEngine:
                     self._rs(t, main)
         emb, wide, route = self.lookup(ids, wts, defer_wide=late)
         if fork_ev is not None:
-            # (forking it behind the output head instead -- beside the backward GEMMs -- was measured: 0.786 vs 0.764 ms)
+            # (forking it behind the output head instead -- beside the backward GEMMs -- was measured: 0.786 vs 0.764 ms;
+            # forking it behind the gather -- which then runs alone -- 0.7576 vs 0.7591 ms: the plan's kernels and whatever
+            # they run beside stretch each other by about the same amount wherever the plan sits)
             self._side.wait_event(fork_ev)
             with torch.cuda.stream(self._side):
                 plan_early = self.k.sparse_plan(ids)
