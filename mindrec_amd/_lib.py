@@ -151,6 +151,10 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(mindrec_amd has no CPU fallback)")
+        # torch first: it ships its own copy of the HIP runtime, and this library must bind to THAT copy (the one whose streams
+        # and allocations it is handed) -- loaded before torch it binds to /opt/rocm's, and the process ends up with two
+        # runtimes (seen as "no usable gfx950 device" from mrec_device_ok)
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, args in _SIGS.items():
             f = getattr(l, name)
