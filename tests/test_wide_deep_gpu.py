@@ -324,6 +324,31 @@ def test_host_cached_tables_engine_equals_resident_engine(dev):
     assert torch.equal(a.dense_flat.detach(), b.dense_flat.detach())
 
 
+def test_host_cached_engine_matches_oracle_engine(dev, oracle):
+    """The cache tier against the ORACLE (not against the resident HIP engine): the engine whose tables live in host DRAM
+    behind a small device cache -- rows evicted, written back and fetched again as the stream moves -- against the engine
+    driven by the oracle on the CPU, which knows nothing of caches."""
+    import _oracle_ops
+    from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
+    kw = dict(vocab_size=40_000, emb_dim=16, field_size=26, batch_size=256, deep_layer_dim=[64, 32], mlp_dtype="fp32")
+    g = WideDeepEngine(WideDeepConfig(host_cache_rows=9000, **kw), dev)
+    c = WideDeepEngine(WideDeepConfig(**kw), "cpu", kernels=_oracle_ops)
+    for s in range(8):
+        ids, wts, label = synthetic_batch(c.cfg, "cpu", "uniform" if s % 2 else "zipf", seed=300 + s)
+        lc = float(c.train_step(ids, wts, label))
+        lg = float(g.train_step(ids.to(dev), wts.to(dev), label.to(dev)))
+        assert abs(lc - lg) <= 1e-5 * max(abs(lc), 1e-3), (s, lc, lg)
+    st = g.hb.stats
+    assert st["evictions"] > 0 and st["hits"] > 0 and st["misses"] > 9000
+    full = g.hb.full_table().numpy()                                   # [V, 3D + 4]: p | m | v | w accum linear pad
+    D = 16
+    assert row_rel(full[:, :D], c.deep.numpy()) <= 2e-5
+    assert np.abs(full[:, 3 * D] - c.wide.numpy()[:, 0]).max() <= 1e-4 * np.abs(c.wide.numpy()).max()
+    untouched = (c.deep_m.numpy() == 0).all(axis=1)
+    assert np.array_equal(full[untouched, :D], c.deep.numpy()[untouched])
+    assert np.allclose(g.dense_flat.detach().cpu().numpy(), c.dense_flat.detach().numpy(), rtol=1e-4, atol=1e-6)
+
+
 def test_hash_tables_behind_the_host_cache_equal_resident_hash_tables(dev):
     """dynamic_embedding + host_cache_rows (BASELINE configs[4]: MapParameter tables larger than HBM): keys -> host rows by
     a second device key index, the cache tier below unchanged; trains bit-identically to the resident hash-table engine and
