@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-graph-front", action="store_true", help="one GPU: only the MLP as HIP graphs, lookups / plan issued kernel by kernel")
     ap.add_argument("--no-graph-step", action="store_true", help="one GPU: the front of the step as one HIP graph, the sparse apply and the dense "
                     "optimizers issued kernel by kernel behind it (instead of the whole step as one graph)")
+    ap.add_argument("--shard-protocol", action="store_true", help="one GPU: run the row-shard protocol (routing kernels + RCCL collectives "
+                    "that talk to themselves) -- what a rank of an N-GPU job does besides moving bytes over xGMI")
     ap.add_argument("--no-graph-mlp", action="store_true", help="issue the MLP step kernel by kernel instead of replaying its HIP graph")
     return ap.parse_args()
 
@@ -196,6 +198,11 @@ def main():
         self_launch(args)                   # never returns
     # RCCL / cross-process tensor sharing on this pool needs dmabuf IPC (the driver image exports this already)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1 or args.shard_protocol:
+        # A shard's step lives on several streams (main, the side stream of the request exchange, RCCL's own); with the HIP
+        # runtime's default of 4 hardware queues they collided on one queue and ran back to back: 1.52 -> 1.21 ms per step on
+        # one GPU talking to itself.  (Must be set before the runtime starts; the one-GPU graph path is 0.6 % slower with 8.)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     from mindrec_amd import _lib, ops
@@ -212,8 +219,9 @@ def main():
     rc = _lib.lib().mrec_device_ok()
     if rc != 0:
         raise SystemExit(f"libmrec_hip.so cannot run on this device: {_lib.lib().mrec_strerror(rc).decode()}")
-    if world > 1:
+    if world > 1 or args.shard_protocol:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)          # "nccl" IS RCCL on ROCm
 
     cfg = WideDeepConfig(vocab_size=args.vocab, emb_dim=args.emb_dim, field_size=args.fields, batch_size=args.batch,
@@ -223,7 +231,7 @@ def main():
                          host_cache_rows=args.host_cache_rows, early_route=not args.no_early_route,
                          late_wide={'auto': None, 'on': True, 'off': False}[args.late_wide],
                          overlap_wide_apply=not args.no_overlap_wide_apply)
-    eng = WideDeepEngine(cfg, dev, rank=rank, world=world)
+    eng = WideDeepEngine(cfg, dev, rank=rank, world=world, shard_protocol=args.shard_protocol)
     batches = [synthetic_batch(cfg, dev, args.dist, seed=1000 + i, rank=rank) for i in range(args.n_batches)]
     torch.cuda.synchronize()
 
@@ -314,7 +322,8 @@ def main():
     # quoted only when this run is the workload that was profiled, and labelled with their source.
     traffic, traffic_source = None, None
     default_cfg = (args.vocab == 200_000_000 and args.emb_dim == 80 and args.batch == 16384 and args.fields == 26
-                   and args.dist == "uniform" and not args.split_state and world == 1 and args.mlp_dtype == "bf16")
+                   and args.dist == "uniform" and not args.split_state and world == 1 and args.mlp_dtype == "bf16"
+                   and not args.shard_protocol)
     for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if default_cfg and os.path.exists(pmc_path):
@@ -364,7 +373,7 @@ def main():
                                f"MLP {cfg.field_size * cfg.emb_dim}-1024-512-256-128-1 in {args.mlp_dtype} "
                                f"({'hand-written MFMA kernels' if eng._mfma else 'torch GEMMs'}; looked-up rows and row gradients in {dt_name})",
                    "global_batch": args.batch * world, "id_dist": args.dist, "hip_graphs": graphs_used, "unique_frac": round(U / max(n_apply, 1), 4),
-                   "parallelism": "1 GPU" if world == 1 else f"tables row-sharded x{world} (RCCL all-to-all), MLP dp{world}"},
+                   "parallelism": ("1 GPU" + (", row-shard protocol over RCCL with itself" if args.shard_protocol else "")) if world == 1 else f"tables row-sharded x{world} (RCCL all-to-all), MLP dp{world}"},
         "roofline": {"bound": "hbm",
                      "kernel": ("k_apply_main<4,int,UpdAdam,%s,WIDE> (segment-sum + LazyAdam row update + FTRL on the row's wide record)" if fold else
                                 "k_apply_main<4,int,UpdAdam,%s> (fused segment-sum + LazyAdam row update)") % (dt_name + "_t" if io16 else "float"),
@@ -406,7 +415,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.shard_protocol:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -268,6 +268,10 @@ int mrec_dense_adam_slabs_f32(float* p, float* m, float* v, const float* g, void
                               const int32_t* splits, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
                               float grad_scale, int nesterov, void* step_state /* nullable mrec_step_state_t: lr_t */,
                               void* stream);
+/* The same slab sums WITHOUT the optimizer, all segments in one launch: g[starts[q] + e] = sum_s slabs[q][s*lens[q] + e] in slab
+ * order -- what a data-parallel rank needs before the all-reduce of the dense gradients (train_and_eval_distribute.py:135-138). */
+int mrec_dense_sum_slab_segments_f32(float* g, int64_t n, int32_t nseg, const float* const* slabs, const int64_t* starts,
+                                     const int64_t* lens, const int32_t* splits, void* stream);
 int mrec_dense_ftrl_f32(float* var, float* accum, float* linear, const float* g, int64_t n, float lr,
                         float l1, float l2, float lr_power, float grad_scale, void* stream);
 

@@ -380,6 +380,30 @@ __global__ __launch_bounds__(256) void k_dense_adam4_slabs(float4* __restrict__ 
     }
 }
 
+// g[start_q + e] = sum over s of slabs_q[s * len_q + e], slab order, for every segment q in ONE launch (the data-parallel
+// all-reduce needs the summed gradient; 7 launches of a one-segment kernel whose bias segments had 256 lanes of work and 64
+// dependent loads each took 210 us).  A thread owns one float4 of one segment; 8 slab loads in flight.
+__global__ __launch_bounds__(256) void k_sum_slab_segments(float4* __restrict__ g, SlabSegs sg, int64_t total4) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total4; t += (int64_t)gridDim.x * 256) {
+        int k = 0;
+        int64_t off = t;
+        while (k < sg.n - 1 && off >= sg.len4[k]) { off -= sg.len4[k]; ++k; }
+        const float4* src = sg.part[k] + off;
+        const int S = sg.S[k];
+        const int64_t L = sg.len4[k];
+        float4 gg = src[0];
+        for (int s0 = 1; s0 < S; s0 += 8) {
+            float4 u[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) u[q] = (s0 + q < S) ? src[(int64_t)(s0 + q) * L] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (s0 + q < S) { gg.x += u[q].x; gg.y += u[q].y; gg.z += u[q].z; gg.w += u[q].w; }
+        }
+        g[sg.start4[k] + off] = gg;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_dense_ftrl(float* __restrict__ w, float* __restrict__ a,
                                                     float* __restrict__ lin, const float* __restrict__ g,
                                                     int64_t n, FtrlH h) {
@@ -723,6 +747,30 @@ MREC_API int mrec_dense_adam_slabs_f32(float* p, float* m, float* v, const float
     if (shadow_kind == 1) k_dense_adam4_slabs<1><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow16, sg, ss);
     else if (shadow_kind == 2) k_dense_adam4_slabs<2><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow16, sg, ss);
     else k_dense_adam4_slabs<0><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, nullptr, sg, ss);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+MREC_API int mrec_dense_sum_slab_segments_f32(float* g, int64_t n, int32_t nseg, const float* const* slabs, const int64_t* starts,
+                                              const int64_t* lens, const int32_t* splits, void* stream) {
+    if (n < 0 || nseg < 0 || nseg > 16) return MREC_EINVAL;
+    if (nseg == 0) return MREC_OK;
+    if (!g || !slabs || !starts || !lens || !splits) return MREC_EINVAL;
+    if (!al16(g)) return MREC_EUNSUPPORTED;
+    SlabSegs sg;
+    sg.n = nseg;
+    int64_t total4 = 0;
+    for (int q = 0; q < nseg; ++q) {
+        if (!slabs[q] || starts[q] < 0 || lens[q] <= 0 || starts[q] % 4 || lens[q] % 4 || starts[q] + lens[q] > n || splits[q] <= 0 ||
+            !al16(slabs[q]))
+            return MREC_EINVAL;
+        sg.part[q] = (const float4*)slabs[q];
+        sg.start4[q] = starts[q] / 4;
+        sg.len4[q] = lens[q] / 4;
+        sg.S[q] = splits[q];
+        total4 += lens[q] / 4;
+    }
+    k_sum_slab_segments<<<stream_grid(total4), 256, 0, (hipStream_t)stream>>>((float4*)g, sg, total4);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }

@@ -925,6 +925,26 @@ def sum_slabs(slabs, out):
     return out
 
 
+def sum_slab_segments_(g, slabs):
+    """g[start : start + len] = tensor.sum(0) in slab order for every (start, tensor [S, ...]) of `slabs`, ONE launch."""
+    _need_cuda(g)
+    k = len(slabs)
+    if k == 0:
+        return
+    if k > 16:
+        raise ValueError("at most 16 slab segments")
+    ptrs = (C.c_void_p * k)()
+    starts = (C.c_int64 * k)()
+    lens = (C.c_int64 * k)()
+    splits = (C.c_int32 * k)()
+    for q, (start, part) in enumerate(slabs):
+        if part.dtype != torch.float32 or not part.is_contiguous():
+            raise TypeError("slabs must be contiguous float32 [S, ...]")
+        ptrs[q], starts[q], lens[q], splits[q] = part.data_ptr(), int(start), part[0].numel(), part.shape[0]
+    _lib.call("mrec_dense_sum_slab_segments_f32", _ptr(g), g.numel(), k, C.cast(ptrs, C.c_void_p), C.cast(starts, C.c_void_p),
+              C.cast(lens, C.c_void_p), C.cast(splits, C.c_void_p), _stream())
+
+
 def dense_adam_slabs_(p, m, v, g, slabs, shadow16=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, beta1_power=0.9,
                       beta2_power=0.999, grad_scale=1.0, use_nesterov=False, step_state=None):
     """dense_adam_ whose gradient is, for some segments, still the fp32 batch slabs of dense_bwd_weight:

@@ -928,13 +928,15 @@ class WideDeepEngine:
             return loss
         return loss + self.cfg.l2_coef * 0.5 * float((self.deep.double() ** 2).sum())
 
+    def _slab_segments(self):
+        """[(offset in the flat gradient, slab tensor)] of the weight- and bias-gradient slabs of the last backward."""
+        return ([(self.dense_grad[2 * i].storage_offset(), t) for i, t in sorted(self._dw.items())] +
+                [(self.dense_grad[2 * i + 1].storage_offset(), t) for i, t in sorted(self._db.items())])
+
     def _sum_dw_slabs(self):
-        """Weight- and bias-gradient slabs -> the flat gradient buffer (needed only where somebody other than the dense
-        Adam reads the summed gradient: the data-parallel all-reduce)."""
-        for i, t in self._dw.items():
-            self.k.sum_slabs(t, self.dense_grad[2 * i])
-        for i, t in self._db.items():
-            self.k.sum_slabs(t, self.dense_grad[2 * i + 1])
+        """Weight- and bias-gradient slabs -> the flat gradient buffer, one launch (needed only where somebody other than the
+        dense Adam reads the summed gradient: the data-parallel all-reduce, the dense-gradient mode)."""
+        self.k.sum_slab_segments_(self.dense_grad_flat, self._slab_segments())
 
     # ---- one training step -------------------------------------------------------------------
     def train_step(self, ids, wts, label):
@@ -1097,8 +1099,7 @@ class WideDeepEngine:
             # one GPU: the weight gradients stay fp32 batch slabs and are added up inside the Adam kernel (nobody else
             # needs the sums); shards: they were summed for the all-reduce above.  Either way the kernel also refreshes
             # the 16-bit operand shadow.
-            slabs = [] if self._sharded else ([(self.dense_grad[2 * i].storage_offset(), t) for i, t in sorted(self._dw.items())] +
-                                              [(self.dense_grad[2 * i + 1].storage_offset(), t) for i, t in sorted(self._db.items())])
+            slabs = [] if self._sharded else self._slab_segments()
             self.k.dense_adam_slabs_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, slabs,
                                      shadow16=self.dense16_flat, step_state=state, **akw)
         else:

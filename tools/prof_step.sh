@@ -4,7 +4,7 @@ OUT=${1:-gpurun_out/p1}
 mkdir -p $OUT
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -- python3 $R/bench.py --steps 20 --warmup 3 --repeats 2 --no-cpu-baseline > $R/$OUT/bench_line_under_rocprof.json 2> $R/$OUT/prof.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -- python3 $R/bench.py --steps 20 --warmup 3 --repeats 2 --no-cpu-baseline $BENCH_FLAGS > $R/$OUT/bench_line_under_rocprof.json 2> $R/$OUT/prof.err
 cd $R
 cp $(find $OUT/prof -name "*kernel_stats.csv") $OUT/kernel_stats.csv
 python tools/prof_summary.py $OUT/kernel_stats.csv > $OUT/kernel_summary.txt
