@@ -120,10 +120,12 @@ int mrec_gather_rows_f16_i64(const float* table, int64_t V, int64_t ld, int32_t 
  * 2), and wide_prod[2 i] = table[ids[i], wide_col] * row_scale[i] (0 for ids outside [0, V); wide_prod[2 i + 1] = 0: the
  * products are stored as 8-byte pairs).  wide_col must equal D (the wide word right behind the deep columns), D % 4 == 0,
  * D <= 252.  The per-sample sum over the fields + bias is taken by mrec_head_fwd_bwd_wide in field order: same adds, same
- * order as mrec_wide_sum. */
+ * order as mrec_wide_sum.  ldo: row stride of `out` in 16-bit elements (D for a plain [n, D] result),
+ * ldw: stride of wide_prod in floats (2 for the plain [n, 2] result) -- a shard's answer message packs both into one row
+ * [D 16-bit values | product, 0 | pad] by pointing wide_prod at column D / 2 of the same rows. */
 int mrec_gather_rows_wide(const float* table, int64_t V, int64_t ld, int32_t D, const void* ids, int32_t id_bytes, int64_t n,
-                          const float* row_scale, void* out, int32_t out_kind, int32_t wide_col, float* wide_prod,
-                          void* stream);
+                          const float* row_scale, void* out, int32_t out_kind, int64_t ldo, int32_t wide_col, float* wide_prod,
+                          int64_t ldw, void* stream);
 
 /* Wide branch of WideDeepModel.construct (wide_and_deep.py:300,303-306) in one pass:
  * out[b] = sum_f w[ids[b,f] * ldw] * wts[b,f] + *bias_dev   (w is the [V,1] wide table, row
@@ -203,7 +205,9 @@ int mrec_sparse_lazy_adam_f16g_i64(float* p, float* m, float* v, int64_t V, int6
  * gw[i / F] (the head's dlogit of sample i / F: Mul bprop of wide_and_deep.py:304), scaled by row_scale[i] * grad_scale and
  * summed per id in the same window / tree order as the deep columns.  uniq_bytes 4 / 8; g_kind 0 f32, 1 bf16, 2 f16;
  * D % 4 == 0, D <= 252, wide_col == D (the record right behind p: it is loaded and stored by the instruction that moves p),
- * 16-byte aligned rows (128-byte aligned rows avoid a second line per record), n * F < 2^32.
+ * 16-byte aligned rows (128-byte aligned rows avoid a second line per record), n * F < 2^32.  gw_stride: distance in floats
+ * between consecutive gradients (1 for a plain array); F == 1 gives every position its own gradient gw[i * gw_stride] (a
+ * shard's owner: the received positions are not grouped by sample, and the gradient is a column of the gradient message).
  * ws: mrec_sparse_apply_workspace_bytes(n, D + 4).
  * step_state (nullable): an mrec_step_state_t in device memory; when given, the Adam step size comes from it instead of
  * b1_pow / b2_pow, and the main kernel leaves its begin / end wall clock stamps there. */
@@ -211,7 +215,7 @@ int mrec_sparse_lazy_adam_wide(float* p, float* m, float* v, int64_t V, int64_t 
                                int32_t uniq_bytes, const int32_t* sorted_pos, const int32_t* sorted_seg,
                                const int32_t* seg_offsets, int64_t n, const void* g, int32_t g_kind, int64_t ldg,
                                const float* row_scale, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
-                               float grad_scale, int nesterov, const float* gw, int32_t F, int32_t wide_col, float ftrl_lr,
+                               float grad_scale, int nesterov, const float* gw, int64_t gw_stride, int32_t F, int32_t wide_col, float ftrl_lr,
                                float l1, float l2, float lr_power, void* ws, size_t ws_bytes, void* step_state, void* stream);
 
 /* ---- step scalars in device memory ------------------------------------------------------------------------------
@@ -515,6 +519,15 @@ int mrec_shard_unroute_f32(const float* rows, const int32_t* send_perm, int64_t 
  * row gradients for the backward all-to-all. */
 int mrec_shard_route_rows_f32(const float* g, int64_t ldg, const int32_t* send_perm, int64_t n, int32_t D,
                               const float* row_scale, float* rows_out, void* stream);
+/* The same two permutations with explicit row strides on both sides (rows of a message that carries more than one thing),
+ * and the (id, weight) pairs of a request message: out_pairs[k] = {send_local[k], bits(wts[send_perm[k]])}. */
+int mrec_shard_unroute_ld_f32(const float* rows, int64_t ldr, const int32_t* send_perm, int64_t n, int32_t D,
+                              const float* row_scale, float* out, int64_t ldo, void* stream);
+int mrec_shard_route_rows_ld_f32(const float* g, int64_t ldg, const int32_t* send_perm, int64_t n, int32_t D,
+                                 const float* row_scale, float* rows_out, int64_t ldo, void* stream);
+int mrec_shard_pack_iw_i32(const int32_t* send_local, const float* wts, const int32_t* send_perm, int64_t n, int32_t* out_pairs,
+                           void* stream);
+int mrec_shard_unpack_iw_i32(const int32_t* pairs, int64_t n, int32_t* ids_out, float* wts_out, void* stream);
 
 /* ---- measurement hooks (used by bench.py; no effect on results) --------------------------
  * HIP events owned by the library, and a one-shot hook: the NEXT sparse-apply call (segment_sum /

@@ -50,9 +50,9 @@ _SIGS = {
     "mrec_gather_rows_bf16_i64": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_gather_rows_f16_i32": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_gather_rows_f16_i64": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
-    "mrec_gather_rows_wide": [_vp, _i64, _i64, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp],
+    "mrec_gather_rows_wide": [_vp, _i64, _i64, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _i64, _i32, _vp, _i64, _vp],
     "mrec_sparse_lazy_adam_wide": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i64, _vp,
-                                   _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _sz, _vp, _vp],
+                                   _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _sz, _vp, _vp],
     "mrec_step_state_init": [_vp, _f32, _f32, _i64, _vp],
     "mrec_step_advance": [_vp, _f32, _f32, _f32, _vp],
     "mrec_wall_clock_khz": [_vp],
@@ -134,6 +134,10 @@ _SIGS = {
     "mrec_shard_route_hash_i64": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_shard_unroute_f32": [_vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_shard_route_rows_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp],
+    "mrec_shard_unroute_ld_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp],
+    "mrec_shard_route_rows_ld_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp],
+    "mrec_shard_pack_iw_i32": [_vp, _vp, _vp, _i64, _vp, _vp],
+    "mrec_shard_unpack_iw_i32": [_vp, _i64, _vp, _vp, _vp],
     "mrec_event_create": [C.POINTER(_vp)],
     "mrec_event_destroy": [_vp],
     "mrec_event_elapsed_ms": [_vp, _vp, C.POINTER(C.c_float)],

@@ -260,7 +260,7 @@ struct ApplyGeom { int lpr; int G; int D; };
 //   * the per-sample gradient gw[pos / F] is one group-uniform, cached load (pos / F by multiply-high with `magic`).
 // Two earlier forms cost +35 % (separate nontemporal load + store of the record: the line is fetched again) and +55 %
 // (the wide lane pointed at dummy lines for m / v: two more line requests per load and store).
-struct WideArgs { const float* gw; int F; int wcol; FtrlH h; unsigned magic; float* dummy; };
+struct WideArgs { const float* gw; int F; int wcol; FtrlH h; unsigned magic; float* dummy; unsigned gws; };
 
 // uniq == nullptr means "row = group number" (segment-sum into a dense [U, D] output).
 template <class K>
@@ -313,7 +313,8 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
             if (e < e_end) {
                 const int pos = spos[e];
                 if (WIDE) {
-                    const float gwv = wa.gw[__umulhi((unsigned)pos, wa.magic)];      // same address for the whole lane-group
+                    // (F == 1: one gradient per position -- a shard's owner, whose received positions are not grouped by sample)
+                    const float gwv = wa.gw[(wa.F == 1 ? (unsigned)pos : __umulhi((unsigned)pos, wa.magic)) * wa.gws];      // same address for the whole lane-group
                     if (!wl) vload<NT>(gvv[q], g + (int64_t)pos * ldg + col);
                     else vset_x(gvv[q], gwv);
                 } else {
@@ -597,7 +598,7 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
         wa = *wide;
         wa.magic = (unsigned)(((uint64_t)1 << 32) / (uint64_t)wa.F + 1);       // pos / F = umulhi(pos, magic) while pos * F < 2^32
         wa.dummy = w.dummy;
-        if ((uint64_t)n * (uint64_t)wa.F >= ((uint64_t)1 << 32)) return MREC_EUNSUPPORTED;
+        if ((uint64_t)n * (uint64_t)wa.F >= ((uint64_t)1 << 32) || (uint64_t)n * (uint64_t)wa.gws >= ((uint64_t)1 << 32)) return MREC_EUNSUPPORTED;
     }
     const int64_t nsw = mrec_cdiv(n, vec == 4 ? ACfg<4>::AW : ACfg<1>::AW);
     const unsigned blocks = (unsigned)mrec_cdiv(nsw, (int64_t)4 * gm.G);
@@ -852,12 +853,12 @@ MREC_API int mrec_sparse_lazy_adam_wide(float* p, float* m, float* v, int64_t V,
                                         int32_t uniq_bytes, const int32_t* sorted_pos, const int32_t* sorted_seg,
                                         const int32_t* seg_offsets, int64_t n, const void* g, int32_t g_kind, int64_t ldg,
                                         const float* row_scale, float lr, float b1, float b2, float eps, float b1_pow,
-                                        float b2_pow, float grad_scale, int nesterov, const float* gw, int32_t F,
+                                        float b2_pow, float grad_scale, int nesterov, const float* gw, int64_t gw_stride, int32_t F,
                                         int32_t wide_col, float ftrl_lr, float l1, float l2, float lr_power, void* ws,
                                         size_t ws_bytes, void* step_state, void* stream) {
-    if ((uniq_bytes != 4 && uniq_bytes != 8) || g_kind < 0 || g_kind > 2) return MREC_EINVAL;
+    if ((uniq_bytes != 4 && uniq_bytes != 8) || g_kind < 0 || g_kind > 2 || gw_stride < 1 || gw_stride > (1 << 20)) return MREC_EINVAL;
     WideArgs wa;
-    wa.gw = gw; wa.F = F; wa.wcol = wide_col; wa.magic = 0; wa.dummy = nullptr;
+    wa.gw = gw; wa.F = F; wa.wcol = wide_col; wa.magic = 0; wa.dummy = nullptr; wa.gws = (unsigned)gw_stride;
     wa.h = FtrlH{ftrl_lr, l1, l2, lr_power, grad_scale};
 #define MREC_WIDE_CALL(KT, GT)                                                                                          \
     return lazy_adam_impl<KT, GT>(p, m, v, V, ld, D, (const KT*)uniq, sorted_pos, sorted_seg, seg_offsets, n, (const GT*)g, ldg, \

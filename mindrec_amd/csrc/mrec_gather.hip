@@ -72,10 +72,11 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
                                                      const K* __restrict__ ids, int64_t n,
                                                      const float* __restrict__ row_scale,
                                                      OT* __restrict__ out, int D, RowGeom gm,
-                                                     float* __restrict__ wprod = nullptr) {
+                                                     float* __restrict__ wprod = nullptr, int64_t ldo = 0, int64_t ldw = 2) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
     if (grp >= gm.G) return;
+    if (ldo == 0) ldo = D;                 // row stride of `out` in elements; ldw: stride of the wide products in floats
     const int col = sub * VEC;
     const bool wl = VEC == 4 && sizeof(OT) == 2 && wprod != nullptr && col >= D;      // the wide lane (column D)
     const int64_t wave_row0 = ((int64_t)blockIdx.x * 4 + wave) * (gm.G * GB);
@@ -107,13 +108,13 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
                 const float4 yv = y.v;
                 uint2 u = pack16((const OT*)nullptr, yv);
                 if (wl) u = make_uint2(__float_as_uint(yv.x), 0u);
-                uint2* dst = wl ? (uint2*)(wprod + 2 * i) : (uint2*)(out + i * D + col);
+                uint2* dst = wl ? (uint2*)(wprod + ldw * i) : (uint2*)(out + i * ldo + col);
                 *dst = u;
               } else {
-                vstore(out + i * D + col, y);
+                vstore(out + i * ldo + col, y);
               }
             } else {
-                vstore(out + i * D + col, y);
+                vstore(out + i * ldo + col, y);
             }
         }
     }
@@ -418,7 +419,9 @@ inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 template <class K, class OT = bf16o_t>
 int gather_bf16_impl(const float* table, int64_t V, int64_t ld, int32_t D, const K* ids, int64_t n,
-                     const float* row_scale, uint16_t* out, void* stream, int wcol = 0, float* wprod = nullptr) {
+                     const float* row_scale, uint16_t* out, void* stream, int wcol = 0, float* wprod = nullptr, int64_t ldo = 0,
+                     int64_t ldw = 2) {
+    if ((ldo != 0 && (ldo < D || ldo % 4)) || (wprod && (ldw < 2 || ldw % 2))) return MREC_EINVAL;
     if (wprod && (wcol != D || D % 4 || D > 252 || ld % 4 || ld < D + 4 || !al16(table) || (((uintptr_t)out) & 7) || (((uintptr_t)wprod) & 7)))
         return MREC_EUNSUPPORTED;       // the wide word must sit right behind the deep columns of 16-byte aligned rows
     hipStream_t st = (hipStream_t)stream;
@@ -430,8 +433,8 @@ int gather_bf16_impl(const float* table, int64_t V, int64_t ld, int32_t D, const
         const int lpr = D / 4 + (wprod ? 1 : 0);
         RowGeom gm{lpr, 64 / lpr};
         k_gather_rows<4, K, OT><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
-            table, V, ld, ids, n, row_scale, (OT*)out, D, gm, wprod);
-    } else if (D <= 64 && !wprod) {
+            table, V, ld, ids, n, row_scale, (OT*)out, D, gm, wprod, ldo, ldw);
+    } else if (D <= 64 && !wprod && ldo == 0) {
         RowGeom gm{D, 64 / D};
         k_gather_rows<1, K, OT><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
             table, V, ld, ids, n, row_scale, (OT*)out, D, gm);
@@ -560,16 +563,17 @@ MREC_API int mrec_gather_rows_f16_i64(const float* table, int64_t V, int64_t ld,
 
 /* Gather + the wide branch's products in one pass (see include/mrec.h): out_kind 1 = bf16, 2 = f16 rows. */
 MREC_API int mrec_gather_rows_wide(const float* table, int64_t V, int64_t ld, int32_t D, const void* ids, int32_t id_bytes,
-                                   int64_t n, const float* row_scale, void* out, int32_t out_kind, int32_t wide_col,
-                                   float* wide_prod, void* stream) {
+                                   int64_t n, const float* row_scale, void* out, int32_t out_kind, int64_t ldo, int32_t wide_col,
+                                   float* wide_prod, int64_t ldw, void* stream) {
     if ((id_bytes != 4 && id_bytes != 8) || (out_kind != 1 && out_kind != 2)) return MREC_EINVAL;
     if (!wide_prod || wide_col < 0 || wide_col >= ld) return MREC_EINVAL;
+    if (ldo == D) ldo = 0;
     if (id_bytes == 4) {
-        if (out_kind == 1) return gather_bf16_impl<int32_t, bf16o_t>(table, V, ld, D, (const int32_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod);
-        return gather_bf16_impl<int32_t, f16o_t>(table, V, ld, D, (const int32_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod);
+        if (out_kind == 1) return gather_bf16_impl<int32_t, bf16o_t>(table, V, ld, D, (const int32_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw);
+        return gather_bf16_impl<int32_t, f16o_t>(table, V, ld, D, (const int32_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw);
     }
-    if (out_kind == 1) return gather_bf16_impl<int64_t, bf16o_t>(table, V, ld, D, (const int64_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod);
-    return gather_bf16_impl<int64_t, f16o_t>(table, V, ld, D, (const int64_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod);
+    if (out_kind == 1) return gather_bf16_impl<int64_t, bf16o_t>(table, V, ld, D, (const int64_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw);
+    return gather_bf16_impl<int64_t, f16o_t>(table, V, ld, D, (const int64_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw);
 }
 
 MREC_API int mrec_wide_sum_f32_i32(const float* w, int64_t V, int64_t ldw, const int32_t* ids, const float* wts,

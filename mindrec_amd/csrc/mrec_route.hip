@@ -55,7 +55,7 @@ constexpr int PB = 4;
 template <bool SCATTER, int VEC>
 __global__ __launch_bounds__(256) void k_perm_rows(const float* __restrict__ src, int64_t lds,
                                                    const int* __restrict__ perm, int64_t n, int D, int lpr, int G,
-                                                   const float* __restrict__ row_scale, float* __restrict__ dst) {
+                                                   const float* __restrict__ row_scale, float* __restrict__ dst, int64_t ldd) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / lpr, sub = lane - grp * lpr;
     if (grp >= G) return;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_perm_rows(const float* __restrict__ src
     for (int q = 0; q < PB; ++q) {
         const int64_t k = k0 + (int64_t)q * G + grp;
         if (p[q] >= 0) {
-            float* o = (SCATTER ? dst + p[q] * (int64_t)D : dst + k * (int64_t)D) + sub * VEC;
+            float* o = (SCATTER ? dst + p[q] * ldd : dst + k * ldd) + sub * VEC;
             if (VEC == 4) {
                 float4 v = make_float4(x[q][0], x[q][1 % VEC], x[q][2 % VEC], x[q][3 % VEC]);
                 if (row_scale) { v.x *= s[q]; v.y *= s[q]; v.z *= s[q]; v.w *= s[q]; }
@@ -107,34 +107,51 @@ template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_perm_rows_generic(const float* __restrict__ src, int64_t lds,
                                                            const int* __restrict__ perm, int64_t n, int D,
                                                            const float* __restrict__ row_scale,
-                                                           float* __restrict__ dst) {
+                                                           float* __restrict__ dst, int64_t ldd) {
     const int lane = threadIdx.x & 63;
     const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= n) return;
     const int64_t p = perm[k];
     const float s = row_scale ? row_scale[p] : 1.0f;
     const float* a = SCATTER ? src + k * lds : src + p * lds;
-    float* o = SCATTER ? dst + p * (int64_t)D : dst + k * (int64_t)D;
+    float* o = SCATTER ? dst + p * ldd : dst + k * ldd;
     for (int c = lane; c < D; c += 64) o[c] = row_scale ? a[c] * s : a[c];
 }
 
 template <bool SCATTER>
 int perm_rows_launch(const float* src, int64_t lds, const int* perm, int64_t n, int D, const float* row_scale,
-                     float* dst, hipStream_t st) {
-    const bool al = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0 && (lds % 4 == 0);
+                     float* dst, hipStream_t st, int64_t ldd = 0) {
+    if (ldd == 0) ldd = D;
+    const bool al = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0 && (lds % 4 == 0) && (ldd % 4 == 0);
     if (D % 4 == 0 && D <= 256 && al) {
         const int lpr = D / 4, G = 64 / lpr;
         k_perm_rows<SCATTER, 4><<<(unsigned)mrec_cdiv(n, (int64_t)4 * G * PB), 256, 0, st>>>(src, lds, perm, n, D, lpr, G,
-                                                                                           row_scale, dst);
+                                                                                           row_scale, dst, ldd);
     } else if (D <= 64) {
         const int lpr = D, G = 64 / lpr;
         k_perm_rows<SCATTER, 1><<<(unsigned)mrec_cdiv(n, (int64_t)4 * G * PB), 256, 0, st>>>(src, lds, perm, n, D, lpr, G,
-                                                                                           row_scale, dst);
+                                                                                           row_scale, dst, ldd);
     } else {
-        k_perm_rows_generic<SCATTER><<<(unsigned)mrec_cdiv(n, 4), 256, 0, st>>>(src, lds, perm, n, D, row_scale, dst);
+        k_perm_rows_generic<SCATTER><<<(unsigned)mrec_cdiv(n, 4), 256, 0, st>>>(src, lds, perm, n, D, row_scale, dst, ldd);
     }
     MREC_LAUNCH_CHECK();
     return MREC_OK;
+}
+
+// (id, weight) pairs of one request message: out[k] = {send_local[k], bits(wts[perm[k]])}; and their split on arrival
+__global__ __launch_bounds__(256) void k_pack_iw(const int* __restrict__ send_local, const float* __restrict__ wts,
+                                                 const int* __restrict__ perm, int64_t n, int2* __restrict__ out) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) out[k] = make_int2(send_local[k], __float_as_int(wts[perm[k]]));
+}
+__global__ __launch_bounds__(256) void k_unpack_iw(const int2* __restrict__ in, int64_t n, int* __restrict__ ids,
+                                                   float* __restrict__ wts) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) {
+        const int2 v = in[k];
+        ids[k] = v.x;
+        wts[k] = __int_as_float(v.y);
+    }
 }
 
 template <class K>
@@ -211,4 +228,38 @@ MREC_API int mrec_shard_route_rows_f32(const float* g, int64_t ldg, const int32_
     if (n == 0) return MREC_OK;
     if (!g || !send_perm || !rows_out) return MREC_EINVAL;
     return perm_rows_launch<false>(g, ldg, send_perm, n, D, row_scale, rows_out, (hipStream_t)stream);
+}
+
+/* The same two permutations with explicit row strides on both sides (messages that carry more than one thing per row:
+ * [16-bit embedding row | wide value | pad], see mindrec_amd/wide_deep.py) */
+MREC_API int mrec_shard_unroute_ld_f32(const float* rows, int64_t ldr, const int32_t* send_perm, int64_t n, int32_t D,
+                                       const float* row_scale, float* out, int64_t ldo, void* stream) {
+    if (n < 0 || D <= 0 || ldr < D || ldo < D) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!rows || !send_perm || !out) return MREC_EINVAL;
+    return perm_rows_launch<true>(rows, ldr, send_perm, n, D, row_scale, out, (hipStream_t)stream, ldo);
+}
+MREC_API int mrec_shard_route_rows_ld_f32(const float* g, int64_t ldg, const int32_t* send_perm, int64_t n, int32_t D,
+                                          const float* row_scale, float* rows_out, int64_t ldo, void* stream) {
+    if (n < 0 || D <= 0 || ldg < D || ldo < D) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!g || !send_perm || !rows_out) return MREC_EINVAL;
+    return perm_rows_launch<false>(g, ldg, send_perm, n, D, row_scale, rows_out, (hipStream_t)stream, ldo);
+}
+MREC_API int mrec_shard_pack_iw_i32(const int32_t* send_local, const float* wts, const int32_t* send_perm, int64_t n,
+                                    int32_t* out_pairs, void* stream) {
+    if (n < 0) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!send_local || !wts || !send_perm || !out_pairs || (((uintptr_t)out_pairs) & 7)) return MREC_EINVAL;
+    k_pack_iw<<<(unsigned)mrec_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(send_local, wts, send_perm, n, (int2*)out_pairs);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+MREC_API int mrec_shard_unpack_iw_i32(const int32_t* pairs, int64_t n, int32_t* ids_out, float* wts_out, void* stream) {
+    if (n < 0) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!pairs || !ids_out || !wts_out || (((uintptr_t)pairs) & 7)) return MREC_EINVAL;
+    k_unpack_iw<<<(unsigned)mrec_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>((const int2*)pairs, n, ids_out, wts_out);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
 }

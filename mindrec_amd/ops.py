@@ -17,7 +17,10 @@ _WS_RETIRED = []      # outgrown workspaces stay referenced: a captured HIP grap
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current stream's raw handle.  Through torch's C entry points: torch.cuda.current_stream() builds a Python Stream object
+    and re-checks device availability (an os.environ lookup) on every call -- tens of microseconds of host time per kernel
+    launch, which a step issued kernel by kernel (a shard's: ~30 launches) cannot afford."""
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _ptr(t):
@@ -30,7 +33,7 @@ _MAP_PRIMED = {}
 
 def workspace(tag, nbytes, device):
     """Stream-ordered scratch, cached per (tag, device, stream) and grown geometrically."""
-    key = (tag, str(device), torch.cuda.current_stream().cuda_stream)
+    key = (tag, str(device), torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
         if t is not None:
@@ -182,10 +185,12 @@ def gather_rows(table, ids, row_scale=None, out=None, out_dtype=torch.float32):
     return out.view(tuple(ids.shape) + (D,))
 
 
-def gather_rows_wide(table, ids, row_scale, wide_col, out=None, out_dtype=torch.bfloat16):
+def gather_rows_wide(table, ids, row_scale, wide_col, out=None, out_dtype=torch.bfloat16, packed_words=0):
     """Both lookups of WideDeepModel.construct (wide_and_deep.py:300-302) in one pass over fused rows: returns
     (rows [.., D] in out_dtype, wide_prod [.., 2] with [.., 0] = table_row[wide_col] * row_scale and [.., 1] = 0).  `table` is the [V, D] view of the deep
-    columns; wide_col is the column (relative to it, >= D) of the wide weight in the same rows."""
+    columns; wide_col is the column (relative to it, >= D) of the wide weight in the same rows.
+    packed_words=W (>= D/2 + 2, multiple of 4): ONE float32 [n, W] result whose row is [D 16-bit values | product, 0 | pad] --
+    a shard's answer message (one collective for both tables)."""
     _need_cuda(table, ids, row_scale, out)
     V, D, ld = _table(table)
     flat = ids.reshape(-1).contiguous()
@@ -196,11 +201,20 @@ def gather_rows_wide(table, ids, row_scale, wide_col, out=None, out_dtype=torch.
             raise TypeError("row_scale must be float32 with one value per id")
     if out_dtype not in _DT16:
         raise TypeError("gather_rows_wide writes bfloat16 or float16 rows")
+    kind = 1 if out_dtype == torch.bfloat16 else 2
+    if packed_words:
+        W = int(packed_words)
+        if D % 2 or W < D // 2 + 2 or W % 4:
+            raise ValueError("packed_words must be a multiple of 4 that holds D / 2 + 2 words")
+        msg = torch.empty((max(n, 1), W), dtype=torch.float32, device=table.device)[:n]
+        _lib.call("mrec_gather_rows_wide", _ptr(table), V, ld, D, _ptr(flat), flat.element_size(), n, _ptr(row_scale), _ptr(msg),
+                  kind, 2 * W, int(wide_col), C.c_void_p(msg.data_ptr() + 2 * D), W, _stream())
+        return msg
     if out is None:
         out = torch.empty((n, D), dtype=out_dtype, device=table.device)
     wprod = torch.empty((max(n, 1), 2), dtype=torch.float32, device=table.device)[:n]      # (product, pad) pairs
     _lib.call("mrec_gather_rows_wide", _ptr(table), V, ld, D, _ptr(flat), flat.element_size(), n, _ptr(row_scale), _ptr(out),
-              1 if out.dtype == torch.bfloat16 else 2, int(wide_col), _ptr(wprod), _stream())
+              1 if out.dtype == torch.bfloat16 else 2, D, int(wide_col), _ptr(wprod), 2, _stream())
     return out.view(tuple(ids.shape) + (D,)), wprod.view(tuple(ids.shape) + (2,))
 
 
@@ -324,14 +338,20 @@ def sparse_lazy_adam_wide_(p, m, v, plan, g, row_scale, gw, F, wide_col, lr=3.5e
             raise ValueError("p, m, v must share shape and row stride")
     g2, ldg = _grads(plan, g, D, allow_bf16=True)
     rs = _row_scale(plan, row_scale)
-    if gw.dtype != torch.float32 or not gw.is_contiguous() or gw.numel() * F != plan.n:
-        raise TypeError("gw must be contiguous float32 with one value per sample (n / F)")
+    if gw.dtype != torch.float32 or gw.numel() * F != plan.n:
+        raise TypeError("gw must be float32 with one value per sample (n / F)")
+    if gw.dim() == 2 and gw.shape[1] == 1:
+        gws = gw.stride(0) if gw.shape[0] > 1 else 1            # a column of wider rows (a shard's gradient message)
+    elif gw.is_contiguous():
+        gws = 1
+    else:
+        raise TypeError("gw must be contiguous, or an [n, 1] column view")
     nb = _lib.query_bytes("mrec_sparse_apply_workspace_bytes", max(plan.n, 1), D + 4)
     ws = workspace("apply", nb, p.device)
     kind = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[g2.dtype]
     _lib.call("mrec_sparse_lazy_adam_wide", _ptr(p), _ptr(m), _ptr(v), V, ld, D, _ptr(plan.uniq_buf), plan.uniq_buf.element_size(),
               _ptr(plan.sorted_pos), _ptr(plan.sorted_seg), _ptr(plan.seg_offsets), plan.n, _ptr(g2), kind, ldg, _ptr(rs), lr,
-              beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _ptr(gw), int(F), int(wide_col),
+              beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _ptr(gw), int(gws), int(F), int(wide_col),
               ftrl_lr, l1, l2, lr_power, _ptr(ws), ws.numel(), _ptr(step_state.buf) if step_state is not None else None, _stream())
 
 
@@ -665,29 +685,58 @@ def shard_route(ids, n_shards, hashed=False):
     return send_local, send_perm, counts
 
 
-def shard_unroute(rows, send_perm, row_scale=None, out=None):
-    n, D = rows.shape
-    rows = rows.contiguous()
+def shard_unroute(rows, send_perm, row_scale=None, out=None, cols=None):
+    """out[send_perm[k], :] = rows[k, :cols] (* row_scale): a request's answers back in position order.  `rows` may be a
+    column window of wider message rows (any row stride)."""
+    n = rows.shape[0]
+    D = rows.shape[1] if cols is None else int(cols)
+    if rows.dim() != 2 or rows.stride(1) != 1 or rows.dtype != torch.float32:
+        raise TypeError("shard_unroute: rows must be float32 [n, D] with unit column stride")
     if out is None:
         out = torch.empty((n, D), dtype=torch.float32, device=rows.device)
     elif out.dtype != torch.float32 or tuple(out.shape) != (n, D) or not out.is_contiguous():
         raise TypeError("shard_unroute: out must be a contiguous float32 [n, D] tensor")
     rs = row_scale.reshape(-1).contiguous() if row_scale is not None else None
-    _lib.call("mrec_shard_unroute_f32", _ptr(rows), _ptr(send_perm), n, D, _ptr(rs), _ptr(out), _stream())
+    _lib.call("mrec_shard_unroute_ld_f32", _ptr(rows), rows.stride(0) if n > 1 else max(D, rows.shape[1]), _ptr(send_perm), n, D,
+              _ptr(rs), _ptr(out), D, _stream())
     return out
 
 
-def shard_route_rows(g, send_perm, row_scale=None):
+def shard_route_rows(g, send_perm, row_scale=None, out=None):
+    """rows_out[k, :D] = g[send_perm[k], :] (* row_scale): rows bucketed by owner.  out: a float32 [n, >= D] column window of a
+    wider message (any row stride) to write into."""
     n = send_perm.numel()
     D = g.shape[-1]
     g2 = g.reshape(n, D)
     if g2.stride(1) != 1:
         g2 = g2.contiguous()
-    out = torch.empty((n, D), dtype=torch.float32, device=g.device)
+    if out is None:
+        out = torch.empty((n, D), dtype=torch.float32, device=g.device)
+    elif out.dtype != torch.float32 or out.dim() != 2 or out.shape[0] != n or out.shape[1] < D or out.stride(1) != 1:
+        raise TypeError("shard_route_rows: out must be a float32 [n, >= D] tensor with unit column stride")
     rs = row_scale.reshape(-1).contiguous() if row_scale is not None else None
-    _lib.call("mrec_shard_route_rows_f32", _ptr(g2), g2.stride(0) if n > 1 else D, _ptr(send_perm), n, D, _ptr(rs),
-              _ptr(out), _stream())
+    _lib.call("mrec_shard_route_rows_ld_f32", _ptr(g2), g2.stride(0) if n > 1 else D, _ptr(send_perm), n, D, _ptr(rs),
+              _ptr(out), out.stride(0) if n > 1 else max(D, out.shape[1]), _stream())
     return out
+
+
+def shard_pack_iw(send_local, wts, send_perm):
+    """One request message instead of two: int32 [n, 2] rows {local id, bits of the position's weight}."""
+    _need_cuda(send_local, wts, send_perm)
+    if send_local.dtype != torch.int32:
+        raise TypeError("shard_pack_iw packs int32 ids")
+    n = send_local.numel()
+    out = torch.empty((max(n, 1), 2), dtype=torch.int32, device=send_local.device)[:n]
+    _lib.call("mrec_shard_pack_iw_i32", _ptr(send_local), _ptr(wts.reshape(-1).contiguous()), _ptr(send_perm), n, _ptr(out), _stream())
+    return out
+
+
+def shard_unpack_iw(pairs):
+    n = pairs.shape[0]
+    ids = torch.empty(max(n, 1), dtype=torch.int32, device=pairs.device)[:n]
+    wts = torch.empty(max(n, 1), dtype=torch.float32, device=pairs.device)[:n]
+    _lib.call("mrec_shard_unpack_iw_i32", _ptr(pairs), n, _ptr(ids), _ptr(wts), _stream())
+    return ids, wts
 
 
 # ---- measurement hook ------------------------------------------------------------------------

@@ -290,6 +290,8 @@ class WideDeepEngine:
             if self.dense16 is not None:
                 self.dense16_flat.copy_(self.dense_flat.detach())
         self._hashed = bool(cfg.dynamic_embedding)
+        self._fused_rows = bool(cfg.fused_state and cfg.sparse and cfg.host_cache_rows == 0 and self._gpu)   # [p | w ... | m | v] rows
+        self._pack_msgs = bool(self._gpu and kernels is None and D % 2 == 0)     # shards: merged request / answer / gradient messages
         self._recv_plan = None        # shards with a host-backed table: the plan of the received keys (made by the cache tier)
         self.beta1, self.beta2 = np.float32(0.9), np.float32(0.999)
         self.beta1_power, self.beta2_power = np.float32(1.0), np.float32(1.0)
@@ -570,17 +572,26 @@ class WideDeepEngine:
             self.comm.all_to_all(recv_counts_t, counts)
             recv_counts = recv_counts_t.tolist()
             n_recv = int(sum(recv_counts))
-            recv_local = torch.empty(n_recv, dtype=ids.dtype, device=self.device)
-            self.comm.all_to_all(recv_local, send_local, recv_counts, send_counts)
+            pack = self._pack_msgs and wire16 and ids.dtype == torch.int32
             recv_wts = None
-            if wire16:
-                # 16 bits on the wire: the per-position weights travel with the ids so the OWNER applies the mask in
-                # fp32 and rounds once -- bit-identical to the one-GPU gather -- and rows / row-gradients
-                # cross xGMI at half the bytes.  A row of D 16-bit values is moved as D/2 fp32 words (pure permutation).
-                send_w = self.k.shard_route_rows(wts.reshape(n, 1), perm, None)
-                recv_wts = torch.empty((n_recv, 1), dtype=torch.float32, device=self.device)
-                self.comm.all_to_all(recv_wts, send_w, recv_counts, send_counts)
-                recv_wts = recv_wts.view(-1)
+            if pack:
+                # ONE request message: int32 pairs (local id, bits of the position's weight) -- a collective costs 30-40 us of
+                # host and launch latency whatever its size, so the step carries 5 of them instead of 8
+                send_iw = self.k.shard_pack_iw(send_local, wts, perm)
+                recv_iw = torch.empty((n_recv, 2), dtype=torch.int32, device=self.device)
+                self.comm.all_to_all(recv_iw, send_iw, recv_counts, send_counts)
+                recv_local, recv_wts = self.k.shard_unpack_iw(recv_iw)
+            else:
+                recv_local = torch.empty(n_recv, dtype=ids.dtype, device=self.device)
+                self.comm.all_to_all(recv_local, send_local, recv_counts, send_counts)
+                if wire16:
+                    # 16 bits on the wire: the per-position weights travel with the ids so the OWNER applies the mask in
+                    # fp32 and rounds once -- bit-identical to the one-GPU gather -- and rows / row-gradients
+                    # cross xGMI at half the bytes.  A row of D 16-bit values is moved as D/2 fp32 words (pure permutation).
+                    send_w = self.k.shard_route_rows(wts.reshape(n, 1), perm, None)
+                    recv_wts = torch.empty((n_recv, 1), dtype=torch.float32, device=self.device)
+                    self.comm.all_to_all(recv_wts, send_w, recv_counts, send_counts)
+                    recv_wts = recv_wts.view(-1)
         if early:
             main.wait_stream(self._side)
             for t in (send_local, perm, recv_local, recv_wts):
@@ -594,7 +605,14 @@ class WideDeepEngine:
             self._recv_plan, recv_local = self.hb.prepare(recv_local)          # rows of the device cache
         self._tock(ev)
         ev = self._tick("gather_deep")
-        if wire16:
+        packed = bool(self._pack_msgs and wire16 and self._fused_rows)
+        W = D // 2 + 4 - (D // 2) % 4 if packed else 0          # words per answer row: D/2 (16-bit row) + (product, 0) + pad
+        wrows = None
+        if packed:
+            # ONE answer message per position: [D 16-bit values | wide weight * mask, 0 | pad], written by one pass over the
+            # fused rows (the wide word sits right behind the deep columns)
+            rows = self.k.gather_rows_wide(self.deep, recv_local, recv_wts, D, out_dtype=self._amp, packed_words=W)
+        elif wire16:
             rows = self.k.gather_rows(self.deep, recv_local, recv_wts, out_dtype=self._amp)          # [n_recv, D] 16-bit
             wrows = self.k.gather_rows(self.wide, recv_local, recv_wts)                               # [n_recv, 1], masked
         else:
@@ -602,14 +620,17 @@ class WideDeepEngine:
             wrows = self.k.gather_rows(self.wide, recv_local)               # [n_recv, 1]
         self._tock(ev)
         ev = self._tick("a2a_rows")
-        back = torch.empty((n, D), dtype=rows.dtype, device=self.device)
+        back = torch.empty((n, W) if packed else (n, D), dtype=rows.dtype, device=self.device)
         self.comm.all_to_all(back, rows, send_counts, recv_counts)
 
         def wide_branch():
-            # wide rows back from their owners, un-permuted, summed over the fields (+ bias)
-            wback = torch.empty((n, 1), dtype=torch.float32, device=self.device)
-            self.comm.all_to_all(wback, wrows, send_counts, recv_counts)
-            wv = self.k.shard_unroute(wback, perm, None if wire16 else wts.reshape(-1)).view(B, Fd)
+            # wide values back from their owners, un-permuted, summed over the fields (+ bias)
+            if packed:
+                wv = self.k.shard_unroute(back[:, D // 2:], perm, None, cols=1).view(B, Fd)
+            else:
+                wback = torch.empty((n, 1), dtype=torch.float32, device=self.device)
+                self.comm.all_to_all(wback, wrows, send_counts, recv_counts)
+                wv = self.k.shard_unroute(wback, perm, None if wire16 else wts.reshape(-1)).view(B, Fd)
             return wv.sum(dim=1) + self.wide_b
 
         wide = wide_branch if defer_wide else wide_branch()
@@ -619,12 +640,13 @@ class WideDeepEngine:
             eo = self._emb_out(n, D, self._amp)            # static graph input, when the MLP graph exists
             if eo is not None:
                 eo = eo.view(torch.float32)
-            emb = self.k.shard_unroute(back.view(torch.float32), perm, None, out=eo).view(self._amp).view(B, Fd * D)
+            src = back if packed else back.view(torch.float32)
+            emb = self.k.shard_unroute(src, perm, None, out=eo, cols=D // 2).view(self._amp).view(B, Fd * D)
         else:
             emb = self.k.shard_unroute(back, perm, wts.reshape(-1)).view(B, Fd * D)
         self._tock(ev)
         if defer_wide:
-            wrows.record_stream(self._side)
+            (wrows if wrows is not None else back).record_stream(self._side)
         return emb, wide, (perm, send_counts, recv_counts, recv_local, recv_wts)
 
     def predict(self, ids, wts):
@@ -762,7 +784,8 @@ class WideDeepEngine:
                                             l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=inv_sens)
                 wide_done = True
             early_gw = None
-            if after_head is None and route is not None and self._side is not None and cfg.early_wide_grad:
+            if (after_head is None and route is not None and self._side is not None and cfg.early_wide_grad
+                    and not (self._pack_msgs and route[4] is not None)):       # (packed messages: it rides the row gradients)
                 holder = {}
 
                 def after_head(gw_b):
@@ -1025,7 +1048,22 @@ class WideDeepEngine:
             ev = self._tick("a2a_grads")
             n_recv = recv_local.numel()
             have_gw = fused and early_gw is not None and "recv_gw" in early_gw
-            if recv_wts is not None:
+            packed_g = bool(self._pack_msgs and recv_wts is not None and not have_gw)
+            if packed_g:
+                # ONE gradient message per position: [D 16-bit row-gradient values | the wide branch's gradient | pad]; the
+                # owner's two applies read their parts through row strides
+                Wg = D // 2 + 4 - (D // 2) % 4
+                n = B * Fd
+                send_g = torch.empty((n, Wg), dtype=torch.float32, device=self.device)
+                self.k.shard_route_rows(g_emb.view(n, D).view(torch.float32), perm, None, out=send_g)
+                gw = g_wide.view(B, 1).expand(B, Fd).reshape(n, 1).contiguous()
+                self.k.shard_route_rows(gw, perm, None, out=send_g[:, D // 2:])
+                recv_msg = torch.empty((n_recv, Wg), dtype=torch.float32, device=self.device)
+                self.comm.all_to_all(recv_msg, send_g, recv_counts, send_counts)
+                recv_g = recv_msg.view(self._amp)[:, :D]                  # [n_recv, D] 16-bit, row stride 2 * Wg
+                recv_gw = recv_msg[:, D // 2:D // 2 + 1]                  # [n_recv, 1] fp32, row stride Wg
+                row_scale = recv_wts
+            elif recv_wts is not None:
                 # 16-bit wire: raw 16-bit row-gradients travel (as D/2 fp32 words); the owner multiplies by the
                 # weights it received in the forward, inside the apply kernel, exactly as on one GPU
                 send_g = self.k.shard_route_rows(g_emb.view(B * Fd, D).view(torch.float32), perm, None)
@@ -1045,7 +1083,9 @@ class WideDeepEngine:
                 recv_g = torch.empty((n_recv, D), dtype=torch.float32, device=self.device)
                 self.comm.all_to_all(recv_g, send_g, recv_counts, send_counts)
                 row_scale = None
-            if have_gw:
+            if packed_g:
+                pass                                   # came inside the row-gradient message
+            elif have_gw:
                 recv_gw = early_gw["recv_gw"]          # exchanged on the side stream during the backward; joined below
                 recv_gw.record_stream(torch.cuda.current_stream())
             else:
@@ -1071,15 +1111,25 @@ class WideDeepEngine:
             if self.deep_apply_timer is not None:
                 self.deep_apply_timer.arm()
                 self.deep_apply_timer = None
-            self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, recv_g, row_scale, lr=cfg.adam_lr,
-                                  beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
-                                  beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
-                                  grad_scale=scale)
+            fold_shard = bool(packed_g and self._fused_rows and cfg.fold_wide and D <= 252)
+            if fold_shard:
+                # LazyAdam + the wide record's FTRL in one visit per touched row, as on one GPU; the wide gradient of a
+                # received position is a column of the gradient message (one value per position: F = 1)
+                self.k.sparse_lazy_adam_wide_(self.deep, self.deep_m, self.deep_v, plan, recv_g, row_scale, recv_gw, 1, D,
+                                              lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
+                                              beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
+                                              grad_scale=scale, ftrl_lr=cfg.ftrl_lr, l1=cfg.ftrl_l1, l2=cfg.ftrl_l2)
+            else:
+                self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, recv_g, row_scale, lr=cfg.adam_lr,
+                                         beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
+                                         beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
+                                         grad_scale=scale)
             self._tock(ev)
-            ev = self._tick("apply_wide")
-            self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, recv_gw, row_scale, lr=cfg.ftrl_lr,
-                             l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=scale)
-            self._tock(ev)
+            if not fold_shard:
+                ev = self._tick("apply_wide")
+                self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, recv_gw, row_scale, lr=cfg.ftrl_lr,
+                                    l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=scale)
+                self._tock(ev)
 
         if self._sharded:
             if dense_work is not None:
