@@ -23,6 +23,8 @@ python tools/paths_bench.py > $O/paths_bench.txt 2>/dev/null
 python tools/dcn_bench.py > $O/dcn_bench.txt 2>/dev/null
 cat $O/paths_bench.txt $O/dcn_bench.txt
 timeout -k 10 200 ./tools/probes/dense_gemm_test > $O/dense_gemm_probe.txt 2>&1 || true
+# what a rank of an N-GPU job does besides moving bytes over xGMI: the row-shard protocol over RCCL with itself
+python bench.py --no-cpu-baseline --shard-protocol 2>/dev/null | tail -1 > $O/bench_line_shard_protocol.json
 
 # id-distribution sweep: uniform / Zipf(1.05), 26 / 39 fields
 for d in uniform zipf; do for f in 26 39; do
