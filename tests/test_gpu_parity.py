@@ -616,3 +616,83 @@ def test_fused_row_kernels_wide_branch(dev, oracle, dtype, kind, D, F):
     assert float((np.abs(gp - rp).max(axis=1) / den).max()) <= 1e-5
     assert np.abs(gw_ - rw).max() <= 1e-4 * np.abs(rw).max() and np.allclose(gwa, rwa, rtol=1e-5)
     assert (state[:, D + 3] == 0).all() and (state[:, 3 * D + 4:] == 0).all()        # the pad words are never written
+
+
+def test_shard_messages_pack_unpack_and_column_windows(dev, oracle):
+    """The merged shard messages: (id, weight) pairs; permutations that write into / read from column windows of wider
+    message rows; the owner's one-pass answer rows [D 16-bit values | wide weight * mask, 0 | pad]; the folded apply with one
+    wide gradient per position read as a column of the gradient message (F = 1)."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(21)
+    n, S, D = 9001, 4, 80
+    ids = rng.integers(0, 50000, size=n).astype(np.int32)
+    wts = rng.random(n).astype(np.float32)
+    loc, perm, counts = ops.shard_route(T(ids, dev), S)
+    rperm = perm.cpu().numpy()
+    pairs = ops.shard_pack_iw(loc, T(wts, dev), perm)
+    pk = pairs.cpu().numpy()
+    assert np.array_equal(pk[:, 0], loc.cpu().numpy()) and np.array_equal(pk[:, 1].view(np.float32), wts[rperm])
+    i2, w2 = ops.shard_unpack_iw(pairs)
+    assert np.array_equal(i2.cpu().numpy(), loc.cpu().numpy()) and np.array_equal(w2.cpu().numpy(), wts[rperm])
+    # route_rows into column windows of one message, unroute out of them
+    W = D // 2 + 4
+    g = rng.standard_normal((n, D // 2)).astype(np.float32)
+    gw = rng.standard_normal((n, 1)).astype(np.float32)
+    msg = torch.full((n, W), 7.0, device=dev)
+    ops.shard_route_rows(T(g, dev), perm, None, out=msg)
+    ops.shard_route_rows(T(gw, dev), perm, None, out=msg[:, D // 2:])
+    m = msg.cpu().numpy()
+    assert np.array_equal(m[:, : D // 2], g[rperm]) and np.array_equal(m[:, D // 2], gw[rperm, 0]) and (m[:, D // 2 + 1:] == 7.0).all()
+    back = ops.shard_unroute(msg, perm, None, cols=D // 2).cpu().numpy()
+    assert np.array_equal(back, g)
+    backw = ops.shard_unroute(msg[:, D // 2:], perm, None, cols=1).cpu().numpy()
+    assert np.array_equal(backw, gw)
+    # the owner's answer rows, one pass over fused rows
+    V = 4000
+    ld = -(-(3 * D + 4) // 32) * 32
+    state = torch.zeros((V, ld), dtype=torch.float32, device=dev)
+    p, w = state[:, :D], state[:, D:D + 1]
+    ops.fill_normal_(p, seed=5, sigma=0.01); ops.fill_normal_(w, seed=6, sigma=0.01)
+    rp, rw = oracle.fill_normal(5, V, D, 0.01), oracle.fill_normal(6, V, 1, 0.01)
+    rid = rng.integers(0, V, size=n).astype(np.int32)
+    ans = ops.gather_rows_wide(p, T(rid, dev), T(wts, dev), D, out_dtype=torch.bfloat16, packed_words=W)
+    assert tuple(ans.shape) == (n, W)
+    rows16 = ans.view(torch.bfloat16)[:, :D].float().cpu().numpy()
+    assert np.array_equal(rows16, oracle.round16(oracle.gather_rows(rp, rid, wts), "bf16"))
+    a = ans.cpu().numpy()
+    assert np.array_equal(a[:, D // 2], oracle.gather_rows(rw, rid, wts)[:, 0]) and (a[:, D // 2 + 1] == 0).all()
+    # folded apply with per-position wide gradients == the two separate applies
+    m_, v_ = state[:, D + 4:2 * D + 4], state[:, 2 * D + 4:3 * D + 4]
+    wa, wl = state[:, D + 1:D + 2], state[:, D + 2:D + 3]
+    wa.fill_(1.0)
+    ref = state.clone()
+    plan = ops.sparse_plan(T(rid, dev))
+    gmsg = torch.zeros((n, W), device=dev)
+    g16 = torch.from_numpy(rng.standard_normal((n, D)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    gmsg.view(torch.bfloat16)[:, :D] = g16
+    gmsg[:, D // 2] = T(gw[:, 0], dev)
+    ops.sparse_lazy_adam_wide_(p, m_, v_, plan, gmsg.view(torch.bfloat16)[:, :D], T(wts, dev), gmsg[:, D // 2:D // 2 + 1], 1, D,
+                               grad_scale=1 / 64)
+    rp2, rm2, rv2 = ref[:, :D], ref[:, D + 4:2 * D + 4], ref[:, 2 * D + 4:3 * D + 4]
+    ops.sparse_lazy_adam_(rp2, rm2, rv2, plan, g16, T(wts, dev), grad_scale=1 / 64)
+    ops.sparse_ftrl_(ref[:, D:D + 1], ref[:, D + 1:D + 2], ref[:, D + 2:D + 3], plan, T(gw, dev), T(wts, dev), grad_scale=1 / 64)
+    assert torch.equal(state[:, :D], ref[:, :D]) and torch.equal(state[:, D + 4:], ref[:, D + 4:])
+    assert float((state[:, D:D + 3] - ref[:, D:D + 3]).abs().max()) <= 1e-6 * float(ref[:, D:D + 3].abs().max())
+
+
+def test_sum_slab_segments(dev):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(3)
+    flat = torch.full((5000,), -1.0, device=dev)
+    segs = [(0, torch.from_numpy(rng.standard_normal((7, 40, 20)).astype(np.float32)).to(dev)),
+            (1000, torch.from_numpy(rng.standard_normal((64, 128)).astype(np.float32)).to(dev)),
+            (2000, torch.from_numpy(rng.standard_normal((1, 16, 4)).astype(np.float32)).to(dev))]
+    ops.sum_slab_segments_(flat, segs)
+    out = flat.cpu().numpy()
+    for start, t in segs:
+        a = t.cpu().numpy()
+        acc = a[0].copy()
+        for s in range(1, a.shape[0]):
+            acc = acc + a[s]                                    # slab order
+        assert np.array_equal(out[start:start + acc.size], acc.ravel())
+    assert (out[800:1000] == -1).all() and (out[1128:2000] == -1).all() and (out[2064:] == -1).all()
