@@ -734,7 +734,8 @@ class WideDeepEngine:
         if fork_ev is not None:
             # (forking it behind the output head instead -- beside the backward GEMMs -- was measured: 0.786 vs 0.764 ms;
             # forking it behind the gather -- which then runs alone -- 0.7576 vs 0.7591 ms: the plan's kernels and whatever
-            # they run beside stretch each other by about the same amount wherever the plan sits; the chain cut in two -- the
+            # they run beside stretch each other by about the same amount wherever the plan sits (behind the first GEMM: 0.774);
+            # the chain cut in two -- the
             # insert kernel here, the rest behind the first GEMM through a second event -- 0.853 ms: another cross-branch
             # dependency, and the graph runtime serialises more than the dependencies ask for)
             self._side.wait_event(fork_ev)
