@@ -108,3 +108,84 @@ class CriteoDataset:
                 return
             out = self.stats.encode(chunk)
             yield tuple(self.to_device(a) for a in out) if self.to_device else out
+
+
+# ---- record files: 1000 samples per record, sharded by rank ------------------------------------------------------
+# Reference: the training scripts read MindRecord files whose every row packs `line_per_sample = 1000` samples
+# (process_data.py:203-283 writes them; models/wide_deep/src/datasets.py:274-325 reads them: MindDataset(columns
+# feat_ids / feat_vals / label, num_shards=rank_size, shard_id=rank_id) -> batch(batch_size / 1000, drop_remainder=True) ->
+# reshape to [batch, 39] / [batch, 39] / [batch, 1]).  MindRecord itself is MindSpore's container format; the same records
+# are kept here in plain .npz shards (`train_XXXX.npz` / `test_XXXX.npz`, arrays feat_ids [R, 1000*39] int32, feat_vals
+# [R, 1000*39] float32, label [R, 1000] float32), and the reading contract is the reference's.
+LINE_PER_SAMPLE = 1000
+FIELD_SIZE = NUM_INTEGER_COLUMNS + NUM_CATEGORICAL_COLUMNS
+
+
+def write_records(directory, prefix, ids, wts, label, records_per_file=64, line_per_sample=LINE_PER_SAMPLE):
+    """Packs samples into records of `line_per_sample` (the tail that does not fill a record is dropped, as the reference's
+    writer does, process_data.py:262-283) and writes `prefix_0000.npz`, ...  Returns the number of records written."""
+    import os
+    ids = np.asarray(ids, np.int32); wts = np.asarray(wts, np.float32); label = np.asarray(label, np.float32).reshape(-1)
+    n, F = ids.shape
+    R = n // line_per_sample
+    os.makedirs(directory, exist_ok=True)
+    fi = 0
+    for r0 in range(0, R, records_per_file):
+        r1 = min(R, r0 + records_per_file)
+        sl = slice(r0 * line_per_sample, r1 * line_per_sample)
+        np.savez(os.path.join(directory, f"{prefix}_{fi:04d}.npz"),
+                 feat_ids=ids[sl].reshape(r1 - r0, line_per_sample * F), feat_vals=wts[sl].reshape(r1 - r0, line_per_sample * F),
+                 label=label[sl].reshape(r1 - r0, line_per_sample))
+        fi += 1
+    return R
+
+
+class RecordDataset:
+    """The reading side: records of 1000 samples from `directory/{train,test}_*.npz`, record r goes to rank r mod rank_size,
+    `batch_size / line_per_sample` records per batch, the remainder dropped, shuffled per epoch in train mode (seeded).
+    Yields (ids [B, 39] int32, wts [B, 39] float32, label [B, 1] float32) like the reference's padding function
+    (datasets.py:210-217); `to_device` as in CriteoDataset."""
+
+    def __init__(self, directory, train_mode=True, batch_size=1000, line_per_sample=LINE_PER_SAMPLE, rank_size=None, rank_id=None,
+                 field_size=FIELD_SIZE, seed=0, to_device=None):
+        import glob
+        import os
+        if batch_size % line_per_sample:
+            raise ValueError("batch_size must be a multiple of line_per_sample (datasets.py:319)")
+        self.files = sorted(glob.glob(os.path.join(directory, ("train" if train_mode else "test") + "_*.npz")))
+        if not self.files:
+            raise FileNotFoundError(f"no record files in {directory}")
+        self.shuffle, self.seed, self.epoch = bool(train_mode), int(seed), 0
+        self.B, self.lps, self.F = int(batch_size), int(line_per_sample), int(field_size)
+        self.rank_size, self.rank_id = (int(rank_size), int(rank_id)) if rank_size is not None and rank_id is not None else (1, 0)
+        self.to_device = to_device
+        counts = [np.load(f)["label"].shape[0] for f in self.files]
+        self._index = [(fi, r) for fi, c in enumerate(counts) for r in range(c)]            # global record order
+        self._mine = [k for k in range(len(self._index)) if k % self.rank_size == self.rank_id]
+
+    def get_dataset_size(self):
+        return len(self._mine) // (self.B // self.lps)
+
+    def reset(self):
+        self.epoch += 1
+
+    def __iter__(self):
+        order = list(self._mine)
+        if self.shuffle:
+            np.random.default_rng(self.seed + self.epoch).shuffle(order)
+        rpb = self.B // self.lps
+        cache = {}
+        for b in range(len(order) // rpb):
+            ids = np.empty((self.B, self.F), np.int32); wts = np.empty((self.B, self.F), np.float32)
+            label = np.empty((self.B, 1), np.float32)
+            for j, k in enumerate(order[b * rpb:(b + 1) * rpb]):
+                fi, r = self._index[k]
+                if fi not in cache:
+                    cache = {fi: np.load(self.files[fi])}
+                z = cache[fi]
+                sl = slice(j * self.lps, (j + 1) * self.lps)
+                ids[sl] = z["feat_ids"][r].reshape(self.lps, self.F)
+                wts[sl] = z["feat_vals"][r].reshape(self.lps, self.F)
+                label[sl, 0] = z["label"][r]
+            out = (ids, wts, label)
+            yield tuple(self.to_device(a) for a in out) if self.to_device else out

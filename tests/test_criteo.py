@@ -1,6 +1,7 @@
 """The Criteo encoder against a line-by-line restatement of the reference's map_cat2id
 (datasets/criteo_1tb/process_data.py:132-163) on a synthetic TSV."""
 import numpy as np
+import pytest
 
 from mindrec_amd.criteo import CAT_COUNT_THRESHOLD, CriteoDataset, StatsDict
 
@@ -61,3 +62,37 @@ def test_dataset_batches():
     batches = list(ds)
     assert ds.get_dataset_size() == 2 and len(batches) == 2 and batches[0][0].shape == (100, 39)
     assert len(list(CriteoDataset(lines, st, 100, drop_remainder=False))) == 3
+
+
+def test_record_files_roundtrip_and_rank_sharding(tmp_path):
+    """Records of 1000 samples (the reference's MindRecord row), sharded record by record over the ranks, batch = whole
+    records, remainder dropped (datasets.py:274-325)."""
+    from mindrec_amd.criteo import RecordDataset, write_records
+    rng = np.random.default_rng(0)
+    n = 10 * 1000 + 377                                   # 10 full records; the tail does not make a record
+    ids = rng.integers(0, 10 ** 6, size=(n, 39)).astype(np.int32)
+    wts = rng.random((n, 39)).astype(np.float32)
+    label = (rng.random(n) < 0.3).astype(np.float32)
+    assert write_records(str(tmp_path), "train", ids, wts, label, records_per_file=4) == 10
+    assert write_records(str(tmp_path), "test", ids[:3000], wts[:3000], label[:3000]) == 3
+    ev = RecordDataset(str(tmp_path), train_mode=False, batch_size=2000)
+    assert ev.get_dataset_size() == 1                      # 3 records -> one batch of 2, remainder dropped
+    (bi, bw, bl), = list(ev)
+    assert bi.shape == (2000, 39) and bl.shape == (2000, 1) and bi.dtype == np.int32 and bw.dtype == np.float32
+    assert np.array_equal(bi, ids[:2000]) and np.array_equal(bw, wts[:2000]) and np.array_equal(bl[:, 0], label[:2000])
+    seen = []
+    for rank in range(3):
+        ds = RecordDataset(str(tmp_path), train_mode=True, batch_size=1000, rank_size=3, rank_id=rank, seed=5)
+        assert ds.get_dataset_size() == len(range(rank, 10, 3))
+        for bi, bw, bl in ds:
+            r = int(np.nonzero((ids[::1000][:10] == bi[0]).all(axis=1))[0][0])       # which record this batch is
+            assert r % 3 == rank and np.array_equal(bi, ids[r * 1000:(r + 1) * 1000]) and np.array_equal(bl[:, 0], label[r * 1000:(r + 1) * 1000])
+            seen.append(r)
+    assert sorted(seen) == list(range(10))                 # every record on exactly one rank
+    a = [b[0][0, 0] for b in RecordDataset(str(tmp_path), batch_size=1000, seed=1)]
+    d = RecordDataset(str(tmp_path), batch_size=1000, seed=1)
+    assert [b[0][0, 0] for b in d] == a                    # same seed, same epoch: same order
+    d.reset()
+    assert [b[0][0, 0] for b in d] != a                    # next epoch reshuffles
+    with pytest.raises(ValueError):
+        RecordDataset(str(tmp_path), batch_size=1500)
