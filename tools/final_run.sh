@@ -20,6 +20,7 @@ echo "pmc done"; cat $O/pmc_traffic.txt
 cd $R
 python bench.py --no-cpu-baseline --dist zipf --fields 39 > $O/bench_line_zipf39.json 2>/dev/null
 python tools/paths_bench.py > $O/paths_bench.txt 2>/dev/null
+python tools/embed_bench.py --layout folded --tag final 2>/dev/null > $O/embed_folded.txt
 python tools/dcn_bench.py > $O/dcn_bench.txt 2>/dev/null
 cat $O/paths_bench.txt $O/dcn_bench.txt
 timeout -k 10 200 ./tools/probes/dense_gemm_test > $O/dense_gemm_probe.txt 2>&1 || true
