@@ -133,15 +133,16 @@ __device__ __forceinline__ int lookback_excl(unsigned* status, int tile) {
     return excl;
 }
 
-// Numbers the first occurrences in position order in ONE pass (flag + count + scan + rank), and hands every claimed slot
-// back to EMPTY on the way: a slot's only reader that needs its value is the thread of the first occurrence itself (every
-// other position of the key sees "not me" before and after), so the scratch table leaves the call as it entered it and the
-// next call on the same workspace needs no memset.
+// Numbers the first occurrences in position order in ONE pass (flag + count + scan + rank).  The scratch table is left as
+// it is -- a slot keeps the first position of its key, which is how a duplicate finds its group afterwards
+// (inv[slots[sidx[j]]]) -- and is cleared by a 4-MB memset at the head of the next call: handing the slots back one by
+// one, and keeping a rank per slot for the duplicates, were 850 k random 4-byte writes per call, a third of this kernel.
 template <class K>
-__global__ __launch_bounds__(DB) void k_dedup_rank(const K* __restrict__ ids, int* __restrict__ slots,
+__global__ __launch_bounds__(DB) void k_dedup_rank(const K* __restrict__ ids, const int* __restrict__ slots,
                                                    const int* __restrict__ sidx, int n, unsigned* __restrict__ status,
-                                                   int nblk, K* __restrict__ uniq, int* __restrict__ srank,
-                                                   int64_t* __restrict__ n_uniq_dev) {
+                                                   int nblk, K* __restrict__ uniq, int* __restrict__ inv,
+                                                   int64_t* __restrict__ n_uniq_dev, int* __restrict__ first_pos = nullptr,
+                                                   int* __restrict__ dup_pos = nullptr, int64_t* __restrict__ n_dup_dev = nullptr) {
     __shared__ int sm[8];
     __shared__ int s_excl;
     const int base = blockIdx.x * DT + threadIdx.x * DI;
@@ -178,32 +179,112 @@ __global__ __launch_bounds__(DB) void k_dedup_rank(const K* __restrict__ ids, in
     int r = tile_base + pre;
 #pragma unroll
     for (int k = 0; k < DI; ++k) {
+        const int i = base + k;
         if (first[k]) {
-            const int i = base + k;
             uniq[r] = ids[i];
-            srank[slot[k]] = r;
-            slots[slot[k]] = kEmpty;
+            inv[i] = r;                      // (a duplicate finds its group here, through the slot that still holds i)
+            if (first_pos) first_pos[r] = i; // the step's plan: where the group starts
             ++r;
+        } else if (dup_pos && i < n) {
+            // every position before i is a first occurrence or a duplicate, so the duplicates need no scan of their own:
+            // i is duplicate number i - (first occurrences before i), in position order
+            dup_pos[i - r] = i;
         }
     }
-    if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 0) *n_uniq_dev = (int64_t)tile_base + tot;
+    if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 0) {
+        *n_uniq_dev = (int64_t)tile_base + tot;
+        if (n_dup_dev) *n_dup_dev = (int64_t)n - ((int64_t)tile_base + tot);
+    }
 }
 
-__global__ __launch_bounds__(DB) void k_dedup_inv(const int* __restrict__ srank, const int* __restrict__ sidx,
+// The inverted index from the sorted duplicates.  First occurrences arrive already in group order (group g starts at
+// first_pos[g]), so only the duplicate positions were sorted by group (stable: ascending position inside a group); with
+// lb(g) = number of duplicates of groups < g (a binary search in the sorted duplicate keys) group g's run starts at
+// g + lb(g), holds its first occurrence and then its duplicates.  Thread t places group t and duplicate t.
+__global__ __launch_bounds__(256) void k_plan_place(const int* __restrict__ first_pos, const int64_t* __restrict__ n_uniq_dev,
+                                                    const int* __restrict__ dkey, const int* __restrict__ dpos,
+                                                    const int64_t* __restrict__ n_dup_dev, int n, int* __restrict__ sorted_pos,
+                                                    int* __restrict__ sorted_seg, int* __restrict__ seg_offsets) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int U = (int)*n_uniq_dev, nD = (int)*n_dup_dev;
+    auto lower = [&](int g) {            // first e in [0, nD) with dkey[e] >= g
+        int lo = 0, hi = nD;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (dkey[mid] < g) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    if (t < U) {
+        const int off = t + lower(t);
+        seg_offsets[t] = off;
+        sorted_pos[off] = first_pos[t];
+        sorted_seg[off] = t;
+        if (t == U - 1) seg_offsets[U] = n;
+    }
+    if (t < nD) {
+        const int g = dkey[t];
+        const int lb = lower(g);
+        const int dst = g + lb + 1 + (t - lb);
+        sorted_pos[dst] = dpos[t];
+        sorted_seg[dst] = g;
+    }
+    if (t == 0 && U == 0) seg_offsets[0] = 0;
+}
+
+__global__ __launch_bounds__(DB) void k_dedup_inv(const int* __restrict__ slots, const int* __restrict__ sidx,
                                                   int n, int* __restrict__ inv, unsigned* __restrict__ status, int nstatus) {
     const int i = blockIdx.x * DB + threadIdx.x;
     if (i < nstatus) status[i] = 0;                   // the look-back words of k_dedup_rank, for the next call
-    if (i < n) inv[i] = srank[sidx[i]];
+    if (i < n) {
+        const int p = slots[sidx[i]];                 // first position of i's key (its inverse is final: written by k_dedup_rank)
+        if (p != i) inv[i] = inv[p];
+    }
+}
+
+// Few duplicates (uniform ids over a large vocabulary: ~n^2 / 2V of them): ONE workgroup resolves their groups and sorts them
+// by (group, position) by counting, in LDS, and tells the radix passes behind it that there is nothing left to do
+// (*n_radix = 0) -- a radix pass over one live tile still costs its three launches' single-workgroup latencies (~25 us).
+constexpr int kSmallDups = 1024;
+__global__ __launch_bounds__(1024) void k_plan_small(const int* __restrict__ slots, const int* __restrict__ sidx,
+                                                     const int* __restrict__ dup_pos, const int64_t* __restrict__ n_dup_dev,
+                                                     int* __restrict__ inv, int* __restrict__ dkey, int* __restrict__ dpos,
+                                                     int64_t* __restrict__ n_radix) {
+    __shared__ int skey[kSmallDups];
+    const int64_t nD64 = *n_dup_dev;
+    if (nD64 > kSmallDups) {
+        if (threadIdx.x == 0) *n_radix = nD64;
+        return;
+    }
+    const int nD = (int)nD64, t = threadIdx.x;
+    if (t == 0) *n_radix = 0;
+    int key = 0, pos = 0;
+    if (t < nD) {
+        pos = dup_pos[t];
+        key = inv[slots[sidx[pos]]];
+        inv[pos] = key;
+        skey[t] = key;
+    }
+    __syncthreads();
+    if (t < nD) {
+        int rank = 0;                                  // duplicates with a smaller group, or the same group and an earlier position
+        for (int e = 0; e < nD; ++e) {
+            const int k = skey[e];
+            rank += (k < key) || (k == key && e < t);
+        }
+        dkey[rank] = key;
+        dpos[rank] = pos;
+    }
 }
 
 __global__ void k_set_i64(int64_t* p, int64_t v) { *p = v; }
 
-struct DedupScratch { int* srank; int* sidx; unsigned* status; int nstatus; };
+struct DedupScratch { int* slots; int* sidx; unsigned* status; int nstatus; int* first_pos; int* dup_pos; int64_t* n_dup; int64_t* n_radix; };
 
-// fuse_inv_out != nullptr: skip the inverse kernel and hand back (srank, sidx) so the caller's first
-// radix histogram can produce inv on the fly.
+// fuse_inv_out != nullptr (the step's plan): the rank kernel also separates first occurrences (first_pos) from duplicates
+// (dup_pos, their count on the device), the inverse of the duplicates is left to the caller's sort of the duplicates.
 // primed: the caller vouches that the last thing that wrote this workspace was a completed call of this function with the
-// same n (see MREC_PLAN_WS_PRIMED in include/mrec.h) -- the scratch table and the look-back words are then already clean.
+// same n: the look-back words are then already zero (the scratch table is cleared by a memset either way).
 template <class K>
 int dedup_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_dev, void* ws, size_t ws_bytes,
                void* stream_v, DedupScratch* fuse_inv_out = nullptr, bool primed = false) {
@@ -221,19 +302,25 @@ int dedup_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_d
     const int nblk = (int)mrec_cdiv(n, DT);
     MrecArena a(ws, ws_bytes);
     int* slots = a.take<int>(cap);
-    int* srank = a.take<int>(cap);
     int* sidx = a.take<int>(n);
     unsigned* status = (unsigned*)a.take<int>(nblk);
-    if (!a.ok) return MREC_EWORKSPACE;
-    if (!primed) {
-        MREC_HIP_CHECK(hipMemsetAsync(slots, 0x7f, cap * sizeof(int), st));
-        MREC_HIP_CHECK(hipMemsetAsync(status, 0, (size_t)nblk * sizeof(int), st));
+    int* first_pos = nullptr; int* dup_pos = nullptr; int64_t* n_dup = nullptr;
+    if (fuse_inv_out) {                    // the step's plan: first occurrences and duplicates leave the rank kernel separated
+        first_pos = a.take<int>(n);
+        dup_pos = a.take<int>(n);
+        n_dup = a.take<int64_t>(2);        // [0] duplicates, [1] duplicates left to the radix passes
     }
+    if (!a.ok) return MREC_EWORKSPACE;
+    MREC_HIP_CHECK(hipMemsetAsync(slots, 0x7f, cap * sizeof(int), st));
+    if (!primed) MREC_HIP_CHECK(hipMemsetAsync(status, 0, (size_t)nblk * sizeof(int), st));     // (a completed call leaves them zero)
     const int g256 = (int)mrec_cdiv(n, DB);
     k_dedup_insert<K><<<(int)mrec_cdiv(n, IT), DB, 0, st>>>(ids, (int)n, slots, (uint32_t)(cap - 1), sidx);
-    k_dedup_rank<K><<<nblk, DB, 0, st>>>(ids, slots, sidx, (int)n, status, nblk, uniq, srank, n_uniq_dev);
-    if (fuse_inv_out) { fuse_inv_out->srank = srank; fuse_inv_out->sidx = sidx; fuse_inv_out->status = status; fuse_inv_out->nstatus = nblk; }
-    else k_dedup_inv<<<g256, DB, 0, st>>>(srank, sidx, (int)n, inv, status, nblk);
+    k_dedup_rank<K><<<nblk, DB, 0, st>>>(ids, slots, sidx, (int)n, status, nblk, uniq, inv, n_uniq_dev, first_pos, dup_pos, n_dup);
+    if (fuse_inv_out) {
+        fuse_inv_out->slots = slots; fuse_inv_out->sidx = sidx; fuse_inv_out->status = status; fuse_inv_out->nstatus = nblk;
+        fuse_inv_out->first_pos = first_pos; fuse_inv_out->dup_pos = dup_pos; fuse_inv_out->n_dup = n_dup;
+        fuse_inv_out->n_radix = n_dup ? n_dup + 1 : nullptr;
+    } else k_dedup_inv<<<g256, DB, 0, st>>>(slots, sidx, (int)n, inv, status, nblk);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -285,14 +372,14 @@ MREC_API int mrec_group_workspace_bytes(int64_t n, size_t* out) {
 }
 
 static int group_impl(const int32_t* inv, int64_t n, int32_t* sorted_pos, int32_t* sorted_seg, int32_t* seg_offsets,
-                      void* ws, size_t ws_bytes, void* stream, const DedupScratch* fuse, int32_t* inv_out) {
+                      void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || !seg_offsets) return MREC_EINVAL;
     if (n == 0) {
         MREC_HIP_CHECK(hipMemsetAsync(seg_offsets, 0, sizeof(int32_t), st));
         return MREC_OK;
     }
-    if ((!inv && !fuse) || !sorted_pos || !sorted_seg || !ws) return MREC_EINVAL;
+    if (!inv || !sorted_pos || !sorted_seg || !ws) return MREC_EINVAL;
     if (n > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
     const int nblk = (int)mrec_cdiv(n, RT);
     MrecArena a(ws, ws_bytes);
@@ -306,18 +393,13 @@ static int group_impl(const int32_t* inv, int64_t n, int32_t* sorted_pos, int32_
     while (((int64_t)1 << bits) < n) ++bits;  // group numbers are < n
     const int passes = (bits + RMAXB - 1) / RMAXB;
     const int pbits = (bits + passes - 1) / passes;
-    const int* kin = fuse ? inv_out : inv;
+    const int* kin = inv;
     const int* vin = nullptr;
     for (int p = 0; p < passes; ++p) {
         const bool to_user = ((passes - 1 - p) % 2) == 0;
         int* kout = to_user ? sorted_seg : tk;
         int* vout = to_user ? sorted_pos : tv;
-        const int shift = p * pbits;
-        if (p == 0 && fuse)      // pass 0 computes inv = srank[sidx[i]] while it builds its histogram
-            radix_pass(inv_out, vin, (int)n, shift, pbits, hist, hscan, totals, nullptr, kout, vout, st, fuse->srank,
-                       fuse->sidx, inv_out, fuse->status, fuse->nstatus);
-        else
-            radix_pass(kin, vin, (int)n, shift, pbits, hist, hscan, totals, nullptr, kout, vout, st);
+        radix_pass(kin, vin, (int)n, p * pbits, pbits, hist, hscan, totals, nullptr, kout, vout, st);
         kin = kout;
         vin = vout;
     }
@@ -328,11 +410,16 @@ static int group_impl(const int32_t* inv, int64_t n, int32_t* sorted_pos, int32_
 
 MREC_API int mrec_group_by_inverse(const int32_t* inv, int64_t n, int32_t* sorted_pos, int32_t* sorted_seg,
                                    int32_t* seg_offsets, void* ws, size_t ws_bytes, void* stream) {
-    return group_impl(inv, n, sorted_pos, sorted_seg, seg_offsets, ws, ws_bytes, stream, nullptr, nullptr);
+    return group_impl(inv, n, sorted_pos, sorted_seg, seg_offsets, ws, ws_bytes, stream);
 }
 
 // Unique + inverted index in one call (what a training step needs): the inverse rides on the first
 // radix histogram, saving a pass and a launch over mrec_dedup_* followed by mrec_group_by_inverse.
+static size_t plan_extra_bytes(int64_t n) { return mrec_align_up((size_t)(n ? n : 1) * 4, 256) * 2 + 256; }
+
+// Unique + inverted index in one call (what a training step needs).  First occurrences leave the rank kernel already in
+// group order; only the DUPLICATE positions are sorted by group (their count lives on the device: the radix kernels run
+// over the live tiles only -- a handful on uniform ids), and one placement kernel writes the inverted index.
 template <class K>
 static int plan_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_dev, int32_t* sorted_pos,
                      int32_t* sorted_seg, int32_t* seg_offsets, void* ws, size_t ws_bytes, void* stream, bool primed = false) {
@@ -340,19 +427,66 @@ static int plan_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_
     size_t db = 0, gb = 0;
     int rc = mrec_dedup_workspace_bytes(n, &db);
     if (rc != MREC_OK) return rc;
+    db += plan_extra_bytes(n);
     rc = mrec_group_workspace_bytes(n, &gb);
     if (rc != MREC_OK) return rc;
     if (n > 0 && (!ws || ws_bytes < db + gb)) return MREC_EWORKSPACE;
-    DedupScratch sc{nullptr, nullptr, nullptr, 0};
-    rc = dedup_impl<K>(ids, n, uniq, inv, n_uniq_dev, ws, db, stream, n > 0 ? &sc : nullptr, primed);
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        rc = dedup_impl<K>(ids, n, uniq, inv, n_uniq_dev, ws, db, stream, nullptr, primed);
+        if (rc != MREC_OK) return rc;
+        MREC_HIP_CHECK(hipMemsetAsync(seg_offsets, 0, sizeof(int32_t), st));
+        return MREC_OK;
+    }
+    if (!sorted_pos || !sorted_seg) return MREC_EINVAL;
+    DedupScratch sc{};
+    rc = dedup_impl<K>(ids, n, uniq, inv, n_uniq_dev, ws, db, stream, &sc, primed);
     if (rc != MREC_OK) return rc;
-    return group_impl(nullptr, n, sorted_pos, sorted_seg, seg_offsets, (char*)ws + db, gb, stream, n > 0 ? &sc : nullptr, inv);
+    const int nblk = (int)mrec_cdiv(n, RT);
+    MrecArena a((char*)ws + db, gb);
+    int* hist = a.take<int>((size_t)nblk * RNB);
+    int* hscan = a.take<int>((size_t)nblk * RNB);
+    int* totals = a.take<int>(RNB);
+    int* tk = a.take<int>(n);
+    int* tv = a.take<int>(n);
+    if (!a.ok) return MREC_EWORKSPACE;
+    int bits = 1;
+    while (((int64_t)1 << bits) < n) ++bits;  // group numbers are < n
+    const int passes = (bits + RMAXB - 1) / RMAXB;
+    const int pbits = (bits + passes - 1) / passes;
+    // ping-pong between A = the caller's (sorted_seg, sorted_pos), free until the placement kernel writes them, and
+    // B = (tk, tv); the last pass lands in B.  The generated keys of pass 0 live in the key array pass 0 does not write.
+    const bool first_to_b = ((passes - 1) % 2) == 0;
+    int* kgen = first_to_b ? sorted_seg : tk;
+    // few duplicates: one workgroup sorts them straight into B and zeroes the count the radix passes run on
+    k_plan_small<<<1, 1024, 0, st>>>(sc.slots, sc.sidx, sc.dup_pos, sc.n_dup, inv, tk, tv, sc.n_radix);
+    const int* kin = kgen;
+    const int* vin = sc.dup_pos;
+    for (int p = 0; p < passes; ++p) {
+        const bool to_b = ((passes - 1 - p) % 2) == 0;
+        int* kout = to_b ? tk : sorted_seg;
+        int* vout = to_b ? tv : sorted_pos;
+        const int shift = p * pbits;
+        if (p == 0)      // keys = group of every duplicate = the rank at its scratch slot; also its entry of `inv`
+            radix_pass(kin, vin, (int)n, shift, pbits, hist, hscan, totals, nullptr, kout, vout, st, sc.slots, sc.sidx, kgen,
+                       sc.status, sc.nstatus, sc.dup_pos, inv, sc.n_radix);
+        else
+            radix_pass(kin, vin, (int)n, shift, pbits, hist, hscan, totals, nullptr, kout, vout, st, nullptr, nullptr, nullptr,
+                       nullptr, 0, nullptr, nullptr, sc.n_radix);
+        kin = kout;
+        vin = vout;
+    }
+    k_plan_place<<<(unsigned)mrec_cdiv(n, 256), 256, 0, st>>>(sc.first_pos, n_uniq_dev, tk, tv, sc.n_dup, (int)n, sorted_pos,
+                                                             sorted_seg, seg_offsets);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
 }
 
 MREC_API int mrec_sparse_plan_workspace_bytes(int64_t n, size_t* out) {
     size_t db = 0, gb = 0;
     int rc = mrec_dedup_workspace_bytes(n, &db);
     if (rc != MREC_OK) return rc;
+    db += plan_extra_bytes(n);
     rc = mrec_group_workspace_bytes(n, &gb);
     if (rc != MREC_OK) return rc;
     *out = db + gb;

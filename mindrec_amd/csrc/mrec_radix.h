@@ -15,26 +15,36 @@ constexpr int RNB = 1 << RMAXB;       // max bins
 constexpr int RT = 2048;              // keys per tile: 4 waves x 8 rounds x 64 lanes
 constexpr int RROUNDS = 8;
 
-// When (srank, sidx) are given, the keys are produced here -- keys_out[i] = srank[sidx[i]], the
+// When (slots, sidx, pos, inv) are given, the keys are produced here -- the group of the i-th duplicate, the
 // inverse of the dedup -- instead of being read: the Unique's last pass rides on the first histogram.
 __global__ __launch_bounds__(256) void k_radix_hist(const int* __restrict__ keys, int n, int shift, int nbits,
-                                                    int* __restrict__ hist, const int* __restrict__ srank,
+                                                    int* __restrict__ hist, const int* __restrict__ slots,
                                                     const int* __restrict__ sidx, int* __restrict__ keys_out,
-                                                    unsigned* __restrict__ clear, int nclear) {
+                                                    unsigned* __restrict__ clear, int nclear,
+                                                    const int* __restrict__ pos = nullptr, int* __restrict__ inv_out = nullptr,
+                                                    const int64_t* __restrict__ n_dev = nullptr) {
     __shared__ int h[RNB];
     // (the look-back words the Unique's rank kernel left behind: zeroed here for the next call, no launch of their own)
     for (int j = blockIdx.x * 256 + threadIdx.x; j < nclear; j += gridDim.x * 256) clear[j] = 0;
+    if (n_dev) { const int64_t nd = *n_dev; n = nd < n ? (int)(nd < 0 ? 0 : nd) : n; }      // element count known on the device only
+    const int base = blockIdx.x * RT;
+    if (base >= n) return;                 // (the column scan reads the rows of the live tiles only)
     const int NB = 1 << nbits;
     for (int d = threadIdx.x; d < NB; d += 256) h[d] = 0;
     __syncthreads();
-    const int base = blockIdx.x * RT;
 #pragma unroll
     for (int k = 0; k < RT / 256; ++k) {
         const int i = base + k * 256 + threadIdx.x;
         if (i < n) {
             int key;
-            if (srank) { key = srank[sidx[i]]; keys_out[i] = key; }
-            else key = keys[i];
+            if (slots) {
+                // keys produced here: the group of the i-th duplicate (position pos[i]) = the inverse of the first position of
+                // its key, which its scratch slot still holds; also written as the duplicate's own inverse
+                const int p_ = pos[i];
+                key = inv_out[slots[sidx[p_]]];
+                inv_out[p_] = key;
+                keys_out[i] = key;
+            } else key = keys[i];
             atomicAdd(&h[(key >> shift) & (NB - 1)], 1);
         }
     }
@@ -48,8 +58,14 @@ __global__ __launch_bounds__(256) void k_radix_hist(const int* __restrict__ keys
 // then each thread rewrites its chunk as running prefixes.  2^nbits / 32 blocks instead of
 // 2^nbits / 256 keeps this latency-bound pass off the critical path (11.8 -> ~4 us at 208 tiles).
 __global__ __launch_bounds__(256) void k_radix_colscan(const int* __restrict__ hist, int nblk, int nbits,
-                                                       int* __restrict__ hscan, int* __restrict__ totals) {
+                                                       int* __restrict__ hscan, int* __restrict__ totals,
+                                                       const int64_t* __restrict__ n_dev = nullptr) {
     __shared__ int part[8][32];
+    if (n_dev) {                           // live tiles only
+        const int64_t nd = *n_dev < 0 ? 0 : *n_dev;
+        const int64_t live = (nd + RT - 1) / RT;
+        if (live < nblk) nblk = (int)live;
+    }
     const int NB = 1 << nbits;
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int d = blockIdx.x * 32 + cx;
@@ -95,8 +111,11 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const int* __restrict__ k
                                                        const int* __restrict__ vals_in, int n, int shift,
                                                        int nbits, const int* __restrict__ hist,
                                                        const int* __restrict__ totals, int* __restrict__ keys_out,
-                                                       int* __restrict__ vals_out, int* __restrict__ dbase_out) {
+                                                       int* __restrict__ vals_out, int* __restrict__ dbase_out,
+                                                       const int64_t* __restrict__ n_dev = nullptr) {
     __shared__ int cnt[4][RNB];
+    if (n_dev) { const int64_t nd = *n_dev; n = nd < n ? (int)(nd < 0 ? 0 : nd) : n; }
+    if ((int)blockIdx.x * RT >= n && !(dbase_out && blockIdx.x == 0)) return;
     __shared__ int dbase[RNB];
     __shared__ int sm[8];
     const int NB = 1 << nbits;
@@ -178,13 +197,14 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const int* __restrict__ k
 // means "identity").  hist, hscan: [nblk * 2^nbits] ints each; totals: [2^nbits]; dbase (nullable):
 // [2^nbits] ints, receives the exclusive digit offsets.
 inline void radix_pass(const int* kin, const int* vin, int n, int shift, int nbits, int* hist, int* hscan, int* totals,
-                       int* dbase, int* kout, int* vout, hipStream_t st, const int* srank = nullptr,
-                       const int* sidx = nullptr, int* keys_gen = nullptr, unsigned* clear = nullptr, int nclear = 0) {
+                       int* dbase, int* kout, int* vout, hipStream_t st, const int* slots = nullptr,
+                       const int* sidx = nullptr, int* keys_gen = nullptr, unsigned* clear = nullptr, int nclear = 0,
+                       const int* pos = nullptr, int* inv_out = nullptr, const int64_t* n_dev = nullptr) {
     const int nblk = (int)mrec_cdiv(n, RT);
     const int NB = 1 << nbits;
-    k_radix_hist<<<nblk, 256, 0, st>>>(kin, n, shift, nbits, hist, srank, sidx, keys_gen, clear, nclear);
-    k_radix_colscan<<<(NB + 31) / 32, 256, 0, st>>>(hist, nblk, nbits, hscan, totals);
-    k_radix_scatter<<<nblk, 256, 0, st>>>(kin, vin, n, shift, nbits, hscan, totals, kout, vout, dbase);
+    k_radix_hist<<<nblk, 256, 0, st>>>(kin, n, shift, nbits, hist, slots, sidx, keys_gen, clear, nclear, pos, inv_out, n_dev);
+    k_radix_colscan<<<(NB + 31) / 32, 256, 0, st>>>(hist, nblk, nbits, hscan, totals, n_dev);
+    k_radix_scatter<<<nblk, 256, 0, st>>>(kin, vin, n, shift, nbits, hscan, totals, kout, vout, dbase, n_dev);
 }
 
 }  // namespace
