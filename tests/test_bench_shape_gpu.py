@@ -125,12 +125,14 @@ def test_one_step_layer_by_layer_vs_mixed_oracle(dev, oracle, dt):
 
 
 @pytest.mark.timeout(1200)
-def test_free_running_steps_with_graphs_vs_mixed_oracle(dev, oracle):
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_free_running_steps_with_graphs_vs_mixed_oracle(dev, oracle, dt):
+    """bf16 (bench.py's default) and the reference's own fp16 (wide_and_deep.py:119-128), both at the full bench batch."""
     from _oracle_mixed import OracleMixedEngine
     from mindrec_amd.wide_deep import WideDeepEngine, synthetic_batch
-    cfg = _cfg("bf16")
+    cfg = _cfg(dt)
     g = WideDeepEngine(cfg, dev)
-    o = OracleMixedEngine(cfg, "bf16")
+    o = OracleMixedEngine(cfg, dt)
     steps = 5
     lg, lo = [], []
     for s in range(steps):
