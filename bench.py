@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--fields", type=int, default=26, help="26 = north-star categorical slots; 39 = reference field_size")
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--mlp-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dropout", action="store_true", help="dropout_flag: True as in benchmarks/wide_deep/default_config.yaml:15 (Dropout(0.5) on every "
+                    "DenseLayer input; models/wide_deep/default_config.yaml:27, the configuration of configs[1], has it off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of each cpu_baseline leg")
     ap.add_argument("--n-batches", type=int, default=4, help="distinct resident batches cycled through")
@@ -230,7 +232,7 @@ def main():
                          dynamic_embedding=args.dynamic_embedding, hash_capacity=args.hash_capacity,
                          host_cache_rows=args.host_cache_rows, early_route=not args.no_early_route,
                          late_wide={'auto': None, 'on': True, 'off': False}[args.late_wide],
-                         overlap_wide_apply=not args.no_overlap_wide_apply)
+                         overlap_wide_apply=not args.no_overlap_wide_apply, dropout_flag=args.dropout)
     eng = WideDeepEngine(cfg, dev, rank=rank, world=world, shard_protocol=args.shard_protocol)
     batches = [synthetic_batch(cfg, dev, args.dist, seed=1000 + i, rank=rank) for i in range(args.n_batches)]
     torch.cuda.synchronize()
@@ -371,7 +373,8 @@ def main():
                                f"layout), {args.dist} ids{', hash tables keyed by id (dynamic_embedding)' if args.dynamic_embedding else ''}"
                                f"{f', tables in host DRAM behind a {args.host_cache_rows}-row device cache' if args.host_cache_rows else ''}, "
                                f"MLP {cfg.field_size * cfg.emb_dim}-1024-512-256-128-1 in {args.mlp_dtype} "
-                               f"({'hand-written MFMA kernels' if eng._mfma else 'torch GEMMs'}; looked-up rows and row gradients in {dt_name})",
+                               f"({'hand-written MFMA kernels' if eng._mfma else 'torch GEMMs'}; looked-up rows and row gradients in {dt_name})"
+                               f"{', Dropout(0.5) on every DenseLayer input' if args.dropout else ''}",
                    "global_batch": args.batch * world, "id_dist": args.dist, "hip_graphs": graphs_used, "unique_frac": round(U / max(n_apply, 1), 4),
                    "parallelism": ("1 GPU" + (", row-shard protocol over RCCL with itself" if args.shard_protocol else "")) if world == 1 else f"tables row-sharded x{world} (RCCL all-to-all), MLP dp{world}"},
         "roofline": {"bound": "hbm",

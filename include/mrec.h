@@ -285,27 +285,56 @@ int mrec_dense_ftrl_f32(float* var, float* accum, float* linear, const float* g,
  * `_f16`: IEEE half, the reference's dtype), fp32 accumulation, one rounding of the result.  All matrices row-major with
  * row strides in elements; x / dy / w 16-byte aligned, strides multiples of 8.
  *
+ * Dropout (wide_and_deep.py:98,117-118: `x = self.dropout(x)` on the INPUT of every DenseLayer while training,
+ * Dropout(p = 1 - keep_prob)): the mask is a pure function of (seed, step, layer, sample row, column) -- spec in
+ * csrc/mrec_dropout.h, restated by the oracle -- so nothing is stored between forward and backward and a captured step
+ * replays with a moving step.  A descriptor names the DenseLayer whose [M, W] input is dropped out:
+ *   keep(r, c)  <=>  bits16(seed, step, layer, row0 + r, c; W) < round(keep_prob * 65536);  kept: x * (1 / keep_prob), else 0.
+ * step_state (nullable): an mrec_step_state_t in device memory whose `step` is used instead of `step`. keep_prob in (0, 1]
+ * (1: identity); layer in [0, 16); W % 4 == 0. */
+typedef struct mrec_dropout {
+    const void* step_state;
+    uint64_t seed;
+    int64_t step;
+    int64_t row0;      /* global sample index of row 0 (a data-parallel rank: rank * local batch) */
+    int32_t layer;
+    float keep_prob;
+} mrec_dropout_t;
+/* y = Dropout(x) for a [M, W] matrix, kind 0: fp32, 1: bfloat16, 2: IEEE half (the product is rounded once to the kind);
+ * y == x allowed.  Being its own bprop, the same call maps dy to dx.  Used for the first layer's input (the looked-up
+ * rows) and by the fp32 net; the hidden layers of the 16-bit net get theirs in the GEMM epilogues below. */
+int mrec_dropout(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t kind, int64_t M, int32_t W,
+                 const mrec_dropout_t* drop, void* stream);
+/* the mask alone, as fp32 {0, 1 / keep_prob} (tests; the autograd fp32 net multiplies by it) */
+int mrec_dropout_mask_f32(float* mask, int64_t ld, int64_t M, int32_t W, const mrec_dropout_t* drop, void* stream);
+/*
  * forward:  y[M, N] = act(x[M, K] . w[K, N] + bias[N])   bias fp32 (nullable), relu != 0 applies max(., 0);
- *           K % 8 == 0, N % 8 == 0.  w is the weight as the reference stores it ([in, out], :100-103). */
+ *           K % 8 == 0, N % 8 == 0.  w is the weight as the reference stores it ([in, out], :100-103).
+ *           drop_next (nullable): y is the input of DenseLayer drop_next->layer -- y = Dropout(round16(act(.))), W = N. */
 int mrec_dense_fwd_bf16(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bias, int64_t M, int32_t K,
-                        int32_t N, int relu, uint16_t* y, int64_t ldy, void* stream);
+                        int32_t N, int relu, uint16_t* y, int64_t ldy, const mrec_dropout_t* drop_next, void* stream);
 int mrec_dense_fwd_f16(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bias, int64_t M, int32_t K,
-                       int32_t N, int relu, uint16_t* y, int64_t ldy, void* stream);
+                       int32_t N, int relu, uint16_t* y, int64_t ldy, const mrec_dropout_t* drop_next, void* stream);
 /* bprop with respect to the layer's input, fused with the ReLU and BiasAdd bprops of the layer BELOW:
  *   dx[m, k] = h[m, k] > 0 ? sum_n dy[m, n] * w[k, n] : 0      (h nullable: no mask -- the first layer's input)
  *   db[k]    = sum_m dx[m, k]                                  (db nullable; sums of the rounded dx, fp32, fixed order)
  * N % 8 == 0, K % 4 == 0.  ws: mrec_dense_bwd_input_workspace_bytes(M, K) bytes when db != NULL.  With db == NULL and
  * ws != NULL the per-tile-row column sums are left in ws as T fp32 slabs of K (T from mrec_dense_bwd_bias_slabs);
- * mrec_dense_adam_slabs_f32 / mrec_dense_sum_slabs_f32 add them up in slab order. */
+ * mrec_dense_adam_slabs_f32 / mrec_dense_sum_slabs_f32 add them up in slab order.
+ * drop_in (nullable): this layer's input went through Dropout (W = K): dx is the gradient of the value BEFORE it --
+ * (sum) * (1 / keep_prob), then masked: by h > 0 when h is given (h is the dropped-out activation: its zeros are the ReLU's
+ * and the mask's), by the mask function itself otherwise. */
 int mrec_dense_bwd_input_workspace_bytes(int64_t M, int32_t K, size_t* out);
 /* Rows T of the bias-gradient slabs [T, K] that mrec_dense_bwd_* (fused != 0) or mrec_dense_bwd_input_* (fused == 0) with
  * db == NULL leave in ws for this shape on this device: one per row tile of the configuration the library picks
  * (256 or 128 batch rows per tile). */
 int mrec_dense_bwd_bias_slabs(int64_t M, int32_t K, int32_t N, int fused, int32_t* rows_out);
 int mrec_dense_bwd_input_bf16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M, int32_t K,
-                              int32_t N, uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, void* stream);
+                              int32_t N, uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes,
+                              const mrec_dropout_t* drop_in, void* stream);
 int mrec_dense_bwd_input_f16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M, int32_t K,
-                             int32_t N, uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, void* stream);
+                             int32_t N, uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes,
+                             const mrec_dropout_t* drop_in, void* stream);
 /* bprop with respect to the weight: dw[K, N] = x[M, K]^T . dy[M, N], the batch cut in S slabs whose fp32 partial sums
  * are written to dw_slabs[S, K, N] (slab s = rows [s*c, (s+1)*c) of the batch, c = 64*ceil(ceil(M/64)/S)); the
  * optimizer adds them up (mrec_dense_adam_slabs_f32).  mrec_dense_bwd_weight_slabs proposes S for this device.
@@ -322,10 +351,10 @@ int mrec_dense_bwd_weight_f16(const uint16_t* x, int64_t ldx, const uint16_t* dy
  * below has a ReLU to back-propagate through.  M > 0. */
 int mrec_dense_bwd_bf16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x, int64_t ldx,
                         int64_t M, int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_slabs, size_t db_slabs_bytes,
-                        int32_t S, float* dw_slabs, void* stream);
+                        int32_t S, float* dw_slabs, const mrec_dropout_t* drop_in, void* stream);
 int mrec_dense_bwd_f16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x, int64_t ldx,
                        int64_t M, int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_slabs, size_t db_slabs_bytes,
-                       int32_t S, float* dw_slabs, void* stream);
+                       int32_t S, float* dw_slabs, const mrec_dropout_t* drop_in, void* stream);
 /* out[e] = sum over s < S of slabs[s*len + e], in slab order: the weight gradient as one tensor, for consumers other than
  * mrec_dense_adam_slabs_f32 (the data-parallel all-reduce).  len % 4 == 0, 16-byte aligned. */
 int mrec_dense_sum_slabs_f32(const float* slabs, int32_t S, int64_t len, float* out, void* stream);
@@ -336,15 +365,16 @@ int mrec_dense_sum_slabs_f32(const float* slabs, int32_t S, int64_t len, float* 
  * (= sens / B):   logit[b] = h4[b,:].w5 + b5 + wide[b];  loss = mean_b BCE(logit, label);
  *   dlogit[b] = (sigmoid(logit[b]) - label[b]) * dscale;   dh4[b,k] = h4[b,k] > 0 ? dlogit[b] * w5[k] : 0;
  *   dw5[k] = sum_b h4[b,k] * dlogit[b];  db5 = sum_b dlogit[b];  db4[k] = sum_b dh4[b,k].
+ * dh_scale: 1, or 1 / keep_prob when h4 went through Dropout (its zeros then carry the mask): dh4 = (dlogit * w5) * dh_scale.
  * K5 / 8 must be a power of two <= 64. */
 int mrec_head_workspace_bytes(int64_t B, int32_t K5, size_t* out);
 int mrec_head_fwd_bwd_bf16(const uint16_t* h4, const float* w5, const float* b5, const float* wide,
-                           const float* label, int64_t B, int32_t K5, float dscale, float* logit, float* dlogit,
+                           const float* label, int64_t B, int32_t K5, float dscale, float dh_scale, float* logit, float* dlogit,
                            uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss, void* ws,
                            size_t ws_bytes, void* stream);
 /* the same with IEEE half activations (the reference's mixed-precision dtype, wide_and_deep.py:119-128) */
 int mrec_head_fwd_bwd_f16(const uint16_t* h4, const float* w5, const float* b5, const float* wide,
-                          const float* label, int64_t B, int32_t K5, float dscale, float* logit, float* dlogit,
+                          const float* label, int64_t B, int32_t K5, float dscale, float dh_scale, float* logit, float* dlogit,
                           uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss, void* ws,
                           size_t ws_bytes, void* stream);
 
@@ -353,7 +383,7 @@ int mrec_head_fwd_bwd_f16(const uint16_t* h4, const float* w5, const float* b5, 
  * dwide_bias (nullable): receives d loss / d wide_bias = sum of dlogit (the value db5 gets), so that "Wide_b", which the
  * reference's deep optimizer owns (wide_and_deep.py:407-411), has its gradient in place without a copy. */
 int mrec_head_fwd_bwd_wide(int32_t f16, const uint16_t* h4, const float* w5, const float* b5, const float* wide_prod, int32_t F,
-                           const float* wide_bias, const float* label, int64_t B, int32_t K5, float dscale, float* logit,
+                           const float* wide_bias, const float* label, int64_t B, int32_t K5, float dscale, float dh_scale, float* logit,
                            float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* dwide_bias, float* loss,
                            void* ws, size_t ws_bytes, void* stream);
 

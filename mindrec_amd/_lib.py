@@ -56,7 +56,7 @@ _SIGS = {
     "mrec_step_state_init": [_vp, _f32, _f32, _i64, _vp],
     "mrec_step_advance": [_vp, _f32, _f32, _f32, _vp],
     "mrec_wall_clock_khz": [_vp],
-    "mrec_head_fwd_bwd_wide": [_i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_head_fwd_bwd_wide": [_i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_wide_sum_f32_i32": [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_wide_sum_f32_i64": [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_sparse_apply_workspace_bytes": [_i64, _i32, _szp],
@@ -83,22 +83,24 @@ _SIGS = {
     "mrec_dense_sum_slab_segments_f32": [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp],
     "mrec_dense_adam_slabs_f32": [_vp, _vp, _vp, _vp, _vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32,
                                   _f32, _int, _vp, _vp],
-    "mrec_dense_fwd_bf16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp],
-    "mrec_dense_fwd_f16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp],
+    "mrec_dense_fwd_bf16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp, _vp],
+    "mrec_dense_fwd_f16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp, _vp],
     "mrec_dense_bwd_input_workspace_bytes": [_i64, _i32, _szp],
     "mrec_dense_bwd_bias_slabs": [_i64, _i32, _i32, _int, C.POINTER(C.c_int32)],
-    "mrec_dense_bwd_input_bf16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp],
-    "mrec_dense_bwd_input_f16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp],
+    "mrec_dense_bwd_input_bf16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp, _vp],
+    "mrec_dense_bwd_input_f16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp, _vp],
     "mrec_dense_bwd_weight_slabs": [_i64, _i32, _i32, C.POINTER(C.c_int32)],
     "mrec_dense_bwd_weight_bf16": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp],
-    "mrec_dense_bwd_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _sz, _i32, _vp, _vp],
-    "mrec_dense_bwd_f16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _sz, _i32, _vp, _vp],
+    "mrec_dense_bwd_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _sz, _i32, _vp, _vp, _vp],
+    "mrec_dense_bwd_f16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _sz, _i32, _vp, _vp, _vp],
+    "mrec_dropout": [_vp, _i64, _vp, _i64, _i32, _i64, _i32, _vp, _vp],
+    "mrec_dropout_mask_f32": [_vp, _i64, _i64, _i32, _vp, _vp],
     "mrec_dense_sum_slabs_f32": [_vp, _i32, _i64, _vp, _vp],
     "mrec_dense_bwd_weight_f16": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp],
     "mrec_dense_ftrl_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp],
     "mrec_head_workspace_bytes": [_i64, _i32, _szp],
-    "mrec_head_fwd_bwd_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
-    "mrec_head_fwd_bwd_f16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_head_fwd_bwd_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_head_fwd_bwd_f16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_map_bytes": [_i64, _szp],
     "mrec_map_create": [C.POINTER(_vp), _vp, _sz, _i64, _vp],
     "mrec_map_destroy": [_vp],

@@ -73,8 +73,10 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const float4* __restrict__ sl
 
 template <bool F16>
 int fwd_impl(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bias, int64_t M, int32_t K, int32_t N, int relu,
-             uint16_t* y, int64_t ldy, void* stream) {
+             uint16_t* y, int64_t ldy, const mrec_dropout_t* drop, void* stream) {
     if (M < 0 || K <= 0 || N <= 0 || ldx < K || ldy < N) return MREC_EINVAL;
+    DropArgs da;
+    if (!drop_from(drop, N, &da)) return MREC_EINVAL;
     if (M == 0) return MREC_OK;
     if (!x || !w || !y) return MREC_EINVAL;
     if (K % 8 || N % 8 || ldx % 8 || ldy % 4 || !al16(x) || !al16(w) || (((uintptr_t)y) & 7)) return MREC_EUNSUPPORTED;
@@ -87,6 +89,7 @@ int fwd_impl(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bia
     a.nTp = (int)mrec_cdiv(M, mr * 32); a.nTq = (int)mrec_cdiv(N, 256);
     a.kt_per_slab = (K + 63) / 64;
     a.relu = relu;
+    a.drop = da;
     if (mr == 8) mgemm::k_gemm256<false, true, mgemm::EPI_FWD, F16, 0, 8><<<a.nTp * a.nTq, mgemm::kThreads, 0, (hipStream_t)stream>>>(a);
     else mgemm::k_gemm256<false, true, mgemm::EPI_FWD, F16, 0, 4><<<a.nTp * a.nTq, mgemm::kThreads, 0, (hipStream_t)stream>>>(a);
     MREC_LAUNCH_CHECK();
@@ -95,8 +98,10 @@ int fwd_impl(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bia
 
 // argument checks + Args of the two bprops (shared by the separate and the fused entry points)
 int bwd_input_args(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M, int32_t K, int32_t N,
-                   uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, int mr, Args* out) {
+                   uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, int mr, const mrec_dropout_t* drop, Args* out) {
     if (M <= 0 || K <= 0 || N <= 0 || lddy < N || lddx < K) return MREC_EINVAL;
+    DropArgs da;
+    if (!drop_from(drop, K, &da)) return MREC_EINVAL;
     if (!dy || !w || !dx) return MREC_EINVAL;
     if (N % 8 || K % 4 || lddy % 8 || lddx % 4 || !al16(dy) || !al16(w) || (((uintptr_t)dx) & 7) || (h && (((uintptr_t)h) & 7)))
         return MREC_EUNSUPPORTED;
@@ -113,6 +118,7 @@ int bwd_input_args(const uint16_t* dy, int64_t lddy, const uint16_t* w, const ui
     a.Pext = (int)M; a.Qext = K; a.K = N;
     a.nTp = nTp; a.nTq = (int)mrec_cdiv(K, 256);
     a.kt_per_slab = (N + 63) / 64;
+    a.drop = da;
     *out = a;
     return MREC_OK;
 }
@@ -137,14 +143,14 @@ int bwd_weight_args(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t 
 
 template <bool F16>
 int bwd_input_impl(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M, int32_t K, int32_t N,
-                   uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, void* stream) {
+                   uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes, const mrec_dropout_t* drop, void* stream) {
     if (M == 0 && K > 0) {
         if (db) MREC_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)K * 4, (hipStream_t)stream));
         return MREC_OK;
     }
     Args a;
     const int mr = bwd_input_mr(M, K);
-    const int rc = bwd_input_args(dy, lddy, w, h, M, K, N, dx, lddx, db, ws, ws_bytes, mr, &a);
+    const int rc = bwd_input_args(dy, lddy, w, h, M, K, N, dx, lddx, db, ws, ws_bytes, mr, drop, &a);
     if (rc != MREC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (mr == 8) mgemm::k_gemm256<false, false, mgemm::EPI_DGRAD, F16, 0, 8><<<a.nTp * a.nTq, mgemm::kThreads, 0, st>>>(a);
@@ -197,10 +203,11 @@ int bwd_weight_impl(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t 
 
 template <bool F16>
 int bwd_impl(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x, int64_t ldx, int64_t M,
-             int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_ws, size_t db_ws_bytes, int32_t S, float* dw, void* stream) {
+             int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_ws, size_t db_ws_bytes, int32_t S, float* dw,
+             const mrec_dropout_t* drop, void* stream) {
     Args ad, aw;
     const int mrd = bwd_input_mr(M, K), mrw = bwd_mr(M, K, N);
-    int rc = bwd_input_args(dy, lddy, w, h, M, K, N, dx, lddx, nullptr, db_ws, db_ws_bytes, mrd, &ad);
+    int rc = bwd_input_args(dy, lddy, w, h, M, K, N, dx, lddx, nullptr, db_ws, db_ws_bytes, mrd, drop, &ad);
     if (rc != MREC_OK) return rc;
     rc = bwd_weight_args(x, ldx, dy, lddy, M, K, N, S, dw, mrw, &aw);
     if (rc != MREC_OK) return rc;
@@ -220,12 +227,12 @@ int bwd_impl(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t
 }  // namespace
 
 MREC_API int mrec_dense_fwd_bf16(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bias, int64_t M, int32_t K,
-                                 int32_t N, int relu, uint16_t* y, int64_t ldy, void* stream) {
-    return fwd_impl<false>(x, ldx, w, bias, M, K, N, relu, y, ldy, stream);
+                                 int32_t N, int relu, uint16_t* y, int64_t ldy, const mrec_dropout_t* drop_next, void* stream) {
+    return fwd_impl<false>(x, ldx, w, bias, M, K, N, relu, y, ldy, drop_next, stream);
 }
 MREC_API int mrec_dense_fwd_f16(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bias, int64_t M, int32_t K,
-                                int32_t N, int relu, uint16_t* y, int64_t ldy, void* stream) {
-    return fwd_impl<true>(x, ldx, w, bias, M, K, N, relu, y, ldy, stream);
+                                int32_t N, int relu, uint16_t* y, int64_t ldy, const mrec_dropout_t* drop_next, void* stream) {
+    return fwd_impl<true>(x, ldx, w, bias, M, K, N, relu, y, ldy, drop_next, stream);
 }
 
 MREC_API int mrec_dense_bwd_input_workspace_bytes(int64_t M, int32_t K, size_t* out) {
@@ -243,13 +250,13 @@ MREC_API int mrec_dense_bwd_bias_slabs(int64_t M, int32_t K, int32_t N, int fuse
 }
 MREC_API int mrec_dense_bwd_input_bf16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M,
                                        int32_t K, int32_t N, uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes,
-                                       void* stream) {
-    return bwd_input_impl<false>(dy, lddy, w, h, M, K, N, dx, lddx, db, ws, ws_bytes, stream);
+                                       const mrec_dropout_t* drop_in, void* stream) {
+    return bwd_input_impl<false>(dy, lddy, w, h, M, K, N, dx, lddx, db, ws, ws_bytes, drop_in, stream);
 }
 MREC_API int mrec_dense_bwd_input_f16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, int64_t M,
                                       int32_t K, int32_t N, uint16_t* dx, int64_t lddx, float* db, void* ws, size_t ws_bytes,
-                                      void* stream) {
-    return bwd_input_impl<true>(dy, lddy, w, h, M, K, N, dx, lddx, db, ws, ws_bytes, stream);
+                                      const mrec_dropout_t* drop_in, void* stream) {
+    return bwd_input_impl<true>(dy, lddy, w, h, M, K, N, dx, lddx, db, ws, ws_bytes, drop_in, stream);
 }
 
 MREC_API int mrec_dense_bwd_weight_slabs(int64_t M, int32_t K, int32_t N, int32_t* S_out) {
@@ -281,11 +288,11 @@ MREC_API int mrec_dense_sum_slabs_f32(const float* slabs, int32_t S, int64_t len
 /* both bprops of one layer in one launch (see include/mrec.h) */
 MREC_API int mrec_dense_bwd_bf16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x,
                                  int64_t ldx, int64_t M, int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_slabs,
-                                 size_t db_slabs_bytes, int32_t S, float* dw_slabs, void* stream) {
-    return bwd_impl<false>(dy, lddy, w, h, x, ldx, M, K, N, dx, lddx, db_slabs, db_slabs_bytes, S, dw_slabs, stream);
+                                 size_t db_slabs_bytes, int32_t S, float* dw_slabs, const mrec_dropout_t* drop_in, void* stream) {
+    return bwd_impl<false>(dy, lddy, w, h, x, ldx, M, K, N, dx, lddx, db_slabs, db_slabs_bytes, S, dw_slabs, drop_in, stream);
 }
 MREC_API int mrec_dense_bwd_f16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x,
                                 int64_t ldx, int64_t M, int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_slabs,
-                                size_t db_slabs_bytes, int32_t S, float* dw_slabs, void* stream) {
-    return bwd_impl<true>(dy, lddy, w, h, x, ldx, M, K, N, dx, lddx, db_slabs, db_slabs_bytes, S, dw_slabs, stream);
+                                size_t db_slabs_bytes, int32_t S, float* dw_slabs, const mrec_dropout_t* drop_in, void* stream) {
+    return bwd_impl<true>(dy, lddy, w, h, x, ldx, M, K, N, dx, lddx, db_slabs, db_slabs_bytes, S, dw_slabs, drop_in, stream);
 }

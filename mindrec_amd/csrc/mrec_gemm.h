@@ -32,6 +32,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "mrec_dropout.h"
 
 namespace mgemm {
 
@@ -63,6 +64,9 @@ struct Args {
     int kt_per_slab;        // K-tiles per split slab (grid has nTp * nTq * S workgroups; no split: all of them)
     int64_t slab_stride;    // elements between consecutive slabs of C
     int relu;               // EPI_FWD
+    DropArgs drop;          // thresh != 0: Dropout on the layer input this launch produces (EPI_FWD: C is the next layer's input,
+                            // masked and scaled after the rounding; EPI_DGRAD: C is the gradient of this layer's dropped-out
+                            // input -- scaled, and masked by the hash when there is no H whose zeros already carry the mask)
 };
 
 template <bool F16> struct Elem;
@@ -397,6 +401,8 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
         }
     } else {
         uint16_t* C = (uint16_t*)a.C;
+        const bool drop = a.drop.thresh != 0;
+        const uint64_t dkey = drop ? drop_key(a.drop) : 0ull;
         float bq[4][4];
         if (EPI == EPI_FWD) {
 #pragma unroll
@@ -428,7 +434,22 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
                         if (a.relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
                     }
                 }
+                if (EPI == EPI_DGRAD && drop) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= a.drop.scale;
+                }
                 u32x2_t o = {E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
+                if (drop && (EPI == EPI_FWD || a.H == nullptr)) {
+                    const uint64_t qd = drop_quad(dkey, a.drop.row0 + p, a.Qext, q);
+                    if (EPI == EPI_FWD) {        // Dropout acts on the stored (rounded) activation: x * (1 / keep), rounded again
+                        o[0] = E::pack2(E::widen(o[0] & 0xFFFFu) * a.drop.scale, E::widen(o[0] >> 16) * a.drop.scale);
+                        o[1] = E::pack2(E::widen(o[1] & 0xFFFFu) * a.drop.scale, E::widen(o[1] >> 16) * a.drop.scale);
+                    }
+                    if (!drop_keep(qd, 0, a.drop.thresh)) o[0] &= 0xFFFF0000u;
+                    if (!drop_keep(qd, 1, a.drop.thresh)) o[0] &= 0x0000FFFFu;
+                    if (!drop_keep(qd, 2, a.drop.thresh)) o[1] &= 0xFFFF0000u;
+                    if (!drop_keep(qd, 3, a.drop.thresh)) o[1] &= 0x0000FFFFu;
+                }
                 if (EPI == EPI_DGRAD) {
                     if (a.H != nullptr) {
                         u32x2_t hb = {0u, 0u};

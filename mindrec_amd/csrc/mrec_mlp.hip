@@ -12,6 +12,7 @@
 // It reduces over the batch with per-block partials written to a workspace and a second tiny kernel
 // that adds the partials in block order: bitwise reproducible, no float atomics.
 #include "mrec_common.h"
+#include "mrec_dropout.h"
 
 namespace {
 
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(MB) void k_head_fwd_bwd(const uint4* __restrict__ h
                                                      int rows_per_block, float dscale, float* __restrict__ logit_out,
                                                      float* __restrict__ dlogit_out, uint4* __restrict__ dh4,
                                                      float* __restrict__ partial, const float* __restrict__ wprod, int F,
-                                                     const float* __restrict__ wide_bias) {
+                                                     const float* __restrict__ wide_bias, float dh_scale) {
     __shared__ float red[MB][8];
     __shared__ float red2[MB][2];
     const int cg = threadIdx.x % CG, rl = threadIdx.x / CG, RP = MB / CG;
@@ -158,7 +159,8 @@ __global__ __launch_bounds__(MB) void k_head_fwd_bwd(const uint4* __restrict__ h
             float o[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                o[k] = fh[k] > 0.0f ? dl * w[k] : 0.0f;      // d h4 through the last layer, masked by its ReLU
+                // d h4 through the last layer, masked by its ReLU (and, where h4 went through Dropout, by that mask: its zeros)
+                o[k] = fh[k] > 0.0f ? (dl * w[k]) * dh_scale : 0.0f;
                 accw[k] += fh[k] * dl;
                 accd[k] += o[k];
             }
@@ -239,11 +241,11 @@ MREC_API int mrec_head_workspace_bytes(int64_t B, int32_t K5, size_t* out) {
 }
 
 static int head_impl(bool f16, const uint16_t* h4, const float* w5, const float* b5, const float* wide,
-                     const float* label, int64_t B, int32_t K5, float dscale, float* logit,
+                     const float* label, int64_t B, int32_t K5, float dscale, float dh_scale, float* logit,
                      float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
                      void* ws, size_t ws_bytes, void* stream, const float* wprod = nullptr, int F = 0,
                      const float* wide_bias = nullptr, float* dwide_b = nullptr) {
-    if (B <= 0 || K5 <= 0) return MREC_EINVAL;
+    if (B <= 0 || K5 <= 0 || !(dh_scale >= 1.0f)) return MREC_EINVAL;
     if (wprod && (F <= 0 || !wide_bias)) return MREC_EINVAL;
     if (!h4 || !w5 || !b5 || (!wide && !wprod) || !label || !logit || !dlogit || !dh4 || !dw5 || !db4 || !db5 || !loss || !ws) return MREC_EINVAL;
     if (K5 % 8 || !pow2(K5 / 8) || K5 / 8 > 64) return MREC_EUNSUPPORTED;
@@ -256,34 +258,126 @@ static int head_impl(bool f16, const uint16_t* h4, const float* w5, const float*
     hipStream_t st = (hipStream_t)stream;
     if (f16)
         k_head_fwd_bwd<true><<<nb, MB, 0, st>>>((const uint4*)h4, w5, b5, wide, label, B, CG, rows_per_block, dscale, logit, dlogit,
-                                                (uint4*)dh4, (float*)ws, wprod, F, wide_bias);
+                                                (uint4*)dh4, (float*)ws, wprod, F, wide_bias, dh_scale);
     else
         k_head_fwd_bwd<false><<<nb, MB, 0, st>>>((const uint4*)h4, w5, b5, wide, label, B, CG, rows_per_block, dscale, logit, dlogit,
-                                                 (uint4*)dh4, (float*)ws, wprod, F, wide_bias);
+                                                 (uint4*)dh4, (float*)ws, wprod, F, wide_bias, dh_scale);
     k_head_finish<<<(unsigned)mrec_cdiv(2 * K5 + 2, 32), MB, 0, st>>>((const float*)ws, nb, K5, 1.0f / (float)B, dw5, db4, db5, loss, dwide_b);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
 
 MREC_API int mrec_head_fwd_bwd_bf16(const uint16_t* h4, const float* w5, const float* b5, const float* wide,
-                                    const float* label, int64_t B, int32_t K5, float dscale, float* logit,
+                                    const float* label, int64_t B, int32_t K5, float dscale, float dh_scale, float* logit,
                                     float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
                                     void* ws, size_t ws_bytes, void* stream) {
-    return head_impl(false, h4, w5, b5, wide, label, B, K5, dscale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes, stream);
+    return head_impl(false, h4, w5, b5, wide, label, B, K5, dscale, dh_scale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes, stream);
 }
 
 MREC_API int mrec_head_fwd_bwd_f16(const uint16_t* h4, const float* w5, const float* b5, const float* wide,
-                                   const float* label, int64_t B, int32_t K5, float dscale, float* logit,
+                                   const float* label, int64_t B, int32_t K5, float dscale, float dh_scale, float* logit,
                                    float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
                                    void* ws, size_t ws_bytes, void* stream) {
-    return head_impl(true, h4, w5, b5, wide, label, B, K5, dscale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes, stream);
+    return head_impl(true, h4, w5, b5, wide, label, B, K5, dscale, dh_scale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes, stream);
 }
 
 /* The same head with the wide branch given as per-field products [B, F] + the wide bias (see include/mrec.h). */
 MREC_API int mrec_head_fwd_bwd_wide(int32_t f16, const uint16_t* h4, const float* w5, const float* b5, const float* wide_prod,
                                     int32_t F, const float* wide_bias, const float* label, int64_t B, int32_t K5, float dscale,
-                                    float* logit, float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* dwide_bias,
+                                    float dh_scale, float* logit, float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* dwide_bias,
                                     float* loss, void* ws, size_t ws_bytes, void* stream) {
-    return head_impl(f16 != 0, h4, w5, b5, nullptr, label, B, K5, dscale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes,
+    return head_impl(f16 != 0, h4, w5, b5, nullptr, label, B, K5, dscale, dh_scale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes,
                      stream, wide_prod, F, wide_bias, dwide_bias);
+}
+
+// ---- Dropout as a pass of its own (spec: mrec_dropout.h): the first DenseLayer's input (the looked-up rows) and the fp32 net --
+namespace {
+template <int KIND>      // 0: fp32, 1: bfloat16, 2: IEEE half
+__global__ __launch_bounds__(256) void k_dropout(const void* __restrict__ x, int64_t ldx, void* __restrict__ y, int64_t ldy, int64_t M,
+                                                 int W, DropArgs d) {
+    const uint64_t key = drop_key(d);
+    const int W4 = W >> 2;
+    const int64_t nq = M * W4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nq; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / W4;
+        const int c = (int)(i - r * W4) * 4;
+        const uint64_t qd = drop_quad(key, d.row0 + r, W, c);
+        float v[4];
+        if (KIND == 0) {
+            const float4 t = *(const float4*)((const float*)x + r * ldx + c);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+            const uint2 t = *(const uint2*)((const uint16_t*)x + r * ldx + c);
+            const uint32_t b[4] = {t.x & 0xFFFFu, t.x >> 16, t.y & 0xFFFFu, t.y >> 16};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v[j] = KIND == 1 ? __uint_as_float(b[j] << 16) : (float)__builtin_bit_cast(_Float16, (uint16_t)b[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = drop_keep(qd, j, d.thresh) ? v[j] * d.scale : 0.0f;
+        if (KIND == 0) {
+            *(float4*)((float*)y + r * ldy + c) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            uint32_t b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (KIND == 1) b[j] = f2bf(v[j]);
+                else b[j] = __builtin_bit_cast(uint16_t, (_Float16)v[j]);
+            }
+            *(uint2*)((uint16_t*)y + r * ldy + c) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_dropout_mask(float* __restrict__ mask, int64_t ld, int64_t M, int W, DropArgs d) {
+    const uint64_t key = drop_key(d);
+    const int W4 = W >> 2;
+    const int64_t nq = M * W4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nq; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / W4;
+        const int c = (int)(i - r * W4) * 4;
+        const uint64_t qd = d.thresh ? drop_quad(key, d.row0 + r, W, c) : 0ull;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = d.thresh == 0 ? 1.0f : (drop_keep(qd, j, d.thresh) ? d.scale : 0.0f);
+        *(float4*)(mask + r * ld + c) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+}  // namespace
+
+MREC_API int mrec_dropout(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t kind, int64_t M, int32_t W,
+                          const mrec_dropout_t* drop, void* stream) {
+    if (M < 0 || W <= 0 || ldx < W || ldy < W || kind < 0 || kind > 2 || !drop) return MREC_EINVAL;
+    DropArgs d;
+    if (!drop_from(drop, W, &d)) return MREC_EINVAL;
+    if (M == 0) return MREC_OK;
+    if (!x || !y) return MREC_EINVAL;
+    const int al = kind == 0 ? 15 : 7;
+    if (ldx % 4 || ldy % 4 || (((uintptr_t)x | (uintptr_t)y) & al)) return MREC_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (d.thresh == 0) {             // keep_prob 1: the identity
+        if (x != y) MREC_HIP_CHECK(hipMemcpy2DAsync(y, (size_t)ldy * (kind ? 2 : 4), x, (size_t)ldx * (kind ? 2 : 4),
+                                                    (size_t)W * (kind ? 2 : 4), (size_t)M, hipMemcpyDeviceToDevice, st));
+        return MREC_OK;
+    }
+    const int64_t nq = M * (W / 4);
+    const unsigned g = (unsigned)(mrec_cdiv(nq, 256) < 8192 ? mrec_cdiv(nq, 256) : 8192);
+    if (kind == 0) k_dropout<0><<<g, 256, 0, st>>>(x, ldx, y, ldy, M, W, d);
+    else if (kind == 1) k_dropout<1><<<g, 256, 0, st>>>(x, ldx, y, ldy, M, W, d);
+    else k_dropout<2><<<g, 256, 0, st>>>(x, ldx, y, ldy, M, W, d);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+MREC_API int mrec_dropout_mask_f32(float* mask, int64_t ld, int64_t M, int32_t W, const mrec_dropout_t* drop, void* stream) {
+    if (M < 0 || W <= 0 || ld < W || !drop) return MREC_EINVAL;
+    DropArgs d;
+    if (!drop_from(drop, W, &d)) return MREC_EINVAL;
+    if (M == 0) return MREC_OK;
+    if (!mask) return MREC_EINVAL;
+    if (ld % 4 || (((uintptr_t)mask) & 15)) return MREC_EUNSUPPORTED;
+    const int64_t nq = M * (W / 4);
+    const unsigned g = (unsigned)(mrec_cdiv(nq, 256) < 8192 ? mrec_cdiv(nq, 256) : 8192);
+    k_dropout_mask<<<g, 256, 0, (hipStream_t)stream>>>(mask, ld, M, W, d);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
 }

@@ -804,7 +804,7 @@ def head_supported(K5):
     return K5 % 8 == 0 and (K5 // 8) & (K5 // 8 - 1) == 0 and K5 // 8 <= 64
 
 
-def head_fwd_bwd(h4, w5, b5, wide, label, dscale, dw5_out, db4_out, db5_out):
+def head_fwd_bwd(h4, w5, b5, wide, label, dscale, dw5_out, db4_out, db5_out, dh_scale=1.0):
     """Output layer + wide/deep add + sigmoid cross-entropy, forward and backward, one pass over h4.
     Returns (loss [1], logit [B], dlogit [B], dh4 [B, K5] bf16)."""
     _need_cuda(h4, w5, b5, wide, label)
@@ -819,12 +819,12 @@ def head_fwd_bwd(h4, w5, b5, wide, label, dscale, dw5_out, db4_out, db5_out):
     if h4.dtype not in _DT16:
         raise TypeError("h4 must be bfloat16 or float16")
     _lib.call("mrec_head_fwd_bwd_" + _DT16[h4.dtype], _ptr(h4.contiguous()), _ptr(w5), _ptr(b5), _ptr(wide.contiguous()),
-              _ptr(label.contiguous()), B, K5, float(dscale), _ptr(logit), _ptr(dlogit), _ptr(dh4), _ptr(dw5_out),
+              _ptr(label.contiguous()), B, K5, float(dscale), float(dh_scale), _ptr(logit), _ptr(dlogit), _ptr(dh4), _ptr(dw5_out),
               _ptr(db4_out), _ptr(db5_out), _ptr(loss), _ptr(ws), ws.numel(), _stream())
     return loss, logit, dlogit, dh4
 
 
-def head_fwd_bwd_wide(h4, w5, b5, wide_prod, wide_bias, label, dscale, dw5_out, db4_out, db5_out, dwide_bias_out=None):
+def head_fwd_bwd_wide(h4, w5, b5, wide_prod, wide_bias, label, dscale, dw5_out, db4_out, db5_out, dwide_bias_out=None, dh_scale=1.0):
     """head_fwd_bwd with the wide branch given as the per-field products of gather_rows_wide ([B, F]) + the wide bias:
     the ReduceSum over the fields (wide_and_deep.py:305-306) happens inside the head, in field order."""
     _need_cuda(h4, w5, b5, wide_prod, wide_bias, label)
@@ -842,9 +842,56 @@ def head_fwd_bwd_wide(h4, w5, b5, wide_prod, wide_bias, label, dscale, dw5_out, 
     nb = _lib.query_bytes("mrec_head_workspace_bytes", B, K5)
     ws = workspace("head", nb, dev)
     _lib.call("mrec_head_fwd_bwd_wide", int(h4.dtype == torch.float16), _ptr(h4.contiguous()), _ptr(w5), _ptr(b5), _ptr(wide_prod),
-              wide_prod.shape[1], _ptr(wide_bias), _ptr(label.contiguous()), B, K5, float(dscale), _ptr(logit), _ptr(dlogit),
+              wide_prod.shape[1], _ptr(wide_bias), _ptr(label.contiguous()), B, K5, float(dscale), float(dh_scale), _ptr(logit), _ptr(dlogit),
               _ptr(dh4), _ptr(dw5_out), _ptr(db4_out), _ptr(db5_out), _ptr(dwide_bias_out), _ptr(loss), _ptr(ws), ws.numel(), _stream())
     return loss, logit, dlogit, dh4
+
+
+# ---- Dropout (csrc/mrec_dropout.h) ---------------------------------------------------------------------
+class _DropDesc(C.Structure):      # mrec_dropout_t
+    _fields_ = [("step_state", C.c_void_p), ("seed", C.c_uint64), ("step", C.c_int64), ("row0", C.c_int64), ("layer", C.c_int32),
+                ("keep_prob", C.c_float)]
+
+
+class Dropout:
+    """Names the DenseLayer whose input is dropped out (wide_and_deep.py:98,117-118) and the mask: a pure function of
+    (seed, step, layer, row0 + row, column).  step_state (ops.StepState): the step is read from device memory instead."""
+
+    def __init__(self, keep_prob, seed, layer, step=0, row0=0, step_state=None):
+        if not 0.0 < keep_prob <= 1.0:
+            raise ValueError("keep_prob must be in (0, 1]")
+        self.keep_prob, self.seed, self.layer, self.step, self.row0, self.step_state = float(keep_prob), int(seed), int(layer), int(step), int(row0), step_state
+        self._c = _DropDesc(step_state.buf.data_ptr() if step_state is not None else None, self.seed & (2 ** 64 - 1), self.step, self.row0,
+                            self.layer, self.keep_prob)
+
+    @property
+    def scale(self):
+        return float(np.float32(1.0) / np.float32(self.keep_prob))
+
+
+def _drop_ref(d):
+    return C.cast(C.pointer(d._c), C.c_void_p) if d is not None else None
+
+
+_KIND = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def dropout_(x, drop, out=None):
+    """Dropout over a [M, W] matrix (fp32 / bf16 / f16), in place unless `out`; its own bprop (apply it to the gradient)."""
+    _need_cuda(x, out)
+    y = x if out is None else out
+    if x.dim() != 2 or x.stride(1) != 1 or y.shape != x.shape or y.dtype != x.dtype or y.stride(1) != 1 or x.dtype not in _KIND:
+        raise TypeError("dropout_: [M, W] fp32 / bf16 / f16 matrices with unit column stride")
+    _lib.call("mrec_dropout", _ptr(x), x.stride(0), _ptr(y), y.stride(0), _KIND[x.dtype], x.shape[0], x.shape[1], _drop_ref(drop), _stream())
+    return y
+
+
+def dropout_mask(M, W, drop, device):
+    """The mask as fp32 {0, 1 / keep_prob} [M, W]."""
+    m = torch.empty((M, W), dtype=torch.float32, device=device)
+    _need_cuda(m)
+    _lib.call("mrec_dropout_mask_f32", _ptr(m), W, M, W, _drop_ref(drop), _stream())
+    return m
 
 
 # ---- DenseLayer on the matrix cores (csrc/mrec_dense.hip) --------------------------------------------
@@ -859,9 +906,10 @@ def dense_supported(M, K, N):
     return K % 8 == 0 and N % 8 == 0
 
 
-def dense_fwd(x, w, bias, relu=True, out=None):
+def dense_fwd(x, w, bias, relu=True, out=None, drop_next=None):
     """DenseLayer.construct (wide_and_deep.py:113-133): act(x . w + bias).  x [M, K], w [K, N] 16-bit (same dtype),
-    bias fp32 [N] or None.  Returns y [M, N] in x's dtype (fp32 accumulation, one rounding)."""
+    bias fp32 [N] or None.  Returns y [M, N] in x's dtype (fp32 accumulation, one rounding).  drop_next (Dropout): y is the
+    input of the DenseLayer the descriptor names and leaves the kernel dropped out (:117-118)."""
     _need_cuda(x, w, bias, out)
     M, K, ldx = _mat16(x, "x")
     K2, N, ldw = _mat16(w, "w")
@@ -874,11 +922,11 @@ def dense_fwd(x, w, bias, relu=True, out=None):
     if y.shape != (M, N) or y.dtype != x.dtype:
         raise TypeError("out must be [M, N] of x's dtype")
     _lib.call("mrec_dense_fwd_" + _DT16[x.dtype], _ptr(x), ldx, _ptr(w), _ptr(bias), M, K, N, int(bool(relu)), _ptr(y), ldy,
-              _stream())
+              _drop_ref(drop_next), _stream())
     return y
 
 
-def dense_bwd_input(dy, w, h=None, db_out=None, out=None, db_slabs=None):
+def dense_bwd_input(dy, w, h=None, db_out=None, out=None, db_slabs=None, drop_in=None):
     """MatMul bprop with respect to the input, fused with the ReLU + BiasAdd bprops of the layer below:
     dx = (dy . w^T) * (h > 0); db_out[:] = dx.sum(0).  dy [M, N], w [K, N], h [M, K] or None, db_out fp32 [K] or None.
     db_slabs (fp32 [ceil(M/256), K], instead of db_out): the bias gradient is left as per-tile-row partial sums for
@@ -905,7 +953,7 @@ def dense_bwd_input(dy, w, h=None, db_out=None, out=None, db_slabs=None):
         nb = _lib.query_bytes("mrec_dense_bwd_input_workspace_bytes", M, K)
         ws = workspace("dense_bwd_input", nb, dy.device)
     _lib.call("mrec_dense_bwd_input_" + _DT16[dy.dtype], _ptr(dy), lddy, _ptr(w), _ptr(h), M, K, N, _ptr(dx), lddx,
-              _ptr(db_out), _ptr(ws), ws.numel() if ws is not None else 0, _stream())
+              _ptr(db_out), _ptr(ws), ws.numel() if ws is not None else 0, _drop_ref(drop_in), _stream())
     return dx
 
 
@@ -937,10 +985,11 @@ def dense_bwd_weight(x, dy, out_slabs):
     return out_slabs
 
 
-def dense_bwd(dy, w, x, dw_slabs, mask=True, db_slabs=None, out=None):
+def dense_bwd(dy, w, x, dw_slabs, mask=True, db_slabs=None, out=None, drop_in=None):
     """Both bprops of one DenseLayer in one launch: returns dx = (dy . w^T) [* (x > 0) when mask], fills dw_slabs
     [S, K, N] with x^T . dy by batch slab and db_slabs [ceil(M/256), K] (optional) with the bias-gradient partials of
-    the layer below.  dy [M, N], w [K, N], x [M, K] (the layer's input = the activation of the layer below)."""
+    the layer below.  dy [M, N], w [K, N], x [M, K] (the layer's input = the activation of the layer below).  drop_in
+    (Dropout): x went through Dropout on its way into this layer; dx is the gradient in front of it."""
     _need_cuda(dy, w, x, dw_slabs, db_slabs, out)
     M, N, lddy = _mat16(dy, "dy")
     K, N2, ldw = _mat16(w, "w")
@@ -959,7 +1008,7 @@ def dense_bwd(dy, w, x, dw_slabs, mask=True, db_slabs=None, out=None):
             raise TypeError("db_slabs must be contiguous float32 [dense_bwd_bias_slabs(M, K, N), K]")
         nb = db_slabs.numel() * 4
     _lib.call("mrec_dense_bwd_" + _DT16[dy.dtype], _ptr(dy), lddy, _ptr(w), _ptr(x) if mask else None, _ptr(x), ldx, M, K, N,
-              _ptr(dx), lddx, _ptr(db_slabs), nb, dw_slabs.shape[0], _ptr(dw_slabs), _stream())
+              _ptr(dx), lddx, _ptr(db_slabs), nb, dw_slabs.shape[0], _ptr(dw_slabs), _drop_ref(drop_in), _stream())
     return dx
 
 

@@ -79,6 +79,9 @@ class WideDeepConfig:
                                      # embedding gradients are dense [V, D] tensors, nn.Adam / nn.FTRL visit every row every step
                                      # and the deep loss carries l2_coef * sum(E^2) / 2 (wide_and_deep.py:337-339,356-360,434-445)
     l2_coef: float = 8e-5            # default_config.yaml:43
+    dropout_flag: bool = False       # default_config.yaml:27 (benchmarks/wide_deep/default_config.yaml:15 switches it on): Dropout on the
+                                     # INPUT of every DenseLayer while training (wide_and_deep.py:117-118)
+    dropout_keep_prob: float = 0.5   # DenseLayer's own default (:85) -- WideDeepModel never forwards config.keep_prob (:164-205)
     dynamic_embedding: bool = False  # both tables are hash tables keyed by the raw ids (train_and_eval.py --dynamic_embedding=True,
                                      # wide_and_deep.py:271-274): rows are created on first sight with their default values
     hash_capacity: int = 1 << 22     # rows reserved in HBM for each hash table (dynamic_embedding)
@@ -310,6 +313,8 @@ class WideDeepEngine:
         self._step_graph = None       # ... and, with the wide branch folded, the whole step
         self._step_state = None       # ops.StepState (device-side beta powers / step size), created on first use
         self._state_step = -1         # the step count the device-side state stands at
+        self._dropout = bool(cfg.dropout_flag and cfg.dropout_keep_prob < 1.0)
+        self._training = False        # inside train_step (`self.training and self.drop_out`, wide_and_deep.py:117)
 
     # ---- helpers -----------------------------------------------------------------------------
     def _tick(self, name):
@@ -327,6 +332,15 @@ class WideDeepEngine:
         if ev is not None:
             ev[1].record()
 
+    def _drop(self, layer, B):
+        """Dropout descriptor of DenseLayer `layer`'s input for the training step in flight (None: no dropout).  The mask is a
+        function of (seed, step, layer, global sample row, column): on the GPU the step is read from the device-side step
+        state (a captured step replays with a moving step), row0 makes N data-parallel ranks draw the mask of one big batch."""
+        if not (self._dropout and self._training):
+            return None
+        return self.k.Dropout(self.cfg.dropout_keep_prob, self.cfg.seed + 4, layer, step=self.step_count - 1, row0=self.rank * B,
+                              step_state=self._step_state if self._gpu and self.k is ops else None)
+
     def mlp(self, x):
         """DenseLayer x5 (wide_and_deep.py:113-133): act(x W + b), ReLU on all but the last; returns the fp32 logit.
         On the GPU in 16-bit mode the hidden layers are the MFMA kernels of csrc/mrec_dense.hip (inference path,
@@ -341,6 +355,9 @@ class WideDeepEngine:
         h = x.to(amp) if amp is not None else x
         for i in range(n):
             W, b = self.dense[2 * i], self.dense[2 * i + 1]
+            d = self._drop(i, h.shape[0])
+            if d is not None:              # `x = self.dropout(x)`, :117-118 (autograd multiplies the gradient by the same mask)
+                h = h * self.k.dropout_mask(h.shape[0], h.shape[1], d, self.device).to(h.dtype)
             if amp is not None and i < n - 1:
                 h = torch.addmm(b.to(amp), h, W.to(amp))
             else:
@@ -380,8 +397,13 @@ class WideDeepEngine:
         """Hidden layers forward: the activations hs[0..n-1] (hs[0] = the MLP input), bias + ReLU in the GEMM epilogue."""
         n = len(self.dims) - 1
         hs = [emb if emb.dtype == self._amp else emb.to(self._amp)]
+        B = hs[0].shape[0]
+        d0 = self._drop(0, B)
+        if d0 is not None:
+            self.k.dropout_(hs[0], d0)     # the looked-up rows are consumed by the first layer only: in place
         for i in range(n - 1):
-            hs.append(self.k.dense_fwd(hs[i], self.dense16[2 * i], self.dense[2 * i + 1].detach(), relu=True))
+            # Dropout on the input of layer i + 1 (:117-118) = on this layer's output, in the GEMM epilogue
+            hs.append(self.k.dense_fwd(hs[i], self.dense16[2 * i], self.dense[2 * i + 1].detach(), relu=True, drop_next=self._drop(i + 1, B)))
         return hs
 
     @torch.no_grad()
@@ -392,17 +414,19 @@ class WideDeepEngine:
         B = hs[0].shape[0]
         W5, b5 = self.dense[2 * (n - 1)], self.dense[2 * (n - 1) + 1]
         K5 = self.dims[n - 1]
+        dl = self._drop(n - 1, B)
+        dhs = dl.scale if dl is not None else 1.0
         if isinstance(wide, _WideProd):
             loss, _, dlogit, dh = self.k.head_fwd_bwd_wide(hs[-1], W5.detach().view(-1), b5.detach(), wide.prod, self.wide_b,
                                                             label.view(-1), self.cfg.sens / B, self.dense_grad[2 * (n - 1)].view(-1),
                                                             self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1],
-                                                            dwide_bias_out=self.wide_b_grad)
+                                                            dwide_bias_out=self.wide_b_grad, dh_scale=dhs)
             loss = loss.view(())
         elif self.k.head_supported(K5):
             # output layer + wide/deep add + sigmoid cross-entropy, forward AND backward, one pass over h4
             loss, _, dlogit, dh = self.k.head_fwd_bwd(hs[-1], W5.detach().view(-1), b5.detach(), wide, label.view(-1),
                                                        self.cfg.sens / B, self.dense_grad[2 * (n - 1)].view(-1),
-                                                       self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1])
+                                                       self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1], dh_scale=dhs)
             loss = loss.view(())
         else:
             h4 = hs[-1].float()
@@ -411,7 +435,7 @@ class WideDeepEngine:
             dlogit = (torch.sigmoid(logit) - label) * (self.cfg.sens / B)          # d(sens * mean BCE)/d logit
             torch.mm(h4.t(), dlogit, out=self.dense_grad[2 * (n - 1)])
             torch.sum(dlogit, dim=0, out=self.dense_grad[2 * (n - 1) + 1])
-            dh = torch.ops.aten.threshold_backward(torch.mm(dlogit, W5.t()).to(amp), hs[-1], 0)
+            dh = torch.ops.aten.threshold_backward((torch.mm(dlogit, W5.t()) * dhs).to(amp), hs[-1], 0)
             torch.sum(dh, dim=0, dtype=torch.float32, out=self.dense_grad[2 * (n - 2) + 1])
         return {"hs": hs, "loss": loss, "g_wide": dlogit.view(-1), "dh": dh}
 
@@ -428,7 +452,7 @@ class WideDeepEngine:
         B = hs[0].shape[0]
         for i in range(n - 2, -1, -1):
             dh = self.k.dense_bwd(dh, self.dense16[2 * i], hs[i], self._dw_slabs(i, B), mask=i > 0,
-                                  db_slabs=self._db_slabs(i - 1, B) if i > 0 else None)
+                                  db_slabs=self._db_slabs(i - 1, B) if i > 0 else None, drop_in=self._drop(i, B))
         return dh
 
     def _mlp_step_eager(self, emb, wide, label, after_head=None):
@@ -964,6 +988,13 @@ class WideDeepEngine:
 
     # ---- one training step -------------------------------------------------------------------
     def train_step(self, ids, wts, label):
+        self._training = True
+        try:
+            return self._train_step(ids, wts, label)
+        finally:
+            self._training = False
+
+    def _train_step(self, ids, wts, label):
         cfg = self.cfg
         B, Fd = ids.shape
         D = cfg.emb_dim
@@ -976,6 +1007,12 @@ class WideDeepEngine:
                 self._step_state = self.k.StepState(self.device)
             if self._state_step != self.step_count:
                 self._step_state.reset(self.beta1_power, self.beta2_power, self.step_count)
+        elif self._dropout and self._gpu and self.k is ops:
+            # the Dropout kernels read the step from device memory (so that captured MLP graphs replay with a moving step):
+            # where nothing else keeps a device-side step state, keep one for them
+            if self._step_state is None:
+                self._step_state = self.k.StepState(self.device)
+            self._step_state.reset(self.beta1_power, self.beta2_power, self.step_count)
         self.step_count += 1
         self.beta1_power = np.float32(self.beta1_power * self.beta1)
         self.beta2_power = np.float32(self.beta2_power * self.beta2)

@@ -262,15 +262,16 @@ def relu_bwd_colsum(g, h):
     return dh, dh.astype(np.float64).sum(axis=0)
 
 
-def head_fwd_bwd(h4, w5, b5, wide, label, dscale):
+def head_fwd_bwd(h4, w5, b5, wide, label, dscale, dh_scale=1.0):
     """dense_layer_5 (K5 -> 1) + wide/deep add + SigmoidCrossEntropyWithLogits/ReduceMean, forward and
-    backward.  Returns dict(loss, logit, dlogit, dh4, dw5, db4, db5) in float64 where reduced."""
+    backward.  Returns dict(loss, logit, dlogit, dh4, dw5, db4, db5) in float64 where reduced.  dh_scale: 1 / keep_prob
+    when h4 went through Dropout (its zeros then carry the mask as well as the ReLU)."""
     h4 = np.asarray(h4, np.float64); w5 = np.asarray(w5, np.float64).ravel()
     z = h4 @ w5 + float(b5) + np.asarray(wide, np.float64)
     y = np.asarray(label, np.float64).ravel()
     loss = np.maximum(z, 0) - z * y + np.log1p(np.exp(-np.abs(z)))
     dl = (1.0 / (1.0 + np.exp(-z)) - y) * dscale
-    dh4 = np.where(h4 > 0, dl[:, None] * w5[None, :], 0.0)
+    dh4 = np.where(h4 > 0, dl[:, None] * w5[None, :] * float(np.float32(dh_scale)), 0.0)
     return dict(loss=loss.mean(), logit=z, dlogit=dl, dh4=dh4, dw5=h4.T @ dl, db4=dh4.sum(axis=0), db5=dl.sum())
 
 
@@ -317,15 +318,60 @@ def dense_layer(x16, w16, bias, relu, dtype):
     return round16(acc.astype(np.float32), dtype)
 
 
-def dense_bwd_input(dy16, w16, h16, dtype):
+def dense_bwd_input(dy16, w16, h16, dtype, scale=1.0, mask=None):
     """MatMul bprop wrt the input, then the ReLU bprop of the layer below and its BiasAdd bprop:
-    dx = round16(dy . w^T) where h > 0 else 0;  db = sum over the batch of the rounded dx (float64)."""
-    g = round16((np.asarray(dy16, np.float64) @ np.asarray(w16, np.float64).T).astype(np.float32), dtype)
+    dx = round16(dy . w^T) where h > 0 else 0;  db = sum over the batch of the rounded dx (float64).
+    With Dropout on this layer's input (scale = 1 / keep_prob): dx = round16((dy . w^T) * scale), masked by h > 0 when h (the
+    dropped-out activation: its zeros are the ReLU's and the mask's) is given, by `mask` > 0 otherwise (the first layer)."""
+    g = (np.asarray(dy16, np.float64) @ np.asarray(w16, np.float64).T).astype(np.float32)
+    if scale != 1.0:
+        g = g * np.float32(scale)
+    g = round16(g, dtype)
     if h16 is not None:
         g = np.where(np.asarray(h16) > 0, g, np.float32(0))
+    elif mask is not None:
+        g = np.where(np.asarray(mask) > 0, g, np.float32(0))
     return g, g.astype(np.float64).sum(axis=0)
 
 
 def dense_bwd_weight(x16, dy16):
     """MatMul bprop wrt the weight: dw = x^T . dy, exact products summed in float64 (the GPU sums in fp32)."""
     return np.asarray(x16, np.float64).T @ np.asarray(dy16, np.float64)
+
+
+# ---- Dropout (numpy restatement) ----------------------------------------------------------------------------
+# Reference: DenseLayer.construct, models/wide_deep/src/wide_and_deep.py:98,117-118 -- `x = self.dropout(x)` on the layer's
+# INPUT while training, Dropout(p = 1 - keep_prob); DenseLayer's keep_prob defaults to 0.5 (:85) and WideDeepModel never
+# passes one (:164-205), so dropout_flag alone switches a 0.5 dropout on.  MindSpore's generator cannot be restated
+# (PARITY UNPINNED); the mask is the counter-based function the MI355X path documents in include/mrec.h, stated here
+# independently over numpy uint64 arithmetic.
+def _mix64(z):
+    z = np.asarray(z, np.uint64)
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def dropout_mask(M, W, seed, step, layer, keep_prob, row0=0):
+    """fp32 [M, W]: 1 / keep_prob where element (row0 + r, c) of the input of DenseLayer `layer` at step `step` is kept, else 0."""
+    if W % 4:
+        raise ValueError("W must be a multiple of 4")
+    thresh = int(np.rint(np.float32(keep_prob) * np.float32(65536.0)))
+    if thresh >= 65536:
+        return np.ones((M, W), np.float32)
+    thresh = max(thresh, 1)
+    key = _mix64(np.uint64(seed % (1 << 64)) ^ _mix64(np.uint64(step * 16 + layer)))
+    r = (np.arange(M, dtype=np.uint64) + np.uint64(row0))[:, None]
+    c = np.arange(W, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        quad = _mix64(key + ((r * np.uint64(W) + c) >> np.uint64(2)))
+    bits = (quad >> (np.uint64(16) * (c & np.uint64(3)))) & np.uint64(0xFFFF)
+    return np.where(bits < np.uint64(thresh), np.float32(1.0) / np.float32(keep_prob), np.float32(0)).astype(np.float32)
+
+
+def dropout(x, mask, dtype=None):
+    """x * mask in fp32, rounded once to `dtype` ("bf16" / "f16"; None: fp32)."""
+    y = np.asarray(x, np.float32) * np.asarray(mask, np.float32)
+    return round16(y, dtype) if dtype else y

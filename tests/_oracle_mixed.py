@@ -13,6 +13,8 @@ configuration with use_mixed_precision (DenseLayer casts input and weight to 16 
   5. weight gradients     dW_i = h^T . dh in full precision (never rounded)
   6. row gradients        g_emb is 16-bit; the sparse apply widens it exactly and works in fp32 (oracle C code)
   7. operand shadow       the next step's W16 = round16(updated fp32 W)
+  8. Dropout (cfg.dropout_flag; :117-118, on every DenseLayer's input while training): the stored 16-bit input is replaced by
+     round16(x * mask / keep); the input gradients carry the same factor before their rounding (oracle.dropout_mask)
 Sums the GPU takes in fp32 are taken in float64 here: the oracle is at least as exact as the device."""
 import numpy as np
 
@@ -51,6 +53,13 @@ class OracleMixedEngine:
         self.wide_b = self.flat[n_real: n_real + 1]
         self.wide_b[:] = O.fill_normal(cfg.seed + 3, 1, 1, cfg.init_sigma).ravel()
         self.b1p = np.float32(1.0); self.b2p = np.float32(1.0)
+        self.t = 0                                    # 0-based index of the training step (keys the Dropout masks)
+
+    def _mask(self, layer, B, row0=0):
+        cfg = self.cfg
+        if not (getattr(cfg, "dropout_flag", False) and cfg.dropout_keep_prob < 1.0):
+            return None
+        return O.dropout_mask(B, self.dims[layer], cfg.seed + 4, self.t, layer, cfg.dropout_keep_prob, row0)
 
     def forward_backward(self, ids, wts, label):
         """Everything of a step in front of the optimizers; returns a dict of every intermediate."""
@@ -61,19 +70,25 @@ class OracleMixedEngine:
         emb = O.round16(O.gather_rows(self.deep, ids, wts).reshape(B, -1), dt)             # 1.
         wide = O.wide_sum(self.wide, ids, wts, float(self.wide_b[0]))
         W16 = [O.round16(w, dt) for w in self.W]
+        masks = [self._mask(i, B) for i in range(nl)]                                      # 8.
+        drop = masks[0] is not None
+        scale = float(np.float32(1.0) / np.float32(cfg.dropout_keep_prob)) if drop else 1.0
+        if drop:
+            emb = O.dropout(emb, masks[0], dt)
         hs = [emb]
         for i in range(nl - 1):                                                            # 2.
-            hs.append(O.dense_layer(hs[i], W16[i], self.b[i], True, dt))
-        head = O.head_fwd_bwd(hs[-1], self.w5, float(self.b5[0]), wide, label, cfg.sens / B)   # 3. (float64 inside)
+            h = O.dense_layer(hs[i], W16[i], self.b[i], True, dt)
+            hs.append(O.dropout(h, masks[i + 1], dt) if drop else h)
+        head = O.head_fwd_bwd(hs[-1], self.w5, float(self.b5[0]), wide, label, cfg.sens / B, dh_scale=scale)   # 3. (float64 inside)
         dh = O.round16(head["dh4"].astype(np.float32), dt)
         r.update(emb=emb, wide=wide, hs=hs, loss=float(head["loss"]), dlogit=head["dlogit"].astype(np.float32), dh_top=dh)
         gW, gb = [None] * (nl - 1), [None] * (nl - 1)
         gb[nl - 2] = head["db4"]                                                           # sum of the UNrounded dh4 (head kernel)
         for i in range(nl - 2, 0, -1):
             gW[i] = O.dense_bwd_weight(hs[i], dh)                                          # 5.
-            dh, gb[i - 1] = O.dense_bwd_input(dh, W16[i], hs[i], dt)                       # 4.
+            dh, gb[i - 1] = O.dense_bwd_input(dh, W16[i], hs[i], dt, scale=scale)          # 4.
         gW[0] = O.dense_bwd_weight(hs[0], dh)
-        g_emb, _ = O.dense_bwd_input(dh, W16[0], None, dt)
+        g_emb, _ = O.dense_bwd_input(dh, W16[0], None, dt, scale=scale, mask=masks[0])
         r.update(gW=gW, gb=gb, gw5=head["dw5"], gb5=head["db5"], g_emb=g_emb)
         return r
 
@@ -84,6 +99,7 @@ class OracleMixedEngine:
         D = cfg.emb_dim
         nl = len(self.dims) - 1
         self.b1p = np.float32(self.b1p * np.float32(0.9)); self.b2p = np.float32(self.b2p * np.float32(0.999))
+        self.t += 1
         inv = 1.0 / cfg.sens
         g = (r["g_emb"] if g_emb is None else g_emb).reshape(B * Fd, D)
         O.sparse_lazy_adam(self.deep, self.deep_m, self.deep_v, ids, g, wts, lr=cfg.adam_lr, eps=cfg.adam_eps,

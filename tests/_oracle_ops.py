@@ -120,3 +120,19 @@ def scatter_unique_rows_add_(table, plan, vals):
     u = plan._uniq
     ok = (u >= 0) & (u < table.shape[0])
     _np(table)[u[ok]] += _np(vals)[: u.size][ok]
+
+
+class Dropout:
+    """ops.Dropout for the CPU stand-in: the descriptor only (the step always by value)."""
+
+    def __init__(self, keep_prob, seed, layer, step=0, row0=0, step_state=None):
+        assert step_state is None
+        self.keep_prob, self.seed, self.layer, self.step, self.row0 = float(keep_prob), int(seed), int(layer), int(step), int(row0)
+
+    @property
+    def scale(self):
+        return float(np.float32(1.0) / np.float32(self.keep_prob))
+
+
+def dropout_mask(M, W, drop, device):
+    return torch.from_numpy(O.dropout_mask(M, W, drop.seed, drop.step, drop.layer, drop.keep_prob, drop.row0))
