@@ -2,8 +2,8 @@
 
 SOURCE OF THESE VECTORS: our restatement (oracle/mrec_oracle.c), NOT MindSpore -- the reference's
 own tests hold no vectors for this path and MindSpore cannot be imported here.
-They pin (a) the bit stream of the table initialiser shared by CPU and GPU and (b) one Wide&Deep
-embedding step at BASELINE config-1 shape (dim 16, 39 fields), so that a change to either side's
+They pin (a) the bit stream of the table initialiser shared by CPU and GPU, (b) one Wide&Deep
+embedding step at BASELINE config-1 shape (dim 16, 39 fields) and (c) the Dropout mask function, so that a change to either side's
 arithmetic is caught even when oracle and kernels are edited together.
 
 Run from the repo root:  python tests/golden/make_golden.py
@@ -27,6 +27,14 @@ def main():
     bits = O.normal_rows(seed, rows, D, sigma).view(np.uint32).ravel().tolist()
     json.dump({"seed": seed, "rows": rows, "D": D, "sigma": sigma, "bits": bits},
               open(os.path.join(HERE, "normal_seed1000.json"), "w"))
+
+    # (c) the Dropout mask function (csrc/mrec_dropout.h / oracle.dropout_mask): kept-bits of a few small masks
+    cases = [dict(M=5, W=16, seed=1004, step=0, layer=0, keep=0.5, row0=0), dict(M=3, W=8, seed=1004, step=7, layer=4, keep=0.8, row0=16384),
+             dict(M=2, W=12, seed=2 ** 63 + 11, step=100000, layer=15, keep=0.25, row0=3)]
+    for c in cases:
+        mk = O.dropout_mask(c["M"], c["W"], c["seed"], c["step"], c["layer"], c["keep"], c["row0"])
+        c["kept"] = "".join("1" if x > 0 else "0" for x in mk.ravel())
+    json.dump(cases, open(os.path.join(HERE, "dropout_masks.json"), "w"))
 
     rng = np.random.default_rng(1000)          # set_seed(1000), train_and_eval_distribute.py:72
     V, Dm, B, F = 20000, 16, 64, 39

@@ -33,6 +33,14 @@ def test_mask_matches_oracle(dev, oracle, M, W, keep, seed, step, layer, row0):
     assert np.array_equal(ops.dropout_mask(M, W, d2, dev).cpu().numpy(), ref)
 
 
+def test_mask_matches_golden(dev):
+    import json
+    from mindrec_amd import ops
+    for c in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dropout_masks.json"))):
+        mk = ops.dropout_mask(c["M"], c["W"], ops.Dropout(c["keep"], c["seed"], c["layer"], step=c["step"], row0=c["row0"]), dev).cpu().numpy()
+        assert "".join("1" if x > 0 else "0" for x in mk.ravel()) == c["kept"]
+
+
 def test_mask_rows_do_not_depend_on_the_split(dev, oracle):
     """N data-parallel ranks draw the mask of the one big batch: rows [row0, row0 + m) of the [M, W] mask."""
     from mindrec_amd import ops

@@ -244,3 +244,33 @@ def test_mt_entries_are_bit_identical_to_single_thread(oracle):
         out.append((p, m, v, w, a, l))
     for x, y in zip(*out):
         assert np.array_equal(x, y)
+
+
+def test_dropout_mask_golden_and_scalar_restatement(oracle):
+    """The Dropout mask function: committed golden masks (tests/golden/dropout_masks.json) and a scalar restatement of the spec in
+    plain Python integers (include/mrec.h, csrc/mrec_dropout.h) against the vectorised oracle."""
+    import json
+    M64 = (1 << 64) - 1
+
+    def mix(z):
+        z = (z + 0x9E3779B97F4A7C15) & M64
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+        return z ^ (z >> 31)
+
+    for c in json.load(open(os.path.join(GOLD, "dropout_masks.json"))):
+        mk = oracle.dropout_mask(c["M"], c["W"], c["seed"], c["step"], c["layer"], c["keep"], c["row0"])
+        assert "".join("1" if x > 0 else "0" for x in mk.ravel()) == c["kept"]
+        assert set(np.unique(mk)) <= {np.float32(0), np.float32(1) / np.float32(c["keep"])}
+        key = mix((c["seed"] & M64) ^ mix(c["step"] * 16 + c["layer"]))
+        thresh = int(round(c["keep"] * 65536))
+        for r in range(c["M"]):
+            for col in range(c["W"]):
+                quad = mix((key + (((c["row0"] + r) * c["W"] + col) >> 2)) & M64)
+                keep = ((quad >> (16 * (col & 3))) & 0xFFFF) < thresh
+                assert keep == bool(mk[r, col] > 0)
+    # keep_prob 1 is the identity; the kept fraction follows keep_prob
+    assert (oracle.dropout_mask(7, 8, 1, 2, 3, 1.0) == 1).all()
+    for keep in (0.5, 0.8, 0.1):
+        mk = oracle.dropout_mask(2000, 512, 5, 9, 1, keep)
+        assert abs((mk > 0).mean() - keep) <= 5 * np.sqrt(keep * (1 - keep) / mk.size) + 2.0 ** -16

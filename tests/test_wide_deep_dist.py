@@ -17,9 +17,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def _cfg(B):
+def _cfg(B, dropout=False):
     from mindrec_amd.wide_deep import WideDeepConfig
-    return WideDeepConfig(vocab_size=997, emb_dim=8, field_size=39, batch_size=B, deep_layer_dim=[16, 8], mlp_dtype="fp32")
+    return WideDeepConfig(vocab_size=997, emb_dim=8, field_size=39, batch_size=B, deep_layer_dim=[16, 8], mlp_dtype="fp32",
+                          dropout_flag=dropout)
 
 
 def _batch(cfg, seed):
@@ -27,14 +28,14 @@ def _batch(cfg, seed):
     return synthetic_batch(cfg, "cpu", "zipf", seed=seed)
 
 
-def _worker(rank, world, port, steps, out_dir):
+def _worker(rank, world, port, steps, out_dir, dropout=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import _oracle_ops
     from mindrec_amd.wide_deep import WideDeepEngine
     torch.set_num_threads(1)
-    cfg = _cfg(24)
+    cfg = _cfg(24, dropout)
     eng = WideDeepEngine(cfg, "cpu", rank=rank, world=world, kernels=_oracle_ops)
     losses = []
     for s in range(steps):
@@ -52,18 +53,19 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_sharded_step_matches_single_process(tmp_path, world):
+@pytest.mark.parametrize("world,dropout", [(2, False), (4, False), (8, False), (2, True)])
+def test_sharded_step_matches_single_process(tmp_path, world, dropout):
     """world = 4 / 8 with V = 997 also cover shards of unequal length (250, 249, ... / 125, 125, ..., 124 rows);
-    world = 8 is the driver's scaling-bench geometry (BASELINE configs[3])."""
+    world = 8 is the driver's scaling-bench geometry (BASELINE configs[3]).  dropout: the ranks draw the Dropout mask of the
+    one concatenated batch (row0 = rank * local batch)."""
     import _oracle_ops
     from mindrec_amd.wide_deep import WideDeepEngine
     steps = 3
-    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), dropout), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
 
     # single process, concatenated batch of world x 24
-    cfg1 = _cfg(24 * world)
+    cfg1 = _cfg(24 * world, dropout)
     eng = WideDeepEngine(cfg1, "cpu", kernels=_oracle_ops)
     losses = []
     for s in range(steps):
