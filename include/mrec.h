@@ -387,6 +387,34 @@ int mrec_head_fwd_bwd_wide(int32_t f16, const uint16_t* h4, const float* w5, con
                            float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* dwide_bias, float* loss,
                            void* ws, size_t ws_bytes, void* stream);
 
+/* ---- the tail of the dense net in one launch -------------------------------------------------
+ * dense_layer_3, dense_layer_4 (512 -> 256 -> 128, wide_and_deep.py:176-199), the output head above and the input-gradient
+ * bprops back through both layers, for 64 samples per workgroup with every intermediate in LDS -- five latency-bound launches
+ * (mrec_dense_fwd_* x2, mrec_head_fwd_bwd_*, mrec_dense_bwd_input_* x2) as one; results identical to theirs (same products in
+ * the same order; the bias-gradient partial sums come per 64 rows).  The two weight gradients stay mrec_dense_bwd_weight_*.
+ *   x [B, K2] (row stride ldx) input of the first tail layer; packed: the two weights w2 [K2, N2], w3 [N2, N3] in the kernel's
+ *   operand order (mrec_tail_pack_weights: mrec_tail_packed_elems 16-bit elements, to be refreshed whenever the weights
+ *   change); b2, b3, w5 [N3], b5 fp32; the wide branch and label as for
+ *   mrec_head_fwd_bwd_wide (wide_prod != NULL) or mrec_head_fwd_bwd_* (wide).
+ * out: y2 [B, N2] (the second tail layer's input, needed by its weight gradient), dz4 [B, N3], dz3 [B, N2], dz2 [B, K2] the
+ *   gradients at the outputs of the second / first tail layer and at x's layer output (masked by the ReLUs: the `dy` of the
+ *   weight-gradient calls and of the next mrec_dense_bwd_*), logit, dlogit [B], dw5 [N3], db4 [N3], db5, dwide_bias (nullable),
+ *   loss as the head's; db3 [N2], db2 [K2]: the column sums of dz3 / dz2 = the bias gradients of the first tail layer and of the
+ *   layer below it (per-workgroup partial sums added up in workgroup order by a second small launch, like the head's).
+ * drop_in (nullable): Dropout descriptor of the FIRST tail layer's input (layers +1, +2 are derived).
+ * Supported (mrec_tail_supported != 0): K2 = 512, N2 = 256, N3 = 128, B % 64 == 0, B <= 32768.  ws: mrec_tail_workspace_bytes(B). */
+int mrec_tail_supported(int64_t B, int32_t K2, int32_t N2, int32_t N3);
+int mrec_tail_workspace_bytes(int64_t B, size_t* out);
+int mrec_tail_packed_elems(int32_t K2, int32_t N2, int32_t N3, int64_t* out);
+int mrec_tail_pack_weights(const uint16_t* w2, const uint16_t* w3, int32_t K2, int32_t N2, int32_t N3, uint16_t* packed, void* stream);
+int mrec_tail_fwd_bwd(int32_t f16, const uint16_t* x, int64_t ldx, const uint16_t* packed, const float* b2,
+                      const float* b3, const float* w5, const float* b5,
+                      const float* wide, const float* wide_prod, int32_t F, const float* wide_bias, const float* label,
+                      int64_t B, int32_t K2, int32_t N2, int32_t N3, float dscale, uint16_t* y2, uint16_t* dz4,
+                      uint16_t* dz3, uint16_t* dz2, float* logit, float* dlogit, float* dw5, float* db4, float* db5,
+                      float* dwide_bias, float* loss, float* db3, float* db2, void* ws, size_t ws_bytes,
+                      const mrec_dropout_t* drop_in, void* stream);
+
 /* ---- MapParameter key index ---------------------------------------------------------------
  * mindspore.experimental.MapParameter as built by HashEmbeddingLookup
  * (mindspore_rec/ops/embedding.py:136-146) and driven by MapTensorGet/Put/Erase

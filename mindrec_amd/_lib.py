@@ -93,6 +93,12 @@ _SIGS = {
     "mrec_dense_bwd_weight_bf16": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp],
     "mrec_dense_bwd_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _sz, _i32, _vp, _vp, _vp],
     "mrec_dense_bwd_f16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _sz, _i32, _vp, _vp, _vp],
+    "mrec_tail_supported": [_i64, _i32, _i32, _i32],
+    "mrec_tail_workspace_bytes": [_i64, _szp],
+    "mrec_tail_packed_elems": [_i32, _i32, _i32, C.POINTER(C.c_int64)],
+    "mrec_tail_pack_weights": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    "mrec_tail_fwd_bwd": [_i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _f32,
+                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp],
     "mrec_dropout": [_vp, _i64, _vp, _i64, _i32, _i64, _i32, _vp, _vp],
     "mrec_dropout_mask_f32": [_vp, _i64, _i64, _i32, _vp, _vp],
     "mrec_dense_sum_slabs_f32": [_vp, _i32, _i64, _vp, _vp],

@@ -847,6 +847,72 @@ def head_fwd_bwd_wide(h4, w5, b5, wide_prod, wide_bias, label, dscale, dw5_out, 
     return loss, logit, dlogit, dh4
 
 
+# ---- the tail of the dense net in one launch (csrc/mrec_mlp.hip: k_tail) -------------------------------------------------
+def tail_supported(B, K2, N2, N3):
+    return bool(_lib.lib().mrec_tail_supported(int(B), int(K2), int(N2), int(N3)))
+
+
+def tail_pack_weights(w2, w3, out=None):
+    """The two tail weights w2 [K2, N2], w3 [N2, N3] (contiguous, 16-bit) in the tail kernel's operand order (both the forward and
+    the backward operand of either: 2 * (K2*N2 + N2*N3) elements).  To be refreshed whenever the weights change."""
+    _need_cuda(w2, w3, out)
+    if w2.dim() != 2 or w3.dim() != 2 or w2.dtype not in _DT16 or w3.dtype != w2.dtype or not w2.is_contiguous() or not w3.is_contiguous() \
+            or w3.shape[0] != w2.shape[1]:
+        raise TypeError("tail_pack_weights: contiguous 16-bit matrices w2 [K2, N2], w3 [N2, N3]")
+    n = C.c_int64(0)
+    _lib.call("mrec_tail_packed_elems", w2.shape[0], w2.shape[1], w3.shape[1], C.byref(n))
+    if out is None:
+        out = torch.empty(int(n.value), dtype=w2.dtype, device=w2.device)
+    if out.numel() != int(n.value) or out.dtype != w2.dtype or not out.is_contiguous():
+        raise TypeError("tail_pack_weights: out must hold mrec_tail_packed_elems elements of the weights' dtype")
+    _lib.call("mrec_tail_pack_weights", _ptr(w2), _ptr(w3), w2.shape[0], w2.shape[1], w3.shape[1], _ptr(out), _stream())
+    return out
+
+
+def tail_fwd_bwd(x, packed, b2, b3, w5, b5, wide, wide_bias, label, dscale, dw5_out, db4_out, db5_out, db3_out, db2_out,
+                 dwide_bias_out=None, drop_in=None, out=None):
+    """The last two hidden DenseLayers forward, the output head forward + backward and the input-gradient bprops back through
+    both layers in ONE launch (64 samples per workgroup, intermediates in LDS).  packed: tail_pack_weights(w2, w3).  wide: the [B, F, 2] per-field products of
+    gather_rows_wide (then wide_bias is needed) or the per-sample wide sum [B].  db3_out [N2], db2_out [K2]: bias gradients of the first
+    tail layer and of the layer below it.  Returns (loss [1], dlogit [B], y2 [B, N2],
+    dz4 [B, N3], dz3 [B, N2], dz2 [B, K2]); out: dict of preallocated tensors with those names (+ "logit")."""
+    _need_cuda(x, packed, b2, b3, w5, b5, wide, label)
+    B, K2, ldx = _mat16(x, "x")
+    N2, N3 = b2.numel(), b3.numel()
+    dt, dev = x.dtype, x.device
+    if not tail_supported(B, K2, N2, N3):
+        raise ValueError("tail_fwd_bwd: unsupported shape (see tail_supported)")
+    if packed.dtype != dt or packed.numel() != 2 * (K2 * N2 + N2 * N3) or not packed.is_contiguous():
+        raise TypeError("tail_fwd_bwd: packed must be tail_pack_weights(w2, w3) in x's dtype")
+    for t in (b2, b3, w5, b5):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError("tail_fwd_bwd: biases and the output layer's weight are contiguous float32")
+    prod = wide.dim() == 3
+    if prod and (wide.shape[0] != B or wide.shape[2] != 2 or wide.dtype != torch.float32 or not wide.is_contiguous() or wide_bias is None):
+        raise TypeError("wide must be the contiguous float32 [B, F, 2] tensor of gather_rows_wide (with wide_bias) or a [B] tensor")
+    o = out if out is not None else {}
+
+    def buf(name, shape, dtype):
+        t = o.get(name)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=dev)
+            o[name] = t
+        return t
+    y2, dz4, dz3, dz2 = buf("y2", (B, N2), dt), buf("dz4", (B, N3), dt), buf("dz3", (B, N2), dt), buf("dz2", (B, K2), dt)
+    logit, dlogit, loss = buf("logit", (B,), torch.float32), buf("dlogit", (B,), torch.float32), buf("loss", (1,), torch.float32)
+    for t, n_ in ((db3_out, N2), (db2_out, K2), (dw5_out, N3), (db4_out, N3)):
+        if t.numel() != n_ or t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError("tail_fwd_bwd: dw5_out [N3], db4_out [N3], db3_out [N2], db2_out [K2] contiguous float32")
+    nb = _lib.query_bytes("mrec_tail_workspace_bytes", B)
+    ws = workspace("tail", nb, dev)
+    _lib.call("mrec_tail_fwd_bwd", int(dt == torch.float16), _ptr(x), ldx, _ptr(packed), _ptr(b2), _ptr(b3),
+              _ptr(w5), _ptr(b5), None if prod else _ptr(wide.contiguous()), _ptr(wide) if prod else None, wide.shape[1] if prod else 0,
+              _ptr(wide_bias) if prod else None, _ptr(label.contiguous()), B, K2, N2, N3, float(dscale), _ptr(y2), _ptr(dz4), _ptr(dz3),
+              _ptr(dz2), _ptr(logit), _ptr(dlogit), _ptr(dw5_out), _ptr(db4_out), _ptr(db5_out), _ptr(dwide_bias_out), _ptr(loss),
+              _ptr(db3_out), _ptr(db2_out), _ptr(ws), ws.numel(), _drop_ref(drop_in), _stream())
+    return loss, dlogit, y2, dz4, dz3, dz2
+
+
 # ---- Dropout (csrc/mrec_dropout.h) ---------------------------------------------------------------------
 class _DropDesc(C.Structure):      # mrec_dropout_t
     _fields_ = [("step_state", C.c_void_p), ("seed", C.c_uint64), ("step", C.c_int64), ("row0", C.c_int64), ("layer", C.c_int32),

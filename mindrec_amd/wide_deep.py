@@ -91,6 +91,7 @@ class WideDeepConfig:
     graph_step: bool = True        # one GPU, folded wide branch: the sparse apply and the dense optimizers join that graph too (the
                                    # Adam bias-correction powers live in device memory and advance by a kernel: ops.StepState)
     graph_mlp: bool = True         # replay the MLP forward+backward as captured HIP graphs (one host launch, not ~25)
+    fused_tail: bool = True        # the last two hidden layers, the output head and their input-gradient bprops as one launch
 
 
 _TUNED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "tunableop_gfx950.csv")
@@ -292,6 +293,13 @@ class WideDeepEngine:
             self.k.fill_normal_(self.wide_b.view(1, 1), cfg.seed + 3, cfg.init_sigma)
             if self.dense16 is not None:
                 self.dense16_flat.copy_(self.dense_flat.detach())
+        # The last two hidden layers + the output head + their input-gradient bprops as ONE launch (ops.tail_fwd_bwd) where the net
+        # ends ... -> 512 -> 256 -> 128 -> 1 (the reference's) and the batch is a multiple of 64; any other net: layer by layer.
+        self._tail_packed = None
+        nl_ = len(self.dims) - 1
+        self._tail_ok = bool(self._mfma and cfg.fused_tail and nl_ >= 4 and self.k.tail_supported(64, *self.dims[nl_ - 3:nl_]))
+        if self._tail_ok:
+            self._refresh_tail()
         self._hashed = bool(cfg.dynamic_embedding)
         self._fused_rows = bool(cfg.fused_state and cfg.sparse and cfg.host_cache_rows == 0 and self._gpu)   # [p | w ... | m | v] rows
         self._pack_msgs = bool(self._gpu and kernels is None and D % 2 == 0)     # shards: merged request / answer / gradient messages
@@ -307,6 +315,7 @@ class WideDeepEngine:
                                       # graph replays and eager steps write the same buffers, the dense Adam reads them)
         self._db = {}                 # hidden layer -> fp32 partial sums of its bias gradient (same idea)
         self._dw_batch = None
+        self._tail_out = {}           # (batch, dtype) -> the tail launch's output tensors (persistent: graph replays write them)
         self.deep_apply_timer = None  # optional ops.KernelTimer armed right before the deep table's sparse apply
         self._dyn = False             # step scalars (Adam powers / step size) in device memory: set per step
         self._front_graph = None      # one-GPU: the whole front of the step (lookups .. MLP backward) as one captured graph
@@ -340,6 +349,15 @@ class WideDeepEngine:
             return None
         return self.k.Dropout(self.cfg.dropout_keep_prob, self.cfg.seed + 4, layer, step=self.step_count - 1, row0=self.rank * B,
                               step_state=self._step_state if self._gpu and self.k is ops else None)
+
+    def _refresh_tail(self):
+        """The tail kernel reads the two tail weights in its own operand order: re-packed whenever the 16-bit shadow changes."""
+        if self._tail_ok:
+            n = len(self.dims) - 1
+            self._tail_packed = self.k.tail_pack_weights(self.dense16[2 * (n - 3)], self.dense16[2 * (n - 2)], out=self._tail_packed)
+
+    def _tail_now(self, B):
+        return bool(self._tail_ok and self.k.tail_supported(B, *self.dims[len(self.dims) - 4:len(self.dims) - 1]))
 
     def mlp(self, x):
         """DenseLayer x5 (wide_and_deep.py:113-133): act(x W + b), ReLU on all but the last; returns the fp32 logit.
@@ -401,7 +419,7 @@ class WideDeepEngine:
         d0 = self._drop(0, B)
         if d0 is not None:
             self.k.dropout_(hs[0], d0)     # the looked-up rows are consumed by the first layer only: in place
-        for i in range(n - 1):
+        for i in range(n - 3 if self._tail_now(B) else n - 1):         # (fused tail: its two layers run in _mlp_head's launch)
             # Dropout on the input of layer i + 1 (:117-118) = on this layer's output, in the GEMM epilogue
             hs.append(self.k.dense_fwd(hs[i], self.dense16[2 * i], self.dense[2 * i + 1].detach(), relu=True, drop_next=self._drop(i + 1, B)))
         return hs
@@ -416,6 +434,16 @@ class WideDeepEngine:
         K5 = self.dims[n - 1]
         dl = self._drop(n - 1, B)
         dhs = dl.scale if dl is not None else 1.0
+        if len(hs) == n - 2:
+            # fused tail: layers n - 3 and n - 2 forward, the head, and the input gradients back to the output of layer n - 4
+            prod = isinstance(wide, _WideProd)
+            loss, dlogit, y2, dz4, dz3, dz2 = self.k.tail_fwd_bwd(
+                hs[-1], self._tail_packed, self.dense[2 * (n - 3) + 1].detach(), self.dense[2 * (n - 2) + 1].detach(), W5.detach().view(-1),
+                b5.detach(), wide.prod if prod else wide, self.wide_b if prod else None, label.view(-1), self.cfg.sens / B,
+                self.dense_grad[2 * (n - 1)].view(-1), self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1],
+                self.dense_grad[2 * (n - 3) + 1], self.dense_grad[2 * (n - 4) + 1], dwide_bias_out=self.wide_b_grad if prod else None,
+                drop_in=self._drop(n - 3, B), out=self._tail_out.setdefault((B, hs[-1].dtype), {}))
+            return {"hs": hs + [y2], "loss": loss.view(()), "g_wide": dlogit.view(-1), "dh": dz2, "tail": (dz4, dz3)}
         if isinstance(wide, _WideProd):
             loss, _, dlogit, dh = self.k.head_fwd_bwd_wide(hs[-1], W5.detach().view(-1), b5.detach(), wide.prod, self.wide_b,
                                                             label.view(-1), self.cfg.sens / B, self.dense_grad[2 * (n - 1)].view(-1),
@@ -450,7 +478,14 @@ class WideDeepEngine:
         n = len(self.dims) - 1
         hs, dh = ctx["hs"], ctx["dh"]
         B = hs[0].shape[0]
-        for i in range(n - 2, -1, -1):
+        top = n - 2
+        if "tail" in ctx:
+            # the tail launch has gone back through layers n - 2 and n - 3 already; their weight gradients (batch reductions) remain
+            dz4, dz3 = ctx["tail"]
+            self.k.dense_bwd_weight(hs[n - 2], dz4, self._dw_slabs(n - 2, B))
+            self.k.dense_bwd_weight(hs[n - 3], dz3, self._dw_slabs(n - 3, B))
+            top = n - 4
+        for i in range(top, -1, -1):
             dh = self.k.dense_bwd(dh, self.dense16[2 * i], hs[i], self._dw_slabs(i, B), mask=i > 0,
                                   db_slabs=self._db_slabs(i - 1, B) if i > 0 else None, drop_in=self._drop(i, B))
         return dh
@@ -963,6 +998,7 @@ class WideDeepEngine:
         self.k.dense_adam_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, **akw)
         if fused:
             self.dense16_flat.copy_(self.dense_flat.detach())
+            self._refresh_tail()
         self._tock(ev)
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
@@ -1190,6 +1226,7 @@ class WideDeepEngine:
             slabs = [] if self._sharded else self._slab_segments()
             self.k.dense_adam_slabs_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, slabs,
                                      shadow16=self.dense16_flat, step_state=state, **akw)
+            self._refresh_tail()
         else:
             self.k.dense_adam_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, **akw)
         self._tock(ev)
@@ -1263,6 +1300,7 @@ def load_checkpoint(eng, path):
                     dst.copy_(ck[grp][k].to(dst.device))
         if eng.dense16 is not None:
             eng.dense16_flat.copy_(eng.dense_flat.detach())
+            eng._refresh_tail()
     eng.step_count = m["step_count"]
     eng.beta1_power, eng.beta2_power = np.float32(m["beta1_power"]), np.float32(m["beta2_power"])
 

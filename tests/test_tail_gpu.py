@@ -1,0 +1,88 @@
+"""The tail of the dense net as ONE launch (mrec_tail_fwd_bwd: two DenseLayers forward, the output head, two input-gradient
+bprops; csrc/mrec_mlp.hip k_tail) against the five separate launches it replaces -- which are the ones checked against the
+oracle (tests/test_dense_gpu.py, test_gpu_parity.py, test_bench_shape_gpu.py).  Same products in the same order: the 16-bit
+tensors, the logits and the per-sample gradients must be IDENTICAL; the batch reductions (dw5, bias gradients, loss) are taken
+over different partial groupings and agree to fp32 summation accuracy."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+T16 = {"bf16": torch.bfloat16, "f16": torch.float16}
+K2, N2, N3 = 512, 256, 128
+
+
+def _inputs(dev, dt, B, seed, F=0):
+    rng = np.random.default_rng(seed)
+    t16 = T16[dt]
+    x = torch.from_numpy(np.maximum(rng.standard_normal((B, K2)), 0).astype(np.float32)).to(dev).to(t16)     # a ReLU output
+    w2 = torch.from_numpy((rng.standard_normal((K2, N2)) * 0.06).astype(np.float32)).to(dev).to(t16)
+    w3 = torch.from_numpy((rng.standard_normal((N2, N3)) * 0.08).astype(np.float32)).to(dev).to(t16)
+    b2 = torch.from_numpy((rng.standard_normal(N2) * 0.1).astype(np.float32)).to(dev)
+    b3 = torch.from_numpy((rng.standard_normal(N3) * 0.1).astype(np.float32)).to(dev)
+    w5 = torch.from_numpy((rng.standard_normal(N3) * 0.1).astype(np.float32)).to(dev)
+    b5 = torch.from_numpy(rng.standard_normal(1).astype(np.float32) * 0.1).to(dev)
+    label = torch.from_numpy((rng.random(B) < 0.3).astype(np.float32)).to(dev)
+    if F:
+        wide = torch.zeros((B, F, 2), dtype=torch.float32, device=dev)
+        wide[:, :, 0] = torch.from_numpy((rng.standard_normal((B, F)) * 0.05).astype(np.float32)).to(dev)
+        wb = torch.from_numpy(rng.standard_normal(1).astype(np.float32) * 0.1).to(dev)
+    else:
+        wide = torch.from_numpy((rng.standard_normal(B) * 0.2).astype(np.float32)).to(dev)
+        wb = None
+    return x, w2, b2, w3, b3, w5, b5, wide, wb, label
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("B,F,keep", [(16384, 26, None), (16384, 0, None), (64, 0, None), (4096, 26, 0.5), (1024, 39, 0.8)])
+def test_tail_equals_the_separate_launches(dev, dt, B, F, keep):
+    from mindrec_amd import ops
+    x, w2, b2, w3, b3, w5, b5, wide, wb, label = _inputs(dev, dt, B, seed=B + F, F=F)
+    assert ops.tail_supported(B, K2, N2, N3)
+    dscale = 1024.0 / B
+    d = (lambda layer: ops.Dropout(keep, 1004, layer, step=3, row0=128)) if keep else (lambda layer: None)
+    if keep:                               # x is then the dropped-out input of the first tail layer (layer index 2)
+        x = ops.dropout_(x.clone(), d(2))
+    dhs = d(2).scale if keep else 1.0
+    # --- the five launches
+    y2 = ops.dense_fwd(x, w2, b2, relu=True, drop_next=d(3))
+    y3 = ops.dense_fwd(y2, w3, b3, relu=True, drop_next=d(4))
+    dw5 = torch.empty(N3, device=dev); db4 = torch.empty(N3, device=dev); db5 = torch.empty(1, device=dev)
+    if F:
+        loss, logit, dlogit, dz4 = ops.head_fwd_bwd_wide(y3, w5, b5, wide, wb, label, dscale, dw5, db4, db5, dh_scale=dhs)
+    else:
+        loss, logit, dlogit, dz4 = ops.head_fwd_bwd(y3, w5, b5, wide, label, dscale, dw5, db4, db5, dh_scale=dhs)
+    db3 = torch.empty(N2, device=dev); db2 = torch.empty(K2, device=dev)
+    dz3 = ops.dense_bwd_input(dz4, w3, h=y2, db_out=db3, drop_in=d(3))
+    dz2 = ops.dense_bwd_input(dz3, w2, h=x, db_out=db2, drop_in=d(2))
+    # --- the one launch
+    packed = ops.tail_pack_weights(w2, w3)
+    tdw5 = torch.empty(N3, device=dev); tdb4 = torch.empty(N3, device=dev); tdb5 = torch.empty(1, device=dev)
+    s3 = torch.empty(N2, device=dev); s2 = torch.empty(K2, device=dev)
+    out = {}
+    tloss, tdlogit, ty2, tdz4, tdz3, tdz2 = ops.tail_fwd_bwd(x, packed, b2, b3, w5, b5, wide, wb, label, dscale, tdw5, tdb4, tdb5,
+                                                              s3, s2, drop_in=d(2), out=out)
+    torch.cuda.synchronize()
+    assert torch.equal(ty2, y2), "second tail layer's input"
+    assert torch.equal(out["logit"], logit) and torch.equal(tdlogit, dlogit)
+    assert torch.equal(tdz4, dz4) and torch.equal(tdz3, dz3) and torch.equal(tdz2, dz2)
+    assert abs(float(tloss) - float(loss)) <= 2e-6 * abs(float(loss))
+
+    def close(a, b, what):
+        a, b = a.double().cpu().numpy(), b.double().cpu().numpy()
+        assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max() + 1e-9, what
+    close(tdw5, dw5, "dw5"); close(tdb4, db4, "db4"); close(tdb5, db5, "db5")
+    close(s3, db3, "bias gradient of the first tail layer"); close(s2, db2, "bias gradient of the layer below")
+    if keep:
+        assert float((ty2 == 0).float().mean()) > 0.3          # the masks act
+
+
+def test_tail_rejects_other_shapes(dev):
+    from mindrec_amd import ops
+    assert not ops.tail_supported(100, K2, N2, N3) and not ops.tail_supported(64, 256, N2, N3) and not ops.tail_supported(1 << 20, K2, N2, N3)
+    assert ops.tail_supported(32768, K2, N2, N3)
