@@ -348,13 +348,22 @@ int mrec_dense_bwd_weight_f16(const uint16_t* x, int64_t ldx, const uint16_t* dy
 /* Both bprops of one DenseLayer in ONE launch (the two are independent and, for the narrow layers, neither fills the chip
  * alone): dx / bias-gradient slabs exactly as mrec_dense_bwd_input_* with db == NULL (db_slabs nullable: no bias gradient),
  * dw_slabs exactly as mrec_dense_bwd_weight_*.  x [M, K] is the layer's input, h (nullable) the same tensor when the layer
- * below has a ReLU to back-propagate through.  M > 0. */
+ * below has a ReLU to back-propagate through.  M > 0.
+ * extra / n_extra (<= 2): weight-gradient problems of OTHER layers over the same batch (dw_slabs[S, K, N] = x[M, K]^T . dy[M, N]
+ * exactly as mrec_dense_bwd_weight_*) whose workgroups ride this launch behind its own -- mrec_tail_fwd_bwd leaves its two
+ * layers' weight gradients to be computed, and alone each is a latency-bound launch. */
+typedef struct mrec_wgrad {
+    const uint16_t* x; int64_t ldx;
+    const uint16_t* dy; int64_t lddy;
+    int32_t K, N, S, reserved;
+    float* dw_slabs;
+} mrec_wgrad_t;
 int mrec_dense_bwd_bf16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x, int64_t ldx,
                         int64_t M, int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_slabs, size_t db_slabs_bytes,
-                        int32_t S, float* dw_slabs, const mrec_dropout_t* drop_in, void* stream);
+                        int32_t S, float* dw_slabs, const mrec_dropout_t* drop_in, const mrec_wgrad_t* extra, int32_t n_extra, void* stream);
 int mrec_dense_bwd_f16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x, int64_t ldx,
                        int64_t M, int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_slabs, size_t db_slabs_bytes,
-                       int32_t S, float* dw_slabs, const mrec_dropout_t* drop_in, void* stream);
+                       int32_t S, float* dw_slabs, const mrec_dropout_t* drop_in, const mrec_wgrad_t* extra, int32_t n_extra, void* stream);
 /* out[e] = sum over s < S of slabs[s*len + e], in slab order: the weight gradient as one tensor, for consumers other than
  * mrec_dense_adam_slabs_f32 (the data-parallel all-reduce).  len % 4 == 0, 16-byte aligned. */
 int mrec_dense_sum_slabs_f32(const float* slabs, int32_t S, int64_t len, float* out, void* stream);

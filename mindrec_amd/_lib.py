@@ -91,8 +91,8 @@ _SIGS = {
     "mrec_dense_bwd_input_f16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp, _vp],
     "mrec_dense_bwd_weight_slabs": [_i64, _i32, _i32, C.POINTER(C.c_int32)],
     "mrec_dense_bwd_weight_bf16": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp],
-    "mrec_dense_bwd_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _sz, _i32, _vp, _vp, _vp],
-    "mrec_dense_bwd_f16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _sz, _i32, _vp, _vp, _vp],
+    "mrec_dense_bwd_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _sz, _i32, _vp, _vp, _vp, _i32, _vp],
+    "mrec_dense_bwd_f16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _sz, _i32, _vp, _vp, _vp, _i32, _vp],
     "mrec_tail_supported": [_i64, _i32, _i32, _i32],
     "mrec_tail_workspace_bytes": [_i64, _szp],
     "mrec_tail_packed_elems": [_i32, _i32, _i32, C.POINTER(C.c_int64)],

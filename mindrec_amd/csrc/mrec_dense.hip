@@ -204,22 +204,32 @@ int bwd_weight_impl(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t 
 template <bool F16>
 int bwd_impl(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x, int64_t ldx, int64_t M,
              int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_ws, size_t db_ws_bytes, int32_t S, float* dw,
-             const mrec_dropout_t* drop, void* stream) {
+             const mrec_dropout_t* drop, const mrec_wgrad_t* extra, int32_t n_extra, void* stream) {
     Args ad, aw;
+    if (n_extra < 0 || n_extra > 2 || (n_extra && !extra)) return MREC_EINVAL;
     const int mrd = bwd_input_mr(M, K), mrw = bwd_mr(M, K, N);
     int rc = bwd_input_args(dy, lddy, w, h, M, K, N, dx, lddx, nullptr, db_ws, db_ws_bytes, mrd, drop, &ad);
     if (rc != MREC_OK) return rc;
     rc = bwd_weight_args(x, ldx, dy, lddy, M, K, N, S, dw, mrw, &aw);
     if (rc != MREC_OK) return rc;
     const int nd = ad.nTp * ad.nTq, nw = aw.nTp * aw.nTq * S;
+    // other layers' weight gradients riding this launch: the same batch, tiled in this launch's weight-gradient configuration
+    mgemm::ExtraW ex{};
+    for (int e = 0; e < n_extra; ++e) {
+        rc = bwd_weight_args(extra[e].x, extra[e].ldx, extra[e].dy, extra[e].lddy, M, extra[e].K, extra[e].N, extra[e].S, extra[e].dw_slabs,
+                             mrw, &ex.a[e]);
+        if (rc != MREC_OK) return rc;
+        ex.n[e] = ex.a[e].nTp * ex.a[e].nTq * extra[e].S;
+    }
+    const int ntot = nd + nw + ex.n[0] + ex.n[1];
     // longer workgroups first (time per K-tile goes with the tile height)
     const int wfirst = (int64_t)aw.kt_per_slab * mrw >= (int64_t)ad.kt_per_slab * mrd;
     hipStream_t st = (hipStream_t)stream;
     const int n1 = wfirst ? nw : nd;
-    if (mrd == 8 && mrw == 8) mgemm::k_gemm256_bwd<F16, 8, 8><<<nd + nw, mgemm::kThreads, 0, st>>>(ad, aw, n1, wfirst);
-    else if (mrd == 8) mgemm::k_gemm256_bwd<F16, 8, 4><<<nd + nw, mgemm::kThreads, 0, st>>>(ad, aw, n1, wfirst);
-    else if (mrw == 8) mgemm::k_gemm256_bwd<F16, 4, 8><<<nd + nw, mgemm::kThreads, 0, st>>>(ad, aw, n1, wfirst);
-    else mgemm::k_gemm256_bwd<F16, 4, 4><<<nd + nw, mgemm::kThreads, 0, st>>>(ad, aw, n1, wfirst);
+    if (mrd == 8 && mrw == 8) mgemm::k_gemm256_bwd<F16, 8, 8><<<ntot, mgemm::kThreads, 0, st>>>(ad, aw, n1, wfirst, ex);
+    else if (mrd == 8) mgemm::k_gemm256_bwd<F16, 8, 4><<<ntot, mgemm::kThreads, 0, st>>>(ad, aw, n1, wfirst, ex);
+    else if (mrw == 8) mgemm::k_gemm256_bwd<F16, 4, 8><<<ntot, mgemm::kThreads, 0, st>>>(ad, aw, n1, wfirst, ex);
+    else mgemm::k_gemm256_bwd<F16, 4, 4><<<ntot, mgemm::kThreads, 0, st>>>(ad, aw, n1, wfirst, ex);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -288,11 +298,13 @@ MREC_API int mrec_dense_sum_slabs_f32(const float* slabs, int32_t S, int64_t len
 /* both bprops of one layer in one launch (see include/mrec.h) */
 MREC_API int mrec_dense_bwd_bf16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x,
                                  int64_t ldx, int64_t M, int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_slabs,
-                                 size_t db_slabs_bytes, int32_t S, float* dw_slabs, const mrec_dropout_t* drop_in, void* stream) {
-    return bwd_impl<false>(dy, lddy, w, h, x, ldx, M, K, N, dx, lddx, db_slabs, db_slabs_bytes, S, dw_slabs, drop_in, stream);
+                                 size_t db_slabs_bytes, int32_t S, float* dw_slabs, const mrec_dropout_t* drop_in, const mrec_wgrad_t* extra,
+                                 int32_t n_extra, void* stream) {
+    return bwd_impl<false>(dy, lddy, w, h, x, ldx, M, K, N, dx, lddx, db_slabs, db_slabs_bytes, S, dw_slabs, drop_in, extra, n_extra, stream);
 }
 MREC_API int mrec_dense_bwd_f16(const uint16_t* dy, int64_t lddy, const uint16_t* w, const uint16_t* h, const uint16_t* x,
                                 int64_t ldx, int64_t M, int32_t K, int32_t N, uint16_t* dx, int64_t lddx, void* db_slabs,
-                                size_t db_slabs_bytes, int32_t S, float* dw_slabs, const mrec_dropout_t* drop_in, void* stream) {
-    return bwd_impl<true>(dy, lddy, w, h, x, ldx, M, K, N, dx, lddx, db_slabs, db_slabs_bytes, S, dw_slabs, drop_in, stream);
+                                size_t db_slabs_bytes, int32_t S, float* dw_slabs, const mrec_dropout_t* drop_in, const mrec_wgrad_t* extra,
+                                int32_t n_extra, void* stream) {
+    return bwd_impl<true>(dy, lddy, w, h, x, ldx, M, K, N, dx, lddx, db_slabs, db_slabs_bytes, S, dw_slabs, drop_in, extra, n_extra, stream);
 }

@@ -510,13 +510,29 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm256(const Args a) {
 // Both bprops of one DenseLayer in ONE launch: the two problems are independent (both read dy) and, for the narrow
 // layers, neither fills the chip alone.  Workgroups [0, n1) run the problem whose workgroups take longer (more K-tiles
 // each; dispatched first so that the short ones pack behind them), the rest the other one.
+// ... plus, behind them, the workgroups of up to two MORE weight-gradient problems (other layers' -- the tail launch of
+// mrec_mlp.hip leaves its two layers' weight gradients to be computed, and alone each is a latency-bound 10-16 us launch).
+struct ExtraW { Args a[2]; int n[2]; };
 template <bool F16, int MRD = 8, int MRW = 8>
-__global__ __launch_bounds__(kThreads, 2) void k_gemm256_bwd(const Args ad, const Args aw, const int n1, const int wfirst) {
+__global__ __launch_bounds__(kThreads, 2) void k_gemm256_bwd(const Args ad, const Args aw, const int n1, const int wfirst, const ExtraW ex) {
     __shared__ __attribute__((aligned(1024))) char smem[Lds<(MRD < MRW ? MRD : MRW)>::bytes];      // the 128 x 256 config needs more
-    const int b = blockIdx.x, n2 = (int)gridDim.x - n1;
+    const int nx = ex.n[0] + ex.n[1];
+    int b = blockIdx.x;
+    const int n2 = (int)gridDim.x - nx - n1;
     const bool second = b >= n1;
-    if (second != (wfirst != 0)) gemm256_body<MRW, true, true, EPI_F32, F16>(aw, second ? b - n1 : b, second ? n2 : n1, (MGEMM_LDS char*)smem);
-    else gemm256_body<MRD, false, false, EPI_DGRAD, F16>(ad, second ? b - n1 : b, second ? n2 : n1, (MGEMM_LDS char*)smem);
+    if (b < n1 + n2 && second == (wfirst != 0)) {
+        gemm256_body<MRD, false, false, EPI_DGRAD, F16>(ad, second ? b - n1 : b, second ? n2 : n1, (MGEMM_LDS char*)smem);
+        return;
+    }
+    // a weight-gradient workgroup: of this layer, or of one of the extra problems (uniform selects: the arguments stay in SGPRs)
+    Args sel = aw;
+    int nb = second ? n2 : n1;
+    if (b >= n1 + n2) {
+        b -= n1 + n2;
+        if (b < ex.n[0]) { sel = ex.a[0]; nb = ex.n[0]; }
+        else { b -= ex.n[0]; sel = ex.a[1]; nb = ex.n[1]; }
+    } else if (second) b -= n1;
+    gemm256_body<MRW, true, true, EPI_F32, F16>(sel, b, nb, (MGEMM_LDS char*)smem);
 }
 
 }  // namespace mgemm

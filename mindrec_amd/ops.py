@@ -961,6 +961,11 @@ def dropout_mask(M, W, drop, device):
 
 
 # ---- DenseLayer on the matrix cores (csrc/mrec_dense.hip) --------------------------------------------
+class _WGrad(C.Structure):         # mrec_wgrad_t
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("dy", C.c_void_p), ("lddy", C.c_int64), ("K", C.c_int32), ("N", C.c_int32),
+                ("S", C.c_int32), ("reserved", C.c_int32), ("dw_slabs", C.c_void_p)]
+
+
 def _mat16(t, name):
     if t.dtype not in _DT16 or t.dim() != 2 or t.stride(1) != 1:
         raise TypeError(f"{name} must be a bfloat16 / float16 [rows, cols] tensor with unit column stride")
@@ -1051,11 +1056,12 @@ def dense_bwd_weight(x, dy, out_slabs):
     return out_slabs
 
 
-def dense_bwd(dy, w, x, dw_slabs, mask=True, db_slabs=None, out=None, drop_in=None):
+def dense_bwd(dy, w, x, dw_slabs, mask=True, db_slabs=None, out=None, drop_in=None, extra=None):
     """Both bprops of one DenseLayer in one launch: returns dx = (dy . w^T) [* (x > 0) when mask], fills dw_slabs
     [S, K, N] with x^T . dy by batch slab and db_slabs [ceil(M/256), K] (optional) with the bias-gradient partials of
     the layer below.  dy [M, N], w [K, N], x [M, K] (the layer's input = the activation of the layer below).  drop_in
-    (Dropout): x went through Dropout on its way into this layer; dx is the gradient in front of it."""
+    (Dropout): x went through Dropout on its way into this layer; dx is the gradient in front of it.  extra: up to two
+    (x_e, dy_e, dw_slabs_e) weight-gradient problems of other layers over the same batch, computed by the same launch."""
     _need_cuda(dy, w, x, dw_slabs, db_slabs, out)
     M, N, lddy = _mat16(dy, "dy")
     K, N2, ldw = _mat16(w, "w")
@@ -1073,8 +1079,23 @@ def dense_bwd(dy, w, x, dw_slabs, mask=True, db_slabs=None, out=None, drop_in=No
         if db_slabs.dtype != torch.float32 or not db_slabs.is_contiguous() or db_slabs.shape != (dense_bwd_bias_slabs(M, K, N, True), K):
             raise TypeError("db_slabs must be contiguous float32 [dense_bwd_bias_slabs(M, K, N), K]")
         nb = db_slabs.numel() * 4
+    ex, nex = None, 0
+    if extra:
+        if len(extra) > 2:
+            raise ValueError("dense_bwd: at most two extra weight-gradient problems")
+        arr = (_WGrad * len(extra))()
+        for e, (xe, dye, dwe) in enumerate(extra):
+            _need_cuda(xe, dye, dwe)
+            Me, Ke, ldxe = _mat16(xe, "extra x")
+            Me2, Ne, lddye = _mat16(dye, "extra dy")
+            if Me != M or Me2 != M or xe.dtype != dy.dtype or dye.dtype != dy.dtype:
+                raise TypeError("dense_bwd: extra problems share the batch and the dtype")
+            if dwe.dtype != torch.float32 or dwe.dim() != 3 or dwe.shape[1:] != (Ke, Ne) or not dwe.is_contiguous():
+                raise TypeError("dense_bwd: extra dw_slabs must be contiguous float32 [S, K, N]")
+            arr[e] = _WGrad(xe.data_ptr(), ldxe, dye.data_ptr(), lddye, Ke, Ne, dwe.shape[0], 0, dwe.data_ptr())
+        ex, nex = C.cast(arr, C.c_void_p), len(extra)
     _lib.call("mrec_dense_bwd_" + _DT16[dy.dtype], _ptr(dy), lddy, _ptr(w), _ptr(x) if mask else None, _ptr(x), ldx, M, K, N,
-              _ptr(dx), lddx, _ptr(db_slabs), nb, dw_slabs.shape[0], _ptr(dw_slabs), _drop_ref(drop_in), _stream())
+              _ptr(dx), lddx, _ptr(db_slabs), nb, dw_slabs.shape[0], _ptr(dw_slabs), _drop_ref(drop_in), ex, nex, _stream())
     return dx
 
 

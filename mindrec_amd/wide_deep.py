@@ -478,16 +478,17 @@ class WideDeepEngine:
         n = len(self.dims) - 1
         hs, dh = ctx["hs"], ctx["dh"]
         B = hs[0].shape[0]
-        top = n - 2
+        top, extra = n - 2, None
         if "tail" in ctx:
-            # the tail launch has gone back through layers n - 2 and n - 3 already; their weight gradients (batch reductions) remain
+            # the tail launch has gone back through layers n - 2 and n - 3 already; their weight gradients (batch reductions) remain:
+            # they ride the backward launch of layer n - 4
             dz4, dz3 = ctx["tail"]
-            self.k.dense_bwd_weight(hs[n - 2], dz4, self._dw_slabs(n - 2, B))
-            self.k.dense_bwd_weight(hs[n - 3], dz3, self._dw_slabs(n - 3, B))
+            extra = [(hs[n - 3], dz3, self._dw_slabs(n - 3, B)), (hs[n - 2], dz4, self._dw_slabs(n - 2, B))]
             top = n - 4
         for i in range(top, -1, -1):
             dh = self.k.dense_bwd(dh, self.dense16[2 * i], hs[i], self._dw_slabs(i, B), mask=i > 0,
-                                  db_slabs=self._db_slabs(i - 1, B) if i > 0 else None, drop_in=self._drop(i, B))
+                                  db_slabs=self._db_slabs(i - 1, B) if i > 0 else None, drop_in=self._drop(i, B), extra=extra)
+            extra = None
         return dh
 
     def _mlp_step_eager(self, emb, wide, label, after_head=None):

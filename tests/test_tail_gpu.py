@@ -86,3 +86,33 @@ def test_tail_rejects_other_shapes(dev):
     from mindrec_amd import ops
     assert not ops.tail_supported(100, K2, N2, N3) and not ops.tail_supported(64, 256, N2, N3) and not ops.tail_supported(1 << 20, K2, N2, N3)
     assert ops.tail_supported(32768, K2, N2, N3)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_extra_weight_gradients_ride_the_backward_launch(dev, dt):
+    """ops.dense_bwd(..., extra=[...]): the weight gradients of two other layers computed by the workgroups behind a layer's own
+    backward launch must equal the separate mrec_dense_bwd_weight_* launches slab by slab, and leave the launch's own results alone."""
+    from mindrec_amd import ops
+    torch.manual_seed(0)
+    M = 16384
+    t16 = T16[dt]
+
+    def r(*s):
+        return (torch.randn(*s, device=dev) * 0.1).to(t16)
+
+    def slabs(K, N):
+        return torch.empty((ops.dense_bwd_weight_slabs(M, K, N), K, N), device=dev)
+    dy, w, x = r(M, 512), r(1024, 512), torch.relu(r(M, 1024))
+    x2, dy2, x3, dy3 = torch.relu(r(M, 512)), r(M, 256), torch.relu(r(M, 256)), r(M, 128)
+    s1, s2, s3, r2, r3 = slabs(1024, 512), slabs(512, 256), slabs(256, 128), slabs(512, 256), slabs(256, 128)
+    db = torch.empty((ops.dense_bwd_bias_slabs(M, 1024, 512), 1024), device=dev)
+    dx_a = ops.dense_bwd(dy, w, x, s1, mask=True, db_slabs=db).clone()
+    s1a, dba = s1.clone(), db.clone()
+    ops.dense_bwd_weight(x2, dy2, r2)
+    ops.dense_bwd_weight(x3, dy3, r3)
+    s1.zero_(); db.zero_()
+    dx_b = ops.dense_bwd(dy, w, x, s1, mask=True, db_slabs=db, extra=[(x2, dy2, s2), (x3, dy3, s3)])
+    assert torch.equal(dx_a, dx_b) and torch.equal(s1a, s1) and torch.equal(dba, db)
+    assert torch.equal(r2, s2) and torch.equal(r3, s3)
+    with pytest.raises(ValueError):
+        ops.dense_bwd(dy, w, x, s1, extra=[(x2, dy2, s2)] * 3)
