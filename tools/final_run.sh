@@ -8,6 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_line.json 2> $O/bench.err
 echo "bench done"; cut -c1-200 $O/bench_line.json
 python3 $R/bench.py --mlp-dtype fp16 --no-cpu-baseline > $O/bench_line_fp16.json 2>> $O/bench.err
+python3 $R/bench.py --dropout --no-cpu-baseline > $O/bench_line_dropout.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_line_under_rocprof.json 2> $O/prof.err
 cp $(find $O/prof -name "*kernel_stats.csv") $O/bench_kernel_stats.csv
 python3 $R/tools/prof_summary.py $O/bench_kernel_stats.csv > $O/bench_kernel_summary.txt
@@ -24,6 +25,7 @@ python tools/embed_bench.py --layout folded --tag final 2>/dev/null > $O/embed_f
 python tools/dcn_bench.py > $O/dcn_bench.txt 2>/dev/null
 cat $O/paths_bench.txt $O/dcn_bench.txt
 timeout -k 10 200 ./tools/probes/dense_gemm_test > $O/dense_gemm_probe.txt 2>&1 || true
+timeout -k 10 200 python tools/probes/tail_probe.py 2>/dev/null > $O/tail_probe.txt || true
 # what a rank of an N-GPU job does besides moving bytes over xGMI: the row-shard protocol over RCCL with itself
 python bench.py --no-cpu-baseline --shard-protocol 2>/dev/null | tail -1 > $O/bench_line_shard_protocol.json
 
