@@ -315,6 +315,22 @@ int mrec_dense_fwd_bf16(const uint16_t* x, int64_t ldx, const uint16_t* w, const
                         int32_t N, int relu, uint16_t* y, int64_t ldy, const mrec_dropout_t* drop_next, void* stream);
 int mrec_dense_fwd_f16(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bias, int64_t M, int32_t K,
                        int32_t N, int relu, uint16_t* y, int64_t ldy, const mrec_dropout_t* drop_next, void* stream);
+/* The same forward with the weight given TRANSPOSED, wt[N, K] (mrec_dense_operand_copies keeps such copies current): both
+ * operands are then read along the reduction dimension, which the kernel does 15 % faster (layer 0: 72 -> 62 us).  Same products
+ * in the same order: identical results. */
+int mrec_dense_fwd_wt_bf16(const uint16_t* x, int64_t ldx, const uint16_t* wt, const float* bias, int64_t M, int32_t K,
+                           int32_t N, int relu, uint16_t* y, int64_t ldy, const mrec_dropout_t* drop_next, void* stream);
+int mrec_dense_fwd_wt_f16(const uint16_t* x, int64_t ldx, const uint16_t* wt, const float* bias, int64_t M, int32_t K,
+                          int32_t N, int relu, uint16_t* y, int64_t ldy, const mrec_dropout_t* drop_next, void* stream);
+/* Every derived copy of the 16-bit weights in one launch: up to 4 transposes dst[cols, rows] = src[rows, cols]^T (rows, cols
+ * multiples of 8) and, when tail_packed != NULL, mrec_tail_pack_weights(tail_w2, tail_w3) (declared below). */
+typedef struct mrec_transpose {
+    const uint16_t* src;
+    int64_t rows, cols;
+    uint16_t* dst;
+} mrec_transpose_t;
+int mrec_dense_operand_copies(int32_t n_t, const mrec_transpose_t* t, const uint16_t* tail_w2, const uint16_t* tail_w3, int32_t K2,
+                              int32_t N2, int32_t N3, uint16_t* tail_packed, void* stream);
 /* bprop with respect to the layer's input, fused with the ReLU and BiasAdd bprops of the layer BELOW:
  *   dx[m, k] = h[m, k] > 0 ? sum_n dy[m, n] * w[k, n] : 0      (h nullable: no mask -- the first layer's input)
  *   db[k]    = sum_m dx[m, k]                                  (db nullable; sums of the rounded dx, fp32, fixed order)

@@ -85,6 +85,9 @@ _SIGS = {
                                   _f32, _int, _vp, _vp],
     "mrec_dense_fwd_bf16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp, _vp],
     "mrec_dense_fwd_f16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp, _vp],
+    "mrec_dense_fwd_wt_bf16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp, _vp],
+    "mrec_dense_fwd_wt_f16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp, _vp],
+    "mrec_dense_operand_copies": [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mrec_dense_bwd_input_workspace_bytes": [_i64, _i32, _szp],
     "mrec_dense_bwd_bias_slabs": [_i64, _i32, _i32, _int, C.POINTER(C.c_int32)],
     "mrec_dense_bwd_input_bf16": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp, _vp],

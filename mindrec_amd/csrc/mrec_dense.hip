@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const float4* __restrict__ sl
     }
 }
 
-template <bool F16>
+template <bool F16, bool WT = false>      // WT: w is the TRANSPOSED weight [N, K] (both operands K-contiguous)
 int fwd_impl(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bias, int64_t M, int32_t K, int32_t N, int relu,
              uint16_t* y, int64_t ldy, const mrec_dropout_t* drop, void* stream) {
     if (M < 0 || K <= 0 || N <= 0 || ldx < K || ldy < N) return MREC_EINVAL;
@@ -84,14 +84,14 @@ int fwd_impl(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bia
     const int mr = pick_mr(mrec_cdiv(M, 256) * mrec_cdiv(N, 256));
     Args a{};
     a.P = x; a.Q = w; a.C = y; a.bias = bias;
-    a.ldp = ldx; a.ldq = N; a.ldc = ldy;
+    a.ldp = ldx; a.ldq = WT ? K : N; a.ldc = ldy;
     a.Pext = (int)M; a.Qext = N; a.K = K;
     a.nTp = (int)mrec_cdiv(M, mr * 32); a.nTq = (int)mrec_cdiv(N, 256);
     a.kt_per_slab = (K + 63) / 64;
     a.relu = relu;
     a.drop = da;
-    if (mr == 8) mgemm::k_gemm256<false, true, mgemm::EPI_FWD, F16, 0, 8><<<a.nTp * a.nTq, mgemm::kThreads, 0, (hipStream_t)stream>>>(a);
-    else mgemm::k_gemm256<false, true, mgemm::EPI_FWD, F16, 0, 4><<<a.nTp * a.nTq, mgemm::kThreads, 0, (hipStream_t)stream>>>(a);
+    if (mr == 8) mgemm::k_gemm256<false, !WT, mgemm::EPI_FWD, F16, 0, 8><<<a.nTp * a.nTq, mgemm::kThreads, 0, (hipStream_t)stream>>>(a);
+    else mgemm::k_gemm256<false, !WT, mgemm::EPI_FWD, F16, 0, 4><<<a.nTp * a.nTq, mgemm::kThreads, 0, (hipStream_t)stream>>>(a);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -243,6 +243,15 @@ MREC_API int mrec_dense_fwd_bf16(const uint16_t* x, int64_t ldx, const uint16_t*
 MREC_API int mrec_dense_fwd_f16(const uint16_t* x, int64_t ldx, const uint16_t* w, const float* bias, int64_t M, int32_t K,
                                 int32_t N, int relu, uint16_t* y, int64_t ldy, const mrec_dropout_t* drop_next, void* stream) {
     return fwd_impl<true>(x, ldx, w, bias, M, K, N, relu, y, ldy, drop_next, stream);
+}
+
+MREC_API int mrec_dense_fwd_wt_bf16(const uint16_t* x, int64_t ldx, const uint16_t* wt, const float* bias, int64_t M, int32_t K,
+                                    int32_t N, int relu, uint16_t* y, int64_t ldy, const mrec_dropout_t* drop_next, void* stream) {
+    return fwd_impl<false, true>(x, ldx, wt, bias, M, K, N, relu, y, ldy, drop_next, stream);
+}
+MREC_API int mrec_dense_fwd_wt_f16(const uint16_t* x, int64_t ldx, const uint16_t* wt, const float* bias, int64_t M, int32_t K,
+                                   int32_t N, int relu, uint16_t* y, int64_t ldy, const mrec_dropout_t* drop_next, void* stream) {
+    return fwd_impl<true, true>(x, ldx, wt, bias, M, K, N, relu, y, ldy, drop_next, stream);
 }
 
 MREC_API int mrec_dense_bwd_input_workspace_bytes(int64_t M, int32_t K, size_t* out) {

@@ -778,9 +778,8 @@ __global__ __launch_bounds__(MB) void k_tail_finish(const float* __restrict__ pa
 // Fragment-ordered copies of one weight W [K, N] (row-major, as the reference stores it): one thread per 16-byte chunk.
 //   forward operand  F[ks][nt][l][j] = W[ks*32 + 8*(l>>4) + j][nt*16 + (l&15)]     (output column q = n, reduction over k)
 //   backward operand G[ks][kt][l][j] = W[kt*16 + (l&15)][ks*32 + 8*(l>>4) + j]     (output column q = k, reduction over n)
-__global__ __launch_bounds__(256) void k_tail_pack(const uint16_t* __restrict__ w2, const uint16_t* __restrict__ w3, uint4* __restrict__ out) {
+__device__ __forceinline__ void tail_pack_chunk(const uint16_t* __restrict__ w2, const uint16_t* __restrict__ w3, uint4* __restrict__ out, int i) {
     constexpr int C2 = K2 * N2 / 8, C3 = N2 * N3 / 8;            // chunks per copy
-    int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= 2 * (C2 + C3)) return;
     const uint4* dst = out + i;
     // order of the copies in `out`: W2 forward | W3 forward | W3 backward | W2 backward
@@ -804,6 +803,48 @@ __global__ __launch_bounds__(256) void k_tail_pack(const uint16_t* __restrict__ 
     }
     *(uint4*)dst = v;
 }
+__global__ __launch_bounds__(256) void k_tail_pack(const uint16_t* __restrict__ w2, const uint16_t* __restrict__ w3, uint4* __restrict__ out) {
+    tail_pack_chunk(w2, w3, out, blockIdx.x * 256 + threadIdx.x);
+}
+
+// Every derived copy of the 16-bit weights in ONE launch (each launch costs ~4 us of a step that is one dependent chain): the
+// tail launch's fragment-ordered weights, and the TRANSPOSES [out, in] of the other hidden layers' weights -- with them the
+// forward GEMM reads both operands K-contiguous (ds_read_b128), 15 % faster than through ds_read_b64_tr_b16 on W as stored.
+struct TransDesc { const uint16_t* src; uint16_t* dst; int rows, cols, tiles_c, first_block; };
+struct CopyArgs { TransDesc t[4]; int n_t, pack_blocks; const uint16_t *w2, *w3; uint4* packed; };
+__global__ __launch_bounds__(256) void k_operand_copies(const CopyArgs a) {
+    int b = blockIdx.x;
+    if (b < a.pack_blocks) { tail_pack_chunk(a.w2, a.w3, a.packed, b * 256 + threadIdx.x); return; }
+    b -= a.pack_blocks;
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < a.n_t && b >= a.t[k].first_block) q = k;
+    const TransDesc d = a.t[q];
+    b -= d.first_block;
+    // 64 x 64 tile through LDS: 16-byte loads along the rows, 16-byte stores along the columns
+    __shared__ uint16_t tile[64][72];
+    const int r0 = (b / d.tiles_c) * 64, c0 = (b % d.tiles_c) * 64;
+    const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = r0 + tr + 32 * i, c = c0 + tc;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < d.rows && c < d.cols) v = *(const uint4*)(d.src + (int64_t)r * d.cols + c);       // cols % 8 == 0
+        *(uint4*)&tile[tr + 32 * i][tc] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = c0 + tr + 32 * i, r = r0 + tc;            // output row c, 8 consecutive source rows r .. r + 7
+        if (c < d.cols && r < d.rows) {
+            uint32_t e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = tile[tc + j][tr + 32 * i];
+            *(uint4*)(d.dst + (int64_t)c * d.rows + r) = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+        }
+    }
+}
 }  // namespace tail
 
 MREC_API int mrec_tail_packed_elems(int32_t K2, int32_t N2, int32_t N3, int64_t* out) {
@@ -819,6 +860,36 @@ MREC_API int mrec_tail_pack_weights(const uint16_t* w2, const uint16_t* w3, int3
     if (((uintptr_t)w2 | (uintptr_t)w3 | (uintptr_t)packed) & 15) return MREC_EUNSUPPORTED;
     const int n = 2 * (K2 * N2 + N2 * N3) / 8;
     tail::k_tail_pack<<<(unsigned)mrec_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(w2, w3, (uint4*)packed);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+MREC_API int mrec_dense_operand_copies(int32_t n_t, const mrec_transpose_t* t, const uint16_t* tail_w2, const uint16_t* tail_w3,
+                                       int32_t K2, int32_t N2, int32_t N3, uint16_t* tail_packed, void* stream) {
+    if (n_t < 0 || n_t > 4 || (n_t && !t)) return MREC_EINVAL;
+    tail::CopyArgs a{};
+    int blocks = 0;
+    if (tail_packed) {
+        if (K2 != tail::K2 || N2 != tail::N2 || N3 != tail::N3) return MREC_EUNSUPPORTED;
+        if (!tail_w2 || !tail_w3) return MREC_EINVAL;
+        if (((uintptr_t)tail_w2 | (uintptr_t)tail_w3 | (uintptr_t)tail_packed) & 15) return MREC_EUNSUPPORTED;
+        a.w2 = tail_w2; a.w3 = tail_w3; a.packed = (uint4*)tail_packed;
+        a.pack_blocks = (int)mrec_cdiv(2 * (K2 * N2 + N2 * N3) / 8, 256);
+        blocks = a.pack_blocks;
+    }
+    int tb = 0;
+    for (int k = 0; k < n_t; ++k) {
+        if (!t[k].src || !t[k].dst || t[k].rows <= 0 || t[k].cols <= 0 || t[k].rows > (1 << 20) || t[k].cols > (1 << 20)) return MREC_EINVAL;
+        if (t[k].rows % 8 || t[k].cols % 8 || (((uintptr_t)t[k].src | (uintptr_t)t[k].dst) & 15)) return MREC_EUNSUPPORTED;
+        a.t[k].src = t[k].src; a.t[k].dst = t[k].dst; a.t[k].rows = (int)t[k].rows; a.t[k].cols = (int)t[k].cols;
+        a.t[k].tiles_c = (int)mrec_cdiv(t[k].cols, 64);
+        a.t[k].first_block = tb;
+        tb += (int)mrec_cdiv(t[k].rows, 64) * a.t[k].tiles_c;
+    }
+    a.n_t = n_t;
+    blocks += tb;
+    if (blocks == 0) return MREC_OK;
+    tail::k_operand_copies<<<blocks, 256, 0, (hipStream_t)stream>>>(a);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }

@@ -869,6 +869,29 @@ def tail_pack_weights(w2, w3, out=None):
     return out
 
 
+class _Transpose(C.Structure):      # mrec_transpose_t
+    _fields_ = [("src", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64), ("dst", C.c_void_p)]
+
+
+def operand_copies(transposes=(), tail=None):
+    """Every derived copy of the 16-bit weights in one launch: transposes = [(src [r, c], dst [c, r]), ...] (at most 4), tail =
+    (w2, w3, packed) as for tail_pack_weights."""
+    arr = (_Transpose * max(len(transposes), 1))()
+    for k, (src, dst) in enumerate(transposes):
+        _need_cuda(src, dst)
+        if src.dim() != 2 or not src.is_contiguous() or src.dtype not in _DT16 or dst.shape != (src.shape[1], src.shape[0]) \
+                or dst.dtype != src.dtype or not dst.is_contiguous():
+            raise TypeError("operand_copies: (src [r, c], dst [c, r]) contiguous 16-bit matrices")
+        arr[k] = _Transpose(src.data_ptr(), src.shape[0], src.shape[1], dst.data_ptr())
+    w2 = w3 = packed = None
+    K2 = N2 = N3 = 0
+    if tail is not None:
+        w2, w3, packed = tail
+        _need_cuda(w2, w3, packed)
+        K2, N2, N3 = w2.shape[0], w2.shape[1], w3.shape[1]
+    _lib.call("mrec_dense_operand_copies", len(transposes), C.cast(arr, C.c_void_p), _ptr(w2), _ptr(w3), K2, N2, N3, _ptr(packed), _stream())
+
+
 def tail_fwd_bwd(x, packed, b2, b3, w5, b5, wide, wide_bias, label, dscale, dw5_out, db4_out, db5_out, db3_out, db2_out,
                  dwide_bias_out=None, drop_in=None, out=None):
     """The last two hidden DenseLayers forward, the output head forward + backward and the input-gradient bprops back through
@@ -977,23 +1000,30 @@ def dense_supported(M, K, N):
     return K % 8 == 0 and N % 8 == 0
 
 
-def dense_fwd(x, w, bias, relu=True, out=None, drop_next=None):
+def dense_fwd(x, w, bias, relu=True, out=None, drop_next=None, wt=None):
     """DenseLayer.construct (wide_and_deep.py:113-133): act(x . w + bias).  x [M, K], w [K, N] 16-bit (same dtype),
     bias fp32 [N] or None.  Returns y [M, N] in x's dtype (fp32 accumulation, one rounding).  drop_next (Dropout): y is the
-    input of the DenseLayer the descriptor names and leaves the kernel dropped out (:117-118)."""
+    input of the DenseLayer the descriptor names and leaves the kernel dropped out (:117-118).  wt: the transposed weight
+    [N, K] (operand_copies keeps it current): the same result from the faster both-operands-K-contiguous kernel; w may then be None."""
     _need_cuda(x, w, bias, out)
     M, K, ldx = _mat16(x, "x")
-    K2, N, ldw = _mat16(w, "w")
-    if K2 != K or ldw != N or w.dtype != x.dtype:
-        raise TypeError("w must be a contiguous [K, N] tensor of x's dtype")
+    if wt is not None:
+        _need_cuda(wt)
+        N, K2, ldw = _mat16(wt, "wt")
+        if K2 != K or ldw != K or wt.dtype != x.dtype:
+            raise TypeError("wt must be a contiguous [N, K] tensor of x's dtype")
+    else:
+        K2, N, ldw = _mat16(w, "w")
+        if K2 != K or ldw != N or w.dtype != x.dtype:
+            raise TypeError("w must be a contiguous [K, N] tensor of x's dtype")
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N or not bias.is_contiguous()):
         raise TypeError("bias must be contiguous float32 [N]")
     y = out if out is not None else torch.empty((M, N), dtype=x.dtype, device=x.device)
     _, _, ldy = _mat16(y, "out")
     if y.shape != (M, N) or y.dtype != x.dtype:
         raise TypeError("out must be [M, N] of x's dtype")
-    _lib.call("mrec_dense_fwd_" + _DT16[x.dtype], _ptr(x), ldx, _ptr(w), _ptr(bias), M, K, N, int(bool(relu)), _ptr(y), ldy,
-              _drop_ref(drop_next), _stream())
+    _lib.call(("mrec_dense_fwd_wt_" if wt is not None else "mrec_dense_fwd_") + _DT16[x.dtype], _ptr(x), ldx, _ptr(wt if wt is not None else w),
+              _ptr(bias), M, K, N, int(bool(relu)), _ptr(y), ldy, _drop_ref(drop_next), _stream())
     return y
 
 

@@ -295,11 +295,10 @@ class WideDeepEngine:
                 self.dense16_flat.copy_(self.dense_flat.detach())
         # The last two hidden layers + the output head + their input-gradient bprops as ONE launch (ops.tail_fwd_bwd) where the net
         # ends ... -> 512 -> 256 -> 128 -> 1 (the reference's) and the batch is a multiple of 64; any other net: layer by layer.
-        self._tail_packed = None
+        self._tail_packed, self._dense16_t = None, None
         nl_ = len(self.dims) - 1
         self._tail_ok = bool(self._mfma and cfg.fused_tail and nl_ >= 4 and self.k.tail_supported(64, *self.dims[nl_ - 3:nl_]))
-        if self._tail_ok:
-            self._refresh_tail()
+        self._refresh_tail()
         self._hashed = bool(cfg.dynamic_embedding)
         self._fused_rows = bool(cfg.fused_state and cfg.sparse and cfg.host_cache_rows == 0 and self._gpu)   # [p | w ... | m | v] rows
         self._pack_msgs = bool(self._gpu and kernels is None and D % 2 == 0)     # shards: merged request / answer / gradient messages
@@ -351,10 +350,22 @@ class WideDeepEngine:
                               step_state=self._step_state if self._gpu and self.k is ops else None)
 
     def _refresh_tail(self):
-        """The tail kernel reads the two tail weights in its own operand order: re-packed whenever the 16-bit shadow changes."""
-        if self._tail_ok:
-            n = len(self.dims) - 1
-            self._tail_packed = self.k.tail_pack_weights(self.dense16[2 * (n - 3)], self.dense16[2 * (n - 2)], out=self._tail_packed)
+        """Derived copies of the 16-bit weights, rewritten (one launch) whenever the shadow changes: the transposes [out, in] the
+        forward GEMMs read (both operands K-contiguous: 15 % faster than W as stored through transposing LDS reads) and the tail
+        kernel's fragment-ordered weights."""
+        if not self._mfma:
+            return
+        n = len(self.dims) - 1
+        hidden = range(n - 3 if self._tail_ok else n - 1)          # the layers that run as GEMM launches of their own
+        if self._dense16_t is None:
+            self._dense16_t = {i: torch.empty((self.dims[i + 1], self.dims[i]), dtype=self._amp, device=self.device) for i in hidden}
+            if self._tail_ok:
+                self._tail_packed = torch.empty(2 * (self.dims[n - 3] * self.dims[n - 2] + self.dims[n - 2] * self.dims[n - 1]),
+                                                dtype=self._amp, device=self.device)
+        tr = [(self.dense16[2 * i], self._dense16_t[i]) for i in hidden]
+        tail = (self.dense16[2 * (n - 3)], self.dense16[2 * (n - 2)], self._tail_packed) if self._tail_ok else None
+        for k in range(0, max(len(tr), 1), 4):                      # (at most 4 transposes per launch; the reference's net: 2)
+            self.k.operand_copies(tr[k:k + 4], tail if k == 0 else None)
 
     def _tail_now(self, B):
         return bool(self._tail_ok and self.k.tail_supported(B, *self.dims[len(self.dims) - 4:len(self.dims) - 1]))
@@ -421,7 +432,8 @@ class WideDeepEngine:
             self.k.dropout_(hs[0], d0)     # the looked-up rows are consumed by the first layer only: in place
         for i in range(n - 3 if self._tail_now(B) else n - 1):         # (fused tail: its two layers run in _mlp_head's launch)
             # Dropout on the input of layer i + 1 (:117-118) = on this layer's output, in the GEMM epilogue
-            hs.append(self.k.dense_fwd(hs[i], self.dense16[2 * i], self.dense[2 * i + 1].detach(), relu=True, drop_next=self._drop(i + 1, B)))
+            hs.append(self.k.dense_fwd(hs[i], self.dense16[2 * i], self.dense[2 * i + 1].detach(), relu=True, drop_next=self._drop(i + 1, B),
+                                       wt=self._dense16_t.get(i)))
         return hs
 
     @torch.no_grad()

@@ -116,3 +116,36 @@ def test_extra_weight_gradients_ride_the_backward_launch(dev, dt):
     assert torch.equal(r2, s2) and torch.equal(r3, s3)
     with pytest.raises(ValueError):
         ops.dense_bwd(dy, w, x, s1, extra=[(x2, dy2, s2)] * 3)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,K,N", [(16384, 2080, 1024), (16384, 1024, 512), (300, 264, 136), (1000, 3120, 264)])
+def test_forward_with_transposed_weight_is_identical(dev, dt, M, K, N):
+    """mrec_dense_fwd_wt_*: the weight given as [N, K] (written by mrec_dense_operand_copies) -- same products in the same order as
+    the kernel that reads W [K, N] as stored, so the outputs must be bit-identical (ragged edges, K tails, both tile shapes, Dropout)."""
+    from mindrec_amd import ops
+    t16 = T16[dt]
+    rng = np.random.default_rng(K + N)
+    x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(dev).to(t16)
+    w = torch.from_numpy((rng.standard_normal((K, N)) * 0.05).astype(np.float32)).to(dev).to(t16)
+    b = torch.from_numpy((rng.standard_normal(N) * 0.1).astype(np.float32)).to(dev)
+    wt = torch.empty((N, K), dtype=t16, device=dev)
+    other = torch.from_numpy(rng.standard_normal((64, 40)).astype(np.float32)).to(dev).to(t16)
+    other_t = torch.empty((40, 64), dtype=t16, device=dev)
+    ops.operand_copies([(w, wt), (other, other_t)])
+    assert torch.equal(wt, w.t().contiguous()) and torch.equal(other_t, other.t().contiguous())
+    for drop in (None, ops.Dropout(0.5, 9, 1, step=2)):
+        y0 = ops.dense_fwd(x, w, b, relu=True, drop_next=drop)
+        y1 = ops.dense_fwd(x, None, b, relu=True, drop_next=drop, wt=wt)
+        assert torch.equal(y0, y1)
+
+
+def test_operand_copies_with_the_tail_pack(dev):
+    from mindrec_amd import ops
+    _, w2, _, w3, *_ = _inputs(dev, "bf16", 64, 3)
+    ref = ops.tail_pack_weights(w2, w3)
+    a = torch.randn(2080, 1024, device=dev).to(torch.bfloat16)
+    at = torch.empty((1024, 2080), dtype=torch.bfloat16, device=dev)
+    packed = torch.empty_like(ref)
+    ops.operand_copies([(a, at)], tail=(w2, w3, packed))
+    assert torch.equal(packed, ref) and torch.equal(at, a.t().contiguous())
