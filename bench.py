@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--mlp-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--dropout", action="store_true", help="dropout_flag: True as in benchmarks/wide_deep/default_config.yaml:15 (Dropout(0.5) on every "
                     "DenseLayer input; models/wide_deep/default_config.yaml:27, the configuration of configs[1], has it off)")
+    ap.add_argument("--dw-slabs", default="", help="layer:S,... weight-gradient slab counts instead of the library's proposal (sweeps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of each cpu_baseline leg")
     ap.add_argument("--n-batches", type=int, default=4, help="distinct resident batches cycled through")
@@ -233,6 +234,8 @@ def main():
                          host_cache_rows=args.host_cache_rows, early_route=not args.no_early_route,
                          late_wide={'auto': None, 'on': True, 'off': False}[args.late_wide],
                          overlap_wide_apply=not args.no_overlap_wide_apply, dropout_flag=args.dropout)
+    if args.dw_slabs:
+        cfg.dw_slabs = {int(k): int(v) for k, v in (kv.split(":") for kv in args.dw_slabs.split(","))}
     eng = WideDeepEngine(cfg, dev, rank=rank, world=world, shard_protocol=args.shard_protocol)
     batches = [synthetic_batch(cfg, dev, args.dist, seed=1000 + i, rank=rank) for i in range(args.n_batches)]
     torch.cuda.synchronize()

@@ -167,12 +167,11 @@ int bwd_mr(int64_t M, int32_t K, int32_t N) {            // weight gradient
 }
 int bwd_input_mr(int64_t M, int32_t K) { return pick_mr(mrec_cdiv(M, 256) * mrec_cdiv(K, 256)); }
 
+// slabs with which this weight gradient ALONE would fill the chip: decides its tile configuration
 int weight_slabs_mr(int64_t M, int32_t K, int32_t N, int mr) {
     const int64_t tiles = mrec_cdiv(K, mr * 32) * mrec_cdiv(N, 256);
     const int64_t Ttot = mrec_cdiv(M, 64);
     int64_t S = cu_count() / tiles;
-    // each slab is K*N fp32 written once and read once by the optimizer: beyond 16 slabs keep them within 16 MB in all
-    // (the narrow layers then get short workgroups: 32 / 64 slabs of 0.5 / 0.13 MB for 512x256 / 256x128)
     int64_t cap = ((int64_t)16 << 20) / ((int64_t)K * N * 4);
     if (cap < 16) cap = 16;
     if (cap > 64) cap = 64;
@@ -181,7 +180,25 @@ int weight_slabs_mr(int64_t M, int32_t K, int32_t N, int mr) {
     if (S < 1) S = 1;
     return (int)S;
 }
-int weight_slabs(int64_t M, int32_t K, int32_t N) { return weight_slabs_mr(M, K, N, bwd_mr(M, K, N)); }
+// The slab count proposed to the caller.  The weight gradient runs in ONE launch with the layer's input gradient (>= one
+// workgroup per CU of its own), so it needs about half a chip of workgroups, not a full one: fewer, longer workgroups pay the
+// prologue / epilogue (a 128-KB fp32 tile each) less often and leave half the slab bytes for the optimizer to read.  A layer whose
+// weight gradient is a full round of 256 x 256 tiles (layer 0 of the reference's net: 36 tiles) keeps ~0.85 of a round, so
+// that the input-gradient workgroups dispatched behind it pack into the CUs it leaves free.  Measured on the reference's net at
+// batch 16384 (tools/probes/slab_sweep.sh): slabs 7 / 16 / 32 / 64 -> 6 / 8 / 16 / 32 took the step from 0.695 to 0.652 ms.
+int weight_slabs(int64_t M, int32_t K, int32_t N) {
+    const int mr = bwd_mr(M, K, N);
+    const int64_t tiles = mrec_cdiv(K, mr * 32) * mrec_cdiv(N, 256);
+    const int64_t Ttot = mrec_cdiv(M, 64);
+    int64_t S = tiles >= 32 ? (int64_t)(0.85 * cu_count() / tiles + 0.5) : cu_count() / (2 * tiles);
+    int64_t cap = ((int64_t)8 << 20) / ((int64_t)K * N * 4);        // slabs are written once and read once by the optimizer
+    if (cap < 8) cap = 8;
+    if (cap > 32) cap = 32;
+    if (S > cap) S = cap;
+    if (S > Ttot) S = Ttot;
+    if (S < 1) S = 1;
+    return (int)S;
+}
 
 template <bool F16>
 int bwd_weight_impl(const uint16_t* x, int64_t ldx, const uint16_t* dy, int64_t lddy, int64_t M, int32_t K, int32_t N, int32_t S,

@@ -91,6 +91,7 @@ class WideDeepConfig:
     graph_step: bool = True        # one GPU, folded wide branch: the sparse apply and the dense optimizers join that graph too (the
                                    # Adam bias-correction powers live in device memory and advance by a kernel: ops.StepState)
     graph_mlp: bool = True         # replay the MLP forward+backward as captured HIP graphs (one host launch, not ~25)
+    dw_slabs: object = None        # {hidden layer: batch slabs of its weight gradient} instead of the library's proposal (tuning sweeps)
     fused_tail: bool = True        # the last two hidden layers, the output head and their input-gradient bprops as one launch
 
 
@@ -416,7 +417,7 @@ class WideDeepEngine:
         t = self._dw.get(i)
         if t is None:
             K, N = self.dims[i], self.dims[i + 1]
-            S = self.k.dense_bwd_weight_slabs(B, K, N)
+            S = int((self.cfg.dw_slabs or {}).get(i, 0)) or self.k.dense_bwd_weight_slabs(B, K, N)
             t = torch.empty((S, K, N), dtype=torch.float32, device=self.device)
             self._dw[i] = t
         return t
