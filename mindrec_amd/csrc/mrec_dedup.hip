@@ -279,12 +279,14 @@ __global__ __launch_bounds__(1024) void k_plan_small(const int* __restrict__ slo
 
 __global__ void k_set_i64(int64_t* p, int64_t v) { *p = v; }
 
-struct DedupScratch { int* slots; int* sidx; unsigned* status; int nstatus; int* first_pos; int* dup_pos; int64_t* n_dup; int64_t* n_radix; };
+struct DedupScratch { int* slots; int* sidx; unsigned* status; int nstatus; int* first_pos; int* dup_pos; int64_t* n_dup; int64_t* n_radix; size_t slot_bytes; };
 
 // fuse_inv_out != nullptr (the step's plan): the rank kernel also separates first occurrences (first_pos) from duplicates
 // (dup_pos, their count on the device), the inverse of the duplicates is left to the caller's sort of the duplicates.
 // primed: the caller vouches that the last thing that wrote this workspace was a completed call of this function with the
-// same n: the look-back words are then already zero (the scratch table is cleared by a memset either way).
+// same n: the look-back words are then already zero -- and, for the step's plan (fuse_inv_out), so is the scratch table, which
+// plan_impl clears BEHIND its last kernel instead of in front of the first (a 4-MB memset: 10 us by which the insert kernel now
+// starts earlier; the chain's end is far off the step's critical path, its head runs beside the lookup).
 template <class K>
 int dedup_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_dev, void* ws, size_t ws_bytes,
                void* stream_v, DedupScratch* fuse_inv_out = nullptr, bool primed = false) {
@@ -311,7 +313,7 @@ int dedup_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_d
         n_dup = a.take<int64_t>(2);        // [0] duplicates, [1] duplicates left to the radix passes
     }
     if (!a.ok) return MREC_EWORKSPACE;
-    MREC_HIP_CHECK(hipMemsetAsync(slots, 0x7f, cap * sizeof(int), st));
+    if (!(primed && fuse_inv_out)) MREC_HIP_CHECK(hipMemsetAsync(slots, 0x7f, cap * sizeof(int), st));
     if (!primed) MREC_HIP_CHECK(hipMemsetAsync(status, 0, (size_t)nblk * sizeof(int), st));     // (a completed call leaves them zero)
     const int g256 = (int)mrec_cdiv(n, DB);
     k_dedup_insert<K><<<(int)mrec_cdiv(n, IT), DB, 0, st>>>(ids, (int)n, slots, (uint32_t)(cap - 1), sidx);
@@ -320,6 +322,7 @@ int dedup_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_d
         fuse_inv_out->slots = slots; fuse_inv_out->sidx = sidx; fuse_inv_out->status = status; fuse_inv_out->nstatus = nblk;
         fuse_inv_out->first_pos = first_pos; fuse_inv_out->dup_pos = dup_pos; fuse_inv_out->n_dup = n_dup;
         fuse_inv_out->n_radix = n_dup ? n_dup + 1 : nullptr;
+        fuse_inv_out->slot_bytes = cap * sizeof(int);
     } else k_dedup_inv<<<g256, DB, 0, st>>>(slots, sidx, (int)n, inv, status, nblk);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
@@ -479,6 +482,7 @@ static int plan_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_
     k_plan_place<<<(unsigned)mrec_cdiv(n, 256), 256, 0, st>>>(sc.first_pos, n_uniq_dev, tk, tv, sc.n_dup, (int)n, sorted_pos,
                                                              sorted_seg, seg_offsets);
     MREC_LAUNCH_CHECK();
+    MREC_HIP_CHECK(hipMemsetAsync(sc.slots, 0x7f, sc.slot_bytes, st));       // hand the scratch table back clean (MREC_PLAN_WS_PRIMED)
     return MREC_OK;
 }
 
