@@ -149,3 +149,26 @@ def test_operand_copies_with_the_tail_pack(dev):
     packed = torch.empty_like(ref)
     ops.operand_copies([(a, at)], tail=(w2, w3, packed))
     assert torch.equal(packed, ref) and torch.equal(at, a.t().contiguous())
+
+
+@pytest.mark.parametrize("B", [192, 160])
+def test_engine_with_and_without_the_fused_tail(dev, B):
+    """The engine with the tail launch (B = 192) against the engine that runs the same net layer by layer: identical 16-bit
+    tensors, so everything downstream agrees to the accuracy of the few fp32 batch sums that are grouped differently (loss,
+    dW5, bias gradients).  B = 160 is not a multiple of 64: both engines then run layer by layer and must agree bit for bit."""
+    from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
+    kw = dict(vocab_size=100_000, emb_dim=16, field_size=26, batch_size=B, deep_layer_dim=[1024, 512, 256, 128], mlp_dtype="bf16")
+    a = WideDeepEngine(WideDeepConfig(fused_tail=True, **kw), dev)
+    b = WideDeepEngine(WideDeepConfig(fused_tail=False, **kw), dev)
+    assert a._tail_ok and not b._tail_ok and a._tail_now(B) == (B % 64 == 0)
+    for s in range(6):
+        ids, wts, label = synthetic_batch(a.cfg, dev, "zipf", seed=900 + s)
+        la, lb = float(a.train_step(ids, wts, label)), float(b.train_step(ids, wts, label))
+        assert abs(la - lb) <= (2e-6 * abs(lb) if B % 64 == 0 else 0.0), (s, la, lb)
+    if B % 64:
+        assert torch.equal(a.deep, b.deep) and torch.equal(a.dense_flat.detach(), b.dense_flat.detach())
+    else:
+        assert float((a.deep - b.deep).abs().max()) <= 2 * a.cfg.adam_lr * 6
+        frac = float(((a.dense_flat.detach() - b.dense_flat.detach()).abs() <= 0.05 * a.cfg.adam_lr).float().mean())
+        assert frac >= 0.999, frac
+        assert float(((a.deep - b.deep).abs() <= 0.05 * a.cfg.adam_lr).float().mean()) >= 0.9999
