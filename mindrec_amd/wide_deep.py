@@ -298,7 +298,8 @@ class WideDeepEngine:
         # ends ... -> 512 -> 256 -> 128 -> 1 (the reference's) and the batch is a multiple of 64; any other net: layer by layer.
         self._tail_packed, self._dense16_t = None, None
         nl_ = len(self.dims) - 1
-        self._tail_ok = bool(self._mfma and cfg.fused_tail and nl_ >= 4 and self.k.tail_supported(64, *self.dims[nl_ - 3:nl_]))
+        self._tail_ok = bool(self._mfma and cfg.fused_tail and nl_ >= 4 and cfg.field_size <= 64      # (<= 64 wide products per sample)
+                             and self.k.tail_supported(64, *self.dims[nl_ - 3:nl_]))
         self._refresh_tail()
         self._hashed = bool(cfg.dynamic_embedding)
         self._fused_rows = bool(cfg.fused_state and cfg.sparse and cfg.host_cache_rows == 0 and self._gpu)   # [p | w ... | m | v] rows
