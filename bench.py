@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--mlp-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--dropout", action="store_true", help="dropout_flag: True as in benchmarks/wide_deep/default_config.yaml:15 (Dropout(0.5) on every "
                     "DenseLayer input; models/wide_deep/default_config.yaml:27, the configuration of configs[1], has it off)")
+    ap.add_argument("--sink-size", type=int, default=5, help="training steps per host call (the reference's dataset_sink_mode / sink_size: "
+                    "train_and_eval_distribute.py:115-116); with the whole-step graph a sink is ONE graph launch")
     ap.add_argument("--dw-slabs", default="", help="layer:S,... weight-gradient slab counts instead of the library's proposal (sweeps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of each cpu_baseline leg")
@@ -245,21 +247,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    S = max(1, args.sink_size) if (world == 1 and not args.shard_protocol) else 1       # (a sink is a graph of whole steps: one GPU)
+
+    def run_steps(n, timers=None):
+        """n training steps over the resident batches, S per host call where S > 1 (a remainder step by step)."""
+        i = 0
+        while i < n:
+            if S > 1 and n - i >= S:
+                eng.train_steps([batches[(i + j) % len(batches)] for j in range(S)])
+                i += S
+            else:
+                if timers is not None:
+                    eng.deep_apply_timer = timers[i]      # armed by the engine right before the deep-table LazyAdam launch
+                eng.train_step(*batches[i % len(batches)])
+                i += 1
+
     # Priming (setup, whatever --warmup says): workspaces and the HIP graphs come into being in the engine's first steps.
     for i in range(5):
         eng.train_step(*batches[i % len(batches)])
+    if S > 1:
+        run_steps(S)
     barrier()
-    for i in range(args.warmup):
-        eng.train_step(*batches[i % len(batches)])
+    run_steps(args.warmup)
     barrier()
     block_s, kmain = [], []
     for r in range(max(1, args.repeats)):
         ktimers = [ops.KernelTimer() for _ in range(args.steps)]     # HIP events around k_apply_main only
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            eng.deep_apply_timer = ktimers[i]      # armed by the engine right before the deep-table LazyAdam launch
-            eng.train_step(*batches[i % len(batches)])
+        run_steps(args.steps, ktimers)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -281,7 +297,8 @@ def main():
         apply_timing = ("device wall-clock stamps written by k_apply_main itself (first workgroup begin -> last wave end; the step "
                         "is one HIP graph, whose event nodes cannot be timed), averaged over the last {n} timed steps")
     dt = median(block_s)
-    graphs_used = {"step": eng._step_graph is not None, "front": eng._front_graph is not None, "mlp": eng._mlp_graph is not None}
+    graphs_used = {"step": eng._step_graph is not None, "front": eng._front_graph is not None, "mlp": eng._mlp_graph is not None,
+                   "sink_size": S if eng._sink_graphs.get(S) else 1}
 
     # Per-phase device times (informational "kernels_ms"): HIP events around every phase, recorded in a few
     # EXTRA steps after the timed region -- two dozen timing events per step serialise the queue and cost
@@ -377,6 +394,7 @@ def main():
                                f"{f', tables in host DRAM behind a {args.host_cache_rows}-row device cache' if args.host_cache_rows else ''}, "
                                f"MLP {cfg.field_size * cfg.emb_dim}-1024-512-256-128-1 in {args.mlp_dtype} "
                                f"({'hand-written MFMA kernels' if eng._mfma else 'torch GEMMs'}; looked-up rows and row gradients in {dt_name})"
+                               f"{f', {S} steps per host call (sink_size)' if graphs_used.get('sink_size', 1) > 1 else ''}"
                                f"{', Dropout(0.5) on every DenseLayer input' if args.dropout else ''}",
                    "global_batch": args.batch * world, "id_dist": args.dist, "hip_graphs": graphs_used, "unique_frac": round(U / max(n_apply, 1), 4),
                    "parallelism": ("1 GPU" + (", row-shard protocol over RCCL with itself" if args.shard_protocol else "")) if world == 1 else f"tables row-sharded x{world} (RCCL all-to-all), MLP dp{world}"},

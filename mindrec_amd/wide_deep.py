@@ -321,6 +321,8 @@ class WideDeepEngine:
         self._dyn = False             # step scalars (Adam powers / step size) in device memory: set per step
         self._front_graph = None      # one-GPU: the whole front of the step (lookups .. MLP backward) as one captured graph
         self._step_graph = None       # ... and, with the wide branch folded, the whole step
+        self._sink_graphs = {}        # sink size -> that many whole steps as one graph (train_steps)
+        self._slot = 0
         self._step_state = None       # ops.StepState (device-side beta powers / step size), created on first use
         self._state_step = -1         # the step count the device-side state stands at
         self._dropout = bool(cfg.dropout_flag and cfg.dropout_keep_prob < 1.0)
@@ -456,7 +458,7 @@ class WideDeepEngine:
                 b5.detach(), wide.prod if prod else wide, self.wide_b if prod else None, label.view(-1), self.cfg.sens / B,
                 self.dense_grad[2 * (n - 1)].view(-1), self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1],
                 self.dense_grad[2 * (n - 3) + 1], self.dense_grad[2 * (n - 4) + 1], dwide_bias_out=self.wide_b_grad if prod else None,
-                drop_in=self._drop(n - 3, B), out=self._tail_out.setdefault((B, hs[-1].dtype), {}))
+                drop_in=self._drop(n - 3, B), out=self._tail_out.setdefault((B, hs[-1].dtype, self._slot), {}))
             return {"hs": hs + [y2], "loss": loss.view(()), "g_wide": dlogit.view(-1), "dh": dz2, "tail": (dz4, dz3)}
         if isinstance(wide, _WideProd):
             loss, _, dlogit, dh = self.k.head_fwd_bwd_wide(hs[-1], W5.detach().view(-1), b5.detach(), wide.prod, self.wide_b,
@@ -1038,6 +1040,56 @@ class WideDeepEngine:
         self.k.sum_slab_segments_(self.dense_grad_flat, self._slab_segments())
 
     # ---- one training step -------------------------------------------------------------------
+    def train_steps(self, batches):
+        """`len(batches)` training steps per host call -- the reference's dataset_sink_mode / sink_size (rec_model.py:119-150,
+        train_and_eval_distribute.py:115-116: the steps of a sink run on the device without returning to the host).  Where the whole
+        step replays as one HIP graph, a sink of S steps replays as ONE graph of S steps: between two graph launches the GPU idles
+        for ~14 us (launch latency, with or without the staging copy in between), which a sink pays once per S steps.  Same
+        kernels on the same data in the same order as S train_step calls: identical results.  Returns the S losses."""
+        S = len(batches)
+        g = self._step_graph
+        if (S > 1 and g is not None and self.cfg.graph_step and self._front_graph_ok() and self._dyn and self._state_step == self.step_count
+                and all(b[0].shape == g["ids"].shape and b[0].dtype == g["ids"].dtype for b in batches)):
+            sg = self._sink_graphs.get(S)
+            if sg is None and S not in self._sink_graphs:
+                sg = self._capture_sink([tuple(t.clone() for t in b) for b in batches])
+            if sg is not None:
+                for dst, src in zip(sg["inputs"], batches):
+                    self.k.copy3_(dst, tuple(src))
+                for _ in range(S):
+                    self.step_count += 1
+                    self.beta1_power = np.float32(self.beta1_power * self.beta1)
+                    self.beta2_power = np.float32(self.beta2_power * self.beta2)
+                self._state_step = self.step_count
+                self.deep_apply_timer = None
+                sg["graph"].replay()
+                self.last_plan = sg["plan"]
+                return sg["losses"]
+        return [self.train_step(*b).clone() for b in batches]       # (train_step hands out a static buffer once graphs replay)
+
+    def _capture_sink(self, inputs):
+        try:
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            losses = []
+            self._training = True
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                for slot, (ids, wts, label) in enumerate(inputs):
+                    self._slot = slot                 # per-step output buffers of the tail launch (the losses must not alias)
+                    front = self._front(ids, wts, label, capturing=True)
+                    losses.append(self._tail(front, ids, wts))
+            sg = {"graph": graph, "inputs": inputs, "losses": losses, "plan": self.last_plan}
+            self._sink_graphs[len(inputs)] = sg
+            return sg
+        except RuntimeError as e:
+            import warnings
+            warnings.warn(f"HIP-graph capture of a {len(inputs)}-step sink failed, running it step by step: {e}")
+            self._sink_graphs[len(inputs)] = None
+            return None
+        finally:
+            self._training = False
+            self._slot = 0
+
     def train_step(self, ids, wts, label):
         self._training = True
         try:

@@ -424,3 +424,27 @@ def test_folded_wide_branch_equals_separate_wide_kernels(dev):
         else:
             assert float((a.wide - b.wide).abs().max()) <= 1e-5 * float(b.wide.abs().max())
             assert float((a.deep - b.deep).abs().max()) <= 1e-5 * float(b.deep.abs().max())
+
+
+def test_sink_of_steps_equals_step_by_step(dev):
+    """train_steps (the reference's dataset_sink_mode / sink_size): S steps replayed as ONE graph must equal S train_step calls
+    bit for bit -- losses, tables, dense parameters, the device-side step state; a sink of another size, a shorter remainder and
+    a step-by-step call in between keep working; Dropout's masks move with the step inside the sink."""
+    from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
+    kw = dict(vocab_size=50000, emb_dim=16, field_size=26, batch_size=2048, deep_layer_dim=[256, 128, 64, 32], mlp_dtype="bf16",
+              dropout_flag=True)
+    a = WideDeepEngine(WideDeepConfig(**kw), dev)
+    b = WideDeepEngine(WideDeepConfig(**kw), dev)
+    bs = [synthetic_batch(a.cfg, dev, "zipf", seed=600 + s) for s in range(24)]
+    la, lb = [], []
+    i = 0
+    for chunk in (4, 1, 3, 3, 1, 3, 4, 2, 3):                     # the first sinks run step by step (no graph yet), then 2-, 3- and 4-step graphs
+        la += [float(x) for x in a.train_steps(bs[i:i + chunk])]
+        lb += [float(b.train_step(*bs[i + j])) for j in range(chunk)]
+        i += chunk
+    assert la == lb, (la, lb)
+    assert set(k for k, v in a._sink_graphs.items() if v) == {2, 3, 4} and not b._sink_graphs
+    assert torch.equal(a.deep, b.deep) and torch.equal(a.wide, b.wide) and torch.equal(a.dense_flat.detach(), b.dense_flat.detach())
+    sa, sb = a._step_state.read(), b._step_state.read()
+    assert int(sa["step"]) == int(sb["step"]) == a.step_count == b.step_count == 24
+    assert float(sa["beta1_power"]) == float(sb["beta1_power"]) == float(a.beta1_power)
