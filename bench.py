@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--dropout", action="store_true", help="dropout_flag: True as in benchmarks/wide_deep/default_config.yaml:15 (Dropout(0.5) on every "
                     "DenseLayer input; models/wide_deep/default_config.yaml:27, the configuration of configs[1], has it off)")
     ap.add_argument("--sink-size", type=int, default=5, help="training steps per host call (the reference's dataset_sink_mode / sink_size: "
-                    "train_and_eval_distribute.py:115-116); with the whole-step graph a sink is ONE graph launch")
+                    "train_and_eval.py:98-101, train_and_eval_distribute.py:115-116); with the whole-step graph a sink is ONE graph launch")
     ap.add_argument("--dw-slabs", default="", help="layer:S,... weight-gradient slab counts instead of the library's proposal (sweeps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of each cpu_baseline leg")

@@ -1041,8 +1041,9 @@ class WideDeepEngine:
 
     # ---- one training step -------------------------------------------------------------------
     def train_steps(self, batches):
-        """`len(batches)` training steps per host call -- the reference's dataset_sink_mode / sink_size (rec_model.py:119-150,
-        train_and_eval_distribute.py:115-116: the steps of a sink run on the device without returning to the host).  Where the whole
+        """`len(batches)` training steps per host call -- the reference's dataset_sink_mode / sink_size (Model.train(...,
+        dataset_sink_mode=True), models/wide_deep/train_and_eval.py:98-101; sink_size, train_and_eval_distribute.py:115-116: the steps
+        of a sink run on the device without returning to the host; RecModel.online_train restricts it to 1, rec_model.py:268-271).  Where the whole
         step replays as one HIP graph, a sink of S steps replays as ONE graph of S steps: between two graph launches the GPU idles
         for ~14 us (launch latency, with or without the staging copy in between), which a sink pays once per S steps.  Same
         kernels on the same data in the same order as S train_step calls: identical results.  Returns the S losses."""
