@@ -511,7 +511,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm256(const Args a) {
 // layers, neither fills the chip alone.  Workgroups [0, n1) run the problem whose workgroups take longer (more K-tiles
 // each; dispatched first so that the short ones pack behind them), the rest the other one.
 // ... plus, behind them, the workgroups of up to two MORE weight-gradient problems (other layers' -- the tail launch of
-// mrec_mlp.hip leaves its two layers' weight gradients to be computed, and alone each is a latency-bound 10-16 us launch).
+// mrec_tail.hip leaves its two layers' weight gradients to be computed, and alone each is a latency-bound 10-16 us launch).
 struct ExtraW { Args a[2]; int n[2]; };
 template <bool F16, int MRD = 8, int MRW = 8>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm256_bwd(const Args ad, const Args aw, const int n1, const int wfirst, const ExtraW ex) {

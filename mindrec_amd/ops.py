@@ -847,7 +847,7 @@ def head_fwd_bwd_wide(h4, w5, b5, wide_prod, wide_bias, label, dscale, dw5_out, 
     return loss, logit, dlogit, dh4
 
 
-# ---- the tail of the dense net in one launch (csrc/mrec_mlp.hip: k_tail) -------------------------------------------------
+# ---- the tail of the dense net in one launch (csrc/mrec_tail.hip: k_tail) -------------------------------------------------
 def tail_supported(B, K2, N2, N3):
     return bool(_lib.lib().mrec_tail_supported(int(B), int(K2), int(N2), int(N3)))
 

@@ -1,5 +1,5 @@
 """The tail of the dense net as ONE launch (mrec_tail_fwd_bwd: two DenseLayers forward, the output head, two input-gradient
-bprops; csrc/mrec_mlp.hip k_tail) against the five separate launches it replaces -- which are the ones checked against the
+bprops; csrc/mrec_tail.hip k_tail) against the five separate launches it replaces -- which are the ones checked against the
 oracle (tests/test_dense_gpu.py, test_gpu_parity.py, test_bench_shape_gpu.py).  Same products in the same order: the 16-bit
 tensors, the logits and the per-sample gradients must be IDENTICAL; the batch reductions (dw5, bias gradients, loss) are taken
 over different partial groupings and agree to fp32 summation accuracy."""
