@@ -1,0 +1,268 @@
+"""The dense net of the Wide&Deep engine: DenseLayer x5 (models/wide_deep/src/wide_and_deep.py:113-133, :164-205) forward and
+backward on the hand-written MFMA kernels (csrc/mrec_dense.hip, csrc/mrec_tail.hip), Dropout on the layer inputs, the HIP graphs
+of the MLP step.  A mixin of WideDeepEngine (mindrec_amd/wide_deep.py), which owns the state these methods work on."""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+class _WideProd:
+    """The wide branch as its per-field products [B, F] (written by the fused lookup, summed inside the output head)."""
+
+    def __init__(self, prod):
+        self.prod = prod
+
+
+class DenseNetMixin:
+    def _drop(self, layer, B):
+        """Dropout descriptor of DenseLayer `layer`'s input for the training step in flight (None: no dropout).  The mask is a
+        function of (seed, step, layer, global sample row, column): on the GPU the step is read from the device-side step
+        state (a captured step replays with a moving step), row0 makes N data-parallel ranks draw the mask of one big batch."""
+        if not (self._dropout and self._training):
+            return None
+        return self.k.Dropout(self.cfg.dropout_keep_prob, self.cfg.seed + 4, layer, step=self.step_count - 1, row0=self.rank * B,
+                              step_state=self._step_state if self._gpu and self.k is ops else None)
+
+    def _refresh_tail(self):
+        """Derived copies of the 16-bit weights, rewritten (one launch) whenever the shadow changes: the transposes [out, in] the
+        forward GEMMs read (both operands K-contiguous: 15 % faster than W as stored through transposing LDS reads) and the tail
+        kernel's fragment-ordered weights."""
+        if not self._mfma:
+            return
+        n = len(self.dims) - 1
+        hidden = range(n - 3 if self._tail_ok else n - 1)          # the layers that run as GEMM launches of their own
+        if self._dense16_t is None:
+            self._dense16_t = {i: torch.empty((self.dims[i + 1], self.dims[i]), dtype=self._amp, device=self.device) for i in hidden}
+            if self._tail_ok:
+                self._tail_packed = torch.empty(2 * (self.dims[n - 3] * self.dims[n - 2] + self.dims[n - 2] * self.dims[n - 1]),
+                                                dtype=self._amp, device=self.device)
+        tr = [(self.dense16[2 * i], self._dense16_t[i]) for i in hidden]
+        tail = (self.dense16[2 * (n - 3)], self.dense16[2 * (n - 2)], self._tail_packed) if self._tail_ok else None
+        for k in range(0, max(len(tr), 1), 4):                      # (at most 4 transposes per launch; the reference's net: 2)
+            self.k.operand_copies(tr[k:k + 4], tail if k == 0 else None)
+
+    def _tail_now(self, B):
+        return bool(self._tail_ok and self.k.tail_supported(B, *self.dims[len(self.dims) - 4:len(self.dims) - 1]))
+
+    def mlp(self, x):
+        """DenseLayer x5 (wide_and_deep.py:113-133): act(x W + b), ReLU on all but the last; returns the fp32 logit.
+        On the GPU in 16-bit mode the hidden layers are the MFMA kernels of csrc/mrec_dense.hip (inference path,
+        no autograd); the last layer (128 -> 1, a GEMV) is fp32.  Otherwise (fp32 net, CPU stand-in) plain autograd."""
+        n = len(self.dims) - 1
+        amp = self._amp
+        if self._mfma and not torch.is_grad_enabled():
+            h = x if x.dtype == amp else x.to(amp)
+            for i in range(n - 1):
+                h = self.k.dense_fwd(h, self.dense16[2 * i], self.dense[2 * i + 1].detach(), relu=True)
+            return torch.addmm(self.dense[2 * (n - 1) + 1].detach(), h.float(), self.dense[2 * (n - 1)].detach())
+        h = x.to(amp) if amp is not None else x
+        for i in range(n):
+            W, b = self.dense[2 * i], self.dense[2 * i + 1]
+            d = self._drop(i, h.shape[0])
+            if d is not None:              # `x = self.dropout(x)`, :117-118 (autograd multiplies the gradient by the same mask)
+                h = h * self.k.dropout_mask(h.shape[0], h.shape[1], d, self.device).to(h.dtype)
+            if amp is not None and i < n - 1:
+                h = torch.addmm(b.to(amp), h, W.to(amp))
+            else:
+                h = torch.addmm(b, h.float(), W)
+            if i < n - 1:
+                h = torch.relu(h)
+        return h.float()
+
+    # ---- the mixed-precision dense net, forward + backward by hand on the MFMA kernels -----------------
+    def _db_slabs(self, i, B):
+        """fp32 per-tile-row partial sums [ceil(B/256), out_i] of hidden layer i's bias gradient (written by the input-gradient
+        kernel of layer i + 1, added up inside the dense Adam like the weight-gradient slabs)."""
+        if self._dw_batch != B:
+            self._dw, self._db, self._dw_batch = {}, {}, B
+        t = self._db.get(i)
+        if t is None:
+            # written by the backward launch of layer i + 1, whose reduction width is dims[i + 2]
+            rows = self.k.dense_bwd_bias_slabs(B, self.dims[i + 1], self.dims[i + 2])
+            t = torch.empty((rows, self.dims[i + 1]), dtype=torch.float32, device=self.device)
+            self._db[i] = t
+        return t
+
+    def _dw_slabs(self, i, B):
+        """fp32 batch slabs [S, in, out] the weight-gradient kernel of hidden layer i writes (allocated once per batch size)."""
+        if self._dw_batch != B:
+            self._dw, self._db, self._dw_batch = {}, {}, B
+        t = self._dw.get(i)
+        if t is None:
+            K, N = self.dims[i], self.dims[i + 1]
+            S = int((self.cfg.dw_slabs or {}).get(i, 0)) or self.k.dense_bwd_weight_slabs(B, K, N)
+            t = torch.empty((S, K, N), dtype=torch.float32, device=self.device)
+            self._dw[i] = t
+        return t
+
+    @torch.no_grad()
+    def _mlp_fwd(self, emb):
+        """Hidden layers forward: the activations hs[0..n-1] (hs[0] = the MLP input), bias + ReLU in the GEMM epilogue."""
+        n = len(self.dims) - 1
+        hs = [emb if emb.dtype == self._amp else emb.to(self._amp)]
+        B = hs[0].shape[0]
+        d0 = self._drop(0, B)
+        if d0 is not None:
+            self.k.dropout_(hs[0], d0)     # the looked-up rows are consumed by the first layer only: in place
+        for i in range(n - 3 if self._tail_now(B) else n - 1):         # (fused tail: its two layers run in _mlp_head's launch)
+            # Dropout on the input of layer i + 1 (:117-118) = on this layer's output, in the GEMM epilogue
+            hs.append(self.k.dense_fwd(hs[i], self.dense16[2 * i], self.dense[2 * i + 1].detach(), relu=True, drop_next=self._drop(i + 1, B),
+                                       wt=self._dense16_t.get(i)))
+        return hs
+
+    @torch.no_grad()
+    def _mlp_head(self, hs, wide, label):
+        """Output layer + wide/deep add + sigmoid cross-entropy, forward AND backward.  Returns the context the
+        backward needs: hs, loss, dlogit (= the wide branch's gradient), dh."""
+        amp, n = self._amp, len(self.dims) - 1
+        B = hs[0].shape[0]
+        W5, b5 = self.dense[2 * (n - 1)], self.dense[2 * (n - 1) + 1]
+        K5 = self.dims[n - 1]
+        dl = self._drop(n - 1, B)
+        dhs = dl.scale if dl is not None else 1.0
+        if len(hs) == n - 2:
+            # fused tail: layers n - 3 and n - 2 forward, the head, and the input gradients back to the output of layer n - 4
+            prod = isinstance(wide, _WideProd)
+            loss, dlogit, y2, dz4, dz3, dz2 = self.k.tail_fwd_bwd(
+                hs[-1], self._tail_packed, self.dense[2 * (n - 3) + 1].detach(), self.dense[2 * (n - 2) + 1].detach(), W5.detach().view(-1),
+                b5.detach(), wide.prod if prod else wide, self.wide_b if prod else None, label.view(-1), self.cfg.sens / B,
+                self.dense_grad[2 * (n - 1)].view(-1), self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1],
+                self.dense_grad[2 * (n - 3) + 1], self.dense_grad[2 * (n - 4) + 1], dwide_bias_out=self.wide_b_grad if prod else None,
+                drop_in=self._drop(n - 3, B), out=self._tail_out.setdefault((B, hs[-1].dtype, self._slot), {}))
+            return {"hs": hs + [y2], "loss": loss.view(()), "g_wide": dlogit.view(-1), "dh": dz2, "tail": (dz4, dz3)}
+        if isinstance(wide, _WideProd):
+            loss, _, dlogit, dh = self.k.head_fwd_bwd_wide(hs[-1], W5.detach().view(-1), b5.detach(), wide.prod, self.wide_b,
+                                                            label.view(-1), self.cfg.sens / B, self.dense_grad[2 * (n - 1)].view(-1),
+                                                            self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1],
+                                                            dwide_bias_out=self.wide_b_grad, dh_scale=dhs)
+            loss = loss.view(())
+        elif self.k.head_supported(K5):
+            # output layer + wide/deep add + sigmoid cross-entropy, forward AND backward, one pass over h4
+            loss, _, dlogit, dh = self.k.head_fwd_bwd(hs[-1], W5.detach().view(-1), b5.detach(), wide, label.view(-1),
+                                                       self.cfg.sens / B, self.dense_grad[2 * (n - 1)].view(-1),
+                                                       self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1], dh_scale=dhs)
+            loss = loss.view(())
+        else:
+            h4 = hs[-1].float()
+            logit = torch.addmm(b5, h4, W5) + wide.view(-1, 1)
+            loss = F.binary_cross_entropy_with_logits(logit, label)
+            dlogit = (torch.sigmoid(logit) - label) * (self.cfg.sens / B)          # d(sens * mean BCE)/d logit
+            torch.mm(h4.t(), dlogit, out=self.dense_grad[2 * (n - 1)])
+            torch.sum(dlogit, dim=0, out=self.dense_grad[2 * (n - 1) + 1])
+            dh = torch.ops.aten.threshold_backward((torch.mm(dlogit, W5.t()) * dhs).to(amp), hs[-1], 0)
+            torch.sum(dh, dim=0, dtype=torch.float32, out=self.dense_grad[2 * (n - 2) + 1])
+        return {"hs": hs, "loss": loss, "g_wide": dlogit.view(-1), "dh": dh}
+
+    @torch.no_grad()
+    def _mlp_bwd(self, ctx):
+        """Backward through the hidden layers; returns g_emb [B, F*D] (16-bit).  One launch per layer, from the top:
+        the input gradient (MatMul bprop fused with the ReLU and BiasAdd bprops of the layer below: that layer's bias
+        gradient is left as per-tile-row partial sums) and the weight gradient (fp32 batch slabs) are workgroups of the
+        same kernel -- both read dh, and for the narrow layers neither fills the chip alone.  Slabs and partial sums are
+        added up inside the dense Adam.  (Weight gradients on a parallel stream / graph branch instead were measured:
+        the graph runtime queues chain kernels behind side-branch work, 0.87 -> 0.95 ms/step.)"""
+        n = len(self.dims) - 1
+        hs, dh = ctx["hs"], ctx["dh"]
+        B = hs[0].shape[0]
+        top, extra = n - 2, None
+        if "tail" in ctx:
+            # the tail launch has gone back through layers n - 2 and n - 3 already; their weight gradients (batch reductions) remain:
+            # they ride the backward launch of layer n - 4
+            dz4, dz3 = ctx["tail"]
+            extra = [(hs[n - 3], dz3, self._dw_slabs(n - 3, B)), (hs[n - 2], dz4, self._dw_slabs(n - 2, B))]
+            top = n - 4
+        for i in range(top, -1, -1):
+            dh = self.k.dense_bwd(dh, self.dense16[2 * i], hs[i], self._dw_slabs(i, B), mask=i > 0,
+                                  db_slabs=self._db_slabs(i - 1, B) if i > 0 else None, drop_in=self._drop(i, B), extra=extra)
+            extra = None
+        return dh
+
+    def _mlp_step_eager(self, emb, wide, label, after_head=None):
+        """Forward + backward of the mixed-precision MLP written out by hand (no autograd graph).  `emb` arrives
+        in 16 bits straight from the gather kernel, and the gradient of the MLP input is returned in 16 bits
+        for the sparse apply to widen on load.  Weights are read from their 16-bit shadows (no per-step cast kernels).
+        Returns (loss, g_emb [B, F*D] 16-bit, g_wide [B] fp32).  after_head(g_wide) is called as soon as the wide
+        branch's gradient exists (the caller may start the wide table's update beside the backward GEMMs)."""
+        hs = self._mlp_fwd(emb)
+        if callable(wide):
+            wide = wide()                  # joins whatever stream computed the wide branch; returns the tensor
+        ctx = self._mlp_head(hs, wide, label)
+        if after_head is not None:
+            after_head(ctx["g_wide"])
+        g_emb = self._mlp_bwd(ctx)
+        return ctx["loss"], g_emb, ctx["g_wide"]
+
+    def _mlp_step(self, emb, wide, label, after_head=None):
+        """The MLP step, replayed from HIP graphs once the engine has run two eager steps (workspaces exist by then).
+        The graphs hold exactly the kernels of the eager path, in the same order, on the same buffers (weights /
+        gradients are updated in place, so their addresses are stable); inputs are staged in three static tensors --
+        the gather writes the embeddings there directly.  Graphs: hidden-layer forward [| head] | backward.  `wide` may
+        be a function: it is called between the first two (the wide branch is computed on the side stream meanwhile);
+        after_head runs before the backward graph (the wide branch's gradient exists from there on)."""
+        if not (self.cfg.graph_mlp and self._gpu and self.step_count > 2):
+            return self._mlp_step_eager(emb, wide, label, after_head=after_head)
+        g = self._mlp_graph
+        if (g is None or g["emb"].shape != emb.shape or g["emb"].dtype != emb.dtype or (g["graph_head"] is None) == callable(wide)
+                or isinstance(g["wide"], _WideProd) != isinstance(wide, _WideProd)):
+            try:
+                g = self._capture_mlp(emb, wide, label)
+            except RuntimeError as e:          # capture refused: stay eager
+                import warnings
+                warnings.warn(f"HIP-graph capture of the MLP step failed, running it eagerly: {e}")
+                self.cfg.graph_mlp = False
+                self._mlp_graph = None
+                return self._mlp_step_eager(emb, wide, label, after_head=after_head)
+        if emb.data_ptr() != g["emb"].data_ptr():
+            g["emb"].copy_(emb)
+        g["label"].copy_(label)
+
+        def stage_wide():
+            w_ = wide() if callable(wide) else wide
+            if isinstance(w_, _WideProd):
+                g["wide"].prod.copy_(w_.prod)
+            else:
+                g["wide"].copy_(w_)
+
+        if g["graph_head"] is None:
+            stage_wide()
+            g["graph_fwd"].replay()                # hidden layers + head in one graph
+        else:
+            g["graph_fwd"].replay()
+            stage_wide()
+            g["graph_head"].replay()
+        if after_head is not None:
+            after_head(g["ctx"]["g_wide"])
+        g["graph_bwd"].replay()
+        return g["ctx"]["loss"], g["g_emb"], g["ctx"]["g_wide"]
+
+    def _capture_mlp(self, emb, wide, label):
+        late = callable(wide)
+        if late:
+            wide = wide()
+        g = {"emb": torch.empty_like(emb), "label": torch.empty_like(label)}
+        g["wide"] = _WideProd(wide.prod.clone()) if isinstance(wide, _WideProd) else wide.clone()
+        g["emb"].copy_(emb)
+        g["label"].copy_(label)
+        torch.cuda.synchronize(self.device)
+        # thread_local: RCCL's watchdog thread may query events while this thread captures
+        g1 = torch.cuda.CUDAGraph()
+        if late:
+            # cut between the hidden layers and the head: the wide branch arrives in between
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                g["hs"] = self._mlp_fwd(g["emb"])
+            gh = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gh, capture_error_mode="thread_local"):
+                g["ctx"] = self._mlp_head(g["hs"], g["wide"], g["label"])
+            g["graph_head"] = gh
+        else:
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                g["hs"] = self._mlp_fwd(g["emb"])
+                g["ctx"] = self._mlp_head(g["hs"], g["wide"], g["label"])
+            g["graph_head"] = None
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+            g["g_emb"] = self._mlp_bwd(g["ctx"])
+        g["graph_fwd"], g["graph_bwd"] = g1, g2
+        self._mlp_graph = g
+        return g
