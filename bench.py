@@ -298,7 +298,7 @@ def main():
                         "is one HIP graph, whose event nodes cannot be timed), averaged over the last {n} timed steps")
     dt = median(block_s)
     graphs_used = {"step": eng._step_graph is not None, "front": eng._front_graph is not None, "mlp": eng._mlp_graph is not None,
-                   "sink_size": S if (eng._sink_graphs.get(S) and args.steps >= S) else 1}
+                   "sink_size": S if (any(k[0] == S and v for k, v in eng._sink_graphs.items()) and args.steps >= S) else 1}
 
     # Per-phase device times (informational "kernels_ms"): HIP events around every phase, recorded in a few
     # EXTRA steps after the timed region -- two dozen timing events per step serialise the queue and cost

@@ -316,7 +316,7 @@ class WideDeepEngine(DenseNetMixin):
         self._dyn = False             # step scalars (Adam powers / step size) in device memory: set per step
         self._front_graph = None      # one-GPU: the whole front of the step (lookups .. MLP backward) as one captured graph
         self._step_graph = None       # ... and, with the wide branch folded, the whole step
-        self._sink_graphs = {}        # sink size -> that many whole steps as one graph (train_steps)
+        self._sink_graphs = {}        # (sink size, batch shape, id dtype) -> that many whole steps as one graph (train_steps)
         self._slot = 0
         self._step_state = None       # ops.StepState (device-side beta powers / step size), created on first use
         self._state_step = -1         # the step count the device-side state stands at
@@ -794,9 +794,10 @@ class WideDeepEngine(DenseNetMixin):
         g = self._step_graph
         if (S > 1 and g is not None and self.cfg.graph_step and self._front_graph_ok() and self._dyn and self._state_step == self.step_count
                 and all(b[0].shape == g["ids"].shape and b[0].dtype == g["ids"].dtype for b in batches)):
-            sg = self._sink_graphs.get(S)
-            if sg is None and S not in self._sink_graphs:
-                sg = self._capture_sink([tuple(t.clone() for t in b) for b in batches])
+            key = (S, tuple(g["ids"].shape), g["ids"].dtype)
+            sg = self._sink_graphs.get(key)
+            if sg is None and key not in self._sink_graphs:
+                sg = self._capture_sink(key, [tuple(t.clone() for t in b) for b in batches])
             if sg is not None:
                 for dst, src in zip(sg["inputs"], batches):
                     self.k.copy3_(dst, tuple(src))
@@ -811,7 +812,7 @@ class WideDeepEngine(DenseNetMixin):
                 return sg["losses"]
         return [self.train_step(*b).clone() for b in batches]       # (train_step hands out a static buffer once graphs replay)
 
-    def _capture_sink(self, inputs):
+    def _capture_sink(self, key, inputs):
         try:
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
@@ -823,12 +824,12 @@ class WideDeepEngine(DenseNetMixin):
                     front = self._front(ids, wts, label, capturing=True)
                     losses.append(self._tail(front, ids, wts))
             sg = {"graph": graph, "inputs": inputs, "losses": losses, "plan": self.last_plan}
-            self._sink_graphs[len(inputs)] = sg
+            self._sink_graphs[key] = sg
             return sg
         except RuntimeError as e:
             import warnings
             warnings.warn(f"HIP-graph capture of a {len(inputs)}-step sink failed, running it step by step: {e}")
-            self._sink_graphs[len(inputs)] = None
+            self._sink_graphs[key] = None
             return None
         finally:
             self._training = False
