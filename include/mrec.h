@@ -122,10 +122,14 @@ int mrec_gather_rows_f16_i64(const float* table, int64_t V, int64_t ld, int32_t 
  * D <= 252.  The per-sample sum over the fields + bias is taken by mrec_head_fwd_bwd_wide in field order: same adds, same
  * order as mrec_wide_sum.  ldo: row stride of `out` in 16-bit elements (D for a plain [n, D] result),
  * ldw: stride of wide_prod in floats (2 for the plain [n, 2] result) -- a shard's answer message packs both into one row
- * [D 16-bit values | product, 0 | pad] by pointing wide_prod at column D / 2 of the same rows. */
+ * [D 16-bit values | product, 0 | pad] by pointing wide_prod at column D / 2 of the same rows.
+ * drop (nullable; mrec_dropout_t, declared with the DenseLayer entries below) + fields: the ids are [n / fields, fields] and the
+ * looked-up rows the [fields * D] input of DenseLayer drop->layer: Dropout is applied to the rounded rows on their way out
+ * (x * (1 / keep_prob), rounded again: what mrec_dropout would do in a pass of its own). */
+struct mrec_dropout;
 int mrec_gather_rows_wide(const float* table, int64_t V, int64_t ld, int32_t D, const void* ids, int32_t id_bytes, int64_t n,
                           const float* row_scale, void* out, int32_t out_kind, int64_t ldo, int32_t wide_col, float* wide_prod,
-                          int64_t ldw, void* stream);
+                          int64_t ldw, const struct mrec_dropout* drop, int32_t fields, void* stream);
 
 /* Wide branch of WideDeepModel.construct (wide_and_deep.py:300,303-306) in one pass:
  * out[b] = sum_f w[ids[b,f] * ldw] * wts[b,f] + *bias_dev   (w is the [V,1] wide table, row

@@ -50,7 +50,7 @@ _SIGS = {
     "mrec_gather_rows_bf16_i64": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_gather_rows_f16_i32": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_gather_rows_f16_i64": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
-    "mrec_gather_rows_wide": [_vp, _i64, _i64, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _i64, _i32, _vp, _i64, _vp],
+    "mrec_gather_rows_wide": [_vp, _i64, _i64, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _i32, _vp],
     "mrec_sparse_lazy_adam_wide": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i64, _vp,
                                    _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _sz, _vp, _vp],
     "mrec_step_state_init": [_vp, _f32, _f32, _i64, _vp],

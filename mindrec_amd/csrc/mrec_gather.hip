@@ -10,6 +10,7 @@
 #include "mrec_common.h"
 #include "mrec_rng.h"
 #include "mrec_optim.h"
+#include "mrec_dropout.h"
 
 int g_mrec_last_hip_error = 0;
 
@@ -67,12 +68,31 @@ __device__ __forceinline__ uint2 pack16(const bf16o_t*, const float4& v) {
 __device__ __forceinline__ uint2 pack16(const f16o_t*, const float4& v) { return make_uint2(f2h2(v.x, v.y), f2h2(v.z, v.w)); }
 __device__ __forceinline__ uint2 pack16(const float*, const float4&) { return make_uint2(0u, 0u); }
 
+// Dropout on looked-up 16-bit rows (the first DenseLayer's input, wide_and_deep.py:117-118) inside the lookup: position i of
+// the id list is sample i / F, columns (i % F) * D + col .. + 3 of that sample's [F * D] input; x * (1 / keep) rounded again.
+struct GatherDrop { DropArgs d; int F; };
+__device__ __forceinline__ float widen16(const bf16o_t*, uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ float widen16(const f16o_t*, uint32_t b) { return (float)__builtin_bit_cast(_Float16, (uint16_t)b); }
+__device__ __forceinline__ float widen16(const float*, uint32_t) { return 0.0f; }
+template <class OT>
+__device__ __forceinline__ uint2 drop16(uint2 u, const GatherDrop& gd, uint64_t key, int64_t i, int D, int col) {
+    const int64_t r = i / gd.F;
+    const int64_t c = (i - r * gd.F) * D + col;
+    const uint64_t qd = drop_quad(key, gd.d.row0 + r, (int64_t)gd.F * D, c);
+    float v[4] = {widen16((const OT*)nullptr, u.x & 0xFFFFu), widen16((const OT*)nullptr, u.x >> 16),
+                  widen16((const OT*)nullptr, u.y & 0xFFFFu), widen16((const OT*)nullptr, u.y >> 16)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = drop_keep(qd, j, gd.d.thresh) ? v[j] * gd.d.scale : 0.0f;
+    return pack16((const OT*)nullptr, make_float4(v[0], v[1], v[2], v[3]));
+}
+
 template <int VEC, class K, class OT = float>
 __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ table, int64_t V, int64_t ld,
                                                      const K* __restrict__ ids, int64_t n,
                                                      const float* __restrict__ row_scale,
                                                      OT* __restrict__ out, int D, RowGeom gm,
-                                                     float* __restrict__ wprod = nullptr, int64_t ldo = 0, int64_t ldw = 2) {
+                                                     float* __restrict__ wprod = nullptr, int64_t ldo = 0, int64_t ldw = 2,
+                                                     GatherDrop gd = GatherDrop{}) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
     if (grp >= gm.G) return;
@@ -107,6 +127,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
               if (wprod != nullptr) {
                 const float4 yv = y.v;
                 uint2 u = pack16((const OT*)nullptr, yv);
+                if (gd.d.thresh && !wl) u = drop16<OT>(u, gd, drop_key(gd.d), i, D, col);
                 if (wl) u = make_uint2(__float_as_uint(yv.x), 0u);
                 uint2* dst = wl ? (uint2*)(wprod + ldw * i) : (uint2*)(out + i * ldo + col);
                 *dst = u;
@@ -420,7 +441,7 @@ inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 template <class K, class OT = bf16o_t>
 int gather_bf16_impl(const float* table, int64_t V, int64_t ld, int32_t D, const K* ids, int64_t n,
                      const float* row_scale, uint16_t* out, void* stream, int wcol = 0, float* wprod = nullptr, int64_t ldo = 0,
-                     int64_t ldw = 2) {
+                     int64_t ldw = 2, GatherDrop gd = GatherDrop{}) {
     if ((ldo != 0 && (ldo < D || ldo % 4)) || (wprod && (ldw < 2 || ldw % 2))) return MREC_EINVAL;
     if (wprod && (wcol != D || D % 4 || D > 252 || ld % 4 || ld < D + 4 || !al16(table) || (((uintptr_t)out) & 7) || (((uintptr_t)wprod) & 7)))
         return MREC_EUNSUPPORTED;       // the wide word must sit right behind the deep columns of 16-byte aligned rows
@@ -433,7 +454,7 @@ int gather_bf16_impl(const float* table, int64_t V, int64_t ld, int32_t D, const
         const int lpr = D / 4 + (wprod ? 1 : 0);
         RowGeom gm{lpr, 64 / lpr};
         k_gather_rows<4, K, OT><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
-            table, V, ld, ids, n, row_scale, (OT*)out, D, gm, wprod, ldo, ldw);
+            table, V, ld, ids, n, row_scale, (OT*)out, D, gm, wprod, ldo, ldw, gd);
     } else if (D <= 64 && !wprod && ldo == 0) {
         RowGeom gm{D, 64 / D};
         k_gather_rows<1, K, OT><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
@@ -564,16 +585,21 @@ MREC_API int mrec_gather_rows_f16_i64(const float* table, int64_t V, int64_t ld,
 /* Gather + the wide branch's products in one pass (see include/mrec.h): out_kind 1 = bf16, 2 = f16 rows. */
 MREC_API int mrec_gather_rows_wide(const float* table, int64_t V, int64_t ld, int32_t D, const void* ids, int32_t id_bytes,
                                    int64_t n, const float* row_scale, void* out, int32_t out_kind, int64_t ldo, int32_t wide_col,
-                                   float* wide_prod, int64_t ldw, void* stream) {
+                                   float* wide_prod, int64_t ldw, const mrec_dropout_t* drop, int32_t fields, void* stream) {
     if ((id_bytes != 4 && id_bytes != 8) || (out_kind != 1 && out_kind != 2)) return MREC_EINVAL;
     if (!wide_prod || wide_col < 0 || wide_col >= ld) return MREC_EINVAL;
+    GatherDrop gd{};
+    if (drop) {
+        if (fields <= 0 || n % fields || !drop_from(drop, (int64_t)fields * D, &gd.d)) return MREC_EINVAL;
+        gd.F = fields;
+    }
     if (ldo == D) ldo = 0;
     if (id_bytes == 4) {
-        if (out_kind == 1) return gather_bf16_impl<int32_t, bf16o_t>(table, V, ld, D, (const int32_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw);
-        return gather_bf16_impl<int32_t, f16o_t>(table, V, ld, D, (const int32_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw);
+        if (out_kind == 1) return gather_bf16_impl<int32_t, bf16o_t>(table, V, ld, D, (const int32_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw, gd);
+        return gather_bf16_impl<int32_t, f16o_t>(table, V, ld, D, (const int32_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw, gd);
     }
-    if (out_kind == 1) return gather_bf16_impl<int64_t, bf16o_t>(table, V, ld, D, (const int64_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw);
-    return gather_bf16_impl<int64_t, f16o_t>(table, V, ld, D, (const int64_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw);
+    if (out_kind == 1) return gather_bf16_impl<int64_t, bf16o_t>(table, V, ld, D, (const int64_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw, gd);
+    return gather_bf16_impl<int64_t, f16o_t>(table, V, ld, D, (const int64_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw, gd);
 }
 
 MREC_API int mrec_wide_sum_f32_i32(const float* w, int64_t V, int64_t ldw, const int32_t* ids, const float* wts,

@@ -185,12 +185,13 @@ def gather_rows(table, ids, row_scale=None, out=None, out_dtype=torch.float32):
     return out.view(tuple(ids.shape) + (D,))
 
 
-def gather_rows_wide(table, ids, row_scale, wide_col, out=None, out_dtype=torch.bfloat16, packed_words=0):
+def gather_rows_wide(table, ids, row_scale, wide_col, out=None, out_dtype=torch.bfloat16, packed_words=0, drop=None):
     """Both lookups of WideDeepModel.construct (wide_and_deep.py:300-302) in one pass over fused rows: returns
     (rows [.., D] in out_dtype, wide_prod [.., 2] with [.., 0] = table_row[wide_col] * row_scale and [.., 1] = 0).  `table` is the [V, D] view of the deep
     columns; wide_col is the column (relative to it, >= D) of the wide weight in the same rows.
     packed_words=W (>= D/2 + 2, multiple of 4): ONE float32 [n, W] result whose row is [D 16-bit values | product, 0 | pad] --
-    a shard's answer message (one collective for both tables)."""
+    a shard's answer message (one collective for both tables).  drop (Dropout; ids [B, F]): the looked-up rows are the
+    [F * D] input of the DenseLayer the descriptor names and leave the kernel dropped out."""
     _need_cuda(table, ids, row_scale, out)
     V, D, ld = _table(table)
     flat = ids.reshape(-1).contiguous()
@@ -208,13 +209,14 @@ def gather_rows_wide(table, ids, row_scale, wide_col, out=None, out_dtype=torch.
             raise ValueError("packed_words must be a multiple of 4 that holds D / 2 + 2 words")
         msg = torch.empty((max(n, 1), W), dtype=torch.float32, device=table.device)[:n]
         _lib.call("mrec_gather_rows_wide", _ptr(table), V, ld, D, _ptr(flat), flat.element_size(), n, _ptr(row_scale), _ptr(msg),
-                  kind, 2 * W, int(wide_col), C.c_void_p(msg.data_ptr() + 2 * D), W, _stream())
+                  kind, 2 * W, int(wide_col), C.c_void_p(msg.data_ptr() + 2 * D), W, None, 0, _stream())
         return msg
     if out is None:
         out = torch.empty((n, D), dtype=out_dtype, device=table.device)
     wprod = torch.empty((max(n, 1), 2), dtype=torch.float32, device=table.device)[:n]      # (product, pad) pairs
     _lib.call("mrec_gather_rows_wide", _ptr(table), V, ld, D, _ptr(flat), flat.element_size(), n, _ptr(row_scale), _ptr(out),
-              1 if out.dtype == torch.bfloat16 else 2, D, int(wide_col), _ptr(wprod), 2, _stream())
+              1 if out.dtype == torch.bfloat16 else 2, D, int(wide_col), _ptr(wprod), 2, _drop_ref(drop),
+              ids.shape[-1] if drop is not None else 0, _stream())
     return out.view(tuple(ids.shape) + (D,)), wprod.view(tuple(ids.shape) + (2,))
 
 

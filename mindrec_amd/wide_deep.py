@@ -321,6 +321,7 @@ class WideDeepEngine(DenseNetMixin):
         self._step_state = None       # ops.StepState (device-side beta powers / step size), created on first use
         self._state_step = -1         # the step count the device-side state stands at
         self._dropout = bool(cfg.dropout_flag and cfg.dropout_keep_prob < 1.0)
+        self._emb_dropped = False     # the lookup has already applied the first layer's Dropout to the rows it handed out
         self._training = False        # inside train_step (`self.training and self.drop_out`, wide_and_deep.py:117)
 
     # ---- helpers -----------------------------------------------------------------------------
@@ -357,7 +358,9 @@ class WideDeepEngine(DenseNetMixin):
             ev = self._tick("gather_deep")
             if self._fold_wide and torch.is_grad_enabled():
                 # both lookups in one pass over the fused rows; the per-sample sum of the wide products is taken by the head
-                emb, wprod = self.k.gather_rows_wide(self.deep, ids, wts, cfg.emb_dim, out=self._emb_out(B * Fd, cfg.emb_dim, self._amp),
+                d0 = self._drop(0, B)                  # Dropout on the first layer's input rides the lookup (train_step only)
+                self._emb_dropped = d0 is not None
+                emb, wprod = self.k.gather_rows_wide(self.deep, ids, wts, cfg.emb_dim, out=self._emb_out(B * Fd, cfg.emb_dim, self._amp), drop=d0,
                                                      out_dtype=self._amp)
                 self._tock(ev)
                 return emb.view(B, Fd * cfg.emb_dim), _WideProd(wprod), None

@@ -103,8 +103,9 @@ class DenseNetMixin:
         hs = [emb if emb.dtype == self._amp else emb.to(self._amp)]
         B = hs[0].shape[0]
         d0 = self._drop(0, B)
-        if d0 is not None:
+        if d0 is not None and not self._emb_dropped:
             self.k.dropout_(hs[0], d0)     # the looked-up rows are consumed by the first layer only: in place
+        self._emb_dropped = False
         for i in range(n - 3 if self._tail_now(B) else n - 1):         # (fused tail: its two layers run in _mlp_head's launch)
             # Dropout on the input of layer i + 1 (:117-118) = on this layer's output, in the GEMM epilogue
             hs.append(self.k.dense_fwd(hs[i], self.dense16[2 * i], self.dense[2 * i + 1].detach(), relu=True, drop_next=self._drop(i + 1, B),

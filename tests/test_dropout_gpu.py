@@ -249,3 +249,23 @@ def test_dropout_graph_replay_equals_eager(dev):
         assert la == lb, (s, la, lb)
     assert a._step_graph is not None and b._step_graph is None
     assert torch.equal(a.deep, b.deep) and torch.equal(a.wide, b.wide) and torch.equal(a.dense_flat, b.dense_flat)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("keep", [0.5, 0.8])
+def test_lookup_with_dropout_equals_lookup_then_dropout(dev, oracle, dt, keep):
+    """mrec_gather_rows_wide(drop=...): the first layer's Dropout applied to the looked-up rows on their way out of the lookup must
+    equal the lookup followed by the Dropout pass (which is checked against the oracle above), wide products untouched."""
+    from mindrec_amd import ops
+    B, F, D, V = 1000, 26, 80, 5000
+    rows = torch.randn(V, 3 * D + 4, device=dev)
+    table = rows[:, :D + 4]                          # fused rows: the wide word right behind the deep columns
+    ids = torch.randint(0, V, (B, F), device=dev, dtype=torch.int32)
+    wts = torch.rand(B, F, device=dev)
+    d = ops.Dropout(keep, 1004, 0, step=6, row0=4096)
+    e0, w0 = ops.gather_rows_wide(table[:, :D], ids, wts, D, out_dtype=T16[dt])
+    e1, w1 = ops.gather_rows_wide(table[:, :D], ids, wts, D, out_dtype=T16[dt], drop=d)
+    ref = ops.dropout_(e0.reshape(B, F * D).clone(), d)
+    assert torch.equal(e1.reshape(B, F * D), ref) and torch.equal(w0, w1)
+    mask = oracle.dropout_mask(B, F * D, 1004, 6, 0, keep, row0=4096)
+    assert np.array_equal(e1.reshape(B, F * D).float().cpu().numpy(), oracle.dropout(e0.reshape(B, F * D).float().cpu().numpy(), mask, dt))
