@@ -547,6 +547,8 @@ int mrec_init_rows_f32(float* table, int64_t ld, int32_t D, const int32_t* rows,
  * of 16 bytes, pointers 16-byte aligned. */
 int mrec_copy3(void* dst0, const void* src0, int64_t bytes0, void* dst1, const void* src1, int64_t bytes1, void* dst2,
                const void* src2, int64_t bytes2, void* stream);
+/* the same for up to 24 tensors */
+int mrec_copy_many(int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, void* stream);
 /* out[i] = table[idx[i]] for int32 arrays (idx[i] < 0 gives -1): rows_of_position = rows_of_unique[inv]. */
 int mrec_compose_i32(const int32_t* table, const int32_t* idx, int64_t n, int32_t* out, void* stream);
 /* int32 -> int64 widening of key arrays (MapParameter key_dtype int32). */

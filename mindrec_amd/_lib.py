@@ -129,6 +129,7 @@ _SIGS = {
     "mrec_map_export": [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_init_rows_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _u64, _f32, _f32, _vp],
     "mrec_copy3": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp],
+    "mrec_copy_many": [_i32, _vp, _vp, _vp, _vp],
     "mrec_compose_i32": [_vp, _vp, _i64, _vp, _vp],
     "mrec_widen_i32_i64": [_vp, _i64, _vp, _vp],
     "mrec_scatter_rows_f32": [_vp, _i64, _i32, _vp, _i64, _vp, _vp],

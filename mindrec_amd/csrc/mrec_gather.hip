@@ -650,6 +650,31 @@ MREC_API int mrec_copy3(void* dst0, const void* src0, int64_t bytes0, void* dst1
     return MREC_OK;
 }
 
+// the same for up to 24 tensors (a sink of steps stages all its inputs with one launch)
+struct CopyMany { uint4* dst[24]; const uint4* src[24]; int64_t n16[24]; int n; };
+__global__ __launch_bounds__(256) void k_copy_many(CopyMany c) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int k = 0; k < c.n; ++k)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < c.n16[k]; i += stride) c.dst[k][i] = c.src[k][i];
+}
+MREC_API int mrec_copy_many(int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, void* stream) {
+    if (n < 0 || n > 24 || (n && (!dst || !src || !bytes))) return MREC_EINVAL;
+    CopyMany c{};
+    int64_t most = 0;
+    for (int k = 0; k < n; ++k) {
+        if (bytes[k] < 0 || (bytes[k] > 0 && (!dst[k] || !src[k]))) return MREC_EINVAL;
+        if (bytes[k] % 16 || (((uintptr_t)dst[k] | (uintptr_t)src[k]) & 15)) return MREC_EUNSUPPORTED;
+        c.dst[k] = (uint4*)dst[k]; c.src[k] = (const uint4*)src[k]; c.n16[k] = bytes[k] / 16;
+        if (c.n16[k] > most) most = c.n16[k];
+    }
+    c.n = n;
+    if (most == 0) return MREC_OK;
+    const unsigned g = (unsigned)(mrec_cdiv(most, 256) < 1024 ? mrec_cdiv(most, 256) : 1024);
+    k_copy_many<<<g, 256, 0, (hipStream_t)stream>>>(c);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
 MREC_API int mrec_compose_i32(const int32_t* table, const int32_t* idx, int64_t n, int32_t* out, void* stream) {
     if (n < 0) return MREC_EINVAL;
     if (n == 0) return MREC_OK;

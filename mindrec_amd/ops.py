@@ -583,6 +583,24 @@ def copy3_(dsts, srcs):
               nb[2], _stream())
 
 
+def copy_many_(dsts, srcs):
+    """Up to 24 contiguous device tensors copied in one launch (all the inputs of a sink of steps into its graph's static
+    buffers); falls back to copy3_ / tensor.copy_ otherwise."""
+    _need_cuda(*dsts, *srcs)
+    n = len(dsts)
+    nb = [d.numel() * d.element_size() for d in dsts]
+    ok = n <= 24 and all(d.is_contiguous() and s_.is_contiguous() and d.dtype == s_.dtype and d.numel() == s_.numel() and b % 16 == 0
+                         and d.data_ptr() % 16 == 0 and s_.data_ptr() % 16 == 0 for d, s_, b in zip(dsts, srcs, nb))
+    if not ok:
+        for d, s_ in zip(dsts, srcs):
+            d.copy_(s_)
+        return
+    da = (C.c_void_p * n)(*[d.data_ptr() for d in dsts])
+    sa = (C.c_void_p * n)(*[s_.data_ptr() for s_ in srcs])
+    ba = (C.c_int64 * n)(*nb)
+    _lib.call("mrec_copy_many", n, C.cast(da, C.c_void_p), C.cast(sa, C.c_void_p), C.cast(ba, C.c_void_p), _stream())
+
+
 def put_rows_last_(table, rows, vals, winner):
     """table[rows[i]] = vals[i] for the LAST position of every row (duplicates: a sequential upsert); winner: int32 [rows of
     table] scratch, all -1 before and after."""

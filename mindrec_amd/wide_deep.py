@@ -802,8 +802,7 @@ class WideDeepEngine(DenseNetMixin):
             if sg is None and key not in self._sink_graphs:
                 sg = self._capture_sink(key, [tuple(t.clone() for t in b) for b in batches])
             if sg is not None:
-                for dst, src in zip(sg["inputs"], batches):
-                    self.k.copy3_(dst, tuple(src))
+                self.k.copy_many_([t for b in sg["inputs"] for t in b], [t for b in batches for t in b])       # one launch
                 for _ in range(S):
                     self.step_count += 1
                     self.beta1_power = np.float32(self.beta1_power * self.beta1)
