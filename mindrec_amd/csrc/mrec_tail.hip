@@ -285,9 +285,13 @@ __global__ __launch_bounds__(TT, 2) void k_tail(const TailArgs a) {
 #pragma unroll
                 for (int q = 0; q < WR; ++q) {
                     const int f0 = q * CG;
-                    if (f0 < a.F) {
-                        const int nf = (a.F - f0 < CG) ? a.F - f0 : CG;
-                        for (int c = 0; c < nf; ++c) acc_w = acc_w + __shfl(hw[pass][q], lane_row0 + c, 64);
+                    if (f0 < a.F) {            // (uniform) all 16 lane reads issued together, then the adds in field order
+                        float pv[CG];
+#pragma unroll
+                        for (int c = 0; c < CG; ++c) pv[c] = __shfl(hw[pass][q], lane_row0 + c, 64);
+#pragma unroll
+                        for (int c = 0; c < CG; ++c)
+                            if (f0 + c < a.F) acc_w = acc_w + pv[c];
                     }
                 }
                 wv = acc_w + wbias;
