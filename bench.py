@@ -253,7 +253,7 @@ def main():
         """n training steps over the resident batches, S per host call where S > 1 (a remainder step by step)."""
         i = 0
         while i < n:
-            if S > 1 and n - i >= S:
+            if S > 1 and n - i >= S and eng._step_graph is not None:       # (a sink is a graph of whole steps: where the step has one)
                 eng.train_steps([batches[(i + j) % len(batches)] for j in range(S)])
                 i += S
             else:
