@@ -126,3 +126,18 @@ def test_checkpoint_roundtrip_and_shard_merge(tmp_path):
     assert torch.equal(full["deep"], fresh.deep) and torch.equal(full["wide"], fresh.wide)
     with pytest.raises(ValueError):
         load_checkpoint(WideDeepEngine(cfg, "cpu", rank=1, world=2, kernels=_oracle_ops), tmp_path / "a.pt")
+
+
+def test_train_steps_without_graphs_is_step_by_step():
+    """train_steps (sink_size steps per host call) on an engine that has no whole-step graph -- here the CPU stand-in -- is the
+    same as that many train_step calls, and hands out losses that later steps do not overwrite."""
+    import _oracle_ops
+    from mindrec_amd.wide_deep import WideDeepEngine
+    cfg = _cfg(24)
+    a = WideDeepEngine(cfg, "cpu", kernels=_oracle_ops)
+    b = WideDeepEngine(cfg, "cpu", kernels=_oracle_ops)
+    bs = [_batch(cfg, seed=40 + s) for s in range(4)]
+    la = [float(x) for x in a.train_steps(bs)]
+    lb = [float(b.train_step(*x)) for x in bs]
+    assert la == lb and len(set(la)) == 4
+    assert torch.equal(a.deep, b.deep) and torch.equal(a.dense_flat, b.dense_flat) and a.step_count == b.step_count == 4
