@@ -141,13 +141,16 @@ def write_records(directory, prefix, ids, wts, label, records_per_file=64, line_
 
 
 class RecordDataset:
-    """The reading side: records of 1000 samples from `directory/{train,test}_*.npz`, record r goes to rank r mod rank_size,
-    `batch_size / line_per_sample` records per batch, the remainder dropped, shuffled per epoch in train mode (seeded).
-    Yields (ids [B, 39] int32, wts [B, 39] float32, label [B, 1] float32) like the reference's padding function
-    (datasets.py:210-217); `to_device` as in CriteoDataset."""
+    """The reading side: records of 1000 samples from `directory/{train,test}_*.npz`, sharded over the ranks the way
+    MindDataset(num_shards, shard_id) shards a MindRecord file [EXT]: every rank gets the SAME number of records,
+    ceil(R / rank_size) -- rank k reads records k, k + rank_size, ... and, where R is not a multiple of rank_size, wraps around to
+    the first records -- so that all ranks run the same number of steps per epoch (a row-sharded job meets in an all-to-all and
+    an all-reduce every step: a rank with one batch more would wait forever).  `batch_size / line_per_sample` records per
+    batch, the remainder dropped, shuffled per epoch in train mode (seeded).  Yields (ids [B, 39] int32, wts [B, 39] float32,
+    label [B, 1] float32) like the reference's padding function (datasets.py:210-217); `to_device` as in CriteoDataset."""
 
     def __init__(self, directory, train_mode=True, batch_size=1000, line_per_sample=LINE_PER_SAMPLE, rank_size=None, rank_id=None,
-                 field_size=FIELD_SIZE, seed=0, to_device=None):
+                 field_size=FIELD_SIZE, seed=0, to_device=None, cached_files=4):
         import glob
         import os
         if batch_size % line_per_sample:
@@ -158,16 +161,36 @@ class RecordDataset:
         self.shuffle, self.seed, self.epoch = bool(train_mode), int(seed), 0
         self.B, self.lps, self.F = int(batch_size), int(line_per_sample), int(field_size)
         self.rank_size, self.rank_id = (int(rank_size), int(rank_id)) if rank_size is not None and rank_id is not None else (1, 0)
+        if not 0 <= self.rank_id < self.rank_size:
+            raise ValueError("rank_id must be in [0, rank_size)")
         self.to_device = to_device
-        counts = [np.load(f)["label"].shape[0] for f in self.files]
+        self._cached_files = max(1, int(cached_files))
+        counts = []
+        for f in self.files:
+            with np.load(f) as z:
+                counts.append(z["label"].shape[0])
         self._index = [(fi, r) for fi, c in enumerate(counts) for r in range(c)]            # global record order
-        self._mine = [k for k in range(len(self._index)) if k % self.rank_size == self.rank_id]
+        R = len(self._index)
+        per_rank = -(-R // self.rank_size)                                                  # the same on every rank
+        self._mine = [(self.rank_id + j * self.rank_size) % R for j in range(per_rank)]
 
     def get_dataset_size(self):
         return len(self._mine) // (self.B // self.lps)
 
     def reset(self):
         self.epoch += 1
+
+    def _file(self, cache, fi):
+        """File fi as {name: ndarray}, read ONCE (np.load's NpzFile re-reads and decompresses a member on every access); a small
+        LRU, because a shuffled epoch jumps between files."""
+        z = cache.pop(fi, None)
+        if z is None:
+            with np.load(self.files[fi]) as f:
+                z = {k: f[k] for k in ("feat_ids", "feat_vals", "label")}
+            while len(cache) >= self._cached_files:
+                cache.pop(next(iter(cache)))
+        cache[fi] = z                    # most recently used last
+        return z
 
     def __iter__(self):
         order = list(self._mine)
@@ -180,9 +203,7 @@ class RecordDataset:
             label = np.empty((self.B, 1), np.float32)
             for j, k in enumerate(order[b * rpb:(b + 1) * rpb]):
                 fi, r = self._index[k]
-                if fi not in cache:
-                    cache = {fi: np.load(self.files[fi])}
-                z = cache[fi]
+                z = self._file(cache, fi)
                 sl = slice(j * self.lps, (j + 1) * self.lps)
                 ids[sl] = z["feat_ids"][r].reshape(self.lps, self.F)
                 wts[sl] = z["feat_vals"][r].reshape(self.lps, self.F)

@@ -75,6 +75,15 @@ class HostBackedTable:
         self.slots = [self.cols[n] for n, _, _ in self.columns[1:]]
 
     @property
+    def col_ranges(self):
+        """{column group: (first column, one past the last)} of a row."""
+        out, off = {}, 0
+        for name, w, _ in self.columns:
+            out[name] = (off, off + w)
+            off += w
+        return out
+
+    @property
     def stats(self):
         return {"hits": self._hits, "misses": self._misses, "evictions": self._evictions,
                 "first_touch": int(self._first_touch.item())}

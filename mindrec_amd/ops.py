@@ -158,7 +158,10 @@ def sparse_plan(ids):
     primed = _PLAN_PRIMED.pop(key, False)          # (dropped while the call is in flight: an exception leaves it unprimed)
     _lib.call(f"mrec_sparse_plan_ex_{sfx}", _ptr(flat), n, _ptr(uniq), _ptr(inv), _ptr(n_uniq), _ptr(sorted_pos),
               _ptr(sorted_seg), _ptr(seg_offsets), _ptr(ws), ws.numel(), 1 if primed else 0, _stream())
-    _PLAN_PRIMED[key] = True
+    # a call issued under HIP-graph capture has not RUN: it primes nothing (it leaves a primed workspace primed -- every
+    # replay of the captured chain hands the workspace back clean, as an eager call does)
+    if primed or not torch.cuda.is_current_stream_capturing():
+        _PLAN_PRIMED[key] = True
     return SparsePlan(Dedup(flat, uniq, inv, n_uniq), sorted_pos, sorted_seg, seg_offsets)
 
 
@@ -507,10 +510,8 @@ class KeyIndex:
         tabs = self._tables(tables)
         _lib.call("mrec_map_lookup", self._h, _ptr(flat), flat.element_size(), n, _ptr(n_dev), flags, int(step), int(permit),
                   C.cast(tabs, C.c_void_p), len(tables), _ptr(rows), _ptr(adm), _ptr(ws), ws.numel(), _stream())
-        if insert:
-            _MAP_PRIMED[key] = True
-        elif primed:
-            _MAP_PRIMED[key] = True        # a probe-only call leaves the workspace untouched
+        if primed or (insert and not torch.cuda.is_current_stream_capturing()):
+            _MAP_PRIMED[key] = True        # (a probe-only call leaves the workspace untouched; a captured call has not run)
         return (rows, adm) if want_admitted else rows
 
     def fill_missing(self, keys, rows, out, sigma, fill, seed):

@@ -792,7 +792,8 @@ class WideDeepEngine(DenseNetMixin):
         of a sink run on the device without returning to the host; RecModel.online_train restricts it to 1, rec_model.py:268-271).  Where the whole
         step replays as one HIP graph, a sink of S steps replays as ONE graph of S steps: between two graph launches the GPU idles
         for ~14 us (launch latency, with or without the staging copy in between), which a sink pays once per S steps.  Same
-        kernels on the same data in the same order as S train_step calls: identical results.  Returns the S losses."""
+        kernels on the same data in the same order as S train_step calls: identical results.  Returns the S losses (copies the
+        caller may keep)."""
         S = len(batches)
         g = self._step_graph
         if (S > 1 and g is not None and self.cfg.graph_step and self._front_graph_ok() and self._dyn and self._state_step == self.step_count
@@ -811,7 +812,7 @@ class WideDeepEngine(DenseNetMixin):
                 self.deep_apply_timer = None
                 sg["graph"].replay()
                 self.last_plan = sg["plan"]
-                return sg["losses"]
+                return torch.stack(sg["losses"])       # a copy: the graph's own loss buffers are overwritten by the next sink
         return [self.train_step(*b).clone() for b in batches]       # (train_step hands out a static buffer once graphs replay)
 
     def _capture_sink(self, key, inputs):

@@ -21,10 +21,23 @@ def _engine_state(eng):
 
 def save_checkpoint(eng, path):
     """Writes this rank's shard (tables + optimizer state + dense parameters) to `path` (torch.save)."""
-    if eng.hb is not None:
-        raise NotImplementedError("host-cached tables: flush the cache (eng.hb.flush()) and save eng.hb.host; not wired "
-                                  "into save_checkpoint")
     st = _engine_state(eng)
+    if eng.hb is not None:
+        # host-backed tables: write the device cache back, then save the pinned host store itself (every row of the shard;
+        # hash tables: the rows of the live keys, in key-export order, like the resident hash tables below)
+        eng.hb.flush()
+        torch.cuda.synchronize(eng.device)
+        dense = {k: v.detach().cpu().contiguous() for k, v in st["dense"].items()}
+        names = ("deep", "deep_m", "deep_v", "wide", "wide_accum", "wide_linear")
+        if eng.hb.hashed:
+            keys, rows = eng.hb.export_hashed()
+            tables = {k: rows[:, a:b].contiguous() for k, (a, b) in eng.hb.col_ranges.items() if k in names}
+            torch.save({"meta": dict(st["meta"], dynamic_embedding=True, host_cache=True), "keys": keys, "tables": tables, "dense": dense}, path)
+        else:
+            full = eng.hb.full_table()          # never-touched rows are generated on demand (their default values)
+            tables = {k: full[:, a:b].contiguous() for k, (a, b) in eng.hb.col_ranges.items() if k in names}
+            torch.save({"meta": dict(st["meta"], host_cache=True), "tables": tables, "dense": dense}, path)
+        return
     if eng.index is not None:
         # hash tables: the live keys and, per table, the rows of those keys in key-export order (the analogue of
         # MapParameter.export_data: keys + values; row numbers are not part of the state)
@@ -49,6 +62,9 @@ def load_checkpoint(eng, path):
         if m[k] != have:
             raise ValueError(f"checkpoint {path}: {k} = {m[k]} but the engine has {have}")
     st = _engine_state(eng)
+    if eng.hb is not None:
+        raise NotImplementedError("load_checkpoint restores into resident tables; a checkpoint written by a host-cached engine loads "
+                                  "into a resident engine of the same geometry")
     if bool(m.get("dynamic_embedding", False)) != (eng.index is not None):
         raise ValueError(f"checkpoint {path}: dynamic_embedding does not match the engine")
     with torch.no_grad():
@@ -83,6 +99,18 @@ def merge_shards(paths):
         raise ValueError("merge_shards needs exactly one checkpoint per rank")
     V = cks[0]["meta"]["vocab_size"]
     out = {}
+    if any(c["meta"].get("dynamic_embedding") for c in cks):
+        # hash tables: owner = hash(key) mod world and every rank exports its own keys with their rows, in its own order and
+        # number -- the whole table is the concatenation of the ranks' (keys, rows) pairs (MapParameter.export_data's form)
+        if not all(c["meta"].get("dynamic_embedding") for c in cks):
+            raise ValueError("merge_shards: hash-table and dense-table checkpoints cannot be mixed")
+        out["keys"] = torch.cat([c["keys"] for c in cks])
+        if out["keys"].unique().numel() != out["keys"].numel():
+            raise ValueError("merge_shards: a key lives on more than one rank")
+        for name in cks[0]["tables"]:
+            out[name] = torch.cat([c["tables"][name] for c in cks])
+        out.update(cks[0]["dense"])
+        return out
     for name, t0 in cks[0]["tables"].items():
         full = torch.empty((V, t0.shape[1]), dtype=t0.dtype)
         for c in cks:
