@@ -37,32 +37,27 @@ def parse():
     ap.add_argument("--batch", type=int, default=16384, help="per-GPU batch (reference passes batch_size per worker)")
     ap.add_argument("--fields", type=int, default=26, help="26 = north-star categorical slots; 39 = reference field_size")
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
-    ap.add_argument("--mlp-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--mlp-dtype", default="fp16", choices=["fp16", "bf16", "fp32"],
+                    help="fp16 = the reference's own mixed precision (use_mixed_precision, wide_and_deep.py:119-128); bf16 runs the same kernels")
     ap.add_argument("--dropout", action="store_true", help="dropout_flag: True as in benchmarks/wide_deep/default_config.yaml:15 (Dropout(0.5) on every "
                     "DenseLayer input; models/wide_deep/default_config.yaml:27, the configuration of configs[1], has it off)")
     ap.add_argument("--sink-size", type=int, default=5, help="training steps per host call (the reference's dataset_sink_mode / sink_size: "
                     "train_and_eval.py:98-101, train_and_eval_distribute.py:115-116); with the whole-step graph a sink is ONE graph launch")
-    ap.add_argument("--dw-slabs", default="", help="layer:S,... weight-gradient slab counts instead of the library's proposal (sweeps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of each cpu_baseline leg")
     ap.add_argument("--n-batches", type=int, default=4, help="distinct resident batches cycled through")
     ap.add_argument("--split-state", action="store_true", help="p, m, v as three separate arrays (default: fused rows)")
-    ap.add_argument("--no-overlap-plan", action="store_true", help="run dedup + inverted index on the main stream")
-    ap.add_argument("--no-overlap-wide-apply", action="store_true", help="wide FTRL after the deep apply on the main stream")
-    ap.add_argument("--late-wide", choices=["auto", "on", "off"], default="auto",
-                    help="wide branch on the side stream under the hidden-layer GEMMs (auto: when sharded / in the front graph)")
-    ap.add_argument("--no-early-route", action="store_true", help="shards: request exchange on the main stream (waits for the previous step)")
     ap.add_argument("--dynamic-embedding", action="store_true", help="hash tables keyed by the raw ids (reference --dynamic_embedding=True); "
                     "use a --vocab small enough for --hash-capacity, e.g. --vocab 3000000")
     ap.add_argument("--hash-capacity", type=int, default=1 << 22)
     ap.add_argument("--host-cache-rows", type=int, default=0, help="tables in pinned host DRAM behind a device cache of this many rows "
                     "(the reference's vocab_cache_size); keep --vocab x 976 B within the host's RAM")
-    ap.add_argument("--no-graph-front", action="store_true", help="one GPU: only the MLP as HIP graphs, lookups / plan issued kernel by kernel")
-    ap.add_argument("--no-graph-step", action="store_true", help="one GPU: the front of the step as one HIP graph, the sparse apply and the dense "
-                    "optimizers issued kernel by kernel behind it (instead of the whole step as one graph)")
+    ap.add_argument("--graphs", default="step", choices=["step", "front", "mlp", "none"],
+                    help="what replays as HIP graphs: the whole step (default; sinks of --sink-size steps as one graph), everything in front "
+                    "of the optimizers, the dense net only, or nothing (kernel by kernel)")
     ap.add_argument("--shard-protocol", action="store_true", help="one GPU: run the row-shard protocol (routing kernels + RCCL collectives "
                     "that talk to themselves) -- what a rank of an N-GPU job does besides moving bytes over xGMI")
-    ap.add_argument("--no-graph-mlp", action="store_true", help="issue the MLP step kernel by kernel instead of replaying its HIP graph")
+    ap.add_argument("--capacity-factor", type=float, default=1.25, help="row shards: request slots per owner = ceil(factor * ids / ranks)")
     return ap.parse_args()
 
 
@@ -230,14 +225,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)          # "nccl" IS RCCL on ROCm
 
     cfg = WideDeepConfig(vocab_size=args.vocab, emb_dim=args.emb_dim, field_size=args.fields, batch_size=args.batch,
-                         mlp_dtype=args.mlp_dtype, fused_state=not args.split_state,
-                         overlap_plan=not args.no_overlap_plan, graph_mlp=not args.no_graph_mlp, graph_front=not args.no_graph_front, graph_step=not args.no_graph_step,
+                         mlp_dtype=args.mlp_dtype, fused_state=not args.split_state, graphs=args.graphs,
                          dynamic_embedding=args.dynamic_embedding, hash_capacity=args.hash_capacity,
-                         host_cache_rows=args.host_cache_rows, early_route=not args.no_early_route,
-                         late_wide={'auto': None, 'on': True, 'off': False}[args.late_wide],
-                         overlap_wide_apply=not args.no_overlap_wide_apply, dropout_flag=args.dropout)
-    if args.dw_slabs:
-        cfg.dw_slabs = {int(k): int(v) for k, v in (kv.split(":") for kv in args.dw_slabs.split(","))}
+                         host_cache_rows=args.host_cache_rows, shard_capacity_factor=args.capacity_factor, dropout_flag=args.dropout)
     eng = WideDeepEngine(cfg, dev, rank=rank, world=world, shard_protocol=args.shard_protocol)
     batches = [synthetic_batch(cfg, dev, args.dist, seed=1000 + i, rank=rank) for i in range(args.n_batches)]
     torch.cuda.synchronize()
@@ -247,7 +237,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    S = max(1, args.sink_size) if (world == 1 and not args.shard_protocol) else 1       # (a sink is a graph of whole steps: one GPU)
+    S = max(1, args.sink_size)            # (a sink is ONE graph of whole steps wherever the step has a graph: one GPU, or a shard over RCCL)
 
     def run_steps(n, timers=None):
         """n training steps over the resident batches, S per host call where S > 1 (a remainder step by step)."""
@@ -344,7 +334,7 @@ def main():
     # quoted only when this run is the workload that was profiled, and labelled with their source.
     traffic, traffic_source = None, None
     default_cfg = (args.vocab == 200_000_000 and args.emb_dim == 80 and args.batch == 16384 and args.fields == 26
-                   and args.dist == "uniform" and not args.split_state and world == 1 and args.mlp_dtype == "bf16"
+                   and args.dist == "uniform" and not args.split_state and world == 1 and args.mlp_dtype in ("bf16", "fp16")
                    and not args.shard_protocol)
     for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
@@ -407,7 +397,9 @@ def main():
                      "avg_ms_hip_events_eager": round(sum(ev_ms) / len(ev_ms), 5) if ev_ms else None,
                      "measured_copy_gbps": copy_gbps,
                      "timing": apply_timing.format(n=len(kmain))},
-        "kernels_ms": {k: round(sum(v) / len(v), 5) for k, v in sorted(kern_ms.items()) if v},
+        # medians over n eager extra steps behind the timed region (HIP events around each phase on the main stream: a phase that only
+        # ENQUEUES work on the side stream -- the plan -- is not listed; one cold outlier does not move a median)
+        "kernels_ms": {k: {"median": round(median(v), 5), "n": len(v)} for k, v in sorted(kern_ms.items()) if v and k != "plan"},
     }
     if world == 1 and lookup_ms:
         out["roofline_lookup"] = {"bound": "hbm", "kernel": "k_gather_rows (EmbeddingLookup, mask fused%s)" % (" + the row's wide word" if fold else ""),
@@ -433,6 +425,12 @@ def main():
         slab_el = sum(t.numel() for t in list(eng._dw.values()) + list(eng._db.values()))
         covered = sum(t[0].numel() for t in list(eng._dw.values()) + list(eng._db.values()))
         out["dense_adam_bytes"] = {"read": 4 * (3 * n_el + slab_el + (n_el - covered)), "write": 4 * 3 * n_el + 2 * n_el}
+    if world > 1 or args.shard_protocol:
+        dropped = eng.shard_overflow()
+        out["config"]["shard_capacity"] = {"factor": args.capacity_factor, "dropped_positions": dropped}
+        if dropped:
+            raise SystemExit(f"{dropped} id positions did not fit the fixed-capacity request message: not a valid run "
+                             f"(raise --capacity-factor)")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

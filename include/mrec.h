@@ -83,6 +83,12 @@ int mrec_sparse_plan_i64(const int64_t* ids, int64_t n, int64_t* uniq, int32_t* 
  * look-back words are then already clean -- every call hands them back clean (the table by a memset BEHIND its last kernel) --
  * and the two memsets at the head of the chain are skipped: the first kernel starts 10 us earlier.  (A training step replays the same plan on the same workspace every step.) */
 #define MREC_PLAN_WS_PRIMED 1u
+/* MREC_PLAN_SKIP_NEGATIVE: negative ids are padding, not keys (the unused slots of a shard's fixed-capacity request
+ * message, mrec_shard_route_slots_*): they get no group (inv = -1) and no entry of the index proper, which is then the first
+ * n_valid = (number of non-negative ids) entries of sorted_pos / sorted_seg, seg_offsets[U] = n_valid; the padding positions
+ * follow as a pseudo-group U whose row uniq[U] is -1.  n_uniq_dev must then point at TWO words: [0] = U, [1] = n_valid --
+ * the count the apply kernels clamp their n to (n_valid_dev of mrec_sparse_lazy_adam_wide). */
+#define MREC_PLAN_SKIP_NEGATIVE 2u
 int mrec_sparse_plan_ex_i32(const int32_t* ids, int64_t n, int32_t* uniq, int32_t* inv, int64_t* n_uniq_dev,
                             int32_t* sorted_pos, int32_t* sorted_seg, int32_t* seg_offsets, void* ws, size_t ws_bytes,
                             uint32_t flags, void* stream);
@@ -130,6 +136,16 @@ struct mrec_dropout;
 int mrec_gather_rows_wide(const float* table, int64_t V, int64_t ld, int32_t D, const void* ids, int32_t id_bytes, int64_t n,
                           const float* row_scale, void* out, int32_t out_kind, int64_t ldo, int32_t wide_col, float* wide_prod,
                           int64_t ldw, const struct mrec_dropout* drop, int32_t fields, void* stream);
+/* The same pass serving a shard's request message in place (the owner's side of nn.EmbeddingLookup(..., slice_mode=
+ * TABLE_ROW_SLICE), wide_and_deep.py:232-249): ids[i * id_stride] and row_scale[i * scale_stride] let ids and weights be read
+ * straight out of the received {id, weight} entries; out_kind 0 adds fp32 rows (ldo then in floats; the fp32 wire format of
+ * an fp32 net); MREC_GATHER_SKIP_INVALID leaves the rows of ids outside [0, V) alone instead of writing zeros (the padding
+ * slots of a fixed-capacity message: nobody reads their answers). */
+#define MREC_GATHER_SKIP_INVALID 1u
+int mrec_gather_rows_wide_ex(const float* table, int64_t V, int64_t ld, int32_t D, const void* ids, int32_t id_bytes,
+                             int64_t id_stride, int64_t n, const float* row_scale, int64_t scale_stride, void* out, int32_t out_kind,
+                             int64_t ldo, int32_t wide_col, float* wide_prod, int64_t ldw, const struct mrec_dropout* drop,
+                             int32_t fields, uint32_t flags, void* stream);
 
 /* Wide branch of WideDeepModel.construct (wide_and_deep.py:300,303-306) in one pass:
  * out[b] = sum_f w[ids[b,f] * ldw] * wts[b,f] + *bias_dev   (w is the [V,1] wide table, row
@@ -214,13 +230,16 @@ int mrec_sparse_lazy_adam_f16g_i64(float* p, float* m, float* v, int64_t V, int6
  * shard's owner: the received positions are not grouped by sample, and the gradient is a column of the gradient message).
  * ws: mrec_sparse_apply_workspace_bytes(n, D + 4).
  * step_state (nullable): an mrec_step_state_t in device memory; when given, the Adam step size comes from it instead of
- * b1_pow / b2_pow, and the main kernel leaves its begin / end wall clock stamps there. */
+ * b1_pow / b2_pow, and the main kernel leaves its begin / end wall clock stamps there.
+ * n_valid_dev (nullable): a device word holding the number of entries of the index proper (MREC_PLAN_SKIP_NEGATIVE); the
+ * kernels walk min(n, *n_valid_dev) entries -- the size of a shard's received batch is known on the device only. */
 int mrec_sparse_lazy_adam_wide(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D, const void* uniq,
                                int32_t uniq_bytes, const int32_t* sorted_pos, const int32_t* sorted_seg,
                                const int32_t* seg_offsets, int64_t n, const void* g, int32_t g_kind, int64_t ldg,
                                const float* row_scale, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
                                float grad_scale, int nesterov, const float* gw, int64_t gw_stride, int32_t F, int32_t wide_col, float ftrl_lr,
-                               float l1, float l2, float lr_power, void* ws, size_t ws_bytes, void* step_state, void* stream);
+                               float l1, float l2, float lr_power, void* ws, size_t ws_bytes, void* step_state,
+                               const int64_t* n_valid_dev, void* stream);
 
 /* ---- step scalars in device memory ------------------------------------------------------------------------------
  * nn.Adam / nn.LazyAdam keep beta1_power and beta2_power as Parameters that the optimizer's own graph multiplies by
@@ -513,6 +532,8 @@ typedef struct mrec_map_table {
 #define MREC_MAP_UNIQUE 2u
 #define MREC_MAP_TRAIN 4u
 #define MREC_MAP_WS_PRIMED 8u
+#define MREC_MAP_SKIP_PAD 16u      /* key -1 (reserved by the reference: "any integers except -1, -2", embedding.py:53) is a padding slot
+                                    * of a shard's request message: rows_out = -1, never inserted */
 int mrec_map_lookup_workspace_bytes(int64_t n, size_t* out);
 int mrec_map_lookup(mrec_map_t* h, const void* keys, int32_t key_bytes, int64_t n, const int64_t* n_dev, uint32_t flags,
                     int64_t step, int32_t permit, const mrec_map_table_t* tables, int32_t n_tables, int32_t* rows_out,
@@ -617,6 +638,37 @@ int mrec_shard_route_rows_ld_f32(const float* g, int64_t ldg, const int32_t* sen
 int mrec_shard_pack_iw_i32(const int32_t* send_local, const float* wts, const int32_t* send_perm, int64_t n, int32_t* out_pairs,
                            void* stream);
 int mrec_shard_unpack_iw_i32(const int32_t* pairs, int64_t n, int32_t* ids_out, float* wts_out, void* stream);
+
+/* ---- fixed-capacity routing: a sharded step whose every message has a static shape ------------------------------------
+ * (hybrid parallel, README.md:140-144; models/wide_deep/train_and_eval_distribute.py:135-138; the reference's own mechanism,
+ * replicated ids + masked local Gather + AllReduce of [N, D] partials, wide_and_deep.py:232-249, has static shapes too.)
+ * Every rank hands every owner exactly `cap` request slots, so the three all-to-alls of a step (requests, answers, row
+ * gradients) have equal, host-known splits: no bucket sizes cross the host, and the step can be captured as one HIP graph.
+ *   mrec_shard_route_slots_*: position i (owner o = id mod n_shards, or (mix64(key) >> 33) mod n_shards when `hashed`) takes
+ *     slot o * cap + j, j = its rank among the positions of owner o in ascending position order (stable: the owner's
+ *     summation order is a function of the batch alone).  req[slot] = {id' , wts[i]} with id' = id div n_shards (dense
+ *     tables) or the raw key (hashed); entries are 8 bytes {int32, float} for int32 ids, 16 bytes {int64, float, 0} for int64.
+ *     Unused slots carry id' = -1, weight 0.  slot_of_pos[i] = the slot (or -1: the bucket was full), pos_of_slot[slot] = i
+ *     (or -1).  *overflow_dev += the number of positions that found their bucket full (sticky; the caller checks it once per
+ *     sink and raises: the step that dropped positions is not a valid step).  wts nullable (all 1).
+ *   mrec_shard_unpack_req: the received entries as two plain arrays (the plan and the apply's row_scale want them so).
+ *   mrec_shard_unroute_slots: back at the requester, position i reads row slot_of_pos[i] of the returned message
+ *     ([Dw words of the looked-up row | wide product, 0 | pad], W words per row) and writes emb_out[i, 0:Dw] and
+ *     wprod_out[2 i] = (product, 0): what mrec_gather_rows_wide hands out on one GPU.  Dw = D / 2 (16-bit rows) or D (fp32).
+ *   mrec_shard_route_grads: the gradient message, msg[slot] = [Dw words of g[pos_of_slot[slot]] | dlogit[pos / F] | pad];
+ *     padding slots are left alone. */
+int mrec_shard_route_slots_workspace_bytes(int64_t n, int32_t n_shards, size_t* out);
+int mrec_shard_route_slots_i32(const int32_t* ids, const float* wts, int64_t n, int32_t n_shards, int64_t cap, int hashed, void* req,
+                               int32_t* slot_of_pos, int32_t* pos_of_slot, int64_t* overflow_dev, void* ws, size_t ws_bytes,
+                               void* stream);
+int mrec_shard_route_slots_i64(const int64_t* ids, const float* wts, int64_t n, int32_t n_shards, int64_t cap, int hashed, void* req,
+                               int32_t* slot_of_pos, int32_t* pos_of_slot, int64_t* overflow_dev, void* ws, size_t ws_bytes,
+                               void* stream);
+int mrec_shard_unpack_req(const void* req, int32_t id_bytes, int64_t n_slots, void* ids_out, float* wts_out, void* stream);
+int mrec_shard_unroute_slots(const float* back, int64_t W, const int32_t* slot_of_pos, int64_t n, int32_t Dw, float* emb_out,
+                             float* wprod_out, void* stream);
+int mrec_shard_route_grads(const float* g, int64_t ldg, const float* dlogit, int32_t F, const int32_t* pos_of_slot, int64_t n_slots,
+                           int32_t Dw, float* msg, int64_t W, void* stream);
 
 /* ---- measurement hooks (used by bench.py; no effect on results) --------------------------
  * HIP events owned by the library, and a one-shot hook: the NEXT sparse-apply call (segment_sum /

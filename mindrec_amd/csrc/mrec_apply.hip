@@ -412,8 +412,9 @@ __global__ __launch_bounds__(256, WIDE ? 5 : 1) void k_apply_main(Upd upd, int64
                                                     const float* __restrict__ rscale, float gscale, ApplyGeom gm,
                                                     float* __restrict__ carry_head, float* __restrict__ carry_tail,
                                                     int* __restrict__ owners, const int* __restrict__ seg_offsets,
-                                                    WideArgs wa, StepState* ss) {
+                                                    WideArgs wa, StepState* ss, const int64_t* __restrict__ nv = nullptr) {
     resolve_step(upd, ss);
+    if (nv) { const int64_t x = *nv; if (x < n) n = x < 0 ? 0 : (int)x; }      // entries of the index proper: known on the device only
     // Stamps: workgroup 0 (dispatched first) stores the begin; the last wave of every workgroup raises the end -- ONE global
     // atomic per workgroup (an atomic per wave on the one address serialised at ~6 ns each and made the kernel 140 us longer).
     __shared__ int waves_done;
@@ -446,10 +447,14 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
                                                     const float* __restrict__ carry_head,
                                                     const float* __restrict__ carry_tail,
                                                     const int* __restrict__ owners, int nsw, WideArgs wa,
-                                                    const StepState* ss) {
+                                                    const StepState* ss, const int64_t* __restrict__ nv = nullptr) {
     resolve_step(upd, ss);
     // the partials of a run are consecutive carry rows: stream them 16 deep per lane-group
     constexpr int AW = ACfg<VEC>::AW, AB = 16;
+    if (nv) {
+        const int64_t x = *nv;
+        if (x < n) { n = x < 0 ? 0 : (int)x; nsw = (n + AW - 1) / AW; }
+    }
     __shared__ float red[256 * 4];
     __shared__ int list[256];
     __shared__ int nlist;
@@ -588,7 +593,8 @@ size_t apply_ws_bytes(int64_t n, int32_t D) {
 template <class K, class Upd, class GT>
 int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, const int* sseg,
                const int* seg_offsets, int64_t n, const GT* g, int64_t ldg, const float* rscale, float gscale,
-               int Dc, int vec, const ApplyWs& w, hipStream_t st, const WideArgs* wide = nullptr, StepState* ss = nullptr) {
+               int Dc, int vec, const ApplyWs& w, hipStream_t st, const WideArgs* wide = nullptr, StepState* ss = nullptr,
+               const int64_t* nv = nullptr) {
     ApplyGeom gm;
     gm.D = Dc + (wide ? 4 : 0);
     gm.lpr = Dc / vec + (wide ? 1 : 0);
@@ -607,12 +613,13 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
     const hipEvent_t ev0 = t_prof_start, ev1 = t_prof_stop;
     t_prof_start = t_prof_stop = nullptr;
     if (ev0) MREC_HIP_CHECK(hipEventRecord(ev0, st));
+    if (nv && !(vec == 4 && wide)) return MREC_EUNSUPPORTED;
     if (vec == 4 && wide) {
         k_apply_main<4, K, Upd, GT, true><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
-                                                             w.carry_head, w.carry_tail, w.owners, seg_offsets, wa, ss);
+                                                             w.carry_head, w.carry_tail, w.owners, seg_offsets, wa, ss, nv);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         k_apply_long<4, K, Upd, true><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
-                                                              w.carry_head, w.carry_tail, w.owners, (int)nsw, wa, ss);
+                                                              w.carry_head, w.carry_tail, w.owners, (int)nsw, wa, ss, nv);
     } else if (vec == 4) {
         k_apply_main<4, K, Upd, GT><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
                                                        w.carry_head, w.carry_tail, w.owners, seg_offsets, wa, ss);
@@ -639,7 +646,8 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
 template <class K, class Upd, class GT = float>
 int apply_impl(Upd upd, int64_t V, int64_t ld, int32_t D, const K* uniq, const int32_t* spos, const int32_t* sseg,
                const int32_t* seg_offsets, int64_t n, const GT* g, int64_t ldg, const float* rscale,
-               float gscale, void* ws, size_t ws_bytes, void* stream, const WideArgs* wide = nullptr, StepState* ss = nullptr) {
+               float gscale, void* ws, size_t ws_bytes, void* stream, const WideArgs* wide = nullptr, StepState* ss = nullptr,
+               const int64_t* nv = nullptr) {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || D <= 0 || V < 0 || ld < D || ldg < D) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
@@ -669,7 +677,7 @@ int apply_impl(Upd upd, int64_t V, int64_t ld, int32_t D, const K* uniq, const i
         const int Dc = (D - c0 < CB) ? D - c0 : CB;
         Upd u2 = upd;
         for (int i = 0; i < Upd::NS; ++i) u2.s[i] = upd.s[i] + c0;
-        int rc = apply_cols<K, Upd, GT>(u2, V, ld, uniq, spos, sseg, seg_offsets, n, g + c0, ldg, rscale, gscale, Dc, vec, w, st, wide, ss);
+        int rc = apply_cols<K, Upd, GT>(u2, V, ld, uniq, spos, sseg, seg_offsets, n, g + c0, ldg, rscale, gscale, Dc, vec, w, st, wide, ss, nv);
         if (rc != MREC_OK) return rc;
     }
     return MREC_OK;
@@ -680,7 +688,7 @@ int lazy_adam_impl(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t 
                    const int32_t* spos, const int32_t* sseg, const int32_t* seg_offsets, int64_t n, const GT* g,
                    int64_t ldg, const float* rscale, float lr, float b1, float b2, float eps, float b1_pow,
                    float b2_pow, float gscale, int nesterov, void* ws, size_t ws_bytes, void* stream,
-                   const WideArgs* wide = nullptr, StepState* ss = nullptr) {
+                   const WideArgs* wide = nullptr, StepState* ss = nullptr, const int64_t* nv = nullptr) {
     if (!uniq && n > 0) return MREC_EINVAL;
     UpdAdam u;
     u.s[0] = p; u.s[1] = m; u.s[2] = v;
@@ -688,7 +696,7 @@ int lazy_adam_impl(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t 
     u.h.b1 = b1; u.h.b2 = b2; u.h.omb1 = 1.0f - b1; u.h.omb2 = 1.0f - b2; u.h.eps = eps; u.h.gscale = gscale;
     u.h.nesterov = nesterov;
     return apply_impl<K, UpdAdam, GT>(u, V, ld, D, uniq, spos, sseg, seg_offsets, n, g, ldg, rscale, gscale, ws, ws_bytes,
-                                  stream, wide, ss);
+                                  stream, wide, ss, nv);
 }
 
 template <class K>
@@ -855,7 +863,7 @@ MREC_API int mrec_sparse_lazy_adam_wide(float* p, float* m, float* v, int64_t V,
                                         const float* row_scale, float lr, float b1, float b2, float eps, float b1_pow,
                                         float b2_pow, float grad_scale, int nesterov, const float* gw, int64_t gw_stride, int32_t F,
                                         int32_t wide_col, float ftrl_lr, float l1, float l2, float lr_power, void* ws,
-                                        size_t ws_bytes, void* step_state, void* stream) {
+                                        size_t ws_bytes, void* step_state, const int64_t* n_valid_dev, void* stream) {
     if ((uniq_bytes != 4 && uniq_bytes != 8) || g_kind < 0 || g_kind > 2 || gw_stride < 1 || gw_stride > (1 << 20)) return MREC_EINVAL;
     WideArgs wa;
     wa.gw = gw; wa.F = F; wa.wcol = wide_col; wa.magic = 0; wa.dummy = nullptr; wa.gws = (unsigned)gw_stride;
@@ -863,7 +871,7 @@ MREC_API int mrec_sparse_lazy_adam_wide(float* p, float* m, float* v, int64_t V,
 #define MREC_WIDE_CALL(KT, GT)                                                                                          \
     return lazy_adam_impl<KT, GT>(p, m, v, V, ld, D, (const KT*)uniq, sorted_pos, sorted_seg, seg_offsets, n, (const GT*)g, ldg, \
                                   row_scale, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale, nesterov, ws, ws_bytes, stream, &wa,      \
-                                  (StepState*)step_state)
+                                  (StepState*)step_state, n_valid_dev)
     if (uniq_bytes == 4) {
         if (g_kind == 0) { MREC_WIDE_CALL(int32_t, float); }
         if (g_kind == 1) { MREC_WIDE_CALL(int32_t, bf16_t); }

@@ -36,7 +36,7 @@ constexpr int LT = 2 * IT;       // slots of the per-tile LDS table (load factor
 // 12 KB of LDS per block (int32 keys) keeps the latency-bound global phase at full occupancy.
 template <class K>
 __global__ __launch_bounds__(DB) void k_dedup_insert(const K* __restrict__ ids, int n, int* slots,
-                                                     uint32_t mask, int* __restrict__ sidx) {
+                                                     uint32_t mask, int* __restrict__ sidx, bool skipneg = false) {
     __shared__ int ltab[LT];       // phase 1: local position of the tile-first occurrence of the slot's key
                                    // phase 2: the global slot its leader found
     __shared__ K lkey[IT];
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(DB) void k_dedup_insert(const K* __restrict__ ids, 
     for (int k = 0; k < II; ++k) {
         const int li = k * DB + threadIdx.x;
         ls[k] = -1;
-        if (base + li >= n) continue;
+        if (base + li >= n || (skipneg && key[k] < 0)) continue;       // (skipneg: negative ids are nobody's key -- padding)
         uint32_t s = (hsh[k] >> 11) & (LT - 1);       // different bits than the global probe start
         for (;;) {
             int cur = *(volatile int*)&ltab[s];
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(DB) void k_dedup_insert(const K* __restrict__ ids, 
     for (int k = 0; k < II; ++k) {
         const int li = k * DB + threadIdx.x;
         if (ls[k] >= 0) sidx[base + li] = ltab[ls[k]];
+        else if (skipneg && base + li < n) sidx[base + li] = -1;
     }
 }
 
@@ -142,7 +143,8 @@ __global__ __launch_bounds__(DB) void k_dedup_rank(const K* __restrict__ ids, co
                                                    const int* __restrict__ sidx, int n, unsigned* __restrict__ status,
                                                    int nblk, K* __restrict__ uniq, int* __restrict__ inv,
                                                    int64_t* __restrict__ n_uniq_dev, int* __restrict__ first_pos = nullptr,
-                                                   int* __restrict__ dup_pos = nullptr, int64_t* __restrict__ n_dup_dev = nullptr) {
+                                                   int* __restrict__ dup_pos = nullptr, int64_t* __restrict__ n_dup_dev = nullptr,
+                                                   bool skipneg = false) {
     __shared__ int sm[8];
     __shared__ int s_excl;
     const int base = blockIdx.x * DT + threadIdx.x * DI;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(DB) void k_dedup_rank(const K* __restrict__ ids, co
 #pragma unroll
     for (int k = 0; k < DI; ++k) {
         const int i = base + k;
-        first[k] = (i < n) && (slots[slot[k]] == i);
+        first[k] = (i < n) && slot[k] >= 0 && (slots[slot[k]] == i);      // (slot < 0: a skipped negative id -- counted with the duplicates)
         c += first[k];
     }
     int tot;
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(DB) void k_dedup_rank(const K* __restrict__ ids, co
     if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 0) {
         *n_uniq_dev = (int64_t)tile_base + tot;
         if (n_dup_dev) *n_dup_dev = (int64_t)n - ((int64_t)tile_base + tot);
+        if (skipneg && tile_base + tot < n) uniq[tile_base + tot] = (K)-1;     // the row of the skipped ids' pseudo-group: none
     }
 }
 
@@ -204,7 +207,8 @@ __global__ __launch_bounds__(DB) void k_dedup_rank(const K* __restrict__ ids, co
 __global__ __launch_bounds__(256) void k_plan_place(const int* __restrict__ first_pos, const int64_t* __restrict__ n_uniq_dev,
                                                     const int* __restrict__ dkey, const int* __restrict__ dpos,
                                                     const int64_t* __restrict__ n_dup_dev, int n, int* __restrict__ sorted_pos,
-                                                    int* __restrict__ sorted_seg, int* __restrict__ seg_offsets) {
+                                                    int* __restrict__ sorted_seg, int* __restrict__ seg_offsets, int gkey = -1,
+                                                    int64_t* __restrict__ n_valid_dev = nullptr) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int U = (int)*n_uniq_dev, nD = (int)*n_dup_dev;
     auto lower = [&](int g) {            // first e in [0, nD) with dkey[e] >= g
@@ -215,21 +219,36 @@ __global__ __launch_bounds__(256) void k_plan_place(const int* __restrict__ firs
         }
         return lo;
     };
+    // gkey >= 0: "duplicates" carrying this key are the skipped negative ids (key n - 1: above every real group, which are
+    // < U <= n - 1 whenever a skipped id exists).  They sort behind the real duplicates and are placed behind every group's
+    // run, as a pseudo-group U that nobody reads: the index proper is its first n_valid = U + (real duplicates) entries.
+    const int nDr = (gkey >= 0) ? lower(gkey) : nD;
     if (t < U) {
         const int off = t + lower(t);
         seg_offsets[t] = off;
         sorted_pos[off] = first_pos[t];
         sorted_seg[off] = t;
-        if (t == U - 1) seg_offsets[U] = n;
+        if (t == U - 1) {
+            seg_offsets[U] = U + nDr;
+            if (nDr < nD) seg_offsets[U + 1] = n;
+        }
     }
     if (t < nD) {
         const int g = dkey[t];
-        const int lb = lower(g);
-        const int dst = g + lb + 1 + (t - lb);
-        sorted_pos[dst] = dpos[t];
-        sorted_seg[dst] = g;
+        if (t >= nDr) {
+            sorted_pos[U + t] = dpos[t];
+            sorted_seg[U + t] = U;
+        } else {
+            const int lb = lower(g);
+            const int dst = g + lb + 1 + (t - lb);
+            sorted_pos[dst] = dpos[t];
+            sorted_seg[dst] = g;
+        }
     }
-    if (t == 0 && U == 0) seg_offsets[0] = 0;
+    if (t == 0) {
+        if (U == 0) { seg_offsets[0] = 0; if (nDr < nD) seg_offsets[1] = n; }
+        if (n_valid_dev) *n_valid_dev = (int64_t)U + nDr;
+    }
 }
 
 __global__ __launch_bounds__(DB) void k_dedup_inv(const int* __restrict__ slots, const int* __restrict__ sidx,
@@ -249,7 +268,7 @@ constexpr int kSmallDups = 1024;
 __global__ __launch_bounds__(1024) void k_plan_small(const int* __restrict__ slots, const int* __restrict__ sidx,
                                                      const int* __restrict__ dup_pos, const int64_t* __restrict__ n_dup_dev,
                                                      int* __restrict__ inv, int* __restrict__ dkey, int* __restrict__ dpos,
-                                                     int64_t* __restrict__ n_radix) {
+                                                     int64_t* __restrict__ n_radix, int gkey = -1) {
     __shared__ int skey[kSmallDups];
     const int64_t nD64 = *n_dup_dev;
     if (nD64 > kSmallDups) {
@@ -261,8 +280,9 @@ __global__ __launch_bounds__(1024) void k_plan_small(const int* __restrict__ slo
     int key = 0, pos = 0;
     if (t < nD) {
         pos = dup_pos[t];
-        key = inv[slots[sidx[pos]]];
-        inv[pos] = key;
+        const int sx = sidx[pos];
+        key = sx >= 0 ? inv[slots[sx]] : gkey;           // (a skipped negative id: the pseudo-group behind all others)
+        inv[pos] = sx >= 0 ? key : -1;
         skey[t] = key;
     }
     __syncthreads();
@@ -289,7 +309,7 @@ struct DedupScratch { int* slots; int* sidx; unsigned* status; int nstatus; int*
 // starts earlier; the chain's end is far off the step's critical path, its head runs beside the lookup).
 template <class K>
 int dedup_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_dev, void* ws, size_t ws_bytes,
-               void* stream_v, DedupScratch* fuse_inv_out = nullptr, bool primed = false) {
+               void* stream_v, DedupScratch* fuse_inv_out = nullptr, bool primed = false, bool skipneg = false) {
     hipStream_t st = (hipStream_t)stream_v;
     if (n < 0 || !n_uniq_dev) return MREC_EINVAL;
     if (n == 0) {
@@ -316,8 +336,8 @@ int dedup_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_d
     if (!(primed && fuse_inv_out)) MREC_HIP_CHECK(hipMemsetAsync(slots, 0x7f, cap * sizeof(int), st));
     if (!primed) MREC_HIP_CHECK(hipMemsetAsync(status, 0, (size_t)nblk * sizeof(int), st));     // (a completed call leaves them zero)
     const int g256 = (int)mrec_cdiv(n, DB);
-    k_dedup_insert<K><<<(int)mrec_cdiv(n, IT), DB, 0, st>>>(ids, (int)n, slots, (uint32_t)(cap - 1), sidx);
-    k_dedup_rank<K><<<nblk, DB, 0, st>>>(ids, slots, sidx, (int)n, status, nblk, uniq, inv, n_uniq_dev, first_pos, dup_pos, n_dup);
+    k_dedup_insert<K><<<(int)mrec_cdiv(n, IT), DB, 0, st>>>(ids, (int)n, slots, (uint32_t)(cap - 1), sidx, skipneg);
+    k_dedup_rank<K><<<nblk, DB, 0, st>>>(ids, slots, sidx, (int)n, status, nblk, uniq, inv, n_uniq_dev, first_pos, dup_pos, n_dup, skipneg);
     if (fuse_inv_out) {
         fuse_inv_out->slots = slots; fuse_inv_out->sidx = sidx; fuse_inv_out->status = status; fuse_inv_out->nstatus = nblk;
         fuse_inv_out->first_pos = first_pos; fuse_inv_out->dup_pos = dup_pos; fuse_inv_out->n_dup = n_dup;
@@ -425,8 +445,12 @@ static size_t plan_extra_bytes(int64_t n) { return mrec_align_up((size_t)(n ? n 
 // over the live tiles only -- a handful on uniform ids), and one placement kernel writes the inverted index.
 template <class K>
 static int plan_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_uniq_dev, int32_t* sorted_pos,
-                     int32_t* sorted_seg, int32_t* seg_offsets, void* ws, size_t ws_bytes, void* stream, bool primed = false) {
+                     int32_t* sorted_seg, int32_t* seg_offsets, void* ws, size_t ws_bytes, void* stream, bool primed = false,
+                     bool skipneg = false) {
     if (n < 0 || !n_uniq_dev || !seg_offsets) return MREC_EINVAL;
+    // skipneg: negative ids are padding (a shard's fixed-capacity request message): no group, no entry of the index proper;
+    // n_uniq_dev is then two words, [1] = the number of entries of the index proper (valid positions)
+    const int gkey = skipneg ? (int)(n - 1) : -1;
     size_t db = 0, gb = 0;
     int rc = mrec_dedup_workspace_bytes(n, &db);
     if (rc != MREC_OK) return rc;
@@ -439,11 +463,12 @@ static int plan_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_
         rc = dedup_impl<K>(ids, n, uniq, inv, n_uniq_dev, ws, db, stream, nullptr, primed);
         if (rc != MREC_OK) return rc;
         MREC_HIP_CHECK(hipMemsetAsync(seg_offsets, 0, sizeof(int32_t), st));
+        if (skipneg) MREC_HIP_CHECK(hipMemsetAsync(n_uniq_dev + 1, 0, sizeof(int64_t), st));
         return MREC_OK;
     }
     if (!sorted_pos || !sorted_seg) return MREC_EINVAL;
     DedupScratch sc{};
-    rc = dedup_impl<K>(ids, n, uniq, inv, n_uniq_dev, ws, db, stream, &sc, primed);
+    rc = dedup_impl<K>(ids, n, uniq, inv, n_uniq_dev, ws, db, stream, &sc, primed, skipneg);
     if (rc != MREC_OK) return rc;
     const int nblk = (int)mrec_cdiv(n, RT);
     MrecArena a((char*)ws + db, gb);
@@ -462,7 +487,7 @@ static int plan_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_
     const bool first_to_b = ((passes - 1) % 2) == 0;
     int* kgen = first_to_b ? sorted_seg : tk;
     // few duplicates: one workgroup sorts them straight into B and zeroes the count the radix passes run on
-    k_plan_small<<<1, 1024, 0, st>>>(sc.slots, sc.sidx, sc.dup_pos, sc.n_dup, inv, tk, tv, sc.n_radix);
+    k_plan_small<<<1, 1024, 0, st>>>(sc.slots, sc.sidx, sc.dup_pos, sc.n_dup, inv, tk, tv, sc.n_radix, gkey);
     const int* kin = kgen;
     const int* vin = sc.dup_pos;
     for (int p = 0; p < passes; ++p) {
@@ -472,7 +497,7 @@ static int plan_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_
         const int shift = p * pbits;
         if (p == 0)      // keys = group of every duplicate = the rank at its scratch slot; also its entry of `inv`
             radix_pass(kin, vin, (int)n, shift, pbits, hist, hscan, totals, nullptr, kout, vout, st, sc.slots, sc.sidx, kgen,
-                       sc.status, sc.nstatus, sc.dup_pos, inv, sc.n_radix);
+                       sc.status, sc.nstatus, sc.dup_pos, inv, sc.n_radix, gkey);
         else
             radix_pass(kin, vin, (int)n, shift, pbits, hist, hscan, totals, nullptr, kout, vout, st, nullptr, nullptr, nullptr,
                        nullptr, 0, nullptr, nullptr, sc.n_radix);
@@ -480,7 +505,7 @@ static int plan_impl(const K* ids, int64_t n, K* uniq, int32_t* inv, int64_t* n_
         vin = vout;
     }
     k_plan_place<<<(unsigned)mrec_cdiv(n, 256), 256, 0, st>>>(sc.first_pos, n_uniq_dev, tk, tv, sc.n_dup, (int)n, sorted_pos,
-                                                             sorted_seg, seg_offsets);
+                                                             sorted_seg, seg_offsets, gkey, skipneg ? n_uniq_dev + 1 : nullptr);
     MREC_LAUNCH_CHECK();
     MREC_HIP_CHECK(hipMemsetAsync(sc.slots, 0x7f, sc.slot_bytes, st));       // hand the scratch table back clean (MREC_PLAN_WS_PRIMED)
     return MREC_OK;
@@ -512,11 +537,11 @@ MREC_API int mrec_sparse_plan_ex_i32(const int32_t* ids, int64_t n, int32_t* uni
                                      int32_t* sorted_pos, int32_t* sorted_seg, int32_t* seg_offsets, void* ws,
                                      size_t ws_bytes, uint32_t flags, void* stream) {
     return plan_impl<int32_t>(ids, n, uniq, inv, n_uniq_dev, sorted_pos, sorted_seg, seg_offsets, ws, ws_bytes, stream,
-                              (flags & MREC_PLAN_WS_PRIMED) != 0);
+                              (flags & MREC_PLAN_WS_PRIMED) != 0, (flags & MREC_PLAN_SKIP_NEGATIVE) != 0);
 }
 MREC_API int mrec_sparse_plan_ex_i64(const int64_t* ids, int64_t n, int64_t* uniq, int32_t* inv, int64_t* n_uniq_dev,
                                      int32_t* sorted_pos, int32_t* sorted_seg, int32_t* seg_offsets, void* ws,
                                      size_t ws_bytes, uint32_t flags, void* stream) {
     return plan_impl<int64_t>(ids, n, uniq, inv, n_uniq_dev, sorted_pos, sorted_seg, seg_offsets, ws, ws_bytes, stream,
-                              (flags & MREC_PLAN_WS_PRIMED) != 0);
+                              (flags & MREC_PLAN_WS_PRIMED) != 0, (flags & MREC_PLAN_SKIP_NEGATIVE) != 0);
 }

@@ -92,13 +92,14 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
                                                      const float* __restrict__ row_scale,
                                                      OT* __restrict__ out, int D, RowGeom gm,
                                                      float* __restrict__ wprod = nullptr, int64_t ldo = 0, int64_t ldw = 2,
-                                                     GatherDrop gd = GatherDrop{}) {
+                                                     GatherDrop gd = GatherDrop{}, int ids_stride = 1, int rs_stride = 1,
+                                                     bool skip_invalid = false) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
     if (grp >= gm.G) return;
     if (ldo == 0) ldo = D;                 // row stride of `out` in elements; ldw: stride of the wide products in floats
     const int col = sub * VEC;
-    const bool wl = VEC == 4 && sizeof(OT) == 2 && wprod != nullptr && col >= D;      // the wide lane (column D)
+    const bool wl = VEC == 4 && wprod != nullptr && col >= D;      // the wide lane (column D)
     const int64_t wave_row0 = ((int64_t)blockIdx.x * 4 + wave) * (gm.G * GB);
     Vf<VEC> x[GB];
     float sc[GB];
@@ -109,8 +110,8 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
         row[k] = -1;
         sc[k] = 1.0f;
         if (i < n) {
-            row[k] = (int64_t)ids[i];
-            if (row_scale) sc[k] = row_scale[i];
+            row[k] = (int64_t)ids[i * ids_stride];      // (strides: the ids / weights of a shard's request message, read in place)
+            if (row_scale) sc[k] = row_scale[i * rs_stride];
         }
     }
 #pragma unroll
@@ -121,16 +122,23 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
 #pragma unroll
     for (int k = 0; k < GB; ++k) {
         const int64_t i = wave_row0 + (int64_t)k * gm.G + grp;
-        if (i < n) {
+        if (i < n && !(skip_invalid && row[k] < 0)) {       // (skip_invalid: padding slots of a message are left alone)
             const Vf<VEC> y = row_scale ? vscale(x[k], sc[k]) : x[k];
-            if constexpr (VEC == 4 && sizeof(OT) == 2) {
+            if constexpr (VEC == 4) {
               if (wprod != nullptr) {
                 const float4 yv = y.v;
-                uint2 u = pack16((const OT*)nullptr, yv);
-                if (gd.d.thresh && !wl) u = drop16<OT>(u, gd, drop_key(gd.d), i, D, col);
-                if (wl) u = make_uint2(__float_as_uint(yv.x), 0u);
-                uint2* dst = wl ? (uint2*)(wprod + ldw * i) : (uint2*)(out + i * ldo + col);
-                *dst = u;
+                if constexpr (sizeof(OT) == 2) {
+                    // ONE store instruction for the whole lane-group: the wide lane's address points into wprod
+                    uint2 u = pack16((const OT*)nullptr, yv);
+                    if (gd.d.thresh && !wl) u = drop16<OT>(u, gd, drop_key(gd.d), i, D, col);
+                    if (wl) u = make_uint2(__float_as_uint(yv.x), 0u);
+                    uint2* dst = wl ? (uint2*)(wprod + ldw * i) : (uint2*)(out + i * ldo + col);
+                    *dst = u;
+                } else if (wl) {
+                    *(uint2*)(wprod + ldw * i) = make_uint2(__float_as_uint(yv.x), 0u);      // fp32 rows (the fp32 wire format)
+                } else {
+                    vstore(out + i * ldo + col, y);
+                }
               } else {
                 vstore(out + i * ldo + col, y);
               }
@@ -441,21 +449,24 @@ inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 template <class K, class OT = bf16o_t>
 int gather_bf16_impl(const float* table, int64_t V, int64_t ld, int32_t D, const K* ids, int64_t n,
                      const float* row_scale, uint16_t* out, void* stream, int wcol = 0, float* wprod = nullptr, int64_t ldo = 0,
-                     int64_t ldw = 2, GatherDrop gd = GatherDrop{}) {
-    if ((ldo != 0 && (ldo < D || ldo % 4)) || (wprod && (ldw < 2 || ldw % 2))) return MREC_EINVAL;
-    if (wprod && (wcol != D || D % 4 || D > 252 || ld % 4 || ld < D + 4 || !al16(table) || (((uintptr_t)out) & 7) || (((uintptr_t)wprod) & 7)))
+                     int64_t ldw = 2, GatherDrop gd = GatherDrop{}, int ids_stride = 1, int rs_stride = 1, bool skip_invalid = false) {
+    constexpr int ob = (int)sizeof(OT);                    // bytes per output element (2: bf16 / f16, 4: fp32 rows + the wide lane)
+    const int oa = ob == 2 ? 7 : 15;                       // alignment of an output row's 4-element quad
+    if ((ldo != 0 && (ldo < D || ldo % 4)) || (wprod && (ldw < 2 || ldw % 2)) || ids_stride < 1 || rs_stride < 1) return MREC_EINVAL;
+    if (wprod && (wcol != D || D % 4 || D > 252 || ld % 4 || ld < D + 4 || !al16(table) || (((uintptr_t)out) & oa) || (((uintptr_t)wprod) & 7)))
         return MREC_EUNSUPPORTED;       // the wide word must sit right behind the deep columns of 16-byte aligned rows
+    if (ob == 4 && !wprod) return MREC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || D <= 0 || V < 0 || ld < D) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
     if (!table || !ids || !out) return MREC_EINVAL;
-    const bool vec = (D % 4 == 0) && (D <= 256) && (ld % 4 == 0) && al16(table) && ((((uintptr_t)out) & 7) == 0);
+    const bool vec = (D % 4 == 0) && (D <= 256) && (ld % 4 == 0) && al16(table) && ((((uintptr_t)out) & oa) == 0);
     if (vec) {
         const int lpr = D / 4 + (wprod ? 1 : 0);
         RowGeom gm{lpr, 64 / lpr};
         k_gather_rows<4, K, OT><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
-            table, V, ld, ids, n, row_scale, (OT*)out, D, gm, wprod, ldo, ldw, gd);
-    } else if (D <= 64 && !wprod && ldo == 0) {
+            table, V, ld, ids, n, row_scale, (OT*)out, D, gm, wprod, ldo, ldw, gd, ids_stride, rs_stride, skip_invalid);
+    } else if (D <= 64 && !wprod && ldo == 0 && ids_stride == 1 && rs_stride == 1 && !skip_invalid) {
         RowGeom gm{D, 64 / D};
         k_gather_rows<1, K, OT><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
             table, V, ld, ids, n, row_scale, (OT*)out, D, gm);
@@ -582,24 +593,41 @@ MREC_API int mrec_gather_rows_f16_i64(const float* table, int64_t V, int64_t ld,
     return gather_bf16_impl<int64_t, f16o_t>(table, V, ld, D, ids, n, row_scale, out, stream);
 }
 
-/* Gather + the wide branch's products in one pass (see include/mrec.h): out_kind 1 = bf16, 2 = f16 rows. */
-MREC_API int mrec_gather_rows_wide(const float* table, int64_t V, int64_t ld, int32_t D, const void* ids, int32_t id_bytes,
-                                   int64_t n, const float* row_scale, void* out, int32_t out_kind, int64_t ldo, int32_t wide_col,
-                                   float* wide_prod, int64_t ldw, const mrec_dropout_t* drop, int32_t fields, void* stream) {
-    if ((id_bytes != 4 && id_bytes != 8) || (out_kind != 1 && out_kind != 2)) return MREC_EINVAL;
+/* Gather + the wide branch's products in one pass (see include/mrec.h): out_kind 0 = fp32, 1 = bf16, 2 = f16 rows. */
+MREC_API int mrec_gather_rows_wide_ex(const float* table, int64_t V, int64_t ld, int32_t D, const void* ids, int32_t id_bytes,
+                                      int64_t id_stride, int64_t n, const float* row_scale, int64_t scale_stride, void* out,
+                                      int32_t out_kind, int64_t ldo, int32_t wide_col, float* wide_prod, int64_t ldw,
+                                      const mrec_dropout_t* drop, int32_t fields, uint32_t flags, void* stream) {
+    if ((id_bytes != 4 && id_bytes != 8) || out_kind < 0 || out_kind > 2 || id_stride < 1 || id_stride > (1 << 20) || scale_stride < 1 ||
+        scale_stride > (1 << 20))
+        return MREC_EINVAL;
     if (!wide_prod || wide_col < 0 || wide_col >= ld) return MREC_EINVAL;
     GatherDrop gd{};
     if (drop) {
-        if (fields <= 0 || n % fields || !drop_from(drop, (int64_t)fields * D, &gd.d)) return MREC_EINVAL;
+        if (out_kind == 0 || fields <= 0 || n % fields || !drop_from(drop, (int64_t)fields * D, &gd.d)) return MREC_EINVAL;
         gd.F = fields;
     }
     if (ldo == D) ldo = 0;
+    const int is = (int)id_stride, rs = (int)scale_stride;
+    const bool skip = (flags & MREC_GATHER_SKIP_INVALID) != 0;
+#define MREC_GW(KT, OT) return gather_bf16_impl<KT, OT>(table, V, ld, D, (const KT*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, \
+                                                        wide_prod, ldo, ldw, gd, is, rs, skip)
     if (id_bytes == 4) {
-        if (out_kind == 1) return gather_bf16_impl<int32_t, bf16o_t>(table, V, ld, D, (const int32_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw, gd);
-        return gather_bf16_impl<int32_t, f16o_t>(table, V, ld, D, (const int32_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw, gd);
+        if (out_kind == 0) { MREC_GW(int32_t, float); }
+        if (out_kind == 1) { MREC_GW(int32_t, bf16o_t); }
+        MREC_GW(int32_t, f16o_t);
     }
-    if (out_kind == 1) return gather_bf16_impl<int64_t, bf16o_t>(table, V, ld, D, (const int64_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw, gd);
-    return gather_bf16_impl<int64_t, f16o_t>(table, V, ld, D, (const int64_t*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, wide_prod, ldo, ldw, gd);
+    if (out_kind == 0) { MREC_GW(int64_t, float); }
+    if (out_kind == 1) { MREC_GW(int64_t, bf16o_t); }
+    MREC_GW(int64_t, f16o_t);
+#undef MREC_GW
+}
+MREC_API int mrec_gather_rows_wide(const float* table, int64_t V, int64_t ld, int32_t D, const void* ids, int32_t id_bytes,
+                                   int64_t n, const float* row_scale, void* out, int32_t out_kind, int64_t ldo, int32_t wide_col,
+                                   float* wide_prod, int64_t ldw, const mrec_dropout_t* drop, int32_t fields, void* stream) {
+    if (out_kind != 1 && out_kind != 2) return MREC_EINVAL;
+    return mrec_gather_rows_wide_ex(table, V, ld, D, ids, id_bytes, 1, n, row_scale, 1, out, out_kind, ldo, wide_col, wide_prod, ldw, drop,
+                                    fields, 0u, stream);
 }
 
 MREC_API int mrec_wide_sum_f32_i32(const float* w, int64_t V, int64_t ldw, const int32_t* ids, const float* wts,

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(HB) void k_map_export(MapDev m, const int* __restri
 //           positions of new keys, the admission mask.
 constexpr int kEmptyPos = 0x7f7f7f7f;
 constexpr unsigned kMFlagA = 1u << 30, kMFlagP = 2u << 30, kMFlagMask = 3u << 30;
-constexpr uint32_t F_INSERT = 1u, F_UNIQUE = 2u, F_TRAIN = 4u, F_PRIMED = 8u;
+constexpr uint32_t F_INSERT = 1u, F_UNIQUE = 2u, F_TRAIN = 4u, F_PRIMED = 8u, F_SKIP_PAD = 16u;
 
 struct MapTab { float* rows; int64_t ld; int D; float sigma; float fill; uint64_t seed; };
 struct MapTabs { MapTab t[8]; int n; };
@@ -314,6 +314,11 @@ __global__ __launch_bounds__(HB) void k_map_probe(MapDev m, const K* __restrict_
     if (i >= n_max) return;
     if (i >= eff_n(n_max, n_dev)) { rows_out[i] = -1; return; }
     const int64_t key = (int64_t)keys[i];
+    if ((flags & F_SKIP_PAD) && key == -1) {      // a padding slot of a request message: nobody's key
+        rows_out[i] = -1;
+        w.sidx[i] = -1;
+        return;
+    }
     const uint32_t hsh = mrec_hash_key(key);
     uint32_t s = hsh & m.mask;
     int row = -1;
@@ -370,6 +375,7 @@ __global__ __launch_bounds__(HB) void k_map_place(MapDev m, const K* __restrict_
     for (int k = 0; k < HI; ++k) {
         const int64_t i = base + k;
         bool f = (i < eff) && rows_out[i] < 0;
+        if (f && (flags & F_SKIP_PAD) && (int64_t)keys[i] == -1) f = false;
         if (f && !(flags & F_UNIQUE)) f = (w.slots[w.sidx[i]] == (int)i);
         first[k] = f;
         c += f;
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(HB) void k_map_finish(MapDev m, MapTabs tabs, int64
     if (!fix && !rows_adm) return;
     for (int64_t i = tid; i < n_max; i += nthreads) {
         int row = rows_out[i];
-        if (fix && i < eff && row < 0) {
+        if (fix && i < eff && row < 0 && !((flags & F_SKIP_PAD) && w.sidx[i] < 0)) {
             row = w.srank[w.sidx[i]];
             rows_out[i] = row;
         }

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void k_radix_hist(const int* __restrict__ keys
                                                     const int* __restrict__ sidx, int* __restrict__ keys_out,
                                                     unsigned* __restrict__ clear, int nclear,
                                                     const int* __restrict__ pos = nullptr, int* __restrict__ inv_out = nullptr,
-                                                    const int64_t* __restrict__ n_dev = nullptr) {
+                                                    const int64_t* __restrict__ n_dev = nullptr, int gkey = -1) {
     __shared__ int h[RNB];
     // (the look-back words the Unique's rank kernel left behind: zeroed here for the next call, no launch of their own)
     for (int j = blockIdx.x * 256 + threadIdx.x; j < nclear; j += gridDim.x * 256) clear[j] = 0;
@@ -41,8 +41,9 @@ __global__ __launch_bounds__(256) void k_radix_hist(const int* __restrict__ keys
                 // keys produced here: the group of the i-th duplicate (position pos[i]) = the inverse of the first position of
                 // its key, which its scratch slot still holds; also written as the duplicate's own inverse
                 const int p_ = pos[i];
-                key = inv_out[slots[sidx[p_]]];
-                inv_out[p_] = key;
+                const int sx = sidx[p_];
+                key = sx >= 0 ? inv_out[slots[sx]] : gkey;       // (sx < 0: a skipped negative id -- the pseudo-group behind all others)
+                inv_out[p_] = sx >= 0 ? key : -1;
                 keys_out[i] = key;
             } else key = keys[i];
             atomicAdd(&h[(key >> shift) & (NB - 1)], 1);
@@ -199,10 +200,10 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const int* __restrict__ k
 inline void radix_pass(const int* kin, const int* vin, int n, int shift, int nbits, int* hist, int* hscan, int* totals,
                        int* dbase, int* kout, int* vout, hipStream_t st, const int* slots = nullptr,
                        const int* sidx = nullptr, int* keys_gen = nullptr, unsigned* clear = nullptr, int nclear = 0,
-                       const int* pos = nullptr, int* inv_out = nullptr, const int64_t* n_dev = nullptr) {
+                       const int* pos = nullptr, int* inv_out = nullptr, const int64_t* n_dev = nullptr, int gkey = -1) {
     const int nblk = (int)mrec_cdiv(n, RT);
     const int NB = 1 << nbits;
-    k_radix_hist<<<nblk, 256, 0, st>>>(kin, n, shift, nbits, hist, slots, sidx, keys_gen, clear, nclear, pos, inv_out, n_dev);
+    k_radix_hist<<<nblk, 256, 0, st>>>(kin, n, shift, nbits, hist, slots, sidx, keys_gen, clear, nclear, pos, inv_out, n_dev, gkey);
     k_radix_colscan<<<(NB + 31) / 32, 256, 0, st>>>(hist, nblk, nbits, hscan, totals, n_dev);
     k_radix_scatter<<<nblk, 256, 0, st>>>(kin, vin, n, shift, nbits, hscan, totals, kout, vout, dbase, n_dev);
 }

@@ -154,6 +154,158 @@ __global__ __launch_bounds__(256) void k_unpack_iw(const int2* __restrict__ in, 
     }
 }
 
+// ---- fixed-capacity routing (no host round trip: every message of the step has a static shape) ------------------------------
+// A request entry: the id (dense tables: the owner's local row; hash tables: the raw key) and the position's weight, which
+// travels so that the OWNER applies the mask in fp32 and rounds once.  int32 ids: 8 bytes; int64 ids: 16 bytes.
+template <class K> struct ReqEntry;
+template <> struct ReqEntry<int32_t> { int32_t id; float wt; };
+template <> struct ReqEntry<int64_t> { int64_t id; float wt; int32_t pad; };
+
+// Thread k < n: sorted position k (bucket order, stable) takes slot owner * cap + (k - bucket start); positions past a
+// bucket's capacity are dropped and counted.  Thread t < S * cap: slots past a bucket's count carry id -1 (the owner's gather
+// skips them, its plan sorts them behind everything else).
+template <class K>
+__global__ __launch_bounds__(256) void k_route_slots(const K* __restrict__ ids, const float* __restrict__ wts, int64_t n, int S,
+                                                     int64_t cap, const int* __restrict__ perm, const int* __restrict__ dbase,
+                                                     ReqEntry<K>* __restrict__ req, int* __restrict__ slot_of_pos,
+                                                     int* __restrict__ pos_of_slot, unsigned long long* __restrict__ overflow,
+                                                     bool hash) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) {
+        const int pos = perm[t];
+        const K id = ids[pos];
+        const int o = owner_of(id, S, hash);
+        const int64_t j = t - dbase[o];
+        if (j < cap) {
+            const int64_t s = (int64_t)o * cap + j;
+            ReqEntry<K> e{};
+            e.id = hash ? id : (id - (K)o) / (K)S;
+            e.wt = wts ? wts[pos] : 1.0f;
+            req[s] = e;
+            slot_of_pos[pos] = (int)s;
+            pos_of_slot[s] = pos;
+        } else {
+            slot_of_pos[pos] = -1;
+            atomicAdd(overflow, 1ull);
+        }
+    }
+    if (t < (int64_t)S * cap) {
+        const int o = (int)(t / cap);
+        const int64_t j = t - (int64_t)o * cap;
+        const int64_t cnt = (int64_t)((o + 1 < S) ? dbase[o + 1] : (int)n) - dbase[o];
+        if (j >= cnt) {
+            ReqEntry<K> e{};
+            e.id = (K)-1;
+            e.wt = 0.0f;
+            req[t] = e;
+            pos_of_slot[t] = -1;
+        }
+    }
+}
+
+template <class K>
+__global__ __launch_bounds__(256) void k_unpack_req(const ReqEntry<K>* __restrict__ req, int64_t n, K* __restrict__ ids,
+                                                    float* __restrict__ wts) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) {
+        const ReqEntry<K> e = req[k];
+        ids[k] = e.id;
+        wts[k] = e.wt;
+    }
+}
+
+// The answers back in position order: position p reads message row slot_of_pos[p] ([Dw words of the looked-up row | wide
+// product, 0 | pad], W words) and writes its row of the MLP input and its (product, 0) pair -- exactly what the one-GPU fused
+// lookup hands out.  A lane per 16 bytes; the lane behind the row's last moves the pair.
+__global__ __launch_bounds__(256) void k_unroute_slots(const float* __restrict__ back, int64_t W, const int* __restrict__ slot_of_pos,
+                                                       int64_t n, int Dw, int lpr, int G, float* __restrict__ emb,
+                                                       float* __restrict__ wprod) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / lpr, sub = lane - grp * lpr;
+    if (grp >= G) return;
+    const int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * (G * PB);
+    const bool wl = sub * 4 >= Dw;
+    float4 x[PB];
+    int s[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int64_t p = p0 + (int64_t)q * G + grp;
+        s[q] = (p < n) ? slot_of_pos[p] : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s[q] >= 0) x[q] = *(const float4*)(back + (int64_t)s[q] * W + sub * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int64_t p = p0 + (int64_t)q * G + grp;
+        if (p >= n) continue;
+        if (wl) *(float2*)(wprod + 2 * p) = make_float2(x[q].x, 0.0f);
+        else *(float4*)(emb + p * Dw + sub * 4) = x[q];
+    }
+}
+
+// The gradient message in slot order: slot s of position p = pos_of_slot[s] carries [Dw words of p's row gradient | the wide
+// branch's gradient of p's sample (the head's dlogit) | pad]; padding slots are left alone (nobody reads them).
+__global__ __launch_bounds__(256) void k_route_grads(const float* __restrict__ g, int64_t ldg, const float* __restrict__ dlogit,
+                                                     unsigned magic, int F, const int* __restrict__ pos_of_slot, int64_t n_slots,
+                                                     int Dw, int lpr, int G, float* __restrict__ msg, int64_t W) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / lpr, sub = lane - grp * lpr;
+    if (grp >= G) return;
+    const int64_t s0 = ((int64_t)blockIdx.x * 4 + wave) * (G * PB);
+    const bool wl = sub * 4 >= Dw;
+    float4 x[PB];
+    int p[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int64_t s = s0 + (int64_t)q * G + grp;
+        p[q] = (s < n_slots) ? pos_of_slot[s] : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p[q] >= 0) {
+            if (wl) x[q].x = dlogit[F == 1 ? (unsigned)p[q] : __umulhi((unsigned)p[q], magic)];
+            else x[q] = *(const float4*)(g + (int64_t)p[q] * ldg + sub * 4);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int64_t s = s0 + (int64_t)q * G + grp;
+        if (p[q] >= 0) *(float4*)(msg + s * W + sub * 4) = x[q];
+    }
+}
+
+template <class K>
+int route_slots_impl(const K* ids, const float* wts, int64_t n, int32_t S, int64_t cap, int hashed, void* req, int32_t* slot_of_pos,
+                     int32_t* pos_of_slot, int64_t* overflow_dev, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= 0 || S <= 0 || S > RNB || cap <= 0 || !ids || !req || !slot_of_pos || !pos_of_slot || !overflow_dev || !ws) return MREC_EINVAL;
+    if (n > (int64_t(1) << 30) || (int64_t)S * cap > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
+    if (((uintptr_t)req) & (sizeof(ReqEntry<K>) - 1)) return MREC_EINVAL;
+    const int nblk = (int)mrec_cdiv(n, RT);
+    MrecArena a(ws, ws_bytes);
+    int* hist = a.take<int>((size_t)nblk * RNB);
+    int* hscan = a.take<int>((size_t)nblk * RNB);
+    int* totals = a.take<int>(RNB);
+    int* dbase = a.take<int>(RNB);
+    int* owner = a.take<int>(n);
+    int* okeys = a.take<int>(n);
+    int* perm = a.take<int>(n);
+    if (!a.ok) return MREC_EWORKSPACE;
+    int nbits = 1;
+    while ((1 << nbits) < S) ++nbits;
+    k_owner<K><<<(unsigned)mrec_cdiv(n, 256), 256, 0, st>>>(ids, n, S, owner, hashed != 0);
+    radix_pass(owner, nullptr, (int)n, 0, nbits, hist, hscan, totals, dbase, okeys, perm, st);
+    const int64_t m = n > (int64_t)S * cap ? n : (int64_t)S * cap;
+    k_route_slots<K><<<(unsigned)mrec_cdiv(m, 256), 256, 0, st>>>(ids, wts, n, S, cap, perm, dbase, (ReqEntry<K>*)req, slot_of_pos,
+                                                                 pos_of_slot, (unsigned long long*)overflow_dev, hashed != 0);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
 template <class K>
 int route_impl(const K* ids, int64_t n, int32_t S, K* send_local, int32_t* send_perm, int64_t* counts_dev, void* ws,
                size_t ws_bytes, void* stream, bool hash = false) {
@@ -260,6 +412,61 @@ MREC_API int mrec_shard_unpack_iw_i32(const int32_t* pairs, int64_t n, int32_t* 
     if (n == 0) return MREC_OK;
     if (!pairs || !ids_out || !wts_out || (((uintptr_t)pairs) & 7)) return MREC_EINVAL;
     k_unpack_iw<<<(unsigned)mrec_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>((const int2*)pairs, n, ids_out, wts_out);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+/* ---- fixed-capacity routing: every message of a sharded step has a static shape (include/mrec.h) ---- */
+MREC_API int mrec_shard_route_slots_workspace_bytes(int64_t n, int32_t n_shards, size_t* out) {
+    if (!out || n < 0 || n_shards <= 0) return MREC_EINVAL;
+    const size_t nn = (size_t)(n ? n : 1);
+    *out = mrec_align_up((size_t)mrec_cdiv(nn, RT) * RNB * 4, 256) * 2 + mrec_align_up((size_t)RNB * 4, 256) * 2 +
+           mrec_align_up(nn * 4, 256) * 3;
+    return MREC_OK;
+}
+MREC_API int mrec_shard_route_slots_i32(const int32_t* ids, const float* wts, int64_t n, int32_t n_shards, int64_t cap, int hashed,
+                                        void* req, int32_t* slot_of_pos, int32_t* pos_of_slot, int64_t* overflow_dev, void* ws,
+                                        size_t ws_bytes, void* stream) {
+    return route_slots_impl<int32_t>(ids, wts, n, n_shards, cap, hashed, req, slot_of_pos, pos_of_slot, overflow_dev, ws, ws_bytes, stream);
+}
+MREC_API int mrec_shard_route_slots_i64(const int64_t* ids, const float* wts, int64_t n, int32_t n_shards, int64_t cap, int hashed,
+                                        void* req, int32_t* slot_of_pos, int32_t* pos_of_slot, int64_t* overflow_dev, void* ws,
+                                        size_t ws_bytes, void* stream) {
+    return route_slots_impl<int64_t>(ids, wts, n, n_shards, cap, hashed, req, slot_of_pos, pos_of_slot, overflow_dev, ws, ws_bytes, stream);
+}
+MREC_API int mrec_shard_unpack_req(const void* req, int32_t id_bytes, int64_t n_slots, void* ids_out, float* wts_out, void* stream) {
+    if (n_slots < 0 || (id_bytes != 4 && id_bytes != 8)) return MREC_EINVAL;
+    if (n_slots == 0) return MREC_OK;
+    if (!req || !ids_out || !wts_out) return MREC_EINVAL;
+    const unsigned grid = (unsigned)mrec_cdiv(n_slots, 256);
+    if (id_bytes == 4) k_unpack_req<int32_t><<<grid, 256, 0, (hipStream_t)stream>>>((const ReqEntry<int32_t>*)req, n_slots, (int32_t*)ids_out, wts_out);
+    else k_unpack_req<int64_t><<<grid, 256, 0, (hipStream_t)stream>>>((const ReqEntry<int64_t>*)req, n_slots, (int64_t*)ids_out, wts_out);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+MREC_API int mrec_shard_unroute_slots(const float* back, int64_t W, const int32_t* slot_of_pos, int64_t n, int32_t Dw, float* emb_out,
+                                      float* wprod_out, void* stream) {
+    if (n < 0 || Dw <= 0 || Dw % 4 || Dw > 252 || W < Dw + 4 || W % 4) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!back || !slot_of_pos || !emb_out || !wprod_out) return MREC_EINVAL;
+    if ((((uintptr_t)back) | ((uintptr_t)emb_out)) & 15 || (((uintptr_t)wprod_out) & 7)) return MREC_EINVAL;
+    const int lpr = Dw / 4 + 1, G = 64 / lpr;
+    k_unroute_slots<<<(unsigned)mrec_cdiv(n, (int64_t)4 * G * PB), 256, 0, (hipStream_t)stream>>>(back, W, slot_of_pos, n, Dw, lpr, G,
+                                                                                                emb_out, wprod_out);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+MREC_API int mrec_shard_route_grads(const float* g, int64_t ldg, const float* dlogit, int32_t F, const int32_t* pos_of_slot,
+                                    int64_t n_slots, int32_t Dw, float* msg, int64_t W, void* stream) {
+    if (n_slots < 0 || Dw <= 0 || Dw % 4 || Dw > 252 || W < Dw + 4 || W % 4 || ldg < Dw || ldg % 4 || F <= 0) return MREC_EINVAL;
+    if (n_slots == 0) return MREC_OK;
+    if (!g || !dlogit || !pos_of_slot || !msg) return MREC_EINVAL;
+    if ((((uintptr_t)g) | ((uintptr_t)msg)) & 15) return MREC_EINVAL;
+    if ((uint64_t)n_slots * (uint64_t)F >= ((uint64_t)1 << 32)) return MREC_EUNSUPPORTED;
+    const unsigned magic = (unsigned)(((uint64_t)1 << 32) / (uint64_t)F + 1);       // pos / F = umulhi(pos, magic) while pos * F < 2^32
+    const int lpr = Dw / 4 + 1, G = 64 / lpr;
+    k_route_grads<<<(unsigned)mrec_cdiv(n_slots, (int64_t)4 * G * PB), 256, 0, (hipStream_t)stream>>>(g, ldg, dlogit, magic, F, pos_of_slot,
+                                                                                                    n_slots, Dw, lpr, G, msg, W);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }

@@ -94,16 +94,17 @@ class HostBackedTable:
         self._first_touch.fill_(int(d.get("first_touch", 0)))
 
     # ------------------------------------------------------------------------------------------
-    def prepare(self, ids):
+    def prepare(self, ids, skip_negative=False):
         """Makes all ids resident; returns a SparsePlan whose groups map to CACHE rows (plan.uniq_buf) and
-        the per-position cache rows (int32 [n]) for the gather."""
+        the per-position cache rows (int32 [n]) for the gather.  skip_negative: ids of -1 are padding slots of a shard's
+        request message (no group, cache row -1)."""
         self.step += 1
         C, dev = self.C, self.device
         if self.hashed:
             # keys -> host rows (every position probes `home`; new keys take the next host row): from here on `ids` are
             # host-row numbers and the tier is the dense-table one
-            ids = self.home.lookup(ids, insert=True).view(ids.shape)
-        plan = ops.sparse_plan(ids)
+            ids = self.home.lookup(ids, insert=True, skip_pad=skip_negative).view(ids.shape)
+        plan = ops.sparse_plan(ids, skip_negative=skip_negative)
         U = plan.U                                                    # host sync #1
         if U > C:
             raise RuntimeError(f"batch has {U} unique ids but the device cache holds {C} rows")

@@ -116,12 +116,13 @@ def unique(ids):
 class SparsePlan(Dedup):
     """Dedup + inverted index of one step's ids: what the optimizer-side RowTensor dedup needs."""
 
-    def __init__(self, d, sorted_pos, sorted_seg, seg_offsets):
+    def __init__(self, d, sorted_pos, sorted_seg, seg_offsets, n_valid_dev=None):
         super().__init__(d.ids, d.uniq_buf, d.inv, d.n_uniq_dev)
         self._U = d._U
         self.sorted_pos = sorted_pos
         self.sorted_seg = sorted_seg
         self.seg_offsets = seg_offsets
+        self.n_valid_dev = n_valid_dev      # device word: entries of the index proper (sparse_plan(skip_negative=True)); None: all n
 
 
 def group_by_inverse(d):
@@ -137,8 +138,10 @@ def group_by_inverse(d):
     return SparsePlan(d, sorted_pos, sorted_seg, seg_offsets)
 
 
-def sparse_plan(ids):
-    """Unique + inverted index of a step's ids in one library call (mrec_sparse_plan_*)."""
+def sparse_plan(ids, skip_negative=False):
+    """Unique + inverted index of a step's ids in one library call (mrec_sparse_plan_*).  skip_negative: negative ids are
+    padding (the unused slots of a shard's fixed-capacity request message) -- no group, no entry of the index proper, whose
+    length then lives in plan.n_valid_dev."""
     _need_cuda(ids)
     sfx = _suffix(ids)
     flat = ids.reshape(-1).contiguous()
@@ -146,10 +149,11 @@ def sparse_plan(ids):
     dev = flat.device
     uniq = torch.empty(max(n, 1), dtype=flat.dtype, device=dev)
     inv = torch.empty(max(n, 1), dtype=torch.int32, device=dev)[:n]
-    n_uniq = torch.empty(1, dtype=torch.int64, device=dev)
+    n_uniq2 = torch.empty(2, dtype=torch.int64, device=dev)          # [U, entries of the index proper]
+    n_uniq = n_uniq2[:1]
     sorted_pos = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     sorted_seg = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    seg_offsets = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    seg_offsets = torch.empty(n + 2, dtype=torch.int32, device=dev)
     nb = _lib.query_bytes("mrec_sparse_plan_workspace_bytes", n)
     # a workspace of its own per problem size: only plans of this n ever write it, and each of them hands the scratch table
     # and the scan's look-back words back clean -- so every call after the first skips the memsets (MREC_PLAN_WS_PRIMED)
@@ -157,12 +161,12 @@ def sparse_plan(ids):
     key = (ws.data_ptr(), n, sfx)
     primed = _PLAN_PRIMED.pop(key, False)          # (dropped while the call is in flight: an exception leaves it unprimed)
     _lib.call(f"mrec_sparse_plan_ex_{sfx}", _ptr(flat), n, _ptr(uniq), _ptr(inv), _ptr(n_uniq), _ptr(sorted_pos),
-              _ptr(sorted_seg), _ptr(seg_offsets), _ptr(ws), ws.numel(), 1 if primed else 0, _stream())
+              _ptr(sorted_seg), _ptr(seg_offsets), _ptr(ws), ws.numel(), (1 if primed else 0) | (2 if skip_negative else 0), _stream())
     # a call issued under HIP-graph capture has not RUN: it primes nothing (it leaves a primed workspace primed -- every
     # replay of the captured chain hands the workspace back clean, as an eager call does)
     if primed or not torch.cuda.is_current_stream_capturing():
         _PLAN_PRIMED[key] = True
-    return SparsePlan(Dedup(flat, uniq, inv, n_uniq), sorted_pos, sorted_seg, seg_offsets)
+    return SparsePlan(Dedup(flat, uniq, inv, n_uniq), sorted_pos, sorted_seg, seg_offsets, n_uniq2[1:] if skip_negative else None)
 
 
 def gather_rows(table, ids, row_scale=None, out=None, out_dtype=torch.float32):
@@ -357,7 +361,8 @@ def sparse_lazy_adam_wide_(p, m, v, plan, g, row_scale, gw, F, wide_col, lr=3.5e
     _lib.call("mrec_sparse_lazy_adam_wide", _ptr(p), _ptr(m), _ptr(v), V, ld, D, _ptr(plan.uniq_buf), plan.uniq_buf.element_size(),
               _ptr(plan.sorted_pos), _ptr(plan.sorted_seg), _ptr(plan.seg_offsets), plan.n, _ptr(g2), kind, ldg, _ptr(rs), lr,
               beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _ptr(gw), int(gws), int(F), int(wide_col),
-              ftrl_lr, l1, l2, lr_power, _ptr(ws), ws.numel(), _ptr(step_state.buf) if step_state is not None else None, _stream())
+              ftrl_lr, l1, l2, lr_power, _ptr(ws), ws.numel(), _ptr(step_state.buf) if step_state is not None else None,
+              _ptr(getattr(plan, "n_valid_dev", None)), _stream())
 
 
 def sparse_ftrl_(var, accum, linear, plan, g, row_scale=None, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):
@@ -493,10 +498,12 @@ class KeyIndex:
             arr[q] = cls._MapTable(t.data_ptr(), ld, D, -1.0 if sigma is None else float(sigma), float(fill or 0.0), int(seed))
         return arr
 
-    def lookup(self, keys, insert=True, unique=False, train=False, step=0, permit=1, tables=(), n_dev=None, want_admitted=False):
+    def lookup(self, keys, insert=True, unique=False, train=False, step=0, permit=1, tables=(), n_dev=None, want_admitted=False,
+               skip_pad=False):
         """Rows of `keys` (int32 / int64, any shape, duplicates allowed) in 3 launches (1 when not inserting): probe, rank and
         place the missing keys in order of first appearance, default rows of `tables` = [(tensor [C, D], sigma or None, fill,
-        seed)] + admission.  Returns rows int32 [n] (and the admitted rows when want_admitted)."""
+        seed)] + admission.  Returns rows int32 [n] (and the admitted rows when want_admitted).  skip_pad: key -1 is a padding
+        slot (row -1, never inserted)."""
         _need_cuda(keys)
         flat = keys.reshape(-1).contiguous()
         n = flat.numel()
@@ -506,7 +513,7 @@ class KeyIndex:
         ws = workspace(f"maplookup:{n}", nb, self.device)           # one per problem size, so it stays primed
         key = (ws.data_ptr(), n)
         primed = _MAP_PRIMED.pop(key, False)
-        flags = (1 if insert else 0) | (2 if unique else 0) | (4 if train else 0) | (8 if primed else 0)
+        flags = (1 if insert else 0) | (2 if unique else 0) | (4 if train else 0) | (8 if primed else 0) | (16 if skip_pad else 0)
         tabs = self._tables(tables)
         _lib.call("mrec_map_lookup", self._h, _ptr(flat), flat.element_size(), n, _ptr(n_dev), flags, int(step), int(permit),
                   C.cast(tabs, C.c_void_p), len(tables), _ptr(rows), _ptr(adm), _ptr(ws), ws.numel(), _stream())
@@ -758,6 +765,111 @@ def shard_unpack_iw(pairs):
     wts = torch.empty(max(n, 1), dtype=torch.float32, device=pairs.device)[:n]
     _lib.call("mrec_shard_unpack_iw_i32", _ptr(pairs), n, _ptr(ids), _ptr(wts), _stream())
     return ids, wts
+
+
+# ---- fixed-capacity routing: a sharded step with static message shapes (include/mrec.h) -----------------------------------
+def shard_capacity(n, n_shards, factor=1.25):
+    """Request slots a rank reserves per owner: ceil(factor * n / n_shards) rounded up to a multiple of 64, never more than n
+    (one shard: exactly n)."""
+    if n_shards <= 1:
+        return int(n)
+    c = -(-int(n * factor) // n_shards)
+    return int(min(n, -(-c // 64) * 64))
+
+
+def shard_route_slots(ids, wts, n_shards, cap, hashed=False, overflow=None):
+    """Request message of a step (all owners, `cap` slots each): returns (req, slot_of_pos int32 [n], pos_of_slot int32
+    [n_shards * cap]); req is int32 [n_shards * cap, 2] ({id, weight bits}) for int32 ids, int64-addressable
+    [n_shards * cap, 2] ({key, weight bits | 0}) for int64.  overflow: int64 [1] device counter (sticky)."""
+    _need_cuda(ids, wts, overflow)
+    sfx = _suffix(ids)
+    flat = ids.reshape(-1).contiguous()
+    n = flat.numel()
+    dev = flat.device
+    ns = int(n_shards) * int(cap)
+    req = torch.empty((ns, 2), dtype=flat.dtype, device=dev)
+    slot_of_pos = torch.empty(max(n, 1), dtype=torch.int32, device=dev)[:n]
+    pos_of_slot = torch.empty(max(ns, 1), dtype=torch.int32, device=dev)[:ns]
+    w = None
+    if wts is not None:
+        w = wts.reshape(-1).contiguous()
+        if w.dtype != torch.float32 or w.numel() != n:
+            raise TypeError("wts must be float32 with one value per id")
+    nb = _lib.query_bytes("mrec_shard_route_slots_workspace_bytes", n, n_shards)
+    ws = workspace("route_slots", nb, dev)
+    _lib.call(f"mrec_shard_route_slots_{sfx}", _ptr(flat), _ptr(w), n, int(n_shards), int(cap), int(bool(hashed)), _ptr(req),
+              _ptr(slot_of_pos), _ptr(pos_of_slot), _ptr(overflow), _ptr(ws), ws.numel(), _stream())
+    return req, slot_of_pos, pos_of_slot
+
+
+def shard_unpack_req(req):
+    """(ids [n_slots] of req's dtype, wts float32 [n_slots]) of a received request message."""
+    _need_cuda(req)
+    ns = req.shape[0]
+    ids = torch.empty(max(ns, 1), dtype=req.dtype, device=req.device)[:ns]
+    wts = torch.empty(max(ns, 1), dtype=torch.float32, device=req.device)[:ns]
+    _lib.call("mrec_shard_unpack_req", _ptr(req), req.element_size(), ns, _ptr(ids), _ptr(wts), _stream())
+    return ids, wts
+
+
+def shard_msg_words(D, act_dtype):
+    """(Dw, W): words of a looked-up row / of a message row [row | wide value, 0 | pad] for rows of act_dtype."""
+    if act_dtype == torch.float32:
+        Dw = D
+    else:
+        if D % 2:
+            raise ValueError("16-bit message rows need an even D")
+        Dw = D // 2
+    if Dw % 4:
+        raise ValueError("message rows need D % 4 == 0 (fp32) / D % 8 == 0 (16-bit)")
+    return Dw, Dw + 4
+
+
+def gather_rows_req(table, rows, rows_stride, wts, wts_stride, n_slots, wide_col, act_dtype, out=None):
+    """The owner's answer to a request message: float32 [n_slots, W] rows [looked-up row (act_dtype) | w * weight, 0 | pad] in
+    one pass over the fused rows; `rows` / `wts` are read with the given element strides (straight out of the request
+    entries); slots whose row is outside the table (padding: -1) are left alone."""
+    _need_cuda(table, rows, wts)
+    V, D, ld = _table(table)
+    Dw, W = shard_msg_words(D, act_dtype)
+    msg = out if out is not None else torch.empty((max(n_slots, 1), W), dtype=torch.float32, device=table.device)[:n_slots]
+    if msg.dtype != torch.float32 or tuple(msg.shape) != (n_slots, W) or not msg.is_contiguous():
+        raise TypeError("gather_rows_req: out must be a contiguous float32 [n_slots, W] tensor")
+    kind = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[act_dtype]
+    ldo = W if kind == 0 else 2 * W
+    _lib.call("mrec_gather_rows_wide_ex", _ptr(table), V, ld, D, _ptr(rows), rows.element_size(), int(rows_stride), n_slots, _ptr(wts),
+              int(wts_stride), _ptr(msg), kind, ldo, int(wide_col), C.c_void_p(msg.data_ptr() + 4 * Dw), W, None, 0, 1, _stream())
+    return msg
+
+
+def shard_unroute_slots(back, slot_of_pos, D, act_dtype, out=None):
+    """The returned message in position order: (emb [n, D] act_dtype, wprod float32 [n, 2])."""
+    _need_cuda(back, slot_of_pos, out)
+    Dw, W = shard_msg_words(D, act_dtype)
+    if back.dtype != torch.float32 or back.dim() != 2 or back.shape[1] != W or not back.is_contiguous():
+        raise TypeError("shard_unroute_slots: back must be the contiguous float32 [n_slots, W] message")
+    n = slot_of_pos.numel()
+    if out is None:
+        out = torch.empty((max(n, 1), D), dtype=act_dtype, device=back.device)[:n]
+    elif out.dtype != act_dtype or out.numel() != n * D or not out.is_contiguous():
+        raise TypeError("shard_unroute_slots: out must be a contiguous [n, D] tensor of the row dtype")
+    wprod = torch.empty((max(n, 1), 2), dtype=torch.float32, device=back.device)[:n]
+    _lib.call("mrec_shard_unroute_slots", _ptr(back), W, _ptr(slot_of_pos), n, Dw, _ptr(out), _ptr(wprod), _stream())
+    return out.view(n, D), wprod
+
+
+def shard_route_grads(g, dlogit, F, pos_of_slot):
+    """The gradient message float32 [n_slots, W]: [row gradient of the slot's position | dlogit of its sample | pad]."""
+    _need_cuda(g, dlogit, pos_of_slot)
+    n, D = g.shape
+    Dw, W = shard_msg_words(D, g.dtype)
+    if g.stride(1) != 1 or dlogit.dtype != torch.float32 or not dlogit.is_contiguous() or dlogit.numel() * F != n:
+        raise TypeError("shard_route_grads: g [n, D] with unit column stride, dlogit float32 [n / F]")
+    ldg = g.stride(0) * g.element_size() // 4 if n > 1 else Dw
+    ns = pos_of_slot.numel()
+    msg = torch.empty((max(ns, 1), W), dtype=torch.float32, device=g.device)[:ns]
+    _lib.call("mrec_shard_route_grads", _ptr(g), ldg, _ptr(dlogit), int(F), _ptr(pos_of_slot), ns, Dw, _ptr(msg), W, _stream())
+    return msg
 
 
 # ---- measurement hook ------------------------------------------------------------------------

@@ -37,6 +37,7 @@ import torch.nn.functional as F
 from . import ops
 from .wide_deep_ckpt import load_checkpoint, merge_shards, save_checkpoint  # noqa: F401  (re-exported)
 from .wide_deep_mlp import DenseNetMixin, _WideProd
+from .wide_deep_shard import ShardCapacityError, ShardStepMixin  # noqa: F401  (re-exported)
 
 
 @dataclass
@@ -56,27 +57,16 @@ class WideDeepConfig:
     ftrl_initial_accum: float = 1.0
     init_sigma: float = 0.01             # emb_init / weight_bias_init 'normal' [EXT: N(0, 0.01)]
     seed: int = 1000                     # set_seed(1000), train_and_eval_distribute.py:72
-    mlp_dtype: str = "bf16"              # reference casts the MLP to fp16 (use_mixed_precision); bf16 on MI355X
+    mlp_dtype: str = "fp16"              # the reference's own mixed precision (use_mixed_precision: Cast to float16, wide_and_deep.py:119-128,
+                                         # default_config.yaml:28); "bf16" runs the same kernels, "fp32" the library GEMMs
     id_dtype: str = "int32"              # dataset contract, process_data.py:204-206
     # HBM layout: one allocation per table with the optimizer state beside the weights --
-    # deep rows are [p(D) | m(D) | v(D)] (960 B contiguous at D = 80), wide rows [w | accum | linear | pad]
-    # (16 B).  The sparse apply then touches one contiguous run per row instead of three rows 64 GB
-    # apart (fewer DRAM activations and TLB walks per byte: +6-8 % on MI355X); the API still sees
-    # p, m, v, w, ... as separate (strided) [V, D] / [V, 1] tensors.  False = three separate arrays.
+    # deep rows are [p(D) | w accum linear pad | m(D) | v(D)] (1 KB at D = 80): the sparse apply touches one contiguous run per
+    # row instead of three rows 64 GB apart, and the wide record rides the deep row's lines; the API still sees
+    # p, m, v, w, ... as separate (strided) [V, D] / [V, 1] tensors.  False = separate arrays.
     fused_state: bool = True
-    fold_wide: bool = True               # one GPU, fused rows, 16-bit MLP: the wide lookup rides the deep gather and the wide FTRL
+    fold_wide: bool = True               # fused rows, 16-bit MLP: the wide lookup rides the deep gather and the wide FTRL
                                          # the deep LazyAdam apply (one row visit each); False keeps the separate wide kernels
-    overlap_plan: bool = True            # dedup + inverted index (and the wide branch) on a side HIP stream, under the MLP
-    overlap_wide_apply: bool = True  # wide-table FTRL on the side stream as soon as the head's backward has produced its gradient:
-                                     # a latency-bound kernel hidden under the backward GEMMs (one GPU)
-    late_wide: object = None       # the wide branch (one GPU: wide_sum; shards: wide-row exchange + unroute + sum) runs on the side
-                                   # stream while the hidden-layer GEMMs run; the main stream joins it right before the output head.
-                                   # None = on when sharded (it hides a collective) and inside the one-GPU whole-front graph
-    early_route: bool = False      # shards: bucket the ids and run the request exchange (sizes, ids, weights) on the side stream
-                                   # WITHOUT waiting for the previous step's tail on the main stream -- it hides three small
-                                   # collectives, the routing kernels and the bucket-size host sync under the previous step's
-                                   # applies.  Requires ids / wts to be complete in HBM when train_step is called (bench.py: yes)
-    early_wide_grad: bool = True   # shards: the wide branch's row-gradient exchange starts at the head's backward, under the backward GEMMs
     sparse: bool = True              # False: the reference's DEFAULT mode (default_config.yaml:36, the CPU-runnable configs[0]): the
                                      # embedding gradients are dense [V, D] tensors, nn.Adam / nn.FTRL visit every row every step
                                      # and the deep loss carries l2_coef * sum(E^2) / 2 (wide_and_deep.py:337-339,356-360,434-445)
@@ -88,15 +78,15 @@ class WideDeepConfig:
                                      # wide_and_deep.py:271-274): rows are created on first sight with their default values
     hash_capacity: int = 1 << 22     # rows reserved in HBM for each hash table (dynamic_embedding)
     host_cache_rows: int = 0         # > 0: both tables live in pinned host DRAM behind a device cache of this many rows (the
-                                     # reference's vocab_cache_size, wide_and_deep.py:215-265); one GPU
-    graph_front: bool = True       # one GPU: lookups + plan + MLP + wide FTRL replayed as ONE graph (needs graph_mlp)
-    graph_step: bool = True        # one GPU, folded wide branch: the sparse apply and the dense optimizers join that graph too (the
-                                   # Adam bias-correction powers live in device memory and advance by a kernel: ops.StepState)
-    graph_mlp: bool = True         # replay the MLP forward+backward as captured HIP graphs (one host launch, not ~25)
-    dw_slabs: object = None        # {hidden layer: batch slabs of its weight gradient} instead of the library's proposal (tuning sweeps)
+                                     # reference's vocab_cache_size, wide_and_deep.py:215-265)
+    shard_capacity_factor: float = 1.25   # row shards: request slots a rank reserves per owner = ceil(factor * ids / ranks) -- every
+                                          # message of a sharded step has a static shape (mindrec_amd/wide_deep_shard.py)
+    graphs: str = "step"           # what replays as HIP graphs: "step" the whole step (sinks of steps: train_steps), "front" everything in
+                                   # front of the optimizers, "mlp" the dense net only, "none" kernel by kernel
     fused_tail: bool = True        # the last two hidden layers, the output head and their input-gradient bprops as one launch
 
 
+_GRAPH_LEVEL = {"none": 0, "mlp": 1, "front": 2, "step": 3}
 _TUNED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "tunableop_gfx950.csv")
 
 
@@ -136,6 +126,11 @@ class _DirectComm:
     def __init__(self, group=None):
         self.group = group
 
+    @property
+    def capturable(self):
+        """RCCL collectives on device tensors can be captured into a HIP graph (tools/probes/rccl_graph_probe.py); gloo cannot."""
+        return dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+
     def all_to_all(self, out, inp, out_splits=None, in_splits=None):
         dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
@@ -148,31 +143,34 @@ class _DirectComm:
         return None
 
 
-class WideDeepEngine(DenseNetMixin):
+class WideDeepEngine(DenseNetMixin, ShardStepMixin):
     """State + one training step.  rank/world describe the row sharding; world == 1 is one GPU."""
+    _kernels = ops               # the op set (tests/ subclass the engine with a CPU stand-in to run the multi-rank host logic under gloo)
+    _allow_cpu = False           # the product has no CPU path
 
-    def __init__(self, cfg: WideDeepConfig, device, rank=0, world=1, group=None, kernels=None, tuned_gemms=True, comm=None,
-                 shard_protocol=False):
-        """kernels: module providing the op set of mindrec_amd.ops.  The product always uses the HIP
-        one (default); tests/ inject a CPU stand-in to exercise the multi-rank host logic under gloo.
-        comm: collectives provider (default: torch.distributed as is, see _DirectComm).
+    def __init__(self, cfg: WideDeepConfig, device, rank=0, world=1, group=None, tuned_gemms=True, comm=None, shard_protocol=False):
+        """comm: collectives provider (default: torch.distributed as is, see _DirectComm).
         shard_protocol: run the row-shard protocol (routing kernels + collectives) even when world == 1 -- every
         collective then talks to itself, which executes the RCCL code path on a single GPU."""
         self.cfg, self.device, self.rank, self.world, self.group = cfg, torch.device(device), rank, world, group
         self._sharded = bool(world > 1 or shard_protocol)
         self._fold_wide = False       # set below: one GPU, fused rows, 16-bit MLP -> the wide branch rides the deep kernels
-        self.k = kernels if kernels is not None else ops
+        self.k = self._kernels
+        kernels = None if self.k is ops else self.k
         self.comm = comm if comm is not None else _DirectComm(group)
         self._gpu = self.device.type == "cuda"
-        if kernels is None and not self._gpu:
+        if not self._gpu and not self._allow_cpu:
             raise RuntimeError("WideDeepEngine runs on an MI355X (no CPU fallback)")
+        if cfg.graphs not in _GRAPH_LEVEL:
+            raise ValueError(f"graphs must be one of {sorted(_GRAPH_LEVEL)}")
+        self._graph_level = _GRAPH_LEVEL[cfg.graphs]      # lowered when a capture is refused
         V, D = cfg.vocab_size, cfg.emb_dim
         self.local_rows = (V - rank + world - 1) // world          # rows r with r*world + rank < V
         self.index = None
         self.hb = None
         if cfg.host_cache_rows > 0:
             if kernels is not None:
-                raise ValueError("host_cache_rows needs the HIP kernels (no CPU stand-in)")
+                raise ValueError("host_cache_rows needs the HIP kernels")
             self.local_rows = int(cfg.host_cache_rows)
         if cfg.dynamic_embedding:
             # HashEmbeddingLookup x2 with all defaults (wide_and_deep.py:271-274; embedding.py:88-93): a device
@@ -180,7 +178,7 @@ class WideDeepEngine(DenseNetMixin):
             # every kernel downstream of the index probe is the one the dense-table mode uses.  Row-sharded: the raw keys
             # travel to owner = hash(key) mod n, whose own index translates them (BASELINE configs[4]).
             if kernels is not None:
-                raise ValueError("dynamic_embedding needs the device key index (no CPU stand-in)")
+                raise ValueError("dynamic_embedding needs the device key index")
             if cfg.host_cache_rows == 0:
                 self.local_rows = int(cfg.hash_capacity)
                 self.index = ops.KeyIndex(self.local_rows, self.device)
@@ -298,14 +296,15 @@ class WideDeepEngine(DenseNetMixin):
         self._refresh_tail()
         self._hashed = bool(cfg.dynamic_embedding)
         self._fused_rows = bool(cfg.fused_state and cfg.sparse and cfg.host_cache_rows == 0 and self._gpu)   # [p | w ... | m | v] rows
-        self._pack_msgs = bool(self._gpu and kernels is None and D % 2 == 0)     # shards: merged request / answer / gradient messages
-        self._recv_plan = None        # shards with a host-backed table: the plan of the received keys (made by the cache tier)
+        if self._sharded:
+            self._shard_init()
         self.beta1, self.beta2 = np.float32(0.9), np.float32(0.999)
         self.beta1_power, self.beta2_power = np.float32(1.0), np.float32(1.0)
         self.step_count = 0
         self.timers = None            # optional dict name -> list[(start_event, stop_event)]
+        # the step's Unique + inverted index runs on a side stream, under the MLP
         # (default priority: a high-priority side stream was measured at 1.52 ms/step instead of 0.88)
-        self._side = torch.cuda.Stream(device=self.device) if (self._gpu and cfg.overlap_plan) else None
+        self._side = torch.cuda.Stream(device=self.device) if self._gpu else None
         self._mlp_graph = None        # dict: captured MLP step + its static input / output tensors
         self._dw = {}                 # hidden layer -> fp32 batch slabs [S, in, out] of its weight gradient (persistent:
                                       # graph replays and eager steps write the same buffers, the dense Adam reads them)
@@ -349,133 +348,42 @@ class WideDeepEngine(DenseNetMixin):
 
     # ---- forward (eval path: PredictWithSigmoid, wide_and_deep.py:495-518) ---------------------
     def lookup(self, ids, wts, defer_wide=False):
-        """Returns (deep_in [B, F*D] already mask-multiplied, wide_out [B] incl. bias) and the
-        routing state needed by the backward (None on one GPU).  defer_wide=True: wide_out is returned as a
-        function to call (on whatever stream should do the work) instead of a tensor."""
+        """One GPU: returns (deep_in [B, F*D] already mask-multiplied, wide_out [B] incl. bias -- or, with the wide branch folded
+        into the deep table's kernels, its per-field products for the output head to sum --, None).  defer_wide=True: wide_out is
+        returned as a function to call (on whatever stream should do the work) instead of a tensor."""
         cfg = self.cfg
         B, Fd = ids.shape
-        if not self._sharded:
-            ev = self._tick("gather_deep")
-            if self._fold_wide and torch.is_grad_enabled():
-                # both lookups in one pass over the fused rows; the per-sample sum of the wide products is taken by the head
-                d0 = self._drop(0, B)                  # Dropout on the first layer's input rides the lookup (train_step only)
-                self._emb_dropped = d0 is not None
-                emb, wprod = self.k.gather_rows_wide(self.deep, ids, wts, cfg.emb_dim, out=self._emb_out(B * Fd, cfg.emb_dim, self._amp), drop=d0,
-                                                     out_dtype=self._amp)
-                self._tock(ev)
-                return emb.view(B, Fd * cfg.emb_dim), _WideProd(wprod), None
-            if self._mfma and torch.is_grad_enabled():
-                emb = self.k.gather_rows(self.deep, ids, wts, out=self._emb_out(B * Fd, cfg.emb_dim, self._amp),
-                                         out_dtype=self._amp).view(B, Fd * cfg.emb_dim)
-            else:
-                emb = self.k.gather_rows(self.deep, ids, wts).view(B, Fd * cfg.emb_dim)
-            self._tock(ev)
-            if defer_wide:
-                return emb, (lambda: self.k.wide_sum(self.wide, ids, wts, self.wide_b)), None
-            ev = self._tick("wide_sum")
-            wide = self.k.wide_sum(self.wide, ids, wts, self.wide_b)
-            self._tock(ev)
-            return emb, wide, None
-        # --- row-sharded: bucket by owner, exchange ids, gather locally, exchange rows back
-        ev = self._tick("route")
-        n = ids.numel()
-        D = cfg.emb_dim
-        wire16 = self._mfma and torch.is_grad_enabled() and D % 2 == 0
-        early = self._side is not None and cfg.early_route and torch.is_grad_enabled()
-        main = torch.cuda.current_stream() if self._gpu else None
-        with (torch.cuda.stream(self._side) if early else contextlib.nullcontext()):
-            # early: issued on the side stream, so neither the routing kernels, nor the host sync for the bucket
-            # sizes, nor the collectives (RCCL orders them after the *current* stream) wait for the main stream,
-            # where the previous step's sparse applies may still be running.
-            send_local, perm, counts = (self.k.shard_route(ids, self.world, hashed=True) if self._hashed
-                                        else self.k.shard_route(ids, self.world))
-            send_counts = counts.tolist()                                    # host sync: n_shards ints
-            recv_counts_t = torch.empty_like(counts)
-            self.comm.all_to_all(recv_counts_t, counts)
-            recv_counts = recv_counts_t.tolist()
-            n_recv = int(sum(recv_counts))
-            pack = self._pack_msgs and wire16 and ids.dtype == torch.int32
-            recv_wts = None
-            if pack:
-                # ONE request message: int32 pairs (local id, bits of the position's weight) -- a collective costs 30-40 us of
-                # host and launch latency whatever its size, so the step carries 5 of them instead of 8
-                send_iw = self.k.shard_pack_iw(send_local, wts, perm)
-                recv_iw = torch.empty((n_recv, 2), dtype=torch.int32, device=self.device)
-                self.comm.all_to_all(recv_iw, send_iw, recv_counts, send_counts)
-                recv_local, recv_wts = self.k.shard_unpack_iw(recv_iw)
-            else:
-                recv_local = torch.empty(n_recv, dtype=ids.dtype, device=self.device)
-                self.comm.all_to_all(recv_local, send_local, recv_counts, send_counts)
-                if wire16:
-                    # 16 bits on the wire: the per-position weights travel with the ids so the OWNER applies the mask in
-                    # fp32 and rounds once -- bit-identical to the one-GPU gather -- and rows / row-gradients
-                    # cross xGMI at half the bytes.  A row of D 16-bit values is moved as D/2 fp32 words (pure permutation).
-                    send_w = self.k.shard_route_rows(wts.reshape(n, 1), perm, None)
-                    recv_wts = torch.empty((n_recv, 1), dtype=torch.float32, device=self.device)
-                    self.comm.all_to_all(recv_wts, send_w, recv_counts, send_counts)
-                    recv_wts = recv_wts.view(-1)
-        if early:
-            main.wait_stream(self._side)
-            for t in (send_local, perm, recv_local, recv_wts):
-                if t is not None:
-                    t.record_stream(main)
-        if self.index is not None:
-            # hash tables: what arrived are raw keys; this owner's index gives them rows (new keys: the next rows, default
-            # values keyed by the key) -- one chain of three launches, duplicates welcome
-            recv_local = self.index.lookup(recv_local, insert=True, tables=self._map_tables())
-        elif self.hb is not None:
-            self._recv_plan, recv_local = self.hb.prepare(recv_local)          # rows of the device cache
-        self._tock(ev)
         ev = self._tick("gather_deep")
-        packed = bool(self._pack_msgs and wire16 and self._fused_rows)
-        W = D // 2 + 4 - (D // 2) % 4 if packed else 0          # words per answer row: D/2 (16-bit row) + (product, 0) + pad
-        wrows = None
-        if packed:
-            # ONE answer message per position: [D 16-bit values | wide weight * mask, 0 | pad], written by one pass over the
-            # fused rows (the wide word sits right behind the deep columns)
-            rows = self.k.gather_rows_wide(self.deep, recv_local, recv_wts, D, out_dtype=self._amp, packed_words=W)
-        elif wire16:
-            rows = self.k.gather_rows(self.deep, recv_local, recv_wts, out_dtype=self._amp)          # [n_recv, D] 16-bit
-            wrows = self.k.gather_rows(self.wide, recv_local, recv_wts)                               # [n_recv, 1], masked
+        if self._fold_wide and torch.is_grad_enabled():
+            # both lookups in one pass over the fused rows; the per-sample sum of the wide products is taken by the head
+            d0 = self._drop(0, B)                  # Dropout on the first layer's input rides the lookup (train_step only)
+            self._emb_dropped = d0 is not None
+            emb, wprod = self.k.gather_rows_wide(self.deep, ids, wts, cfg.emb_dim, out=self._emb_out(B * Fd, cfg.emb_dim, self._amp), drop=d0,
+                                                 out_dtype=self._amp)
+            self._tock(ev)
+            return emb.view(B, Fd * cfg.emb_dim), _WideProd(wprod), None
+        if self._mfma and torch.is_grad_enabled():
+            emb = self.k.gather_rows(self.deep, ids, wts, out=self._emb_out(B * Fd, cfg.emb_dim, self._amp),
+                                     out_dtype=self._amp).view(B, Fd * cfg.emb_dim)
         else:
-            rows = self.k.gather_rows(self.deep, recv_local)                # [n_recv, D]
-            wrows = self.k.gather_rows(self.wide, recv_local)               # [n_recv, 1]
-        self._tock(ev)
-        ev = self._tick("a2a_rows")
-        back = torch.empty((n, W) if packed else (n, D), dtype=rows.dtype, device=self.device)
-        self.comm.all_to_all(back, rows, send_counts, recv_counts)
-
-        def wide_branch():
-            # wide values back from their owners, un-permuted, summed over the fields (+ bias)
-            if packed:
-                wv = self.k.shard_unroute(back[:, D // 2:], perm, None, cols=1).view(B, Fd)
-            else:
-                wback = torch.empty((n, 1), dtype=torch.float32, device=self.device)
-                self.comm.all_to_all(wback, wrows, send_counts, recv_counts)
-                wv = self.k.shard_unroute(wback, perm, None if wire16 else wts.reshape(-1)).view(B, Fd)
-            return wv.sum(dim=1) + self.wide_b
-
-        wide = wide_branch if defer_wide else wide_branch()
-        self._tock(ev)
-        ev = self._tick("unroute")
-        if wire16:
-            eo = self._emb_out(n, D, self._amp)            # static graph input, when the MLP graph exists
-            if eo is not None:
-                eo = eo.view(torch.float32)
-            src = back if packed else back.view(torch.float32)
-            emb = self.k.shard_unroute(src, perm, None, out=eo, cols=D // 2).view(self._amp).view(B, Fd * D)
-        else:
-            emb = self.k.shard_unroute(back, perm, wts.reshape(-1)).view(B, Fd * D)
+            emb = self.k.gather_rows(self.deep, ids, wts).view(B, Fd * cfg.emb_dim)
         self._tock(ev)
         if defer_wide:
-            (wrows if wrows is not None else back).record_stream(self._side)
-        return emb, wide, (perm, send_counts, recv_counts, recv_local, recv_wts)
+            return emb, (lambda: self.k.wide_sum(self.wide, ids, wts, self.wide_b)), None
+        ev = self._tick("wide_sum")
+        wide = self.k.wide_sum(self.wide, ids, wts, self.wide_b)
+        self._tock(ev)
+        return emb, wide, None
 
     def predict(self, ids, wts):
         with torch.no_grad():
-            if (self.index is not None or self.hb is not None) and not self._sharded:
-                ids, _ = self._translate_keys(ids)      # MapTensorGet inserts default rows in eval too (embedding.py:193)
-            emb, wide, _ = self.lookup(ids, wts)
+            if self._sharded:
+                emb, wprod, _ = self._shard_lookup(ids, wts, want_plan=False)       # (a collective: every rank calls predict)
+                wide = wprod[..., 0].sum(dim=1) + self.wide_b
+            else:
+                if self.index is not None or self.hb is not None:
+                    ids, _ = self._translate_keys(ids)      # MapTensorGet inserts default rows in eval too (embedding.py:193)
+                emb, wide, _ = self.lookup(ids, wts)
             logit = wide.view(-1, 1) + self.mlp(emb)
         return logit, torch.sigmoid(logit)
 
@@ -522,20 +430,20 @@ class WideDeepEngine(DenseNetMixin):
         """Everything of a step in front of the sparse applies: lookups, the step's Unique + inverted index (side
         stream), the MLP forward/backward with the wide branch's work hooked in.  Returns
         (loss, g_emb, g_wide, plan_early, wide_done, route, early_gw, fused); the side stream is joined on return.
-        capturing=True: called under HIP-graph capture (one GPU) -- the MLP is issued kernel by kernel."""
+        capturing=True: called under HIP-graph capture -- the MLP is issued kernel by kernel."""
+        if self._sharded:
+            return self._front_sharded(ids, wts, label, capturing)
         cfg = self.cfg
         B, Fd = ids.shape
-        D = cfg.emb_dim
         inv_sens = 1.0 / cfg.sens
-        # the wide branch on the side stream: on when sharded (hides a collective) and inside the whole-front graph (no
-        # graph cut to pay for there); off for the one-GPU MLP-graph path, where it costs an extra graph boundary
-        late_cfg = cfg.late_wide if cfg.late_wide is not None else (self._sharded or capturing)
-        late = bool(self._side is not None and late_cfg and self._mfma and not self._fold_wide)
+        # the wide branch on the side stream inside the whole-front graph (no graph cut to pay for there); not for the MLP-graph
+        # path, where it costs an extra graph boundary
+        late = bool(self._side is not None and capturing and self._mfma and not self._fold_wide)
         plan_early, fork_ev = None, None
-        if (self.index is not None or self.hb is not None) and not self._sharded:
+        if self.index is not None or self.hb is not None:
             ids, plan_early = self._translate_keys(ids)        # from here on `ids` are table row numbers
-        elif self._side is not None and not self._sharded and not late:
-            # one GPU: the plan needs nothing but the ids -- start it on the side stream BEFORE the gathers are
+        elif self._side is not None and not late:
+            # the plan needs nothing but the ids -- start it on the side stream BEFORE the gathers are
             # queued, so that it runs beside them (HBM-bound) and eats less into the first GEMM
             main = torch.cuda.current_stream()
             if capturing:
@@ -557,20 +465,15 @@ class WideDeepEngine(DenseNetMixin):
             # (forking it behind the output head instead -- beside the backward GEMMs -- was measured: 0.786 vs 0.764 ms;
             # forking it behind the gather -- which then runs alone -- 0.7576 vs 0.7591 ms: the plan's kernels and whatever
             # they run beside stretch each other by about the same amount wherever the plan sits (behind the first GEMM: 0.774);
-            # the chain cut in two -- the
-            # insert kernel here, the rest behind the first GEMM through a second event -- 0.853 ms: another cross-branch
-            # dependency, and the graph runtime serialises more than the dependencies ask for)
+            # the chain cut in two -- the insert kernel here, the rest behind the first GEMM through a second event -- 0.853 ms:
+            # another cross-branch dependency, and the graph runtime serialises more than the dependencies ask for)
             self._side.wait_event(fork_ev)
             with torch.cuda.stream(self._side):
                 plan_early = self.k.sparse_plan(ids)
-        if route is not None and self.hb is not None:
-            plan_early = self._recv_plan       # the cache tier planned the received keys while making them resident
-        if (self._side is not None and plan_early is None and fork_ev is None
-                and ((self.index is None and self.hb is None) or route is not None)):
+        if self._side is not None and plan_early is None:
             # Side stream, in this order: (1) the wide branch, which the main stream joins only right before the
             # output head -- it runs while the hidden-layer GEMMs do; (2) the step's Unique + inverted index, which
-            # needs only the ids (on a shard: the ids received from the other ranks) and is joined before the sparse
-            # applies: its dozen small latency-bound kernels hide under the MLP.
+            # needs only the ids and is joined before the sparse applies: its dozen small latency-bound kernels hide under the MLP.
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)          # the gathers are queued on main: the wide branch starts behind them
             with torch.cuda.stream(self._side):
@@ -582,7 +485,7 @@ class WideDeepEngine(DenseNetMixin):
                         torch.cuda.current_stream().wait_event(ev_wide)
                         self._rs(wide_t, torch.cuda.current_stream())
                         return wide_t
-                plan_early = self.k.sparse_plan(ids if route is None else route[3])
+                plan_early = self.k.sparse_plan(ids)
             for t in (plan_early.uniq_buf, plan_early.inv, plan_early.n_uniq_dev, plan_early.sorted_pos,
                       plan_early.sorted_seg, plan_early.seg_offsets):
                 self._rs(t, main)
@@ -592,9 +495,9 @@ class WideDeepEngine(DenseNetMixin):
         wide_done = False
         if fused:
             after_head = None
-            if self._fold_wide and route is None:
+            if self._fold_wide:
                 wide_done = True             # the wide table's FTRL rides the deep table's apply (train_step)
-            elif plan_early is not None and route is None and cfg.overlap_wide_apply and cfg.sparse:
+            elif plan_early is not None and self._side is not None and cfg.sparse:
                 def after_head(gw_b):
                     # wide FTRL beside the backward GEMMs: needs only the plan (already on the side stream, in order)
                     # and the head's dlogit.  The Mul bprop of wide_mul (:304) is applied as row_scale.
@@ -606,34 +509,10 @@ class WideDeepEngine(DenseNetMixin):
                         self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan_early, gw, wts, lr=cfg.ftrl_lr,
                                             l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=inv_sens)
                 wide_done = True
-            early_gw = None
-            if (after_head is None and route is not None and self._side is not None and cfg.early_wide_grad
-                    and not (self._pack_msgs and route[4] is not None)):       # (packed messages: it rides the row gradients)
-                holder = {}
-
-                def after_head(gw_b):
-                    # shards: the wide branch's row-gradients need only the head's dlogit -- bucket them and start
-                    # their all-to-all now, on the side stream, while the backward GEMMs run on the main stream
-                    perm_, send_counts_, recv_counts_, recv_local_, recv_wts_ = route
-                    main = torch.cuda.current_stream()
-                    self._side.wait_event(main.record_event())
-                    self._rs(gw_b, self._side)
-                    with torch.cuda.stream(self._side):
-                        if recv_wts_ is not None:
-                            gw = gw_b.view(B, 1).expand(B, Fd).reshape(B * Fd, 1).contiguous()
-                        else:
-                            gw = (gw_b.view(B, 1) * wts).view(B * Fd, 1)
-                        send_gw = self.k.shard_route_rows(gw, perm_, None)
-                        recv_gw = torch.empty((recv_local_.numel(), 1), dtype=torch.float32, device=self.device)
-                        self.comm.all_to_all(recv_gw, send_gw, recv_counts_, send_counts_)
-                    holder["recv_gw"] = recv_gw
-                early_gw = holder
             if capturing:
                 loss, g_emb, g_wide = self._mlp_step_eager(emb, wide, label, after_head=after_head)
             else:
                 loss, g_emb, g_wide = self._mlp_step(emb, wide, label, after_head=after_head)
-            if route is not None and route[4] is None:
-                g_emb = g_emb.float()          # fp32 wire format
         else:
             emb.requires_grad_(True)
             wide.requires_grad_(True)
@@ -642,18 +521,20 @@ class WideDeepEngine(DenseNetMixin):
             loss = F.binary_cross_entropy_with_logits(logit, label)      # SigmoidCrossEntropyWithLogits + ReduceMean
             (loss * cfg.sens).backward()                                  # sens_param seeding, :479-486
             g_emb, g_wide = emb.grad, wide.grad                           # [B, F*D], [B]
-            early_gw = None
         self._tock(ev)
 
         if plan_early is not None and self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)          # the plan (queued long ago) is done
-        return loss, g_emb, g_wide, plan_early, wide_done, route, early_gw, fused
+        return loss, g_emb, g_wide, plan_early, wide_done, route, None, fused
 
     # ---- the whole front of a one-GPU step as ONE HIP graph ------------------------------------------
     def _front_graph_ok(self):
-        return bool(self.cfg.graph_front and self.cfg.graph_mlp and self._gpu and not self._sharded and self._side is not None
+        """The front of the step (and, with device-side step scalars, the whole step) can replay as one graph: one GPU, or a
+        shard whose collectives can be captured (RCCL) and whose whole step has constant arguments."""
+        return bool(self._graph_level >= 2 and self._gpu and self._side is not None
                     and self._mfma and self.step_count > 2 and torch.is_grad_enabled() and self.timers is None
-                    and self.hb is None)
+                    and self.hb is None
+                    and (not self._sharded or (self._graph_level >= 3 and self._shard_fold and getattr(self.comm, "capturable", False))))
 
     def _front_replay(self, ids, wts, label):
         """ids / wts / label are copied into static buffers (3.5 MB) and the captured front is replayed: the deep
@@ -684,7 +565,7 @@ class WideDeepEngine(DenseNetMixin):
         except RuntimeError as e:
             import warnings
             warnings.warn(f"HIP-graph capture of the step front failed, falling back to the MLP graphs: {e}")
-            self.cfg.graph_front = False
+            self._graph_level = min(self._graph_level, 1)
             self._front_graph = None
             return None
 
@@ -714,7 +595,7 @@ class WideDeepEngine(DenseNetMixin):
         except RuntimeError as e:
             import warnings
             warnings.warn(f"HIP-graph capture of the whole step failed, falling back to the front graph: {e}")
-            self.cfg.graph_step = False
+            self._graph_level = min(self._graph_level, 2)
             self._step_graph = None
             return None
 
@@ -796,7 +677,7 @@ class WideDeepEngine(DenseNetMixin):
         caller may keep)."""
         S = len(batches)
         g = self._step_graph
-        if (S > 1 and g is not None and self.cfg.graph_step and self._front_graph_ok() and self._dyn and self._state_step == self.step_count
+        if (S > 1 and g is not None and self._graph_level >= 3 and self._front_graph_ok() and self._dyn and self._state_step == self.step_count
                 and all(b[0].shape == g["ids"].shape and b[0].dtype == g["ids"].dtype for b in batches)):
             key = (S, tuple(g["ids"].shape), g["ids"].dtype)
             sg = self._sink_graphs.get(key)
@@ -850,7 +731,7 @@ class WideDeepEngine(DenseNetMixin):
         B, Fd = ids.shape
         D = cfg.emb_dim
         inv_sens = 1.0 / cfg.sens
-        self._dyn = bool(self._fold_wide and self._mfma and not self._sharded and self._gpu)
+        self._dyn = bool((self._fold_wide or (self._sharded and self._shard_fold)) and self._mfma and self._gpu)
         if self._dyn:
             # device-side step scalars (ops.StepState): brought in line with the host mirrors whenever somebody else moved
             # those (first step, load_checkpoint)
@@ -869,25 +750,27 @@ class WideDeepEngine(DenseNetMixin):
         self.beta2_power = np.float32(self.beta2_power * self.beta2)
         self._state_step = self.step_count
 
-        if self._dyn and cfg.graph_step and self._front_graph_ok():
+        if self._dyn and self._graph_level >= 3 and self._front_graph_ok():
             self.deep_apply_timer = None              # (HIP events cannot be timed from inside a graph; the kernel stamps
             loss = self._step_replay(ids, wts, label)  # its own begin / end in the step state instead)
             if loss is not None:
                 return loss
         front = None
-        if self._front_graph_ok():
+        if self._front_graph_ok() and not self._sharded:
             front = self._front_replay(ids, wts, label)
         if front is None:
             front = self._front(ids, wts, label)
         return self._tail(front, ids, wts)
 
     def _tail(self, front, ids, wts):
-        """The optimizer half of a step: sparse applies, (shards) gradient exchange, dense Adam / FTRL."""
+        """The optimizer half of a step: sparse applies, dense Adam / FTRL (shards: mindrec_amd/wide_deep_shard.py)."""
         cfg = self.cfg
         B, Fd = ids.shape
         D = cfg.emb_dim
         inv_sens = 1.0 / cfg.sens
         loss, g_emb, g_wide, plan_early, wide_done, route, early_gw, fused = front
+        if route is not None:
+            return self._tail_sharded(front, ids, wts)
         if not cfg.sparse:
             return self._tail_dense(front, ids, wts)
         state = None
@@ -901,145 +784,47 @@ class WideDeepEngine(DenseNetMixin):
             gb = self.dense_grad[2 * (len(self.dims) - 2) + 1].view(1)
         else:
             gb = g_wide.sum().view(1)
-        dense_work = None
-
-        if route is None:
-            ev = self._tick("plan")
-            plan = plan_early if plan_early is not None else self.k.sparse_plan(ids)
-            self._tock(ev)
-            # (Running the wide FTRL apply on the side stream beside the deep apply was tried and rejected:
-            # sharing CUs drops the deep kernel from 5.0 to 4.0 TB/s and the step gets 0.11 ms longer.)
-            ev = self._tick("apply_deep")
-            if self.deep_apply_timer is not None:
-                self.deep_apply_timer.arm()
-                self.deep_apply_timer = None
-            if self._fold_wide and fused:
-                # LazyAdam on the deep columns + FTRL on the wide record of the same rows: one visit per touched row
-                self.k.sparse_lazy_adam_wide_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, g_wide, Fd, D,
-                                              lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
-                                              beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
-                                              grad_scale=inv_sens, ftrl_lr=cfg.ftrl_lr, l1=cfg.ftrl_l1, l2=cfg.ftrl_l2,
-                                              step_state=state)
-            else:
-                self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, lr=cfg.adam_lr,
-                                         beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
-                                         beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
-                                         grad_scale=inv_sens)
-            self._tock(ev)
-            if not wide_done:
-                ev = self._tick("apply_wide")
-                gw = g_wide.view(B, 1).expand(B, Fd).reshape(B * Fd, 1)      # Mul bprop of wide_mul (:304): the mask is
-                self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, gw, wts, lr=cfg.ftrl_lr,   # applied as row_scale
-                                    l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=inv_sens)
-                self._tock(ev)
+        ev = self._tick("plan")
+        plan = plan_early if plan_early is not None else self.k.sparse_plan(ids)
+        self._tock(ev)
+        # (Running the wide FTRL apply on the side stream beside the deep apply was tried and rejected:
+        # sharing CUs drops the deep kernel from 5.0 to 4.0 TB/s and the step gets 0.11 ms longer.)
+        ev = self._tick("apply_deep")
+        if self.deep_apply_timer is not None:
+            self.deep_apply_timer.arm()
+            self.deep_apply_timer = None
+        if self._fold_wide and fused:
+            # LazyAdam on the deep columns + FTRL on the wide record of the same rows: one visit per touched row
+            self.k.sparse_lazy_adam_wide_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, g_wide, Fd, D,
+                                          lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
+                                          beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
+                                          grad_scale=inv_sens, ftrl_lr=cfg.ftrl_lr, l1=cfg.ftrl_l1, l2=cfg.ftrl_l2,
+                                          step_state=state)
         else:
-            perm, send_counts, recv_counts, recv_local, recv_wts = route
-            ev = self._tick("a2a_grads")
-            n_recv = recv_local.numel()
-            have_gw = fused and early_gw is not None and "recv_gw" in early_gw
-            packed_g = bool(self._pack_msgs and recv_wts is not None and not have_gw)
-            if packed_g:
-                # ONE gradient message per position: [D 16-bit row-gradient values | the wide branch's gradient | pad]; the
-                # owner's two applies read their parts through row strides
-                Wg = D // 2 + 4 - (D // 2) % 4
-                n = B * Fd
-                send_g = torch.empty((n, Wg), dtype=torch.float32, device=self.device)
-                self.k.shard_route_rows(g_emb.view(n, D).view(torch.float32), perm, None, out=send_g)
-                gw = g_wide.view(B, 1).expand(B, Fd).reshape(n, 1).contiguous()
-                self.k.shard_route_rows(gw, perm, None, out=send_g[:, D // 2:])
-                recv_msg = torch.empty((n_recv, Wg), dtype=torch.float32, device=self.device)
-                self.comm.all_to_all(recv_msg, send_g, recv_counts, send_counts)
-                recv_g = recv_msg.view(self._amp)[:, :D]                  # [n_recv, D] 16-bit, row stride 2 * Wg
-                recv_gw = recv_msg[:, D // 2:D // 2 + 1]                  # [n_recv, 1] fp32, row stride Wg
-                row_scale = recv_wts
-            elif recv_wts is not None:
-                # 16-bit wire: raw 16-bit row-gradients travel (as D/2 fp32 words); the owner multiplies by the
-                # weights it received in the forward, inside the apply kernel, exactly as on one GPU
-                send_g = self.k.shard_route_rows(g_emb.view(B * Fd, D).view(torch.float32), perm, None)
-                recv_g32 = torch.empty((n_recv, D // 2), dtype=torch.float32, device=self.device)
-                self.comm.all_to_all(recv_g32, send_g, recv_counts, send_counts)
-                recv_g = recv_g32.view(self._amp)
-                if not have_gw:
-                    gw = g_wide.view(B, 1).expand(B, Fd).reshape(B * Fd, 1).contiguous()
-                    send_gw = self.k.shard_route_rows(gw, perm, None)
-                row_scale = recv_wts
-            else:
-                wflat = wts.reshape(-1)
-                send_g = self.k.shard_route_rows(g_emb.view(B * Fd, D), perm, wflat)
-                if not have_gw:
-                    gw = (g_wide.view(B, 1) * wts).view(B * Fd, 1)
-                    send_gw = self.k.shard_route_rows(gw, perm, None)
-                recv_g = torch.empty((n_recv, D), dtype=torch.float32, device=self.device)
-                self.comm.all_to_all(recv_g, send_g, recv_counts, send_counts)
-                row_scale = None
-            if packed_g:
-                pass                                   # came inside the row-gradient message
-            elif have_gw:
-                recv_gw = early_gw["recv_gw"]          # exchanged on the side stream during the backward; joined below
-                recv_gw.record_stream(torch.cuda.current_stream())
-            else:
-                recv_gw = torch.empty((n_recv, 1), dtype=torch.float32, device=self.device)
-                self.comm.all_to_all(recv_gw, send_gw, recv_counts, send_counts)
+            self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, lr=cfg.adam_lr,
+                                     beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
+                                     beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
+                                     grad_scale=inv_sens)
+        self._tock(ev)
+        if not wide_done:
+            ev = self._tick("apply_wide")
+            gw = g_wide.view(B, 1).expand(B, Fd).reshape(B * Fd, 1)      # Mul bprop of wide_mul (:304): the mask is
+            self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, gw, wts, lr=cfg.ftrl_lr,   # applied as row_scale
+                                l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=inv_sens)
             self._tock(ev)
-            # Dense gradients (+ the wide bias gradient riding in the same buffer): all-reduce queued behind the
-            # row-gradient exchange and left running while the sparse applies execute -- they do not need it.
-            ev = self._tick("allreduce_dense")
-            if self._side is not None:
-                torch.cuda.current_stream().wait_stream(self._side)
-            if fused:
-                self._sum_dw_slabs()
-            self.wide_b_grad.copy_(gb)                 # rides the same all-reduce, in Wide_b's slot of the dense gradient
-            dense_work = self.comm.all_reduce(self.dense_grad_flat, async_op=True)
-            self._tock(ev)
-            ev = self._tick("plan")
-            plan = plan_early if plan_early is not None else self.k.sparse_plan(recv_local)
-            self._tock(ev)
-            # RowTensor gradients of all ranks are summed at the owner; gradients_mean divides by world
-            scale = inv_sens / self.world
-            ev = self._tick("apply_deep")
-            if self.deep_apply_timer is not None:
-                self.deep_apply_timer.arm()
-                self.deep_apply_timer = None
-            fold_shard = bool(packed_g and self._fused_rows and cfg.fold_wide and D <= 252)
-            if fold_shard:
-                # LazyAdam + the wide record's FTRL in one visit per touched row, as on one GPU; the wide gradient of a
-                # received position is a column of the gradient message (one value per position: F = 1)
-                self.k.sparse_lazy_adam_wide_(self.deep, self.deep_m, self.deep_v, plan, recv_g, row_scale, recv_gw, 1, D,
-                                              lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
-                                              beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
-                                              grad_scale=scale, ftrl_lr=cfg.ftrl_lr, l1=cfg.ftrl_l1, l2=cfg.ftrl_l2)
-            else:
-                self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, recv_g, row_scale, lr=cfg.adam_lr,
-                                         beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
-                                         beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
-                                         grad_scale=scale)
-            self._tock(ev)
-            if not fold_shard:
-                ev = self._tick("apply_wide")
-                self.k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, recv_gw, row_scale, lr=cfg.ftrl_lr,
-                                    l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=scale)
-                self._tock(ev)
-
-        if self._sharded:
-            if dense_work is not None:
-                dense_work.wait()                     # the current stream waits for RCCL's stream; no host block
-            if self.world > 1:
-                self.dense_grad_flat.div_(self.world)  # gradients_mean=True (train_and_eval_distribute.py:137)
         if self._side is not None and not self._dyn:          # (folded one-GPU step: nothing was queued on the side stream since
             torch.cuda.current_stream().wait_stream(self._side)   # the front joined it, and a join costs ~6 us inside a graph)
         ev = self._tick("apply_dense")
         akw = dict(lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
                    beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=inv_sens)
         flat = self.dense_flat.detach()
-        if not self._sharded and not (self._fold_wide and fused):
+        if not (self._fold_wide and fused):
             self.wide_b_grad.copy_(gb)                     # Wide_b's slot of the dense gradient (updated by the Adam below;
                                                            # the folded path's head kernel has already written it)
         if fused:
-            # one GPU: the weight gradients stay fp32 batch slabs and are added up inside the Adam kernel (nobody else
-            # needs the sums); shards: they were summed for the all-reduce above.  Either way the kernel also refreshes
-            # the 16-bit operand shadow.
-            slabs = [] if self._sharded else self._slab_segments()
-            self.k.dense_adam_slabs_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, slabs,
+            # the weight gradients stay fp32 batch slabs and are added up inside the Adam kernel (nobody else needs the sums);
+            # the kernel also refreshes the 16-bit operand shadow
+            self.k.dense_adam_slabs_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, self._slab_segments(),
                                      shadow16=self.dense16_flat, step_state=state, **akw)
             self._refresh_tail()
         else:

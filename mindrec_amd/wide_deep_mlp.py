@@ -91,7 +91,7 @@ class DenseNetMixin:
         t = self._dw.get(i)
         if t is None:
             K, N = self.dims[i], self.dims[i + 1]
-            S = int((self.cfg.dw_slabs or {}).get(i, 0)) or self.k.dense_bwd_weight_slabs(B, K, N)
+            S = self.k.dense_bwd_weight_slabs(B, K, N)
             t = torch.empty((S, K, N), dtype=torch.float32, device=self.device)
             self._dw[i] = t
         return t
@@ -201,7 +201,7 @@ class DenseNetMixin:
         the gather writes the embeddings there directly.  Graphs: hidden-layer forward [| head] | backward.  `wide` may
         be a function: it is called between the first two (the wide branch is computed on the side stream meanwhile);
         after_head runs before the backward graph (the wide branch's gradient exists from there on)."""
-        if not (self.cfg.graph_mlp and self._gpu and self.step_count > 2):
+        if not (self._graph_level >= 1 and self._gpu and self.step_count > 2):
             return self._mlp_step_eager(emb, wide, label, after_head=after_head)
         g = self._mlp_graph
         if (g is None or g["emb"].shape != emb.shape or g["emb"].dtype != emb.dtype or (g["graph_head"] is None) == callable(wide)
@@ -211,7 +211,7 @@ class DenseNetMixin:
             except RuntimeError as e:          # capture refused: stay eager
                 import warnings
                 warnings.warn(f"HIP-graph capture of the MLP step failed, running it eagerly: {e}")
-                self.cfg.graph_mlp = False
+                self._graph_level = 0
                 self._mlp_graph = None
                 return self._mlp_step_eager(emb, wide, label, after_head=after_head)
         if emb.data_ptr() != g["emb"].data_ptr():

@@ -1,0 +1,232 @@
+"""The row-sharded ("hybrid parallel") half of the Wide&Deep step: a mixin of WideDeepEngine (mindrec_amd/wide_deep.py).
+
+Reference: README.md:140-144; models/wide_deep/train_and_eval_distribute.py:135-138 (gradients_mean=True); the reference's own
+mechanism -- replicated ids, masked local Gather of the row slice, AllReduce of the [N, D] partials (wide_and_deep.py:232-249) --
+has static shapes and no host round trip, which is what this protocol keeps while moving 1 / n of those bytes:
+
+  requester                                   owner (= every rank, for its rows: id mod n, or hash(key) mod n)
+  ---------                                   -----
+  route_slots: position -> slot o * cap + j   .
+  all-to-all  [n * cap] {id, weight}   --->   gather: ONE pass over the fused rows, one message row per slot
+              (equal splits: static)          [looked-up row (16-bit / fp32) | wide weight * mask, 0 | pad]
+  unroute_slots: message rows -> the    <---  all-to-all [n * cap, W]
+     MLP input + the wide products            (side branch: Unique + inverted index of the received ids, under the MLP)
+  MLP forward / backward (data parallel)
+  route_grads: [row gradient | dlogit]  --->  all-to-all [n * cap, W] -> ONE apply kernel reads the message in place:
+                                              LazyAdam on the deep columns + FTRL on the wide record of every touched row
+  all-reduce(mean) of the dense gradient, dense Adam
+
+Every rank hands every owner exactly `cap` = ceil(shard_capacity_factor * N / n) slots (unused ones carry id -1: the owner's
+gather skips them, its plan sorts them behind the index proper, its apply never sees them), so every message has a static,
+host-known shape: no bucket sizes cross the host, and with a capturable communicator (RCCL) the whole step -- collectives
+included -- is ONE HIP graph per rank.  A position that finds its bucket full is dropped and counted in a sticky device
+counter (`shard_overflow()`, checked by the caller once per sink: such a step is not a valid step)."""
+import torch
+import torch.nn.functional as F
+
+from .wide_deep_mlp import _WideProd
+
+
+class ShardCapacityError(RuntimeError):
+    """A step's ids did not fit the fixed-capacity request message: raise WideDeepConfig.shard_capacity_factor."""
+
+
+class ShardStepMixin:
+    def _shard_init(self):
+        D = self.cfg.emb_dim
+        self._act = self._amp if self._mfma else torch.float32           # dtype of looked-up rows / row gradients, also on the wire
+        self._shard_fold = bool(self._fused_rows and D <= 252 and D % (4 if self._act == torch.float32 else 8) == 0)
+        self._overflow = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._overflow_seen = 0
+
+    def shard_overflow(self):
+        """Positions dropped so far because an owner's bucket of the request message was full (host sync)."""
+        return int(self._overflow.item())
+
+    def check_shard_overflow(self):
+        """Raises ShardCapacityError if positions were dropped since the last check (one host sync; call once per sink / epoch)."""
+        n = self.shard_overflow()
+        if n > self._overflow_seen:
+            d, self._overflow_seen = n - self._overflow_seen, n
+            raise ShardCapacityError(f"{d} id positions did not fit the request message (capacity factor "
+                                     f"{self.cfg.shard_capacity_factor}): the affected steps are not valid steps")
+
+    # ---- forward half -------------------------------------------------------------------------------------------------
+    def _answer(self, rows, rstride, wts, wstride, ns):
+        """The owner's message [ns, W]: looked-up (masked) deep rows + the wide products of the requested rows."""
+        cfg, k = self.cfg, self.k
+        D, act = cfg.emb_dim, self._act
+        if self._shard_fold:
+            return k.gather_rows_req(self.deep, rows, rstride, wts, wstride, ns, D, act)
+        # separate tables (split state, the cache tier, the CPU stand-in): two gathers, packed here
+        assert rstride == 1 and wstride == 1
+        Dw, W = k.shard_msg_words(D, act)
+        msg = torch.zeros((ns, W), dtype=torch.float32, device=self.device)
+        e = k.gather_rows(self.deep, rows, wts) if act == torch.float32 else k.gather_rows(self.deep, rows, wts, out_dtype=act)
+        msg[:, :Dw] = e.reshape(ns, D) if act == torch.float32 else e.reshape(ns, D).view(torch.float32)
+        msg[:, Dw] = k.gather_rows(self.wide, rows, wts).reshape(ns)
+        return msg
+
+    def _shard_lookup(self, ids, wts, want_plan=True):
+        """Requests out, answers back.  Returns (emb [B, F * D] act dtype, wprod [B, F, 2] fp32, route state)."""
+        cfg, k = self.cfg, self.k
+        B, Fd = ids.shape
+        D, n, act = cfg.emb_dim, ids.numel(), self._act
+        cap = k.shard_capacity(n, self.world, cfg.shard_capacity_factor)
+        ns = self.world * cap
+        ev = self._tick("route")
+        req, slot_of_pos, pos_of_slot = k.shard_route_slots(ids, wts, self.world, cap, hashed=self._hashed, overflow=self._overflow)
+        recv_req = torch.empty_like(req)
+        self.comm.all_to_all(recv_req, req)
+        self._tock(ev)
+        ev = self._tick("gather_deep")
+        plan = recv_wts = rows = None
+        translate = self.index is not None or self.hb is not None
+        if translate:
+            # hash tables / the cache tier: what arrived are raw keys (or rows of a host table); the owner's own index gives them
+            # rows -- new keys: the next rows, default values keyed by the key; padding (-1) stays -1
+            recv_ids, recv_wts = k.shard_unpack_req(recv_req)
+            if self.hb is not None:
+                plan, rows = self.hb.prepare(recv_ids, skip_negative=True)
+            else:
+                rows = self.index.lookup(recv_ids, insert=True, tables=self._map_tables(), skip_pad=True)
+            ans = self._answer(rows, 1, recv_wts, 1, ns)
+        elif self._shard_fold:
+            # ids and weights are read straight out of the received entries ({id, weight}: stride 2 in units of either)
+            if recv_req.dtype == torch.int32:
+                ans = self._answer(recv_req, 2, recv_req.view(torch.float32).view(-1)[1:], 2, ns)
+            else:
+                ans = self._answer(recv_req, 2, recv_req.view(torch.float32).view(-1)[2:], 4, ns)
+        else:
+            rows, recv_wts = k.shard_unpack_req(recv_req)
+            ans = self._answer(rows, 1, recv_wts, 1, ns)
+        fork_ev = None
+        if self._side is not None and want_plan:
+            # the step's Unique + inverted index of the received ids: a dozen small latency-bound kernels, on the side branch
+            # under the MLP.  Marked here, ISSUED behind the answer exchange and the un-permute (under capture the branch whose
+            # first node is created first stays on the launch queue: that must be the critical chain)
+            fork_ev = torch.cuda.Event()
+            fork_ev.record(torch.cuda.current_stream())
+        self._tock(ev)
+        ev = self._tick("a2a_rows")
+        back = torch.empty_like(ans)
+        self.comm.all_to_all(back, ans)
+        self._tock(ev)
+        ev = self._tick("unroute")
+        eo = self._emb_out(n, D, act) if act != torch.float32 else None       # static graph input, when the MLP graph exists
+        emb, wprod = k.shard_unroute_slots(back, slot_of_pos, D, act, out=eo)
+        self._tock(ev)
+        if want_plan:
+            with (torch.cuda.stream(self._side) if fork_ev is not None else _null()):
+                if fork_ev is not None:
+                    self._side.wait_event(fork_ev)
+                if rows is None:
+                    rows, recv_wts = k.shard_unpack_req(recv_req)
+                if plan is None:
+                    plan = k.sparse_plan(rows, skip_negative=True)
+            if fork_ev is not None:
+                main = torch.cuda.current_stream()
+                for t in (rows, recv_wts, recv_req, plan.uniq_buf, plan.inv, plan.n_uniq_dev, plan.sorted_pos, plan.sorted_seg, plan.seg_offsets):
+                    self._rs(t, main)
+                    self._rs(t, self._side)
+        route = {"pos_of_slot": pos_of_slot, "recv_wts": recv_wts, "plan": plan, "ns": ns}
+        return emb.view(B, Fd * D), wprod.view(B, Fd, 2), route
+
+    def _front_sharded(self, ids, wts, label, capturing=False):
+        cfg = self.cfg
+        emb, wprod, route = self._shard_lookup(ids, wts)
+        ev = self._tick("mlp_fwd_bwd")
+        fused = self._mfma
+        if fused:
+            K5 = self.dims[len(self.dims) - 2]
+            if self.k.head_supported(K5):
+                wide = _WideProd(wprod)            # the per-sample sum over the fields (+ Wide_b) is taken inside the output head
+            else:
+                wide = wprod[..., 0].sum(dim=1) + self.wide_b
+            step = self._mlp_step_eager if capturing else self._mlp_step
+            loss, g_emb, g_wide = step(emb, wide, label)
+            route["wide_b_in_head"] = isinstance(wide, _WideProd)
+        else:
+            emb.requires_grad_(True)
+            wide = (wprod[..., 0].sum(dim=1) + self.wide_b).requires_grad_(True)
+            self.dense_grad_flat.zero_()
+            logit = wide.view(-1, 1) + self.mlp(emb)
+            loss = F.binary_cross_entropy_with_logits(logit, label)      # SigmoidCrossEntropyWithLogits + ReduceMean
+            (loss * cfg.sens).backward()                                  # sens_param seeding, wide_and_deep.py:479-486
+            g_emb, g_wide = emb.grad, wide.grad
+            route["wide_b_in_head"] = False
+        self._tock(ev)
+        return loss, g_emb, g_wide, route["plan"], True, route, None, fused
+
+    # ---- optimizer half -----------------------------------------------------------------------------------------------
+    def _tail_sharded(self, front, ids, wts):
+        cfg, k = self.cfg, self.k
+        B, Fd = ids.shape
+        D, n, act = cfg.emb_dim, ids.numel(), self._act
+        loss, g_emb, g_wide, plan, _, route, _, fused = front
+        inv_sens = 1.0 / cfg.sens
+        state = None
+        if self._dyn:
+            state = self._step_state
+            state.advance(cfg.adam_lr, float(self.beta1), float(self.beta2))
+        ev = self._tick("a2a_grads")
+        gmsg = k.shard_route_grads(g_emb.reshape(n, D), g_wide.reshape(B).contiguous(), Fd, route["pos_of_slot"])
+        recv_g = torch.empty_like(gmsg)
+        self.comm.all_to_all(recv_g, gmsg)
+        self._tock(ev)
+        # Dense gradients (+ Wide_b's, an element of the same buffer): all-reduce queued behind the row-gradient exchange and
+        # left running while the sparse apply executes -- it does not need it.
+        ev = self._tick("allreduce_dense")
+        if fused:
+            self._sum_dw_slabs()
+            if not route["wide_b_in_head"]:
+                self.wide_b_grad.copy_(self.dense_grad[2 * (len(self.dims) - 2) + 1].view(1))      # = the output layer's bias gradient
+        else:
+            self.wide_b_grad.copy_(g_wide.sum().view(1))
+        dense_work = self.comm.all_reduce(self.dense_grad_flat, async_op=True)
+        self._tock(ev)
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)           # the plan (queued under the MLP) is done
+        # RowTensor gradients of all ranks are summed at the owner; gradients_mean divides by the number of ranks
+        scale = inv_sens / self.world
+        Dw, _ = k.shard_msg_words(D, act)
+        recv_rows = recv_g[:, :D] if act == torch.float32 else recv_g.view(act)[:, :D]       # [ns, D], read in place
+        recv_gw = recv_g[:, Dw:Dw + 1]                                                         # [ns, 1] fp32: one value per position
+        akw = dict(lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
+                   beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=scale)
+        ev = self._tick("apply_deep")
+        if self.deep_apply_timer is not None:
+            self.deep_apply_timer.arm()
+            self.deep_apply_timer = None
+        if self._shard_fold:
+            # LazyAdam + the wide record's FTRL in one visit per touched row, as on one GPU; the wide gradient of a received
+            # position is a column of the gradient message (one value per position: F = 1)
+            k.sparse_lazy_adam_wide_(self.deep, self.deep_m, self.deep_v, plan, recv_rows, route["recv_wts"], recv_gw, 1, D,
+                                     ftrl_lr=cfg.ftrl_lr, l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, step_state=state, **akw)
+        else:
+            k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, recv_rows, route["recv_wts"], **akw)
+            k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, recv_gw, route["recv_wts"], lr=cfg.ftrl_lr,
+                           l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=scale)
+        self._tock(ev)
+        if dense_work is not None:
+            dense_work.wait()                     # the current stream waits for RCCL's stream; no host block
+        ev = self._tick("apply_dense")
+        flat = self.dense_flat.detach()
+        if fused:
+            # (the weight-gradient slabs were summed for the all-reduce above; the kernel also refreshes the 16-bit operand shadow)
+            k.dense_adam_slabs_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, [], shadow16=self.dense16_flat,
+                                step_state=state, **akw)
+            self._refresh_tail()
+        else:
+            k.dense_adam_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, **akw)
+        self._tock(ev)
+        self.last_plan = plan
+        return loss.detach()
+
+
+class _null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False

@@ -254,6 +254,61 @@ def shard_route(ids, n_shards):
     return send_local, perm, counts
 
 
+# ---- fixed-capacity routing of a sharded step (numpy restatements of include/mrec.h's mrec_shard_route_slots_* etc.;
+# ---- reference semantics: owner = id mod n / hash(key) mod n, hybrid parallel, README.md:140-144) ------------------------
+def shard_owner(ids, n_shards, hashed=False):
+    ids = _i64(ids).ravel()
+    if hashed:
+        return ((_mix64(ids.astype(np.uint64)) >> np.uint64(33)) % np.uint64(n_shards)).astype(np.int64)
+    return np.mod(ids, n_shards)
+
+
+def shard_capacity(n, n_shards, factor=1.25):
+    if n_shards <= 1:
+        return int(n)
+    c = -(-int(n * factor) // n_shards)
+    return int(min(n, -(-c // 64) * 64))
+
+
+def shard_route_slots(ids, wts, n_shards, cap, hashed=False):
+    """Returns (req_ids int64 [n_shards * cap] (-1: unused slot), req_wts float32, slot_of_pos int32 [n] (-1: bucket full),
+    pos_of_slot int32 [n_shards * cap] (-1), dropped): position i takes slot owner * cap + (its rank among the positions of the
+    same owner, ascending position)."""
+    ids = _i64(ids).ravel()
+    n = ids.size
+    w = np.ones(n, np.float32) if wts is None else _f32(wts).ravel()
+    own = shard_owner(ids, n_shards, hashed)
+    req_ids = np.full(n_shards * cap, -1, np.int64)
+    req_wts = np.zeros(n_shards * cap, np.float32)
+    slot_of_pos = np.full(n, -1, np.int32)
+    pos_of_slot = np.full(n_shards * cap, -1, np.int32)
+    fill = np.zeros(n_shards, np.int64)
+    dropped = 0
+    for i in range(n):
+        o = int(own[i])
+        j = int(fill[o])
+        fill[o] += 1
+        if j >= cap:
+            dropped += 1
+            continue
+        s = o * cap + j
+        req_ids[s] = ids[i] if hashed else (ids[i] - o) // n_shards
+        req_wts[s] = w[i]
+        slot_of_pos[i] = s
+        pos_of_slot[s] = i
+    return req_ids, req_wts, slot_of_pos, pos_of_slot, dropped
+
+
+def unique_skip_negative(ids):
+    """ops.Unique over the non-negative ids only: (uniq, inv) with inv = -1 at the negative (padding) positions."""
+    ids = _i64(ids).ravel()
+    ok = ids >= 0
+    u, inv_ok = unique(ids[ok])
+    inv = np.full(ids.size, -1, np.int64)
+    inv[ok] = inv_ok
+    return u, inv
+
+
 # ---- elementwise ends of the dense net (numpy restatements; reference: wide_and_deep.py:113-133,315,352-354)
 def relu_bwd_colsum(g, h):
     """ReLU bprop + BiasAdd bprop: dh = g where h > 0 else 0; db = dh.sum(0) (float64 accumulate)."""

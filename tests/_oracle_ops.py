@@ -25,8 +25,13 @@ class Plan:
         self.n = self.ids.size
 
 
-def sparse_plan(ids):
+def sparse_plan(ids, skip_negative=False):
+    """(negative ids need no special care here: the oracle's row updates skip rows outside the table)"""
     return Plan(ids)
+
+
+def head_supported(K5):
+    return False
 
 
 def gather_rows(table, ids, row_scale=None):
@@ -61,23 +66,50 @@ def dense_ftrl_(var, accum, linear, g, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5,
     O.dense_ftrl(_np(var), _np(accum), _np(linear), _np(g), lr=lr, l1=l1, l2=l2, lr_power=lr_power, grad_scale=grad_scale)
 
 
-def shard_route(ids, n_shards):
-    loc, perm, counts = O.shard_route(_np(ids), n_shards)
-    return torch.from_numpy(loc.astype(_np(ids).dtype)), torch.from_numpy(perm), torch.from_numpy(counts)
+# ---- fixed-capacity routing of a sharded step (oracle/oracle.py restatements; fp32 rows) ------------------------------------
+def shard_capacity(n, n_shards, factor=1.25):
+    return O.shard_capacity(n, n_shards, factor)
 
 
-def shard_unroute(rows, send_perm, row_scale=None):
-    r, p = _np(rows), _np(send_perm)
-    out = np.empty_like(r)
-    out[p] = r * (_np(row_scale)[p][:, None] if row_scale is not None else 1.0)
-    return torch.from_numpy(out.astype(np.float32))
+def shard_msg_words(D, act_dtype):
+    assert act_dtype == torch.float32
+    return D, D + 4
 
 
-def shard_route_rows(g, send_perm, row_scale=None):
-    p = _np(send_perm)
-    gg = _np(g).reshape(p.size, -1)
-    out = gg[p] * (_np(row_scale)[p][:, None] if row_scale is not None else 1.0)
-    return torch.from_numpy(np.ascontiguousarray(out, dtype=np.float32))
+def shard_route_slots(ids, wts, n_shards, cap, hashed=False, overflow=None):
+    rid, rw, sop, pos, dropped = O.shard_route_slots(_np(ids), _np(wts) if wts is not None else None, n_shards, cap, hashed)
+    idt = _np(ids).dtype
+    req = np.empty((n_shards * cap, 2), idt)
+    req[:, 0] = rid.astype(idt)
+    req[:, 1] = rw.view(np.int32).astype(idt)                       # the weight's bits in the entry's second word
+    if overflow is not None:
+        overflow += dropped
+    return torch.from_numpy(req), torch.from_numpy(sop), torch.from_numpy(pos)
+
+
+def shard_unpack_req(req):
+    r = _np(req)
+    return torch.from_numpy(r[:, 0].copy()), torch.from_numpy(r[:, 1].astype(np.int32).view(np.float32).copy())
+
+
+def shard_unroute_slots(back, slot_of_pos, D, act_dtype, out=None):
+    b, s = _np(back), _np(slot_of_pos)
+    ok = s >= 0
+    emb = np.zeros((s.size, D), np.float32)
+    wp = np.zeros((s.size, 2), np.float32)
+    emb[ok] = b[s[ok], :D]
+    wp[ok, 0] = b[s[ok], D]
+    return torch.from_numpy(emb), torch.from_numpy(wp)
+
+
+def shard_route_grads(g, dlogit, F, pos_of_slot):
+    gg, dl, p = _np(g), _np(dlogit), _np(pos_of_slot)
+    D = gg.shape[1]
+    msg = np.zeros((p.size, D + 4), np.float32)
+    ok = p >= 0
+    msg[ok, :D] = gg[p[ok]]
+    msg[ok, D] = dl[p[ok] // F]
+    return torch.from_numpy(msg)
 
 
 def segment_sum(plan, g, row_scale=None, grad_scale=1.0):

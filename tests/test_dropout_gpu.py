@@ -164,12 +164,12 @@ def _row_rel(a, b):
 def test_fp32_engine_with_dropout_matches_oracle_engine(dev, oracle):
     """The autograd fp32 net (`x = self.dropout(x)` as a multiply by the mask) against the same engine driven by the oracle on the
     CPU, whose masks come from oracle.dropout_mask."""
-    import _oracle_ops
+    from _oracle_engine import OracleDeepCrossEngine, OracleDeepFMEngine, OracleWideDeepEngine  # noqa: F401
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     cfg = WideDeepConfig(vocab_size=50_000, emb_dim=80, field_size=26, batch_size=256, deep_layer_dim=[64, 32], mlp_dtype="fp32",
                          dropout_flag=True)
     g = WideDeepEngine(cfg, dev)
-    c = WideDeepEngine(cfg, "cpu", kernels=_oracle_ops)
+    c = OracleWideDeepEngine(cfg, "cpu")
     n = WideDeepEngine(WideDeepConfig(**{**cfg.__dict__, "dropout_flag": False}), dev)
     for s in range(3):
         ids, wts, label = synthetic_batch(cfg, "cpu", "zipf", seed=7 + s)
@@ -240,7 +240,7 @@ def test_dropout_graph_replay_equals_eager(dev):
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     base = dict(vocab_size=200_000, emb_dim=80, field_size=26, batch_size=2048, deep_layer_dim=[256, 128], mlp_dtype="bf16", dropout_flag=True)
     a = WideDeepEngine(WideDeepConfig(**base), dev)
-    b = WideDeepEngine(WideDeepConfig(**base, graph_step=False, graph_front=False, graph_mlp=False), dev)
+    b = WideDeepEngine(WideDeepConfig(**base, graphs="none"), dev)
     cfg = a.cfg
     for s in range(7):
         ids, wts, label = synthetic_batch(cfg, dev, "zipf", seed=40 + s)

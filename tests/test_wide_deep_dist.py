@@ -32,11 +32,11 @@ def _worker(rank, world, port, steps, out_dir, dropout=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import _oracle_ops
+    from _oracle_engine import OracleDeepCrossEngine, OracleDeepFMEngine, OracleWideDeepEngine  # noqa: F401
     from mindrec_amd.wide_deep import WideDeepEngine
     torch.set_num_threads(1)
     cfg = _cfg(24, dropout)
-    eng = WideDeepEngine(cfg, "cpu", rank=rank, world=world, kernels=_oracle_ops)
+    eng = OracleWideDeepEngine(cfg, "cpu", rank=rank, world=world)
     losses = []
     for s in range(steps):
         ids, wts, label = _batch(cfg, seed=100 * s + rank)
@@ -58,7 +58,7 @@ def test_sharded_step_matches_single_process(tmp_path, world, dropout):
     """world = 4 / 8 with V = 997 also cover shards of unequal length (250, 249, ... / 125, 125, ..., 124 rows);
     world = 8 is the driver's scaling-bench geometry (BASELINE configs[3]).  dropout: the ranks draw the Dropout mask of the
     one concatenated batch (row0 = rank * local batch)."""
-    import _oracle_ops
+    from _oracle_engine import OracleDeepCrossEngine, OracleDeepFMEngine, OracleWideDeepEngine  # noqa: F401
     from mindrec_amd.wide_deep import WideDeepEngine
     steps = 3
     mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), dropout), nprocs=world, join=True)
@@ -66,7 +66,7 @@ def test_sharded_step_matches_single_process(tmp_path, world, dropout):
 
     # single process, concatenated batch of world x 24
     cfg1 = _cfg(24 * world, dropout)
-    eng = WideDeepEngine(cfg1, "cpu", kernels=_oracle_ops)
+    eng = OracleWideDeepEngine(cfg1, "cpu")
     losses = []
     for s in range(steps):
         parts = [_batch(_cfg(24), seed=100 * s + k) for k in range(world)]
@@ -101,15 +101,15 @@ def test_engine_refuses_cpu_without_kernels():
 def test_checkpoint_roundtrip_and_shard_merge(tmp_path):
     """save -> train on -> load restores the exact state and training continues identically; two rank
     shards merge back into the single-process tables (eval.py:86-107 analogue)."""
-    import _oracle_ops
+    from _oracle_engine import OracleDeepCrossEngine, OracleDeepFMEngine, OracleWideDeepEngine  # noqa: F401
     from mindrec_amd.wide_deep import WideDeepEngine, load_checkpoint, merge_shards, save_checkpoint
     cfg = _cfg(24)
-    a = WideDeepEngine(cfg, "cpu", kernels=_oracle_ops)
+    a = OracleWideDeepEngine(cfg, "cpu")
     for s in range(2):
         a.train_step(*_batch(cfg, seed=s))
     save_checkpoint(a, tmp_path / "a.pt")
     ref = [float(a.train_step(*_batch(cfg, seed=10 + s))) for s in range(2)]
-    b = WideDeepEngine(cfg, "cpu", kernels=_oracle_ops)
+    b = OracleWideDeepEngine(cfg, "cpu")
     load_checkpoint(b, tmp_path / "a.pt")
     got = [float(b.train_step(*_batch(cfg, seed=10 + s))) for s in range(2)]
     assert got == ref
@@ -118,24 +118,24 @@ def test_checkpoint_roundtrip_and_shard_merge(tmp_path):
     # shards of a 2-rank layout interleave back to the full table
     shards = []
     for r in range(2):
-        e = WideDeepEngine(cfg, "cpu", rank=r, world=2, kernels=_oracle_ops)
+        e = OracleWideDeepEngine(cfg, "cpu", rank=r, world=2)
         save_checkpoint(e, tmp_path / f"r{r}.pt")
         shards.append(tmp_path / f"r{r}.pt")
     full = merge_shards(shards)
-    fresh = WideDeepEngine(cfg, "cpu", kernels=_oracle_ops)
+    fresh = OracleWideDeepEngine(cfg, "cpu")
     assert torch.equal(full["deep"], fresh.deep) and torch.equal(full["wide"], fresh.wide)
     with pytest.raises(ValueError):
-        load_checkpoint(WideDeepEngine(cfg, "cpu", rank=1, world=2, kernels=_oracle_ops), tmp_path / "a.pt")
+        load_checkpoint(OracleWideDeepEngine(cfg, "cpu", rank=1, world=2), tmp_path / "a.pt")
 
 
 def test_train_steps_without_graphs_is_step_by_step():
     """train_steps (sink_size steps per host call) on an engine that has no whole-step graph -- here the CPU stand-in -- is the
     same as that many train_step calls, and hands out losses that later steps do not overwrite."""
-    import _oracle_ops
+    from _oracle_engine import OracleDeepCrossEngine, OracleDeepFMEngine, OracleWideDeepEngine  # noqa: F401
     from mindrec_amd.wide_deep import WideDeepEngine
     cfg = _cfg(24)
-    a = WideDeepEngine(cfg, "cpu", kernels=_oracle_ops)
-    b = WideDeepEngine(cfg, "cpu", kernels=_oracle_ops)
+    a = OracleWideDeepEngine(cfg, "cpu")
+    b = OracleWideDeepEngine(cfg, "cpu")
     bs = [_batch(cfg, seed=40 + s) for s in range(4)]
     la = [float(x) for x in a.train_steps(bs)]
     lb = [float(b.train_step(*x)) for x in bs]

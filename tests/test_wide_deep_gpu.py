@@ -18,12 +18,12 @@ def row_rel(a, b):
 
 @pytest.mark.parametrize("fields,dist_kind", [(39, "zipf"), (26, "uniform")])
 def test_engine_matches_oracle_engine(dev, oracle, fields, dist_kind):
-    import _oracle_ops
+    from _oracle_engine import OracleDeepCrossEngine, OracleDeepFMEngine, OracleWideDeepEngine  # noqa: F401
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     cfg = WideDeepConfig(vocab_size=50_000, emb_dim=80, field_size=fields, batch_size=256, deep_layer_dim=[64, 32],
                          mlp_dtype="fp32")
     g = WideDeepEngine(cfg, dev)
-    c = WideDeepEngine(cfg, "cpu", kernels=_oracle_ops)
+    c = OracleWideDeepEngine(cfg, "cpu")
     assert np.array_equal(g.deep.cpu().numpy(), c.deep.numpy())                 # same init, bit for bit
     assert np.array_equal(g.dense_flat.detach().cpu().numpy(), c.dense_flat.detach().numpy())
     for s in range(3):
@@ -51,11 +51,11 @@ def test_dense_gradient_mode_matches_oracle_engine(dev, oracle):
     batch 1024, 39 fields): dense [V, D] embedding gradients with the L2 term, nn.Adam / nn.FTRL over every row.  The engine on
     the GPU against the same engine driven by the oracle on the CPU: every row moves every step (Adam on l2_coef * E), the
     untouched wide weights collapse onto FTRL's fixed point, and both sides must agree on all of it."""
-    import _oracle_ops
+    from _oracle_engine import OracleDeepCrossEngine, OracleDeepFMEngine, OracleWideDeepEngine  # noqa: F401
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     cfg = WideDeepConfig(vocab_size=2_000_000, emb_dim=16, field_size=39, batch_size=1024, mlp_dtype="fp32", sparse=False)
     g = WideDeepEngine(cfg, dev)
-    c = WideDeepEngine(cfg, "cpu", kernels=_oracle_ops)
+    c = OracleWideDeepEngine(cfg, "cpu")
     d0 = c.deep.numpy().copy()
     w0 = c.wide.numpy().copy()
     untouched = np.ones(cfg.vocab_size, bool)
@@ -92,12 +92,12 @@ def test_predict_and_lookup(dev, oracle):
 
 def test_deep_cross_engine_matches_oracle_engine(dev, oracle):
     """DCN step (gather, 6 fused cross layers, MLP, dense Adam over the table) vs the oracle-driven engine."""
-    import _oracle_ops
+    from _oracle_engine import OracleDeepCrossEngine, OracleDeepFMEngine, OracleWideDeepEngine  # noqa: F401
     from mindrec_amd.deep_cross import DeepCrossConfig, DeepCrossEngine
     from mindrec_amd.wide_deep import WideDeepConfig, synthetic_batch
     cfg = DeepCrossConfig(vocab_size=5000, emb_dim=30, field_size=39, batch_size=128, deep_layer_dim=[64, 32])
     g = DeepCrossEngine(cfg, dev)
-    c = DeepCrossEngine(cfg, "cpu", kernels=_oracle_ops)
+    c = OracleDeepCrossEngine(cfg, "cpu")
     assert np.array_equal(g.table.cpu().numpy(), c.table.numpy())
     bcfg = WideDeepConfig(vocab_size=5000, emb_dim=30, field_size=39, batch_size=128)
     for s in range(3):
@@ -115,13 +115,13 @@ def test_deep_cross_engine_matches_oracle_engine(dev, oracle):
 def test_auc_parity_on_planted_signal(dev, oracle):
     """BASELINE "AUC parity": the GPU engine and the oracle-driven engine, trained on the same
     synthetic stream with a planted signal, reach the same held-out AUC (and both learn)."""
-    import _oracle_ops
+    from _oracle_engine import OracleDeepCrossEngine, OracleDeepFMEngine, OracleWideDeepEngine  # noqa: F401
     from sklearn.metrics import roc_auc_score
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     cfg = WideDeepConfig(vocab_size=3000, emb_dim=16, field_size=39, batch_size=1024, deep_layer_dim=[64, 32],
                          mlp_dtype="fp32", adam_lr=3e-3)          # cfg1-like shape, larger lr so 40 steps suffice
     g = WideDeepEngine(cfg, dev)
-    c = WideDeepEngine(cfg, "cpu", kernels=_oracle_ops)
+    c = OracleWideDeepEngine(cfg, "cpu")
     for s in range(40):
         ids, wts, label = synthetic_batch(cfg, "cpu", "uniform", seed=300 + s, signal=True)
         c.train_step(ids, wts, label)
@@ -177,12 +177,12 @@ def test_mfma_mlp_step_matches_torch_fp32_reference(dev):
 
 def test_deepfm_engine_matches_oracle_engine(dev, oracle):
     """DeepFM step (two gathers, FM term, MLP, L2 over both whole tables, dense Adam) vs the oracle-driven engine."""
-    import _oracle_ops
+    from _oracle_engine import OracleDeepCrossEngine, OracleDeepFMEngine, OracleWideDeepEngine  # noqa: F401
     from mindrec_amd.deepfm import DeepFMConfig, DeepFMEngine
     from mindrec_amd.wide_deep import WideDeepConfig, synthetic_batch
     cfg = DeepFMConfig(data_vocab_size=4000, data_emb_dim=16, data_field_size=39, batch_size=128, deep_layer_dims=[64, 32])
     g = DeepFMEngine(cfg, dev)
-    c = DeepFMEngine(cfg, "cpu", kernels=_oracle_ops)
+    c = OracleDeepFMEngine(cfg, "cpu")
     assert np.array_equal(g.V_l2.cpu().numpy(), c.V_l2.numpy())
     bcfg = WideDeepConfig(vocab_size=4000, emb_dim=16, field_size=39, batch_size=128)
     for s in range(3):
@@ -207,8 +207,8 @@ def test_graph_replay_is_bit_identical_to_eager(dev, level):
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     kw = dict(vocab_size=50000, emb_dim=16, field_size=26, batch_size=2048, deep_layer_dim=[256, 128, 64, 32],
               mlp_dtype="bf16")
-    a = WideDeepEngine(WideDeepConfig(graph_mlp=True, graph_front=level != "mlp", graph_step=level == "step", **kw), dev)
-    b = WideDeepEngine(WideDeepConfig(graph_mlp=False, **kw), dev)
+    a = WideDeepEngine(WideDeepConfig(graphs=level, **kw), dev)
+    b = WideDeepEngine(WideDeepConfig(graphs="none", **kw), dev)
     assert a._mfma and a._fold_wide, "MFMA MLP path with the folded wide branch expected"
     for s in range(9):
         ids, wts, label = synthetic_batch(a.cfg, dev, "zipf", seed=70 + s)
@@ -260,7 +260,7 @@ def test_dynamic_embedding_engine_equals_dense_table_engine(dev, graph):
     from mindrec_amd import ops
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     kw = dict(vocab_size=50000, emb_dim=16, field_size=39, batch_size=1024, deep_layer_dim=[128, 64, 32],
-              mlp_dtype="bf16", graph_mlp=graph)
+              mlp_dtype="bf16", graphs="step" if graph else "none")
     a = WideDeepEngine(WideDeepConfig(**kw), dev)
     b = WideDeepEngine(WideDeepConfig(dynamic_embedding=True, hash_capacity=1 << 16, **kw), dev)
     seen = []
@@ -328,11 +328,11 @@ def test_host_cached_engine_matches_oracle_engine(dev, oracle):
     """The cache tier against the ORACLE (not against the resident HIP engine): the engine whose tables live in host DRAM
     behind a small device cache -- rows evicted, written back and fetched again as the stream moves -- against the engine
     driven by the oracle on the CPU, which knows nothing of caches."""
-    import _oracle_ops
+    from _oracle_engine import OracleDeepCrossEngine, OracleDeepFMEngine, OracleWideDeepEngine  # noqa: F401
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     kw = dict(vocab_size=40_000, emb_dim=16, field_size=26, batch_size=256, deep_layer_dim=[64, 32], mlp_dtype="fp32")
     g = WideDeepEngine(WideDeepConfig(host_cache_rows=9000, **kw), dev)
-    c = WideDeepEngine(WideDeepConfig(**kw), "cpu", kernels=_oracle_ops)
+    c = OracleWideDeepEngine(WideDeepConfig(**kw), "cpu")
     for s in range(8):
         ids, wts, label = synthetic_batch(c.cfg, "cpu", "uniform" if s % 2 else "zipf", seed=300 + s)
         lc = float(c.train_step(ids, wts, label))
@@ -385,7 +385,7 @@ def test_weight_gradient_slabs_and_graph_switching(dev):
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     kw = dict(vocab_size=50000, emb_dim=80, field_size=26, batch_size=4096, mlp_dtype="bf16")
     a = WideDeepEngine(WideDeepConfig(**kw), dev)
-    b = WideDeepEngine(WideDeepConfig(graph_mlp=False, **kw), dev)
+    b = WideDeepEngine(WideDeepConfig(graphs="none", **kw), dev)
     for s in range(12):
         if s == 5:
             a.timers = {}              # leaves the step graph: MLP graphs get captured

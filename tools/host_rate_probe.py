@@ -12,7 +12,7 @@ from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batc
 dev = torch.device("cuda:0")
 graph = "--no-graph" not in sys.argv
 nb = 4 if "--rotate" in sys.argv else 1
-cfg = WideDeepConfig(field_size=26, graph_mlp=graph)
+cfg = WideDeepConfig(field_size=26, graphs="step" if graph else "none")
 eng = WideDeepEngine(cfg, dev)
 batches = [synthetic_batch(cfg, dev, "uniform", 1000 + i) for i in range(nb)]
 for i in range(5):
