@@ -275,6 +275,7 @@ def main():
         block_s.append(dt)
         if eng._step_graph is None:
             kmain += [t.ms() for t in ktimers]
+    embed_stamps = []
     apply_timing = ("HIP events around k_apply_main on its launch stream (mrec_profile_next_apply), "
                     "averaged over the {n} timed steps")
     if eng._step_graph is not None:
@@ -284,6 +285,7 @@ def main():
         last = eng.step_count
         n_timed = min(len(block_s) * args.steps, ops.StepState.RING - 1)
         kmain = eng._step_state.apply_ms(range(last - n_timed + 1, last + 1))
+        embed_stamps = eng._step_state.embed_ms(range(last - n_timed + 1, last + 1))      # (lookup, apply incl. k_apply_long) per step
         apply_timing = ("device wall-clock stamps written by k_apply_main itself (first workgroup begin -> last wave end; the step "
                         "is one HIP graph, whose event nodes cannot be timed), averaged over the last {n} timed steps")
     dt = median(block_s)
@@ -401,16 +403,25 @@ def main():
         # ENQUEUES work on the side stream -- the plan -- is not listed; one cold outlier does not move a median)
         "kernels_ms": {k: {"median": round(median(v), 5), "n": len(v)} for k, v in sorted(kern_ms.items()) if v and k != "plan"},
     }
+    lookup_timing = "torch events around the gather in eager extra steps after the timed region"
+    apply_all_ms = None
+    if fold and embed_stamps:
+        # in-graph truth: both kernels stamp the device wall clock themselves in every timed step
+        lookup_ms = sum(a for a, _ in embed_stamps) / len(embed_stamps)
+        apply_all_ms = sum(b for _, b in embed_stamps) / len(embed_stamps)
+        lookup_timing = (f"device wall-clock stamps written by the lookup kernel itself inside the timed steps' graph (first workgroup begin -> last "
+                         f"wave end of the last-dispatched workgroups), averaged over {len(embed_stamps)} timed steps")
     if world == 1 and lookup_ms:
         out["roofline_lookup"] = {"bound": "hbm", "kernel": "k_gather_rows (EmbeddingLookup, mask fused%s)" % (" + the row's wide word" if fold else ""),
                                   "achieved": round(lookup_bytes / (lookup_ms * 1e-3) / 1e9, 1),
                                   "peak": peak, "unit": "GB/s", "frac": round(lookup_bytes / (lookup_ms * 1e-3) / 1e9 / peak, 4),
-                                  "algorithmic_bytes": lookup_bytes, "avg_ms": round(lookup_ms, 5),
-                                  "timing": "torch events around the gather in extra steps after the timed region"}
+                                  "algorithmic_bytes": lookup_bytes, "avg_ms": round(lookup_ms, 5), "timing": lookup_timing}
         tot_b = tot_ms = None
         if fold:
-            # both tables' lookup and apply are these two kernels (the per-sample sum of the wide products is in the head kernel)
-            tot_b, tot_ms = lookup_bytes + apply_bytes, lookup_ms + apply_ms
+            # both tables' lookup and apply are these kernels (the per-sample sum of the wide products is in the head kernel); the
+            # apply's finishing kernel (k_apply_long: the runs that cross windows) and the launch gap in front of it are counted
+            tot_b = lookup_bytes + apply_bytes
+            tot_ms = lookup_ms + (apply_all_ms if apply_all_ms is not None else apply_ms)
         elif wide_ms and wapply_ms:
             tot_b = by["lookup"] + by["apply_deep"] + by["wide_lookup"] + by["apply_wide"]
             tot_ms = lookup_ms + apply_ms + wide_ms + wapply_ms
@@ -418,7 +429,9 @@ def main():
             out["roofline_embedding_path"] = {"what": "EmbeddingLookup + sparse apply, deep AND wide tables (north-star quantity)",
                                               "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 1), "peak": peak, "unit": "GB/s",
                                               "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / peak, 4), "algorithmic_bytes": tot_b,
-                                              "sum_ms": round(tot_ms, 5)}
+                                              "sum_ms": round(tot_ms, 5), "lookup_ms": round(lookup_ms, 5),
+                                              "apply_ms_incl_finishing_kernel": round(apply_all_ms, 5) if apply_all_ms is not None else None,
+                                              "timing": "in-graph kernel stamps" if apply_all_ms is not None else "events in eager extra steps; k_apply_long not counted"}
     if world == 1 and eng._mfma:
         # exact HBM bytes of one k_dense_adam4_slabs launch (tools/pmc_summary.py checks its counter correction on these)
         n_el = eng.dense_flat.numel()

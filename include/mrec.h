@@ -140,12 +140,13 @@ int mrec_gather_rows_wide(const float* table, int64_t V, int64_t ld, int32_t D, 
  * TABLE_ROW_SLICE), wide_and_deep.py:232-249): ids[i * id_stride] and row_scale[i * scale_stride] let ids and weights be read
  * straight out of the received {id, weight} entries; out_kind 0 adds fp32 rows (ldo then in floats; the fp32 wire format of
  * an fp32 net); MREC_GATHER_SKIP_INVALID leaves the rows of ids outside [0, V) alone instead of writing zeros (the padding
- * slots of a fixed-capacity message: nobody reads their answers). */
+ * slots of a fixed-capacity message: nobody reads their answers).  step_state (nullable, an mrec_step_state_t): the kernel
+ * leaves its begin / end wall-clock stamps in stamps_aux[(step + 1) % ring] (measurement only). */
 #define MREC_GATHER_SKIP_INVALID 1u
 int mrec_gather_rows_wide_ex(const float* table, int64_t V, int64_t ld, int32_t D, const void* ids, int32_t id_bytes,
                              int64_t id_stride, int64_t n, const float* row_scale, int64_t scale_stride, void* out, int32_t out_kind,
                              int64_t ldo, int32_t wide_col, float* wide_prod, int64_t ldw, const struct mrec_dropout* drop,
-                             int32_t fields, uint32_t flags, void* stream);
+                             int32_t fields, uint32_t flags, void* step_state, void* stream);
 
 /* Wide branch of WideDeepModel.construct (wide_and_deep.py:300,303-306) in one pass:
  * out[b] = sum_f w[ids[b,f] * ldw] * wts[b,f] + *bias_dev   (w is the [V,1] wide table, row
@@ -256,6 +257,10 @@ typedef struct mrec_step_state {
     /* [step % MREC_STAMP_RING] = {begin of the first workgroup, end of the last wave} of the main sparse-apply kernel that
      * ran with this state, in ticks of the device wall clock (mrec_wall_clock_khz) */
     uint64_t stamps[MREC_STAMP_RING][2];
+    /* [step % MREC_STAMP_RING] = {begin, end of the step's fused lookup kernel (mrec_gather_rows_wide_ex with step_state: it runs
+     * BEFORE the step's mrec_step_advance and stamps the slot of step + 1), end of the finishing kernel of the sparse apply
+     * (k_apply_long), 0}: what bench.py reads the in-graph times of EmbeddingLookup + sparse apply from */
+    uint64_t stamps_aux[MREC_STAMP_RING][4];
 } mrec_step_state_t;
 int mrec_step_state_init(void* state, float beta1_power, float beta2_power, int64_t step, void* stream);
 /* powers *= betas, step += 1, lr_t recomputed, the stamp slot of the new step reset */

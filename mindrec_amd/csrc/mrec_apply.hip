@@ -575,6 +575,9 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
         }
         __syncthreads();
     }
+    // end stamp (measurement): the last-dispatched workgroups raise it -- one atomic each, 256 at most
+    if (ss && threadIdx.x == 0 && (int)blockIdx.x + 256 >= (int)gridDim.x)
+        atomicMax((unsigned long long*)&ss->aux[(unsigned)ss->step % kStampRing][2], (unsigned long long)wall_clock64());
 }
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -718,7 +721,10 @@ namespace {
 __global__ void k_step_init(StepState* s, float b1p, float b2p, long long step) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) { s->b1p = b1p; s->b2p = b2p; s->lr_t = 0.f; s->pad0 = 0.f; s->step = step; s->pad1 = 0; }
-    if (i < kStampRing) { s->stamps[i][0] = ~0ull; s->stamps[i][1] = 0ull; }
+    if (i < kStampRing) {
+        s->stamps[i][0] = ~0ull; s->stamps[i][1] = 0ull;
+        s->aux[i][0] = ~0ull; s->aux[i][1] = 0ull; s->aux[i][2] = 0ull; s->aux[i][3] = 0ull;
+    }
 }
 __global__ void k_step_advance(StepState* s, float lr, float b1, float b2) {
     const float b1p = s->b1p * b1, b2p = s->b2p * b2;
@@ -727,6 +733,9 @@ __global__ void k_step_advance(StepState* s, float lr, float b1, float b2) {
     s->lr_t = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);      // same fp32 operations as the host-side entries
     s->stamps[(unsigned)step % kStampRing][0] = ~0ull;
     s->stamps[(unsigned)step % kStampRing][1] = 0ull;
+    s->aux[(unsigned)step % kStampRing][2] = 0ull;                   // this step's k_apply_long end
+    s->aux[(unsigned)(step + 1) % kStampRing][0] = ~0ull;            // the NEXT step's lookup (it runs before that step's advance)
+    s->aux[(unsigned)(step + 1) % kStampRing][1] = 0ull;
 }
 }  // namespace
 

@@ -93,10 +93,21 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
                                                      OT* __restrict__ out, int D, RowGeom gm,
                                                      float* __restrict__ wprod = nullptr, int64_t ldo = 0, int64_t ldw = 2,
                                                      GatherDrop gd = GatherDrop{}, int ids_stride = 1, int rs_stride = 1,
-                                                     bool skip_invalid = false) {
+                                                     bool skip_invalid = false, StepState* ss = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
-    if (grp >= gm.G) return;
+    // Stamps (measurement only; ss == nullptr: none): workgroup 0 stores the begin, the last wave of each of the LAST-dispatched
+    // 512 workgroups raises the end -- this lookup belongs to step ss->step + 1 (the step's advance runs behind it).
+    __shared__ int waves_done;
+    unsigned long long* stamp = ss ? ss->aux[(unsigned)(ss->step + 1) % kStampRing] : nullptr;
+    if (stamp) {
+        if (threadIdx.x == 0) {
+            waves_done = 0;
+            if (blockIdx.x == 0) stamp[0] = (unsigned long long)wall_clock64();
+        }
+        __syncthreads();
+    }
+    if (grp < gm.G) {
     if (ldo == 0) ldo = D;                 // row stride of `out` in elements; ldw: stride of the wide products in floats
     const int col = sub * VEC;
     const bool wl = VEC == 4 && wprod != nullptr && col >= D;      // the wide lane (column D)
@@ -147,6 +158,9 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
             }
         }
     }
+    }
+    if (stamp && (int)blockIdx.x + 512 >= (int)gridDim.x && lane == 0 && atomicAdd(&waves_done, 1) == 3)
+        atomicMax(&stamp[1], (unsigned long long)wall_clock64());
 }
 
 // Generic-D fallback (D not a multiple of 4, or misaligned): one wave per GB rows, lanes stride columns.
@@ -449,7 +463,8 @@ inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 template <class K, class OT = bf16o_t>
 int gather_bf16_impl(const float* table, int64_t V, int64_t ld, int32_t D, const K* ids, int64_t n,
                      const float* row_scale, uint16_t* out, void* stream, int wcol = 0, float* wprod = nullptr, int64_t ldo = 0,
-                     int64_t ldw = 2, GatherDrop gd = GatherDrop{}, int ids_stride = 1, int rs_stride = 1, bool skip_invalid = false) {
+                     int64_t ldw = 2, GatherDrop gd = GatherDrop{}, int ids_stride = 1, int rs_stride = 1, bool skip_invalid = false,
+                     StepState* ss = nullptr) {
     constexpr int ob = (int)sizeof(OT);                    // bytes per output element (2: bf16 / f16, 4: fp32 rows + the wide lane)
     const int oa = ob == 2 ? 7 : 15;                       // alignment of an output row's 4-element quad
     if ((ldo != 0 && (ldo < D || ldo % 4)) || (wprod && (ldw < 2 || ldw % 2)) || ids_stride < 1 || rs_stride < 1) return MREC_EINVAL;
@@ -465,7 +480,7 @@ int gather_bf16_impl(const float* table, int64_t V, int64_t ld, int32_t D, const
         const int lpr = D / 4 + (wprod ? 1 : 0);
         RowGeom gm{lpr, 64 / lpr};
         k_gather_rows<4, K, OT><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
-            table, V, ld, ids, n, row_scale, (OT*)out, D, gm, wprod, ldo, ldw, gd, ids_stride, rs_stride, skip_invalid);
+            table, V, ld, ids, n, row_scale, (OT*)out, D, gm, wprod, ldo, ldw, gd, ids_stride, rs_stride, skip_invalid, ss);
     } else if (D <= 64 && !wprod && ldo == 0 && ids_stride == 1 && rs_stride == 1 && !skip_invalid) {
         RowGeom gm{D, 64 / D};
         k_gather_rows<1, K, OT><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
@@ -597,7 +612,7 @@ MREC_API int mrec_gather_rows_f16_i64(const float* table, int64_t V, int64_t ld,
 MREC_API int mrec_gather_rows_wide_ex(const float* table, int64_t V, int64_t ld, int32_t D, const void* ids, int32_t id_bytes,
                                       int64_t id_stride, int64_t n, const float* row_scale, int64_t scale_stride, void* out,
                                       int32_t out_kind, int64_t ldo, int32_t wide_col, float* wide_prod, int64_t ldw,
-                                      const mrec_dropout_t* drop, int32_t fields, uint32_t flags, void* stream) {
+                                      const mrec_dropout_t* drop, int32_t fields, uint32_t flags, void* step_state, void* stream) {
     if ((id_bytes != 4 && id_bytes != 8) || out_kind < 0 || out_kind > 2 || id_stride < 1 || id_stride > (1 << 20) || scale_stride < 1 ||
         scale_stride > (1 << 20))
         return MREC_EINVAL;
@@ -611,7 +626,7 @@ MREC_API int mrec_gather_rows_wide_ex(const float* table, int64_t V, int64_t ld,
     const int is = (int)id_stride, rs = (int)scale_stride;
     const bool skip = (flags & MREC_GATHER_SKIP_INVALID) != 0;
 #define MREC_GW(KT, OT) return gather_bf16_impl<KT, OT>(table, V, ld, D, (const KT*)ids, n, row_scale, (uint16_t*)out, stream, wide_col, \
-                                                        wide_prod, ldo, ldw, gd, is, rs, skip)
+                                                        wide_prod, ldo, ldw, gd, is, rs, skip, (StepState*)step_state)
     if (id_bytes == 4) {
         if (out_kind == 0) { MREC_GW(int32_t, float); }
         if (out_kind == 1) { MREC_GW(int32_t, bf16o_t); }
@@ -627,7 +642,7 @@ MREC_API int mrec_gather_rows_wide(const float* table, int64_t V, int64_t ld, in
                                    float* wide_prod, int64_t ldw, const mrec_dropout_t* drop, int32_t fields, void* stream) {
     if (out_kind != 1 && out_kind != 2) return MREC_EINVAL;
     return mrec_gather_rows_wide_ex(table, V, ld, D, ids, id_bytes, 1, n, row_scale, 1, out, out_kind, ldo, wide_col, wide_prod, ldw, drop,
-                                    fields, 0u, stream);
+                                    fields, 0u, nullptr, stream);
 }
 
 MREC_API int mrec_wide_sum_f32_i32(const float* w, int64_t V, int64_t ldw, const int32_t* ids, const float* wts,

@@ -23,6 +23,8 @@ struct StepState {
     long long step;
     unsigned long long pad1;
     unsigned long long stamps[kStampRing][2];   // [step % ring] = {first workgroup start, last wave end} of k_apply_main, wall clock ticks
+    // [step % ring] = {begin, end of the step's fused lookup kernel (k_gather_rows with the wide lane), end of k_apply_long, 0}
+    unsigned long long aux[kStampRing][4];
 };
 
 struct FtrlH { float lr, l1, l2, lr_power, gscale; };

@@ -176,11 +176,20 @@ class DeepFMHashEngine:
     One Unique serves both tables (same keys, as wide_and_deep.py:300-302)."""
 
     def __init__(self, cfg: DeepFMConfig, device, key_dtype=torch.int64, capacity=1 << 22, permit_filter_value=1,
-                 evict_filter_value=None):
+                 evict_filter_value=None, rank=0, world=1, comm=None, shard_capacity_factor=1.25):
+        """rank / world > 1: both hash tables are sharded by key -- owner = hash(key) mod world, the raw keys travel, every owner
+        keeps its own key index, admission counters and optimizer state -- over the fixed-capacity exchange of
+        mindrec_amd/wide_deep_shard.py (static message shapes, no host round trip); the dense net is data parallel with one
+        all-reduce(mean).  comm: collectives provider (default: torch.distributed, i.e. RCCL on device tensors)."""
         from .experimental import MAX_SIZE, MapParameter
         self.cfg, self.device = cfg, torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DeepFMHashEngine runs on an MI355X (no CPU fallback)")
+        self.rank, self.world, self.cap_factor = int(rank), int(world), float(shard_capacity_factor)
+        if self.world > 1:
+            from .wide_deep import _DirectComm
+            self.comm = comm if comm is not None else _DirectComm()
+            self._overflow = torch.zeros(1, dtype=torch.int64, device=self.device)
         D, dev = cfg.data_emb_dim, self.device
         ev = MAX_SIZE if evict_filter_value is None else evict_filter_value
         mk = dict(key_dtype=key_dtype, default_value="normal", permit_filter_value=permit_filter_value,
@@ -238,12 +247,73 @@ class DeepFMHashEngine:
         _, rows_w, pos_w = self.W.lookup_rows(flat, insert=insert, dedup=d)
         return d, rows_v, pos_v, rows_w, pos_w
 
+    # ---- key-sharded tables: the fixed-capacity exchange (mindrec_amd/wide_deep_shard.py) over two MapParameters ------------
+    def shard_overflow(self):
+        """Positions dropped because an owner's bucket of the request message was full (host sync); 0 on one GPU."""
+        return int(self._overflow.item()) if self.world > 1 else 0
+
+    def _shard_lookup(self, keys, wts, train):
+        """Raw keys to their owners, looked-up rows back.  Returns (vx [B, F, D] fp32 masked, linear [B], route state)."""
+        B, Fd = keys.shape
+        D, n = self.cfg.data_emb_dim, keys.numel()
+        flat = self.V._keys(keys)
+        cap = ops.shard_capacity(n, self.world, self.cap_factor)
+        ns = self.world * cap
+        req, slot_of_pos, pos_of_slot = ops.shard_route_slots(flat, wts, self.world, cap, hashed=True, overflow=self._overflow)
+        recv_req = torch.empty_like(req)
+        self.comm.all_to_all(recv_req, req)
+        recv_keys, recv_wts = ops.shard_unpack_req(recv_req)              # padding slots carry key -1 (reserved: embedding.py:53)
+        # the owner's MapTensorGet: every received position probes the index (duplicates and other ranks' copies of a key
+        # welcome: one hit per key and step), new keys take the next rows in order of arrival with their default values;
+        # V and W see the same keys in the same order, so they number their rows alike
+        _, _, rows = self.V.lookup_rows(recv_keys, insert=True, train=train, skip_pad=True)
+        _, _, rows_w = self.W.lookup_rows(recv_keys, insert=True, train=train, skip_pad=True)
+        Dw, W = ops.shard_msg_words(D, torch.float32)
+        ans = torch.empty((ns, W), dtype=torch.float32, device=self.device)
+        ans[:, :D] = ops.gather_rows(self.V.values, rows, recv_wts)       # rows of padding slots (-1) read as zeros
+        ans[:, D] = ops.gather_rows(self.W.values, rows_w, recv_wts).view(ns)
+        back = torch.empty_like(ans)
+        self.comm.all_to_all(back, ans)
+        vx, wprod = ops.shard_unroute_slots(back, slot_of_pos, D, torch.float32)
+        linear = wprod.view(B, Fd, 2)[..., 0].sum(dim=1)
+        return vx.view(B, Fd, D), linear, {"pos_of_slot": pos_of_slot, "rows": rows, "recv_wts": recv_wts, "ns": ns}
+
+    def _train_step_sharded(self, keys, wts, label):
+        cfg = self.cfg
+        B, Fd = keys.shape
+        D = cfg.data_emb_dim
+        vx, linear, route = self._shard_lookup(keys, wts, train=None)
+        plan = ops.sparse_plan(route["rows"], skip_negative=True)         # Unique + inverted index of the received rows
+        vx.requires_grad_(True)
+        linear.requires_grad_(True)
+        self.dense_grad_flat.zero_()
+        fm = _FMTerm.apply(vx, ops)
+        logit = (linear + fm).view(-1, 1) + self._mlp(vx.view(B, Fd * D))
+        loss = F.binary_cross_entropy_with_logits(logit, label)
+        (loss * cfg.loss_scale).backward()
+        gmsg = ops.shard_route_grads(vx.grad.view(B * Fd, D), linear.grad.view(B).contiguous(), Fd, route["pos_of_slot"])
+        recv_g = torch.empty_like(gmsg)
+        self.comm.all_to_all(recv_g, gmsg)
+        self.comm.all_reduce(self.dense_grad_flat)
+        # gradients_mean: the owner sums the row gradients of all ranks, the mean divides by their number
+        kw = dict(lr=cfg.learning_rate, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.epsilon,
+                  beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=1.0 / (cfg.loss_scale * self.world))
+        rows_u = plan.uniq_buf
+        for t, g in ((self.V, recv_g[:, :D]), (self.W, recv_g[:, D:D + 1])):
+            plan.uniq_buf = t.admitted_rows(rows_u)               # groups -> table rows, un-admitted keys -> -1 (skipped)
+            ops.sparse_lazy_adam_(t.values, t.slots["moment1"]["table"], t.slots["moment2"]["table"], plan, g, route["recv_wts"], **kw)
+        ops.dense_adam_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, **kw)
+        return loss.detach()
+
     def predict(self, keys, wts):
         B, Fd = keys.shape
         with torch.no_grad():
-            _, _, pos_v, _, pos_w = self._lookup(keys, insert=True)
-            vx = ops.gather_rows(self.V.values, pos_v.view(B, Fd), wts)
-            linear = ops.wide_sum(self.W.values, pos_w.view(B, Fd), wts)
+            if self.world > 1:
+                vx, linear, _ = self._shard_lookup(keys, wts, train=False)      # (a collective: every rank calls predict)
+            else:
+                _, _, pos_v, _, pos_w = self._lookup(keys, insert=True)
+                vx = ops.gather_rows(self.V.values, pos_v.view(B, Fd), wts)
+                linear = ops.wide_sum(self.W.values, pos_w.view(B, Fd), wts)
             fm, _ = ops.fm_forward(vx)
             logit = (linear + fm).view(-1, 1) + self._mlp(vx.view(B, -1))
         return logit, torch.sigmoid(logit)
@@ -254,6 +324,8 @@ class DeepFMHashEngine:
         D = cfg.data_emb_dim
         self.beta1_power = np.float32(self.beta1_power * self.beta1)
         self.beta2_power = np.float32(self.beta2_power * self.beta2)
+        if self.world > 1:
+            return self._train_step_sharded(keys, wts, label)
         d, rows_v, pos_v, rows_w, pos_w = self._lookup(keys, insert=True)
         vx = ops.gather_rows(self.V.values, pos_v.view(B, Fd), wts)             # [B, F, D], mask fused
         linear = ops.wide_sum(self.W.values, pos_w.view(B, Fd), wts)             # [B]

@@ -102,7 +102,7 @@ class MapParameter:
         tabs += [(t["table"], None, t["init"], 0) for t in self.slots.values()]
         return tabs
 
-    def lookup_rows(self, keys_flat, insert=True, dedup=None, train=None):
+    def lookup_rows(self, keys_flat, insert=True, dedup=None, train=None, skip_pad=False):
         """(dedup, rows_uniq int32, rows_pos int32 [n]) for flat device keys, without host sync.  One chain of three launches
         (mrec_map_lookup): probe, rank + place the missing keys in first-occurrence order, default rows of the values and of
         every optimizer slot.  `dedup`: an ops.unique(keys_flat) result when the caller needs the Unique anyway (a training
@@ -116,7 +116,7 @@ class MapParameter:
         if dedup is not None:
             rows_u = self.index.lookup(dedup.uniq_buf, unique=True, n_dev=dedup.n_uniq_dev, **kw)
             return dedup, rows_u, ops.compose_i32(rows_u, dedup.inv)
-        rows_pos = self.index.lookup(keys_flat, **kw)
+        rows_pos = self.index.lookup(keys_flat, skip_pad=skip_pad, **kw)      # (skip_pad: key -1 = a padding slot of a shard's request)
         return None, None, rows_pos
 
     def admitted_rows(self, rows):
@@ -124,7 +124,7 @@ class MapParameter:
         which the sparse-apply kernels skip: such keys read their default row and are not updated."""
         if self.permit_filter_value <= 1:
             return rows
-        ok = (rows >= 0) & (self.hits[rows.clamp_min(0).long()] >= self.permit_filter_value)
+        ok = (rows >= 0) & (rows < self.capacity) & (self.hits[rows.clamp(0, self.capacity - 1).long()] >= self.permit_filter_value)
         return torch.where(ok, rows, torch.full_like(rows, -1))
 
     @property

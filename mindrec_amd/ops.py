@@ -192,13 +192,14 @@ def gather_rows(table, ids, row_scale=None, out=None, out_dtype=torch.float32):
     return out.view(tuple(ids.shape) + (D,))
 
 
-def gather_rows_wide(table, ids, row_scale, wide_col, out=None, out_dtype=torch.bfloat16, packed_words=0, drop=None):
+def gather_rows_wide(table, ids, row_scale, wide_col, out=None, out_dtype=torch.bfloat16, packed_words=0, drop=None, step_state=None):
     """Both lookups of WideDeepModel.construct (wide_and_deep.py:300-302) in one pass over fused rows: returns
     (rows [.., D] in out_dtype, wide_prod [.., 2] with [.., 0] = table_row[wide_col] * row_scale and [.., 1] = 0).  `table` is the [V, D] view of the deep
     columns; wide_col is the column (relative to it, >= D) of the wide weight in the same rows.
     packed_words=W (>= D/2 + 2, multiple of 4): ONE float32 [n, W] result whose row is [D 16-bit values | product, 0 | pad] --
     a shard's answer message (one collective for both tables).  drop (Dropout; ids [B, F]): the looked-up rows are the
-    [F * D] input of the DenseLayer the descriptor names and leave the kernel dropped out."""
+    [F * D] input of the DenseLayer the descriptor names and leave the kernel dropped out.  step_state (StepState): the kernel
+    leaves its begin / end stamps there (StepState.lookup_ms)."""
     _need_cuda(table, ids, row_scale, out)
     V, D, ld = _table(table)
     flat = ids.reshape(-1).contiguous()
@@ -221,9 +222,9 @@ def gather_rows_wide(table, ids, row_scale, wide_col, out=None, out_dtype=torch.
     if out is None:
         out = torch.empty((n, D), dtype=out_dtype, device=table.device)
     wprod = torch.empty((max(n, 1), 2), dtype=torch.float32, device=table.device)[:n]      # (product, pad) pairs
-    _lib.call("mrec_gather_rows_wide", _ptr(table), V, ld, D, _ptr(flat), flat.element_size(), n, _ptr(row_scale), _ptr(out),
+    _lib.call("mrec_gather_rows_wide_ex", _ptr(table), V, ld, D, _ptr(flat), flat.element_size(), 1, n, _ptr(row_scale), 1, _ptr(out),
               1 if out.dtype == torch.bfloat16 else 2, D, int(wide_col), _ptr(wprod), 2, _drop_ref(drop),
-              ids.shape[-1] if drop is not None else 0, _stream())
+              ids.shape[-1] if drop is not None else 0, 0, _ptr(step_state.buf) if step_state is not None else None, _stream())
     return out.view(tuple(ids.shape) + (D,)), wprod.view(tuple(ids.shape) + (2,))
 
 
@@ -838,7 +839,7 @@ def gather_rows_req(table, rows, rows_stride, wts, wts_stride, n_slots, wide_col
     kind = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[act_dtype]
     ldo = W if kind == 0 else 2 * W
     _lib.call("mrec_gather_rows_wide_ex", _ptr(table), V, ld, D, _ptr(rows), rows.element_size(), int(rows_stride), n_slots, _ptr(wts),
-              int(wts_stride), _ptr(msg), kind, ldo, int(wide_col), C.c_void_p(msg.data_ptr() + 4 * Dw), W, None, 0, 1, _stream())
+              int(wts_stride), _ptr(msg), kind, ldo, int(wide_col), C.c_void_p(msg.data_ptr() + 4 * Dw), W, None, 0, 1, None, _stream())
     return msg
 
 
@@ -878,7 +879,7 @@ class StepState:
     state the optimizer's own graph advances (nn.Adam: beta1_power *= beta1) -- so that a captured step has constant arguments."""
     RING = 256
     _DT = np.dtype([("beta1_power", "<f4"), ("beta2_power", "<f4"), ("lr_t", "<f4"), ("r0", "<f4"), ("step", "<i8"), ("r1", "<u8"),
-                    ("stamps", "<u8", (256, 2))])
+                    ("stamps", "<u8", (256, 2)), ("stamps_aux", "<u8", (256, 4))])
 
     def __init__(self, device, beta1_power=1.0, beta2_power=1.0, step=0):
         self.buf = torch.empty(self._DT.itemsize, dtype=torch.uint8, device=device)
@@ -906,6 +907,19 @@ class StepState:
             a, b = int(st[k % self.RING][0]), int(st[k % self.RING][1])
             if b > a and a != 0xFFFFFFFFFFFFFFFF:
                 out.append((b - a) / self.clock_khz)
+        return out
+
+    def embed_ms(self, steps):
+        """Per step: (fused lookup kernel ms, sparse apply incl. its finishing kernel ms: begin of k_apply_main -> end of
+        k_apply_long) from the kernels' own stamps -- the in-graph times of EmbeddingLookup + sparse apply."""
+        r = self.read()
+        st, aux = r["stamps"], r["stamps_aux"]
+        out = []
+        for k in steps:
+            a0, a1, l0, l1, e2 = (int(st[k % self.RING][0]), int(st[k % self.RING][1]), int(aux[k % self.RING][0]), int(aux[k % self.RING][1]),
+                                  int(aux[k % self.RING][2]))
+            if a1 > a0 and a0 != 0xFFFFFFFFFFFFFFFF and l1 > l0 and l0 != 0xFFFFFFFFFFFFFFFF and e2 >= a1:
+                out.append(((l1 - l0) / self.clock_khz, (e2 - a0) / self.clock_khz))
         return out
 
 

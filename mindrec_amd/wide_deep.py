@@ -359,7 +359,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
             d0 = self._drop(0, B)                  # Dropout on the first layer's input rides the lookup (train_step only)
             self._emb_dropped = d0 is not None
             emb, wprod = self.k.gather_rows_wide(self.deep, ids, wts, cfg.emb_dim, out=self._emb_out(B * Fd, cfg.emb_dim, self._amp), drop=d0,
-                                                 out_dtype=self._amp)
+                                                 out_dtype=self._amp, step_state=self._step_state if self._dyn else None)
             self._tock(ev)
             return emb.view(B, Fd * cfg.emb_dim), _WideProd(wprod), None
         if self._mfma and torch.is_grad_enabled():
@@ -706,6 +706,8 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
                 for slot, (ids, wts, label) in enumerate(inputs):
                     self._slot = slot                 # per-step output buffers of the tail launch (the losses must not alias)
                     front = self._front(ids, wts, label, capturing=True)
+                    if self._sharded and slot + 1 < len(inputs):
+                        self._prefetch_request(*inputs[slot + 1][:2])      # the next step's request exchange, under this step's apply
                     losses.append(self._tail(front, ids, wts))
             sg = {"graph": graph, "inputs": inputs, "losses": losses, "plan": self.last_plan}
             self._sink_graphs[key] = sg

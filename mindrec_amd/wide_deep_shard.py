@@ -38,6 +38,9 @@ class ShardStepMixin:
         self._shard_fold = bool(self._fused_rows and D <= 252 and D % (4 if self._act == torch.float32 else 8) == 0)
         self._overflow = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._overflow_seen = 0
+        self._prefetched = None       # the next step's request (a sink of steps issues it early)
+        # a second side stream: the next step's request exchange / the dense-gradient all-reduce run beside the critical chain
+        self._side2 = torch.cuda.Stream(device=self.device) if self._gpu else None
 
     def shard_overflow(self):
         """Positions dropped so far because an owner's bucket of the request message was full (host sync)."""
@@ -67,17 +70,31 @@ class ShardStepMixin:
         msg[:, Dw] = k.gather_rows(self.wide, rows, wts).reshape(ns)
         return msg
 
+    def _shard_request(self, ids, wts):
+        """The request half of a lookup: positions -> slots, the request exchange.  Needs nothing but the batch, so a sink of
+        steps issues it for step t + 1 on a side branch under step t's sparse apply (train_steps)."""
+        cfg, k = self.cfg, self.k
+        n = ids.numel()
+        cap = k.shard_capacity(n, self.world, cfg.shard_capacity_factor)
+        req, slot_of_pos, pos_of_slot = k.shard_route_slots(ids, wts, self.world, cap, hashed=self._hashed, overflow=self._overflow)
+        recv_req = torch.empty_like(req)
+        self.comm.all_to_all(recv_req, req)
+        return {"ids": ids, "recv_req": recv_req, "slot_of_pos": slot_of_pos, "pos_of_slot": pos_of_slot, "ns": self.world * cap,
+                "stream": torch.cuda.current_stream() if self._gpu else None}
+
     def _shard_lookup(self, ids, wts, want_plan=True):
         """Requests out, answers back.  Returns (emb [B, F * D] act dtype, wprod [B, F, 2] fp32, route state)."""
         cfg, k = self.cfg, self.k
         B, Fd = ids.shape
         D, n, act = cfg.emb_dim, ids.numel(), self._act
-        cap = k.shard_capacity(n, self.world, cfg.shard_capacity_factor)
-        ns = self.world * cap
         ev = self._tick("route")
-        req, slot_of_pos, pos_of_slot = k.shard_route_slots(ids, wts, self.world, cap, hashed=self._hashed, overflow=self._overflow)
-        recv_req = torch.empty_like(req)
-        self.comm.all_to_all(recv_req, req)
+        rq = self._prefetched
+        self._prefetched = None
+        if rq is not None and rq["ids"] is ids:
+            torch.cuda.current_stream().wait_stream(rq["stream"])        # issued on a side branch under the previous step's apply
+        else:
+            rq = self._shard_request(ids, wts)
+        recv_req, slot_of_pos, pos_of_slot, ns = rq["recv_req"], rq["slot_of_pos"], rq["pos_of_slot"], rq["ns"]
         self._tock(ev)
         ev = self._tick("gather_deep")
         plan = recv_wts = rows = None
@@ -132,6 +149,15 @@ class ShardStepMixin:
         route = {"pos_of_slot": pos_of_slot, "recv_wts": recv_wts, "plan": plan, "ns": ns}
         return emb.view(B, Fd * D), wprod.view(B, Fd, 2), route
 
+    def _prefetch_request(self, ids, wts):
+        """A sink of steps: the NEXT step's request exchange on a side branch, behind the MLP of the step in flight -- it runs
+        under that step's gradient exchange and sparse apply instead of in front of the next lookup."""
+        if self._side2 is None:
+            return
+        self._side2.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side2):
+            self._prefetched = self._shard_request(ids, wts)
+
     def _front_sharded(self, ids, wts, label, capturing=False):
         cfg = self.cfg
         emb, wprod, route = self._shard_lookup(ids, wts)
@@ -169,21 +195,25 @@ class ShardStepMixin:
         if self._dyn:
             state = self._step_state
             state.advance(cfg.adam_lr, float(self.beta1), float(self.beta2))
+        # Dense gradients (+ Wide_b's, an element of the same buffer): summed over the batch slabs and all-reduced on a side
+        # branch of their own, beside the row-gradient exchange and the sparse apply -- neither needs them.
+        ev = self._tick("allreduce_dense")
+        main = torch.cuda.current_stream() if self._gpu else None
+        if self._side2 is not None:
+            self._side2.wait_stream(main)
+        with (torch.cuda.stream(self._side2) if self._side2 is not None else _null()):
+            if fused:
+                self._sum_dw_slabs()
+                if not route["wide_b_in_head"]:
+                    self.wide_b_grad.copy_(self.dense_grad[2 * (len(self.dims) - 2) + 1].view(1))      # = the output layer's bias gradient
+            else:
+                self.wide_b_grad.copy_(g_wide.sum().view(1))
+            self.comm.all_reduce(self.dense_grad_flat)
+        self._tock(ev)
         ev = self._tick("a2a_grads")
         gmsg = k.shard_route_grads(g_emb.reshape(n, D), g_wide.reshape(B).contiguous(), Fd, route["pos_of_slot"])
         recv_g = torch.empty_like(gmsg)
         self.comm.all_to_all(recv_g, gmsg)
-        self._tock(ev)
-        # Dense gradients (+ Wide_b's, an element of the same buffer): all-reduce queued behind the row-gradient exchange and
-        # left running while the sparse apply executes -- it does not need it.
-        ev = self._tick("allreduce_dense")
-        if fused:
-            self._sum_dw_slabs()
-            if not route["wide_b_in_head"]:
-                self.wide_b_grad.copy_(self.dense_grad[2 * (len(self.dims) - 2) + 1].view(1))      # = the output layer's bias gradient
-        else:
-            self.wide_b_grad.copy_(g_wide.sum().view(1))
-        dense_work = self.comm.all_reduce(self.dense_grad_flat, async_op=True)
         self._tock(ev)
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)           # the plan (queued under the MLP) is done
@@ -208,8 +238,8 @@ class ShardStepMixin:
             k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, recv_gw, route["recv_wts"], lr=cfg.ftrl_lr,
                            l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=scale)
         self._tock(ev)
-        if dense_work is not None:
-            dense_work.wait()                     # the current stream waits for RCCL's stream; no host block
+        if self._side2 is not None:
+            main.wait_stream(self._side2)         # the all-reduced dense gradient
         ev = self._tick("apply_dense")
         flat = self.dense_flat.detach()
         if fused:

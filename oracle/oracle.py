@@ -355,9 +355,14 @@ def round16(x, dtype):
     x = np.ascontiguousarray(x, np.float32)
     if dtype == "f16":
         return x.astype(np.float16).astype(np.float32)
-    u = x.view(np.uint32).astype(np.uint64)
-    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
-    out = (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32).copy()
+    # (u + 0x7FFF + lsb) >> 16 << 16 in uint32: the sum wraps only for negative NaN payloads, which are fixed up below
+    u = x.view(np.uint32)
+    with np.errstate(over="ignore"):
+        r = (u >> np.uint32(16)) & np.uint32(1)
+        r += np.uint32(0x7FFF)
+        r += u
+        r &= np.uint32(0xFFFF0000)
+    out = r.view(np.float32)
     nan = np.isnan(x)
     out[nan] = np.float32("nan")
     return out.reshape(x.shape)

@@ -15,15 +15,59 @@ configuration with use_mixed_precision (DenseLayer casts input and weight to 16 
   7. operand shadow       the next step's W16 = round16(updated fp32 W)
   8. Dropout (cfg.dropout_flag; :117-118, on every DenseLayer's input while training): the stored 16-bit input is replaced by
      round16(x * mask / keep); the input gradients carry the same factor before their rounding (oracle.dropout_mask)
-Sums the GPU takes in fp32 are taken in float64 here: the oracle is at least as exact as the device."""
+Sums the GPU takes in fp32 are taken in float64 here: the oracle is at least as exact as the device.
+
+fast=True (the long statistical runs: AUC over hundreds of steps at the bench shape, where a float64 numpy step takes ~20 s):
+the same restatement with the three GEMMs of every layer taken by torch's CPU BLAS in fp32 -- the precision of the device's
+accumulators, in the host library's summation order -- and the 16-bit roundings by torch's casts (round-to-nearest-even, as
+oracle.round16).  tests/test_bench_shape_gpu.py checks one fast step against the float64 one."""
 import numpy as np
+import torch
 
 from oracle import oracle as O
 
+_T16 = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32))
+
+
+class _Fast:
+    """oracle.dense_layer / dense_bwd_input / dense_bwd_weight / round16 on torch-CPU fp32 (see the module docstring)."""
+
+    @staticmethod
+    def round16(x, dt):
+        return _t(x).to(_T16[dt]).float().numpy()
+
+    @staticmethod
+    def dense_layer(x16, w16, bias, relu, dt):
+        acc = torch.addmm(_t(bias), _t(x16), _t(w16)) if bias is not None else _t(x16) @ _t(w16)
+        if relu:
+            acc.relu_()
+        return acc.to(_T16[dt]).float().numpy()
+
+    @staticmethod
+    def dense_bwd_input(dy16, w16, h16, dt, scale=1.0, mask=None):
+        g = _t(dy16) @ _t(w16).t()
+        if scale != 1.0:
+            g *= float(np.float32(scale))
+        g = g.to(_T16[dt]).float()
+        if h16 is not None:
+            g = torch.where(_t(h16) > 0, g, torch.zeros((), dtype=torch.float32))
+        elif mask is not None:
+            g = torch.where(_t(mask) > 0, g, torch.zeros((), dtype=torch.float32))
+        return g.numpy(), g.double().sum(dim=0).numpy()
+
+    @staticmethod
+    def dense_bwd_weight(x16, dy16):
+        return (_t(x16).t() @ _t(dy16)).numpy()
+
 
 class OracleMixedEngine:
-    def __init__(self, cfg, dt):
+    def __init__(self, cfg, dt, fast=False):
         self.cfg, self.dt = cfg, dt
+        self._g = _Fast if fast else O              # who takes the GEMMs and the roundings
         V, D = cfg.vocab_size, cfg.emb_dim
         self.deep = O.fill_normal(cfg.seed, V, D, cfg.init_sigma)
         self.deep_m = np.zeros_like(self.deep); self.deep_v = np.zeros_like(self.deep)
@@ -67,9 +111,10 @@ class OracleMixedEngine:
         B, Fd = ids.shape
         nl = len(self.dims) - 1
         r = {}
-        emb = O.round16(O.gather_rows(self.deep, ids, wts).reshape(B, -1), dt)             # 1.
+        G = self._g
+        emb = G.round16(O.gather_rows(self.deep, ids, wts, threads=8).reshape(B, -1), dt)   # 1.
         wide = O.wide_sum(self.wide, ids, wts, float(self.wide_b[0]))
-        W16 = [O.round16(w, dt) for w in self.W]
+        W16 = [G.round16(w, dt) for w in self.W]
         masks = [self._mask(i, B) for i in range(nl)]                                      # 8.
         drop = masks[0] is not None
         scale = float(np.float32(1.0) / np.float32(cfg.dropout_keep_prob)) if drop else 1.0
@@ -77,18 +122,18 @@ class OracleMixedEngine:
             emb = O.dropout(emb, masks[0], dt)
         hs = [emb]
         for i in range(nl - 1):                                                            # 2.
-            h = O.dense_layer(hs[i], W16[i], self.b[i], True, dt)
+            h = G.dense_layer(hs[i], W16[i], self.b[i], True, dt)
             hs.append(O.dropout(h, masks[i + 1], dt) if drop else h)
         head = O.head_fwd_bwd(hs[-1], self.w5, float(self.b5[0]), wide, label, cfg.sens / B, dh_scale=scale)   # 3. (float64 inside)
-        dh = O.round16(head["dh4"].astype(np.float32), dt)
+        dh = G.round16(head["dh4"].astype(np.float32), dt)
         r.update(emb=emb, wide=wide, hs=hs, loss=float(head["loss"]), dlogit=head["dlogit"].astype(np.float32), dh_top=dh)
         gW, gb = [None] * (nl - 1), [None] * (nl - 1)
         gb[nl - 2] = head["db4"]                                                           # sum of the UNrounded dh4 (head kernel)
         for i in range(nl - 2, 0, -1):
-            gW[i] = O.dense_bwd_weight(hs[i], dh)                                          # 5.
-            dh, gb[i - 1] = O.dense_bwd_input(dh, W16[i], hs[i], dt, scale=scale)          # 4.
-        gW[0] = O.dense_bwd_weight(hs[0], dh)
-        g_emb, _ = O.dense_bwd_input(dh, W16[0], None, dt, scale=scale, mask=masks[0])
+            gW[i] = G.dense_bwd_weight(hs[i], dh)                                          # 5.
+            dh, gb[i - 1] = G.dense_bwd_input(dh, W16[i], hs[i], dt, scale=scale)          # 4.
+        gW[0] = G.dense_bwd_weight(hs[0], dh)
+        g_emb, _ = G.dense_bwd_input(dh, W16[0], None, dt, scale=scale, mask=masks[0])
         r.update(gW=gW, gb=gb, gw5=head["dw5"], gb5=head["db5"], g_emb=g_emb)
         return r
 
@@ -122,6 +167,17 @@ class OracleMixedEngine:
         O.dense_adam(self.flat, self.m, self.v, grad, lr=cfg.adam_lr, eps=cfg.adam_eps, b1_pow=float(self.b1p), b2_pow=float(self.b2p),
                      grad_scale=inv)
 
+
+    def predict(self, ids, wts):
+        """PredictWithSigmoid (wide_and_deep.py:495-518) on the engine's inference path: 16-bit hidden layers, fp32 output layer."""
+        G, dt = self._g, self.dt
+        B = ids.shape[0]
+        nl = len(self.dims) - 1
+        h = G.round16(O.gather_rows(self.deep, ids, wts, threads=8).reshape(B, -1), dt)
+        for i in range(nl - 1):
+            h = G.dense_layer(h, G.round16(self.W[i], dt), self.b[i], True, dt)
+        logit = h.astype(np.float64) @ self.w5.astype(np.float64) + float(self.b5[0]) + O.wide_sum(self.wide, ids, wts, float(self.wide_b[0]))
+        return logit, 1.0 / (1.0 + np.exp(-logit))
 
     def train_step(self, ids, wts, label):
         r = self.forward_backward(ids, wts, label)

@@ -47,7 +47,7 @@ def test_one_step_layer_by_layer_vs_mixed_oracle(dev, oracle, dt):
     from _oracle_mixed import OracleMixedEngine
     from mindrec_amd import ops
     from mindrec_amd.wide_deep import WideDeepEngine, synthetic_batch
-    cfg = _cfg(dt) if dt == "bf16" else _cfg(dt, B=4096, V=500_000)          # the reference's own dtype at a quarter of the batch
+    cfg = _cfg(dt)                                                               # both dtypes at the full bench batch
     B, Fd, D = cfg.batch_size, cfg.field_size, cfg.emb_dim
     g = WideDeepEngine(cfg, dev)
     assert g._mfma
@@ -127,7 +127,7 @@ def test_one_step_layer_by_layer_vs_mixed_oracle(dev, oracle, dt):
 @pytest.mark.timeout(1200)
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 def test_free_running_steps_with_graphs_vs_mixed_oracle(dev, oracle, dt):
-    """bf16 (bench.py's default) and the reference's own fp16 (wide_and_deep.py:119-128), both at the full bench batch."""
+    """The reference's own fp16 (wide_and_deep.py:119-128; bench.py's default) and bf16, both at the full bench batch."""
     from _oracle_mixed import OracleMixedEngine
     from mindrec_amd.wide_deep import WideDeepEngine, synthetic_batch
     cfg = _cfg(dt)
@@ -160,3 +160,52 @@ def test_free_running_steps_with_graphs_vs_mixed_oracle(dev, oracle, dt):
     dd = np.abs(g.dense_flat.detach().cpu().numpy().astype(np.float64) - o.flat)
     print(f"  dense parameters: max |diff| = {dd.max():.3e}, fraction within 5 % of lr: {np.mean(dd <= 0.05 * cfg.adam_lr):.5f}")
     assert dd.max() <= 2 * cfg.adam_lr * steps and np.mean(dd <= 0.05 * cfg.adam_lr) >= 0.99
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_auc_parity_on_the_benchmarked_path(dev, oracle, dt):
+    """BASELINE north_star "AUC parity to the reference" ON THE PATH bench.py MEASURES: batch 16384, 26 fields, dim 80, MLP
+    2080-1024-512-256-128-1 in fp16 (the reference's use_mixed_precision, wide_and_deep.py:119-128) and bf16, fused-row fp32
+    tables (V = 2 M so that the oracle's tables fit the host), the whole step replayed as HIP graphs in sinks of 5 steps
+    (train_steps: dataset_sink_mode), 205 steps on a Criteo-like Zipf stream with a planted signal.  The oracle side is the
+    mixed-precision restatement (tests/_oracle_mixed.py, fast=True: fp32 GEMMs on the host).  Both learn (AUC > 0.7 on a
+    held-out batch, models/wide_deep/src/metrics.py:37-52 uses sklearn's roc_auc_score too) and agree within 2e-3."""
+    from _oracle_mixed import OracleMixedEngine
+    from sklearn.metrics import roc_auc_score
+    from mindrec_amd.wide_deep import WideDeepEngine, synthetic_batch
+    cfg = _cfg(dt)
+    g = WideDeepEngine(cfg, dev)
+    o = OracleMixedEngine(cfg, dt, fast=True)
+    S, sinks = 5, 40
+
+    def batch(s):
+        return synthetic_batch(cfg, "cpu", "zipf", seed=7000 + s, signal=True)
+
+    step = 0
+    for _ in range(S):                       # the first steps one by one: the whole-step graph is captured on the fourth
+        ids, wts, label = batch(step)
+        g.train_step(ids.to(dev), wts.to(dev), label.to(dev))
+        o.train_step(ids.numpy(), wts.numpy(), label.numpy().ravel())
+        step += 1
+    assert g._step_graph is not None
+    for _ in range(sinks):
+        bs = [batch(step + j) for j in range(S)]
+        lg = g.train_steps([tuple(t.to(dev) for t in b) for b in bs])
+        lo = [o.train_step(b[0].numpy(), b[1].numpy(), b[2].numpy().ravel()) for b in bs]
+        step += S
+    assert any(v is not None for v in g._sink_graphs.values()), "the sinks must have replayed as one graph of 5 steps"
+    assert step == 205 and g.step_count == 205
+    print(f"  last sink's losses: gpu {[round(float(x), 5) for x in lg]}, oracle {[round(x, 5) for x in lo]}")
+    assert np.allclose([float(x) for x in lg], lo, rtol=5e-3)
+    y, pg, po = [], [], []
+    for s in (99990, 99991):                 # held out: 32768 samples
+        ids, wts, label = batch(s)
+        y.append(label.numpy().ravel())
+        pg.append(g.predict(ids.to(dev), wts.to(dev))[1].cpu().numpy().ravel())
+        po.append(o.predict(ids.numpy(), wts.numpy())[1].ravel())
+    y, pg, po = np.concatenate(y), np.concatenate(pg), np.concatenate(po)
+    auc_g, auc_o = roc_auc_score(y, pg), roc_auc_score(y, po)
+    print(f"  held-out AUC after {step} steps: gpu {auc_g:.5f}, oracle {auc_o:.5f}")
+    assert auc_g > 0.7 and auc_o > 0.7, (auc_g, auc_o)
+    assert abs(auc_g - auc_o) < 2e-3, (auc_g, auc_o)

@@ -274,3 +274,25 @@ def test_dropout_mask_golden_and_scalar_restatement(oracle):
     for keep in (0.5, 0.8, 0.1):
         mk = oracle.dropout_mask(2000, 512, 5, 9, 1, keep)
         assert abs((mk > 0).mean() - keep) <= 5 * np.sqrt(keep * (1 - keep) / mk.size) + 2.0 ** -16
+
+
+def test_fast_mixed_oracle_agrees_with_the_float64_one():
+    """tests/_oracle_mixed.py fast=True (fp32 GEMMs on the host, torch's 16-bit casts) against the float64 numpy restatement:
+    three training steps, both 16-bit dtypes -- losses, tables and dense parameters agree to fp32 accumulation error."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _oracle_mixed import OracleMixedEngine
+    from mindrec_amd.wide_deep import WideDeepConfig, synthetic_batch
+    for dt, name in (("f16", "fp16"), ("bf16", "bf16")):
+        cfg = WideDeepConfig(vocab_size=5000, emb_dim=16, field_size=13, batch_size=256, deep_layer_dim=[64, 32, 16], mlp_dtype=name)
+        a, b = OracleMixedEngine(cfg, dt), OracleMixedEngine(cfg, dt, fast=True)
+        for s in range(3):
+            ids, wts, label = synthetic_batch(cfg, "cpu", "zipf", seed=2 + s, signal=True)
+            la = a.train_step(ids.numpy(), wts.numpy(), label.numpy().ravel())
+            lb = b.train_step(ids.numpy(), wts.numpy(), label.numpy().ravel())
+            assert abs(la - lb) <= 1e-6 * abs(la)
+        assert np.abs(a.deep - b.deep).max() <= 2 * cfg.adam_lr * 3 and np.mean(a.deep == b.deep) > 0.99
+        assert np.abs(a.flat - b.flat).max() <= 2 * cfg.adam_lr * 3 and np.mean(np.abs(a.flat - b.flat) <= 1e-6) > 0.99
+        pa, pb = a.predict(ids.numpy(), wts.numpy())[1], b.predict(ids.numpy(), wts.numpy())[1]
+        assert np.abs(pa - pb).max() <= 1e-3

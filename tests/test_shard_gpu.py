@@ -35,7 +35,7 @@ def test_route_slots_matches_oracle(dev, idt, world, hashed, factor):
     g_ids, g_wts = ops.shard_unpack_req(req)
     assert np.array_equal(g_sop.cpu().numpy(), sop) and np.array_equal(g_pos.cpu().numpy(), pos)
     assert np.array_equal(g_ids.cpu().numpy().astype(np.int64), rid) and np.array_equal(g_wts.cpu().numpy(), rw)
-    assert int(ov.item()) == dropped and (dropped > 0) == (factor < 1.0)
+    assert int(ov.item()) == dropped and (dropped > 0 or factor >= 1.0)       # (factor 0.9: some bucket must overflow; the hot id may fill one at 1.25 too)
     # second call accumulates (sticky counter)
     ops.shard_route_slots(T(ids, dev), T(wts, dev), world, cap, hashed=hashed, overflow=ov)
     assert int(ov.item()) == 2 * dropped

@@ -178,3 +178,91 @@ def test_sharded_hash_tables_match_single_process(dev, tmp_path, world, host_cac
     for k in range(1, world):
         assert np.array_equal(r[0]["dense"], r[k]["dense"])
     assert np.allclose(r[0]["dense"], eng.dense_flat.detach().cpu().numpy(), rtol=1e-4, atol=1e-7)
+
+
+# ---- DeepFM over key-sharded MapParameters (BASELINE configs[4]: the model of the configuration, on shards) ---------------
+def _dfm_cfg(B):
+    from mindrec_amd.deepfm import DeepFMConfig
+    return DeepFMConfig(data_emb_dim=128, data_field_size=6, batch_size=B, deep_layer_dims=[64, 32], learning_rate=1e-2)
+
+
+def _dfm_batch(B, F, seed, dev, pool_id):
+    g = torch.Generator().manual_seed(seed)
+    pool = torch.randint(1, 2 ** 40, (400,), generator=torch.Generator().manual_seed(11 + pool_id), dtype=torch.int64) + (pool_id << 41)
+    keys = pool[torch.randint(0, 400, (B, F), generator=g)]
+    wts = torch.rand(B, F, generator=g)
+    label = (torch.rand(B, 1, generator=g) < 0.4).float()
+    return keys.to(dev), wts.to(dev), label.to(dev)
+
+
+_DFM_PHASES = ((0, 3), (1, 4), (0, 2))          # pool 0, then only pool 1 (pool 0 goes stale and is evicted), then pool 0 again
+
+
+def _dfm_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from _staged_comm import StagedGlooComm
+    from mindrec_amd.deepfm import DeepFMHashEngine
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    Bl = 48
+    eng = DeepFMHashEngine(_dfm_cfg(Bl), dev, key_dtype=torch.int64, capacity=4096, permit_filter_value=2, evict_filter_value=2,
+                           rank=rank, world=world, comm=StagedGlooComm(), shard_capacity_factor=1.5)
+    losses, s = [], 0
+    for pool_id, nsteps in _DFM_PHASES:
+        for _ in range(nsteps):
+            keys, wts, label = _dfm_batch(Bl * world, 6, 500 + s, dev, pool_id)
+            sl = slice(Bl * rank, Bl * (rank + 1))
+            losses.append(float(eng.train_step(keys[sl].contiguous(), wts[sl].contiguous(), label[sl].contiguous())))
+            eng.evict()
+            s += 1
+    assert eng.shard_overflow() == 0
+    keys, wts, _ = _dfm_batch(Bl * world, 6, 999, dev, 0)
+    sl = slice(Bl * rank, Bl * (rank + 1))
+    _, prob = eng.predict(keys[sl].contiguous(), wts[sl].contiguous())
+    kv, vv = eng.V.get_data()
+    kw, vw = eng.W.get_data()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), kv=kv.cpu().numpy(), vv=vv.cpu().numpy(), kw=kw.cpu().numpy(), vw=vw.cpu().numpy(),
+             dense=eng.dense_flat.detach().cpu().numpy(), losses=np.array(losses), prob=prob.cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_deepfm_on_key_sharded_hash_tables_matches_one_gpu(dev, tmp_path, world):
+    """DeepFMHashEngine(world > 1): keys travel to owner = hash(key) mod n over the fixed-capacity exchange, every owner keeps
+    its own index / admission counters (permit 2) / eviction (2 steps) / LazyAdam state; the sharded steps must reproduce the
+    one-GPU engine on the whole batch key by key -- values, which keys are alive after the evictions, the dense net, the
+    losses and a held-out prediction."""
+    from mindrec_amd.deepfm import DeepFMHashEngine
+    mp.spawn(_dfm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
+    Bl = 48
+    eng = DeepFMHashEngine(_dfm_cfg(Bl * world), dev, key_dtype=torch.int64, capacity=4096, permit_filter_value=2, evict_filter_value=2)
+    losses, s = [], 0
+    for pool_id, nsteps in _DFM_PHASES:
+        for _ in range(nsteps):
+            losses.append(float(eng.train_step(*_dfm_batch(Bl * world, 6, 500 + s, dev, pool_id))))
+            eng.evict()
+            s += 1
+    keys, wts, _ = _dfm_batch(Bl * world, 6, 999, dev, 0)
+    _, prob = eng.predict(keys, wts)
+    for tab, kn, vn in ((eng.V, "kv", "vv"), (eng.W, "kw", "vw")):
+        k1, v1 = tab.get_data()
+        ref = {int(k): v for k, v in zip(k1.cpu().numpy(), v1.cpu().numpy())}
+        seen = set()
+        for k in range(world):
+            for key, val in zip(r[k][kn], r[k][vn]):
+                key = int(key)
+                assert key in ref and key not in seen
+                seen.add(key)
+                assert np.allclose(val, ref[key], rtol=2e-4, atol=2e-6), (kn, key)
+        assert seen == set(ref)                                   # the same keys are alive: evictions agree
+    assert np.allclose(sum(r[k]["losses"] for k in range(world)) / world, losses, rtol=1e-5)
+    for k in range(1, world):
+        assert np.array_equal(r[0]["dense"], r[k]["dense"])
+    assert np.allclose(r[0]["dense"], eng.dense_flat.detach().cpu().numpy(), rtol=1e-4, atol=1e-7)
+    assert np.allclose(np.concatenate([r[k]["prob"] for k in range(world)]), prob.cpu().numpy(), rtol=1e-4, atol=1e-6)
