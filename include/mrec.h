@@ -605,10 +605,47 @@ int mrec_cross_layers_bwd_f32(const float* x0, const float* w, const float* b, i
 int mrec_fm_fwd_f32(const float* vx, int64_t B, int32_t F, int32_t D, float* fm_out, float* colsum, void* stream);
 int mrec_fm_bwd_f32(const float* vx, const float* colsum, const float* dout, int64_t B, int32_t F, int32_t D,
                     float* g, void* stream);
+/* The same two with the model's other terms riding along (DeepFMModel.construct, deepfm.py:229-237: out = linear + fm + deep):
+ * fm_out[b] = addend[b] + fm(b) (addend = the linear term: what the MLP's output head takes as its per-sample addend);
+ * g_out[i] = widen(g16[i]) + dout[b] * (colsum - vx[i]): the FM gradient ADDED to the 16-bit input gradient of the
+ * mixed-precision MLP (g16_kind 1 bf16, 2 f16; DenseLayer with convert_dtype, :135-145), written as the fp32 row gradient the
+ * lookup's bprop hands the optimizer.  D % 4 == 0. */
+int mrec_fm_fwd_add_f32(const float* vx, int64_t B, int32_t F, int32_t D, const float* addend, float* fm_out, float* colsum, void* stream);
+int mrec_fm_bwd_mix_f32(const float* vx, const float* colsum, const float* dout, const void* g16, int32_t g16_kind, int64_t B, int32_t F,
+                        int32_t D, float* g_out, void* stream);
 /* table[rows[i], :] += vals[i, :] for distinct rows (rows < 0 skipped): adds a segment-sum into a dense
  * [V, D] gradient that already holds the L2 term (deepfm.py:252-259). */
 int mrec_scatter_add_rows_f32(float* table, int64_t ld, int32_t D, const int32_t* rows, int64_t n,
                               const float* vals, void* stream);
+
+/* ---- DenseLayer in fp32 (convert_dtype=False: Deep&Cross, models/deep_and_cross/src/deep_and_cross.py:94-114,293-309) --------
+ * MatMul + BiasAdd + ReLU and the two MatMul bprops on v_mfma_f32_32x32x2_f32: exact fp32 (a k-ordered chain of fmaf's per
+ * output element), 157 TFLOP/s peak.  Row strides in floats; rows need 4-byte alignment only (16 / 8-byte aligned rows load
+ * wider).
+ *   mrec_dense32_fwd:        y = relu?(x . w + bias): x [M, K], w [K, N], bias [N] (nullable), y [M, N]
+ *   mrec_dense32_bwd_input:  dx = (dy . w^T) masked by h > 0 (h [M, K]: the activation of the layer below, nullable); colsum_ws
+ *                            (nullable): [ceil(M / 128), K] column sums of dx per 128-row tile = partial sums of the layer
+ *                            below's bias gradient, to be added up in tile order (mrec_dense_adam_slabs_f32 does)
+ *   mrec_dense32_bwd_weight: dw_slabs[s] = x[rows of slab s]^T . dy[rows of slab s], fp32 [S, K, N]: the batch is cut into S
+ *                            slabs of ceil(M / S / 32) * 32 rows (mrec_dense32_bwd_weight_slabs proposes an S that fills the chip) */
+int mrec_dense32_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int64_t M, int32_t K, int32_t N,
+                     int relu, float* y, int64_t ldy, void* stream);
+int mrec_dense32_bwd_input(const float* dy, int64_t lddy, const float* w, int64_t ldw, const float* h, int64_t ldh, int64_t M, int32_t K,
+                           int32_t N, float* dx, int64_t lddx, float* colsum_ws, void* stream);
+int mrec_dense32_bwd_weight(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t M, int32_t K, int32_t N, int32_t S,
+                            float* dw_slabs, void* stream);
+int mrec_dense32_bwd_weight_slabs(int64_t M, int32_t K, int32_t N, int32_t* out);
+
+/* The output end of Deep&Cross in one pass (deep_and_cross.py:306-309,326-331): logit = [d2 | c] . w3 + b3 (the concat is never
+ * materialised), loss = mean sigmoid cross-entropy, dlogit = (sigmoid(logit) - label) * dscale, and the bprops that hang off it:
+ * dd2 = dlogit * w3[:H] where d2 > 0 (the gradient at dense_layer_2's pre-activation), dc = dlogit * w3[H:], dw3 = [d2 | c]^T .
+ * dlogit, db3 = sum dlogit, db2 = column sums of dd2.  d2 [B, H] / c [B, X] fp32 with row strides ldd / ldc; H % 4 == 0,
+ * H <= 1024, X % 2 == 0, X <= 1280; batch sums are added in a fixed order (reproducible).  ws: mrec_dcn_head_workspace_bytes. */
+int mrec_dcn_head_workspace_bytes(int64_t B, int32_t H, int32_t X, size_t* out);
+int mrec_dcn_head_fwd_bwd(const float* d2, int64_t ldd, const float* c, int64_t ldc, const float* w3, const float* b3,
+                          const float* label, int64_t B, int32_t H, int32_t X, float dscale, float* logit_out, float* dd2, int64_t lddd,
+                          float* dc, int64_t lddc, float* dw3_out, float* db2_out, float* db3_out, float* loss_out, void* ws,
+                          size_t ws_bytes, void* stream);
 
 /* ---- row-shard routing (hybrid-parallel embedding, README.md:140-144) --------
  * owner(id) = id mod n_shards, local row = id div n_shards.  Stable bucketing of ids by owner so

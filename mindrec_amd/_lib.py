@@ -144,8 +144,17 @@ _SIGS = {
     "mrec_cross_layers_f32": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp],
     "mrec_cross_layers_bwd_workspace_bytes": [_i32, _i64, _i32, _szp],
     "mrec_cross_layers_bwd_f32": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_dcn_head_workspace_bytes": [_i64, _i32, _i32, _szp],
+    "mrec_dcn_head_fwd_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp,
+                              _vp, _sz, _vp],
+    "mrec_dense32_fwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp],
+    "mrec_dense32_bwd_input": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp],
+    "mrec_dense32_bwd_weight": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp],
+    "mrec_dense32_bwd_weight_slabs": [_i64, _i32, _i32, C.POINTER(C.c_int32)],
     "mrec_fm_fwd_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp],
     "mrec_fm_bwd_f32": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
+    "mrec_fm_fwd_add_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp],
+    "mrec_fm_bwd_mix_f32": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp],
     "mrec_scatter_add_rows_f32": [_vp, _i64, _i32, _vp, _i64, _vp, _vp],
     "mrec_shard_route_workspace_bytes": [_i64, _i32, _szp],
     "mrec_shard_route_i32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp],

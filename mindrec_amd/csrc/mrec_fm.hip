@@ -20,7 +20,8 @@ __device__ __forceinline__ float wave_sum_f(float x) {
 }
 
 __global__ __launch_bounds__(256) void k_fm_fwd(const float* __restrict__ vx, int64_t B, int F, int D,
-                                                float* __restrict__ fm_out, float* __restrict__ colsum) {
+                                                float* __restrict__ fm_out, float* __restrict__ colsum,
+                                                const float* __restrict__ add = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t nw = (int64_t)gridDim.x * 4;
     for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += nw) {
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void k_fm_fwd(const float* __restrict__ vx, in
             }
         }
         const float tot = wave_sum_f(part);
-        if (lane == 0) fm_out[b] = 0.5f * tot;
+        if (lane == 0) fm_out[b] = add ? add[b] + 0.5f * tot : 0.5f * tot;
     }
 }
 
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(256) void k_fm_fwd(const float* __restrict__ vx, in
 // Column sums are accumulated in field order exactly as above (colsum stays bit-identical); the sum over the
 // columns is a fixed shuffle tree inside the lane-group.
 __global__ __launch_bounds__(256) void k_fm_fwd4(const float4* __restrict__ vx, int64_t B, int F, int lpr, int G,
-                                                 float* __restrict__ fm_out, float4* __restrict__ colsum) {
+                                                 float* __restrict__ fm_out, float4* __restrict__ colsum,
+                                                 const float* __restrict__ add = nullptr) {
     const int lane = threadIdx.x & 63;
     const int grp = lane / lpr, sub = lane - grp * lpr;
     const bool act = grp < G;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void k_fm_fwd4(const float4* __restrict__ vx, 
             const float o = __shfl_down(part, off, 64);
             if (sub + off < lpr) part += o;
         }
-        if (live && sub == 0) fm_out[b] = 0.5f * part;
+        if (live && sub == 0) fm_out[b] = add ? add[b] + 0.5f * part : 0.5f * part;
     }
 }
 
@@ -122,6 +124,32 @@ __global__ __launch_bounds__(256) void k_fm_bwd4(const float4* __restrict__ vx, 
     }
 }
 
+// g_out[i] = widen(g16[i]) + dout[b] * (colsum[b, d] - vx[i]): the FM term's gradient added onto the 16-bit input gradient of the
+// mixed-precision MLP (DenseLayer with convert_dtype, deepfm.py:135-145), written as the fp32 row gradient of the lookup
+template <bool F16>
+__global__ __launch_bounds__(256) void k_fm_bwd4_mix(const float4* __restrict__ vx, const float4* __restrict__ colsum,
+                                                     const float* __restrict__ dout, const uint2* __restrict__ g16, unsigned total4,
+                                                     unsigned FD4, unsigned D4, float4* __restrict__ g) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += gridDim.x * 256u) {
+        const unsigned b = i / FD4;
+        const unsigned d4 = i % D4;
+        const float w = dout[b];
+        const float4 c = colsum[b * D4 + d4], x = vx[i];
+        const uint2 u = g16[i];
+        float4 y;
+        if (F16) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 a = __builtin_bit_cast(h2, u.x), bb = __builtin_bit_cast(h2, u.y);
+            y = make_float4((float)a[0], (float)a[1], (float)bb[0], (float)bb[1]);
+        } else {
+            y = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                            __uint_as_float(u.y & 0xFFFF0000u));
+        }
+        y.x = y.x + w * (c.x - x.x); y.y = y.y + w * (c.y - x.y); y.z = y.z + w * (c.z - x.z); y.w = y.w + w * (c.w - x.w);
+        g[i] = y;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_scatter_add_rows(float* __restrict__ table, int64_t ld, int D,
                                                           const int* __restrict__ rows, int64_t n,
                                                           const float* __restrict__ vals) {
@@ -137,6 +165,11 @@ __global__ __launch_bounds__(256) void k_scatter_add_rows(float* __restrict__ ta
 
 MREC_API int mrec_fm_fwd_f32(const float* vx, int64_t B, int32_t F, int32_t D, float* fm_out, float* colsum,
                              void* stream) {
+    return mrec_fm_fwd_add_f32(vx, B, F, D, nullptr, fm_out, colsum, stream);
+}
+
+MREC_API int mrec_fm_fwd_add_f32(const float* vx, int64_t B, int32_t F, int32_t D, const float* addend, float* fm_out, float* colsum,
+                                 void* stream) {
     if (B < 0 || F <= 0 || D <= 0) return MREC_EINVAL;
     if (D > 64 * FM_MAXC) return MREC_EUNSUPPORTED;
     if (B == 0) return MREC_OK;
@@ -146,11 +179,11 @@ MREC_API int mrec_fm_fwd_f32(const float* vx, int64_t B, int32_t F, int32_t D, f
         const int lpr = D / 4, G = 64 / lpr;
         int64_t blocks = mrec_cdiv(B, (int64_t)4 * G);
         if (blocks > 256 * 8) blocks = 256 * 8;
-        k_fm_fwd4<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const float4*)vx, B, F, lpr, G, fm_out, (float4*)colsum);
+        k_fm_fwd4<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const float4*)vx, B, F, lpr, G, fm_out, (float4*)colsum, addend);
     } else {
         int64_t blocks = mrec_cdiv(B, 4);
         if (blocks > 256 * 8) blocks = 256 * 8;
-        k_fm_fwd<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(vx, B, F, D, fm_out, colsum);
+        k_fm_fwd<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(vx, B, F, D, fm_out, colsum, addend);
     }
     MREC_LAUNCH_CHECK();
     return MREC_OK;
@@ -174,6 +207,26 @@ MREC_API int mrec_fm_bwd_f32(const float* vx, const float* colsum, const float* 
         if (blocks > 256 * 16) blocks = 256 * 16;
         k_fm_bwd<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(vx, colsum, dout, B, F, D, g);
     }
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+MREC_API int mrec_fm_bwd_mix_f32(const float* vx, const float* colsum, const float* dout, const void* g16, int32_t g16_kind, int64_t B,
+                                 int32_t F, int32_t D, float* g_out, void* stream) {
+    if (B < 0 || F <= 0 || D <= 0 || (g16_kind != 1 && g16_kind != 2)) return MREC_EINVAL;
+    if (B == 0) return MREC_OK;
+    if (!vx || !colsum || !dout || !g16 || !g_out) return MREC_EINVAL;
+    const int64_t total = B * (int64_t)F * D;
+    const bool al = ((((uintptr_t)vx) | ((uintptr_t)colsum) | ((uintptr_t)g_out)) & 15) == 0 && (((uintptr_t)g16) & 7) == 0;
+    if (D % 4 || !al || total / 4 >= (int64_t(1) << 31)) return MREC_EUNSUPPORTED;
+    int64_t blocks = mrec_cdiv(total / 4, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (g16_kind == 2)
+        k_fm_bwd4_mix<true><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const float4*)vx, (const float4*)colsum, dout, (const uint2*)g16,
+                                                                              (unsigned)(total / 4), (unsigned)(F * (D / 4)), (unsigned)(D / 4), (float4*)g_out);
+    else
+        k_fm_bwd4_mix<false><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const float4*)vx, (const float4*)colsum, dout, (const uint2*)g16,
+                                                                               (unsigned)(total / 4), (unsigned)(F * (D / 4)), (unsigned)(D / 4), (float4*)g_out);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }

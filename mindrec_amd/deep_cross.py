@@ -10,8 +10,14 @@ Mirrors models/deep_and_cross/src/deep_and_cross.py of the reference:
                                         the embedding table included (dense UnsortedSegmentSum gradient)
 
 The six cross layers run as ONE HBM pass (mrec_cross_layers_f32 / _bwd_f32); the table's dense
-gradient is the fused segment-sum of the row gradients scattered into a zero [V, D] buffer; the two
-hidden DenseLayers and the output layer are GEMMs (hipBLASLt through torch).
+gradient is the fused segment-sum of the row gradients scattered into a zero [V, D] buffer.  The two
+hidden DenseLayers run in exact fp32 on the fp32-input matrix instruction (csrc/mrec_gemm_f32.hip:
+forward with bias + ReLU epilogue, input gradient with the ReLU mask and the bias gradient's column sums in
+its epilogue, weight gradients as fp32 batch slabs added up inside the dense Adam); the output layer over
+[deep | cross] -- never concatenated --, the loss and every bprop that hangs off the logit are one pass
+(csrc/mrec_dcn.hip).  No library GEMM and no autograd on the product path; with `graphs="step"` the whole
+step -- Adam's bias-correction powers live in device memory -- replays as one HIP graph.  The oracle-side
+engine (tests/) runs a torch restatement of the same math.
 """
 import contextlib
 from dataclasses import dataclass, field
@@ -38,6 +44,7 @@ class DeepCrossConfig:
     loss_scale: float = 1000.0
     seed: int = 1000
     init_sigma: float = 0.01
+    graphs: str = "step"          # "step": the whole training step replays as one HIP graph; "none": kernel by kernel
 
 
 def _flat_views(shapes, device):
@@ -83,9 +90,20 @@ class DeepCrossEngine:
             self.table_m = torch.zeros_like(self.table)
             self.table_v = torch.zeros_like(self.table)
             h1, h2 = cfg.deep_layer_dim
+            # one flat buffer; every parameter starts on a 16-byte boundary (padding elements are parameters nobody reads:
+            # gradient always 0), the whole a multiple of 4 floats: the dense Adam is one float4 launch
             shapes = [(X, h1), (h1,), (h1, h2), (h2,), (X + h2, 1), (1,), (cfg.cross_layer_num, X), (cfg.cross_layer_num, X)]
-            self.dense_flat, self.dense = _flat_views(shapes, dev)
-            self.dense_grad_flat, self.dense_grad = _flat_views(shapes, dev)
+            padded, keep = [], []
+            for sh in shapes:
+                keep.append(len(padded))
+                padded.append(sh)
+                n_ = int(np.prod(sh))
+                if n_ % 4:
+                    padded.append((4 - n_ % 4,))
+            self.dense_flat, views = _flat_views(padded, dev)
+            self.dense = [views[i] for i in keep]
+            self.dense_grad_flat, gviews = _flat_views(padded, dev)
+            self.dense_grad = [gviews[i] for i in keep]
             self.dense_m = torch.zeros_like(self.dense_flat)
             self.dense_v = torch.zeros_like(self.dense_flat)
             self.k.fill_normal_(self.dense_flat.view(-1, 1), cfg.seed + 2, cfg.init_sigma)
@@ -94,18 +112,32 @@ class DeepCrossEngine:
                 p.grad = g
         self.beta1, self.beta2 = np.float32(0.9), np.float32(0.999)
         self.beta1_power, self.beta2_power = np.float32(1.0), np.float32(1.0)
-        if self._gpu:
+        self.step_count = 0
+        h1, h2 = cfg.deep_layer_dim
+        # the hand-written fp32 path: the product on the GPU whenever the output end fits its kernel
+        self._native = bool(self._gpu and self.k is ops and ops.dcn_head_supported(h2, X) and (V * D) % 4 == 0)
+        self._graph = None            # {"ids", "wts", "label", "graph", "loss"}: the captured step and its static inputs
+        self._state = None            # ops.StepState: Adam's powers / step size in device memory (constant kernel arguments)
+        self._state_step = -1
+        self._bufs = {}               # batch size -> the step's persistent intermediates (graph replays write the same buffers)
+        if self._gpu and not self._native:
             from .wide_deep import enable_tuned_gemms
             enable_tuned_gemms()                     # shipped GEMM selections (tools/tune_gemms.py), tuning off
 
     def forward(self, emb):
         W1, b1, W2, b2, W3, b3, cw, cb = self.dense
+        if self._native and not torch.is_grad_enabled():
+            d1 = self.k.dense32_fwd(emb, W1.detach(), b1.detach(), relu=True)
+            d2 = self.k.dense32_fwd(d1, W2.detach(), b2.detach(), relu=True)
+            c = self.k.cross_layers(emb, cw.detach(), cb.detach())
+            h2 = d2.shape[1]
+            w3 = W3.detach()
+            return ((d2 * w3[:h2, 0]).sum(dim=1) + (c * w3[h2:, 0]).sum(dim=1)).view(-1, 1) + b3.detach()
         d1 = torch.relu(torch.addmm(b1, emb, W1))
         d2 = torch.relu(torch.addmm(b2, d1, W2))
         c = _CrossStack.apply(emb, cw, cb, self.k)
         # concat([deep, cross]) . W3 (deep_and_cross.py:306-308) on the halves of W3, without materialising the
-        # [B, 2194] concat.  An N = 1 product is a GEMV: through the GEMM library it ran at 50-130 us per call
-        # (forward and both backward products); as a broadcast multiply + row sum it is a bandwidth-bound pass.
+        # [B, 2194] concat.
         h2 = d2.shape[1]
         return ((d2 * W3[:h2, 0]).sum(dim=1) + (c * W3[h2:, 0]).sum(dim=1)).view(-1, 1) + b3
 
@@ -116,8 +148,93 @@ class DeepCrossEngine:
             logit = self.forward(emb)
         return logit, torch.sigmoid(logit)
 
+    # ---- the hand-written step ------------------------------------------------------------------------------------------
+    def _buffers(self, B):
+        """Intermediates of a step at batch B (allocated once: a captured step writes the same addresses every replay)."""
+        b = self._bufs.get(B)
+        if b is None:
+            cfg, k, dev = self.cfg, self.k, self.device
+            X = cfg.field_size * cfg.emb_dim
+            h1, h2 = cfg.deep_layer_dim
+            f32 = dict(dtype=torch.float32, device=dev)
+            T = k.dense32_colsum_tiles(B)
+            b = {"d1": torch.empty((B, h1), **f32), "d2": torch.empty((B, h2), **f32), "dd1": torch.empty((B, h1), **f32),
+                 "g2": torch.empty((2, B, X), **f32),             # the MLP's and the cross stack's input gradients, added up below
+                 "g": torch.empty((B, X), **f32), "head": {},
+                 "dW1": torch.empty((k.dense32_bwd_weight_slabs(B, X, h1), X, h1), **f32),
+                 "dW2": torch.empty((k.dense32_bwd_weight_slabs(B, h1, h2), h1, h2), **f32),
+                 "db1": torch.empty((T, h1), **f32), "gtab": torch.empty_like(self.table)}
+            self._bufs[B] = b
+        return b
+
+    def _step_native(self, ids, wts, label):
+        """One training step, kernel by kernel (every argument constant from step to step: capturable)."""
+        cfg, k = self.cfg, self.k
+        B, Fd = ids.shape
+        D = cfg.emb_dim
+        X = Fd * D
+        W1, b1, W2, b2, W3, b3, cw, cb = [p.detach() for p in self.dense]
+        gW1, gb1, gW2, gb2, gW3, gb3, gcw, gcb = self.dense_grad
+        bf = self._buffers(B)
+        self._state.advance(cfg.learning_rate, float(self.beta1), float(self.beta2))
+        emb = k.gather_rows(self.table, ids, wts).view(B, X)
+        d1 = k.dense32_fwd(emb, W1, b1, relu=True, out=bf["d1"])
+        d2 = k.dense32_fwd(d1, W2, b2, relu=True, out=bf["d2"])
+        c = k.cross_layers(emb, cw, cb)
+        loss, _, dd2, dc = k.dcn_head_fwd_bwd(d2, c, W3.view(-1), b3, label.view(-1), cfg.loss_scale / B, gW3.view(-1), gb2, gb3,
+                                              out=bf["head"])
+        k.dense32_bwd_weight(d1, dd2, bf["dW2"])
+        dd1 = k.dense32_bwd_input(dd2, W2, h=d1, out=bf["dd1"], colsum=bf["db1"])
+        k.dense32_bwd_weight(emb, dd1, bf["dW1"])
+        k.dense32_bwd_input(dd1, W1, out=bf["g2"][0])
+        k.cross_layers_bwd(emb, cw, cb, dc, dx0_out=bf["g2"][1], dw_out=gcw, db_out=gcb)
+        g = k.sum_slabs(bf["g2"].view(2, B * X), bf["g"].view(-1)).view(B, X)
+        # dense table gradient = UnsortedSegmentSum of the masked row gradients (bprop of Gather)
+        plan = k.sparse_plan(ids)
+        sums = k.segment_sum(plan, g.view(B * Fd, D), wts)
+        gtab = bf["gtab"]
+        gtab.zero_()
+        k.scatter_unique_rows_(gtab, plan, sums)
+        kw = dict(lr=cfg.learning_rate, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.eps, beta1_power=0.0, beta2_power=0.0,
+                  grad_scale=1.0 / cfg.loss_scale, step_state=self._state)
+        k.dense_adam_slabs_(self.table.view(-1), self.table_m.view(-1), self.table_v.view(-1), gtab.view(-1), [], **kw)
+        slabs = [(gW1.storage_offset(), bf["dW1"]), (gW2.storage_offset(), bf["dW2"]), (gb1.storage_offset(), bf["db1"])]
+        k.dense_adam_slabs_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, slabs, **kw)
+        return loss.view(())
+
+    def _train_step_native(self, ids, wts, label):
+        if self._state is None:
+            self._state = self.k.StepState(self.device)
+        if self._state_step != self.step_count:
+            self._state.reset(self.beta1_power, self.beta2_power, self.step_count)
+        self.step_count += 1
+        self.beta1_power = np.float32(self.beta1_power * self.beta1)
+        self.beta2_power = np.float32(self.beta2_power * self.beta2)
+        self._state_step = self.step_count
+        if self.cfg.graphs != "step" or self.step_count <= 2:        # (the first steps run eagerly: workspaces come into being)
+            return self._step_native(ids, wts, label)
+        g = self._graph
+        if g is None or g["ids"].shape != ids.shape or g["ids"].dtype != ids.dtype:
+            g = {"ids": ids.clone(), "wts": wts.clone(), "label": label.clone()}
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                g["loss"] = self._step_native(g["ids"], g["wts"], g["label"])
+            g["graph"] = graph
+            self._graph = g
+        self.k.copy3_((g["ids"], g["wts"], g["label"]), (ids, wts, label))
+        g["graph"].replay()
+        return g["loss"]
+
     def train_step(self, ids, wts, label):
+        if self._native:
+            return self._train_step_native(ids, wts, label)
+        return self._train_step_autograd(ids, wts, label)
+
+    def _train_step_autograd(self, ids, wts, label):
+        """The torch restatement (the oracle-side engine; shapes the output kernel does not cover)."""
         cfg = self.cfg
+        self.step_count += 1
         B, Fd = ids.shape
         D = cfg.emb_dim
         self.beta1_power = np.float32(self.beta1_power * self.beta1)

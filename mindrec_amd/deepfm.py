@@ -9,7 +9,11 @@ Mirrors models/deepfm/src/deepfm.py of the reference:
 Both tables carry an L2 term over every row, so their gradients are dense: sens * l2_coef * table, plus
 the segment-sum of the row gradients scattered onto the touched rows; Adam then sweeps the whole tables
 (vocab 184 965: 59 MB, trivial next to the batch).  Lookups, the FM term (one pass, mrec_fm.hip), the
-segment-sums and the Adam sweeps are libmrec_hip.so kernels; the MLP GEMMs go to hipBLASLt through torch.
+segment-sums and the Adam sweeps are libmrec_hip.so kernels, and so is the dense net in the reference's
+precision (convert_dtype: float16): the hand-written MFMA DenseLayer kernels of the Wide&Deep step
+(mindrec_amd/wide_deep_mlp.py: forward with bias + ReLU epilogues, fused backward, the tail of the net as one
+launch, dense Adam over fp32 batch slabs), the output head taking linear + fm as its per-sample addend.
+mlp_dtype="fp32" keeps a torch restatement (library GEMMs) -- the form the oracle-side engine runs.
 """
 import contextlib
 from dataclasses import dataclass, field
@@ -20,6 +24,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
+from .wide_deep_mlp import DenseNetMixin
 
 
 @dataclass
@@ -36,7 +41,9 @@ class DeepFMConfig:
     loss_scale: float = 1024.0
     seed: int = 1000
     init_sigma: float = 0.01
-    mlp_dtype: str = "fp32"
+    mlp_dtype: str = "fp16"       # DenseLayer casts input, weight and bias to float16 (convert_dtype: True, default_config.yaml:27;
+                                  # deepfm.py:135-145); "bf16" runs the same kernels, "fp32" the library GEMMs through torch
+    graphs: str = "mlp"           # "mlp": the dense net's step replays as HIP graphs (16-bit net), "none": kernel by kernel
 
 
 class _FMTerm(torch.autograd.Function):
@@ -55,7 +62,60 @@ class _FMTerm(torch.autograd.Function):
         return g, None
 
 
-class DeepFMEngine:
+class _DeepFMNet(DenseNetMixin):
+    """The dense side both DeepFM engines share: DenseNetMixin's state and 16-bit MFMA step when the shapes allow it
+    (self._mfma), the torch fp32 restatement otherwise."""
+
+    def _init_net(self, cfg, dims):
+        self._amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[cfg.mlp_dtype]
+        self._mfma = bool(self._gpu and self.k is ops and self._amp is not None and self.mfma_net_ok(dims) and cfg.data_emb_dim % 4 == 0)
+        self._graph_level = 1 if (cfg.graphs == "mlp" and self._mfma) else 0
+        self.rank, self.step_count, self._step_state = getattr(self, "rank", 0), 0, None
+        self._dropout = self._training = self._emb_dropped = False
+        self._init_dense_net(dims, cfg.seed + 2, cfg.init_sigma, cfg.loss_scale)
+        self.beta1, self.beta2 = np.float32(0.9), np.float32(0.999)
+        self.beta1_power, self.beta2_power = np.float32(1.0), np.float32(1.0)
+
+    def _adam_kw(self, grad_scale):
+        cfg = self.cfg
+        return dict(lr=cfg.learning_rate, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.epsilon,
+                    beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=grad_scale)
+
+    def _mlp(self, x):
+        """DenseLayer x5 (deepfm.py:98-150): the 16-bit kernels' inference path, or the torch restatement."""
+        return self.mlp(x)
+
+    def _net_step(self, vx, vx16, linear, label):
+        """Forward + backward of everything behind the lookups: FM term, the dense net, the loss.  Returns (loss, g_vx fp32
+        [B, F, D], g_linear [B]); dense gradients are left in the slabs / the flat gradient buffer for _dense_adam."""
+        cfg = self.cfg
+        B, Fd, D = vx.shape
+        if self._mfma:
+            lin_fm, cs = self.k.fm_forward(vx, add=linear)                     # linear + fm: the output head's per-sample addend
+            loss, g16, dlogit = self._mlp_step(vx16.view(B, Fd * D), lin_fm, label)
+            return loss, self.k.fm_backward_mix(g16.view(B, Fd, D), vx, cs, dlogit), dlogit
+        vx.requires_grad_(True)
+        linear.requires_grad_(True)
+        self.dense_grad_flat.zero_()
+        fm = _FMTerm.apply(vx, self.k)
+        logit = (linear + fm).view(-1, 1) + self.mlp(vx.view(B, Fd * D))
+        loss = F.binary_cross_entropy_with_logits(logit, label)
+        (loss * cfg.loss_scale).backward()
+        return loss.detach(), vx.grad, linear.grad
+
+    def _dense_adam(self, grad_scale, summed=False):
+        """nn.Adam over the dense net.  summed: the weight-gradient slabs have been added into the flat gradient already (a shard
+        all-reduces the sum)."""
+        kw = self._adam_kw(grad_scale)
+        if self._mfma:
+            self.k.dense_adam_slabs_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat,
+                                     [] if summed else self._slab_segments(), shadow16=self.dense16_flat, **kw)
+            self._refresh_tail()
+        else:
+            self.k.dense_adam_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, **kw)
+
+
+class DeepFMEngine(_DeepFMNet):
     _kernels = ops               # the op set (tests/ subclass the engine with the oracle's restatements to check it step for step)
     _allow_cpu = False           # the product has no CPU path
 
@@ -72,45 +132,10 @@ class DeepFMEngine:
             self.W_l2 = torch.empty((V, 1), dtype=torch.float32, device=dev)
             self.k.fill_normal_(self.W_l2, cfg.seed + 1, cfg.init_sigma)
             self.state = {n: (torch.zeros_like(t), torch.zeros_like(t)) for n, t in (("V", self.V_l2), ("W", self.W_l2))}
-            dims = [cfg.data_field_size * D] + list(cfg.deep_layer_dims) + [1]
-            self.dims = dims
-            shapes = []
-            for i in range(len(dims) - 1):
-                shapes += [(dims[i], dims[i + 1]), (dims[i + 1],)]
-            n = sum(int(np.prod(s)) for s in shapes)
-            self.dense_flat = torch.zeros(n, dtype=torch.float32, device=dev)
-            self.dense_grad_flat = torch.zeros(n, dtype=torch.float32, device=dev)
-            self.k.fill_normal_(self.dense_flat.view(-1, 1), cfg.seed + 2, cfg.init_sigma)
-            self.dense, off = [], 0
-            for s in shapes:
-                k = int(np.prod(s))
-                p = self.dense_flat[off:off + k].view(s)
-                p.requires_grad_(True)
-                p.grad = self.dense_grad_flat[off:off + k].view(s)
-                self.dense.append(p)
-                off += k
-            self.dense_m = torch.zeros_like(self.dense_flat)
-            self.dense_v = torch.zeros_like(self.dense_flat)
-        self.beta1, self.beta2 = np.float32(0.9), np.float32(0.999)
-        self.beta1_power, self.beta2_power = np.float32(1.0), np.float32(1.0)
-        self._amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[cfg.mlp_dtype]
-        if self._gpu:
+            self._init_net(cfg, [cfg.data_field_size * D] + list(cfg.deep_layer_dims) + [1])
+        if self._gpu and not self._mfma:
             from .wide_deep import enable_tuned_gemms
             enable_tuned_gemms()                     # shipped GEMM selections (tools/tune_gemms*.py), tuning off
-
-    def _mlp(self, x):
-        n = len(self.dims) - 1
-        amp = self._amp
-        h = x.to(amp) if amp is not None else x
-        for i in range(n):
-            W, b = self.dense[2 * i], self.dense[2 * i + 1]
-            if amp is not None and i < n - 1:
-                h = torch.addmm(b.to(amp), h, W.to(amp))
-            else:
-                h = torch.addmm(b, h.float(), W)
-            if i < n - 1:
-                h = torch.relu(h)
-        return h.float()
 
     def _forward(self, ids, wts):
         cfg = self.cfg
@@ -133,34 +158,30 @@ class DeepFMEngine:
         D = cfg.data_emb_dim
         self.beta1_power = np.float32(self.beta1_power * self.beta1)
         self.beta2_power = np.float32(self.beta2_power * self.beta2)
+        self.step_count += 1
         vx, linear = self._forward(ids, wts)
-        vx.requires_grad_(True)
-        linear.requires_grad_(True)
-        self.dense_grad_flat.zero_()
-        fm = _FMTerm.apply(vx, self.k)
-        logit = (linear + fm).view(-1, 1) + self._mlp(vx.view(B, Fd * D))
-        log_loss = F.binary_cross_entropy_with_logits(logit, label)
+        vx16 = self.k.gather_rows(self.V_l2, ids, wts, out_dtype=self._amp) if self._mfma else None     # the net's input, rounded once
         with torch.no_grad():
             l2 = cfg.l2_coef * 0.5 * ((self.V_l2 * self.V_l2).sum() + (self.W_l2 * self.W_l2).sum())
-        (log_loss * cfg.loss_scale).backward()
+        log_loss, g_vx, g_lin = self._net_step(vx, vx16, linear, label)
         loss = log_loss.detach() + l2
         # dense table gradients: sens * l2_coef * table everywhere, plus the segment-sums on the touched rows
         plan = self.k.sparse_plan(ids)
         sens = cfg.loss_scale
         kw = dict(lr=cfg.learning_rate, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.epsilon,
                   beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=1.0 / sens)
-        for name, table, g, scale in (("V", self.V_l2, vx.grad.view(B * Fd, D), wts),
-                                      ("W", self.W_l2, (linear.grad.view(B, 1) * wts).view(B * Fd, 1), None)):
+        for name, table, g, scale in (("V", self.V_l2, g_vx.view(B * Fd, D), wts),
+                                      ("W", self.W_l2, (g_lin.view(B, 1) * wts).view(B * Fd, 1), None)):
             gtab = table * (cfg.l2_coef * sens)
             sums = self.k.segment_sum(plan, g, scale)
             self.k.scatter_unique_rows_add_(gtab, plan, sums)
             m, v = self.state[name]
             self.k.dense_adam_(table.view(-1), m.view(-1), v.view(-1), gtab.view(-1), **kw)
-        self.k.dense_adam_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, **kw)
+        self._dense_adam(1.0 / sens)
         return loss
 
 
-class DeepFMHashEngine:
+class DeepFMHashEngine(_DeepFMNet):
     """BASELINE configs[4]: the DeepFM model over MapParameter hash embeddings (int64 keys, dim 128,
     admission / eviction filters on).  The reference contains the two halves but not this composition
     (only models/wide_deep builds a HashEmbeddingLookup, wide_and_deep.py:271-274), so it is assembled
@@ -199,46 +220,12 @@ class DeepFMHashEngine:
         for t in (self.V, self.W):
             t.add_slot("moment1", 0.0)
             t.add_slot("moment2", 0.0)
-        dims = [cfg.data_field_size * D] + list(cfg.deep_layer_dims) + [1]
-        self.dims = dims
-        shapes = []
-        for i in range(len(dims) - 1):
-            shapes += [(dims[i], dims[i + 1]), (dims[i + 1],)]
-        n = sum(int(np.prod(s)) for s in shapes)
+        self.k, self._gpu = ops, True
         with torch.cuda.device(dev):
-            self.dense_flat = torch.zeros(n, dtype=torch.float32, device=dev)
-            self.dense_grad_flat = torch.zeros(n, dtype=torch.float32, device=dev)
-            ops.fill_normal_(self.dense_flat.view(-1, 1), cfg.seed + 2, cfg.init_sigma)
-            self.dense, off = [], 0
-            for s in shapes:
-                k = int(np.prod(s))
-                p = self.dense_flat[off:off + k].view(s)
-                p.requires_grad_(True)
-                p.grad = self.dense_grad_flat[off:off + k].view(s)
-                self.dense.append(p)
-                off += k
-            self.dense_m = torch.zeros_like(self.dense_flat)
-            self.dense_v = torch.zeros_like(self.dense_flat)
-        self.beta1, self.beta2 = np.float32(0.9), np.float32(0.999)
-        self.beta1_power, self.beta2_power = np.float32(1.0), np.float32(1.0)
-        self._amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[cfg.mlp_dtype]
-        from .wide_deep import enable_tuned_gemms
-        enable_tuned_gemms()
-
-    def _mlp(self, x):
-        """Hidden layers in cfg.mlp_dtype (bf16: MFMA GEMMs, fp32 master weights cast per step), last layer fp32."""
-        n = len(self.dims) - 1
-        amp = self._amp
-        h = x.to(amp) if amp is not None else x
-        for i in range(n):
-            W, b = self.dense[2 * i], self.dense[2 * i + 1]
-            if amp is not None and i < n - 1:
-                h = torch.addmm(b.to(amp), h, W.to(amp))
-            else:
-                h = torch.addmm(b, h.float(), W)
-            if i < n - 1:
-                h = torch.relu(h)
-        return h.float()
+            self._init_net(cfg, [cfg.data_field_size * D] + list(cfg.deep_layer_dims) + [1])
+        if not self._mfma:
+            from .wide_deep import enable_tuned_gemms
+            enable_tuned_gemms()
 
     def _lookup(self, keys, insert):
         flat = self.V._keys(keys)
@@ -284,25 +271,22 @@ class DeepFMHashEngine:
         D = cfg.data_emb_dim
         vx, linear, route = self._shard_lookup(keys, wts, train=None)
         plan = ops.sparse_plan(route["rows"], skip_negative=True)         # Unique + inverted index of the received rows
-        vx.requires_grad_(True)
-        linear.requires_grad_(True)
-        self.dense_grad_flat.zero_()
-        fm = _FMTerm.apply(vx, ops)
-        logit = (linear + fm).view(-1, 1) + self._mlp(vx.view(B, Fd * D))
-        loss = F.binary_cross_entropy_with_logits(logit, label)
-        (loss * cfg.loss_scale).backward()
-        gmsg = ops.shard_route_grads(vx.grad.view(B * Fd, D), linear.grad.view(B).contiguous(), Fd, route["pos_of_slot"])
+        vx16 = vx.to(self._amp) if self._mfma else None                    # (the rows arrive in fp32: the FM term wants them so)
+        loss, g_vx, g_lin = self._net_step(vx, vx16, linear.contiguous(), label)
+        gmsg = ops.shard_route_grads(g_vx.view(B * Fd, D), g_lin.view(B).contiguous(), Fd, route["pos_of_slot"])
         recv_g = torch.empty_like(gmsg)
         self.comm.all_to_all(recv_g, gmsg)
+        if self._mfma:
+            self._sum_dw_slabs()
         self.comm.all_reduce(self.dense_grad_flat)
         # gradients_mean: the owner sums the row gradients of all ranks, the mean divides by their number
-        kw = dict(lr=cfg.learning_rate, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.epsilon,
-                  beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=1.0 / (cfg.loss_scale * self.world))
+        scale = 1.0 / (cfg.loss_scale * self.world)
+        kw = self._adam_kw(scale)
         rows_u = plan.uniq_buf
         for t, g in ((self.V, recv_g[:, :D]), (self.W, recv_g[:, D:D + 1])):
             plan.uniq_buf = t.admitted_rows(rows_u)               # groups -> table rows, un-admitted keys -> -1 (skipped)
             ops.sparse_lazy_adam_(t.values, t.slots["moment1"]["table"], t.slots["moment2"]["table"], plan, g, route["recv_wts"], **kw)
-        ops.dense_adam_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, **kw)
+        self._dense_adam(scale, summed=True)
         return loss.detach()
 
     def predict(self, keys, wts):
@@ -324,26 +308,21 @@ class DeepFMHashEngine:
         D = cfg.data_emb_dim
         self.beta1_power = np.float32(self.beta1_power * self.beta1)
         self.beta2_power = np.float32(self.beta2_power * self.beta2)
+        self.step_count += 1
         if self.world > 1:
             return self._train_step_sharded(keys, wts, label)
         d, rows_v, pos_v, rows_w, pos_w = self._lookup(keys, insert=True)
         vx = ops.gather_rows(self.V.values, pos_v.view(B, Fd), wts)             # [B, F, D], mask fused
+        vx16 = ops.gather_rows(self.V.values, pos_v.view(B, Fd), wts, out_dtype=self._amp) if self._mfma else None
         linear = ops.wide_sum(self.W.values, pos_w.view(B, Fd), wts)             # [B]
-        vx.requires_grad_(True)
-        linear.requires_grad_(True)
-        self.dense_grad_flat.zero_()
-        fm = _FMTerm.apply(vx, ops)
-        logit = (linear + fm).view(-1, 1) + self._mlp(vx.view(B, Fd * D))
-        loss = F.binary_cross_entropy_with_logits(logit, label)
-        (loss * cfg.loss_scale).backward()
-        kw = dict(lr=cfg.learning_rate, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.epsilon,
-                  beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=1.0 / cfg.loss_scale)
+        loss, g_vx, g_lin = self._net_step(vx, vx16, linear, label)
+        kw = self._adam_kw(1.0 / cfg.loss_scale)
         plan = ops.group_by_inverse(d)
-        for t, rows_u, g, scale in ((self.V, rows_v, vx.grad.view(B * Fd, D), wts),
-                                    (self.W, rows_w, (linear.grad.view(B, 1) * wts).view(B * Fd, 1), None)):
+        for t, rows_u, g, scale in ((self.V, rows_v, g_vx.view(B * Fd, D), wts),
+                                    (self.W, rows_w, (g_lin.view(B, 1) * wts).view(B * Fd, 1), None)):
             plan.uniq_buf = t.admitted_rows(rows_u)               # groups -> table rows, un-admitted keys -> -1 (skipped)
             ops.sparse_lazy_adam_(t.values, t.slots["moment1"]["table"], t.slots["moment2"]["table"], plan, g, scale, **kw)
-        ops.dense_adam_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, **kw)
+        self._dense_adam(1.0 / cfg.loss_scale)
         return loss.detach()
 
     def evict(self):

@@ -680,14 +680,18 @@ def cross_layers(x0, w, b):
     return out
 
 
-def cross_layers_bwd(x0, w, b, dy):
-    _need_cuda(x0, w, b, dy)
+def cross_layers_bwd(x0, w, b, dy, dx0_out=None, dw_out=None, db_out=None):
+    """(dx0, dw, db) of the cross stack; *_out: contiguous tensors to write into (views of a flat gradient buffer)."""
+    _need_cuda(x0, w, b, dy, dx0_out, dw_out, db_out)
     x0 = x0.contiguous(); w = w.contiguous(); b = b.contiguous(); dy = dy.contiguous()
     B, D = x0.shape
     L = w.shape[0]
-    dx0 = torch.empty_like(x0)
-    dw = torch.empty_like(w)
-    db = torch.empty_like(b)
+    for t_, ref in ((dx0_out, x0), (dw_out, w), (db_out, b)):
+        if t_ is not None and (t_.shape != ref.shape or t_.dtype != torch.float32 or not t_.is_contiguous()):
+            raise TypeError("cross_layers_bwd: outputs must be contiguous float32 tensors of the inputs' shapes")
+    dx0 = dx0_out if dx0_out is not None else torch.empty_like(x0)
+    dw = dw_out if dw_out is not None else torch.empty_like(w)
+    db = db_out if db_out is not None else torch.empty_like(b)
     nb = _lib.query_bytes("mrec_cross_layers_bwd_workspace_bytes", L, B, D)
     ws = workspace("cross", nb, x0.device)
     _lib.call("mrec_cross_layers_bwd_f32", _ptr(x0), _ptr(w), _ptr(b), L, B, D, _ptr(dy), _ptr(dx0), _ptr(dw), _ptr(db),
@@ -1338,16 +1342,129 @@ def dense_adam_slabs_(p, m, v, g, slabs, shadow16=None, lr=1e-3, beta1=0.9, beta
               _ptr(step_state.buf) if step_state is not None else None, _stream())
 
 
+# ---- DenseLayer in fp32 on the fp32-input matrix instruction (csrc/mrec_gemm_f32.hip) -----------------------------------
+def _mat32(t, name):
+    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+        raise TypeError(f"{name} must be a float32 [rows, cols] tensor with unit column stride")
+    return t.shape[0], t.shape[1], (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+
+
+def dense32_fwd(x, w, bias=None, relu=True, out=None):
+    """DenseLayer.construct with convert_dtype=False (deep_and_cross.py:94-114): act(x . w + bias) in exact fp32."""
+    _need_cuda(x, w, bias, out)
+    M, K, ldx = _mat32(x, "x")
+    K2, N, ldw = _mat32(w, "w")
+    if K2 != K:
+        raise TypeError("dense32_fwd: x [M, K], w [K, N]")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N or not bias.is_contiguous()):
+        raise TypeError("bias must be contiguous float32 [N]")
+    y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=x.device)
+    M2, N2, ldy = _mat32(y, "out")
+    if (M2, N2) != (M, N):
+        raise TypeError("out must be [M, N]")
+    _lib.call("mrec_dense32_fwd", _ptr(x), ldx, _ptr(w), ldw, _ptr(bias), M, K, N, int(bool(relu)), _ptr(y), ldy, _stream())
+    return y
+
+
+def dense32_colsum_tiles(M):
+    return (int(M) + 127) // 128
+
+
+def dense32_bwd_input(dy, w, h=None, out=None, colsum=None):
+    """dx = (dy . w^T) masked by h > 0; colsum (optional fp32 [ceil(M / 128), K]): per-tile-row column sums of dx."""
+    _need_cuda(dy, w, h, out, colsum)
+    M, N, lddy = _mat32(dy, "dy")
+    K, N2, ldw = _mat32(w, "w")
+    if N2 != N:
+        raise TypeError("dense32_bwd_input: dy [M, N], w [K, N]")
+    dx = out if out is not None else torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    M2, K2, lddx = _mat32(dx, "out")
+    if (M2, K2) != (M, K):
+        raise TypeError("out must be [M, K]")
+    ldh = 0
+    if h is not None:
+        M3, K3, ldh = _mat32(h, "h")
+        if (M3, K3) != (M, K):
+            raise TypeError("h must be [M, K]")
+    if colsum is not None and (colsum.dtype != torch.float32 or tuple(colsum.shape) != (dense32_colsum_tiles(M), K) or not colsum.is_contiguous()):
+        raise TypeError("colsum must be contiguous float32 [ceil(M / 128), K]")
+    _lib.call("mrec_dense32_bwd_input", _ptr(dy), lddy, _ptr(w), ldw, _ptr(h), ldh, M, K, N, _ptr(dx), lddx, _ptr(colsum), _stream())
+    return dx
+
+
+def dense32_bwd_weight_slabs(M, K, N):
+    s = C.c_int32(0)
+    _lib.call("mrec_dense32_bwd_weight_slabs", M, K, N, C.byref(s))
+    return int(s.value)
+
+
+def dense32_bwd_weight(x, dy, out_slabs):
+    """out_slabs[s] = x[slab s]^T . dy[slab s], fp32 [S, K, N]."""
+    _need_cuda(x, dy, out_slabs)
+    M, K, ldx = _mat32(x, "x")
+    M2, N, lddy = _mat32(dy, "dy")
+    if M2 != M or out_slabs.dtype != torch.float32 or out_slabs.dim() != 3 or tuple(out_slabs.shape[1:]) != (K, N) or not out_slabs.is_contiguous():
+        raise TypeError("dense32_bwd_weight: x [M, K], dy [M, N], out_slabs contiguous float32 [S, K, N]")
+    _lib.call("mrec_dense32_bwd_weight", _ptr(x), ldx, _ptr(dy), lddy, M, K, N, out_slabs.shape[0], _ptr(out_slabs), _stream())
+    return out_slabs
+
+
+def dcn_head_supported(H, X):
+    return H % 4 == 0 and H <= 1024 and X % 2 == 0 and X <= 1280
+
+
+def dcn_head_fwd_bwd(d2, c, w3, b3, label, dscale, dw3_out, db2_out, db3_out, out=None):
+    """Deep&Cross output layer over [d2 | c] without the concat + sigmoid cross-entropy + every bprop that hangs off the logit, one
+    pass (csrc/mrec_dcn.hip).  Returns (loss [1], logit [B], dd2 [B, H], dc [B, X]); dw3_out [H + X], db2_out [H], db3_out [1]
+    receive the batch sums.  out: dict of preallocated "loss", "logit", "dd2", "dc"."""
+    _need_cuda(d2, c, w3, b3, label, dw3_out, db2_out, db3_out)
+    B, H, ldd = _mat32(d2, "d2")
+    B2, X, ldc = _mat32(c, "c")
+    if B2 != B or w3.numel() != H + X or not w3.is_contiguous() or w3.dtype != torch.float32 or label.numel() != B:
+        raise TypeError("dcn_head_fwd_bwd: d2 [B, H], c [B, X], w3 [H + X], label [B]")
+    o = out if out is not None else {}
+    dev = d2.device
+
+    def buf(name, shape):
+        t = o.get(name)
+        if t is None:
+            t = torch.empty(shape, dtype=torch.float32, device=dev)
+            o[name] = t
+        return t
+    loss, logit, dd2, dc = buf("loss", (1,)), buf("logit", (B,)), buf("dd2", (B, H)), buf("dc", (B, X))
+    nb = _lib.query_bytes("mrec_dcn_head_workspace_bytes", B, H, X)
+    ws = workspace("dcn_head", nb, dev)
+    _lib.call("mrec_dcn_head_fwd_bwd", _ptr(d2), ldd, _ptr(c), ldc, _ptr(w3), _ptr(b3), _ptr(label.contiguous()), B, H, X, float(dscale),
+              _ptr(logit), _ptr(dd2), dd2.stride(0), _ptr(dc), dc.stride(0), _ptr(dw3_out), _ptr(db2_out), _ptr(db3_out), _ptr(loss), _ptr(ws),
+              ws.numel(), _stream())
+    return loss, logit, dd2, dc
+
+
 # ---- DeepFM second-order term ------------------------------------------------------------------
-def fm_forward(vx):
-    """vx [B, F, D] fp32 -> (fm_out [B], colsum [B, D]) (deepfm.py:221-228)."""
-    _need_cuda(vx)
+def fm_forward(vx, add=None):
+    """vx [B, F, D] fp32 -> (fm_out [B], colsum [B, D]) (deepfm.py:221-228).  add [B] (the linear term): fm_out = add + fm."""
+    _need_cuda(vx, add)
     B, F_, D = vx.shape
     vx = vx.contiguous()
+    if add is not None and (add.dtype != torch.float32 or add.numel() != B or not add.is_contiguous()):
+        raise TypeError("fm_forward: add must be contiguous float32 [B]")
     fm = torch.empty(B, dtype=torch.float32, device=vx.device)
     cs = torch.empty((B, D), dtype=torch.float32, device=vx.device)
-    _lib.call("mrec_fm_fwd_f32", _ptr(vx), B, F_, D, _ptr(fm), _ptr(cs), _stream())
+    _lib.call("mrec_fm_fwd_add_f32", _ptr(vx), B, F_, D, _ptr(add), _ptr(fm), _ptr(cs), _stream())
     return fm, cs
+
+
+def fm_backward_mix(g16, vx, colsum, dout):
+    """fp32 [B, F, D]: widen(g16) + dout[b] * (colsum[b, d] - vx[b, f, d]) -- the FM gradient added to the 16-bit input gradient
+    of the mixed-precision MLP, one pass."""
+    _need_cuda(g16, vx, colsum, dout)
+    B, F_, D = vx.shape
+    if g16.dtype not in _DT16 or g16.numel() != vx.numel() or not g16.is_contiguous():
+        raise TypeError("fm_backward_mix: g16 must be a contiguous bfloat16 / float16 tensor of vx's size")
+    out = torch.empty_like(vx)
+    _lib.call("mrec_fm_bwd_mix_f32", _ptr(vx.contiguous()), _ptr(colsum), _ptr(dout.contiguous()), _ptr(g16), 1 if g16.dtype == torch.bfloat16 else 2,
+              B, F_, D, _ptr(out), _stream())
+    return out
 
 
 def fm_backward_(g, vx, colsum, dout):

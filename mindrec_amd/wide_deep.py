@@ -107,17 +107,6 @@ def enable_tuned_gemms():
         return False
 
 
-def _flat_views(shapes, device, dtype=torch.float32):
-    n = sum(int(np.prod(s)) for s in shapes)
-    flat = torch.zeros(n, dtype=dtype, device=device)
-    views, off = [], 0
-    for s in shapes:
-        k = int(np.prod(s))
-        views.append(flat[off:off + k].view(s))
-        off += k
-    return flat, views
-
-
 class _DirectComm:
     """The engine's collectives: torch.distributed on the tensors as they are -- device tensors under backend "nccl"
     (= RCCL over xGMI, the product path), host tensors under gloo (the CPU logic tests).  Test harnesses that put
@@ -189,8 +178,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         self.dims = dims
         # The mixed-precision dense net runs on the hand-written MFMA kernels (csrc/mrec_dense.hip); widths that are not
         # multiples of 8 (rows not 16-byte aligned), an fp32 net and the CPU stand-in take the autograd path below.
-        self._mfma = bool(self._gpu and kernels is None and self._amp is not None and nl >= 2 and D % 4 == 0 and D <= 256
-                          and all(d % 8 == 0 for d in dims[:-1]))
+        self._mfma = bool(self._gpu and kernels is None and self._amp is not None and D % 4 == 0 and D <= 256 and self.mfma_net_ok(dims))
         self.tuned_gemms = bool(tuned_gemms and self._gpu and not self._mfma and enable_tuned_gemms())
         if not cfg.sparse and (self._sharded or cfg.dynamic_embedding or cfg.host_cache_rows > 0):
             raise ValueError("sparse=False (dense gradients over the whole table) runs on one GPU with resident dense tables")
@@ -238,62 +226,12 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
                 self.wide_accum.fill_(cfg.ftrl_initial_accum)
                 self.wide_linear.zero_()
             # (dynamic_embedding: rows get exactly these values when their key is first seen, _translate_keys)
-            # MLP: fp32 master weights in one flat buffer, same for grads / m / v.  Flat order: the hidden
-            # layers' weight matrices first (group H: the 16-bit GEMM operands), then the biases
-            # and the fp32 last layer (group S); `self.dense` lists them in layer order W0, b0, W1, b1, ...
-            shapes_h = [(dims[i], dims[i + 1]) for i in range(nl - 1)]
-            shapes_s = [(dims[i + 1],) for i in range(nl - 1)] + [(dims[nl - 1], dims[nl]), (dims[nl],)]
-            self.n_h = sum(int(np.prod(x)) for x in shapes_h)
-
-            def interleave(vh, vs):
-                out = []
-                for i in range(nl - 1):
-                    out += [vh[i], vs[i]]
-                return out + [vs[nl - 1], vs[nl]]
-
-            # pad the flat buffers to a multiple of 4 floats: the dense Adam then is one float4 launch (a 1-element tail
-            # launch cost 5 us + a gap every step); the pad element is a parameter nobody reads (gradient always 0)
-            # ... plus "Wide_b" in the first element behind them: TrainStepWrap sorts parameters by the case-sensitive test
+            # "Wide_b" lives in the dense net's flat buffer: TrainStepWrap sorts parameters by the case-sensitive test
             # `"wide" in params.name` (wide_and_deep.py:407-411) and the bias is named "Wide_b" (:161-163), so it belongs to the
-            # DEEP optimizer (Adam), not to FTRL; living in this buffer it is updated by the same dense-Adam launch.
-            n_real = sum(int(np.prod(x)) for x in shapes_h + shapes_s)
-            pad = [(((-n_real - 1) % 4) + 1,)]
-            self._wb_off = n_real
-            self.dense_flat, views = _flat_views(shapes_h + shapes_s + pad, dev)
-            views = views[:len(shapes_h + shapes_s)]
-            self.dense = interleave(views[:nl - 1], views[nl - 1:])
-            # one extra slot at the end carries the wide-bias gradient through the same all-reduce
-            self.dense_grad_ext, gviews = _flat_views(shapes_h + shapes_s + pad + [(1,)], dev)
-            self.dense_grad_flat = self.dense_grad_ext[:-1]
-            gviews = gviews[:len(shapes_h + shapes_s)]
-            self.dense_grad = interleave(gviews[:nl - 1], gviews[nl - 1:])
-            self.dense_m = torch.zeros_like(self.dense_flat)
-            self.dense_v = torch.zeros_like(self.dense_flat)
-            # identical on every rank: global row 0.. of a [n,1] "table" keyed by a private seed
-            self.k.fill_normal_(self.dense_flat.view(-1, 1), cfg.seed + 2, cfg.init_sigma)
-            for p, g in zip(self.dense, self.dense_grad):
-                p.requires_grad_(True)
-                p.grad = g
-            self.dense16 = None
-            if self._mfma:
-                # 16-bit shadow of every dense parameter, kept current by the dense-Adam kernel: the hidden layers'
-                # [in, out] weight matrices in it are the GEMM operands of the forward AND of the input-gradient kernel
-                flat16, v16 = _flat_views(shapes_h + shapes_s + pad, dev, self._amp)
-                v16 = v16[:len(shapes_h + shapes_s)]
-                flat16.copy_(self.dense_flat.detach())
-                self.dense16_flat, self.dense16 = flat16, interleave(v16[:nl - 1], v16[nl - 1:])
-            self.wide_b = self.dense_flat.detach()[self._wb_off:self._wb_off + 1]       # "Wide_b": a view into the dense buffer
-            self.wide_b_grad = self.dense_grad_flat[self._wb_off:self._wb_off + 1]
-            self.k.fill_normal_(self.wide_b.view(1, 1), cfg.seed + 3, cfg.init_sigma)
-            if self.dense16 is not None:
-                self.dense16_flat.copy_(self.dense_flat.detach())
-        # The last two hidden layers + the output head + their input-gradient bprops as ONE launch (ops.tail_fwd_bwd) where the net
-        # ends ... -> 512 -> 256 -> 128 -> 1 (the reference's) and the batch is a multiple of 64; any other net: layer by layer.
-        self._tail_packed, self._dense16_t = None, None
-        nl_ = len(self.dims) - 1
-        self._tail_ok = bool(self._mfma and cfg.fused_tail and nl_ >= 4 and cfg.field_size <= 64      # (<= 64 wide products per sample)
-                             and self.k.tail_supported(64, *self.dims[nl_ - 3:nl_]))
-        self._refresh_tail()
+            # DEEP optimizer (Adam), not to FTRL; in that buffer it is updated by the same dense-Adam launch.
+            self._init_dense_net(dims, cfg.seed + 2, cfg.init_sigma, cfg.sens, extra_seed=cfg.seed + 3,
+                                 fused_tail=bool(cfg.fused_tail and cfg.field_size <= 64))      # (<= 64 wide products per sample)
+            self.wide_b, self.wide_b_grad = self.extra_p, self.extra_g
         self._hashed = bool(cfg.dynamic_embedding)
         self._fused_rows = bool(cfg.fused_state and cfg.sparse and cfg.host_cache_rows == 0 and self._gpu)   # [p | w ... | m | v] rows
         if self._sharded:
@@ -305,18 +243,11 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         # the step's Unique + inverted index runs on a side stream, under the MLP
         # (default priority: a high-priority side stream was measured at 1.52 ms/step instead of 0.88)
         self._side = torch.cuda.Stream(device=self.device) if self._gpu else None
-        self._mlp_graph = None        # dict: captured MLP step + its static input / output tensors
-        self._dw = {}                 # hidden layer -> fp32 batch slabs [S, in, out] of its weight gradient (persistent:
-                                      # graph replays and eager steps write the same buffers, the dense Adam reads them)
-        self._db = {}                 # hidden layer -> fp32 partial sums of its bias gradient (same idea)
-        self._dw_batch = None
-        self._tail_out = {}           # (batch, dtype) -> the tail launch's output tensors (persistent: graph replays write them)
         self.deep_apply_timer = None  # optional ops.KernelTimer armed right before the deep table's sparse apply
         self._dyn = False             # step scalars (Adam powers / step size) in device memory: set per step
         self._front_graph = None      # one-GPU: the whole front of the step (lookups .. MLP backward) as one captured graph
         self._step_graph = None       # ... and, with the wide branch folded, the whole step
         self._sink_graphs = {}        # (sink size, batch shape, id dtype) -> that many whole steps as one graph (train_steps)
-        self._slot = 0
         self._step_state = None       # ops.StepState (device-side beta powers / step size), created on first use
         self._state_step = -1         # the step count the device-side state stands at
         self._dropout = bool(cfg.dropout_flag and cfg.dropout_keep_prob < 1.0)
@@ -656,16 +587,6 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
             return loss
         return loss + self.cfg.l2_coef * 0.5 * float((self.deep.double() ** 2).sum())
 
-    def _slab_segments(self):
-        """[(offset in the flat gradient, slab tensor)] of the weight- and bias-gradient slabs of the last backward."""
-        return ([(self.dense_grad[2 * i].storage_offset(), t) for i, t in sorted(self._dw.items())] +
-                [(self.dense_grad[2 * i + 1].storage_offset(), t) for i, t in sorted(self._db.items())])
-
-    def _sum_dw_slabs(self):
-        """Weight- and bias-gradient slabs -> the flat gradient buffer, one launch (needed only where somebody other than the
-        dense Adam reads the summed gradient: the data-parallel all-reduce, the dense-gradient mode)."""
-        self.k.sum_slab_segments_(self.dense_grad_flat, self._slab_segments())
-
     # ---- one training step -------------------------------------------------------------------
     def train_steps(self, batches):
         """`len(batches)` training steps per host call -- the reference's dataset_sink_mode / sink_size (Model.train(...,
@@ -719,8 +640,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
             return None
         finally:
             self._training = False
-            self._slot = 0
-
+    
     def train_step(self, ids, wts, label):
         self._training = True
         try:

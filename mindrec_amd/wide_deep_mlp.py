@@ -1,10 +1,22 @@
 """The dense net of the Wide&Deep engine: DenseLayer x5 (models/wide_deep/src/wide_and_deep.py:113-133, :164-205) forward and
 backward on the hand-written MFMA kernels (csrc/mrec_dense.hip, csrc/mrec_tail.hip), Dropout on the layer inputs, the HIP graphs
 of the MLP step.  A mixin of WideDeepEngine (mindrec_amd/wide_deep.py), which owns the state these methods work on."""
+import numpy as np
 import torch
 import torch.nn.functional as F
 
 from . import ops
+
+
+def _flat_views(shapes, device, dtype=torch.float32):
+    n = sum(int(np.prod(s)) for s in shapes)
+    flat = torch.zeros(n, dtype=dtype, device=device)
+    views, off = [], 0
+    for s in shapes:
+        k = int(np.prod(s))
+        views.append(flat[off:off + k].view(s))
+        off += k
+    return flat, views
 
 
 class _WideProd:
@@ -15,6 +27,88 @@ class _WideProd:
 
 
 class DenseNetMixin:
+    """Needs from its host class: self.k (op set), self.device, self._gpu, self._amp (torch dtype of the 16-bit net, None: fp32),
+    self._mfma, self._graph_level, self.rank, self.step_count, self._step_state, self._dropout / self._training / self._emb_dropped,
+    self.cfg.dropout_keep_prob / .seed (Dropout only)."""
+
+    def _init_dense_net(self, dims, seed, init_sigma, sens, extra_seed=None, fused_tail=True):
+        """The dense net's state: fp32 master weights in one flat buffer, same for gradients / Adam moments.  Flat order: the
+        hidden layers' weight matrices first (the 16-bit GEMM operands), then the biases and the fp32 output layer; `self.dense`
+        lists them in layer order W0, b0, W1, b1, ...  One EXTRA scalar parameter rides behind them (self.extra_p / extra_g: the
+        Wide&Deep model's "Wide_b"), then padding to a multiple of 4 floats: the dense Adam is one float4 launch (a 1-element
+        tail launch cost 5 us + a gap every step; the pad elements are parameters nobody reads, gradient always 0).
+        sens: the loss scale the backward is seeded with (TrainStepWrap(sens=...), wide_and_deep.py:390,479-486)."""
+        dev = self.device
+        self.dims, self._sens = list(dims), float(sens)
+        nl = len(dims) - 1
+        shapes_h = [(dims[i], dims[i + 1]) for i in range(nl - 1)]
+        shapes_s = [(dims[i + 1],) for i in range(nl - 1)] + [(dims[nl - 1], dims[nl]), (dims[nl],)]
+        self.n_h = sum(int(np.prod(x)) for x in shapes_h)
+
+        def interleave(vh, vs):
+            out = []
+            for i in range(nl - 1):
+                out += [vh[i], vs[i]]
+            return out + [vs[nl - 1], vs[nl]]
+
+        n_real = sum(int(np.prod(x)) for x in shapes_h + shapes_s)
+        pad = [(((-n_real - 1) % 4) + 1,)]
+        self._wb_off = n_real
+        self.dense_flat, views = _flat_views(shapes_h + shapes_s + pad, dev)
+        views = views[:len(shapes_h + shapes_s)]
+        self.dense = interleave(views[:nl - 1], views[nl - 1:])
+        self.dense_grad_flat, gviews = _flat_views(shapes_h + shapes_s + pad, dev)
+        gviews = gviews[:len(shapes_h + shapes_s)]
+        self.dense_grad = interleave(gviews[:nl - 1], gviews[nl - 1:])
+        self.dense_m = torch.zeros_like(self.dense_flat)
+        self.dense_v = torch.zeros_like(self.dense_flat)
+        # identical on every rank: global row 0.. of a [n, 1] "table" keyed by a private seed
+        self.k.fill_normal_(self.dense_flat.view(-1, 1), seed, init_sigma)
+        for p, g in zip(self.dense, self.dense_grad):
+            p.requires_grad_(True)
+            p.grad = g
+        self.extra_p = self.dense_flat.detach()[self._wb_off:self._wb_off + 1]
+        self.extra_g = self.dense_grad_flat[self._wb_off:self._wb_off + 1]
+        if extra_seed is not None:
+            self.k.fill_normal_(self.extra_p.view(1, 1), extra_seed, init_sigma)
+        else:
+            self.extra_p.zero_()
+        self.dense16 = None
+        if self._mfma:
+            # 16-bit shadow of every dense parameter, kept current by the dense-Adam kernel: the hidden layers'
+            # [in, out] weight matrices in it are the GEMM operands of the forward AND of the input-gradient kernel
+            flat16, v16 = _flat_views(shapes_h + shapes_s + pad, dev, self._amp)
+            v16 = v16[:len(shapes_h + shapes_s)]
+            flat16.copy_(self.dense_flat.detach())
+            self.dense16_flat, self.dense16 = flat16, interleave(v16[:nl - 1], v16[nl - 1:])
+        # The last two hidden layers + the output head + their input-gradient bprops as ONE launch (ops.tail_fwd_bwd) where the
+        # net ends ... -> 512 -> 256 -> 128 -> 1 (the reference's) and the batch is a multiple of 64; any other net: layer by layer.
+        self._tail_packed, self._dense16_t = None, None
+        self._tail_ok = bool(self._mfma and fused_tail and nl >= 4 and self.k.tail_supported(64, *self.dims[nl - 3:nl]))
+        self._mlp_graph = None        # dict: captured MLP step + its static input / output tensors
+        self._dw = {}                 # hidden layer -> fp32 batch slabs [S, in, out] of its weight gradient (persistent:
+                                      # graph replays and eager steps write the same buffers, the dense Adam reads them)
+        self._db = {}                 # hidden layer -> fp32 partial sums of its bias gradient (same idea)
+        self._dw_batch = None
+        self._tail_out = {}           # (batch, dtype, slot) -> the tail launch's output tensors (persistent: graph replays write them)
+        self._slot = 0
+        self._refresh_tail()
+
+    @staticmethod
+    def mfma_net_ok(dims):
+        """Shapes the hand-written 16-bit net covers: at least one hidden layer, every width a multiple of 8 (16-byte rows)."""
+        return len(dims) - 1 >= 2 and all(d % 8 == 0 for d in dims[:-1])
+
+    def _slab_segments(self):
+        """[(offset in the flat gradient, slab tensor)] of the weight- and bias-gradient slabs of the last backward."""
+        return ([(self.dense_grad[2 * i].storage_offset(), t) for i, t in sorted(self._dw.items())] +
+                [(self.dense_grad[2 * i + 1].storage_offset(), t) for i, t in sorted(self._db.items())])
+
+    def _sum_dw_slabs(self):
+        """Weight- and bias-gradient slabs -> the flat gradient buffer, one launch (needed only where somebody other than the
+        dense Adam reads the summed gradient: the data-parallel all-reduce, the dense-gradient mode)."""
+        self.k.sum_slab_segments_(self.dense_grad_flat, self._slab_segments())
+
     def _drop(self, layer, B):
         """Dropout descriptor of DenseLayer `layer`'s input for the training step in flight (None: no dropout).  The mask is a
         function of (seed, step, layer, global sample row, column): on the GPU the step is read from the device-side step
@@ -127,28 +221,28 @@ class DenseNetMixin:
             prod = isinstance(wide, _WideProd)
             loss, dlogit, y2, dz4, dz3, dz2 = self.k.tail_fwd_bwd(
                 hs[-1], self._tail_packed, self.dense[2 * (n - 3) + 1].detach(), self.dense[2 * (n - 2) + 1].detach(), W5.detach().view(-1),
-                b5.detach(), wide.prod if prod else wide, self.wide_b if prod else None, label.view(-1), self.cfg.sens / B,
+                b5.detach(), wide.prod if prod else wide, self.wide_b if prod else None, label.view(-1), self._sens / B,
                 self.dense_grad[2 * (n - 1)].view(-1), self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1],
                 self.dense_grad[2 * (n - 3) + 1], self.dense_grad[2 * (n - 4) + 1], dwide_bias_out=self.wide_b_grad if prod else None,
                 drop_in=self._drop(n - 3, B), out=self._tail_out.setdefault((B, hs[-1].dtype, self._slot), {}))
             return {"hs": hs + [y2], "loss": loss.view(()), "g_wide": dlogit.view(-1), "dh": dz2, "tail": (dz4, dz3)}
         if isinstance(wide, _WideProd):
             loss, _, dlogit, dh = self.k.head_fwd_bwd_wide(hs[-1], W5.detach().view(-1), b5.detach(), wide.prod, self.wide_b,
-                                                            label.view(-1), self.cfg.sens / B, self.dense_grad[2 * (n - 1)].view(-1),
+                                                            label.view(-1), self._sens / B, self.dense_grad[2 * (n - 1)].view(-1),
                                                             self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1],
                                                             dwide_bias_out=self.wide_b_grad, dh_scale=dhs)
             loss = loss.view(())
         elif self.k.head_supported(K5):
             # output layer + wide/deep add + sigmoid cross-entropy, forward AND backward, one pass over h4
             loss, _, dlogit, dh = self.k.head_fwd_bwd(hs[-1], W5.detach().view(-1), b5.detach(), wide, label.view(-1),
-                                                       self.cfg.sens / B, self.dense_grad[2 * (n - 1)].view(-1),
+                                                       self._sens / B, self.dense_grad[2 * (n - 1)].view(-1),
                                                        self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1], dh_scale=dhs)
             loss = loss.view(())
         else:
             h4 = hs[-1].float()
             logit = torch.addmm(b5, h4, W5) + wide.view(-1, 1)
             loss = F.binary_cross_entropy_with_logits(logit, label)
-            dlogit = (torch.sigmoid(logit) - label) * (self.cfg.sens / B)          # d(sens * mean BCE)/d logit
+            dlogit = (torch.sigmoid(logit) - label) * (self._sens / B)          # d(sens * mean BCE)/d logit
             torch.mm(h4.t(), dlogit, out=self.dense_grad[2 * (n - 1)])
             torch.sum(dlogit, dim=0, out=self.dense_grad[2 * (n - 1) + 1])
             dh = torch.ops.aten.threshold_backward((torch.mm(dlogit, W5.t()) * dhs).to(amp), hs[-1], 0)

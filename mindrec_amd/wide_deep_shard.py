@@ -41,6 +41,9 @@ class ShardStepMixin:
         self._prefetched = None       # the next step's request (a sink of steps issues it early)
         # a second side stream: the next step's request exchange / the dense-gradient all-reduce run beside the critical chain
         self._side2 = torch.cuda.Stream(device=self.device) if self._gpu else None
+        import os
+        self._opt_prefetch = os.environ.get("MREC_SHARD_PREFETCH", "1") != "0"       # (A/B switches of the two side branches)
+        self._opt_ar_side = os.environ.get("MREC_SHARD_AR_SIDE", "1") != "0"
 
     def shard_overflow(self):
         """Positions dropped so far because an owner's bucket of the request message was full (host sync)."""
@@ -152,7 +155,7 @@ class ShardStepMixin:
     def _prefetch_request(self, ids, wts):
         """A sink of steps: the NEXT step's request exchange on a side branch, behind the MLP of the step in flight -- it runs
         under that step's gradient exchange and sparse apply instead of in front of the next lookup."""
-        if self._side2 is None:
+        if self._side2 is None or not self._opt_prefetch:
             return
         self._side2.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._side2):
@@ -199,9 +202,10 @@ class ShardStepMixin:
         # branch of their own, beside the row-gradient exchange and the sparse apply -- neither needs them.
         ev = self._tick("allreduce_dense")
         main = torch.cuda.current_stream() if self._gpu else None
-        if self._side2 is not None:
-            self._side2.wait_stream(main)
-        with (torch.cuda.stream(self._side2) if self._side2 is not None else _null()):
+        side2 = self._side2 if self._opt_ar_side else None
+        if side2 is not None:
+            side2.wait_stream(main)
+        with (torch.cuda.stream(side2) if side2 is not None else _null()):
             if fused:
                 self._sum_dw_slabs()
                 if not route["wide_b_in_head"]:
@@ -238,8 +242,8 @@ class ShardStepMixin:
             k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, recv_gw, route["recv_wts"], lr=cfg.ftrl_lr,
                            l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=scale)
         self._tock(ev)
-        if self._side2 is not None:
-            main.wait_stream(self._side2)         # the all-reduced dense gradient
+        if side2 is not None:
+            main.wait_stream(side2)               # the all-reduced dense gradient
         ev = self._tick("apply_dense")
         flat = self.dense_flat.detach()
         if fused:

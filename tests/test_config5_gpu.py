@@ -29,7 +29,7 @@ def test_deepfm_over_hash_tables_with_admission_and_eviction(dev, oracle, B, Fd,
     """The second case is the configuration's own shape: batch 16384, 26 fields, dim 128 (BASELINE configs[4])."""
     from mindrec_amd.deepfm import DeepFMConfig, DeepFMHashEngine
     D = 128
-    cfg = DeepFMConfig(data_emb_dim=D, data_field_size=Fd, batch_size=B, deep_layer_dims=[64, 32], learning_rate=1e-2)
+    cfg = DeepFMConfig(data_emb_dim=D, data_field_size=Fd, batch_size=B, deep_layer_dims=[64, 32], learning_rate=1e-2, mlp_dtype="fp32")
     eng = DeepFMHashEngine(cfg, dev, key_dtype=torch.int64, capacity=cap, permit_filter_value=2, evict_filter_value=2)
     # ---- reference state
     oV, oW = oracle.Map(D, cap, seed=cfg.seed, sigma=0.01), oracle.Map(1, cap, seed=cfg.seed + 1, sigma=0.01)
@@ -44,11 +44,13 @@ def test_deepfm_over_hash_tables_with_admission_and_eviction(dev, oracle, B, Fd,
     rng = np.random.default_rng(5)
     pools = [rng.integers(1, 2 ** 40, size=pool), rng.integers(2 ** 41, 2 ** 42, size=pool)]    # two disjoint key sets
 
+    offs = [p.storage_offset() for p in eng.dense]       # where W0, b0, W1, b1, ... live in the flat parameter buffer
+
     def ref_mlp(x):
-        off, h = 0, x
+        h = x
         for i in range(len(dims) - 1):
-            W = dense[off:off + dims[i] * dims[i + 1]].view(dims[i], dims[i + 1]); off += dims[i] * dims[i + 1]
-            b = dense[off:off + dims[i + 1]]; off += dims[i + 1]
+            W = dense[offs[2 * i]:offs[2 * i] + dims[i] * dims[i + 1]].view(dims[i], dims[i + 1])
+            b = dense[offs[2 * i + 1]:offs[2 * i + 1] + dims[i + 1]]
             h = torch.addmm(b, h, W)
             if i < len(dims) - 2:
                 h = torch.relu(h)

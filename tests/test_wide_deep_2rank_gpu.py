@@ -181,9 +181,12 @@ def test_sharded_hash_tables_match_single_process(dev, tmp_path, world, host_cac
 
 
 # ---- DeepFM over key-sharded MapParameters (BASELINE configs[4]: the model of the configuration, on shards) ---------------
+DFM_DTYPE = "fp32"
+
+
 def _dfm_cfg(B):
     from mindrec_amd.deepfm import DeepFMConfig
-    return DeepFMConfig(data_emb_dim=128, data_field_size=6, batch_size=B, deep_layer_dims=[64, 32], learning_rate=1e-2)
+    return DeepFMConfig(data_emb_dim=128, data_field_size=6, batch_size=B, deep_layer_dims=[64, 32], learning_rate=1e-2, mlp_dtype=DFM_DTYPE)
 
 
 def _dfm_batch(B, F, seed, dev, pool_id):

@@ -180,7 +180,7 @@ def test_deepfm_engine_matches_oracle_engine(dev, oracle):
     from _oracle_engine import OracleDeepCrossEngine, OracleDeepFMEngine, OracleWideDeepEngine  # noqa: F401
     from mindrec_amd.deepfm import DeepFMConfig, DeepFMEngine
     from mindrec_amd.wide_deep import WideDeepConfig, synthetic_batch
-    cfg = DeepFMConfig(data_vocab_size=4000, data_emb_dim=16, data_field_size=39, batch_size=128, deep_layer_dims=[64, 32])
+    cfg = DeepFMConfig(data_vocab_size=4000, data_emb_dim=16, data_field_size=39, batch_size=128, deep_layer_dims=[64, 32], mlp_dtype="fp32")
     g = DeepFMEngine(cfg, dev)
     c = OracleDeepFMEngine(cfg, "cpu")
     assert np.array_equal(g.V_l2.cpu().numpy(), c.V_l2.numpy())
@@ -448,3 +448,55 @@ def test_sink_of_steps_equals_step_by_step(dev):
     sa, sb = a._step_state.read(), b._step_state.read()
     assert int(sa["step"]) == int(sb["step"]) == a.step_count == b.step_count == 24
     assert float(sa["beta1_power"]) == float(sb["beta1_power"]) == float(a.beta1_power)
+
+
+def test_fm_kernels_with_the_models_other_terms(dev, oracle):
+    """mrec_fm_fwd_add_f32 / mrec_fm_bwd_mix_f32 (the DeepFM step's glue around the 16-bit net) against numpy: fm + linear, and
+    widen(g16) + dout * (colsum - vx), bit-exact (same fp32 operations in the same order)."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(4)
+    B, Fd, D = 700, 13, 80
+    vx = rng.standard_normal((B, Fd, D)).astype(np.float32)
+    lin = rng.standard_normal(B).astype(np.float32)
+    tv = torch.from_numpy(vx).to(dev)
+    fm0, cs0 = ops.fm_forward(tv)
+    fm1, cs1 = ops.fm_forward(tv, add=torch.from_numpy(lin).to(dev))
+    assert torch.equal(cs0, cs1) and np.array_equal(fm1.cpu().numpy(), lin + fm0.cpu().numpy())
+    dout = rng.standard_normal(B).astype(np.float32)
+    for tdt, name in ((torch.bfloat16, "bf16"), (torch.float16, "f16")):
+        g16 = oracle.round16(rng.standard_normal((B, Fd, D)).astype(np.float32), name)
+        got = ops.fm_backward_mix(torch.from_numpy(g16).to(dev).to(tdt), tv, cs0, torch.from_numpy(dout).to(dev)).cpu().numpy()
+        cs = cs0.cpu().numpy()
+        ref = g16 + dout[:, None, None] * (cs[:, None, :] - vx)
+        assert np.array_equal(got, ref.astype(np.float32))
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_deepfm_engine_in_the_references_precision(dev, dt):
+    """DeepFM with convert_dtype (the reference's default: DenseLayer in float16, models/deepfm/default_config.yaml:27) runs its
+    dense net on the hand-written MFMA kernels -- no library GEMM, the MLP step replayed as HIP graphs -- and tracks the fp32
+    oracle-side engine to 16-bit accuracy: losses, both tables, the dense parameters."""
+    from _oracle_engine import OracleDeepFMEngine
+    from mindrec_amd.deepfm import DeepFMConfig, DeepFMEngine
+    from mindrec_amd.wide_deep import WideDeepConfig, synthetic_batch
+    kw = dict(data_vocab_size=4000, data_emb_dim=16, data_field_size=39, batch_size=256, deep_layer_dims=[128, 64, 32, 16])
+    g = DeepFMEngine(DeepFMConfig(mlp_dtype=dt, **kw), dev)
+    c = OracleDeepFMEngine(DeepFMConfig(mlp_dtype="fp32", **kw), "cpu")
+    assert g._mfma and g._tail_ok and torch.equal(g.dense_flat.detach().cpu()[:c.dense_flat.numel()], c.dense_flat.detach()[:g.dense_flat.numel()])
+    bcfg = WideDeepConfig(vocab_size=4000, emb_dim=16, field_size=39, batch_size=256)
+    for s in range(6):
+        ids, wts, label = synthetic_batch(bcfg, "cpu", "zipf", seed=70 + s)
+        lc = float(c.train_step(ids, wts, label))
+        lg = float(g.train_step(ids.to(dev), wts.to(dev), label.to(dev)))
+        assert abs(lg - lc) <= 3e-3 * abs(lc), (s, lg, lc)
+    assert g._mlp_graph is not None
+    for a, b, name in ((g.V_l2, c.V_l2, "V"), (g.W_l2, c.W_l2, "W")):
+        a, b = a.cpu().numpy(), b.numpy()
+        assert np.abs(a - b).max() <= 2 * g.cfg.learning_rate * 6, name          # Adam: a flipped sign of a ~0 gradient is +-lr per step
+        assert np.mean(np.abs(a - b) <= 0.1 * g.cfg.learning_rate) > 0.97, name
+    n = c.dense_flat.numel()
+    d = np.abs(g.dense_flat.detach().cpu().numpy()[:n] - c.dense_flat.detach().numpy()[:n])
+    assert d.max() <= 2 * g.cfg.learning_rate * 6 and np.mean(d <= 0.1 * g.cfg.learning_rate) > 0.9
+    ids, wts, _ = synthetic_batch(bcfg, "cpu", "zipf", seed=99)
+    pg, pc = g.predict(ids.to(dev), wts.to(dev))[1].cpu().numpy(), c.predict(ids, wts)[1].numpy()
+    assert np.abs(pg - pc).max() <= 2e-2
