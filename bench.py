@@ -452,6 +452,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1 or args.shard_protocol:
         dist.barrier()
+        eng.release_graphs()             # (graphs that hold RCCL kernels must go before the process group does)
+        del eng
         dist.destroy_process_group()
 
 

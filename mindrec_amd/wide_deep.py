@@ -587,6 +587,16 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
             return loss
         return loss + self.cfg.l2_coef * 0.5 * float((self.deep.double() ** 2).sum())
 
+    def release_graphs(self):
+        """Drops every captured HIP graph (they are re-captured on demand).  A shard's graphs hold RCCL kernels: they must be gone
+        before the process group is destroyed -- destroy_process_group() waits for them forever otherwise."""
+        if self._gpu:
+            torch.cuda.synchronize(self.device)
+        self._step_graph = self._front_graph = self._mlp_graph = None
+        self._sink_graphs = {}
+        if self._gpu:
+            torch.cuda.synchronize(self.device)
+
     # ---- one training step -------------------------------------------------------------------
     def train_steps(self, batches):
         """`len(batches)` training steps per host call -- the reference's dataset_sink_mode / sink_size (Model.train(...,
@@ -627,8 +637,6 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
                 for slot, (ids, wts, label) in enumerate(inputs):
                     self._slot = slot                 # per-step output buffers of the tail launch (the losses must not alias)
                     front = self._front(ids, wts, label, capturing=True)
-                    if self._sharded and slot + 1 < len(inputs):
-                        self._prefetch_request(*inputs[slot + 1][:2])      # the next step's request exchange, under this step's apply
                     losses.append(self._tail(front, ids, wts))
             sg = {"graph": graph, "inputs": inputs, "losses": losses, "plan": self.last_plan}
             self._sink_graphs[key] = sg

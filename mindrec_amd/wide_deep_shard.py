@@ -38,12 +38,6 @@ class ShardStepMixin:
         self._shard_fold = bool(self._fused_rows and D <= 252 and D % (4 if self._act == torch.float32 else 8) == 0)
         self._overflow = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._overflow_seen = 0
-        self._prefetched = None       # the next step's request (a sink of steps issues it early)
-        # a second side stream: the next step's request exchange / the dense-gradient all-reduce run beside the critical chain
-        self._side2 = torch.cuda.Stream(device=self.device) if self._gpu else None
-        import os
-        self._opt_prefetch = os.environ.get("MREC_SHARD_PREFETCH", "1") != "0"       # (A/B switches of the two side branches)
-        self._opt_ar_side = os.environ.get("MREC_SHARD_AR_SIDE", "1") != "0"
 
     def shard_overflow(self):
         """Positions dropped so far because an owner's bucket of the request message was full (host sync)."""
@@ -74,16 +68,14 @@ class ShardStepMixin:
         return msg
 
     def _shard_request(self, ids, wts):
-        """The request half of a lookup: positions -> slots, the request exchange.  Needs nothing but the batch, so a sink of
-        steps issues it for step t + 1 on a side branch under step t's sparse apply (train_steps)."""
+        """The request half of a lookup: positions -> slots, the request exchange."""
         cfg, k = self.cfg, self.k
         n = ids.numel()
         cap = k.shard_capacity(n, self.world, cfg.shard_capacity_factor)
         req, slot_of_pos, pos_of_slot = k.shard_route_slots(ids, wts, self.world, cap, hashed=self._hashed, overflow=self._overflow)
         recv_req = torch.empty_like(req)
         self.comm.all_to_all(recv_req, req)
-        return {"ids": ids, "recv_req": recv_req, "slot_of_pos": slot_of_pos, "pos_of_slot": pos_of_slot, "ns": self.world * cap,
-                "stream": torch.cuda.current_stream() if self._gpu else None}
+        return {"recv_req": recv_req, "slot_of_pos": slot_of_pos, "pos_of_slot": pos_of_slot, "ns": self.world * cap}
 
     def _shard_lookup(self, ids, wts, want_plan=True):
         """Requests out, answers back.  Returns (emb [B, F * D] act dtype, wprod [B, F, 2] fp32, route state)."""
@@ -91,12 +83,7 @@ class ShardStepMixin:
         B, Fd = ids.shape
         D, n, act = cfg.emb_dim, ids.numel(), self._act
         ev = self._tick("route")
-        rq = self._prefetched
-        self._prefetched = None
-        if rq is not None and rq["ids"] is ids:
-            torch.cuda.current_stream().wait_stream(rq["stream"])        # issued on a side branch under the previous step's apply
-        else:
-            rq = self._shard_request(ids, wts)
+        rq = self._shard_request(ids, wts)
         recv_req, slot_of_pos, pos_of_slot, ns = rq["recv_req"], rq["slot_of_pos"], rq["pos_of_slot"], rq["ns"]
         self._tock(ev)
         ev = self._tick("gather_deep")
@@ -149,17 +136,10 @@ class ShardStepMixin:
                 for t in (rows, recv_wts, recv_req, plan.uniq_buf, plan.inv, plan.n_uniq_dev, plan.sorted_pos, plan.sorted_seg, plan.seg_offsets):
                     self._rs(t, main)
                     self._rs(t, self._side)
-        route = {"pos_of_slot": pos_of_slot, "recv_wts": recv_wts, "plan": plan, "ns": ns}
+        # (recv_req is read by the side branch: it must stay alive until the branches join -- under capture a freed block is
+        # handed to the next allocation of the SAME capture, whatever another branch still does with it)
+        route = {"pos_of_slot": pos_of_slot, "recv_wts": recv_wts, "plan": plan, "ns": ns, "keep": (recv_req, rows)}
         return emb.view(B, Fd * D), wprod.view(B, Fd, 2), route
-
-    def _prefetch_request(self, ids, wts):
-        """A sink of steps: the NEXT step's request exchange on a side branch, behind the MLP of the step in flight -- it runs
-        under that step's gradient exchange and sparse apply instead of in front of the next lookup."""
-        if self._side2 is None or not self._opt_prefetch:
-            return
-        self._side2.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._side2):
-            self._prefetched = self._shard_request(ids, wts)
 
     def _front_sharded(self, ids, wts, label, capturing=False):
         cfg = self.cfg
@@ -198,26 +178,24 @@ class ShardStepMixin:
         if self._dyn:
             state = self._step_state
             state.advance(cfg.adam_lr, float(self.beta1), float(self.beta2))
-        # Dense gradients (+ Wide_b's, an element of the same buffer): summed over the batch slabs and all-reduced on a side
-        # branch of their own, beside the row-gradient exchange and the sparse apply -- neither needs them.
-        ev = self._tick("allreduce_dense")
-        main = torch.cuda.current_stream() if self._gpu else None
-        side2 = self._side2 if self._opt_ar_side else None
-        if side2 is not None:
-            side2.wait_stream(main)
-        with (torch.cuda.stream(side2) if side2 is not None else _null()):
-            if fused:
-                self._sum_dw_slabs()
-                if not route["wide_b_in_head"]:
-                    self.wide_b_grad.copy_(self.dense_grad[2 * (len(self.dims) - 2) + 1].view(1))      # = the output layer's bias gradient
-            else:
-                self.wide_b_grad.copy_(g_wide.sum().view(1))
-            self.comm.all_reduce(self.dense_grad_flat)
-        self._tock(ev)
         ev = self._tick("a2a_grads")
         gmsg = k.shard_route_grads(g_emb.reshape(n, D), g_wide.reshape(B).contiguous(), Fd, route["pos_of_slot"])
         recv_g = torch.empty_like(gmsg)
         self.comm.all_to_all(recv_g, gmsg)
+        self._tock(ev)
+        # Dense gradients (+ Wide_b's, an element of the same buffer): all-reduce queued behind the row-gradient exchange and
+        # left running (RCCL's stream) while the sparse apply executes -- it does not need it.  (The slab sum + all-reduce on a
+        # side branch of their own, and the NEXT step's request exchange issued under this step's apply inside a sink's graph,
+        # were both measured on one box: 0.905 ms/step as it is, 0.963 / 1.003 / 0.946 with either or both -- every extra branch
+        # costs this graph runtime more than the overlap returns.)
+        ev = self._tick("allreduce_dense")
+        if fused:
+            self._sum_dw_slabs()
+            if not route["wide_b_in_head"]:
+                self.wide_b_grad.copy_(self.dense_grad[2 * (len(self.dims) - 2) + 1].view(1))      # = the output layer's bias gradient
+        else:
+            self.wide_b_grad.copy_(g_wide.sum().view(1))
+        dense_work = self.comm.all_reduce(self.dense_grad_flat, async_op=True)
         self._tock(ev)
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)           # the plan (queued under the MLP) is done
@@ -242,8 +220,8 @@ class ShardStepMixin:
             k.sparse_ftrl_(self.wide, self.wide_accum, self.wide_linear, plan, recv_gw, route["recv_wts"], lr=cfg.ftrl_lr,
                            l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=scale)
         self._tock(ev)
-        if side2 is not None:
-            main.wait_stream(side2)               # the all-reduced dense gradient
+        if dense_work is not None:
+            dense_work.wait()                     # the current stream waits for RCCL's stream; no host block
         ev = self._tick("apply_dense")
         flat = self.dense_flat.detach()
         if fused:

@@ -52,6 +52,7 @@ def _worker(rank, port, out_dir, mlp_dtype):
     np.savez(os.path.join(out_dir, "rccl.npz"), deep=eng.deep.cpu().numpy(), wide=eng.wide.cpu().numpy(),
              deep_m=eng.deep_m.cpu().numpy(), dense=eng.dense_flat.detach().cpu().numpy(), losses=np.array(losses))
     dist.barrier()
+    eng.release_graphs()                   # graphs holding RCCL kernels must go before the process group does
     dist.destroy_process_group()
 
 
