@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--shard-protocol", action="store_true", help="one GPU: run the row-shard protocol (routing kernels + RCCL collectives "
                     "that talk to themselves) -- what a rank of an N-GPU job does besides moving bytes over xGMI")
     ap.add_argument("--capacity-factor", type=float, default=1.25, help="row shards: request slots per owner = ceil(factor * ids / ranks)")
+    ap.add_argument("--no-zipf39", action="store_true", help="skip the secondary Criteo-like measurement (Zipf ids, 39 fields) behind the timed region")
     return ap.parse_args()
 
 
@@ -189,6 +190,46 @@ def cpu_baseline(args, seconds):
             "sample": f"embedding path (lookup + wide_sum + sparse LazyAdam + sparse FTRL) at batch {B}x{Fd}, dim {D}, table scaled to "
                       f"V={V}, uniform ids, a fresh batch per step; value = all-core oracle leg + torch-CPU MLP {dims[0]}-1024-512-256-128-1 "
                       f"fwd+bwd; MindSpore CPU not installable here"}
+
+
+def zipf39_line(args, eng, dev, peak):
+    """The embedding path under Criteo-like ids (Zipf, 39 fields) through a second engine sharing the first one's tables."""
+    import torch
+    from mindrec_amd import ops
+    from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, embedding_bytes, synthetic_batch
+    cfg = WideDeepConfig(vocab_size=args.vocab, emb_dim=args.emb_dim, field_size=39, batch_size=args.batch, mlp_dtype=args.mlp_dtype,
+                         graphs=args.graphs, dropout_flag=args.dropout)
+    e2 = WideDeepEngine(cfg, dev, tables_from=eng)
+    batches = [synthetic_batch(cfg, dev, "zipf", seed=2000 + i) for i in range(4)]
+    S = max(1, args.sink_size)
+    for i in range(5):
+        e2.train_step(*batches[i % 4])
+    e2.train_steps([batches[j % 4] for j in range(S)])
+    torch.cuda.synchronize()
+    steps = 4 * S
+    t0 = time.perf_counter()
+    for i in range(0, steps, S):
+        e2.train_steps([batches[(i + j) % 4] for j in range(S)])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    st = e2._step_state.embed_ms(range(e2.step_count - steps + 1, e2.step_count + 1))
+    main_ms = e2._step_state.apply_ms(range(e2.step_count - steps + 1, e2.step_count + 1))
+    plan = e2.last_plan
+    U, n = plan.U, plan.n
+    by = embedding_bytes(n, U, args.emb_dim, act_bytes=2)
+    apply_b = by["apply_deep"] + U * 24 + args.batch * 4
+    lookup_b = by["lookup"] + U * 4 + n * 4
+    a_ms = sum(main_ms) / len(main_ms)
+    l_ms = sum(a for a, _ in st) / len(st)
+    all_ms = sum(b for _, b in st) / len(st)
+    del e2
+    return {"workload": f"same tables, batch {args.batch} x 39 fields, Zipf(1.05) ids per slot + the 13 constant dense-field ids", "unique_frac": round(U / n, 4),
+            "ms_per_step": round(ms, 4), "samples_per_s": round(args.batch / ms * 1e3, 1),
+            "kernel": "k_apply_main (dominant)", "algorithmic_bytes": apply_b, "avg_ms": round(a_ms, 5),
+            "achieved": round(apply_b / (a_ms * 1e-3) / 1e9, 1), "peak": peak, "unit": "GB/s", "frac": round(apply_b / (a_ms * 1e-3) / 1e9 / peak, 4),
+            "embedding_path": {"algorithmic_bytes": lookup_b + apply_b, "lookup_ms": round(l_ms, 5), "apply_ms_incl_finishing_kernel": round(all_ms, 5),
+                               "frac": round((lookup_b + apply_b) / ((l_ms + all_ms) * 1e-3) / 1e9 / peak, 4)},
+            "timing": f"in-graph kernel stamps over {len(st)} steps behind the timed region"}
 
 
 def main():
@@ -438,6 +479,14 @@ def main():
         slab_el = sum(t.numel() for t in list(eng._dw.values()) + list(eng._db.values()))
         covered = sum(t[0].numel() for t in list(eng._dw.values()) + list(eng._db.values()))
         out["dense_adam_bytes"] = {"read": 4 * (3 * n_el + slab_el + (n_el - covered)), "write": 4 * 3 * n_el + 2 * n_el}
+    if (world == 1 and not args.shard_protocol and not args.no_zipf39 and fold and default_cfg and eng._step_graph is not None):
+        # SURVEY 8(d) distribution (C): Criteo-like ids -- Zipf(1.05) per slot + the 13 constant dense-field ids of field_size 39
+        # (process_data.py:138-147) -- on a second engine that trains on the SAME tables: the duplicate-heavy case of the same
+        # kernels (U / N ~ 0.2), a secondary line, not `value`
+        try:
+            out["roofline_zipf39"] = zipf39_line(args, eng, dev, peak)
+        except Exception as e:       # noqa: BLE001  (a secondary measurement must not take the line down)
+            out["roofline_zipf39"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     if world > 1 or args.shard_protocol:
         dropped = eng.shard_overflow()
         out["config"]["shard_capacity"] = {"factor": args.capacity_factor, "dropped_positions": dropped}

@@ -137,10 +137,13 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
     _kernels = ops               # the op set (tests/ subclass the engine with a CPU stand-in to run the multi-rank host logic under gloo)
     _allow_cpu = False           # the product has no CPU path
 
-    def __init__(self, cfg: WideDeepConfig, device, rank=0, world=1, group=None, tuned_gemms=True, comm=None, shard_protocol=False):
+    def __init__(self, cfg: WideDeepConfig, device, rank=0, world=1, group=None, tuned_gemms=True, comm=None, shard_protocol=False,
+                 tables_from=None):
         """comm: collectives provider (default: torch.distributed as is, see _DirectComm).
         shard_protocol: run the row-shard protocol (routing kernels + collectives) even when world == 1 -- every
-        collective then talks to itself, which executes the RCCL code path on a single GPU."""
+        collective then talks to itself, which executes the RCCL code path on a single GPU.
+        tables_from: another engine of the same vocabulary / dim / layout whose fused-row tables this one trains on instead of
+        allocating its own (a second workload over the same 205-GB table: bench.py's Criteo-like line)."""
         self.cfg, self.device, self.rank, self.world, self.group = cfg, torch.device(device), rank, world, group
         self._sharded = bool(world > 1 or shard_protocol)
         self._fold_wide = False       # set below: one GPU, fused rows, 16-bit MLP -> the wide branch rides the deep kernels
@@ -208,7 +211,12 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
                 # both lookups and both sparse applies visit a row once.  The API still sees p, m, v [V, D] and w, accum,
                 # linear [V, 1] as (strided) tensors.
                 ldrow = -(-(3 * D + 4) // 32) * 32
-                self.deep_state = torch.zeros((R, ldrow), dtype=torch.float32, device=dev)
+                if tables_from is not None:
+                    if getattr(tables_from, "deep_state", None) is None or tuple(tables_from.deep_state.shape) != (R, ldrow):
+                        raise ValueError("tables_from: an engine with fused rows of the same vocabulary and dim")
+                    self.deep_state = tables_from.deep_state
+                else:
+                    self.deep_state = torch.zeros((R, ldrow), dtype=torch.float32, device=dev)
                 self.deep, self.deep_m, self.deep_v = (self.deep_state[:, :D], self.deep_state[:, D + 4:2 * D + 4],
                                                        self.deep_state[:, 2 * D + 4:3 * D + 4])
                 self.wide, self.wide_accum, self.wide_linear = (self.deep_state[:, D:D + 1], self.deep_state[:, D + 1:D + 2],
@@ -218,7 +226,9 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
                 self.deep_m, self.deep_v = torch.empty_like(self.deep), torch.empty_like(self.deep)
                 self.wide = torch.empty((R, 1), dtype=torch.float32, device=dev)
                 self.wide_accum, self.wide_linear = torch.empty_like(self.wide), torch.empty_like(self.wide)
-            if not cfg.dynamic_embedding and self.hb is None:
+            if tables_from is not None and getattr(self, "deep_state", None) is not tables_from.deep_state:
+                raise ValueError("tables_from needs the fused-row layout (fused_state, sparse, no host cache)")
+            if not cfg.dynamic_embedding and self.hb is None and tables_from is None:
                 self.k.fill_normal_(self.deep, cfg.seed, cfg.init_sigma, row0=rank, row_stride=world)
                 self.deep_m.zero_()
                 self.deep_v.zero_()
