@@ -57,7 +57,7 @@ class _Fast:
             g = torch.where(_t(h16) > 0, g, torch.zeros((), dtype=torch.float32))
         elif mask is not None:
             g = torch.where(_t(mask) > 0, g, torch.zeros((), dtype=torch.float32))
-        return g.numpy(), g.double().sum(dim=0).numpy()
+        return g.numpy(), g.sum(dim=0, dtype=torch.float64).numpy()
 
     @staticmethod
     def dense_bwd_weight(x16, dy16):

@@ -12,6 +12,11 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_runtest_logstart(nodeid, location):
+    if os.environ.get("GRAFT_REPO_ROOT") or os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        heartbeat(f"start {nodeid}")
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O
@@ -28,3 +33,16 @@ def dev():
     rc = _lib.lib().mrec_device_ok()
     assert rc == 0, f"libmrec_hip.so cannot use this device (rc={rc})"
     return torch.device("cuda:0")
+
+
+def heartbeat(msg):
+    """A long test's progress line, appended to gpurun_out/test_progress.log (pytest captures stdout; the GPU box's watchdog
+    takes a run that writes nothing for 7 minutes to be hung)."""
+    import time
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "test_progress.log"), "a") as f:
+            f.write(f"{time.strftime('%H:%M:%S')} {msg}\n")
+    except OSError:
+        pass

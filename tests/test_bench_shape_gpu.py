@@ -22,6 +22,7 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 ULP = {"bf16": 2.0 ** -7, "f16": 2.0 ** -10}
+_AUC_POOL = {}       # seed -> batch: the AUC test's training batches, shared by its two parametrizations
 
 
 def _cfg(dt, B=16384, V=2_000_000, layers=(1024, 512, 256, 128)):
@@ -174,13 +175,21 @@ def test_auc_parity_on_the_benchmarked_path(dev, oracle, dt):
     from _oracle_mixed import OracleMixedEngine
     from sklearn.metrics import roc_auc_score
     from mindrec_amd.wide_deep import WideDeepEngine, synthetic_batch
+    import time
+    from conftest import heartbeat
     cfg = _cfg(dt)
     g = WideDeepEngine(cfg, dev)
     o = OracleMixedEngine(cfg, dt, fast=True)
     S, sinks = 5, 40
+    t0 = time.time()
 
     def batch(s):
-        return synthetic_batch(cfg, "cpu", "zipf", seed=7000 + s, signal=True)
+        """41 distinct training batches, cycled five times (the Zipf generator takes a second per batch; both parametrizations
+        share the pool): 672 k samples per pass, the hot ids of every pass the same, the tail new to the tables each time."""
+        key = s % 41 if s < 90000 else s
+        if key not in _AUC_POOL:
+            _AUC_POOL[key] = synthetic_batch(cfg, "cpu", "zipf", seed=7000 + key, signal=True)
+        return _AUC_POOL[key]
 
     step = 0
     for _ in range(S):                       # the first steps one by one: the whole-step graph is captured on the fourth
@@ -189,11 +198,13 @@ def test_auc_parity_on_the_benchmarked_path(dev, oracle, dt):
         o.train_step(ids.numpy(), wts.numpy(), label.numpy().ravel())
         step += 1
     assert g._step_graph is not None
-    for _ in range(sinks):
+    for k in range(sinks):
         bs = [batch(step + j) for j in range(S)]
         lg = g.train_steps([tuple(t.to(dev) for t in b) for b in bs])
         lo = [o.train_step(b[0].numpy(), b[1].numpy(), b[2].numpy().ravel()) for b in bs]
         step += S
+        if k % 4 == 3:
+            heartbeat(f"test_auc_parity[{dt}]: step {step} / 205, {time.time() - t0:.0f} s")
     assert any(v is not None for v in g._sink_graphs.values()), "the sinks must have replayed as one graph of 5 steps"
     assert step == 205 and g.step_count == 205
     print(f"  last sink's losses: gpu {[round(float(x), 5) for x in lg]}, oracle {[round(x, 5) for x in lo]}")
