@@ -57,9 +57,6 @@ def parse():
                     "of the optimizers, the dense net only, or nothing (kernel by kernel)")
     ap.add_argument("--shard-protocol", action="store_true", help="one GPU: run the row-shard protocol (routing kernels + RCCL collectives "
                     "that talk to themselves) -- what a rank of an N-GPU job does besides moving bytes over xGMI")
-    ap.add_argument("--shard-no-exchange", action="store_true", help="with --shard-protocol: elide the collectives (a message is received where it was "
-                    "written) -- the protocol's KERNELS alone; RCCL exchanging two 75-MB messages with itself is a slow device copy that no "
-                    "rank of a real job performs at that size")
     ap.add_argument("--capacity-factor", type=float, default=1.25, help="row shards: request slots per owner = ceil(factor * ids / ranks)")
     ap.add_argument("--no-zipf39", action="store_true", help="skip the secondary Criteo-like measurement (Zipf ids, 39 fields) behind the timed region")
     return ap.parse_args()
@@ -272,21 +269,7 @@ def main():
                          mlp_dtype=args.mlp_dtype, fused_state=not args.split_state, graphs=args.graphs,
                          dynamic_embedding=args.dynamic_embedding, hash_capacity=args.hash_capacity,
                          host_cache_rows=args.host_cache_rows, shard_capacity_factor=args.capacity_factor, dropout_flag=args.dropout)
-    comm = None
-    if args.shard_no_exchange:
-        if not (args.shard_protocol and world == 1):
-            raise SystemExit("--shard-no-exchange goes with --shard-protocol on one GPU")
-
-        class _NoExchange:          # measurement aid: world 1, every message "arrives" by a kernel-free alias
-            capturable = True
-
-            def all_to_all(self, out, inp, out_splits=None, in_splits=None):
-                out.set_(inp)
-
-            def all_reduce(self, t, async_op=False):
-                return None
-        comm = _NoExchange()
-    eng = WideDeepEngine(cfg, dev, rank=rank, world=world, shard_protocol=args.shard_protocol, comm=comm)
+    eng = WideDeepEngine(cfg, dev, rank=rank, world=world, shard_protocol=args.shard_protocol)
     batches = [synthetic_batch(cfg, dev, args.dist, seed=1000 + i, rank=rank) for i in range(args.n_batches)]
     torch.cuda.synchronize()
 
@@ -447,7 +430,7 @@ def main():
                                f"{f', {S} steps per host call (sink_size)' if graphs_used.get('sink_size', 1) > 1 else ''}"
                                f"{', Dropout(0.5) on every DenseLayer input' if args.dropout else ''}",
                    "global_batch": args.batch * world, "id_dist": args.dist, "hip_graphs": graphs_used, "unique_frac": round(U / max(n_apply, 1), 4),
-                   "parallelism": ("1 GPU" + ((", row-shard protocol, collectives elided (kernels only)" if args.shard_no_exchange else ", row-shard protocol over RCCL with itself") if args.shard_protocol else "")) if world == 1 else f"tables row-sharded x{world} (RCCL all-to-all), MLP dp{world}"},
+                   "parallelism": ("1 GPU" + (", row-shard protocol over RCCL with itself" if args.shard_protocol else "")) if world == 1 else f"tables row-sharded x{world} (RCCL all-to-all), MLP dp{world}"},
         "roofline": {"bound": "hbm",
                      "kernel": ("k_apply_main<4,int,UpdAdam,%s,WIDE> (segment-sum + LazyAdam row update + FTRL on the row's wide record)" if fold else
                                 "k_apply_main<4,int,UpdAdam,%s> (fused segment-sum + LazyAdam row update)") % (dt_name + "_t" if io16 else "float"),

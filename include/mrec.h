@@ -582,6 +582,12 @@ int mrec_widen_i32_i64(const int32_t* in, int64_t n, int64_t* out, void* stream)
 /* MapTensorPut: table[rows[i], :] = vals[i, :] (rows < 0 skipped). */
 int mrec_scatter_rows_f32(float* table, int64_t ld, int32_t D, const int32_t* rows, int64_t n,
                           const float* vals, void* stream);
+/* dst[dst_rows[i], 0:W] = src[src_rows[i], 0:W] for i < min(n, *n_dev) (n_dev: device word, NULL = n); a pair with a negative
+ * row is skipped.  Either table may be pinned host memory (the device reads / writes it over PCIe): the row traffic of the
+ * embedding cache (vocab_cache_size: mindspore_rec/ops/embedding.py:164-182 -- evicted rows to their host home, missing rows
+ * back), driven by victim / miss lists that were compacted on the device and whose lengths the host never learns. */
+int mrec_move_rows_f32(const float* src, int64_t ld_src, const int64_t* src_rows, float* dst, int64_t ld_dst,
+                       const int64_t* dst_rows, int64_t n, const int64_t* n_dev, int32_t W, void* stream);
 
 /* ---- DCN-v1 cross layers -----------------------------------------------------------------
  * CrossLayer.construct, models/deep_and_cross/src/deep_and_cross.py:139-149, all L layers of
@@ -624,7 +630,7 @@ int mrec_scatter_add_rows_f32(float* table, int64_t ld, int32_t D, const int32_t
  * wider).
  *   mrec_dense32_fwd:        y = relu?(x . w + bias): x [M, K], w [K, N], bias [N] (nullable), y [M, N]
  *   mrec_dense32_bwd_input:  dx = (dy . w^T) masked by h > 0 (h [M, K]: the activation of the layer below, nullable); colsum_ws
- *                            (nullable): [ceil(M / 128), K] column sums of dx per 128-row tile = partial sums of the layer
+ *                            (nullable): [ceil(M / 64), K] column sums of dx per 64 rows = partial sums of the layer
  *                            below's bias gradient, to be added up in tile order (mrec_dense_adam_slabs_f32 does)
  *   mrec_dense32_bwd_weight: dw_slabs[s] = x[rows of slab s]^T . dy[rows of slab s], fp32 [S, K, N]: the batch is cut into S
  *                            slabs of ceil(M / S / 32) * 32 rows (mrec_dense32_bwd_weight_slabs proposes an S that fills the chip) */

@@ -141,6 +141,7 @@ _SIGS = {
     "mrec_compose_i32": [_vp, _vp, _i64, _vp, _vp],
     "mrec_widen_i32_i64": [_vp, _i64, _vp, _vp],
     "mrec_scatter_rows_f32": [_vp, _i64, _i32, _vp, _i64, _vp, _vp],
+    "mrec_move_rows_f32": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _vp],
     "mrec_cross_layers_f32": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp],
     "mrec_cross_layers_bwd_workspace_bytes": [_i32, _i64, _i32, _szp],
     "mrec_cross_layers_bwd_f32": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],

@@ -46,6 +46,9 @@ namespace {
 #ifndef MREC_GP4
 #define MREC_GP4 2
 #endif
+#ifndef MREC_WPS4
+#define MREC_WPS4 5         // waves per SIMD asked of the register allocator for the float4 + wide-lane kernel
+#endif
 #ifndef MREC_GP1
 #define MREC_GP1 4
 #endif
@@ -406,7 +409,7 @@ __device__ __forceinline__ void resolve_step(Upd&, const StepState*) {}
 __device__ __forceinline__ void resolve_step(UpdAdam& u, const StepState* ss) { if (ss) u.h.lr_t = ss->lr_t; }
 
 template <int VEC, class K, class Upd, class GT, bool WIDE = false>
-__global__ __launch_bounds__(256, WIDE ? 5 : 1) void k_apply_main(Upd upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
+__global__ __launch_bounds__(256, WIDE ? MREC_WPS4 : 1) void k_apply_main(Upd upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
                                                     const int* __restrict__ spos, const int* __restrict__ sseg,
                                                     int n, const GT* __restrict__ g, int64_t ldg,
                                                     const float* __restrict__ rscale, float gscale, ApplyGeom gm,

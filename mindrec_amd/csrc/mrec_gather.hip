@@ -313,6 +313,29 @@ __global__ __launch_bounds__(256) void k_scatter_rows(float* __restrict__ table,
     for (int c = lane; c < D; c += 64) table[(int64_t)r * ld + c] = vals[i * D + c];
 }
 
+// dst[dst_rows[i], :] = src[src_rows[i], :] for i < min(n, *n_dev): rows between a device cache and its pinned host home (either side
+// may be host memory read / written over PCIe), lists compacted on the device, their length known there only.  A wave per
+// row, 16-byte lanes when the geometry allows; i beyond the device count and negative rows cost nothing.
+template <bool V4>
+__global__ __launch_bounds__(256) void k_move_rows(const float* __restrict__ src, int64_t lds_, const int64_t* __restrict__ src_rows,
+                                                   float* __restrict__ dst, int64_t ldd, const int64_t* __restrict__ dst_rows,
+                                                   int64_t n, const int64_t* __restrict__ n_dev, int W) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int64_t lim = n;
+    if (n_dev) { const int64_t x = *n_dev; lim = x < 0 ? 0 : (x < n ? x : n); }
+    if (i >= lim) return;
+    const int64_t rs = src_rows[i], rd = dst_rows[i];
+    if (rs < 0 || rd < 0) return;
+    if (V4) {
+        const float4* s4 = (const float4*)(src + rs * lds_);
+        float4* d4 = (float4*)(dst + rd * ldd);
+        for (int c = lane; c < W / 4; c += 64) d4[c] = s4[c];
+    } else {
+        for (int c = lane; c < W; c += 64) dst[rd * ldd + c] = src[rs * lds_ + c];
+    }
+}
+
 // ---- dense optimizers ------------------------------------------------------------------------
 // Dense Adam over n elements.  GT = float or bf16 gradients (the GEMM that produced a weight gradient
 // in a bf16 MLP writes bf16; widening on load is exact).  SH: also write the updated parameter, rounded
@@ -753,6 +776,19 @@ MREC_API int mrec_scatter_rows_f32(float* table, int64_t ld, int32_t D, const in
     if (n == 0) return MREC_OK;
     if (!table || !rows || !vals) return MREC_EINVAL;
     k_scatter_rows<<<(unsigned)mrec_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(table, ld, D, rows, n, vals);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+MREC_API int mrec_move_rows_f32(const float* src, int64_t ld_src, const int64_t* src_rows, float* dst, int64_t ld_dst,
+                                const int64_t* dst_rows, int64_t n, const int64_t* n_dev, int32_t W, void* stream) {
+    if (n < 0 || W <= 0 || ld_src < W || ld_dst < W) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!src || !dst || !src_rows || !dst_rows) return MREC_EINVAL;
+    const bool v4 = W % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && al16(src) && al16(dst);
+    const unsigned grid = (unsigned)mrec_cdiv(n, 4);
+    if (v4) k_move_rows<true><<<grid, 256, 0, (hipStream_t)stream>>>(src, ld_src, src_rows, dst, ld_dst, dst_rows, n, n_dev, W);
+    else k_move_rows<false><<<grid, 256, 0, (hipStream_t)stream>>>(src, ld_src, src_rows, dst, ld_dst, dst_rows, n, n_dev, W);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }

@@ -2,27 +2,37 @@
 // 293-309) and its two bprops on the fp32-input matrix instruction of gfx950, v_mfma_f32_32x32x2_f32.
 //
 // The fp32 MFMA runs at the fp32 vector rate (157 TFLOP/s, 1/16 of the 16-bit forms) and is bit-for-bit a k-ordered chain of
-// fmaf's: one rounding per product, no wider accumulation.  At that rate nothing else on the CU is near its limit, so the
-// structure is the plain one: a 128 x 128 output tile per 256-thread workgroup, four waves as 2 x 2 with 64 x 64 (2 x 2
-// accumulators of 32 x 32) each, a 32-deep K-tile staged through registers into LDS in REDUCTION-MAJOR order (rows = k, 132
-// floats apart: conflict-free ds_read_b32 fragments: the instruction wants A[i = lane & 31][k = lane >> 5]), the next
-// K-tile's global loads in flight while the current one is multiplied.
+// fmaf's: one rounding per product, no wider accumulation.  At that rate nothing else on the CU is near its limit -- what
+// costs is an idle matrix pipe: rounds of workgroups that do not fill the chip, and the waits around the staging.  So:
+//   * a BM x 128 output tile per 256-thread workgroup, BM = 128 or 64 picked per problem so that the tiles come out in full
+//     rounds of the 512 workgroups the chip holds (2 per CU); four waves as 2 x 2, each (BM / 2) x 64 = BM / 64 x 2
+//     accumulators of 32 x 32;
+//   * a 32-deep K-tile in LDS in REDUCTION-MAJOR order (rows = k, 132 floats apart; the instruction wants
+//     A[i = lane & 31][k = lane >> 5], so a fragment is one conflict-free ds_read_b32), two buffers: the next K-tile's global
+//     loads are issued before the current one is multiplied and written to the other buffer behind its MFMAs -- ONE barrier
+//     per K-tile, with the second workgroup of the CU computing across it;
+//   * branch-free staging: a load whose vector lies outside the operand reads the operand's first element instead and is
+//     zeroed by a select (rows need only 8-byte alignment -- the DCN input is 39 x 30 = 1170 floats wide -- so VEC = 4, 2 or 1
+//     floats per load is picked per operand such that no vector straddles an edge);
+//   * a tile that hangs over the output's edge skips the MFMAs of its 32 x 32 blocks that lie wholly outside.
 //
 // Operands are either reduction-contiguous (X[r, k]: a row of the operand is a row of the matrix: transposed on its way into
-// LDS, four ds_write_b32 per 16-byte load) or reduction-strided (Y[k, c]: written as loaded):
+// LDS, VEC ds_write_b32 per load) or reduction-strided (Y[k, c]: written as loaded):
 //   forward   y  = x . W        A = x  [M, K] contiguous      B = W  [K, N] strided
 //   dgrad     dx = dy . W^T     A = dy [M, N] contiguous      B = W  [K, N] contiguous (its rows ARE the outputs)
 //   wgrad     dW = x^T . dy     A = x  [M, K] strided         B = dy [M, N] strided, reduction over the batch, split in slabs
-// Epilogues: bias + ReLU; mask by the activation below > 0 + per-tile-row column sums (the layer below's BiasAdd bprop);
-// plain fp32 slabs.  Rows need only 8-byte alignment (the DCN input is 39 x 30 = 1170 floats wide): VEC = 4, 2 or 1 floats per
-// load is picked per operand.
+// Epilogues: bias + ReLU; mask by the activation below > 0 + column sums per 64 output rows (the layer below's BiasAdd
+// bprop; the same partials in the same order whichever BM ran); plain fp32 slabs.
 #include "mrec_common.h"
 
 namespace gf32 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32, LD = 132;      // tile; LDS row stride in floats (528 B: 16-byte aligned rows)
+constexpr int BN = 128, BK = 32, LD = 132;      // column tile, K-tile; LDS row stride in floats (528 B: 16-byte aligned rows)
+constexpr int TILE_F = BK * LD;                 // floats per operand tile in LDS
+constexpr int LDS_BYTES = (4 * TILE_F + 2 * BN) * (int)sizeof(float);
+constexpr int SLOTS = 512;                      // workgroups the chip holds at 2 per CU
 enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_PLAIN = 2 };
 
 struct Args {
@@ -35,14 +45,14 @@ struct Args {
     const float* bias;         // EPI_FWD: [N] (nullable)
     int relu;
     const float* H; int64_t ldh;   // EPI_DGRAD: [M, N] activations of the layer below (nullable: no mask)
-    float* colsum;             // EPI_DGRAD: [tiles_m, N] per-tile-row column sums (nullable)
+    float* colsum;             // EPI_DGRAD: [ceil(M / 64), N] column sums per 64 output rows (nullable)
 };
 
-// one K-tile of an operand, global -> registers.  KC: stored [R, K] (reduction contiguous), R = the tile's 128 output
-// rows / columns; else stored [K, R].  VEC floats per load.
-template <bool KC, int VEC>
+// one K-tile of an operand, global -> registers -> LDS.  KC: stored [R, K] (reduction contiguous), R = the tile's ROWS output
+// rows / columns; else stored [K, R].  VEC floats per load; the host guarantees that no vector straddles an edge.
+template <bool KC, int VEC, int ROWS>
 struct Stage {
-    static constexpr int NV = BM * BK / 256 / VEC;       // loads per thread
+    static constexpr int NV = ROWS * BK / 256 / VEC;       // loads per thread
     float v[NV][VEC];
     __device__ __forceinline__ void load(const float* __restrict__ X, int64_t ldx, int r0, int R, int k0, int k_end, int t) {
 #pragma unroll
@@ -53,23 +63,21 @@ struct Stage {
                 const int q = t % QK, rr = t / QK + (256 / QK) * it;
                 r = r0 + rr; k = k0 + q * VEC;
             } else {
-                constexpr int QR = BM / VEC;             // loads per k-row
+                constexpr int QR = ROWS / VEC;           // loads per k-row
                 const int q = t % QR, kk = t / QR + (256 / QR) * it;
                 r = r0 + q * VEC; k = k0 + kk;
             }
-            const bool ok = KC ? (r < R && k + VEC <= k_end) : (k < k_end && r + VEC <= R);
-            const float* p = KC ? X + (int64_t)r * ldx + k : X + (int64_t)k * ldx + r;
-            if (ok) {
-                if (VEC == 4) { const float4 x = *(const float4*)p; v[it][0] = x.x; v[it][1 % VEC] = x.y; v[it][2 % VEC] = x.z; v[it][3 % VEC] = x.w; }
-                else if (VEC == 2) { const float2 x = *(const float2*)p; v[it][0] = x.x; v[it][1 % VEC] = x.y; }
-                else v[it][0] = *p;
+            const bool ok = r < R && k < k_end;
+            const float* p = ok ? (KC ? X + (int64_t)r * ldx + k : X + (int64_t)k * ldx + r) : X;
+            if (VEC == 4) {
+                const float4 x = *(const float4*)p;
+                v[it][0] = ok ? x.x : 0.0f; v[it][1 % VEC] = ok ? x.y : 0.0f; v[it][2 % VEC] = ok ? x.z : 0.0f; v[it][3 % VEC] = ok ? x.w : 0.0f;
+            } else if (VEC == 2) {
+                const float2 x = *(const float2*)p;
+                v[it][0] = ok ? x.x : 0.0f; v[it][1 % VEC] = ok ? x.y : 0.0f;
             } else {
-                // the ragged edge: element by element (k_end / R not multiples of VEC)
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) {
-                    const bool in = KC ? (r < R && k + c < k_end) : (k < k_end && r + c < R);
-                    v[it][c] = in ? p[c] : 0.0f;
-                }
+                const float x = *p;
+                v[it][0] = ok ? x : 0.0f;
             }
         }
     }
@@ -82,7 +90,7 @@ struct Stage {
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) S[(q * VEC + c) * LD + rr] = v[it][c];
             } else {
-                constexpr int QR = BM / VEC;
+                constexpr int QR = ROWS / VEC;
                 const int q = t % QR, kk = t / QR + (256 / QR) * it;
                 float* d = S + kk * LD + q * VEC;
                 if (VEC == 4) *(float4*)d = make_float4(v[it][0], v[it][1 % VEC], v[it][2 % VEC], v[it][3 % VEC]);
@@ -93,12 +101,44 @@ struct Stage {
     }
 };
 
-template <bool AKC, bool BKC, int EPI, int VA, int VB>
+// the 16 k-steps of one K-tile: fragments of step s + 1 are requested before the MFMAs of step s
+template <int MI, bool FULL>
+__device__ __forceinline__ void ktile(f32x16 (&acc)[MI][2], const float* __restrict__ As, const float* __restrict__ Bs, int ai, int bj, int kh,
+                                      const bool (&mv)[MI], const bool (&nv)[2]) {
+    float fa[2][MI], fb[2][2];
+    const float* ar = As + kh * LD + ai;
+    const float* br = Bs + kh * LD + bj;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) fa[0][mi] = ar[mi * 32];
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) fb[0][nj] = br[nj * 32];
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < BK / 2) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) fa[nxt][mi] = ar[(2 * s + 2) * LD + mi * 32];
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) fb[nxt][nj] = br[(2 * s + 2) * LD + nj * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // (left alone the scheduler sinks the reads to just in front of their MFMAs)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
+                if (FULL || (mv[mi] && nv[nj]))
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mi], fb[cur][nj], acc[mi][nj], 0, 0, 0);
+    }
+}
+
+template <int BM, bool AKC, bool BKC, int EPI, int VA, int VB>
 __global__ __launch_bounds__(256, 2) void k_gemm_f32(const Args a) {
-    __shared__ __attribute__((aligned(16))) float As[BK * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LD];
-    __shared__ float red[2][BN];
-    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // As[2] | Bs[2] | red[2][BN]
+    constexpr int MI = BM / 64;
+    float* const As = smem;
+    float* const Bs = smem + 2 * TILE_F;
+    float* const red = smem + 4 * TILE_F;
+    const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = w >> 1, wc = w & 1;
     // workgroup -> (tn, tm, z); column tiles fastest: neighbours share the A panel
     int bid = blockIdx.x;
@@ -109,53 +149,64 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const Args a) {
     const int kbeg = z * a.k_per_slab;
     const int kend = min(a.K, kbeg + a.k_per_slab);
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    Stage<AKC, VA> sa;
-    Stage<BKC, VB> sb;
-    sa.load(a.A, a.lda, m0, a.M, kbeg, kend, t);
-    sb.load(a.B, a.ldb, n0, a.N, kbeg, kend, t);
-    const int ai = wr * 64 + (l & 31), bj = wc * 64 + (l & 31), kh = l >> 5;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();                 // everybody is done reading the previous K-tile
+    // 32 x 32 blocks of this wave that hold any output at all (wave-uniform)
+    bool mv[MI], nv[2];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) mv[mi] = m0 + wr * (BM / 2) + mi * 32 < a.M;
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) nv[nj] = n0 + wc * 64 + nj * 32 < a.N;
+    const bool full = (m0 + BM <= a.M) && (n0 + BN <= a.N);
+
+    Stage<AKC, VA, BM> sa;
+    Stage<BKC, VB, BN> sb;
+    const int ai = wr * (BM / 2) + (l & 31), bj = wc * 64 + (l & 31), kh = l >> 5;
+    if (kbeg < kend) {
+        sa.load(a.A, a.lda, m0, a.M, kbeg, kend, t);
+        sb.load(a.B, a.ldb, n0, a.N, kbeg, kend, t);
         sa.store(As, t);
         sb.store(Bs, t);
-        __syncthreads();
-        if (k0 + BK < kend) {            // the next K-tile's loads fly while this one is multiplied
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = k0 + BK < kend;
+        if (more) {                      // the next K-tile's loads fly while this one is multiplied
             sa.load(a.A, a.lda, m0, a.M, k0 + BK, kend, t);
             sb.load(a.B, a.ldb, n0, a.N, k0 + BK, kend, t);
         }
-#pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
-            const float* ar = As + (2 * s + kh) * LD + ai;
-            const float* br = Bs + (2 * s + kh) * LD + bj;
-            const float a0 = ar[0], a1 = ar[32], b0 = br[0], b1 = br[32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        if (full) ktile<MI, true>(acc, As + cur * TILE_F, Bs + cur * TILE_F, ai, bj, kh, mv, nv);
+        else ktile<MI, false>(acc, As + cur * TILE_F, Bs + cur * TILE_F, ai, bj, kh, mv, nv);
+        if (more) {                      // the other buffer was last read one K-tile ago, in front of the barrier below
+            sa.store(As + (cur ^ 1) * TILE_F, t);
+            sb.store(Bs + (cur ^ 1) * TILE_F, t);
         }
+        __syncthreads();
+        cur ^= 1;
     }
 
-    // ---- epilogue: lane owns column j = n0 + wc*64 + nj*32 + (l & 31), rows i = m0 + wr*64 + mi*32 + (r & 3) + 8 (r >> 2) + 4 kh
+    // ---- epilogue: lane owns column j = n0 + wc*64 + nj*32 + (l & 31), rows i = m0 + wr*(BM/2) + mi*32 + (r & 3) + 8 (r >> 2) + 4 kh
     float* C = a.C + (EPI == EPI_PLAIN ? (int64_t)z * a.slab_stride : 0);
-    float cs[2] = {0.0f, 0.0f};
+    float cs[MI][2];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) cs[mi][0] = cs[mi][1] = 0.0f;
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
         const int j = n0 + wc * 64 + nj * 32 + (l & 31);
         const bool jok = j < a.N;
         const float bv = (EPI == EPI_FWD && a.bias != nullptr && jok) ? a.bias[j] : 0.0f;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int i = m0 + wr * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 float v = acc[mi][nj][r];
                 if (EPI == EPI_FWD) {
                     v = v + bv;
@@ -164,36 +215,65 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const Args a) {
                 const bool ok = jok && i < a.M;
                 if (EPI == EPI_DGRAD) {
                     if (a.H != nullptr && ok && !(a.H[(int64_t)i * a.ldh + j] > 0.0f)) v = 0.0f;
-                    if (ok) cs[nj] += v;         // rows in register order, then the fixed tree below
+                    if (ok) cs[mi][nj] += v;     // rows in register order, then the fixed tree below
                 }
                 if (ok) C[(int64_t)i * a.ldc + j] = v;
             }
         }
     }
     if (EPI == EPI_DGRAD && a.colsum != nullptr) {
-        // the lane halves (rows 4 kh), then the two wave rows through LDS: one partial per 128-row tile and column
+        // per 32-row block: the two lane halves (rows 4 kh); per 64 rows: block 0 + block 1 -- the two blocks of a wave
+        // (BM = 128) or of the two wave rows (BM = 64, through LDS): the same partials in the same order either way
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
-            cs[nj] += __shfl_xor(cs[nj], 32, 64);
-            if (kh == 0) red[wr][wc * 64 + nj * 32 + (l & 31)] = cs[nj];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) cs[mi][nj] += __shfl_xor(cs[mi][nj], 32, 64);
+            const int jl = wc * 64 + nj * 32 + (l & 31);
+            if (MI == 2) {
+                const int row = 2 * tm + wr;
+                if (kh == 0 && n0 + jl < a.N && (int64_t)row * 64 < a.M) a.colsum[(int64_t)row * a.N + n0 + jl] = cs[0][nj] + cs[MI - 1][nj];
+            } else if (kh == 0) {
+                red[wr * BN + jl] = cs[0][nj];
+            }
         }
-        __syncthreads();
-        if (t < BN && n0 + t < a.N) a.colsum[(int64_t)tm * a.N + n0 + t] = red[0][t] + red[1][t];
+        if (MI == 1) {
+            __syncthreads();
+            if (t < BN && n0 + t < a.N) a.colsum[(int64_t)tm * a.N + n0 + t] = red[t] + red[BN + t];
+        }
     }
 }
 
-inline int vec_of(const float* p, int64_t ld, int ext_c) {      // widest aligned load for rows `ld` apart whose contiguous extent is ext_c
+// widest aligned load for rows `ld` apart whose contiguous extent is ext_c: no vector may straddle the extent's end
+inline int vec_of(const float* p, int64_t ld, int ext_c) {
     const uintptr_t u = (uintptr_t)p;
-    if ((u & 15) == 0 && ld % 4 == 0) return 4;
-    if ((u & 7) == 0 && ld % 2 == 0) return 2;
-    (void)ext_c;
+    if ((u & 15) == 0 && ld % 4 == 0 && ext_c % 4 == 0) return 4;
+    if ((u & 7) == 0 && ld % 2 == 0 && ext_c % 2 == 0) return 2;
     return 1;
 }
 
-template <bool AKC, bool BKC, int EPI>
-int launch(const Args& a, int va, int vb, int S, hipStream_t st) {
-    const unsigned grid = (unsigned)((int64_t)a.tiles_m * a.tiles_n * S);
-#define GF_GO(VA, VB) k_gemm_f32<AKC, BKC, EPI, VA, VB><<<grid, 256, 0, st>>>(a)
+// BM = 64 when its tiles come out in fewer (half-length) rounds of the chip than those of BM = 128
+inline int pick_bm(int64_t M, int64_t N, int64_t S) {
+    const int64_t tn = mrec_cdiv(N, BN);
+    const int64_t c128 = mrec_cdiv(mrec_cdiv(M, 128) * tn * S, SLOTS) * 2;
+    const int64_t c64 = mrec_cdiv(mrec_cdiv(M, 64) * tn * S, SLOTS);
+    return c64 < c128 ? 64 : 128;
+}
+
+template <int BM, bool AKC, bool BKC, int EPI, int VA, int VB>
+int launch_one(const Args& a, unsigned grid, hipStream_t st) {
+    static bool attr_done = false;      // (per instantiation; racing threads set the same value)
+    if (!attr_done) {
+        MREC_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm_f32<BM, AKC, BKC, EPI, VA, VB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_done = true;
+    }
+    k_gemm_f32<BM, AKC, BKC, EPI, VA, VB><<<grid, 256, LDS_BYTES, st>>>(a);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+template <int BM, bool AKC, bool BKC, int EPI>
+int launch_bm(const Args& a, int va, int vb, unsigned grid, hipStream_t st) {
+#define GF_GO(VA, VB) return launch_one<BM, AKC, BKC, EPI, VA, VB>(a, grid, st)
     if (va == 4 && vb == 4) GF_GO(4, 4);
     else if (va == 4 && vb == 2) GF_GO(4, 2);
     else if (va == 2 && vb == 4) GF_GO(2, 4);
@@ -202,8 +282,16 @@ int launch(const Args& a, int va, int vb, int S, hipStream_t st) {
     else if (va == 1) { if (vb == 4) GF_GO(1, 4); else GF_GO(1, 2); }
     else { if (va == 4) GF_GO(4, 1); else GF_GO(2, 1); }
 #undef GF_GO
-    MREC_LAUNCH_CHECK();
-    return MREC_OK;
+}
+
+// a: M, N, K, operands and epilogue set; tiles and the grid are filled in here
+template <bool AKC, bool BKC, int EPI>
+int launch(Args a, int va, int vb, int S, hipStream_t st) {
+    const int bm = pick_bm(a.M, a.N, S);
+    a.tiles_m = (int)mrec_cdiv(a.M, bm);
+    a.tiles_n = (int)mrec_cdiv(a.N, BN);
+    const unsigned grid = (unsigned)((int64_t)a.tiles_m * a.tiles_n * S);
+    return bm == 64 ? launch_bm<64, AKC, BKC, EPI>(a, va, vb, grid, st) : launch_bm<128, AKC, BKC, EPI>(a, va, vb, grid, st);
 }
 
 }  // namespace gf32
@@ -220,14 +308,13 @@ MREC_API int mrec_dense32_fwd(const float* x, int64_t ldx, const float* w, int64
     Args a{};
     a.A = x; a.lda = ldx; a.B = w; a.ldb = ldw; a.C = y; a.ldc = ldy;
     a.M = (int)M; a.N = N; a.K = K;
-    a.tiles_m = (int)mrec_cdiv(M, gf32::BM); a.tiles_n = (int)mrec_cdiv(N, gf32::BN);
     a.k_per_slab = (int)mrec_align_up((size_t)K, gf32::BK);
     a.bias = bias; a.relu = relu;
     return gf32::launch<true, false, gf32::EPI_FWD>(a, gf32::vec_of(x, ldx, K), gf32::vec_of(w, ldw, N), 1, (hipStream_t)stream);
 }
 
 /* dx = (dy . w^T) * (h > 0): dy [M, N] (lddy), w [K, N] (ldw), h [M, K] (ldh, nullable), dx [M, K] (lddx);
- * colsum_ws (nullable): [ceil(M / 128), K] per-tile-row column sums of dx = the partials of the layer below's bias gradient */
+ * colsum_ws (nullable): [ceil(M / 64), K] column sums of dx per 64 rows = the partials of the layer below's bias gradient */
 MREC_API int mrec_dense32_bwd_input(const float* dy, int64_t lddy, const float* w, int64_t ldw, const float* h, int64_t ldh, int64_t M,
                                     int32_t K, int32_t N, float* dx, int64_t lddx, float* colsum_ws, void* stream) {
     if (M < 0 || K <= 0 || N <= 0 || lddy < N || ldw < N || lddx < K || (h && ldh < K)) return MREC_EINVAL;
@@ -237,7 +324,6 @@ MREC_API int mrec_dense32_bwd_input(const float* dy, int64_t lddy, const float* 
     Args a{};
     a.A = dy; a.lda = lddy; a.B = w; a.ldb = ldw; a.C = dx; a.ldc = lddx;
     a.M = (int)M; a.N = K; a.K = N;                       // outputs [M, K], reduction over N
-    a.tiles_m = (int)mrec_cdiv(M, gf32::BM); a.tiles_n = (int)mrec_cdiv(K, gf32::BN);
     a.k_per_slab = (int)mrec_align_up((size_t)N, gf32::BK);
     a.H = h; a.ldh = ldh; a.colsum = colsum_ws;
     return gf32::launch<true, true, gf32::EPI_DGRAD>(a, gf32::vec_of(dy, lddy, N), gf32::vec_of(w, ldw, N), 1, (hipStream_t)stream);
@@ -258,22 +344,28 @@ MREC_API int mrec_dense32_bwd_weight(const float* x, int64_t ldx, const float* d
     Args a{};
     a.A = x; a.lda = ldx; a.B = dy; a.ldb = lddy; a.C = dw_slabs; a.ldc = N;
     a.M = K; a.N = N; a.K = (int)M;                       // outputs [K, N], reduction over the batch
-    a.tiles_m = (int)mrec_cdiv(K, gf32::BM); a.tiles_n = (int)mrec_cdiv(N, gf32::BN);
     a.k_per_slab = (int)mrec_align_up((size_t)mrec_cdiv(M, S), gf32::BK);
     a.slab_stride = (int64_t)K * N;
     if ((int64_t)a.k_per_slab * (S - 1) >= M && S > 1) return MREC_EINVAL;      // an empty slab: S too large for this batch
     return gf32::launch<false, false, gf32::EPI_PLAIN>(a, gf32::vec_of(x, ldx, K), gf32::vec_of(dy, lddy, N), S, (hipStream_t)stream);
 }
 
-/* Batch slabs that fill the chip about twice: the output has only ceil(K / 128) * ceil(N / 128) tiles */
+/* Batch slabs: the output has only ceil(K / BM) * ceil(N / 128) tiles.  The count (and with it the tile height the launch will pick)
+ * that takes the fewest rounds of the chip's 512 workgroup slots x rows per workgroup; among equals the smallest (the slabs are
+ * the optimizer's to read). */
 MREC_API int mrec_dense32_bwd_weight_slabs(int64_t M, int32_t K, int32_t N, int32_t* out) {
     if (!out || M < 0 || K <= 0 || N <= 0) return MREC_EINVAL;
-    const int64_t tiles = mrec_cdiv(K, gf32::BM) * mrec_cdiv(N, gf32::BN);
-    int64_t S = mrec_cdiv(512, tiles);
-    const int64_t smax = M / 256 > 0 ? M / 256 : 1;       // at least 256 batch rows per slab
-    if (S > smax) S = smax;
-    if (S > 64) S = 64;
-    while (S > 1 && (int64_t)mrec_align_up((size_t)mrec_cdiv(M, S), gf32::BK) * (S - 1) >= M) --S;
-    *out = (int32_t)S;
+    int64_t smax = M / 256 > 0 ? M / 256 : 1;             // at least 256 batch rows per slab
+    if (smax > 64) smax = 64;
+    int64_t best = 1, best_cost = -1;
+    for (int64_t S = 1; S <= smax; ++S) {
+        const int64_t rows = (int64_t)mrec_align_up((size_t)mrec_cdiv(M, S), gf32::BK);
+        if (S > 1 && rows * (S - 1) >= M) continue;       // an empty slab
+        const int bm = gf32::pick_bm(K, N, S);
+        const int64_t rounds = mrec_cdiv(mrec_cdiv(K, bm) * mrec_cdiv(N, gf32::BN) * S, gf32::SLOTS);
+        const int64_t cost = rounds * bm * rows;
+        if (best_cost < 0 || cost < best_cost) { best = S; best_cost = cost; }
+    }
+    *out = (int32_t)best;
     return MREC_OK;
 }

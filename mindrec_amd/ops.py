@@ -255,6 +255,24 @@ def scatter_rows_pinned_(host_table, rows, vals):
     _lib.call("mrec_scatter_rows_f32", _ptr(host_table), ld, D, _ptr(r32), n, _ptr(vals), _stream())
 
 
+def move_rows_(dst, dst_rows, src, src_rows, n_dev=None):
+    """dst[dst_rows[i], :] = src[src_rows[i], :] for i < n_dev (device int64 word; None: every i); pairs with a negative row are
+    skipped.  dst / src: float32 [*, W] device tensors or PINNED host tensors (device-addressable; moved over PCIe); the row
+    lists are int64 device tensors of one length."""
+    for t in (dst, src):
+        if not t.is_cuda and not t.is_pinned():
+            raise TypeError("move_rows_ needs device tensors or pinned host tensors")
+    _need_cuda(dst_rows, src_rows, n_dev)
+    if dst_rows.dtype != torch.int64 or src_rows.dtype != torch.int64 or dst_rows.numel() != src_rows.numel():
+        raise TypeError("row lists must be int64 tensors of one length")
+    _, W, ldd = _table(dst)
+    _, Ws, lds = _table(src)
+    if W != Ws:
+        raise ValueError("row widths differ")
+    _lib.call("mrec_move_rows_f32", _ptr(src), lds, _ptr(src_rows.contiguous()), _ptr(dst), ldd, _ptr(dst_rows.contiguous()),
+              dst_rows.numel(), _ptr(n_dev), W, _stream())
+
+
 def wide_sum(w, ids, wts, bias=None):
     """Wide branch of WideDeepModel.construct (wide_and_deep.py:300,303-306): [B]."""
     _need_cuda(w, ids, wts, bias)
@@ -1367,11 +1385,11 @@ def dense32_fwd(x, w, bias=None, relu=True, out=None):
 
 
 def dense32_colsum_tiles(M):
-    return (int(M) + 127) // 128
+    return (int(M) + 63) // 64
 
 
 def dense32_bwd_input(dy, w, h=None, out=None, colsum=None):
-    """dx = (dy . w^T) masked by h > 0; colsum (optional fp32 [ceil(M / 128), K]): per-tile-row column sums of dx."""
+    """dx = (dy . w^T) masked by h > 0; colsum (optional fp32 [ceil(M / 64), K]): column sums of dx per 64 rows."""
     _need_cuda(dy, w, h, out, colsum)
     M, N, lddy = _mat32(dy, "dy")
     K, N2, ldw = _mat32(w, "w")
@@ -1387,7 +1405,7 @@ def dense32_bwd_input(dy, w, h=None, out=None, colsum=None):
         if (M3, K3) != (M, K):
             raise TypeError("h must be [M, K]")
     if colsum is not None and (colsum.dtype != torch.float32 or tuple(colsum.shape) != (dense32_colsum_tiles(M), K) or not colsum.is_contiguous()):
-        raise TypeError("colsum must be contiguous float32 [ceil(M / 128), K]")
+        raise TypeError("colsum must be contiguous float32 [ceil(M / 64), K]")
     _lib.call("mrec_dense32_bwd_input", _ptr(dy), lddy, _ptr(w), ldw, _ptr(h), ldh, M, K, N, _ptr(dx), lddx, _ptr(colsum), _stream())
     return dx
 
