@@ -493,6 +493,7 @@ def main():
         if dropped:
             raise SystemExit(f"{dropped} id positions did not fit the fixed-capacity request message: not a valid run "
                              f"(raise --capacity-factor)")
+    eng.check_cache()           # host_cache_rows: a batch that did not fit the device cache is latched on the device
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

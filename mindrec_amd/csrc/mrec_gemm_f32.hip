@@ -4,13 +4,12 @@
 // The fp32 MFMA runs at the fp32 vector rate (157 TFLOP/s, 1/16 of the 16-bit forms) and is bit-for-bit a k-ordered chain of
 // fmaf's: one rounding per product, no wider accumulation.  At that rate nothing else on the CU is near its limit -- what
 // costs is an idle matrix pipe: rounds of workgroups that do not fill the chip, and the waits around the staging.  So:
-//   * a BM x 128 output tile per 256-thread workgroup, BM = 128 or 64 picked per problem so that the tiles come out in full
-//     rounds of the 512 workgroups the chip holds (2 per CU); four waves as 2 x 2, each (BM / 2) x 64 = BM / 64 x 2
-//     accumulators of 32 x 32;
+//   * a 128 x 128 output tile per 256-thread workgroup, two workgroups per CU (one computes across the other's barrier);
+//     four waves as 2 x 2, each 64 x 64 = 2 x 2 accumulators of 32 x 32;
 //   * a 32-deep K-tile in LDS in REDUCTION-MAJOR order (rows = k, 132 floats apart; the instruction wants
-//     A[i = lane & 31][k = lane >> 5], so a fragment is one conflict-free ds_read_b32), two buffers: the next K-tile's global
-//     loads are issued before the current one is multiplied and written to the other buffer behind its MFMAs -- ONE barrier
-//     per K-tile, with the second workgroup of the CU computing across it;
+//     A[i = lane & 31][k = lane >> 5], so a fragment is one conflict-free ds_read_b32), two buffers, and a staging
+//     pipeline whose every instruction sits in a gap between MFMAs: while K-tile j is multiplied, K-tile j + 1 is requested
+//     from memory (first half of the MFMAs) and written to the other buffer (second half) -- ONE barrier per K-tile;
 //   * branch-free staging: a load whose vector lies outside the operand reads the operand's first element instead and is
 //     zeroed by a select (rows need only 8-byte alignment -- the DCN input is 39 x 30 = 1170 floats wide -- so VEC = 4, 2 or 1
 //     floats per load is picked per operand such that no vector straddles an edge);
@@ -22,16 +21,21 @@
 //   dgrad     dx = dy . W^T     A = dy [M, N] contiguous      B = W  [K, N] contiguous (its rows ARE the outputs)
 //   wgrad     dW = x^T . dy     A = x  [M, K] strided         B = dy [M, N] strided, reduction over the batch, split in slabs
 // Epilogues: bias + ReLU; mask by the activation below > 0 + column sums per 64 output rows (the layer below's BiasAdd
-// bprop; the same partials in the same order whichever BM ran); plain fp32 slabs.
+// bprop); plain fp32 slabs.
+//
+// Measured (MI355X, DCN layer 1, tools/dcn_bench.py): the bare loop -- fragments from LDS + MFMAs, no staging, no barrier -- runs
+// at 110 TFLOP/s, 70 % of the 157 TF the instruction's cycle count gives at 2.4 GHz: under this load the chip holds ~1.65 GHz
+// (MI355X guide, DVFS give-back (5)); that, not 157, is what a kernel on this instruction can approach.
+#include <type_traits>
 #include "mrec_common.h"
 
 namespace gf32 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BN = 128, BK = 32, LD = 132;      // column tile, K-tile; LDS row stride in floats (528 B: 16-byte aligned rows)
+constexpr int BM = 128, BN = 128, BK = 32, LD = 132;      // tile, K-tile; LDS row stride in floats (528 B: 16-byte aligned rows)
 constexpr int TILE_F = BK * LD;                 // floats per operand tile in LDS
-constexpr int LDS_BYTES = (4 * TILE_F + 2 * BN) * (int)sizeof(float);
+constexpr int LDS_BYTES = 4 * TILE_F * (int)sizeof(float);
 constexpr int SLOTS = 512;                      // workgroups the chip holds at 2 per CU
 enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_PLAIN = 2 };
 
@@ -48,96 +52,86 @@ struct Args {
     float* colsum;             // EPI_DGRAD: [ceil(M / 64), N] column sums per 64 output rows (nullable)
 };
 
-// one K-tile of an operand, global -> registers -> LDS.  KC: stored [R, K] (reduction contiguous), R = the tile's ROWS output
-// rows / columns; else stored [K, R].  VEC floats per load; the host guarantees that no vector straddles an edge.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// one K-tile of an operand, global -> registers -> LDS, one load at a time (the K-loop spreads them between its MFMAs).
+// KC: stored [R, K] (reduction contiguous), R = the tile's ROWS output rows / columns; else stored [K, R].  VEC floats per load;
+// the host guarantees that no vector straddles an edge.  A load that lies outside the operand reads X[0] instead and is zeroed
+// on its way into LDS (NOT behind the load: a select there makes the wave wait for the load at once).
 template <bool KC, int VEC, int ROWS>
 struct Stage {
-    static constexpr int NV = ROWS * BK / 256 / VEC;       // loads per thread
+    static constexpr int NV = ROWS * BK / 256 / VEC;       // loads per thread and K-tile
+    static constexpr int QK = BK / VEC, QR = ROWS / VEC;   // loads per row (KC) / per k-row
     float v[NV][VEC];
-    __device__ __forceinline__ void load(const float* __restrict__ X, int64_t ldx, int r0, int R, int k0, int k_end, int t) {
+    uint32_t off[NV];          // element offset of load `it` in K-tile 0
+    unsigned rowok, okm;       // bit it: the load's row is inside the operand / the load in flight is inside it
+    int kq;                    // k of this thread's loads inside a K-tile: kq + kstep(it)
+    static __device__ __forceinline__ constexpr int kstep(int it) { return KC ? 0 : (256 / QR) * it; }
+    __device__ __forceinline__ void init(int64_t ldx, int r0, int R, int kbeg, int t) {
+        rowok = 0u; okm = 0u;
+        kq = KC ? (t % QK) * VEC : t / QR;
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
-            int r, k;
-            if (KC) {
-                constexpr int QK = BK / VEC;             // loads per row
-                const int q = t % QK, rr = t / QK + (256 / QK) * it;
-                r = r0 + rr; k = k0 + q * VEC;
-            } else {
-                constexpr int QR = ROWS / VEC;           // loads per k-row
-                const int q = t % QR, kk = t / QR + (256 / QR) * it;
-                r = r0 + q * VEC; k = k0 + kk;
-            }
-            const bool ok = r < R && k < k_end;
-            const float* p = ok ? (KC ? X + (int64_t)r * ldx + k : X + (int64_t)k * ldx + r) : X;
-            if (VEC == 4) {
-                const float4 x = *(const float4*)p;
-                v[it][0] = ok ? x.x : 0.0f; v[it][1 % VEC] = ok ? x.y : 0.0f; v[it][2 % VEC] = ok ? x.z : 0.0f; v[it][3 % VEC] = ok ? x.w : 0.0f;
-            } else if (VEC == 2) {
-                const float2 x = *(const float2*)p;
-                v[it][0] = ok ? x.x : 0.0f; v[it][1 % VEC] = ok ? x.y : 0.0f;
-            } else {
-                const float x = *p;
-                v[it][0] = ok ? x : 0.0f;
-            }
+            const int r = KC ? r0 + t / QK + (256 / QK) * it : r0 + (t % QR) * VEC;
+            const int k = kbeg + kq + kstep(it);
+            rowok |= r < R ? (1u << it) : 0u;
+            off[it] = r < R ? (uint32_t)(KC ? (int64_t)r * ldx + k : (int64_t)k * ldx + r) : 0u;
         }
     }
-    __device__ __forceinline__ void store(float* __restrict__ S, int t) const {      // S: [BK][LD] reduction-major
+    // kadv: element offset of the K-tile against K-tile 0 (KC: its k0 - kbeg; else that times the row stride)
+    template <int IT>
+    __device__ __forceinline__ void load_one(const float* __restrict__ X, uint32_t kadv, int k0, int k_end) {
+        const unsigned ok = ((rowok >> IT) & 1u) & (unsigned)(k0 + kq + kstep(IT) < k_end);      // (no &&: no branch)
+        okm = (okm & ~(1u << IT)) | (ok << IT);
+        const float* p = X + (ok ? off[IT] + kadv : 0u);
+        if (VEC == 4) {
+            const float4 x = *(const float4*)p;
+            v[IT][0] = x.x; v[IT][1 % VEC] = x.y; v[IT][2 % VEC] = x.z; v[IT][3 % VEC] = x.w;
+        } else if (VEC == 2) {
+            const float2 x = *(const float2*)p;
+            v[IT][0] = x.x; v[IT][1 % VEC] = x.y;
+        } else {
+            v[IT][0] = *p;
+        }
+    }
+    template <int IT>
+    __device__ __forceinline__ void store_one(float* __restrict__ S, int t) const {      // S: [BK][LD] reduction-major
+        const bool ok = (okm >> IT) & 1u;
+        float x[VEC];
 #pragma unroll
-        for (int it = 0; it < NV; ++it) {
-            if (KC) {
-                constexpr int QK = BK / VEC;
-                const int q = t % QK, rr = t / QK + (256 / QK) * it;
+        for (int c = 0; c < VEC; ++c) x[c] = ok ? v[IT][c] : 0.0f;
+        if (KC) {
+            const int q = t % QK, rr = t / QK + (256 / QK) * IT;
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) S[(q * VEC + c) * LD + rr] = v[it][c];
-            } else {
-                constexpr int QR = ROWS / VEC;
-                const int q = t % QR, kk = t / QR + (256 / QR) * it;
-                float* d = S + kk * LD + q * VEC;
-                if (VEC == 4) *(float4*)d = make_float4(v[it][0], v[it][1 % VEC], v[it][2 % VEC], v[it][3 % VEC]);
-                else if (VEC == 2) *(float2*)d = make_float2(v[it][0], v[it][1 % VEC]);
-                else *d = v[it][0];
-            }
+            for (int c = 0; c < VEC; ++c) S[(q * VEC + c) * LD + rr] = x[c];
+        } else {
+            const int q = t % QR, kk = t / QR + (256 / QR) * IT;
+            float* d = S + kk * LD + q * VEC;
+            if (VEC == 4) *(float4*)d = make_float4(x[0], x[1 % VEC], x[2 % VEC], x[3 % VEC]);
+            else if (VEC == 2) *(float2*)d = make_float2(x[0], x[1 % VEC]);
+            else *d = x[0];
         }
     }
 };
 
-// the 16 k-steps of one K-tile: fragments of step s + 1 are requested before the MFMAs of step s
-template <int MI, bool FULL>
-__device__ __forceinline__ void ktile(f32x16 (&acc)[MI][2], const float* __restrict__ As, const float* __restrict__ Bs, int ai, int bj, int kh,
-                                      const bool (&mv)[MI], const bool (&nv)[2]) {
-    float fa[2][MI], fb[2][2];
-    const float* ar = As + kh * LD + ai;
-    const float* br = Bs + kh * LD + bj;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) fa[0][mi] = ar[mi * 32];
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj) fb[0][nj] = br[nj * 32];
-#pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
-        const int cur = s & 1, nxt = cur ^ 1;
-        if (s + 1 < BK / 2) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) fa[nxt][mi] = ar[(2 * s + 2) * LD + mi * 32];
-#pragma unroll
-            for (int nj = 0; nj < 2; ++nj) fb[nxt][nj] = br[(2 * s + 2) * LD + nj * 32];
-        }
-        __builtin_amdgcn_sched_barrier(0);      // (left alone the scheduler sinks the reads to just in front of their MFMAs)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int nj = 0; nj < 2; ++nj)
-                if (FULL || (mv[mi] && nv[nj]))
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mi], fb[cur][nj], acc[mi][nj], 0, 0, 0);
-    }
+// workgroup barrier that waits for this wave's LDS traffic only: the global loads of the K-tile after next stay in flight
+// across it (__syncthreads waits for vmcnt(0) as well)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int BM, bool AKC, bool BKC, int EPI, int VA, int VB>
+template <bool AKC, bool BKC, int EPI, int VA, int VB>
 __global__ __launch_bounds__(256, 2) void k_gemm_f32(const Args a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // As[2] | Bs[2] | red[2][BN]
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // As[2] | Bs[2]
     constexpr int MI = BM / 64;
     float* const As = smem;
     float* const Bs = smem + 2 * TILE_F;
-    float* const red = smem + 4 * TILE_F;
     const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = w >> 1, wc = w & 1;
     // workgroup -> (tn, tm, z); column tiles fastest: neighbours share the A panel
@@ -148,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const Args a) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = z * a.k_per_slab;
     const int kend = min(a.K, kbeg + a.k_per_slab);
+    const int T = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
 
     f32x16 acc[MI][2];
 #pragma unroll
@@ -165,32 +160,75 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const Args a) {
     for (int nj = 0; nj < 2; ++nj) nv[nj] = n0 + wc * 64 + nj * 32 < a.N;
     const bool full = (m0 + BM <= a.M) && (n0 + BN <= a.N);
 
-    Stage<AKC, VA, BM> sa;
-    Stage<BKC, VB, BN> sb;
-    const int ai = wr * (BM / 2) + (l & 31), bj = wc * 64 + (l & 31), kh = l >> 5;
-    if (kbeg < kend) {
-        sa.load(a.A, a.lda, m0, a.M, kbeg, kend, t);
-        sb.load(a.B, a.ldb, n0, a.N, kbeg, kend, t);
-        sa.store(As, t);
-        sb.store(Bs, t);
+    typedef Stage<AKC, VA, BM> SA;
+    typedef Stage<BKC, VB, BN> SB;
+    constexpr int NA = SA::NV, NT = SA::NV + SB::NV;       // staging items per thread and K-tile: A's loads, then B's
+    SA sa;
+    SB sb;
+    sa.init(a.lda, m0, a.M, kbeg, t);
+    sb.init(a.ldb, n0, a.N, kbeg, t);
+    const uint32_t advA = AKC ? (uint32_t)BK : (uint32_t)(BK * a.lda), advB = BKC ? (uint32_t)BK : (uint32_t)(BK * a.ldb);
+    auto load_item = [&](auto I, int tile) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i < NA) sa.template load_one<i>(a.A, advA * (uint32_t)tile, kbeg + tile * BK, kend);
+        else sb.template load_one<i - NA>(a.B, advB * (uint32_t)tile, kbeg + tile * BK, kend);
+    };
+    auto store_item = [&](auto I, int buf) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i < NA) sa.template store_one<i>(As + buf * TILE_F, t);
+        else sb.template store_one<i - NA>(Bs + buf * TILE_F, t);
+    };
+    // ---- prologue: K-tile 0 in LDS
+    if (T > 0) {
+        static_for<0, NT>([&](auto I) { load_item(I, 0); });
+        static_for<0, NT>([&](auto I) { store_item(I, 0); });
     }
     __syncthreads();
-    int cur = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        const bool more = k0 + BK < kend;
-        if (more) {                      // the next K-tile's loads fly while this one is multiplied
-            sa.load(a.A, a.lda, m0, a.M, k0 + BK, kend, t);
-            sb.load(a.B, a.ldb, n0, a.N, k0 + BK, kend, t);
-        }
-        if (full) ktile<MI, true>(acc, As + cur * TILE_F, Bs + cur * TILE_F, ai, bj, kh, mv, nv);
-        else ktile<MI, false>(acc, As + cur * TILE_F, Bs + cur * TILE_F, ai, bj, kh, mv, nv);
-        if (more) {                      // the other buffer was last read one K-tile ago, in front of the barrier below
-            sa.store(As + (cur ^ 1) * TILE_F, t);
-            sb.store(Bs + (cur ^ 1) * TILE_F, t);
-        }
-        __syncthreads();
-        cur ^= 1;
+
+    const int ai = wr * (BM / 2) + (l & 31), bj = wc * 64 + (l & 31), kh = l >> 5;
+    // ---- K-loop.  K-tile j is multiplied from buffer j & 1 in 16 steps of 2 k; the loads of K-tile j + 1 are issued in the
+    // gaps between the MFMAs of steps 0-7, one staged load per gap, and written to the other buffer in the gaps of steps 8-15
+    // (a load has eight steps -- ~4000 cycles of MFMAs -- to land): everything but the MFMAs runs in their shadow, and ONE
+    // barrier per K-tile closes it.
+    auto kloop = [&](auto FULLC) {
+    constexpr bool FULL = decltype(FULLC)::value;      // the tile lies wholly inside the output: no per-block tests
+    for (int j = 0; j < T; ++j) {
+        const float* ar = As + (j & 1) * TILE_F + kh * LD + ai;
+        const float* br = Bs + (j & 1) * TILE_F + kh * LD + bj;
+        float fa[2][MI], fb[2][2];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fa[0][mi] = ar[mi * 32];
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) fb[0][nj] = br[nj * 32];
+        static_for<0, BK / 2>([&](auto Sx) {
+            constexpr int s = decltype(Sx)::value, cur = s & 1, nxt = cur ^ 1;
+            if constexpr (s + 1 < BK / 2) {      // fragments of step s + 1 are requested before the MFMAs of step s
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) fa[nxt][mi] = ar[(2 * s + 2) * LD + mi * 32];
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj) fb[nxt][nj] = br[(2 * s + 2) * LD + nj * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // (left alone the scheduler sinks the reads to just in front of their MFMAs)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj)
+                    if (FULL || (mv[mi] && nv[nj]))
+                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mi], fb[cur][nj], acc[mi][nj], 0, 0, 0);
+            // the staging work of this gap
+            constexpr int h = BK / 4;                                                   // steps per half
+            constexpr int lo = (s % h) * NT / h, hi = (s % h + 1) * NT / h;
+            // (unconditional: behind the last K-tile every load lies outside the operand -- it reads X[0] and stores zeros
+            // nobody reads -- and the loop body stays one basic block, which is what lets the waits be counted exactly)
+            if constexpr (s < h) static_for<lo, hi>([&](auto I) { load_item(I, j + 1); });
+            else static_for<lo, hi>([&](auto I) { store_item(I, (j + 1) & 1); });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        lds_barrier();
     }
+    };
+    if (full) kloop(std::true_type{});
+    else kloop(std::false_type{});
 
     // ---- epilogue: lane owns column j = n0 + wc*64 + nj*32 + (l & 31), rows i = m0 + wr*(BM/2) + mi*32 + (r & 3) + 8 (r >> 2) + 4 kh
     float* C = a.C + (EPI == EPI_PLAIN ? (int64_t)z * a.slab_stride : 0);
@@ -222,23 +260,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const Args a) {
         }
     }
     if (EPI == EPI_DGRAD && a.colsum != nullptr) {
-        // per 32-row block: the two lane halves (rows 4 kh); per 64 rows: block 0 + block 1 -- the two blocks of a wave
-        // (BM = 128) or of the two wave rows (BM = 64, through LDS): the same partials in the same order either way
+        // per 32-row block: the two lane halves (rows 4 kh); per 64 rows (a wave's): block 0 + block 1
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) cs[mi][nj] += __shfl_xor(cs[mi][nj], 32, 64);
             const int jl = wc * 64 + nj * 32 + (l & 31);
-            if (MI == 2) {
-                const int row = 2 * tm + wr;
-                if (kh == 0 && n0 + jl < a.N && (int64_t)row * 64 < a.M) a.colsum[(int64_t)row * a.N + n0 + jl] = cs[0][nj] + cs[MI - 1][nj];
-            } else if (kh == 0) {
-                red[wr * BN + jl] = cs[0][nj];
-            }
-        }
-        if (MI == 1) {
-            __syncthreads();
-            if (t < BN && n0 + t < a.N) a.colsum[(int64_t)tm * a.N + n0 + t] = red[t] + red[BN + t];
+            const int row = 2 * tm + wr;
+            if (kh == 0 && n0 + jl < a.N && (int64_t)row * 64 < a.M) a.colsum[(int64_t)row * a.N + n0 + jl] = cs[0][nj] + cs[1][nj];
         }
     }
 }
@@ -251,29 +280,28 @@ inline int vec_of(const float* p, int64_t ld, int ext_c) {
     return 1;
 }
 
-// BM = 64 when its tiles come out in fewer (half-length) rounds of the chip than those of BM = 128
-inline int pick_bm(int64_t M, int64_t N, int64_t S) {
-    const int64_t tn = mrec_cdiv(N, BN);
-    const int64_t c128 = mrec_cdiv(mrec_cdiv(M, 128) * tn * S, SLOTS) * 2;
-    const int64_t c64 = mrec_cdiv(mrec_cdiv(M, 64) * tn * S, SLOTS);
-    return c64 < c128 ? 64 : 128;
-}
-
-template <int BM, bool AKC, bool BKC, int EPI, int VA, int VB>
+template <bool AKC, bool BKC, int EPI, int VA, int VB>
 int launch_one(const Args& a, unsigned grid, hipStream_t st) {
     static bool attr_done = false;      // (per instantiation; racing threads set the same value)
     if (!attr_done) {
-        MREC_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm_f32<BM, AKC, BKC, EPI, VA, VB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        MREC_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm_f32<AKC, BKC, EPI, VA, VB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_done = true;
     }
-    k_gemm_f32<BM, AKC, BKC, EPI, VA, VB><<<grid, 256, LDS_BYTES, st>>>(a);
+    k_gemm_f32<AKC, BKC, EPI, VA, VB><<<grid, 256, LDS_BYTES, st>>>(a);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
 
-template <int BM, bool AKC, bool BKC, int EPI>
-int launch_bm(const Args& a, int va, int vb, unsigned grid, hipStream_t st) {
-#define GF_GO(VA, VB) return launch_one<BM, AKC, BKC, EPI, VA, VB>(a, grid, st)
+// a: M, N, K, operands and epilogue set; tiles and the grid are filled in here
+template <bool AKC, bool BKC, int EPI>
+int launch(Args a, int va, int vb, int S, hipStream_t st) {
+    // staged loads are addressed by 32-bit element offsets
+    const int64_t ea = (AKC ? (int64_t)a.M : (int64_t)a.K) * a.lda, eb = (BKC ? (int64_t)a.N : (int64_t)a.K) * a.ldb;
+    if (ea >= (int64_t(1) << 32) || eb >= (int64_t(1) << 32)) return MREC_EUNSUPPORTED;
+    a.tiles_m = (int)mrec_cdiv(a.M, BM);
+    a.tiles_n = (int)mrec_cdiv(a.N, BN);
+    const unsigned grid = (unsigned)((int64_t)a.tiles_m * a.tiles_n * S);
+#define GF_GO(VA, VB) return launch_one<AKC, BKC, EPI, VA, VB>(a, grid, st)
     if (va == 4 && vb == 4) GF_GO(4, 4);
     else if (va == 4 && vb == 2) GF_GO(4, 2);
     else if (va == 2 && vb == 4) GF_GO(2, 4);
@@ -282,16 +310,6 @@ int launch_bm(const Args& a, int va, int vb, unsigned grid, hipStream_t st) {
     else if (va == 1) { if (vb == 4) GF_GO(1, 4); else GF_GO(1, 2); }
     else { if (va == 4) GF_GO(4, 1); else GF_GO(2, 1); }
 #undef GF_GO
-}
-
-// a: M, N, K, operands and epilogue set; tiles and the grid are filled in here
-template <bool AKC, bool BKC, int EPI>
-int launch(Args a, int va, int vb, int S, hipStream_t st) {
-    const int bm = pick_bm(a.M, a.N, S);
-    a.tiles_m = (int)mrec_cdiv(a.M, bm);
-    a.tiles_n = (int)mrec_cdiv(a.N, BN);
-    const unsigned grid = (unsigned)((int64_t)a.tiles_m * a.tiles_n * S);
-    return bm == 64 ? launch_bm<64, AKC, BKC, EPI>(a, va, vb, grid, st) : launch_bm<128, AKC, BKC, EPI>(a, va, vb, grid, st);
 }
 
 }  // namespace gf32
@@ -350,7 +368,7 @@ MREC_API int mrec_dense32_bwd_weight(const float* x, int64_t ldx, const float* d
     return gf32::launch<false, false, gf32::EPI_PLAIN>(a, gf32::vec_of(x, ldx, K), gf32::vec_of(dy, lddy, N), S, (hipStream_t)stream);
 }
 
-/* Batch slabs: the output has only ceil(K / BM) * ceil(N / 128) tiles.  The count (and with it the tile height the launch will pick)
+/* Batch slabs: the output has only ceil(K / 128) * ceil(N / 128) tiles.  The count
  * that takes the fewest rounds of the chip's 512 workgroup slots x rows per workgroup; among equals the smallest (the slabs are
  * the optimizer's to read). */
 MREC_API int mrec_dense32_bwd_weight_slabs(int64_t M, int32_t K, int32_t N, int32_t* out) {
@@ -361,9 +379,10 @@ MREC_API int mrec_dense32_bwd_weight_slabs(int64_t M, int32_t K, int32_t N, int3
     for (int64_t S = 1; S <= smax; ++S) {
         const int64_t rows = (int64_t)mrec_align_up((size_t)mrec_cdiv(M, S), gf32::BK);
         if (S > 1 && rows * (S - 1) >= M) continue;       // an empty slab
-        const int bm = gf32::pick_bm(K, N, S);
-        const int64_t rounds = mrec_cdiv(mrec_cdiv(K, bm) * mrec_cdiv(N, gf32::BN) * S, gf32::SLOTS);
-        const int64_t cost = rounds * bm * rows;
+        const int64_t rounds = mrec_cdiv(mrec_cdiv(K, gf32::BM) * mrec_cdiv(N, gf32::BN) * S, gf32::SLOTS);
+        // in units of one tile row x one batch row (~1.2 ns of a workgroup's MFMAs): the rounds, a workgroup's fill and drain,
+        // and the slab's trip to HBM and back into the optimizer (8 bytes per element at ~4 TB/s)
+        const int64_t cost = rounds * (gf32::BM * rows + 8192) + S * ((int64_t)K * N / 600);
         if (best_cost < 0 || cost < best_cost) { best = S; best_cost = cost; }
     }
     *out = (int32_t)best;

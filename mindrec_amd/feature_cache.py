@@ -16,10 +16,19 @@ host DRAM instead of a parameter server:
     from the host;
   * gather / sparse apply then run unchanged on cache rows (the plan's `uniq` holds cache rows).
 
-All bookkeeping (residency flags, LRU stamps, victim selection, the miss list) lives on the device, and rows move
-between the pinned host array and the cache by the ordinary gather / scatter kernels addressing host memory over
-PCIe -- no host-side indexing, no staging buffers.  The host takes part twice per step: it reads the number of
-unique ids and the number of misses (two scalar syncs).
+All bookkeeping (residency flags, LRU stamps, victim selection, the miss and victim lists, the counters) lives on the
+device, every array has a shape the host knows in advance (lists are compacted into buffers of the batch's length and
+carry their true length in a device word), and rows move between the pinned host array and the cache by a row-copy kernel
+that addresses host memory over PCIe and reads its list length on the device (ops.move_rows_) -- no host-side indexing,
+no staging buffers, and NO host synchronisation inside a step: prepare() never reads a value back
+(tests/test_feature_cache_gpu.py runs it under torch.cuda.set_sync_debug_mode("error")).  What cannot be raised without
+reading back -- a batch with more unique ids than the cache has rows, a working set that leaves too few eviction
+candidates -- is latched in a device word and raised by check() (called by flush(), stats and the engines' overflow
+checks), like the shard exchange's overflow counter.
+
+Victims are the least-recently-used rows that are not in this batch: ages (steps since last use, capped at 4095) are
+sorted once, the age of the n_evict-th oldest row is the threshold, rows above it go, rows at it go in row order until the
+count is met -- exact LRU below the cap, reproducible.
 
 The tier is transparent: a table driven through it ends bit-identical to a fully device-resident table
 (tests/test_feature_cache_gpu.py).
@@ -63,9 +72,10 @@ class HostBackedTable:
         self.row_key = torch.full((C + 1,), -1, dtype=torch.int64, device=dev)
         self.stamp = torch.zeros(C + 1, dtype=torch.int64, device=dev)               # last step a row was used
         self.step = 0
-        self.resident = 0                                                            # keys in the index (host copy)
-        self._hits = self._misses = self._evictions = 0
-        self._first_touch = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._resident = torch.zeros(1, dtype=torch.int64, device=dev)               # keys in the index
+        self._counts = torch.zeros(4, dtype=torch.int64, device=dev)                 # hits, misses, evictions, first touches
+        self._err = torch.zeros(1, dtype=torch.int64, device=dev)                    # latched errors (check())
+        self._iota_buf = torch.arange(C, dtype=torch.int64, device=dev)
         self.cols, off = {}, 0
         for name, w, _ in self.columns:
             self.cols[name] = self.cache[:, off:off + w]
@@ -83,68 +93,113 @@ class HostBackedTable:
             off += w
         return out
 
+    _AGE_CAP = 4095
+
+    def check(self):
+        """Raises what prepare() latched on the device (host sync)."""
+        e = int(self._err.item())
+        dropped = self.index.counters()[2]
+        if e & 1:
+            raise RuntimeError(f"a batch had more unique ids than the device cache holds ({self.C} rows)")
+        if (e & 2) or dropped:
+            raise RuntimeError("device cache too small for this batch's working set")
+
+    @property
+    def resident(self):
+        """Keys in the cache (host sync)."""
+        return int(self._resident.item())
+
     @property
     def stats(self):
-        return {"hits": self._hits, "misses": self._misses, "evictions": self._evictions,
-                "first_touch": int(self._first_touch.item())}
+        self.check()
+        h, m, e, f = (int(x) for x in self._counts.tolist())
+        return {"hits": h, "misses": m, "evictions": e, "first_touch": f}
 
     @stats.setter
     def stats(self, d):
-        self._hits, self._misses, self._evictions = int(d.get("hits", 0)), int(d.get("misses", 0)), int(d.get("evictions", 0))
-        self._first_touch.fill_(int(d.get("first_touch", 0)))
+        self._counts.copy_(torch.tensor([int(d.get(k, 0)) for k in ("hits", "misses", "evictions", "first_touch")], dtype=torch.int64))
+
+    def _iota(self, n):
+        if self._iota_buf.numel() < n:
+            self._iota_buf = torch.arange(n, dtype=torch.int64, device=self.device)
+        return self._iota_buf[:n]
+
+    @staticmethod
+    def _compact(mask, values, length):
+        """values[mask] in order, in a buffer of `length` entries padded with -1 (entries beyond it are dropped)."""
+        pos = torch.cumsum(mask, 0) - 1
+        out = torch.full((length + 1,), -1, dtype=values.dtype, device=values.device)
+        out.scatter_(0, torch.where(mask & (pos < length), pos, length), values)
+        return out[:length]
 
     # ------------------------------------------------------------------------------------------
     def prepare(self, ids, skip_negative=False):
         """Makes all ids resident; returns a SparsePlan whose groups map to CACHE rows (plan.uniq_buf) and
         the per-position cache rows (int32 [n]) for the gather.  skip_negative: ids of -1 are padding slots of a shard's
-        request message (no group, cache row -1)."""
+        request message (no group, cache row -1).  No host synchronisation (module docstring)."""
         self.step += 1
-        C, dev = self.C, self.device
+        C, V, dev, step = self.C, self.V, self.device, self.step
         if self.hashed:
             # keys -> host rows (every position probes `home`; new keys take the next host row): from here on `ids` are
             # host-row numbers and the tier is the dense-table one
             ids = self.home.lookup(ids, insert=True, skip_pad=skip_negative).view(ids.shape)
         plan = ops.sparse_plan(ids, skip_negative=skip_negative)
-        U = plan.U                                                    # host sync #1
-        if U > C:
-            raise RuntimeError(f"batch has {U} unique ids but the device cache holds {C} rows")
-        keys = ops.widen_keys(plan.uniq_buf)[:U].contiguous()
-        rows, _ = self.index.find_or_insert(keys, insert=False)
+        n = plan.n
+        U = plan.n_uniq_dev                                           # device word
+        iota = self._iota(max(n, C))
+        valid = iota[:n] < U
+        keys = torch.where(valid, ops.widen_keys(plan.uniq_buf)[:n], -1)
+        rows, _ = self.index.find_or_insert(keys, insert=False, n_dev=U)       # entries >= U: -1
         hit = rows >= 0
-        slot = torch.where(hit, rows, torch.full_like(rows, C)).long()
-        self.stamp.scatter_(0, slot, torch.full_like(slot, self.step))   # rows of this batch are not eviction candidates
-        n_miss = U - int(hit.sum())                                   # host sync #2
-        self._hits += U - n_miss
-        self._misses += n_miss
-        if n_miss:
-            free = C - self.resident
-            if n_miss > free:
-                self._evict(n_miss - free, n_hits=U - n_miss)
-            rows, is_new = self.index.find_or_insert(keys, insert=True)
-            self.resident += n_miss
-            new = is_new.view(-1)[:U].bool()
-            # the miss list, compacted on the device (its length is known on the host, so no sync)
-            mpos = torch.argsort(new.to(torch.int8), descending=True, stable=True)[:n_miss]
-            mkeys, mrows = keys[mpos].contiguous(), rows[mpos].contiguous()
-            self.row_key[mrows.long()] = mkeys
-            self.stamp[mrows.long()] = self.step
-            seen = self.materialised[mkeys]
-            # rows with a home on the host: fetched over PCIe by the gather kernel; first-touch rows: initialised here
-            fetched = ops.gather_rows_pinned(self.host, torch.where(seen, mkeys, torch.full_like(mkeys, -1)))
-            ops.scatter_rows_(self.cache, torch.where(seen, mrows, torch.full_like(mrows, -1)), fetched)
-            fresh = (~seen).to(torch.uint8)
-            self._first_touch += fresh.sum()
-            self._init_groups(self.cols, mrows, mkeys, fresh)
-        if plan.n > U:      # groups >= U do not exist; keep the buffer's length (n) with skipped rows
-            rows = torch.cat([rows, torch.full((plan.n - U,), -1, dtype=torch.int32, device=dev)])
-        plan.uniq_buf = rows
+        self.stamp.scatter_(0, torch.where(hit, rows.long(), C), step)           # rows of this batch are not eviction candidates
+        n_hit = hit.sum()
+        n_miss = U[0] - n_hit
+        n_evict = torch.clamp(n_miss - (C - self._resident[0]), min=0)
+        self._err |= (U[0] > C).to(torch.int64)
+        # ---- victims: the n_evict least-recently-used rows that are not in this batch
+        live = self.row_key[:C] >= 0
+        age = torch.where(live, torch.clamp(step - self.stamp[:C], max=self._AGE_CAP), 0)   # 0: free, or used this step
+        by_age = torch.sort(age.to(torch.int16), descending=True).values
+        thr = by_age.index_select(0, torch.clamp(n_evict - 1, min=0, max=C - 1).view(1))[0].to(torch.int64)   # age of the n_evict-th oldest row
+        self._err |= ((n_evict > 0) & (thr == 0)).to(torch.int64) << 1
+        above = age > thr
+        at = (age == thr) & (thr > 0)
+        need_at = n_evict - above.sum()
+        sel = (above | (at & (torch.cumsum(at, 0) <= need_at))) & (n_evict > 0)
+        vrows = self._compact(sel, iota[:C], n)                                            # cache rows, -1 padded
+        vkeys = torch.where(vrows >= 0, self.row_key[torch.clamp(vrows, min=0)], -1)
+        n_evict_w = n_evict.view(1)
+        ops.move_rows_(self.host, vkeys, self.cache, vrows, n_dev=n_evict_w)                # device writes host memory (PCIe)
+        self.materialised.scatter_(0, torch.where(vkeys >= 0, vkeys, V), True)
+        self.materialised[V:].fill_(False)          # (`t[i] = value` stages the value through a synchronising copy)
+        self.index.erase(vkeys)                                                             # (key -1: not there)
+        self.row_key.scatter_(0, torch.where(vrows >= 0, vrows, C), -1)
+        # ---- the misses take rows (fresh ones first, then the ones just freed)
+        rows, is_new = self.index.find_or_insert(keys, insert=True, n_dev=U)
+        new = valid & (is_new.view(-1)[:n] != 0)
+        n_new = new.sum()
+        self._resident += n_new - n_evict
+        self._counts[:3] += torch.stack([n_hit, n_miss, n_evict])
+        mkeys = self._compact(new, keys, n)
+        mrows = self._compact(new, rows.long(), n)
+        mslot = torch.where(mrows >= 0, mrows, C)
+        self.row_key.scatter_(0, mslot, mkeys)
+        self.row_key[C:].fill_(-1)
+        self.stamp.scatter_(0, mslot, step)
+        seen = self.materialised[torch.where(mkeys >= 0, mkeys, V)]
+        # rows with a home on the host: fetched over PCIe; first-touch rows: initialised here
+        ops.move_rows_(self.cache, torch.where(seen, mrows, -1), self.host, torch.where(seen, mkeys, -1), n_dev=n_new.view(1))
+        fresh = (mkeys >= 0) & ~seen
+        self._counts[3] += fresh.sum()
+        self._init_groups(self.cols, mrows.to(torch.int32), mkeys, fresh.to(torch.uint8))
+        plan.uniq_buf = torch.where(valid, rows, -1)
         rows_pos = ops.compose_i32(plan.uniq_buf, plan.inv)
         return plan, rows_pos
 
     def _init_groups(self, views, rows, keys, mask):
         """Default values of first-touch rows, column group by column group (the generator is keyed by the GLOBAL id)."""
         if self.hashed:
-            keys = self.home.row_keys()[keys]                   # host row -> the key it belongs to
+            keys = self.home.row_keys()[torch.clamp(keys, min=0)]                   # host row -> the key it belongs to
         elif self.key_scale != 1 or self.key_offset != 0:
             keys = keys * self.key_scale + self.key_offset
         for name, _, init in self.columns:
@@ -152,24 +207,6 @@ class HostBackedTable:
                 ops.init_rows_(views[name], rows, keys, mask, seed=int(init[1]), sigma=float(init[2]))
             else:
                 ops.init_rows_(views[name], rows, keys, mask, seed=0, sigma=None, fill=float(init[1]))
-
-    def _evict(self, k, n_hits=0):
-        """Writes the k least-recently-used rows (never rows stamped this step) back to the host and frees them."""
-        C = self.C
-        if self.resident - n_hits < k:
-            raise RuntimeError("device cache too small for this batch's working set")
-        live = self.row_key[:C] >= 0
-        cand = live & (self.stamp[:C] < self.step)
-        score = torch.where(cand, self.stamp[:C], torch.full_like(self.stamp[:C], torch.iinfo(torch.int64).max))
-        victims = torch.topk(score, k, largest=False).indices                       # cache rows
-        vkeys = self.row_key[victims].contiguous()
-        data = ops.gather_rows(self.cache, victims.to(torch.int32))
-        ops.scatter_rows_pinned_(self.host, vkeys, data)                             # device writes host memory (PCIe)
-        self.materialised[vkeys] = True
-        self.index.erase(vkeys)
-        self.row_key[victims] = -1
-        self.resident -= k
-        self._evictions += int(k)
 
     # ------------------------------------------------------------------------------------------
     def gather(self, rows_pos, row_scale=None, out_dtype=torch.float32):
@@ -184,6 +221,7 @@ class HostBackedTable:
                                    torch.ones(C, dtype=torch.bool, device=self.device))
         self.materialised[self.V] = False
         torch.cuda.synchronize(self.device)
+        self.check()
 
     def export_hashed(self):
         """hashed tables: (keys int64 [n], rows float32 [n, W]) of every key seen so far (host tensors)."""

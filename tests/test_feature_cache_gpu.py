@@ -32,8 +32,12 @@ def test_cache_tier_is_transparent(dev, dist_kind):
         plan_f = ops.sparse_plan(tid)
         emb_f = ops.gather_rows(fp, tid, wts)
         ops.sparse_lazy_adam_(fp, fm, fv, plan_f, g, wts, beta1_power=b1p, beta2_power=b2p)
-        # through the cache tier
-        plan_c, rows_pos = hb.prepare(tid)
+        # through the cache tier: not one host synchronisation (a synchronising call raises in this mode)
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            plan_c, rows_pos = hb.prepare(tid)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
         emb_c = hb.gather(rows_pos, wts.reshape(-1)).view(B, F, D)
         assert torch.equal(emb_c, emb_f), step
         ops.sparse_lazy_adam_(hb.p, hb.slots[0], hb.slots[1], plan_c, g, wts, beta1_power=b1p, beta2_power=b2p)
@@ -45,5 +49,19 @@ def test_cache_tier_is_transparent(dev, dist_kind):
 def test_cache_too_small_is_reported(dev):
     from mindrec_amd.feature_cache import HostBackedTable
     hb = HostBackedTable(1000, 8, 16, dev)
+    hb.prepare(torch.arange(0, 100, dtype=torch.int64, device=dev))      # latched on the device, raised at the next host read
     with pytest.raises(RuntimeError, match="unique ids"):
-        hb.prepare(torch.arange(0, 100, dtype=torch.int64, device=dev))
+        hb.check()
+    with pytest.raises(RuntimeError, match="unique ids"):
+        hb.stats
+
+
+def test_lru_eviction_by_the_count(dev):
+    """The second batch keeps 20 rows, needs 40 more and finds 4 free: the 36 oldest rows not in it go (counters are device words)."""
+    from mindrec_amd.feature_cache import HostBackedTable
+    hb = HostBackedTable(1000, 8, 64, dev)
+    hb.prepare(torch.arange(0, 60, dtype=torch.int64, device=dev))
+    hb.check()
+    hb.prepare(torch.arange(40, 100, dtype=torch.int64, device=dev))      # 20 hits + 40 misses: 4 free rows + 40 stale rows: fits
+    hb.check()
+    assert hb.resident == 64 and hb.stats == {"hits": 20, "misses": 100, "evictions": 36, "first_touch": 100}

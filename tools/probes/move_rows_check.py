@@ -1,5 +1,7 @@
-import torch, numpy as np
-from mindrec_amd import ops
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from mindrec_amd import ops  # noqa: E402
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(3)
 for W in (240, 81, 4):
@@ -7,7 +9,7 @@ for W in (240, 81, 4):
     host = src.clone().pin_memory()
     dst = torch.zeros(500, W, device=dev)
     n = 300
-    sr = torch.randint(0, 1000, (n,), generator=g); dr = torch.randperm(500, generator=g)[:n]
+    sr = torch.randperm(1000, generator=g)[:n]; dr = torch.randperm(500, generator=g)[:n]
     sr[::7] = -1; dr[3::11] = -1
     nd = torch.tensor([250], dtype=torch.int64, device=dev)
     ops.move_rows_(dst, dr.to(dev), host, sr.to(dev), n_dev=nd)          # host -> device
