@@ -251,8 +251,10 @@ __global__ __launch_bounds__(256) void k_fill_normal(float* __restrict__ out, in
         const int c0 = (int)(t - r * cpr) * 4;
         float* o = out + r * ld + c0;
         float x[4];
+        mrec_det_normal2(seed, row0 + r * row_stride, c0 >> 1, x[0], x[1]);            // (c0 is a multiple of 4: two column pairs)
+        mrec_det_normal2(seed, row0 + r * row_stride, (c0 >> 1) + 1, x[2], x[3]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = (c0 + k < D) ? sigma * mrec_det_normal(seed, row0 + r * row_stride, c0 + k) : 0.0f;
+        for (int k = 0; k < 4; ++k) x[k] = (c0 + k < D) ? sigma * x[k] : 0.0f;
         if (c0 + 4 <= D && ((ld & 3) == 0) && ((((uintptr_t)out) & 15) == 0)) {
             *(float4*)o = make_float4(x[0], x[1], x[2], x[3]);
         } else {
@@ -296,8 +298,15 @@ __global__ __launch_bounds__(256) void k_init_rows(float* __restrict__ table, in
             mask &= mask - 1;
             const int rr = __shfl(r, src, 64);
             const int64_t kk = ((int64_t)__shfl((int)(key >> 32), src, 64) << 32) | (uint32_t)__shfl((int)key, src, 64);
-            for (int c = lane; c < D; c += 64)
-                table[(int64_t)rr * ld + c] = sigma >= 0.0f ? sigma * mrec_det_normal(seed, kk, c) : fill;
+            for (int c = 2 * lane; c < D; c += 128) {          // a lane fills a pair of columns: one transform
+                float z0 = fill, z1 = fill;
+                if (sigma >= 0.0f) {
+                    mrec_det_normal2(seed, kk, c >> 1, z0, z1);
+                    z0 *= sigma; z1 *= sigma;
+                }
+                table[(int64_t)rr * ld + c] = z0;
+                if (c + 1 < D) table[(int64_t)rr * ld + c + 1] = z1;
+            }
         }
     }
 }

@@ -470,10 +470,9 @@ __global__ __launch_bounds__(HB) void k_map_finish(MapDev m, MapTabs tabs, int64
                     for (int c = sub * 4; c < tb.D; c += lpr * 4) {
                         float4 v;
                         if (tb.sigma >= 0.0f) {
-                            v.x = tb.sigma * mrec_det_normal(tb.seed, key, c);
-                            v.y = tb.sigma * mrec_det_normal(tb.seed, key, c + 1);
-                            v.z = tb.sigma * mrec_det_normal(tb.seed, key, c + 2);
-                            v.w = tb.sigma * mrec_det_normal(tb.seed, key, c + 3);
+                            mrec_det_normal2(tb.seed, key, c >> 1, v.x, v.y);          // (c is a multiple of 4)
+                            mrec_det_normal2(tb.seed, key, (c >> 1) + 1, v.z, v.w);
+                            v.x *= tb.sigma; v.y *= tb.sigma; v.z *= tb.sigma; v.w *= tb.sigma;
                         } else {
                             v = make_float4(tb.fill, tb.fill, tb.fill, tb.fill);
                         }
@@ -515,7 +514,15 @@ __global__ __launch_bounds__(HB) void k_map_fill_missing(const K* __restrict__ k
             mask &= mask - 1;
             const int64_t kk = ((int64_t)__shfl((int)(key >> 32), src, 64) << 32) | (uint32_t)__shfl((int)key, src, 64);
             float* dst = out + (base + src) * ldo;
-            for (int c = lane; c < tb.D; c += 64) dst[c] = tb.sigma >= 0.0f ? tb.sigma * mrec_det_normal(tb.seed, kk, c) : tb.fill;
+            for (int c = 2 * lane; c < tb.D; c += 128) {          // a lane fills a pair of columns: one transform
+                float z0 = tb.fill, z1 = tb.fill;
+                if (tb.sigma >= 0.0f) {
+                    mrec_det_normal2(tb.seed, kk, c >> 1, z0, z1);
+                    z0 *= tb.sigma; z1 *= tb.sigma;
+                }
+                dst[c] = z0;
+                if (c + 1 < tb.D) dst[c + 1] = z1;
+            }
         }
     }
 }

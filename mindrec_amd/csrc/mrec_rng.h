@@ -1,8 +1,10 @@
 // mrec_rng.h -- counter-based N(0,1) generator for table / default-row initialisation.
-// Spec (shared bit-for-bit with oracle/mrec_oracle.c, which states it independently):
-//   h  = mix64(seed ^ mix64(row * 0xD1342543DE82EF95 + col))
+// Spec (shared bit-for-bit with oracle/mrec_oracle.c, which states it independently): columns come in PAIRS, both outputs of
+// one Box-Muller transform (half the hashing, logarithm, root and trigonometry per value -- default rows of new hash-table
+// keys and the initialisation of a table are ALU-bound on this generator):
+//   h  = mix64(seed ^ mix64(row * 0xD1342543DE82EF95 + (col >> 1)))
 //   u1 = ((h >> 40) + 1) * 2^-24  in (0,1],   k = (h >> 8) & 0xFFFFFF
-//   z  = sqrt(-2 ln u1) * cos(2 pi k / 2^24)
+//   z(col even) = sqrt(-2 ln u1) * cos(2 pi k / 2^24),   z(col odd) = sqrt(-2 ln u1) * sin(2 pi k / 2^24)
 // ln and cos are polynomial kernels whose every multiply-add is an explicit fma, so the result
 // does not depend on the compiler's contraction choices (the library is built -ffp-contract=off).
 #pragma once
@@ -38,7 +40,8 @@ __device__ __forceinline__ float mrec_det_logf(float x) {
     return r;
 }
 
-__device__ __forceinline__ float mrec_det_cos2pi_u24(uint32_t k) {
+// (cos, sin)(2 pi k / 2^24) for integer k in [0, 2^24): integer quadrant reduction + fma polynomials on [0, pi/4]
+__device__ __forceinline__ void mrec_det_sincos2pi_u24(uint32_t k, float& cos_out, float& sin_out) {
     uint32_t q = k >> 22;
     uint32_t r = k & 0x3FFFFFu;
     bool swap = false;
@@ -57,17 +60,28 @@ __device__ __forceinline__ float mrec_det_cos2pi_u24(uint32_t k) {
     c = c * z;
     c = __builtin_fmaf(-0.5f, z, c);
     c = c + 1.0f;
-    float cs = swap ? s : c;
-    float sn = swap ? c : s;
-    float out = (q & 1u) ? sn : cs;
-    return (q == 1u || q == 2u) ? -out : out;
+    const float cs = swap ? s : c;      // of the angle inside the quadrant
+    const float sn = swap ? c : s;
+    const float co = (q & 1u) ? sn : cs, so = (q & 1u) ? cs : sn;
+    cos_out = (q == 1u || q == 2u) ? -co : co;
+    sin_out = (q >= 2u) ? -so : so;
 }
 
-__device__ __forceinline__ float mrec_det_normal(uint64_t seed, int64_t row, int32_t col) {
-    uint64_t h = mrec_mix64(seed ^ mrec_mix64((uint64_t)row * 0xD1342543DE82EF95ull + (uint64_t)(uint32_t)col));
+// columns 2 * pair and 2 * pair + 1 of `row`
+__device__ __forceinline__ void mrec_det_normal2(uint64_t seed, int64_t row, int32_t pair, float& z0, float& z1) {
+    uint64_t h = mrec_mix64(seed ^ mrec_mix64((uint64_t)row * 0xD1342543DE82EF95ull + (uint64_t)(uint32_t)pair));
     uint32_t a = (uint32_t)(h >> 40);
     uint32_t b = (uint32_t)(h >> 8) & 0xFFFFFFu;
     float u1 = ((float)a + 1.0f) * 5.9604644775390625e-08f;
     float rad = sqrtf(-2.0f * mrec_det_logf(u1));
-    return rad * mrec_det_cos2pi_u24(b);
+    float c, s;
+    mrec_det_sincos2pi_u24(b, c, s);
+    z0 = rad * c;
+    z1 = rad * s;
+}
+
+__device__ __forceinline__ float mrec_det_normal(uint64_t seed, int64_t row, int32_t col) {
+    float z0, z1;
+    mrec_det_normal2(seed, row, col >> 1, z0, z1);
+    return (col & 1) ? z1 : z0;
 }

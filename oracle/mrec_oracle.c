@@ -73,12 +73,12 @@ static inline float det_logf(float x) {
     return r;
 }
 
-/* cos(2*pi*k/2^24) for integer k in [0,2^24): integer octant reduction + fmaf polynomials. */
-static inline float det_cos2pi_u24(uint32_t k) {
+/* (cos, sin)(2*pi*k/2^24) for integer k in [0,2^24): integer quadrant reduction + fmaf polynomials on [0, pi/4]. */
+static inline void det_sincos2pi_u24(uint32_t k, float* cos_out, float* sin_out) {
     uint32_t q = k >> 22;            /* quadrant */
-    uint32_t r = k & 0x3FFFFFu;      /* theta = (pi/2) * r / 2^22 */
+    uint32_t r = k & 0x3FFFFFu;      /* phi = (pi/2) * r / 2^22 */
     int swap = 0;
-    if (r > 0x200000u) { r = 0x400000u - r; swap = 1; } /* theta' = pi/2 - theta in [0,pi/4] */
+    if (r > 0x200000u) { r = 0x400000u - r; swap = 1; } /* phi' = pi/2 - phi in [0,pi/4] */
     float t = (float)r * 3.7450703e-07f; /* (pi/2)/2^22 */
     float z = t * t;
     float s = -1.9515295891E-4f;
@@ -93,23 +93,26 @@ static inline float det_cos2pi_u24(uint32_t k) {
     c = c * z;
     c = fmaf(-0.5f, z, c);
     c = c + 1.0f;
-    float cs = swap ? s : c; /* cos(theta) */
-    float sn = swap ? c : s; /* sin(theta) */
-    switch (q) {
-        case 0: return cs;
-        case 1: return -sn;
-        case 2: return -cs;
-        default: return sn;
+    float cs = swap ? s : c; /* cos(phi) */
+    float sn = swap ? c : s; /* sin(phi) */
+    switch (q) {             /* theta = q * pi/2 + phi */
+        case 0: *cos_out = cs; *sin_out = sn; break;
+        case 1: *cos_out = -sn; *sin_out = cs; break;
+        case 2: *cos_out = -cs; *sin_out = -sn; break;
+        default: *cos_out = sn; *sin_out = -cs; break;
     }
 }
 
+/* Columns come in pairs: both outputs of one Box-Muller transform keyed by (row, col >> 1). */
 static inline float det_normal(uint64_t seed, int64_t row, int32_t col) {
-    uint64_t h = mix64(seed ^ mix64((uint64_t)row * 0xD1342543DE82EF95ull + (uint64_t)(uint32_t)col));
+    uint64_t h = mix64(seed ^ mix64((uint64_t)row * 0xD1342543DE82EF95ull + (uint64_t)(uint32_t)(col >> 1)));
     uint32_t a = (uint32_t)(h >> 40);            /* 24 bits */
     uint32_t b = (uint32_t)(h >> 8) & 0xFFFFFFu; /* 24 bits */
     float u1 = ((float)a + 1.0f) * 5.9604644775390625e-08f; /* (0,1] */
     float rad = sqrtf(-2.0f * det_logf(u1));
-    return rad * det_cos2pi_u24(b);
+    float c, s;
+    det_sincos2pi_u24(b, &c, &s);
+    return rad * ((col & 1) ? s : c);
 }
 
 MREC_O_API void mrec_o_normal_rows_f32(uint64_t seed, const int64_t* rows, int64_t n, int32_t D,
