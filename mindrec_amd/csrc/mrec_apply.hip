@@ -47,8 +47,8 @@ namespace {
 #define MREC_GP4 2
 #endif
 #ifndef MREC_WPS4
-#define MREC_WPS4 5         // waves per SIMD asked of the register allocator for the float4 + wide-lane kernel
-#endif
+#define MREC_WPS4 4         // waves per SIMD asked of the register allocator for the float4 + wide-lane kernel (128 VGPRs: the
+#endif                      // window's index words live in registers; 5 waves measured 5 % slower, 3 the same)
 #ifndef MREC_GP1
 #define MREC_GP1 4
 #endif
@@ -271,9 +271,7 @@ __device__ __forceinline__ int64_t seg_row(const K* uniq, int seg) {
     return uniq ? (int64_t)uniq[seg] : (int64_t)seg;
 }
 
-// (WIDE: 5 waves per SIMD asked of the register allocator -- the wide lane's FTRL path took the kernel from 74 to 97
-// VGPRs, i.e. from 6 to 4 waves per SIMD, and the lost latency hiding cost more than everything else the wide lane does;
-// 96 registers fit without spilling, 80 do not)
+// (WIDE: MREC_WPS4 waves per SIMD asked of the register allocator)
 template <int VEC, class K, class Upd, class GT, bool WIDE = false>
 __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
                                                     const int* __restrict__ spos, const int* __restrict__ sseg,
@@ -287,6 +285,8 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
     if (grp >= gm.G) return;  // spare lanes; this kernel has no barriers
+    // (Handing the windows out in a strided order instead -- so that the waves in flight sample the list's duplicate-heavy
+    // head and its unique tail at once -- was measured: Zipf x 39 fields 0.133 -> 0.188 ms; neighbouring windows share lines.)
     const int64_t sw = ((int64_t)blockIdx.x * 4 + wave) * gm.G + grp;
     const int64_t s64 = sw * AW;
     if (s64 >= n) return;
@@ -296,28 +296,47 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     const int ccol = sub * VEC;                         // column in the carry rows
     const int col = wl ? wa.wcol : ccol;                // column in the table rows
 
-    const int first_seg = sseg[s];
+    // The window's index entries all at once (one round trip for the 2 x AW + 1 words, a second one for the rows of its run
+    // ends) instead of batch by batch: a window's time is the length of its chain of dependent loads -- index -> row number
+    // -> row -- which this takes from three round trips per batch to one (uniform ids 0.186 -> 0.179 ms, Zipf x 39 fields
+    // 0.141 -> 0.133; deeper gradient prefetch on top of it changed nothing: what remains is the AB-deep chain of row
+    // read-modify-writes).
+    int posw[AW], segw[AW + 1];
+#pragma unroll
+    for (int q = 0; q < AW; ++q) {
+        const int e = s + q;
+        posw[q] = e < e_end ? spos[e] : 0;
+        segw[q] = e < e_end ? sseg[e] : -2;
+    }
+    segw[AW] = (s + AW < n) ? sseg[s + AW] : -2;
+    const int first_seg = segw[0];
     const bool head_open = (s > 0) && (sseg[s - 1] == first_seg);
-    int seg_cur = first_seg;
-    int seg_prev = -3;  // group of the entry before the current batch (unused for the first batch)
+    unsigned endm = 0u, openm = 0u;                       // bit q: entry q ends its run / belongs to the run open at the head
+    int64_t rowv[AW];                                     // table row of the run that ends at entry q (-1: none / out of range)
+#pragma unroll
+    for (int q = 0; q < AW; ++q) {
+        const bool valid = s + q < e_end;
+        const bool is_end = valid && segw[q + 1] != segw[q];
+        const bool open = head_open && segw[q] == first_seg;
+        endm |= is_end ? (1u << q) : 0u;
+        openm |= open ? (1u << q) : 0u;
+        rowv[q] = (is_end && !open) ? seg_row<K>(uniq, segw[q]) : (int64_t)-1;
+    }
     Vf<VEC> acc;
     vzero(acc);
-
-    // Gradient rows are prefetched GP entries at a time (one load each, always needed); state rows are
-    // loaded AB entries at a time just before their update (only run ends need them).
-    for (int jg = s; jg < e_end; jg += GP) {
+#pragma unroll
+    for (int jb = 0; jb < AW; jb += GP) {
+        if (s + jb >= e_end) break;
         Vf<VEC> gvv[GP];
         float rsv[GP];
 #pragma unroll
         for (int q = 0; q < GP; ++q) {
-            const int e = jg + q;
             rsv[q] = 1.0f;
             vzero(gvv[q]);
-            if (e < e_end) {
-                const int pos = spos[e];
+            if (s + jb + q < e_end) {
+                const int pos = posw[jb + q];
                 if (WIDE) {
-                    // (F == 1: one gradient per position -- a shard's owner, whose received positions are not grouped by sample)
-                    const float gwv = wa.gw[(wa.F == 1 ? (unsigned)pos : __umulhi((unsigned)pos, wa.magic)) * wa.gws];      // same address for the whole lane-group
+                    const float gwv = wa.gw[(wa.F == 1 ? (unsigned)pos : __umulhi((unsigned)pos, wa.magic)) * wa.gws];
                     if (!wl) vload<NT>(gvv[q], g + (int64_t)pos * ldg + col);
                     else vset_x(gvv[q], gwv);
                 } else {
@@ -328,49 +347,33 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
         }
 #pragma unroll
         for (int sb = 0; sb < GP / AB; ++sb) {
-            const int j0 = jg + sb * AB;
-            if (j0 >= e_end) break;
-            int seg[AB + 1];
-            bool valid[AB], is_end[AB], is_start[AB], open[AB], upd_ok[AB];
+            const int j0 = jb + sb * AB;
+            if (s + j0 >= e_end) break;
+            bool upd_ok[AB];
             int64_t roff[AB];
             Vf<VEC> st[AB][Upd::NS];
-            seg[0] = seg_cur;
 #pragma unroll
             for (int k = 0; k < AB; ++k) {
-                const int e = j0 + k;
-                valid[k] = e < e_end;
-                seg[k + 1] = (e + 1 < n) ? sseg[e + 1] : -2;
-            }
+                const int64_t row = rowv[j0 + k];
+                upd_ok[k] = row >= 0 && row < V;
+                roff[k] = upd_ok[k] ? row * ld + col : 0;
+                if (upd_ok[k] && Upd::kLoad) {
 #pragma unroll
-            for (int k = 0; k < AB; ++k) {
-                const int e = j0 + k;
-                is_start[k] = (e == s) || (seg[k] != (k > 0 ? seg[k - 1] : seg_prev));
-                is_end[k] = valid[k] && (seg[k + 1] != seg[k]);
-                open[k] = head_open && (seg[k] == first_seg);
-                upd_ok[k] = false;
-                roff[k] = 0;
-                if (is_end[k] && !open[k]) {
-                    const int64_t row = seg_row<K>(uniq, seg[k]);
-                    if (row >= 0 && row < V) {
-                        upd_ok[k] = true;
-                        roff[k] = row * ld + col;
-                        if (Upd::kLoad) {
-#pragma unroll
-                            for (int i = 0; i < Upd::NS; ++i)
-                                if (!(WIDE && wl && i > 0)) vload<NT>(st[k][i], upd.s[i] + roff[k]);
-                        }
-                    }
+                    for (int i = 0; i < Upd::NS; ++i)
+                        if (!(WIDE && wl && i > 0)) vload<NT>(st[k][i], upd.s[i] + roff[k]);
                 }
             }
 #pragma unroll
             for (int k = 0; k < AB; ++k) {
-                if (!valid[k]) continue;
+                const int q = j0 + k;
+                if (s + q >= e_end) continue;
                 Vf<VEC> x = gvv[sb * AB + k];
                 if (rscale) vmul(x, rsv[sb * AB + k]);
                 vmul(x, gscale);
-                if (is_start[k]) acc = x; else vadd(acc, x);
-                if (is_end[k]) {
-                    if (open[k]) {
+                const bool is_start = q == 0 || segw[q] != segw[q - 1];
+                if (is_start) acc = x; else vadd(acc, x);
+                if ((endm >> q) & 1u) {
+                    if ((openm >> q) & 1u) {
                         vstore<false>(carry_head + sw * gm.D + ccol, acc);
                     } else if (upd_ok[k]) {
                         if (WIDE && wl) wide_apply(st[k][0], acc, wa.h);
@@ -381,8 +384,6 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
                     }
                 }
             }
-            seg_prev = seg[AB - 1];
-            seg_cur = seg[AB];
         }
     }
     // run continues past this window?  owners[sw]: 0 = no run of this window continues, 1 = this window owns

