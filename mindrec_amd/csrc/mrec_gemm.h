@@ -418,6 +418,20 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r) cs[ni][r] = 0.f;
+        // EPI_DGRAD: the activations the ReLU mask is read from, ALL requested before the first is used (an out-of-range element
+        // reads H[0] and is never stored).  Loaded one by one in front of their stores, each load was followed by a wait for
+        // everything in flight -- the store before it included: 32 memory round trips in a row per lane.
+        u32x2_t hmask[MR][4];
+        if (EPI == EPI_DGRAD && a.H != nullptr) {
+#pragma unroll
+            for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int p = p0 + mi * 16, q = q0 + ni * 16;
+                    const bool ok = p < a.Pext && q < a.Qext;
+                    hmask[mi][ni] = *(const u32x2_t*)((const uint16_t*)a.H + (ok ? (int64_t)p * a.ldc + q : (int64_t)0));
+                }
+        }
 #pragma unroll
         for (int mi = 0; mi < MR; ++mi) {
             const int p = p0 + mi * 16;
@@ -452,8 +466,7 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
                 }
                 if (EPI == EPI_DGRAD) {
                     if (a.H != nullptr) {
-                        u32x2_t hb = {0u, 0u};
-                        if (ok) hb = *(const u32x2_t*)((const uint16_t*)a.H + (int64_t)p * a.ldc + q);
+                        const u32x2_t hb = hmask[mi][ni];
                         // activation > 0 <=> its 16-bit pattern is a positive number (sign clear, not zero)
                         if (!((hb[0] & 0xFFFFu) - 1u < 0x7FFFu)) o[0] &= 0xFFFF0000u;
                         if (!((hb[0] >> 16) - 1u < 0x7FFFu)) o[0] &= 0x0000FFFFu;
