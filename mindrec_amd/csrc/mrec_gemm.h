@@ -213,6 +213,9 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
         }
     }
 
+    // (Skipping the MFMAs of the wave quadrants that lie outside the output in the tiles that hang over its edge -- 2080 =
+    // 8 x 256 + 32: the ninth column tile of layer 0's input gradient -- was measured: the launch takes as long; such a
+    // workgroup's K-tile takes what its staging and barriers take.)
     u32x4_t fP[4][2], fQ0[2][2], fQ1[2][2];       // fragments [rep][ks]
     f32x4_t acc[MR][4];
 #pragma unroll
