@@ -379,7 +379,7 @@ def main():
     default_cfg = (args.vocab == 200_000_000 and args.emb_dim == 80 and args.batch == 16384 and args.fields == 26
                    and args.dist == "uniform" and not args.split_state and world == 1 and args.mlp_dtype in ("bf16", "fp16")
                    and not args.shard_protocol)
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if default_cfg and os.path.exists(pmc_path):
             traffic = json.load(open(pmc_path)).get("apply_main_adam", {}).get("total_bytes")
@@ -499,12 +499,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
     if world > 1 or args.shard_protocol:
         dist.barrier()
         eng.release_graphs()             # (graphs that hold RCCL kernels must go before the process group does)
         del eng
         dist.destroy_process_group()
+    if rank == 0:
+        # the LAST line of stdout: whatever the communication library has printf'd into the C runtime's buffer (RCCL announces
+        # the path it was loaded from) comes out first
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -29,7 +29,7 @@ fi
 if [ "$PART" = 2 ]; then
 cd $R
 # what a rank of an N-GPU job does besides moving bytes over xGMI: the row-shard protocol over RCCL with itself, and its kernels alone
-python bench.py --no-cpu-baseline --shard-protocol 2>/dev/null | tail -1 > $O/bench_line_shard_protocol.json
+python bench.py --no-cpu-baseline --shard-protocol 2>/dev/null | grep "^{\"metric\"" | tail -1 > $O/bench_line_shard_protocol.json
 cut -c1-220 $O/bench_line_shard_protocol.json
 python bench.py --no-cpu-baseline --dist zipf --fields 39 > $O/bench_line_zipf39.json 2>/dev/null
 # id-distribution sweep: uniform / Zipf(1.05), 26 / 39 fields
