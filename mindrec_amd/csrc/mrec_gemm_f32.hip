@@ -10,9 +10,10 @@
 //     A[i = lane & 31][k = lane >> 5], so a fragment is one conflict-free ds_read_b32), two buffers, and a staging
 //     pipeline whose every instruction sits in a gap between MFMAs: while K-tile j is multiplied, K-tile j + 1 is requested
 //     from memory (first half of the MFMAs) and written to the other buffer (second half) -- ONE barrier per K-tile;
-//   * branch-free staging: a load whose vector lies outside the operand reads the operand's first element instead and is
-//     zeroed by a select (rows need only 8-byte alignment -- the DCN input is 39 x 30 = 1170 floats wide -- so VEC = 4, 2 or 1
-//     floats per load is picked per operand such that no vector straddles an edge);
+//   * staging by buffer loads: per-lane byte offsets computed once, the K-tile's advance in the scalar offset, rows and k
+//     outside the operand switched off through the hardware range check (rows need only 8-byte alignment -- the DCN input is
+//     39 x 30 = 1170 floats wide -- so VEC = 4, 2 or 1 floats per load is picked per operand such that no vector straddles an
+//     edge);
 //   * a tile that hangs over the output's edge skips the MFMAs of its 32 x 32 blocks that lie wholly outside.
 //
 // Operands are either reduction-contiguous (X[r, k]: a row of the operand is a row of the matrix: transposed on its way into
@@ -23,13 +24,13 @@
 // Epilogues: bias + ReLU; mask by the activation below > 0 + column sums per 64 output rows (the layer below's BiasAdd
 // bprop); plain fp32 slabs.
 //
-// Measured (MI355X, Deep&Cross layer 1, tools/dcn_bench.py; tools/probes/mfma_f32_shape_probe.hip): a bare loop of this
-// instruction with its fragments re-read from LDS sustains 154 TFLOP/s (98 %, either shape -- 32x32x2 or 16x16x4); this kernel
-// reaches 92-99 (forward 415 us, the two bprops 395-400 us for 39.3 GFLOP each).  Ablations of the K-loop: without the global
-// loads 352 us, without the LDS stores and the barrier too 340, without the epilogue's stores 329 -- the loads, although every
-// one of them sits in an MFMA's shadow, cost 18 %: their address arithmetic (2.7 VALU instructions per MFMA, PMC) competes
-// for the issue port, and under the mixed load the chip holds 2.07 GHz instead of 2.4 (GRBM_GUI_ACTIVE / wall time).  What
-// would come next: buffer loads (scalar K-tile offset, hardware range check: no per-load address arithmetic, no selects).
+// Measured (MI355X, Deep&Cross layer 1: 39.3 GFLOP per launch; tools/dcn_bench.py, tools/probes/mfma_f32_shape_probe.hip): a bare
+// loop of this instruction with its fragments re-read from LDS sustains 154 TFLOP/s (98 %, either shape -- 32x32x2 or 16x16x4).
+// This kernel: forward 373 us (105 TFLOP/s), weight gradient 353 (111), input gradient 400 (98: 1280 tiles = 2.5 rounds of the
+// chip).  How it got there: plain structure (loads, barrier, stores, barrier, MFMAs) 506 / 474 / 681 us; two LDS buffers, one
+// barrier, branch-free loads 437 / 433 / 428; staging spread between the MFMAs 423 / 401 / 395; epilogue loads up front 408 / 397 /
+// 397; buffer loads (2.7 -> 0.75 VALU instructions per MFMA in the K-loop) 373 / 400 / 353.  Ablations before the last step: no
+// global loads in the K-loop 352 us, no LDS stores / barrier either 340, no epilogue stores 329; the chip held 2.07 GHz.
 #include <type_traits>
 #include "mrec_common.h"
 
@@ -66,60 +67,58 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // one K-tile of an operand, global -> registers -> LDS, one load at a time (the K-loop spreads them between its MFMAs).
 // KC: stored [R, K] (reduction contiguous), R = the tile's ROWS output rows / columns; else stored [K, R].  VEC floats per load;
-// the host guarantees that no vector straddles an edge.  A load that lies outside the operand reads X[0] instead and is zeroed
-// on its way into LDS (NOT behind the load: a select there makes the wave wait for the load at once).
+// the host guarantees that no vector straddles an edge.  Loads are BUFFER loads: the lane's byte offset inside K-tile 0 is
+// computed once (a row outside the operand gets an offset beyond any buffer: the hardware range check returns zeros and
+// fetches nothing), the K-tile's advance is the instruction's scalar offset, and the one K-tile that can hold k beyond the
+// reduction extent has a second offset set with those loads switched off -- so a staged load costs one select between the two
+// sets (a wave-uniform condition) and no address arithmetic, and nothing needs zeroing on the way into LDS.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOob = 0x80000000u;
+
 template <bool KC, int VEC, int ROWS>
 struct Stage {
     static constexpr int NV = ROWS * BK / 256 / VEC;       // loads per thread and K-tile
     static constexpr int QK = BK / VEC, QR = ROWS / VEC;   // loads per row (KC) / per k-row
     float v[NV][VEC];
-    uint32_t off[NV];          // element offset of load `it` in K-tile 0
-    unsigned rowok, okm;       // bit it: the load's row is inside the operand / the load in flight is inside it
-    int kq;                    // k of this thread's loads inside a K-tile: kq + kstep(it)
-    static __device__ __forceinline__ constexpr int kstep(int it) { return KC ? 0 : (256 / QR) * it; }
-    __device__ __forceinline__ void init(int64_t ldx, int r0, int R, int kbeg, int t) {
-        rowok = 0u; okm = 0u;
-        kq = KC ? (t % QK) * VEC : t / QR;
+    uint32_t off[NV], offl[NV];      // byte offset of load `it` in K-tile 0; the same with the k >= k_end loads of the LAST K-tile off
+    __device__ __forceinline__ void init(int64_t ldx, int r0, int R, int kbeg, int k_last_valid, int t) {
+        const int kq = KC ? (t % QK) * VEC : t / QR;       // k of this thread's loads inside a K-tile: kq + (256 / QR) * it (strided)
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
             const int r = KC ? r0 + t / QK + (256 / QK) * it : r0 + (t % QR) * VEC;
-            const int k = kbeg + kq + kstep(it);
-            rowok |= r < R ? (1u << it) : 0u;
-            off[it] = r < R ? (uint32_t)(KC ? (int64_t)r * ldx + k : (int64_t)k * ldx + r) : 0u;
+            const int kl = kq + (KC ? 0 : (256 / QR) * it);
+            const int64_t e = KC ? (int64_t)r * ldx + kbeg + kl : (int64_t)(kbeg + kl) * ldx + r;
+            off[it] = r < R ? (uint32_t)(e * 4) : kOob;
+            offl[it] = kl < k_last_valid ? off[it] : kOob;
         }
     }
-    // kadv: element offset of the K-tile against K-tile 0 (KC: its k0 - kbeg; else that times the row stride)
+    // soff: byte offset of the K-tile against K-tile 0 (wave-uniform); last: it is the workgroup's last K-tile (wave-uniform)
     template <int IT>
-    __device__ __forceinline__ void load_one(const float* __restrict__ X, uint32_t kadv, int k0, int k_end) {
-        const unsigned ok = ((rowok >> IT) & 1u) & (unsigned)(k0 + kq + kstep(IT) < k_end);      // (no &&: no branch)
-        okm = (okm & ~(1u << IT)) | (ok << IT);
-        const float* p = X + (ok ? off[IT] + kadv : 0u);
+    __device__ __forceinline__ void load_one(__amdgpu_buffer_rsrc_t rs, uint32_t soff, bool last) {
+        const uint32_t vo = last ? offl[IT] : off[IT];
         if (VEC == 4) {
-            const float4 x = *(const float4*)p;
-            v[IT][0] = x.x; v[IT][1 % VEC] = x.y; v[IT][2 % VEC] = x.z; v[IT][3 % VEC] = x.w;
+            const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff, 0);
+            v[IT][0] = __uint_as_float(x[0]); v[IT][1 % VEC] = __uint_as_float(x[1]); v[IT][2 % VEC] = __uint_as_float(x[2]); v[IT][3 % VEC] = __uint_as_float(x[3]);
         } else if (VEC == 2) {
-            const float2 x = *(const float2*)p;
-            v[IT][0] = x.x; v[IT][1 % VEC] = x.y;
+            const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, soff, 0);
+            v[IT][0] = __uint_as_float(x[0]); v[IT][1 % VEC] = __uint_as_float(x[1]);
         } else {
-            v[IT][0] = *p;
+            v[IT][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, soff, 0));
         }
     }
     template <int IT>
     __device__ __forceinline__ void store_one(float* __restrict__ S, int t) const {      // S: [BK][LD] reduction-major
-        const bool ok = (okm >> IT) & 1u;
-        float x[VEC];
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) x[c] = ok ? v[IT][c] : 0.0f;
         if (KC) {
             const int q = t % QK, rr = t / QK + (256 / QK) * IT;
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) S[(q * VEC + c) * LD + rr] = x[c];
+            for (int c = 0; c < VEC; ++c) S[(q * VEC + c) * LD + rr] = v[IT][c];
         } else {
             const int q = t % QR, kk = t / QR + (256 / QR) * IT;
             float* d = S + kk * LD + q * VEC;
-            if (VEC == 4) *(float4*)d = make_float4(x[0], x[1 % VEC], x[2 % VEC], x[3 % VEC]);
-            else if (VEC == 2) *(float2*)d = make_float2(x[0], x[1 % VEC]);
-            else *d = x[0];
+            if (VEC == 4) *(float4*)d = make_float4(v[IT][0], v[IT][1 % VEC], v[IT][2 % VEC], v[IT][3 % VEC]);
+            else if (VEC == 2) *(float2*)d = make_float2(v[IT][0], v[IT][1 % VEC]);
+            else *d = v[IT][0];
         }
     }
 };
@@ -169,13 +168,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const Args a) {
     constexpr int NA = SA::NV, NT = SA::NV + SB::NV;       // staging items per thread and K-tile: A's loads, then B's
     SA sa;
     SB sb;
-    sa.init(a.lda, m0, a.M, kbeg, t);
-    sb.init(a.ldb, n0, a.N, kbeg, t);
-    const uint32_t advA = AKC ? (uint32_t)BK : (uint32_t)(BK * a.lda), advB = BKC ? (uint32_t)BK : (uint32_t)(BK * a.ldb);
+    const int k_last_valid = kend - (kbeg + (T - 1) * BK);       // k inside the last K-tile (1 .. BK)
+    sa.init(a.lda, m0, a.M, kbeg, k_last_valid, t);
+    sb.init(a.ldb, n0, a.N, kbeg, k_last_valid, t);
+    // the operands as buffers of exactly their extent (rows x stride, the last row without its padding)
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.A), 0, (int)((((int64_t)(AKC ? a.M : a.K) - 1) * a.lda + (AKC ? a.K : a.M)) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.B), 0, (int)((((int64_t)(BKC ? a.N : a.K) - 1) * a.ldb + (BKC ? a.K : a.N)) * 4), 0x00020000);
+    const uint32_t advA = (AKC ? (uint32_t)BK : (uint32_t)(BK * a.lda)) * 4u, advB = (BKC ? (uint32_t)BK : (uint32_t)(BK * a.ldb)) * 4u;
     auto load_item = [&](auto I, int tile) {
         constexpr int i = decltype(I)::value;
-        if constexpr (i < NA) sa.template load_one<i>(a.A, advA * (uint32_t)tile, kbeg + tile * BK, kend);
-        else sb.template load_one<i - NA>(a.B, advB * (uint32_t)tile, kbeg + tile * BK, kend);
+        if constexpr (i < NA) sa.template load_one<i>(rA, advA * (uint32_t)tile, tile == T - 1);
+        else sb.template load_one<i - NA>(rB, advB * (uint32_t)tile, tile == T - 1);
     };
     auto store_item = [&](auto I, int buf) {
         constexpr int i = decltype(I)::value;
@@ -222,8 +227,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const Args a) {
             // the staging work of this gap
             constexpr int h = BK / 4;                                                   // steps per half
             constexpr int lo = (s % h) * NT / h, hi = (s % h + 1) * NT / h;
-            // (unconditional: behind the last K-tile every load lies outside the operand -- it reads X[0] and stores zeros
-            // nobody reads -- and the loop body stays one basic block, which is what lets the waits be counted exactly)
+            // (unconditional: what is loaded behind the last K-tile -- zeros, or the next slab's rows -- goes into a buffer
+            // nobody reads, and the loop body stays one basic block, which is what lets the waits be counted exactly)
             if constexpr (s < h) static_for<lo, hi>([&](auto I) { load_item(I, j + 1); });
             else static_for<lo, hi>([&](auto I) { store_item(I, (j + 1) & 1); });
             __builtin_amdgcn_sched_barrier(0);
@@ -320,9 +325,9 @@ int launch_one(const Args& a, unsigned grid, hipStream_t st) {
 // a: M, N, K, operands and epilogue set; tiles and the grid are filled in here
 template <bool AKC, bool BKC, int EPI>
 int launch(Args a, int va, int vb, int S, hipStream_t st) {
-    // staged loads are addressed by 32-bit element offsets
+    // staged loads are buffer loads: 31-bit byte offsets
     const int64_t ea = (AKC ? (int64_t)a.M : (int64_t)a.K) * a.lda, eb = (BKC ? (int64_t)a.N : (int64_t)a.K) * a.ldb;
-    if (ea >= (int64_t(1) << 32) || eb >= (int64_t(1) << 32)) return MREC_EUNSUPPORTED;
+    if (ea * 4 >= (int64_t(1) << 31) || eb * 4 >= (int64_t(1) << 31)) return MREC_EUNSUPPORTED;
     a.tiles_m = (int)mrec_cdiv(a.M, BM);
     a.tiles_n = (int)mrec_cdiv(a.N, BN);
     const unsigned grid = (unsigned)((int64_t)a.tiles_m * a.tiles_n * S);
