@@ -65,3 +65,35 @@ def test_lru_eviction_by_the_count(dev):
     hb.prepare(torch.arange(40, 100, dtype=torch.int64, device=dev))      # 20 hits + 40 misses: 4 free rows + 40 stale rows: fits
     hb.check()
     assert hb.resident == 64 and hb.stats == {"hits": 20, "misses": 100, "evictions": 36, "first_touch": 100}
+
+
+@pytest.mark.parametrize("W", [240, 81, 4])
+def test_move_rows_between_device_and_pinned_host(dev, W):
+    """mrec_move_rows_f32 (the cache tier's write-backs and fetches): device-side list length, negative rows skipped, either side
+    pinned host memory; against a loop."""
+    from mindrec_amd import ops
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(1000, W, generator=g)
+    host = src.clone().pin_memory()
+    dst = torch.zeros(500, W, device=dev)
+    n = 300
+    sr, dr = torch.randperm(1000, generator=g)[:n], torch.randperm(500, generator=g)[:n]
+    sr[::7] = -1
+    dr[3::11] = -1
+    nd = torch.tensor([250], dtype=torch.int64, device=dev)
+    ops.move_rows_(dst, dr.to(dev), host, sr.to(dev), n_dev=nd)          # host -> device, the first 250 pairs
+    ref = torch.zeros(500, W)
+    for i in range(250):
+        if sr[i] >= 0 and dr[i] >= 0:
+            ref[dr[i]] = src[sr[i]]
+    assert torch.equal(dst.cpu(), ref)
+    back = torch.zeros(1000, W).pin_memory()
+    ops.move_rows_(back, sr.to(dev), dst, dr.to(dev))                    # device -> host, all n
+    torch.cuda.synchronize()
+    ref2 = torch.zeros(1000, W)
+    for i in range(n):
+        if sr[i] >= 0 and dr[i] >= 0:
+            ref2[sr[i]] = ref[dr[i]]
+    assert torch.equal(back, ref2)
+    with pytest.raises(TypeError):
+        ops.move_rows_(dst, dr.to(dev).int(), host, sr.to(dev))
