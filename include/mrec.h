@@ -699,6 +699,10 @@ int mrec_shard_unpack_iw_i32(const int32_t* pairs, int64_t n, int32_t* ids_out, 
  *     Unused slots carry id' = -1, weight 0.  slot_of_pos[i] = the slot (or -1: the bucket was full), pos_of_slot[slot] = i
  *     (or -1).  *overflow_dev += the number of positions that found their bucket full (sticky; the caller checks it once per
  *     sink and raises: the step that dropped positions is not a valid step).  wts nullable (all 1).
+ *     chunk_rot (0 .. n_shards - 1): owner o's slots are chunk (o - chunk_rot) mod n_shards of the message (0: chunk = owner).
+ *     A rank that passes its own rank + 1 finds its OWN chunk last; with the receive buffer laid out so that the sender's
+ *     chunk comes first (chunk (s - rank) mod n for sender s), send buffer = X[0 : n] and receive buffer = X[n - 1 : 2n - 1] of
+ *     one allocation share exactly the rank's own chunk, which then needs no copy at all (mindrec_amd/wide_deep_shard.py).
  *   mrec_shard_unpack_req: the received entries as two plain arrays (the plan and the apply's row_scale want them so).
  *   mrec_shard_unroute_slots: back at the requester, position i reads row slot_of_pos[i] of the returned message
  *     ([Dw words of the looked-up row | wide product, 0 | pad], W words per row) and writes emb_out[i, 0:Dw] and
@@ -706,12 +710,12 @@ int mrec_shard_unpack_iw_i32(const int32_t* pairs, int64_t n, int32_t* ids_out, 
  *   mrec_shard_route_grads: the gradient message, msg[slot] = [Dw words of g[pos_of_slot[slot]] | dlogit[pos / F] | pad];
  *     padding slots are left alone. */
 int mrec_shard_route_slots_workspace_bytes(int64_t n, int32_t n_shards, size_t* out);
-int mrec_shard_route_slots_i32(const int32_t* ids, const float* wts, int64_t n, int32_t n_shards, int64_t cap, int hashed, void* req,
-                               int32_t* slot_of_pos, int32_t* pos_of_slot, int64_t* overflow_dev, void* ws, size_t ws_bytes,
-                               void* stream);
-int mrec_shard_route_slots_i64(const int64_t* ids, const float* wts, int64_t n, int32_t n_shards, int64_t cap, int hashed, void* req,
-                               int32_t* slot_of_pos, int32_t* pos_of_slot, int64_t* overflow_dev, void* ws, size_t ws_bytes,
-                               void* stream);
+int mrec_shard_route_slots_i32(const int32_t* ids, const float* wts, int64_t n, int32_t n_shards, int64_t cap, int hashed,
+                               int32_t chunk_rot, void* req, int32_t* slot_of_pos, int32_t* pos_of_slot, int64_t* overflow_dev, void* ws,
+                               size_t ws_bytes, void* stream);
+int mrec_shard_route_slots_i64(const int64_t* ids, const float* wts, int64_t n, int32_t n_shards, int64_t cap, int hashed,
+                               int32_t chunk_rot, void* req, int32_t* slot_of_pos, int32_t* pos_of_slot, int64_t* overflow_dev, void* ws,
+                               size_t ws_bytes, void* stream);
 int mrec_shard_unpack_req(const void* req, int32_t id_bytes, int64_t n_slots, void* ids_out, float* wts_out, void* stream);
 int mrec_shard_unroute_slots(const float* back, int64_t W, const int32_t* slot_of_pos, int64_t n, int32_t Dw, float* emb_out,
                              float* wprod_out, void* stream);

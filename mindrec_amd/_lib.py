@@ -56,8 +56,8 @@ _SIGS = {
     "mrec_gather_rows_wide_ex": [_vp, _i64, _i64, _i32, _vp, _i32, _i64, _i64, _vp, _i64, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _i32,
                                  C.c_uint32, _vp, _vp],
     "mrec_shard_route_slots_workspace_bytes": [_i64, _i32, _szp],
-    "mrec_shard_route_slots_i32": [_vp, _vp, _i64, _i32, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
-    "mrec_shard_route_slots_i64": [_vp, _vp, _i64, _i32, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_shard_route_slots_i32": [_vp, _vp, _i64, _i32, _i64, _int, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_shard_route_slots_i64": [_vp, _vp, _i64, _i32, _i64, _int, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_shard_unpack_req": [_vp, _i32, _i64, _vp, _vp, _vp],
     "mrec_shard_unroute_slots": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_shard_route_grads": [_vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp, _i64, _vp],

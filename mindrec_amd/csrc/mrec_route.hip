@@ -24,10 +24,13 @@ __device__ __forceinline__ int owner_of(K id, int S, bool hash) {
 }
 
 template <class K>
-__global__ __launch_bounds__(256) void k_owner(const K* __restrict__ ids, int64_t n, int S, int* __restrict__ owner, bool hash) {
+__global__ __launch_bounds__(256) void k_owner(const K* __restrict__ ids, int64_t n, int S, int* __restrict__ owner, bool hash,
+                                               int rot = 0) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    owner[i] = owner_of(ids[i], S, hash);
+    int c = owner_of(ids[i], S, hash) - rot;      // the message chunk of the id's owner (rot = 0: chunk = owner)
+    if (c < 0) c += S;
+    owner[i] = c;
 }
 
 template <class K>
@@ -161,7 +164,8 @@ template <class K> struct ReqEntry;
 template <> struct ReqEntry<int32_t> { int32_t id; float wt; };
 template <> struct ReqEntry<int64_t> { int64_t id; float wt; int32_t pad; };
 
-// Thread k < n: sorted position k (bucket order, stable) takes slot owner * cap + (k - bucket start); positions past a
+// Thread k < n: sorted position k (bucket order, stable) takes slot chunk * cap + (k - bucket start), chunk = (owner - rot)
+// mod S (rot = 0: the owner itself; the engine rotates so that a rank's own chunk is the LAST one, see mrec.h); positions past a
 // bucket's capacity are dropped and counted.  Thread t < S * cap: slots past a bucket's count carry id -1 (the owner's gather
 // skips them, its plan sorts them behind everything else).
 template <class K>
@@ -169,15 +173,17 @@ __global__ __launch_bounds__(256) void k_route_slots(const K* __restrict__ ids, 
                                                      int64_t cap, const int* __restrict__ perm, const int* __restrict__ dbase,
                                                      ReqEntry<K>* __restrict__ req, int* __restrict__ slot_of_pos,
                                                      int* __restrict__ pos_of_slot, unsigned long long* __restrict__ overflow,
-                                                     bool hash) {
+                                                     bool hash, int rot) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t < n) {
         const int pos = perm[t];
         const K id = ids[pos];
         const int o = owner_of(id, S, hash);
-        const int64_t j = t - dbase[o];
+        int c = o - rot;                                   // the owner's chunk of the message
+        if (c < 0) c += S;
+        const int64_t j = t - dbase[c];
         if (j < cap) {
-            const int64_t s = (int64_t)o * cap + j;
+            const int64_t s = (int64_t)c * cap + j;
             ReqEntry<K> e{};
             e.id = hash ? id : (id - (K)o) / (K)S;
             e.wt = wts ? wts[pos] : 1.0f;
@@ -279,10 +285,11 @@ __global__ __launch_bounds__(256) void k_route_grads(const float* __restrict__ g
 }
 
 template <class K>
-int route_slots_impl(const K* ids, const float* wts, int64_t n, int32_t S, int64_t cap, int hashed, void* req, int32_t* slot_of_pos,
+int route_slots_impl(const K* ids, const float* wts, int64_t n, int32_t S, int64_t cap, int hashed, int32_t rot, void* req, int32_t* slot_of_pos,
                      int32_t* pos_of_slot, int64_t* overflow_dev, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n <= 0 || S <= 0 || S > RNB || cap <= 0 || !ids || !req || !slot_of_pos || !pos_of_slot || !overflow_dev || !ws) return MREC_EINVAL;
+    if (rot < 0 || rot >= S) return MREC_EINVAL;
     if (n > (int64_t(1) << 30) || (int64_t)S * cap > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
     if (((uintptr_t)req) & (sizeof(ReqEntry<K>) - 1)) return MREC_EINVAL;
     const int nblk = (int)mrec_cdiv(n, RT);
@@ -297,11 +304,11 @@ int route_slots_impl(const K* ids, const float* wts, int64_t n, int32_t S, int64
     if (!a.ok) return MREC_EWORKSPACE;
     int nbits = 1;
     while ((1 << nbits) < S) ++nbits;
-    k_owner<K><<<(unsigned)mrec_cdiv(n, 256), 256, 0, st>>>(ids, n, S, owner, hashed != 0);
+    k_owner<K><<<(unsigned)mrec_cdiv(n, 256), 256, 0, st>>>(ids, n, S, owner, hashed != 0, rot);
     radix_pass(owner, nullptr, (int)n, 0, nbits, hist, hscan, totals, dbase, okeys, perm, st);
     const int64_t m = n > (int64_t)S * cap ? n : (int64_t)S * cap;
     k_route_slots<K><<<(unsigned)mrec_cdiv(m, 256), 256, 0, st>>>(ids, wts, n, S, cap, perm, dbase, (ReqEntry<K>*)req, slot_of_pos,
-                                                                 pos_of_slot, (unsigned long long*)overflow_dev, hashed != 0);
+                                                                 pos_of_slot, (unsigned long long*)overflow_dev, hashed != 0, rot);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -425,14 +432,14 @@ MREC_API int mrec_shard_route_slots_workspace_bytes(int64_t n, int32_t n_shards,
     return MREC_OK;
 }
 MREC_API int mrec_shard_route_slots_i32(const int32_t* ids, const float* wts, int64_t n, int32_t n_shards, int64_t cap, int hashed,
-                                        void* req, int32_t* slot_of_pos, int32_t* pos_of_slot, int64_t* overflow_dev, void* ws,
-                                        size_t ws_bytes, void* stream) {
-    return route_slots_impl<int32_t>(ids, wts, n, n_shards, cap, hashed, req, slot_of_pos, pos_of_slot, overflow_dev, ws, ws_bytes, stream);
+                                        int32_t chunk_rot, void* req, int32_t* slot_of_pos, int32_t* pos_of_slot, int64_t* overflow_dev,
+                                        void* ws, size_t ws_bytes, void* stream) {
+    return route_slots_impl<int32_t>(ids, wts, n, n_shards, cap, hashed, chunk_rot, req, slot_of_pos, pos_of_slot, overflow_dev, ws, ws_bytes, stream);
 }
 MREC_API int mrec_shard_route_slots_i64(const int64_t* ids, const float* wts, int64_t n, int32_t n_shards, int64_t cap, int hashed,
-                                        void* req, int32_t* slot_of_pos, int32_t* pos_of_slot, int64_t* overflow_dev, void* ws,
-                                        size_t ws_bytes, void* stream) {
-    return route_slots_impl<int64_t>(ids, wts, n, n_shards, cap, hashed, req, slot_of_pos, pos_of_slot, overflow_dev, ws, ws_bytes, stream);
+                                        int32_t chunk_rot, void* req, int32_t* slot_of_pos, int32_t* pos_of_slot, int64_t* overflow_dev,
+                                        void* ws, size_t ws_bytes, void* stream) {
+    return route_slots_impl<int64_t>(ids, wts, n, n_shards, cap, hashed, chunk_rot, req, slot_of_pos, pos_of_slot, overflow_dev, ws, ws_bytes, stream);
 }
 MREC_API int mrec_shard_unpack_req(const void* req, int32_t id_bytes, int64_t n_slots, void* ids_out, float* wts_out, void* stream) {
     if (n_slots < 0 || (id_bytes != 4 && id_bytes != 8)) return MREC_EINVAL;

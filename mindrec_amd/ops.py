@@ -800,17 +800,23 @@ def shard_capacity(n, n_shards, factor=1.25):
     return int(min(n, -(-c // 64) * 64))
 
 
-def shard_route_slots(ids, wts, n_shards, cap, hashed=False, overflow=None):
+def shard_route_slots(ids, wts, n_shards, cap, hashed=False, overflow=None, rot=0, out=None):
     """Request message of a step (all owners, `cap` slots each): returns (req, slot_of_pos int32 [n], pos_of_slot int32
     [n_shards * cap]); req is int32 [n_shards * cap, 2] ({id, weight bits}) for int32 ids, int64-addressable
-    [n_shards * cap, 2] ({key, weight bits | 0}) for int64.  overflow: int64 [1] device counter (sticky)."""
-    _need_cuda(ids, wts, overflow)
+    [n_shards * cap, 2] ({key, weight bits | 0}) for int64.  overflow: int64 [1] device counter (sticky).  rot: owner o's slots
+    are chunk (o - rot) mod n_shards of the message.  out: the message buffer to write (contiguous, req's shape and dtype)."""
+    _need_cuda(ids, wts, overflow, out)
     sfx = _suffix(ids)
     flat = ids.reshape(-1).contiguous()
     n = flat.numel()
     dev = flat.device
     ns = int(n_shards) * int(cap)
-    req = torch.empty((ns, 2), dtype=flat.dtype, device=dev)
+    if out is not None:
+        if out.dtype != flat.dtype or tuple(out.shape) != (ns, 2) or not out.is_contiguous():
+            raise TypeError("out must be a contiguous [n_shards * cap, 2] tensor of the ids' dtype")
+        req = out
+    else:
+        req = torch.empty((ns, 2), dtype=flat.dtype, device=dev)
     slot_of_pos = torch.empty(max(n, 1), dtype=torch.int32, device=dev)[:n]
     pos_of_slot = torch.empty(max(ns, 1), dtype=torch.int32, device=dev)[:ns]
     w = None
@@ -820,7 +826,7 @@ def shard_route_slots(ids, wts, n_shards, cap, hashed=False, overflow=None):
             raise TypeError("wts must be float32 with one value per id")
     nb = _lib.query_bytes("mrec_shard_route_slots_workspace_bytes", n, n_shards)
     ws = workspace("route_slots", nb, dev)
-    _lib.call(f"mrec_shard_route_slots_{sfx}", _ptr(flat), _ptr(w), n, int(n_shards), int(cap), int(bool(hashed)), _ptr(req),
+    _lib.call(f"mrec_shard_route_slots_{sfx}", _ptr(flat), _ptr(w), n, int(n_shards), int(cap), int(bool(hashed)), int(rot), _ptr(req),
               _ptr(slot_of_pos), _ptr(pos_of_slot), _ptr(overflow), _ptr(ws), ws.numel(), _stream())
     return req, slot_of_pos, pos_of_slot
 
@@ -881,16 +887,22 @@ def shard_unroute_slots(back, slot_of_pos, D, act_dtype, out=None):
     return out.view(n, D), wprod
 
 
-def shard_route_grads(g, dlogit, F, pos_of_slot):
-    """The gradient message float32 [n_slots, W]: [row gradient of the slot's position | dlogit of its sample | pad]."""
-    _need_cuda(g, dlogit, pos_of_slot)
+def shard_route_grads(g, dlogit, F, pos_of_slot, out=None):
+    """The gradient message float32 [n_slots, W]: [row gradient of the slot's position | dlogit of its sample | pad].  out: the
+    message buffer to write (contiguous float32 [n_slots, W])."""
+    _need_cuda(g, dlogit, pos_of_slot, out)
     n, D = g.shape
     Dw, W = shard_msg_words(D, g.dtype)
     if g.stride(1) != 1 or dlogit.dtype != torch.float32 or not dlogit.is_contiguous() or dlogit.numel() * F != n:
         raise TypeError("shard_route_grads: g [n, D] with unit column stride, dlogit float32 [n / F]")
     ldg = g.stride(0) * g.element_size() // 4 if n > 1 else Dw
     ns = pos_of_slot.numel()
-    msg = torch.empty((max(ns, 1), W), dtype=torch.float32, device=g.device)[:ns]
+    if out is not None:
+        if out.dtype != torch.float32 or tuple(out.shape) != (ns, W) or not out.is_contiguous():
+            raise TypeError("out must be contiguous float32 [n_slots, W]")
+        msg = out
+    else:
+        msg = torch.empty((max(ns, 1), W), dtype=torch.float32, device=g.device)[:ns]
     _lib.call("mrec_shard_route_grads", _ptr(g), ldg, _ptr(dlogit), int(F), _ptr(pos_of_slot), ns, Dw, _ptr(msg), W, _stream())
     return msg
 

@@ -123,6 +123,10 @@ class _DirectComm:
     def all_to_all(self, out, inp, out_splits=None, in_splits=None):
         dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
+    def all_to_all_lists(self, outs, ins):
+        """outs[r] <- what rank r sends to this rank, ins[r] -> rank r; entries may differ in length (zero-length: nothing moves)."""
+        dist.all_to_all(outs, ins, group=self.group)
+
     def all_reduce(self, t, async_op=False):
         """Sum over ranks.  async_op=True returns a work handle (device tensors only): the reduction proceeds on RCCL's
         stream while the calling stream keeps issuing kernels."""

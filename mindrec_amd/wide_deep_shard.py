@@ -20,7 +20,13 @@ Every rank hands every owner exactly `cap` = ceil(shard_capacity_factor * N / n)
 gather skips them, its plan sorts them behind the index proper, its apply never sees them), so every message has a static,
 host-known shape: no bucket sizes cross the host, and with a capturable communicator (RCCL) the whole step -- collectives
 included -- is ONE HIP graph per rank.  A position that finds its bucket full is dropped and counted in a sticky device
-counter (`shard_overflow()`, checked by the caller once per sink: such a step is not a valid step)."""
+counter (`shard_overflow()`, checked by the caller once per sink: such a step is not a valid step).
+
+A rank's OWN chunk of a message never moves: the requester numbers the chunks of what it sends so that its own comes last
+(owner o -> chunk (o - rank - 1) mod n: `chunk_rot` of mrec_shard_route_slots), an owner lays out what it receives so that its
+own comes first (sender s -> chunk (s - rank) mod n), and the send buffer X[0 : n] and the receive buffer X[n - 1 : 2n - 1] of one
+allocation then share exactly that chunk; the collective moves the other n - 1 (`_exchange`).  On one rank nothing is left to
+move at all."""
 import torch
 import torch.nn.functional as F
 
@@ -34,6 +40,9 @@ class ShardCapacityError(RuntimeError):
 class ShardStepMixin:
     def _shard_init(self):
         D = self.cfg.emb_dim
+        # the own-chunk bypass needs a communicator that takes per-peer tensor lists (the product's; the CPU stand-in keeps the
+        # plain equal-split exchange)
+        self._bypass = bool(self._gpu and hasattr(self.comm, "all_to_all_lists"))
         self._act = self._amp if self._mfma else torch.float32           # dtype of looked-up rows / row gradients, also on the wire
         self._shard_fold = bool(self._fused_rows and D <= 252 and D % (4 if self._act == torch.float32 else 8) == 0)
         self._overflow = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -51,17 +60,46 @@ class ShardStepMixin:
             raise ShardCapacityError(f"{d} id positions did not fit the request message (capacity factor "
                                      f"{self.cfg.shard_capacity_factor}): the affected steps are not valid steps")
 
+    # ---- the exchange ---------------------------------------------------------------------------------------------------
+    def _xbuf(self, rows, width, dtype):
+        """(first window, second window) of one exchange buffer for a message of `rows` = n * cap rows: what is laid out by
+        rotated owner chunk goes into the first, what is laid out by sender into the second; they share the rank's own chunk."""
+        n = self.world
+        cap = rows // n
+        X = torch.empty(((2 * n - 1) * cap, width), dtype=dtype, device=self.device)
+        return X[: n * cap], X[(n - 1) * cap:]
+
+    def _exchange(self, recv, send, to_owner):
+        """All-to-all of the n - 1 chunks that belong to other ranks.  to_owner: requests / gradients (send laid out by rotated
+        owner chunk, recv by sender); else answers (send laid out by sender, recv by rotated owner chunk)."""
+        n, me = self.world, self.rank
+        if n == 1:
+            return
+        cap = send.shape[0] // n
+        ins, outs = [], []
+        for r in range(n):
+            if r == me:
+                ins.append(send[:0])
+                outs.append(recv[:0])
+                continue
+            by_owner, by_sender = (r - me - 1) % n, (r - me) % n
+            a, b = (by_owner, by_sender) if to_owner else (by_sender, by_owner)
+            ins.append(send[a * cap:(a + 1) * cap])
+            outs.append(recv[b * cap:(b + 1) * cap])
+        self.comm.all_to_all_lists(outs, ins)
+
     # ---- forward half -------------------------------------------------------------------------------------------------
-    def _answer(self, rows, rstride, wts, wstride, ns):
+    def _answer(self, rows, rstride, wts, wstride, ns, out=None):
         """The owner's message [ns, W]: looked-up (masked) deep rows + the wide products of the requested rows."""
         cfg, k = self.cfg, self.k
         D, act = cfg.emb_dim, self._act
         if self._shard_fold:
-            return k.gather_rows_req(self.deep, rows, rstride, wts, wstride, ns, D, act)
+            return k.gather_rows_req(self.deep, rows, rstride, wts, wstride, ns, D, act, out=out)
         # separate tables (split state, the cache tier, the CPU stand-in): two gathers, packed here
         assert rstride == 1 and wstride == 1
         Dw, W = k.shard_msg_words(D, act)
-        msg = torch.zeros((ns, W), dtype=torch.float32, device=self.device)
+        msg = out if out is not None else torch.empty((ns, W), dtype=torch.float32, device=self.device)
+        msg.zero_()
         e = k.gather_rows(self.deep, rows, wts) if act == torch.float32 else k.gather_rows(self.deep, rows, wts, out_dtype=act)
         msg[:, :Dw] = e.reshape(ns, D) if act == torch.float32 else e.reshape(ns, D).view(torch.float32)
         msg[:, Dw] = k.gather_rows(self.wide, rows, wts).reshape(ns)
@@ -72,9 +110,15 @@ class ShardStepMixin:
         cfg, k = self.cfg, self.k
         n = ids.numel()
         cap = k.shard_capacity(n, self.world, cfg.shard_capacity_factor)
-        req, slot_of_pos, pos_of_slot = k.shard_route_slots(ids, wts, self.world, cap, hashed=self._hashed, overflow=self._overflow)
-        recv_req = torch.empty_like(req)
-        self.comm.all_to_all(recv_req, req)
+        if self._bypass:
+            req, recv_req = self._xbuf(self.world * cap, 2, ids.dtype)
+            _, slot_of_pos, pos_of_slot = k.shard_route_slots(ids, wts, self.world, cap, hashed=self._hashed, overflow=self._overflow,
+                                                              rot=(self.rank + 1) % self.world, out=req)
+            self._exchange(recv_req, req, to_owner=True)
+        else:
+            req, slot_of_pos, pos_of_slot = k.shard_route_slots(ids, wts, self.world, cap, hashed=self._hashed, overflow=self._overflow)
+            recv_req = torch.empty_like(req)
+            self.comm.all_to_all(recv_req, req)
         return {"recv_req": recv_req, "slot_of_pos": slot_of_pos, "pos_of_slot": pos_of_slot, "ns": self.world * cap}
 
     def _shard_lookup(self, ids, wts, want_plan=True):
@@ -88,6 +132,9 @@ class ShardStepMixin:
         self._tock(ev)
         ev = self._tick("gather_deep")
         plan = recv_wts = rows = None
+        back = ans_out = None
+        if self._bypass:
+            back, ans_out = self._xbuf(ns, k.shard_msg_words(D, act)[1], torch.float32)
         translate = self.index is not None or self.hb is not None
         if translate:
             # hash tables / the cache tier: what arrived are raw keys (or rows of a host table); the owner's own index gives them
@@ -97,16 +144,16 @@ class ShardStepMixin:
                 plan, rows = self.hb.prepare(recv_ids, skip_negative=True)
             else:
                 rows = self.index.lookup(recv_ids, insert=True, tables=self._map_tables(), skip_pad=True)
-            ans = self._answer(rows, 1, recv_wts, 1, ns)
+            ans = self._answer(rows, 1, recv_wts, 1, ns, out=ans_out)
         elif self._shard_fold:
             # ids and weights are read straight out of the received entries ({id, weight}: stride 2 in units of either)
             if recv_req.dtype == torch.int32:
-                ans = self._answer(recv_req, 2, recv_req.view(torch.float32).view(-1)[1:], 2, ns)
+                ans = self._answer(recv_req, 2, recv_req.view(torch.float32).view(-1)[1:], 2, ns, out=ans_out)
             else:
-                ans = self._answer(recv_req, 2, recv_req.view(torch.float32).view(-1)[2:], 4, ns)
+                ans = self._answer(recv_req, 2, recv_req.view(torch.float32).view(-1)[2:], 4, ns, out=ans_out)
         else:
             rows, recv_wts = k.shard_unpack_req(recv_req)
-            ans = self._answer(rows, 1, recv_wts, 1, ns)
+            ans = self._answer(rows, 1, recv_wts, 1, ns, out=ans_out)
         fork_ev = None
         if self._side is not None and want_plan:
             # the step's Unique + inverted index of the received ids: a dozen small latency-bound kernels, on the side branch
@@ -116,8 +163,11 @@ class ShardStepMixin:
             fork_ev.record(torch.cuda.current_stream())
         self._tock(ev)
         ev = self._tick("a2a_rows")
-        back = torch.empty_like(ans)
-        self.comm.all_to_all(back, ans)
+        if self._bypass:
+            self._exchange(back, ans, to_owner=False)
+        else:
+            back = torch.empty_like(ans)
+            self.comm.all_to_all(back, ans)
         self._tock(ev)
         ev = self._tick("unroute")
         eo = self._emb_out(n, D, act) if act != torch.float32 else None       # static graph input, when the MLP graph exists
@@ -179,9 +229,14 @@ class ShardStepMixin:
             state = self._step_state
             state.advance(cfg.adam_lr, float(self.beta1), float(self.beta2))
         ev = self._tick("a2a_grads")
-        gmsg = k.shard_route_grads(g_emb.reshape(n, D), g_wide.reshape(B).contiguous(), Fd, route["pos_of_slot"])
-        recv_g = torch.empty_like(gmsg)
-        self.comm.all_to_all(recv_g, gmsg)
+        if self._bypass:
+            gmsg, recv_g = self._xbuf(route["ns"], k.shard_msg_words(D, act)[1], torch.float32)
+            k.shard_route_grads(g_emb.reshape(n, D), g_wide.reshape(B).contiguous(), Fd, route["pos_of_slot"], out=gmsg)
+            self._exchange(recv_g, gmsg, to_owner=True)
+        else:
+            gmsg = k.shard_route_grads(g_emb.reshape(n, D), g_wide.reshape(B).contiguous(), Fd, route["pos_of_slot"])
+            recv_g = torch.empty_like(gmsg)
+            self.comm.all_to_all(recv_g, gmsg)
         self._tock(ev)
         # Dense gradients (+ Wide_b's, an element of the same buffer): all-reduce queued behind the row-gradient exchange and
         # left running (RCCL's stream) while the sparse apply executes -- it does not need it.  (The slab sum + all-reduce on a

@@ -270,10 +270,10 @@ def shard_capacity(n, n_shards, factor=1.25):
     return int(min(n, -(-c // 64) * 64))
 
 
-def shard_route_slots(ids, wts, n_shards, cap, hashed=False):
+def shard_route_slots(ids, wts, n_shards, cap, hashed=False, rot=0):
     """Returns (req_ids int64 [n_shards * cap] (-1: unused slot), req_wts float32, slot_of_pos int32 [n] (-1: bucket full),
-    pos_of_slot int32 [n_shards * cap] (-1), dropped): position i takes slot owner * cap + (its rank among the positions of the
-    same owner, ascending position)."""
+    pos_of_slot int32 [n_shards * cap] (-1), dropped): position i takes slot chunk * cap + (its rank among the positions of the
+    same owner, ascending position), chunk = (owner - rot) mod n_shards."""
     ids = _i64(ids).ravel()
     n = ids.size
     w = np.ones(n, np.float32) if wts is None else _f32(wts).ravel()
@@ -291,7 +291,7 @@ def shard_route_slots(ids, wts, n_shards, cap, hashed=False):
         if j >= cap:
             dropped += 1
             continue
-        s = o * cap + j
+        s = ((o - rot) % n_shards) * cap + j
         req_ids[s] = ids[i] if hashed else (ids[i] - o) // n_shards
         req_wts[s] = w[i]
         slot_of_pos[i] = s

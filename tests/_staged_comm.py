@@ -20,6 +20,18 @@ class StagedGlooComm:
         dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
         out.copy_(o)
 
+    def all_to_all_lists(self, outs, ins):
+        """Per-peer tensor lists (rows of one width and dtype, any row counts) through one staged uneven all-to-all."""
+        ref = next(t for t in list(ins) + list(outs))
+        tail = tuple(ref.shape[1:])
+        send = torch.cat([t.reshape((-1,) + tail) for t in ins]) if ins else ref[:0]
+        recv = torch.empty((sum(t.shape[0] for t in outs),) + tail, dtype=ref.dtype, device=ref.device)
+        self.all_to_all(recv, send, [t.shape[0] for t in outs], [t.shape[0] for t in ins])
+        o = 0
+        for t in outs:
+            t.copy_(recv[o:o + t.shape[0]])
+            o += t.shape[0]
+
     def all_reduce(self, t, async_op=False):
         c = t.cpu()
         dist.all_reduce(c, group=self.group)

@@ -45,6 +45,33 @@ def test_route_slots_matches_oracle(dev, idt, world, hashed, factor):
     assert np.array_equal(np.nonzero(ok)[0] // cap, O.shard_owner(ids[pos[ok]], world, hashed))
 
 
+@pytest.mark.parametrize("world,rank", [(1, 0), (2, 0), (2, 1), (5, 3), (8, 7)])
+def test_route_slots_with_rotated_chunks(dev, world, rank):
+    """chunk_rot = rank + 1 (what the engine passes so that a rank's own chunk comes last): against the oracle, written into a
+    caller-provided window of a larger buffer, and the own chunk is the last one."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(3 + world)
+    n = 4000
+    ids = rng.integers(0, 100_000, size=n).astype(np.int32)
+    wts = rng.random(n).astype(np.float32)
+    cap = O.shard_capacity(n, world, 1.5)
+    rot = (rank + 1) % world
+    rid, rw, sop, pos, dropped = O.shard_route_slots(ids, wts, world, cap, False, rot=rot)
+    ov = torch.zeros(1, dtype=torch.int64, device=dev)
+    X = torch.full(((2 * world - 1) * cap, 2), 77, dtype=torch.int32, device=dev)
+    req, g_sop, g_pos = ops.shard_route_slots(T(ids, dev), T(wts, dev), world, cap, overflow=ov, rot=rot, out=X[: world * cap])
+    assert req.data_ptr() == X.data_ptr() and bool((X[world * cap:] == 77).all())
+    g_ids, g_wts = ops.shard_unpack_req(req)
+    assert np.array_equal(g_sop.cpu().numpy(), sop) and np.array_equal(g_pos.cpu().numpy(), pos) and int(ov.item()) == dropped == 0
+    assert np.array_equal(g_ids.cpu().numpy().astype(np.int64), rid) and np.array_equal(g_wts.cpu().numpy(), rw)
+    ok = pos >= 0
+    own = O.shard_owner(ids[pos[ok]], world, False)
+    assert np.array_equal(np.nonzero(ok)[0] // cap, (own - rot) % world)
+    assert set((np.nonzero(ok)[0] // cap)[own == rank]) <= {world - 1}          # the rank's own rows: the last chunk
+    with pytest.raises(RuntimeError):
+        ops.shard_route_slots(T(ids, dev), T(wts, dev), world, cap, overflow=ov, rot=world)
+
+
 @pytest.mark.parametrize("act", ["fp32", "bf16", "f16"])
 @pytest.mark.parametrize("idt", [np.int32, np.int64])
 def test_answer_message_unroute_and_gradient_message(dev, act, idt):
