@@ -43,6 +43,8 @@ class ShardStepMixin:
         # the own-chunk bypass needs a communicator that takes per-peer tensor lists (the product's; the CPU stand-in keeps the
         # plain equal-split exchange)
         self._bypass = bool(self._gpu and hasattr(self.comm, "all_to_all_lists"))
+        if self._bypass and self.world > 1:
+            self._bypass = self._exchange_selftest()
         self._act = self._amp if self._mfma else torch.float32           # dtype of looked-up rows / row gradients, also on the wire
         self._shard_fold = bool(self._fused_rows and D <= 252 and D % (4 if self._act == torch.float32 else 8) == 0)
         self._overflow = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -87,6 +89,30 @@ class ShardStepMixin:
             ins.append(send[a * cap:(a + 1) * cap])
             outs.append(recv[b * cap:(b + 1) * cap])
         self.comm.all_to_all_lists(outs, ins)
+
+    def _exchange_selftest(self):
+        """One small exchange through `_exchange` at start-up, checked element by element; all ranks agree on the outcome (a
+        communicator that cannot do it -- per-peer lists with an empty own entry -- sends every rank to the plain equal-split
+        all-to-all instead of failing in the first captured step)."""
+        n, me, cap = self.world, self.rank, 8
+        ok = 1
+        try:
+            send, recv = self._xbuf(n * cap, 2, torch.float32)
+            for r in range(n):                                   # chunk of owner r carries (me, r)
+                c = (r - me - 1) % n
+                send[c * cap:(c + 1) * cap, 0] = float(me)
+                send[c * cap:(c + 1) * cap, 1] = float(r)
+            self._exchange(recv, send, to_owner=True)
+            torch.cuda.synchronize(self.device)
+            for s_ in range(n):                                  # chunk of sender s must carry (s, me)
+                c = (s_ - me) % n
+                blk = recv[c * cap:(c + 1) * cap]
+                ok &= int(bool((blk[:, 0] == float(s_)).all()) and bool((blk[:, 1] == float(me)).all()))
+        except Exception:      # noqa: BLE001
+            ok = 0
+        flag = torch.tensor([float(ok)], device=self.device)
+        self.comm.all_reduce(flag)
+        return bool(flag.item() == float(n))
 
     # ---- forward half -------------------------------------------------------------------------------------------------
     def _answer(self, rows, rstride, wts, wstride, ns, out=None):

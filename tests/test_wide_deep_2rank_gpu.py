@@ -41,6 +41,7 @@ def _worker(rank, world, port, steps, out_dir, mlp_dtype="fp32", cap_factor=1.25
     torch.cuda.set_device(dev)
     cfg = _cfg(128)
     eng = WideDeepEngine(cfg, dev, rank=rank, world=world, comm=StagedGlooComm())
+    assert eng._bypass, "the own-chunk bypass of the exchange must have passed its start-up self-test"
     losses = []
     for s in range(steps):
         ids, wts, label = synthetic_batch(cfg, dev, "zipf", seed=50 + s, rank=rank)
@@ -131,6 +132,7 @@ def _hash_worker(rank, world, port, steps, out_dir, host_cache_rows):
     torch.cuda.set_device(dev)
     cfg = _hash_cfg(64, host_cache_rows)
     eng = WideDeepEngine(cfg, dev, rank=rank, world=world, comm=StagedGlooComm())
+    assert eng._bypass, "the own-chunk bypass of the exchange must have passed its start-up self-test"
     losses = []
     for s in range(steps):
         ids, wts, label = _hash_batch(64 * world, cfg.field_size, 100 + s, dev)
