@@ -471,11 +471,25 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
     const int NG = 4 * gm.G;
     const int gi = wave * gm.G + grp;
 
+    // ---- this block's windows: 4 per lane-group, their flags read in ONE coalesced load and sorted into two lists in LDS (with
+    // flags read window by window inside the passes, every iteration was a memory round trip to find, mostly, a zero)
+    __shared__ int list_a[256], n_a;
+    const int WPB = 4 * NG < 256 ? 4 * NG : 256;      // (the same expression sizes the grid in apply_cols)
+    const int64_t w0 = (int64_t)blockIdx.x * WPB;
+    if (threadIdx.x == 0) { n_a = 0; nlist = 0; }
+    __syncthreads();
+    if ((int)threadIdx.x < WPB && w0 + threadIdx.x < nsw) {
+        const int f = owners[w0 + threadIdx.x];
+        if (f == 1) list_a[atomicAdd(&n_a, 1)] = (int)(w0 + threadIdx.x);
+        else if (f == 2) list[atomicAdd(&nlist, 1)] = (int)(w0 + threadIdx.x);
+    }
+    __syncthreads();
+    const int cnt_a = n_a, cnt = nlist;
+
     // ---- pass A
     if (active) {
-        for (int64_t w = (int64_t)blockIdx.x * NG + gi; w < nsw; w += (int64_t)gridDim.x * NG) {
-            if (owners[w] != 1) continue;
-            const int sw = (int)w;
+        for (int ia = gi; ia < cnt_a; ia += NG) {
+            const int sw = list_a[ia];
             const int last_e = ((sw + 1) * AW < n ? (sw + 1) * AW : n) - 1;
             const int u = sseg[last_e];
             const int k = (seg_offsets[u + 1] - 1) / AW - sw;
@@ -507,17 +521,8 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
         }
     }
 
-    // ---- pass B: each block scans its slice of the flags, 256 at a time, and works through the long runs
-    const int64_t chunk = (nsw + gridDim.x - 1) / gridDim.x;
-    const int64_t w0 = (int64_t)blockIdx.x * chunk;
-    const int64_t w1 = (w0 + chunk < nsw) ? w0 + chunk : nsw;
-    for (int64_t base = w0; base < w1; base += 256) {
-        if (threadIdx.x == 0) nlist = 0;
-        __syncthreads();
-        const int64_t wq = base + threadIdx.x;
-        if (wq < w1 && owners[wq] == 2) list[atomicAdd(&nlist, 1)] = (int)wq;
-        __syncthreads();
-        const int cnt = nlist;
+    // ---- pass B: the long runs among this block's windows, one after the other, the whole block on each
+    {
         for (int o = 0; o < cnt; ++o) {
             const int sw = list[o];
             const int last_e = ((sw + 1) * AW < n ? (sw + 1) * AW : n) - 1;
@@ -577,7 +582,6 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
             }
             __syncthreads();
         }
-        __syncthreads();
     }
     // end stamp (measurement): the last-dispatched workgroups raise it -- one atomic each, 256 at most
     if (ss && threadIdx.x == 0 && (int)blockIdx.x + 256 >= (int)gridDim.x)
@@ -615,8 +619,7 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
     }
     const int64_t nsw = mrec_cdiv(n, vec == 4 ? ACfg<4>::AW : ACfg<1>::AW);
     const unsigned blocks = (unsigned)mrec_cdiv(nsw, (int64_t)4 * gm.G);
-    const int64_t lneed = mrec_cdiv(nsw, (int64_t)4 * gm.G);
-    const unsigned lblocks = (unsigned)(lneed < 2048 ? lneed : 2048);
+    const unsigned lblocks = (unsigned)mrec_cdiv(nsw, (int64_t)(16 * gm.G < 256 ? 16 * gm.G : 256));      // k_apply_long: 4 windows per lane-group, 4 G lane-groups, 256 at most
     const hipEvent_t ev0 = t_prof_start, ev1 = t_prof_stop;
     t_prof_start = t_prof_stop = nullptr;
     if (ev0) MREC_HIP_CHECK(hipEventRecord(ev0, st));
