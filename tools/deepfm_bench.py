@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mindrec_amd.deepfm import DeepFMConfig, DeepFMEngine  # noqa: E402
 
 dev = torch.device("cuda:0")
-for dt in ("fp16", "bf16", "fp32"):     # fp16: the reference's convert_dtype (hand-written MFMA net); fp32: library GEMMs through torch
+for dt in (sys.argv[1:] or ("fp16", "bf16", "fp32")):     # fp16: the reference's convert_dtype (hand-written MFMA net); fp32: library GEMMs through torch
     cfg = DeepFMConfig(mlp_dtype=dt)
     eng = DeepFMEngine(cfg, dev)
     B, F = cfg.batch_size, cfg.data_field_size
@@ -18,7 +18,7 @@ for dt in ("fp16", "bf16", "fp32"):     # fp16: the reference's convert_dtype (h
     ids = torch.randint(0, cfg.data_vocab_size, (B, F), dtype=torch.int32, device=dev, generator=g)
     wts = torch.rand((B, F), device=dev, generator=g)
     label = (torch.rand((B, 1), device=dev, generator=g) < 0.3).float()
-    for _ in range(3):
+    for _ in range(8):                     # (the MLP's HIP graphs are captured in the engine's third step)
         eng.train_step(ids, wts, label)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -45,7 +45,7 @@ if [ "$PART" = 3 ]; then
 cd $R
 python tools/paths_bench.py > $O/paths_bench.txt 2>/dev/null
 python tools/dcn_bench.py > $O/dcn_bench.txt 2>/dev/null
-python tools/deepfm_bench.py > $O/deepfm_bench.txt 2>/dev/null || true
+for dt in fp16 bf16 fp32; do python tools/deepfm_bench.py $dt 2>/dev/null | tail -1; done > $O/deepfm_bench.txt || true      # (a process per dtype: a second engine in one process runs slower)
 cat $O/paths_bench.txt $O/dcn_bench.txt $O/deepfm_bench.txt
 timeout -k 10 200 ./tools/probes/dense_gemm_test > $O/dense_gemm_probe.txt 2>&1 || true
 timeout -k 10 200 python tools/probes/tail_probe.py 2>/dev/null > $O/tail_probe.txt || true
