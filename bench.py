@@ -84,6 +84,25 @@ def self_launch(args):
     raise SystemExit(proc.returncode)
 
 
+def _usable_cores():
+    """Cores this process may actually use: the scheduler affinity, cut by the container's CPU quota (a GPU box gives a job
+    16 cores of a 256-thread host through cgroup cpu.max: threads beyond the quota only take turns)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(args, seconds):
     """CPU legs on the GPU box's host cores, each on a bounded sample of the same workload (same batch shape, table
     scaled down to fit host RAM: random-row bandwidth is insensitive to V once V*D*4 >> LLC):
@@ -96,7 +115,7 @@ def cpu_baseline(args, seconds):
     import torch
     import torch.nn.functional as F
     from oracle import oracle as O
-    ncpu = max(1, os.cpu_count() or 1)
+    ncpu = _usable_cores()
     threads = min(ncpu, 64)
     V = min(args.vocab, 2_000_000)
     D, B, Fd = args.emb_dim, args.batch, args.fields
@@ -178,7 +197,7 @@ def cpu_baseline(args, seconds):
         model = "unknown"
     by = (B * Fd) * 4 + 2 * (B * Fd) * D * 4 + (B * Fd) * 4 + (B * Fd) * D * 4 + 6 * (B * Fd) * D * 4      # lookup + apply, U = N
     return {"value": round(B / (t_mt + t_mlp), 1) if reps else round(B / t_mt, 1), "unit": "samples/s", "cores": threads,
-            "kind": "port", "host_cpu": model, "host_threads_available": ncpu,
+            "kind": "port", "host_cpu": model, "host_cores_usable": ncpu, "host_threads": os.cpu_count(),
             "legs": {
                 "port_1t": {"samples_per_s": round(B / t_1t, 1), "ms": round(t_1t * 1e3, 1), "cores": 1, "steps": n_1t,
                             "embed_gbps": round(by / t_1t / 1e9, 2)},

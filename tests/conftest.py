@@ -8,6 +8,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_sessionstart(session):
+    """The oracle side of the parity tests runs torch / BLAS on the host: a test box gives the process 16 cores of a 256-thread
+    host, and a thread per hardware thread spends its time switching (the AUC test: 320 s -> 140 s per dtype)."""
+    import os
+    import torch
+    n = len(os.sched_getaffinity(0))
+    try:                                   # the container's CPU quota (cgroup v2)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        n = min(n, 16)
+    torch.set_num_threads(max(1, n))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

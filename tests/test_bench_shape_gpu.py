@@ -183,6 +183,7 @@ def test_auc_parity_on_the_benchmarked_path(dev, oracle, dt):
     g = WideDeepEngine(cfg, dev)
     o = OracleMixedEngine(cfg, dt, fast=True)
     S, sinks = 5, 40
+    # (host BLAS threads: tests/conftest.py sizes them to the container's CPU quota -- 320 s -> 140 s per dtype on the test box)
     t0 = time.time()
 
     def batch(s):
@@ -218,7 +219,7 @@ def test_auc_parity_on_the_benchmarked_path(dev, oracle, dt):
         po.append(o.predict(ids.numpy(), wts.numpy())[1].ravel())
     y, pg, po = np.concatenate(y), np.concatenate(pg), np.concatenate(po)
     auc_g, auc_o = roc_auc_score(y, pg), roc_auc_score(y, po)
-    print(f"  held-out AUC after {step} steps: gpu {auc_g:.5f}, oracle {auc_o:.5f}")
+    print(f"  held-out AUC after {step} steps: gpu {auc_g:.5f}, oracle {auc_o:.5f}  ({time.time() - t0:.0f} s)")
     assert auc_g > 0.7 and auc_o > 0.7, (auc_g, auc_o)
     assert abs(auc_g - auc_o) < 2e-3, (auc_g, auc_o)
     # two free-running 16-bit trajectories 200 steps apart from their common start: the training losses (by now on batches seen
