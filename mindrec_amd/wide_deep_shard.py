@@ -92,8 +92,9 @@ class ShardStepMixin:
 
     def _exchange_selftest(self):
         """One small exchange through `_exchange` at start-up, checked element by element; all ranks agree on the outcome (a
-        communicator that cannot do it -- per-peer lists with an empty own entry -- sends every rank to the plain equal-split
-        all-to-all instead of failing in the first captured step)."""
+        communicator that refuses the call -- per-peer lists with an empty own entry -- or delivers the wrong chunks sends
+        every rank to the plain equal-split all-to-all instead of failing in the first captured step; a refusal is an argument
+        check of the library and comes on every rank alike, before anything is exchanged)."""
         n, me, cap = self.world, self.rank, 8
         ok = 1
         try:

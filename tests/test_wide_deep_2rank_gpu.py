@@ -26,7 +26,7 @@ def _cfg(B, fields=39, mlp_dtype=None):
                           mlp_dtype=mlp_dtype or MLP_DTYPE, shard_capacity_factor=CAP_FACTOR)
 
 
-def _worker(rank, world, port, steps, out_dir, mlp_dtype="fp32", cap_factor=1.25):
+def _worker(rank, world, port, steps, out_dir, mlp_dtype="fp32", cap_factor=1.25, broken_lists=False):
     global MLP_DTYPE, CAP_FACTOR
     MLP_DTYPE = mlp_dtype
     CAP_FACTOR = cap_factor
@@ -40,8 +40,14 @@ def _worker(rank, world, port, steps, out_dir, mlp_dtype="fp32", cap_factor=1.25
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     cfg = _cfg(128)
-    eng = WideDeepEngine(cfg, dev, rank=rank, world=world, comm=StagedGlooComm())
-    assert eng._bypass, "the own-chunk bypass of the exchange must have passed its start-up self-test"
+    comm = StagedGlooComm()
+    if broken_lists:                      # a communicator whose per-peer-list all-to-all refuses the call (as a library that does
+        class _Broken(StagedGlooComm):    # not take empty entries would: on every rank alike)
+            def all_to_all_lists(self, outs, ins):
+                raise RuntimeError("no per-peer lists here")
+        comm = _Broken()
+    eng = WideDeepEngine(cfg, dev, rank=rank, world=world, comm=comm)
+    assert eng._bypass == (not broken_lists), "own-chunk bypass: on after its start-up self-test, off when the communicator refuses it"
     losses = []
     for s in range(steps):
         ids, wts, label = synthetic_batch(cfg, dev, "zipf", seed=50 + s, rank=rank)
@@ -58,9 +64,10 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mlp_dtype,world,cap_factor", [("fp32", 2, 1.25), ("bf16", 2, 1.25), ("fp16", 2, 1.25), ("bf16", 4, 1.25), ("fp16", 4, 2.0),
-                                                         ("bf16", 5, 1.5)])
-def test_ranks_on_one_gpu_match_single_process(dev, tmp_path, mlp_dtype, world, cap_factor):
+@pytest.mark.parametrize("mlp_dtype,world,cap_factor,broken_lists", [("fp32", 2, 1.25, False), ("bf16", 2, 1.25, False), ("fp16", 2, 1.25, False),
+                                                                      ("bf16", 4, 1.25, False), ("fp16", 4, 2.0, False), ("bf16", 5, 1.5, False),
+                                                                      ("fp16", 3, 1.5, True)])
+def test_ranks_on_one_gpu_match_single_process(dev, tmp_path, mlp_dtype, world, cap_factor, broken_lists):
     """The fixed-capacity protocol (mindrec_amd/wide_deep_shard.py) with the real HIP kernels.  fp32: fp32 rows on the wire,
     torch MLP.  bf16 / fp16: the production path -- weights travel with the ids, 16-bit rows and 16-bit row-gradients on the
     wire, hand-written MLP step, one apply kernel for both tables reading the received gradient message in place.  (Criteo-like
@@ -69,7 +76,8 @@ def test_ranks_on_one_gpu_match_single_process(dev, tmp_path, mlp_dtype, world, 
     from mindrec_amd.wide_deep import WideDeepEngine, synthetic_batch
     MLP_DTYPE = mlp_dtype
     steps = 4          # the MLP graphs are captured on step 3 and replayed on step 4
-    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), mlp_dtype, cap_factor), nprocs=world, join=True)
+    # (broken_lists: the communicator refuses the per-peer-list all-to-all -- every rank falls back to the plain one)
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), mlp_dtype, cap_factor, broken_lists), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
     eng = WideDeepEngine(_cfg(128 * world), dev)
     losses = []
