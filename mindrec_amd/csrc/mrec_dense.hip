@@ -187,7 +187,7 @@ int weight_slabs_mr(int64_t M, int32_t K, int32_t N, int mr) {
 // prologue / epilogue (a 128-KB fp32 tile each) less often and leave half the slab bytes for the optimizer to read.  A layer whose
 // weight gradient is a full round of 256 x 256 tiles (layer 0 of the reference's net: 36 tiles) keeps ~0.85 of a round, so
 // that the input-gradient workgroups dispatched behind it pack into the CUs it leaves free.  Measured on the reference's net at
-// batch 16384 (tools/probes/slab_sweep.sh): slabs 7 / 16 / 32 / 64 -> 6 / 8 / 16 / 32 took the step from 0.695 to 0.652 ms.
+// batch 16384 (a sweep over per-layer counts): slabs 7 / 16 / 32 / 64 -> 6 / 8 / 16 / 32 took the step from 0.695 to 0.652 ms.
 int weight_slabs(int64_t M, int32_t K, int32_t N) {
     const int mr = bwd_mr(M, K, N);
     const int64_t tiles = mrec_cdiv(K, mr * 32) * mrec_cdiv(N, 256);
