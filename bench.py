@@ -61,7 +61,10 @@ def parse():
                     "default 1.05 for uniform ids (an owner's share of 425 984 uniform ids is within 0.6 %% of the mean at 12 sigma for 8 ranks), "
                     "1.25 otherwise (the engine's default); a run that drops a position is refused")
     ap.add_argument("--no-zipf39", action="store_true", help="skip the secondary Criteo-like measurement (Zipf ids, 39 fields) behind the timed region")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.capacity_factor is None:
+        args.capacity_factor = 1.05 if args.dist == "uniform" else 1.25
+    return args
 
 
 def median(xs):
@@ -218,8 +221,6 @@ def zipf39_line(args, eng, dev, peak):
     import torch
     from mindrec_amd import ops
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, embedding_bytes, synthetic_batch
-    if args.capacity_factor is None:
-        args.capacity_factor = 1.05 if args.dist == "uniform" else 1.25
     cfg = WideDeepConfig(vocab_size=args.vocab, emb_dim=args.emb_dim, field_size=39, batch_size=args.batch, mlp_dtype=args.mlp_dtype,
                          graphs=args.graphs, dropout_flag=args.dropout)
     e2 = WideDeepEngine(cfg, dev, tables_from=eng)
