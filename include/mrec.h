@@ -430,6 +430,12 @@ int mrec_head_fwd_bwd_f16(const uint16_t* h4, const float* w5, const float* b5, 
                           const float* label, int64_t B, int32_t K5, float dscale, float dh_scale, float* logit, float* dlogit,
                           uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss, void* ws,
                           size_t ws_bytes, void* stream);
+/* the same with fp32 activations (h4, dh4 float32 [B, K5]): the output end of the fp32 net -- DenseLayer without casts, as
+ * models/deepfm with convert_dtype False or wide_deep without use_mixed_precision; the hidden layers: mrec_dense32_* */
+int mrec_head_fwd_bwd_f32(const float* h4, const float* w5, const float* b5, const float* wide,
+                          const float* label, int64_t B, int32_t K5, float dscale, float dh_scale, float* logit, float* dlogit,
+                          float* dh4, float* dw5, float* db4, float* db5, float* loss, void* ws,
+                          size_t ws_bytes, void* stream);
 
 /* The same head (f16 != 0: IEEE half activations) with the wide branch given as the per-field products of
  * mrec_gather_rows_wide ([B, F, 2] floats: product, pad): wide[b] = (((0 + prod[b,0]) + prod[b,1]) + ...) + *wide_bias.

@@ -118,6 +118,7 @@ _SIGS = {
     "mrec_head_workspace_bytes": [_i64, _i32, _szp],
     "mrec_head_fwd_bwd_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_head_fwd_bwd_f16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_head_fwd_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_map_bytes": [_i64, _szp],
     "mrec_map_create": [C.POINTER(_vp), _vp, _sz, _i64, _vp],
     "mrec_map_destroy": [_vp],

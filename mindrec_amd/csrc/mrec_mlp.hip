@@ -20,7 +20,25 @@ namespace {
 // Output head.  K5 = width of the last hidden layer (multiple of 8, K5/8 a power of two <= 64).
 // partial layout per block: [K5] dW5 partials, [K5] column sums of dh4 (= bias gradient of the last
 // hidden layer), then db5 partial, then loss partial.
-template <bool F16>
+// the row's 8 values of this lane: 16 bytes of 16-bit values, or 32 bytes of fp32 (KIND 2: the fp32 net)
+template <int KIND> __device__ __forceinline__ void load8k(const uint4* __restrict__ h, int64_t idx, float (&f)[8]) {
+    if (KIND == 2) {
+        const float4 a = ((const float4*)h)[2 * idx], b = ((const float4*)h)[2 * idx + 1];
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    } else {
+        unpack8t<KIND == 1>(h[idx], f);
+    }
+}
+template <int KIND> __device__ __forceinline__ void store8k(uint4* __restrict__ h, int64_t idx, const float (&f)[8]) {
+    if (KIND == 2) {
+        ((float4*)h)[2 * idx] = make_float4(f[0], f[1], f[2], f[3]);
+        ((float4*)h)[2 * idx + 1] = make_float4(f[4], f[5], f[6], f[7]);
+    } else {
+        h[idx] = pack8t<KIND == 1>(f);
+    }
+}
+
+template <int KIND>      // 0: bfloat16, 1: IEEE half, 2: fp32 activations
 __global__ __launch_bounds__(MB) void k_head_fwd_bwd(const uint4* __restrict__ h4, const float* __restrict__ w5,
                                                      const float* __restrict__ b5, const float* __restrict__ wide,
                                                      const float* __restrict__ label, int64_t B, int CG,
@@ -45,7 +63,7 @@ __global__ __launch_bounds__(MB) void k_head_fwd_bwd(const uint4* __restrict__ h
         const int64_t r = r0 + rl;
         const bool valid = r < r_end;
         float fh[8];
-        if (valid) unpack8t<F16>(h4[r * CG + cg], fh);
+        if (valid) load8k<KIND>(h4, r * CG + cg, fh);
         else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) fh[k] = 0.0f;
@@ -96,7 +114,7 @@ __global__ __launch_bounds__(MB) void k_head_fwd_bwd(const uint4* __restrict__ h
                 accw[k] += fh[k] * dl;
                 accd[k] += o[k];
             }
-            dh4[r * CG + cg] = pack8t<F16>(o);
+            store8k<KIND>(dh4, r * CG + cg, o);
         }
     }
 #pragma unroll
@@ -172,9 +190,9 @@ MREC_API int mrec_head_workspace_bytes(int64_t B, int32_t K5, size_t* out) {
     return MREC_OK;
 }
 
-static int head_impl(bool f16, const uint16_t* h4, const float* w5, const float* b5, const float* wide,
+static int head_impl(int kind, const void* h4, const float* w5, const float* b5, const float* wide,
                      const float* label, int64_t B, int32_t K5, float dscale, float dh_scale, float* logit,
-                     float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
+                     float* dlogit, void* dh4, float* dw5, float* db4, float* db5, float* loss,
                      void* ws, size_t ws_bytes, void* stream, const float* wprod = nullptr, int F = 0,
                      const float* wide_bias = nullptr, float* dwide_b = nullptr) {
     if (B <= 0 || K5 <= 0 || !(dh_scale >= 1.0f)) return MREC_EINVAL;
@@ -188,12 +206,13 @@ static int head_impl(bool f16, const uint16_t* h4, const float* w5, const float*
     const int rows_per_block = (int)mrec_cdiv(mrec_cdiv(B, nblk), RP) * RP;
     const int nb = (int)mrec_cdiv(B, rows_per_block);
     hipStream_t st = (hipStream_t)stream;
-    if (f16)
-        k_head_fwd_bwd<true><<<nb, MB, 0, st>>>((const uint4*)h4, w5, b5, wide, label, B, CG, rows_per_block, dscale, logit, dlogit,
-                                                (uint4*)dh4, (float*)ws, wprod, F, wide_bias, dh_scale);
-    else
-        k_head_fwd_bwd<false><<<nb, MB, 0, st>>>((const uint4*)h4, w5, b5, wide, label, B, CG, rows_per_block, dscale, logit, dlogit,
-                                                 (uint4*)dh4, (float*)ws, wprod, F, wide_bias, dh_scale);
+#define MREC_HEAD_GO(KIND)                                                                                                 \
+    k_head_fwd_bwd<KIND><<<nb, MB, 0, st>>>((const uint4*)h4, w5, b5, wide, label, B, CG, rows_per_block, dscale, logit, dlogit, \
+                                            (uint4*)dh4, (float*)ws, wprod, F, wide_bias, dh_scale)
+    if (kind == 2) MREC_HEAD_GO(2);
+    else if (kind == 1) MREC_HEAD_GO(1);
+    else MREC_HEAD_GO(0);
+#undef MREC_HEAD_GO
     k_head_finish<<<(unsigned)mrec_cdiv(2 * K5 + 2, 32), MB, 0, st>>>((const float*)ws, nb, K5, 1.0f / (float)B, dw5, db4, db5, loss, dwide_b);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
@@ -203,14 +222,22 @@ MREC_API int mrec_head_fwd_bwd_bf16(const uint16_t* h4, const float* w5, const f
                                     const float* label, int64_t B, int32_t K5, float dscale, float dh_scale, float* logit,
                                     float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
                                     void* ws, size_t ws_bytes, void* stream) {
-    return head_impl(false, h4, w5, b5, wide, label, B, K5, dscale, dh_scale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes, stream);
+    return head_impl(0, h4, w5, b5, wide, label, B, K5, dscale, dh_scale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes, stream);
 }
 
 MREC_API int mrec_head_fwd_bwd_f16(const uint16_t* h4, const float* w5, const float* b5, const float* wide,
                                    const float* label, int64_t B, int32_t K5, float dscale, float dh_scale, float* logit,
                                    float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* loss,
                                    void* ws, size_t ws_bytes, void* stream) {
-    return head_impl(true, h4, w5, b5, wide, label, B, K5, dscale, dh_scale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes, stream);
+    return head_impl(1, h4, w5, b5, wide, label, B, K5, dscale, dh_scale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes, stream);
+}
+
+/* fp32 activations (the fp32 net: mlp_dtype = fp32 of the Wide&Deep / DeepFM engines): h4, dh4 float32 [B, K5] */
+MREC_API int mrec_head_fwd_bwd_f32(const float* h4, const float* w5, const float* b5, const float* wide,
+                                   const float* label, int64_t B, int32_t K5, float dscale, float dh_scale, float* logit,
+                                   float* dlogit, float* dh4, float* dw5, float* db4, float* db5, float* loss,
+                                   void* ws, size_t ws_bytes, void* stream) {
+    return head_impl(2, h4, w5, b5, wide, label, B, K5, dscale, dh_scale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes, stream);
 }
 
 /* The same head with the wide branch given as per-field products [B, F] + the wide bias (see include/mrec.h). */
@@ -218,7 +245,7 @@ MREC_API int mrec_head_fwd_bwd_wide(int32_t f16, const uint16_t* h4, const float
                                     int32_t F, const float* wide_bias, const float* label, int64_t B, int32_t K5, float dscale,
                                     float dh_scale, float* logit, float* dlogit, uint16_t* dh4, float* dw5, float* db4, float* db5, float* dwide_bias,
                                     float* loss, void* ws, size_t ws_bytes, void* stream) {
-    return head_impl(f16 != 0, h4, w5, b5, nullptr, label, B, K5, dscale, dh_scale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes,
+    return head_impl(f16 != 0 ? 1 : 0, h4, w5, b5, nullptr, label, B, K5, dscale, dh_scale, logit, dlogit, dh4, dw5, db4, db5, loss, ws, ws_bytes,
                      stream, wide_prod, F, wide_bias, dwide_bias);
 }
 

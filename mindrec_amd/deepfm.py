@@ -94,6 +94,13 @@ class _DeepFMNet(DenseNetMixin):
             lin_fm, cs = self.k.fm_forward(vx, add=linear)                     # linear + fm: the output head's per-sample addend
             loss, g16, dlogit = self._mlp_step(vx16.view(B, Fd * D), lin_fm, label)
             return loss, self.k.fm_backward_mix(g16.view(B, Fd, D), vx, cs, dlogit), dlogit
+        if self._f32net:
+            # the fp32 net by hand (ops.dense32_*, the fp32 output head); the FM term's bprop is added to the MLP's input gradient
+            lin_fm, cs = self.k.fm_forward(vx, add=linear)
+            loss, g, dlogit = self._mlp_step_f32(vx.view(B, Fd * D), lin_fm, label)
+            g = g.view(B, Fd, D)
+            self.k.fm_backward_(g, vx, cs, dlogit)
+            return loss, g, dlogit
         vx.requires_grad_(True)
         linear.requires_grad_(True)
         self.dense_grad_flat.zero_()

@@ -987,7 +987,7 @@ def head_supported(K5):
 
 def head_fwd_bwd(h4, w5, b5, wide, label, dscale, dw5_out, db4_out, db5_out, dh_scale=1.0):
     """Output layer + wide/deep add + sigmoid cross-entropy, forward and backward, one pass over h4.
-    Returns (loss [1], logit [B], dlogit [B], dh4 [B, K5] bf16)."""
+    Returns (loss [1], logit [B], dlogit [B], dh4 [B, K5] of h4's dtype: bfloat16, float16 or float32)."""
     _need_cuda(h4, w5, b5, wide, label)
     B, K5 = h4.shape
     dev = h4.device
@@ -997,9 +997,9 @@ def head_fwd_bwd(h4, w5, b5, wide, label, dscale, dw5_out, db4_out, db5_out, dh_
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     nb = _lib.query_bytes("mrec_head_workspace_bytes", B, K5)
     ws = workspace("head", nb, dev)
-    if h4.dtype not in _DT16:
-        raise TypeError("h4 must be bfloat16 or float16")
-    _lib.call("mrec_head_fwd_bwd_" + _DT16[h4.dtype], _ptr(h4.contiguous()), _ptr(w5), _ptr(b5), _ptr(wide.contiguous()),
+    if h4.dtype not in _DT16 and h4.dtype != torch.float32:
+        raise TypeError("h4 must be bfloat16, float16 or float32")
+    _lib.call("mrec_head_fwd_bwd_" + ("f32" if h4.dtype == torch.float32 else _DT16[h4.dtype]), _ptr(h4.contiguous()), _ptr(w5), _ptr(b5), _ptr(wide.contiguous()),
               _ptr(label.contiguous()), B, K5, float(dscale), float(dh_scale), _ptr(logit), _ptr(dlogit), _ptr(dh4), _ptr(dw5_out),
               _ptr(db4_out), _ptr(db5_out), _ptr(loss), _ptr(ws), ws.numel(), _stream())
     return loss, logit, dlogit, dh4

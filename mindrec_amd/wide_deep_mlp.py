@@ -83,6 +83,10 @@ class DenseNetMixin:
             self.dense16_flat, self.dense16 = flat16, interleave(v16[:nl - 1], v16[nl - 1:])
         # The last two hidden layers + the output head + their input-gradient bprops as ONE launch (ops.tail_fwd_bwd) where the
         # net ends ... -> 512 -> 256 -> 128 -> 1 (the reference's) and the batch is a multiple of 64; any other net: layer by layer.
+        # The fp32 net (mlp_dtype "fp32": DenseLayer without casts) by hand as well: hidden layers on the fp32 matrix instruction
+        # (ops.dense32_*), the output end as one pass (ops.head_fwd_bwd on fp32 activations); Dropout keeps the torch restatement.
+        self._f32net = bool(self._gpu and self.k is ops and not self._mfma and getattr(self, "_amp", None) is None and nl >= 2
+                            and self.k.head_supported(dims[nl - 1]))
         self._tail_packed, self._dense16_t = None, None
         self._tail_ok = bool(self._mfma and fused_tail and nl >= 4 and self.k.tail_supported(64, *self.dims[nl - 3:nl]))
         self._mlp_graph = None        # dict: captured MLP step + its static input / output tensors
@@ -150,6 +154,11 @@ class DenseNetMixin:
             for i in range(n - 1):
                 h = self.k.dense_fwd(h, self.dense16[2 * i], self.dense[2 * i + 1].detach(), relu=True)
             return torch.addmm(self.dense[2 * (n - 1) + 1].detach(), h.float(), self.dense[2 * (n - 1)].detach())
+        if self._f32net and not torch.is_grad_enabled():
+            h = x.contiguous()
+            for i in range(n - 1):
+                h = self.k.dense32_fwd(h, self.dense[2 * i].detach(), self.dense[2 * i + 1].detach(), relu=True)
+            return self.k.dense32_fwd(h, self.dense[2 * (n - 1)].detach(), self.dense[2 * (n - 1) + 1].detach(), relu=False)
         h = x.to(amp) if amp is not None else x
         for i in range(n):
             W, b = self.dense[2 * i], self.dense[2 * i + 1]
@@ -173,7 +182,8 @@ class DenseNetMixin:
         t = self._db.get(i)
         if t is None:
             # written by the backward launch of layer i + 1, whose reduction width is dims[i + 2]
-            rows = self.k.dense_bwd_bias_slabs(B, self.dims[i + 1], self.dims[i + 2])
+            rows = (self.k.dense32_colsum_tiles(B) if self._f32net else
+                    self.k.dense_bwd_bias_slabs(B, self.dims[i + 1], self.dims[i + 2]))
             t = torch.empty((rows, self.dims[i + 1]), dtype=torch.float32, device=self.device)
             self._db[i] = t
         return t
@@ -185,7 +195,7 @@ class DenseNetMixin:
         t = self._dw.get(i)
         if t is None:
             K, N = self.dims[i], self.dims[i + 1]
-            S = self.k.dense_bwd_weight_slabs(B, K, N)
+            S = self.k.dense32_bwd_weight_slabs(B, K, N) if self._f32net else self.k.dense_bwd_weight_slabs(B, K, N)
             t = torch.empty((S, K, N), dtype=torch.float32, device=self.device)
             self._dw[i] = t
         return t
@@ -272,6 +282,29 @@ class DenseNetMixin:
                                   db_slabs=self._db_slabs(i - 1, B) if i > 0 else None, drop_in=self._drop(i, B), extra=extra)
             extra = None
         return dh
+
+    @torch.no_grad()
+    def _mlp_step_f32(self, emb, wide, label):
+        """Forward + backward of the fp32 net by hand (self._f32net): DenseLayer = MatMul + BiasAdd + ReLU in fp32
+        (wide_and_deep.py:113-133 without use_mixed_precision; deepfm.py:98-150 with convert_dtype False) on ops.dense32_*, the
+        output layer + wide/deep add + sigmoid cross-entropy and their bprops in one pass (ops.head_fwd_bwd), every gradient of
+        the dense parameters summed into the flat gradient buffer.  Returns (loss, g_emb fp32 [B, F * D], g_wide [B])."""
+        k, n = self.k, len(self.dims) - 1
+        B = emb.shape[0]
+        hs = [emb]
+        for i in range(n - 1):
+            hs.append(k.dense32_fwd(hs[i], self.dense[2 * i].detach(), self.dense[2 * i + 1].detach(), relu=True))
+        loss, _, dlogit, dh = k.head_fwd_bwd(hs[-1], self.dense[2 * (n - 1)].detach().view(-1), self.dense[2 * (n - 1) + 1].detach(),
+                                             wide, label.view(-1), self._sens / B, self.dense_grad[2 * (n - 1)].view(-1),
+                                             self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1])
+        for i in range(n - 2, -1, -1):
+            k.dense32_bwd_weight(hs[i], dh, self._dw_slabs(i, B))
+            if i > 0:      # through the ReLU of layer i - 1; the column sums are that layer's bias gradient
+                dh = k.dense32_bwd_input(dh, self.dense[2 * i].detach(), h=hs[i], colsum=self._db_slabs(i - 1, B))
+            else:
+                dh = k.dense32_bwd_input(dh, self.dense[0].detach())
+        self._sum_dw_slabs()
+        return loss.view(()), dh, dlogit.view(-1)
 
     def _mlp_step_eager(self, emb, wide, label, after_head=None):
         """Forward + backward of the mixed-precision MLP written out by hand (no autograd graph).  `emb` arrives

@@ -539,6 +539,30 @@ def test_head_fwd_bwd(dev, oracle, B, K5):
     assert abs(float(db5) - r["db5"]) <= 1e-4 * max(abs(r["db5"]), 1e-3)
 
 
+@pytest.mark.parametrize("B,K5", [(16384, 128), (1000, 64), (77, 8)])
+def test_head_fwd_bwd_fp32(dev, oracle, B, K5):
+    """The fp32 instantiation (h4 in, dh4 out as float32: the mlp_dtype="fp32" net) against the same oracle, at fp32 tolerances."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(K5 + B + 1)
+    h4 = np.maximum(rng.standard_normal((B, K5)), 0).astype(np.float32)
+    w5 = (rng.standard_normal(K5) * 0.1).astype(np.float32); b5 = np.array([0.05], np.float32)
+    wide = rng.standard_normal(B).astype(np.float32) * 0.3
+    label = (rng.random(B) < 0.3).astype(np.float32)
+    dscale = 1.0 / B
+    dw5 = torch.empty(K5, device=dev); db4 = torch.empty(K5, device=dev); db5 = torch.empty(1, device=dev)
+    loss, logit, dlogit, dh4 = ops.head_fwd_bwd(T(h4, dev), T(w5, dev), T(b5, dev), T(wide, dev), T(label, dev), dscale, dw5, db4, db5)
+    assert dh4.dtype == torch.float32
+    r = oracle.head_fwd_bwd(h4, w5, b5[0], wide, label, dscale)
+    assert abs(float(loss) - r["loss"]) <= 1e-5 * abs(r["loss"])
+    assert np.allclose(logit.cpu().numpy(), r["logit"], rtol=1e-5, atol=1e-5)
+    assert np.allclose(dlogit.cpu().numpy(), r["dlogit"], rtol=1e-4, atol=1e-9)
+    assert np.allclose(dh4.cpu().numpy(), r["dh4"], rtol=1e-4, atol=1e-10)
+    assert np.array_equal(dh4.cpu().numpy() == 0, r["dh4"] == 0)
+    assert np.abs(dw5.cpu().numpy() - r["dw5"]).max() <= 1e-4 * np.abs(r["dw5"]).max()
+    assert np.abs(db4.cpu().numpy() - r["db4"]).max() <= 1e-4 * np.abs(r["db4"]).max()
+    assert abs(float(db5) - r["db5"]) <= 1e-4 * max(abs(r["db5"]), 1e-6)
+
+
 @pytest.mark.parametrize("B,F,D", [(300, 39, 80), (64, 26, 16), (5, 3, 200), (7, 5, 30), (1000, 39, 128)])
 def test_fm_term(dev, oracle, B, F, D):
     from mindrec_amd import ops
