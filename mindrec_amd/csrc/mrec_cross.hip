@@ -28,6 +28,23 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
+// The same sum on the DPP network (__shfl_xor compiles to ds_bpermute: an LDS round trip per step, six dependent ones per
+// sum): two quad permutes and the two row mirrors leave every lane of a 16-lane row with the row's sum, row_bcast15 /
+// row_bcast31 carry the sums down the rows, lane 63 ends with the total.  A different (but fixed) order of additions.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_take(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+    x += dpp_take<0xB1, 0xF>(x);      // quad_perm [1,0,3,2]
+    x += dpp_take<0x4E, 0xF>(x);      // quad_perm [2,3,0,1]
+    x += dpp_take<0x141, 0xF>(x);     // row_half_mirror
+    x += dpp_take<0x140, 0xF>(x);     // row_mirror
+    x += dpp_take<0x142, 0xA>(x);     // row_bcast15 into rows 1, 3
+    x += dpp_take<0x143, 0xC>(x);     // row_bcast31 into rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
 // One activation row as a buffer resource of D*4 bytes (0 bytes = a row that does not exist): the hardware
 // range check returns 0 for the padded columns c >= D and drops stores to them, so the row loops carry no
 // guards, and every access is base + lane*4 + an immediate (one address register, not one per load).
@@ -101,6 +118,19 @@ __device__ __forceinline__ f4 row_load4(__amdgpu_buffer_rsrc_t r, int voff, int 
 __device__ __forceinline__ void row_store4(__amdgpu_buffer_rsrc_t r, int voff, int soff, f4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff, soff, 0);
 }
+// the activation rows: touched once per launch
+#ifndef MREC_CROSS_AUX_LD
+#define MREC_CROSS_AUX_LD 0
+#endif
+#ifndef MREC_CROSS_AUX_ST
+#define MREC_CROSS_AUX_ST 2      // results: nontemporal (B = 32768: backward 94 -> 83 us, forward 64 -> 56; B = 16384: the same
+#endif                           // to 1 % better); nontemporal LOADS of the rows cost 2-5 us at B = 16384 (r03_cross_bwd_steps.txt)
+__device__ __forceinline__ f4 act_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, MREC_CROSS_AUX_LD));
+}
+__device__ __forceinline__ void act_store4(__amdgpu_buffer_rsrc_t r, int voff, int soff, f4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff, soff, MREC_CROSS_AUX_ST);
+}
 __device__ __forceinline__ f4 fma4(f4 a, f4 b, f4 c) {
     const f2 lo = __builtin_elementwise_fma(a.lo, b.lo, c.lo), hi = __builtin_elementwise_fma(a.hi, b.hi, c.hi);
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
@@ -108,6 +138,34 @@ __device__ __forceinline__ f4 fma4(f4 a, f4 b, f4 c) {
 __device__ __forceinline__ f4 bc4(float u) { return f4{u, u, u, u}; }
 __device__ __forceinline__ float hsum4(f4 v) { return (v.x + v.y) + (v.z + v.w); }
 
+
+// w (and b) of all layers into LDS in ONE memory round trip: the (array, layer, 256-column block) pieces are dealt out to the
+// waves, every wave requests its pieces as 16-byte buffer loads (the range check pads the rows with zeros) before it stores
+// the first.  (stage_wb above takes total / (4 NT) dependent rounds: two in the forward -- 4 of its 32 us.)
+template <int NT, int NPL, bool WITH_B>
+__device__ __forceinline__ void stage_rows4(const float* __restrict__ w, const float* __restrict__ b, int L, int D,
+                                            float* sw, float* sb) {
+    constexpr int DP = NPL * 64, NQ = NPL / 4, WPB = NT / 64;
+    constexpr int NSTG = ((WITH_B ? 2 : 1) * LMAX * NQ + WPB - 1) / WPB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = L * NQ, total = (WITH_B ? 2 : 1) * per;
+    f4 stg[NSTG];
+#pragma unroll
+    for (int i = 0; i < NSTG; ++i) {
+        const int pc = wave + i * WPB;
+        const bool ok = pc < total;
+        const int a = pc >= per ? 1 : 0, r = pc - a * per, l = r / NQ, q = r - l * NQ;
+        const float* src = (WITH_B && a) ? b : w;
+        stg[i] = row_load4(row_rsrc(src + (int64_t)(ok ? l : 0) * D, ok ? D * 4 : 0), lane * 16, 1024 * q);
+    }
+#pragma unroll
+    for (int i = 0; i < NSTG; ++i) {
+        const int pc = wave + i * WPB;
+        const int a = pc >= per ? 1 : 0, r = pc - a * per, l = r / NQ, q = r - l * NQ;
+        if (pc < total) *(f4*)(((WITH_B && a) ? sb : sw) + l * DP + 256 * q + 4 * lane) = stg[i];
+    }
+    __syncthreads();
+}
 
 // forward, 4 columns per lane (NPL a multiple of 4: every D > 128): 16-byte row accesses, ds_read_b128 for w and b, packed
 // fp32 arithmetic; the update keeps the oracle's operation order (x * s + b, then + x_l; no fused multiply-add)
@@ -181,12 +239,13 @@ __global__ __launch_bounds__(FWD_NT) void k_cross_fwd4(const float* __restrict__
     extern __shared__ float smem[];
     float* sw = smem;
     float* sb = smem + (WLDS ? L * DP : 0);
-    if (WLDS) stage_wb<FWD_NT, DP>(w, b, L, D, sw, sb);
+    if (WLDS) stage_rows4<FWD_NT, NPL, true>(w, b, L, D, sw, sb);
     const int lane = threadIdx.x & 63;
     const int voff = lane * 16;
     constexpr int WPB = FWD_NT / 64;
     const int64_t nw = (int64_t)gridDim.x * WPB;
-    // two rows per wave per iteration: one LDS read of w / b serves both
+    // two rows per wave per iteration: one LDS read of w / b serves both.  (Requesting a wave's next pair right behind the
+    // stores of the one before, the first pair in front of the staging: 31.1 us against 28.4 at B = 16384 -- not kept.)
     for (int64_t rowA = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); rowA < B; rowA += 2 * nw) {
         const int64_t rowB = rowA + nw;
         const bool vB = rowB < B;
@@ -195,8 +254,8 @@ __global__ __launch_bounds__(FWD_NT) void k_cross_fwd4(const float* __restrict__
         const __amdgpu_buffer_rsrc_t rB = row_rsrc(x0 + (vB ? rowB : rowA) * D, vB ? D * 4 : 0);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            xA[q] = row_load4(rA, voff, 1024 * q);
-            xB[q] = row_load4(rB, voff, 1024 * q);
+            xA[q] = act_load4(rA, voff, 1024 * q);
+            xB[q] = act_load4(rB, voff, 1024 * q);
             lA[q] = xA[q];
             lB[q] = xB[q];
         }
@@ -208,7 +267,7 @@ __global__ __launch_bounds__(FWD_NT) void k_cross_fwd4(const float* __restrict__
                 pA += lA[q] * wv;
                 pB += lB[q] * wv;
             }
-            const f4 sA = bc4(wave_sum(hsum4(pA))), sB = bc4(wave_sum(hsum4(pB)));
+            const f4 sA = bc4(wave_sum_dpp(hsum4(pA))), sB = bc4(wave_sum_dpp(hsum4(pB)));
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const f4 bv = wload4<WLDS>(b, sb, l, lane, q, D, DP);
@@ -220,8 +279,8 @@ __global__ __launch_bounds__(FWD_NT) void k_cross_fwd4(const float* __restrict__
         const __amdgpu_buffer_rsrc_t oB = row_rsrc(out + (vB ? rowB : rowA) * D, vB ? D * 4 : 0);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            row_store4(oA, voff, 1024 * q, lA[q]);
-            row_store4(oB, voff, 1024 * q, lB[q]);
+            act_store4(oA, voff, 1024 * q, lA[q]);
+            act_store4(oB, voff, 1024 * q, lB[q]);
         }
     }
 }
@@ -232,57 +291,91 @@ __host__ __device__ inline int64_t slab_floats(int D) { return (int64_t)(LMAX + 
 // two waves per SIMD where the [LT][NPL] accumulators + x, dy, colsum rows leave room under 256 registers
 constexpr int bwd_occ(int npl, int lt) { return (lt + 3) * npl <= 180 ? 2 : 1; }
 
+// LDS of the backward: w of all layers while the rows are walked; afterwards the same area holds up to four REGIONS of
+// (LT + 1) * DP + 64 floats through which the waves' batch sums are added up pairwise.
+constexpr int bwd_region_floats(int npl, int lt) { return (lt + 1) * npl * 64 + 64; }
+constexpr int bwd_regions(int npl, int lt) {
+    const int fit = (int)(160 * 1024 / (bwd_region_floats(npl, lt) * sizeof(float)));
+    return fit >= 4 ? 4 : (fit >= 2 ? 2 : 1);
+}
+
 // LT = compile-time bound on the layer count (2, 4, 6 or 8): the [LT][NPL] batch-sum accumulators live in
 // registers, so they must be sized statically.
 //
 // Per row the kernel needs only the L dots P_l = x0 . w_l (independent of each other, so their wave
 // reductions overlap): with x_l = a_l x0 + beta_l,  s_l = x_l . w_l = a_l P_l + c_l,  a_{l+1} = a_l + s_l.
-// x_l itself is never rebuilt, b is not read at all; fmaf is used freely -- this kernel is checked against
-// the oracle's double-precision backward to a tolerance, not bit for bit.
+// x_l itself is never rebuilt; fmaf is used freely -- this kernel is checked against the oracle's
+// double-precision backward to a tolerance, not bit for bit.
+//
+// What a launch costs besides the rows (measured with one block on an idle chip, profiles/r03_cross_bwd_steps.txt: 16 us of
+// the 53 us at B = 16384 were prologue and epilogue) is kept to one memory round trip in front and three LDS exchanges behind:
+//  * prologue: every wave requests its share of w's rows (on their way to LDS; the range check pads them with zeros) and,
+//    wave l = 1 .. L-1, the rows b_0 .. b_{l-1} and w_l for c_l = (b_0 + .. + b_{l-1}) . w_l, all before the first wait
+//    (before: four dependent staging rounds, then 15 pair dots b_l' . w_l four or five deep per wave, each a load + a
+//    six-step shuffle chain);
+//  * epilogue: the eight waves' sums are added pairwise through LDS -- (w0+w4), (w1+w5), .. then (.. + ..) -- three
+//    exchanges instead of eight turns on one LDS slab; wave 0 stores the block's slab straight from its registers.
 template <int NPL, int LT, bool WLDS>
 __global__ __launch_bounds__(BWD_NT) __attribute__((amdgpu_waves_per_eu(bwd_occ(NPL, LT), bwd_occ(NPL, LT)))) void k_cross_bwd(const float* __restrict__ x0, const float* __restrict__ w,
                                                       const float* __restrict__ b, int L, int64_t B, int D,
                                                       const float* __restrict__ dy, float* __restrict__ dx0,
-                                                      float* __restrict__ slabs, int* __restrict__ tile_counters, int ntiles) {
+                                                      float* __restrict__ slabs) {
     static_assert(NPL % 4 == 0 && WLDS, "the backward is instantiated for 256-column blocks with w staged in LDS");
     constexpr int DP = NPL * 64;
     constexpr int NQ = NPL / 4;             // 256-column blocks
     extern __shared__ float smem[];
-    __shared__ float s_pd[LMAX * LMAX];
+    __shared__ float s_cl[LMAX];
     float* sw = smem;
-    stage_wb<BWD_NT, DP, false>(w, nullptr, L, D, sw, nullptr);
     const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const int voff = lane * 16;
     constexpr int WPB = BWD_NT / 64;
-    const int64_t wid = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t wid = (int64_t)blockIdx.x * WPB + wave;
     const int64_t nw = (int64_t)gridDim.x * WPB;
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < ntiles; i += BWD_NT) tile_counters[i] = 0;      // for the reduction kernel behind this one
-    // pair dots b_l' . w_l (l' < l), the row-independent part of s_l = x_l . w_l: every block computes them itself (15 dots of
-    // D terms against 60 KB of rows per wave: nothing); fixed order
-    for (int pr = threadIdx.x >> 6; pr < L * L; pr += WPB) {
-        const int lp = pr / L, l = pr - lp * L;
-        float sdot = 0.0f;
-        if (lp < l) {
-            const __amdgpu_buffer_rsrc_t rb = row_rsrc(b + (int64_t)lp * D, D * 4);
+    {
+        constexpr int NSTG = (LT * NQ + WPB - 1) / WPB;       // (layer, 256-column block) pieces of w per wave
+        f4 stg[NSTG];
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i) {
+            const int pc = wave + i * WPB, l = pc / NQ, q = pc - l * NQ;
+            const bool ok = l < L;
+            stg[i] = row_load4(row_rsrc(w + (int64_t)(ok ? l : 0) * D, ok ? D * 4 : 0), voff, 1024 * q);
+        }
+        const bool dot = wave >= 1 && wave < L;                 // c_wave; wave-uniform
+        f4 wl[NQ], beta[NQ];
+        {
+            const __amdgpu_buffer_rsrc_t rw = row_rsrc(w + (int64_t)(dot ? wave : 0) * D, dot ? D * 4 : 0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                wl[q] = row_load4(rw, voff, 1024 * q);
+                beta[q] = bc4(0.0f);
+            }
+        }
+#pragma unroll
+        for (int lp = 0; lp < LT - 1; ++lp) {
+            const bool ok = dot && lp < wave;
+            const __amdgpu_buffer_rsrc_t rb = row_rsrc(b + (int64_t)(ok ? lp : 0) * D, ok ? D * 4 : 0);
             f4 bv[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) bv[q] = row_load4(rb, voff, 1024 * q);
-            f4 acc = bc4(0.0f);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) acc = fma4(bv[q], *(const f4*)(sw + l * DP + 256 * q + 4 * lane), acc);
-            sdot = wave_sum(hsum4(acc));
+            for (int q = 0; q < NQ; ++q) beta[q] += bv[q];      // rows past the wave's own come back as zeros
         }
-        if (lane == 0) s_pd[pr] = sdot;
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i) {
+            const int pc = wave + i * WPB, l = pc / NQ, q = pc - l * NQ;
+            if (l < L) *(f4*)(sw + l * DP + 256 * q + 4 * lane) = stg[i];
+        }
+        f4 acc = bc4(0.0f);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc = fma4(beta[q], wl[q], acc);
+        const float c = wave_sum_dpp(hsum4(acc));
+        if (lane == 0 && wave < LMAX) s_cl[wave] = dot ? c : 0.0f;
     }
     __syncthreads();
     float cl[LT];
 #pragma unroll
-    for (int l = 0; l < LT; ++l) {
-        float s = 0.0f;
-        for (int lp = 0; lp < l && l < L; ++lp) s += s_pd[lp * L + l];
-        cl[l] = s;
-    }
+    for (int l = 0; l < LT; ++l) cl[l] = s_cl[l];
     f4 accw[LT][NQ];
     f4 accd[NQ];
     float accT[LT];
@@ -295,16 +388,19 @@ __global__ __launch_bounds__(BWD_NT) __attribute__((amdgpu_waves_per_eu(bwd_occ(
 #pragma unroll
     for (int q = 0; q < NQ; ++q) accd[q] = bc4(0.0f);
 
-    // (Requesting the next row ahead of time -- into LDS with buffer_load ... lds, the registers being full -- was built and
-    // measured: no faster; the loop is bound by instruction issue at two waves per SIMD, not by the load latency.)
+    // (Requesting the next row ahead of time -- into a per-wave LDS area with buffer_load ... lds, the registers being full,
+    // waited for with a counted vmcnt so that the row's own stores stay in flight -- was built and measured twice, the second
+    // time on this 4-column layout: 57.2 us against 53.4 at B = 16384, 39.0 against 34.9 for one block on an idle chip.  A
+    // row's turn is a chain of dependent LDS and cross-lane steps, 2.4 us long even with nothing else on the chip, and the
+    // load is the smaller part of it.)
     for (int64_t row = wid; row < B; row += nw) {
         f4 x[NQ], g[NQ];
         const __amdgpu_buffer_rsrc_t rx = row_rsrc(x0 + row * D, D * 4);
         const __amdgpu_buffer_rsrc_t rg = row_rsrc(dy + row * D, D * 4);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            x[q] = row_load4(rx, voff, 1024 * q);
-            g[q] = row_load4(rg, voff, 1024 * q);
+            x[q] = act_load4(rx, voff, 1024 * q);
+            g[q] = act_load4(rg, voff, 1024 * q);
         }
         float P[LT];
         f4 qa = bc4(0.0f);
@@ -320,9 +416,9 @@ __global__ __launch_bounds__(BWD_NT) __attribute__((amdgpu_waves_per_eu(bwd_occ(
             P[l] = hsum4(pa);
             __builtin_amdgcn_sched_barrier(0);   // keep one layer's LDS reads in flight, not all of them (registers)
         }
-        const float qd = wave_sum(hsum4(qa));
+        const float qd = wave_sum_dpp(hsum4(qa));
 #pragma unroll
-        for (int l = 0; l < LT; ++l) P[l] = wave_sum(P[l]);      // P[l] == 0 for l >= L
+        for (int l = 0; l < LT; ++l) P[l] = wave_sum_dpp(P[l]);      // P[l] == 0 for l >= L
         float a[LT + 1], t[LT];
         a[0] = 1.0f;
 #pragma unroll
@@ -356,106 +452,128 @@ __global__ __launch_bounds__(BWD_NT) __attribute__((amdgpu_waves_per_eu(bwd_occ(
         }
         const __amdgpu_buffer_rsrc_t ro = row_rsrc(dx0 + row * D, D * 4);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) row_store4(ro, voff, 1024 * q, g[q]);
+        for (int q = 0; q < NQ; ++q) act_store4(ro, voff, 1024 * q, g[q]);
     }
-    // Block slab: the waves add their sums in wave order into LDS (the w staging area is dead by now;
-    // rows padded to DP, so no guards), one slab per block goes to HBM, same fixed order every run.
+    // Block slab: pairwise through LDS (the w staging area is dead by now; rows padded to DP, so no guards), the same
+    // order every run; wave 0 ends with the block's sums and stores them (the range check drops the padding).
     __syncthreads();
-    float* bs = smem;
-    const int wv_id = threadIdx.x >> 6;
-    for (int turn = 0; turn < WPB; ++turn) {
-        if (wv_id == turn) {
+    constexpr int NR = bwd_regions(NPL, LT);
+    constexpr int RF = bwd_region_floats(NPL, LT);
 #pragma unroll
-            for (int l = 0; l < LT; ++l) {
-                if (l < L) {
+    for (int h = WPB / 2; h >= 1; h >>= 1) {
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        f4* dst = (f4*)(bs + l * DP + 256 * q + 4 * lane);
-                        *dst = (turn ? *dst : bc4(0.0f)) + accw[l][q];
-                    }
-                    if (lane == 0) bs[(L + 1) * DP + l] = (turn ? bs[(L + 1) * DP + l] : 0.0f) + accT[l];
+        for (int c0 = 0; c0 < h; c0 += NR) {
+            if (wave >= h + c0 && wave < h + c0 + NR && wave < 2 * h) {
+                float* rg = smem + (wave - h - c0) * RF;
+#pragma unroll
+                for (int l = 0; l < LT; ++l)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) *(f4*)(rg + l * DP + 256 * q + 4 * lane) = accw[l][q];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) *(f4*)(rg + LT * DP + 256 * q + 4 * lane) = accd[q];
+                if (lane == 0) {
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) rg[(LT + 1) * DP + l] = accT[l];
                 }
             }
+            __syncthreads();
+            if (wave >= c0 && wave < c0 + NR && wave < h) {
+                const float* rg = smem + (wave - c0) * RF;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                f4* dst = (f4*)(bs + L * DP + 256 * q + 4 * lane);
-                *dst = (turn ? *dst : bc4(0.0f)) + accd[q];
+                for (int l = 0; l < LT; ++l)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) accw[l][q] += *(const f4*)(rg + l * DP + 256 * q + 4 * lane);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) accd[q] += *(const f4*)(rg + LT * DP + 256 * q + 4 * lane);
+#pragma unroll
+                for (int l = 0; l < LT; ++l) accT[l] += rg[(LT + 1) * DP + l];
             }
+            if (h > 1 || c0 + NR < h) __syncthreads();
         }
-        __syncthreads();
     }
+    if (wave != 0) return;
     float* sl = slabs + (int64_t)blockIdx.x * slab_floats(D);
-    for (int l = 0; l < L; ++l)
-        for (int i = threadIdx.x; i < D; i += BWD_NT) sl[(int64_t)l * D + i] = bs[l * DP + i];
-    for (int i = threadIdx.x; i < D; i += BWD_NT) sl[(int64_t)LMAX * D + i] = bs[L * DP + i];
-    if ((int)threadIdx.x < L) sl[(int64_t)(LMAX + 1) * D + threadIdx.x] = bs[(L + 1) * DP + threadIdx.x];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+        if (l < L) {
+            const __amdgpu_buffer_rsrc_t ro = row_rsrc(sl + (int64_t)l * D, D * 4);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) row_store4(ro, voff, 1024 * q, accw[l][q]);
+        }
+    }
+    {
+        const __amdgpu_buffer_rsrc_t ro = row_rsrc(sl + (int64_t)LMAX * D, D * 4);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) row_store4(ro, voff, 1024 * q, accd[q]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int l = 0; l < LT; ++l)
+            if (l < L) sl[(int64_t)(LMAX + 1) * D + l] = accT[l];
+    }
 }
 
-// Slab reduction and the composition of dw / db in ONE launch.  blockIdx.y = quantity q (q < L: sum u_l x0 of layer q;
-// q == L: colsum(dy); q == L + 1: the L scalars sum t_l, computed by that block of EVERY column tile -- same slabs, same
-// order, same bits).  A block owns 32 columns; its 32 thread groups each add a strided subset of the slabs, then the 32
-// partial sums are added in group order: a fixed order, independent of timing.  The block that finishes a column tile LAST
-// (a counter per tile, zeroed by k_cross_bwd) composes dw and db of its 32 columns from the reduced sums.
+// Slab reduction and the composition of dw / db in ONE launch with no exchange between its blocks.  blockIdx.y = quantity q
+// (q < L: sum u_l x0 of layer q -> dw_q; q == L: colsum(dy) -> db of every layer).  A block owns 32 columns; its 32 thread
+// groups each add a strided subset of the slabs, then the 32 partial sums are added in group order: a fixed order,
+// independent of timing.  The L scalars T_l = sum over rows of t_l that the compositions need are added up by EVERY block from
+// the same slabs in the same order (same bits; 6 KB out of L2) -- the version before this one reduced them in blocks of their
+// own and had the block finishing a column tile last compose from a scratch slab: a release fence, a counter and a dozen
+// agent-scope loads per tile, 12.7 us for the launch even with a single slab to add; this one: see profiles/r03_cross_bwd_steps.txt.
 __global__ __launch_bounds__(1024) void k_cross_bwd_finish(const float* __restrict__ slabs, int nslabs, int L, int D,
-                                                           float* __restrict__ R, const float* __restrict__ w,
-                                                           const float* __restrict__ b, float* __restrict__ dw,
-                                                           float* __restrict__ db, int* __restrict__ tile_counters) {
+                                                           const float* __restrict__ w, const float* __restrict__ b,
+                                                           float* __restrict__ dw, float* __restrict__ db) {
     __shared__ float part[32][33];
-    __shared__ int s_last;
+    __shared__ float partT[32][LMAX];
+    __shared__ float sT[LMAX];
     const int q = blockIdx.y;
     const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int64_t sf = slab_floats(D);
     const int c = blockIdx.x * 32 + cl;
-    int64_t off;
-    bool live;
-    if (q <= L) {
-        live = c < D;
-        off = (int64_t)(q < L ? q : LMAX) * D + c;
-    } else {
-        live = cl < L;
-        off = (int64_t)(LMAX + 1) * D + cl;
-    }
-    float s = 0.0f;
-    if (live) {
-#pragma unroll 4
-        for (int k = grp; k < nslabs; k += 32) s += slabs[k * sf + off];
-    }
-    part[grp][cl] = s;
-    __syncthreads();
-    if (grp == 0 && live) {
-        float t = part[0][cl];
-#pragma unroll
-        for (int g2 = 1; g2 < 32; ++g2) t += part[g2][cl];
-        R[off] = t;
-        __threadfence();          // (only the 32 writers: a release fence per thread of the block cost 70 us)
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&tile_counters[blockIdx.x], 1) == L + 1);
-    __syncthreads();
-    if (!s_last || threadIdx.x >= 32 || c >= D) return;
-    __threadfence();
-    // compose (what the other blocks of this tile wrote is read past the caches)
-    auto rd = [&](int64_t i) { return __hip_atomic_load(&R[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    float T[LMAX];
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l) T[l] = l < L ? rd((int64_t)(LMAX + 1) * D + l) : 0.0f;
-    const float cs = rd((int64_t)LMAX * D + c);
-    float beta = 0.0f;  // beta_l[c]
-    float tail = 0.0f;  // sum_{l' > l} w_l'[c] * T_l'
-    float dbv[LMAX];
-#pragma unroll
-    for (int l = LMAX - 1; l >= 0; --l) {
-        if (l < L) {
-            dbv[l] = cs + tail;
-            tail += w[l * D + c] * T[l];
-        }
-    }
+    const bool live = c < D;
+    const int64_t off = (int64_t)(q < L ? q : LMAX) * D + (live ? c : 0);
+    const int64_t offT = (int64_t)(LMAX + 1) * D + (cl < L ? cl : 0);
+    // what the composition reads of b / w is requested now, with the slabs, not after them
+    float bw[LMAX];
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
-        if (l < L) {
-            dw[l * D + c] = rd((int64_t)l * D + c) + beta * T[l];
-            db[l * D + c] = dbv[l];
-            beta += b[l * D + c];
+        const bool need = grp == 0 && live && (q < L ? l < q : l < L);
+        bw[l] = need ? (q < L ? b : w)[l * D + c] : 0.0f;
+    }
+    float s = 0.0f, st = 0.0f;
+    const bool tcol = cl < L;
+#pragma unroll 8
+    for (int k = grp; k < nslabs; k += 32) {
+        s += slabs[k * sf + off];
+        if (tcol) st += slabs[k * sf + offT];
+    }
+    part[grp][cl] = s;
+    if (cl < LMAX) partT[grp][cl] = st;
+    __syncthreads();
+    if ((int)threadIdx.x < L) {
+        float t = partT[0][threadIdx.x];
+#pragma unroll
+        for (int g2 = 1; g2 < 32; ++g2) t += partT[g2][threadIdx.x];
+        sT[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (grp != 0 || !live) return;
+    float t = part[0][cl];
+#pragma unroll
+    for (int g2 = 1; g2 < 32; ++g2) t += part[g2][cl];
+    if (q < L) {
+        float beta = 0.0f;                                  // beta_q[c] = b_0[c] + .. + b_{q-1}[c]
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) beta += bw[l];      // (zeros from l = q on)
+        dw[q * D + c] = t + beta * sT[q];
+    } else {
+        float tail = 0.0f;                                  // sum_{l' > l} w_l'[c] * T_l'
+#pragma unroll
+        for (int l = LMAX - 1; l >= 0; --l) {
+            if (l < L) {
+                db[l * D + c] = t + tail;
+                tail += bw[l] * sT[l];
+            }
         }
     }
 }
@@ -528,25 +646,26 @@ int launch_fwd(const float* x0, const float* w, const float* b, int L, int64_t B
 
 template <int NPL, int LT>
 int launch_bwd_lt(const float* x0, const float* w, const float* b, int L, int64_t B, int D, const float* dy, float* dx0,
-                  float* slabs, unsigned blocks, int* counters, int ntiles, hipStream_t st) {
+                  float* slabs, unsigned blocks, hipStream_t st) {
     constexpr int DP = NPL * 64;
-    // w of all layers (<= 8 x 2048 floats = 64 KB) always fits in LDS; the block slab reuses the same area
-    const size_t slab = ((size_t)(L + 1) * DP + L) * sizeof(float);   // <= 74 KB (D <= 2048, L <= 8)
+    // w of all layers (<= 8 x 2048 floats = 64 KB) always fits in LDS; the exchange regions of the epilogue reuse the area
+    const size_t xlds = (size_t)bwd_regions(NPL, LT) * bwd_region_floats(NPL, LT) * sizeof(float);
     const size_t wlds = (size_t)L * DP * sizeof(float);
-    const size_t lds = wlds > slab ? wlds : slab;
+    const size_t lds = wlds > xlds ? wlds : xlds;
+    static_assert((size_t)bwd_regions(NPL, LT) * bwd_region_floats(NPL, LT) * sizeof(float) <= 160 * 1024, "LDS");
     int rc = set_lds(k_cross_bwd<NPL, LT, true>, lds);
     if (rc != MREC_OK) return rc;
-    k_cross_bwd<NPL, LT, true><<<blocks, BWD_NT, lds, st>>>(x0, w, b, L, B, D, dy, dx0, slabs, counters, ntiles);
+    k_cross_bwd<NPL, LT, true><<<blocks, BWD_NT, lds, st>>>(x0, w, b, L, B, D, dy, dx0, slabs);
     return MREC_OK;
 }
 
 template <int NPL>
 int launch_bwd(const float* x0, const float* w, const float* b, int L, int64_t B, int D, const float* dy, float* dx0,
-               float* slabs, unsigned blocks, int* counters, int ntiles, hipStream_t st) {
-    if (L <= 2) return launch_bwd_lt<NPL, 2>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st);
-    if (L <= 4) return launch_bwd_lt<NPL, 4>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st);
-    if (L <= 6) return launch_bwd_lt<NPL, 6>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st);
-    return launch_bwd_lt<NPL, 8>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st);
+               float* slabs, unsigned blocks, hipStream_t st) {
+    if (L <= 2) return launch_bwd_lt<NPL, 2>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st);
+    if (L <= 4) return launch_bwd_lt<NPL, 4>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st);
+    if (L <= 6) return launch_bwd_lt<NPL, 6>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st);
+    return launch_bwd_lt<NPL, 8>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st);
 }
 }  // namespace
 
@@ -567,8 +686,7 @@ MREC_API int mrec_cross_layers_f32(const float* x0, const float* w, const float*
 
 MREC_API int mrec_cross_layers_bwd_workspace_bytes(int32_t L, int64_t B, int32_t D, size_t* out) {
     if (!out || B < 0 || D <= 0 || L < 0) return MREC_EINVAL;
-    // block slabs + the reduced slab + a completion counter per 32-column tile
-    *out = ((size_t)bwd_blocks(B) + 1) * slab_floats(D) * sizeof(float) + (size_t)mrec_cdiv(D, 32) * sizeof(int) + 256;
+    *out = (size_t)bwd_blocks(B) * slab_floats(D) * sizeof(float) + 256;      // one slab of batch sums per block
     return MREC_OK;
 }
 
@@ -583,24 +701,22 @@ MREC_API int mrec_cross_layers_bwd_f32(const float* x0, const float* w, const fl
     const unsigned blocks = bwd_blocks(B);
     const int nslabs = (int)blocks;
     const int ntiles = (int)mrec_cdiv(D, 32);
-    if (ws_bytes < ((size_t)nslabs + 1) * slab_floats(D) * sizeof(float) + (size_t)ntiles * sizeof(int)) return MREC_EWORKSPACE;
+    if (ws_bytes < (size_t)nslabs * slab_floats(D) * sizeof(float)) return MREC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* slabs = (float*)ws;
-    float* R = slabs + (int64_t)nslabs * slab_floats(D);
-    int* counters = (int*)(R + slab_floats(D));
     int rc = MREC_OK;
     // the backward's register-heavy instantiations use coarser column buckets (compile time)
     const int nb = npl <= 4 ? 4 : (npl <= 8 ? 8 : (npl <= 16 ? 16 : (npl <= 20 ? 20 : 32)));
     switch (nb) {
-        case 4: rc = launch_bwd<4>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st); break;
-        case 8: rc = launch_bwd<8>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st); break;
-        case 16: rc = launch_bwd<16>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st); break;
-        case 20: rc = launch_bwd<20>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st); break;
-        default: rc = launch_bwd<32>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, counters, ntiles, st); break;
+        case 4: rc = launch_bwd<4>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st); break;
+        case 8: rc = launch_bwd<8>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st); break;
+        case 16: rc = launch_bwd<16>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st); break;
+        case 20: rc = launch_bwd<20>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st); break;
+        default: rc = launch_bwd<32>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st); break;
     }
     if (rc != MREC_OK) return rc;
     if (L > 0)
-        k_cross_bwd_finish<<<dim3((unsigned)ntiles, (unsigned)(L + 2)), 1024, 0, st>>>(slabs, nslabs, L, D, R, w, b, dw, db, counters);
+        k_cross_bwd_finish<<<dim3((unsigned)ntiles, (unsigned)(L + 1)), 1024, 0, st>>>(slabs, nslabs, L, D, w, b, dw, db);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }

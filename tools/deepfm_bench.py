@@ -28,5 +28,5 @@ for dt in (sys.argv[1:] or ("fp16", "bf16", "fp32")):     # fp16: the reference'
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 20
-    print(f"DeepFM step (MLP {dt}, {'hand-written MFMA net' if eng._mfma else 'torch / library GEMMs'}): {ms:.3f} ms = {B / ms * 1e3 / 1e6:.2f} M samples/s   loss {float(loss):.5f}")
+    print(f"DeepFM step (MLP {dt}, {'hand-written MFMA net' if eng._mfma else ('hand-written exact-fp32 MFMA net' if getattr(eng, '_f32net', False) else 'torch / library GEMMs')}): {ms:.3f} ms = {B / ms * 1e3 / 1e6:.2f} M samples/s   loss {float(loss):.5f}")
     del eng

@@ -51,4 +51,6 @@ timeout -k 10 200 ./tools/probes/dense_gemm_test > $O/dense_gemm_probe.txt 2>&1 
 timeout -k 10 200 python tools/probes/tail_probe.py 2>/dev/null > $O/tail_probe.txt || true
 timeout -k 10 300 python tools/cache_bench.py > $O/cache_bench.txt 2>/dev/null || true
 tail -5 $O/cache_bench.txt
+python bench.py --no-cpu-baseline --no-zipf39 --mlp-dtype fp32 2>/dev/null | tail -1 > $O/bench_line_fp32net.json      # the fp32-net option (exact-fp32 MFMA DenseLayers)
+bash tools/probes/run_cross_trace.sh gpurun_out/final/cross_trace
 fi
