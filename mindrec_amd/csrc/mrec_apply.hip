@@ -49,6 +49,10 @@ namespace {
 #ifndef MREC_WPS4
 #define MREC_WPS4 4         // waves per SIMD asked of the register allocator for the float4 + wide-lane kernel (128 VGPRs: the
 #endif                      // window's index words live in registers; 5 waves measured 5 % slower, 3 the same)
+#ifndef MREC_APPLY_MAXB
+#define MREC_APPLY_MAXB 4096u        // workgroups of k_apply_main (4 waves each; 1024 are resident at 4 waves per SIMD).  Sweep in profiles/r03_apply_chain.txt:
+                                     // duplicate-heavy ids want a cap (Zipf x 39 fields: 121 us uncapped, 94-95 at 1024-4096), uniform ids none (172 / 176 us at 4096 / 2048)
+#endif
 #ifndef MREC_GP1
 #define MREC_GP1 4
 #endif
@@ -142,6 +146,46 @@ template <bool NT> __device__ __forceinline__ void vload(Vf<2>& r, const f16_t* 
 template <bool NT> __device__ __forceinline__ void vload(Vf<1>& r, const f16_t* p) {
     r.v = (float)__builtin_bit_cast(_Float16, p->v);
 }
+// The bytes of VEC gradient values as loaded, widened where they are USED: a load whose value is converted inside the
+// conditional block that issues it is waited for there (s_waitcnt vmcnt(0) in every such block -- the two gradient rows and the
+// state rows of a batch were three dependent round trips, not one).
+template <int VEC, class GT> struct GBits { Vf<VEC> f; };
+template <> struct GBits<4, bf16_t> { unsigned x, y; };
+template <> struct GBits<2, bf16_t> { unsigned x; };
+template <> struct GBits<1, bf16_t> { unsigned x; };
+template <> struct GBits<4, f16_t> { unsigned x, y; };
+template <> struct GBits<2, f16_t> { unsigned x; };
+template <> struct GBits<1, f16_t> { unsigned x; };
+template <bool NT, int VEC> __device__ __forceinline__ void gload(GBits<VEC, float>& b, const float* p) { vload<NT>(b.f, p); }
+#define MREC_GLOAD16(G16)                                                                                              \
+    template <bool NT> __device__ __forceinline__ void gload(GBits<4, G16>& b, const G16* p) {                          \
+        typedef unsigned int mrec_u2 __attribute__((ext_vector_type(2)));                                               \
+        const mrec_u2 t = NT ? __builtin_nontemporal_load((const mrec_u2*)p) : *(const mrec_u2*)p;                      \
+        b.x = t.x; b.y = t.y;                                                                                           \
+    }                                                                                                                   \
+    template <bool NT> __device__ __forceinline__ void gload(GBits<2, G16>& b, const G16* p) {                          \
+        b.x = NT ? __builtin_nontemporal_load((const unsigned int*)p) : *(const unsigned int*)p;                        \
+    }                                                                                                                   \
+    template <bool NT> __device__ __forceinline__ void gload(GBits<1, G16>& b, const G16* p) { b.x = p->v; }
+MREC_GLOAD16(bf16_t)
+MREC_GLOAD16(f16_t)
+#undef MREC_GLOAD16
+template <int VEC> __device__ __forceinline__ void gwiden(Vf<VEC>& r, const GBits<VEC, float>& b) { r = b.f; }
+__device__ __forceinline__ void gwiden(Vf<4>& r, const GBits<4, bf16_t>& b) {
+    r.v = make_float4(__uint_as_float(b.x << 16), __uint_as_float(b.x & 0xFFFF0000u), __uint_as_float(b.y << 16),
+                      __uint_as_float(b.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ void gwiden(Vf<2>& r, const GBits<2, bf16_t>& b) {
+    r.v = make_float2(__uint_as_float(b.x << 16), __uint_as_float(b.x & 0xFFFF0000u));
+}
+__device__ __forceinline__ void gwiden(Vf<1>& r, const GBits<1, bf16_t>& b) { r.v = __uint_as_float(b.x << 16); }
+__device__ __forceinline__ void gwiden(Vf<4>& r, const GBits<4, f16_t>& b) {
+    const float2 lo = mrec_h2f2(b.x), hi = mrec_h2f2(b.y);
+    r.v = make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+__device__ __forceinline__ void gwiden(Vf<2>& r, const GBits<2, f16_t>& b) { r.v = mrec_h2f2(b.x); }
+__device__ __forceinline__ void gwiden(Vf<1>& r, const GBits<1, f16_t>& b) { r.v = (float)__builtin_bit_cast(_Float16, (uint16_t)b.x); }
+
 // Gradient load of the float4 path with a wide lane in the group: ONE load instruction for all lanes (the wide lane's
 // address points into gw); the wide lane keeps the first dword as the fp32 it is, the others widen their 16-bit values.
 template <bool NT> __device__ __forceinline__ void vload_w(Vf<4>& r, const float* p, bool) { vload<NT>(r, p); }
@@ -189,6 +233,22 @@ __device__ __forceinline__ void vadd(Vf<4>& a, const Vf<4>& b) {
 }
 __device__ __forceinline__ void vadd(Vf<2>& a, const Vf<2>& b) { a.v.x = a.v.x + b.v.x; a.v.y = a.v.y + b.v.y; }
 __device__ __forceinline__ void vadd(Vf<1>& a, const Vf<1>& b) { a.v = a.v + b.v; }
+
+// "This value is needed HERE": an empty asm with the registers as in-out operands.  The compiler places its s_waitcnt for a
+// load at the first use of the value; with the first use inside a conditional block, the wait at the next join also covers
+// every store issued on the way (vmcnt counts loads and stores in order) -- a store round trip in the middle of a batch.
+__device__ __forceinline__ void vtouch(Vf<4>& r) { asm volatile("" : "+v"(r.v.x), "+v"(r.v.y), "+v"(r.v.z), "+v"(r.v.w)); }
+__device__ __forceinline__ void vtouch(Vf<2>& r) { asm volatile("" : "+v"(r.v.x), "+v"(r.v.y)); }
+__device__ __forceinline__ void vtouch(Vf<1>& r) { asm volatile("" : "+v"(r.v)); }
+
+template <int VEC> __device__ __forceinline__ void gtouch(GBits<VEC, float>& b) { vtouch(b.f); }
+#define MREC_GTOUCH16(G16)                                                                                         \
+    __device__ __forceinline__ void gtouch(GBits<4, G16>& b) { asm volatile("" : "+v"(b.x), "+v"(b.y)); }         \
+    __device__ __forceinline__ void gtouch(GBits<2, G16>& b) { asm volatile("" : "+v"(b.x)); }                     \
+    __device__ __forceinline__ void gtouch(GBits<1, G16>& b) { asm volatile("" : "+v"(b.x)); }
+MREC_GTOUCH16(bf16_t)
+MREC_GTOUCH16(f16_t)
+#undef MREC_GTOUCH16
 
 // ---- updaters: NS state arrays, each [V, ld]; apply() sees one lane's VEC elements -------------
 struct UpdAdam {
@@ -287,32 +347,50 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     if (grp >= gm.G) return;  // spare lanes; this kernel has no barriers
     // (Handing the windows out in a strided order instead -- so that the waves in flight sample the list's duplicate-heavy
     // head and its unique tail at once -- was measured: Zipf x 39 fields 0.133 -> 0.188 ms; neighbouring windows share lines.)
-    const int64_t sw = ((int64_t)blockIdx.x * 4 + wave) * gm.G + grp;
-    const int64_t s64 = sw * AW;
-    if (s64 >= n) return;
-    const int s = (int)s64;
-    const int e_end = (s + AW < n) ? s + AW : n;
     const bool wl = WIDE && sub == gm.lpr - 1;          // this lane owns the wide record
     const int ccol = sub * VEC;                         // column in the carry rows
     const int col = wl ? wa.wcol : ccol;                // column in the table rows
+    // A wave walks several windows (the grid is capped at MREC_APPLY_MAXB workgroups, the waves in flight at any moment cover a
+    // contiguous stretch of the list): a new wave pays a chain of scalar round trips -- kernel arguments in pieces, the step
+    // state, the device-side length -- before its first index word, as long as the window's own chain.
+    const int64_t sw_stride = (int64_t)gridDim.x * 4 * gm.G;
+    for (int64_t sw = ((int64_t)blockIdx.x * 4 + wave) * gm.G + grp; sw * AW < n; sw += sw_stride) {
+    const int s = (int)(sw * AW);
+    const int e_end = (s + AW < n) ? s + AW : n;
 
     // The window's index entries all at once (one round trip for the 2 x AW + 1 words, a second one for the rows of its run
     // ends) instead of batch by batch: a window's time is the length of its chain of dependent loads -- index -> row number
     // -> row -- which this takes from three round trips per batch to one (uniform ids 0.186 -> 0.179 ms, Zipf x 39 fields
     // 0.141 -> 0.133; deeper gradient prefetch on top of it changed nothing: what remains is the AB-deep chain of row
     // read-modify-writes).
+    // Every load below is REQUESTED unconditionally -- a position past the window's end reads entry n - 1 / position 0 / group 0,
+    // valid addresses whose values are dropped by selects -- and converted only where it is used.  Guarded loads compile to one
+    // basic block each, and a value that is converted (sign-extended, widened) inside its block is waited for inside it: the
+    // eight row numbers of a window were eight dependent round trips, the two gradient rows and the state rows of a batch
+    // three.  One wave's chain on an idle chip: 14.6 us before, see profiles/r03_apply_chain.txt.
     int posw[AW], segw[AW + 1];
+    const int nlast = n - 1;
 #pragma unroll
     for (int q = 0; q < AW; ++q) {
-        const int e = s + q;
-        posw[q] = e < e_end ? spos[e] : 0;
-        segw[q] = e < e_end ? sseg[e] : -2;
+        const int e = s + q < nlast ? s + q : nlast;
+        posw[q] = spos[e];
+        segw[q] = sseg[e];
     }
-    segw[AW] = (s + AW < n) ? sseg[s + AW] : -2;
+    segw[AW] = sseg[s + AW < nlast ? s + AW : nlast];
+    const int seg_before = sseg[s > 0 ? s - 1 : 0];
+#pragma unroll
+    for (int q = 0; q < AW; ++q) {
+        const bool valid = s + q < e_end;
+        posw[q] = valid ? posw[q] : 0;
+        segw[q] = valid ? segw[q] : -2;
+    }
+    if (!(s + AW < n)) segw[AW] = -2;
     const int first_seg = segw[0];
-    const bool head_open = (s > 0) && (sseg[s - 1] == first_seg);
+    const bool head_open = (s > 0) && (seg_before == first_seg);
     unsigned endm = 0u, openm = 0u;                       // bit q: entry q ends its run / belongs to the run open at the head
     int64_t rowv[AW];                                     // table row of the run that ends at entry q (-1: none / out of range)
+#pragma unroll
+    for (int q = 0; q < AW; ++q) rowv[q] = seg_row<K>(uniq, segw[q] < 0 ? 0 : segw[q]);
 #pragma unroll
     for (int q = 0; q < AW; ++q) {
         const bool valid = s + q < e_end;
@@ -320,30 +398,22 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
         const bool open = head_open && segw[q] == first_seg;
         endm |= is_end ? (1u << q) : 0u;
         openm |= open ? (1u << q) : 0u;
-        rowv[q] = (is_end && !open) ? seg_row<K>(uniq, segw[q]) : (int64_t)-1;
+        rowv[q] = (is_end && !open) ? rowv[q] : (int64_t)-1;
     }
     Vf<VEC> acc;
     vzero(acc);
 #pragma unroll
     for (int jb = 0; jb < AW; jb += GP) {
         if (s + jb >= e_end) break;
-        Vf<VEC> gvv[GP];
-        float rsv[GP];
+        GBits<VEC, GT> gb[GP];
+        float rsv[GP], gwq[GP];
 #pragma unroll
         for (int q = 0; q < GP; ++q) {
-            rsv[q] = 1.0f;
-            vzero(gvv[q]);
-            if (s + jb + q < e_end) {
-                const int pos = posw[jb + q];
-                if (WIDE) {
-                    const float gwv = wa.gw[(wa.F == 1 ? (unsigned)pos : __umulhi((unsigned)pos, wa.magic)) * wa.gws];
-                    if (!wl) vload<NT>(gvv[q], g + (int64_t)pos * ldg + col);
-                    else vset_x(gvv[q], gwv);
-                } else {
-                    vload<NT>(gvv[q], g + (int64_t)pos * ldg + col);
-                }
-                if (rscale) rsv[q] = rscale[pos];
-            }
+            const int pos = posw[jb + q];
+            gwq[q] = 0.0f;
+            if (WIDE) gwq[q] = wa.gw[(wa.F == 1 ? (unsigned)pos : __umulhi((unsigned)pos, wa.magic)) * wa.gws];
+            gload<NT>(gb[q], g + (int64_t)pos * ldg + (WIDE && wl ? 0 : col));       // (the wide lane's own gradient is gwq)
+            rsv[q] = rscale ? rscale[pos] : 1.0f;
         }
 #pragma unroll
         for (int sb = 0; sb < GP / AB; ++sb) {
@@ -363,13 +433,26 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
                         if (!(WIDE && wl && i > 0)) vload<NT>(st[k][i], upd.s[i] + roff[k]);
                 }
             }
+            if (GP > AB && sb == 0) {
+#pragma unroll
+                for (int q = 0; q < GP; ++q) gtouch(gb[q]);
+            }
+            // the batch's ONE wait, in straight-line code and before any store: the gradients are needed here, and behind them
+            // (the guarded state-row loads may or may not have been issued, so the wait is for everything) the rows have landed
+            Vf<VEC> xs[AB];
+#pragma unroll
+            for (int k = 0; k < AB; ++k) {
+                gwiden(xs[k], gb[sb * AB + k]);
+                if (WIDE && wl) { vzero(xs[k]); vset_x(xs[k], gwq[sb * AB + k]); }
+                if (rscale) vmul(xs[k], rsv[sb * AB + k]);
+                vmul(xs[k], gscale);
+                vtouch(xs[k]);
+            }
 #pragma unroll
             for (int k = 0; k < AB; ++k) {
                 const int q = j0 + k;
                 if (s + q >= e_end) continue;
-                Vf<VEC> x = gvv[sb * AB + k];
-                if (rscale) vmul(x, rsv[sb * AB + k]);
-                vmul(x, gscale);
+                Vf<VEC> x = xs[k];
                 const bool is_start = q == 0 || segw[q] != segw[q - 1];
                 if (is_start) acc = x; else vadd(acc, x);
                 if ((endm >> q) & 1u) {
@@ -389,9 +472,12 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     // run continues past this window?  owners[sw]: 0 = no run of this window continues, 1 = this window owns
     // a run with few partials (finished by one lane-group of k_apply_long), 2 = a long run (a block's job).
     // Every window writes its flag, so the list needs neither clearing nor an atomic counter.
-    const int last_seg = sseg[e_end - 1];
+    // (the window's last group and the next window's first are index words it already holds)
+    int last_seg = segw[0];
+#pragma unroll
+    for (int q = 1; q < AW; ++q) last_seg = (s + q < e_end) ? segw[q] : last_seg;
     int flag = 0;
-    if (e_end < n && sseg[e_end] == last_seg) {
+    if (e_end < n && segw[AW] == last_seg) {
         if (head_open && last_seg == first_seg) {
             vstore<false>(carry_head + sw * gm.D + ccol, acc);  // window lies wholly inside one run
         } else {
@@ -401,6 +487,7 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
         }
     }
     if (sub == 0) owners[sw] = flag;
+    }
 }
 
 // Step scalars from device memory (ss != nullptr): the Adam step size of this step, and the kernel's own begin / end wall
@@ -486,33 +573,43 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
     __syncthreads();
     const int cnt_a = n_a, cnt = nlist;
 
-    // ---- pass A
+    // ---- pass A.  A run's chain of dependent loads is kept short: its length and its row number are requested together (both
+    // need only the group number), the state rows as soon as the row number is there, and the partials four at a time at
+    // clamped addresses (added in order, the extra ones dropped) -- one partial per round trip before.
     if (active) {
         for (int ia = gi; ia < cnt_a; ia += NG) {
             const int sw = list_a[ia];
             const int last_e = ((sw + 1) * AW < n ? (sw + 1) * AW : n) - 1;
             const int u = sseg[last_e];
-            const int k = (seg_offsets[u + 1] - 1) / AW - sw;
+            const int seg_end = seg_offsets[u + 1];
+            const int64_t row = seg_row<K>(uniq, u);
+            const int k = (seg_end - 1) / AW - sw;
             Vf<VEC> acc;
             vload<false>(acc, carry_tail + (int64_t)sw * gm.D + col);
-            for (int t = 1; t <= k; ++t) {
-                Vf<VEC> x;
-                vload<false>(x, carry_head + (int64_t)(sw + t) * gm.D + col);
-                vadd(acc, x);
+            const bool ok = row >= 0 && row < V;
+            const int64_t roff = (ok ? row : 0) * ld + tcol;          // (row 0 for a row out of range: read, never written)
+            Vf<VEC> st[Upd::NS];
+            if (Upd::kLoad) {
+#pragma unroll
+                for (int i = 0; i < Upd::NS; ++i)
+                    if (!(WIDE && wl && i > 0)) vload<false>(st[i], upd.s[i] + roff);
             }
-            const int64_t row = seg_row<K>(uniq, u);
-            if (row >= 0 && row < V) {
-                const int64_t roff = row * ld + tcol;
-                Vf<VEC> st[Upd::NS];
+            for (int t0 = 1; t0 <= k; t0 += 4) {
+                Vf<VEC> x[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int t = t0 + q <= k ? t0 + q : k;
+                    vload<false>(x[q], carry_head + (int64_t)(sw + t) * gm.D + col);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (t0 + q <= k) vadd(acc, x[q]);
+            }
+            if (ok) {
                 if (WIDE && wl) {
-                    vload<false>(st[0], upd.s[0] + roff);
                     wide_apply(st[0], acc, wa.h);
                     vstore<false>(upd.s[0] + roff, st[0]);
                 } else {
-                    if (Upd::kLoad) {
-#pragma unroll
-                        for (int i = 0; i < Upd::NS; ++i) vload<false>(st[i], upd.s[i] + roff);
-                    }
                     upd_apply<Upd>(upd, st, acc);
 #pragma unroll
                     for (int i = 0; i < Upd::NS; ++i) vstore<false>(upd.s[i] + roff, st[i]);
@@ -618,7 +715,8 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
         if ((uint64_t)n * (uint64_t)wa.F >= ((uint64_t)1 << 32) || (uint64_t)n * (uint64_t)wa.gws >= ((uint64_t)1 << 32)) return MREC_EUNSUPPORTED;
     }
     const int64_t nsw = mrec_cdiv(n, vec == 4 ? ACfg<4>::AW : ACfg<1>::AW);
-    const unsigned blocks = (unsigned)mrec_cdiv(nsw, (int64_t)4 * gm.G);
+    unsigned blocks = (unsigned)mrec_cdiv(nsw, (int64_t)4 * gm.G);
+    if (blocks > MREC_APPLY_MAXB) blocks = MREC_APPLY_MAXB;
     const unsigned lblocks = (unsigned)mrec_cdiv(nsw, (int64_t)(16 * gm.G < 256 ? 16 * gm.G : 256));      // k_apply_long: 4 windows per lane-group, 4 G lane-groups, 256 at most
     const hipEvent_t ev0 = t_prof_start, ev1 = t_prof_stop;
     t_prof_start = t_prof_stop = nullptr;
