@@ -391,6 +391,12 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     int64_t rowv[AW];                                     // table row of the run that ends at entry q (-1: none / out of range)
 #pragma unroll
     for (int q = 0; q < AW; ++q) rowv[q] = seg_row<K>(uniq, segw[q] < 0 ? 0 : segw[q]);
+    // (the window's last group and the next window's first are index words it already holds; where the last run ends is
+    // requested with the row numbers, not behind the window's stores: a load there waits for them -- vmcnt counts in order)
+    int last_seg = segw[0];
+#pragma unroll
+    for (int q = 1; q < AW; ++q) last_seg = (s + q < e_end) ? segw[q] : last_seg;
+    int last_end = seg_offsets[(last_seg < 0 ? 0 : last_seg) + 1];
 #pragma unroll
     for (int q = 0; q < AW; ++q) {
         const bool valid = s + q < e_end;
@@ -400,6 +406,7 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
         openm |= open ? (1u << q) : 0u;
         rowv[q] = (is_end && !open) ? rowv[q] : (int64_t)-1;
     }
+    asm volatile("" : "+v"(last_end));      // landed with the row numbers (needed here: see vtouch)
     Vf<VEC> acc;
     vzero(acc);
 #pragma unroll
@@ -472,17 +479,13 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     // run continues past this window?  owners[sw]: 0 = no run of this window continues, 1 = this window owns
     // a run with few partials (finished by one lane-group of k_apply_long), 2 = a long run (a block's job).
     // Every window writes its flag, so the list needs neither clearing nor an atomic counter.
-    // (the window's last group and the next window's first are index words it already holds)
-    int last_seg = segw[0];
-#pragma unroll
-    for (int q = 1; q < AW; ++q) last_seg = (s + q < e_end) ? segw[q] : last_seg;
     int flag = 0;
     if (e_end < n && segw[AW] == last_seg) {
         if (head_open && last_seg == first_seg) {
             vstore<false>(carry_head + sw * gm.D + ccol, acc);  // window lies wholly inside one run
         } else {
             vstore<false>(carry_tail + sw * gm.D + ccol, acc);
-            const int k = (seg_offsets[last_seg + 1] - 1) / AW - (int)sw;   // head partials that follow
+            const int k = (last_end - 1) / AW - (int)sw;   // head partials that follow
             flag = (k + 1 <= 4 * gm.G) ? 1 : 2;
         }
     }
