@@ -26,6 +26,9 @@ __device__ __forceinline__ void vstore(float* p, const Vf<4>& x) { *(float4*)p =
 __device__ __forceinline__ void vstore(float* p, const Vf<1>& x) { *p = x.v; }
 __device__ __forceinline__ Vf<4> vscale(Vf<4> x, float s) { x.v.x *= s; x.v.y *= s; x.v.z *= s; x.v.w *= s; return x; }
 __device__ __forceinline__ Vf<1> vscale(Vf<1> x, float s) { x.v *= s; return x; }
+// "this value is needed here" (see k_gather_rows)
+__device__ __forceinline__ void vtouch(Vf<4>& r) { asm volatile("" : "+v"(r.v.x), "+v"(r.v.y), "+v"(r.v.z), "+v"(r.v.w)); }
+__device__ __forceinline__ void vtouch(Vf<1>& r) { asm volatile("" : "+v"(r.v)); }
 __device__ __forceinline__ Vf<4> vzero(Vf<4>*) { Vf<4> r; r.v = make_float4(0.f, 0.f, 0.f, 0.f); return r; }
 __device__ __forceinline__ Vf<1> vzero(Vf<1>*) { Vf<1> r; r.v = 0.f; return r; }
 
@@ -115,20 +118,32 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
     Vf<VEC> x[GB];
     float sc[GB];
     int64_t row[GB];
+    // Every load is requested unconditionally (a position past the end reads the last id, an id out of range reads row 0; both
+    // values are dropped) and the rows are "needed" in straight-line code before the first store: a guarded load that is
+    // converted inside its block is waited for there -- the GB ids were GB dependent round trips -- and a wait at a join
+    // behind a store waits for that store as well (vmcnt counts in order): GB - 1 store round trips more per wave.
+    const int64_t nlast = n - 1;
+    uint64_t dkey = 0;                                  // Dropout's key of this step (a device word): read once, with the ids
+    if (sizeof(OT) == 2 && gd.d.thresh) dkey = drop_key(gd.d);
 #pragma unroll
     for (int k = 0; k < GB; ++k) {
         const int64_t i = wave_row0 + (int64_t)k * gm.G + grp;
-        row[k] = -1;
-        sc[k] = 1.0f;
-        if (i < n) {
-            row[k] = (int64_t)ids[i * ids_stride];      // (strides: the ids / weights of a shard's request message, read in place)
-            if (row_scale) sc[k] = row_scale[i * rs_stride];
-        }
+        const int64_t ic = i < n ? i : nlast;
+        row[k] = (int64_t)ids[ic * ids_stride];          // (strides: the ids / weights of a shard's request message, read in place)
+        sc[k] = row_scale ? row_scale[ic * rs_stride] : 1.0f;
+    }
+    bool okr[GB];
+#pragma unroll
+    for (int k = 0; k < GB; ++k) {
+        const int64_t i = wave_row0 + (int64_t)k * gm.G + grp;
+        if (i >= n) row[k] = -1;
+        okr[k] = row[k] >= 0 && row[k] < V;
+        x[k] = vload(table + (okr[k] ? row[k] : 0) * ld + col, (Vf<VEC>*)nullptr);
     }
 #pragma unroll
     for (int k = 0; k < GB; ++k) {
-        x[k] = vzero((Vf<VEC>*)nullptr);
-        if (row[k] >= 0 && row[k] < V) x[k] = vload(table + row[k] * ld + col, (Vf<VEC>*)nullptr);
+        vtouch(x[k]);
+        if (!okr[k]) x[k] = vzero((Vf<VEC>*)nullptr);
     }
 #pragma unroll
     for (int k = 0; k < GB; ++k) {
@@ -141,7 +156,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
                 if constexpr (sizeof(OT) == 2) {
                     // ONE store instruction for the whole lane-group: the wide lane's address points into wprod
                     uint2 u = pack16((const OT*)nullptr, yv);
-                    if (gd.d.thresh && !wl) u = drop16<OT>(u, gd, drop_key(gd.d), i, D, col);
+                    if (gd.d.thresh && !wl) u = drop16<OT>(u, gd, dkey, i, D, col);
                     if (wl) u = make_uint2(__float_as_uint(yv.x), 0u);
                     uint2* dst = wl ? (uint2*)(wprod + ldw * i) : (uint2*)(out + i * ldo + col);
                     *dst = u;
