@@ -20,8 +20,8 @@ cp $(find $O/prof -name "*kernel_stats.csv") $O/bench_kernel_stats.csv
 python3 $R/tools/prof_summary.py $O/bench_kernel_stats.csv > $O/bench_kernel_summary.txt
 python3 $R/tools/step_timeline.py $O/prof > $O/step_timeline_under_rocprof.txt 2>&1 || true
 echo "prof done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-zipf39 > $O/pmc_bench_line.json 2> $O/pmc1.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-zipf39 > /dev/null 2> $O/pmc2.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 6 --warmup 2 --repeats 1 --prime-steps 0 --no-cpu-baseline --no-zipf39 > $O/pmc_bench_line.json 2> $O/pmc1.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 6 --warmup 2 --repeats 1 --prime-steps 0 --no-cpu-baseline --no-zipf39 > /dev/null 2> $O/pmc2.err
 python3 $R/tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json $O/pmc_bench_line.json > $O/pmc_traffic.txt
 echo "pmc done"; cat $O/pmc_traffic.txt
 rm -rf $O/prof $O/pmc_fetch $O/pmc_write
