@@ -32,22 +32,48 @@ __global__ __launch_bounds__(256) void k_radix_hist(const int* __restrict__ keys
     const int NB = 1 << nbits;
     for (int d = threadIdx.x; d < NB; d += 256) h[d] = 0;
     __syncthreads();
+    // A thread's 8 keys are fetched TOGETHER, step by step of the chain (clamped indices, values past the end dropped): as one
+    // guarded block per key -- a four-deep chain of dependent loads each, stores in between -- this kernel was 32 dependent
+    // round trips long (35 us in the step).  The loads of inv_out may pass the stores to it: they read first positions of keys,
+    // the stores write positions of duplicates.
+    constexpr int RK = RT / 256;
+    int key[RK];
+    const int nl = n - 1;
+    if (slots) {
+        // keys produced here: the group of the i-th duplicate (position pos[i]) = the inverse of the first position of
+        // its key, which its scratch slot still holds; also written as the duplicate's own inverse
+        int p_[RK], sx[RK], fp[RK];
 #pragma unroll
-    for (int k = 0; k < RT / 256; ++k) {
-        const int i = base + k * 256 + threadIdx.x;
-        if (i < n) {
-            int key;
-            if (slots) {
-                // keys produced here: the group of the i-th duplicate (position pos[i]) = the inverse of the first position of
-                // its key, which its scratch slot still holds; also written as the duplicate's own inverse
-                const int p_ = pos[i];
-                const int sx = sidx[p_];
-                key = sx >= 0 ? inv_out[slots[sx]] : gkey;       // (sx < 0: a skipped negative id -- the pseudo-group behind all others)
-                inv_out[p_] = sx >= 0 ? key : -1;
-                keys_out[i] = key;
-            } else key = keys[i];
-            atomicAdd(&h[(key >> shift) & (NB - 1)], 1);
+        for (int k = 0; k < RK; ++k) {
+            const int i = base + k * 256 + threadIdx.x;
+            p_[k] = pos[i < nl ? i : nl];
         }
+#pragma unroll
+        for (int k = 0; k < RK; ++k) sx[k] = sidx[p_[k]];
+#pragma unroll
+        for (int k = 0; k < RK; ++k) fp[k] = slots[sx[k] >= 0 ? sx[k] : 0];
+#pragma unroll
+        for (int k = 0; k < RK; ++k) key[k] = inv_out[sx[k] >= 0 ? fp[k] : 0];      // (slot 0 may be empty: not a position)
+#pragma unroll
+        for (int k = 0; k < RK; ++k) {
+            const int i = base + k * 256 + threadIdx.x;
+            key[k] = sx[k] >= 0 ? key[k] : gkey;        // (sx < 0: a skipped negative id -- the pseudo-group behind all others)
+            if (i < n) {
+                inv_out[p_[k]] = sx[k] >= 0 ? key[k] : -1;
+                keys_out[i] = key[k];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RK; ++k) {
+            const int i = base + k * 256 + threadIdx.x;
+            key[k] = keys[i < nl ? i : nl];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        const int i = base + k * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&h[(key[k] >> shift) & (NB - 1)], 1);
     }
     __syncthreads();
     for (int d = threadIdx.x; d < NB; d += 256) hist[(int64_t)blockIdx.x * NB + d] = h[d];
