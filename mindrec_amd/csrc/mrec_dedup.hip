@@ -151,15 +151,23 @@ __global__ __launch_bounds__(DB) void k_dedup_rank(const K* __restrict__ ids, co
     bool first[DI];
     int slot[DI];
     int c = 0;
+    // (a thread's DI ids, scratch-slot numbers and slot contents are each requested together, at clamped indices: as guarded
+    // loads they were DI dependent round trips per step -- see k_radix_hist)
+    K idv[DI];
+    int held[DI];
+    const int nl = n > 0 ? n - 1 : 0;
 #pragma unroll
     for (int k = 0; k < DI; ++k) {
         const int i = base + k;
-        slot[k] = (i < n) ? sidx[i] : 0;
+        slot[k] = sidx[i < nl ? i : nl];
+        idv[k] = ids[i < nl ? i : nl];
     }
 #pragma unroll
+    for (int k = 0; k < DI; ++k) held[k] = slots[slot[k] >= 0 ? slot[k] : 0];
+#pragma unroll
     for (int k = 0; k < DI; ++k) {
         const int i = base + k;
-        first[k] = (i < n) && slot[k] >= 0 && (slots[slot[k]] == i);      // (slot < 0: a skipped negative id -- counted with the duplicates)
+        first[k] = (i < n) && slot[k] >= 0 && (held[k] == i);      // (slot < 0: a skipped negative id -- counted with the duplicates)
         c += first[k];
     }
     int tot;
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(DB) void k_dedup_rank(const K* __restrict__ ids, co
     for (int k = 0; k < DI; ++k) {
         const int i = base + k;
         if (first[k]) {
-            uniq[r] = ids[i];
+            uniq[r] = idv[k];
             inv[i] = r;                      // (a duplicate finds its group here, through the slot that still holds i)
             if (first_pos) first_pos[r] = i; // the step's plan: where the group starts
             ++r;

@@ -153,8 +153,10 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const int* __restrict__ k
         const int d0 = threadIdx.x * per;
         int t[8], s = 0;
 #pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = totals[d0 + k < NB ? d0 + k : NB - 1];      // (requested together; see k_radix_hist)
+#pragma unroll
         for (int k = 0; k < 8; ++k) {
-            t[k] = (k < per && d0 + k < NB) ? totals[d0 + k] : 0;
+            t[k] = (k < per && d0 + k < NB) ? t[k] : 0;
             s += t[k];
         }
         int tot;
@@ -173,11 +175,19 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const int* __restrict__ k
     const int base = blockIdx.x * RT + w * (RROUNDS * 64);
     int key[RROUNDS], pre[RROUNDS];
     const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
+    const int nl = n > 0 ? n - 1 : 0;
+    int val[RROUNDS];
+#pragma unroll
+    for (int r = 0; r < RROUNDS; ++r) {            // the wave's 8 rounds of keys (and values) requested together
+        const int i = base + r * 64 + l;
+        key[r] = keys_in[i < nl ? i : nl];
+        val[r] = vals_in ? vals_in[i < nl ? i : nl] : i;
+    }
 #pragma unroll
     for (int r = 0; r < RROUNDS; ++r) {
         const int i = base + r * 64 + l;
         const bool valid = i < n;
-        key[r] = valid ? keys_in[i] : 0;
+        key[r] = valid ? key[r] : 0;
         const int d = (key[r] >> shift) & (NB - 1);
         uint64_t m = __ballot(valid);
         for (int b = 0; b < nbits; ++b) {
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const int* __restrict__ k
             const int d = (key[r] >> shift) & (NB - 1);
             const int dst = cnt[w][d] + pre[r];
             keys_out[dst] = key[r];
-            vals_out[dst] = vals_in ? vals_in[i] : i;
+            vals_out[dst] = val[r];
         }
     }
 }
