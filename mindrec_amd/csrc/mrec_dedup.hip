@@ -86,6 +86,8 @@ __global__ __launch_bounds__(DB) void k_dedup_insert(const K* __restrict__ ids, 
         const int i = base + k * DB + threadIdx.x;
         uint32_t s = hsh[k] & mask;
         for (;;) {
+            // (Issuing a thread's II first claims together, ahead of the walks, was measured: plan alone 102.7 -> 108.3 us,
+            // the step 0.630 -> 0.639 ms with the lookup beside it 2 us slower -- bursts of atomics; not kept.)
             // CAS first, no read-before-claim: tile leaders are mostly distinct keys, so the common case
             // is an empty slot and one memory operation.  A slot only moves EMPTY -> position -> smaller
             // position of the SAME key, so the returned value is always a valid position to compare.
