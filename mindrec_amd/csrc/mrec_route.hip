@@ -66,28 +66,34 @@ __global__ __launch_bounds__(256) void k_perm_rows(const float* __restrict__ src
     float x[PB][VEC];
     int64_t p[PB];
     float s[PB];
+    // (the PB permutation entries, then the PB scales and rows, each requested together at clamped indices, and "needed"
+    // before the first store -- see k_unroute_slots)
+    const int64_t nl = n > 0 ? n - 1 : 0;
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const int64_t k = k0 + (int64_t)q * G + grp;
-        p[q] = -1;
-        s[q] = 1.0f;
-        if (k < n) {
-            p[q] = perm[k];
-            if (row_scale) s[q] = row_scale[p[q]];
+        p[q] = perm[k < nl ? k : nl];
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int64_t k = k0 + (int64_t)q * G + grp;
+        const int64_t kc = k < nl ? k : nl;
+        s[q] = row_scale ? row_scale[p[q]] : 1.0f;
+        const float* a = (SCATTER ? src + kc * lds : src + p[q] * lds) + sub * VEC;
+        if (VEC == 4) {
+            const float4 v = *(const float4*)a;
+            x[q][0] = v.x; x[q][1 % VEC] = v.y; x[q][2 % VEC] = v.z; x[q][3 % VEC] = v.w;
+        } else {
+            x[q][0] = *a;
         }
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const int64_t k = k0 + (int64_t)q * G + grp;
-        if (p[q] >= 0) {
-            const float* a = (SCATTER ? src + k * lds : src + p[q] * lds) + sub * VEC;
-            if (VEC == 4) {
-                const float4 v = *(const float4*)a;
-                x[q][0] = v.x; x[q][1 % VEC] = v.y; x[q][2 % VEC] = v.z; x[q][3 % VEC] = v.w;
-            } else {
-                x[q][0] = *a;
-            }
-        }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) asm volatile("" : "+v"(x[q][c]));
+        asm volatile("" : "+v"(s[q]));
+        if (k >= n) p[q] = -1;
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
@@ -233,15 +239,24 @@ __global__ __launch_bounds__(256) void k_unroute_slots(const float* __restrict__
     const bool wl = sub * 4 >= Dw;
     float4 x[PB];
     int s[PB];
+    // (all loads at clamped / valid addresses and "needed" before the first store: guarded, every store was preceded by a wait
+    // that also waited for the store before it -- vmcnt counts loads and stores in order; see k_gather_rows in mrec_gather.hip)
+    const int64_t nl = n > 0 ? n - 1 : 0;
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const int64_t p = p0 + (int64_t)q * G + grp;
-        s[q] = (p < n) ? slot_of_pos[p] : -1;
+        s[q] = slot_of_pos[p < nl ? p : nl];
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
-        x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s[q] >= 0) x[q] = *(const float4*)(back + (int64_t)s[q] * W + sub * 4);
+        const int64_t p = p0 + (int64_t)q * G + grp;
+        if (p >= n) s[q] = -1;
+        x[q] = *(const float4*)(back + (int64_t)(s[q] >= 0 ? s[q] : 0) * W + sub * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        asm volatile("" : "+v"(x[q].x), "+v"(x[q].y), "+v"(x[q].z), "+v"(x[q].w));
+        if (s[q] < 0) x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
@@ -263,19 +278,26 @@ __global__ __launch_bounds__(256) void k_route_grads(const float* __restrict__ g
     const int64_t s0 = ((int64_t)blockIdx.x * 4 + wave) * (G * PB);
     const bool wl = sub * 4 >= Dw;
     float4 x[PB];
+    float dl[PB];
     int p[PB];
+    const int64_t sl = n_slots > 0 ? n_slots - 1 : 0;
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const int64_t s = s0 + (int64_t)q * G + grp;
-        p[q] = (s < n_slots) ? pos_of_slot[s] : -1;
+        p[q] = pos_of_slot[s < sl ? s : sl];
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
-        x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p[q] >= 0) {
-            if (wl) x[q].x = dlogit[F == 1 ? (unsigned)p[q] : __umulhi((unsigned)p[q], magic)];
-            else x[q] = *(const float4*)(g + (int64_t)p[q] * ldg + sub * 4);
-        }
+        const int64_t s = s0 + (int64_t)q * G + grp;
+        if (s >= n_slots) p[q] = -1;
+        const unsigned pp = p[q] >= 0 ? (unsigned)p[q] : 0u;       // (a padding slot reads position 0: dropped)
+        dl[q] = dlogit[F == 1 ? pp : __umulhi(pp, magic)];
+        x[q] = *(const float4*)(g + (int64_t)pp * ldg + (wl ? 0 : sub * 4));      // (the pair's lane: column 0, unused)
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        asm volatile("" : "+v"(x[q].x), "+v"(x[q].y), "+v"(x[q].z), "+v"(x[q].w), "+v"(dl[q]));
+        if (wl) x[q] = make_float4(dl[q], 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
