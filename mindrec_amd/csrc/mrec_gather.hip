@@ -54,7 +54,10 @@ __device__ __forceinline__ unsigned f2h2(float lo, float hi) {
 __device__ __forceinline__ void vstore(f16o_t* p, const Vf<4>& x) { *(uint2*)p = make_uint2(f2h2(x.v.x, x.v.y), f2h2(x.v.z, x.v.w)); }
 __device__ __forceinline__ void vstore(f16o_t* p, const Vf<1>& x) { p->v = __builtin_bit_cast(uint16_t, (_Float16)x.v); }
 
-constexpr int GB = 4;  // rows in flight per lane-group
+#ifndef MREC_GB
+#define MREC_GB 4
+#endif
+constexpr int GB = MREC_GB;  // rows in flight per lane-group (2 / 4 / 8 in the step: lookup 49.3 / 48.2 / 49.7 us)
 
 // Lane-group geometry shared by the row kernels: lpr lanes per row, G = 64/lpr groups per wave.
 struct RowGeom { int lpr; int G; };
