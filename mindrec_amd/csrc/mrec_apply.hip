@@ -53,6 +53,9 @@ namespace {
 #define MREC_APPLY_MAXB 4096u        // workgroups of k_apply_main (4 waves each; 1024 are resident at 4 waves per SIMD).  Sweep in profiles/r03_apply_chain.txt:
                                      // duplicate-heavy ids want a cap (Zipf x 39 fields: 121 us uncapped, 94-95 at 1024-4096), uniform ids none (172 / 176 us at 4096 / 2048)
 #endif
+#ifndef MREC_LONG_AB
+#define MREC_LONG_AB 16              // partials in flight per lane-group in k_apply_long's pass over a long run (32: 13.5 -> 36 us on Zipf x 39 fields)
+#endif
 #ifndef MREC_GP1
 #define MREC_GP1 4
 #endif
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
                                                     const StepState* ss, const int64_t* __restrict__ nv = nullptr) {
     resolve_step(upd, ss);
     // the partials of a run are consecutive carry rows: stream them 16 deep per lane-group
-    constexpr int AW = ACfg<VEC>::AW, AB = 16;
+    constexpr int AW = ACfg<VEC>::AW, AB = MREC_LONG_AB;
     if (nv) {
         const int64_t x = *nv;
         if (x < n) { n = x < 0 ? 0 : (int)x; nsw = (n + AW - 1) / AW; }
