@@ -1,7 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out/r5n
-for lib in libmrec_hip.so libmrec_w3.so libmrec_gp4_w3.so libmrec_gp8_w3.so libmrec_hip.so; do
+for lib in libmrec_hip.so libmrec_aw4.so libmrec_aw16.so libmrec_hip.so; do
   export MREC_HIP_LIB=$R/mindrec_amd/csrc/$lib
   python3 $R/bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $R/gpurun_out/r5n/$lib.json || exit 1
   python3 -c "
