@@ -300,6 +300,21 @@ int mrec_dense_adam_slabs_f32(float* p, float* m, float* v, const float* g, void
                               const int32_t* splits, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
                               float grad_scale, int nesterov, void* step_state /* nullable mrec_step_state_t: lr_t */,
                               void* stream);
+/* Both of the above with ONE element of the buffer under FTRL instead of Adam: Wide&Deep's `wide_b` (models/wide_deep/src/
+ * wide_and_deep.py:161-163) is a member of the FTRL optimizer's parameter list -- TrainStepWrap sorts by `"wide" in params.name`
+ * (:407-411) and MindSpore names the Parameter held in the attribute `wide_b` "<prefix>.wide_b" [EXT: Cell.update_parameters_name
+ * uses the attribute path] -- while it lives in the dense net's flat buffer here (its gradient is written by the output-head
+ * kernel).  For element one_ftrl->index, m[index] is FTRL's accum and v[index] its linear (nn.FTRL, :423-430,438-445);
+ * one_ftrl == NULL or index < 0: plain Adam everywhere.  fp32 gradients only. */
+typedef struct mrec_ftrl1_t { int64_t index; float lr, l1, l2, lr_power; } mrec_ftrl1_t;
+int mrec_dense_adam_one_ftrl_f32(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1, float b2, float eps,
+                                 float b1_pow, float b2_pow, float grad_scale, int nesterov, const mrec_ftrl1_t* one_ftrl,
+                                 void* stream);
+int mrec_dense_adam_slabs_one_ftrl_f32(float* p, float* m, float* v, const float* g, void* shadow16, int shadow_kind, int64_t n,
+                                       int32_t nseg, const float* const* slabs, const int64_t* starts, const int64_t* lens,
+                                       const int32_t* splits, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
+                                       float grad_scale, int nesterov, void* step_state, const mrec_ftrl1_t* one_ftrl,
+                                       void* stream);
 /* The same slab sums WITHOUT the optimizer, all segments in one launch: g[starts[q] + e] = sum_s slabs[q][s*lens[q] + e] in slab
  * order -- what a data-parallel rank needs before the all-reduce of the dense gradients (train_and_eval_distribute.py:135-138). */
 int mrec_dense_sum_slab_segments_f32(float* g, int64_t n, int32_t nseg, const float* const* slabs, const int64_t* starts,

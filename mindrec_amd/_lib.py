@@ -88,6 +88,9 @@ _SIGS = {
                                  _f32, _f32, _f32, _f32, _f32, _vp, _sz, _vp],
     "mrec_dense_adam_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp],
     "mrec_dense_adam_ex_f32": [_vp, _vp, _vp, _vp, _int, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp],
+    "mrec_dense_adam_one_ftrl_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _vp],
+    "mrec_dense_adam_slabs_one_ftrl_f32": [_vp, _vp, _vp, _vp, _vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32,
+                                           _f32, _f32, _int, _vp, _vp, _vp],
     "mrec_dense_sum_slab_segments_f32": [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp],
     "mrec_dense_adam_slabs_f32": [_vp, _vp, _vp, _vp, _vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32,
                                   _f32, _int, _vp, _vp],

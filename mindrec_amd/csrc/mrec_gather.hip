@@ -371,13 +371,23 @@ __global__ __launch_bounds__(256) void k_move_rows(const float* __restrict__ src
 __device__ __forceinline__ float g_widen(float x) { return x; }
 __device__ __forceinline__ float g_widen(uint16_t x) { return __uint_as_float(((unsigned)x) << 16); }
 
+// One element of a dense buffer may belong to FTRL instead of Adam (Ftrl1: its index, or -1): Wide&Deep's `wide_b`, which
+// TrainStepWrap hands to the FTRL optimizer with the wide table (wide_and_deep.py:407-411) while it lives in the dense net's flat
+// buffer here -- its `m` word is FTRL's accum, its `v` word FTRL's linear.  A uniform compare per vector; no second launch.
+struct Ftrl1 { int64_t idx; FtrlH h; };
+
+__device__ __forceinline__ void adam_or_ftrl(float& p, float& m, float& v, float g, const AdamH& h, bool ftrl, const FtrlH& fh) {
+    if (ftrl) ftrl_elem(p, m, v, g, fh);
+    else adam_elem(p, m, v, g, h);
+}
+
 template <class GT, bool SH>
 __global__ __launch_bounds__(256) void k_dense_adam(float* __restrict__ p, float* __restrict__ m,
                                                     float* __restrict__ v, const GT* __restrict__ g, int64_t n,
-                                                    AdamH h, uint16_t* __restrict__ shadow) {
+                                                    AdamH h, uint16_t* __restrict__ shadow, Ftrl1 f1) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float pp = p[i], mm = m[i], vv = v[i];
-        adam_elem(pp, mm, vv, g_widen(g[i]) * h.gscale, h);
+        adam_or_ftrl(pp, mm, vv, g_widen(g[i]) * h.gscale, h, i == f1.idx, f1.h);
         p[i] = pp; m[i] = mm; v[i] = vv;
         if (SH) shadow[i] = f2bf(pp);
     }
@@ -386,14 +396,15 @@ __global__ __launch_bounds__(256) void k_dense_adam(float* __restrict__ p, float
 template <bool SH>
 __global__ __launch_bounds__(256) void k_dense_adam4(float4* __restrict__ p, float4* __restrict__ m,
                                                      float4* __restrict__ v, const float4* __restrict__ g,
-                                                     int64_t n4, AdamH h, uint2* __restrict__ shadow) {
+                                                     int64_t n4, AdamH h, uint2* __restrict__ shadow, Ftrl1 f1) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 pp = p[i], mm = m[i], vv = v[i];
         const float4 gg = g[i];
-        adam_elem(pp.x, mm.x, vv.x, gg.x * h.gscale, h);
-        adam_elem(pp.y, mm.y, vv.y, gg.y * h.gscale, h);
-        adam_elem(pp.z, mm.z, vv.z, gg.z * h.gscale, h);
-        adam_elem(pp.w, mm.w, vv.w, gg.w * h.gscale, h);
+        const int fq = (f1.idx >> 2) == i ? (int)(f1.idx & 3) : -1;
+        adam_or_ftrl(pp.x, mm.x, vv.x, gg.x * h.gscale, h, fq == 0, f1.h);
+        adam_or_ftrl(pp.y, mm.y, vv.y, gg.y * h.gscale, h, fq == 1, f1.h);
+        adam_or_ftrl(pp.z, mm.z, vv.z, gg.z * h.gscale, h, fq == 2, f1.h);
+        adam_or_ftrl(pp.w, mm.w, vv.w, gg.w * h.gscale, h, fq == 3, f1.h);
         p[i] = pp; m[i] = mm; v[i] = vv;
         if (SH) shadow[i] = make_uint2((unsigned)f2bf(pp.x) | ((unsigned)f2bf(pp.y) << 16),
                                        (unsigned)f2bf(pp.z) | ((unsigned)f2bf(pp.w) << 16));
@@ -439,7 +450,7 @@ template <int SHK>
 __global__ __launch_bounds__(256) void k_dense_adam4_slabs(float4* __restrict__ p, float4* __restrict__ m,
                                                            float4* __restrict__ v, const float4* __restrict__ g,
                                                            int64_t n4, AdamH h, uint2* __restrict__ shadow, SlabSegs sg,
-                                                           const StepState* ss) {
+                                                           const StepState* ss, Ftrl1 f1) {
     if (ss) h.lr_t = ss->lr_t;             // this step's bias-corrected step size from device memory (mrec_step_advance)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 pp = p[i], mm = m[i], vv = v[i];
@@ -465,10 +476,11 @@ __global__ __launch_bounds__(256) void k_dense_adam4_slabs(float4* __restrict__ 
         } else {
             gg = g[i];
         }
-        adam_elem(pp.x, mm.x, vv.x, gg.x * h.gscale, h);
-        adam_elem(pp.y, mm.y, vv.y, gg.y * h.gscale, h);
-        adam_elem(pp.z, mm.z, vv.z, gg.z * h.gscale, h);
-        adam_elem(pp.w, mm.w, vv.w, gg.w * h.gscale, h);
+        const int fq = (f1.idx >> 2) == i ? (int)(f1.idx & 3) : -1;
+        adam_or_ftrl(pp.x, mm.x, vv.x, gg.x * h.gscale, h, fq == 0, f1.h);
+        adam_or_ftrl(pp.y, mm.y, vv.y, gg.y * h.gscale, h, fq == 1, f1.h);
+        adam_or_ftrl(pp.z, mm.z, vv.z, gg.z * h.gscale, h, fq == 2, f1.h);
+        adam_or_ftrl(pp.w, mm.w, vv.w, gg.w * h.gscale, h, fq == 3, f1.h);
         p[i] = pp; m[i] = mm; v[i] = vv;
         if (SHK) shadow[i] = make_uint2(pack_shadow2(pp.x, pp.y, SHK), pack_shadow2(pp.z, pp.w, SHK));
     }
@@ -820,10 +832,23 @@ MREC_API int mrec_move_rows_f32(const float* src, int64_t ld_src, const int64_t*
     return MREC_OK;
 }
 
+static int ftrl1_from(const mrec_ftrl1_t* one, int64_t n, float grad_scale, Ftrl1* out) {
+    out->idx = -1;
+    out->h.lr = 1.0f; out->h.l1 = 0.0f; out->h.l2 = 0.0f; out->h.lr_power = -0.5f; out->h.gscale = grad_scale;
+    if (!one || one->index < 0) return MREC_OK;
+    if (one->index >= n || !(one->lr > 0.0f) || one->l1 < 0.0f || one->l2 < 0.0f || one->lr_power > 0.0f) return MREC_EINVAL;
+    out->idx = one->index;
+    out->h.lr = one->lr; out->h.l1 = one->l1; out->h.l2 = one->l2; out->h.lr_power = one->lr_power;
+    return MREC_OK;
+}
+
 static int dense_adam_launch(float* p, float* m, float* v, const void* g, int g_bf16, uint16_t* shadow, int64_t n,
                              float lr, float b1, float b2, float eps, float b1_pow, float b2_pow, float grad_scale,
-                             int nesterov, void* stream) {
+                             int nesterov, void* stream, const mrec_ftrl1_t* one = nullptr) {
     if (n < 0) return MREC_EINVAL;
+    Ftrl1 f1;
+    if (int rc = ftrl1_from(one, n, grad_scale, &f1)) return rc;
+    if (f1.idx >= 0 && g_bf16) return MREC_EUNSUPPORTED;
     if (n == 0) return MREC_OK;
     if (!p || !m || !v || !g) return MREC_EINVAL;
     AdamH h;
@@ -840,22 +865,24 @@ static int dense_adam_launch(float* p, float* m, float* v, const void* g, int g_
             if (shadow) k_dense_adam4_g16<true><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const uint2*)g, n4, h, (uint2*)shadow);
             else k_dense_adam4_g16<false><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const uint2*)g, n4, h, nullptr);
         } else {
-            if (shadow) k_dense_adam4<true><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow);
-            else k_dense_adam4<false><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, nullptr);
+            if (shadow) k_dense_adam4<true><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow, f1);
+            else k_dense_adam4<false><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, nullptr, f1);
         }
     }
     const int64_t done = n4 * 4, rem = n - done;
     if (rem > 0) {
         const unsigned gr = stream_grid(rem);
         uint16_t* sh = shadow ? shadow + done : nullptr;
+        Ftrl1 fr = f1;
+        fr.idx = f1.idx >= done ? f1.idx - done : -1;
         if (g_bf16) {
             const uint16_t* gg = (const uint16_t*)g + done;
-            if (sh) k_dense_adam<uint16_t, true><<<gr, 256, 0, st>>>(p + done, m + done, v + done, gg, rem, h, sh);
-            else k_dense_adam<uint16_t, false><<<gr, 256, 0, st>>>(p + done, m + done, v + done, gg, rem, h, nullptr);
+            if (sh) k_dense_adam<uint16_t, true><<<gr, 256, 0, st>>>(p + done, m + done, v + done, gg, rem, h, sh, fr);
+            else k_dense_adam<uint16_t, false><<<gr, 256, 0, st>>>(p + done, m + done, v + done, gg, rem, h, nullptr, fr);
         } else {
             const float* gg = (const float*)g + done;
-            if (sh) k_dense_adam<float, true><<<gr, 256, 0, st>>>(p + done, m + done, v + done, gg, rem, h, sh);
-            else k_dense_adam<float, false><<<gr, 256, 0, st>>>(p + done, m + done, v + done, gg, rem, h, nullptr);
+            if (sh) k_dense_adam<float, true><<<gr, 256, 0, st>>>(p + done, m + done, v + done, gg, rem, h, sh, fr);
+            else k_dense_adam<float, false><<<gr, 256, 0, st>>>(p + done, m + done, v + done, gg, rem, h, nullptr, fr);
         }
     }
     MREC_LAUNCH_CHECK();
@@ -875,12 +902,20 @@ MREC_API int mrec_dense_adam_ex_f32(float* p, float* m, float* v, const void* g,
                              stream);
 }
 
-MREC_API int mrec_dense_adam_slabs_f32(float* p, float* m, float* v, const float* g, void* shadow16, int shadow_kind,
-                                       int64_t n, int32_t nseg, const float* const* slabs, const int64_t* starts,
-                                       const int64_t* lens, const int32_t* splits, float lr, float b1, float b2, float eps,
-                                       float b1_pow, float b2_pow, float grad_scale, int nesterov, void* step_state,
-                                       void* stream) {
+MREC_API int mrec_dense_adam_one_ftrl_f32(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1, float b2,
+                                          float eps, float b1_pow, float b2_pow, float grad_scale, int nesterov,
+                                          const mrec_ftrl1_t* one_ftrl, void* stream) {
+    return dense_adam_launch(p, m, v, g, 0, nullptr, n, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale, nesterov, stream, one_ftrl);
+}
+
+static int dense_adam_slabs_launch(float* p, float* m, float* v, const float* g, void* shadow16, int shadow_kind,
+                                   int64_t n, int32_t nseg, const float* const* slabs, const int64_t* starts,
+                                   const int64_t* lens, const int32_t* splits, float lr, float b1, float b2, float eps,
+                                   float b1_pow, float b2_pow, float grad_scale, int nesterov, void* step_state,
+                                   const mrec_ftrl1_t* one, void* stream) {
     if (n < 0 || nseg < 0 || nseg > 16 || shadow_kind < 0 || shadow_kind > 2) return MREC_EINVAL;
+    Ftrl1 f1;
+    if (int rc = ftrl1_from(one, n, grad_scale, &f1)) return rc;
     const StepState* ss = (const StepState*)step_state;
     if (n == 0) return MREC_OK;
     if (!p || !m || !v || !g || (nseg > 0 && (!slabs || !starts || !lens || !splits)) || (shadow_kind && !shadow16))
@@ -905,11 +940,29 @@ MREC_API int mrec_dense_adam_slabs_f32(float* p, float* m, float* v, const float
     const int64_t n4 = n / 4;
     hipStream_t st = (hipStream_t)stream;
     const unsigned gr = stream_grid(n4);
-    if (shadow_kind == 1) k_dense_adam4_slabs<1><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow16, sg, ss);
-    else if (shadow_kind == 2) k_dense_adam4_slabs<2><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow16, sg, ss);
-    else k_dense_adam4_slabs<0><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, nullptr, sg, ss);
+    if (shadow_kind == 1) k_dense_adam4_slabs<1><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow16, sg, ss, f1);
+    else if (shadow_kind == 2) k_dense_adam4_slabs<2><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, (uint2*)shadow16, sg, ss, f1);
+    else k_dense_adam4_slabs<0><<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, nullptr, sg, ss, f1);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
+}
+
+MREC_API int mrec_dense_adam_slabs_f32(float* p, float* m, float* v, const float* g, void* shadow16, int shadow_kind,
+                                       int64_t n, int32_t nseg, const float* const* slabs, const int64_t* starts,
+                                       const int64_t* lens, const int32_t* splits, float lr, float b1, float b2, float eps,
+                                       float b1_pow, float b2_pow, float grad_scale, int nesterov, void* step_state,
+                                       void* stream) {
+    return dense_adam_slabs_launch(p, m, v, g, shadow16, shadow_kind, n, nseg, slabs, starts, lens, splits, lr, b1, b2, eps, b1_pow,
+                                   b2_pow, grad_scale, nesterov, step_state, nullptr, stream);
+}
+
+MREC_API int mrec_dense_adam_slabs_one_ftrl_f32(float* p, float* m, float* v, const float* g, void* shadow16, int shadow_kind,
+                                                int64_t n, int32_t nseg, const float* const* slabs, const int64_t* starts,
+                                                const int64_t* lens, const int32_t* splits, float lr, float b1, float b2, float eps,
+                                                float b1_pow, float b2_pow, float grad_scale, int nesterov, void* step_state,
+                                                const mrec_ftrl1_t* one_ftrl, void* stream) {
+    return dense_adam_slabs_launch(p, m, v, g, shadow16, shadow_kind, n, nseg, slabs, starts, lens, splits, lr, b1, b2, eps, b1_pow,
+                                   b2_pow, grad_scale, nesterov, step_state, one_ftrl, stream);
 }
 
 MREC_API int mrec_dense_sum_slab_segments_f32(float* g, int64_t n, int32_t nseg, const float* const* slabs, const int64_t* starts,

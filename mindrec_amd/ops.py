@@ -408,13 +408,31 @@ def _flat_same(*ts):
     return n
 
 
+class _Ftrl1(C.Structure):         # mrec_ftrl1_t
+    _fields_ = [("index", C.c_int64), ("lr", C.c_float), ("l1", C.c_float), ("l2", C.c_float), ("lr_power", C.c_float)]
+
+
+def _ftrl1(one):
+    """one = (index, lr, l1, l2, lr_power): the element of a dense buffer that belongs to FTRL (its m word = accum, its v word =
+    linear) -- Wide&Deep's `wide_b` (wide_and_deep.py:407-411)."""
+    idx, lr, l1, l2, lrp = one
+    return _Ftrl1(int(idx), float(lr), float(l1), float(l2), float(lrp))
+
+
 def dense_adam_(p, m, v, g, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, beta1_power=0.9, beta2_power=0.999,
-                grad_scale=1.0, use_nesterov=False, shadow_bf16=None):
+                grad_scale=1.0, use_nesterov=False, shadow_bf16=None, ftrl1=None):
     """nn.Adam over a whole tensor (wide_and_deep.py:435-437; deep_and_cross.py:342-344).  g may be
     bfloat16 (widened on load); shadow_bf16 (optional bf16 tensor of the same size) receives the updated
-    parameters rounded to bf16, ready to be the next forward's GEMM operand."""
+    parameters rounded to bf16, ready to be the next forward's GEMM operand.  ftrl1: see _ftrl1."""
     _need_cuda(p, m, v, g, shadow_bf16)
     n = _flat_same(p, m, v)
+    if ftrl1 is not None:
+        if shadow_bf16 is not None or g.dtype != torch.float32 or g.numel() != n or not g.is_contiguous():
+            raise TypeError("dense_adam_(ftrl1=...): contiguous float32 gradient, no shadow")
+        f = _ftrl1(ftrl1)
+        _lib.call("mrec_dense_adam_one_ftrl_f32", _ptr(p), _ptr(m), _ptr(v), _ptr(g), n, lr, beta1, beta2, eps, beta1_power,
+                  beta2_power, grad_scale, int(use_nesterov), C.cast(C.pointer(f), C.c_void_p), _stream())
+        return
     if g.numel() != n or not g.is_contiguous() or g.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("dense gradient must be contiguous float32 or bfloat16 of the parameter's size")
     if shadow_bf16 is not None and (shadow_bf16.dtype != torch.bfloat16 or shadow_bf16.numel() != n
@@ -1342,7 +1360,7 @@ def sum_slab_segments_(g, slabs):
 
 
 def dense_adam_slabs_(p, m, v, g, slabs, shadow16=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, beta1_power=0.9,
-                      beta2_power=0.999, grad_scale=1.0, use_nesterov=False, step_state=None):
+                      beta2_power=0.999, grad_scale=1.0, use_nesterov=False, step_state=None, ftrl1=None):
     """dense_adam_ whose gradient is, for some segments, still the fp32 batch slabs of dense_bwd_weight:
     slabs = [(start, tensor [S, ...] fp32)], start = element offset of the segment in the flat buffers; the slabs
     are added in slab order inside the Adam kernel.  shadow16 (bf16 / fp16, optional) receives the updated parameters."""
@@ -1366,10 +1384,12 @@ def dense_adam_slabs_(p, m, v, g, slabs, shadow16=None, lr=1e-3, beta1=0.9, beta
         if part.dtype != torch.float32 or not part.is_contiguous():
             raise TypeError("slabs must be contiguous float32 [S, ...]")
         ptrs[q], starts[q], lens[q], splits[q] = part.data_ptr(), int(start), part[0].numel(), part.shape[0]
-    _lib.call("mrec_dense_adam_slabs_f32", _ptr(p), _ptr(m), _ptr(v), _ptr(g), _ptr(shadow16), kind, n, k,
+    f = _ftrl1(ftrl1) if ftrl1 is not None else None
+    _lib.call("mrec_dense_adam_slabs_one_ftrl_f32", _ptr(p), _ptr(m), _ptr(v), _ptr(g), _ptr(shadow16), kind, n, k,
               C.cast(ptrs, C.c_void_p), C.cast(starts, C.c_void_p), C.cast(lens, C.c_void_p), C.cast(splits, C.c_void_p),
               lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov),
-              _ptr(step_state.buf) if step_state is not None else None, _stream())
+              _ptr(step_state.buf) if step_state is not None else None, C.cast(C.pointer(f), C.c_void_p) if f is not None else None,
+              _stream())
 
 
 # ---- DenseLayer in fp32 on the fp32-input matrix instruction (csrc/mrec_gemm_f32.hip) -----------------------------------

@@ -98,6 +98,27 @@ class DenseNetMixin:
         self._slot = 0
         self._refresh_tail()
 
+    def load_dense_parameters(self, weights, biases, extra=None):
+        """Overwrites the dense net's fp32 master parameters -- weights[i] [in_i, out_i] and biases[i] [out_i] in layer order, the
+        layout of DenseLayer.weight / .bias (wide_and_deep.py:92-93) -- and, optionally, the extra scalar (`wide_b`), then refreshes
+        every copy derived from them (16-bit operand shadow, transposes, the tail launch's fragment order).  Optimizer state is left
+        alone.  How a checkpoint, a fixture or a `mindspore` Cell's parameters get into the engine."""
+        n = len(self.dims) - 1
+        if len(weights) != n or len(biases) != n:
+            raise ValueError(f"load_dense_parameters: {n} layers expected, got {len(weights)} weights and {len(biases)} biases")
+        with torch.no_grad():
+            for i in range(n):
+                W, b = self.dense[2 * i], self.dense[2 * i + 1]
+                w_src = torch.as_tensor(weights[i], dtype=torch.float32).reshape(W.shape)
+                b_src = torch.as_tensor(biases[i], dtype=torch.float32).reshape(b.shape)
+                W.copy_(w_src)
+                b.copy_(b_src)
+            if extra is not None:
+                self.extra_p.copy_(torch.as_tensor(extra, dtype=torch.float32).reshape(1))
+            if self.dense16 is not None:
+                self.dense16_flat.copy_(self.dense_flat.detach())
+        self._refresh_tail()
+
     @staticmethod
     def mfma_net_ok(dims):
         """Shapes the hand-written 16-bit net covers: at least one hidden layer, every width a multiple of 8 (16-byte rows)."""

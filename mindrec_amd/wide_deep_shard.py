@@ -312,10 +312,10 @@ class ShardStepMixin:
         if fused:
             # (the weight-gradient slabs were summed for the all-reduce above; the kernel also refreshes the 16-bit operand shadow)
             k.dense_adam_slabs_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, [], shadow16=self.dense16_flat,
-                                step_state=state, **akw)
+                                step_state=state, ftrl1=self._wb_ftrl, **akw)
             self._refresh_tail()
         else:
-            k.dense_adam_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, **akw)
+            k.dense_adam_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, ftrl1=self._wb_ftrl, **akw)
         self._tock(ev)
         self.last_plan = plan
         return loss.detach()

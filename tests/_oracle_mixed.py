@@ -93,9 +93,15 @@ class OracleMixedEngine:
         self.w5 = self.flat[o5[0]: o5[0] + dims[nl - 1]]
         self.b5 = self.flat[offs[2 * (nl - 1) + 1][0]: offs[2 * (nl - 1) + 1][0] + 1]
         self._offs = offs
-        # "wide" in "Wide_b" is False (wide_and_deep.py:407-411 is case-sensitive): the bias belongs to the deep optimizer
+        # the wide bias belongs to the FTRL optimizer: by the time TrainStepWrap tests `"wide" in params.name` (wide_and_deep.py:407-411)
+        # MindSpore has renamed the Parameter held in the attribute `wide_b` to "<prefix>.wide_b" [EXT]; pinned by the fixtures the
+        # reference's own TrainStepWrap produced (tests/golden/ref_wd_*.npz).  It keeps its slot in the flat buffer; its m / v words
+        # are FTRL's accum / linear.
         self.wide_b = self.flat[n_real: n_real + 1]
         self.wide_b[:] = O.fill_normal(cfg.seed + 3, 1, 1, cfg.init_sigma).ravel()
+        self._wb_ftrl = getattr(cfg, "wide_b_optimizer", "ftrl") == "ftrl"
+        if self._wb_ftrl:
+            self.m[n_real] = cfg.ftrl_initial_accum
         self.b1p = np.float32(1.0); self.b2p = np.float32(1.0)
         self.t = 0                                    # 0-based index of the training step (keys the Dropout masks)
 
@@ -164,8 +170,13 @@ class OracleMixedEngine:
         grad[o] = np.float32(r["gb5"])
         grad[self._wb_off] = np.float32(r["gb5"])           # d loss / d Wide_b = sum of dlogit
         self.last_dense_grad = grad
+        i = self._wb_off
+        keep = [a[i:i + 1].copy() for a in (self.flat, self.m, self.v)]
         O.dense_adam(self.flat, self.m, self.v, grad, lr=cfg.adam_lr, eps=cfg.adam_eps, b1_pow=float(self.b1p), b2_pow=float(self.b2p),
                      grad_scale=inv)
+        if self._wb_ftrl:
+            O.dense_ftrl(keep[0], keep[1], keep[2], grad[i:i + 1].copy(), lr=cfg.ftrl_lr, l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=inv)
+            self.flat[i], self.m[i], self.v[i] = keep[0][0], keep[1][0], keep[2][0]
 
 
     def predict(self, ids, wts):

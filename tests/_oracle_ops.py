@@ -57,9 +57,18 @@ def sparse_ftrl_(var, accum, linear, plan, g, row_scale=None, lr=5e-2, l1=1e-8, 
 
 
 def dense_adam_(p, m, v, g, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, beta1_power=0.9, beta2_power=0.999,
-                grad_scale=1.0, use_nesterov=False):
+                grad_scale=1.0, use_nesterov=False, ftrl1=None):
+    """ftrl1 = (index, lr, l1, l2, lr_power): that element belongs to nn.FTRL (m word = accum, v word = linear)."""
+    if ftrl1 is not None:
+        i = int(ftrl1[0])
+        keep = [a.reshape(-1)[i:i + 1].copy() for a in (_np(p), _np(m), _np(v))]
     O.dense_adam(_np(p), _np(m), _np(v), _np(g), lr=lr, b1=beta1, b2=beta2, eps=eps, b1_pow=beta1_power,
                  b2_pow=beta2_power, grad_scale=grad_scale, nesterov=use_nesterov)
+    if ftrl1 is not None:
+        O.dense_ftrl(keep[0], keep[1], keep[2], _np(g).reshape(-1)[i:i + 1].copy(), lr=ftrl1[1], l1=ftrl1[2], l2=ftrl1[3],
+                     lr_power=ftrl1[4], grad_scale=grad_scale)
+        for a, k in zip((_np(p), _np(m), _np(v)), keep):
+            a.reshape(-1)[i] = k[0]
 
 
 def dense_ftrl_(var, accum, linear, g, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):

@@ -1,0 +1,84 @@
+"""TEST INFRASTRUCTURE: replaying tests/golden/ref_*.npz -- recorded from the REFERENCE's own Python by
+tests/golden/make_ref_fixtures.py -- through the engines.  Shared by the CPU tests (the engines' host logic over the oracle op
+set: does the product's composition equal the reference's?) and the GPU tests (the same over libmrec_hip.so)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return z, json.loads(str(z["cfg"])), json.loads(str(z["composition"]))
+
+
+def row_rel(a, b):
+    den = np.maximum(np.abs(b).max(axis=-1), 1e-30)
+    return float((np.abs(a.astype(np.float64) - b).max(axis=-1) / den).max())
+
+
+def wd_config(cfg, comp, **over):
+    from mindrec_amd.wide_deep import WideDeepConfig
+    kw = dict(vocab_size=cfg["vocab_size"], emb_dim=cfg["emb_dim"], field_size=cfg["field_size"], batch_size=cfg["batch_size"],
+              deep_layer_dim=list(cfg["deep_layer_dim"]), sens=comp["sens"], adam_lr=comp["lr_d"], adam_eps=comp["eps_d"],
+              ftrl_lr=comp["lr_w"], ftrl_l1=comp["l1_w"], ftrl_l2=comp["l2_w"], ftrl_initial_accum=comp["initial_accum_w"],
+              mlp_dtype="fp16" if cfg["use_mixed_precision"] else "fp32", sparse=bool(cfg["sparse"]), l2_coef=comp["l2_coef"],
+              dynamic_embedding=bool(cfg["dynamic_embedding"]),
+              wide_b_optimizer="ftrl" if "wide_b" in comp["weights_w"] else "adam")
+    kw.update(over)
+    return WideDeepConfig(**kw)
+
+
+def wd_load_init(eng, z, dynamic=False):
+    n = len(eng.dims) - 1
+    eng.load_dense_parameters([z[f"init/dense_layer_{i + 1}.weight"] for i in range(n)],
+                              [z[f"init/dense_layer_{i + 1}.bias"] for i in range(n)], extra=z["init/wide_b"])
+    if not dynamic:
+        with torch.no_grad():
+            eng.deep.copy_(torch.from_numpy(z["init/embedding_table"]))
+            eng.wide.copy_(torch.from_numpy(z["init/wide_embeddinglookup.embedding_table"]))
+
+
+def wd_replay(eng, z, dev):
+    losses = []
+    for s in range(z["ids"].shape[0]):
+        ids, wts, label = (torch.from_numpy(z[k][s]).to(dev) for k in ("ids", "wts", "label"))
+        losses.append(float(eng.train_step(ids, wts, label)))
+    return np.array(losses)
+
+
+def wd_dense_state(eng):
+    n = len(eng.dims) - 1
+    out = {}
+    for i in range(n):
+        out[f"dense_layer_{i + 1}.weight"] = eng.dense[2 * i].detach().cpu().numpy()
+        out[f"dense_layer_{i + 1}.bias"] = eng.dense[2 * i + 1].detach().cpu().numpy()
+    out["wide_b"] = eng.wide_b.detach().cpu().numpy()
+    return out
+
+
+# ---- Deep&Cross: engine.dense = [W1, b1, W2, b2, W3 [(h2 + X), 1], b3, cross_w [L, X], cross_b [L, X]] -------------------------
+def dcn_load_init(eng, z):
+    L = eng.cfg.cross_layer_num
+    with torch.no_grad():
+        eng.table.copy_(torch.from_numpy(z["init/deep_embeddinglookup.embedding_table"]))
+        W1, b1, W2, b2, W3, b3, cw, cb = eng.dense
+        for t, k in ((W1, "dense_layer_1.weight"), (b1, "dense_layer_1.bias"), (W2, "dense_layer_2.weight"), (b2, "dense_layer_2.bias"),
+                     (W3, "dense_layer_3.weight"), (b3, "dense_layer_3.bias")):
+            t.copy_(torch.from_numpy(z["init/" + k]).reshape(t.shape))
+        for l in range(L):                           # CrossLayer.cross_weight / cross_bias are [X, 1] (deep_and_cross.py:126-127)
+            cw[l].copy_(torch.from_numpy(z[f"init/cross_layer_{l + 1}.cross_weight"]).reshape(-1))
+            cb[l].copy_(torch.from_numpy(z[f"init/cross_layer_{l + 1}.cross_bias"]).reshape(-1))
+
+
+def dcn_state(eng):
+    W1, b1, W2, b2, W3, b3, cw, cb = (t.detach().cpu().numpy() for t in eng.dense)
+    out = {"deep_embeddinglookup.embedding_table": eng.table.detach().cpu().numpy(), "dense_layer_1.weight": W1, "dense_layer_1.bias": b1,
+           "dense_layer_2.weight": W2, "dense_layer_2.bias": b2, "dense_layer_3.weight": W3, "dense_layer_3.bias": b3}
+    for l in range(eng.cfg.cross_layer_num):
+        out[f"cross_layer_{l + 1}.cross_weight"] = cw[l].reshape(-1, 1)
+        out[f"cross_layer_{l + 1}.cross_bias"] = cb[l].reshape(-1, 1)
+    return out

@@ -1,0 +1,222 @@
+"""BUILD-CONTAINER-ONLY generator of tests/golden/ref_*.npz: runs the REFERENCE's own Python -- unmodified, imported from
+/root/reference -- and records what it computes.
+
+What runs: models/wide_deep/src/wide_and_deep.py (WideDeepModel, NetWithLossClass, TrainStepWrap, PredictWithSigmoid :136-518),
+models/deep_and_cross/src/deep_and_cross.py (DeepCrossModel, NetWithLossClass, TrainStepWrap :206-354),
+mindspore_rec/ops/embedding.py (HashEmbeddingLookup :47-206), mindspore_rec/train/rec_model.py (RecModel :34-309) and the three
+cases of ci/st/online_learning/test_online_learning.py:54-114.
+
+What they run ON: `compat/mindspore` (this repo's own mindspore-named API; MindSpore itself is not installable here) with the
+CPU kernel set tests/_ms_cpu_kernels.py = the oracle's restatements of the primitives.  So the fixtures pin the reference's
+COMPOSITION -- which parameter goes to which optimizer, which hyper-parameters, the op order of construct, the L2 term, the
+sens seeding, the three-forward step -- by the reference's code; the per-primitive formulas underneath (Adam, FTRL, Unique,
+MapTensorGet defaults, initializer streams) stay this repo's restatement of MindSpore's published semantics [EXT].
+
+Nothing under /root/reference travels: only the .npz files written here are committed.  Usage (build container):
+    python tests/golden/make_ref_fixtures.py
+"""
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("MREC_REFERENCE", "/root/reference")
+for p in (os.path.join(ROOT, "tests"), ROOT, os.path.join(ROOT, "compat"), REF):
+    if p not in sys.path:
+        sys.path.insert(0, p)                   # REF first: `mindspore_rec` resolves to the REFERENCE's package
+
+import mindspore  # noqa: E402
+from mindspore import Tensor, context  # noqa: E402
+
+import _ms_cpu_kernels  # noqa: E402
+
+mindspore._kernels._install(_ms_cpu_kernels)
+context.set_context(mode=context.GRAPH_MODE, device_target="CPU")
+
+import mindspore_rec  # noqa: E402
+
+assert mindspore_rec.__file__.startswith(REF), mindspore_rec.__file__
+
+
+def _ref_module(model_dir, name):
+    """Imports <REF>/models/<model_dir>/src/<name>.py as its own package tree (both models call their package `src`)."""
+    for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        del sys.modules[k]
+    sys.path.insert(0, os.path.join(REF, "models", model_dir))
+    try:
+        return importlib.import_module("src." + name)
+    finally:
+        sys.path.pop(0)
+
+
+def _np(t):
+    return t.asnumpy().copy() if hasattr(t, "asnumpy") else np.asarray(t)
+
+
+def _batches(rng, S, B, F, V, keys=None):
+    """Criteo-like: the first 3 fields are the constants 0..2 with fractional weights (datasets/criteo_1tb/process_data.py:138-147),
+    the rest Zipf-distributed categorical ids with weight 1 (:149-162)."""
+    ids = np.minimum(rng.zipf(1.3, size=(S, B, F)) + 2, V - 1).astype(np.int32)
+    ids[:, :, :3] = np.arange(3, dtype=np.int32)
+    wts = np.ones((S, B, F), np.float32)
+    wts[:, :, :3] = rng.random((S, B, 3)).astype(np.float32)
+    label = (rng.random((S, B, 1)) < 0.3).astype(np.float32)
+    if keys is not None:
+        ids = keys(ids)
+    return ids, wts, label
+
+
+def wide_deep_case(name, S=3, mixed=False, key_dtype=np.int32, **mode):
+    wd = _ref_module("wide_deep", "wide_and_deep")
+    cfg = types.SimpleNamespace(batch_size=64, field_size=9, emb_dim=8, vocab_size=3000, vocab_cache_size=0,
+                                deep_layer_dim=[32, 16, 16, 8], deep_layer_act="relu", keep_prob=1.0, dropout_flag=False,
+                                use_mixed_precision=bool(mixed), parameter_server=0, sparse=False, dynamic_embedding=False,
+                                weight_bias_init=["normal", "normal"], emb_init="normal", init_args=[-0.01, 0.01], l2_coef=8e-5,
+                                full_batch=False, field_slice=False)
+    for k, v in mode.items():
+        setattr(cfg, k, v)
+    mindspore.set_seed(1000)
+    net = wd.WideDeepModel(cfg)
+    loss_net = wd.NetWithLossClass(net, cfg)
+    train = wd.TrainStepWrap(loss_net, parameter_server=bool(cfg.parameter_server), sparse=cfg.sparse,
+                             dynamic_embedding=cfg.dynamic_embedding)
+    evaln = wd.PredictWithSigmoid(net)
+    train.set_train()
+    out = {}
+    struct = dict(net.parameters_and_names())
+    dyn = bool(cfg.dynamic_embedding)
+    comp = {"optimizer_w": type(train.optimizer_w).__name__, "optimizer_d": type(train.optimizer_d).__name__,
+            "weights_w": sorted(k for k, p in struct.items() if any(p is q for q in train.weights_w)),
+            "weights_d": sorted(k for k, p in struct.items() if any(p is q for q in train.weights_d)),
+            "sens": float(train.sens), "lr_d": train.optimizer_d.get_lr(), "lr_w": train.optimizer_w.get_lr(),
+            "eps_d": train.optimizer_d.eps, "l1_w": train.optimizer_w.l1, "l2_w": train.optimizer_w.l2,
+            "initial_accum_w": train.optimizer_w.initial_accum, "loss_scale_d": train.optimizer_d.loss_scale,
+            "no_l2loss": bool(loss_net.no_l2loss), "l2_coef": float(loss_net.l2_coef)}
+    rng = np.random.default_rng(20240 + len(name))
+    keys = (lambda i: (i.astype(np.int64) * 2654435761 + 17).astype(key_dtype) if key_dtype == np.int64 else i * 7 + 100) if dyn else None
+    ids, wts, label = _batches(rng, S, cfg.batch_size, cfg.field_size, cfg.vocab_size, keys)
+    for k, p in struct.items():
+        if not dyn or "embedding_table" not in k:
+            out["init/" + k] = _np(p)
+    if dyn:
+        out["deep_seed"], out["wide_seed"] = np.int64(net.deep_embeddinglookup.embedding_table.seed), np.int64(net.wide_embeddinglookup.embedding_table.seed)
+        assert int(out["wide_seed"]) == int(out["deep_seed"]) + 1
+    lw, ld = [], []
+    for s in range(S):
+        a, b = train(Tensor(ids[s]), Tensor(wts[s]), Tensor(label[s]))
+        lw.append(float(_np(a)))
+        ld.append(float(_np(b)))
+    evaln.set_train(False)
+    logits, probs, _ = evaln(Tensor(ids[S - 1]), Tensor(wts[S - 1]), Tensor(label[S - 1]))
+    for k, p in struct.items():
+        if dyn and "embedding_table" in k:
+            kk, vv = p.get_data()
+            order = np.argsort(_np(kk))
+            out["final/" + k + "::keys"], out["final/" + k + "::values"] = _np(kk)[order], _np(vv)[order]
+        else:
+            out["final/" + k] = _np(p)
+    for opt, slots in ((train.optimizer_d, ("moment1", "moment2")), (train.optimizer_w, ("accum", "linear"))):
+        for k, p in struct.items():
+            if any(p is q for q in opt.parameters) and not (dyn and "embedding_table" in k):
+                for sl in slots:
+                    out[f"state/{sl}/{k}"] = _np(opt._slot(p, sl, 0.0))
+    out.update(ids=ids, wts=wts, label=label, loss_w=np.array(lw, np.float64), loss_d=np.array(ld, np.float64),
+               eval_logits=_np(logits), eval_probs=_np(probs),
+               cfg=np.array(json.dumps({k: v for k, v in vars(cfg).items()})), composition=np.array(json.dumps(comp)))
+    _save(name, out)
+    return comp
+
+
+def deep_cross_case(name, S=3):
+    dcn = _ref_module("deep_and_cross", "deep_and_cross")
+    cfg = types.SimpleNamespace(batch_size=64, field_size=5, emb_dim=6, vocab_size=400, deep_layer_dim=[16, 8], cross_layer_num=6,
+                                keep_prob=1.0)
+    mindspore.set_seed(1000)
+    net = dcn.DeepCrossModel(cfg)
+    loss_net = dcn.NetWithLossClass(net)
+    train = dcn.TrainStepWrap(loss_net)                       # lr 1e-4, eps 1e-8, loss_scale 1000 (deep_and_cross.py:336)
+    evaln = dcn.PredictWithSigmoid(net)
+    train.set_train()
+    struct = dict(net.parameters_and_names())
+    out = {"init/" + k: _np(p) for k, p in struct.items()}
+    rng = np.random.default_rng(77)
+    ids, wts, label = _batches(rng, S, cfg.batch_size, cfg.field_size, cfg.vocab_size)
+    losses = [float(_np(train(Tensor(ids[s]), Tensor(wts[s]), Tensor(label[s])))) for s in range(S)]
+    evaln.set_train(False)
+    logits, probs, _ = evaln(Tensor(ids[S - 1]), Tensor(wts[S - 1]), Tensor(label[S - 1]))
+    for k, p in struct.items():
+        out["final/" + k] = _np(p)
+    comp = {"optimizer": type(train.optimizer).__name__, "lr": train.optimizer.get_lr(), "eps": train.optimizer.eps,
+            "loss_scale": train.optimizer.loss_scale, "sens": float(train.sens), "weights": list(struct)}
+    out.update(ids=ids, wts=wts, label=label, loss=np.array(losses, np.float64), eval_logits=_np(logits), eval_probs=_np(probs),
+               cfg=np.array(json.dumps(vars(cfg))), composition=np.array(json.dumps(comp)))
+    _save(name, out)
+    return comp
+
+
+def hash_lookup_case(name):
+    """HashEmbeddingLookup.construct alone (embedding.py:184-206): sparse True / False, int32 / int64 keys, max_norm."""
+    from mindspore_rec import HashEmbeddingLookup
+    out = {}
+    rng = np.random.default_rng(5)
+    variants = []
+    for i, (kd, sparse, max_norm, D) in enumerate([(mindspore.int32, True, None, 8), (mindspore.int64, True, None, 16),
+                                                   (mindspore.int32, False, None, 8), (mindspore.int64, True, 0.02, 8)]):
+        mindspore.set_seed(300 + i)
+        layer = HashEmbeddingLookup(embedding_size=D, key_dtype=kd, sparse=sparse, max_norm=max_norm)
+        npd = np.int32 if kd == mindspore.int32 else np.int64
+        raw = rng.integers(0, 60, size=(2, 11, 4))
+        keys = (raw * 9 + 1000).astype(npd) if npd == np.int32 else (raw.astype(np.int64) * (2**33 + 5) - 2**40)
+        ys = [_np(layer(Tensor(keys[c]))) for c in range(2)]
+        k, v = layer.embedding_table.get_data()
+        order = np.argsort(_np(k))
+        out[f"v{i}/keys"], out[f"v{i}/out0"], out[f"v{i}/out1"] = keys, ys[0], ys[1]
+        out[f"v{i}/table_keys"], out[f"v{i}/table_values"] = _np(k)[order], _np(v)[order]
+        variants.append({"key_dtype": str(kd), "sparse": sparse, "max_norm": max_norm, "D": D, "seed": int(layer.embedding_table.seed)})
+    out["variants"] = np.array(json.dumps(variants))
+    _save(name, out)
+
+
+def online_learning_ci():
+    """ci/st/online_learning/test_online_learning.py:54-114 through the reference's RecModel (it asks for device_target "GPU":
+    tensors are kept on the host by the test hook, the argument checks under test never touch a tensor)."""
+    import importlib.util
+    context._host_tensors = True
+    try:
+        spec = importlib.util.spec_from_file_location("ref_ci_online_learning", os.path.join(REF, "ci/st/online_learning/test_online_learning.py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        ran = []
+        for n in sorted(dir(m)):
+            if n.startswith("test_"):
+                getattr(m, n)()
+                ran.append(n)
+    finally:
+        context._host_tensors = False
+        context.set_context(device_target="CPU")
+    return ran
+
+
+def _save(name, arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KB, {len(arrays)} arrays")
+
+
+if __name__ == "__main__":
+    report = {"reference_ci_cases_passed": online_learning_ci()}
+    report["ref_wd_dense"] = wide_deep_case("ref_wd_dense")                                               # the default: sparse False
+    report["ref_wd_sparse"] = wide_deep_case("ref_wd_sparse", sparse=True, parameter_server=1)             # LazyAdam + FTRL on RowTensors
+    report["ref_wd_dynamic"] = wide_deep_case("ref_wd_dynamic", sparse=True, dynamic_embedding=True)       # HashEmbeddingLookup x2
+    report["ref_wd_dynamic_i64"] = None
+    report["ref_wd_mixed"] = wide_deep_case("ref_wd_mixed", mixed=True, sparse=True, parameter_server=1)   # fp16 DenseLayers
+    report["ref_dcn"] = deep_cross_case("ref_dcn")
+    hash_lookup_case("ref_hash_lookup")
+    with open(os.path.join(HERE, "ref_composition.json"), "w") as f:
+        json.dump(report, f, indent=1, sort_keys=True)
+    print(json.dumps(report, indent=1, sort_keys=True))

@@ -1,0 +1,132 @@
+"""CPU: the fixtures the REFERENCE's own Python produced (tests/golden/ref_*.npz, make_ref_fixtures.py) against (a) the
+product engines' HOST logic driven by the oracle op set -- is the engines' composition (optimizer split, hyper-parameters, L2
+term, sens, op order) the reference's? -- and (b) this repo's own `mindspore_rec` package over compat/mindspore with the same
+CPU kernel set -- does it compute what the reference's package computes?  The GPU twin is tests/test_ref_fixtures_gpu.py."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _ref_fixtures as RF  # noqa: E402
+
+
+def test_reference_composition_record():
+    """What the reference's TrainStepWrap did with its parameters when it ran over compat/mindspore (ref_composition.json)."""
+    with open(os.path.join(RF.GOLDEN, "ref_composition.json")) as f:
+        rep = json.load(f)
+    assert sorted(rep["reference_ci_cases_passed"]) == ["test_online_learning_api_data_sink_mode_not_bool",
+                                                        "test_online_learning_api_sink_size_is_negative",
+                                                        "test_online_learning_api_sink_size_not_equal_one"]
+    for case, opt_d in (("ref_wd_dense", "Adam"), ("ref_wd_sparse", "LazyAdam"), ("ref_wd_dynamic", "LazyAdam"), ("ref_wd_mixed", "LazyAdam")):
+        c = rep[case]
+        assert c["optimizer_d"] == opt_d and c["optimizer_w"] == "FTRL"
+        assert c["weights_w"] == ["wide_b", "wide_embeddinglookup.embedding_table"]          # the wide bias belongs to FTRL
+        assert (c["sens"], c["lr_d"], c["eps_d"], c["lr_w"], c["l1_w"], c["l2_w"], c["initial_accum_w"]) == (1024.0, 3.5e-4, 1e-8, 5e-2, 1e-8, 1e-8, 1.0)
+    assert rep["ref_wd_dense"]["no_l2loss"] is False and rep["ref_wd_sparse"]["no_l2loss"] is True
+    assert (rep["ref_dcn"]["optimizer"], rep["ref_dcn"]["lr"], rep["ref_dcn"]["loss_scale"]) == ("Adam", 1e-4, 1000.0)
+
+
+@pytest.mark.parametrize("case", ["ref_wd_sparse", "ref_wd_dense"])
+def test_wide_deep_engine_host_logic_matches_reference(oracle, case):
+    from _oracle_engine import OracleWideDeepEngine
+    z, cfg, comp = RF.load(case)
+    eng = OracleWideDeepEngine(RF.wd_config(cfg, comp), "cpu")
+    RF.wd_load_init(eng, z)
+    losses = RF.wd_replay(eng, z, "cpu")
+    assert np.allclose(losses, z["loss_w"], rtol=2e-6, atol=0), (losses, z["loss_w"])
+    if not cfg["sparse"]:
+        dl = np.array([eng.deep_loss(losses[-1])])       # the deep optimizer's loss carries the L2 term (wide_and_deep.py:356-360)
+        assert dl[0] > losses[-1]
+    assert RF.row_rel(eng.deep.numpy(), z["final/embedding_table"]) <= 1e-5
+    w_ref = z["final/wide_embeddinglookup.embedding_table"]
+    assert np.abs(eng.wide.numpy() - w_ref).max() <= 1e-4 * np.abs(w_ref).max()
+    for k, v in RF.wd_dense_state(eng).items():
+        assert np.allclose(v, z["final/" + k], rtol=1e-4, atol=1e-7), k
+    # optimizer state: Adam moments of the deep table, FTRL accumulators of the wide table and of wide_b
+    assert np.allclose(eng.deep_m.numpy(), z["state/moment1/embedding_table"], rtol=1e-4, atol=1e-9)
+    assert np.allclose(eng.wide_accum.numpy(), z["state/accum/wide_embeddinglookup.embedding_table"], rtol=1e-5, atol=0)
+    assert np.allclose(float(eng.dense_m[eng._wb_off]), float(z["state/accum/wide_b"][0]), rtol=1e-5)
+
+
+def test_deep_cross_engine_host_logic_matches_reference(oracle):
+    from _oracle_engine import OracleDeepCrossEngine
+    from mindrec_amd.deep_cross import DeepCrossConfig
+    z, cfg, comp = RF.load("ref_dcn")
+    eng = OracleDeepCrossEngine(DeepCrossConfig(vocab_size=cfg["vocab_size"], emb_dim=cfg["emb_dim"], field_size=cfg["field_size"],
+                                                batch_size=cfg["batch_size"], deep_layer_dim=list(cfg["deep_layer_dim"]),
+                                                cross_layer_num=cfg["cross_layer_num"]), "cpu")
+    RF.dcn_load_init(eng, z)
+    losses = np.array([float(eng.train_step(*(torch.from_numpy(z[k][s]) for k in ("ids", "wts", "label")))) for s in range(z["ids"].shape[0])])
+    assert np.allclose(losses, z["loss"], rtol=2e-6, atol=0), (losses, z["loss"])
+    for k, v in RF.dcn_state(eng).items():
+        assert np.allclose(v, z["final/" + k], rtol=2e-4, atol=1e-7), k
+
+
+# ---- this repo's own mindspore_rec + a mindspore-style script over compat/mindspore, CPU kernel set -------------------------------
+@pytest.fixture
+def ms_cpu(oracle):
+    """compat/ on the path, host tensors, the oracle-backed kernel set installed for the duration of one test."""
+    compat = os.path.join(os.path.dirname(RF.GOLDEN.rstrip("/")), "..", "compat")
+    sys.path.insert(0, os.path.abspath(compat))
+    import mindspore
+    from mindspore import context
+    import _ms_cpu_kernels
+    prev = mindspore._kernels._install(_ms_cpu_kernels)
+    prev_target = context.get_context("device_target")
+    context.set_context(device_target="CPU")
+    yield mindspore
+    context.set_context(device_target=prev_target)
+    mindspore._kernels._install(prev)
+
+
+def test_own_hash_embedding_lookup_matches_reference_package(ms_cpu):
+    """compat/mindspore_rec.HashEmbeddingLookup (one fused MapTensorGet) == the reference's Unique -> MapTensorGet -> Gather chain
+    (mindspore_rec/ops/embedding.py:184-206) recorded in ref_hash_lookup.npz: outputs, inserted keys and rows, bit for bit."""
+    import mindspore_rec
+    assert "compat" in mindspore_rec.__file__
+    z = np.load(os.path.join(RF.GOLDEN, "ref_hash_lookup.npz"))
+    for i, v in enumerate(json.loads(str(z["variants"]))):
+        kd = ms_cpu.int32 if "int32" in v["key_dtype"] else ms_cpu.int64
+        ms_cpu.set_seed(300 + i)
+        layer = mindspore_rec.HashEmbeddingLookup(embedding_size=v["D"], key_dtype=kd, sparse=v["sparse"], max_norm=v["max_norm"])
+        assert layer.embedding_table.seed == v["seed"]
+        for c in range(2):
+            out = layer(ms_cpu.Tensor(z[f"v{i}/keys"][c])).asnumpy()
+            ref = z[f"v{i}/out{c}"]
+            assert out.shape == ref.shape
+            assert np.array_equal(out, ref) if v["max_norm"] is None else np.allclose(out, ref, rtol=1e-6, atol=0)
+        k, vals = layer.embedding_table.get_data()
+        order = np.argsort(k.asnumpy())
+        assert np.array_equal(k.asnumpy()[order], z[f"v{i}/table_keys"]) and np.array_equal(vals.asnumpy()[order], z[f"v{i}/table_values"])
+
+
+@pytest.mark.parametrize("case", ["ref_wd_sparse", "ref_wd_dense", "ref_wd_dynamic", "ref_wd_mixed"])
+def test_mindspore_style_script_matches_reference(ms_cpu, case):
+    """A Wide&Deep train step written against the compat surface (tests/_ms_models.py, own code) reproduces what the reference's
+    model code computed, including hash tables created on first sight (ref_wd_dynamic) and the fp16 DenseLayers (ref_wd_mixed)."""
+    import _ms_models
+    z, cfg, comp = RF.load(case)
+    if cfg["dynamic_embedding"]:
+        ms_cpu.set_seed(1000)
+        from mindspore.common import initializer as I
+        I._state["calls"] = int(z["deep_seed"]) - (1000 * 1_000_003) - 1        # the next table takes the fixture's seed
+    step, net = _ms_models.wide_deep_from_fixture(z, cfg, comp)
+    assert sorted(p.name.split(".")[-1] + "@" + p.name.split(".")[-2] for p in step.w_wide) == ["embedding_table@wide_table", "wide_bias@net"]
+    losses = []
+    for s in range(z["ids"].shape[0]):
+        lw, ld = step(ms_cpu.Tensor(z["ids"][s]), ms_cpu.Tensor(z["wts"][s]), ms_cpu.Tensor(z["label"][s]))
+        losses.append((float(lw.asnumpy()), float(ld.asnumpy())))
+    losses = np.array(losses)
+    assert np.allclose(losses[:, 0], z["loss_w"], rtol=1e-6, atol=0) and np.allclose(losses[:, 1], z["loss_d"], rtol=1e-6, atol=0)
+    assert np.allclose(net.wide_bias.asnumpy(), z["final/wide_b"], rtol=1e-5, atol=1e-9)
+    if cfg["dynamic_embedding"]:
+        k, v = net.deep_table.embedding_table.get_data()
+        order = np.argsort(k.asnumpy())
+        assert np.array_equal(k.asnumpy()[order], z["final/embedding_table::keys"])
+        assert RF.row_rel(v.asnumpy()[order], z["final/embedding_table::values"]) <= 1e-5
+    else:
+        assert RF.row_rel(net.deep_table.embedding_table.asnumpy(), z["final/embedding_table"]) <= 1e-5

@@ -1,0 +1,167 @@
+"""GPU: the fixtures recorded from the REFERENCE's own Python (tests/golden/ref_*.npz; generator make_ref_fixtures.py, which
+ran models/wide_deep/src/wide_and_deep.py, models/deep_and_cross/src/deep_and_cross.py and mindspore_rec/ unmodified over
+compat/mindspore with the oracle's primitives) replayed on an MI355X:
+
+  (1) through the fused engines (WideDeepEngine / DeepCrossEngine: the benchmarked product path, HIP kernels + HIP graphs),
+  (2) through compat/mindspore on the HIP kernel set, driven by this repo's own mindspore_rec package and a mindspore-style
+      script (tests/_ms_models.py) -- the reference's sources cannot travel to the GPU box.
+
+Bars (north_star): keys / dedup bit-exact; fp32 embedding rows 1e-5 row-relative; losses 2e-6 (fp32 nets); the fp16 net is
+compared within the reference's own double rounding (wide_and_deep.py:121-126 rounds the MatMul output and the bias sum
+separately, the kernels round once)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _ref_fixtures as RF  # noqa: E402
+
+
+def _check_wd_engine(eng, z, cfg, losses, rows_tol=1e-5, dense_rtol=1e-4, loss_rtol=2e-6, wide_tol=1e-4):
+    assert np.allclose(losses, z["loss_w"], rtol=loss_rtol, atol=0), (losses, z["loss_w"])
+    for k, v in RF.wd_dense_state(eng).items():
+        assert np.allclose(v, z["final/" + k], rtol=dense_rtol, atol=dense_rtol * 1e-3), k
+    if cfg["dynamic_embedding"]:
+        keys, rows = eng.index.export()
+        keys, rows = keys.cpu().numpy(), rows.cpu().numpy().astype(np.int64)
+        order = np.argsort(keys)
+        assert np.array_equal(keys[order], z["final/embedding_table::keys"].astype(np.int64))          # the same keys were created
+        assert np.array_equal(keys[order], z["final/wide_embeddinglookup.embedding_table::keys"].astype(np.int64))
+        deep = eng.deep.cpu().numpy()[rows[order]]
+        wide = eng.wide.cpu().numpy()[rows[order]]
+        ref_d, ref_w = z["final/embedding_table::values"], z["final/wide_embeddinglookup.embedding_table::values"]
+    else:
+        deep, wide = eng.deep.cpu().numpy(), eng.wide.cpu().numpy()
+        ref_d, ref_w = z["final/embedding_table"], z["final/wide_embeddinglookup.embedding_table"]
+    assert RF.row_rel(deep, ref_d) <= rows_tol, RF.row_rel(deep, ref_d)
+    assert np.abs(wide - ref_w).max() <= wide_tol * np.abs(ref_w).max()
+
+
+@pytest.mark.parametrize("case", ["ref_wd_sparse", "ref_wd_dense", "ref_wd_dynamic"])
+@pytest.mark.parametrize("graphs", ["step", "none"])
+def test_wide_deep_engine_replays_reference_fixture(dev, case, graphs):
+    from mindrec_amd.wide_deep import WideDeepEngine
+    z, cfg, comp = RF.load(case)
+    over = dict(graphs=graphs, hash_capacity=1 << 12)
+    if cfg["dynamic_embedding"]:
+        over["seed"] = int(z["deep_seed"])              # default rows are a function of (seed, key): deep = seed, wide = seed + 1
+    eng = WideDeepEngine(RF.wd_config(cfg, comp, **over), dev)
+    RF.wd_load_init(eng, z, dynamic=bool(cfg["dynamic_embedding"]))
+    losses = RF.wd_replay(eng, z, dev)
+    _check_wd_engine(eng, z, cfg, losses)
+    if not cfg["dynamic_embedding"]:
+        untouched = np.ones(cfg["vocab_size"], bool)
+        untouched[z["ids"].reshape(-1)] = False
+        if cfg["sparse"]:                                   # lazy: rows the batches never touched are bit-identical to their initial values
+            assert np.array_equal(eng.deep.cpu().numpy()[untouched], z["init/embedding_table"][untouched])
+        assert np.allclose(eng.deep_m.cpu().numpy(), z["state/moment1/embedding_table"], rtol=1e-4, atol=1e-9)
+        assert np.allclose(eng.wide_accum.cpu().numpy(), z["state/accum/wide_embeddinglookup.embedding_table"], rtol=1e-5, atol=0)
+    # PredictWithSigmoid on the last batch (wide_and_deep.py:495-518)
+    ids, wts = (torch.from_numpy(z[k][-1]).to(dev) for k in ("ids", "wts"))
+    logit, prob = eng.predict(ids, wts)
+    assert np.allclose(logit.cpu().numpy().reshape(-1), z["eval_logits"].reshape(-1), rtol=1e-4, atol=1e-6)
+    assert np.allclose(prob.cpu().numpy().reshape(-1), z["eval_probs"].reshape(-1), rtol=1e-5, atol=1e-7)
+
+
+def test_wide_deep_engine_fp16_net_against_the_reference_fp16_run(dev):
+    """use_mixed_precision=True (default_config.yaml:28), the benchmarked arithmetic.  The reference's DenseLayer rounds the fp16
+    MatMul output, then the fp16 bias sum; the kernels add an fp32 bias to the fp32 accumulator and round once (DESIGN.md
+    section 2): at most an fp16 ulp per activation, so the two runs are compared at 5e-4 on the loss, 2e-3 on touched rows."""
+    from mindrec_amd.wide_deep import WideDeepEngine
+    z, cfg, comp = RF.load("ref_wd_mixed")
+    eng = WideDeepEngine(RF.wd_config(cfg, comp), dev)
+    assert eng._mfma
+    RF.wd_load_init(eng, z)
+    losses = RF.wd_replay(eng, z, dev)
+    assert np.allclose(losses, z["loss_w"], rtol=5e-4, atol=0), (losses, z["loss_w"])
+    touched = np.zeros(cfg["vocab_size"], bool)
+    touched[z["ids"].reshape(-1)] = True
+    deep, ref = eng.deep.cpu().numpy(), z["final/embedding_table"]
+    assert np.array_equal(deep[~touched], ref[~touched])
+    step = np.abs(ref[touched] - z["init/embedding_table"][touched]).max()
+    assert np.abs(deep[touched] - ref[touched]).max() <= 0.05 * step          # the updates agree to 5 % of their own size (Adam's sign-like first steps)
+
+
+def test_deep_cross_engine_replays_reference_fixture(dev):
+    from mindrec_amd.deep_cross import DeepCrossConfig, DeepCrossEngine
+    z, cfg, comp = RF.load("ref_dcn")
+    eng = DeepCrossEngine(DeepCrossConfig(vocab_size=cfg["vocab_size"], emb_dim=cfg["emb_dim"], field_size=cfg["field_size"],
+                                          batch_size=cfg["batch_size"], deep_layer_dim=list(cfg["deep_layer_dim"]),
+                                          cross_layer_num=cfg["cross_layer_num"], learning_rate=comp["lr"], eps=comp["eps"],
+                                          loss_scale=comp["loss_scale"]), dev)
+    assert eng._native
+    RF.dcn_load_init(eng, z)
+    losses = np.array([float(eng.train_step(*(torch.from_numpy(z[k][s]).to(dev) for k in ("ids", "wts", "label"))))
+                       for s in range(z["ids"].shape[0])])
+    assert np.allclose(losses, z["loss"], rtol=2e-6, atol=0), (losses, z["loss"])
+    for k, v in RF.dcn_state(eng).items():
+        assert np.allclose(v, z["final/" + k], rtol=2e-4, atol=1e-7), k
+    logit, prob = eng.predict(*(torch.from_numpy(z[k][-1]).to(dev) for k in ("ids", "wts")))
+    assert np.allclose(logit.cpu().numpy().reshape(-1), z["eval_logits"].reshape(-1), rtol=1e-4, atol=1e-6)
+
+
+# ---- compat/mindspore on the HIP kernel set ---------------------------------------------------------------------------------------
+@pytest.fixture
+def ms_hip(dev):
+    compat = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "compat"))
+    if compat not in sys.path:
+        sys.path.insert(0, compat)
+    import mindspore
+    from mindspore import context
+    from mindspore import _hip_kernels
+    prev = mindspore._kernels._install(_hip_kernels)          # (a CPU test of the same session may have left its own set installed)
+    context.set_context(mode=context.GRAPH_MODE, device_target="GPU", device_id=0)
+    yield mindspore
+    mindspore._kernels._install(prev)
+
+
+def test_hash_embedding_lookup_on_hip_matches_reference_package(ms_hip):
+    import mindspore_rec
+    z = np.load(os.path.join(RF.GOLDEN, "ref_hash_lookup.npz"))
+    for i, v in enumerate(json.loads(str(z["variants"]))):
+        kd = ms_hip.int32 if "int32" in v["key_dtype"] else ms_hip.int64
+        ms_hip.set_seed(300 + i)
+        layer = mindspore_rec.HashEmbeddingLookup(embedding_size=v["D"], key_dtype=kd, sparse=v["sparse"], max_norm=v["max_norm"], capacity=4096)
+        assert layer.embedding_table.seed == v["seed"]
+        for c in range(2):
+            out = layer(ms_hip.Tensor(z[f"v{i}/keys"][c]))
+            assert out.is_cuda
+            ref = z[f"v{i}/out{c}"]
+            assert np.array_equal(out.asnumpy(), ref) if v["max_norm"] is None else np.allclose(out.asnumpy(), ref, rtol=1e-6, atol=0)
+        k, vals = layer.embedding_table.get_data()
+        order = np.argsort(k.asnumpy())
+        assert np.array_equal(k.asnumpy()[order], z[f"v{i}/table_keys"]) and np.array_equal(vals.asnumpy()[order], z[f"v{i}/table_values"])
+
+
+@pytest.mark.parametrize("case", ["ref_wd_sparse", "ref_wd_dense", "ref_wd_dynamic", "ref_wd_mixed"])
+def test_mindspore_style_script_on_hip_matches_reference(ms_hip, case):
+    import _ms_models
+    z, cfg, comp = RF.load(case)
+    if cfg["dynamic_embedding"]:
+        ms_hip.set_seed(1000)
+        from mindspore.common import initializer as I
+        I._state["calls"] = int(z["deep_seed"]) - (1000 * 1_000_003) - 1
+    step, net = _ms_models.wide_deep_from_fixture(z, cfg, comp, capacity=4096)
+    losses = []
+    for s in range(z["ids"].shape[0]):
+        lw, ld = step(ms_hip.Tensor(z["ids"][s]), ms_hip.Tensor(z["wts"][s]), ms_hip.Tensor(z["label"][s]))
+        assert lw.is_cuda
+        losses.append((float(lw.asnumpy()), float(ld.asnumpy())))
+    losses = np.array(losses)
+    mixed = bool(cfg["use_mixed_precision"])
+    assert np.allclose(losses[:, 0], z["loss_w"], rtol=5e-5 if mixed else 2e-6, atol=0), (losses[:, 0], z["loss_w"])
+    assert np.allclose(losses[:, 1], z["loss_d"], rtol=5e-5 if mixed else 2e-6, atol=0)
+    assert np.allclose(net.wide_bias.asnumpy(), z["final/wide_b"], rtol=1e-4, atol=1e-8)
+    if cfg["dynamic_embedding"]:
+        k, v = net.deep_table.embedding_table.get_data()
+        order = np.argsort(k.asnumpy())
+        assert np.array_equal(k.asnumpy()[order], z["final/embedding_table::keys"])
+        if not mixed:
+            assert RF.row_rel(v.asnumpy()[order], z["final/embedding_table::values"]) <= 1e-5
+    elif not mixed:
+        assert RF.row_rel(net.deep_table.embedding_table.asnumpy(), z["final/embedding_table"]) <= 1e-5
