@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--capacity-factor", type=float, default=None, help="row shards: request slots per owner = ceil(factor * ids / ranks); "
                     "default 1.05 for uniform ids (an owner's share of 425 984 uniform ids is within 0.6 %% of the mean at 12 sigma for 8 ranks), "
                     "1.25 otherwise (the engine's default); a run that drops a position is refused")
+    ap.add_argument("--comm-timeout", type=int, default=180, help="seconds after which a rendezvous or a collective that a peer never joined "
+                    "raises instead of hanging")
     ap.add_argument("--no-zipf39", action="store_true", help="skip the secondary Criteo-like measurement (Zipf ids, 39 fields) behind the timed region")
     args = ap.parse_args()
     if args.capacity_factor is None:
@@ -288,13 +290,50 @@ def main():
     if world > 1 or args.shard_protocol:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)          # "nccl" IS RCCL on ROCm
+        # "nccl" IS RCCL on ROCm.  The timeout bounds the rendezvous AND every later collective: a rank that died leaves its
+        # peers with an error after --comm-timeout seconds instead of a hang (the launcher then takes the job down, exit code != 0)
+        import datetime
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=args.comm_timeout))
 
+    eng = None
+    try:
+        out = _measure(args, world, rank, dev)
+    except BaseException as e:      # noqa: BLE001  (SystemExit included: every exit path releases the graphs that hold RCCL kernels)
+        if world > 1 or args.shard_protocol:
+            print(f"[bench rank {rank}] {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        raise
+    finally:
+        if world > 1 or args.shard_protocol:
+            try:
+                for e_ in list(_ENGINES):
+                    e_.release_graphs()           # graphs that hold RCCL kernels must go before the process group does
+                _ENGINES.clear()
+                dist.destroy_process_group()
+            except Exception as e:      # noqa: BLE001
+                print(f"[bench rank {rank}] teardown: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+    if rank == 0:
+        # the LAST line of stdout: whatever the communication library has printf'd into the C runtime's buffer (RCCL announces
+        # the path it was loaded from) comes out first
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
+
+
+_ENGINES = []
+
+
+def _measure(args, world, rank, dev):
+    import torch
+    import torch.distributed as dist
+    from mindrec_amd import ops
+    from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, embedding_bytes, synthetic_batch
     cfg = WideDeepConfig(vocab_size=args.vocab, emb_dim=args.emb_dim, field_size=args.fields, batch_size=args.batch,
                          mlp_dtype=args.mlp_dtype, fused_state=not args.split_state, graphs=args.graphs,
                          dynamic_embedding=args.dynamic_embedding, hash_capacity=args.hash_capacity,
                          host_cache_rows=args.host_cache_rows, shard_capacity_factor=args.capacity_factor, dropout_flag=args.dropout)
     eng = WideDeepEngine(cfg, dev, rank=rank, world=world, shard_protocol=args.shard_protocol)
+    _ENGINES.append(eng)
     batches = [synthetic_batch(cfg, dev, args.dist, seed=1000 + i, rank=rank) for i in range(args.n_batches)]
     torch.cuda.synchronize()
 
@@ -517,11 +556,23 @@ def main():
         except Exception as e:       # noqa: BLE001  (a secondary measurement must not take the line down)
             out["roofline_zipf39"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     if world > 1 or args.shard_protocol:
-        dropped = eng.shard_overflow()
-        out["config"]["shard_capacity"] = {"factor": args.capacity_factor, "dropped_positions": dropped}
-        if dropped:
-            raise SystemExit(f"{dropped} id positions did not fit the fixed-capacity request message: not a valid run "
-                             f"(raise --capacity-factor)")
+        # what a first multi-GPU run needs in order to be diagnosable from its one line
+        ns = eng.k.shard_capacity(args.batch * args.fields, world, args.capacity_factor) * world
+        W = eng.k.shard_msg_words(args.emb_dim, eng._act)[1]
+        off = (world - 1) / world                  # a rank's own chunk never moves
+        id_b = 8 if batches[0][0].dtype == torch.int32 else 16
+        out["rccl"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                       "own_chunk_bypass": bool(eng._bypass),          # did _exchange_selftest keep the per-peer-list exchange?
+                       "whole_step_graph": eng._step_graph is not None,
+                       "slots_per_rank": ns, "capacity_factor": args.capacity_factor,
+                       "a2a_bytes_per_rank_per_step": {"request": int(ns * id_b * off), "answer": int(ns * W * 4 * off),
+                                                       "gradient": int(ns * W * 4 * off)},
+                       "allreduce_bytes_per_step": int(eng.dense_grad_full.numel() * 4),
+                       "kernels_ms_keys": ["route", "a2a_rows", "unroute", "a2a_grads", "allreduce_dense"]}
+        # dropped positions: the count every rank holds is the SUM over all ranks (it rides the dense all-reduce), so all ranks
+        # take the same branch here -- nobody is left inside a barrier
+        eng.check_shard_overflow()
+        out["config"]["shard_capacity"] = {"factor": args.capacity_factor, "dropped_positions": 0}
     eng.check_cache()           # host_cache_rows: a batch that did not fit the device cache is latched on the device
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
@@ -530,16 +581,7 @@ def main():
             out["cpu_baseline"] = None
     if world > 1 or args.shard_protocol:
         dist.barrier()
-        eng.release_graphs()             # (graphs that hold RCCL kernels must go before the process group does)
-        del eng
-        dist.destroy_process_group()
-    if rank == 0:
-        # the LAST line of stdout: whatever the communication library has printf'd into the C runtime's buffer (RCCL announces
-        # the path it was loaded from) comes out first
-        import ctypes
-        sys.stdout.flush()
-        ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+    return out
 
 
 if __name__ == "__main__":

@@ -769,6 +769,7 @@ int apply_impl(Upd upd, int64_t V, int64_t ld, int32_t D, const K* uniq, const i
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || D <= 0 || V < 0 || ld < D || ldg < D) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
+    if (V == 0) return MREC_EINVAL;      // rows are read unconditionally at clamped addresses: an empty table has no valid one
     if (!spos || !sseg || !seg_offsets || !g || !ws) return MREC_EINVAL;
     for (int i = 0; i < Upd::NS; ++i) if (!upd.s[i]) return MREC_EINVAL;
     if (n > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;

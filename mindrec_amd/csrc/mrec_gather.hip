@@ -536,6 +536,7 @@ int gather_bf16_impl(const float* table, int64_t V, int64_t ld, int32_t D, const
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || D <= 0 || V < 0 || ld < D) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
+    if (V == 0) return MREC_EINVAL;      // rows are read unconditionally at clamped addresses: an empty table has no valid one
     if (!table || !ids || !out) return MREC_EINVAL;
     const bool vec = (D % 4 == 0) && (D <= 256) && (ld % 4 == 0) && al16(table) && ((((uintptr_t)out) & oa) == 0);
     if (vec) {
@@ -560,6 +561,7 @@ int gather_impl(const float* table, int64_t V, int64_t ld, int32_t D, const K* i
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || D <= 0 || V < 0 || ld < D) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
+    if (V == 0) return MREC_EINVAL;      // rows are read unconditionally at clamped addresses: an empty table has no valid one
     if (!table || !ids || !out) return MREC_EINVAL;
     const bool vec = (D % 4 == 0) && (D <= 256) && (ld % 4 == 0) && al16(table) && al16(out);
     if (vec) {

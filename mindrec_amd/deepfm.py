@@ -230,6 +230,10 @@ class DeepFMHashEngine(_DeepFMNet):
         self.k, self._gpu = ops, True
         with torch.cuda.device(dev):
             self._init_net(cfg, [cfg.data_field_size * D] + list(cfg.deep_layer_dims) + [1])
+        if self.world > 1:
+            from .wide_deep_shard import OverflowGuard
+            n = self.dense_flat.numel()
+            self._guard = OverflowGuard(self.dense_grad_full[n:n + 1], self.cap_factor)
         if not self._mfma:
             from .wide_deep import enable_tuned_gemms
             enable_tuned_gemms()
@@ -243,8 +247,15 @@ class DeepFMHashEngine(_DeepFMNet):
 
     # ---- key-sharded tables: the fixed-capacity exchange (mindrec_amd/wide_deep_shard.py) over two MapParameters ------------
     def shard_overflow(self):
-        """Positions dropped because an owner's bucket of the request message was full (host sync); 0 on one GPU."""
+        """Positions THIS rank dropped because an owner's bucket of the request message was full (host sync); 0 on one GPU."""
         return int(self._overflow.item()) if self.world > 1 else 0
+
+    def check_shard_overflow(self):
+        """Raises ShardCapacityError on every rank alike if any rank dropped positions since the last check (waits for the last
+        step; train_step / predict poll by themselves -- OverflowGuard, mindrec_amd/wide_deep_shard.py)."""
+        if self.world > 1:
+            self._guard.probe()
+            self._guard.poll(block=True)
 
     def _shard_lookup(self, keys, wts, train):
         """Raw keys to their owners, looked-up rows back.  Returns (vx [B, F, D] fp32 masked, linear [B], route state)."""
@@ -285,7 +296,8 @@ class DeepFMHashEngine(_DeepFMNet):
         self.comm.all_to_all(recv_g, gmsg)
         if self._mfma:
             self._sum_dw_slabs()
-        self.comm.all_reduce(self.dense_grad_flat)
+        self._guard.stage(self._overflow)                     # the dropped-position count rides the dense all-reduce
+        self.comm.all_reduce(self.dense_grad_full)
         # gradients_mean: the owner sums the row gradients of all ranks, the mean divides by their number
         scale = 1.0 / (cfg.loss_scale * self.world)
         kw = self._adam_kw(scale)
@@ -298,6 +310,8 @@ class DeepFMHashEngine(_DeepFMNet):
 
     def predict(self, keys, wts):
         B, Fd = keys.shape
+        if self.world > 1:
+            self._guard.poll()
         with torch.no_grad():
             if self.world > 1:
                 vx, linear, _ = self._shard_lookup(keys, wts, train=False)      # (a collective: every rank calls predict)
@@ -317,7 +331,10 @@ class DeepFMHashEngine(_DeepFMNet):
         self.beta2_power = np.float32(self.beta2_power * self.beta2)
         self.step_count += 1
         if self.world > 1:
-            return self._train_step_sharded(keys, wts, label)
+            self._guard.poll()                                # drops of the previous step: raised here, on every rank
+            loss = self._train_step_sharded(keys, wts, label)
+            self._guard.probe()
+            return loss
         d, rows_v, pos_v, rows_w, pos_w = self._lookup(keys, insert=True)
         vx = ops.gather_rows(self.V.values, pos_v.view(B, Fd), wts)             # [B, F, D], mask fused
         vx16 = ops.gather_rows(self.V.values, pos_v.view(B, Fd), wts, out_dtype=self._amp) if self._mfma else None

@@ -130,8 +130,21 @@ class _DirectComm:
         dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
     def all_to_all_lists(self, outs, ins):
-        """outs[r] <- what rank r sends to this rank, ins[r] -> rank r; entries may differ in length (zero-length: nothing moves)."""
-        dist.all_to_all(outs, ins, group=self.group)
+        """outs[r] <- what rank r sends to this rank, ins[r] -> rank r; entries may differ in length (zero-length: nothing moves).
+        RCCL: one grouped all-to-all (capturable).  A backend without the list form (gloo: the CPU logic tests) gets the same
+        exchange as point-to-point sends and receives -- which is what RCCL's all-to-all is made of."""
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_to_all(outs, ins, group=self.group)
+            return
+        ops_ = []
+        for r, (o, i) in enumerate(zip(outs, ins)):
+            if i.numel():
+                ops_.append(dist.P2POp(dist.isend, i, r, self.group))
+            if o.numel():
+                ops_.append(dist.P2POp(dist.irecv, o, r, self.group))
+        if ops_:
+            for w in dist.batch_isend_irecv(ops_):
+                w.wait()
 
     def all_reduce(self, t, async_op=False):
         """Sum over ranks.  async_op=True returns a work handle (device tensors only): the reduction proceeds on RCCL's
@@ -335,6 +348,8 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         return emb, wide, None
 
     def predict(self, ids, wts):
+        if self._sharded:
+            self._guard.poll()
         with torch.no_grad():
             if self._sharded:
                 emb, wprod, _ = self._shard_lookup(ids, wts, want_plan=False)       # (a collective: every rank calls predict)
@@ -633,6 +648,33 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         if self._gpu:
             torch.cuda.synchronize(self.device)
 
+    def close(self):
+        """End of training: the last steps' dropped-position check (row shards; raises ShardCapacityError on every rank alike),
+        then the captured graphs are released -- call it (or leave a `with engine:` block) before destroy_process_group()."""
+        try:
+            if self._sharded:
+                self.check_shard_overflow()
+            self.check_cache()
+        finally:
+            self.release_graphs()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if exc[0] is None:
+            self.close()
+        else:
+            self.release_graphs()
+        return False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_sink_graphs", None) or getattr(self, "_step_graph", None) is not None:
+                self.release_graphs()
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
+
     # ---- one training step -------------------------------------------------------------------
     def train_steps(self, batches):
         """`len(batches)` training steps per host call -- the reference's dataset_sink_mode / sink_size (Model.train(...,
@@ -644,6 +686,8 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         caller may keep)."""
         S = len(batches)
         g = self._step_graph
+        if self._sharded:
+            self._guard.poll()                        # drops of the previous call: raised here, on every rank (OverflowGuard)
         if (S > 1 and g is not None and self._graph_level >= 3 and self._front_graph_ok() and self._dyn and self._state_step == self.step_count
                 and all(b[0].shape == g["ids"].shape and b[0].dtype == g["ids"].dtype for b in batches)):
             key = (S, tuple(g["ids"].shape), g["ids"].dtype)
@@ -660,7 +704,9 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
                 self.deep_apply_timer = None
                 sg["graph"].replay()
                 self.last_plan = sg["plan"]
-                return torch.stack(sg["losses"])       # a copy: the graph's own loss buffers are overwritten by the next sink
+                if self._sharded:
+                    self._guard.probe()
+                return sg["out"]       # the sink's losses [S], gathered inside the graph: valid until this sink shape runs again
         return [self.train_step(*b).clone() for b in batches]       # (train_step hands out a static buffer once graphs replay)
 
     def _capture_sink(self, key, inputs):
@@ -674,7 +720,8 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
                     self._slot = slot                 # per-step output buffers of the tail launch (the losses must not alias)
                     front = self._front(ids, wts, label, capturing=True)
                     losses.append(self._tail(front, ids, wts))
-            sg = {"graph": graph, "inputs": inputs, "losses": losses, "plan": self.last_plan}
+                out = torch.stack([l.reshape(()) for l in losses])       # inside the graph: no eager kernel between two sinks
+            sg = {"graph": graph, "inputs": inputs, "losses": losses, "out": out, "plan": self.last_plan}
             self._sink_graphs[key] = sg
             return sg
         except RuntimeError as e:
@@ -687,8 +734,13 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
     
     def train_step(self, ids, wts, label):
         self._training = True
+        if self._sharded:
+            self._guard.poll()
         try:
-            return self._train_step(ids, wts, label)
+            loss = self._train_step(ids, wts, label)
+            if self._sharded and not (self._gpu and torch.cuda.is_current_stream_capturing()):
+                self._guard.probe()
+            return loss
         finally:
             self._training = False
 

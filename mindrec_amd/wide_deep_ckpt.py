@@ -21,6 +21,9 @@ def _engine_state(eng):
 
 def save_checkpoint(eng, path):
     """Writes this rank's shard (tables + optimizer state + dense parameters) to `path` (torch.save)."""
+    if getattr(eng, "_sharded", False):
+        eng.check_shard_overflow()          # a checkpoint of steps that dropped positions must not be written (every rank raises alike)
+    eng.check_cache()
     st = _engine_state(eng)
     if eng.hb is not None:
         # host-backed tables: write the device cache back, then save the pinned host store itself (every row of the shard;

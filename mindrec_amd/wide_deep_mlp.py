@@ -57,7 +57,10 @@ class DenseNetMixin:
         self.dense_flat, views = _flat_views(shapes_h + shapes_s + pad, dev)
         views = views[:len(shapes_h + shapes_s)]
         self.dense = interleave(views[:nl - 1], views[nl - 1:])
-        self.dense_grad_flat, gviews = _flat_views(shapes_h + shapes_s + pad, dev)
+        # the gradient buffer carries 4 more floats than the parameters: [n] is the row shards' dropped-position count, summed over
+        # the ranks by the dense all-reduce it rides on (OverflowGuard, wide_deep_shard.py); the optimizers see [:n]
+        self.dense_grad_full, gviews = _flat_views(shapes_h + shapes_s + pad + [(4,)], dev)
+        self.dense_grad_flat = self.dense_grad_full[:self.dense_flat.numel()]
         gviews = gviews[:len(shapes_h + shapes_s)]
         self.dense_grad = interleave(gviews[:nl - 1], gviews[nl - 1:])
         self.dense_m = torch.zeros_like(self.dense_flat)

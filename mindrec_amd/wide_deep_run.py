@@ -184,4 +184,11 @@ class WideDeepRunner:
             logit, prob = self.engine.predict(ids, wts)
             for m in self.metrics.values():
                 m.update(logit, prob, label)
+        # an epoch's end (EvalCallBack.epoch_end runs this): steps that dropped positions or overflowed the cache are not valid steps
+        if getattr(self.engine, "_sharded", False):
+            self.engine.check_shard_overflow()
+        self.engine.check_cache()
         return {k: m.eval() for k, m in self.metrics.items()}
+
+    def close(self):
+        self.engine.close()

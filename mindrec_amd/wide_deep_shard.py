@@ -37,30 +37,75 @@ class ShardCapacityError(RuntimeError):
     """A step's ids did not fit the fixed-capacity request message: raise WideDeepConfig.shard_capacity_factor."""
 
 
+class OverflowGuard:
+    """Makes a dropped position impossible to miss: the library itself raises, on EVERY rank, at most one call late.
+
+    The routing kernel counts positions that found their owner's bucket full in a sticky device counter.  Each step copies that
+    counter into a spare word behind the dense gradient, so the all-reduce of the dense gradients -- which every step runs
+    anyway -- hands every rank the SUM over all ranks (no extra collective: all ranks take the same branch, nobody is left
+    inside a barrier).  After a step or sink the word is copied to pinned host memory asynchronously; the NEXT call into the
+    engine (or close / checkpoint / an epoch's end, which wait for it) reads it and raises ShardCapacityError.  No host
+    synchronisation is added to the step."""
+
+    def __init__(self, slot, factor):
+        self.slot, self.factor = slot, factor             # slot: one float32 element behind the dense gradient
+        self.seen = 0.0
+        self._host = torch.zeros(1, dtype=torch.float32).pin_memory() if slot.is_cuda else torch.zeros(1, dtype=torch.float32)
+        self._event = None
+
+    def stage(self, counter):
+        """Inside the step (capturable): the local sticky counter -> the word the dense all-reduce will sum."""
+        self.slot.copy_(counter)
+
+    def probe(self):
+        """Behind a step / sink, outside capture: start the copy of the summed word to the host."""
+        if self.slot.is_cuda:
+            self._host.copy_(self.slot, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+        else:
+            self._host.copy_(self.slot)
+            self._event = None
+
+    def poll(self, block=False):
+        """Raises if the last probed value shows new drops.  block=False: only if the copy has landed (no host wait)."""
+        if self._event is not None:
+            if block:
+                self._event.synchronize()
+            elif not self._event.query():
+                return
+            self._event = None
+        n = float(self._host[0])
+        if n > self.seen:
+            d, self.seen = n - self.seen, n
+            raise ShardCapacityError(f"{int(d)} id positions (all ranks) did not fit the fixed-capacity request message "
+                                     f"(shard_capacity_factor {self.factor}): the steps since the last check are not valid "
+                                     f"steps -- raise the factor")
+
+
 class ShardStepMixin:
     def _shard_init(self):
         D = self.cfg.emb_dim
         # the own-chunk bypass needs a communicator that takes per-peer tensor lists (the product's; the CPU stand-in keeps the
         # plain equal-split exchange)
-        self._bypass = bool(self._gpu and hasattr(self.comm, "all_to_all_lists"))
+        self._bypass = bool((self._gpu or getattr(self, "_cpu_bypass", False)) and hasattr(self.comm, "all_to_all_lists"))
         if self._bypass and self.world > 1:
             self._bypass = self._exchange_selftest()
         self._act = self._amp if self._mfma else torch.float32           # dtype of looked-up rows / row gradients, also on the wire
         self._shard_fold = bool(self._fused_rows and D <= 252 and D % (4 if self._act == torch.float32 else 8) == 0)
         self._overflow = torch.zeros(1, dtype=torch.int64, device=self.device)
-        self._overflow_seen = 0
+        n = self.dense_flat.numel()
+        self._guard = OverflowGuard(self.dense_grad_full[n:n + 1], self.cfg.shard_capacity_factor)
 
     def shard_overflow(self):
-        """Positions dropped so far because an owner's bucket of the request message was full (host sync)."""
+        """Positions THIS rank dropped so far because an owner's bucket of the request message was full (host sync)."""
         return int(self._overflow.item())
 
     def check_shard_overflow(self):
-        """Raises ShardCapacityError if positions were dropped since the last check (one host sync; call once per sink / epoch)."""
-        n = self.shard_overflow()
-        if n > self._overflow_seen:
-            d, self._overflow_seen = n - self._overflow_seen, n
-            raise ShardCapacityError(f"{d} id positions did not fit the request message (capacity factor "
-                                     f"{self.cfg.shard_capacity_factor}): the affected steps are not valid steps")
+        """Raises ShardCapacityError, on every rank alike, if any rank dropped positions since the last check (waits for the
+        last step; train_step / train_steps / predict / release_graphs / save_checkpoint poll by themselves)."""
+        self._guard.probe()
+        self._guard.poll(block=True)
 
     # ---- the exchange ---------------------------------------------------------------------------------------------------
     def _xbuf(self, rows, width, dtype):
@@ -104,12 +149,19 @@ class ShardStepMixin:
                 send[c * cap:(c + 1) * cap, 0] = float(me)
                 send[c * cap:(c + 1) * cap, 1] = float(r)
             self._exchange(recv, send, to_owner=True)
-            torch.cuda.synchronize(self.device)
+            if self._gpu:
+                torch.cuda.synchronize(self.device)
             for s_ in range(n):                                  # chunk of sender s must carry (s, me)
                 c = (s_ - me) % n
                 blk = recv[c * cap:(c + 1) * cap]
                 ok &= int(bool((blk[:, 0] == float(s_)).all()) and bool((blk[:, 1] == float(me)).all()))
-        except Exception:      # noqa: BLE001
+        except (TypeError, ValueError, NotImplementedError) as e:
+            # an ARGUMENT refusal of the library (per-peer lists with an empty own entry): raised on every rank alike, before
+            # anything was enqueued, so all ranks reach the all-reduce below together.  Anything else -- an asynchronous RCCL or
+            # device error surfacing at the synchronize, out of memory -- is local to this rank and must not be swallowed: the
+            # peers would be inside the all-to-all while this rank enters an all-reduce.
+            import warnings
+            warnings.warn(f"own-chunk bypass refused by the communicator ({type(e).__name__}: {e}); using the equal-split all-to-all")
             ok = 0
         flag = torch.tensor([float(ok)], device=self.device)
         self.comm.all_reduce(flag)
@@ -280,7 +332,8 @@ class ShardStepMixin:
                 self.wide_b_grad.copy_(self.dense_grad[2 * (len(self.dims) - 2) + 1].view(1))      # = the output layer's bias gradient
         else:
             self.wide_b_grad.copy_(g_wide.sum().view(1))
-        dense_work = self.comm.all_reduce(self.dense_grad_flat, async_op=True)
+        self._guard.stage(self._overflow)                                  # the dropped-position count rides the dense all-reduce
+        dense_work = self.comm.all_reduce(self.dense_grad_full, async_op=True)
         self._tock(ev)
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)           # the plan (queued under the MLP) is done

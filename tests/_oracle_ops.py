@@ -85,15 +85,15 @@ def shard_msg_words(D, act_dtype):
     return D, D + 4
 
 
-def shard_route_slots(ids, wts, n_shards, cap, hashed=False, overflow=None):
-    rid, rw, sop, pos, dropped = O.shard_route_slots(_np(ids), _np(wts) if wts is not None else None, n_shards, cap, hashed)
+def shard_route_slots(ids, wts, n_shards, cap, hashed=False, overflow=None, rot=0, out=None):
+    rid, rw, sop, pos, dropped = O.shard_route_slots(_np(ids), _np(wts) if wts is not None else None, n_shards, cap, hashed, rot)
     idt = _np(ids).dtype
-    req = np.empty((n_shards * cap, 2), idt)
+    req = np.empty((n_shards * cap, 2), idt) if out is None else _np(out)
     req[:, 0] = rid.astype(idt)
     req[:, 1] = rw.view(np.int32).astype(idt)                       # the weight's bits in the entry's second word
     if overflow is not None:
         overflow += dropped
-    return torch.from_numpy(req), torch.from_numpy(sop), torch.from_numpy(pos)
+    return (torch.from_numpy(req) if out is None else out), torch.from_numpy(sop), torch.from_numpy(pos)
 
 
 def shard_unpack_req(req):
@@ -111,14 +111,18 @@ def shard_unroute_slots(back, slot_of_pos, D, act_dtype, out=None):
     return torch.from_numpy(emb), torch.from_numpy(wp)
 
 
-def shard_route_grads(g, dlogit, F, pos_of_slot):
+def shard_route_grads(g, dlogit, F, pos_of_slot, out=None):
     gg, dl, p = _np(g), _np(dlogit), _np(pos_of_slot)
     D = gg.shape[1]
-    msg = np.zeros((p.size, D + 4), np.float32)
+    if out is not None:
+        msg = _np(out)
+        msg[...] = 0
+    else:
+        msg = np.zeros((p.size, D + 4), np.float32)
     ok = p >= 0
     msg[ok, :D] = gg[p[ok]]
     msg[ok, D] = dl[p[ok] // F]
-    return torch.from_numpy(msg)
+    return torch.from_numpy(msg) if out is None else out
 
 
 def segment_sum(plan, g, row_scale=None, grad_scale=1.0):

@@ -28,7 +28,7 @@ def _batch(cfg, seed):
     return synthetic_batch(cfg, "cpu", "zipf", seed=seed)
 
 
-def _worker(rank, world, port, steps, out_dir, dropout=False):
+def _worker(rank, world, port, steps, out_dir, dropout=False, bypass=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -36,7 +36,15 @@ def _worker(rank, world, port, steps, out_dir, dropout=False):
     from mindrec_amd.wide_deep import WideDeepEngine
     torch.set_num_threads(1)
     cfg = _cfg(24, dropout)
-    eng = OracleWideDeepEngine(cfg, "cpu", rank=rank, world=world)
+    if bypass:
+        # the PRODUCT's exchange: ShardStepMixin._exchange over _DirectComm.all_to_all_lists with the aliased send / receive
+        # windows of one buffer and the rank's own chunk left in place (what runs over RCCL), here over gloo
+        class _Bypass(OracleWideDeepEngine):
+            _cpu_bypass = True
+        eng = _Bypass(cfg, "cpu", rank=rank, world=world)
+        assert eng._bypass and type(eng.comm).__name__ == "_DirectComm"
+    else:
+        eng = OracleWideDeepEngine(cfg, "cpu", rank=rank, world=world)
     losses = []
     for s in range(steps):
         ids, wts, label = _batch(cfg, seed=100 * s + rank)
@@ -53,15 +61,16 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,dropout", [(2, False), (4, False), (8, False), (2, True)])
-def test_sharded_step_matches_single_process(tmp_path, world, dropout):
+@pytest.mark.parametrize("world,dropout,bypass", [(2, False, False), (4, False, False), (8, False, False), (2, True, False),
+                                                  (2, False, True), (3, False, True)])
+def test_sharded_step_matches_single_process(tmp_path, world, dropout, bypass):
     """world = 4 / 8 with V = 997 also cover shards of unequal length (250, 249, ... / 125, 125, ..., 124 rows);
     world = 8 is the driver's scaling-bench geometry (BASELINE configs[3]).  dropout: the ranks draw the Dropout mask of the
     one concatenated batch (row0 = rank * local batch)."""
     from _oracle_engine import OracleDeepCrossEngine, OracleDeepFMEngine, OracleWideDeepEngine  # noqa: F401
     from mindrec_amd.wide_deep import WideDeepEngine
     steps = 3
-    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), dropout), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), dropout, bypass), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
 
     # single process, concatenated batch of world x 24
@@ -90,6 +99,42 @@ def test_sharded_step_matches_single_process(tmp_path, world, dropout):
         assert np.array_equal(r[0]["dense"], r[k]["dense"])
     # mean of the per-rank mean losses == loss of the concatenated batch
     assert np.allclose(sum(r[k]["losses"] for k in range(world)) / world, losses, rtol=1e-5)
+
+
+def _overflow_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from _oracle_engine import OracleWideDeepEngine
+    from mindrec_amd.wide_deep_shard import ShardCapacityError
+    torch.set_num_threads(1)
+    cfg = _cfg(24)
+    cfg.shard_capacity_factor = 1.0            # a bucket holds the mean share (rounded up to 64)
+    eng = OracleWideDeepEngine(cfg, "cpu", rank=rank, world=world)
+    ids, wts, label = _batch(cfg, seed=rank)
+    flat = torch.arange(ids.numel(), dtype=ids.dtype)
+    # rank 0: every id even -- all of its positions go to owner 0, whose bucket overflows; rank 1: evenly spread, drops nothing
+    ids = ((flat % 400) * 2 if rank == 0 else flat % cfg.vocab_size).view_as(ids)
+    eng.train_step(ids, wts, label)
+    local = eng.shard_overflow()
+    raised = False
+    try:
+        eng.train_step(ids, wts, label)        # the library itself raises at the next call, on EVERY rank
+    except ShardCapacityError:
+        raised = True
+    np.savez(os.path.join(out_dir, f"ovf{rank}.npz"), local=local, raised=raised)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_dropped_positions_raise_on_every_rank(tmp_path):
+    """positions that do not fit the fixed-capacity request are counted on the device; the engine -- not the caller --
+    raises ShardCapacityError one call later, and on ALL ranks (the count rides the dense all-reduce), so nobody is left
+    waiting inside a collective."""
+    mp.spawn(_overflow_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = [np.load(tmp_path / f"ovf{k}.npz") for k in range(2)]
+    assert int(r[0]["local"]) > 0 and int(r[1]["local"]) == 0          # only rank 0 dropped something ...
+    assert bool(r[0]["raised"]) and bool(r[1]["raised"])               # ... and both ranks raised
 
 
 def test_engine_refuses_cpu_without_kernels():
