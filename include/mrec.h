@@ -300,6 +300,16 @@ int mrec_dense_adam_slabs_f32(float* p, float* m, float* v, const float* g, void
                               const int32_t* splits, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
                               float grad_scale, int nesterov, void* step_state /* nullable mrec_step_state_t: lr_t */,
                               void* stream);
+/* nn.Adam over a whole TABLE whose loss carries the L2 term l2_coef * sum(p^2) / 2 (NetWithLossClass.construct with sparse=False,
+ * models/wide_deep/src/wide_and_deep.py:356-360; both tables of models/deepfm/src/deepfm.py:252-259): g holds the scattered
+ * row-gradient sums only, the kernel adds l2_scaled * p (l2_scaled = l2_coef * sens; product rounded, then added) and, when
+ * sumsq != NULL, leaves sum(p^2) of the values BEFORE the update in *sumsq (fp64, fixed summation order; sumsq_accumulate != 0:
+ * added onto what *sumsq holds -- the second table of DeepFM).  n % 4 == 0, 16-byte aligned; ws from
+ * mrec_dense_adam_l2_workspace_bytes. */
+int mrec_dense_adam_l2_workspace_bytes(int64_t n, size_t* out);
+int mrec_dense_adam_l2_f32(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1, float b2, float eps,
+                           float b1_pow, float b2_pow, float grad_scale, int nesterov, float l2_scaled, double* sumsq,
+                           int sumsq_accumulate, void* ws, size_t ws_bytes, void* stream);
 /* Both of the above with ONE element of the buffer under FTRL instead of Adam: Wide&Deep's `wide_b` (models/wide_deep/src/
  * wide_and_deep.py:161-163) is a member of the FTRL optimizer's parameter list -- TrainStepWrap sorts by `"wide" in params.name`
  * (:407-411) and MindSpore names the Parameter held in the attribute `wide_b` "<prefix>.wide_b" [EXT: Cell.update_parameters_name

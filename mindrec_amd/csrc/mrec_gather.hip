@@ -411,6 +411,42 @@ __global__ __launch_bounds__(256) void k_dense_adam4(float4* __restrict__ p, flo
     }
 }
 
+// Dense Adam whose gradient carries the L2 term of the loss: g_i = sums_i + l2s * p_i (l2s = l2_coef * sens: d/dp of
+// l2_coef * sum(p^2) / 2 at the loss scale; NetWithLossClass.construct, wide_and_deep.py:356-360; deepfm.py:252-259), with the
+// loss term's own by-product -- sum(p^2) BEFORE the update -- reduced in the same pass: per-thread fp64 partials, wave shuffle,
+// LDS, one fp64 word per workgroup; k_sumsq_finish adds them in workgroup order.  Replaces three torch passes over the table
+// (the product, the add onto the scattered sums, the sum of squares).
+__global__ __launch_bounds__(256) void k_dense_adam4_l2(float4* __restrict__ p, float4* __restrict__ m, float4* __restrict__ v,
+                                                        const float4* __restrict__ g, int64_t n4, AdamH h, float l2s,
+                                                        double* __restrict__ partial) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pp = p[i], mm = m[i], vv = v[i];
+        float4 gg = g[i];
+        acc += (double)pp.x * pp.x + (double)pp.y * pp.y + (double)pp.z * pp.z + (double)pp.w * pp.w;
+        gg.x += l2s * pp.x; gg.y += l2s * pp.y; gg.z += l2s * pp.z; gg.w += l2s * pp.w;       // product rounded, then added (no fma)
+        adam_elem(pp.x, mm.x, vv.x, gg.x * h.gscale, h);
+        adam_elem(pp.y, mm.y, vv.y, gg.y * h.gscale, h);
+        adam_elem(pp.z, mm.z, vv.z, gg.z * h.gscale, h);
+        adam_elem(pp.w, mm.w, vv.w, gg.w * h.gscale, h);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+    if (!partial) return;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+__global__ __launch_bounds__(64) void k_sumsq_finish(const double* __restrict__ partial, int nb, double* __restrict__ out, int accumulate) {
+    if (threadIdx.x) return;
+    double s = accumulate ? *out : 0.0;
+    for (int b = 0; b < nb; ++b) s += partial[b];
+    *out = s;
+}
+
 template <bool SH>
 __global__ __launch_bounds__(256) void k_dense_adam4_g16(float4* __restrict__ p, float4* __restrict__ m,
                                                          float4* __restrict__ v, const uint2* __restrict__ g,
@@ -902,6 +938,38 @@ MREC_API int mrec_dense_adam_ex_f32(float* p, float* m, float* v, const void* g,
                                     float grad_scale, int nesterov, void* stream) {
     return dense_adam_launch(p, m, v, g, g_is_bf16, shadow_bf16, n, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale, nesterov,
                              stream);
+}
+
+MREC_API int mrec_dense_adam_l2_workspace_bytes(int64_t n, size_t* out) {
+    if (!out || n < 0) return MREC_EINVAL;
+    *out = (size_t)stream_grid(n / 4 > 0 ? n / 4 : 1) * sizeof(double) + 256;
+    return MREC_OK;
+}
+
+MREC_API int mrec_dense_adam_l2_f32(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1, float b2, float eps,
+                                    float b1_pow, float b2_pow, float grad_scale, int nesterov, float l2_scaled, double* sumsq,
+                                    int sumsq_accumulate, void* ws, size_t ws_bytes, void* stream) {
+    if (n < 0) return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!p || !m || !v || !g) return MREC_EINVAL;
+    if (n % 4 || !al16(p) || !al16(m) || !al16(v) || !al16(g)) return MREC_EUNSUPPORTED;
+    const int64_t n4 = n / 4;
+    const unsigned gr = stream_grid(n4);
+    double* partial = nullptr;
+    if (sumsq) {
+        MrecArena a(ws, ws_bytes);
+        partial = a.take<double>(gr);
+        if (!a.ok || !partial) return MREC_EWORKSPACE;
+    }
+    AdamH h;
+    h.lr_t = lr * sqrtf(1.0f - b2_pow) / (1.0f - b1_pow);
+    h.b1 = b1; h.b2 = b2; h.omb1 = 1.0f - b1; h.omb2 = 1.0f - b2; h.eps = eps; h.gscale = grad_scale;
+    h.nesterov = nesterov;
+    hipStream_t st = (hipStream_t)stream;
+    k_dense_adam4_l2<<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, l2_scaled, partial);
+    if (sumsq) k_sumsq_finish<<<1, 64, 0, st>>>(partial, (int)gr, sumsq, sumsq_accumulate);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
 }
 
 MREC_API int mrec_dense_adam_one_ftrl_f32(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1, float b2,

@@ -25,7 +25,6 @@ from typing import List
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import ops
 
@@ -56,20 +55,6 @@ def _flat_views(shapes, device):
         views.append(flat[off:off + k].view(s))
         off += k
     return flat, views
-
-
-class _CrossStack(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x0, w, b, k):
-        ctx.k = k
-        ctx.save_for_backward(x0, w, b)
-        return k.cross_layers(x0, w, b)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x0, w, b = ctx.saved_tensors
-        dx0, dw, db = ctx.k.cross_layers_bwd(x0, w, b, dy.contiguous())
-        return dx0, dw, db, None
 
 
 class DeepCrossEngine:
@@ -120,26 +105,32 @@ class DeepCrossEngine:
         self._state = None            # ops.StepState: Adam's powers / step size in device memory (constant kernel arguments)
         self._state_step = -1
         self._bufs = {}               # batch size -> the step's persistent intermediates (graph replays write the same buffers)
-        if self._gpu and not self._native:
-            from .wide_deep import enable_tuned_gemms
-            enable_tuned_gemms()                     # shipped GEMM selections (tools/tune_gemms.py), tuning off
 
     def forward(self, emb):
-        W1, b1, W2, b2, W3, b3, cw, cb = self.dense
-        if self._native and not torch.is_grad_enabled():
-            d1 = self.k.dense32_fwd(emb, W1.detach(), b1.detach(), relu=True)
-            d2 = self.k.dense32_fwd(d1, W2.detach(), b2.detach(), relu=True)
-            c = self.k.cross_layers(emb, cw.detach(), cb.detach())
-            h2 = d2.shape[1]
-            w3 = W3.detach()
-            return ((d2 * w3[:h2, 0]).sum(dim=1) + (c * w3[h2:, 0]).sum(dim=1)).view(-1, 1) + b3.detach()
-        d1 = torch.relu(torch.addmm(b1, emb, W1))
-        d2 = torch.relu(torch.addmm(b2, d1, W2))
-        c = _CrossStack.apply(emb, cw, cb, self.k)
-        # concat([deep, cross]) . W3 (deep_and_cross.py:306-308) on the halves of W3, without materialising the
-        # [B, 2194] concat.
+        """DeepCrossModel.construct behind the lookup (deep_and_cross.py:299-309), inference: logit [B, 1]."""
+        if not self._native:
+            return self._forward_generic(emb)
+        W1, b1, W2, b2, W3, b3, cw, cb = [p.detach() for p in self.dense]
+        d1 = self.k.dense32_fwd(emb, W1, b1, relu=True)
+        d2 = self.k.dense32_fwd(d1, W2, b2, relu=True)
+        c = self.k.cross_layers(emb, cw, cb)
         h2 = d2.shape[1]
-        return ((d2 * W3[:h2, 0]).sum(dim=1) + (c * W3[h2:, 0]).sum(dim=1)).view(-1, 1) + b3
+        # concat([deep, cross]) . W3 + b3 (:306-308) on the two halves of W3, without materialising the [B, h2 + X] concat
+        return self.k.dense32_fwd(d2, W3[:h2], None, relu=False) + self.k.dense32_fwd(c, W3[h2:], b3, relu=False)
+
+    # ---- hooks: shapes without a HIP path.  The product refuses them; tests/_torch_net.py implements them for the oracle side ----
+    def _unsupported(self, what):
+        from .wide_deep_mlp import UnsupportedNet
+        cfg = self.cfg
+        return UnsupportedNet(f"MREC_EUNSUPPORTED: {what}: no hand-written HIP path for Deep&Cross with deep_layer_dim {cfg.deep_layer_dim}, "
+                              f"input width {cfg.field_size * cfg.emb_dim}, table {cfg.vocab_size} x {cfg.emb_dim} on {self.device} (second hidden "
+                              f"width a multiple of 4 and <= 1024, input width even and <= 1280, vocab_size * emb_dim a multiple of 4)")
+
+    def _forward_generic(self, emb):
+        raise self._unsupported("inference forward")
+
+    def _train_step_generic(self, ids, wts, label):
+        raise self._unsupported("training step")
 
     def predict(self, ids, wts):
         B, Fd = ids.shape
@@ -229,30 +220,4 @@ class DeepCrossEngine:
     def train_step(self, ids, wts, label):
         if self._native:
             return self._train_step_native(ids, wts, label)
-        return self._train_step_autograd(ids, wts, label)
-
-    def _train_step_autograd(self, ids, wts, label):
-        """The torch restatement (the oracle-side engine; shapes the output kernel does not cover)."""
-        cfg = self.cfg
-        self.step_count += 1
-        B, Fd = ids.shape
-        D = cfg.emb_dim
-        self.beta1_power = np.float32(self.beta1_power * self.beta1)
-        self.beta2_power = np.float32(self.beta2_power * self.beta2)
-        emb = self.k.gather_rows(self.table, ids, wts).view(B, Fd * D)
-        emb.requires_grad_(True)
-        self.dense_grad_flat.zero_()
-        logit = self.forward(emb)
-        loss = F.binary_cross_entropy_with_logits(logit, label)
-        (loss * cfg.loss_scale).backward()
-        # dense table gradient = UnsortedSegmentSum of the masked row gradients (bprop of Gather)
-        plan = self.k.sparse_plan(ids)
-        sums = self.k.segment_sum(plan, emb.grad.view(B * Fd, D), wts)
-        gtab = torch.zeros_like(self.table)
-        self.k.scatter_unique_rows_(gtab, plan, sums)
-        kw = dict(lr=cfg.learning_rate, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.eps,
-                  beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
-                  grad_scale=1.0 / cfg.loss_scale)
-        self.k.dense_adam_(self.table, self.table_m, self.table_v, gtab, **kw)
-        self.k.dense_adam_(self.dense_flat, self.dense_m, self.dense_v, self.dense_grad_flat, **kw)
-        return loss.detach()
+        return self._train_step_generic(ids, wts, label)

@@ -21,7 +21,6 @@ from typing import List
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import ops
 from .wide_deep_mlp import DenseNetMixin
@@ -44,22 +43,6 @@ class DeepFMConfig:
     mlp_dtype: str = "fp16"       # DenseLayer casts input, weight and bias to float16 (convert_dtype: True, default_config.yaml:27;
                                   # deepfm.py:135-145); "bf16" runs the same kernels, "fp32" the library GEMMs through torch
     graphs: str = "mlp"           # "mlp": the dense net's step replays as HIP graphs (16-bit net), "none": kernel by kernel
-
-
-class _FMTerm(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, vx, k):
-        fm, cs = k.fm_forward(vx)
-        ctx.k = k
-        ctx.save_for_backward(vx, cs)
-        return fm
-
-    @staticmethod
-    def backward(ctx, dout):
-        vx, cs = ctx.saved_tensors
-        g = torch.zeros_like(vx)
-        ctx.k.fm_backward_(g, vx, cs, dout.contiguous())
-        return g, None
 
 
 class _DeepFMNet(DenseNetMixin):
@@ -101,14 +84,11 @@ class _DeepFMNet(DenseNetMixin):
             g = g.view(B, Fd, D)
             self.k.fm_backward_(g, vx, cs, dlogit)
             return loss, g, dlogit
-        vx.requires_grad_(True)
-        linear.requires_grad_(True)
-        self.dense_grad_flat.zero_()
-        fm = _FMTerm.apply(vx, self.k)
-        logit = (linear + fm).view(-1, 1) + self.mlp(vx.view(B, Fd * D))
-        loss = F.binary_cross_entropy_with_logits(logit, label)
-        (loss * cfg.loss_scale).backward()
-        return loss.detach(), vx.grad, linear.grad
+        return self._net_step_generic(vx, linear, label)
+
+    def _net_step_generic(self, vx, linear, label):
+        """No HIP path for this net: the product refuses (tests/_torch_net.py implements it for the oracle side)."""
+        raise self._unsupported("training step")
 
     def _dense_adam(self, grad_scale, summed=False):
         """nn.Adam over the dense net.  summed: the weight-gradient slabs have been added into the flat gradient already (a shard
@@ -140,9 +120,6 @@ class DeepFMEngine(_DeepFMNet):
             self.k.fill_normal_(self.W_l2, cfg.seed + 1, cfg.init_sigma)
             self.state = {n: (torch.zeros_like(t), torch.zeros_like(t)) for n, t in (("V", self.V_l2), ("W", self.W_l2))}
             self._init_net(cfg, [cfg.data_field_size * D] + list(cfg.deep_layer_dims) + [1])
-        if self._gpu and not self._mfma:
-            from .wide_deep import enable_tuned_gemms
-            enable_tuned_gemms()                     # shipped GEMM selections (tools/tune_gemms*.py), tuning off
 
     def _forward(self, ids, wts):
         cfg = self.cfg
@@ -168,22 +145,26 @@ class DeepFMEngine(_DeepFMNet):
         self.step_count += 1
         vx, linear = self._forward(ids, wts)
         vx16 = self.k.gather_rows(self.V_l2, ids, wts, out_dtype=self._amp) if self._mfma else None     # the net's input, rounded once
-        with torch.no_grad():
-            l2 = cfg.l2_coef * 0.5 * ((self.V_l2 * self.V_l2).sum() + (self.W_l2 * self.W_l2).sum())
         log_loss, g_vx, g_lin = self._net_step(vx, vx16, linear, label)
-        loss = log_loss.detach() + l2
-        # dense table gradients: sens * l2_coef * table everywhere, plus the segment-sums on the touched rows
+        # Dense table gradients = the segment sums scattered to the touched rows + sens * l2_coef * table everywhere (the L2 term of
+        # the loss, deepfm.py:252-259).  The second half -- and the term's own value, l2_coef / 2 * (sum V^2 + sum W^2) at the
+        # step's starting values -- come out of the Adam kernel's one pass over each table (ops.dense_adam_l2_).
         plan = self.k.sparse_plan(ids)
         sens = cfg.loss_scale
         kw = dict(lr=cfg.learning_rate, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.epsilon,
                   beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=1.0 / sens)
-        for name, table, g, scale in (("V", self.V_l2, g_vx.view(B * Fd, D), wts),
-                                      ("W", self.W_l2, (g_lin.view(B, 1) * wts).view(B * Fd, 1), None)):
-            gtab = table * (cfg.l2_coef * sens)
-            sums = self.k.segment_sum(plan, g, scale)
-            self.k.scatter_unique_rows_add_(gtab, plan, sums)
+        if getattr(self, "_sumsq", None) is None:
+            self._sumsq = torch.zeros(1, dtype=torch.float64, device=self.device)
+            self._gtab = {n: torch.empty_like(t) for n, t in (("V", self.V_l2), ("W", self.W_l2))}
+        for i, (name, table, g, scale) in enumerate((("V", self.V_l2, g_vx.view(B * Fd, D), wts),
+                                                      ("W", self.W_l2, (g_lin.view(B, 1) * wts).view(B * Fd, 1), None))):
+            gtab = self._gtab[name]
+            gtab.zero_()
+            self.k.scatter_unique_rows_(gtab, plan, self.k.segment_sum(plan, g, scale))
             m, v = self.state[name]
-            self.k.dense_adam_(table.view(-1), m.view(-1), v.view(-1), gtab.view(-1), **kw)
+            self.k.dense_adam_l2_(table.view(-1), m.view(-1), v.view(-1), gtab.view(-1), cfg.l2_coef * sens, sumsq=self._sumsq,
+                                  accumulate=i > 0, **kw)
+        loss = log_loss.detach() + (self._sumsq * (cfg.l2_coef * 0.5)).to(torch.float32).view(())
         self._dense_adam(1.0 / sens)
         return loss
 
@@ -234,9 +215,6 @@ class DeepFMHashEngine(_DeepFMNet):
             from .wide_deep_shard import OverflowGuard
             n = self.dense_flat.numel()
             self._guard = OverflowGuard(self.dense_grad_full[n:n + 1], self.cap_factor)
-        if not self._mfma:
-            from .wide_deep import enable_tuned_gemms
-            enable_tuned_gemms()
 
     def _lookup(self, keys, insert):
         flat = self.V._keys(keys)

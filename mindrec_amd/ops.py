@@ -443,6 +443,20 @@ def dense_adam_(p, m, v, g, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, beta1_p
               _stream())
 
 
+def dense_adam_l2_(p, m, v, g, l2_scaled, sumsq=None, accumulate=False, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, beta1_power=0.9,
+                   beta2_power=0.999, grad_scale=1.0, use_nesterov=False):
+    """nn.Adam over a whole table whose loss carries l2_coef * sum(p^2) / 2 (wide_and_deep.py:356-360; deepfm.py:252-259): `g` holds
+    the scattered row-gradient sums only; the kernel adds l2_scaled * p (= l2_coef * sens * p) and leaves sum(p^2) of the values
+    before the update in `sumsq` (float64 [1] device tensor; accumulate=True: added onto it) -- one pass instead of four."""
+    _need_cuda(p, m, v, g, sumsq)
+    n = _flat_same(p, m, v, g)
+    if sumsq is not None and (sumsq.dtype != torch.float64 or sumsq.numel() != 1):
+        raise TypeError("sumsq must be a float64 [1] device tensor")
+    ws = workspace("adam_l2", _lib.query_bytes("mrec_dense_adam_l2_workspace_bytes", n), p.device)
+    _lib.call("mrec_dense_adam_l2_f32", _ptr(p), _ptr(m), _ptr(v), _ptr(g), n, lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale,
+              int(use_nesterov), float(l2_scaled), _ptr(sumsq), int(bool(accumulate)), _ptr(ws), ws.numel(), _stream())
+
+
 def dense_ftrl_(var, accum, linear, g, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):
     """nn.FTRL over a whole tensor (wide_and_deep.py:438-445)."""
     _need_cuda(var, accum, linear, g)

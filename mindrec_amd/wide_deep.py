@@ -25,14 +25,12 @@ data-parallel with one flat all-reduce(mean) (gradients_mean=True,
 train_and_eval_distribute.py:135-138).
 """
 import contextlib
-import os
 from dataclasses import dataclass, field
 from typing import List
 
 import numpy as np
 import torch
 import torch.distributed as dist
-import torch.nn.functional as F
 
 from . import ops
 from .wide_deep_ckpt import load_checkpoint, merge_shards, save_checkpoint  # noqa: F401  (re-exported)
@@ -93,26 +91,6 @@ class WideDeepConfig:
 
 
 _GRAPH_LEVEL = {"none": 0, "mlp": 1, "front": 2, "step": 3}
-_TUNED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "tunableop_gfx950.csv")
-
-
-def enable_tuned_gemms():
-    """Loads the shipped TunableOp table (tools/tune_gemms.py) with tuning disabled: the MLP GEMMs
-    use the hipBLASLt / rocBLAS solutions measured fastest on MI355X for these shapes (0.56 ms vs
-    0.83 ms of GEMM time per Wide&Deep step); unknown shapes fall back to the library default."""
-    if os.environ.get("MREC_NO_TUNED_GEMMS") or not os.path.exists(_TUNED):
-        return False
-    try:
-        import torch.cuda.tunable as tn
-        tn.enable(True)
-        tn.tuning_enable(False)
-        tn.set_filename(_TUNED, insert_device_ordinal=False)
-        tn.read_file(_TUNED)
-        return True
-    except Exception:      # table from another library version: run on defaults
-        return False
-
-
 class _DirectComm:
     """The engine's collectives: torch.distributed on the tensors as they are -- device tensors under backend "nccl"
     (= RCCL over xGMI, the product path), host tensors under gloo (the CPU logic tests).  Test harnesses that put
@@ -160,7 +138,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
     _kernels = ops               # the op set (tests/ subclass the engine with a CPU stand-in to run the multi-rank host logic under gloo)
     _allow_cpu = False           # the product has no CPU path
 
-    def __init__(self, cfg: WideDeepConfig, device, rank=0, world=1, group=None, tuned_gemms=True, comm=None, shard_protocol=False,
+    def __init__(self, cfg: WideDeepConfig, device, rank=0, world=1, group=None, comm=None, shard_protocol=False,
                  tables_from=None):
         """comm: collectives provider (default: torch.distributed as is, see _DirectComm).
         shard_protocol: run the row-shard protocol (routing kernels + collectives) even when world == 1 -- every
@@ -205,7 +183,6 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         # The mixed-precision dense net runs on the hand-written MFMA kernels (csrc/mrec_dense.hip); widths that are not
         # multiples of 8 (rows not 16-byte aligned), an fp32 net and the CPU stand-in take the autograd path below.
         self._mfma = bool(self._gpu and kernels is None and self._amp is not None and D % 4 == 0 and D <= 256 and self.mfma_net_ok(dims))
-        self.tuned_gemms = bool(tuned_gemms and self._gpu and not self._mfma and enable_tuned_gemms())
         if not cfg.sparse and (self._sharded or cfg.dynamic_embedding or cfg.host_cache_rows > 0):
             raise ValueError("sparse=False (dense gradients over the whole table) runs on one GPU with resident dense tables")
         self._fold_wide = bool(cfg.sparse and cfg.fold_wide and self._mfma and not self._sharded and cfg.fused_state and cfg.host_cache_rows == 0 and D <= 252
@@ -496,13 +473,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         elif self._f32net and not (self._dropout and self._training):
             loss, g_emb, g_wide = self._mlp_step_f32(emb, wide, label)   # the fp32 net by hand (ops.dense32_*)
         else:
-            emb.requires_grad_(True)
-            wide.requires_grad_(True)
-            self.dense_grad_flat.zero_()
-            logit = wide.view(-1, 1) + self.mlp(emb)
-            loss = F.binary_cross_entropy_with_logits(logit, label)      # SigmoidCrossEntropyWithLogits + ReduceMean
-            (loss * cfg.sens).backward()                                  # sens_param seeding, :479-486
-            g_emb, g_wide = emb.grad, wide.grad                           # [B, F*D], [B]
+            loss, g_emb, g_wide = self._mlp_step_generic(emb, wide, label)      # (no HIP path: the product raises UnsupportedNet)
         self._tock(ev)
 
         if plan_early is not None and self._side is not None:
@@ -603,9 +574,12 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         sums = self.k.segment_sum(plan, g_emb.view(B * Fd, D).float(), wts)           # UnsortedSegmentSum of the row gradients
         self._gdeep.zero_()
         self.k.scatter_unique_rows_(self._gdeep, plan, sums)
-        # d/dE [l2_coef * sum(E^2) / 2] = l2_coef * E, carried at the loss scale like every other gradient
-        self._gdeep.add_(self.deep * np.float32(cfg.l2_coef * cfg.sens))     # (product rounded, then added: no fused multiply-add)
-        self.k.dense_adam_(self.deep.view(-1), self.deep_m.view(-1), self.deep_v.view(-1), self._gdeep.view(-1), **akw)
+        # d/dE [l2_coef * sum(E^2) / 2] = l2_coef * E, carried at the loss scale like every other gradient: added inside the Adam
+        # kernel (product rounded, then added: no fused multiply-add), which also leaves sum(E^2) of the step's starting values behind
+        if getattr(self, "_l2_sumsq", None) is None:
+            self._l2_sumsq = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.k.dense_adam_l2_(self.deep.view(-1), self.deep_m.view(-1), self.deep_v.view(-1), self._gdeep.view(-1), cfg.l2_coef * cfg.sens,
+                              sumsq=self._l2_sumsq, **akw)
         self._tock(ev)
         ev = self._tick("apply_wide")
         gw = (g_wide.view(B, 1) * wts).view(B * Fd, 1)                                # Mul bprop of wide_mul (:304)
@@ -632,11 +606,14 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         return loss.detach()
 
     def deep_loss(self, loss):
-        """The deep optimizer's loss of NetWithLossClass.construct (:356-360): log loss + l2_coef * sum(E^2) / 2 in dense mode,
-        the log loss itself in sparse mode."""
+        """The deep optimizer's loss of NetWithLossClass.construct (:356-360) of the LAST step: log loss + l2_coef * sum(E^2) / 2
+        in dense mode -- sum(E^2) at the step's starting values, a by-product of that step's Adam pass over the table --, the
+        log loss itself in sparse mode."""
         if self.cfg.sparse:
             return loss
-        return loss + self.cfg.l2_coef * 0.5 * float((self.deep.double() ** 2).sum())
+        if getattr(self, "_l2_sumsq", None) is None:
+            raise RuntimeError("deep_loss: no training step has run yet")
+        return loss + self.cfg.l2_coef * 0.5 * float(self._l2_sumsq[0])
 
     def release_graphs(self):
         """Drops every captured HIP graph (they are re-captured on demand).  A shard's graphs hold RCCL kernels: they must be gone

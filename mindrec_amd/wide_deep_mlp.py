@@ -3,9 +3,14 @@ backward on the hand-written MFMA kernels (csrc/mrec_dense.hip, csrc/mrec_tail.h
 of the MLP step.  A mixin of WideDeepEngine (mindrec_amd/wide_deep.py), which owns the state these methods work on."""
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import ops
+
+
+class UnsupportedNet(NotImplementedError):
+    """MREC_EUNSUPPORTED at the engine level: the requested dense net has no hand-written HIP path.  The product never falls back
+    to a library GEMM or to autograd; the torch restatements of these nets live under tests/ (tests/_torch_net.py), where the
+    oracle-side engines use them."""
 
 
 def _flat_views(shapes, device, dtype=torch.float32):
@@ -167,35 +172,40 @@ class DenseNetMixin:
     def _tail_now(self, B):
         return bool(self._tail_ok and self.k.tail_supported(B, *self.dims[len(self.dims) - 4:len(self.dims) - 1]))
 
+    @torch.no_grad()
     def mlp(self, x):
-        """DenseLayer x5 (wide_and_deep.py:113-133): act(x W + b), ReLU on all but the last; returns the fp32 logit.
-        On the GPU in 16-bit mode the hidden layers are the MFMA kernels of csrc/mrec_dense.hip (inference path,
-        no autograd); the last layer (128 -> 1, a GEMV) is fp32.  Otherwise (fp32 net, CPU stand-in) plain autograd."""
+        """DenseLayer x5 (wide_and_deep.py:113-133), inference: act(x W + b), ReLU on all but the last; returns the fp32 logit.
+        16-bit nets: the MFMA kernels of csrc/mrec_dense.hip, the output layer in fp32; fp32 nets: the exact-fp32 MFMA kernels."""
         n = len(self.dims) - 1
         amp = self._amp
-        if self._mfma and not torch.is_grad_enabled():
+        if self._mfma:
             h = x if x.dtype == amp else x.to(amp)
             for i in range(n - 1):
                 h = self.k.dense_fwd(h, self.dense16[2 * i], self.dense[2 * i + 1].detach(), relu=True)
-            return torch.addmm(self.dense[2 * (n - 1) + 1].detach(), h.float(), self.dense[2 * (n - 1)].detach())
-        if self._f32net and not torch.is_grad_enabled():
+            # the output layer (K5 -> 1) in fp32, on the exact-fp32 matrix kernel
+            return self.k.dense32_fwd(h.float(), self.dense[2 * (n - 1)].detach(), self.dense[2 * (n - 1) + 1].detach(), relu=False)
+        if self._f32net:
             h = x.contiguous()
             for i in range(n - 1):
                 h = self.k.dense32_fwd(h, self.dense[2 * i].detach(), self.dense[2 * i + 1].detach(), relu=True)
             return self.k.dense32_fwd(h, self.dense[2 * (n - 1)].detach(), self.dense[2 * (n - 1) + 1].detach(), relu=False)
-        h = x.to(amp) if amp is not None else x
-        for i in range(n):
-            W, b = self.dense[2 * i], self.dense[2 * i + 1]
-            d = self._drop(i, h.shape[0])
-            if d is not None:              # `x = self.dropout(x)`, :117-118 (autograd multiplies the gradient by the same mask)
-                h = h * self.k.dropout_mask(h.shape[0], h.shape[1], d, self.device).to(h.dtype)
-            if amp is not None and i < n - 1:
-                h = torch.addmm(b.to(amp), h, W.to(amp))
-            else:
-                h = torch.addmm(b, h.float(), W)
-            if i < n - 1:
-                h = torch.relu(h)
-        return h.float()
+        return self._mlp_generic(x)
+
+    # ---- hooks: nets without a HIP path.  The product refuses them; tests/_torch_net.py implements them for the oracle side ----
+    def _unsupported(self, what):
+        dt = {None: "fp32", torch.float16: "fp16", torch.bfloat16: "bf16"}[getattr(self, "_amp", None)]
+        return UnsupportedNet(f"MREC_EUNSUPPORTED: {what}: no hand-written HIP path for the {dt} dense net {self.dims} on {self.device} "
+                              f"(16-bit nets: every width a multiple of 8; the layer in front of the output a power of two times 8, <= 512; "
+                              f"Dropout on the fp32 net is not provided)")
+
+    def _mlp_generic(self, x):
+        raise self._unsupported("inference forward")
+
+    def _head_generic(self, hs, wide, label, dhs):
+        raise self._unsupported("output head")
+
+    def _mlp_step_generic(self, emb, wide, label):
+        raise self._unsupported("training step")
 
     # ---- the mixed-precision dense net, forward + backward by hand on the MFMA kernels -----------------
     def _db_slabs(self, i, B):
@@ -273,14 +283,7 @@ class DenseNetMixin:
                                                        self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1], dh_scale=dhs)
             loss = loss.view(())
         else:
-            h4 = hs[-1].float()
-            logit = torch.addmm(b5, h4, W5) + wide.view(-1, 1)
-            loss = F.binary_cross_entropy_with_logits(logit, label)
-            dlogit = (torch.sigmoid(logit) - label) * (self._sens / B)          # d(sens * mean BCE)/d logit
-            torch.mm(h4.t(), dlogit, out=self.dense_grad[2 * (n - 1)])
-            torch.sum(dlogit, dim=0, out=self.dense_grad[2 * (n - 1) + 1])
-            dh = torch.ops.aten.threshold_backward((torch.mm(dlogit, W5.t()) * dhs).to(amp), hs[-1], 0)
-            torch.sum(dh, dim=0, dtype=torch.float32, out=self.dense_grad[2 * (n - 2) + 1])
+            return self._head_generic(hs, wide, label, dhs)
         return {"hs": hs, "loss": loss, "g_wide": dlogit.view(-1), "dh": dh}
 
     @torch.no_grad()

@@ -28,7 +28,6 @@ own comes first (sender s -> chunk (s - rank) mod n), and the send buffer X[0 : 
 allocation then share exactly that chunk; the collective moves the other n - 1 (`_exchange`).  On one rank nothing is left to
 move at all."""
 import torch
-import torch.nn.functional as F
 
 from .wide_deep_mlp import _WideProd
 
@@ -288,13 +287,7 @@ class ShardStepMixin:
             loss, g_emb, g_wide = self._mlp_step_f32(emb, wprod[..., 0].sum(dim=1) + self.wide_b, label)
             route["wide_b_in_head"] = False
         else:
-            emb.requires_grad_(True)
-            wide = (wprod[..., 0].sum(dim=1) + self.wide_b).requires_grad_(True)
-            self.dense_grad_flat.zero_()
-            logit = wide.view(-1, 1) + self.mlp(emb)
-            loss = F.binary_cross_entropy_with_logits(logit, label)      # SigmoidCrossEntropyWithLogits + ReduceMean
-            (loss * cfg.sens).backward()                                  # sens_param seeding, wide_and_deep.py:479-486
-            g_emb, g_wide = emb.grad, wide.grad
+            loss, g_emb, g_wide = self._mlp_step_generic(emb, wprod[..., 0].sum(dim=1) + self.wide_b, label)
             route["wide_b_in_head"] = False
         self._tock(ev)
         return loss, g_emb, g_wide, route["plan"], True, route, None, fused

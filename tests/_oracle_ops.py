@@ -71,6 +71,16 @@ def dense_adam_(p, m, v, g, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, beta1_p
             a.reshape(-1)[i] = k[0]
 
 
+def dense_adam_l2_(p, m, v, g, l2_scaled, sumsq=None, accumulate=False, **kw):
+    """g + fl(l2_scaled * p) (product rounded, then added), sum(p^2) of the old values in float64."""
+    pp = _np(p)
+    if sumsq is not None:
+        ss = float((pp.astype(np.float64) ** 2).sum())
+        sumsq[0] = (float(sumsq[0]) if accumulate else 0.0) + ss
+    gg = (_np(g) + (pp * np.float32(l2_scaled)).astype(np.float32)).astype(np.float32)
+    dense_adam_(p, m, v, torch.from_numpy(gg), **kw)
+
+
 def dense_ftrl_(var, accum, linear, g, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):
     O.dense_ftrl(_np(var), _np(accum), _np(linear), _np(g), lr=lr, l1=l1, l2=l2, lr_power=lr_power, grad_scale=grad_scale)
 

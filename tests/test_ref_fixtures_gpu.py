@@ -54,6 +54,8 @@ def test_wide_deep_engine_replays_reference_fixture(dev, case, graphs):
     RF.wd_load_init(eng, z, dynamic=bool(cfg["dynamic_embedding"]))
     losses = RF.wd_replay(eng, z, dev)
     _check_wd_engine(eng, z, cfg, losses)
+    if not cfg["sparse"]:      # the deep optimizer's loss: + l2_coef * sum(E^2) / 2 at the step's starting values (:356-360)
+        assert np.isclose(eng.deep_loss(losses[-1]), z["loss_d"][-1], rtol=2e-6, atol=0) and z["loss_d"][-1] > z["loss_w"][-1]
     if not cfg["dynamic_embedding"]:
         untouched = np.ones(cfg["vocab_size"], bool)
         untouched[z["ids"].reshape(-1)] = False
