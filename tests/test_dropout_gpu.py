@@ -162,13 +162,17 @@ def _row_rel(a, b):
 
 
 def test_fp32_engine_with_dropout_matches_oracle_engine(dev, oracle):
-    """The autograd fp32 net (`x = self.dropout(x)` as a multiply by the mask) against the same engine driven by the oracle on the
-    CPU, whose masks come from oracle.dropout_mask."""
-    from _oracle_engine import OracleDeepCrossEngine, OracleDeepFMEngine, OracleWideDeepEngine  # noqa: F401
+    """Dropout on the fp32 net has no HIP path: the product engine refuses it (UnsupportedNet, no silent torch fallback).  The
+    test-side engine with the torch net (`x = self.dropout(x)` as a multiply by the mask; embedding path on the HIP kernels, mask from
+    mrec_dropout_mask_f32) against the same engine driven by the oracle on the CPU, whose masks come from oracle.dropout_mask."""
+    from _oracle_engine import OracleWideDeepEngine, TorchNetWideDeepEngine
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
+    from mindrec_amd.wide_deep_mlp import UnsupportedNet
     cfg = WideDeepConfig(vocab_size=50_000, emb_dim=80, field_size=26, batch_size=256, deep_layer_dim=[64, 32], mlp_dtype="fp32",
                          dropout_flag=True)
-    g = WideDeepEngine(cfg, dev)
+    with pytest.raises(UnsupportedNet, match="MREC_EUNSUPPORTED"):
+        WideDeepEngine(cfg, dev).train_step(*(t.to(dev) for t in synthetic_batch(cfg, "cpu", "zipf", seed=7)))
+    g = TorchNetWideDeepEngine(cfg, dev)
     c = OracleWideDeepEngine(cfg, "cpu")
     n = WideDeepEngine(WideDeepConfig(**{**cfg.__dict__, "dropout_flag": False}), dev)
     for s in range(3):

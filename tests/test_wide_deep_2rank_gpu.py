@@ -44,7 +44,7 @@ def _worker(rank, world, port, steps, out_dir, mlp_dtype="fp32", cap_factor=1.25
     if broken_lists:                      # a communicator whose per-peer-list all-to-all refuses the call (as a library that does
         class _Broken(StagedGlooComm):    # not take empty entries would: on every rank alike)
             def all_to_all_lists(self, outs, ins):
-                raise RuntimeError("no per-peer lists here")
+                raise TypeError("no per-peer lists here")      # (an argument refusal: what the self-test may swallow)
         comm = _Broken()
     eng = WideDeepEngine(cfg, dev, rank=rank, world=world, comm=comm)
     assert eng._bypass == (not broken_lists), "own-chunk bypass: on after its start-up self-test, off when the communicator refuses it"

@@ -74,8 +74,11 @@ def test_dense_gradient_mode_matches_oracle_engine(dev, oracle):
     assert np.abs(aw - bw).max() <= 1e-4 * np.abs(w0).max()
     assert (bw[untouched] == 0).all() and (w0[untouched] != 0).any()   # dense FTRL re-derives w from linear = 0
     assert np.allclose(g.dense_flat.detach().cpu().numpy(), c.dense_flat.detach().numpy(), rtol=1e-4, atol=1e-6)
-    dl = g.deep_loss(lg)
-    assert dl > lg and abs((dl - lg) - cfg.l2_coef * 0.5 * float((b.astype(np.float64) ** 2).sum())) <= 1e-6 * dl
+    # the deep optimizer's loss: + l2_coef * sum(E^2) / 2 at the last step's STARTING values (the forward's, wide_and_deep.py:356-360),
+    # a by-product of that step's Adam pass; the oracle-side engine states the same over numpy
+    dl, dlc = g.deep_loss(lg), c.deep_loss(lc)
+    assert dl > lg and abs(dl - dlc) <= 2e-6 * dl
+    assert abs((dl - lg) - cfg.l2_coef * 0.5 * float((b.astype(np.float64) ** 2).sum())) <= 0.1 * (dl - lg)      # (close to the final table's)
 
 
 def test_predict_and_lookup(dev, oracle):
