@@ -6,6 +6,7 @@ import torch
 from ..._kernels import K
 from ...common.parameter import Parameter, ParameterTuple
 from ...common.sparse_tensor import MapTensorGrad, RowTensor
+from ...common.tensor import Tensor
 from ...experimental import MapParameter
 from ..cell import Cell
 
@@ -101,12 +102,32 @@ class _AdamBase(Optimizer):
         self.beta1, self.beta2, self.eps = np.float32(beta1), np.float32(beta2), float(eps)
         self.use_nesterov, self.use_locking = bool(use_nesterov), bool(use_locking)
         self.beta1_power, self.beta2_power = np.float32(1.0), np.float32(1.0)
+        for p in self.parameters:                    # state exists from construction on (a checkpoint can be loaded before step 1)
+            if isinstance(p, Parameter):
+                self._slot(p, "moment1", 0.0)
+                self._slot(p, "moment2", 0.0)
+        # the step scalars as (non-trainable) Parameters too, so that a checkpoint carries them: resuming continues bit for bit
+        self.__dict__["_scalars"] = {n: Parameter(Tensor(np.array([v], np.float64), device="cpu"), name=n, requires_grad=False)
+                                     for n, v in (("beta1_power", 1.0), ("beta2_power", 1.0), ("global_step", 0.0))}
+
+    def get_parameters(self, expand=True):
+        yield from super().get_parameters(expand)
+        yield from self._scalars.values()
+
+    def _sync_from_parameters(self):
+        """After load_param_into_net: the host mirrors follow the loaded Parameters."""
+        s = self._scalars
+        self.beta1_power = np.float32(float(s["beta1_power"][0]))
+        self.beta2_power = np.float32(float(s["beta2_power"][0]))
+        self.global_step = int(round(float(s["global_step"][0])))
 
     def construct(self, gradients):
         self._check(gradients)
         self.global_step += 1
         self.beta1_power = np.float32(self.beta1_power * self.beta1)
         self.beta2_power = np.float32(self.beta2_power * self.beta2)
+        for n, v in (("beta1_power", self.beta1_power), ("beta2_power", self.beta2_power), ("global_step", self.global_step)):
+            self._scalars[n].as_subclass(torch.Tensor)[0] = float(v)
         kw = dict(lr=self.get_lr(), beta1=float(self.beta1), beta2=float(self.beta2), eps=self.eps,
                   beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
                   grad_scale=self.reciprocal_scale, use_nesterov=self.use_nesterov)
@@ -159,10 +180,24 @@ class FTRL(Optimizer):
                              f"but got {learning_rate!r}.")
         self.initial_accum, self.lr_power, self.l1, self.l2 = float(initial_accum), float(lr_power), float(l1), float(l2)
         self.use_locking = bool(use_locking)
+        for p in self.parameters:
+            if isinstance(p, Parameter):
+                self._slot(p, "accum", self.initial_accum)
+                self._slot(p, "linear", 0.0)
+        self.__dict__["_scalars"] = {"global_step": Parameter(Tensor(np.array([0.0], np.float64), device="cpu"), name="global_step",
+                                                                requires_grad=False)}
+
+    def get_parameters(self, expand=True):
+        yield from super().get_parameters(expand)
+        yield from self._scalars.values()
+
+    def _sync_from_parameters(self):
+        self.global_step = int(round(float(self._scalars["global_step"][0])))
 
     def construct(self, gradients):
         self._check(gradients)
         self.global_step += 1
+        self._scalars["global_step"].as_subclass(torch.Tensor)[0] = float(self.global_step)
         kw = dict(lr=self.get_lr(), l1=self.l1, l2=self.l2, lr_power=self.lr_power, grad_scale=self.reciprocal_scale)
         k = K()
         with torch.no_grad():

@@ -16,11 +16,15 @@ def _items(save_obj):
     from ..nn.cell import Cell
     if isinstance(save_obj, Cell):
         seen = set()
-        for _, c in save_obj.cells_and_names():
-            for p in list(c._params.values()) + list(c.get_parameters(expand=False)):
+        for cname, c in save_obj.cells_and_names():
+            for p in c._params.values():
                 if id(p) not in seen:
                     seen.add(id(p))
                     yield p.name, p
+            for p in c.get_parameters(expand=False):          # state a cell keeps outside its attributes (optimizers): under its path
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    yield (cname + "." if cname else "") + p.name, p
         return
     if isinstance(save_obj, dict):
         yield from save_obj.items()
@@ -129,6 +133,9 @@ def load_param_into_net(net, parameter_dict, strict_load=False):
                                f"the argument 'parameter_dict'. But got its shape {tuple(p.shape)} in the argument 'net' and shape "
                                f"{tuple(src.shape)} in the argument 'parameter_dict'.")
         p.set_data(src.to(p.device, p.dtype))
+    for _, c in net.cells_and_names():
+        if hasattr(c, "_sync_from_parameters"):
+            c._sync_from_parameters()           # optimizers: step scalars held on the host follow the loaded Parameters
     if strict_load and missing:
         raise RuntimeError(f"For 'load_param_into_net', {missing} in the argument 'net' are not loaded.")
     return missing
