@@ -45,13 +45,17 @@ class RecModel(Model):
         p.cur_epoch_num, p.cur_step_num, p.dataset_sink_mode = 0, 0, sink
         rc = RunContext(p)
         cbs.on_train_begin(rc)
-        helper, net = self._exec_preprocess(is_train=True, dataset=dataset, dataset_sink_mode=sink, sink_size=-1, epoch_num=-1)
+        # sink mode: an "epoch" of the callback protocol is one sink of `step_inc` batches (the reference re-enters its dataset
+        # helper once per epoch, rec_model.py:281-303 -- checkpoint names `<prefix>-<epoch>_<step>` count sinks); feed mode: one
+        # pass over the dataset, then reset()
+        helper, net = self._exec_preprocess(is_train=True, dataset=dataset, dataset_sink_mode=sink, sink_size=step_inc if sink else -1,
+                                            epoch_num=-1)
         for epoch in range(1, sys.maxsize):
             p.cur_epoch_num = epoch
             cbs.on_train_epoch_begin(rc)
             p.train_network = net
             for batch in helper:
-                p.cur_step_num += step_inc
+                p.cur_step_num += 1
                 cbs.on_train_step_begin(rc)
                 net = self._check_network_mode(net, True)
                 p.net_outputs = self._run_step(net, batch)

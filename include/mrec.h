@@ -325,6 +325,26 @@ int mrec_dense_adam_slabs_one_ftrl_f32(float* p, float* m, float* v, const float
                                        const int32_t* splits, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
                                        float grad_scale, int nesterov, void* step_state, const mrec_ftrl1_t* one_ftrl,
                                        void* stream);
+/* The finishing pass of mrec_sparse_lazy_adam_wide -- the runs of duplicates that cross windows of the sorted index: a chain of
+ * dependent round trips with almost nothing to move -- handed back instead of launched, and run as the first workgroups of the
+ * dense net's Adam launch (independent work: embedding rows vs the dense flat buffers): the step loses a latency-bound launch.
+ * mrec_sparse_lazy_adam_wide_defer fills *finish_out (an opaque record of launch arguments, valid until the workspace `ws`, the
+ * index arrays and the tables are reused); mrec_dense_adam_slabs_finish_f32 = mrec_dense_adam_slabs_one_ftrl_f32 + that pass.
+ * Results are bit-identical to the two separate launches.  Replaces the optimizer half of TrainStepWrap.construct,
+ * models/wide_deep/src/wide_and_deep.py:490-492. */
+typedef struct mrec_apply_finish_t { unsigned char opaque[384]; } mrec_apply_finish_t;
+int mrec_sparse_lazy_adam_wide_defer(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D, const void* uniq,
+                                     int32_t uniq_bytes, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                     const int32_t* seg_offsets, int64_t n, const void* g, int32_t g_kind, int64_t ldg,
+                                     const float* row_scale, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
+                                     float grad_scale, int nesterov, const float* gw, int64_t gw_stride, int32_t F, int32_t wide_col,
+                                     float ftrl_lr, float l1, float l2, float lr_power, void* ws, size_t ws_bytes, void* step_state,
+                                     const int64_t* n_valid_dev, mrec_apply_finish_t* finish_out, void* stream);
+int mrec_dense_adam_slabs_finish_f32(float* p, float* m, float* v, const float* g, void* shadow16, int shadow_kind, int64_t n,
+                                     int32_t nseg, const float* const* slabs, const int64_t* starts, const int64_t* lens,
+                                     const int32_t* splits, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
+                                     float grad_scale, int nesterov, void* step_state, const mrec_ftrl1_t* one_ftrl,
+                                     const mrec_apply_finish_t* finish, void* stream);
 /* The same slab sums WITHOUT the optimizer, all segments in one launch: g[starts[q] + e] = sum_s slabs[q][s*lens[q] + e] in slab
  * order -- what a data-parallel rank needs before the all-reduce of the dense gradients (train_and_eval_distribute.py:135-138). */
 int mrec_dense_sum_slab_segments_f32(float* g, int64_t n, int32_t nseg, const float* const* slabs, const int64_t* starts,

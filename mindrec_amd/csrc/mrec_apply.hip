@@ -22,8 +22,11 @@
 // no counter, no atomic.  A second launch (k_apply_long) finishes the short runs with one lane-group
 // each, partials in order, and the long ones with a whole 256-thread block in a fixed tree order.
 // Both passes are bitwise reproducible.
+#include <type_traits>
+
 #include "mrec_common.h"
 #include "mrec_optim.h"
+#include "mrec_dense_adam.h"
 
 namespace {
 
@@ -541,14 +544,16 @@ __global__ __launch_bounds__(256, WIDE ? MREC_WPS4 : 1) void k_apply_main(Upd up
 //   pass B: longer runs -- one block each: lane-groups take partials round-robin (fixed assignment), then
 //           group 0 adds the per-group sums in group order.
 // For k + 1 <= NG both orders coincide (each group holds one partial), so the split does not change results.
+// (bid, nblocks): the workgroup's number among those of this pass and their count -- the kernel below passes its own grid; the
+// launch that carries this pass in front of the dense Adam (k_finish_dense_adam) passes the pass's share of its grid)
 template <int VEC, class K, class Upd, bool WIDE = false>
-__global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
-                                                    const int* __restrict__ sseg,
-                                                    const int* __restrict__ seg_offsets, int n, ApplyGeom gm,
-                                                    const float* __restrict__ carry_head,
-                                                    const float* __restrict__ carry_tail,
-                                                    const int* __restrict__ owners, int nsw, WideArgs wa,
-                                                    const StepState* ss, const int64_t* __restrict__ nv = nullptr) {
+__device__ __forceinline__ void apply_long_body(Upd upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
+                                                const int* __restrict__ sseg,
+                                                const int* __restrict__ seg_offsets, int n, ApplyGeom gm,
+                                                const float* __restrict__ carry_head,
+                                                const float* __restrict__ carry_tail,
+                                                const int* __restrict__ owners, int nsw, const WideArgs& wa,
+                                                const StepState* ss, const int64_t* __restrict__ nv, int bid, int nblocks) {
     resolve_step(upd, ss);
     // the partials of a run are consecutive carry rows: stream them 16 deep per lane-group
     constexpr int AW = ACfg<VEC>::AW, AB = MREC_LONG_AB;
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
     // flags read window by window inside the passes, every iteration was a memory round trip to find, mostly, a zero)
     __shared__ int list_a[256], n_a;
     const int WPB = 4 * NG < 256 ? 4 * NG : 256;      // (the same expression sizes the grid in apply_cols)
-    const int64_t w0 = (int64_t)blockIdx.x * WPB;
+    const int64_t w0 = (int64_t)bid * WPB;
     if (threadIdx.x == 0) { n_a = 0; nlist = 0; }
     __syncthreads();
     if ((int)threadIdx.x < WPB && w0 + threadIdx.x < nsw) {
@@ -691,13 +696,51 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
         }
     }
     // end stamp (measurement): the last-dispatched workgroups raise it -- one atomic each, 256 at most
-    if (ss && threadIdx.x == 0 && (int)blockIdx.x + 256 >= (int)gridDim.x)
+    if (ss && threadIdx.x == 0 && bid + 256 >= nblocks)
         atomicMax((unsigned long long*)&ss->aux[(unsigned)ss->step % kStampRing][2], (unsigned long long)wall_clock64());
+}
+
+template <int VEC, class K, class Upd, bool WIDE = false>
+__global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
+                                                    const int* __restrict__ sseg,
+                                                    const int* __restrict__ seg_offsets, int n, ApplyGeom gm,
+                                                    const float* __restrict__ carry_head,
+                                                    const float* __restrict__ carry_tail,
+                                                    const int* __restrict__ owners, int nsw, WideArgs wa,
+                                                    const StepState* ss, const int64_t* __restrict__ nv = nullptr) {
+    apply_long_body<VEC, K, Upd, WIDE>(upd, V, ld, uniq, sseg, seg_offsets, n, gm, carry_head, carry_tail, owners, nsw, wa, ss, nv,
+                                       (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The finishing pass of the wide-folded apply (k_apply_long<4, K, UpdAdam, true>) and the dense net's Adam in ONE launch: the
+// first `lblocks` workgroups finish the runs that cross windows, the rest run the dense Adam.  The two are independent -- one
+// touches embedding rows, the other the dense net's flat buffers -- and the finishing pass is a chain of four or five
+// dependent round trips with almost nothing to move (uniform ids: ~450 runs; 9-10 us as a launch of its own behind
+// k_apply_main, 13 us on Zipf ids x 39 fields), which hides entirely inside the 32-us HBM-bound Adam pass beside it.  (As a graph
+// side branch instead the cross-branch join costs more than the overlap returns)
+struct ApplyFinish {
+    UpdAdam upd; int64_t V, ld; const void* uniq; int key_bytes; const int* sseg; const int* seg_offsets; int n; ApplyGeom gm;
+    const float* carry_head; const float* carry_tail; const int* owners; int nsw; WideArgs wa; const StepState* ss;
+    const int64_t* nv; unsigned lblocks; unsigned magic;
+};
+static_assert(sizeof(ApplyFinish) <= sizeof(mrec_apply_finish_t), "mrec_apply_finish_t too small");
+constexpr unsigned kFinishMagic = 0x4D524543u;
+
+template <class K, int SHK>
+__global__ __launch_bounds__(256) void k_finish_dense_adam(ApplyFinish f, DenseAdamSlabArgs a, SlabSegs sg) {
+    if (blockIdx.x < f.lblocks) {
+        apply_long_body<4, K, UpdAdam, true>(f.upd, f.V, f.ld, (const K*)f.uniq, f.sseg, f.seg_offsets, f.n, f.gm, f.carry_head,
+                                             f.carry_tail, f.owners, f.nsw, f.wa, f.ss, f.nv, (int)blockIdx.x, (int)f.lblocks);
+        return;
+    }
+    dense_adam4_slabs_body<SHK>(a.p, a.m, a.v, a.g, a.n4, a.h, a.shadow, sg, a.ss, a.f1,
+                                (int64_t)(blockIdx.x - f.lblocks) * 256 + threadIdx.x, (int64_t)(gridDim.x - f.lblocks) * 256);
 }
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 thread_local hipEvent_t t_prof_start = nullptr, t_prof_stop = nullptr;
+thread_local ApplyFinish* t_defer = nullptr;        // set by mrec_sparse_lazy_adam_wide_defer: the finishing pass is handed back, not launched
 
 struct ApplyWs { float* carry_head; float* carry_tail; int* owners; int* n_owners; float* dummy; };
 
@@ -736,8 +779,19 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
         k_apply_main<4, K, Upd, GT, true><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
                                                              w.carry_head, w.carry_tail, w.owners, seg_offsets, wa, ss, nv);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
-        k_apply_long<4, K, Upd, true><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
-                                                              w.carry_head, w.carry_tail, w.owners, (int)nsw, wa, ss, nv);
+        if (t_defer) {
+            if constexpr (std::is_same<Upd, UpdAdam>::value) {
+                ApplyFinish* f = t_defer;
+                f->upd = upd; f->V = V; f->ld = ld; f->uniq = uniq; f->key_bytes = (int)sizeof(K); f->sseg = sseg; f->seg_offsets = seg_offsets;
+                f->n = (int)n; f->gm = gm; f->carry_head = w.carry_head; f->carry_tail = w.carry_tail; f->owners = w.owners; f->nsw = (int)nsw;
+                f->wa = wa; f->ss = ss; f->nv = nv; f->lblocks = lblocks; f->magic = kFinishMagic;
+            } else {
+                return MREC_EUNSUPPORTED;
+            }
+        } else {
+            k_apply_long<4, K, Upd, true><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
+                                                                  w.carry_head, w.carry_tail, w.owners, (int)nsw, wa, ss, nv);
+        }
     } else if (vec == 4) {
         k_apply_main<4, K, Upd, GT><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
                                                        w.carry_head, w.carry_tail, w.owners, seg_offsets, wa, ss);
@@ -1006,6 +1060,78 @@ MREC_API int mrec_sparse_lazy_adam_wide(float* p, float* m, float* v, int64_t V,
     if (g_kind == 1) { MREC_WIDE_CALL(int64_t, bf16_t); }
     MREC_WIDE_CALL(int64_t, f16_t);
 #undef MREC_WIDE_CALL
+}
+
+/* The same with the finishing pass handed back instead of launched (see include/mrec.h). */
+MREC_API int mrec_sparse_lazy_adam_wide_defer(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D, const void* uniq,
+                                              int32_t uniq_bytes, const int32_t* sorted_pos, const int32_t* sorted_seg,
+                                              const int32_t* seg_offsets, int64_t n, const void* g, int32_t g_kind, int64_t ldg,
+                                              const float* row_scale, float lr, float b1, float b2, float eps, float b1_pow,
+                                              float b2_pow, float grad_scale, int nesterov, const float* gw, int64_t gw_stride, int32_t F,
+                                              int32_t wide_col, float ftrl_lr, float l1, float l2, float lr_power, void* ws,
+                                              size_t ws_bytes, void* step_state, const int64_t* n_valid_dev,
+                                              mrec_apply_finish_t* finish_out, void* stream) {
+    if (!finish_out) return MREC_EINVAL;
+    if (D > 252) return MREC_EUNSUPPORTED;            // (one column block: one finishing pass)
+    ApplyFinish* f = (ApplyFinish*)finish_out;
+    f->magic = 0u;
+    t_defer = f;
+    const int rc = mrec_sparse_lazy_adam_wide(p, m, v, V, ld, D, uniq, uniq_bytes, sorted_pos, sorted_seg, seg_offsets, n, g, g_kind, ldg,
+                                              row_scale, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale, nesterov, gw, gw_stride, F, wide_col,
+                                              ftrl_lr, l1, l2, lr_power, ws, ws_bytes, step_state, n_valid_dev, stream);
+    t_defer = nullptr;
+    if (rc == MREC_OK && f->magic != kFinishMagic) { f->lblocks = 0; f->magic = kFinishMagic; }      // (n == 0: nothing to finish)
+    return rc;
+}
+
+/* mrec_dense_adam_slabs_one_ftrl_f32 + the finishing pass a deferred apply handed back, one launch. */
+MREC_API int mrec_dense_adam_slabs_finish_f32(float* p, float* m, float* v, const float* g, void* shadow16, int shadow_kind, int64_t n,
+                                              int32_t nseg, const float* const* slabs, const int64_t* starts, const int64_t* lens,
+                                              const int32_t* splits, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
+                                              float grad_scale, int nesterov, void* step_state, const mrec_ftrl1_t* one,
+                                              const mrec_apply_finish_t* finish, void* stream) {
+    if (!finish || n <= 0 || nseg < 0 || nseg > 16 || shadow_kind < 0 || shadow_kind > 2) return MREC_EINVAL;
+    const ApplyFinish* fp = (const ApplyFinish*)finish;
+    if (fp->magic != kFinishMagic) return MREC_EINVAL;
+    if (!p || !m || !v || !g || (nseg > 0 && (!slabs || !starts || !lens || !splits)) || (shadow_kind && !shadow16)) return MREC_EINVAL;
+    if (n % 4 || !al16(p) || !al16(m) || !al16(v) || !al16(g) || (shadow16 && (((uintptr_t)shadow16) & 7))) return MREC_EUNSUPPORTED;
+    SlabSegs sg;
+    sg.n = nseg;
+    for (int q = 0; q < nseg; ++q) {
+        if (!slabs[q] || starts[q] < 0 || lens[q] <= 0 || starts[q] % 4 || lens[q] % 4 || starts[q] + lens[q] > n || splits[q] <= 0 ||
+            !al16(slabs[q]))
+            return MREC_EINVAL;
+        sg.part[q] = (const float4*)slabs[q];
+        sg.start4[q] = starts[q] / 4;
+        sg.len4[q] = lens[q] / 4;
+        sg.S[q] = splits[q];
+    }
+    DenseAdamSlabArgs a;
+    a.p = (float4*)p; a.m = (float4*)m; a.v = (float4*)v; a.g = (const float4*)g; a.n4 = n / 4; a.shadow = (uint2*)shadow16;
+    a.ss = (const StepState*)step_state;
+    a.h.lr_t = lr * sqrtf(1.0f - b2_pow) / (1.0f - b1_pow);
+    a.h.b1 = b1; a.h.b2 = b2; a.h.omb1 = 1.0f - b1; a.h.omb2 = 1.0f - b2; a.h.eps = eps; a.h.gscale = grad_scale; a.h.nesterov = nesterov;
+    a.f1.idx = -1;
+    a.f1.h = FtrlH{1.0f, 0.0f, 0.0f, -0.5f, grad_scale};
+    if (one && one->index >= 0) {
+        if (one->index >= n || !(one->lr > 0.0f) || one->l1 < 0.0f || one->l2 < 0.0f || one->lr_power > 0.0f) return MREC_EINVAL;
+        a.f1.idx = one->index;
+        a.f1.h = FtrlH{one->lr, one->l1, one->l2, one->lr_power, grad_scale};
+    }
+    int64_t ab = mrec_cdiv(a.n4, 256);
+    if (ab > 256 * 16) ab = 256 * 16;
+    const unsigned grid = fp->lblocks + (unsigned)ab;
+    hipStream_t st = (hipStream_t)stream;
+#define MREC_FIN(KT)                                                                                      \
+    do {                                                                                                   \
+        if (shadow_kind == 1) k_finish_dense_adam<KT, 1><<<grid, 256, 0, st>>>(*fp, a, sg);                \
+        else if (shadow_kind == 2) k_finish_dense_adam<KT, 2><<<grid, 256, 0, st>>>(*fp, a, sg);           \
+        else k_finish_dense_adam<KT, 0><<<grid, 256, 0, st>>>(*fp, a, sg);                                 \
+    } while (0)
+    if (fp->key_bytes == 8) MREC_FIN(int64_t); else MREC_FIN(int32_t);
+#undef MREC_FIN
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
 }
 
 MREC_API int mrec_sparse_ftrl_f32_i32(float* var, float* accum, float* linear, int64_t V, int64_t ld, int32_t D,

@@ -11,6 +11,7 @@
 #include "mrec_rng.h"
 #include "mrec_optim.h"
 #include "mrec_dropout.h"
+#include "mrec_dense_adam.h"
 
 int g_mrec_last_hip_error = 0;
 
@@ -35,7 +36,6 @@ __device__ __forceinline__ Vf<1> vzero(Vf<1>*) { Vf<1> r; r.v = 0.f; return r; }
 // bf16 output rows (round-to-nearest-even, the cast the reference applies to the masked embeddings
 // before its mixed-precision MLP, wide_and_deep.py:113-133): halves the gather's write stream.
 struct bf16o_t { uint16_t v; };
-__device__ __forceinline__ uint16_t f2bf(float x) { __bf16 b = (__bf16)x; return __builtin_bit_cast(uint16_t, b); }
 __device__ __forceinline__ void vstore(bf16o_t* p, const Vf<4>& x) {
     uint2 u;
     u.x = (unsigned)f2bf(x.v.x) | ((unsigned)f2bf(x.v.y) << 16);
@@ -371,16 +371,6 @@ __global__ __launch_bounds__(256) void k_move_rows(const float* __restrict__ src
 __device__ __forceinline__ float g_widen(float x) { return x; }
 __device__ __forceinline__ float g_widen(uint16_t x) { return __uint_as_float(((unsigned)x) << 16); }
 
-// One element of a dense buffer may belong to FTRL instead of Adam (Ftrl1: its index, or -1): Wide&Deep's `wide_b`, which
-// TrainStepWrap hands to the FTRL optimizer with the wide table (wide_and_deep.py:407-411) while it lives in the dense net's flat
-// buffer here -- its `m` word is FTRL's accum, its `v` word FTRL's linear.  A uniform compare per vector; no second launch.
-struct Ftrl1 { int64_t idx; FtrlH h; };
-
-__device__ __forceinline__ void adam_or_ftrl(float& p, float& m, float& v, float g, const AdamH& h, bool ftrl, const FtrlH& fh) {
-    if (ftrl) ftrl_elem(p, m, v, g, fh);
-    else adam_elem(p, m, v, g, h);
-}
-
 template <class GT, bool SH>
 __global__ __launch_bounds__(256) void k_dense_adam(float* __restrict__ p, float* __restrict__ m,
                                                     float* __restrict__ v, const GT* __restrict__ g, int64_t n,
@@ -461,64 +451,6 @@ __global__ __launch_bounds__(256) void k_dense_adam4_g16(float4* __restrict__ p,
         p[i] = pp; m[i] = mm; v[i] = vv;
         if (SH) shadow[i] = make_uint2((unsigned)f2bf(pp.x) | ((unsigned)f2bf(pp.y) << 16),
                                        (unsigned)f2bf(pp.z) | ((unsigned)f2bf(pp.w) << 16));
-    }
-}
-
-// The same, for the hand-written MFMA weight-gradient kernel (mrec_dense.hip): its split slabs are fp32 partial
-// sums (never rounded), added here in slab order.  SHK: 0 = no shadow, 1 = bf16 shadow, 2 = fp16 shadow.
-struct SlabSegs {
-    const float4* part[16];
-    int64_t start4[16], len4[16];
-    int S[16];
-    int n;
-};
-
-__device__ __forceinline__ unsigned pack_shadow2(float lo, float hi, int shk) {
-    if (shk == 2) {
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        h2 v = {(_Float16)lo, (_Float16)hi};
-        return __builtin_bit_cast(unsigned, v);
-    }
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
-}
-
-template <int SHK>
-__global__ __launch_bounds__(256) void k_dense_adam4_slabs(float4* __restrict__ p, float4* __restrict__ m,
-                                                           float4* __restrict__ v, const float4* __restrict__ g,
-                                                           int64_t n4, AdamH h, uint2* __restrict__ shadow, SlabSegs sg,
-                                                           const StepState* ss, Ftrl1 f1) {
-    if (ss) h.lr_t = ss->lr_t;             // this step's bias-corrected step size from device memory (mrec_step_advance)
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 pp = p[i], mm = m[i], vv = v[i];
-        float4 gg;
-        int k = -1;
-        for (int q = 0; q < sg.n; ++q)
-            if (i >= sg.start4[q] && i < sg.start4[q] + sg.len4[q]) k = q;
-        if (k >= 0) {
-            // slabs added in slab order, eight loads in flight at a time (a serial loop over 64 bias-gradient slabs is 64
-            // dependent L2 round trips for the threads that own bias elements: it doubled the kernel's time)
-            const float4* src = sg.part[k] + (i - sg.start4[k]);
-            const int S = sg.S[k];
-            const int64_t L = sg.len4[k];
-            gg = src[0];
-            for (int s0 = 1; s0 < S; s0 += 8) {
-                float4 u[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) u[q] = (s0 + q < S) ? src[(int64_t)(s0 + q) * L] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (s0 + q < S) { gg.x += u[q].x; gg.y += u[q].y; gg.z += u[q].z; gg.w += u[q].w; }
-            }
-        } else {
-            gg = g[i];
-        }
-        const int fq = (f1.idx >> 2) == i ? (int)(f1.idx & 3) : -1;
-        adam_or_ftrl(pp.x, mm.x, vv.x, gg.x * h.gscale, h, fq == 0, f1.h);
-        adam_or_ftrl(pp.y, mm.y, vv.y, gg.y * h.gscale, h, fq == 1, f1.h);
-        adam_or_ftrl(pp.z, mm.z, vv.z, gg.z * h.gscale, h, fq == 2, f1.h);
-        adam_or_ftrl(pp.w, mm.w, vv.w, gg.w * h.gscale, h, fq == 3, f1.h);
-        p[i] = pp; m[i] = mm; v[i] = vv;
-        if (SHK) shadow[i] = make_uint2(pack_shadow2(pp.x, pp.y, SHK), pack_shadow2(pp.z, pp.w, SHK));
     }
 }
 

@@ -352,9 +352,13 @@ def sparse_lazy_adam_(p, m, v, plan, g, row_scale=None, lr=3.5e-4, beta1=0.9, be
               beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _ptr(ws), ws.numel(), _stream())
 
 
+class ApplyFinish(C.Structure):      # mrec_apply_finish_t
+    _fields_ = [("opaque", C.c_ubyte * 384)]
+
+
 def sparse_lazy_adam_wide_(p, m, v, plan, g, row_scale, gw, F, wide_col, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8,
                            beta1_power=0.9, beta2_power=0.999, grad_scale=1.0, use_nesterov=False, ftrl_lr=5e-2, l1=1e-8, l2=1e-8,
-                           lr_power=-0.5, step_state=None):
+                           lr_power=-0.5, step_state=None, defer=False):
     """LazyAdam on the deep columns and FTRL on the wide record of the same fused rows in ONE pass (wide_and_deep.py:420-430):
     gw [n / F] is the wide branch's gradient per sample (the head's dlogit); position i contributes gw[i // F] * row_scale[i].
     step_state (StepState): the Adam step size comes from device memory (beta powers ignored) and the main kernel stamps its
@@ -377,11 +381,21 @@ def sparse_lazy_adam_wide_(p, m, v, plan, g, row_scale, gw, F, wide_col, lr=3.5e
     nb = _lib.query_bytes("mrec_sparse_apply_workspace_bytes", max(plan.n, 1), D + 4)
     ws = workspace("apply", nb, p.device)
     kind = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[g2.dtype]
-    _lib.call("mrec_sparse_lazy_adam_wide", _ptr(p), _ptr(m), _ptr(v), V, ld, D, _ptr(plan.uniq_buf), plan.uniq_buf.element_size(),
-              _ptr(plan.sorted_pos), _ptr(plan.sorted_seg), _ptr(plan.seg_offsets), plan.n, _ptr(g2), kind, ldg, _ptr(rs), lr,
-              beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _ptr(gw), int(gws), int(F), int(wide_col),
-              ftrl_lr, l1, l2, lr_power, _ptr(ws), ws.numel(), _ptr(step_state.buf) if step_state is not None else None,
-              _ptr(getattr(plan, "n_valid_dev", None)), _stream())
+    args = (_ptr(p), _ptr(m), _ptr(v), V, ld, D, _ptr(plan.uniq_buf), plan.uniq_buf.element_size(),
+            _ptr(plan.sorted_pos), _ptr(plan.sorted_seg), _ptr(plan.seg_offsets), plan.n, _ptr(g2), kind, ldg, _ptr(rs), lr,
+            beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _ptr(gw), int(gws), int(F), int(wide_col),
+            ftrl_lr, l1, l2, lr_power, _ptr(ws), ws.numel(), _ptr(step_state.buf) if step_state is not None else None,
+            _ptr(getattr(plan, "n_valid_dev", None)))
+    if defer:
+        # the finishing pass (runs of duplicates that cross windows of the sorted index) is handed back: dense_adam_slabs_(...,
+        # finish=...) runs it as the first workgroups of the dense net's Adam launch.  The record points into `ws`, the plan and
+        # the tables: run the finish before any of them is reused.
+        fin = ApplyFinish()
+        fin.keep = (ws, plan, p, g2, rs, gw)
+        _lib.call("mrec_sparse_lazy_adam_wide_defer", *args, C.cast(C.pointer(fin), C.c_void_p), _stream())
+        return fin
+    _lib.call("mrec_sparse_lazy_adam_wide", *args, _stream())
+    return None
 
 
 def sparse_ftrl_(var, accum, linear, plan, g, row_scale=None, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):
@@ -1374,7 +1388,7 @@ def sum_slab_segments_(g, slabs):
 
 
 def dense_adam_slabs_(p, m, v, g, slabs, shadow16=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, beta1_power=0.9,
-                      beta2_power=0.999, grad_scale=1.0, use_nesterov=False, step_state=None, ftrl1=None):
+                      beta2_power=0.999, grad_scale=1.0, use_nesterov=False, step_state=None, ftrl1=None, finish=None):
     """dense_adam_ whose gradient is, for some segments, still the fp32 batch slabs of dense_bwd_weight:
     slabs = [(start, tensor [S, ...] fp32)], start = element offset of the segment in the flat buffers; the slabs
     are added in slab order inside the Adam kernel.  shadow16 (bf16 / fp16, optional) receives the updated parameters."""
@@ -1399,11 +1413,15 @@ def dense_adam_slabs_(p, m, v, g, slabs, shadow16=None, lr=1e-3, beta1=0.9, beta
             raise TypeError("slabs must be contiguous float32 [S, ...]")
         ptrs[q], starts[q], lens[q], splits[q] = part.data_ptr(), int(start), part[0].numel(), part.shape[0]
     f = _ftrl1(ftrl1) if ftrl1 is not None else None
-    _lib.call("mrec_dense_adam_slabs_one_ftrl_f32", _ptr(p), _ptr(m), _ptr(v), _ptr(g), _ptr(shadow16), kind, n, k,
-              C.cast(ptrs, C.c_void_p), C.cast(starts, C.c_void_p), C.cast(lens, C.c_void_p), C.cast(splits, C.c_void_p),
-              lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov),
-              _ptr(step_state.buf) if step_state is not None else None, C.cast(C.pointer(f), C.c_void_p) if f is not None else None,
-              _stream())
+    args = (_ptr(p), _ptr(m), _ptr(v), _ptr(g), _ptr(shadow16), kind, n, k,
+            C.cast(ptrs, C.c_void_p), C.cast(starts, C.c_void_p), C.cast(lens, C.c_void_p), C.cast(splits, C.c_void_p),
+            lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov),
+            _ptr(step_state.buf) if step_state is not None else None, C.cast(C.pointer(f), C.c_void_p) if f is not None else None)
+    if finish is not None:        # + the finishing pass of a deferred sparse apply, as the first workgroups of this launch
+        _lib.call("mrec_dense_adam_slabs_finish_f32", *args, C.cast(C.pointer(finish), C.c_void_p), _stream())
+        finish.keep = None
+        return
+    _lib.call("mrec_dense_adam_slabs_one_ftrl_f32", *args, _stream())
 
 
 # ---- DenseLayer in fp32 on the fp32-input matrix instruction (csrc/mrec_gemm_f32.hip) -----------------------------------

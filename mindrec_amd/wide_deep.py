@@ -790,13 +790,16 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         if self.deep_apply_timer is not None:
             self.deep_apply_timer.arm()
             self.deep_apply_timer = None
+        finish = None
         if self._fold_wide and fused:
-            # LazyAdam on the deep columns + FTRL on the wide record of the same rows: one visit per touched row
-            self.k.sparse_lazy_adam_wide_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, g_wide, Fd, D,
-                                          lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
-                                          beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
-                                          grad_scale=inv_sens, ftrl_lr=cfg.ftrl_lr, l1=cfg.ftrl_l1, l2=cfg.ftrl_l2,
-                                          step_state=state)
+            # LazyAdam on the deep columns + FTRL on the wide record of the same rows: one visit per touched row.  The pass that
+            # finishes the runs crossing windows of the sorted index is handed back (`finish`) and rides the dense Adam launch
+            # below: a latency-bound launch less on the critical path
+            finish = self.k.sparse_lazy_adam_wide_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, g_wide, Fd, D,
+                                                   lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
+                                                   beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
+                                                   grad_scale=inv_sens, ftrl_lr=cfg.ftrl_lr, l1=cfg.ftrl_l1, l2=cfg.ftrl_l2,
+                                                   step_state=state, defer=True)
         else:
             self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, lr=cfg.adam_lr,
                                      beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
@@ -822,7 +825,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
             # the weight gradients stay fp32 batch slabs and are added up inside the Adam kernel (nobody else needs the sums);
             # the kernel also refreshes the 16-bit operand shadow
             self.k.dense_adam_slabs_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, self._slab_segments(),
-                                     shadow16=self.dense16_flat, step_state=state, ftrl1=self._wb_ftrl, **akw)
+                                     shadow16=self.dense16_flat, step_state=state, ftrl1=self._wb_ftrl, finish=finish, **akw)
             self._refresh_tail()
         else:
             self.k.dense_adam_(flat, self.dense_m, self.dense_v, self.dense_grad_flat, ftrl1=self._wb_ftrl, **akw)
