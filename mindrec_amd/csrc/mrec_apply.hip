@@ -16,6 +16,12 @@
 // (gradient rows and state rows) are issued together before the first dependent op, so every
 // lane-group keeps up to 4*AB 16-byte loads in flight.
 //
+// (Tried in round 4 and not kept: the gradient rows of a batch's two entries fetched by ONE 16-byte-per-lane load -- even lanes 8
+// columns of the first entry's row, odd lanes of the second's -- with the halves traded over the DPP network, the trick that took
+// the lookup's stores from 8 to 16 bytes per lane (mrec_gather.hip, k_gather_rows_w16).  Bit-identical, and slower: uniform ids
+// 188 -> 201 us, Zipf x 39 fields 122 -> 128, Zipf x 26 fields 109 -> 127 (kernel alone, HIP events): at 128 VGPRs the exchange's
+// registers and selects cost more than the halved load count returns.)
+//
 // Runs that cross a window boundary (duplicate-heavy ids, e.g. Criteo's 13 constant dense-field ids
 // with 16384 copies each) leave per-window partial sums in a carry buffer, and every window writes a
 // flag (0 = no run continues past it, 1 = it owns a run with few partials, 2 = a long run): no list,
@@ -576,7 +582,7 @@ __device__ __forceinline__ void apply_long_body(Upd upd, int64_t V, int64_t ld, 
     // ---- this block's windows: 4 per lane-group, their flags read in ONE coalesced load and sorted into two lists in LDS (with
     // flags read window by window inside the passes, every iteration was a memory round trip to find, mostly, a zero)
     __shared__ int list_a[256], n_a;
-    const int WPB = 4 * NG < 256 ? 4 * NG : 256;      // (the same expression sizes the grid in apply_cols)
+    const int WPB = 16 * NG < 256 ? 16 * NG : 256;    // (the same expression sizes the grid in apply_cols)
     const int64_t w0 = (int64_t)bid * WPB;
     if (threadIdx.x == 0) { n_a = 0; nlist = 0; }
     __syncthreads();
@@ -770,7 +776,7 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
     const int64_t nsw = mrec_cdiv(n, vec == 4 ? ACfg<4>::AW : ACfg<1>::AW);
     unsigned blocks = (unsigned)mrec_cdiv(nsw, (int64_t)4 * gm.G);
     if (blocks > MREC_APPLY_MAXB) blocks = MREC_APPLY_MAXB;
-    const unsigned lblocks = (unsigned)mrec_cdiv(nsw, (int64_t)(16 * gm.G < 256 ? 16 * gm.G : 256));      // k_apply_long: 4 windows per lane-group, 4 G lane-groups, 256 at most
+    const unsigned lblocks = (unsigned)mrec_cdiv(nsw, (int64_t)(64 * gm.G < 256 ? 64 * gm.G : 256));      // k_apply_long: 16 windows per lane-group, 4 G lane-groups, 256 at most
     const hipEvent_t ev0 = t_prof_start, ev1 = t_prof_stop;
     t_prof_start = t_prof_stop = nullptr;
     if (ev0) MREC_HIP_CHECK(hipEventRecord(ev0, st));

@@ -7,6 +7,8 @@
 // All of these are HBM-bound byte movers.  A row of D floats is covered by lpr = D/4 lanes holding
 // one float4 each (D = 80 -> 20 lanes, three rows per wave64 instruction, 60/64 lanes busy); each
 // lane-group keeps GB independent row loads in flight before the first store.
+#include <stdlib.h>
+
 #include "mrec_common.h"
 #include "mrec_rng.h"
 #include "mrec_optim.h"
@@ -141,7 +143,11 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
         const int64_t i = wave_row0 + (int64_t)k * gm.G + grp;
         if (i >= n) row[k] = -1;
         okr[k] = row[k] >= 0 && row[k] < V;
+#if defined(MREC_GATHER_ABL) && MREC_GATHER_ABL == 2      // ablation: no row loads (every lane-group reads row 0)
+        x[k] = vload(table + col, (Vf<VEC>*)nullptr);
+#else
         x[k] = vload(table + (okr[k] ? row[k] : 0) * ld + col, (Vf<VEC>*)nullptr);
+#endif
     }
 #pragma unroll
     for (int k = 0; k < GB; ++k) {
@@ -151,7 +157,11 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
 #pragma unroll
     for (int k = 0; k < GB; ++k) {
         const int64_t i = wave_row0 + (int64_t)k * gm.G + grp;
+#if defined(MREC_GATHER_ABL) && MREC_GATHER_ABL == 1      // ablation: no stores (a condition the compiler cannot fold)
+        if (i < n && sc[k] == 1.2345e30f) {
+#else
         if (i < n && !(skip_invalid && row[k] < 0)) {       // (skip_invalid: padding slots of a message are left alone)
+#endif
             const Vf<VEC> y = row_scale ? vscale(x[k], sc[k]) : x[k];
             if constexpr (VEC == 4) {
               if (wprod != nullptr) {
@@ -176,6 +186,107 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
             }
         }
     }
+    }
+    if (stamp && (int)blockIdx.x + 512 >= (int)gridDim.x && lane == 0 && atomicAdd(&waves_done, 1) == 3)
+        atomicMax(&stamp[1], (unsigned long long)wall_clock64());
+}
+
+// ---- the lookup with 16-byte stores (16-bit rows, D % 8 == 0) ---------------------------------------------------------
+// What the kernel above is bound by turned out to be its STORES, not its row reads (profiles/r04_gather_ablation.txt: without
+// stores 33 us, without row loads 24 us, both 45 us on uniform ids; on Zipf ids x 39 fields 28 / 32 / 52): a lane holds 4 columns
+// = 8 bytes of 16-bit output, and 8-byte-per-lane stores issue at about half the rate of 16-byte ones.  Here neighbouring lanes
+// of a row trade halves of TWO rows through the DPP network (quad_perm [1,0,3,2]: one VALU move per dword, no LDS) so that the
+// even lane stores 16 bytes (8 columns) of row k and the odd lane 16 bytes of row k + 1 -- ONE store instruction per pair of
+// rows, half as many as before, every one 16 bytes wide; the wide lane stores the products of both rows as one 16-byte word.
+// A lane-group takes 4 CONSECUTIVE positions (their ids and weights are one 16-byte load each instead of four scalar ones).
+// Odd lane-groups keep their wide lane FIRST so that every deep pair starts on an even hardware lane (lpr = D / 4 + 1 is odd).
+__device__ __forceinline__ unsigned dpp_swap1(unsigned x) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+template <class K> struct Ids4;
+template <> struct Ids4<int32_t> {
+    int4 v;
+    __device__ __forceinline__ void load(const int32_t* p) { v = *(const int4*)p; }
+    __device__ __forceinline__ int64_t at(int k) const { return (int64_t)(k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w); }
+};
+template <> struct Ids4<int64_t> {
+    longlong2 a, b;
+    __device__ __forceinline__ void load(const int64_t* p) { a = *(const longlong2*)p; b = *(const longlong2*)(p + 2); }
+    __device__ __forceinline__ int64_t at(int k) const { return k == 0 ? a.x : k == 1 ? a.y : k == 2 ? b.x : b.y; }
+};
+
+template <class K, class OT>
+__global__ __launch_bounds__(256) void k_gather_rows_w16(const float* __restrict__ table, int64_t V, int64_t ld,
+                                                         const K* __restrict__ ids, int64_t n, const float* __restrict__ row_scale,
+                                                         OT* __restrict__ out, int D, RowGeom gm, float* __restrict__ wprod,
+                                                         int64_t ldo, GatherDrop gd, StepState* ss) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
+    __shared__ int waves_done;
+    unsigned long long* stamp = ss ? ss->aux[(unsigned)(ss->step + 1) % kStampRing] : nullptr;      // (as k_gather_rows)
+    if (stamp) {
+        if (threadIdx.x == 0) {
+            waves_done = 0;
+            if (blockIdx.x == 0) stamp[0] = (unsigned long long)wall_clock64();
+        }
+        __syncthreads();
+    }
+    if (grp < gm.G) {
+        const bool has_w = wprod != nullptr;
+        const bool wfirst = has_w && (grp & 1);
+        const bool wl = has_w && (wfirst ? sub == 0 : sub == gm.lpr - 1);
+        const int ds = wfirst ? sub - 1 : sub;                     // deep lane number (4 columns each); parity = the hardware lane's
+        const int col = wl ? D : ds * 4;
+        const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * (gm.G * 4) + grp * 4;
+        const bool live = i0 < n;                                  // (n % 4 == 0: a lane-group's 4 positions are all inside or all outside)
+        const int64_t ic = live ? i0 : n - 4;
+        Ids4<K> idv;
+        idv.load(ids + ic);
+        float4 scv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (row_scale) scv = *(const float4*)(row_scale + ic);
+        uint64_t dkey = 0;
+        if (gd.d.thresh) dkey = drop_key(gd.d);
+        Vf<4> x[4];
+        bool okr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t r = idv.at(k);
+            okr[k] = r >= 0 && r < V;
+            x[k] = vload(table + (okr[k] ? r : 0) * ld + col, (Vf<4>*)nullptr);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            vtouch(x[k]);
+            if (!okr[k]) x[k] = vzero((Vf<4>*)nullptr);
+        }
+        const float sc[4] = {scv.x, scv.y, scv.z, scv.w};
+        uint2 pk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const Vf<4> y = row_scale ? vscale(x[k], sc[k]) : x[k];
+            pk[k] = pack16((const OT*)nullptr, y.v);
+            if (gd.d.thresh && !wl) pk[k] = drop16<OT>(pk[k], gd, dkey, i0 + k, D, col);
+            if (wl) pk[k] = make_uint2(__float_as_uint(y.v.x), 0u);
+        }
+        const bool odd = (ds & 1) != 0;
+#pragma unroll
+        for (int kp = 0; kp < 4; kp += 2) {
+            const uint2 pa = make_uint2(dpp_swap1(pk[kp].x), dpp_swap1(pk[kp].y));              // the partner's half of row kp
+            const uint2 pb = make_uint2(dpp_swap1(pk[kp + 1].x), dpp_swap1(pk[kp + 1].y));      // ... of row kp + 1
+            uint4 o;
+            void* dst;
+            if (wl) {
+                o = make_uint4(pk[kp].x, 0u, pk[kp + 1].x, 0u);
+                dst = wprod + 2 * (i0 + kp);
+            } else if (odd) {
+                o = make_uint4(pb.x, pb.y, pk[kp + 1].x, pk[kp + 1].y);
+                dst = out + (i0 + kp + 1) * ldo + (col - 4);
+            } else {
+                o = make_uint4(pk[kp].x, pk[kp].y, pa.x, pa.y);
+                dst = out + (i0 + kp) * ldo + col;
+            }
+            if (live) *(uint4*)dst = o;
+        }
     }
     if (stamp && (int)blockIdx.x + 512 >= (int)gridDim.x && lane == 0 && atomicAdd(&waves_done, 1) == 3)
         atomicMax(&stamp[1], (unsigned long long)wall_clock64());
@@ -507,7 +618,18 @@ int gather_bf16_impl(const float* table, int64_t V, int64_t ld, int32_t D, const
     if (V == 0) return MREC_EINVAL;      // rows are read unconditionally at clamped addresses: an empty table has no valid one
     if (!table || !ids || !out) return MREC_EINVAL;
     const bool vec = (D % 4 == 0) && (D <= 256) && (ld % 4 == 0) && al16(table) && ((((uintptr_t)out) & oa) == 0);
-    if (vec) {
+    const int64_t ldo_e = ldo ? ldo : D;
+    const bool w16 = vec && ob == 2 && D % 8 == 0 && n % 4 == 0 && n >= 4 && ids_stride == 1 && rs_stride == 1 && !skip_invalid && ldw == 2 &&
+                     ldo_e % 8 == 0 && al16(out) && (!wprod || al16(wprod)) && al16(ids) && (!row_scale || al16(row_scale)) &&
+                     !getenv("MREC_GATHER_W8");
+    if (w16) {
+        if constexpr (ob == 2) {
+            const int lpr = D / 4 + (wprod ? 1 : 0);
+            RowGeom gm{lpr, 64 / lpr};
+            k_gather_rows_w16<K, OT><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * 4), 256, 0, st>>>(table, V, ld, ids, n, row_scale, (OT*)out, D, gm,
+                                                                                                 wprod, ldo_e, gd, ss);
+        }
+    } else if (vec) {
         const int lpr = D / 4 + (wprod ? 1 : 0);
         RowGeom gm{lpr, 64 / lpr};
         k_gather_rows<4, K, OT><<<(unsigned)mrec_cdiv(n, (int64_t)4 * gm.G * GB), 256, 0, st>>>(
