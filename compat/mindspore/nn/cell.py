@@ -9,6 +9,7 @@ from ..common.parameter import Parameter
 from ..experimental import MapParameter
 
 _PARAM_TYPES = (Parameter, MapParameter)
+_call_depth = [0]
 
 
 class Cell:
@@ -68,7 +69,18 @@ class Cell:
 
     # ---- calling -----------------------------------------------------------------------------------------------
     def __call__(self, *args, **kwargs):
-        return self.construct(*args, **kwargs)
+        # A TOP-LEVEL call of a training cell is where MindSpore's GRAPH_MODE compiles; here it is where a recognised train step is
+        # handed to the fused engine (mindspore/_lower.py).  Calls made from inside another cell's construct just run.
+        if _call_depth[0] == 0 and self.__dict__["training"] and not kwargs and self.__dict__.get("_lowered") is not False:
+            from .._lower import lowered
+            low = lowered(self, args)
+            if low is not None:
+                return low(*args)
+        _call_depth[0] += 1
+        try:
+            return self.construct(*args, **kwargs)
+        finally:
+            _call_depth[0] -= 1
 
     def construct(self, *args, **kwargs):
         raise NotImplementedError(f"For 'Cell', the method 'construct' of {self.cls_name} is not defined.")

@@ -122,18 +122,11 @@ class Model:
             network.set_train(is_train)
         return network
 
-    def _lowered(self, network):
-        """GRAPH_MODE's compile step (see the module docstring); None when the network is not a recognised train step
-        or the target is not an MI355X."""
-        if context.get_context("mode") != context.GRAPH_MODE or context.get_context("device_target") != "GPU":
-            return None
-        if network.__dict__.get("_lowered") is None:
-            try:
-                from mindrec_amd import lowering
-            except ImportError:
-                return None
-            network.__dict__["_lowered"] = lowering.lower_train_step(network) or False
-        return network.__dict__["_lowered"] or None
+    @staticmethod
+    def _lowered(network, batch=None):
+        """GRAPH_MODE's compile step (mindspore/_lower.py): the fused engine behind a recognised train cell, or None."""
+        from .._lower import lowered
+        return lowered(network, batch)
 
     def _exec_preprocess(self, is_train, dataset, dataset_sink_mode, sink_size=-1, epoch_num=1, dataset_helper=None):
         if dataset_sink_mode and not is_train:
@@ -198,12 +191,17 @@ class Model:
             cbs.on_train_end(rc)
 
     def _run_step(self, net, batch):
-        low = self._lowered(net)
+        low = self._lowered(net, batch)
         return low(*batch) if low is not None else net(*batch)
 
     def _run_sink(self, net, helper, steps, p):
-        low = self._lowered(net)
         it = iter(DatasetHelper(helper.dataset, True, steps))
+        first = next(it, None)
+        if first is None:
+            return
+        low = self._lowered(net, first)
+        import itertools
+        it = itertools.chain([first], it)
         if low is not None and hasattr(low, "run_sink"):
             p.net_outputs = low.run_sink(list(it))
             return

@@ -1,0 +1,351 @@
+"""GRAPH_MODE's compile step on an MI355X: a recognised train step written against the `mindspore` API (compat/mindspore) is
+lowered to the fused engine -- the whole step as ONE HIP graph over hand-written kernels -- instead of being executed primitive
+by primitive.  This is what lets the reference's model scripts (models/wide_deep/src/wide_and_deep.py:136-492,
+models/deep_and_cross/src/deep_and_cross.py:206-354) run unmodified AND at the engine's speed.
+
+Recognition is structural, not by class or attribute name: a train cell owning one FTRL and one (Lazy)Adam optimizer over a
+model with two embedding lookups sharing one id tensor (one of width 1: the wide table) and a chain of DenseLayer-shaped cells
+(`weight` [in, out] + `bias` [out]) from F * D down to 1 is Wide&Deep; one Adam over one embedding lookup, a chain of
+DenseLayer-shaped cells and a stack of cross layers (`[X, 1]` weight and bias pairs) is Deep&Cross.  Because structure alone
+cannot prove the arithmetic (activation, loss, L2 term), a lowering is VERIFIED before it is used: the engine's logits on the
+first batch must equal the cell's own eager forward, and the engine's first loss the cell's own loss; a mismatch refuses the
+lowering (the cell then runs eagerly) -- it never silently computes something else.
+
+After lowering the cell's Parameters ARE the engine's memory (tables, dense weights, optimizer state are re-bound as views), so
+an evaluation network over the same model, checkpoints and `asnumpy()` see what the engine trains.
+"""
+import numpy as np
+import torch
+
+from .wide_deep_mlp import UnsupportedNet
+
+
+class LoweringRefused(Exception):
+    """Why a train cell was not lowered (kept on the cell as `_lowering_refused`; the cell runs eagerly)."""
+
+
+def _cells(cell):
+    return [c for _, c in cell.cells_and_names()]
+
+
+def _opt_kind(c):
+    n = type(c).__name__
+    return n if n in ("FTRL", "Adam", "LazyAdam") and hasattr(c, "parameters") and hasattr(c, "loss_scale") else None
+
+
+def _is_dense_layer(c):
+    p = c.__dict__.get("_params", {})
+    w, b = p.get("weight"), p.get("bias")
+    return (isinstance(w, torch.Tensor) and isinstance(b, torch.Tensor) and w.dim() == 2 and b.dim() == 1 and w.shape[1] == b.shape[0])
+
+
+def _is_cross_layer(c):
+    ps = [q for q in c.__dict__.get("_params", {}).values() if isinstance(q, torch.Tensor)]
+    return len(ps) == 2 and all(q.dim() == 2 and q.shape[1] == 1 for q in ps) and ps[0].shape == ps[1].shape
+
+
+def _lookup_table(c):
+    """(table, kind) of an embedding-lookup cell: kind 'dense' / 'sparse' (RowTensor gradient) / 'hash' (MapParameter)."""
+    t = c.__dict__.get("_params", {}).get("embedding_table")
+    if t is None:
+        return None
+    if hasattr(t, "_store"):
+        return t, "hash"
+    if not (isinstance(t, torch.Tensor) and t.dim() == 2):
+        return None
+    g = getattr(c, "gather", None) or getattr(c, "gatherv2", None)
+    sparse = bool(getattr(c, "sparse", False)) or type(g).__name__ in ("SparseGatherV2", "EmbeddingLookup")
+    return t, ("sparse" if sparse else "dense")
+
+
+def _chain(layers, width_in):
+    """Orders DenseLayer-shaped cells into a chain width_in -> ... by their weight shapes; None if they do not form one."""
+    if layers and layers[0].weight.shape[0] == width_in and all(a.weight.shape[1] == b.weight.shape[0] for a, b in zip(layers, layers[1:])):
+        return list(layers)                    # definition order already is the chain (the usual case; also resolves equal widths)
+    rest, out, w = list(layers), [], width_in
+    while rest:
+        nxt = [c for c in rest if c.weight.shape[0] == w]
+        if len(nxt) != 1:
+            return None
+        out.append(nxt[0])
+        rest.remove(nxt[0])
+        w = nxt[0].weight.shape[1]
+    return out
+
+
+def _rebind(param, view):
+    """The Parameter becomes a view of engine memory (same shape / dtype); autograd leaf status is kept."""
+    if tuple(param.shape) != tuple(view.shape) or param.dtype != view.dtype:
+        raise LoweringRefused(f"cannot alias parameter {getattr(param, 'name', '?')}: {tuple(param.shape)} vs {tuple(view.shape)}")
+    with torch.no_grad():
+        torch.Tensor.data.__set__(param, view.detach())
+
+
+def _as_t(x, cls):
+    return x.as_subclass(cls) if isinstance(x, torch.Tensor) else x
+
+
+class LoweredStep:
+    """What Model.train / RecModel.online_train call instead of the cell."""
+
+    def __init__(self, engine, out_cls, n_losses, deep_loss=None, optimizers=()):
+        self.engine, self._cls, self._n, self._deep_loss, self._opts = engine, out_cls, n_losses, deep_loss, tuple(optimizers)
+
+    def _sync_back(self):
+        """The cell's optimizers keep their step scalars on the host (and checkpoint them): they follow the engine's."""
+        e = self.engine
+        for o in self._opts:
+            o.global_step = int(e.step_count)
+            if hasattr(o, "beta1_power"):
+                o.beta1_power, o.beta2_power = np.float32(e.beta1_power), np.float32(e.beta2_power)
+            sc = o.__dict__.get("_scalars", {})
+            for n, t in sc.items():
+                t.as_subclass(torch.Tensor)[0] = float(getattr(o, n))
+
+    def _outs(self, loss):
+        self._sync_back()
+        loss = _as_t(loss.reshape(()), self._cls)
+        if self._n == 1:
+            return loss
+        return loss, (self._deep_loss(loss) if self._deep_loss is not None else loss)
+
+    def __call__(self, ids, wts, label):
+        return self._outs(self.engine.train_step(_raw(ids), _raw(wts), _raw(label)))
+
+    def run_sink(self, batches):
+        """One sink of steps (dataset_sink_mode): ONE HIP graph launch where the step has a graph; the last step's outputs."""
+        bs = [tuple(_raw(t) for t in b) for b in batches]
+        if hasattr(self.engine, "train_steps"):
+            losses = self.engine.train_steps(bs)
+            return self._outs(losses[-1])
+        for b in bs:
+            loss = self.engine.train_step(*b)
+        return self._outs(loss)
+
+
+def _raw(t):
+    return t.as_subclass(torch.Tensor) if isinstance(t, torch.Tensor) else t
+
+
+def lower_train_step(cell, first_batch=None):
+    """-> LoweredStep, or None when the cell is not a recognised train step (the reason is left in cell._lowering_refused)."""
+    try:
+        low = _lower_wide_deep(cell) or _lower_deep_cross(cell)
+    except (LoweringRefused, UnsupportedNet) as e:
+        cell.__dict__["_lowering_refused"] = str(e)
+        return None
+    if low is None:
+        cell.__dict__["_lowering_refused"] = "not a Wide&Deep or Deep&Cross train step by structure"
+    return low
+
+
+# ---- Wide&Deep -------------------------------------------------------------------------------------------------------------------
+def _lower_wide_deep(cell):
+    from .wide_deep import WideDeepConfig, WideDeepEngine
+    opts = [(c, _opt_kind(c)) for c in cell.cells() if _opt_kind(c)]
+    kinds = [k for _, k in opts]
+    if len(opts) != 2 or kinds.count("FTRL") != 1:
+        return None
+    ftrl = next(c for c, k in opts if k == "FTRL")
+    adam = next(c for c, k in opts if k != "FTRL")
+    owner = None
+    for c in _cells(cell):
+        looks = [x for x in c.cells() if _lookup_table(x)]
+        if len(looks) == 2 and sum(_is_dense_layer(x) for x in c.cells()) >= 2:
+            owner, lookups = c, looks
+            break
+    if owner is None:
+        return None
+    wide_l = [x for x in lookups if _lookup_table(x)[0].shape[-1] == 1 or getattr(x, "embedding_size", 0) == 1]
+    deep_l = [x for x in lookups if x not in wide_l]
+    if len(wide_l) != 1 or len(deep_l) != 1:
+        return None
+    (deep_t, deep_kind), (wide_t, wide_kind) = _lookup_table(deep_l[0]), _lookup_table(wide_l[0])
+    if deep_kind != wide_kind:
+        raise LoweringRefused("the two tables are looked up differently")
+    if deep_kind == "hash":
+        raise LoweringRefused("hash-table (dynamic_embedding) models run eagerly: MapParameter storage is not re-bound yet "
+                              "(use mindrec_amd.wide_deep.WideDeepEngine(dynamic_embedding=True) directly)")
+    V, D = int(deep_t.shape[0]), int(deep_t.shape[1])
+    B, F = int(getattr(owner, "batch_size", 0) or getattr(owner, "B", 0)), int(getattr(owner, "field_size", 0) or getattr(owner, "F", 0))
+    if B <= 0 or F <= 0:
+        raise LoweringRefused("the model does not state batch_size / field_size")
+    layers = _chain([x for x in owner.cells() if _is_dense_layer(x)], F * D)
+    if layers is None or layers[-1].weight.shape[1] != 1 or len(layers) < 2:
+        raise LoweringRefused("the DenseLayer cells do not form a chain F * D -> ... -> 1")
+    extra = [p for p in owner.__dict__["_params"].values() if isinstance(p, torch.Tensor) and p.numel() == 1]
+    if len(extra) != 1:
+        raise LoweringRefused("expected exactly one scalar parameter (the wide bias) on the model")
+    wide_b = extra[0]
+    in_ftrl = any(p is wide_b for p in ftrl.parameters)
+    if not in_ftrl and not any(p is wide_b for p in adam.parameters):
+        raise LoweringRefused("the wide bias belongs to neither optimizer")
+    if not any(p is wide_t for p in ftrl.parameters) or not any(p is deep_t for p in adam.parameters):
+        raise LoweringRefused("unexpected parameter split: the wide table must belong to FTRL, the deep table to (Lazy)Adam")
+    lazy = type(adam).__name__ == "LazyAdam"
+    if deep_kind == "sparse" and not lazy:
+        raise LoweringRefused("sparse lookups under a non-lazy Adam (RowTensor gradients densified every step) have no engine mode")
+    if deep_kind == "dense" and lazy:
+        lazy = False               # LazyAdam on dense gradients IS Adam
+    loss_cell = next((c for c in _cells(cell) if any(x is owner for x in c.cells()) and hasattr(c, "l2_coef")), None)
+    l2 = float(getattr(loss_cell, "l2_coef", 0.0)) if loss_cell is not None else 0.0
+    no_l2 = bool(getattr(loss_cell, "no_l2loss", not getattr(loss_cell, "with_l2", False))) if loss_cell is not None else True
+    if deep_kind == "sparse" and not no_l2:
+        raise LoweringRefused("an L2 term over a sparsely-updated table has no engine mode")
+    half = bool(getattr(layers[0], "convert_dtype", getattr(layers[0], "half", False)))
+    drop = bool(getattr(layers[0], "drop_out", False))
+    keep = float(getattr(getattr(layers[0], "dropout", None), "keep_prob", 0.5)) if drop else 0.5
+    if float(adam.loss_scale) != float(ftrl.loss_scale) or float(getattr(cell, "sens", adam.loss_scale)) != float(adam.loss_scale):
+        raise LoweringRefused("sens and the optimizers' loss_scale differ")
+    if any(getattr(o, "weight_decay", 0.0) for o in (adam, ftrl)) or getattr(adam, "use_nesterov", False):
+        raise LoweringRefused("weight decay / Nesterov are not lowered")
+    cfg = WideDeepConfig(vocab_size=V, emb_dim=D, field_size=F, batch_size=B, deep_layer_dim=[int(l.weight.shape[1]) for l in layers[:-1]],
+                         sens=float(adam.loss_scale), adam_lr=adam.get_lr(), adam_eps=float(adam.eps), ftrl_lr=ftrl.get_lr(), ftrl_l1=ftrl.l1,
+                         ftrl_l2=ftrl.l2, ftrl_initial_accum=ftrl.initial_accum, mlp_dtype="fp16" if half else "fp32",
+                         sparse=deep_kind == "sparse", l2_coef=l2 if not no_l2 else 0.0, dropout_flag=drop, dropout_keep_prob=keep,
+                         id_dtype="int32", wide_b_optimizer="ftrl" if in_ftrl else "adam")
+    if not cfg.sparse and no_l2:
+        cfg.l2_coef = 0.0
+    dev = deep_t.device
+    if dev.type != "cuda":
+        raise LoweringRefused("parameters are not on an MI355X")
+    if abs(float(adam.beta1) - 0.9) > 1e-6 or abs(float(adam.beta2) - 0.999) > 1e-6:
+        raise LoweringRefused("non-default Adam betas are not lowered")
+    eng = WideDeepEngine(cfg, dev)
+    # parameters and optimizer state move into the engine, then the cell's Parameters are re-bound as views of engine memory
+    with torch.no_grad():
+        eng.deep.copy_(_raw(deep_t))
+        eng.wide.copy_(_raw(wide_t))
+        eng.load_dense_parameters([_raw(l.weight) for l in layers], [_raw(l.bias) for l in layers], extra=_raw(wide_b))
+        st = adam.__dict__.get("_state", {})
+        for (prefix, pid), s in st.items():
+            tgt = None
+            if pid == id(deep_t):
+                tgt = eng.deep_m if prefix == "moment1" else eng.deep_v
+            else:
+                for i, l in enumerate(layers):
+                    if pid == id(l.weight):
+                        tgt = (eng.dense_m if prefix == "moment1" else eng.dense_v)[_off(eng, 2 * i)].view(l.weight.shape)
+                    elif pid == id(l.bias):
+                        tgt = (eng.dense_m if prefix == "moment1" else eng.dense_v)[_off(eng, 2 * i + 1)].view(l.bias.shape)
+            if tgt is not None:
+                tgt.copy_(_raw(s))
+                _rebind(s, tgt)
+        for (prefix, pid), s in ftrl.__dict__.get("_state", {}).items():
+            if pid == id(wide_t):
+                tgt = eng.wide_accum if prefix == "accum" else eng.wide_linear
+                tgt.copy_(_raw(s))
+                _rebind(s, tgt)
+            elif pid == id(wide_b) and in_ftrl:
+                tgt = (eng.dense_m if prefix == "accum" else eng.dense_v)[eng._wb_off:eng._wb_off + 1]
+                tgt.copy_(_raw(s).reshape(1))
+                _rebind(s, tgt.view(s.shape))
+    eng.beta1_power, eng.beta2_power = np.float32(adam.beta1_power), np.float32(adam.beta2_power)
+    eng.step_count = int(adam.global_step)
+    _rebind(deep_t, eng.deep)
+    _rebind(wide_t, eng.wide)
+    for i, l in enumerate(layers):
+        _rebind(l.weight, eng.dense[2 * i])
+        _rebind(l.bias, eng.dense[2 * i + 1])
+    _rebind(wide_b, eng.wide_b.view(wide_b.shape))
+    cls = type(deep_t).__mro__[1] if type(deep_t).__name__ == "Parameter" else type(deep_t)
+
+    def deep_loss(loss):
+        if cfg.sparse or cfg.l2_coef == 0.0:
+            return loss
+        return _as_t(_raw(loss) + (eng._l2_sumsq * (cfg.l2_coef * 0.5)).to(torch.float32).view(()), cls)
+
+    low = LoweredStep(eng, cls, 2, deep_loss, optimizers=(adam, ftrl))
+    low.kind, low.verify = "wide_deep", lambda ids, wts: _verify_logits(eng, owner, ids, wts, half)
+    return low
+
+
+def _off(eng, k):
+    t = eng.dense[k]
+    return slice(t.storage_offset(), t.storage_offset() + t.numel())
+
+
+def _verify_logits(eng, owner, ids, wts, half):
+    """The engine's inference logits against the model cell's own eager forward on the same batch."""
+    with torch.no_grad():
+        mode = owner.training
+        owner.set_train(False)
+        out = owner(ids, wts)
+        owner.set_train(mode)
+        ref = _raw(out[0] if isinstance(out, (tuple, list)) else out).reshape(-1).float()
+        got = eng.predict(_raw(ids), _raw(wts))[0].reshape(-1).float()
+    tol = 2e-2 if half else 1e-4
+    err = float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+    if not err <= tol:
+        raise LoweringRefused(f"the engine's logits differ from the cell's eager forward (relative {err:.3g} > {tol}): not this model")
+    return err
+
+
+# ---- Deep&Cross ------------------------------------------------------------------------------------------------------------------
+def _lower_deep_cross(cell):
+    from .deep_cross import DeepCrossConfig, DeepCrossEngine
+    opts = [(c, _opt_kind(c)) for c in cell.cells() if _opt_kind(c)]
+    if len(opts) != 1 or opts[0][1] != "Adam":
+        return None
+    adam = opts[0][0]
+    owner = None
+    for c in _cells(cell):
+        if (sum(1 for x in c.cells() if _lookup_table(x)) == 1 and sum(_is_cross_layer(x) for x in c.cells()) >= 1
+                and sum(_is_dense_layer(x) for x in c.cells()) == 3):
+            owner = c
+            break
+    if owner is None:
+        return None
+    look = next(x for x in owner.cells() if _lookup_table(x))
+    table, kind = _lookup_table(look)
+    if kind != "dense":
+        raise LoweringRefused("Deep&Cross is lowered with a dense Gather table only")
+    V, D = int(table.shape[0]), int(table.shape[1])
+    B, F = int(getattr(owner, "batch_size", 0)), int(getattr(owner, "field_size", 0))
+    if B <= 0 or F <= 0:
+        raise LoweringRefused("the model does not state batch_size / field_size")
+    X = F * D
+    crosses = [x for x in owner.cells() if _is_cross_layer(x)]         # in attribute (= application) order
+    dense = [x for x in owner.cells() if _is_dense_layer(x) and not _is_cross_layer(x)]
+    hidden = _chain([x for x in dense if x.weight.shape[1] != 1], X)
+    last = [x for x in dense if x.weight.shape[1] == 1]
+    if hidden is None or len(hidden) != 2 or len(last) != 1 or last[0].weight.shape[0] != X + hidden[1].weight.shape[1]:
+        raise LoweringRefused("not the Deep&Cross shape: two hidden DenseLayers, six-ish cross layers, concat -> 1")
+    if any(c.__dict__["_params"] and tuple(next(iter(c.__dict__["_params"].values())).shape) != (X, 1) for c in crosses):
+        raise LoweringRefused("cross layers must be [F * D, 1]")
+    if getattr(adam, "weight_decay", 0.0) or abs(float(adam.beta1) - 0.9) > 1e-6 or abs(float(adam.beta2) - 0.999) > 1e-6:
+        raise LoweringRefused("non-default Adam settings are not lowered")
+    cfg = DeepCrossConfig(vocab_size=V, emb_dim=D, field_size=F, batch_size=B, deep_layer_dim=[int(h.weight.shape[1]) for h in hidden],
+                          cross_layer_num=len(crosses), learning_rate=adam.get_lr(), eps=float(adam.eps), loss_scale=float(adam.loss_scale))
+    if table.device.type != "cuda":
+        raise LoweringRefused("parameters are not on an MI355X")
+    eng = DeepCrossEngine(cfg, table.device)
+    if not eng._native:
+        raise LoweringRefused("these Deep&Cross shapes have no hand-written path")
+    W1, b1, W2, b2, W3, b3, cw, cb = eng.dense
+    with torch.no_grad():
+        eng.table.copy_(_raw(table))
+        for t, src in ((W1, hidden[0].weight), (b1, hidden[0].bias), (W2, hidden[1].weight), (b2, hidden[1].bias), (W3, last[0].weight), (b3, last[0].bias)):
+            t.copy_(_raw(src).reshape(t.shape))
+        for l, c in enumerate(crosses):
+            ps = list(c.__dict__["_params"].items())
+            wname = next((n for n, _ in ps if "weight" in n), ps[0][0])
+            cw[l].copy_(_raw(c.__dict__["_params"][wname]).reshape(-1))
+            bname = next(n for n, _ in ps if n != wname)
+            cb[l].copy_(_raw(c.__dict__["_params"][bname]).reshape(-1))
+    eng.beta1_power, eng.beta2_power, eng.step_count = np.float32(adam.beta1_power), np.float32(adam.beta2_power), int(adam.global_step)
+    if eng.step_count:
+        raise LoweringRefused("Deep&Cross is lowered from a fresh optimizer only")
+    _rebind(table, eng.table)
+    for t, src in ((W1, hidden[0].weight), (b1, hidden[0].bias), (W2, hidden[1].weight), (b2, hidden[1].bias), (W3, last[0].weight), (b3, last[0].bias)):
+        _rebind(src, t.detach().view(src.shape))
+    for l, c in enumerate(crosses):
+        ps = list(c.__dict__["_params"].items())
+        wname = next((n for n, _ in ps if "weight" in n), ps[0][0])
+        bname = next(n for n, _ in ps if n != wname)
+        _rebind(c.__dict__["_params"][wname], cw[l].detach().view(-1, 1))
+        _rebind(c.__dict__["_params"][bname], cb[l].detach().view(-1, 1))
+    cls = type(table).__mro__[1] if type(table).__name__ == "Parameter" else type(table)
+    low = LoweredStep(eng, cls, 1, optimizers=(adam,))
+    low.kind, low.verify = "deep_cross", lambda ids, wts: _verify_logits(eng, owner, ids, wts, False)
+    return low

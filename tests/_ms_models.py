@@ -121,3 +121,80 @@ def wide_deep_from_fixture(z, cfg, comp, capacity=None):
     step = WideDeepTrainStep(WideDeepLoss(net, comp["l2_coef"], not comp["no_l2loss"]), lazy=comp["optimizer_d"] == "LazyAdam", sens=comp["sens"])
     step.set_train()
     return step, net
+
+
+# ---- Deep&Cross (models/deep_and_cross/src/deep_and_cross.py:117-354 restated against the same API) ---------------------------------
+class Cross(nn.Cell):
+    """y = x0 * (x_l . w) + b + x_l  (DCN-v1 cross layer, :139-149)."""
+
+    def __init__(self, width):
+        super().__init__()
+        self.cross_weight = Parameter(initializer("normal", [width, 1], mstype.float32), name="cross_weight")
+        self.cross_bias = Parameter(initializer("normal", [width, 1], mstype.float32), name="cross_bias")
+        self.mm, self.reshape = ops.MatMul(), ops.Reshape()
+
+    def construct(self, x_l, x_0):
+        s = self.mm(x_l, self.cross_weight)                                   # [B, 1]
+        return x_0 * s + self.reshape(self.cross_bias, (1, -1)) + x_l
+
+
+class DeepCross(nn.Cell):
+    def __init__(self, vocab, dim, fields, batch, hidden, n_cross):
+        super().__init__()
+        self.batch_size, self.field_size, self.D = batch, fields, dim
+        self.lookup = nn.EmbeddingLookup(vocab, dim, target="DEVICE", sparse=False)
+        X = fields * dim
+        self.n_cross = n_cross
+        for i in range(n_cross):
+            setattr(self, f"cross{i}", Cross(X))
+        self.hidden0, self.hidden1 = Layer(X, hidden[0]), Layer(hidden[0], hidden[1])
+        self.out = Layer(hidden[1] + X, 1, relu=False)
+        self.reshape, self.mul, self.concat = ops.Reshape(), ops.Mul(), ops.Concat(axis=1)
+
+    def construct(self, ids, wts):
+        x = self.reshape(self.mul(self.lookup(ids), self.reshape(wts, (self.batch_size, self.field_size, 1))), (-1, self.field_size * self.D))
+        d = self.hidden1(self.hidden0(x))
+        c = x
+        for i in range(self.n_cross):
+            c = getattr(self, f"cross{i}")(c, x)
+        return self.out(self.concat((d, c)))
+
+
+class LogLoss(nn.Cell):
+    def __init__(self, net):
+        super().__init__(auto_prefix=False)
+        self.net, self.ce, self.mean = net, ops.SigmoidCrossEntropyWithLogits(), ops.ReduceMean()
+
+    def construct(self, ids, wts, label):
+        return self.mean(self.ce(self.net(ids, wts), label))
+
+
+class AdamTrainStep(nn.Cell):
+    def __init__(self, loss_net, lr=1e-4, eps=1e-8, loss_scale=1000.0):
+        super().__init__(auto_prefix=False)
+        self.loss_net = loss_net
+        self.weights = ParameterTuple(loss_net.trainable_params())
+        self.optimizer = Adam(self.weights, learning_rate=lr, eps=eps, loss_scale=loss_scale)
+        self.grad, self.sens = ops.GradOperation(get_by_list=True, sens_param=True), loss_scale
+
+    def construct(self, ids, wts, label):
+        loss = self.loss_net(ids, wts, label)
+        seed = ops.Fill()(ops.DType()(loss), ops.Shape()(loss), self.sens)
+        self.optimizer(self.grad(self.loss_net, self.weights)(ids, wts, label, seed))
+        return loss
+
+
+def deep_cross_from_fixture(z, cfg, comp):
+    from mindspore import Tensor
+    net = DeepCross(cfg["vocab_size"], cfg["emb_dim"], cfg["field_size"], cfg["batch_size"], cfg["deep_layer_dim"], cfg["cross_layer_num"])
+    net.lookup.embedding_table.set_data(Tensor(z["init/deep_embeddinglookup.embedding_table"]))
+    for i in range(net.n_cross):
+        c = getattr(net, f"cross{i}")
+        c.cross_weight.set_data(Tensor(z[f"init/cross_layer_{i + 1}.cross_weight"]))
+        c.cross_bias.set_data(Tensor(z[f"init/cross_layer_{i + 1}.cross_bias"]))
+    for lay, k in ((net.hidden0, 1), (net.hidden1, 2), (net.out, 3)):
+        lay.weight.set_data(Tensor(z[f"init/dense_layer_{k}.weight"]))
+        lay.bias.set_data(Tensor(z[f"init/dense_layer_{k}.bias"]))
+    step = AdamTrainStep(LogLoss(net), lr=comp["lr"], eps=comp["eps"], loss_scale=comp["loss_scale"])
+    step.set_train()
+    return step, net

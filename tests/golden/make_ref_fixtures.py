@@ -97,6 +97,11 @@ def wide_deep_case(name, S=3, mixed=False, key_dtype=np.int32, **mode):
             "eps_d": train.optimizer_d.eps, "l1_w": train.optimizer_w.l1, "l2_w": train.optimizer_w.l2,
             "initial_accum_w": train.optimizer_w.initial_accum, "loss_scale_d": train.optimizer_d.loss_scale,
             "no_l2loss": bool(loss_net.no_l2loss), "l2_coef": float(loss_net.l2_coef)}
+    # does the structural recogniser of mindrec_amd/lowering.py (GRAPH_MODE's compile step on an MI355X) see this -- the
+    # REFERENCE's -- train cell for what it is?  Here (host tensors) it must get as far as the device check
+    from mindrec_amd import lowering
+    assert lowering.lower_train_step(train) is None
+    comp["lowering_on_cpu"] = train._lowering_refused
     rng = np.random.default_rng(20240 + len(name))
     keys = (lambda i: (i.astype(np.int64) * 2654435761 + 17).astype(key_dtype) if key_dtype == np.int64 else i * 7 + 100) if dyn else None
     ids, wts, label = _batches(rng, S, cfg.batch_size, cfg.field_size, cfg.vocab_size, keys)
@@ -153,6 +158,9 @@ def deep_cross_case(name, S=3):
         out["final/" + k] = _np(p)
     comp = {"optimizer": type(train.optimizer).__name__, "lr": train.optimizer.get_lr(), "eps": train.optimizer.eps,
             "loss_scale": train.optimizer.loss_scale, "sens": float(train.sens), "weights": list(struct)}
+    from mindrec_amd import lowering
+    assert lowering.lower_train_step(train) is None
+    comp["lowering_on_cpu"] = train._lowering_refused
     out.update(ids=ids, wts=wts, label=label, loss=np.array(losses, np.float64), eval_logits=_np(logits), eval_probs=_np(probs),
                cfg=np.array(json.dumps(vars(cfg))), composition=np.array(json.dumps(comp)))
     _save(name, out)
@@ -213,7 +221,6 @@ if __name__ == "__main__":
     report["ref_wd_dense"] = wide_deep_case("ref_wd_dense")                                               # the default: sparse False
     report["ref_wd_sparse"] = wide_deep_case("ref_wd_sparse", sparse=True, parameter_server=1)             # LazyAdam + FTRL on RowTensors
     report["ref_wd_dynamic"] = wide_deep_case("ref_wd_dynamic", sparse=True, dynamic_embedding=True)       # HashEmbeddingLookup x2
-    report["ref_wd_dynamic_i64"] = None
     report["ref_wd_mixed"] = wide_deep_case("ref_wd_mixed", mixed=True, sparse=True, parameter_server=1)   # fp16 DenseLayers
     report["ref_dcn"] = deep_cross_case("ref_dcn")
     hash_lookup_case("ref_hash_lookup")

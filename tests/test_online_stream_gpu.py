@@ -51,7 +51,11 @@ def _build(ms):
     return step, net
 
 
-def test_online_train_on_a_stream_with_periodic_checkpoints(dev, tmp_path):
+@pytest.mark.parametrize("mode", ["pynative", "graph"])
+def test_online_train_on_a_stream_with_periodic_checkpoints(dev, tmp_path, mode):
+    """mode "pynative": every step runs primitive by primitive on the HIP kernel set; "graph": the train cell is lowered to the
+    fused engine (mindrec_amd/lowering.py) -- checkpoints are then read out of, and restored into, engine memory through the
+    cell's re-bound Parameters."""
     compat = os.path.abspath(os.path.join(HERE, "..", "compat"))
     if compat not in sys.path:
         sys.path.insert(0, compat)
@@ -62,7 +66,7 @@ def test_online_train_on_a_stream_with_periodic_checkpoints(dev, tmp_path):
     from mindspore.train.serialization import load_checkpoint, load_param_into_net
     from mindspore_rec import RecModel
     prev = ms._kernels._install(_hip_kernels)
-    context.set_context(mode=context.GRAPH_MODE, device_target="GPU", device_id=0)
+    context.set_context(mode=context.GRAPH_MODE if mode == "graph" else context.PYNATIVE_MODE, device_target="GPU", device_id=0)
     try:
         class Watch(Callback):
             def __init__(self, stop_at):
@@ -100,5 +104,7 @@ def test_online_train_on_a_stream_with_periodic_checkpoints(dev, tmp_path):
         assert torch.equal(net2.deep_table.embedding_table, net.deep_table.embedding_table)
         assert torch.equal(net2.wide_table.embedding_table, net.wide_table.embedding_table)
         assert torch.equal(net2.layer0.weight, net.layer0.weight) and torch.equal(net2.wide_bias, net.wide_bias)
+        assert (step.__dict__.get("_lowered") not in (None, False)) == (mode == "graph")
     finally:
+        context.set_context(mode=context.GRAPH_MODE)
         ms._kernels._install(prev)

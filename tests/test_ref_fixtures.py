@@ -26,6 +26,11 @@ def test_reference_composition_record():
         assert c["optimizer_d"] == opt_d and c["optimizer_w"] == "FTRL"
         assert c["weights_w"] == ["wide_b", "wide_embeddinglookup.embedding_table"]          # the wide bias belongs to FTRL
         assert (c["sens"], c["lr_d"], c["eps_d"], c["lr_w"], c["l1_w"], c["l2_w"], c["initial_accum_w"]) == (1024.0, 3.5e-4, 1e-8, 5e-2, 1e-8, 1e-8, 1.0)
+    # mindrec_amd/lowering.py recognises the REFERENCE's train cells by structure (on the generator's host tensors it gets as far as
+    # the device check); the hash-table model is left to run eagerly
+    for case in ("ref_wd_dense", "ref_wd_sparse", "ref_wd_mixed", "ref_dcn"):
+        assert rep[case]["lowering_on_cpu"] == "parameters are not on an MI355X", (case, rep[case]["lowering_on_cpu"])
+    assert rep["ref_wd_dynamic"]["lowering_on_cpu"].startswith("hash-table (dynamic_embedding) models run eagerly")
     assert rep["ref_wd_dense"]["no_l2loss"] is False and rep["ref_wd_sparse"]["no_l2loss"] is True
     assert (rep["ref_dcn"]["optimizer"], rep["ref_dcn"]["lr"], rep["ref_dcn"]["loss_scale"]) == ("Adam", 1e-4, 1000.0)
 
@@ -102,6 +107,18 @@ def test_own_hash_embedding_lookup_matches_reference_package(ms_cpu):
         k, vals = layer.embedding_table.get_data()
         order = np.argsort(k.asnumpy())
         assert np.array_equal(k.asnumpy()[order], z[f"v{i}/table_keys"]) and np.array_equal(vals.asnumpy()[order], z[f"v{i}/table_values"])
+
+
+def test_mindspore_style_deep_cross_script_matches_reference(ms_cpu):
+    import _ms_models
+    z, cfg, comp = RF.load("ref_dcn")
+    step, net = _ms_models.deep_cross_from_fixture(z, cfg, comp)
+    losses = [float(step(ms_cpu.Tensor(z["ids"][s]), ms_cpu.Tensor(z["wts"][s]), ms_cpu.Tensor(z["label"][s])).asnumpy()) for s in range(z["ids"].shape[0])]
+    assert np.allclose(losses, z["loss"], rtol=2e-6, atol=0), (losses, z["loss"])
+    assert np.allclose(net.out.weight.asnumpy(), z["final/dense_layer_3.weight"], rtol=2e-4, atol=1e-7)
+    assert np.allclose(net.cross3.cross_weight.asnumpy(), z["final/cross_layer_4.cross_weight"], rtol=2e-4, atol=1e-7)
+    from mindrec_amd import lowering
+    assert lowering.lower_train_step(step) is None and step._lowering_refused == "parameters are not on an MI355X"
 
 
 @pytest.mark.parametrize("case", ["ref_wd_sparse", "ref_wd_dense", "ref_wd_dynamic", "ref_wd_mixed"])

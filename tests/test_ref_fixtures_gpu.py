@@ -120,6 +120,7 @@ def ms_hip(dev):
     prev = mindspore._kernels._install(_hip_kernels)          # (a CPU test of the same session may have left its own set installed)
     context.set_context(mode=context.GRAPH_MODE, device_target="GPU", device_id=0)
     yield mindspore
+    context.set_context(mode=context.GRAPH_MODE)
     mindspore._kernels._install(prev)
 
 
@@ -143,7 +144,10 @@ def test_hash_embedding_lookup_on_hip_matches_reference_package(ms_hip):
 
 @pytest.mark.parametrize("case", ["ref_wd_sparse", "ref_wd_dense", "ref_wd_dynamic", "ref_wd_mixed"])
 def test_mindspore_style_script_on_hip_matches_reference(ms_hip, case):
+    """PYNATIVE_MODE: the script's construct bodies run primitive by primitive on the HIP kernel set (no lowering)."""
     import _ms_models
+    from mindspore import context
+    context.set_context(mode=context.PYNATIVE_MODE)
     z, cfg, comp = RF.load(case)
     if cfg["dynamic_embedding"]:
         ms_hip.set_seed(1000)
@@ -168,3 +172,67 @@ def test_mindspore_style_script_on_hip_matches_reference(ms_hip, case):
             assert RF.row_rel(v.asnumpy()[order], z["final/embedding_table::values"]) <= 1e-5
     elif not mixed:
         assert RF.row_rel(net.deep_table.embedding_table.asnumpy(), z["final/embedding_table"]) <= 1e-5
+
+
+# ---- GRAPH_MODE's compile step: a recognised train cell is lowered to the fused engine (mindrec_amd/lowering.py) -----------------------
+@pytest.mark.parametrize("case", ["ref_wd_sparse", "ref_wd_dense", "ref_wd_mixed"])
+def test_lowered_wide_deep_script_matches_reference(ms_hip, case):
+    """`mindspore.Model` recognises the script's train cell, moves its parameters into a WideDeepEngine, re-binds them as views of
+    engine memory and runs every step as the engine's HIP graph; the losses and -- read back THROUGH THE CELL'S OWN Parameters --
+    the trained tables and weights are the reference's."""
+    import _ms_models
+    from mindrec_amd.lowering import LoweredStep
+    z, cfg, comp = RF.load(case)
+    step, net = _ms_models.wide_deep_from_fixture(z, cfg, comp)
+    model = ms_hip.Model(step)
+    losses = []
+    for s in range(z["ids"].shape[0]):
+        batch = tuple(ms_hip.Tensor(z[k][s]) for k in ("ids", "wts", "label"))
+        lw, ld = model._run_step(step, batch)
+        losses.append((float(lw.asnumpy()), float(ld.asnumpy())))
+    low = step.__dict__["_lowered"]
+    assert isinstance(low, LoweredStep) and low.kind == "wide_deep", step.__dict__.get("_lowering_refused")
+    mixed = bool(cfg["use_mixed_precision"])
+    losses = np.array(losses)
+    assert np.allclose(losses[:, 0], z["loss_w"], rtol=5e-4 if mixed else 2e-6, atol=0), (losses[:, 0], z["loss_w"])
+    assert np.allclose(losses[:, 1], z["loss_d"], rtol=5e-4 if mixed else 2e-6, atol=0)
+    # the cell's Parameters are the engine's memory
+    assert net.deep_table.embedding_table.data_ptr() == low.engine.deep.data_ptr()
+    deep = net.deep_table.embedding_table.asnumpy()
+    assert RF.row_rel(deep, z["final/embedding_table"]) <= (1e-4 if mixed else 1e-5)
+    if not mixed:
+        assert np.allclose(net.wide_bias.asnumpy(), z["final/wide_b"], rtol=1e-4, atol=1e-8)
+        assert np.allclose(net.layer0.weight.asnumpy(), z["final/dense_layer_1.weight"], rtol=1e-4, atol=1e-7)
+    # an evaluation pass through the SAME model cell (eager primitives over the re-bound Parameters) sees the trained state
+    net.set_train(False)
+    logits, _ = net(ms_hip.Tensor(z["ids"][-1]), ms_hip.Tensor(z["wts"][-1]))
+    assert np.allclose(logits.asnumpy().reshape(-1), z["eval_logits"].reshape(-1), rtol=2e-2 if mixed else 1e-4, atol=1e-4 if mixed else 1e-6)
+
+
+def test_lowered_deep_cross_script_matches_reference(ms_hip):
+    import _ms_models
+    from mindrec_amd.lowering import LoweredStep
+    z, cfg, comp = RF.load("ref_dcn")
+    step, net = _ms_models.deep_cross_from_fixture(z, cfg, comp)
+    model = ms_hip.Model(step)
+    losses = [float(model._run_step(step, tuple(ms_hip.Tensor(z[k][s]) for k in ("ids", "wts", "label"))).asnumpy()) for s in range(z["ids"].shape[0])]
+    low = step.__dict__["_lowered"]
+    assert isinstance(low, LoweredStep) and low.kind == "deep_cross", step.__dict__.get("_lowering_refused")
+    assert np.allclose(losses, z["loss"], rtol=2e-6, atol=0), (losses, z["loss"])
+    assert np.allclose(net.out.weight.asnumpy(), z["final/dense_layer_3.weight"], rtol=2e-4, atol=1e-7)
+    assert np.allclose(net.cross5.cross_bias.asnumpy(), z["final/cross_layer_6.cross_bias"], rtol=2e-4, atol=1e-7)
+    assert np.allclose(net.lookup.embedding_table.asnumpy(), z["final/deep_embeddinglookup.embedding_table"], rtol=2e-4, atol=1e-7)
+
+
+def test_a_model_the_engine_does_not_compute_is_not_lowered(ms_hip):
+    """Structure alone does not prove the arithmetic: a Wide&Deep-shaped script whose hidden layers use tanh is recognised by
+    structure, fails the verification against its own eager forward, and is refused loudly instead of computed wrongly."""
+    import _ms_models
+    from mindspore import ops
+    z, cfg, comp = RF.load("ref_wd_sparse")
+    step, net = _ms_models.wide_deep_from_fixture(z, cfg, comp)
+    for i in range(net.n_layers - 1):
+        getattr(net, f"layer{i}").act = ops.Tanh()
+    batch = tuple(ms_hip.Tensor(z[k][0]) for k in ("ids", "wts", "label"))
+    with pytest.raises(RuntimeError, match="failed its verification"):
+        ms_hip.Model(step)._run_step(step, batch)
