@@ -582,7 +582,9 @@ __device__ __forceinline__ void apply_long_body(Upd upd, int64_t V, int64_t ld, 
     // ---- this block's windows: 4 per lane-group, their flags read in ONE coalesced load and sorted into two lists in LDS (with
     // flags read window by window inside the passes, every iteration was a memory round trip to find, mostly, a zero)
     __shared__ int list_a[256], n_a;
-    const int WPB = 16 * NG < 256 ? 16 * NG : 256;    // (the same expression sizes the grid in apply_cols)
+    const int WPB = 4 * NG < 256 ? 4 * NG : 256;      // (the same expression sizes the grid in apply_cols; 16 * NG -- a quarter of the
+                                                      // workgroups in front of the dense Adam's -- was measured: uniform ids 36.4 -> 34.4 us for the fused
+                                                      // launch, but Zipf ids x 39 fields 46 us for the pass itself: a block walks its flagged windows serially)
     const int64_t w0 = (int64_t)bid * WPB;
     if (threadIdx.x == 0) { n_a = 0; nlist = 0; }
     __syncthreads();
@@ -776,7 +778,7 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
     const int64_t nsw = mrec_cdiv(n, vec == 4 ? ACfg<4>::AW : ACfg<1>::AW);
     unsigned blocks = (unsigned)mrec_cdiv(nsw, (int64_t)4 * gm.G);
     if (blocks > MREC_APPLY_MAXB) blocks = MREC_APPLY_MAXB;
-    const unsigned lblocks = (unsigned)mrec_cdiv(nsw, (int64_t)(64 * gm.G < 256 ? 64 * gm.G : 256));      // k_apply_long: 16 windows per lane-group, 4 G lane-groups, 256 at most
+    const unsigned lblocks = (unsigned)mrec_cdiv(nsw, (int64_t)(16 * gm.G < 256 ? 16 * gm.G : 256));      // k_apply_long: 4 windows per lane-group, 4 G lane-groups, 256 at most
     const hipEvent_t ev0 = t_prof_start, ev1 = t_prof_stop;
     t_prof_start = t_prof_stop = nullptr;
     if (ev0) MREC_HIP_CHECK(hipEventRecord(ev0, st));
