@@ -470,7 +470,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
                 loss, g_emb, g_wide = self._mlp_step_eager(emb, wide, label, after_head=after_head)
             else:
                 loss, g_emb, g_wide = self._mlp_step(emb, wide, label, after_head=after_head)
-        elif self._f32net and not (self._dropout and self._training):
+        elif self._f32net:
             loss, g_emb, g_wide = self._mlp_step_f32(emb, wide, label)   # the fp32 net by hand (ops.dense32_*)
         else:
             loss, g_emb, g_wide = self._mlp_step_generic(emb, wide, label)      # (no HIP path: the product raises UnsupportedNet)

@@ -196,7 +196,7 @@ class DenseNetMixin:
         dt = {None: "fp32", torch.float16: "fp16", torch.bfloat16: "bf16"}[getattr(self, "_amp", None)]
         return UnsupportedNet(f"MREC_EUNSUPPORTED: {what}: no hand-written HIP path for the {dt} dense net {self.dims} on {self.device} "
                               f"(16-bit nets: every width a multiple of 8; the layer in front of the output a power of two times 8, <= 512; "
-                              f"Dropout on the fp32 net is not provided)")
+                              f"head widths as above)")
 
     def _mlp_generic(self, x):
         raise self._unsupported("inference forward")
@@ -318,18 +318,33 @@ class DenseNetMixin:
         the dense parameters summed into the flat gradient buffer.  Returns (loss, g_emb fp32 [B, F * D], g_wide [B])."""
         k, n = self.k, len(self.dims) - 1
         B = emb.shape[0]
+        # Dropout on every DenseLayer's input while training (wide_and_deep.py:117-118; on in benchmarks/wide_deep/default_config.yaml:15,
+        # whose net is fp32): x_i = h_(i-1) * mask_i / keep, applied in place to the stored activation -- its zeros then carry the ReLU's
+        # AND the mask's pattern for the input-gradient kernel -- and the 1 / keep of the bprop is applied to dz_i before it goes back
+        # through W_i (after the weight gradient, which wants dz_i itself)
+        drops = [self._drop(i, B) for i in range(n)]
+        if drops[0] is not None:
+            k.dropout_(emb, drops[0])
         hs = [emb]
         for i in range(n - 1):
-            hs.append(k.dense32_fwd(hs[i], self.dense[2 * i].detach(), self.dense[2 * i + 1].detach(), relu=True))
+            h = k.dense32_fwd(hs[i], self.dense[2 * i].detach(), self.dense[2 * i + 1].detach(), relu=True)
+            if drops[i + 1] is not None:
+                k.dropout_(h, drops[i + 1])
+            hs.append(h)
         loss, _, dlogit, dh = k.head_fwd_bwd(hs[-1], self.dense[2 * (n - 1)].detach().view(-1), self.dense[2 * (n - 1) + 1].detach(),
                                              wide, label.view(-1), self._sens / B, self.dense_grad[2 * (n - 1)].view(-1),
-                                             self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1])
+                                             self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1],
+                                             dh_scale=drops[n - 1].scale if drops[n - 1] is not None else 1.0)
         for i in range(n - 2, -1, -1):
             k.dense32_bwd_weight(hs[i], dh, self._dw_slabs(i, B))
-            if i > 0:      # through the ReLU of layer i - 1; the column sums are that layer's bias gradient
+            if drops[i] is not None and i > 0:
+                dh.mul_(drops[i].scale)
+            if i > 0:      # through the ReLU (and the Dropout mask) of layer i - 1; the column sums are that layer's bias gradient
                 dh = k.dense32_bwd_input(dh, self.dense[2 * i].detach(), h=hs[i], colsum=self._db_slabs(i - 1, B))
             else:
                 dh = k.dense32_bwd_input(dh, self.dense[0].detach())
+                if drops[0] is not None:
+                    k.dropout_(dh, drops[0])            # mask and 1 / keep of the looked-up rows (no ReLU in front of them to carry the mask)
         self._sum_dw_slabs()
         return loss.view(()), dh, dlogit.view(-1)
 

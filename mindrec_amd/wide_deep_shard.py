@@ -283,7 +283,7 @@ class ShardStepMixin:
             step = self._mlp_step_eager if capturing else self._mlp_step
             loss, g_emb, g_wide = step(emb, wide, label)
             route["wide_b_in_head"] = isinstance(wide, _WideProd)
-        elif self._f32net and not (self._dropout and self._training):
+        elif self._f32net:
             loss, g_emb, g_wide = self._mlp_step_f32(emb, wprod[..., 0].sum(dim=1) + self.wide_b, label)
             route["wide_b_in_head"] = False
         else:

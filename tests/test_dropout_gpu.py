@@ -162,17 +162,15 @@ def _row_rel(a, b):
 
 
 def test_fp32_engine_with_dropout_matches_oracle_engine(dev, oracle):
-    """Dropout on the fp32 net has no HIP path: the product engine refuses it (UnsupportedNet, no silent torch fallback).  The
-    test-side engine with the torch net (`x = self.dropout(x)` as a multiply by the mask; embedding path on the HIP kernels, mask from
-    mrec_dropout_mask_f32) against the same engine driven by the oracle on the CPU, whose masks come from oracle.dropout_mask."""
-    from _oracle_engine import OracleWideDeepEngine, TorchNetWideDeepEngine
+    """Dropout on the fp32 net (the reference's published benchmark configuration, benchmarks/wide_deep/default_config.yaml:15-16):
+    the hand-written fp32 MFMA net -- masks applied in place to the stored activations by mrec_dropout, 1 / keep folded into the
+    backward -- against the oracle-side engine on the CPU, whose masks come from oracle.dropout_mask through autograd."""
+    from _oracle_engine import OracleWideDeepEngine
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
-    from mindrec_amd.wide_deep_mlp import UnsupportedNet
     cfg = WideDeepConfig(vocab_size=50_000, emb_dim=80, field_size=26, batch_size=256, deep_layer_dim=[64, 32], mlp_dtype="fp32",
                          dropout_flag=True)
-    with pytest.raises(UnsupportedNet, match="MREC_EUNSUPPORTED"):
-        WideDeepEngine(cfg, dev).train_step(*(t.to(dev) for t in synthetic_batch(cfg, "cpu", "zipf", seed=7)))
-    g = TorchNetWideDeepEngine(cfg, dev)
+    g = WideDeepEngine(cfg, dev)
+    assert g._f32net
     c = OracleWideDeepEngine(cfg, "cpu")
     n = WideDeepEngine(WideDeepConfig(**{**cfg.__dict__, "dropout_flag": False}), dev)
     for s in range(3):
