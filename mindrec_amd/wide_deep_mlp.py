@@ -94,7 +94,7 @@ class DenseNetMixin:
         # The fp32 net (mlp_dtype "fp32": DenseLayer without casts) by hand as well: hidden layers on the fp32 matrix instruction
         # (ops.dense32_*), the output end as one pass (ops.head_fwd_bwd on fp32 activations); Dropout keeps the torch restatement.
         self._f32net = bool(self._gpu and self.k is ops and not self._mfma and getattr(self, "_amp", None) is None and nl >= 2
-                            and self.k.head_supported(dims[nl - 1]))
+                            and (self.k.head_supported(dims[nl - 1]) or self.k.dcn_head_supported(dims[nl - 1], 2)))
         self._tail_packed, self._dense16_t = None, None
         self._tail_ok = bool(self._mfma and fused_tail and nl >= 4 and self.k.tail_supported(64, *self.dims[nl - 3:nl]))
         self._mlp_graph = None        # dict: captured MLP step + its static input / output tensors
@@ -331,10 +331,31 @@ class DenseNetMixin:
             if drops[i + 1] is not None:
                 k.dropout_(h, drops[i + 1])
             hs.append(h)
-        loss, _, dlogit, dh = k.head_fwd_bwd(hs[-1], self.dense[2 * (n - 1)].detach().view(-1), self.dense[2 * (n - 1) + 1].detach(),
-                                             wide, label.view(-1), self._sens / B, self.dense_grad[2 * (n - 1)].view(-1),
-                                             self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1],
-                                             dh_scale=drops[n - 1].scale if drops[n - 1] is not None else 1.0)
+        K5 = self.dims[n - 1]
+        if k.head_supported(K5):
+            loss, _, dlogit, dh = k.head_fwd_bwd(hs[-1], self.dense[2 * (n - 1)].detach().view(-1), self.dense[2 * (n - 1) + 1].detach(),
+                                                 wide, label.view(-1), self._sens / B, self.dense_grad[2 * (n - 1)].view(-1),
+                                                 self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1],
+                                                 dh_scale=drops[n - 1].scale if drops[n - 1] is not None else 1.0)
+        else:
+            # a last hidden layer wider than the head kernel's 512 columns (the reference's benchmark net ends 1024 -> 1): the
+            # output end of Deep&Cross does the same arithmetic over [h | c] . w3 -- with c = [wide, 0] and w3 = [W5 | 1, 0] that is
+            # h . W5 + wide + b5, its loss and every bprop, in one pass (csrc/mrec_dcn.hip)
+            st = self.__dict__.setdefault("_wide_head", {})
+            if st.get("B") != B:
+                st.update(B=B, c=torch.zeros((B, 2), dtype=torch.float32, device=self.device),
+                          w3=torch.zeros(K5 + 2, dtype=torch.float32, device=self.device),
+                          dw3=torch.empty(K5 + 2, dtype=torch.float32, device=self.device), out={})
+                st["w3"][K5] = 1.0
+            st["c"][:, 0].copy_(wide.view(-1))
+            st["w3"][:K5].copy_(self.dense[2 * (n - 1)].detach().view(-1))
+            loss, _, dh, dc = k.dcn_head_fwd_bwd(hs[-1], st["c"], st["w3"], self.dense[2 * (n - 1) + 1].detach(), label.view(-1), self._sens / B,
+                                                 st["dw3"], self.dense_grad[2 * (n - 2) + 1], self.dense_grad[2 * (n - 1) + 1], out=st["out"])
+            self.dense_grad[2 * (n - 1)].view(-1).copy_(st["dw3"][:K5])
+            dlogit = dc[:, 0].contiguous()
+            if drops[n - 1] is not None:
+                dh.mul_(drops[n - 1].scale)
+                self.dense_grad[2 * (n - 2) + 1].mul_(drops[n - 1].scale)
         for i in range(n - 2, -1, -1):
             k.dense32_bwd_weight(hs[i], dh, self._dw_slabs(i, B))
             if drops[i] is not None and i > 0:

@@ -516,3 +516,23 @@ def test_engine_refuses_a_net_without_hip_path(dev):
         eng.train_step(*synthetic_batch(cfg, dev, "uniform", seed=1))
     with pytest.raises(UnsupportedNet, match="MREC_EUNSUPPORTED"):
         eng.predict(*synthetic_batch(cfg, dev, "uniform", seed=1)[:2])
+
+
+@pytest.mark.parametrize("dropout", [False, True])
+def test_fp32_net_with_a_wide_last_layer_matches_oracle_engine(dev, oracle, dropout):
+    """The reference's benchmark net ends 1024 -> 1 (benchmarks/wide_deep/default_config.yaml:12): wider than the output-head
+    kernel's 512 columns, so the fp32 engine takes its output end through the Deep&Cross head kernel ([h | wide, 0] . [W5 | 1, 0]).
+    Against the oracle-side engine (torch autograd on the CPU), with and without Dropout."""
+    from _oracle_engine import OracleWideDeepEngine
+    from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
+    cfg = WideDeepConfig(vocab_size=20_000, emb_dim=16, field_size=39, batch_size=128, deep_layer_dim=[64, 1024], mlp_dtype="fp32",
+                         dropout_flag=dropout)
+    g, c = WideDeepEngine(cfg, dev), OracleWideDeepEngine(cfg, "cpu")
+    assert g._f32net and not g.k.head_supported(1024)
+    for s in range(3):
+        ids, wts, label = synthetic_batch(cfg, "cpu", "zipf", seed=31 + s)
+        lc = float(c.train_step(ids, wts, label))
+        lg = float(g.train_step(ids.to(dev), wts.to(dev), label.to(dev)))
+        assert abs(lc - lg) <= 1e-5 * max(abs(lc), 1e-3)
+    assert row_rel(g.deep.cpu().numpy(), c.deep.numpy()) <= 2e-5
+    assert np.allclose(g.dense_flat.detach().cpu().numpy(), c.dense_flat.detach().numpy(), rtol=1e-4, atol=1e-6)
