@@ -506,12 +506,13 @@ def test_deepfm_engine_in_the_references_precision(dev, dt):
 
 
 def test_engine_refuses_a_net_without_hip_path(dev):
-    """No library-GEMM / autograd fallback in the product: a dense net the hand-written kernels do not cover (here an fp32 net
-    whose last hidden width, 24, is not a power of two times 8) raises UnsupportedNet (MREC_EUNSUPPORTED) at its first step."""
+    """No library-GEMM / autograd fallback in the product: a dense net the hand-written kernels do not cover (here a 16-bit net
+    whose widths are not multiples of 8: rows that are not 16-byte aligned) raises UnsupportedNet (MREC_EUNSUPPORTED)."""
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     from mindrec_amd.wide_deep_mlp import UnsupportedNet
-    cfg = WideDeepConfig(vocab_size=5000, emb_dim=16, field_size=5, batch_size=64, deep_layer_dim=[32, 24], mlp_dtype="fp32")
+    cfg = WideDeepConfig(vocab_size=5000, emb_dim=16, field_size=5, batch_size=64, deep_layer_dim=[36, 20], mlp_dtype="fp16")
     eng = WideDeepEngine(cfg, dev)
+    assert not eng._mfma and not eng._f32net
     with pytest.raises(UnsupportedNet, match="MREC_EUNSUPPORTED"):
         eng.train_step(*synthetic_batch(cfg, dev, "uniform", seed=1))
     with pytest.raises(UnsupportedNet, match="MREC_EUNSUPPORTED"):
