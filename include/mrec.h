@@ -783,6 +783,30 @@ int mrec_event_destroy(void* ev);
 int mrec_event_elapsed_ms(void* start, void* stop, float* ms_out); /* waits for `stop` */
 int mrec_profile_next_apply(void* start, void* stop);
 
+/* ---- fp32 DenseLayers at the 16-bit matrix rate: three-part bf16 operands (csrc/mrec_gemm_x3.hip) ---------------------------------
+ * DenseLayer.construct with convert_dtype=False (models/deep_and_cross/src/deep_and_cross.py:94-114; the reference's benchmark
+ * net, benchmarks/wide_deep/default_config.yaml:16) and its bprops.  An fp32 operand x is held as x1 + x2 + x3, bf16 each
+ * (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 24 mantissa bits); a . b is the six bf16 products a1 b1, a1 b2, a2 b1,
+ * a1 b3, a2 b2, a3 b1 accumulated in fp32 by the MFMA, smallest first -- an fp32-class result (<= ~2^-22 of sum |a b|) in 6/16 of
+ * the time of the fp32-input matrix instruction.  mrec_dense32_* (exact fp32 products, csrc/mrec_gemm_f32.hip) stay as they are.
+ *   parts image of an fp32 [R, C] tensor: bf16 [3][Rp][Cp], Rp / Cp = R / C rounded up to 64, zero padded
+ *   (mrec_x3_parts_elems gives 3 * Rp * Cp); one image serves every GEMM the tensor is an operand of.
+ *   mrec_x3_gemm form 0: C[M, N] = P[M, K] . Q[K, N]         P = parts of x [M, K],  Q = parts of w [K, N]
+ *                form 1: C[M, K] = P[M, N] . Q[K, N]^T       P = parts of dy [M, N], Q = parts of w [K, N]
+ *                form 2: C[S][K, N] = P[M, K]^T . Q[M, N]    P = parts of x [M, K],  Q = parts of dy [M, N]; S batch slabs of
+ *                        fp32 partial sums (slab s at C + s * K * ldc), added up by mrec_dense_adam_slabs_* / mrec_dense_sum_slabs_f32
+ *   C is fp32 with row stride ldc (even; 16-byte stores when ldc % 4 == 0).
+ *   mrec_x3_bias_relu: y = relu?(acc + bias) in place (BiasAdd + ReLU) and, parts_out != NULL, y's parts image in the same pass.
+ *   mrec_x3_mask_colsum: dx = (h > 0 ? acc : 0) in place (the ReLU bprop of the layer below; h nullable), colsum [ceil(M / 64), K]
+ *   (nullable) = column sums of dx per 64 rows (that layer's BiasAdd bprop), and dx's parts image. */
+int mrec_x3_parts_elems(int64_t rows, int64_t cols, int64_t* out);
+int mrec_x3_split(const float* x, int64_t ldx, int64_t R, int32_t C, uint16_t* parts, void* stream);
+int mrec_x3_gemm(int form, const uint16_t* Pparts, const uint16_t* Qparts, int64_t M, int32_t K, int32_t N, float* C, int64_t ldc,
+                 int32_t S, void* stream);
+int mrec_x3_bias_relu(float* acc, int64_t ld, int64_t M, int32_t N, const float* bias, int relu, uint16_t* parts_out, void* stream);
+int mrec_x3_mask_colsum(float* acc, int64_t ld, int64_t M, int32_t K, const float* h, int64_t ldh, float* colsum, uint16_t* parts_out,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,11 @@ _SIGS = {
                                          _vp, _vp, _vp, _vp],
     "mrec_dense_adam_slabs_finish_f32": [_vp, _vp, _vp, _vp, _vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32,
                                          _f32, _f32, _int, _vp, _vp, _vp, _vp],
+    "mrec_x3_parts_elems": [_i64, _i64, _vp],
+    "mrec_x3_split": [_vp, _i64, _i64, _i32, _vp, _vp],
+    "mrec_x3_gemm": [_int, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp],
+    "mrec_x3_bias_relu": [_vp, _i64, _i64, _i32, _vp, _int, _vp, _vp],
+    "mrec_x3_mask_colsum": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
     "mrec_dense_adam_l2_workspace_bytes": [_i64, _vp],
     "mrec_dense_adam_l2_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _f32, _vp, _int, _vp, _sz, _vp],
     "mrec_dense_adam_one_ftrl_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _vp],

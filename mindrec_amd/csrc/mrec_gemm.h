@@ -64,6 +64,13 @@ struct Args {
     int kt_per_slab;        // K-tiles per split slab (grid has nTp * nTq * S workgroups; no split: all of them)
     int64_t slab_stride;    // elements between consecutive slabs of C
     int relu;               // EPI_FWD
+    // VAR & 4 -- a SEGMENTED reduction: the K-tiles [s * seg_tiles, (s + 1) * seg_tiles) of the launch read P from byte offset
+    // seg_offP[s] and Q from seg_offQ[s] of their buffers (+ the tile's offset inside the segment).  What an fp32 GEMM needs when
+    // each fp32 operand is held as THREE bf16 parts (x = x1 + x2 + x3, 8 mantissa bits each): the six products a1 b1, a1 b2,
+    // a2 b1, a1 b3, a2 b2, a3 b1 are six segments of one reduction into the same fp32 accumulators (mrec_gemm_x3.hip).
+    int seg_tiles;          // K-tiles per segment (K = 6 * 64 * seg_tiles); 0: an ordinary reduction
+    uint32_t seg_offP[6], seg_offQ[6];
+    int64_t rangeP, rangeQ; // VAR & 4: bytes the P / Q buffer resources span (all parts)
     DropArgs drop;          // thresh != 0: Dropout on the layer input this launch produces (EPI_FWD: C is the next layer's input,
                             // masked and scaled after the rounding; EPI_DGRAD: C is the gradient of this layer's dropped-out
                             // input -- scaled, and masked by the hash when there is no H whose zeros already carry the mask)
@@ -135,10 +142,11 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
     const int krem = a.K & 63;                        // k in the trailing partial K-tile (0: none)
     const bool ktail = krem != 0;
 
+    constexpr bool SEG = (VAR & 4) != 0;
     const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(a.P), 0, (int)((PT ? (int64_t)a.K : (int64_t)a.Pext) * a.ldp * 2), 0x00020000);
+        const_cast<void*>(a.P), 0, (int)(SEG ? a.rangeP : (PT ? (int64_t)a.K : (int64_t)a.Pext) * a.ldp * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(a.Q), 0, (int)((QT ? (int64_t)a.K : (int64_t)a.Qext) * a.ldq * 2), 0x00020000);
+        const_cast<void*>(a.Q), 0, (int)(SEG ? a.rangeQ : (QT ? (int64_t)a.K : (int64_t)a.Qext) * a.ldq * 2), 0x00020000);
 
     // ---- per-lane source offsets of the staging loads (bytes); [half][e]
     uint32_t voffP[2][2], voffQ[2][2];        // ... and for the trailing partial K-tile (loads of k >= K dropped)
@@ -173,6 +181,16 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
     }
     const uint32_t ktP = PT ? (uint32_t)(64 * a.ldp * 2) : 128u;     // soffset step per K-tile
     const uint32_t ktQ = QT ? (uint32_t)(64 * a.ldq * 2) : 128u;
+    // byte offset of K-tile tg of the launch (SEG: inside its segment's part of the operand)
+    auto soffOf = [&](int tg, bool isP) -> uint32_t {
+        if constexpr (SEG) {
+            int sg = tg / a.seg_tiles;
+            sg = sg > 5 ? 5 : sg;
+            return (isP ? a.seg_offP[sg] : a.seg_offQ[sg]) + (uint32_t)(tg - sg * a.seg_tiles) * (isP ? ktP : ktQ);
+        } else {
+            return (uint32_t)tg * (isP ? ktP : ktQ);
+        }
+    };
     // piece types: 0 = P rows 0-63 of each wave row, 1 = Q cols 0-31 of each wave column, 2 = Q cols 32-63, 3 = P rows 64-127
 #define MG_STAGE(TYPE, BUF, tt)                                                                                   \
     do {                                                                                                          \
@@ -180,7 +198,7 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
         const bool live_ = tt_ < T;                                                                               \
         constexpr bool isP_ = (TYPE) == 0 || (TYPE) == 3;                                                         \
         constexpr int h_ = ((TYPE) >= 2) ? 1 : 0;                                                                 \
-        const uint32_t soff_ = (uint32_t)(kt0 + tt_) * (isP_ ? ktP : ktQ);                                        \
+        const uint32_t soff_ = soffOf(kt0 + tt_, isP_);                                                           \
         MGEMM_LDS char* dst_ = (MGEMM_LDS char*)smem + slot_off(BUF, TYPE) + w * 2048;                           \
         const bool last_ = ktail && (kt0 + tt_ == Ttot - 1);                                                      \
         const uint32_t v0_ = !live_ ? kOob : last_ ? (isP_ ? voffPt[h_][0] : voffQt[h_][0]) : (isP_ ? voffP[h_][0] : voffQ[h_][0]); \
@@ -323,7 +341,7 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
         const bool live_ = tt_ < T;                                                                               \
         constexpr bool isP_ = (TYPE) == 0;                                                                        \
         constexpr int h_ = (TYPE) == 2 ? 1 : 0;                                                                   \
-        const uint32_t soff_ = (uint32_t)(kt0 + tt_) * (isP_ ? ktP : ktQ);                                        \
+        const uint32_t soff_ = soffOf(kt0 + tt_, isP_);                                                           \
         MGEMM_LDS char* dst_ = smem + (bo_) + (TYPE) * 16384 + w * 2048;                                         \
         const bool last_ = ktail && (kt0 + tt_ == Ttot - 1);                                                      \
         const uint32_t v0_ = !live_ ? kOob : last_ ? (isP_ ? voffPt[0][0] : voffQt[h_][0]) : (isP_ ? voffP[0][0] : voffQ[h_][0]); \
@@ -398,7 +416,16 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const int q = q0 + ni * 16;
-                    if (q < a.Qext) *(f32x4_t*)(C + (int64_t)p * a.ldc + q) = acc[mi][ni];
+                    if (q < a.Qext) {
+                        float* dst = C + (int64_t)p * a.ldc + q;
+                        if ((a.ldc & 3) == 0) {
+                            *(f32x4_t*)dst = acc[mi][ni];
+                        } else {            // rows that are only 8-byte aligned (Deep&Cross's 1170-column input gradient)
+                            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                            *(f32x2_t*)dst = f32x2_t{acc[mi][ni][0], acc[mi][ni][1]};
+                            if (q + 2 < a.Qext) *(f32x2_t*)(dst + 2) = f32x2_t{acc[mi][ni][2], acc[mi][ni][3]};
+                        }
+                    }
                 }
             }
         }

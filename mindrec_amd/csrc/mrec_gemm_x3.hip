@@ -1,0 +1,213 @@
+// mrec_gemm_x3.hip -- fp32 DenseLayers (models/deep_and_cross/src/deep_and_cross.py:94-114, convert_dtype=False; the reference's
+// benchmark net, benchmarks/wide_deep/default_config.yaml:16 use_mixed_precision: False) at the 16-bit matrix rate.
+//
+// gfx950's fp32-input MFMA runs at 1/16 of the bf16 one (157 vs 2500 TFLOP/s), and the exact-fp32 kernel of mrec_gemm_f32.hip
+// holds 62-71 % of that.  Here every fp32 operand is held as THREE bf16 parts, x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1),
+// x3 = bf16(x - x1 - x2): 3 x 8 = 24 mantissa bits, the residuals exact in fp32 -- and a product a . b becomes the six bf16
+// products a1 b1, a1 b2, a2 b1, a1 b3, a2 b2, a3 b1 (the three left out are below 2^-24 of a . b: under fp32's own rounding),
+// all accumulated in the MFMA's fp32 accumulators as six SEGMENTS of ONE reduction (smallest terms first) through the 16-bit
+// GEMM body of mrec_gemm.h (VAR & 4: a K-tile's operand offset comes from its segment): 6/16 of the fp32-MFMA time at the same
+// accuracy class as an fp32 GEMM (error <= ~2^-22 of sum |a b|, measured against float64 in tests/test_dense32_gpu.py).
+//
+//   mrec_x3_split         fp32 [R, C] -> bf16 parts [3][Rp][Cp] (Rp, Cp = R, C rounded up to 64, zero padded)
+//   mrec_x3_gemm          form 0: C[M, N] = P[M, K] . Q[K, N]      (DenseLayer forward)
+//                         form 1: C[M, K] = P[M, N] . Q[K, N]^T    (input gradient)
+//                         form 2: C[S][K, N] = P[M, K]^T . Q[M, N] (weight gradient, S batch slabs of fp32 partial sums)
+//   mrec_x3_bias_relu     y = relu?(acc + bias) in place, and (optionally) y's own three parts for the next GEMM, one pass
+//   mrec_x3_mask_colsum   dx = acc masked by h > 0 in place, column sums per 64 rows (the bias gradient of the layer below),
+//                         and (optionally) dx's parts, one pass
+#include "mrec_common.h"
+#include "mrec_gemm.h"
+
+namespace {
+
+using mgemm::Args;
+
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+inline int64_t up64(int64_t x) { return (x + 63) / 64 * 64; }
+
+__device__ __forceinline__ void split3(float x, uint16_t& a, uint16_t& b, uint16_t& c) {
+    const __bf16 x1 = (__bf16)x;
+    const float r1 = x - (float)x1;
+    const __bf16 x2 = (__bf16)r1;
+    const float r2 = r1 - (float)x2;
+    const __bf16 x3 = (__bf16)r2;
+    a = __builtin_bit_cast(uint16_t, x1); b = __builtin_bit_cast(uint16_t, x2); c = __builtin_bit_cast(uint16_t, x3);
+}
+
+// 8 consecutive values -> the three parts' 16-byte groups
+__device__ __forceinline__ void split8(const float (&v)[8], uint4& a, uint4& b, uint4& c) {
+    uint16_t pa[8], pb[8], pc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) split3(v[k], pa[k], pb[k], pc[k]);
+    a = make_uint4(pa[0] | ((unsigned)pa[1] << 16), pa[2] | ((unsigned)pa[3] << 16), pa[4] | ((unsigned)pa[5] << 16), pa[6] | ((unsigned)pa[7] << 16));
+    b = make_uint4(pb[0] | ((unsigned)pb[1] << 16), pb[2] | ((unsigned)pb[3] << 16), pb[4] | ((unsigned)pb[5] << 16), pb[6] | ((unsigned)pb[7] << 16));
+    c = make_uint4(pc[0] | ((unsigned)pc[1] << 16), pc[2] | ((unsigned)pc[3] << 16), pc[4] | ((unsigned)pc[5] << 16), pc[6] | ((unsigned)pc[7] << 16));
+}
+
+// One thread per 8 columns of the PADDED image.  MODE 0: plain split; 1: y = relu?(x + bias) written back + split;
+// 2: dx = h > 0 ? x : 0 written back + split, column sums per 64 rows.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_x3_post(float* __restrict__ x, int64_t ldx, int64_t R, int C, const float* __restrict__ bias,
+                                                 int relu, const float* __restrict__ h, int64_t ldh, float* __restrict__ colsum,
+                                                 uint16_t* __restrict__ parts, int64_t Rp, int64_t Cp) {
+    // block = 64 rows x 32 column groups (256 columns); thread (rq, cg): rows rq, rq + 8, ... of column group cg
+    const int cg = threadIdx.x & 31, rq = threadIdx.x >> 5;
+    const int64_t r0 = (int64_t)blockIdx.y * 64;
+    const int c0 = (blockIdx.x * 32 + cg) * 8;
+    if (c0 >= Cp) return;
+    float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1 && bias) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b8[k] = (c0 + k < C) ? bias[c0 + k] : 0.f;
+    }
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool vec = (ldx % 4 == 0) && (c0 + 8 <= C);
+    for (int rr = rq; rr < 64; rr += 8) {
+        const int64_t r = r0 + rr;
+        if (r >= Rp) break;
+        float v[8];
+        const bool live = r < R;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        if (live) {
+            if (vec) {
+                const float4 lo = *(const float4*)(x + r * ldx + c0), hi = *(const float4*)(x + r * ldx + c0 + 4);
+                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (c0 + k < C) v[k] = x[r * ldx + c0 + k];
+            }
+            if (MODE == 1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[k] = v[k] + b8[k];
+                    if (relu) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                    if (c0 + k >= C) v[k] = 0.f;
+                }
+            }
+            if (MODE == 2) {
+                if (h) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) if (c0 + k < C && !(h[r * ldh + c0 + k] > 0.f)) v[k] = 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cs[k] += v[k];
+            }
+            if (MODE != 0) {
+                if (vec) {
+                    *(float4*)(x + r * ldx + c0) = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(x + r * ldx + c0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) if (c0 + k < C) x[r * ldx + c0 + k] = v[k];
+                }
+            }
+        }
+        if (parts) {
+            uint4 a, b, c;
+            split8(v, a, b, c);
+            const int64_t o = r * Cp + c0;
+            *(uint4*)(parts + o) = a;
+            *(uint4*)(parts + Rp * Cp + o) = b;
+            *(uint4*)(parts + 2 * Rp * Cp + o) = c;
+        }
+    }
+    if (MODE == 2 && colsum) {
+        __shared__ float red[8][32][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[rq][cg][k] = cs[k];
+        __syncthreads();
+        if (rq == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float s = red[0][cg][k];
+                for (int q = 1; q < 8; ++q) s += red[q][cg][k];
+                if (c0 + k < C && r0 < R) colsum[(int64_t)blockIdx.y * C + c0 + k] = s;
+            }
+        }
+    }
+}
+
+template <int MODE>
+int post_launch(float* x, int64_t ldx, int64_t R, int32_t C, const float* bias, int relu, const float* h, int64_t ldh, float* colsum,
+                uint16_t* parts, void* stream) {
+    if (R < 0 || C <= 0 || ldx < C || !x) return MREC_EINVAL;
+    if (R == 0) return MREC_OK;
+    if (ldx % 2 || (parts && !al16(parts)) || (((uintptr_t)x) & 7)) return MREC_EUNSUPPORTED;
+    const int64_t Rp = up64(R), Cp = up64(C);
+    const int64_t rows = parts ? Rp : R;
+    dim3 grid((unsigned)mrec_cdiv(Cp, 256), (unsigned)mrec_cdiv(rows, 64));
+    k_x3_post<MODE><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, R, C, bias, relu, h, ldh, colsum, parts, Rp, Cp);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+}  // namespace
+
+MREC_API int mrec_x3_parts_elems(int64_t rows, int64_t cols, int64_t* out) {
+    if (!out || rows < 0 || cols < 0) return MREC_EINVAL;
+    *out = 3 * up64(rows) * up64(cols);
+    return MREC_OK;
+}
+
+MREC_API int mrec_x3_split(const float* x, int64_t ldx, int64_t R, int32_t C, uint16_t* parts, void* stream) {
+    if (!parts) return MREC_EINVAL;
+    return post_launch<0>(const_cast<float*>(x), ldx, R, C, nullptr, 0, nullptr, 0, nullptr, parts, stream);
+}
+
+MREC_API int mrec_x3_bias_relu(float* acc, int64_t ld, int64_t M, int32_t N, const float* bias, int relu, uint16_t* parts_out, void* stream) {
+    return post_launch<1>(acc, ld, M, N, bias, relu, nullptr, 0, nullptr, parts_out, stream);
+}
+
+MREC_API int mrec_x3_mask_colsum(float* acc, int64_t ld, int64_t M, int32_t K, const float* h, int64_t ldh, float* colsum,
+                                 uint16_t* parts_out, void* stream) {
+    if (h && ldh < K) return MREC_EINVAL;
+    return post_launch<2>(acc, ld, M, K, nullptr, 0, h, ldh, colsum, parts_out, stream);
+}
+
+MREC_API int mrec_x3_gemm(int form, const uint16_t* Pparts, const uint16_t* Qparts, int64_t M, int32_t K, int32_t N, float* C, int64_t ldc,
+                          int32_t S, void* stream) {
+    if (form < 0 || form > 2 || M <= 0 || K <= 0 || N <= 0 || !Pparts || !Qparts || !C || S <= 0) return MREC_EINVAL;
+    if (!al16(Pparts) || !al16(Qparts) || (((uintptr_t)C) & 7) || ldc % 2) return MREC_EUNSUPPORTED;
+    const int64_t Mp = up64(M), Kp = up64(K), Np = up64(N);
+    static const int pa[6] = {2, 1, 0, 1, 0, 0}, pb[6] = {0, 1, 2, 0, 1, 0};          // smallest products first
+    Args a{};
+    a.P = Pparts; a.Q = Qparts; a.C = C; a.ldc = ldc;
+    int64_t partP, partQ, red;                    // elements per part of P / Q; the reduction extent (padded)
+    if (form == 0) {          // P = x parts [Mp][Kp], Q = w parts [Kp][Np]
+        a.ldp = Kp; a.ldq = Np; a.Pext = (int)M; a.Qext = N; red = Kp; partP = Mp * Kp; partQ = Kp * Np;
+        if (ldc < N || S != 1) return MREC_EINVAL;
+    } else if (form == 1) {   // P = dy parts [Mp][Np], Q = w parts [Kp][Np] (rows = outputs)
+        a.ldp = Np; a.ldq = Np; a.Pext = (int)M; a.Qext = K; red = Np; partP = Mp * Np; partQ = Kp * Np;
+        if (ldc < K || S != 1) return MREC_EINVAL;
+    } else {                  // P = x parts [Mp][Kp] (reduction over rows), Q = dy parts [Mp][Np]
+        a.ldp = Kp; a.ldq = Np; a.Pext = K; a.Qext = N; red = Mp; partP = Mp * Kp; partQ = Mp * Np;
+        if (ldc < N) return MREC_EINVAL;
+        a.slab_stride = (int64_t)K * ldc;
+    }
+    if (3 * partP * 2 >= (int64_t(1) << 31) || 3 * partQ * 2 >= (int64_t(1) << 31)) return MREC_EUNSUPPORTED;
+    a.K = (int)(6 * red);
+    a.seg_tiles = (int)(red / 64);
+    for (int s = 0; s < 6; ++s) { a.seg_offP[s] = (uint32_t)(pa[s] * partP * 2); a.seg_offQ[s] = (uint32_t)(pb[s] * partQ * 2); }
+    a.rangeP = 3 * partP * 2; a.rangeQ = 3 * partQ * 2;
+    const int Ttot = 6 * a.seg_tiles;
+    a.kt_per_slab = (Ttot + S - 1) / S;
+    if ((int64_t)a.kt_per_slab * (S - 1) >= Ttot && S > 1) return MREC_EINVAL;
+    const int64_t b256 = mrec_cdiv(a.Pext, 256) * mrec_cdiv(a.Qext, 256) * S;
+    const int mr = b256 * 4 >= 256 * 3 ? 8 : 4;
+    a.nTp = (int)mrec_cdiv(a.Pext, mr * 32); a.nTq = (int)mrec_cdiv(a.Qext, 256);
+    const unsigned grid = (unsigned)(a.nTp * a.nTq * S);
+    hipStream_t st = (hipStream_t)stream;
+#define MREC_X3(PT, QT)                                                                                              \
+    do {                                                                                                              \
+        if (mr == 8) mgemm::k_gemm256<PT, QT, mgemm::EPI_F32, false, 4, 8><<<grid, mgemm::kThreads, 0, st>>>(a);      \
+        else mgemm::k_gemm256<PT, QT, mgemm::EPI_F32, false, 4, 4><<<grid, mgemm::kThreads, 0, st>>>(a);              \
+    } while (0)
+    if (form == 0) MREC_X3(false, true);
+    else if (form == 1) MREC_X3(false, false);
+    else MREC_X3(true, true);
+#undef MREC_X3
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}

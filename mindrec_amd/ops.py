@@ -1491,6 +1491,62 @@ def dense32_bwd_weight(x, dy, out_slabs):
     return out_slabs
 
 
+# ---- fp32 DenseLayers at the 16-bit matrix rate: three-part bf16 operands (csrc/mrec_gemm_x3.hip) -----------------------------------
+def _up64(x):
+    return (int(x) + 63) // 64 * 64
+
+
+def x3_supported(M, K, N):
+    """Shapes the split path takes: everything an fp32 DenseLayer of realistic size has; tiny problems stay on dense32_*."""
+    return M >= 256 and K >= 64 and N >= 64 and 3 * _up64(M) * max(_up64(K), _up64(N)) * 2 < 2 ** 31
+
+
+def x3_parts(rows, cols, device):
+    return torch.empty((3, _up64(rows), _up64(cols)), dtype=torch.bfloat16, device=device)
+
+
+def x3_split(x, out=None):
+    """fp32 [R, C] -> its parts image bf16 [3][Rp][Cp] (x = x1 + x2 + x3, zero padded to multiples of 64)."""
+    _need_cuda(x, out)
+    R, Cc, ld = _mat32(x, "x")
+    p = out if out is not None else x3_parts(R, Cc, x.device)
+    if tuple(p.shape) != (3, _up64(R), _up64(Cc)) or p.dtype != torch.bfloat16 or not p.is_contiguous():
+        raise TypeError("x3_split: out must be the contiguous bfloat16 parts image [3, Rp, Cp]")
+    _lib.call("mrec_x3_split", _ptr(x), ld, R, Cc, _ptr(p), _stream())
+    return p
+
+
+def x3_gemm(form, P, Q, M, K, N, out, S=1):
+    """form 0: out [M, N] = x . w; 1: out [M, K] = dy . w^T; 2: out [S, K, N] = x^T . dy in S batch slabs (parts images in)."""
+    _need_cuda(P, Q, out)
+    if out.dtype != torch.float32 or out.stride(-1) != 1:
+        raise TypeError("x3_gemm: out must be float32 with unit column stride")
+    ldc = out.stride(-2)
+    _lib.call("mrec_x3_gemm", int(form), _ptr(P), _ptr(Q), int(M), int(K), int(N), _ptr(out), int(ldc), int(S), _stream())
+    return out
+
+
+def x3_bias_relu_(acc, bias, relu=True, parts_out=None):
+    _need_cuda(acc, bias, parts_out)
+    M, N, ld = _mat32(acc, "acc")
+    _lib.call("mrec_x3_bias_relu", _ptr(acc), ld, M, N, _ptr(bias), int(bool(relu)), _ptr(parts_out), _stream())
+    return acc
+
+
+def x3_mask_colsum_(acc, h=None, colsum=None, parts_out=None):
+    _need_cuda(acc, h, colsum, parts_out)
+    M, K, ld = _mat32(acc, "acc")
+    ldh = 0
+    if h is not None:
+        M2, K2, ldh = _mat32(h, "h")
+        if (M2, K2) != (M, K):
+            raise TypeError("h must be [M, K]")
+    if colsum is not None and (colsum.dtype != torch.float32 or tuple(colsum.shape) != ((M + 63) // 64, K) or not colsum.is_contiguous()):
+        raise TypeError("colsum must be contiguous float32 [ceil(M / 64), K]")
+    _lib.call("mrec_x3_mask_colsum", _ptr(acc), ld, M, K, _ptr(h), ldh, _ptr(colsum), _ptr(parts_out), _stream())
+    return acc
+
+
 def dcn_head_supported(H, X):
     return H % 4 == 0 and H <= 1024 and X % 2 == 0 and X <= 1280
 

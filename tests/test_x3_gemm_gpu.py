@@ -1,0 +1,67 @@
+"""fp32 DenseLayers at the 16-bit matrix rate (csrc/mrec_gemm_x3.hip): every fp32 operand as three bf16 parts, six bf16 products per
+fp32 product accumulated in fp32.  Against float64 on the same inputs: the error must be that of an fp32 GEMM -- a few ulps of
+sum |a| |b| -- for the forward product, the input gradient and the weight gradient, at ragged shapes (Deep&Cross's K = 1170), with
+operands spanning many binades (gradients at the loss scale down to 1e-12)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _err(got, ref64, absum):
+    return float((np.abs(got.astype(np.float64) - ref64) / absum).max())
+
+
+@pytest.mark.parametrize("M,K,N", [(1024, 1170, 1024), (512, 1024, 256), (768, 200, 136), (256, 64, 64)])
+def test_x3_products_have_fp32_accuracy(dev, M, K, N):
+    from mindrec_amd import ops
+    rng = np.random.default_rng(M + K)
+    x = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-12, 2, (M, 1)))).astype(np.float32)       # rows over 6 decades
+    w = (rng.standard_normal((K, N)) * 0.05).astype(np.float32)
+    dy = (rng.standard_normal((M, N)) * np.exp(rng.uniform(-20, 0, (M, 1)))).astype(np.float32)
+    tx, tw, tdy = (torch.from_numpy(a).to(dev) for a in (x, w, dy))
+    xp, wp, dyp = ops.x3_split(tx), ops.x3_split(tw), ops.x3_split(tdy)
+    # the parts add up to the operand exactly (three 8-bit pieces of a 24-bit mantissa)
+    back = xp[:, :M, :K].to(torch.float32).sum(0)
+    assert torch.equal(back, tx)
+    x64, w64, dy64 = x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64)
+    u = 2.0 ** -24
+    # forward
+    y = ops.x3_gemm(0, xp, wp, M, K, N, torch.empty((M, N), dtype=torch.float32, device=dev)).cpu().numpy()
+    assert _err(y, x64 @ w64, np.abs(x64) @ np.abs(w64)) <= 6 * u
+    # the exact-fp32 kernel on the same inputs, for scale: the split path is no less accurate than twice its error + 2 ulp
+    y32 = ops.dense32_fwd(tx, tw, None, relu=False).cpu().numpy()
+    assert _err(y, x64 @ w64, np.abs(x64) @ np.abs(w64)) <= 2 * _err(y32, x64 @ w64, np.abs(x64) @ np.abs(w64)) + 2 * u
+    # input gradient: dx = dy . w^T  (ld of the output not a multiple of 4 when K = 1170)
+    dx = ops.x3_gemm(1, dyp, wp, M, K, N, torch.empty((M, K), dtype=torch.float32, device=dev)).cpu().numpy()
+    assert _err(dx, dy64 @ w64.T, np.abs(dy64) @ np.abs(w64.T)) <= 6 * u
+    # weight gradient in S batch slabs
+    for S in (1, 3):
+        slabs = ops.x3_gemm(2, xp, dyp, M, K, N, torch.empty((S, K, N), dtype=torch.float32, device=dev), S=S).cpu().numpy()
+        assert _err(slabs.astype(np.float64).sum(0), x64.T @ dy64, np.abs(x64.T) @ np.abs(dy64)) <= 8 * u
+
+
+def test_x3_post_ops(dev):
+    """bias + ReLU in place with the result's own parts image; ReLU mask + column sums per 64 rows with the parts image."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(3)
+    M, N = 300, 136
+    acc = rng.standard_normal((M, N)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    t = torch.from_numpy(acc.copy()).to(dev)
+    parts = ops.x3_parts(M, N, dev)
+    ops.x3_bias_relu_(t, torch.from_numpy(b).to(dev), relu=True, parts_out=parts)
+    ref = np.maximum(acc + b, 0).astype(np.float32)
+    assert np.array_equal(t.cpu().numpy(), ref)
+    assert torch.equal(parts[:, :M, :N].to(torch.float32).sum(0).cpu(), torch.from_numpy(ref))
+    assert float(parts[:, M:, :].abs().max()) == 0 and float(parts[:, :, N:].abs().max()) == 0      # padding is zero
+    h = rng.standard_normal((M, N)).astype(np.float32)
+    t2 = torch.from_numpy(acc.copy()).to(dev)
+    cs = torch.empty(((M + 63) // 64, N), dtype=torch.float32, device=dev)
+    ops.x3_mask_colsum_(t2, torch.from_numpy(h).to(dev), cs, parts)
+    ref2 = np.where(h > 0, acc, 0).astype(np.float32)
+    assert np.array_equal(t2.cpu().numpy(), ref2)
+    for tile in range(cs.shape[0]):
+        assert np.allclose(cs[tile].cpu().numpy(), ref2[tile * 64:(tile + 1) * 64].astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
+    assert torch.equal(parts[:, :M, :N].to(torch.float32).sum(0).cpu(), torch.from_numpy(ref2))
