@@ -654,6 +654,11 @@ int mrec_cross_layers_bwd_workspace_bytes(int32_t L, int64_t B, int32_t D, size_
 int mrec_cross_layers_bwd_f32(const float* x0, const float* w, const float* b, int32_t L, int64_t B,
                               int32_t D, const float* dy, float* dx0, float* dw, float* db, void* ws,
                               size_t ws_bytes, void* stream);
+/* the same with dx0 += ... : onto the gradient of x0 another branch of the net left in dx0 (DeepCrossModel.construct feeds the
+ * embeddings to the deep net and to the cross stack, deep_and_cross.py:300-306: the two input gradients add) */
+int mrec_cross_layers_bwd_acc_f32(const float* x0, const float* w, const float* b, int32_t L, int64_t B,
+                                  int32_t D, const float* dy, float* dx0, float* dw, float* db, void* ws,
+                                  size_t ws_bytes, void* stream);
 
 /* ---- DeepFM second-order term ----------------------------------------------------------------
  * models/deepfm/src/deepfm.py:221-228 on the gathered, masked embeddings vx [B, F, D] (fp32):
@@ -797,15 +802,23 @@ int mrec_profile_next_apply(void* start, void* stop);
  *                        fp32 partial sums (slab s at C + s * K * ldc), added up by mrec_dense_adam_slabs_* / mrec_dense_sum_slabs_f32
  *   C is fp32 with row stride ldc (even; 16-byte stores when ldc % 4 == 0).
  *   mrec_x3_bias_relu: y = relu?(acc + bias) in place (BiasAdd + ReLU) and, parts_out != NULL, y's parts image in the same pass.
- *   mrec_x3_mask_colsum: dx = (h > 0 ? acc : 0) in place (the ReLU bprop of the layer below; h nullable), colsum [ceil(M / 64), K]
+ *   mrec_x3_mask_colsum: dx = (h > 0 ? acc : 0) * scale in place (scale: 1 / keep of a Dropout on the layer's input, else 1) (the ReLU bprop of the layer below; h nullable), colsum [ceil(M / 64), K]
  *   (nullable) = column sums of dx per 64 rows (that layer's BiasAdd bprop), and dx's parts image. */
 int mrec_x3_parts_elems(int64_t rows, int64_t cols, int64_t* out);
 int mrec_x3_split(const float* x, int64_t ldx, int64_t R, int32_t C, uint16_t* parts, void* stream);
 int mrec_x3_gemm(int form, const uint16_t* Pparts, const uint16_t* Qparts, int64_t M, int32_t K, int32_t N, float* C, int64_t ldc,
                  int32_t S, void* stream);
 int mrec_x3_bias_relu(float* acc, int64_t ld, int64_t M, int32_t N, const float* bias, int relu, uint16_t* parts_out, void* stream);
-int mrec_x3_mask_colsum(float* acc, int64_t ld, int64_t M, int32_t K, const float* h, int64_t ldh, float* colsum, uint16_t* parts_out,
-                        void* stream);
+int mrec_x3_mask_colsum(float* acc, int64_t ld, int64_t M, int32_t K, const float* h, int64_t ldh, float scale, float* colsum,
+                        uint16_t* parts_out, void* stream);
+/* the same output ends inside the GEMM's epilogue (no second pass over the layer's output):
+ *   mrec_x3_gemm_fwd:   y = relu?(x . w + bias) [M, N] AND (parts_out != NULL) y's parts image
+ *   mrec_x3_gemm_dgrad: dx = (h > 0 ? dy . w^T : 0) * scale [M, K], colsum [ceil(M / 64), K] (nullable) AND (parts_out != NULL) dx's parts
+ * parts_out: the padding of the image (rows M.., columns past the width) is NOT written -- the caller zeroes the image once. */
+int mrec_x3_gemm_fwd(const uint16_t* xparts, const uint16_t* wparts, int64_t M, int32_t K, int32_t N, float* y, int64_t ldy,
+                     const float* bias, int relu, uint16_t* parts_out, void* stream);
+int mrec_x3_gemm_dgrad(const uint16_t* dyparts, const uint16_t* wparts, int64_t M, int32_t K, int32_t N, float* dx, int64_t lddx,
+                       const float* h, int64_t ldh, float scale, float* colsum, uint16_t* parts_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -97,7 +97,9 @@ _SIGS = {
     "mrec_x3_split": [_vp, _i64, _i64, _i32, _vp, _vp],
     "mrec_x3_gemm": [_int, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp],
     "mrec_x3_bias_relu": [_vp, _i64, _i64, _i32, _vp, _int, _vp, _vp],
-    "mrec_x3_mask_colsum": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp],
+    "mrec_x3_gemm_fwd": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _vp],
+    "mrec_x3_gemm_dgrad": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _f32, _vp, _vp, _vp],
+    "mrec_x3_mask_colsum": [_vp, _i64, _i64, _i32, _vp, _i64, _f32, _vp, _vp, _vp],
     "mrec_dense_adam_l2_workspace_bytes": [_i64, _vp],
     "mrec_dense_adam_l2_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _f32, _vp, _int, _vp, _sz, _vp],
     "mrec_dense_adam_one_ftrl_f32": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _vp],
@@ -161,6 +163,7 @@ _SIGS = {
     "mrec_cross_layers_f32": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp],
     "mrec_cross_layers_bwd_workspace_bytes": [_i32, _i64, _i32, _szp],
     "mrec_cross_layers_bwd_f32": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_cross_layers_bwd_acc_f32": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_dcn_head_workspace_bytes": [_i64, _i32, _i32, _szp],
     "mrec_dcn_head_fwd_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp,
                               _vp, _sz, _vp],

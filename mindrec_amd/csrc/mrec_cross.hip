@@ -319,7 +319,7 @@ template <int NPL, int LT, bool WLDS>
 __global__ __launch_bounds__(BWD_NT) __attribute__((amdgpu_waves_per_eu(bwd_occ(NPL, LT), bwd_occ(NPL, LT)))) void k_cross_bwd(const float* __restrict__ x0, const float* __restrict__ w,
                                                       const float* __restrict__ b, int L, int64_t B, int D,
                                                       const float* __restrict__ dy, float* __restrict__ dx0,
-                                                      float* __restrict__ slabs) {
+                                                      float* __restrict__ slabs, int accumulate) {
     static_assert(NPL % 4 == 0 && WLDS, "the backward is instantiated for 256-column blocks with w staged in LDS");
     constexpr int DP = NPL * 64;
     constexpr int NQ = NPL / 4;             // 256-column blocks
@@ -451,6 +451,10 @@ __global__ __launch_bounds__(BWD_NT) __attribute__((amdgpu_waves_per_eu(bwd_occ(
             __builtin_amdgcn_sched_barrier(0);
         }
         const __amdgpu_buffer_rsrc_t ro = row_rsrc(dx0 + row * D, D * 4);
+        if (accumulate) {              // dx0 += ...: onto the gradient another branch left there (Deep&Cross: the deep net's)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) g[q] += act_load4(ro, voff, 1024 * q);
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) act_store4(ro, voff, 1024 * q, g[q]);
     }
@@ -646,7 +650,7 @@ int launch_fwd(const float* x0, const float* w, const float* b, int L, int64_t B
 
 template <int NPL, int LT>
 int launch_bwd_lt(const float* x0, const float* w, const float* b, int L, int64_t B, int D, const float* dy, float* dx0,
-                  float* slabs, unsigned blocks, hipStream_t st) {
+                  float* slabs, unsigned blocks, hipStream_t st, int acc) {
     constexpr int DP = NPL * 64;
     // w of all layers (<= 8 x 2048 floats = 64 KB) always fits in LDS; the exchange regions of the epilogue reuse the area
     const size_t xlds = (size_t)bwd_regions(NPL, LT) * bwd_region_floats(NPL, LT) * sizeof(float);
@@ -655,17 +659,17 @@ int launch_bwd_lt(const float* x0, const float* w, const float* b, int L, int64_
     static_assert((size_t)bwd_regions(NPL, LT) * bwd_region_floats(NPL, LT) * sizeof(float) <= 160 * 1024, "LDS");
     int rc = set_lds(k_cross_bwd<NPL, LT, true>, lds);
     if (rc != MREC_OK) return rc;
-    k_cross_bwd<NPL, LT, true><<<blocks, BWD_NT, lds, st>>>(x0, w, b, L, B, D, dy, dx0, slabs);
+    k_cross_bwd<NPL, LT, true><<<blocks, BWD_NT, lds, st>>>(x0, w, b, L, B, D, dy, dx0, slabs, acc);
     return MREC_OK;
 }
 
 template <int NPL>
 int launch_bwd(const float* x0, const float* w, const float* b, int L, int64_t B, int D, const float* dy, float* dx0,
-               float* slabs, unsigned blocks, hipStream_t st) {
-    if (L <= 2) return launch_bwd_lt<NPL, 2>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st);
-    if (L <= 4) return launch_bwd_lt<NPL, 4>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st);
-    if (L <= 6) return launch_bwd_lt<NPL, 6>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st);
-    return launch_bwd_lt<NPL, 8>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st);
+               float* slabs, unsigned blocks, hipStream_t st, int acc) {
+    if (L <= 2) return launch_bwd_lt<NPL, 2>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st, acc);
+    if (L <= 4) return launch_bwd_lt<NPL, 4>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st, acc);
+    if (L <= 6) return launch_bwd_lt<NPL, 6>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st, acc);
+    return launch_bwd_lt<NPL, 8>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st, acc);
 }
 }  // namespace
 
@@ -690,9 +694,26 @@ MREC_API int mrec_cross_layers_bwd_workspace_bytes(int32_t L, int64_t B, int32_t
     return MREC_OK;
 }
 
+namespace {
+int cross_bwd(const float* x0, const float* w, const float* b, int32_t L, int64_t B, int32_t D, const float* dy, float* dx0, float* dw,
+              float* db, void* ws, size_t ws_bytes, void* stream, int acc);
+}
+
 MREC_API int mrec_cross_layers_bwd_f32(const float* x0, const float* w, const float* b, int32_t L, int64_t B,
                                        int32_t D, const float* dy, float* dx0, float* dw, float* db, void* ws,
                                        size_t ws_bytes, void* stream) {
+    return cross_bwd(x0, w, b, L, B, D, dy, dx0, dw, db, ws, ws_bytes, stream, 0);
+}
+
+MREC_API int mrec_cross_layers_bwd_acc_f32(const float* x0, const float* w, const float* b, int32_t L, int64_t B,
+                                           int32_t D, const float* dy, float* dx0, float* dw, float* db, void* ws,
+                                           size_t ws_bytes, void* stream) {
+    return cross_bwd(x0, w, b, L, B, D, dy, dx0, dw, db, ws, ws_bytes, stream, 1);
+}
+
+namespace {
+int cross_bwd(const float* x0, const float* w, const float* b, int32_t L, int64_t B, int32_t D, const float* dy, float* dx0, float* dw,
+              float* db, void* ws, size_t ws_bytes, void* stream, int acc) {
     if (B < 0 || D <= 0 || L < 0) return MREC_EINVAL;
     if (L > LMAX) return MREC_EUNSUPPORTED;
     if (!x0 || !dy || !dx0 || !ws || (L > 0 && (!w || !b || !dw || !db))) return MREC_EINVAL;
@@ -708,11 +729,11 @@ MREC_API int mrec_cross_layers_bwd_f32(const float* x0, const float* w, const fl
     // the backward's register-heavy instantiations use coarser column buckets (compile time)
     const int nb = npl <= 4 ? 4 : (npl <= 8 ? 8 : (npl <= 16 ? 16 : (npl <= 20 ? 20 : 32)));
     switch (nb) {
-        case 4: rc = launch_bwd<4>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st); break;
-        case 8: rc = launch_bwd<8>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st); break;
-        case 16: rc = launch_bwd<16>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st); break;
-        case 20: rc = launch_bwd<20>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st); break;
-        default: rc = launch_bwd<32>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st); break;
+        case 4: rc = launch_bwd<4>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st, acc); break;
+        case 8: rc = launch_bwd<8>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st, acc); break;
+        case 16: rc = launch_bwd<16>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st, acc); break;
+        case 20: rc = launch_bwd<20>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st, acc); break;
+        default: rc = launch_bwd<32>(x0, w, b, L, B, D, dy, dx0, slabs, blocks, st, acc); break;
     }
     if (rc != MREC_OK) return rc;
     if (L > 0)
@@ -720,3 +741,4 @@ MREC_API int mrec_cross_layers_bwd_f32(const float* x0, const float* w, const fl
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
+}  // namespace

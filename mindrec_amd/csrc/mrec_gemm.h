@@ -49,7 +49,9 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 enum { EPI_FWD = 0,     // out = relu?(acc + bias[q])                      -> 16-bit
        EPI_DGRAD = 1,   // out = H[p, q] > 0 ? acc : 0 (H nullable), optional column sums over p -> 16-bit
-       EPI_F32 = 2 };   // out = acc                                        -> fp32 (split slabs)
+       EPI_F32 = 2,     // out = acc                                        -> fp32 (split slabs)
+       EPI_X3 = 3 };    // fp32 DenseLayer on three-part operands (mrec_gemm_x3.hip): x3_mode 1: out = relu?(acc + bias[q]);
+                        // 2: out = (Hf[p, q] > 0 ? acc : 0) * x3_scale, column sums per 64 rows -> fp32, AND out's own three bf16 parts
 
 struct Args {
     const void* P;
@@ -69,6 +71,15 @@ struct Args {
     // each fp32 operand is held as THREE bf16 parts (x = x1 + x2 + x3, 8 mantissa bits each): the six products a1 b1, a1 b2,
     // a2 b1, a1 b3, a2 b2, a3 b1 are six segments of one reduction into the same fp32 accumulators (mrec_gemm_x3.hip).
     int seg_tiles;          // K-tiles per segment (K = 6 * 64 * seg_tiles); 0: an ordinary reduction
+    // EPI_X3 (H is then fp32 [Pext, ldh]; colsum_ws [ceil(Pext / 64), Qext])
+    int x3_mode;
+    float x3_scale;
+    int64_t ldh;
+    uint16_t* parts;        // nullable: [3][parts_stride] bf16 images of out, rows of parts_ld elements (zero padding is the caller's)
+    int64_t parts_ld, parts_stride;
+    int seg_inter;          // 1: K-tile t of the launch is tile t / 6 of segment t % 6 (the six products of one stretch of the reduction
+                            // back to back: every operand tile is fetched once from HBM and found in L2 the other times); 0: segment
+                            // after segment
     uint32_t seg_offP[6], seg_offQ[6];
     int64_t rangeP, rangeQ; // VAR & 4: bytes the P / Q buffer resources span (all parts)
     DropArgs drop;          // thresh != 0: Dropout on the layer input this launch produces (EPI_FWD: C is the next layer's input,
@@ -184,9 +195,16 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
     // byte offset of K-tile tg of the launch (SEG: inside its segment's part of the operand)
     auto soffOf = [&](int tg, bool isP) -> uint32_t {
         if constexpr (SEG) {
-            int sg = tg / a.seg_tiles;
-            sg = sg > 5 ? 5 : sg;
-            return (isP ? a.seg_offP[sg] : a.seg_offQ[sg]) + (uint32_t)(tg - sg * a.seg_tiles) * (isP ? ktP : ktQ);
+            int sg, ti;
+            if (a.seg_inter) {
+                ti = tg / 6; sg = tg - 6 * ti;
+                if (ti >= a.seg_tiles) { ti = a.seg_tiles - 1; sg = 5; }      // (prefetch past the end: its loads are dropped anyway)
+            } else {
+                sg = tg / a.seg_tiles;
+                sg = sg > 5 ? 5 : sg;
+                ti = tg - sg * a.seg_tiles;
+            }
+            return (isP ? a.seg_offP[sg] : a.seg_offQ[sg]) + (uint32_t)ti * (isP ? ktP : ktQ);
         } else {
             return (uint32_t)tg * (isP ? ktP : ktQ);
         }
@@ -427,6 +445,116 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
                         }
                     }
                 }
+            }
+        }
+    } else if (EPI == EPI_X3) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        float* C = (float*)a.C;
+        const float* Hf = (const float*)a.H;
+        const bool fwd = a.x3_mode == 1;
+        float bq[4][4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = q0 + ni * 16 + r;
+                bq[ni][r] = (fwd && a.bias != nullptr && q < a.Qext) ? a.bias[q] : 0.f;
+            }
+        // a wave's rows are one (MR = 4) or two (MR = 8) of the 64-row groups the column sums are kept for
+        float cs[MR / 4][4][4];
+#pragma unroll
+        for (int g = 0; g < MR / 4; ++g)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cs[g][ni][r] = 0.f;
+        const bool v16 = (a.ldc & 3) == 0, h16 = (a.ldh & 3) == 0;
+#pragma unroll
+        for (int mi = 0; mi < MR; ++mi) {
+            const int p = p0 + mi * 16;
+            const bool pv = p < a.Pext;
+            f32x4_t hv[4];
+            if (!fwd && Hf != nullptr) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int q = q0 + ni * 16;
+                    const bool ok = pv && q < a.Qext;
+                    const float* src = Hf + (ok ? (int64_t)p * a.ldh + q : (int64_t)0);
+                    if (h16) {
+                        hv[ni] = *(const f32x4_t*)src;
+                    } else {
+                        const f32x2_t lo = *(const f32x2_t*)src;
+                        const f32x2_t hi = (ok && q + 2 < a.Qext) ? *(const f32x2_t*)(src + 2) : f32x2_t{0.f, 0.f};
+                        hv[ni] = f32x4_t{lo[0], lo[1], hi[0], hi[1]};
+                    }
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int q = q0 + ni * 16;
+                const bool ok = pv && q < a.Qext;
+                f32x4_t v = acc[mi][ni];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (fwd) {
+                        v[r] += bq[ni][r];
+                        if (a.relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
+                    } else {
+                        if (Hf != nullptr && !(hv[ni][r] > 0.f)) v[r] = 0.f;
+                        v[r] *= a.x3_scale;
+                    }
+                    if (q + r >= a.Qext) v[r] = 0.f;           // (the parts image is zero past the last column)
+                }
+                if (ok) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cs[mi / 4][ni][r] += v[r];
+                    float* dst = C + (int64_t)p * a.ldc + q;
+                    if (v16) {
+                        *(f32x4_t*)dst = v;
+                    } else {
+                        *(f32x2_t*)dst = f32x2_t{v[0], v[1]};
+                        if (q + 2 < a.Qext) *(f32x2_t*)(dst + 2) = f32x2_t{v[2], v[3]};
+                    }
+                    if (a.parts != nullptr) {
+                        // x = x1 + x2 + x3, each part the bf16 rounding of what the parts before it leave (residuals exact in fp32)
+                        uint32_t pk[3][2];
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            float x0 = v[2 * hh], x1 = v[2 * hh + 1];
+                            uint32_t w0[3], w1[3];
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) {
+                                const __bf16 b0 = (__bf16)x0, b1 = (__bf16)x1;
+                                w0[t] = __builtin_bit_cast(uint16_t, b0); w1[t] = __builtin_bit_cast(uint16_t, b1);
+                                x0 -= (float)b0; x1 -= (float)b1;
+                            }
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) pk[t][hh] = w0[t] | (w1[t] << 16);
+                        }
+                        uint16_t* pd = a.parts + (int64_t)p * a.parts_ld + q;
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) *(u32x2_t*)(pd + t * a.parts_stride) = u32x2_t{pk[t][0], pk[t][1]};
+                    }
+                }
+            }
+        }
+        if (!fwd && a.colsum_ws != nullptr) {
+            // over the 16 lanes that share l >> 4 (fixed xor tree): a wave owns its 64-row groups x 64 columns outright
+#pragma unroll
+            for (int g = 0; g < MR / 4; ++g) {
+                const int prow = tp * BP + wr * WP + g * 64;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float s_ = cs[g][ni][r];
+                        s_ += __shfl_xor(s_, 1, 64);
+                        s_ += __shfl_xor(s_, 2, 64);
+                        s_ += __shfl_xor(s_, 4, 64);
+                        s_ += __shfl_xor(s_, 8, 64);
+                        const int q = q0 + ni * 16 + r;
+                        if ((l & 15) == 0 && prow < a.Pext && q < a.Qext) a.colsum_ws[(int64_t)(prow >> 6) * a.Qext + q] = s_;
+                    }
             }
         }
     } else {

@@ -17,6 +17,7 @@
 //   mrec_x3_mask_colsum   dx = acc masked by h > 0 in place, column sums per 64 rows (the bias gradient of the layer below),
 //                         and (optionally) dx's parts, one pass
 #include "mrec_common.h"
+#include <cstdlib>
 #include "mrec_gemm.h"
 
 namespace {
@@ -50,7 +51,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& a, uint4& b, 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_x3_post(float* __restrict__ x, int64_t ldx, int64_t R, int C, const float* __restrict__ bias,
                                                  int relu, const float* __restrict__ h, int64_t ldh, float* __restrict__ colsum,
-                                                 uint16_t* __restrict__ parts, int64_t Rp, int64_t Cp) {
+                                                 uint16_t* __restrict__ parts, int64_t Rp, int64_t Cp, float scale) {
     // block = 64 rows x 32 column groups (256 columns); thread (rq, cg): rows rq, rq + 8, ... of column group cg
     const int cg = threadIdx.x & 31, rq = threadIdx.x >> 5;
     const int64_t r0 = (int64_t)blockIdx.y * 64;
@@ -92,6 +93,8 @@ __global__ __launch_bounds__(256) void k_x3_post(float* __restrict__ x, int64_t 
                     for (int k = 0; k < 8; ++k) if (c0 + k < C && !(h[r * ldh + c0 + k] > 0.f)) v[k] = 0.f;
                 }
 #pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] *= scale;            // (1 / keep of a Dropout on the layer's input; 1 otherwise)
+#pragma unroll
                 for (int k = 0; k < 8; ++k) cs[k] += v[k];
             }
             if (MODE != 0) {
@@ -131,14 +134,14 @@ __global__ __launch_bounds__(256) void k_x3_post(float* __restrict__ x, int64_t 
 
 template <int MODE>
 int post_launch(float* x, int64_t ldx, int64_t R, int32_t C, const float* bias, int relu, const float* h, int64_t ldh, float* colsum,
-                uint16_t* parts, void* stream) {
+                uint16_t* parts, void* stream, float scale = 1.0f) {
     if (R < 0 || C <= 0 || ldx < C || !x) return MREC_EINVAL;
     if (R == 0) return MREC_OK;
     if (ldx % 2 || (parts && !al16(parts)) || (((uintptr_t)x) & 7)) return MREC_EUNSUPPORTED;
     const int64_t Rp = up64(R), Cp = up64(C);
     const int64_t rows = parts ? Rp : R;
     dim3 grid((unsigned)mrec_cdiv(Cp, 256), (unsigned)mrec_cdiv(rows, 64));
-    k_x3_post<MODE><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, R, C, bias, relu, h, ldh, colsum, parts, Rp, Cp);
+    k_x3_post<MODE><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, R, C, bias, relu, h, ldh, colsum, parts, Rp, Cp, scale);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -160,14 +163,41 @@ MREC_API int mrec_x3_bias_relu(float* acc, int64_t ld, int64_t M, int32_t N, con
     return post_launch<1>(acc, ld, M, N, bias, relu, nullptr, 0, nullptr, parts_out, stream);
 }
 
-MREC_API int mrec_x3_mask_colsum(float* acc, int64_t ld, int64_t M, int32_t K, const float* h, int64_t ldh, float* colsum,
+MREC_API int mrec_x3_mask_colsum(float* acc, int64_t ld, int64_t M, int32_t K, const float* h, int64_t ldh, float scale, float* colsum,
                                  uint16_t* parts_out, void* stream) {
-    if (h && ldh < K) return MREC_EINVAL;
-    return post_launch<2>(acc, ld, M, K, nullptr, 0, h, ldh, colsum, parts_out, stream);
+    if ((h && ldh < K) || !(scale > 0.0f)) return MREC_EINVAL;
+    return post_launch<2>(acc, ld, M, K, nullptr, 0, h, ldh, colsum, parts_out, stream, scale);
 }
+
+namespace {
+struct X3Epi {                // the fused output end (EPI_X3); mode 0: plain fp32 out
+    int mode; const float* bias; int relu; const float* h; int64_t ldh; float scale; float* colsum; uint16_t* parts;
+};
+int x3_gemm(int form, const uint16_t* Pparts, const uint16_t* Qparts, int64_t M, int32_t K, int32_t N, float* C, int64_t ldc, int32_t S,
+            const X3Epi& e, void* stream);
+}  // namespace
 
 MREC_API int mrec_x3_gemm(int form, const uint16_t* Pparts, const uint16_t* Qparts, int64_t M, int32_t K, int32_t N, float* C, int64_t ldc,
                           int32_t S, void* stream) {
+    return x3_gemm(form, Pparts, Qparts, M, K, N, C, ldc, S, X3Epi{}, stream);
+}
+
+MREC_API int mrec_x3_gemm_fwd(const uint16_t* xparts, const uint16_t* wparts, int64_t M, int32_t K, int32_t N, float* y, int64_t ldy,
+                              const float* bias, int relu, uint16_t* parts_out, void* stream) {
+    if (parts_out && !al16(parts_out)) return MREC_EUNSUPPORTED;
+    return x3_gemm(0, xparts, wparts, M, K, N, y, ldy, 1, X3Epi{1, bias, relu, nullptr, 0, 1.0f, nullptr, parts_out}, stream);
+}
+
+MREC_API int mrec_x3_gemm_dgrad(const uint16_t* dyparts, const uint16_t* wparts, int64_t M, int32_t K, int32_t N, float* dx, int64_t lddx,
+                                const float* h, int64_t ldh, float scale, float* colsum, uint16_t* parts_out, void* stream) {
+    if ((parts_out && !al16(parts_out)) || (h && (ldh < K || ldh % 2 || (((uintptr_t)h) & 7)))) return MREC_EUNSUPPORTED;
+    if (!(scale > 0.0f)) return MREC_EINVAL;
+    return x3_gemm(1, dyparts, wparts, M, K, N, dx, lddx, 1, X3Epi{2, nullptr, 0, h, ldh, scale, colsum, parts_out}, stream);
+}
+
+namespace {
+int x3_gemm(int form, const uint16_t* Pparts, const uint16_t* Qparts, int64_t M, int32_t K, int32_t N, float* C, int64_t ldc, int32_t S,
+            const X3Epi& e, void* stream) {
     if (form < 0 || form > 2 || M <= 0 || K <= 0 || N <= 0 || !Pparts || !Qparts || !C || S <= 0) return MREC_EINVAL;
     if (!al16(Pparts) || !al16(Qparts) || (((uintptr_t)C) & 7) || ldc % 2) return MREC_EUNSUPPORTED;
     const int64_t Mp = up64(M), Kp = up64(K), Np = up64(N);
@@ -189,25 +219,40 @@ MREC_API int mrec_x3_gemm(int form, const uint16_t* Pparts, const uint16_t* Qpar
     if (3 * partP * 2 >= (int64_t(1) << 31) || 3 * partQ * 2 >= (int64_t(1) << 31)) return MREC_EUNSUPPORTED;
     a.K = (int)(6 * red);
     a.seg_tiles = (int)(red / 64);
+    static const int inter = [] { const char* e = getenv("MREC_X3_INTER"); return e ? atoi(e) : 1; }();
+    a.seg_inter = inter;
     for (int s = 0; s < 6; ++s) { a.seg_offP[s] = (uint32_t)(pa[s] * partP * 2); a.seg_offQ[s] = (uint32_t)(pb[s] * partQ * 2); }
     a.rangeP = 3 * partP * 2; a.rangeQ = 3 * partQ * 2;
     const int Ttot = 6 * a.seg_tiles;
     a.kt_per_slab = (Ttot + S - 1) / S;
     if ((int64_t)a.kt_per_slab * (S - 1) >= Ttot && S > 1) return MREC_EINVAL;
-    const int64_t b256 = mrec_cdiv(a.Pext, 256) * mrec_cdiv(a.Qext, 256) * S;
-    const int mr = b256 * 4 >= 256 * 3 ? 8 : 4;
+    // 256- or 128-row tiles: whichever fills the 256 CUs in fewer tile-times (a 128-row tile costs ~0.55 of a 256-row one; the input
+    // gradient into 1170 columns is 320 big tiles = two rounds at 62 %, or 640 small ones = 2.5 rounds of half the length)
+    const int64_t t8 = mrec_cdiv(a.Pext, 256) * mrec_cdiv(a.Qext, 256) * S, t4 = mrec_cdiv(a.Pext, 128) * mrec_cdiv(a.Qext, 256) * S;
+    int mr = (double)mrec_cdiv(t4, 256) * 0.55 < (double)mrec_cdiv(t8, 256) ? 4 : 8;
+    static const int force_mr = [] { const char* e = getenv("MREC_X3_MR"); return e ? atoi(e) : 0; }();      // (tools/probes/x3_bench.py)
+    if (force_mr == 4 || force_mr == 8) mr = force_mr;
     a.nTp = (int)mrec_cdiv(a.Pext, mr * 32); a.nTq = (int)mrec_cdiv(a.Qext, 256);
     const unsigned grid = (unsigned)(a.nTp * a.nTq * S);
     hipStream_t st = (hipStream_t)stream;
-#define MREC_X3(PT, QT)                                                                                              \
+#define MREC_X3(PT, QT, EPI)                                                                                         \
     do {                                                                                                              \
-        if (mr == 8) mgemm::k_gemm256<PT, QT, mgemm::EPI_F32, false, 4, 8><<<grid, mgemm::kThreads, 0, st>>>(a);      \
-        else mgemm::k_gemm256<PT, QT, mgemm::EPI_F32, false, 4, 4><<<grid, mgemm::kThreads, 0, st>>>(a);              \
+        if (mr == 8) mgemm::k_gemm256<PT, QT, EPI, false, 4, 8><<<grid, mgemm::kThreads, 0, st>>>(a);                 \
+        else mgemm::k_gemm256<PT, QT, EPI, false, 4, 4><<<grid, mgemm::kThreads, 0, st>>>(a);                         \
     } while (0)
-    if (form == 0) MREC_X3(false, true);
-    else if (form == 1) MREC_X3(false, false);
-    else MREC_X3(true, true);
+    if (e.mode != 0) {            // the layer's output end in the GEMM's epilogue (form 0: bias + ReLU; 1: ReLU mask, scale, bias gradient)
+        if (form == 2 || (e.mode == 1) != (form == 0)) return MREC_EINVAL;
+        a.x3_mode = e.mode; a.bias = e.bias; a.relu = e.relu; a.H = e.h; a.ldh = e.ldh; a.x3_scale = e.scale; a.colsum_ws = e.colsum;
+        a.parts = e.parts;
+        const int64_t outc = form == 0 ? N : K;
+        a.parts_ld = up64(outc); a.parts_stride = Mp * up64(outc);
+        if (form == 0) MREC_X3(false, true, mgemm::EPI_X3);
+        else MREC_X3(false, false, mgemm::EPI_X3);
+    } else if (form == 0) MREC_X3(false, true, mgemm::EPI_F32);
+    else if (form == 1) MREC_X3(false, false, mgemm::EPI_F32);
+    else MREC_X3(true, true, mgemm::EPI_F32);
 #undef MREC_X3
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
+}  // namespace

@@ -44,6 +44,9 @@ class DeepCrossConfig:
     seed: int = 1000
     init_sigma: float = 0.01
     graphs: str = "step"          # "step": the whole training step replays as one HIP graph; "none": kernel by kernel
+    fp32_matmul: str = "x3"       # the DenseLayers' fp32 MatMuls: "x3" = three-part bf16 operands on the 16-bit matrix instruction
+                                  # (fp32-class accuracy at 6/16 of the fp32-MFMA time, csrc/mrec_gemm_x3.hip); "exact" = the
+                                  # fp32-input matrix instruction (a k-ordered chain of fmaf per output, csrc/mrec_gemm_f32.hip)
 
 
 def _flat_views(shapes, device):
@@ -150,10 +153,10 @@ class DeepCrossEngine:
             f32 = dict(dtype=torch.float32, device=dev)
             T = k.dense32_colsum_tiles(B)
             b = {"d1": torch.empty((B, h1), **f32), "d2": torch.empty((B, h2), **f32), "dd1": torch.empty((B, h1), **f32),
-                 "g2": torch.empty((2, B, X), **f32),             # the MLP's and the cross stack's input gradients, added up below
-                 "g": torch.empty((B, X), **f32), "head": {},
-                 "dW1": torch.empty((k.dense32_bwd_weight_slabs(B, X, h1), X, h1), **f32),
-                 "dW2": torch.empty((k.dense32_bwd_weight_slabs(B, h1, h2), h1, h2), **f32),
+                 "g2": torch.empty((1, B, X), **f32),             # the MLP's input gradient; the cross stack's is added onto it
+                 "head": {},
+                 "dW1": torch.empty((k.x3_slabs(B, k.dense32_bwd_weight_slabs(B, X, h1)), X, h1), **f32),
+                 "dW2": torch.empty((k.x3_slabs(B, k.dense32_bwd_weight_slabs(B, h1, h2)), h1, h2), **f32),
                  "db1": torch.empty((T, h1), **f32), "gtab": torch.empty_like(self.table)}
             self._bufs[B] = b
         return b
@@ -169,17 +172,38 @@ class DeepCrossEngine:
         bf = self._buffers(B)
         self._state.advance(cfg.learning_rate, float(self.beta1), float(self.beta2))
         emb = k.gather_rows(self.table, ids, wts).view(B, X)
-        d1 = k.dense32_fwd(emb, W1, b1, relu=True, out=bf["d1"])
-        d2 = k.dense32_fwd(d1, W2, b2, relu=True, out=bf["d2"])
+        h1, h2 = cfg.deep_layer_dim
+        x3 = cfg.fp32_matmul == "x3" and k.x3_supported(B, X, h1) and k.x3_supported(B, h1, h2)
+        if x3:
+            P = bf.get("x3")
+            if P is None:
+                P = bf["x3"] = {"emb": k.x3_parts(B, X, self.device), "W1": k.x3_parts(X, h1, self.device), "W2": k.x3_parts(h1, h2, self.device),
+                                "d1": k.x3_parts(B, h1, self.device), "dd2": k.x3_parts(B, h2, self.device), "dd1": k.x3_parts(B, h1, self.device)}
+            k.x3_split(emb, out=P["emb"])
+            k.x3_split(W1, out=P["W1"])
+            k.x3_split(W2, out=P["W2"])
+            d1 = k.x3_fwd(P["emb"], P["W1"], B, X, h1, bf["d1"], bias=b1, relu=True, parts_out=P["d1"])
+            d2 = k.x3_fwd(P["d1"], P["W2"], B, h1, h2, bf["d2"], bias=b2, relu=True)
+        else:
+            d1 = k.dense32_fwd(emb, W1, b1, relu=True, out=bf["d1"])
+            d2 = k.dense32_fwd(d1, W2, b2, relu=True, out=bf["d2"])
         c = k.cross_layers(emb, cw, cb)
         loss, _, dd2, dc = k.dcn_head_fwd_bwd(d2, c, W3.view(-1), b3, label.view(-1), cfg.loss_scale / B, gW3.view(-1), gb2, gb3,
                                               out=bf["head"])
-        k.dense32_bwd_weight(d1, dd2, bf["dW2"])
-        dd1 = k.dense32_bwd_input(dd2, W2, h=d1, out=bf["dd1"], colsum=bf["db1"])
-        k.dense32_bwd_weight(emb, dd1, bf["dW1"])
-        k.dense32_bwd_input(dd1, W1, out=bf["g2"][0])
-        k.cross_layers_bwd(emb, cw, cb, dc, dx0_out=bf["g2"][1], dw_out=gcw, db_out=gcb)
-        g = k.sum_slabs(bf["g2"].view(2, B * X), bf["g"].view(-1)).view(B, X)
+        if x3:
+            k.x3_split(dd2, out=P["dd2"])
+            k.x3_gemm(2, P["d1"], P["dd2"], B, h1, h2, bf["dW2"], S=bf["dW2"].shape[0])
+            k.x3_dgrad(P["dd2"], P["W2"], B, h1, h2, bf["dd1"], h=d1, colsum=bf["db1"], parts_out=P["dd1"])
+            k.x3_gemm(2, P["emb"], P["dd1"], B, X, h1, bf["dW1"], S=bf["dW1"].shape[0])
+            k.x3_dgrad(P["dd1"], P["W1"], B, X, h1, bf["g2"][0])
+        else:
+            k.dense32_bwd_weight(d1, dd2, bf["dW2"])
+            dd1 = k.dense32_bwd_input(dd2, W2, h=d1, out=bf["dd1"], colsum=bf["db1"])
+            k.dense32_bwd_weight(emb, dd1, bf["dW1"])
+            k.dense32_bwd_input(dd1, W1, out=bf["g2"][0])
+        # the embeddings feed the deep net and the cross stack (:300-306): the cross stack's input gradient is added onto the deep net's
+        g = bf["g2"][0]
+        k.cross_layers_bwd(emb, cw, cb, dc, dx0_out=g, dw_out=gcw, db_out=gcb, accumulate=True)
         # dense table gradient = UnsortedSegmentSum of the masked row gradients (bprop of Gather)
         plan = k.sparse_plan(ids)
         sums = k.segment_sum(plan, g.view(B * Fd, D), wts)

@@ -41,8 +41,9 @@ class DeepFMConfig:
     seed: int = 1000
     init_sigma: float = 0.01
     mlp_dtype: str = "fp16"       # DenseLayer casts input, weight and bias to float16 (convert_dtype: True, default_config.yaml:27;
-                                  # deepfm.py:135-145); "bf16" runs the same kernels, "fp32" the library GEMMs through torch
+                                  # deepfm.py:135-145); "bf16" runs the same kernels, "fp32" the fp32 kernels (ops.x3_* / ops.dense32_*)
     graphs: str = "mlp"           # "mlp": the dense net's step replays as HIP graphs (16-bit net), "none": kernel by kernel
+    fp32_matmul: str = "x3"       # fp32 net: "x3" three-part bf16 operands on the 16-bit matrix instruction, "exact" the fp32-input one
 
 
 class _DeepFMNet(DenseNetMixin):

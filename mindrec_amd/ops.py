@@ -744,8 +744,9 @@ def cross_layers(x0, w, b):
     return out
 
 
-def cross_layers_bwd(x0, w, b, dy, dx0_out=None, dw_out=None, db_out=None):
-    """(dx0, dw, db) of the cross stack; *_out: contiguous tensors to write into (views of a flat gradient buffer)."""
+def cross_layers_bwd(x0, w, b, dy, dx0_out=None, dw_out=None, db_out=None, accumulate=False):
+    """(dx0, dw, db) of the cross stack; *_out: contiguous tensors to write into (views of a flat gradient buffer).
+    accumulate: dx0_out += dx0 (the gradient another branch left there)."""
     _need_cuda(x0, w, b, dy, dx0_out, dw_out, db_out)
     x0 = x0.contiguous(); w = w.contiguous(); b = b.contiguous(); dy = dy.contiguous()
     B, D = x0.shape
@@ -758,7 +759,9 @@ def cross_layers_bwd(x0, w, b, dy, dx0_out=None, dw_out=None, db_out=None):
     db = db_out if db_out is not None else torch.empty_like(b)
     nb = _lib.query_bytes("mrec_cross_layers_bwd_workspace_bytes", L, B, D)
     ws = workspace("cross", nb, x0.device)
-    _lib.call("mrec_cross_layers_bwd_f32", _ptr(x0), _ptr(w), _ptr(b), L, B, D, _ptr(dy), _ptr(dx0), _ptr(dw), _ptr(db),
+    if accumulate and dx0_out is None:
+        raise TypeError("cross_layers_bwd: accumulate needs dx0_out")
+    _lib.call("mrec_cross_layers_bwd_acc_f32" if accumulate else "mrec_cross_layers_bwd_f32", _ptr(x0), _ptr(w), _ptr(b), L, B, D, _ptr(dy), _ptr(dx0), _ptr(dw), _ptr(db),
               _ptr(ws), ws.numel(), _stream())
     return dx0, dw, db
 
@@ -1502,7 +1505,18 @@ def x3_supported(M, K, N):
 
 
 def x3_parts(rows, cols, device):
-    return torch.empty((3, _up64(rows), _up64(cols)), dtype=torch.bfloat16, device=device)
+    """A parts image [3, Rp, Cp] (zeroed: the fused output ends of x3_fwd / x3_dgrad never write its padding)."""
+    return torch.zeros((3, _up64(rows), _up64(cols)), dtype=torch.bfloat16, device=device)
+
+
+def x3_slabs(M, S):
+    """The largest slab count <= S the batch-reduction form (x3_gemm form 2) takes for M rows: every slab needs a non-empty share of
+    the 6 * ceil(M / 64) reduction tiles."""
+    T = 6 * (_up64(M) // 64)
+    S = max(1, min(int(S), T))
+    while S > 1 and -(-T // S) * (S - 1) >= T:
+        S -= 1
+    return S
 
 
 def x3_split(x, out=None):
@@ -1526,6 +1540,45 @@ def x3_gemm(form, P, Q, M, K, N, out, S=1):
     return out
 
 
+def _x3_out(out, M, C, name):
+    if out.dtype != torch.float32 or out.stride(-1) != 1 or tuple(out.shape) != (M, C):
+        raise TypeError(f"{name}: out must be float32 [{M}, {C}] with unit column stride")
+    return out.stride(0)
+
+
+def _x3_img(parts, M, C, name):
+    if parts is not None and (tuple(parts.shape) != (3, _up64(M), _up64(C)) or parts.dtype != torch.bfloat16 or not parts.is_contiguous()):
+        raise TypeError(f"{name}: parts_out must be the contiguous bfloat16 parts image [3, {_up64(M)}, {_up64(C)}]")
+
+
+def x3_fwd(xP, wP, M, K, N, out, bias=None, relu=True, parts_out=None):
+    """DenseLayer forward on parts images, output end in the GEMM's epilogue: out = relu?(x . w + bias) and, optionally, out's parts."""
+    _need_cuda(xP, wP, out, bias, parts_out)
+    ld = _x3_out(out, M, N, "x3_fwd")
+    _x3_img(parts_out, M, N, "x3_fwd")
+    _lib.call("mrec_x3_gemm_fwd", _ptr(xP), _ptr(wP), int(M), int(K), int(N), _ptr(out), ld, _ptr(bias), int(bool(relu)), _ptr(parts_out),
+              _stream())
+    return out
+
+
+def x3_dgrad(dyP, wP, M, K, N, out, h=None, scale=1.0, colsum=None, parts_out=None):
+    """Input gradient on parts images, output end in the epilogue: out = (h > 0 ? dy . w^T : 0) * scale, colsum [ceil(M / 64), K] the
+    bias gradient of the layer below in 64-row partial sums, and, optionally, out's parts."""
+    _need_cuda(dyP, wP, out, h, colsum, parts_out)
+    ld = _x3_out(out, M, K, "x3_dgrad")
+    _x3_img(parts_out, M, K, "x3_dgrad")
+    ldh = 0
+    if h is not None:
+        M2, K2, ldh = _mat32(h, "h")
+        if (M2, K2) != (M, K):
+            raise TypeError("h must be [M, K]")
+    if colsum is not None and (colsum.dtype != torch.float32 or tuple(colsum.shape) != ((M + 63) // 64, K) or not colsum.is_contiguous()):
+        raise TypeError("colsum must be contiguous float32 [ceil(M / 64), K]")
+    _lib.call("mrec_x3_gemm_dgrad", _ptr(dyP), _ptr(wP), int(M), int(K), int(N), _ptr(out), ld, _ptr(h), ldh, float(scale), _ptr(colsum),
+              _ptr(parts_out), _stream())
+    return out
+
+
 def x3_bias_relu_(acc, bias, relu=True, parts_out=None):
     _need_cuda(acc, bias, parts_out)
     M, N, ld = _mat32(acc, "acc")
@@ -1533,7 +1586,7 @@ def x3_bias_relu_(acc, bias, relu=True, parts_out=None):
     return acc
 
 
-def x3_mask_colsum_(acc, h=None, colsum=None, parts_out=None):
+def x3_mask_colsum_(acc, h=None, colsum=None, parts_out=None, scale=1.0):
     _need_cuda(acc, h, colsum, parts_out)
     M, K, ld = _mat32(acc, "acc")
     ldh = 0
@@ -1543,7 +1596,7 @@ def x3_mask_colsum_(acc, h=None, colsum=None, parts_out=None):
             raise TypeError("h must be [M, K]")
     if colsum is not None and (colsum.dtype != torch.float32 or tuple(colsum.shape) != ((M + 63) // 64, K) or not colsum.is_contiguous()):
         raise TypeError("colsum must be contiguous float32 [ceil(M / 64), K]")
-    _lib.call("mrec_x3_mask_colsum", _ptr(acc), ld, M, K, _ptr(h), ldh, _ptr(colsum), _ptr(parts_out), _stream())
+    _lib.call("mrec_x3_mask_colsum", _ptr(acc), ld, M, K, _ptr(h), ldh, float(scale), _ptr(colsum), _ptr(parts_out), _stream())
     return acc
 
 

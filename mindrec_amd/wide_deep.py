@@ -82,6 +82,8 @@ class WideDeepConfig:
     graphs: str = "step"           # what replays as HIP graphs: "step" the whole step (sinks of steps: train_steps), "front" everything in
                                    # front of the optimizers, "mlp" the dense net only, "none" kernel by kernel
     fused_tail: bool = True        # the last two hidden layers, the output head and their input-gradient bprops as one launch
+    fp32_matmul: str = "x3"        # the MatMuls of an fp32 net (amp "none"): "x3" three-part bf16 operands on the 16-bit matrix
+                                   # instruction (fp32-class accuracy, csrc/mrec_gemm_x3.hip), "exact" the fp32-input matrix instruction
     wide_b_optimizer: str = "ftrl"  # which optimizer owns the wide bias.  "ftrl": what the reference's code does on MindSpore --
                                     # TrainStepWrap sorts by `"wide" in params.name` (wide_and_deep.py:407-411) and the Parameter held in
                                     # the attribute `wide_b` (:161-163) is renamed "<prefix>.wide_b" when its cell is assigned to a

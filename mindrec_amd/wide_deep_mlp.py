@@ -230,6 +230,8 @@ class DenseNetMixin:
         if t is None:
             K, N = self.dims[i], self.dims[i + 1]
             S = self.k.dense32_bwd_weight_slabs(B, K, N) if self._f32net else self.k.dense_bwd_weight_slabs(B, K, N)
+            if self._f32net:
+                S = self.k.x3_slabs(B, S)        # (either fp32 MatMul path writes these)
             t = torch.empty((S, K, N), dtype=torch.float32, device=self.device)
             self._dw[i] = t
         return t
@@ -325,8 +327,34 @@ class DenseNetMixin:
         drops = [self._drop(i, B) for i in range(n)]
         if drops[0] is not None:
             k.dropout_(emb, drops[0])
+        # the MatMuls: fp32 operands as three bf16 parts on the 16-bit matrix instruction (csrc/mrec_gemm_x3.hip; fp32-class accuracy,
+        # measured against the exact kernels in tests/test_x3_gemm_gpu.py) where the shapes are big enough, else the fp32-input
+        # matrix instruction (csrc/mrec_gemm_f32.hip)
+        x3 = (getattr(self.cfg, "fp32_matmul", "x3") == "x3" and n >= 2
+              and all(k.x3_supported(B, self.dims[i], self.dims[i + 1]) for i in range(n - 1)))
         hs = [emb]
-        for i in range(n - 1):
+        if x3:
+            P = self.__dict__.setdefault("_x3_parts", {})
+            if P.get("B") != B:
+                P.clear()
+                P.update(B=B, h=[k.x3_parts(B, self.dims[i], self.device) for i in range(n - 1)],
+                         w=[k.x3_parts(self.dims[i], self.dims[i + 1], self.device) for i in range(n - 1)],
+                         dz=[k.x3_parts(B, self.dims[i + 1], self.device) for i in range(n - 1)],
+                         act=[torch.empty((B, self.dims[i + 1]), dtype=torch.float32, device=self.device) for i in range(n - 1)],
+                         dx=[torch.empty((B, self.dims[i]), dtype=torch.float32, device=self.device) for i in range(n - 1)])
+            k.x3_split(emb, out=P["h"][0])
+            for i in range(n - 1):
+                k.x3_split(self.dense[2 * i].detach(), out=P["w"][i])
+                nxt = P["h"][i + 1] if i + 1 < n - 1 else None
+                # bias + ReLU (and the next layer's parts) in the GEMM's epilogue; under Dropout the parts are those of the DROPPED activation
+                h = k.x3_fwd(P["h"][i], P["w"][i], B, self.dims[i], self.dims[i + 1], P["act"][i], bias=self.dense[2 * i + 1].detach(),
+                             relu=True, parts_out=nxt if drops[i + 1] is None else None)
+                if drops[i + 1] is not None:
+                    k.dropout_(h, drops[i + 1])
+                    if nxt is not None:
+                        k.x3_split(h, out=nxt)
+                hs.append(h)
+        for i in range(0 if x3 else n - 1):
             h = k.dense32_fwd(hs[i], self.dense[2 * i].detach(), self.dense[2 * i + 1].detach(), relu=True)
             if drops[i + 1] is not None:
                 k.dropout_(h, drops[i + 1])
@@ -356,7 +384,20 @@ class DenseNetMixin:
             if drops[n - 1] is not None:
                 dh.mul_(drops[n - 1].scale)
                 self.dense_grad[2 * (n - 2) + 1].mul_(drops[n - 1].scale)
-        for i in range(n - 2, -1, -1):
+        if x3:
+            k.x3_split(dh, out=P["dz"][n - 2])
+        for i in range(n - 2 if x3 else -1, -1, -1):
+            Ki, Ni = self.dims[i], self.dims[i + 1]
+            dw = self._dw_slabs(i, B)
+            k.x3_gemm(2, P["h"][i], P["dz"][i], B, Ki, Ni, dw, S=dw.shape[0])
+            if i > 0:      # ReLU (and Dropout mask) of layer i - 1, the 1 / keep of the Dropout in front of layer i, the bias gradient
+                dh = k.x3_dgrad(P["dz"][i], P["w"][i], B, Ki, Ni, P["dx"][i], h=hs[i], colsum=self._db_slabs(i - 1, B),
+                                parts_out=P["dz"][i - 1], scale=drops[i].scale if drops[i] is not None else 1.0)
+            else:
+                dh = k.x3_dgrad(P["dz"][0], P["w"][0], B, Ki, Ni, P["dx"][0])
+                if drops[0] is not None:
+                    k.dropout_(dh, drops[0])
+        for i in range(-1 if x3 else n - 2, -1, -1):
             k.dense32_bwd_weight(hs[i], dh, self._dw_slabs(i, B))
             if drops[i] is not None and i > 0:
                 dh.mul_(drops[i].scale)

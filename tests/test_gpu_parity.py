@@ -441,6 +441,12 @@ def test_cross_layers(dev, oracle, B, D, L):
     scale = np.abs(rdw).max()
     assert np.abs(dw.cpu().numpy() - rdw).max() <= 2e-5 * max(scale, 1) * np.sqrt(B)
     assert np.abs(db.cpu().numpy() - rdb).max() <= 2e-5 * max(np.abs(rdb).max(), 1) * np.sqrt(B)
+    # dx0 += ...: onto another branch's gradient, the same sum to the bit
+    base = rng.standard_normal((B, D)).astype(np.float32)
+    acc = T(base, dev)
+    _, dw2, db2 = ops.cross_layers_bwd(T(x0, dev), T(w, dev), T(b, dev), T(dy, dev), dx0_out=acc, accumulate=True)
+    assert np.array_equal(acc.cpu().numpy(), base + dx0.cpu().numpy())
+    assert torch.equal(dw2, dw) and torch.equal(db2, db)
 
 
 @pytest.mark.parametrize("S,D", [(2, 80), (8, 80), (3, 1), (8, 30), (4, 300)])

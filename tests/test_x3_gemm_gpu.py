@@ -36,10 +36,15 @@ def test_x3_products_have_fp32_accuracy(dev, M, K, N):
     # input gradient: dx = dy . w^T  (ld of the output not a multiple of 4 when K = 1170)
     dx = ops.x3_gemm(1, dyp, wp, M, K, N, torch.empty((M, K), dtype=torch.float32, device=dev)).cpu().numpy()
     assert _err(dx, dy64 @ w64.T, np.abs(dy64) @ np.abs(w64.T)) <= 6 * u
-    # weight gradient in S batch slabs
+    # weight gradient in S batch slabs: a reduction over the batch, whose rows span many binades -- held to the exact-fp32 kernel's
+    # own error on the same data (an fp32 accumulation of M terms is not better than a few ulps of sum |a| |b| either)
+    S32 = ops.dense32_bwd_weight_slabs(M, K, N)
+    w32 = ops.dense32_bwd_weight(tx, tdy, torch.empty((S32, K, N), dtype=torch.float32, device=dev)).cpu().numpy().astype(np.float64).sum(0)
+    e32 = _err(w32, x64.T @ dy64, np.abs(x64.T) @ np.abs(dy64))
     for S in (1, 3):
         slabs = ops.x3_gemm(2, xp, dyp, M, K, N, torch.empty((S, K, N), dtype=torch.float32, device=dev), S=S).cpu().numpy()
-        assert _err(slabs.astype(np.float64).sum(0), x64.T @ dy64, np.abs(x64.T) @ np.abs(dy64)) <= 8 * u
+        e = _err(slabs.astype(np.float64).sum(0), x64.T @ dy64, np.abs(x64.T) @ np.abs(dy64))
+        assert e <= max(8 * u, 2 * e32 + 2 * u), (e / u, e32 / u)
 
 
 def test_x3_post_ops(dev):
@@ -65,3 +70,37 @@ def test_x3_post_ops(dev):
     for tile in range(cs.shape[0]):
         assert np.allclose(cs[tile].cpu().numpy(), ref2[tile * 64:(tile + 1) * 64].astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
     assert torch.equal(parts[:, :M, :N].to(torch.float32).sum(0).cpu(), torch.from_numpy(ref2))
+
+
+@pytest.mark.parametrize("M,K,N", [(1024, 1170, 1024), (300, 1024, 136), (16384, 200, 72)])
+@pytest.mark.parametrize("scale", [1.0, 1.25])
+def test_x3_fused_output_ends_equal_the_two_pass_form(dev, M, K, N, scale):
+    """x3_fwd / x3_dgrad (bias + ReLU, or ReLU mask + 1 / keep + bias gradient, and the output's own parts inside the GEMM's epilogue)
+    against the GEMM followed by the post pass: outputs and parts to the bit, 64-row column sums to summation order."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(M + N)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dev)
+    x, w, b, dy, h = f(M, K), f(K, N) * 0.05, f(N), f(M, N), f(M, K)
+    xp, wp, dyp = ops.x3_split(x), ops.x3_split(w), ops.x3_split(dy)
+    # forward
+    y1, p1 = torch.empty((M, N), device=dev), ops.x3_parts(M, N, dev)
+    ops.x3_bias_relu_(ops.x3_gemm(0, xp, wp, M, K, N, y1), b, True, parts_out=p1)
+    y2, p2 = torch.empty((M, N), device=dev), ops.x3_parts(M, N, dev)
+    ops.x3_fwd(xp, wp, M, K, N, y2, bias=b, relu=True, parts_out=p2)
+    assert torch.equal(y1, y2) and torch.equal(p1.view(torch.int16), p2.view(torch.int16))
+    y3 = ops.x3_fwd(xp, wp, M, K, N, torch.empty((M, N), device=dev), bias=None, relu=False)
+    assert torch.equal(y3, ops.x3_gemm(0, xp, wp, M, K, N, torch.empty((M, N), device=dev)))
+    # input gradient (the output's row stride is not a multiple of 4 when K = 1170)
+    T = (M + 63) // 64
+    d1, c1, q1 = torch.empty((M, K), device=dev), torch.empty((T, K), device=dev), ops.x3_parts(M, K, dev)
+    ops.x3_mask_colsum_(ops.x3_gemm(1, dyp, wp, M, K, N, d1), h=h, colsum=c1, parts_out=q1, scale=scale)
+    d2, c2, q2 = torch.empty((M, K), device=dev), torch.full((T, K), float("nan"), device=dev), ops.x3_parts(M, K, dev)
+    ops.x3_dgrad(dyp, wp, M, K, N, d2, h=h, scale=scale, colsum=c2, parts_out=q2)
+    assert torch.equal(d1, d2) and torch.equal(q1.view(torch.int16), q2.view(torch.int16))
+    ref = torch.stack([d2[t * 64:(t + 1) * 64].double().sum(0) for t in range(T)])
+    mag = torch.stack([d2[t * 64:(t + 1) * 64].double().abs().sum(0) for t in range(T)])
+    assert float(((c2.double() - ref).abs() / (mag + 1e-30)).max()) <= 64 * 2.0 ** -24
+    assert float(((c1.double() - ref).abs() / (mag + 1e-30)).max()) <= 64 * 2.0 ** -24
+    # no mask, no sums, no parts: the plain input gradient
+    d3 = ops.x3_dgrad(dyp, wp, M, K, N, torch.empty((M, K), device=dev))
+    assert torch.equal(d3, ops.x3_gemm(1, dyp, wp, M, K, N, torch.empty((M, K), device=dev)))

@@ -17,19 +17,22 @@ g = torch.Generator(device=dev).manual_seed(1000)
 ids = torch.randint(0, cfg.vocab_size, (B, F), dtype=torch.int32, device=dev, generator=g)
 wts = torch.rand((B, F), device=dev, generator=g)
 label = (torch.rand((B, 1), device=dev, generator=g) < 0.3).float()
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-for _ in range(3):
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+for _ in range(10):
     eng.train_step(ids, wts, label)
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-a.record()
-for _ in range(steps):
-    loss = eng.train_step(ids, wts, label)
-b.record()
-torch.cuda.synchronize()
-ms = a.elapsed_time(b) / steps
-print(f"DCN step ({'hand-written fp32 MFMA net, one HIP graph' if eng._native and eng._graph is not None else 'torch / library GEMMs'}): {ms:.3f} ms  = "
-      f"{B / ms * 1e3 / 1e6:.2f} M samples/s   loss {float(loss):.5f}")
+runs = []
+for _ in range(3):
+    a.record()
+    for _ in range(steps):
+        loss = eng.train_step(ids, wts, label)
+    b.record()
+    torch.cuda.synchronize()
+    runs.append(a.elapsed_time(b) / steps)
+ms = sorted(runs)[1]
+print(f"DCN step (fp32 net, MatMuls: {cfg.fp32_matmul}; {'one HIP graph' if eng._native and eng._graph is not None else 'kernel by kernel'}): "
+      f"{ms:.3f} ms (median of 3 x {steps} steps: {', '.join(f'{r:.3f}' for r in runs)}) = {B / ms * 1e3 / 1e6:.2f} M samples/s   loss {float(loss):.5f}")
 if eng._native:
     # the three DenseLayer GEMM kinds alone (HIP events, 20 calls each)
     from mindrec_amd import ops
