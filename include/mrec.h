@@ -809,16 +809,22 @@ int mrec_x3_split(const float* x, int64_t ldx, int64_t R, int32_t C, uint16_t* p
 int mrec_x3_gemm(int form, const uint16_t* Pparts, const uint16_t* Qparts, int64_t M, int32_t K, int32_t N, float* C, int64_t ldc,
                  int32_t S, void* stream);
 int mrec_x3_bias_relu(float* acc, int64_t ld, int64_t M, int32_t N, const float* bias, int relu, uint16_t* parts_out, void* stream);
+/* the slab count mrec_x3_gemm's form 2 runs fastest with (a 256 x 256 tile x slab per CU); any S <= 6 * ceil(M / 64) whose slabs are
+ * all non-empty is accepted */
+int mrec_x3_wgrad_slabs(int64_t M, int32_t K, int32_t N, int32_t* out);
 int mrec_x3_mask_colsum(float* acc, int64_t ld, int64_t M, int32_t K, const float* h, int64_t ldh, float scale, float* colsum,
                         uint16_t* parts_out, void* stream);
 /* the same output ends inside the GEMM's epilogue (no second pass over the layer's output):
  *   mrec_x3_gemm_fwd:   y = relu?(x . w + bias) [M, N] AND (parts_out != NULL) y's parts image
  *   mrec_x3_gemm_dgrad: dx = (h > 0 ? dy . w^T : 0) * scale [M, K], colsum [ceil(M / 64), K] (nullable) AND (parts_out != NULL) dx's parts
+ * ws (nullable; mrec_x3_gemm_dgrad_workspace_bytes, 0 for most shapes): lets the PLAIN input gradient (no h, colsum, parts; scale 1) of a
+ * width with a narrow last 256-column tile run that tile as slabs of the reduction behind one round of full tiles.
  * parts_out: the padding of the image (rows M.., columns past the width) is NOT written -- the caller zeroes the image once. */
 int mrec_x3_gemm_fwd(const uint16_t* xparts, const uint16_t* wparts, int64_t M, int32_t K, int32_t N, float* y, int64_t ldy,
                      const float* bias, int relu, uint16_t* parts_out, void* stream);
+int mrec_x3_gemm_dgrad_workspace_bytes(int64_t M, int32_t K, int32_t N, size_t* out);
 int mrec_x3_gemm_dgrad(const uint16_t* dyparts, const uint16_t* wparts, int64_t M, int32_t K, int32_t N, float* dx, int64_t lddx,
-                       const float* h, int64_t ldh, float scale, float* colsum, uint16_t* parts_out, void* stream);
+                       const float* h, int64_t ldh, float scale, float* colsum, uint16_t* parts_out, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

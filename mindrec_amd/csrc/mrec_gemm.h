@@ -66,21 +66,22 @@ struct Args {
     int kt_per_slab;        // K-tiles per split slab (grid has nTp * nTq * S workgroups; no split: all of them)
     int64_t slab_stride;    // elements between consecutive slabs of C
     int relu;               // EPI_FWD
-    // VAR & 4 -- a SEGMENTED reduction: the K-tiles [s * seg_tiles, (s + 1) * seg_tiles) of the launch read P from byte offset
-    // seg_offP[s] and Q from seg_offQ[s] of their buffers (+ the tile's offset inside the segment).  What an fp32 GEMM needs when
+    // VAR & 4 -- a SEGMENTED reduction of six segments: segment s reads P from part (seg_codeP >> 2 s) & 3 of its buffer (parts are
+    // seg_partP bytes apart) and Q from part (seg_codeQ >> 2 s) & 3 (+ the tile's offset inside the part).  What an fp32 GEMM needs when
     // each fp32 operand is held as THREE bf16 parts (x = x1 + x2 + x3, 8 mantissa bits each): the six products a1 b1, a1 b2,
     // a2 b1, a1 b3, a2 b2, a3 b1 are six segments of one reduction into the same fp32 accumulators (mrec_gemm_x3.hip).
+    // (part numbers packed in a word, not arrays: a kernel that selects between two Args keeps them in SGPRs)
     int seg_tiles;          // K-tiles per segment (K = 6 * 64 * seg_tiles); 0: an ordinary reduction
+    uint32_t seg_codeP, seg_codeQ, seg_partP, seg_partQ;
+    int seg_inter;          // 1: K-tile t of the launch is tile t / 6 of segment t % 6 (the six products of one stretch of the reduction
+                            // back to back: every operand tile is fetched once from HBM and found in L2 the other times); 0: segment
+                            // after segment
     // EPI_X3 (H is then fp32 [Pext, ldh]; colsum_ws [ceil(Pext / 64), Qext])
     int x3_mode;
     float x3_scale;
     int64_t ldh;
     uint16_t* parts;        // nullable: [3][parts_stride] bf16 images of out, rows of parts_ld elements (zero padding is the caller's)
     int64_t parts_ld, parts_stride;
-    int seg_inter;          // 1: K-tile t of the launch is tile t / 6 of segment t % 6 (the six products of one stretch of the reduction
-                            // back to back: every operand tile is fetched once from HBM and found in L2 the other times); 0: segment
-                            // after segment
-    uint32_t seg_offP[6], seg_offQ[6];
     int64_t rangeP, rangeQ; // VAR & 4: bytes the P / Q buffer resources span (all parts)
     DropArgs drop;          // thresh != 0: Dropout on the layer input this launch produces (EPI_FWD: C is the next layer's input,
                             // masked and scaled after the rounding; EPI_DGRAD: C is the gradient of this layer's dropped-out
@@ -204,7 +205,7 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
                 sg = sg > 5 ? 5 : sg;
                 ti = tg - sg * a.seg_tiles;
             }
-            return (isP ? a.seg_offP[sg] : a.seg_offQ[sg]) + (uint32_t)ti * (isP ? ktP : ktQ);
+            return (((isP ? a.seg_codeP : a.seg_codeQ) >> (2 * sg)) & 3u) * (isP ? a.seg_partP : a.seg_partQ) + (uint32_t)ti * (isP ? ktP : ktQ);
         } else {
             return (uint32_t)tg * (isP ? ktP : ktQ);
         }

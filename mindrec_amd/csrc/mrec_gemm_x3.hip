@@ -24,6 +24,10 @@ namespace {
 
 using mgemm::Args;
 
+// the six products, smallest first: parts (a, b) = (2, 0) (1, 1) (0, 2) (1, 0) (0, 1) (0, 0); two bits per segment
+constexpr uint32_t kCodeP = 2u | (1u << 2) | (0u << 4) | (1u << 6) | (0u << 8) | (0u << 10);
+constexpr uint32_t kCodeQ = 0u | (1u << 2) | (2u << 4) | (0u << 6) | (1u << 8) | (0u << 10);
+
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 inline int64_t up64(int64_t x) { return (x + 63) / 64 * 64; }
 
@@ -132,6 +136,36 @@ __global__ __launch_bounds__(256) void k_x3_post(float* __restrict__ x, int64_t 
     }
 }
 
+// Two problems of the same kind in one launch: workgroups [0, n1) the first, the rest the second (uniform selects: the arguments stay in
+// SGPRs).  The input gradient into a width that leaves a narrow last column tile (Deep&Cross's 1170 = 4 x 256 + 146) runs its full tiles
+// as one round over the chip and the narrow tile as S short slabs of the reduction behind them, instead of two rounds at 62 %.
+template <bool PT, bool QT, int MR>
+__global__ __launch_bounds__(mgemm::kThreads, 2) void k_x3_pair(const Args a1, const Args a2, const int n1) {
+    __shared__ __attribute__((aligned(1024))) char smem[mgemm::Lds<MR>::bytes];
+    Args sel = a1;
+    int b = blockIdx.x, nb = n1;
+    if (b >= n1) { sel = a2; b -= n1; nb = (int)gridDim.x - n1; }
+    mgemm::gemm256_body<MR, PT, QT, mgemm::EPI_F32, false, 4>(sel, b, nb, (MGEMM_LDS char*)smem);
+}
+
+// dx[r, c0 + c] = sum_s ws[s][r][c]  (c < rem; ws rows of ldw floats, ldw % 4 == 0; dx rows 8-byte aligned)
+__global__ __launch_bounds__(256) void k_x3_fold_cols(const float* __restrict__ ws, int S, int64_t M, int rem, int ldw, float* __restrict__ dx,
+                                                      int64_t lddx, int c0) {
+    const int per = ldw / 4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * per) return;
+    const int64_t r = i / per;
+    const int c = (int)(i - r * per) * 4;
+    float4 acc = *(const float4*)(ws + r * ldw + c);
+    for (int s = 1; s < S; ++s) {
+        const float4 v = *(const float4*)(ws + ((int64_t)s * M + r) * ldw + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float* d = dx + r * lddx + c0 + c;
+    if (c + 2 <= rem) *(float2*)d = make_float2(acc.x, acc.y); else if (c < rem) d[0] = acc.x;
+    if (c + 4 <= rem) *(float2*)(d + 2) = make_float2(acc.z, acc.w); else if (c + 2 < rem) d[2] = acc.z;
+}
+
 template <int MODE>
 int post_launch(float* x, int64_t ldx, int64_t R, int32_t C, const float* bias, int relu, const float* h, int64_t ldh, float* colsum,
                 uint16_t* parts, void* stream, float scale = 1.0f) {
@@ -151,6 +185,20 @@ int post_launch(float* x, int64_t ldx, int64_t R, int32_t C, const float* bias, 
 MREC_API int mrec_x3_parts_elems(int64_t rows, int64_t cols, int64_t* out) {
     if (!out || rows < 0 || cols < 0) return MREC_EINVAL;
     *out = 3 * up64(rows) * up64(cols);
+    return MREC_OK;
+}
+
+// Batch slabs of the weight gradient: as many as put one 256 x 256 tile x slab on each of the 256 CUs (measured at M = 16384: 1170 x 1024
+// in 12 slabs of big tiles 260 us, in 6 slabs of 128-row tiles 298 us; 1024 x 1024 in 16 slabs 181 us, in 8 slabs of 128-row tiles 219 us),
+// every slab with a non-empty share of the 6 * ceil(M / 64) reduction tiles.
+MREC_API int mrec_x3_wgrad_slabs(int64_t M, int32_t K, int32_t N, int32_t* out) {
+    if (!out || M <= 0 || K <= 0 || N <= 0) return MREC_EINVAL;
+    const int64_t tiles = mrec_cdiv(K, 256) * mrec_cdiv(N, 256), T = 6 * (up64(M) / 64);
+    int64_t S = 256 / tiles;
+    S = S < 1 ? 1 : (S > 32 ? 32 : S);
+    S = S > T ? T : S;
+    while (S > 1 && mrec_cdiv(T, S) * (S - 1) >= T) --S;
+    *out = (int32_t)S;
     return MREC_OK;
 }
 
@@ -188,10 +236,46 @@ MREC_API int mrec_x3_gemm_fwd(const uint16_t* xparts, const uint16_t* wparts, in
     return x3_gemm(0, xparts, wparts, M, K, N, y, ldy, 1, X3Epi{1, bias, relu, nullptr, 0, 1.0f, nullptr, parts_out}, stream);
 }
 
+namespace {
+// The plain input gradient whose width leaves a narrow last column tile AND whose full tiles fit one round fewer over the 256 CUs
+// without it: S > 0 = reduction slabs for the narrow tile (through a workspace), 0 = one ordinary launch.
+struct DgradSplit { int S; int c0, rem, ldw; };
+DgradSplit dgrad_split(int64_t M, int32_t K, int32_t N) {
+    DgradSplit d{0, 0, 0, 0};
+    static const int off = [] { const char* e = getenv("MREC_X3_NOSPLIT"); return e ? atoi(e) : 0; }();      // (tools/probes/x3_bench.py)
+    if (off) return d;
+    const int64_t nTp = mrec_cdiv(M, 256), nTq = mrec_cdiv(K, 256);
+    const int rem = (int)(K - 256 * (nTq - 1));
+    if (nTq < 2 || rem >= 224 || mrec_cdiv(nTp * nTq, 256) == mrec_cdiv(nTp * (nTq - 1), 256)) return d;
+    int64_t S = 256 / nTp;
+    S = S > 4 ? 4 : S;
+    const int64_t T = 6 * (up64(N) / 64);
+    while (S > 1 && mrec_cdiv(T, S) * (S - 1) >= T) --S;
+    if (S < 2) return d;
+    d.S = (int)S; d.c0 = (int)(256 * (nTq - 1)); d.rem = rem; d.ldw = (rem + 3) / 4 * 4;
+    return d;
+}
+int x3_dgrad_split(const uint16_t* dyparts, const uint16_t* wparts, int64_t M, int32_t K, int32_t N, float* dx, int64_t lddx, float* ws,
+                   const DgradSplit& d, void* stream);
+}  // namespace
+
+MREC_API int mrec_x3_gemm_dgrad_workspace_bytes(int64_t M, int32_t K, int32_t N, size_t* out) {
+    if (!out || M <= 0 || K <= 0 || N <= 0) return MREC_EINVAL;
+    const DgradSplit d = dgrad_split(M, K, N);
+    *out = d.S ? (size_t)d.S * M * d.ldw * sizeof(float) + 256 : 0;
+    return MREC_OK;
+}
+
 MREC_API int mrec_x3_gemm_dgrad(const uint16_t* dyparts, const uint16_t* wparts, int64_t M, int32_t K, int32_t N, float* dx, int64_t lddx,
-                                const float* h, int64_t ldh, float scale, float* colsum, uint16_t* parts_out, void* stream) {
+                                const float* h, int64_t ldh, float scale, float* colsum, uint16_t* parts_out, void* ws, size_t ws_bytes,
+                                void* stream) {
     if ((parts_out && !al16(parts_out)) || (h && (ldh < K || ldh % 2 || (((uintptr_t)h) & 7)))) return MREC_EUNSUPPORTED;
     if (!(scale > 0.0f)) return MREC_EINVAL;
+    if (!h && !colsum && !parts_out && scale == 1.0f && ws && M > 0 && K > 0 && N > 0) {
+        const DgradSplit d = dgrad_split(M, K, N);
+        if (d.S && al16(ws) && ws_bytes >= (size_t)d.S * M * d.ldw * sizeof(float))
+            return x3_dgrad_split(dyparts, wparts, M, K, N, dx, lddx, (float*)ws, d, stream);
+    }
     return x3_gemm(1, dyparts, wparts, M, K, N, dx, lddx, 1, X3Epi{2, nullptr, 0, h, ldh, scale, colsum, parts_out}, stream);
 }
 
@@ -201,7 +285,6 @@ int x3_gemm(int form, const uint16_t* Pparts, const uint16_t* Qparts, int64_t M,
     if (form < 0 || form > 2 || M <= 0 || K <= 0 || N <= 0 || !Pparts || !Qparts || !C || S <= 0) return MREC_EINVAL;
     if (!al16(Pparts) || !al16(Qparts) || (((uintptr_t)C) & 7) || ldc % 2) return MREC_EUNSUPPORTED;
     const int64_t Mp = up64(M), Kp = up64(K), Np = up64(N);
-    static const int pa[6] = {2, 1, 0, 1, 0, 0}, pb[6] = {0, 1, 2, 0, 1, 0};          // smallest products first
     Args a{};
     a.P = Pparts; a.Q = Qparts; a.C = C; a.ldc = ldc;
     int64_t partP, partQ, red;                    // elements per part of P / Q; the reduction extent (padded)
@@ -221,7 +304,7 @@ int x3_gemm(int form, const uint16_t* Pparts, const uint16_t* Qparts, int64_t M,
     a.seg_tiles = (int)(red / 64);
     static const int inter = [] { const char* e = getenv("MREC_X3_INTER"); return e ? atoi(e) : 1; }();
     a.seg_inter = inter;
-    for (int s = 0; s < 6; ++s) { a.seg_offP[s] = (uint32_t)(pa[s] * partP * 2); a.seg_offQ[s] = (uint32_t)(pb[s] * partQ * 2); }
+    a.seg_codeP = kCodeP; a.seg_codeQ = kCodeQ; a.seg_partP = (uint32_t)(partP * 2); a.seg_partQ = (uint32_t)(partQ * 2);
     a.rangeP = 3 * partP * 2; a.rangeQ = 3 * partQ * 2;
     const int Ttot = 6 * a.seg_tiles;
     a.kt_per_slab = (Ttot + S - 1) / S;
@@ -252,6 +335,36 @@ int x3_gemm(int form, const uint16_t* Pparts, const uint16_t* Qparts, int64_t M,
     else if (form == 1) MREC_X3(false, false, mgemm::EPI_F32);
     else MREC_X3(true, true, mgemm::EPI_F32);
 #undef MREC_X3
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+int x3_dgrad_split(const uint16_t* dyparts, const uint16_t* wparts, int64_t M, int32_t K, int32_t N, float* dx, int64_t lddx, float* ws,
+                   const DgradSplit& d, void* stream) {
+    if (!dyparts || !wparts || !dx || lddx < K) return MREC_EINVAL;
+    if (!al16(dyparts) || !al16(wparts) || (((uintptr_t)dx) & 7) || lddx % 2) return MREC_EUNSUPPORTED;
+    const int64_t Mp = up64(M), Kp = up64(K), Np = up64(N);
+    const int64_t partP = Mp * Np, partQ = Kp * Np;
+    if (3 * partP * 2 >= (int64_t(1) << 31) || 3 * partQ * 2 >= (int64_t(1) << 31)) return MREC_EUNSUPPORTED;
+    Args a{};
+    a.P = dyparts; a.Q = wparts; a.C = dx; a.ldc = lddx;
+    a.ldp = Np; a.ldq = Np; a.Pext = (int)M; a.Qext = d.c0;
+    a.K = (int)(6 * Np); a.seg_tiles = (int)(Np / 64); a.seg_inter = 1;
+    a.seg_codeP = kCodeP; a.seg_codeQ = kCodeQ; a.seg_partP = (uint32_t)(partP * 2); a.seg_partQ = (uint32_t)(partQ * 2);
+    a.rangeP = 3 * partP * 2; a.rangeQ = 3 * partQ * 2;
+    const int Ttot = 6 * a.seg_tiles;
+    a.kt_per_slab = Ttot;
+    a.nTp = (int)mrec_cdiv(M, 256); a.nTq = d.c0 / 256;
+    Args b = a;                     // the narrow tile: rows c0.. of every part of w, S slabs of the reduction into the workspace
+    b.Q = wparts + (int64_t)d.c0 * Np; b.rangeQ = a.rangeQ - (int64_t)d.c0 * Np * 2;
+    b.C = ws; b.ldc = d.ldw; b.slab_stride = M * (int64_t)d.ldw;
+    b.Qext = d.rem; b.nTq = 1;
+    b.kt_per_slab = (Ttot + d.S - 1) / d.S;
+    const int n1 = a.nTp * a.nTq, n2 = b.nTp * d.S;
+    hipStream_t st = (hipStream_t)stream;
+    k_x3_pair<false, false, 8><<<(unsigned)(n1 + n2), mgemm::kThreads, 0, st>>>(a, b, n1);
+    const int64_t items = M * (d.ldw / 4);
+    k_x3_fold_cols<<<(unsigned)mrec_cdiv(items, 256), 256, 0, st>>>(ws, d.S, M, d.rem, d.ldw, dx, lddx, d.c0);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }

@@ -143,6 +143,12 @@ class DeepCrossEngine:
         return logit, torch.sigmoid(logit)
 
     # ---- the hand-written step ------------------------------------------------------------------------------------------
+    def _x3(self, B):
+        """The DenseLayers' MatMuls on three-part bf16 operands (ops.x3_*) at this batch size?"""
+        cfg, k = self.cfg, self.k
+        X, (h1, h2) = cfg.field_size * cfg.emb_dim, cfg.deep_layer_dim
+        return cfg.fp32_matmul == "x3" and k.x3_supported(B, X, h1) and k.x3_supported(B, h1, h2)
+
     def _buffers(self, B):
         """Intermediates of a step at batch B (allocated once: a captured step writes the same addresses every replay)."""
         b = self._bufs.get(B)
@@ -155,8 +161,8 @@ class DeepCrossEngine:
             b = {"d1": torch.empty((B, h1), **f32), "d2": torch.empty((B, h2), **f32), "dd1": torch.empty((B, h1), **f32),
                  "g2": torch.empty((1, B, X), **f32),             # the MLP's input gradient; the cross stack's is added onto it
                  "head": {},
-                 "dW1": torch.empty((k.x3_slabs(B, k.dense32_bwd_weight_slabs(B, X, h1)), X, h1), **f32),
-                 "dW2": torch.empty((k.x3_slabs(B, k.dense32_bwd_weight_slabs(B, h1, h2)), h1, h2), **f32),
+                 "dW1": torch.empty(((k.x3_wgrad_slabs if self._x3(B) else k.dense32_bwd_weight_slabs)(B, X, h1), X, h1), **f32),
+                 "dW2": torch.empty(((k.x3_wgrad_slabs if self._x3(B) else k.dense32_bwd_weight_slabs)(B, h1, h2), h1, h2), **f32),
                  "db1": torch.empty((T, h1), **f32), "gtab": torch.empty_like(self.table)}
             self._bufs[B] = b
         return b
@@ -173,7 +179,7 @@ class DeepCrossEngine:
         self._state.advance(cfg.learning_rate, float(self.beta1), float(self.beta2))
         emb = k.gather_rows(self.table, ids, wts).view(B, X)
         h1, h2 = cfg.deep_layer_dim
-        x3 = cfg.fp32_matmul == "x3" and k.x3_supported(B, X, h1) and k.x3_supported(B, h1, h2)
+        x3 = self._x3(B)
         if x3:
             P = bf.get("x3")
             if P is None:

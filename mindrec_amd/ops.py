@@ -1509,6 +1509,13 @@ def x3_parts(rows, cols, device):
     return torch.zeros((3, _up64(rows), _up64(cols)), dtype=torch.bfloat16, device=device)
 
 
+def x3_wgrad_slabs(M, K, N):
+    """Batch slabs the weight gradient (x3_gemm form 2) runs fastest with."""
+    s = C.c_int32(0)
+    _lib.call("mrec_x3_wgrad_slabs", int(M), int(K), int(N), C.byref(s))
+    return int(s.value)
+
+
 def x3_slabs(M, S):
     """The largest slab count <= S the batch-reduction form (x3_gemm form 2) takes for M rows: every slab needs a non-empty share of
     the 6 * ceil(M / 64) reduction tiles."""
@@ -1574,8 +1581,12 @@ def x3_dgrad(dyP, wP, M, K, N, out, h=None, scale=1.0, colsum=None, parts_out=No
             raise TypeError("h must be [M, K]")
     if colsum is not None and (colsum.dtype != torch.float32 or tuple(colsum.shape) != ((M + 63) // 64, K) or not colsum.is_contiguous()):
         raise TypeError("colsum must be contiguous float32 [ceil(M / 64), K]")
+    ws, nb = None, 0
+    if h is None and colsum is None and parts_out is None and scale == 1.0:
+        nb = _lib.query_bytes("mrec_x3_gemm_dgrad_workspace_bytes", int(M), int(K), int(N))
+        ws = workspace("x3_dgrad", nb, out.device) if nb else None
     _lib.call("mrec_x3_gemm_dgrad", _ptr(dyP), _ptr(wP), int(M), int(K), int(N), _ptr(out), ld, _ptr(h), ldh, float(scale), _ptr(colsum),
-              _ptr(parts_out), _stream())
+              _ptr(parts_out), _ptr(ws), ws.numel() if ws is not None else 0, _stream())
     return out
 
 

@@ -222,6 +222,13 @@ class DenseNetMixin:
             self._db[i] = t
         return t
 
+    def _x3_now(self, B):
+        """fp32 net: its MatMuls on three-part bf16 operands (csrc/mrec_gemm_x3.hip; fp32-class accuracy, measured against the exact
+        kernels in tests/test_x3_gemm_gpu.py) at this batch size?  Shapes too small for it stay on the fp32-input matrix instruction."""
+        n = len(self.dims) - 1
+        return (getattr(self.cfg, "fp32_matmul", "x3") == "x3" and n >= 2
+                and all(self.k.x3_supported(B, self.dims[i], self.dims[i + 1]) for i in range(n - 1)))
+
     def _dw_slabs(self, i, B):
         """fp32 batch slabs [S, in, out] the weight-gradient kernel of hidden layer i writes (allocated once per batch size)."""
         if self._dw_batch != B:
@@ -229,9 +236,8 @@ class DenseNetMixin:
         t = self._dw.get(i)
         if t is None:
             K, N = self.dims[i], self.dims[i + 1]
-            S = self.k.dense32_bwd_weight_slabs(B, K, N) if self._f32net else self.k.dense_bwd_weight_slabs(B, K, N)
-            if self._f32net:
-                S = self.k.x3_slabs(B, S)        # (either fp32 MatMul path writes these)
+            S = ((self.k.x3_wgrad_slabs if self._x3_now(B) else self.k.dense32_bwd_weight_slabs)(B, K, N) if self._f32net else
+                 self.k.dense_bwd_weight_slabs(B, K, N))
             t = torch.empty((S, K, N), dtype=torch.float32, device=self.device)
             self._dw[i] = t
         return t
@@ -327,11 +333,7 @@ class DenseNetMixin:
         drops = [self._drop(i, B) for i in range(n)]
         if drops[0] is not None:
             k.dropout_(emb, drops[0])
-        # the MatMuls: fp32 operands as three bf16 parts on the 16-bit matrix instruction (csrc/mrec_gemm_x3.hip; fp32-class accuracy,
-        # measured against the exact kernels in tests/test_x3_gemm_gpu.py) where the shapes are big enough, else the fp32-input
-        # matrix instruction (csrc/mrec_gemm_f32.hip)
-        x3 = (getattr(self.cfg, "fp32_matmul", "x3") == "x3" and n >= 2
-              and all(k.x3_supported(B, self.dims[i], self.dims[i + 1]) for i in range(n - 1)))
+        x3 = self._x3_now(B)
         hs = [emb]
         if x3:
             P = self.__dict__.setdefault("_x3_parts", {})

@@ -104,3 +104,23 @@ def test_x3_fused_output_ends_equal_the_two_pass_form(dev, M, K, N, scale):
     # no mask, no sums, no parts: the plain input gradient
     d3 = ops.x3_dgrad(dyp, wp, M, K, N, torch.empty((M, K), device=dev))
     assert torch.equal(d3, ops.x3_gemm(1, dyp, wp, M, K, N, torch.empty((M, K), device=dev)))
+
+
+def test_x3_plain_dgrad_with_a_narrow_last_tile(dev):
+    """Deep&Cross's input gradient into 1170 columns at the benchmark batch: 4 full column tiles in one round over the chip and the
+    146-column rest as slabs of the reduction (through the workspace) -- every column still an fp32-class product."""
+    from mindrec_amd import _lib, ops
+    M, K, N = 16384, 1170, 256
+    assert _lib.query_bytes("mrec_x3_gemm_dgrad_workspace_bytes", M, K, N) > 0          # this shape takes the split form
+    assert _lib.query_bytes("mrec_x3_gemm_dgrad_workspace_bytes", 1024, K, N) == 0
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((K, N)) * 0.05).astype(np.float32)
+    dy = (rng.standard_normal((M, N)) * np.exp(rng.uniform(-20, 0, (M, 1)))).astype(np.float32)
+    tw, tdy = torch.from_numpy(w).to(dev), torch.from_numpy(dy).to(dev)
+    wp, dyp = ops.x3_split(tw), ops.x3_split(tdy)
+    dx = torch.full((M, K), float("nan"), device=dev)
+    ops.x3_dgrad(dyp, wp, M, K, N, dx)
+    one = ops.x3_gemm(1, dyp, wp, M, K, N, torch.empty((M, K), device=dev))            # the one-launch form
+    assert torch.equal(dx[:, :1024], one[:, :1024])
+    w64, dy64 = w.astype(np.float64), dy.astype(np.float64)
+    assert _err(dx.cpu().numpy(), dy64 @ w64.T, np.abs(dy64) @ np.abs(w64.T)) <= 6 * 2.0 ** -24

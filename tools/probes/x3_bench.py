@@ -30,11 +30,12 @@ for K, N in ((1170, 1024), (1024, 1024)):
     xp, wp, dyp = ops.x3_split(x), ops.x3_split(w), ops.x3_split(dy)
     y = torch.empty(M, N, device=dev)
     dx = torch.empty(M, K, device=dev)
-    S = ops.dense32_bwd_weight_slabs(M, K, N)
+    S = int(os.environ.get('X3_S', 0)) or ops.x3_slabs(M, ops.dense32_bwd_weight_slabs(M, K, N))
     dw = torch.empty(S, K, N, device=dev)
     fl = 2 * M * K * N
     r = {"split x": t(lambda: ops.x3_split(x, out=xp)),
          "fwd x3": t(lambda: ops.x3_gemm(0, xp, wp, M, K, N, y)), "fwd f32": t(lambda: ops.dense32_fwd(x, w, None, relu=False, out=y)),
+         "dgrad x3 (split tile)": t(lambda: ops.x3_dgrad(dyp, wp, M, K, N, dx)),
          "dgrad x3": t(lambda: ops.x3_gemm(1, dyp, wp, M, K, N, dx)), "dgrad f32": t(lambda: ops.dense32_bwd_input(dy, w, out=dx)),
          "wgrad x3": t(lambda: ops.x3_gemm(2, xp, dyp, M, K, N, dw, S=S)), "wgrad f32": t(lambda: ops.dense32_bwd_weight(x, dy, dw)),
          "bias_relu+parts": t(lambda: ops.x3_bias_relu_(y, torch.zeros(N, device=dev), True, dyp))}
