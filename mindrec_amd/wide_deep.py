@@ -100,6 +100,7 @@ class _DirectComm:
 
     def __init__(self, group=None):
         self.group = group
+        self._stream = None        # eager asynchronous reductions run here (see all_reduce)
 
     @property
     def capturable(self):
@@ -127,12 +128,37 @@ class _DirectComm:
                 w.wait()
 
     def all_reduce(self, t, async_op=False):
-        """Sum over ranks.  async_op=True returns a work handle (device tensors only): the reduction proceeds on RCCL's
-        stream while the calling stream keeps issuing kernels."""
+        """Sum over ranks.  async_op=True returns a handle with wait() (device tensors only): the reduction proceeds beside the
+        calling stream, which keeps issuing kernels until it waits.
+
+        Inside a capture that is the group's own asynchronous op (its internal stream joins the capture).  OUTSIDE one it must not
+        be: an eager asynchronous op leaves its end event on the group's internal stream, torch's watchdog thread queries that
+        event until the work is retired (every ~100 ms), and on HIP a query fails -- and takes the process down from the
+        watchdog thread -- while the event's stream is capturing, which the internal stream is as soon as a captured step issues
+        its first asynchronous op (tools/probes/rccl_capture_race_probe.py reproduces it; it was the 'flaky'
+        hipErrorCapturedEvent of rounds 3-4).  Eager reductions therefore run as the synchronous op on a stream of our own,
+        which never captures; a synchronous op's event lives on the stream it was issued on."""
         if async_op and t.is_cuda:
-            return dist.all_reduce(t, group=self.group, async_op=True)
+            if torch.cuda.is_current_stream_capturing():
+                return dist.all_reduce(t, group=self.group, async_op=True)
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(t.device)
+            self._stream.wait_stream(torch.cuda.current_stream(t.device))
+            with torch.cuda.stream(self._stream):
+                dist.all_reduce(t, group=self.group)
+                return _StreamWork(self._stream.record_event())
         dist.all_reduce(t, group=self.group)
         return None
+
+
+class _StreamWork:
+    """wait(): the current stream waits for the reduction issued on the communicator's side stream (no host block)."""
+
+    def __init__(self, event):
+        self._event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self._event)
 
 
 class WideDeepEngine(DenseNetMixin, ShardStepMixin):

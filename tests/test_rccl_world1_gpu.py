@@ -80,3 +80,43 @@ def test_sharded_engine_over_rccl_world1_matches_one_gpu_engine(dev, tmp_path, m
     else:
         diff = np.abs(r["dense"] - ref)
         assert diff.max() <= 2.0 * cfg.adam_lr * 8 and np.mean(diff <= 5e-2 * np.abs(ref) + 1e-5) >= 0.99
+
+
+def _race_worker(rank, port):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import time
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from mindrec_amd.wide_deep import _DirectComm
+    comm = _DirectComm()
+    t, u = torch.ones(1 << 20, device=dev), torch.ones(1 << 20, device=dev)
+    comm.all_reduce(t)
+    torch.cuda.synchronize()
+    time.sleep(0.5)
+    # an eager asynchronous reduction, NOT yet retired by torch's watchdog thread when the capture begins ...
+    w = comm.all_reduce(t, async_op=True)
+    w.wait()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        w = comm.all_reduce(u, async_op=True)         # ... pulls the group's internal stream into the capture
+        time.sleep(0.5)                               # the watchdog looks at the eager work meanwhile (every 100 ms)
+        w.wait()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    del g
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_eager_async_reduction_cannot_abort_a_later_capture(dev):
+    """On HIP an event cannot be queried while its stream captures, and ProcessGroupNCCL's watchdog queries the end event of every
+    eager work it has not retired: an eager async_op=True reduction (event on the group's internal stream) followed by a captured one
+    aborted the process from the watchdog thread whenever the watchdog was late (tools/probes/rccl_capture_race_probe.py).  The
+    communicator's eager reductions run on a stream of its own instead; this would SIGABRT otherwise."""
+    mp.spawn(_race_worker, args=(_free_port(),), nprocs=1, join=True)
