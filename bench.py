@@ -494,7 +494,7 @@ def _measure(args, world, rank, dev):
                                f"layout), {args.dist} ids{', hash tables keyed by id (dynamic_embedding)' if args.dynamic_embedding else ''}"
                                f"{f', tables in host DRAM behind a {args.host_cache_rows}-row device cache' if args.host_cache_rows else ''}, "
                                f"MLP {cfg.field_size * cfg.emb_dim}-1024-512-256-128-1 in {args.mlp_dtype} "
-                               f"({'hand-written MFMA kernels' if eng._mfma else ('hand-written exact-fp32 MFMA DenseLayers' if getattr(eng, '_f32net', False) else 'torch GEMMs')}; looked-up rows and row gradients in {dt_name})"
+                               f"({'hand-written MFMA kernels' if eng._mfma else (f'hand-written fp32 DenseLayers, MatMuls: {cfg.fp32_matmul}' if getattr(eng, '_f32net', False) else 'torch GEMMs')}; looked-up rows and row gradients in {dt_name})"
                                f"{f', {S} steps per host call (sink_size)' if graphs_used.get('sink_size', 1) > 1 else ''}"
                                f"{', Dropout(0.5) on every DenseLayer input' if args.dropout else ''}",
                    "global_batch": args.batch * world, "id_dist": args.dist, "hip_graphs": graphs_used, "unique_frac": round(U / max(n_apply, 1), 4),

@@ -519,9 +519,20 @@ __global__ __launch_bounds__(256) void k_dense_adam4(float4* __restrict__ p, flo
 // (the product, the add onto the scattered sums, the sum of squares).
 __global__ __launch_bounds__(256) void k_dense_adam4_l2(float4* __restrict__ p, float4* __restrict__ m, float4* __restrict__ v,
                                                         const float4* __restrict__ g, int64_t n4, AdamH h, float l2s,
-                                                        double* __restrict__ partial) {
+                                                        double* __restrict__ partial, int tail) {
     __shared__ double red[4];
     double acc = 0.0;
+    if (tail && blockIdx.x == 0 && threadIdx.x == 0) {          // the n % 4 elements behind the last whole float4 (DeepFM's [184 965, 1] table)
+        float* ps = (float*)(p + n4); float* ms = (float*)(m + n4); float* vs = (float*)(v + n4);
+        const float* gs = (const float*)(g + n4);
+        for (int t = 0; t < tail; ++t) {
+            float pp = ps[t], mm = ms[t], vv = vs[t], gg = gs[t];
+            acc += (double)pp * pp;
+            gg += l2s * pp;
+            adam_elem(pp, mm, vv, gg * h.gscale, h);
+            ps[t] = pp; ms[t] = mm; vs[t] = vv;
+        }
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 pp = p[i], mm = m[i], vv = v[i];
         float4 gg = g[i];
@@ -541,11 +552,20 @@ __global__ __launch_bounds__(256) void k_dense_adam4_l2(float4* __restrict__ p, 
     if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
-__global__ __launch_bounds__(64) void k_sumsq_finish(const double* __restrict__ partial, int nb, double* __restrict__ out, int accumulate) {
-    if (threadIdx.x) return;
-    double s = accumulate ? *out : 0.0;
-    for (int b = 0; b < nb; ++b) s += partial[b];
-    *out = s;
+// One workgroup adds the per-workgroup partials in a FIXED order (thread t takes partials t, t + 256, ...; then a tree over the
+// threads): the same bits every run.  (One thread walking all of them was a chain of ~2000 dependent loads: 110 us per table.)
+__global__ __launch_bounds__(256) void k_sumsq_finish(const double* __restrict__ partial, int nb, double* __restrict__ out, int accumulate) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 256) s += partial[b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+#pragma unroll
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = (accumulate ? *out : 0.0) + red[0];
 }
 
 template <bool SH>
@@ -1006,9 +1026,9 @@ MREC_API int mrec_dense_adam_l2_f32(float* p, float* m, float* v, const float* g
     if (n < 0) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
     if (!p || !m || !v || !g) return MREC_EINVAL;
-    if (n % 4 || !al16(p) || !al16(m) || !al16(v) || !al16(g)) return MREC_EUNSUPPORTED;
+    if (!al16(p) || !al16(m) || !al16(v) || !al16(g)) return MREC_EUNSUPPORTED;
     const int64_t n4 = n / 4;
-    const unsigned gr = stream_grid(n4);
+    const unsigned gr = stream_grid(n4 > 0 ? n4 : 1);
     double* partial = nullptr;
     if (sumsq) {
         MrecArena a(ws, ws_bytes);
@@ -1020,8 +1040,8 @@ MREC_API int mrec_dense_adam_l2_f32(float* p, float* m, float* v, const float* g
     h.b1 = b1; h.b2 = b2; h.omb1 = 1.0f - b1; h.omb2 = 1.0f - b2; h.eps = eps; h.gscale = grad_scale;
     h.nesterov = nesterov;
     hipStream_t st = (hipStream_t)stream;
-    k_dense_adam4_l2<<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, l2_scaled, partial);
-    if (sumsq) k_sumsq_finish<<<1, 64, 0, st>>>(partial, (int)gr, sumsq, sumsq_accumulate);
+    k_dense_adam4_l2<<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, l2_scaled, partial, (int)(n % 4));
+    if (sumsq) k_sumsq_finish<<<1, 256, 0, st>>>(partial, (int)gr, sumsq, sumsq_accumulate);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }

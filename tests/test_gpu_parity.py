@@ -530,6 +530,25 @@ def test_dense_adam_bf16_grad_and_shadow(dev, oracle):
 
 
 
+def test_dense_adam_with_l2_term_any_length(dev, oracle):
+    """nn.Adam over a whole table with the loss's L2 term inside the kernel (sparse=False; DeepFM): bit-exact against the restatement,
+    sum(p^2) of the old values in float64 -- also for lengths that are not a multiple of 4 (DeepFM's [184 965, 1] linear table)."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(11)
+    for n in (3, 4096, 184965, 100003):
+        p = rng.standard_normal(n).astype(np.float32) * 0.01
+        g = rng.standard_normal(n).astype(np.float32) * 30
+        m = (rng.standard_normal(n) * 0.1).astype(np.float32); v = (rng.random(n) * 0.01).astype(np.float32)
+        tp, tm, tv = T(p, dev), T(m, dev), T(v, dev)
+        ss = torch.full((1,), 7.0, dtype=torch.float64, device=dev)
+        ops.dense_adam_l2_(tp, tm, tv, T(g, dev), 8e-5 * 1024, sumsq=ss, accumulate=True, grad_scale=1 / 1024)
+        want = 7.0 + float((p.astype(np.float64) ** 2).sum())
+        gg = (g + (p * np.float32(8e-5 * 1024)).astype(np.float32)).astype(np.float32)
+        oracle.dense_adam(p, m, v, gg, grad_scale=1 / 1024)
+        assert np.array_equal(tp.cpu().numpy(), p) and np.array_equal(tm.cpu().numpy(), m) and np.array_equal(tv.cpu().numpy(), v), n
+        assert abs(float(ss) - want) <= 1e-12 * want, n
+
+
 @pytest.mark.parametrize("B,K5", [(16384, 128), (1000, 64), (77, 8), (4096, 512)])
 def test_head_fwd_bwd(dev, oracle, B, K5):
     from mindrec_amd import ops

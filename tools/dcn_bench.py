@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mindrec_amd.deep_cross import DeepCrossConfig, DeepCrossEngine  # noqa: E402
 
 dev = torch.device("cuda:0")
-cfg = DeepCrossConfig()
+cfg = DeepCrossConfig(fp32_matmul=sys.argv[2] if len(sys.argv) > 2 else "x3")      # argv: [steps [x3 | exact]]
 eng = DeepCrossEngine(cfg, dev)
 B, F = cfg.batch_size, cfg.field_size
 g = torch.Generator(device=dev).manual_seed(1000)

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mindrec_amd.deepfm import DeepFMConfig, DeepFMEngine  # noqa: E402
 
 dev = torch.device("cuda:0")
-for dt in (sys.argv[1:] or ("fp16", "bf16", "fp32")):     # fp16: the reference's convert_dtype (hand-written MFMA net); fp32: library GEMMs through torch
+for dt in (sys.argv[1:] or ("fp16", "bf16", "fp32")):     # fp16: the reference's convert_dtype (hand-written MFMA net); fp32: the fp32 kernels (three-part bf16 operands, or the fp32-input matrix instruction)
     cfg = DeepFMConfig(mlp_dtype=dt)
     eng = DeepFMEngine(cfg, dev)
     B, F = cfg.batch_size, cfg.data_field_size
@@ -28,5 +28,5 @@ for dt in (sys.argv[1:] or ("fp16", "bf16", "fp32")):     # fp16: the reference'
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 20
-    print(f"DeepFM step (MLP {dt}, {'hand-written MFMA net' if eng._mfma else ('hand-written exact-fp32 MFMA net' if getattr(eng, '_f32net', False) else 'torch / library GEMMs')}): {ms:.3f} ms = {B / ms * 1e3 / 1e6:.2f} M samples/s   loss {float(loss):.5f}")
+    print(f"DeepFM step (MLP {dt}, {'hand-written MFMA net' if eng._mfma else (f'hand-written fp32 net, MatMuls: {cfg.fp32_matmul}' if getattr(eng, '_f32net', False) else 'torch / library GEMMs')}): {ms:.3f} ms = {B / ms * 1e3 / 1e6:.2f} M samples/s   loss {float(loss):.5f}")
     del eng

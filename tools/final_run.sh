@@ -18,7 +18,7 @@ python3 $R/bench.py --dropout --no-cpu-baseline --no-zipf39 > $O/bench_line_drop
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-zipf39 > $O/bench_line_under_rocprof.json 2> $O/prof.err
 cp $(find $O/prof -name "*kernel_stats.csv") $O/bench_kernel_stats.csv
 python3 $R/tools/prof_summary.py $O/bench_kernel_stats.csv > $O/bench_kernel_summary.txt
-python3 $R/tools/step_timeline.py $O/prof > $O/step_timeline_under_rocprof.txt 2>&1 || true
+python3 $R/tools/step_timeline.py $O/prof > $O/step_timeline_under_rocprof.txt 2>&1
 echo "prof done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 6 --warmup 2 --repeats 1 --prime-steps 0 --no-cpu-baseline --no-zipf39 > $O/pmc_bench_line.json 2> $O/pmc1.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 6 --warmup 2 --repeats 1 --prime-steps 0 --no-cpu-baseline --no-zipf39 > /dev/null 2> $O/pmc2.err
@@ -44,12 +44,15 @@ fi
 if [ "$PART" = 3 ]; then
 cd $R
 python tools/paths_bench.py > $O/paths_bench.txt 2>/dev/null
-python tools/dcn_bench.py > $O/dcn_bench.txt 2>/dev/null
-for dt in fp16 bf16 fp32; do python tools/deepfm_bench.py $dt 2>/dev/null | tail -1; done > $O/deepfm_bench.txt || true      # (a process per dtype: a second engine in one process runs slower)
+python tools/dcn_bench.py 50 x3 2>/dev/null | grep "DCN step" > $O/dcn_bench.txt
+python tools/dcn_bench.py 50 exact 2>/dev/null >> $O/dcn_bench.txt
+python tools/probes/x3_bench.py 2>/dev/null | grep "^M" > $O/x3_gemm_bench.txt
+python tools/published_config_bench.py 2>/dev/null | tail -1 > $O/published_config_line.json
+for dt in fp16 bf16 fp32; do python tools/deepfm_bench.py $dt 2>/dev/null | tail -1; done > $O/deepfm_bench.txt      # (a process per dtype: a second engine in one process runs slower)
 cat $O/paths_bench.txt $O/dcn_bench.txt $O/deepfm_bench.txt
-timeout -k 10 200 ./tools/probes/dense_gemm_test > $O/dense_gemm_probe.txt 2>&1 || true
-timeout -k 10 200 python tools/probes/tail_probe.py 2>/dev/null > $O/tail_probe.txt || true
-timeout -k 10 300 python tools/cache_bench.py > $O/cache_bench.txt 2>/dev/null || true
+if [ -x ./tools/probes/dense_gemm_test ]; then timeout -k 10 200 ./tools/probes/dense_gemm_test > $O/dense_gemm_probe.txt 2>&1; fi
+timeout -k 10 200 python tools/probes/tail_probe.py 2>/dev/null > $O/tail_probe.txt
+timeout -k 10 300 python tools/cache_bench.py > $O/cache_bench.txt 2>/dev/null
 tail -5 $O/cache_bench.txt
 python bench.py --no-cpu-baseline --no-zipf39 --mlp-dtype fp32 2>/dev/null | tail -1 > $O/bench_line_fp32net.json      # the fp32-net option (exact-fp32 MFMA DenseLayers)
 bash tools/probes/run_cross_trace.sh gpurun_out/final/cross_trace

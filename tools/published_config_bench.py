@@ -40,7 +40,7 @@ def run(sparse, steps=30, warm=8):
 
 if __name__ == "__main__":
     line = {"what": "reference's published Wide&Deep benchmark configuration (benchmarks/wide_deep/default_config.yaml), 1 x MI355X, synthetic "
-                    "Criteo-like ids (Zipf + the 13 constant dense-field ids), fp32 net with Dropout, exact-fp32 MFMA DenseLayers",
+                    "Criteo-like ids (Zipf + the 13 constant dense-field ids), fp32 net with Dropout, fp32 DenseLayers on three-part bf16 operands (ops.x3_*)",
             "published_reference": {"samples_per_s": 267558, "hardware": "1 x Tesla V100-SXM2-16GB, MindSpore 1.8 (benchmarks/README.md:4-26,76-78)"},
             "sparse_false_as_published": run(False), "sparse_true": run(True)}
     line["ratio_vs_published_v100"] = round(line["sparse_false_as_published"]["samples_per_s"] / 267558, 2)
