@@ -28,4 +28,8 @@ def lowered(cell, batch=None):
                 raise RuntimeError(f"lowering of {type(cell).__name__} failed its verification after the parameters were "
                                    f"re-bound: {e}") from e
         d["_lowered"] = low or False
+        if not low:
+            from . import log
+            log.info("GRAPH_MODE: %s stays on the primitive-by-primitive path: %s", type(cell).__name__,
+                     d.get("_lowering_refused", "not lowered"))
     return low or None

@@ -122,6 +122,15 @@ class Model:
             network.set_train(is_train)
         return network
 
+    def close(self):
+        """Releases what a lowered train step holds on the device (captured steps of a sharded engine hold RCCL kernels: call this
+        before destroy_process_group()).  The cells keep their parameters; a later call lowers again."""
+        for net in (self._train_network, self._network):
+            low = getattr(net, "__dict__", {}).get("_lowered")
+            if low:
+                eng = low.engine
+                getattr(eng, "close", getattr(eng, "release_graphs", lambda: None))()
+
     @staticmethod
     def _lowered(network, batch=None):
         """GRAPH_MODE's compile step (mindspore/_lower.py): the fused engine behind a recognised train cell, or None."""

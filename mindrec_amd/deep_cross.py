@@ -223,6 +223,10 @@ class DeepCrossEngine:
         k.dense_adam_slabs_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, slabs, **kw)
         return loss.view(())
 
+    def close(self):
+        """Drops the captured step (nothing of it outlives the engine; symmetrical with WideDeepEngine.close)."""
+        self._graph = None
+
     def _train_step_native(self, ids, wts, label):
         if self._state is None:
             self._state = self.k.StepState(self.device)
