@@ -448,7 +448,8 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         emb, wide, route = self.lookup(ids, wts, defer_wide=late)
         if fork_ev is not None:
             # (forking it behind the output head instead -- beside the backward GEMMs -- was measured: 0.786 vs 0.764 ms;
-            # forking it behind the gather -- which then runs alone -- 0.7576 vs 0.7591 ms: the plan's kernels and whatever
+            # forking it behind the gather -- which then runs alone: 0.7576 vs 0.7591 ms in round 2; round 4, five A/B pairs on one box: the
+            # lookup 47 -> 41 us but the step 0.628-0.629 -> 0.632-0.638 ms -- the plan's kernels and whatever
             # they run beside stretch each other by about the same amount wherever the plan sits (behind the first GEMM: 0.774);
             # the chain cut in two -- the insert kernel here, the rest behind the first GEMM through a second event -- 0.853 ms:
             # another cross-branch dependency, and the graph runtime serialises more than the dependencies ask for)
