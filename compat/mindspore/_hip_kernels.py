@@ -131,12 +131,12 @@ class MapStore:
 
     def export_slots(self):
         k, r = self.m.index.export()
-        return {n: ops.gather_rows(t["table"], r).cpu().numpy() for n, t in self.m.slots.items()}
+        return {n: v.cpu().numpy() for n, v in self.m.slot_rows(r).items()}
 
     def import_slots(self, keys, slots):
         _, _, rows = self.m.lookup_rows(keys.reshape(-1), insert=True, train=False)
         for n, vals in slots.items():
-            ops.scatter_rows_(self.m.add_slot(n, 0.0), rows, vals.to(torch.float32))
+            self.m.import_slot(n, rows, vals)
 
     def _plan(self, keys):
         m = self.m

@@ -214,7 +214,28 @@ class MapParameter:
         if name not in self.slots:
             t = torch.full((self.capacity, self.value_shape[0]), float(init), dtype=torch.float32, device=self.device)
             self.slots[name] = {"table": t, "init": float(init)}
+            pend = self.__dict__.setdefault("_pending_slots", {}).pop(name, None)
+            if pend is not None:                   # restored before the optimizer had created the slot (see import_slot)
+                ops.scatter_rows_(t, pend[0], pend[1])
         return self.slots[name]["table"]
+
+    def import_slot(self, name, rows, vals):
+        """Restores rows of an optimizer slot.  A slot the optimizer has not created yet is NOT created here -- only the optimizer
+        knows what an untouched row holds (FTRL's accumulator starts at initial_accum, not 0) -- its rows wait until add_slot."""
+        vals = vals.to(self.device, torch.float32).reshape(rows.numel(), self.value_shape[0])
+        if name in self.slots:
+            ops.scatter_rows_(self.slots[name]["table"], rows, vals)
+        else:
+            self.__dict__.setdefault("_pending_slots", {})[name] = (rows.clone(), vals.clone())
+
+    def slot_rows(self, rows):
+        """{slot name: its values at `rows`}, restored-but-not-yet-created slots included."""
+        out = {n: ops.gather_rows(t["table"], rows) for n, t in self.slots.items()}
+        for n, (r, v) in self.__dict__.get("_pending_slots", {}).items():
+            t = torch.zeros((self.capacity, self.value_shape[0]), dtype=torch.float32, device=self.device)
+            ops.scatter_rows_(t, r, v)
+            out[n] = ops.gather_rows(t, rows)
+        return out
 
     # ---- eviction (README.md:182-183: thresholds in training steps) -----------------------------
     def evict(self):

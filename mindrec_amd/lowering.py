@@ -17,6 +17,7 @@ an evaluation network over the same model, checkpoints and `asnumpy()` see what 
 import numpy as np
 import torch
 
+from . import ops
 from .wide_deep_mlp import UnsupportedNet
 
 
@@ -139,6 +140,107 @@ def lower_train_step(cell, first_batch=None):
     return low
 
 
+class _EngineMapStore:
+    """What stands behind a `MapParameter` once its model is lowered: the table is one of the engine's two row tables and its key
+    index is the engine's -- ONE index for both tables, as both are looked up with the same ids (wide_and_deep.py:300-302).  Reads,
+    inserts by lookup, puts, exports and the optimizer slots' export work on engine memory; what would let the two tables' key
+    sets drift apart (erase, evict, clear on ONE of them) is refused -- the cell then needs its own two indexes back, i.e. the
+    primitive-by-primitive path."""
+
+    def __init__(self, eng, which, sigma, seed, key_dtype):
+        self.eng, self.which, self.sigma, self.seed, self.key_dtype = eng, which, sigma, int(seed), key_dtype
+        self._winner = None
+
+    def _table(self):
+        return self.eng.deep if self.which == "deep" else self.eng.wide
+
+    def _slots(self):
+        e = self.eng
+        return ({"moment1": e.deep_m, "moment2": e.deep_v} if self.which == "deep" else {"accum": e.wide_accum, "linear": e.wide_linear})
+
+    def _refuse(self, what):
+        raise NotImplementedError(f"MapParameter.{what} on a table of a lowered (GRAPH_MODE) model: both tables share the engine's one "
+                                  f"key index; run the model in PYNATIVE_MODE, or {what} before the first training step")
+
+    def get(self, keys, insert):
+        e = self.eng
+        rows = e.index.lookup(keys, insert=bool(insert), tables=e._map_tables() if insert else ())
+        out = ops.gather_rows(self._table(), rows)
+        if not insert:
+            e.index.fill_missing(keys, rows, out, self.sigma, None, self.seed)
+        return out
+
+    def put(self, keys, vals):
+        e = self.eng
+        rows = e.index.lookup(keys, insert=True, tables=e._map_tables())
+        if self._winner is None:
+            self._winner = torch.full((e.index.capacity,), -1, dtype=torch.int32, device=e.device)
+        ops.put_rows_last_(self._table(), rows, vals, self._winner)
+
+    def size(self):
+        return len(self.eng.index)
+
+    def export(self):
+        k, r = self.eng.index.export()
+        return k.to(self.key_dtype), ops.gather_rows(self._table(), r)
+
+    def export_data(self, incremental):
+        if incremental:
+            self._refuse("export_data(incremental=True)")
+        k, v = self.export()
+        return k, v, torch.zeros(k.numel(), dtype=torch.int32, device=k.device)
+
+    def import_data(self, data):
+        if len(data) > 2 and data[2] is not None and bool((data[2] == 2).any()):
+            self._refuse("import_data with erased keys")
+        if data[0].numel():
+            self.put(data[0].to(self.eng.device).reshape(-1), data[1].to(self.eng.device, torch.float32).reshape(data[0].numel(), -1))
+
+    def export_slots(self):
+        _, r = self.eng.index.export()
+        return {n: ops.gather_rows(t, r).cpu().numpy() for n, t in self._slots().items()}
+
+    def import_slots(self, keys, slots):
+        e = self.eng
+        rows = e.index.lookup(keys.reshape(-1).to(e.device), insert=True, tables=e._map_tables())
+        mine = self._slots()
+        for n, vals in slots.items():
+            if n not in mine:
+                raise KeyError(f"slot {n!r} does not belong to the {self.which} table's optimizer")
+            ops.scatter_rows_(mine[n], rows, vals.to(e.device, torch.float32))
+
+    def erase(self, keys):
+        if keys.numel():
+            self._refuse("erase")
+
+    def evict(self):
+        self._refuse("evict")
+
+    def clear(self):
+        if len(self.eng.index):
+            self._refuse("clear")
+
+    def apply_lazy_adam(self, *a, **k):
+        self._refuse("optimizer apply outside the lowered step")
+
+    apply_ftrl = apply_lazy_adam
+
+
+def _hash_spec(mp):
+    """(sigma, seed, key dtype, capacity) of a MapParameter the engine's hash mode can stand in for, or a refusal."""
+    from mindspore.experimental import MAX_SIZE          # (the compat package: this path only runs under it)
+    st = getattr(mp._store, "m", None)
+    if st is None or not hasattr(st, "index"):
+        raise LoweringRefused("the MapParameter's store is not the HIP one")
+    if mp.default_value != "normal" or st._fill is not None:
+        raise LoweringRefused("hash tables are lowered with default_value='normal' only")
+    if int(mp.permit_filter_value) != 1 or int(mp.evict_filter_value) != MAX_SIZE:
+        raise LoweringRefused("hash tables with admission / eviction filters are not lowered")
+    if mp.key_dtype not in (torch.int32, torch.int64):
+        raise LoweringRefused("hash tables are lowered with int32 / int64 keys")
+    return float(st._sigma), int(st.seed), mp.key_dtype, int(st.capacity)
+
+
 # ---- Wide&Deep -------------------------------------------------------------------------------------------------------------------
 def _lower_wide_deep(cell):
     from .wide_deep import WideDeepConfig, WideDeepEngine
@@ -163,10 +265,17 @@ def _lower_wide_deep(cell):
     (deep_t, deep_kind), (wide_t, wide_kind) = _lookup_table(deep_l[0]), _lookup_table(wide_l[0])
     if deep_kind != wide_kind:
         raise LoweringRefused("the two tables are looked up differently")
-    if deep_kind == "hash":
-        raise LoweringRefused("hash-table (dynamic_embedding) models run eagerly: MapParameter storage is not re-bound yet "
-                              "(use mindrec_amd.wide_deep.WideDeepEngine(dynamic_embedding=True) directly)")
-    V, D = int(deep_t.shape[0]), int(deep_t.shape[1])
+    hashed = deep_kind == "hash"
+    if hashed:
+        (sig_d, seed_d, kd, cap_d), (sig_w, seed_w, kw_, cap_w) = _hash_spec(deep_t), _hash_spec(wide_t)
+        if sig_d != sig_w or seed_w != seed_d + 1 or kd != kw_:
+            raise LoweringRefused("the two hash tables' default-value streams / key types are not the engine's (same sigma, "
+                                  "consecutive seeds, one key dtype)")
+        if deep_t.value_shape[1:] or wide_t.value_shape != (1,):
+            raise LoweringRefused("hash tables are lowered with value_shape (D,) and (1,)")
+        V, D = max(cap_d, cap_w), int(deep_t.value_shape[0])
+    else:
+        V, D = int(deep_t.shape[0]), int(deep_t.shape[1])
     B, F = int(getattr(owner, "batch_size", 0) or getattr(owner, "B", 0)), int(getattr(owner, "field_size", 0) or getattr(owner, "F", 0))
     if B <= 0 or F <= 0:
         raise LoweringRefused("the model does not state batch_size / field_size")
@@ -183,6 +292,8 @@ def _lower_wide_deep(cell):
     if not any(p is wide_t for p in ftrl.parameters) or not any(p is deep_t for p in adam.parameters):
         raise LoweringRefused("unexpected parameter split: the wide table must belong to FTRL, the deep table to (Lazy)Adam")
     lazy = type(adam).__name__ == "LazyAdam"
+    if hashed:
+        deep_kind = "sparse"                   # MapTensorGet's gradient is a row gradient by construction
     if deep_kind == "sparse" and not lazy:
         raise LoweringRefused("sparse lookups under a non-lazy Adam (RowTensor gradients densified every step) have no engine mode")
     if deep_kind == "dense" and lazy:
@@ -203,10 +314,11 @@ def _lower_wide_deep(cell):
                          sens=float(adam.loss_scale), adam_lr=adam.get_lr(), adam_eps=float(adam.eps), ftrl_lr=ftrl.get_lr(), ftrl_l1=ftrl.l1,
                          ftrl_l2=ftrl.l2, ftrl_initial_accum=ftrl.initial_accum, mlp_dtype="fp16" if half else "fp32",
                          sparse=deep_kind == "sparse", l2_coef=l2 if not no_l2 else 0.0, dropout_flag=drop, dropout_keep_prob=keep,
-                         id_dtype="int32", wide_b_optimizer="ftrl" if in_ftrl else "adam")
+                         id_dtype="int64" if hashed and kd == torch.int64 else "int32", wide_b_optimizer="ftrl" if in_ftrl else "adam",
+                         **(dict(dynamic_embedding=True, hash_capacity=V, init_sigma=sig_d, seed=seed_d) if hashed else {}))
     if not cfg.sparse and no_l2:
         cfg.l2_coef = 0.0
-    dev = deep_t.device
+    dev = torch.device(deep_t.device)
     if dev.type != "cuda":
         raise LoweringRefused("parameters are not on an MI355X")
     if abs(float(adam.beta1) - 0.9) > 1e-6 or abs(float(adam.beta2) - 0.999) > 1e-6:
@@ -214,8 +326,11 @@ def _lower_wide_deep(cell):
     eng = WideDeepEngine(cfg, dev)
     # parameters and optimizer state move into the engine, then the cell's Parameters are re-bound as views of engine memory
     with torch.no_grad():
-        eng.deep.copy_(_raw(deep_t))
-        eng.wide.copy_(_raw(wide_t))
+        if hashed:
+            _move_hash_tables(eng, deep_t, wide_t)
+        else:
+            eng.deep.copy_(_raw(deep_t))
+            eng.wide.copy_(_raw(wide_t))
         eng.load_dense_parameters([_raw(l.weight) for l in layers], [_raw(l.bias) for l in layers], extra=_raw(wide_b))
         st = adam.__dict__.get("_state", {})
         for (prefix, pid), s in st.items():
@@ -242,13 +357,18 @@ def _lower_wide_deep(cell):
                 _rebind(s, tgt.view(s.shape))
     eng.beta1_power, eng.beta2_power = np.float32(adam.beta1_power), np.float32(adam.beta2_power)
     eng.step_count = int(adam.global_step)
-    _rebind(deep_t, eng.deep)
-    _rebind(wide_t, eng.wide)
+    if hashed:
+        deep_t._store = _EngineMapStore(eng, "deep", sig_d, seed_d, kd)
+        wide_t._store = _EngineMapStore(eng, "wide", sig_w, seed_w, kd)
+    else:
+        _rebind(deep_t, eng.deep)
+        _rebind(wide_t, eng.wide)
     for i, l in enumerate(layers):
         _rebind(l.weight, eng.dense[2 * i])
         _rebind(l.bias, eng.dense[2 * i + 1])
     _rebind(wide_b, eng.wide_b.view(wide_b.shape))
-    cls = type(deep_t).__mro__[1] if type(deep_t).__name__ == "Parameter" else type(deep_t)
+    ref_t = layers[0].weight
+    cls = type(ref_t).__mro__[1] if type(ref_t).__name__ == "Parameter" else type(ref_t)
 
     def deep_loss(loss):
         if cfg.sparse or cfg.l2_coef == 0.0:
@@ -258,6 +378,31 @@ def _lower_wide_deep(cell):
     low = LoweredStep(eng, cls, 2, deep_loss, optimizers=(adam, ftrl))
     low.kind, low.verify = "wide_deep", lambda ids, wts: _verify_logits(eng, owner, ids, wts, half)
     return low
+
+
+def _move_hash_tables(eng, deep_mp, wide_mp):
+    """Keys, rows and optimizer slots of the cell's two MapParameters into the engine's one key index and its row tables."""
+    kd, vd = deep_mp._store.export()
+    kw, vw = wide_mp._store.export()
+    if kd.numel() != kw.numel():
+        raise LoweringRefused("the two hash tables hold different key sets")
+    if kd.numel() == 0:
+        return
+    od, ow = torch.argsort(kd), torch.argsort(kw)
+    if not torch.equal(kd[od], kw[ow]):
+        raise LoweringRefused("the two hash tables hold different key sets")
+    sd = {n: torch.from_numpy(v).to(eng.device) for n, v in deep_mp._store.export_slots().items()}
+    sw = {n: torch.from_numpy(v).to(eng.device) for n, v in wide_mp._store.export_slots().items()}
+    rows = eng.index.lookup(kd.contiguous(), insert=True, tables=eng._map_tables())          # the deep table's row order
+    w_of_d = ow[torch.searchsorted(kw[ow], kd)]                                               # wide export position of each deep key
+    ops.scatter_rows_(eng.deep, rows, vd.to(torch.float32))
+    ops.scatter_rows_(eng.wide, rows, vw[w_of_d].to(torch.float32).reshape(-1, 1))
+    for n, tgt in (("moment1", eng.deep_m), ("moment2", eng.deep_v)):
+        if n in sd:
+            ops.scatter_rows_(tgt, rows, sd[n].to(torch.float32))
+    for n, tgt in (("accum", eng.wide_accum), ("linear", eng.wide_linear)):
+        if n in sw:
+            ops.scatter_rows_(tgt, rows, sw[n][w_of_d].to(torch.float32).reshape(-1, 1))
 
 
 def _off(eng, k):

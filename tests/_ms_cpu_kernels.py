@@ -129,17 +129,29 @@ class MapStore:
     def _slot(self, name, init):
         if name not in self.slots:
             self.slots[name] = np.full((self.capacity, self.D), np.float32(init), np.float32)
+            pend = self.__dict__.setdefault("_pending", {}).pop(name, None)
+            if pend is not None:                   # restored before the optimizer created the slot: only it knows the untouched rows' value
+                self.slots[name][pend[0]] = pend[1]
         return self.slots[name]
 
     def export_slots(self):
         k, _ = self.map.export()
         rows = self.map.find_or_insert(k, False)
-        return {n: t[rows].copy() for n, t in self.slots.items()}
+        out = {n: t[rows].copy() for n, t in self.slots.items()}
+        for n, (r, v) in self.__dict__.get("_pending", {}).items():
+            t = np.zeros((self.capacity, self.D), np.float32)
+            t[r] = v
+            out[n] = t[rows].copy()
+        return out
 
     def import_slots(self, keys, slots):
         rows = self.map.find_or_insert(_np(keys).astype(np.int64), True)
         for n, vals in slots.items():
-            self._slot(n, 0.0)[rows] = _np(vals)
+            v = _np(vals).astype(np.float32).reshape(len(rows), self.D)
+            if n in self.slots:
+                self.slots[n][rows] = v
+            else:
+                self.__dict__.setdefault("_pending", {})[n] = (rows.copy(), v.copy())
 
     def _rows(self, keys):
         """Row numbers for an apply: one training step of the table; rows of keys not yet admitted -> -1 (skipped)."""

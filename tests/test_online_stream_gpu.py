@@ -42,20 +42,32 @@ class Stream:
         return 2 ** 20 - 1
 
 
-def _build(ms):
+def _build(ms, dynamic=False):
     import _ms_models
     ms.set_seed(1000)
-    net = _ms_models.WideDeep(V, D, F, B, [32, 16, 16, 8], sparse=True, dynamic=False)
+    net = _ms_models.WideDeep(V, D, F, B, [32, 16, 16, 8], sparse=True, dynamic=dynamic)
     step = _ms_models.WideDeepTrainStep(_ms_models.WideDeepLoss(net, 8e-5, with_l2=False), lazy=True)
     step.set_train()
     return step, net
 
 
+def _table_state(t):
+    """A table's contents in a comparable form: the tensor, or (keys, rows) of a MapParameter sorted by key."""
+    if isinstance(t, torch.Tensor):
+        return [t.as_subclass(torch.Tensor)]
+    k, v = t.get_data()
+    k, v = k.as_subclass(torch.Tensor), v.as_subclass(torch.Tensor)
+    o = torch.argsort(k)
+    return [k[o], v[o]]
+
+
+@pytest.mark.parametrize("dynamic", [False, True])
 @pytest.mark.parametrize("mode", ["pynative", "graph"])
-def test_online_train_on_a_stream_with_periodic_checkpoints(dev, tmp_path, mode):
+def test_online_train_on_a_stream_with_periodic_checkpoints(dev, tmp_path, mode, dynamic):
     """mode "pynative": every step runs primitive by primitive on the HIP kernel set; "graph": the train cell is lowered to the
     fused engine (mindrec_amd/lowering.py) -- checkpoints are then read out of, and restored into, engine memory through the
-    cell's re-bound Parameters."""
+    cell's re-bound Parameters.  dynamic: both tables are HashEmbeddingLookups over MapParameters (the reference's
+    --dynamic_embedding, wide_and_deep.py:271-274); lowered, the two maps stand on the engine's one key index."""
     compat = os.path.abspath(os.path.join(HERE, "..", "compat"))
     if compat not in sys.path:
         sys.path.insert(0, compat)
@@ -79,7 +91,7 @@ def test_online_train_on_a_stream_with_periodic_checkpoints(dev, tmp_path, mode)
                     run_context.request_stop()
 
         # run A: 250 steps off the stream, a checkpoint every 100
-        step, net = _build(ms)
+        step, net = _build(ms, dynamic)
         data = ds.GeneratorDataset(Stream(), column_names=["id", "weight", "label"]).batch(B)
         assert data.get_dataset_size() == (2 ** 20 - 1 + B - 1) // B
         watch = Watch(250)
@@ -91,7 +103,7 @@ def test_online_train_on_a_stream_with_periodic_checkpoints(dev, tmp_path, mode)
         ck200 = [f for f in files if f != os.path.basename(ck.latest_ckpt_file_name)][0]
 
         # run B: a fresh network, restored from the step-200 checkpoint, fed the stream from row 200 * B on
-        step2, net2 = _build(ms)
+        step2, net2 = _build(ms, dynamic)
         params = load_checkpoint(os.path.join(str(tmp_path), ck200))
         assert int(params["step_num"]) == 200
         missing = load_param_into_net(step2, {k: v for k, v in params.items() if k not in ("epoch_num", "step_num")})
@@ -101,10 +113,11 @@ def test_online_train_on_a_stream_with_periodic_checkpoints(dev, tmp_path, mode)
         watch2 = Watch(50)
         RecModel(step2).online_train(data2, callbacks=[watch2], dataset_sink_mode=True)
         assert watch2.losses == watch.losses[200:250]                          # bit for bit
-        assert torch.equal(net2.deep_table.embedding_table, net.deep_table.embedding_table)
-        assert torch.equal(net2.wide_table.embedding_table, net.wide_table.embedding_table)
+        for a, b in zip(_table_state(net2.deep_table.embedding_table) + _table_state(net2.wide_table.embedding_table),
+                        _table_state(net.deep_table.embedding_table) + _table_state(net.wide_table.embedding_table)):
+            assert torch.equal(a, b)
         assert torch.equal(net2.layer0.weight, net.layer0.weight) and torch.equal(net2.wide_bias, net.wide_bias)
-        assert (step.__dict__.get("_lowered") not in (None, False)) == (mode == "graph")
+        assert (step.__dict__.get("_lowered") not in (None, False)) == (mode == "graph"), step.__dict__.get("_lowering_refused")
     finally:
         context.set_context(mode=context.GRAPH_MODE)
         ms._kernels._install(prev)

@@ -27,10 +27,10 @@ def test_reference_composition_record():
         assert c["weights_w"] == ["wide_b", "wide_embeddinglookup.embedding_table"]          # the wide bias belongs to FTRL
         assert (c["sens"], c["lr_d"], c["eps_d"], c["lr_w"], c["l1_w"], c["l2_w"], c["initial_accum_w"]) == (1024.0, 3.5e-4, 1e-8, 5e-2, 1e-8, 1e-8, 1.0)
     # mindrec_amd/lowering.py recognises the REFERENCE's train cells by structure (on the generator's host tensors it gets as far as
-    # the device check); the hash-table model is left to run eagerly
+    # the device check; the hash-table model as far as the check that its MapParameters are the HIP ones)
     for case in ("ref_wd_dense", "ref_wd_sparse", "ref_wd_mixed", "ref_dcn"):
         assert rep[case]["lowering_on_cpu"] == "parameters are not on an MI355X", (case, rep[case]["lowering_on_cpu"])
-    assert rep["ref_wd_dynamic"]["lowering_on_cpu"].startswith("hash-table (dynamic_embedding) models run eagerly")
+    assert rep["ref_wd_dynamic"]["lowering_on_cpu"] == "the MapParameter's store is not the HIP one"
     assert rep["ref_wd_dense"]["no_l2loss"] is False and rep["ref_wd_sparse"]["no_l2loss"] is True
     assert (rep["ref_dcn"]["optimizer"], rep["ref_dcn"]["lr"], rep["ref_dcn"]["loss_scale"]) == ("Adam", 1e-4, 1000.0)
 
@@ -147,3 +147,36 @@ def test_mindspore_style_script_matches_reference(ms_cpu, case):
         assert RF.row_rel(v.asnumpy()[order], z["final/embedding_table::values"]) <= 1e-5
     else:
         assert RF.row_rel(net.deep_table.embedding_table.asnumpy(), z["final/embedding_table"]) <= 1e-5
+
+
+def test_hash_table_checkpoint_restores_before_the_optimizer_has_run(ms_cpu, tmp_path):
+    """A fresh network restored from a checkpoint holds optimizer slots the optimizer has not created yet.  Rows of keys first seen
+    AFTER the restore must still start from the optimizer's own initial values (FTRL's accumulator: initial_accum, not 0): six
+    steps straight == three steps, save, restore into a fresh network, three steps -- on keys that keep arriving."""
+    import _ms_models
+    from mindspore.train.serialization import load_checkpoint, load_param_into_net, save_checkpoint
+    Bq, Fq, Dq = 16, 5, 4
+
+    def build():
+        ms_cpu.set_seed(1000)
+        net = _ms_models.WideDeep(10_000, Dq, Fq, Bq, [8, 4], sparse=True, dynamic=True, capacity=1024)
+        step = _ms_models.WideDeepTrainStep(_ms_models.WideDeepLoss(net, 8e-5, with_l2=False), lazy=True)
+        step.set_train()
+        return step, net
+
+    def batch(t):
+        rng = np.random.default_rng(500 + t)
+        ids = (rng.integers(0, 40, size=(Bq, Fq)) + 25 * t).astype(np.int32)          # the key range moves: new keys every step
+        return (ms_cpu.Tensor(ids), ms_cpu.Tensor(rng.random((Bq, Fq)).astype(np.float32)),
+                ms_cpu.Tensor((rng.random((Bq, 1)) < 0.3).astype(np.float32)))
+
+    a, _ = build()
+    straight = [float(a(*batch(t))[0].asnumpy()) for t in range(6)]
+    b, _ = build()
+    first = [float(b(*batch(t))[0].asnumpy()) for t in range(3)]
+    ck = str(tmp_path / "half.ckpt")
+    save_checkpoint(b, ck)
+    c, _ = build()
+    assert load_param_into_net(c, load_checkpoint(ck)) == []
+    rest = [float(c(*batch(t))[0].asnumpy()) for t in range(3, 6)]
+    assert first + rest == straight

@@ -209,6 +209,41 @@ def test_lowered_wide_deep_script_matches_reference(ms_hip, case):
     assert np.allclose(logits.asnumpy().reshape(-1), z["eval_logits"].reshape(-1), rtol=2e-2 if mixed else 1e-4, atol=1e-4 if mixed else 1e-6)
 
 
+def test_lowered_hash_table_script_matches_reference(ms_hip):
+    """The reference's --dynamic_embedding model (two HashEmbeddingLookups over MapParameters, wide_and_deep.py:271-274) lowered: the
+    cell's two MapParameters stand on the engine's ONE key index and its row tables; losses, key set and rows are the reference's,
+    read back through the cell's own MapParameters; an evaluation pass through the model cell reads the same memory."""
+    import _ms_models
+    from mindrec_amd.lowering import LoweredStep
+    z, cfg, comp = RF.load("ref_wd_dynamic")
+    ms_hip.set_seed(1000)
+    from mindspore.common import initializer as I
+    I._state["calls"] = int(z["deep_seed"]) - (1000 * 1_000_003) - 1
+    step, net = _ms_models.wide_deep_from_fixture(z, cfg, comp, capacity=4096)
+    model = ms_hip.Model(step)
+    losses = []
+    for s in range(z["ids"].shape[0]):
+        lw, ld = model._run_step(step, tuple(ms_hip.Tensor(z[k][s]) for k in ("ids", "wts", "label")))
+        losses.append((float(lw.asnumpy()), float(ld.asnumpy())))
+    low = step.__dict__["_lowered"]
+    assert isinstance(low, LoweredStep) and low.kind == "wide_deep" and low.engine.index is not None, step.__dict__.get("_lowering_refused")
+    losses = np.array(losses)
+    assert np.allclose(losses[:, 0], z["loss_w"], rtol=2e-6, atol=0), (losses[:, 0], z["loss_w"])
+    assert np.allclose(losses[:, 1], z["loss_d"], rtol=2e-6, atol=0)
+    for name, mp in (("embedding_table", net.deep_table.embedding_table), ("wide_embeddinglookup.embedding_table", net.wide_table.embedding_table)):
+        k, v = mp.get_data()
+        order = np.argsort(k.asnumpy())
+        assert np.array_equal(k.asnumpy()[order], z[f"final/{name}::keys"]), name
+        assert RF.row_rel(v.asnumpy()[order], z[f"final/{name}::values"]) <= 1e-5, name
+    assert len(net.deep_table.embedding_table) == len(low.engine.index)
+    assert np.allclose(net.wide_bias.asnumpy(), z["final/wide_b"], rtol=1e-4, atol=1e-8)
+    net.set_train(False)
+    logits, _ = net(ms_hip.Tensor(z["ids"][-1]), ms_hip.Tensor(z["wts"][-1]))
+    assert np.allclose(logits.asnumpy().reshape(-1), z["eval_logits"].reshape(-1), rtol=1e-4, atol=1e-6)
+    with pytest.raises(NotImplementedError, match="share the engine's one key index"):
+        net.deep_table.embedding_table.erase(ms_hip.Tensor(z["ids"][0].reshape(-1)[:2]))
+
+
 def test_lowered_deep_cross_script_matches_reference(ms_hip):
     import _ms_models
     from mindrec_amd.lowering import LoweredStep
