@@ -1501,7 +1501,8 @@ def _up64(x):
 
 def x3_supported(M, K, N):
     """Shapes the split path takes: everything an fp32 DenseLayer of realistic size has; tiny problems stay on dense32_*."""
-    return M >= 256 and K >= 64 and N >= 64 and 3 * _up64(M) * max(_up64(K), _up64(N)) * 2 < 2 ** 31
+    return (M >= 256 and K >= 64 and N >= 64 and K % 2 == 0 and N % 2 == 0          # (rows of the fp32 operands 8-byte aligned)
+            and 3 * _up64(M) * max(_up64(K), _up64(N)) * 2 < 2 ** 31 and 3 * _up64(K) * _up64(N) * 2 < 2 ** 31)
 
 
 def x3_parts(rows, cols, device):

@@ -141,27 +141,30 @@ class ShardStepMixin:
         check of the library and comes on every rank alike, before anything is exchanged)."""
         n, me, cap = self.world, self.rank, 8
         ok = 1
+        send, recv = self._xbuf(n * cap, 2, torch.float32)
+        for r in range(n):                                   # chunk of owner r carries (me, r)
+            c = (r - me - 1) % n
+            send[c * cap:(c + 1) * cap, 0] = float(me)
+            send[c * cap:(c + 1) * cap, 1] = float(r)
         try:
-            send, recv = self._xbuf(n * cap, 2, torch.float32)
-            for r in range(n):                                   # chunk of owner r carries (me, r)
-                c = (r - me - 1) % n
-                send[c * cap:(c + 1) * cap, 0] = float(me)
-                send[c * cap:(c + 1) * cap, 1] = float(r)
             self._exchange(recv, send, to_owner=True)
+        except (TypeError, ValueError, NotImplementedError, RuntimeError) as e:
+            # A refusal AT THE CALL: the library's argument checks (per-peer lists with an empty own entry, aliased windows) run
+            # before anything is enqueued and -- same shapes, same code on every rank -- fail on every rank alike (torch raises
+            # them as TypeError / ValueError, c10d's own checks as RuntimeError), so all ranks reach the all-reduce below
+            # together.  What is NOT swallowed: anything surfacing later (the synchronize and the element checks below) -- an
+            # asynchronous RCCL or device error is local to one rank, whose peers would be inside the all-to-all while it enters
+            # an all-reduce.
+            import warnings
+            warnings.warn(f"own-chunk bypass refused by the communicator ({type(e).__name__}: {e}); using the equal-split all-to-all")
+            ok = 0
+        if ok:
             if self._gpu:
                 torch.cuda.synchronize(self.device)
             for s_ in range(n):                                  # chunk of sender s must carry (s, me)
                 c = (s_ - me) % n
                 blk = recv[c * cap:(c + 1) * cap]
                 ok &= int(bool((blk[:, 0] == float(s_)).all()) and bool((blk[:, 1] == float(me)).all()))
-        except (TypeError, ValueError, NotImplementedError) as e:
-            # an ARGUMENT refusal of the library (per-peer lists with an empty own entry): raised on every rank alike, before
-            # anything was enqueued, so all ranks reach the all-reduce below together.  Anything else -- an asynchronous RCCL or
-            # device error surfacing at the synchronize, out of memory -- is local to this rank and must not be swallowed: the
-            # peers would be inside the all-to-all while this rank enters an all-reduce.
-            import warnings
-            warnings.warn(f"own-chunk bypass refused by the communicator ({type(e).__name__}: {e}); using the equal-split all-to-all")
-            ok = 0
         flag = torch.tensor([float(ok)], device=self.device)
         self.comm.all_reduce(flag)
         return bool(flag.item() == float(n))
