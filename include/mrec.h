@@ -815,13 +815,14 @@ int mrec_x3_wgrad_slabs(int64_t M, int32_t K, int32_t N, int32_t* out);
 int mrec_x3_mask_colsum(float* acc, int64_t ld, int64_t M, int32_t K, const float* h, int64_t ldh, float scale, float* colsum,
                         uint16_t* parts_out, void* stream);
 /* the same output ends inside the GEMM's epilogue (no second pass over the layer's output):
- *   mrec_x3_gemm_fwd:   y = relu?(x . w + bias) [M, N] AND (parts_out != NULL) y's parts image
+ *   mrec_x3_gemm_fwd:   y = dropout?(relu?(x . w + bias)) [M, N] AND (parts_out != NULL) y's parts image; drop_next (nullable): the
+ *                       Dropout on the NEXT DenseLayer's input (wide_and_deep.py:117-118), as mrec_dropout would apply it to y
  *   mrec_x3_gemm_dgrad: dx = (h > 0 ? dy . w^T : 0) * scale [M, K], colsum [ceil(M / 64), K] (nullable) AND (parts_out != NULL) dx's parts
  * ws (nullable; mrec_x3_gemm_dgrad_workspace_bytes, 0 for most shapes): lets the PLAIN input gradient (no h, colsum, parts; scale 1) of a
  * width with a narrow last 256-column tile run that tile as slabs of the reduction behind one round of full tiles.
  * parts_out: the padding of the image (rows M.., columns past the width) is NOT written -- the caller zeroes the image once. */
 int mrec_x3_gemm_fwd(const uint16_t* xparts, const uint16_t* wparts, int64_t M, int32_t K, int32_t N, float* y, int64_t ldy,
-                     const float* bias, int relu, uint16_t* parts_out, void* stream);
+                     const float* bias, int relu, const mrec_dropout_t* drop_next, uint16_t* parts_out, void* stream);
 int mrec_x3_gemm_dgrad_workspace_bytes(int64_t M, int32_t K, int32_t N, size_t* out);
 int mrec_x3_gemm_dgrad(const uint16_t* dyparts, const uint16_t* wparts, int64_t M, int32_t K, int32_t N, float* dx, int64_t lddx,
                        const float* h, int64_t ldh, float scale, float* colsum, uint16_t* parts_out, void* ws, size_t ws_bytes, void* stream);

@@ -98,7 +98,7 @@ _SIGS = {
     "mrec_x3_gemm": [_int, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp],
     "mrec_x3_bias_relu": [_vp, _i64, _i64, _i32, _vp, _int, _vp, _vp],
     "mrec_x3_wgrad_slabs": [_i64, _i32, _i32, _vp],
-    "mrec_x3_gemm_fwd": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _vp],
+    "mrec_x3_gemm_fwd": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _vp, _vp],
     "mrec_x3_gemm_dgrad_workspace_bytes": [_i64, _i32, _i32, _vp],
     "mrec_x3_gemm_dgrad": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _f32, _vp, _vp, _vp, _sz, _vp],
     "mrec_x3_mask_colsum": [_vp, _i64, _i64, _i32, _vp, _i64, _f32, _vp, _vp, _vp],

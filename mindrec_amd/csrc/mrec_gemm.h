@@ -470,6 +470,8 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cs[g][ni][r] = 0.f;
         const bool v16 = (a.ldc & 3) == 0, h16 = (a.ldh & 3) == 0;
+        const bool xdrop = fwd && a.drop.thresh != 0;          // Dropout on the NEXT layer's input = this output (fp32: x * (1 / keep) or 0)
+        const uint64_t xkey = xdrop ? drop_key(a.drop) : 0ull;
 #pragma unroll
         for (int mi = 0; mi < MR; ++mi) {
             const int p = p0 + mi * 16;
@@ -495,11 +497,13 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
                 const int q = q0 + ni * 16;
                 const bool ok = pv && q < a.Qext;
                 f32x4_t v = acc[mi][ni];
+                const uint64_t qd = xdrop ? drop_quad(xkey, a.drop.row0 + p, a.Qext, q) : 0ull;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (fwd) {
                         v[r] += bq[ni][r];
                         if (a.relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
+                        if (xdrop) v[r] = drop_keep(qd, r, a.drop.thresh) ? v[r] * a.drop.scale : 0.0f;
                     } else {
                         if (Hf != nullptr && !(hv[ni][r] > 0.f)) v[r] = 0.f;
                         v[r] *= a.x3_scale;

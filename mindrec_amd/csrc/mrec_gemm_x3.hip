@@ -19,6 +19,7 @@
 #include "mrec_common.h"
 #include <cstdlib>
 #include "mrec_gemm.h"
+#include "mrec_dropout.h"
 
 namespace {
 
@@ -220,6 +221,7 @@ MREC_API int mrec_x3_mask_colsum(float* acc, int64_t ld, int64_t M, int32_t K, c
 namespace {
 struct X3Epi {                // the fused output end (EPI_X3); mode 0: plain fp32 out
     int mode; const float* bias; int relu; const float* h; int64_t ldh; float scale; float* colsum; uint16_t* parts;
+    DropArgs drop;            // mode 1: Dropout on the output (thresh 0: none)
 };
 int x3_gemm(int form, const uint16_t* Pparts, const uint16_t* Qparts, int64_t M, int32_t K, int32_t N, float* C, int64_t ldc, int32_t S,
             const X3Epi& e, void* stream);
@@ -231,9 +233,11 @@ MREC_API int mrec_x3_gemm(int form, const uint16_t* Pparts, const uint16_t* Qpar
 }
 
 MREC_API int mrec_x3_gemm_fwd(const uint16_t* xparts, const uint16_t* wparts, int64_t M, int32_t K, int32_t N, float* y, int64_t ldy,
-                              const float* bias, int relu, uint16_t* parts_out, void* stream) {
+                              const float* bias, int relu, const mrec_dropout_t* drop_next, uint16_t* parts_out, void* stream) {
     if (parts_out && !al16(parts_out)) return MREC_EUNSUPPORTED;
-    return x3_gemm(0, xparts, wparts, M, K, N, y, ldy, 1, X3Epi{1, bias, relu, nullptr, 0, 1.0f, nullptr, parts_out}, stream);
+    X3Epi e{1, bias, relu, nullptr, 0, 1.0f, nullptr, parts_out, DropArgs{}};
+    if (!drop_from(drop_next, N, &e.drop)) return MREC_EINVAL;
+    return x3_gemm(0, xparts, wparts, M, K, N, y, ldy, 1, e, stream);
 }
 
 namespace {
@@ -276,7 +280,7 @@ MREC_API int mrec_x3_gemm_dgrad(const uint16_t* dyparts, const uint16_t* wparts,
         if (d.S && al16(ws) && ws_bytes >= (size_t)d.S * M * d.ldw * sizeof(float))
             return x3_dgrad_split(dyparts, wparts, M, K, N, dx, lddx, (float*)ws, d, stream);
     }
-    return x3_gemm(1, dyparts, wparts, M, K, N, dx, lddx, 1, X3Epi{2, nullptr, 0, h, ldh, scale, colsum, parts_out}, stream);
+    return x3_gemm(1, dyparts, wparts, M, K, N, dx, lddx, 1, X3Epi{2, nullptr, 0, h, ldh, scale, colsum, parts_out, DropArgs{}}, stream);
 }
 
 namespace {
@@ -326,7 +330,7 @@ int x3_gemm(int form, const uint16_t* Pparts, const uint16_t* Qparts, int64_t M,
     if (e.mode != 0) {            // the layer's output end in the GEMM's epilogue (form 0: bias + ReLU; 1: ReLU mask, scale, bias gradient)
         if (form == 2 || (e.mode == 1) != (form == 0)) return MREC_EINVAL;
         a.x3_mode = e.mode; a.bias = e.bias; a.relu = e.relu; a.H = e.h; a.ldh = e.ldh; a.x3_scale = e.scale; a.colsum_ws = e.colsum;
-        a.parts = e.parts;
+        a.parts = e.parts; a.drop = e.drop;
         const int64_t outc = form == 0 ? N : K;
         a.parts_ld = up64(outc); a.parts_stride = Mp * up64(outc);
         if (form == 0) MREC_X3(false, true, mgemm::EPI_X3);

@@ -1559,13 +1559,14 @@ def _x3_img(parts, M, C, name):
         raise TypeError(f"{name}: parts_out must be the contiguous bfloat16 parts image [3, {_up64(M)}, {_up64(C)}]")
 
 
-def x3_fwd(xP, wP, M, K, N, out, bias=None, relu=True, parts_out=None):
-    """DenseLayer forward on parts images, output end in the GEMM's epilogue: out = relu?(x . w + bias) and, optionally, out's parts."""
+def x3_fwd(xP, wP, M, K, N, out, bias=None, relu=True, parts_out=None, drop_next=None):
+    """DenseLayer forward on parts images, output end in the GEMM's epilogue: out = relu?(x . w + bias) -- dropped out as the next
+    layer's input when drop_next (ops.Dropout) -- and, optionally, out's parts."""
     _need_cuda(xP, wP, out, bias, parts_out)
     ld = _x3_out(out, M, N, "x3_fwd")
     _x3_img(parts_out, M, N, "x3_fwd")
-    _lib.call("mrec_x3_gemm_fwd", _ptr(xP), _ptr(wP), int(M), int(K), int(N), _ptr(out), ld, _ptr(bias), int(bool(relu)), _ptr(parts_out),
-              _stream())
+    _lib.call("mrec_x3_gemm_fwd", _ptr(xP), _ptr(wP), int(M), int(K), int(N), _ptr(out), ld, _ptr(bias), int(bool(relu)),
+              _drop_ref(drop_next), _ptr(parts_out), _stream())
     return out
 
 

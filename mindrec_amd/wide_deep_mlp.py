@@ -348,13 +348,9 @@ class DenseNetMixin:
             for i in range(n - 1):
                 k.x3_split(self.dense[2 * i].detach(), out=P["w"][i])
                 nxt = P["h"][i + 1] if i + 1 < n - 1 else None
-                # bias + ReLU (and the next layer's parts) in the GEMM's epilogue; under Dropout the parts are those of the DROPPED activation
+                # bias + ReLU, the Dropout on the next layer's input and that input's parts: all in the GEMM's epilogue
                 h = k.x3_fwd(P["h"][i], P["w"][i], B, self.dims[i], self.dims[i + 1], P["act"][i], bias=self.dense[2 * i + 1].detach(),
-                             relu=True, parts_out=nxt if drops[i + 1] is None else None)
-                if drops[i + 1] is not None:
-                    k.dropout_(h, drops[i + 1])
-                    if nxt is not None:
-                        k.x3_split(h, out=nxt)
+                             relu=True, parts_out=nxt, drop_next=drops[i + 1])
                 hs.append(h)
         for i in range(0 if x3 else n - 1):
             h = k.dense32_fwd(hs[i], self.dense[2 * i].detach(), self.dense[2 * i + 1].detach(), relu=True)

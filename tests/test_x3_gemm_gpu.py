@@ -88,6 +88,14 @@ def test_x3_fused_output_ends_equal_the_two_pass_form(dev, M, K, N, scale):
     y2, p2 = torch.empty((M, N), device=dev), ops.x3_parts(M, N, dev)
     ops.x3_fwd(xp, wp, M, K, N, y2, bias=b, relu=True, parts_out=p2)
     assert torch.equal(y1, y2) and torch.equal(p1.view(torch.int16), p2.view(torch.int16))
+    # ... with the Dropout on the next layer's input in the epilogue too: == bias + ReLU, then ops.dropout_, then the split
+    if N % 4 == 0:
+        drop = ops.Dropout(0.5 if scale == 1.0 else 0.8, seed=77, layer=2, step=5, row0=1000)
+        y4, p4 = torch.empty((M, N), device=dev), ops.x3_parts(M, N, dev)
+        ops.x3_fwd(xp, wp, M, K, N, y4, bias=b, relu=True, parts_out=p4, drop_next=drop)
+        y5 = ops.dropout_(y1.clone(), drop)
+        assert torch.equal(y4, y5) and torch.equal(p4.view(torch.int16), ops.x3_split(y5).view(torch.int16))
+        assert 0.3 < float((y4 == 0).float().mean()) < 0.95
     y3 = ops.x3_fwd(xp, wp, M, K, N, torch.empty((M, N), device=dev), bias=None, relu=False)
     assert torch.equal(y3, ops.x3_gemm(0, xp, wp, M, K, N, torch.empty((M, N), device=dev)))
     # input gradient (the output's row stride is not a multiple of 4 when K = 1170)
