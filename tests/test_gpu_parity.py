@@ -754,3 +754,34 @@ def test_sum_slab_segments(dev):
             acc = acc + a[s]                                    # slab order
         assert np.array_equal(out[start:start + acc.size], acc.ravel())
     assert (out[800:1000] == -1).all() and (out[1128:2000] == -1).all() and (out[2064:] == -1).all()
+
+
+def test_committed_goldens_replay_on_the_gpu(dev):
+    """tests/golden/normal_seed1000.json and wd_step_small.npz (committed bits; tests/test_oracle.py holds the oracle to them) through
+    the HIP kernels: the table initialiser to the bit, the lookup to the bit, one LazyAdam step on the touched rows -- to the bit
+    where an id's duplicates sit inside one window of the sorted index, 1e-5 row-relative otherwise."""
+    import json
+    import os
+    from mindrec_amd import ops
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    gold = json.load(open(os.path.join(gold_dir, "normal_seed1000.json")))
+    rows = np.array(gold["rows"], np.int64)
+    t = torch.empty((int(rows.max()) + 1, gold["D"]), dtype=torch.float32, device=dev)
+    ops.fill_normal_(t, gold["seed"], gold["sigma"])
+    assert t.cpu().numpy()[rows].view(np.uint32).ravel().tolist() == gold["bits"]
+    z = np.load(os.path.join(gold_dir, "wd_step_small.npz"))
+    V, D = int(z["V"]), int(z["D"])
+    p = ops.fill_normal_(torch.empty((V, D), dtype=torch.float32, device=dev), int(z["seed"]), 0.01)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    ids, wts = T(z["ids"], dev), T(z["wts"], dev)
+    assert np.array_equal(ops.gather_rows(p, ids, wts).cpu().numpy().reshape(z["emb"].shape), z["emb"])
+    plan = ops.sparse_plan(ids)
+    ops.sparse_lazy_adam_(p, m, v, plan, T(z["g"].reshape(-1, D), dev), wts.reshape(-1), lr=3.5e-4, eps=1e-8, beta1_power=0.9,
+                          beta2_power=0.999, grad_scale=1 / 1024)
+    touched = np.unique(z["ids"])
+    got_p, got_m = p.cpu().numpy()[touched], m.cpu().numpy()[touched]
+    cross = set(plan.uniq.cpu().numpy()[crossing(plan, D)].tolist())
+    inside = np.array([r not in cross for r in touched])
+    assert np.array_equal(got_p[inside], z["p_touched"][inside]) and np.array_equal(got_m[inside], z["m_touched"][inside])
+    den = np.abs(z["p_touched"]).max(axis=1) + 1e-30
+    assert float((np.abs(got_p - z["p_touched"]).max(axis=1) / den).max()) <= 1e-5
