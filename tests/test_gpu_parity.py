@@ -766,9 +766,11 @@ def test_committed_goldens_replay_on_the_gpu(dev):
     gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     gold = json.load(open(os.path.join(gold_dir, "normal_seed1000.json")))
     rows = np.array(gold["rows"], np.int64)
-    t = torch.empty((int(rows.max()) + 1, gold["D"]), dtype=torch.float32, device=dev)
-    ops.fill_normal_(t, gold["seed"], gold["sigma"])
-    assert t.cpu().numpy()[rows].view(np.uint32).ravel().tolist() == gold["bits"]
+    got = []
+    for r in rows.tolist():                     # (the golden rows reach far past any table: one row each, keyed by its global number)
+        t = ops.fill_normal_(torch.empty((1, gold["D"]), dtype=torch.float32, device=dev), gold["seed"], gold["sigma"], row0=int(r))
+        got += t.cpu().numpy().view(np.uint32).ravel().tolist()
+    assert got == gold["bits"]
     z = np.load(os.path.join(gold_dir, "wd_step_small.npz"))
     V, D = int(z["V"]), int(z["D"])
     p = ops.fill_normal_(torch.empty((V, D), dtype=torch.float32, device=dev), int(z["seed"]), 0.01)
