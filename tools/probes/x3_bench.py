@@ -8,8 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from mindrec_amd import ops  # noqa: E402
 
 
-def t(fn, n=10):
-    for _ in range(3):
+def t(fn, n=40):
+    for _ in range(10):          # (clocks settle: a 10-call sample right behind the fp32-MFMA kernel read 339 us where rocprof shows 228)
         fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
