@@ -225,6 +225,16 @@ class Squeeze(Primitive):
         return _w(x)
 
 
+class Tile(Primitive):
+    """Tile(x, multiples): x repeated multiples[i] times along axis i (models/deepfm/src/deepfm.py:204 instantiates one)."""
+
+    def __call__(self, x, multiples):
+        m = tuple(int(v) for v in multiples)
+        if len(m) < x.dim():
+            raise ValueError(f"For 'Tile', the length of 'multiples' must be >= the rank of the input ({x.dim()}), but got {len(m)}.")
+        return _w(x.repeat(m))
+
+
 class Transpose(Primitive):
     def __call__(self, x, perm):
         return _w(x.permute(tuple(perm)))

@@ -131,12 +131,12 @@ def _raw(t):
 def lower_train_step(cell, first_batch=None):
     """-> LoweredStep, or None when the cell is not a recognised train step (the reason is left in cell._lowering_refused)."""
     try:
-        low = _lower_wide_deep(cell) or _lower_deep_cross(cell)
+        low = _lower_wide_deep(cell) or _lower_deep_cross(cell) or _lower_deepfm(cell)
     except (LoweringRefused, UnsupportedNet) as e:
         cell.__dict__["_lowering_refused"] = str(e)
         return None
     if low is None:
-        cell.__dict__["_lowering_refused"] = "not a Wide&Deep or Deep&Cross train step by structure"
+        cell.__dict__["_lowering_refused"] = "not a Wide&Deep, Deep&Cross or DeepFM train step by structure"
     return low
 
 
@@ -493,4 +493,97 @@ def _lower_deep_cross(cell):
     cls = type(table).__mro__[1] if type(table).__name__ == "Parameter" else type(table)
     low = LoweredStep(eng, cls, 1, optimizers=(adam,))
     low.kind, low.verify = "deep_cross", lambda ids, wts: _verify_logits(eng, owner, ids, wts, False)
+    return low
+
+
+# ---- DeepFM ----------------------------------------------------------------------------------------------------------------------
+def _lower_deepfm(cell):
+    """models/deepfm/src/deepfm.py: a model cell that holds its two tables as plain Parameters ([V, D] and [V, 1], looked up with
+    Gather: dense gradients), a chain of DenseLayers F * D -> ... -> 1, one nn.Adam over everything, the L2 term over both whole
+    tables in the loss cell."""
+    from .deepfm import DeepFMConfig, DeepFMEngine
+    opts = [(c, _opt_kind(c)) for c in cell.cells() if _opt_kind(c)]
+    if len(opts) != 1 or opts[0][1] != "Adam":
+        return None
+    adam = opts[0][0]
+    owner = None
+    for c in _cells(cell):
+        tabs = [q for q in c.__dict__.get("_params", {}).values() if isinstance(q, torch.Tensor) and q.dim() == 2]
+        if (len(tabs) == 2 and tabs[0].shape[0] == tabs[1].shape[0] and sorted(int(t.shape[1]) for t in tabs)[0] == 1
+                and sum(_is_dense_layer(x) for x in c.cells()) >= 2 and not any(_is_cross_layer(x) and not _is_dense_layer(x) for x in c.cells())):
+            owner = c
+            break
+    if owner is None:
+        return None
+    tabs = [q for q in owner.__dict__["_params"].values() if isinstance(q, torch.Tensor) and q.dim() == 2]
+    lin_t, emb_t = sorted(tabs, key=lambda t: int(t.shape[1]))
+    V, D = int(emb_t.shape[0]), int(emb_t.shape[1])
+    if D == 1:
+        raise LoweringRefused("the embedding table has dimension 1: cannot tell it from the linear table")
+    B = int(getattr(owner, "batch_size", 0))
+    F = int(getattr(owner, "field_size", 0) or getattr(owner, "data_field_size", 0))
+    if B <= 0 or F <= 0:
+        raise LoweringRefused("the model does not state batch_size / field_size")
+    layers = _chain([x for x in owner.cells() if _is_dense_layer(x)], F * D)
+    if layers is None or layers[-1].weight.shape[1] != 1 or len(layers) < 2:
+        raise LoweringRefused("the DenseLayer cells do not form a chain F * D -> ... -> 1")
+    for l in layers:
+        d = getattr(l, "dropout", None)
+        if d is not None and float(getattr(d, "p", 1.0 - float(getattr(d, "keep_prob", 1.0)))) != 0.0:
+            raise LoweringRefused("DeepFM is lowered without Dropout (the reference's DenseLayer holds Dropout(p=0.0), deepfm.py:114)")
+        if str(type(getattr(l, "act_func", None)).__name__) not in ("ReLU", "NoneType") and getattr(l, "use_act", True):
+            raise LoweringRefused("DeepFM is lowered with ReLU DenseLayers only")
+    if getattr(layers[-1], "use_act", False):
+        raise LoweringRefused("the output DenseLayer must not have an activation")
+    half = bool(getattr(layers[0], "convert_dtype", False))
+    if any(bool(getattr(l, "convert_dtype", False)) != half for l in layers):
+        raise LoweringRefused("mixed convert_dtype settings")
+    if getattr(adam, "weight_decay", 0.0) or getattr(adam, "use_nesterov", False) or abs(float(adam.beta1) - 0.9) > 1e-6 or abs(float(adam.beta2) - 0.999) > 1e-6:
+        raise LoweringRefused("non-default Adam settings are not lowered")
+    want = [lin_t, emb_t] + [p for l in layers for p in (l.weight, l.bias)]
+    if len(list(adam.parameters)) != len(want) or not all(any(p is q for q in adam.parameters) for p in want):
+        raise LoweringRefused("the optimizer does not own exactly the two tables and the DenseLayers")
+    loss_cell = next((c for c in _cells(cell) if any(x is owner for x in c.cells()) and hasattr(c, "l2_coef")), None)
+    if loss_cell is None:
+        raise LoweringRefused("no loss cell with an l2_coef around the model")
+    if float(getattr(cell, "sens", adam.loss_scale)) != float(adam.loss_scale):
+        raise LoweringRefused("sens and the optimizer's loss_scale differ")
+    if emb_t.device.type != "cuda":
+        raise LoweringRefused("parameters are not on an MI355X")
+    if int(adam.global_step):
+        raise LoweringRefused("DeepFM is lowered from a fresh optimizer only")
+    cfg = DeepFMConfig(data_vocab_size=V, data_emb_dim=D, data_field_size=F, batch_size=B, deep_layer_dims=[int(l.weight.shape[1]) for l in layers[:-1]],
+                       l2_coef=float(loss_cell.l2_coef), learning_rate=adam.get_lr(), epsilon=float(adam.eps), loss_scale=float(adam.loss_scale),
+                       mlp_dtype="fp16" if half else "fp32")
+    eng = DeepFMEngine(cfg, emb_t.device)
+    if not (eng._mfma or getattr(eng, "_f32net", False)):
+        raise LoweringRefused("these DeepFM shapes have no hand-written path")
+    with torch.no_grad():
+        eng.V_l2.copy_(_raw(emb_t))
+        eng.W_l2.copy_(_raw(lin_t))
+        eng.load_dense_parameters([_raw(l.weight) for l in layers], [_raw(l.bias) for l in layers])
+        for (prefix, pid), st in adam.__dict__.get("_state", {}).items():
+            which = 0 if prefix == "moment1" else 1
+            tgt = None
+            if pid == id(emb_t):
+                tgt = eng.state["V"][which]
+            elif pid == id(lin_t):
+                tgt = eng.state["W"][which]
+            else:
+                for i, l in enumerate(layers):
+                    if pid == id(l.weight):
+                        tgt = (eng.dense_m if which == 0 else eng.dense_v)[_off(eng, 2 * i)].view(l.weight.shape)
+                    elif pid == id(l.bias):
+                        tgt = (eng.dense_m if which == 0 else eng.dense_v)[_off(eng, 2 * i + 1)].view(l.bias.shape)
+            if tgt is not None:
+                tgt.copy_(_raw(st))
+                _rebind(st, tgt)
+    _rebind(emb_t, eng.V_l2)
+    _rebind(lin_t, eng.W_l2)
+    for i, l in enumerate(layers):
+        _rebind(l.weight, eng.dense[2 * i])
+        _rebind(l.bias, eng.dense[2 * i + 1])
+    cls = type(emb_t).__mro__[1] if type(emb_t).__name__ == "Parameter" else type(emb_t)
+    low = LoweredStep(eng, cls, 1, optimizers=(adam,))
+    low.kind, low.verify = "deepfm", lambda ids, wts: _verify_logits(eng, owner, ids, wts, half)
     return low

@@ -198,3 +198,57 @@ def deep_cross_from_fixture(z, cfg, comp):
     step = AdamTrainStep(LogLoss(net), lr=comp["lr"], eps=comp["eps"], loss_scale=comp["loss_scale"])
     step.set_train()
     return step, net
+
+
+# ---- DeepFM (models/deepfm/src/deepfm.py:152-295 restated against the same API) -----------------------------------------------------
+class DeepFM(nn.Cell):
+    """logit = sum_f w[id_f] * x_f  +  0.5 * sum_d ((sum_f v_f)^2 - sum_f v_f^2)_d  +  MLP(concat_f v_f),  v_f = V[id_f] * x_f."""
+
+    def __init__(self, vocab, dim, fields, batch, hidden, half=False):
+        super().__init__()
+        self.batch_size, self.field_size, self.D = batch, fields, dim
+        self.linear = Parameter(initializer("normal", [vocab, 1], mstype.float32), name="linear")
+        self.factors = Parameter(initializer("normal", [vocab, dim], mstype.float32), name="factors")
+        dims = [fields * dim] + list(hidden) + [1]
+        self.n_layers = len(dims) - 1
+        for i in range(self.n_layers):
+            setattr(self, f"layer{i}", Layer(dims[i], dims[i + 1], relu=i < self.n_layers - 1, half=half))
+        self.gather, self.reshape, self.mul, self.sum, self.sq = ops.Gather(), ops.Reshape(), ops.Mul(), ops.ReduceSum(keep_dims=False), ops.Square()
+
+    def construct(self, ids, wts):
+        x = self.reshape(wts, (self.batch_size, self.field_size, 1))
+        first = self.sum(self.mul(self.gather(self.linear, ids, 0), x), 1)                          # [B, 1]
+        v = self.mul(self.gather(self.factors, ids, 0), x)                                          # [B, F, D]
+        second = self.reshape(0.5 * self.sum(self.sq(self.sum(v, 1)) - self.sum(self.sq(v), 1), 1), (-1, 1))
+        h = self.reshape(v, (-1, self.field_size * self.D))
+        for i in range(self.n_layers):
+            h = getattr(self, f"layer{i}")(h)
+        return first + second + h
+
+
+class DeepFMLoss(nn.Cell):
+    """mean log loss + l2_coef / 2 * (sum V^2 + sum w^2) over the WHOLE tables (deepfm.py:252-259)."""
+
+    def __init__(self, net, l2_coef):
+        super().__init__(auto_prefix=False)
+        self.net, self.l2_coef = net, l2_coef
+        self.ce, self.mean, self.sum, self.sq = ops.SigmoidCrossEntropyWithLogits(), ops.ReduceMean(), ops.ReduceSum(keep_dims=False), ops.Square()
+
+    def construct(self, ids, wts, label):
+        loss = self.mean(self.ce(self.net(ids, wts), label))
+        return loss + self.l2_coef * (self.sum(self.sq(self.net.factors)) + self.sum(self.sq(self.net.linear))) * 0.5
+
+
+def deepfm_from_fixture(z, cfg, comp):
+    from mindspore import Tensor
+    net = DeepFM(cfg["data_vocab_size"], cfg["data_emb_dim"], cfg["data_field_size"], cfg["batch_size"], cfg["deep_layer_args"][0],
+                 half=bool(comp["convert_dtype"]))
+    net.linear.set_data(Tensor(z["init/fm_w"]))
+    net.factors.set_data(Tensor(z["init/embedding_table"]))
+    for i in range(net.n_layers):
+        lay = getattr(net, f"layer{i}")
+        lay.weight.set_data(Tensor(z[f"init/dense_layer_{i + 1}.weight"]))
+        lay.bias.set_data(Tensor(z[f"init/dense_layer_{i + 1}.bias"]))
+    step = AdamTrainStep(DeepFMLoss(net, comp["l2_coef"]), lr=comp["lr"], eps=comp["eps"], loss_scale=comp["loss_scale"])
+    step.set_train()
+    return step, net

@@ -82,3 +82,31 @@ def dcn_state(eng):
         out[f"cross_layer_{l + 1}.cross_weight"] = cw[l].reshape(-1, 1)
         out[f"cross_layer_{l + 1}.cross_bias"] = cb[l].reshape(-1, 1)
     return out
+
+
+# ---- DeepFM: V_l2 [V, D], W_l2 [V, 1], DenseLayer x5 ---------------------------------------------------------------------------------
+def deepfm_config(cfg, comp, **over):
+    from mindrec_amd.deepfm import DeepFMConfig
+    kw = dict(data_vocab_size=cfg["data_vocab_size"], data_emb_dim=cfg["data_emb_dim"], data_field_size=cfg["data_field_size"],
+              batch_size=cfg["batch_size"], deep_layer_dims=list(cfg["deep_layer_args"][0]), l2_coef=comp["l2_coef"],
+              learning_rate=comp["lr"], epsilon=comp["eps"], loss_scale=comp["loss_scale"],
+              mlp_dtype="fp16" if comp["convert_dtype"] else "fp32", graphs="none")
+    kw.update(over)
+    return DeepFMConfig(**kw)
+
+
+def deepfm_load_init(eng, z):
+    n = len(eng.dims) - 1
+    with torch.no_grad():
+        eng.V_l2.copy_(torch.from_numpy(z["init/embedding_table"]))
+        eng.W_l2.copy_(torch.from_numpy(z["init/fm_w"]))
+    eng.load_dense_parameters([z[f"init/dense_layer_{i + 1}.weight"] for i in range(n)], [z[f"init/dense_layer_{i + 1}.bias"] for i in range(n)])
+
+
+def deepfm_state(eng):
+    n = len(eng.dims) - 1
+    out = {"embedding_table": eng.V_l2.detach().cpu().numpy(), "fm_w": eng.W_l2.detach().cpu().numpy()}
+    for i in range(n):
+        out[f"dense_layer_{i + 1}.weight"] = eng.dense[2 * i].detach().cpu().numpy()
+        out[f"dense_layer_{i + 1}.bias"] = eng.dense[2 * i + 1].detach().cpu().numpy()
+    return out

@@ -2,6 +2,7 @@
 /root/reference -- and records what it computes.
 
 What runs: models/wide_deep/src/wide_and_deep.py (WideDeepModel, NetWithLossClass, TrainStepWrap, PredictWithSigmoid :136-518),
+models/deepfm/src/deepfm.py (DeepFMModel, NetWithLossClass, TrainStepWrap, PredictWithSigmoid, ModelBuilder :152-370),
 models/deep_and_cross/src/deep_and_cross.py (DeepCrossModel, NetWithLossClass, TrainStepWrap :206-354),
 mindspore_rec/ops/embedding.py (HashEmbeddingLookup :47-206), mindspore_rec/train/rec_model.py (RecModel :34-309) and the three
 cases of ci/st/online_learning/test_online_learning.py:54-114.
@@ -167,6 +168,43 @@ def deep_cross_case(name, S=3):
     return comp
 
 
+def deepfm_case(name, S=3, convert_dtype=False):
+    """models/deepfm/src/deepfm.py: DeepFMModel + NetWithLossClass + TrainStepWrap + PredictWithSigmoid through ModelBuilder
+    (:322-370), with the hyper-parameters of models/deepfm/default_config.yaml:27-33."""
+    fm = _ref_module("deepfm", "deepfm")
+    mc = types.SimpleNamespace(batch_size=64, data_field_size=7, data_vocab_size=500, data_emb_dim=8, deep_layer_args=[[32, 16, 16, 8], "relu"],
+                               init_args=[-0.01, 0.01], weight_bias_init=["normal", "normal"], keep_prob=0.9, convert_dtype=bool(convert_dtype))
+    tc = types.SimpleNamespace(l2_coef=8e-5, learning_rate=5e-4, epsilon=5e-8, loss_scale=1024.0)
+    mindspore.set_seed(1000)
+    np.random.seed(1000)                                      # (the model draws its initial values from numpy's global generator, :74,92)
+    train, evaln = fm.ModelBuilder(mc, tc).get_train_eval_net()
+    net = evaln.network
+    train.set_train()
+    struct = dict(net.parameters_and_names())
+    out = {"init/" + k: _np(p) for k, p in struct.items()}
+    rng = np.random.default_rng(4242)
+    ids, wts, label = _batches(rng, S, mc.batch_size, mc.data_field_size, mc.data_vocab_size)
+    losses = [float(_np(train(Tensor(ids[s]), Tensor(wts[s]), Tensor(label[s])))) for s in range(S)]
+    evaln.set_train(False)
+    logits, probs, _ = evaln(Tensor(ids[S - 1]), Tensor(wts[S - 1]), Tensor(label[S - 1]))
+    for k, p in struct.items():
+        out["final/" + k] = _np(p)
+    opt = train.optimizer
+    for k, p in struct.items():
+        for sl in ("moment1", "moment2"):
+            out[f"state/{sl}/{k}"] = _np(opt._slot(p, sl, 0.0))
+    comp = {"optimizer": type(opt).__name__, "lr": opt.get_lr(), "eps": opt.eps, "loss_scale": opt.loss_scale, "sens": float(train.sens),
+            "l2_coef": float(train.network.l2_coef), "weights": list(struct), "convert_dtype": bool(convert_dtype),
+            "dropout_keep_prob_in_dense_layers": 1.0 - float(getattr(net.dense_layer_1.dropout, "p", 0.0))}
+    from mindrec_amd import lowering
+    assert lowering.lower_train_step(train) is None
+    comp["lowering_on_cpu"] = train._lowering_refused
+    out.update(ids=ids, wts=wts, label=label, loss=np.array(losses, np.float64), eval_logits=_np(logits), eval_probs=_np(probs),
+               cfg=np.array(json.dumps({**vars(mc), **vars(tc)})), composition=np.array(json.dumps(comp)))
+    _save(name, out)
+    return comp
+
+
 def hash_lookup_case(name):
     """HashEmbeddingLookup.construct alone (embedding.py:184-206): sparse True / False, int32 / int64 keys, max_norm."""
     from mindspore_rec import HashEmbeddingLookup
@@ -223,6 +261,8 @@ if __name__ == "__main__":
     report["ref_wd_dynamic"] = wide_deep_case("ref_wd_dynamic", sparse=True, dynamic_embedding=True)       # HashEmbeddingLookup x2
     report["ref_wd_mixed"] = wide_deep_case("ref_wd_mixed", mixed=True, sparse=True, parameter_server=1)   # fp16 DenseLayers
     report["ref_dcn"] = deep_cross_case("ref_dcn")
+    report["ref_deepfm"] = deepfm_case("ref_deepfm")                                                       # fp32 DenseLayers
+    report["ref_deepfm_mixed"] = deepfm_case("ref_deepfm_mixed", convert_dtype=True)                       # the default: fp16 DenseLayers
     hash_lookup_case("ref_hash_lookup")
     with open(os.path.join(HERE, "ref_composition.json"), "w") as f:
         json.dump(report, f, indent=1, sort_keys=True)

@@ -28,11 +28,15 @@ def test_reference_composition_record():
         assert (c["sens"], c["lr_d"], c["eps_d"], c["lr_w"], c["l1_w"], c["l2_w"], c["initial_accum_w"]) == (1024.0, 3.5e-4, 1e-8, 5e-2, 1e-8, 1e-8, 1.0)
     # mindrec_amd/lowering.py recognises the REFERENCE's train cells by structure (on the generator's host tensors it gets as far as
     # the device check; the hash-table model as far as the check that its MapParameters are the HIP ones)
-    for case in ("ref_wd_dense", "ref_wd_sparse", "ref_wd_mixed", "ref_dcn"):
+    for case in ("ref_wd_dense", "ref_wd_sparse", "ref_wd_mixed", "ref_dcn", "ref_deepfm", "ref_deepfm_mixed"):
         assert rep[case]["lowering_on_cpu"] == "parameters are not on an MI355X", (case, rep[case]["lowering_on_cpu"])
     assert rep["ref_wd_dynamic"]["lowering_on_cpu"] == "the MapParameter's store is not the HIP one"
     assert rep["ref_wd_dense"]["no_l2loss"] is False and rep["ref_wd_sparse"]["no_l2loss"] is True
     assert (rep["ref_dcn"]["optimizer"], rep["ref_dcn"]["lr"], rep["ref_dcn"]["loss_scale"]) == ("Adam", 1e-4, 1000.0)
+    for case in ("ref_deepfm", "ref_deepfm_mixed"):            # ModelBuilder.get_train_eval_net with default_config.yaml's train config
+        c = rep[case]
+        assert (c["optimizer"], c["lr"], c["eps"], c["loss_scale"], c["sens"], c["l2_coef"]) == ("Adam", 5e-4, 5e-8, 1024.0, 1024.0, 8e-5)
+        assert c["weights"][:2] == ["fm_w", "embedding_table"] and len(c["weights"]) == 12
 
 
 @pytest.mark.parametrize("case", ["ref_wd_sparse", "ref_wd_dense"])
@@ -69,6 +73,22 @@ def test_deep_cross_engine_host_logic_matches_reference(oracle):
     assert np.allclose(losses, z["loss"], rtol=2e-6, atol=0), (losses, z["loss"])
     for k, v in RF.dcn_state(eng).items():
         assert np.allclose(v, z["final/" + k], rtol=2e-4, atol=1e-7), k
+
+
+def test_deepfm_engine_host_logic_matches_reference(oracle):
+    """models/deepfm/src/deepfm.py (the reference's own DeepFMModel / NetWithLossClass / TrainStepWrap through ModelBuilder, run over
+    compat/mindspore: ref_deepfm.npz) against the DeepFM engine's host logic on the oracle's primitives: one nn.Adam over BOTH
+    tables and the net, the L2 term over the whole tables, loss scale 1024."""
+    from _oracle_engine import OracleDeepFMEngine
+    z, cfg, comp = RF.load("ref_deepfm")
+    assert comp["optimizer"] == "Adam" and comp["weights"][:2] == ["fm_w", "embedding_table"] and comp["dropout_keep_prob_in_dense_layers"] == 1.0
+    eng = OracleDeepFMEngine(RF.deepfm_config(cfg, comp), "cpu")
+    RF.deepfm_load_init(eng, z)
+    losses = np.array([float(eng.train_step(*(torch.from_numpy(z[k][s]) for k in ("ids", "wts", "label")))) for s in range(z["ids"].shape[0])])
+    assert np.allclose(losses, z["loss"], rtol=2e-6, atol=0), (losses, z["loss"])
+    for k, v in RF.deepfm_state(eng).items():
+        assert np.allclose(v, z["final/" + k], rtol=2e-4, atol=1e-7), k
+    assert np.allclose(eng.state["V"][0].numpy(), z["state/moment1/embedding_table"], rtol=1e-4, atol=1e-9)
 
 
 # ---- this repo's own mindspore_rec + a mindspore-style script over compat/mindspore, CPU kernel set -------------------------------
@@ -117,6 +137,20 @@ def test_mindspore_style_deep_cross_script_matches_reference(ms_cpu):
     assert np.allclose(losses, z["loss"], rtol=2e-6, atol=0), (losses, z["loss"])
     assert np.allclose(net.out.weight.asnumpy(), z["final/dense_layer_3.weight"], rtol=2e-4, atol=1e-7)
     assert np.allclose(net.cross3.cross_weight.asnumpy(), z["final/cross_layer_4.cross_weight"], rtol=2e-4, atol=1e-7)
+    from mindrec_amd import lowering
+    assert lowering.lower_train_step(step) is None and step._lowering_refused == "parameters are not on an MI355X"
+
+
+@pytest.mark.parametrize("case", ["ref_deepfm", "ref_deepfm_mixed"])
+def test_mindspore_style_deepfm_script_matches_reference(ms_cpu, case):
+    import _ms_models
+    z, cfg, comp = RF.load(case)
+    step, net = _ms_models.deepfm_from_fixture(z, cfg, comp)
+    losses = [float(step(ms_cpu.Tensor(z["ids"][s]), ms_cpu.Tensor(z["wts"][s]), ms_cpu.Tensor(z["label"][s])).asnumpy()) for s in range(z["ids"].shape[0])]
+    assert np.allclose(losses, z["loss"], rtol=2e-6, atol=0), (losses, z["loss"])
+    assert np.allclose(net.factors.asnumpy(), z["final/embedding_table"], rtol=2e-4, atol=1e-7)
+    assert np.allclose(net.linear.asnumpy(), z["final/fm_w"], rtol=2e-4, atol=1e-7)
+    assert np.allclose(net.layer0.weight.asnumpy(), z["final/dense_layer_1.weight"], rtol=2e-4, atol=1e-7)
     from mindrec_amd import lowering
     assert lowering.lower_train_step(step) is None and step._lowering_refused == "parameters are not on an MI355X"
 

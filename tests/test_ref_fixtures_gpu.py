@@ -108,6 +108,30 @@ def test_deep_cross_engine_replays_reference_fixture(dev):
     assert np.allclose(logit.cpu().numpy().reshape(-1), z["eval_logits"].reshape(-1), rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("case", ["ref_deepfm", "ref_deepfm_mixed"])
+def test_deepfm_engine_replays_reference_fixture(dev, case):
+    """The reference's DeepFM (models/deepfm/src/deepfm.py through ModelBuilder; fp32 DenseLayers, and its default fp16 ones) on the
+    HIP engine: losses, both tables, the net.  The fp16 case is held within the reference's own double rounding (its DenseLayer
+    rounds the MatMul output and the bias sum separately and runs the OUTPUT layer in fp16 too, :135-145; the kernels round once
+    and keep the output layer in fp32)."""
+    from mindrec_amd.deepfm import DeepFMEngine
+    z, cfg, comp = RF.load(case)
+    mixed = bool(comp["convert_dtype"])
+    eng = DeepFMEngine(RF.deepfm_config(cfg, comp), dev)
+    assert eng._mfma == mixed and (mixed or eng._f32net)
+    RF.deepfm_load_init(eng, z)
+    losses = np.array([float(eng.train_step(*(torch.from_numpy(z[k][s]).to(dev) for k in ("ids", "wts", "label"))))
+                       for s in range(z["ids"].shape[0])])
+    assert np.allclose(losses, z["loss"], rtol=5e-4 if mixed else 2e-6, atol=0), (losses, z["loss"])
+    for k, v in RF.deepfm_state(eng).items():
+        if mixed:
+            assert np.abs(v - z["final/" + k]).max() <= 0.15 * max(np.abs(z["final/" + k] - z["init/" + k]).max(), 1e-12) + 1e-7, k
+        else:
+            assert np.allclose(v, z["final/" + k], rtol=2e-4, atol=1e-7), k
+    logit, _ = eng.predict(*(torch.from_numpy(z[k][-1]).to(dev) for k in ("ids", "wts")))
+    assert np.allclose(logit.cpu().numpy().reshape(-1), z["eval_logits"].reshape(-1), rtol=2e-2 if mixed else 1e-4, atol=1e-4 if mixed else 1e-6)
+
+
 # ---- compat/mindspore on the HIP kernel set ---------------------------------------------------------------------------------------
 @pytest.fixture
 def ms_hip(dev):
@@ -242,6 +266,30 @@ def test_lowered_hash_table_script_matches_reference(ms_hip):
     assert np.allclose(logits.asnumpy().reshape(-1), z["eval_logits"].reshape(-1), rtol=1e-4, atol=1e-6)
     with pytest.raises(NotImplementedError, match="share the engine's one key index"):
         net.deep_table.embedding_table.erase(ms_hip.Tensor(z["ids"][0].reshape(-1)[:2]))
+
+
+@pytest.mark.parametrize("case", ["ref_deepfm", "ref_deepfm_mixed"])
+def test_lowered_deepfm_script_matches_reference(ms_hip, case):
+    """A mindspore-style DeepFM train cell lowered onto DeepFMEngine: the reference's losses, and the trained tables / net read
+    back through the cell's own (re-bound) Parameters."""
+    import _ms_models
+    from mindrec_amd.lowering import LoweredStep
+    z, cfg, comp = RF.load(case)
+    mixed = bool(comp["convert_dtype"])
+    step, net = _ms_models.deepfm_from_fixture(z, cfg, comp)
+    model = ms_hip.Model(step)
+    losses = [float(model._run_step(step, tuple(ms_hip.Tensor(z[k][s]) for k in ("ids", "wts", "label"))).asnumpy()) for s in range(z["ids"].shape[0])]
+    low = step.__dict__["_lowered"]
+    assert isinstance(low, LoweredStep) and low.kind == "deepfm", step.__dict__.get("_lowering_refused")
+    assert np.allclose(losses, z["loss"], rtol=5e-4 if mixed else 2e-6, atol=0), (losses, z["loss"])
+    assert net.factors.data_ptr() == low.engine.V_l2.data_ptr()
+    if not mixed:
+        assert np.allclose(net.factors.asnumpy(), z["final/embedding_table"], rtol=2e-4, atol=1e-7)
+        assert np.allclose(net.linear.asnumpy(), z["final/fm_w"], rtol=2e-4, atol=1e-7)
+        assert np.allclose(net.layer1.bias.asnumpy(), z["final/dense_layer_2.bias"], rtol=2e-4, atol=1e-7)
+    net.set_train(False)
+    logits = net(ms_hip.Tensor(z["ids"][-1]), ms_hip.Tensor(z["wts"][-1]))
+    assert np.allclose(logits.asnumpy().reshape(-1), z["eval_logits"].reshape(-1), rtol=2e-2 if mixed else 1e-4, atol=1e-4 if mixed else 1e-6)
 
 
 def test_lowered_deep_cross_script_matches_reference(ms_hip):
