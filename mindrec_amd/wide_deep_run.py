@@ -134,7 +134,9 @@ class LossCallBack(Callback):
         if out is None:
             return
         wide_loss, deep_loss = (out if isinstance(out, (tuple, list)) else (out, out))[:2]
-        wide_loss, deep_loss = float(_np(wide_loss)), float(_np(deep_loss))
+        # (as the reference prints them: the numpy scalars of `net_outputs[i].asnumpy()`, i.e. float32's shortest repr -- "0.68963903",
+        # not the widened "0.6896390318870544")
+        wide_loss, deep_loss = _np(wide_loss).reshape(()), _np(deep_loss).reshape(())
         step_in_epoch = (p.cur_step_num - 1) % p.batch_num + 1
         print("===loss===", self.rank_id, p.cur_epoch_num, step_in_epoch, wide_loss, deep_loss, flush=True)
         if self._per_print_times != 0 and p.cur_step_num % self._per_print_times == 0 and self.config is not None:

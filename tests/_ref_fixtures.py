@@ -110,3 +110,62 @@ def deepfm_state(eng):
         out[f"dense_layer_{i + 1}.weight"] = eng.dense[2 * i].detach().cpu().numpy()
         out[f"dense_layer_{i + 1}.bias"] = eng.dense[2 * i + 1].detach().cpu().numpy()
     return out
+
+
+# ---- models/wide_deep/train_and_eval.py's flow (ref_train_eval_flow.npz) through this repo's runner ---------------------------------
+def run_train_eval_flow(eng, z, dev, work_dir):
+    """test_train_eval(config) (train_and_eval.py:66-104) restated over the engine-level API: RecModel(WideDeepRunner(engine)) with
+    LossCallBack + EvalCallBack + AUCMetric, `epochs` passes over the training batches.  Returns (loss.log lines, eval.log lines
+    without their time stamps, AUC per epoch)."""
+    import os
+    import re
+    from mindrec_amd.mindspore_rec.train.callback import Callback
+    from mindrec_amd.mindspore_rec.train.rec_model import RecModel
+    from mindrec_amd.wide_deep_run import AUCMetric, Config, EvalCallBack, LossCallBack, WideDeepRunner
+    nt, ne, epochs = int(z["n_train_steps"]), int(z["n_eval_steps"]), int(z["epochs"])
+    run_cfg = Config({"loss_file_name": os.path.join(work_dir, "loss.log"), "eval_file_name": os.path.join(work_dir, "eval.log"), "sparse": False})
+
+    class DS:
+        def __init__(self, lo, hi):
+            self.lo, self.hi = lo, hi
+
+        def get_dataset_size(self):
+            return self.hi - self.lo
+
+        def __iter__(self):
+            for s in range(self.lo, self.hi):
+                yield tuple(torch.from_numpy(z[k][s]).to(dev) for k in ("ids", "wts", "label"))
+
+    class StopAfter(Callback):
+        def epoch_end(self, run_context):
+            if run_context.original_args().cur_epoch_num >= epochs:
+                run_context.request_stop()
+
+    metric = AUCMetric()
+    net = WideDeepRunner(eng, metrics={"auc": metric})
+    ev = EvalCallBack(net, DS(nt, nt + ne), metric, run_cfg)
+    RecModel(net).online_train(DS(0, nt), callbacks=[ev, LossCallBack(config=run_cfg), StopAfter()], dataset_sink_mode=False)
+    loss_lines = open(run_cfg.loss_file_name).read().strip().splitlines()
+    eval_lines = [re.sub(r"eval_time: \d+s", "eval_time: Ns", re.sub(r"^.*?== Rank", "== Rank", ln))
+                  for ln in open(run_cfg.eval_file_name).read().strip().splitlines()]
+    aucs = [float(re.search(r"dict_values\(\[([0-9.eE+-]+)\]\)", ln).group(1)) for ln in eval_lines]
+    return loss_lines, eval_lines, aucs
+
+
+def check_train_eval_flow(z, got, loss_rtol=2e-6, auc_tol=1e-9):
+    import json
+    import re
+    loss_lines, eval_lines, aucs = got
+    ref_loss, ref_eval = json.loads(str(z["loss_log"])), json.loads(str(z["eval_log"]))
+    assert len(loss_lines) == len(ref_loss) and len(eval_lines) == len(ref_eval)
+    pat = re.compile(r"^epoch: (\d+), step: (\d+), wide_loss: ([0-9.eE+-]+), deep_loss: ([0-9.eE+-]+)$")
+    for a, b in zip(loss_lines, ref_loss):
+        ma, mb = pat.match(a), pat.match(b)
+        assert ma and mb, (a, b)                                  # the reference's line format
+        assert ma.group(1, 2) == mb.group(1, 2), (a, b)           # epoch / step-in-epoch numbering
+        for i in (3, 4):
+            assert abs(float(ma.group(i)) - float(mb.group(i))) <= loss_rtol * abs(float(mb.group(i))), (a, b)
+            assert len(ma.group(i)) <= 12, a                      # printed as float32 (shortest repr), like the reference's numpy scalars
+    strip = lambda ln: re.sub(r"dict_values\(\[[0-9.eE+-]+\]\)", "dict_values([AUC])", ln)         # noqa: E731
+    assert [strip(x) for x in eval_lines] == [strip(x) for x in ref_eval]
+    assert np.allclose(aucs, z["auc"], rtol=0, atol=auc_tol), (aucs, z["auc"])

@@ -72,6 +72,17 @@ def _batches(rng, S, B, F, V, keys=None):
     return ids, wts, label
 
 
+def _wd_composition(train, loss_net, struct):
+    """What the reference's TrainStepWrap did with the parameters: which optimizer owns which, with which hyper-parameters."""
+    return {"optimizer_w": type(train.optimizer_w).__name__, "optimizer_d": type(train.optimizer_d).__name__,
+            "weights_w": sorted(k for k, p in struct.items() if any(p is q for q in train.weights_w)),
+            "weights_d": sorted(k for k, p in struct.items() if any(p is q for q in train.weights_d)),
+            "sens": float(train.sens), "lr_d": train.optimizer_d.get_lr(), "lr_w": train.optimizer_w.get_lr(),
+            "eps_d": train.optimizer_d.eps, "l1_w": train.optimizer_w.l1, "l2_w": train.optimizer_w.l2,
+            "initial_accum_w": train.optimizer_w.initial_accum, "loss_scale_d": train.optimizer_d.loss_scale,
+            "no_l2loss": bool(loss_net.no_l2loss), "l2_coef": float(loss_net.l2_coef)}
+
+
 def wide_deep_case(name, S=3, mixed=False, key_dtype=np.int32, **mode):
     wd = _ref_module("wide_deep", "wide_and_deep")
     cfg = types.SimpleNamespace(batch_size=64, field_size=9, emb_dim=8, vocab_size=3000, vocab_cache_size=0,
@@ -91,13 +102,7 @@ def wide_deep_case(name, S=3, mixed=False, key_dtype=np.int32, **mode):
     out = {}
     struct = dict(net.parameters_and_names())
     dyn = bool(cfg.dynamic_embedding)
-    comp = {"optimizer_w": type(train.optimizer_w).__name__, "optimizer_d": type(train.optimizer_d).__name__,
-            "weights_w": sorted(k for k, p in struct.items() if any(p is q for q in train.weights_w)),
-            "weights_d": sorted(k for k, p in struct.items() if any(p is q for q in train.weights_d)),
-            "sens": float(train.sens), "lr_d": train.optimizer_d.get_lr(), "lr_w": train.optimizer_w.get_lr(),
-            "eps_d": train.optimizer_d.eps, "l1_w": train.optimizer_w.l1, "l2_w": train.optimizer_w.l2,
-            "initial_accum_w": train.optimizer_w.initial_accum, "loss_scale_d": train.optimizer_d.loss_scale,
-            "no_l2loss": bool(loss_net.no_l2loss), "l2_coef": float(loss_net.l2_coef)}
+    comp = _wd_composition(train, loss_net, struct)
     # does the structural recogniser of mindrec_amd/lowering.py (GRAPH_MODE's compile step on an MI355X) see this -- the
     # REFERENCE's -- train cell for what it is?  Here (host tensors) it must get as far as the device check
     from mindrec_amd import lowering
@@ -205,6 +210,83 @@ def deepfm_case(name, S=3, convert_dtype=False):
     return comp
 
 
+def train_eval_flow_case(name):
+    """models/wide_deep/train_and_eval.py: `test_train_eval(config)` (:66-104) -- Model(train_net, eval_network, metrics={"auc": AUCMetric()}),
+    EvalCallBack, LossCallBack, ModelCheckpoint, TimeMonitor, model.train(epochs, ds_train, ..., dataset_sink_mode=True) -- run AS IT IS,
+    with its own src/callbacks.py and src/metrics.py; only `create_dataset` (MindRecord files, not available here) is replaced by an
+    in-memory dataset of the same three columns.  Recorded: what the callbacks wrote (loss.log, eval.log), the checkpoints' names."""
+    import re
+    import shutil
+    import tempfile
+    import mindspore.dataset as ds
+    for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        del sys.modules[k]
+    wd_dir = os.path.join(REF, "models", "wide_deep")
+    sys.path.insert(0, wd_dir)
+    argv, sys.argv = sys.argv, [sys.argv[0]]
+    os.environ.setdefault("DEVICE_ID", "0")
+    try:
+        te = importlib.import_module("train_and_eval")
+    finally:
+        sys.argv = argv
+        sys.path.remove(wd_dir)
+    assert te.__file__.startswith(REF)
+    work = tempfile.mkdtemp(prefix="ref_flow_")
+    cfg = te.cfg
+    B, F, V, steps, n_eval, epochs = 64, 9, 3000, 4, 2, 2
+    for k, v in dict(batch_size=B, field_size=F, emb_dim=8, vocab_size=V, deep_layer_dim=[32, 16, 16, 8], epochs=epochs, sparse=False,
+                     use_mixed_precision=False, dynamic_embedding=False, parameter_server=0, vocab_cache_size=0, dropout_flag=False,
+                     ckpt_path=os.path.join(work, "ckpt"), loss_file_name=os.path.join(work, "loss.log"),
+                     eval_file_name=os.path.join(work, "eval.log")).items():
+        setattr(cfg, k, v)
+    rng = np.random.default_rng(31337)
+    ids, wts, label = _batches(rng, steps + n_eval, B, F, V)
+    label = (rng.random(label.shape) < 1.0 / (1.0 + np.exp(-(ids[..., 3:4] % 7 - 3.0)))).astype(np.float32)       # a learnable signal
+
+    def rows(lo, hi):
+        return [(ids[s, b], wts[s, b], label[s, b]) for s in range(lo, hi) for b in range(B)]
+
+    def fake_create_dataset(data_dir, train_mode=True, batch_size=B, **kw):
+        r = rows(0, steps) if train_mode else rows(steps, steps + n_eval)
+        return ds.GeneratorDataset(r, column_names=["feat_ids", "feat_vals", "label"], shuffle=False).batch(batch_size, drop_remainder=True)
+
+    te.create_dataset = fake_create_dataset
+    seen = {}
+    build = te.ModelBuilder.get_net
+
+    def spying_get_net(self, config):                         # (looks, does not touch: the initial parameters are part of the fixture)
+        train_net, eval_net = build(self, config)
+        net = eval_net.network
+        struct = dict(net.parameters_and_names())
+        seen["init"] = {"init/" + k: _np(p) for k, p in struct.items()}
+        seen["comp"] = _wd_composition(train_net, train_net.network, struct)
+        return train_net, eval_net
+
+    te.ModelBuilder.get_net = spying_get_net
+    mindspore.set_seed(1000)
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        te.test_train_eval(cfg)
+    finally:
+        os.chdir(cwd)
+    loss_lines = open(cfg.loss_file_name).read().strip().splitlines()
+    eval_lines = [re.sub(r"^.*?== Rank", "== Rank", ln) for ln in open(cfg.eval_file_name).read().strip().splitlines()]
+    eval_lines = [re.sub(r"eval_time: \d+s", "eval_time: Ns", ln) for ln in eval_lines]
+    ckpts = sorted(f for f in os.listdir(cfg.ckpt_path) if f.endswith(".ckpt"))
+    aucs = [float(re.search(r"dict_values\(\[([0-9.eE+-]+)\]\)", ln).group(1)) for ln in eval_lines]
+    shutil.rmtree(work, ignore_errors=True)
+    out = dict(ids=ids, wts=wts, label=label, n_train_steps=np.int64(steps), n_eval_steps=np.int64(n_eval), epochs=np.int64(epochs),
+               loss_log=np.array(json.dumps(loss_lines)), eval_log=np.array(json.dumps(eval_lines)), ckpts=np.array(json.dumps(ckpts)),
+               auc=np.array(aucs, np.float64), composition=np.array(json.dumps(seen["comp"])),
+               cfg=np.array(json.dumps({k: getattr(cfg, k) for k in ("batch_size", "field_size", "emb_dim", "vocab_size", "deep_layer_dim", "epochs",
+                                                                     "sparse", "use_mixed_precision", "l2_coef", "keep_prob", "dropout_flag",
+                                                                     "dynamic_embedding", "vocab_cache_size", "parameter_server")})))
+    out.update(seen["init"])
+    _save(name, out)
+    return {"loss_log": loss_lines, "eval_log": eval_lines, "ckpts": ckpts, "auc": aucs}
+
+
 def hash_lookup_case(name):
     """HashEmbeddingLookup.construct alone (embedding.py:184-206): sparse True / False, int32 / int64 keys, max_norm."""
     from mindspore_rec import HashEmbeddingLookup
@@ -264,6 +346,7 @@ if __name__ == "__main__":
     report["ref_deepfm"] = deepfm_case("ref_deepfm")                                                       # fp32 DenseLayers
     report["ref_deepfm_mixed"] = deepfm_case("ref_deepfm_mixed", convert_dtype=True)                       # the default: fp16 DenseLayers
     hash_lookup_case("ref_hash_lookup")
+    report["ref_train_eval_flow"] = train_eval_flow_case("ref_train_eval_flow")                            # train_and_eval.py's own flow
     with open(os.path.join(HERE, "ref_composition.json"), "w") as f:
         json.dump(report, f, indent=1, sort_keys=True)
     print(json.dumps(report, indent=1, sort_keys=True))

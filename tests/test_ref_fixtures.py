@@ -214,3 +214,16 @@ def test_hash_table_checkpoint_restores_before_the_optimizer_has_run(ms_cpu, tmp
     assert load_param_into_net(c, load_checkpoint(ck)) == []
     rest = [float(c(*batch(t))[0].asnumpy()) for t in range(3, 6)]
     assert first + rest == straight
+
+
+def test_train_and_eval_flow_matches_the_reference_script(oracle, tmp_path):
+    """ref_train_eval_flow.npz was written by the reference's OWN `test_train_eval(config)` (models/wide_deep/train_and_eval.py:66-104,
+    run as it is over compat/mindspore with its src/callbacks.py and src/metrics.py; only the MindRecord reader was replaced).  The
+    engine-level flow -- RecModel(WideDeepRunner(engine)) + this repo's LossCallBack / EvalCallBack / AUCMetric -- writes the same
+    loss.log and eval.log: line format, epoch / step numbering, losses to 2e-6, the AUC after every epoch."""
+    from _oracle_engine import OracleWideDeepEngine
+    z, cfg, comp = RF.load("ref_train_eval_flow")
+    assert json.loads(str(z["ckpts"])) == ["widedeep_train-1_4.ckpt", "widedeep_train-2_4.ckpt"]       # ModelCheckpoint(save_checkpoint_steps = steps per epoch)
+    eng = OracleWideDeepEngine(RF.wd_config(cfg, comp), "cpu")
+    RF.wd_load_init(eng, z)
+    RF.check_train_eval_flow(z, RF.run_train_eval_flow(eng, z, "cpu", str(tmp_path)))

@@ -132,6 +132,16 @@ def test_deepfm_engine_replays_reference_fixture(dev, case):
     assert np.allclose(logit.cpu().numpy().reshape(-1), z["eval_logits"].reshape(-1), rtol=2e-2 if mixed else 1e-4, atol=1e-4 if mixed else 1e-6)
 
 
+def test_train_and_eval_flow_on_the_engine_matches_the_reference_script(dev, tmp_path):
+    """The same flow (see tests/test_ref_fixtures.py) with the product engine on the MI355X: loss.log / eval.log of the reference's
+    own train_and_eval.py run."""
+    from mindrec_amd.wide_deep import WideDeepEngine
+    z, cfg, comp = RF.load("ref_train_eval_flow")
+    with WideDeepEngine(RF.wd_config(cfg, comp), dev) as eng:
+        RF.wd_load_init(eng, z)
+        RF.check_train_eval_flow(z, RF.run_train_eval_flow(eng, z, dev, str(tmp_path)), auc_tol=1e-6)
+
+
 # ---- compat/mindspore on the HIP kernel set ---------------------------------------------------------------------------------------
 @pytest.fixture
 def ms_hip(dev):
