@@ -1,8 +1,9 @@
 """`mindspore.dataset`: the one source the in-scope online-learning path uses -- `GeneratorDataset(source, column_names)`
 over a random-access or iterable Python object, then `.batch(B)`
 (examples/online_learning/online_train.py:30-46,71-72; ci/st/online_learning/test_online_learning.py:43-51,63-64).
-The MindData C++ engine and its MindRecord / TFRecord readers are out of scope: the record reader
-of this repo is `mindrec_amd.criteo.RecordDataset`, which speaks the same iteration protocol."""
+`Schema` + `TFRecordDataset` read the TFRecord files the reference's training scripts take (models/wide_deep/src/datasets.py:226-271)
+through the codec of `mindrec_amd/tfrecord.py`.  MindRecord is MindSpore's own container and cannot be restated: `MindDataset`
+says so (the same records live in `.npz` shards here, `mindrec_amd.criteo.RecordDataset`)."""
 import numpy as np
 
 from . import config  # noqa: F401
@@ -147,7 +148,11 @@ class RepeatDataset(Dataset):
         i = 0
         while self.count is None or self.count < 0 or i < self.count:
             yield from self.parent
+            self.parent.reset()
             i += 1
+
+    def reset(self):
+        self.parent.reset()
 
 
 class MapDataset(Dataset):
@@ -163,6 +168,9 @@ class MapDataset(Dataset):
 
     def get_batch_size(self):
         return self.parent.get_batch_size()
+
+    def reset(self):
+        self.parent.reset()
 
     def __iter__(self):
         for row in self.parent:
@@ -196,3 +204,109 @@ class NumpySlicesDataset(GeneratorDataset):
                 return tuple(a[i] for a in arrs)
 
         super().__init__(_Src(), column_names or [f"column_{i}" for i in range(len(arrs))], **kw)
+
+
+class Schema:
+    """Schema().add_column(name, de_type, shape=None): the columns a TFRecordDataset parses, in this order."""
+
+    def __init__(self, schema_file=None):
+        if schema_file is not None:
+            raise NotImplementedError("Schema files are not read; add the columns with add_column().")
+        self.columns = []
+
+    def add_column(self, name, de_type, shape=None):
+        if not isinstance(name, str) or not name:
+            raise ValueError("For 'Schema.add_column', the 'name' must be a non-empty string.")
+        self.columns.append((name, de_type, tuple(shape) if shape is not None else None))
+
+
+def _np_dtype(de_type):
+    import torch
+    t = getattr(de_type, "dtype", de_type)
+    return {torch.int32: np.int32, torch.int64: np.int64, torch.float32: np.float32, torch.float16: np.float16,
+            torch.float64: np.float64}.get(t, t if isinstance(t, type) else np.float32)
+
+
+class TFRecordDataset(Dataset):
+    """TFRecordDataset(dataset_files, schema=None, columns_list=None, num_samples=None, num_parallel_workers=None, shuffle=...,
+    num_shards=None, shard_id=None, shard_equal_rows=False): rows of tf.train.Example records, one numpy array per column.
+    Sharding as MindSpore states it: by FILE (file i belongs to shard i mod num_shards), or, with shard_equal_rows, by ROW with
+    every shard getting the same number of rows (row i belongs to shard i mod num_shards; the rows past the last full round are
+    dropped).  shuffle: a permutation of the shard's rows per epoch, seeded by `dataset.config`'s seed (+ the epoch)."""
+
+    def __init__(self, dataset_files, schema=None, columns_list=None, num_samples=None, num_parallel_workers=None, shuffle=True,
+                 num_shards=None, shard_id=None, shard_equal_rows=False, cache=None, compression_type=None):
+        if isinstance(dataset_files, str):
+            dataset_files = [dataset_files]
+        self.files = sorted(dataset_files)
+        if not self.files:
+            raise ValueError("For 'TFRecordDataset', 'dataset_files' is empty.")
+        if compression_type:
+            raise NotImplementedError("compressed TFRecord files are not read")
+        cols = list(schema.columns) if isinstance(schema, Schema) else None
+        if columns_list is not None:
+            cols = [c for c in (cols or [(n, None, None) for n in columns_list]) if c[0] in columns_list]
+        self._cols = cols                     # None: every feature of the first record, by name
+        super().__init__([c[0] for c in cols] if cols else None)
+        self.num_samples = num_samples
+        self.shuffle = bool(shuffle) and shuffle not in (0, "false")
+        self.num_shards, self.shard_id = (num_shards or 1), (shard_id or 0)
+        if not 0 <= self.shard_id < self.num_shards:
+            raise ValueError(f"For 'TFRecordDataset', 'shard_id' must be in [0, num_shards), but got {shard_id} of {num_shards}.")
+        self.shard_equal_rows = bool(shard_equal_rows)
+        self._epoch = 0
+        from mindrec_amd import tfrecord
+        self._codec = tfrecord
+        counts = [tfrecord.count_records(f) for f in self.files]
+        index = [(fi, r) for fi, c in enumerate(counts) for r in range(c)]
+        if self.num_shards > 1:
+            if self.shard_equal_rows:
+                per = len(index) // self.num_shards
+                index = [index[i] for i in range(self.shard_id, per * self.num_shards, self.num_shards)]
+            else:
+                index = [(fi, r) for fi, r in index if fi % self.num_shards == self.shard_id]
+        self._index = index
+
+    def get_dataset_size(self):
+        n = len(self._index)
+        return min(n, self.num_samples) if self.num_samples is not None else n
+
+    def reset(self):
+        self._epoch += 1
+
+    def __iter__(self):
+        order = list(self._index)
+        if self.shuffle:
+            np.random.default_rng(config.get_seed() + self._epoch).shuffle(order)
+        if self.num_samples is not None:
+            order = order[:self.num_samples]
+        by_file = {}
+        for fi, r in order:
+            by_file.setdefault(fi, set()).add(r)
+        cache = {}
+        for fi, r in order:
+            if fi not in cache:               # (one pass over a file keeps the rows this epoch wants)
+                want = by_file[fi]
+                cache[fi] = {j: rec for j, rec in enumerate(self._codec.read_file(self.files[fi])) if j in want}
+            ex = self._codec.decode_example(cache[fi].pop(r))
+            if self._cols is None:
+                self._cols = [(n, None, None) for n in sorted(ex)]
+                self.column_names = [c[0] for c in self._cols]
+            row = []
+            for name, de_type, shape in self._cols:
+                if name not in ex:
+                    raise RuntimeError(f"TFRecordDataset: column {name!r} is not in the record (it has {sorted(ex)}).")
+                a = np.asarray(ex[name])
+                if de_type is not None:
+                    a = a.astype(_np_dtype(de_type))
+                row.append(a.reshape(shape) if shape else a)
+            yield tuple(row)
+            if not cache[fi]:
+                del cache[fi]
+
+
+class MindDataset(Dataset):
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("MindRecord is MindSpore's own container format and is not read here: write the records as TFRecord "
+                                  "files (mindrec_amd.criteo.write_tfrecords; dataset_type 'tfrecord' in the reference's configs) or "
+                                  "read this repo's .npz record shards with mindrec_amd.criteo.RecordDataset.")

@@ -140,6 +140,25 @@ def write_records(directory, prefix, ids, wts, label, records_per_file=64, line_
     return R
 
 
+def write_tfrecords(directory, prefix, ids, wts, label, records_per_file=64, line_per_sample=LINE_PER_SAMPLE):
+    """The same records as TFRecord files of tf.train.Example rows (`feat_ids` Int64List, `feat_vals` / `label` FloatList; 1000 samples
+    per row), named `<prefix>_input_part.tfrecord-0000`, ...: the format the reference's OWN reader takes besides MindRecord
+    (models/wide_deep/src/datasets.py:226-271, `dataset_type: tfrecord`; it picks up every file whose name contains `train` /
+    `test` and `tfrecord`).  Returns the number of records written."""
+    import os
+    from . import tfrecord
+    ids = np.asarray(ids, np.int32); wts = np.asarray(wts, np.float32); label = np.asarray(label, np.float32).reshape(-1)
+    n, F = ids.shape
+    R = n // line_per_sample
+    os.makedirs(directory, exist_ok=True)
+    for fi, r0 in enumerate(range(0, R, records_per_file)):
+        rows = ({"feat_ids": ids[r * line_per_sample:(r + 1) * line_per_sample].reshape(-1),
+                 "feat_vals": wts[r * line_per_sample:(r + 1) * line_per_sample].reshape(-1),
+                 "label": label[r * line_per_sample:(r + 1) * line_per_sample]} for r in range(r0, min(R, r0 + records_per_file)))
+        tfrecord.write_file(os.path.join(directory, f"{prefix}_input_part.tfrecord-{fi:04d}"), rows)
+    return R
+
+
 class RecordDataset:
     """The reading side: records of 1000 samples from `directory/{train,test}_*.npz`, sharded over the ranks the way
     MindDataset(num_shards, shard_id) shards a MindRecord file [EXT]: every rank gets the SAME number of records,

@@ -211,14 +211,18 @@ def deepfm_case(name, S=3, convert_dtype=False):
 
 
 def train_eval_flow_case(name):
-    """models/wide_deep/train_and_eval.py: `test_train_eval(config)` (:66-104) -- Model(train_net, eval_network, metrics={"auc": AUCMetric()}),
-    EvalCallBack, LossCallBack, ModelCheckpoint, TimeMonitor, model.train(epochs, ds_train, ..., dataset_sink_mode=True) -- run AS IT IS,
-    with its own src/callbacks.py and src/metrics.py; only `create_dataset` (MindRecord files, not available here) is replaced by an
-    in-memory dataset of the same three columns.  Recorded: what the callbacks wrote (loss.log, eval.log), the checkpoints' names."""
+    """models/wide_deep/train_and_eval.py: `test_train_eval(config)` (:66-104) run AS IT IS -- its own `create_dataset` (src/datasets.py:
+    226-271, the TFRecord reader: Schema, TFRecordDataset, batch(batch_size / 1000), map(padding function)), Model(train_net,
+    eval_network, metrics={"auc": AUCMetric()}), EvalCallBack, LossCallBack, ModelCheckpoint, TimeMonitor, model.train(epochs, ds_train,
+    ..., dataset_sink_mode=True), with its own src/callbacks.py and src/metrics.py.  Nothing of the script is replaced: the configuration
+    is pointed at TFRecord files (`dataset_type: tfrecord`) that this repo's Criteo writer produced (mindrec_amd.criteo.write_tfrecords:
+    1000 samples per row, as the reference's data preparation packs them).  A look-only wrapper around ModelBuilder.get_net records the
+    initial parameters.  Recorded: what the callbacks wrote (loss.log, eval.log), the checkpoints' names."""
     import re
     import shutil
     import tempfile
     import mindspore.dataset as ds
+    from mindrec_amd import criteo
     for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
         del sys.modules[k]
     wd_dir = os.path.join(REF, "models", "wide_deep")
@@ -230,27 +234,25 @@ def train_eval_flow_case(name):
     finally:
         sys.argv = argv
         sys.path.remove(wd_dir)
-    assert te.__file__.startswith(REF)
+    assert te.__file__.startswith(REF) and te.create_dataset.__module__ == "src.datasets"
     work = tempfile.mkdtemp(prefix="ref_flow_")
     cfg = te.cfg
-    B, F, V, steps, n_eval, epochs = 64, 9, 3000, 4, 2, 2
+    B, F, V, steps, n_eval, epochs = 1000, 39, 3000, 4, 2, 2              # (the reader's rows hold 1000 samples of 39 fields)
     for k, v in dict(batch_size=B, field_size=F, emb_dim=8, vocab_size=V, deep_layer_dim=[32, 16, 16, 8], epochs=epochs, sparse=False,
                      use_mixed_precision=False, dynamic_embedding=False, parameter_server=0, vocab_cache_size=0, dropout_flag=False,
+                     dataset_type="tfrecord", data_path=os.path.join(work, "data"),
                      ckpt_path=os.path.join(work, "ckpt"), loss_file_name=os.path.join(work, "loss.log"),
                      eval_file_name=os.path.join(work, "eval.log")).items():
         setattr(cfg, k, v)
     rng = np.random.default_rng(31337)
     ids, wts, label = _batches(rng, steps + n_eval, B, F, V)
-    label = (rng.random(label.shape) < 1.0 / (1.0 + np.exp(-(ids[..., 3:4] % 7 - 3.0)))).astype(np.float32)       # a learnable signal
-
-    def rows(lo, hi):
-        return [(ids[s, b], wts[s, b], label[s, b]) for s in range(lo, hi) for b in range(B)]
-
-    def fake_create_dataset(data_dir, train_mode=True, batch_size=B, **kw):
-        r = rows(0, steps) if train_mode else rows(steps, steps + n_eval)
-        return ds.GeneratorDataset(r, column_names=["feat_ids", "feat_vals", "label"], shuffle=False).batch(batch_size, drop_remainder=True)
-
-    te.create_dataset = fake_create_dataset
+    ids[:, :, :13] = np.arange(13, dtype=np.int32)                        # Criteo's 13 dense fields: constant ids, the value as the weight
+    wts[:, :, 3:13] = rng.random((steps + n_eval, B, 10)).astype(np.float32)
+    label = (rng.random(label.shape) < 1.0 / (1.0 + np.exp(-(ids[..., 13:14] % 7 - 3.0)))).astype(np.float32)       # a learnable signal
+    flat = lambda a, lo, hi: a[lo:hi].reshape((hi - lo) * B, -1)          # noqa: E731
+    criteo.write_tfrecords(cfg.data_path, "train", flat(ids, 0, steps), flat(wts, 0, steps), flat(label, 0, steps), records_per_file=3)
+    criteo.write_tfrecords(cfg.data_path, "test", flat(ids, steps, steps + n_eval), flat(wts, steps, steps + n_eval),
+                           flat(label, steps, steps + n_eval), records_per_file=3)
     seen = {}
     build = te.ModelBuilder.get_net
 
@@ -264,6 +266,15 @@ def train_eval_flow_case(name):
 
     te.ModelBuilder.get_net = spying_get_net
     mindspore.set_seed(1000)
+    ds.config.set_seed(1000)
+    # the order the reference's shuffling reader hands the training rows out in (its own dataset object, read once more)
+    order = []
+    for epoch in range(epochs):
+        d = te.create_dataset(cfg.data_path, train_mode=True, batch_size=B, data_type=te.DataType.TFRECORD)
+        for _ in range(epoch):
+            d.reset()
+        for bi, wi, li in d:
+            order.append(int(np.flatnonzero((ids[:steps, 0] == np.asarray(bi)[0]).all(axis=1) & np.isclose(wts[:steps, 0], np.asarray(wi)[0]).all(axis=1))[0]))
     cwd = os.getcwd()
     os.chdir(work)
     try:
@@ -277,14 +288,15 @@ def train_eval_flow_case(name):
     aucs = [float(re.search(r"dict_values\(\[([0-9.eE+-]+)\]\)", ln).group(1)) for ln in eval_lines]
     shutil.rmtree(work, ignore_errors=True)
     out = dict(ids=ids, wts=wts, label=label, n_train_steps=np.int64(steps), n_eval_steps=np.int64(n_eval), epochs=np.int64(epochs),
+               train_order=np.array(order, np.int64),
                loss_log=np.array(json.dumps(loss_lines)), eval_log=np.array(json.dumps(eval_lines)), ckpts=np.array(json.dumps(ckpts)),
                auc=np.array(aucs, np.float64), composition=np.array(json.dumps(seen["comp"])),
                cfg=np.array(json.dumps({k: getattr(cfg, k) for k in ("batch_size", "field_size", "emb_dim", "vocab_size", "deep_layer_dim", "epochs",
                                                                      "sparse", "use_mixed_precision", "l2_coef", "keep_prob", "dropout_flag",
-                                                                     "dynamic_embedding", "vocab_cache_size", "parameter_server")})))
+                                                                     "dynamic_embedding", "vocab_cache_size", "parameter_server", "dataset_type")})))
     out.update(seen["init"])
     _save(name, out)
-    return {"loss_log": loss_lines, "eval_log": eval_lines, "ckpts": ckpts, "auc": aucs}
+    return {"loss_log": loss_lines, "eval_log": eval_lines, "ckpts": ckpts, "auc": aucs, "train_order": order}
 
 
 def hash_lookup_case(name):
