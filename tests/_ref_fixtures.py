@@ -181,3 +181,28 @@ def check_train_eval_flow(z, got, loss_rtol=2e-6, auc_tol=3e-6):          # (AUC
     strip = lambda ln: re.sub(r"dict_values\(\[[0-9.eE+-]+\]\)", "dict_values([AUC])", ln)         # noqa: E731
     assert [strip(x) for x in eval_lines] == [strip(x) for x in ref_eval]
     assert np.allclose(aucs, z["auc"], rtol=0, atol=auc_tol), (aucs, z["auc"])
+
+
+def check_data_parallel_fixture(make_engine, dev):
+    """ref_wd_dp2.npz (the reference's 2-process data-parallel run) against ONE engine fed the concatenation of the ranks' batches."""
+    import json
+    import re
+    z, cfg, comp = load("ref_wd_dp2")
+    assert comp["reducer_flag"] and comp["gradients_mean"] and comp["degree"] == 2 and comp["optimizer_d"] == "Adam"
+    world, steps = int(z["world"]), int(z["steps"])
+    eng = make_engine(wd_config(dict(cfg, batch_size=cfg["batch_size"] * world), comp))
+    wd_load_init(eng, {k.replace("rank0/", ""): z[k] for k in z.files if k.startswith("rank0/init/")})
+    logs = json.loads(str(z["logs"]))
+    pat = re.compile(r"wide_loss: ([0-9.eE+-]+), deep_loss: ([0-9.eE+-]+)")
+    for s in range(steps):
+        ids, wts, label = (torch.from_numpy(np.concatenate([z[f"rank{r}/{k}"][s] for r in range(world)])).to(dev) for k in ("ids", "wts", "label"))
+        loss = eng.train_step(ids, wts, label)
+        lw, ld = float(loss), float(eng.deep_loss(loss))
+        ref = [tuple(float(v) for v in pat.search(logs[f"loss_log{r}"][s]).groups()) for r in range(world)]
+        assert abs(lw - np.mean([a for a, _ in ref])) <= 2e-6 * lw, (s, lw, ref)
+        assert abs(ld - np.mean([b for _, b in ref])) <= 2e-6 * ld, (s, ld, ref)
+    for k, v in wd_dense_state(eng).items():
+        assert np.allclose(v, z["rank0/final/" + k], rtol=2e-4, atol=1e-7), k
+    assert row_rel(eng.deep.cpu().numpy(), z["rank0/final/embedding_table"]) <= 1e-5
+    assert np.allclose(eng.wide.cpu().numpy(), z["rank0/final/wide_embeddinglookup.embedding_table"], rtol=1e-4, atol=1e-8)
+    assert json.loads(str(z["ckpts"])) == ["widedeep_train-1_2.ckpt"]            # rank 0 alone checkpoints (train_and_eval_distribute.py:108-110)

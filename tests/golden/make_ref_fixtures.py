@@ -299,6 +299,96 @@ def train_eval_flow_case(name):
     return {"loss_log": loss_lines, "eval_log": eval_lines, "ckpts": ckpts, "auc": aucs, "train_order": order}
 
 
+def _dp_worker(rank, world, port, work, cfg_over):
+    """One rank of models/wide_deep/train_and_eval_distribute.py, run as it is (init(), DATA_PARALLEL with gradients_mean, its sharded
+    TFRecord reader, two DistributedGradReducers, its callbacks) under torch.distributed's gloo backend."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank),
+                      DEVICE_ID=str(rank))
+    for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        del sys.modules[k]
+    sys.path.insert(0, os.path.join(REF, "models", "wide_deep"))
+    sys.argv = [sys.argv[0]]
+    ted = importlib.import_module("train_and_eval_distribute")
+    assert ted.__file__.startswith(REF)
+    cfg = ted.cfg
+    for k, v in cfg_over.items():
+        setattr(cfg, k, v)
+    cfg.loss_file_name, cfg.eval_file_name = os.path.join(work, f"loss{rank}.log"), os.path.join(work, f"eval{rank}.log")
+    seen = {}
+    build = ted.ModelBuilder.get_net
+
+    def spying_get_net(self, config):
+        train_net, eval_net = build(self, config)
+        seen["net"], seen["train"] = eval_net.network, train_net
+        seen["init"] = {k: _np(p) for k, p in seen["net"].parameters_and_names()}
+        return train_net, eval_net
+
+    ted.ModelBuilder.get_net = spying_get_net
+    os.chdir(work)
+    ted.train_wide_and_deep()
+    import mindspore.dataset as ds
+    ds.config.set_seed(ds.config.get_seed())
+    from mindspore.communication.management import get_group_size, get_rank
+    d = ted.create_dataset(cfg.data_path, train_mode=True, batch_size=cfg.batch_size, rank_id=get_rank(), rank_size=get_group_size(),
+                           data_type=ted.DataType.TFRECORD)
+    batches = [tuple(np.asarray(c) for c in row) for row in d]            # what this rank's reader handed out in its (one) epoch
+    struct = dict(seen["net"].parameters_and_names())
+    out = {f"rank{rank}/ids": np.stack([b[0] for b in batches]), f"rank{rank}/wts": np.stack([b[1] for b in batches]),
+           f"rank{rank}/label": np.stack([b[2] for b in batches])}
+    out.update({f"rank{rank}/init/{k}": v for k, v in seen["init"].items()})
+    out.update({f"rank{rank}/final/{k}": _np(p) for k, p in struct.items()})
+    comp = _wd_composition(seen["train"], seen["train"].network, struct)
+    comp["reducer_flag"], comp["gradients_mean"], comp["degree"] = bool(seen["train"].reducer_flag), bool(seen["train"].grad_reducer_d.mean), int(seen["train"].grad_reducer_d.degree)
+    np.savez(os.path.join(work, f"rank{rank}.npz"), composition=np.array(json.dumps(comp)), **out)
+
+
+def dp_flow_case(name, world=2):
+    import re
+    import shutil
+    import tempfile
+    import torch.multiprocessing as mp
+    from mindrec_amd import criteo
+    work = tempfile.mkdtemp(prefix="ref_dp_")
+    B, F, V, steps, n_eval = 1000, 39, 3000, 2, 2
+    rng = np.random.default_rng(777)
+    ids, wts, label = _batches(rng, world * steps + n_eval, B, F, V)
+    ids[:, :, :13] = np.arange(13, dtype=np.int32)
+    flat = lambda a, lo, hi: a[lo:hi].reshape((hi - lo) * B, -1)          # noqa: E731
+    nt = world * steps
+    criteo.write_tfrecords(os.path.join(work, "data"), "train", flat(ids, 0, nt), flat(wts, 0, nt), flat(label, 0, nt), records_per_file=3)
+    criteo.write_tfrecords(os.path.join(work, "data"), "test", flat(ids, nt, nt + n_eval), flat(wts, nt, nt + n_eval), flat(label, nt, nt + n_eval))
+    over = dict(batch_size=B, field_size=F, emb_dim=8, vocab_size=V, deep_layer_dim=[32, 16, 16, 8], epochs=1, sparse=False, use_mixed_precision=False,
+                dynamic_embedding=False, parameter_server=0, vocab_cache_size=0, dropout_flag=False, dataset_type="tfrecord", device_target="CPU",
+                data_path=os.path.join(work, "data"), ckpt_path=os.path.join(work, "ckpt"))
+    import socket
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    cwd = os.getcwd()
+    try:
+        mp.spawn(_dp_worker, args=(world, port, work, over), nprocs=world, join=True)
+    finally:
+        os.chdir(cwd)
+    out, logs = {}, {}
+    for r in range(world):
+        with np.load(os.path.join(work, f"rank{r}.npz")) as z:
+            out.update({k: z[k] for k in z.files if k != "composition"})
+            comp = json.loads(str(z["composition"]))
+        logs[f"loss_log{r}"] = open(os.path.join(work, f"loss{r}.log")).read().strip().splitlines()
+    for k in [k for k in out if k.startswith("rank0/init/")]:             # every replica starts from the same parameters and ends on the same
+        assert np.array_equal(out[k], out[k.replace("rank0/", "rank1/")]), k
+        kf = k.replace("/init/", "/final/")
+        assert np.array_equal(out[kf], out[kf.replace("rank0/", "rank1/")]), kf
+    for k in [k for k in list(out) if k.startswith("rank1/init/") or k.startswith("rank1/final/")]:
+        del out[k]
+    ckpts = sorted(os.listdir(os.path.join(work, "ckpt", "ckpt_0"))) if os.path.isdir(os.path.join(work, "ckpt", "ckpt_0")) else []
+    shutil.rmtree(work, ignore_errors=True)
+    out.update(world=np.int64(world), steps=np.int64(steps), composition=np.array(json.dumps(comp)),
+               logs=np.array(json.dumps(logs)), ckpts=np.array(json.dumps([c for c in ckpts if c.endswith(".ckpt")])),
+               cfg=np.array(json.dumps({k: over[k] for k in ("batch_size", "field_size", "emb_dim", "vocab_size", "deep_layer_dim", "epochs", "sparse",
+                                                             "use_mixed_precision", "dynamic_embedding", "vocab_cache_size", "parameter_server")})))
+    _save(name, out)
+    return {"composition": comp, **logs}
+
+
 def hash_lookup_case(name):
     """HashEmbeddingLookup.construct alone (embedding.py:184-206): sparse True / False, int32 / int64 keys, max_norm."""
     from mindspore_rec import HashEmbeddingLookup
@@ -359,6 +449,7 @@ if __name__ == "__main__":
     report["ref_deepfm_mixed"] = deepfm_case("ref_deepfm_mixed", convert_dtype=True)                       # the default: fp16 DenseLayers
     hash_lookup_case("ref_hash_lookup")
     report["ref_train_eval_flow"] = train_eval_flow_case("ref_train_eval_flow")                            # train_and_eval.py's own flow
+    report["ref_wd_dp2"] = dp_flow_case("ref_wd_dp2")                                                      # train_and_eval_distribute.py, 2 ranks, gloo
     with open(os.path.join(HERE, "ref_composition.json"), "w") as f:
         json.dump(report, f, indent=1, sort_keys=True)
     print(json.dumps(report, indent=1, sort_keys=True))

@@ -227,3 +227,13 @@ def test_train_and_eval_flow_matches_the_reference_script(oracle, tmp_path):
     eng = OracleWideDeepEngine(RF.wd_config(cfg, comp), "cpu")
     RF.wd_load_init(eng, z)
     RF.check_train_eval_flow(z, RF.run_train_eval_flow(eng, z, "cpu", str(tmp_path)))
+
+
+def test_reference_data_parallel_run_equals_one_engine_on_the_concatenated_batch(oracle):
+    """ref_wd_dp2.npz: models/wide_deep/train_and_eval_distribute.py run as it is by TWO processes (compat/mindspore over
+    torch.distributed's gloo; its own sharded TFRecord reader, init(), ParallelMode.DATA_PARALLEL with gradients_mean, two
+    DistributedGradReducers).  What the reference's data parallelism computes is what ONE engine computes on the concatenation of the
+    ranks' batches -- the equivalence this repo's multi-GPU path is built on (tests/test_wide_deep_dist.py proves the row-sharded engine
+    equal to the same single-process step): losses = the mean of the ranks' losses, parameters equal to summation order."""
+    from _oracle_engine import OracleWideDeepEngine
+    RF.check_data_parallel_fixture(lambda c: OracleWideDeepEngine(c, "cpu"), "cpu")

@@ -142,6 +142,13 @@ def test_train_and_eval_flow_on_the_engine_matches_the_reference_script(dev, tmp
         RF.check_train_eval_flow(z, RF.run_train_eval_flow(eng, z, dev, str(tmp_path)))
 
 
+def test_reference_data_parallel_run_equals_the_engine_on_the_concatenated_batch(dev):
+    """ref_wd_dp2.npz (models/wide_deep/train_and_eval_distribute.py, two processes) against the product engine on the MI355X fed the
+    concatenation of the two ranks' batches: see tests/test_ref_fixtures.py."""
+    from mindrec_amd.wide_deep import WideDeepEngine
+    RF.check_data_parallel_fixture(lambda c: WideDeepEngine(c, dev), dev)
+
+
 # ---- compat/mindspore on the HIP kernel set ---------------------------------------------------------------------------------------
 @pytest.fixture
 def ms_hip(dev):
