@@ -320,7 +320,8 @@ def _dp_worker(rank, world, port, work, cfg_over):
     def spying_get_net(self, config):
         train_net, eval_net = build(self, config)
         seen["net"], seen["train"] = eval_net.network, train_net
-        seen["init"] = {k: _np(p) for k, p in seen["net"].parameters_and_names()}
+        seen["init"] = {k: _np(p) for k, p in seen["net"].parameters_and_names() if not hasattr(p, "get_data")}
+        seen["seeds"] = {k: int(p.seed) for k, p in seen["net"].parameters_and_names() if hasattr(p, "get_data")}
         return train_net, eval_net
 
     ted.ModelBuilder.get_net = spying_get_net
@@ -336,13 +337,20 @@ def _dp_worker(rank, world, port, work, cfg_over):
     out = {f"rank{rank}/ids": np.stack([b[0] for b in batches]), f"rank{rank}/wts": np.stack([b[1] for b in batches]),
            f"rank{rank}/label": np.stack([b[2] for b in batches])}
     out.update({f"rank{rank}/init/{k}": v for k, v in seen["init"].items()})
-    out.update({f"rank{rank}/final/{k}": _np(p) for k, p in struct.items()})
+    for k, p in struct.items():
+        if hasattr(p, "get_data"):                            # a hash table: its (key, row) pairs, by key
+            kk, vv = p.get_data()
+            order = np.argsort(_np(kk))
+            out[f"rank{rank}/final/{k}::keys"], out[f"rank{rank}/final/{k}::values"] = _np(kk)[order], _np(vv)[order]
+            out[f"rank{rank}/seed/{k}"] = np.int64(seen["seeds"][k])
+        else:
+            out[f"rank{rank}/final/{k}"] = _np(p)
     comp = _wd_composition(seen["train"], seen["train"].network, struct)
     comp["reducer_flag"], comp["gradients_mean"], comp["degree"] = bool(seen["train"].reducer_flag), bool(seen["train"].grad_reducer_d.mean), int(seen["train"].grad_reducer_d.degree)
     np.savez(os.path.join(work, f"rank{rank}.npz"), composition=np.array(json.dumps(comp)), **out)
 
 
-def dp_flow_case(name, world=2):
+def dp_flow_case(name, world=2, **mode):
     import re
     import shutil
     import tempfile
@@ -353,6 +361,8 @@ def dp_flow_case(name, world=2):
     rng = np.random.default_rng(777)
     ids, wts, label = _batches(rng, world * steps + n_eval, B, F, V)
     ids[:, :, :13] = np.arange(13, dtype=np.int32)
+    if mode.get("dynamic_embedding"):
+        ids = ids * 7 + 100                                               # keys of a hash table: any integers
     flat = lambda a, lo, hi: a[lo:hi].reshape((hi - lo) * B, -1)          # noqa: E731
     nt = world * steps
     criteo.write_tfrecords(os.path.join(work, "data"), "train", flat(ids, 0, nt), flat(wts, 0, nt), flat(label, 0, nt), records_per_file=3)
@@ -360,6 +370,7 @@ def dp_flow_case(name, world=2):
     over = dict(batch_size=B, field_size=F, emb_dim=8, vocab_size=V, deep_layer_dim=[32, 16, 16, 8], epochs=1, sparse=False, use_mixed_precision=False,
                 dynamic_embedding=False, parameter_server=0, vocab_cache_size=0, dropout_flag=False, dataset_type="tfrecord", device_target="CPU",
                 data_path=os.path.join(work, "data"), ckpt_path=os.path.join(work, "ckpt"))
+    over.update(mode)
     import socket
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
     cwd = os.getcwd()
@@ -373,11 +384,19 @@ def dp_flow_case(name, world=2):
             out.update({k: z[k] for k in z.files if k != "composition"})
             comp = json.loads(str(z["composition"]))
         logs[f"loss_log{r}"] = open(os.path.join(work, f"loss{r}.log")).read().strip().splitlines()
-    for k in [k for k in out if k.startswith("rank0/init/")]:             # every replica starts from the same parameters and ends on the same
-        assert np.array_equal(out[k], out[k.replace("rank0/", "rank1/")]), k
-        kf = k.replace("/init/", "/final/")
-        assert np.array_equal(out[kf], out[kf.replace("rank0/", "rank1/")]), kf
-    for k in [k for k in list(out) if k.startswith("rank1/init/") or k.startswith("rank1/final/")]:
+    for k in [k for k in out if k.startswith("rank0/init/") or k.startswith("rank0/final/") or k.startswith("rank0/seed/")]:
+        k1 = k.replace("rank0/", "rank1/")
+        if k.endswith("::keys"):
+            continue
+        if k.endswith("::values"):
+            # hash tables: the replicas' key sets differ by what each rank's EVALUATION shard looked up (MapTensorGet inserts);
+            # every key both hold -- all trained keys among them -- has the same row
+            ka, kb = out[k.replace("::values", "::keys")], out[k1.replace("::values", "::keys")]
+            common, ia, ib = np.intersect1d(ka, kb, return_indices=True)
+            assert len(common) and np.array_equal(out[k][ia], out[k1][ib]), k
+            continue
+        assert np.array_equal(out[k], out[k1]), k                         # every replica starts from the same parameters and ends on the same
+    for k in [k for k in list(out) if k.startswith("rank1/init/") or k.startswith("rank1/final/") or k.startswith("rank1/seed/")]:
         del out[k]
     ckpts = sorted(os.listdir(os.path.join(work, "ckpt", "ckpt_0"))) if os.path.isdir(os.path.join(work, "ckpt", "ckpt_0")) else []
     shutil.rmtree(work, ignore_errors=True)
@@ -450,6 +469,7 @@ if __name__ == "__main__":
     hash_lookup_case("ref_hash_lookup")
     report["ref_train_eval_flow"] = train_eval_flow_case("ref_train_eval_flow")                            # train_and_eval.py's own flow
     report["ref_wd_dp2"] = dp_flow_case("ref_wd_dp2")                                                      # train_and_eval_distribute.py, 2 ranks, gloo
+    report["ref_wd_dp2_dynamic"] = dp_flow_case("ref_wd_dp2_dynamic", dynamic_embedding=True, sparse=True)  # ... over hash tables: LazyAdam + FTRL on gathered row gradients
     with open(os.path.join(HERE, "ref_composition.json"), "w") as f:
         json.dump(report, f, indent=1, sort_keys=True)
     print(json.dumps(report, indent=1, sort_keys=True))

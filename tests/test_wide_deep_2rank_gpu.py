@@ -279,3 +279,71 @@ def test_deepfm_on_key_sharded_hash_tables_matches_one_gpu(dev, tmp_path, world)
         assert np.array_equal(r[0]["dense"], r[k]["dense"])
     assert np.allclose(r[0]["dense"], eng.dense_flat.detach().cpu().numpy(), rtol=1e-4, atol=1e-7)
     assert np.allclose(np.concatenate([r[k]["prob"] for k in range(world)]), prob.cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+# ---- the row-sharded engine against the REFERENCE's own data-parallel run (tests/golden/ref_wd_dp2_dynamic.npz) ----------------------
+def _ref_dp_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import _ref_fixtures as RF
+    from _staged_comm import StagedGlooComm
+    from mindrec_amd.wide_deep import WideDeepEngine
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    z, cfg, comp = RF.load("ref_wd_dp2_dynamic")
+    eng = WideDeepEngine(RF.wd_config(cfg, comp, hash_capacity=8192, seed=int(z["rank0/seed/embedding_table"]), id_dtype="int32"), dev,
+                         rank=rank, world=world, comm=StagedGlooComm())
+    RF.wd_load_init(eng, {k.replace("rank0/", ""): z[k] for k in z.files if k.startswith("rank0/init/")}, dynamic=True)
+    losses = []
+    for s in range(int(z["steps"])):
+        ids, wts, label = (torch.from_numpy(z[f"rank{rank}/{k}"][s]).to(dev) for k in ("ids", "wts", "label"))
+        losses.append(float(eng.train_step(ids, wts, label)))
+    assert eng.shard_overflow() == 0
+    keys, rows = eng.index.export()
+    rows = rows.cpu().numpy().astype(np.int64)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keys=keys.cpu().numpy(), deep=eng.deep.cpu().numpy()[rows], wide=eng.wide.cpu().numpy()[rows],
+             dense=eng.dense_flat.detach().cpu().numpy(), wide_b=eng.wide_b.cpu().numpy(), losses=np.array(losses))
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_row_sharded_hash_tables_match_the_reference_data_parallel_run(dev, tmp_path):
+    """ref_wd_dp2_dynamic.npz was written by the reference's OWN distributed script (models/wide_deep/train_and_eval_distribute.py with
+    --dynamic_embedding, two processes over compat/mindspore + gloo): every rank holds BOTH hash tables whole, the row gradients of
+    both ranks are gathered and averaged (DistributedGradReducer(mean)), LazyAdam + FTRL update the union of the touched keys.  The
+    row-sharded engine (the product's HIP kernels; two ranks sharing the test box's GPU, collectives staged over gloo) fed the same
+    per-rank batches holds each key on ONE rank (owner = hash(key) mod 2), moves requests, rows and
+    row gradients point to point instead -- and must end with the same rows for every trained key, the same dense net on both ranks
+    and the same per-rank losses."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _ref_fixtures as RF
+    import json
+    import re
+    mp.spawn(_ref_dp_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    z, cfg, comp = RF.load("ref_wd_dp2_dynamic")
+    assert comp["optimizer_d"] == "LazyAdam" and comp["reducer_flag"] and comp["gradients_mean"]
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(2)]
+    logs = json.loads(str(z["logs"]))
+    pat = re.compile(r"wide_loss: ([0-9.eE+-]+)")
+    for k in range(2):
+        ref = [float(pat.search(ln).group(1)) for ln in logs[f"loss_log{k}"]]
+        assert np.allclose(r[k]["losses"], ref, rtol=2e-6, atol=0), (k, r[k]["losses"], ref)
+    # a key lives on exactly one shard; together the shards hold every key of the training batches
+    assert len(np.intersect1d(r[0]["keys"], r[1]["keys"])) == 0
+    keys = np.concatenate([r[0]["keys"], r[1]["keys"]])
+    deep, wide = np.concatenate([r[0]["deep"], r[1]["deep"]]), np.concatenate([r[0]["wide"], r[1]["wide"]])
+    trained = np.unique(np.concatenate([z[f"rank{k}/ids"].reshape(-1) for k in range(2)]).astype(np.int64))
+    assert np.array_equal(np.sort(keys), trained)
+    order = np.argsort(keys)
+    for name, got in (("embedding_table", deep[order]), ("wide_embeddinglookup.embedding_table", wide[order])):
+        rk, rv = z[f"rank0/final/{name}::keys"].astype(np.int64), z[f"rank0/final/{name}::values"]
+        pos = np.searchsorted(rk, trained)
+        assert np.array_equal(rk[pos], trained)                                  # the reference's replica holds them too (and its eval keys)
+        assert RF.row_rel(got, rv[pos]) <= 1e-5 if got.shape[1] > 1 else np.allclose(got, rv[pos], rtol=1e-4, atol=1e-8), name
+    names = [k[len("rank0/final/"):] for k in z.files if k.startswith("rank0/final/dense_layer_")]
+    assert np.array_equal(r[0]["dense"], r[1]["dense"])
+    assert np.allclose(r[0]["wide_b"], z["rank0/final/wide_b"], rtol=1e-4, atol=1e-8) and len(names) == 10

@@ -186,3 +186,4 @@ def test_train_steps_without_graphs_is_step_by_step():
     lb = [float(b.train_step(*x)) for x in bs]
     assert la == lb and len(set(la)) == 4
     assert torch.equal(a.deep, b.deep) and torch.equal(a.dense_flat, b.dense_flat) and a.step_count == b.step_count == 4
+
