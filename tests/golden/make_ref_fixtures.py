@@ -286,17 +286,41 @@ def train_eval_flow_case(name):
     eval_lines = [re.sub(r"eval_time: \d+s", "eval_time: Ns", ln) for ln in eval_lines]
     ckpts = sorted(f for f in os.listdir(cfg.ckpt_path) if f.endswith(".ckpt"))
     aucs = [float(re.search(r"dict_values\(\[([0-9.eE+-]+)\]\)", ln).group(1)) for ln in eval_lines]
+    # ... and the reference's evaluation script on the last checkpoint: models/wide_deep/eval.py:test_eval(config) (:67-115) as it is --
+    # load_checkpoint, load_param_into_net(eval_net), Model.eval with its EvalCallBack -- must see what training left
+    import contextlib
+    import io
+    for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        del sys.modules[k]
+    sys.path.insert(0, wd_dir)
+    argv, sys.argv = sys.argv, [sys.argv[0]]
+    try:
+        ev = importlib.import_module("eval")
+    finally:
+        sys.argv = argv
+        sys.path.remove(wd_dir)
+    assert ev.__file__.startswith(REF)
+    for k in ("batch_size", "field_size", "emb_dim", "vocab_size", "deep_layer_dim", "sparse", "use_mixed_precision", "dynamic_embedding",
+              "parameter_server", "vocab_cache_size", "dropout_flag", "dataset_type", "data_path", "loss_file_name"):
+        setattr(ev.cfg, k, getattr(cfg, k))
+    ev.cfg.eval_file_name = os.path.join(work, "eval_py.log")
+    ev.cfg.ckpt_path = os.path.join(cfg.ckpt_path, ckpts[-1])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ev.test_eval(ev.cfg)
+    eval_py_auc = float(re.findall(r"auc: ([0-9.eE+-]+)", buf.getvalue())[-1])
+    assert eval_py_auc == aucs[-1], (eval_py_auc, aucs)
     shutil.rmtree(work, ignore_errors=True)
     out = dict(ids=ids, wts=wts, label=label, n_train_steps=np.int64(steps), n_eval_steps=np.int64(n_eval), epochs=np.int64(epochs),
                train_order=np.array(order, np.int64),
                loss_log=np.array(json.dumps(loss_lines)), eval_log=np.array(json.dumps(eval_lines)), ckpts=np.array(json.dumps(ckpts)),
-               auc=np.array(aucs, np.float64), composition=np.array(json.dumps(seen["comp"])),
+               auc=np.array(aucs, np.float64), eval_py_auc=np.float64(eval_py_auc), composition=np.array(json.dumps(seen["comp"])),
                cfg=np.array(json.dumps({k: getattr(cfg, k) for k in ("batch_size", "field_size", "emb_dim", "vocab_size", "deep_layer_dim", "epochs",
                                                                      "sparse", "use_mixed_precision", "l2_coef", "keep_prob", "dropout_flag",
                                                                      "dynamic_embedding", "vocab_cache_size", "parameter_server", "dataset_type")})))
     out.update(seen["init"])
     _save(name, out)
-    return {"loss_log": loss_lines, "eval_log": eval_lines, "ckpts": ckpts, "auc": aucs, "train_order": order}
+    return {"loss_log": loss_lines, "eval_log": eval_lines, "ckpts": ckpts, "auc": aucs, "train_order": order, "eval_py_auc": eval_py_auc}
 
 
 def _dp_worker(rank, world, port, work, cfg_over):

@@ -224,6 +224,8 @@ def test_train_and_eval_flow_matches_the_reference_script(oracle, tmp_path):
     from _oracle_engine import OracleWideDeepEngine
     z, cfg, comp = RF.load("ref_train_eval_flow")
     assert json.loads(str(z["ckpts"])) == ["widedeep_train-1_4.ckpt", "widedeep_train-2_4.ckpt"]       # ModelCheckpoint(save_checkpoint_steps = steps per epoch)
+    # the reference's eval.py (test_eval, :67-115, as it is) on the last of those checkpoints saw what the training run's last EvalCallBack saw
+    assert float(z["eval_py_auc"]) == float(z["auc"][-1])
     eng = OracleWideDeepEngine(RF.wd_config(cfg, comp), "cpu")
     RF.wd_load_init(eng, z)
     RF.check_train_eval_flow(z, RF.run_train_eval_flow(eng, z, "cpu", str(tmp_path)))
