@@ -108,6 +108,7 @@ class DeepCrossEngine:
         self._state = None            # ops.StepState: Adam's powers / step size in device memory (constant kernel arguments)
         self._state_step = -1
         self._bufs = {}               # batch size -> the step's persistent intermediates (graph replays write the same buffers)
+        self._side = torch.cuda.Stream(self.device) if self._native else None      # the step's Unique + inverted index, under the GEMMs
 
     def forward(self, emb):
         """DeepCrossModel.construct behind the lookup (deep_and_cross.py:299-309), inference: logit [B, 1]."""
@@ -177,7 +178,21 @@ class DeepCrossEngine:
         gW1, gb1, gW2, gb2, gW3, gb3, gcw, gcb = self.dense_grad
         bf = self._buffers(B)
         self._state.advance(cfg.learning_rate, float(self.beta1), float(self.beta2))
+        # The bprop of Gather needs the step's Unique + inverted index, which depend on nothing but the ids: a dozen small latency-bound
+        # kernels (~140 us in a row) on a side branch under the GEMMs instead of behind them.  The fork is MARKED here and issued
+        # behind the lookup: under capture the branch whose first node is created first stays on the launch queue, and that must be
+        # the critical chain (mindrec_amd/wide_deep.py, _front)
+        main = torch.cuda.current_stream()
+        fork = main.record_event() if self._side is not None else None
         emb = k.gather_rows(self.table, ids, wts).view(B, X)
+        plan = None
+        if self._side is not None:
+            self._side.wait_event(fork)
+            with torch.cuda.stream(self._side):
+                plan = k.sparse_plan(ids)
+            if not torch.cuda.is_current_stream_capturing():          # (inside a capture every tensor lives in the graph's own pool)
+                for t in (plan.uniq_buf, plan.inv, plan.n_uniq_dev, plan.sorted_pos, plan.sorted_seg, plan.seg_offsets):
+                    t.record_stream(main)
         h1, h2 = cfg.deep_layer_dim
         x3 = self._x3(B)
         if x3:
@@ -211,7 +226,10 @@ class DeepCrossEngine:
         g = bf["g2"][0]
         k.cross_layers_bwd(emb, cw, cb, dc, dx0_out=g, dw_out=gcw, db_out=gcb, accumulate=True)
         # dense table gradient = UnsortedSegmentSum of the masked row gradients (bprop of Gather)
-        plan = k.sparse_plan(ids)
+        if plan is None:
+            plan = k.sparse_plan(ids)
+        else:
+            main.wait_stream(self._side)
         sums = k.segment_sum(plan, g.view(B * Fd, D), wts)
         gtab = bf["gtab"]
         gtab.zero_()
