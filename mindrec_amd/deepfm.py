@@ -144,13 +144,27 @@ class DeepFMEngine(_DeepFMNet):
         self.beta1_power = np.float32(self.beta1_power * self.beta1)
         self.beta2_power = np.float32(self.beta2_power * self.beta2)
         self.step_count += 1
+        # the step's Unique + inverted index (the bprop of Gather needs them, they need only the ids): on a side stream under the net
+        plan, main = None, None
+        if self._gpu:
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(self.device)
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                plan = self.k.sparse_plan(ids)
+            for t in (plan.uniq_buf, plan.inv, plan.n_uniq_dev, plan.sorted_pos, plan.sorted_seg, plan.seg_offsets):
+                t.record_stream(main)
         vx, linear = self._forward(ids, wts)
         vx16 = self.k.gather_rows(self.V_l2, ids, wts, out_dtype=self._amp) if self._mfma else None     # the net's input, rounded once
         log_loss, g_vx, g_lin = self._net_step(vx, vx16, linear, label)
         # Dense table gradients = the segment sums scattered to the touched rows + sens * l2_coef * table everywhere (the L2 term of
         # the loss, deepfm.py:252-259).  The second half -- and the term's own value, l2_coef / 2 * (sum V^2 + sum W^2) at the
         # step's starting values -- come out of the Adam kernel's one pass over each table (ops.dense_adam_l2_).
-        plan = self.k.sparse_plan(ids)
+        if plan is None:
+            plan = self.k.sparse_plan(ids)
+        else:
+            main.wait_stream(self._side)
         sens = cfg.loss_scale
         kw = dict(lr=cfg.learning_rate, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.epsilon,
                   beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=1.0 / sens)
