@@ -39,6 +39,9 @@ int mrec_last_hip_error(void);
 int mrec_version(void);
 /* 0 when a HIP device is visible and the gfx950 code object loads; MREC_ENODEVICE otherwise. */
 int mrec_device_ok(void);
+/* CRC-32C of a HOST buffer (TFRecord checksums: the reference's second data format, models/wide_deep/src/datasets.py:226-271; host code,
+ * data preparation). */
+int mrec_crc32c_host(const void* data, size_t n, uint32_t* out);
 
 /* ---- table initialisation --------------------------------------------------------------
  * initializer('normal') of nn.EmbeddingLookup / MapParameter default_value

@@ -193,6 +193,7 @@ _SIGS = {
     "mrec_event_destroy": [_vp],
     "mrec_event_elapsed_ms": [_vp, _vp, C.POINTER(C.c_float)],
     "mrec_profile_next_apply": [_vp, _vp],
+    "mrec_crc32c_host": [C.c_char_p, _sz, _vp],
 }
 _RESTYPES = {"mrec_strerror": C.c_char_p, "mrec_map_counters_dev": _vp, "mrec_map_row_keys_dev": _vp}
 

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "mrec_common.h"
+#include <cstring>
 #include "mrec_rng.h"
 #include "mrec_optim.h"
 #include "mrec_dropout.h"
@@ -728,6 +729,39 @@ MREC_API const char* mrec_strerror(int code) {
         case MREC_ENODEVICE: return "no usable gfx950 device";
         default: return "unknown error";
     }
+}
+
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of a host buffer: the checksum of TFRecord files (the reference's second data
+// format, models/wide_deep/src/datasets.py:226-271; mindrec_amd/tfrecord.py).  Host code: data preparation, not the hot path.
+MREC_API int mrec_crc32c_host(const void* data, size_t n, uint32_t* out) {
+    if (!out || (!data && n)) return MREC_EINVAL;
+    static uint32_t table[8][256];
+    static const bool init = [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            table[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
+        return true;
+    }();
+    (void)init;
+    const unsigned char* p = (const unsigned char*)data;
+    uint32_t c = 0xFFFFFFFFu;
+    while (n >= 8) {               // slicing by 8
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4);
+        memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
+            table[3][hi & 0xFF] ^ table[2][(hi >> 8) & 0xFF] ^ table[1][(hi >> 16) & 0xFF] ^ table[0][hi >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = table[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    *out = c ^ 0xFFFFFFFFu;
+    return MREC_OK;
 }
 
 MREC_API int mrec_last_hip_error(void) { return g_mrec_last_hip_error; }
