@@ -313,6 +313,16 @@ int mrec_dense_adam_l2_workspace_bytes(int64_t n, size_t* out);
 int mrec_dense_adam_l2_f32(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1, float b2, float eps,
                            float b1_pow, float b2_pow, float grad_scale, int nesterov, float l2_scaled, double* sumsq,
                            int sumsq_accumulate, void* ws, size_t ws_bytes, void* stream);
+/* The same over a table [V, D] (contiguous) whose gradient is nonzero on the step's touched rows only -- the bprop of a dense Gather
+ * (deep_and_cross.py:199,342-344; deepfm.py:198; wide_and_deep.py:434-437 with sparse False): `sums` [U, D] are the row-gradient sums in
+ * group order (mrec_segment_sum_f32), `uniq_rows` [U] the groups' table rows (n_uniq_dev: device count, nullable), every other row has
+ * gradient zero.  One pass over p, m, v: no [V, D] gradient is zeroed, scattered into or read.  Element for element the arithmetic of
+ * mrec_dense_adam_l2_f32 on the scattered gradient.  step_state (nullable): the step size from an mrec_step_state_t. */
+int mrec_dense_adam_rows_l2_workspace_bytes(int64_t V, int32_t D, size_t* out);
+int mrec_dense_adam_rows_l2_f32(float* p, float* m, float* v, int64_t V, int32_t D, const int32_t* uniq_rows, int64_t U,
+                                const int64_t* n_uniq_dev, const float* sums, float lr, float b1, float b2, float eps, float b1_pow,
+                                float b2_pow, float grad_scale, int nesterov, float l2_scaled, double* sumsq, int sumsq_accumulate,
+                                const void* step_state, void* ws, size_t ws_bytes, void* stream);
 /* Both of the above with ONE element of the buffer under FTRL instead of Adam: Wide&Deep's `wide_b` (models/wide_deep/src/
  * wide_and_deep.py:161-163) is a member of the FTRL optimizer's parameter list -- TrainStepWrap sorts by `"wide" in params.name`
  * (:407-411) and MindSpore names the Parameter held in the attribute `wide_b` "<prefix>.wide_b" [EXT: Cell.update_parameters_name

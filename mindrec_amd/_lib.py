@@ -193,6 +193,9 @@ _SIGS = {
     "mrec_event_destroy": [_vp],
     "mrec_event_elapsed_ms": [_vp, _vp, C.POINTER(C.c_float)],
     "mrec_profile_next_apply": [_vp, _vp],
+    "mrec_dense_adam_rows_l2_workspace_bytes": [_i64, _i32, _vp],
+    "mrec_dense_adam_rows_l2_f32": [_vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _f32, _vp, _int,
+                                    _vp, _vp, _sz, _vp],
     "mrec_crc32c_host": [C.c_char_p, _sz, _vp],
 }
 _RESTYPES = {"mrec_strerror": C.c_char_p, "mrec_map_counters_dev": _vp, "mrec_map_row_keys_dev": _vp}

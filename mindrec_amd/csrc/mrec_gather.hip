@@ -569,6 +569,68 @@ __global__ __launch_bounds__(256) void k_sumsq_finish(const double* __restrict__
     if (threadIdx.x == 0) *out = (accumulate ? *out : 0.0) + red[0];
 }
 
+// nn.Adam over a WHOLE table whose gradient is nonzero on the step's touched rows only (the bprop of a dense Gather:
+// UnsortedSegmentSum into a [V, D] tensor, deep_and_cross.py:199,342-344; deepfm.py:198,267; wide_and_deep.py:434-437 with sparse False):
+// the row sums stay where the segment-sum left them ([U, D], group order) and every row looks its group up in `row_group` (-1: no
+// gradient) -- instead of zeroing a [V, D] gradient, scattering the sums into it and reading it back (three passes over the table's
+// size per step).  VEC = 4: D % 4 == 0, a thread owns 4 columns of a row; VEC = 1: any D.  Same arithmetic, element for element, as
+// k_dense_adam4_l2 on the scattered gradient.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_dense_adam_rows_l2(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, int64_t V,
+                                                            int D, const int* __restrict__ row_group, const float* __restrict__ sums,
+                                                            AdamH h, float l2s, double* __restrict__ partial, const StepState* __restrict__ ss) {
+    __shared__ double red[4];
+    if (ss) h.lr_t = ss->lr_t;
+    const int DV = D / VEC;
+    const int64_t n = V * DV, stride = (int64_t)gridDim.x * 256;
+    const int64_t sr = stride / DV;
+    const int sc = (int)(stride - sr * DV);
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t r = i / DV;
+    int c = (int)(i - r * DV);
+    double acc = 0.0;
+    for (; i < n; i += stride) {
+        const int g = row_group[r];
+        const int64_t e = (r * DV + c) * VEC;
+        if (VEC == 4) {
+            float4 pp = *(float4*)(p + e), mm = *(float4*)(m + e), vv = *(float4*)(v + e);
+            float4 gg = g >= 0 ? *(const float4*)(sums + ((int64_t)g * DV + c) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc += (double)pp.x * pp.x + (double)pp.y * pp.y + (double)pp.z * pp.z + (double)pp.w * pp.w;
+            gg.x += l2s * pp.x; gg.y += l2s * pp.y; gg.z += l2s * pp.z; gg.w += l2s * pp.w;
+            adam_elem(pp.x, mm.x, vv.x, gg.x * h.gscale, h);
+            adam_elem(pp.y, mm.y, vv.y, gg.y * h.gscale, h);
+            adam_elem(pp.z, mm.z, vv.z, gg.z * h.gscale, h);
+            adam_elem(pp.w, mm.w, vv.w, gg.w * h.gscale, h);
+            *(float4*)(p + e) = pp; *(float4*)(m + e) = mm; *(float4*)(v + e) = vv;
+        } else {
+            float pp = p[e], mm = m[e], vv = v[e];
+            float gg = g >= 0 ? sums[(int64_t)g * D + c] : 0.f;
+            acc += (double)pp * pp;
+            gg += l2s * pp;
+            adam_elem(pp, mm, vv, gg * h.gscale, h);
+            p[e] = pp; m[e] = mm; v[e] = vv;
+        }
+        r += sr; c += sc;
+        if (c >= DV) { c -= DV; ++r; }
+    }
+    if (!partial) return;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// row_group[uniq[g]] = g for the step's groups (row_group was set to -1 everywhere before; a negative / out-of-range row: no entry)
+__global__ __launch_bounds__(256) void k_rows_to_groups(const int* __restrict__ uniq, const int64_t* __restrict__ n_uniq_dev, int64_t U, int64_t V,
+                                                        int* __restrict__ row_group) {
+    const int64_t n = n_uniq_dev ? min(U, *n_uniq_dev) : U;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (int64_t)gridDim.x * 256) {
+        const int r = uniq[g];
+        if (r >= 0 && r < V) row_group[r] = (int)g;
+    }
+}
+
 template <bool SH>
 __global__ __launch_bounds__(256) void k_dense_adam4_g16(float4* __restrict__ p, float4* __restrict__ m,
                                                          float4* __restrict__ v, const uint2* __restrict__ g,
@@ -1075,6 +1137,43 @@ MREC_API int mrec_dense_adam_l2_f32(float* p, float* m, float* v, const float* g
     h.nesterov = nesterov;
     hipStream_t st = (hipStream_t)stream;
     k_dense_adam4_l2<<<gr, 256, 0, st>>>((float4*)p, (float4*)m, (float4*)v, (const float4*)g, n4, h, l2_scaled, partial, (int)(n % 4));
+    if (sumsq) k_sumsq_finish<<<1, 256, 0, st>>>(partial, (int)gr, sumsq, sumsq_accumulate);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+
+MREC_API int mrec_dense_adam_rows_l2_workspace_bytes(int64_t V, int32_t D, size_t* out) {
+    if (!out || V < 0 || D <= 0) return MREC_EINVAL;
+    const int64_t items = V * (D % 4 == 0 ? D / 4 : D);
+    *out = mrec_align_up((size_t)(V > 0 ? V : 1) * sizeof(int), 256) + (size_t)stream_grid(items > 0 ? items : 1) * sizeof(double) + 512;
+    return MREC_OK;
+}
+
+MREC_API int mrec_dense_adam_rows_l2_f32(float* p, float* m, float* v, int64_t V, int32_t D, const int32_t* uniq_rows, int64_t U,
+                                         const int64_t* n_uniq_dev, const float* sums, float lr, float b1, float b2, float eps, float b1_pow,
+                                         float b2_pow, float grad_scale, int nesterov, float l2_scaled, double* sumsq, int sumsq_accumulate,
+                                         const void* step_state, void* ws, size_t ws_bytes, void* stream) {
+    if (V < 0 || D <= 0 || U < 0) return MREC_EINVAL;
+    if (V == 0) return MREC_OK;
+    if (!p || !m || !v || !ws || (U > 0 && (!uniq_rows || !sums))) return MREC_EINVAL;
+    const bool v4 = D % 4 == 0;
+    if (v4 && (!al16(p) || !al16(m) || !al16(v) || (sums && !al16(sums)))) return MREC_EUNSUPPORTED;
+    if (V * (int64_t)D >= (int64_t(1) << 40)) return MREC_EUNSUPPORTED;
+    const int64_t items = V * (v4 ? D / 4 : D);
+    const unsigned gr = stream_grid(items);
+    MrecArena a(ws, ws_bytes);
+    int* row_group = a.take<int>(V);
+    double* partial = sumsq ? a.take<double>(gr) : nullptr;
+    if (!a.ok || !row_group || (sumsq && !partial)) return MREC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    MREC_HIP_CHECK(hipMemsetAsync(row_group, 0xFF, (size_t)V * sizeof(int), st));          // -1 everywhere
+    if (U > 0) k_rows_to_groups<<<stream_grid(U), 256, 0, st>>>(uniq_rows, n_uniq_dev, U, V, row_group);
+    AdamH h;
+    h.lr_t = lr * sqrtf(1.0f - b2_pow) / (1.0f - b1_pow);
+    h.b1 = b1; h.b2 = b2; h.omb1 = 1.0f - b1; h.omb2 = 1.0f - b2; h.eps = eps; h.gscale = grad_scale;
+    h.nesterov = nesterov;
+    if (v4) k_dense_adam_rows_l2<4><<<gr, 256, 0, st>>>(p, m, v, V, D, row_group, sums, h, l2_scaled, partial, (const StepState*)step_state);
+    else k_dense_adam_rows_l2<1><<<gr, 256, 0, st>>>(p, m, v, V, D, row_group, sums, h, l2_scaled, partial, (const StepState*)step_state);
     if (sumsq) k_sumsq_finish<<<1, 256, 0, st>>>(partial, (int)gr, sumsq, sumsq_accumulate);
     MREC_LAUNCH_CHECK();
     return MREC_OK;

@@ -164,7 +164,7 @@ class DeepCrossEngine:
                  "head": {},
                  "dW1": torch.empty(((k.x3_wgrad_slabs if self._x3(B) else k.dense32_bwd_weight_slabs)(B, X, h1), X, h1), **f32),
                  "dW2": torch.empty(((k.x3_wgrad_slabs if self._x3(B) else k.dense32_bwd_weight_slabs)(B, h1, h2), h1, h2), **f32),
-                 "db1": torch.empty((T, h1), **f32), "gtab": torch.empty_like(self.table)}
+                 "db1": torch.empty((T, h1), **f32)}
             self._bufs[B] = b
         return b
 
@@ -231,12 +231,10 @@ class DeepCrossEngine:
         else:
             main.wait_stream(self._side)
         sums = k.segment_sum(plan, g.view(B * Fd, D), wts)
-        gtab = bf["gtab"]
-        gtab.zero_()
-        k.scatter_unique_rows_(gtab, plan, sums)
         kw = dict(lr=cfg.learning_rate, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.eps, beta1_power=0.0, beta2_power=0.0,
                   grad_scale=1.0 / cfg.loss_scale, step_state=self._state)
-        k.dense_adam_slabs_(self.table.view(-1), self.table_m.view(-1), self.table_v.view(-1), gtab.view(-1), [], **kw)
+        # nn.Adam over the whole table; its gradient (the bprop of Gather) is nonzero on the touched rows only: looked up per row
+        k.dense_adam_rows_l2_(self.table, self.table_m, self.table_v, plan, sums, **kw)
         slabs = [(gW1.storage_offset(), bf["dW1"]), (gW2.storage_offset(), bf["dW2"]), (gb1.storage_offset(), bf["db1"])]
         k.dense_adam_slabs_(self.dense_flat.detach(), self.dense_m, self.dense_v, self.dense_grad_flat, slabs, **kw)
         return loss.view(())

@@ -170,15 +170,13 @@ class DeepFMEngine(_DeepFMNet):
                   beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=1.0 / sens)
         if getattr(self, "_sumsq", None) is None:
             self._sumsq = torch.zeros(1, dtype=torch.float64, device=self.device)
-            self._gtab = {n: torch.empty_like(t) for n, t in (("V", self.V_l2), ("W", self.W_l2))}
         for i, (name, table, g, scale) in enumerate((("V", self.V_l2, g_vx.view(B * Fd, D), wts),
                                                       ("W", self.W_l2, (g_lin.view(B, 1) * wts).view(B * Fd, 1), None))):
-            gtab = self._gtab[name]
-            gtab.zero_()
-            self.k.scatter_unique_rows_(gtab, plan, self.k.segment_sum(plan, g, scale))
+            # nn.Adam over the WHOLE table, the gradient nonzero on the touched rows only: the group sums are looked up per row inside
+            # the Adam kernel's one pass (no [V, D] gradient is zeroed, scattered into and read back)
             m, v = self.state[name]
-            self.k.dense_adam_l2_(table.view(-1), m.view(-1), v.view(-1), gtab.view(-1), cfg.l2_coef * sens, sumsq=self._sumsq,
-                                  accumulate=i > 0, **kw)
+            self.k.dense_adam_rows_l2_(table, m, v, plan, self.k.segment_sum(plan, g, scale), cfg.l2_coef * sens, sumsq=self._sumsq,
+                                       accumulate=i > 0, **kw)
         loss = log_loss.detach() + (self._sumsq * (cfg.l2_coef * 0.5)).to(torch.float32).view(())
         self._dense_adam(1.0 / sens)
         return loss

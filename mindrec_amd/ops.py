@@ -471,6 +471,29 @@ def dense_adam_l2_(p, m, v, g, l2_scaled, sumsq=None, accumulate=False, lr=3.5e-
               int(use_nesterov), float(l2_scaled), _ptr(sumsq), int(bool(accumulate)), _ptr(ws), ws.numel(), _stream())
 
 
+def dense_adam_rows_l2_(p, m, v, plan, sums, l2_scaled=0.0, sumsq=None, accumulate=False, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8,
+                        beta1_power=0.9, beta2_power=0.999, grad_scale=1.0, use_nesterov=False, step_state=None):
+    """nn.Adam over a whole table [V, D] whose gradient is the bprop of a dense Gather: `sums` [>= U, D] = the row-gradient sums of the
+    plan's groups (ops.segment_sum), every other row's gradient is zero (+ l2_scaled * p everywhere, sum(p^2) into `sumsq` as
+    dense_adam_l2_).  One pass over p, m, v -- no [V, D] gradient is zeroed, scattered into and read back.  step_state: the step size
+    from device memory (a captured step)."""
+    _need_cuda(p, m, v, sums, sumsq)
+    V, D, ld = _table(p)
+    for t in (p, m, v):
+        if _table(t) != (V, D, D) or t.dtype != torch.float32:
+            raise TypeError("dense_adam_rows_l2_: p, m, v must be contiguous float32 [V, D] tables")
+    uniq = plan.uniq_buf if plan.uniq_buf.dtype == torch.int32 else plan.uniq_buf.to(torch.int32)
+    U = uniq.numel()
+    if sums.dtype != torch.float32 or sums.dim() != 2 or sums.shape[1] != D or sums.shape[0] < U or not sums.is_contiguous():
+        raise TypeError("dense_adam_rows_l2_: sums must be contiguous float32 [>= U, D]")
+    if sumsq is not None and (sumsq.dtype != torch.float64 or sumsq.numel() != 1):
+        raise TypeError("sumsq must be a float64 [1] device tensor")
+    ws = workspace(f"adam_rows:{V}:{D}", _lib.query_bytes("mrec_dense_adam_rows_l2_workspace_bytes", V, D), p.device)
+    _lib.call("mrec_dense_adam_rows_l2_f32", _ptr(p), _ptr(m), _ptr(v), V, D, _ptr(uniq), U, _ptr(plan.n_uniq_dev), _ptr(sums), lr, beta1,
+              beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), float(l2_scaled), _ptr(sumsq), int(bool(accumulate)),
+              C.c_void_p(step_state.buf.data_ptr()) if step_state is not None else None, _ptr(ws), ws.numel(), _stream())
+
+
 def dense_ftrl_(var, accum, linear, g, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):
     """nn.FTRL over a whole tensor (wide_and_deep.py:438-445)."""
     _need_cuda(var, accum, linear, g)

@@ -595,20 +595,19 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         ev = self._tick("plan")
         plan = plan_early if plan_early is not None else self.k.sparse_plan(ids)
         self._tock(ev)
-        if getattr(self, "_gdeep", None) is None:
-            self._gdeep, self._gwide = torch.empty_like(self.deep), torch.empty_like(self.wide)
+        if getattr(self, "_gwide", None) is None:
+            self._gwide = torch.empty_like(self.wide)
         akw = dict(lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
                    beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power), grad_scale=inv_sens)
         ev = self._tick("apply_deep")
         sums = self.k.segment_sum(plan, g_emb.view(B * Fd, D).float(), wts)           # UnsortedSegmentSum of the row gradients
-        self._gdeep.zero_()
-        self.k.scatter_unique_rows_(self._gdeep, plan, sums)
+        # nn.Adam over the WHOLE table (:434-437).  Its gradient -- the bprop of Gather -- is nonzero on the touched rows only: the
+        # kernel looks every row's group sum up (no [V, D] gradient is zeroed, scattered into and read back).
         # d/dE [l2_coef * sum(E^2) / 2] = l2_coef * E, carried at the loss scale like every other gradient: added inside the Adam
         # kernel (product rounded, then added: no fused multiply-add), which also leaves sum(E^2) of the step's starting values behind
         if getattr(self, "_l2_sumsq", None) is None:
             self._l2_sumsq = torch.zeros(1, dtype=torch.float64, device=self.device)
-        self.k.dense_adam_l2_(self.deep.view(-1), self.deep_m.view(-1), self.deep_v.view(-1), self._gdeep.view(-1), cfg.l2_coef * cfg.sens,
-                              sumsq=self._l2_sumsq, **akw)
+        self.k.dense_adam_rows_l2_(self.deep, self.deep_m, self.deep_v, plan, sums, cfg.l2_coef * cfg.sens, sumsq=self._l2_sumsq, **akw)
         self._tock(ev)
         ev = self._tick("apply_wide")
         gw = (g_wide.view(B, 1) * wts).view(B * Fd, 1)                                # Mul bprop of wide_mul (:304)

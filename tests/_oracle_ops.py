@@ -81,6 +81,14 @@ def dense_adam_l2_(p, m, v, g, l2_scaled, sumsq=None, accumulate=False, **kw):
     dense_adam_(p, m, v, torch.from_numpy(gg), **kw)
 
 
+def dense_adam_rows_l2_(p, m, v, plan, sums, l2_scaled=0.0, sumsq=None, accumulate=False, step_state=None, **kw):
+    """The restatement: the [V, D] gradient of the Gather -- zeros, the group sums scattered to their rows -- then dense_adam_l2_."""
+    assert step_state is None
+    g = torch.zeros_like(p)
+    scatter_unique_rows_(g, plan, sums)
+    dense_adam_l2_(p, m, v, g, l2_scaled, sumsq=sumsq, accumulate=accumulate, **kw)
+
+
 def dense_ftrl_(var, accum, linear, g, lr=5e-2, l1=1e-8, l2=1e-8, lr_power=-0.5, grad_scale=1.0):
     O.dense_ftrl(_np(var), _np(accum), _np(linear), _np(g), lr=lr, l1=l1, l2=l2, lr_power=lr_power, grad_scale=grad_scale)
 

@@ -549,6 +549,40 @@ def test_dense_adam_with_l2_term_any_length(dev, oracle):
         assert abs(float(ss) - want) <= 1e-12 * want, n
 
 
+@pytest.mark.parametrize("V,D", [(5000, 80), (3001, 30), (184965, 1), (700, 16)])
+def test_dense_adam_over_a_gather_gradient_equals_scatter_then_adam(dev, oracle, V, D):
+    """ops.dense_adam_rows_l2_ (the whole table's nn.Adam with the gradient looked up per row from the step's group sums) against the
+    three-pass form it replaces -- zero a [V, D] gradient, scatter the sums, ops.dense_adam_l2_ -- bit for bit, sum(p^2) included;
+    duplicate-heavy ids, ids outside the table (skipped), with and without the L2 term."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(V + D)
+    n = 4000
+    ids = np.minimum(rng.zipf(1.2, size=n), V + 3).astype(np.int32)            # a few ids >= V: no row
+    ids[:50] = 7
+    g = (rng.standard_normal((n, D)) * 20).astype(np.float32)
+    sc = rng.random(n).astype(np.float32)
+    p0 = (rng.standard_normal((V, D)) * 0.01).astype(np.float32)
+    m0 = (rng.standard_normal((V, D)) * 0.1).astype(np.float32)
+    v0 = (rng.random((V, D)) * 0.01).astype(np.float32)
+    for l2 in (0.0, 8e-5 * 1024):
+        kw = dict(lr=5e-4, eps=5e-8, beta1_power=0.81, beta2_power=0.998, grad_scale=1 / 1024)
+        plan = ops.sparse_plan(T(ids, dev))
+        sums = ops.segment_sum(plan, T(g, dev), T(sc, dev))
+        a = [T(x.copy(), dev) for x in (p0, m0, v0)]
+        sa = torch.full((1,), 3.0, dtype=torch.float64, device=dev)
+        ops.dense_adam_rows_l2_(a[0], a[1], a[2], plan, sums, l2, sumsq=sa, accumulate=True, **kw)
+        b = [T(x.copy(), dev) for x in (p0, m0, v0)]
+        gt = torch.zeros((V, D), device=dev)
+        ops.scatter_unique_rows_(gt, plan, sums)
+        sb = torch.full((1,), 3.0, dtype=torch.float64, device=dev)
+        ops.dense_adam_l2_(b[0].view(-1), b[1].view(-1), b[2].view(-1), gt.view(-1), l2, sumsq=sb, accumulate=True, **kw)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        assert abs(float(sa) - float(sb)) <= 1e-12 * float(sb)
+        touched = np.unique(ids[ids < V])
+        assert not np.array_equal(a[0].cpu().numpy()[touched], p0[touched])
+
+
 @pytest.mark.parametrize("B,K5", [(16384, 128), (1000, 64), (77, 8), (4096, 512)])
 def test_head_fwd_bwd(dev, oracle, B, K5):
     from mindrec_amd import ops
