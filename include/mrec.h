@@ -686,6 +686,10 @@ int mrec_fm_bwd_f32(const float* vx, const float* colsum, const float* dout, int
  * mixed-precision MLP (g16_kind 1 bf16, 2 f16; DenseLayer with convert_dtype, :135-145), written as the fp32 row gradient the
  * lookup's bprop hands the optimizer.  D % 4 == 0. */
 int mrec_fm_fwd_add_f32(const float* vx, int64_t B, int32_t F, int32_t D, const float* addend, float* fm_out, float* colsum, void* stream);
+/* ... and a 16-bit copy of vx (kind16 1: bf16, 2: f16; x16 [B, F, D], D % 4 == 0) written in the same pass: the input of DeepFM's fp16
+ * DenseLayers (deepfm.py:135-137 casts the very tensor the FM term reads). */
+int mrec_fm_fwd_add16_f32(const float* vx, int64_t B, int32_t F, int32_t D, const float* addend, float* fm_out, float* colsum, void* x16,
+                          int32_t kind16, void* stream);
 int mrec_fm_bwd_mix_f32(const float* vx, const float* colsum, const float* dout, const void* g16, int32_t g16_kind, int64_t B, int32_t F,
                         int32_t D, float* g_out, void* stream);
 /* table[rows[i], :] += vals[i, :] for distinct rows (rows < 0 skipped): adds a segment-sum into a dense

@@ -176,6 +176,7 @@ _SIGS = {
     "mrec_fm_fwd_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp],
     "mrec_fm_bwd_f32": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
     "mrec_fm_fwd_add_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp],
+    "mrec_fm_fwd_add16_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
     "mrec_fm_bwd_mix_f32": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp],
     "mrec_scatter_add_rows_f32": [_vp, _i64, _i32, _vp, _i64, _vp, _vp],
     "mrec_shard_route_workspace_bytes": [_i64, _i32, _szp],

@@ -58,9 +58,22 @@ __global__ __launch_bounds__(256) void k_fm_fwd(const float* __restrict__ vx, in
 // samples per wave64 at D = 80), four fields' loads are issued before they are consumed, no per-column guards.
 // Column sums are accumulated in field order exactly as above (colsum stays bit-identical); the sum over the
 // columns is a fixed shuffle tree inside the lane-group.
+// KIND16 1 / 2: the rows also leave as a bf16 / f16 copy (x16 [B, F, D]) -- the dense net's 16-bit input, rounded from the very values
+// the FM term reads (DeepFM looked the table up a second time for it).
+__device__ __forceinline__ uint2 fm_pack16(const float4 x, const int kind) {
+    if (kind == 1) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        const bf2 lo = {(__bf16)x.x, (__bf16)x.y}, hi = {(__bf16)x.z, (__bf16)x.w};
+        return make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+    }
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 lo = {(_Float16)x.x, (_Float16)x.y}, hi = {(_Float16)x.z, (_Float16)x.w};
+    return make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+}
+
 __global__ __launch_bounds__(256) void k_fm_fwd4(const float4* __restrict__ vx, int64_t B, int F, int lpr, int G,
                                                  float* __restrict__ fm_out, float4* __restrict__ colsum,
-                                                 const float* __restrict__ add = nullptr) {
+                                                 const float* __restrict__ add = nullptr, uint2* __restrict__ x16 = nullptr, int kind16 = 0) {
     const int lane = threadIdx.x & 63;
     const int grp = lane / lpr, sub = lane - grp * lpr;
     const bool act = grp < G;
@@ -75,6 +88,10 @@ __global__ __launch_bounds__(256) void k_fm_fwd4(const float4* __restrict__ vx, 
             float4 x[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[k] = live ? row[(int64_t)(f + k) * lpr] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (x16 && live) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x16[(b * F + f + k) * (int64_t)lpr + sub] = fm_pack16(x[k], kind16);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 s.x = s.x + x[k].x; s.y = s.y + x[k].y; s.z = s.z + x[k].z; s.w = s.w + x[k].w;
@@ -83,6 +100,7 @@ __global__ __launch_bounds__(256) void k_fm_fwd4(const float4* __restrict__ vx, 
         }
         for (; f < F; ++f) {
             const float4 x = live ? row[(int64_t)f * lpr] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (x16 && live) x16[(b * F + f) * (int64_t)lpr + sub] = fm_pack16(x, kind16);
             s.x = s.x + x.x; s.y = s.y + x.y; s.z = s.z + x.z; s.w = s.w + x.w;
             q.x = q.x + x.x * x.x; q.y = q.y + x.y * x.y; q.z = q.z + x.z * x.z; q.w = q.w + x.w * x.w;
         }
@@ -170,7 +188,13 @@ MREC_API int mrec_fm_fwd_f32(const float* vx, int64_t B, int32_t F, int32_t D, f
 
 MREC_API int mrec_fm_fwd_add_f32(const float* vx, int64_t B, int32_t F, int32_t D, const float* addend, float* fm_out, float* colsum,
                                  void* stream) {
-    if (B < 0 || F <= 0 || D <= 0) return MREC_EINVAL;
+    return mrec_fm_fwd_add16_f32(vx, B, F, D, addend, fm_out, colsum, nullptr, 0, stream);
+}
+
+MREC_API int mrec_fm_fwd_add16_f32(const float* vx, int64_t B, int32_t F, int32_t D, const float* addend, float* fm_out, float* colsum,
+                                   void* x16, int32_t kind16, void* stream) {
+    if (B < 0 || F <= 0 || D <= 0 || (x16 && kind16 != 1 && kind16 != 2)) return MREC_EINVAL;
+    if (x16 && (D % 4 || (((uintptr_t)x16) & 7) || ((((uintptr_t)vx) | ((uintptr_t)colsum)) & 15))) return MREC_EUNSUPPORTED;
     if (D > 64 * FM_MAXC) return MREC_EUNSUPPORTED;
     if (B == 0) return MREC_OK;
     if (!vx || !fm_out || !colsum) return MREC_EINVAL;
@@ -179,7 +203,8 @@ MREC_API int mrec_fm_fwd_add_f32(const float* vx, int64_t B, int32_t F, int32_t 
         const int lpr = D / 4, G = 64 / lpr;
         int64_t blocks = mrec_cdiv(B, (int64_t)4 * G);
         if (blocks > 256 * 8) blocks = 256 * 8;
-        k_fm_fwd4<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const float4*)vx, B, F, lpr, G, fm_out, (float4*)colsum, addend);
+        k_fm_fwd4<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const float4*)vx, B, F, lpr, G, fm_out, (float4*)colsum, addend,
+                                                                      (uint2*)x16, kind16);
     } else {
         int64_t blocks = mrec_cdiv(B, 4);
         if (blocks > 256 * 8) blocks = 256 * 8;

@@ -75,7 +75,21 @@ class _DeepFMNet(DenseNetMixin):
         cfg = self.cfg
         B, Fd, D = vx.shape
         if self._mfma:
-            lin_fm, cs = self.k.fm_forward(vx, add=linear)                     # linear + fm: the output head's per-sample addend
+            if vx16 is None:
+                # the net's 16-bit input = the very values the FM term reads, rounded once (deepfm.py:135-137 casts that tensor): written
+                # by the FM kernel's pass over them -- straight into the MLP graph's static input where there is one -- not looked up
+                # a second time
+                g = self._mlp_graph
+                if g is not None and g["emb"].dtype == self._amp and g["emb"].numel() == vx.numel():
+                    vx16 = g["emb"].view(B, Fd, D)
+                else:
+                    bufs = self.__dict__.setdefault("_vx16", {})
+                    vx16 = bufs.get((B, Fd, D))
+                    if vx16 is None:
+                        vx16 = bufs[(B, Fd, D)] = torch.empty((B, Fd, D), dtype=self._amp, device=self.device)
+                lin_fm, cs = self.k.fm_forward(vx, add=linear, out16=vx16)     # linear + fm: the output head's per-sample addend
+            else:
+                lin_fm, cs = self.k.fm_forward(vx, add=linear)
             loss, g16, dlogit = self._mlp_step(vx16.view(B, Fd * D), lin_fm, label)
             return loss, self.k.fm_backward_mix(g16.view(B, Fd, D), vx, cs, dlogit), dlogit
         if self._f32net:
@@ -156,8 +170,7 @@ class DeepFMEngine(_DeepFMNet):
             for t in (plan.uniq_buf, plan.inv, plan.n_uniq_dev, plan.sorted_pos, plan.sorted_seg, plan.seg_offsets):
                 t.record_stream(main)
         vx, linear = self._forward(ids, wts)
-        vx16 = self.k.gather_rows(self.V_l2, ids, wts, out_dtype=self._amp) if self._mfma else None     # the net's input, rounded once
-        log_loss, g_vx, g_lin = self._net_step(vx, vx16, linear, label)
+        log_loss, g_vx, g_lin = self._net_step(vx, None, linear, label)
         # Dense table gradients = the segment sums scattered to the touched rows + sens * l2_coef * table everywhere (the L2 term of
         # the loss, deepfm.py:252-259).  The second half -- and the term's own value, l2_coef / 2 * (sum V^2 + sum W^2) at the
         # step's starting values -- come out of the Adam kernel's one pass over each table (ops.dense_adam_l2_).
@@ -280,8 +293,7 @@ class DeepFMHashEngine(_DeepFMNet):
         D = cfg.data_emb_dim
         vx, linear, route = self._shard_lookup(keys, wts, train=None)
         plan = ops.sparse_plan(route["rows"], skip_negative=True)         # Unique + inverted index of the received rows
-        vx16 = vx.to(self._amp) if self._mfma else None                    # (the rows arrive in fp32: the FM term wants them so)
-        loss, g_vx, g_lin = self._net_step(vx, vx16, linear.contiguous(), label)
+        loss, g_vx, g_lin = self._net_step(vx, None, linear.contiguous(), label)   # (the rows arrive in fp32: the FM term wants them so)
         gmsg = ops.shard_route_grads(g_vx.view(B * Fd, D), g_lin.view(B).contiguous(), Fd, route["pos_of_slot"])
         recv_g = torch.empty_like(gmsg)
         self.comm.all_to_all(recv_g, gmsg)
@@ -328,9 +340,8 @@ class DeepFMHashEngine(_DeepFMNet):
             return loss
         d, rows_v, pos_v, rows_w, pos_w = self._lookup(keys, insert=True)
         vx = ops.gather_rows(self.V.values, pos_v.view(B, Fd), wts)             # [B, F, D], mask fused
-        vx16 = ops.gather_rows(self.V.values, pos_v.view(B, Fd), wts, out_dtype=self._amp) if self._mfma else None
         linear = ops.wide_sum(self.W.values, pos_w.view(B, Fd), wts)             # [B]
-        loss, g_vx, g_lin = self._net_step(vx, vx16, linear, label)
+        loss, g_vx, g_lin = self._net_step(vx, None, linear, label)
         kw = self._adam_kw(1.0 / cfg.loss_scale)
         plan = ops.group_by_inverse(d)
         for t, rows_u, g, scale in ((self.V, rows_v, g_vx.view(B * Fd, D), wts),

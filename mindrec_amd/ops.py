@@ -1668,16 +1668,20 @@ def dcn_head_fwd_bwd(d2, c, w3, b3, label, dscale, dw3_out, db2_out, db3_out, ou
 
 
 # ---- DeepFM second-order term ------------------------------------------------------------------
-def fm_forward(vx, add=None):
-    """vx [B, F, D] fp32 -> (fm_out [B], colsum [B, D]) (deepfm.py:221-228).  add [B] (the linear term): fm_out = add + fm."""
-    _need_cuda(vx, add)
+def fm_forward(vx, add=None, out16=None):
+    """vx [B, F, D] fp32 -> (fm_out [B], colsum [B, D]) (deepfm.py:221-228).  add [B] (the linear term): fm_out = add + fm.
+    out16 (bfloat16 / float16 [B, F, D], D % 4 == 0): receives vx rounded to 16 bits in the same pass (the dense net's input)."""
+    _need_cuda(vx, add, out16)
     B, F_, D = vx.shape
     vx = vx.contiguous()
     if add is not None and (add.dtype != torch.float32 or add.numel() != B or not add.is_contiguous()):
         raise TypeError("fm_forward: add must be contiguous float32 [B]")
+    if out16 is not None and (out16.dtype not in _DT16 or out16.numel() != vx.numel() or not out16.is_contiguous() or D % 4):
+        raise TypeError("fm_forward: out16 must be a contiguous bfloat16 / float16 tensor of vx's size (D % 4 == 0)")
     fm = torch.empty(B, dtype=torch.float32, device=vx.device)
     cs = torch.empty((B, D), dtype=torch.float32, device=vx.device)
-    _lib.call("mrec_fm_fwd_add_f32", _ptr(vx), B, F_, D, _ptr(add), _ptr(fm), _ptr(cs), _stream())
+    _lib.call("mrec_fm_fwd_add16_f32", _ptr(vx), B, F_, D, _ptr(add), _ptr(fm), _ptr(cs), _ptr(out16),
+              0 if out16 is None else (1 if out16.dtype == torch.bfloat16 else 2), _stream())
     return fm, cs
 
 

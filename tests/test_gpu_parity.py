@@ -821,3 +821,19 @@ def test_committed_goldens_replay_on_the_gpu(dev):
     assert np.array_equal(got_p[inside], z["p_touched"][inside]) and np.array_equal(got_m[inside], z["m_touched"][inside])
     den = np.abs(z["p_touched"]).max(axis=1) + 1e-30
     assert float((np.abs(got_p - z["p_touched"]).max(axis=1) / den).max()) <= 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_fm_forward_16bit_copy_is_the_rounded_input(dev, dt):
+    """ops.fm_forward(out16=...): the FM term's pass also writes its input rounded to 16 bits (the dense net's input, which DeepFM used to
+    look up a second time) -- the same bits as a cast of the tensor, the FM outputs untouched."""
+    from mindrec_amd import ops
+    rng = np.random.default_rng(3)
+    B, F, D = 1000, 39, 80
+    vx = T((rng.standard_normal((B, F, D)) * 0.05).astype(np.float32), dev)
+    add = T(rng.standard_normal(B).astype(np.float32), dev)
+    fm0, cs0 = ops.fm_forward(vx, add=add)
+    out = torch.empty((B, F, D), dtype=dt, device=dev)
+    fm1, cs1 = ops.fm_forward(vx, add=add, out16=out)
+    assert torch.equal(fm0, fm1) and torch.equal(cs0, cs1)
+    assert torch.equal(out.view(torch.int16), vx.to(dt).view(torch.int16))
