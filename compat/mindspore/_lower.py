@@ -20,16 +20,13 @@ def lowered(cell, batch=None):
         except ImportError:
             d["_lowered"] = False
             return None
-        low = lowering.lower_train_step(cell)
-        if low is not None and batch is not None and len(batch) >= 2 and all(isinstance(t, torch.Tensor) for t in batch[:2]):
-            try:
-                low.verify(batch[0], batch[1])
-            except lowering.LoweringRefused as e:
-                raise RuntimeError(f"lowering of {type(cell).__name__} failed its verification after the parameters were "
-                                   f"re-bound: {e}") from e
+        # build -> verify on this first batch -> (distributed cells: all ranks agree) -> commit; a refusal leaves the cell untouched
+        low = lowering.lower_train_step(cell, batch)
         d["_lowered"] = low or False
         if not low:
+            # a GRAPH_MODE train cell that stays on the interpreter is worth a WARNING, once: the user would otherwise benchmark
+            # primitive-by-primitive execution without being told
             from . import log
-            log.info("GRAPH_MODE: %s stays on the primitive-by-primitive path: %s", type(cell).__name__,
-                     d.get("_lowering_refused", "not lowered"))
+            log.warning("GRAPH_MODE: %s is NOT lowered onto the fused engine and runs primitive by primitive: %s", type(cell).__name__,
+                        d.get("_lowering_refused", "not lowered"))
     return low or None

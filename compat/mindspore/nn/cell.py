@@ -76,6 +76,11 @@ class Cell:
             low = lowered(self, args)
             if low is not None:
                 return low(*args)
+        fwd = self.__dict__.get("_lowered_forward")
+        if fwd is not None and not self.__dict__["training"] and not kwargs and len(args) == 2:
+            # the model cell of a ROW-SHARDED lowered train step, evaluated: its tables are shards on their owner ranks, so the
+            # forward is the engine's collective one (every rank evaluates, as the reference's scripts do)
+            return fwd(*args)
         _call_depth[0] += 1
         try:
             return self.construct(*args, **kwargs)

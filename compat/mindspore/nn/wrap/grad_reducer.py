@@ -10,6 +10,31 @@ from ...common.tensor import as_tensor
 from ..cell import Cell
 
 
+def _staged(t):
+    """A gloo group handed device tensors (ranks sharing one GPU): gloo moves host memory."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_reduce(t):
+    if _staged(t):
+        c = t.cpu()
+        dist.all_reduce(c)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t)
+
+
+def _all_gather(t, n):
+    if _staged(t):
+        c = t.cpu()
+        outs = [torch.empty_like(c) for _ in range(n)]
+        dist.all_gather(outs, c)
+        return [o.to(t.device) for o in outs]
+    outs = [torch.empty_like(t) for _ in range(n)]
+    dist.all_gather(outs, t)
+    return outs
+
+
 class DistributedGradReducer(Cell):
     def __init__(self, parameters, mean=None, degree=None, fusion_type=1, group=None):
         super().__init__(auto_prefix=False)
@@ -25,16 +50,12 @@ class DistributedGradReducer(Cell):
     def _gather_rows(self, idx, vals):
         n = dist.get_world_size()
         cnt = torch.tensor([idx.numel()], device=idx.device, dtype=torch.int64)
-        cnts = [torch.zeros_like(cnt) for _ in range(n)]
-        dist.all_gather(cnts, cnt)
+        cnts = _all_gather(cnt, n)
         cap = int(max(int(c) for c in cnts))
         pi = torch.full((cap,), -1, dtype=idx.dtype, device=idx.device)
         pv = torch.zeros((cap,) + tuple(vals.shape[1:]), dtype=vals.dtype, device=vals.device)
         pi[: idx.numel()], pv[: idx.numel()] = idx, vals
-        gi = [torch.empty_like(pi) for _ in range(n)]
-        gv = [torch.empty_like(pv) for _ in range(n)]
-        dist.all_gather(gi, pi)
-        dist.all_gather(gv, pv)
+        gi, gv = _all_gather(pi, n), _all_gather(pv, n)
         keep = [slice(0, int(c)) for c in cnts]
         return torch.cat([a[s] for a, s in zip(gi, keep)]), torch.cat([a[s] for a, s in zip(gv, keep)])
 
@@ -46,7 +67,7 @@ class DistributedGradReducer(Cell):
         out = list(grads)
         if dense:
             flat = torch.cat([g.reshape(-1).to(torch.float32) for _, g in dense])
-            dist.all_reduce(flat)
+            _all_reduce(flat)
             if self.mean:
                 flat *= scale
             off = 0

@@ -178,7 +178,11 @@ class BatchMatMul(Primitive):
             return _w(_grad.MatMul2D.apply(a, b, False, False))
         if a.shape[-1] == 1:
             return _w(a * b)                     # [.., M, 1] . [.., 1, N]: outer product by broadcasting
-        return _w(torch.matmul(a, b))
+        # a true batched contraction has no call site in the in-scope models and no hand-written kernel here: refuse rather than
+        # hand it to a library GEMM without saying so
+        from mindrec_amd.wide_deep_mlp import UnsupportedNet
+        raise UnsupportedNet(f"BatchMatMul of {tuple(a.shape)} x {tuple(b.shape)}: only 2-D operands (the MFMA MatMul kernels) and "
+                             f"reductions of length 1 (CrossLayer's rank-1 scale, deep_and_cross.py:146) have a kernel")
 
 
 class ReduceSum(Primitive):

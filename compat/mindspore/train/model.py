@@ -131,6 +131,44 @@ class Model:
                 eng = low.engine
                 getattr(eng, "close", getattr(eng, "release_graphs", lambda: None))()
 
+    # ---- a row-sharded lowered train step: the cell's tables are mirrors of the ranks' shards (mindrec_amd/lowering.py) ----------
+    def sync_parameters(self):
+        """A collective (every rank calls it): the train cell's full-size tables / MapParameters are refreshed from all ranks'
+        shards.  Free when nothing was trained since the last call, and when the step is not a sharded lowering."""
+        low = getattr(self._train_network, "__dict__", {}).get("_lowered")
+        if low and getattr(low, "sharded", False):
+            low.sync()
+
+    @staticmethod
+    def _sync_plan(callbacks):
+        """More than one rank: every rank learns the periods at which SOME rank's ModelCheckpoint will read the parameters (the
+        reference checkpoints on rank 0 alone, train_and_eval_distribute.py:108-112), so that all ranks refresh the mirrors
+        together right before -- a checkpoint is a one-rank read, the refresh a collective.  -> [[period, last saved step], ...]"""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return None
+        from .callback import ModelCheckpoint
+        cbs = callbacks if isinstance(callbacks, (list, tuple)) else ([callbacks] if callbacks is not None else [])
+        mine = []
+        for cb in cbs:
+            if isinstance(cb, ModelCheckpoint):
+                mine.append((int(cb._config.save_checkpoint_steps or 1), int(cb._last_saved_step)))       # (seconds-based: every step)
+        every = [None] * dist.get_world_size()
+        dist.all_gather_object(every, mine)
+        return [list(x) for x in sorted({tuple(x) for r in every for x in r})]
+
+    @staticmethod
+    def _sync_if_due(net, p, plan, force=False):
+        low = getattr(net, "__dict__", {}).get("_lowered")
+        if not (plan is not None and low and getattr(low, "sharded", False)):
+            return
+        due = force
+        for st in plan:
+            if p.cur_step_num >= st[1] + st[0]:
+                st[1], due = p.cur_step_num, True
+        if due:
+            low.sync()
+
     @staticmethod
     def _lowered(network, batch=None):
         """GRAPH_MODE's compile step (mindspore/_lower.py): the fused engine behind a recognised train cell, or None."""
@@ -166,6 +204,7 @@ class Model:
         p.mode, p.loss_fn, p.optimizer, p.parallel_mode, p.device_number = "train", self._loss_fn, self._optimizer, self._parallel_mode, self._device_number
         p.train_dataset, p.list_callback, p.train_dataset_element = train_dataset, None, None
         p.cur_epoch_num, p.cur_step_num, p.dataset_sink_mode = initial_epoch, 0, dataset_sink_mode
+        sync_plan = self._sync_plan(callbacks)
         with _CallbackManager(callbacks) as cbs:
             self._check_reuse_dataset(train_dataset)
             rc = RunContext(p)
@@ -181,6 +220,7 @@ class Model:
                     cbs.on_train_step_begin(rc)
                     self._run_sink(net, helper, steps, p)
                     p.cur_step_num += steps
+                    self._sync_if_due(net, p, sync_plan)
                     cbs.on_train_step_end(rc)
                 else:
                     for batch in helper:
@@ -189,6 +229,7 @@ class Model:
                         cbs.on_train_step_begin(rc)
                         net = self._check_network_mode(net, True)
                         p.net_outputs = self._run_step(net, batch)
+                        self._sync_if_due(net, p, sync_plan)
                         cbs.on_train_step_end(rc)
                         if rc.get_stop_requested():
                             break
@@ -197,6 +238,7 @@ class Model:
                 cbs.on_train_epoch_end(rc)
                 if rc.get_stop_requested():
                     break
+            self._sync_if_due(net, p, sync_plan, force=True)          # (ModelCheckpoint saves once more at the end)
             cbs.on_train_end(rc)
 
     def _run_step(self, net, batch):

@@ -47,6 +47,14 @@ def save_checkpoint(save_obj, ckpt_file_name, integrated_save=True, async_save=F
         raise TypeError(f"For 'save_checkpoint', the argument 'ckpt_file_name' must be string, but got {type(ckpt_file_name)}.")
     if not ckpt_file_name.endswith(".ckpt"):
         ckpt_file_name += ".ckpt"
+    from ..nn.cell import Cell
+    if isinstance(save_obj, Cell):
+        for _, c in save_obj.cells_and_names():
+            low = c.__dict__.get("_lowered")
+            if low and getattr(low, "sharded", False) and low.dirty:
+                raise RuntimeError("save_checkpoint: this train cell runs as a ROW-SHARDED engine and its full-size tables are stale "
+                                   "mirrors of the ranks' shards; mindspore.Model.train refreshes them on every rank wherever a "
+                                   "ModelCheckpoint is due -- outside of it call Model.sync_parameters() on every rank first")
     out = {}
     for name, p in _items(save_obj):
         if choice_func is not None and not choice_func(name):

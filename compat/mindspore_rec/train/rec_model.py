@@ -44,6 +44,7 @@ class RecModel(Model):
     def _stream(self, dataset, cbs, p, sink, step_inc):
         p.cur_epoch_num, p.cur_step_num, p.dataset_sink_mode = 0, 0, sink
         rc = RunContext(p)
+        sync_plan = self._sync_plan(list(getattr(cbs, "_callbacks", [])))
         cbs.on_train_begin(rc)
         # sink mode: an "epoch" of the callback protocol is one sink of `step_inc` batches (the reference re-enters its dataset
         # helper once per epoch, rec_model.py:281-303 -- checkpoint names `<prefix>-<epoch>_<step>` count sinks); feed mode: one
@@ -59,6 +60,7 @@ class RecModel(Model):
                 cbs.on_train_step_begin(rc)
                 net = self._check_network_mode(net, True)
                 p.net_outputs = self._run_step(net, batch)
+                self._sync_if_due(net, p, sync_plan)
                 cbs.on_train_step_end(rc)
                 if rc.get_stop_requested():
                     break
@@ -67,4 +69,5 @@ class RecModel(Model):
             cbs.on_train_epoch_end(rc)
             if rc.get_stop_requested():
                 break
+        self._sync_if_due(net, p, sync_plan, force=True)
         cbs.on_train_end(rc)

@@ -1098,10 +1098,14 @@ MREC_API int mrec_dense_adam_slabs_finish_f32(float* p, float* m, float* v, cons
                                               const int32_t* splits, float lr, float b1, float b2, float eps, float b1_pow, float b2_pow,
                                               float grad_scale, int nesterov, void* step_state, const mrec_ftrl1_t* one,
                                               const mrec_apply_finish_t* finish, void* stream) {
-    if (!finish || n <= 0 || nseg < 0 || nseg > 16 || shadow_kind < 0 || shadow_kind > 2) return MREC_EINVAL;
+    if (!finish || n < 0 || nseg < 0 || nseg > 16 || shadow_kind < 0 || shadow_kind > 2) return MREC_EINVAL;
     const ApplyFinish* fp = (const ApplyFinish*)finish;
     if (fp->magic != kFinishMagic) return MREC_EINVAL;
-    if (!p || !m || !v || !g || (nseg > 0 && (!slabs || !starts || !lens || !splits)) || (shadow_kind && !shadow16)) return MREC_EINVAL;
+    if (n == 0) {            /* an empty dense buffer is a valid input (as for mrec_dense_adam_slabs_f32): only the finishing pass runs */
+        if (nseg != 0) return MREC_EINVAL;
+        nseg = 0; shadow_kind = 0;
+    }
+    if (n > 0 && (!p || !m || !v || !g || (nseg > 0 && (!slabs || !starts || !lens || !splits)) || (shadow_kind && !shadow16))) return MREC_EINVAL;
     if (n % 4 || !al16(p) || !al16(m) || !al16(v) || !al16(g) || (shadow16 && (((uintptr_t)shadow16) & 7))) return MREC_EUNSUPPORTED;
     SlabSegs sg;
     sg.n = nseg;
@@ -1129,6 +1133,7 @@ MREC_API int mrec_dense_adam_slabs_finish_f32(float* p, float* m, float* v, cons
     int64_t ab = mrec_cdiv(a.n4, 256);
     if (ab > 256 * 16) ab = 256 * 16;
     const unsigned grid = fp->lblocks + (unsigned)ab;
+    if (grid == 0) return MREC_OK;
     hipStream_t st = (hipStream_t)stream;
 #define MREC_FIN(KT)                                                                                      \
     do {                                                                                                   \

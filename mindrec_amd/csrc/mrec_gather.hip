@@ -701,10 +701,11 @@ int gather_bf16_impl(const float* table, int64_t V, int64_t ld, int32_t D, const
     if (V == 0) return MREC_EINVAL;      // rows are read unconditionally at clamped addresses: an empty table has no valid one
     if (!table || !ids || !out) return MREC_EINVAL;
     const bool vec = (D % 4 == 0) && (D <= 256) && (ld % 4 == 0) && al16(table) && ((((uintptr_t)out) & oa) == 0);
+    static const bool no_w16 = getenv("MREC_GATHER_W8") != nullptr;      // (debug knob: read once, not per lookup)
     const int64_t ldo_e = ldo ? ldo : D;
     const bool w16 = vec && ob == 2 && D % 8 == 0 && n % 4 == 0 && n >= 4 && ids_stride == 1 && rs_stride == 1 && !skip_invalid && ldw == 2 &&
                      ldo_e % 8 == 0 && al16(out) && (!wprod || al16(wprod)) && al16(ids) && (!row_scale || al16(row_scale)) &&
-                     !getenv("MREC_GATHER_W8");
+                     !no_w16;
     if (w16) {
         if constexpr (ob == 2) {
             const int lpr = D / 4 + (wprod ? 1 : 0);

@@ -107,7 +107,39 @@ class _DirectComm:
         """RCCL collectives on device tensors can be captured into a HIP graph (tools/probes/rccl_graph_probe.py); gloo cannot."""
         return dist.is_initialized() and dist.get_backend(self.group) == "nccl"
 
+    def all_gather_rows(self, t):
+        """[rows, ...] of every rank, concatenated in rank order (row counts may differ): what puts the shards of a table back
+        together for a checkpoint (mindrec_amd/lowering.py).  Not on the step's path."""
+        n = dist.get_world_size(self.group)
+        cnt = torch.tensor([t.shape[0]], dtype=torch.int64)
+        cnts = [torch.zeros_like(cnt) for _ in range(n)]
+        if dist.get_backend(self.group) == "nccl":
+            cnt = cnt.to(t.device)
+            cnts = [c.to(t.device) for c in cnts]
+        dist.all_gather(cnts, cnt, group=self.group)
+        cnts = [int(c) for c in cnts]
+        cap = max(cnts)
+        staged = self._staged(t)
+        src = t.contiguous().cpu() if staged else t.contiguous()
+        pad = torch.zeros((cap,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        pad[: src.shape[0]] = src
+        outs = [torch.empty_like(pad) for _ in range(n)]
+        dist.all_gather(outs, pad, group=self.group)
+        full = torch.cat([o[:c] for o, c in zip(outs, cnts)])
+        return (full.to(t.device) if staged else full), cnts
+
+    def _staged(self, t):
+        """A gloo group handed device tensors (several ranks sharing one GPU, a box without RCCL): gloo moves host memory, so the
+        message is staged through the host.  Same results; not capturable; RCCL never takes this branch."""
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
     def all_to_all(self, out, inp, out_splits=None, in_splits=None):
+        if self._staged(out):
+            i8 = inp.contiguous().view(inp.shape[0], -1).view(torch.uint8).cpu()         # (gloo has no 16-bit floats: ship bytes)
+            o8 = torch.empty((out.shape[0], out[0].numel() * out.element_size()), dtype=torch.uint8)
+            dist.all_to_all_single(o8, i8, out_splits, in_splits, group=self.group)
+            out.copy_(o8.view(out.dtype).view(out.shape))
+            return
         dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
     def all_to_all_lists(self, outs, ins):
@@ -116,6 +148,18 @@ class _DirectComm:
         exchange as point-to-point sends and receives -- which is what RCCL's all-to-all is made of."""
         if dist.get_backend(self.group) == "nccl":
             dist.all_to_all(outs, ins, group=self.group)
+            return
+        if any(self._staged(t) for t in list(outs) + list(ins)):
+            def host(t, fill):          # the same rows as bytes in host memory
+                h = torch.empty(t.shape[:-1] + (t.shape[-1] * t.element_size(),), dtype=torch.uint8)
+                if fill and t.numel():
+                    h.copy_(t.contiguous().view(torch.uint8))
+                return h
+            houts, hins = [host(t, False) for t in outs], [host(t, True) for t in ins]
+            self.all_to_all_lists(houts, hins)
+            for o, h in zip(outs, houts):
+                if o.numel():
+                    o.copy_(h.view(o.dtype).view(o.shape))
             return
         ops_ = []
         for r, (o, i) in enumerate(zip(outs, ins)):
@@ -138,6 +182,11 @@ class _DirectComm:
         its first asynchronous op (tools/probes/rccl_capture_race_probe.py reproduces it; it was the 'flaky'
         hipErrorCapturedEvent of rounds 3-4).  Eager reductions therefore run as the synchronous op on a stream of our own,
         which never captures; a synchronous op's event lives on the stream it was issued on."""
+        if self._staged(t):
+            c = t.cpu()
+            dist.all_reduce(c, group=self.group)
+            t.copy_(c)
+            return None
         if async_op and t.is_cuda:
             if torch.cuda.is_current_stream_capturing():
                 return dist.all_reduce(t, group=self.group, async_op=True)

@@ -12,7 +12,10 @@ def _engine_state(eng):
     return {
         "meta": {"rank": eng.rank, "world": eng.world, "vocab_size": eng.cfg.vocab_size, "emb_dim": eng.cfg.emb_dim,
                  "field_size": eng.cfg.field_size, "step_count": eng.step_count,
-                 "beta1_power": float(eng.beta1_power), "beta2_power": float(eng.beta2_power)},
+                 "beta1_power": float(eng.beta1_power), "beta2_power": float(eng.beta2_power),
+                 # which optimizer owns wide_b: under "ftrl" its m / v words of the dense buffer hold FTRL's accum / linear, under
+                 # "adam" Adam's moments -- the same bytes mean different things
+                 "wide_b_optimizer": getattr(eng.cfg, "wide_b_optimizer", "adam")},
         "tables": {"deep": eng.deep, "deep_m": eng.deep_m, "deep_v": eng.deep_v, "wide": eng.wide,
                    "wide_accum": eng.wide_accum, "wide_linear": eng.wide_linear},
         "dense": {"dense": eng.dense_flat.detach(), "dense_m": eng.dense_m, "dense_v": eng.dense_v, "wide_b": eng.wide_b},
@@ -65,6 +68,8 @@ def load_checkpoint(eng, path):
         if m[k] != have:
             raise ValueError(f"checkpoint {path}: {k} = {m[k]} but the engine has {have}")
     st = _engine_state(eng)
+    # checkpoints written before the marker existed (rounds 1-3) kept wide_b under Adam
+    saved_wb, have_wb = m.get("wide_b_optimizer", "adam"), getattr(eng.cfg, "wide_b_optimizer", "adam")
     if eng.hb is not None:
         raise NotImplementedError("load_checkpoint restores into resident tables; a checkpoint written by a host-cached engine loads "
                                   "into a resident engine of the same geometry")
@@ -85,6 +90,14 @@ def load_checkpoint(eng, path):
             for grp in ("tables", "dense"):
                 for k, dst in st[grp].items():
                     dst.copy_(ck[grp][k].to(dst.device))
+        if saved_wb != have_wb and hasattr(eng, "_wb_off"):
+            # the optimizer that owns wide_b changed between save and load: its two state words cannot be reinterpreted -- the new
+            # owner starts from its initial state (FTRL: accum = initial_accum, linear = 0; Adam: zero moments); the weight is kept
+            import warnings
+            warnings.warn(f"checkpoint {path}: wide_b was trained under {saved_wb!r}, this engine updates it with {have_wb!r}; "
+                          f"its optimizer state is reset")
+            eng.dense_m[eng._wb_off] = eng.cfg.ftrl_initial_accum if have_wb == "ftrl" else 0.0
+            eng.dense_v[eng._wb_off] = 0.0
         if eng.dense16 is not None:
             eng.dense16_flat.copy_(eng.dense_flat.detach())
             eng._refresh_tail()

@@ -82,7 +82,7 @@ class _Pick(nn.Cell):
 class WideDeepTrainStep(nn.Cell):
     """FTRL on the wide table and the wide bias, (Lazy)Adam on the rest, both seeded with sens (wide_and_deep.py:387-492)."""
 
-    def __init__(self, loss_net, lazy, sens=1024.0):
+    def __init__(self, loss_net, lazy, sens=1024.0, reduce=False):
         super().__init__()
         self.loss_net = loss_net
         ws = loss_net.trainable_params()
@@ -93,18 +93,27 @@ class WideDeepTrainStep(nn.Cell):
         self.grad = ops.GradOperation(get_by_list=True, sens_param=True)
         self.pick_w, self.pick_d = _Pick(loss_net, 0), _Pick(loss_net, 1)
         self.sens = sens
+        # data parallel (wide_and_deep.py:458-470,487-489): the mean of every rank's gradients before either optimizer sees them
+        self.reducer_flag = bool(reduce)
+        if reduce:
+            from mindspore.communication.management import get_group_size
+            from mindspore.nn.wrap.grad_reducer import DistributedGradReducer
+            self.reduce_w = DistributedGradReducer(self.w_wide, True, get_group_size())
+            self.reduce_d = DistributedGradReducer(self.w_deep, True, get_group_size())
 
     def construct(self, ids, wts, label):
         lw, ld = self.loss_net(ids, wts, label)
         seed = ops.Fill()(ops.DType()(lw), ops.Shape()(lw), self.sens)
         gw = self.grad(self.pick_w, self.w_wide)(ids, wts, label, seed)
         gd = self.grad(self.pick_d, self.w_deep)(ids, wts, label, seed)
+        if self.reducer_flag:
+            gw, gd = self.reduce_w(gw), self.reduce_d(gd)
         self.opt_wide(gw)
         self.opt_deep(gd)
         return lw, ld
 
 
-def wide_deep_from_fixture(z, cfg, comp, capacity=None):
+def wide_deep_from_fixture(z, cfg, comp, capacity=None, reduce=False):
     """The model above with the fixture's configuration and initial parameters; returns (train step, model)."""
     from mindspore import Tensor
     dyn = bool(cfg["dynamic_embedding"])
@@ -118,7 +127,8 @@ def wide_deep_from_fixture(z, cfg, comp, capacity=None):
         lay = getattr(net, f"layer{i}")
         lay.weight.set_data(Tensor(z[f"init/dense_layer_{i + 1}.weight"]))
         lay.bias.set_data(Tensor(z[f"init/dense_layer_{i + 1}.bias"]))
-    step = WideDeepTrainStep(WideDeepLoss(net, comp["l2_coef"], not comp["no_l2loss"]), lazy=comp["optimizer_d"] == "LazyAdam", sens=comp["sens"])
+    step = WideDeepTrainStep(WideDeepLoss(net, comp["l2_coef"], not comp["no_l2loss"]), lazy=comp["optimizer_d"] == "LazyAdam", sens=comp["sens"],
+                             reduce=reduce)
     step.set_train()
     return step, net
 

@@ -324,9 +324,11 @@ def test_lowered_deep_cross_script_matches_reference(ms_hip):
     assert np.allclose(net.lookup.embedding_table.asnumpy(), z["final/deep_embeddinglookup.embedding_table"], rtol=2e-4, atol=1e-7)
 
 
-def test_a_model_the_engine_does_not_compute_is_not_lowered(ms_hip):
+def test_a_model_the_engine_does_not_compute_is_not_lowered(ms_hip, caplog):
     """Structure alone does not prove the arithmetic: a Wide&Deep-shaped script whose hidden layers use tanh is recognised by
-    structure, fails the verification against its own eager forward, and is refused loudly instead of computed wrongly."""
+    structure, fails the verification against its own eager forward BEFORE anything of the cell is re-bound, and runs primitive by
+    primitive -- with a WARNING, once -- instead of being computed wrongly."""
+    import logging
     import _ms_models
     from mindspore import ops
     z, cfg, comp = RF.load("ref_wd_sparse")
@@ -334,5 +336,32 @@ def test_a_model_the_engine_does_not_compute_is_not_lowered(ms_hip):
     for i in range(net.n_layers - 1):
         getattr(net, f"layer{i}").act = ops.Tanh()
     batch = tuple(ms_hip.Tensor(z[k][0]) for k in ("ids", "wts", "label"))
-    with pytest.raises(RuntimeError, match="failed its verification"):
-        ms_hip.Model(step)._run_step(step, batch)
+    ptr = net.layer0.weight.data_ptr()
+    before = net.layer0.weight.asnumpy().copy()
+    with caplog.at_level(logging.WARNING, logger="mindspore"):
+        lw, ld = ms_hip.Model(step)._run_step(step, batch)
+    assert step.__dict__["_lowered"] is False and "differ from the cell's eager forward" in step._lowering_refused
+    assert any("NOT lowered" in r.getMessage() for r in caplog.records)
+    assert net.layer0.weight.data_ptr() == ptr                    # the cell kept its own memory ...
+    assert not np.array_equal(net.layer0.weight.asnumpy(), before) and np.isfinite(float(lw.asnumpy()))      # ... and trained eagerly
+
+
+def test_a_loss_the_engine_does_not_compute_is_not_lowered(ms_hip):
+    """The loss function is part of what the engine computes: a train cell whose loss is not the mean sigmoid cross-entropy of its
+    logits is refused by the first-loss check, as is an FTRL with another lr_power."""
+    import _ms_models
+    z, cfg, comp = RF.load("ref_wd_sparse")
+    batch = tuple(ms_hip.Tensor(z[k][0]) for k in ("ids", "wts", "label"))
+    step, net = _ms_models.wide_deep_from_fixture(z, cfg, comp)
+
+    class Doubled(type(step.loss_net)):
+        def construct(self, ids, wts, label):
+            lw, ld = super().construct(ids, wts, label)
+            return lw * 2.0, ld * 2.0
+    object.__setattr__(step.loss_net, "__class__", Doubled)          # (Cell.__setattr__ files plain attributes in its own dict)
+    ms_hip.Model(step)._run_step(step, batch)
+    assert step.__dict__["_lowered"] is False and "is not the mean sigmoid cross-entropy" in step._lowering_refused
+    step, net = _ms_models.wide_deep_from_fixture(z, cfg, comp)
+    step.opt_wide.lr_power = -0.4
+    ms_hip.Model(step)._run_step(step, batch)
+    assert step.__dict__["_lowered"] is False and "lr_power" in step._lowering_refused

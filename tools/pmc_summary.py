@@ -23,20 +23,30 @@ def load(d):
     return agg
 
 
-NAMES = {"apply_main_adam": "k_apply_main<4, int, UpdAdam", "gather_rows": "k_gather_rows<4, int",
-         "apply_main_ftrl": "k_apply_main<1, int, UpdFtrl", "wide_sum": "k_wide_sum<int>",
-         "dense_adam": "k_dense_adam4", "dedup_insert": "k_dedup_insert<int>", "head": "k_head_fwd_bwd",
-         "gemm_fwd": "k_gemm256<", "gemm_bwd": "k_gemm256_bwd<", "copy_1gib": "copyBuffer"}
+# key -> (substring of the demangled kernel name, required).  A required name that matches no launch is an ERROR (round 4 lost
+# the lookup and dense-Adam rows -- and with them the calibration -- to two renamed kernels without anybody noticing).
+NAMES = {"apply_main_adam": ("k_apply_main<4, int, UpdAdam", True),
+         "gather_rows": ("k_gather_rows_w16<int", True),                      # the fused-row 16-bit lookup (deep row + wide word)
+         "dense_adam": ("k_finish_dense_adam<", True),                         # dense Adam + the apply's finishing pass, one launch
+         "dedup_insert": ("k_dedup_insert<int>", True),
+         "gemm_fwd": ("k_gemm256<", True), "gemm_bwd": ("k_gemm256_bwd<", True), "tail": ("k_tail<", True),
+         "copy_1gib": ("copyBuffer", True),
+         # kernels of the non-default layouts (separate wide table, 4-byte stores): present only when those are benchmarked
+         "gather_rows_w8": ("k_gather_rows<4, int", False), "apply_main_ftrl": ("k_apply_main<1, int, UpdFtrl", False),
+         "wide_sum": ("k_wide_sum<int>", False), "head": ("k_head_fwd_bwd", False), "dense_adam_plain": ("k_dense_adam4", False)}
 
 
 def main(fetch_dir, write_dir, out_json=None, bench_line=None):
     fe, wr = load(fetch_dir), load(write_dir)
     res = {}
     print(f"{'kernel':18s} {'launches':>8s} {'read MB (2*FETCH)':>18s} {'write MB':>10s} {'total MB':>10s}")
-    for key, pat in NAMES.items():
+    missing = []
+    for key, (pat, required) in NAMES.items():
         f = [x for k, v in fe.items() if pat in k for x in v]
         w = [x for k, v in wr.items() if pat in k for x in v]
         if not f or not w:
+            if required:
+                missing.append(f"{key} ({pat!r})")
             continue
         if key == "copy_1gib":                       # keep the large copies only (the 1-GiB ones of bench.py)
             f = [x for x in f if x > 0.25 * max(f)]
@@ -62,6 +72,12 @@ def main(fetch_dir, write_dir, out_json=None, bench_line=None):
     res["calibration"] = cal
     if out_json:
         json.dump(res, open(out_json, "w"), indent=1)
+    if missing:
+        names = sorted({k for k in fe})
+        sys.exit("pmc_summary: no launch matched " + ", ".join(missing) + " -- a kernel was renamed; fix NAMES.  Kernels seen:\n  "
+                 + "\n  ".join(names))
+    if bench_line and "dense_adam" not in cal:
+        sys.exit("pmc_summary: the dense-Adam calibration is missing (no dense_adam_bytes in the bench line)")
 
 
 if __name__ == "__main__":
