@@ -57,7 +57,14 @@ namespace {
 #endif
 #ifndef MREC_WPS4
 #define MREC_WPS4 4         // waves per SIMD asked of the register allocator for the float4 + wide-lane kernel (128 VGPRs: the
-#endif                      // window's index words live in registers; 5 waves measured 5 % slower, 3 the same)
+#endif                      // window's index words live in registers; 5 waves measured 5 % slower; 3 the same on uniform ids but Zipf ids x 39
+                            // fields 96 -> 106 us -- round 5, a variant that needed 139 registers)
+#ifndef MREC_PAIRS
+#define MREC_PAIRS 1                 // a run of two entries that straddles a window boundary is summed by the window its first entry lies in (k_apply_main)
+#endif
+#ifndef MREC_PAIRS_DUP_DIV
+#define MREC_PAIRS_DUP_DIV 16        // ... in batches with at most n / 16 duplicate positions
+#endif
 #ifndef MREC_APPLY_MAXB
 #define MREC_APPLY_MAXB 4096u        // workgroups of k_apply_main (4 waves each; 1024 are resident at 4 waves per SIMD).  Sweep in profiles/r03_apply_chain.txt:
                                      // duplicate-heavy ids want a cap (Zipf x 39 fields: 121 us uncapped, 94-95 at 1024-4096), uniform ids none (172 / 176 us at 4096 / 2048)
@@ -366,6 +373,10 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     // contiguous stretch of the list): a new wave pays a chain of scalar round trips -- kernel arguments in pieces, the step
     // state, the device-side length -- before its first index word, as long as the window's own chain.
     const int64_t sw_stride = (int64_t)gridDim.x * 4 * gm.G;
+    // Straddling pairs are summed in place (below) only where duplicates are rare.  The same decision in every wave of every
+    // window: the number of groups is the last entry's group number + 1.
+    const int n_groups = n > 0 ? sseg[n - 1] + 1 : 0;
+    const bool pairs_on = MREC_PAIRS && (int64_t)(n - n_groups) * MREC_PAIRS_DUP_DIV <= (int64_t)n;
     for (int64_t sw = ((int64_t)blockIdx.x * 4 + wave) * gm.G + grp; sw * AW < n; sw += sw_stride) {
     const int s = (int)(sw * AW);
     const int e_end = (s + AW < n) ? s + AW : n;
@@ -380,7 +391,13 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     // basic block each, and a value that is converted (sign-extended, widened) inside its block is waited for inside it: the
     // eight row numbers of a window were eight dependent round trips, the two gradient rows and the state rows of a batch
     // three.  One wave's chain on an idle chip: 14.6 us before, see profiles/r03_apply_chain.txt.
-    int posw[AW], segw[AW + 1];
+    // PAIRS: a run of exactly two entries that straddles a window boundary (what a nearly duplicate-free batch has instead of
+    // long runs: uniform ids) is summed by the window its first entry lies in -- entry AW, the first one behind the window, is that
+    // window's ninth entry -- and skipped by the next one.  Both decide from index words alone (the run's other neighbours), so
+    // they agree; the pair is summed in position order like every run inside a window, and leaves no partial sums: such a batch
+    // needs no finishing pass at all.  Only where duplicates are rare (`pairs_on`, the same in every wave): on duplicate-heavy ids
+    // a wave would hold one lane-group that walks a ninth entry while the other two wait.
+    int posw[AW + GP], segw[AW + GP];          // (the loop below walks whole batches of GP entries: AW + 1 rounded up)
     const int nlast = n - 1;
 #pragma unroll
     for (int q = 0; q < AW; ++q) {
@@ -389,7 +406,12 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
         segw[q] = sseg[e];
     }
     segw[AW] = sseg[s + AW < nlast ? s + AW : nlast];
+    posw[AW] = spos[s + AW < nlast ? s + AW : nlast];
     const int seg_before = sseg[s > 0 ? s - 1 : 0];
+    const int seg_before2 = sseg[s > 1 ? s - 2 : 0];
+    const int seg_after = sseg[s + AW + 1 < nlast ? s + AW + 1 : nlast];
+#pragma unroll
+    for (int q = AW + 1; q < AW + GP; ++q) { posw[q] = 0; segw[q] = -2; }
 #pragma unroll
     for (int q = 0; q < AW; ++q) {
         const bool valid = s + q < e_end;
@@ -399,10 +421,20 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     if (!(s + AW < n)) segw[AW] = -2;
     const int first_seg = segw[0];
     const bool head_open = (s > 0) && (seg_before == first_seg);
+    // the head entry is the second half of a pair the window before this one sums
+    const bool head_pair = pairs_on && head_open && segw[1] != first_seg && (s < 2 || seg_before2 != first_seg);
+    // the last entry is the first half of a pair whose second half lies right behind the window
+    const bool tail_pair = pairs_on && s + AW < n && segw[AW] == segw[AW - 1] && segw[AW - 2] != segw[AW - 1] &&
+                           (s + AW + 1 >= n || seg_after != segw[AW]);
     unsigned endm = 0u, openm = 0u;                       // bit q: entry q ends its run / belongs to the run open at the head
-    int64_t rowv[AW];                                     // table row of the run that ends at entry q (-1: none / out of range)
+    // (held at the width of the ids: 32-bit ids name 32-bit rows -- registers, in the kernel that sits at its register budget)
+    typedef typename std::conditional<sizeof(K) == 4, int, int64_t>::type RowT;
+    RowT rowv[AW + GP];                                   // table row of the run that ends at entry q (-1: none / out of range)
 #pragma unroll
-    for (int q = 0; q < AW; ++q) rowv[q] = seg_row<K>(uniq, segw[q] < 0 ? 0 : segw[q]);
+    for (int q = 0; q < AW; ++q) rowv[q] = (RowT)seg_row<K>(uniq, segw[q] < 0 ? 0 : segw[q]);
+    rowv[AW] = tail_pair ? rowv[AW - 1] : (RowT)-1;
+#pragma unroll
+    for (int q = AW + 1; q < AW + GP; ++q) rowv[q] = (RowT)-1;
     // (the window's last group and the next window's first are index words it already holds; where the last run ends is
     // requested with the row numbers, not behind the window's stores: a load there waits for them -- vmcnt counts in order)
     int last_seg = segw[0];
@@ -416,16 +448,20 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
         const bool open = head_open && segw[q] == first_seg;
         endm |= is_end ? (1u << q) : 0u;
         openm |= open ? (1u << q) : 0u;
-        rowv[q] = (is_end && !open) ? rowv[q] : (int64_t)-1;
+        rowv[q] = (is_end && !open) ? rowv[q] : (RowT)-1;
     }
+    endm |= tail_pair ? (1u << AW) : 0u;
+    if (!tail_pair) posw[AW] = 0;
+    if (head_pair) posw[0] = posw[1];                     // (skipped: its gradient row is not this window's -- request a line it fetches anyway)
+    const int e_end2 = e_end + (tail_pair ? 1 : 0);       // the entries this window walks
     asm volatile("" : "+v"(last_end));      // landed with the row numbers (needed here: see vtouch)
     // (A two-round-trip path for windows that own no run end -- all eight gradient rows at once, no row numbers; half of the
     // windows on Zipf ids x 39 fields -- was built and measured: 94.6-95.5 us against 95.6-96.1, not kept.)
     Vf<VEC> acc;
     vzero(acc);
 #pragma unroll
-    for (int jb = 0; jb < AW; jb += GP) {
-        if (s + jb >= e_end) break;
+    for (int jb = 0; jb < AW + GP; jb += GP) {
+        if (s + jb >= e_end2) break;
         GBits<VEC, GT> gb[GP];
         float rsv[GP], gwq[GP];
 #pragma unroll
@@ -439,13 +475,13 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
 #pragma unroll
         for (int sb = 0; sb < GP / AB; ++sb) {
             const int j0 = jb + sb * AB;
-            if (s + j0 >= e_end) break;
+            if (s + j0 >= e_end2) break;
             bool upd_ok[AB];
             int64_t roff[AB];
             Vf<VEC> st[AB][Upd::NS];
 #pragma unroll
             for (int k = 0; k < AB; ++k) {
-                const int64_t row = rowv[j0 + k];
+                const int64_t row = (int64_t)rowv[j0 + k];
                 upd_ok[k] = row >= 0 && row < V;
                 roff[k] = upd_ok[k] ? row * ld + col : 0;
                 if (upd_ok[k] && Upd::kLoad) {
@@ -472,13 +508,13 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
 #pragma unroll
             for (int k = 0; k < AB; ++k) {
                 const int q = j0 + k;
-                if (s + q >= e_end) continue;
+                if (s + q >= e_end2) continue;
                 Vf<VEC> x = xs[k];
                 const bool is_start = q == 0 || segw[q] != segw[q - 1];
                 if (is_start) acc = x; else vadd(acc, x);
                 if ((endm >> q) & 1u) {
                     if ((openm >> q) & 1u) {
-                        vstore<false>(carry_head + sw * gm.D + ccol, acc);
+                        if (!head_pair) vstore<false>(carry_head + sw * gm.D + ccol, acc);
                     } else if (upd_ok[k]) {
                         if (WIDE && wl) wide_apply(st[k][0], acc, wa.h);
                         else upd_apply<Upd>(upd, st[k], acc);
@@ -494,7 +530,9 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     // a run with few partials (finished by one lane-group of k_apply_long), 2 = a long run (a block's job).
     // Every window writes its flag, so the list needs neither clearing nor an atomic counter.
     int flag = 0;
-    if (e_end < n && segw[AW] == last_seg) {
+    if (tail_pair) {
+        // (the pair was summed and applied above: nothing is carried)
+    } else if (e_end < n && segw[AW] == last_seg) {
         if (head_open && last_seg == first_seg) {
             vstore<false>(carry_head + sw * gm.D + ccol, acc);  // window lies wholly inside one run
         } else {
@@ -703,8 +741,10 @@ __device__ __forceinline__ void apply_long_body(Upd upd, int64_t V, int64_t ld, 
             __syncthreads();
         }
     }
-    // end stamp (measurement): the last-dispatched workgroups raise it -- one atomic each, 256 at most
-    if (ss && threadIdx.x == 0 && bid + 256 >= nblocks)
+    // end stamp (measurement): the workgroups that had a run to finish raise it -- one atomic each.  A step whose batch left no
+    // partial sums behind (uniform ids since round 5: straddling pairs are summed by k_apply_main) has no finishing work and
+    // no finishing stamp: its apply ends with k_apply_main's own end stamp.
+    if (ss && threadIdx.x == 0 && cnt_a + cnt > 0)
         atomicMax((unsigned long long*)&ss->aux[(unsigned)ss->step % kStampRing][2], (unsigned long long)wall_clock64());
 }
 

@@ -1024,8 +1024,9 @@ class StepState:
         for k in steps:
             a0, a1, l0, l1, e2 = (int(st[k % self.RING][0]), int(st[k % self.RING][1]), int(aux[k % self.RING][0]), int(aux[k % self.RING][1]),
                                   int(aux[k % self.RING][2]))
-            if a1 > a0 and a0 != 0xFFFFFFFFFFFFFFFF and l1 > l0 and l0 != 0xFFFFFFFFFFFFFFFF and e2 >= a1:
-                out.append(((l1 - l0) / self.clock_khz, (e2 - a0) / self.clock_khz))
+            if a1 > a0 and a0 != 0xFFFFFFFFFFFFFFFF and l1 > l0 and l0 != 0xFFFFFFFFFFFFFFFF and (e2 >= a1 or e2 == 0):
+                # (e2 == 0: no workgroup of the finishing pass had a run to finish in this step -- the apply ended with k_apply_main)
+                out.append(((l1 - l0) / self.clock_khz, (max(e2, a1) - a0) / self.clock_khz))
         return out
 
 

@@ -338,6 +338,8 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         # the step's Unique + inverted index runs on a side stream, under the MLP
         # (default priority: a high-priority side stream was measured at 1.52 ms/step instead of 0.88)
         self._side = torch.cuda.Stream(device=self.device) if self._gpu else None
+        import os
+        self._plan_fork = os.environ.get("MREC_PLAN_FORK", "lookup")       # where the captured step forks its plan branch: "lookup" | "head"
         self.deep_apply_timer = None  # optional ops.KernelTimer armed right before the deep table's sparse apply
         self._dyn = False             # step scalars (Adam powers / step size) in device memory: set per step
         self._front_graph = None      # one-GPU: the whole front of the step (lookups .. MLP backward) as one captured graph
@@ -502,9 +504,10 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
             # they run beside stretch each other by about the same amount wherever the plan sits (behind the first GEMM: 0.774);
             # the chain cut in two -- the insert kernel here, the rest behind the first GEMM through a second event -- 0.853 ms:
             # another cross-branch dependency, and the graph runtime serialises more than the dependencies ask for)
-            self._side.wait_event(fork_ev)
-            with torch.cuda.stream(self._side):
-                plan_early = self.k.sparse_plan(ids)
+            if self._plan_fork == "lookup":
+                self._side.wait_event(fork_ev)
+                with torch.cuda.stream(self._side):
+                    plan_early = self.k.sparse_plan(ids)
         if self._side is not None and plan_early is None:
             # Side stream, in this order: (1) the wide branch, which the main stream joins only right before the
             # output head -- it runs while the hidden-layer GEMMs do; (2) the step's Unique + inverted index, which
@@ -532,6 +535,16 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
             after_head = None
             if self._fold_wide:
                 wide_done = True             # the wide table's FTRL rides the deep table's apply (train_step)
+                if fork_ev is not None and plan_early is None:
+                    # MREC_PLAN_FORK=head: the plan's branch starts behind the output head, beside the BACKWARD launches (multi-round
+                    # grids: a CU the plan's kernels slow down simply takes fewer workgroups) instead of beside the lookup and the
+                    # one-round layer-0 forward, whose slowest CU sets its time
+                    box = {}
+
+                    def after_head(_gw):
+                        self._side.wait_event(torch.cuda.current_stream().record_event())
+                        with torch.cuda.stream(self._side):
+                            box["plan"] = self.k.sparse_plan(ids)
             elif plan_early is not None and self._side is not None and cfg.sparse:
                 def after_head(gw_b):
                     # wide FTRL beside the backward GEMMs: needs only the plan (already on the side stream, in order)
@@ -548,6 +561,8 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
                 loss, g_emb, g_wide = self._mlp_step_eager(emb, wide, label, after_head=after_head)
             else:
                 loss, g_emb, g_wide = self._mlp_step(emb, wide, label, after_head=after_head)
+            if plan_early is None and fork_ev is not None:
+                plan_early = box["plan"]
         elif self._f32net:
             loss, g_emb, g_wide = self._mlp_step_f32(emb, wide, label)   # the fp32 net by hand (ops.dense32_*)
         else:
