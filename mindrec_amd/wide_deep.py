@@ -558,7 +558,10 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
                                             l1=cfg.ftrl_l1, l2=cfg.ftrl_l2, grad_scale=inv_sens)
                 wide_done = True
             if capturing:
-                loss, g_emb, g_wide = self._mlp_step_eager(emb, wide, label, after_head=after_head)
+                bh = None
+                if after_head is not None and self._plan_fork == "fwd" and self._fold_wide:
+                    bh, after_head = (lambda: after_head(None)), None      # MREC_PLAN_FORK=fwd: behind the forward GEMMs, beside the tail launch
+                loss, g_emb, g_wide = self._mlp_step_eager(emb, wide, label, after_head=after_head, before_head=bh)
             else:
                 loss, g_emb, g_wide = self._mlp_step(emb, wide, label, after_head=after_head)
             if plan_early is None and fork_ev is not None:

@@ -408,13 +408,15 @@ class DenseNetMixin:
         self._sum_dw_slabs()
         return loss.view(()), dh, dlogit.view(-1)
 
-    def _mlp_step_eager(self, emb, wide, label, after_head=None):
+    def _mlp_step_eager(self, emb, wide, label, after_head=None, before_head=None):
         """Forward + backward of the mixed-precision MLP written out by hand (no autograd graph).  `emb` arrives
         in 16 bits straight from the gather kernel, and the gradient of the MLP input is returned in 16 bits
         for the sparse apply to widen on load.  Weights are read from their 16-bit shadows (no per-step cast kernels).
         Returns (loss, g_emb [B, F*D] 16-bit, g_wide [B] fp32).  after_head(g_wide) is called as soon as the wide
         branch's gradient exists (the caller may start the wide table's update beside the backward GEMMs)."""
         hs = self._mlp_fwd(emb)
+        if before_head is not None:
+            before_head()
         if callable(wide):
             wide = wide()                  # joins whatever stream computed the wide branch; returns the tensor
         ctx = self._mlp_head(hs, wide, label)
