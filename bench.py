@@ -219,7 +219,7 @@ def cpu_baseline(args, seconds):
                       f"fwd+bwd; MindSpore CPU not installable here"}
 
 
-def zipf39_line(args, eng, dev, peak):
+def zipf39_line(args, eng, dev, peak, clock_off=None):
     """The embedding path under Criteo-like ids (Zipf, 39 fields) through a second engine sharing the first one's tables."""
     import torch
     from mindrec_amd import ops
@@ -246,17 +246,22 @@ def zipf39_line(args, eng, dev, peak):
     by = embedding_bytes(n, U, args.emb_dim, act_bytes=2)
     apply_b = by["apply_deep"] + U * 24 + args.batch * 4
     lookup_b = by["lookup"] + U * 4 + n * 4
-    a_ms = sum(main_ms) / len(main_ms)
-    l_ms = sum(a for a, _ in st) / len(st)
-    all_ms = sum(b for _, b in st) / len(st)
+    off = clock_off or {"apply_main_us": 0.0, "lookup_us": 0.0}      # dispatch overhead by rocprofv3's clock (see _measure)
+    a_st, l_st, all_st = sum(main_ms) / len(main_ms), sum(a for a, _ in st) / len(st), sum(b for _, b in st) / len(st)
+    a_ms, l_ms, all_ms = a_st + off["apply_main_us"] * 1e-3, l_st + off["lookup_us"] * 1e-3, all_st + off["apply_main_us"] * 1e-3
     del e2
     return {"workload": f"same tables, batch {args.batch} x 39 fields, Zipf(1.05) ids per slot + the 13 constant dense-field ids", "unique_frac": round(U / n, 4),
             "ms_per_step": round(ms, 4), "samples_per_s": round(args.batch / ms * 1e3, 1),
             "kernel": "k_apply_main (dominant)", "algorithmic_bytes": apply_b, "avg_ms": round(a_ms, 5),
             "achieved": round(apply_b / (a_ms * 1e-3) / 1e9, 1), "peak": peak, "unit": "GB/s", "frac": round(apply_b / (a_ms * 1e-3) / 1e9 / peak, 4),
             "embedding_path": {"algorithmic_bytes": lookup_b + apply_b, "lookup_ms": round(l_ms, 5), "apply_ms_incl_finishing_kernel": round(all_ms, 5),
-                               "frac": round((lookup_b + apply_b) / ((l_ms + all_ms) * 1e-3) / 1e9 / peak, 4)},
-            "timing": f"in-graph kernel stamps over {len(st)} steps behind the timed region"}
+                               "frac": round((lookup_b + apply_b) / ((l_ms + all_ms) * 1e-3) / 1e9 / peak, 4),
+                               "frac_stamps": round((lookup_b + apply_b) / ((l_st + all_st) * 1e-3) / 1e9 / peak, 4),
+                               # begin of k_apply_main -> the LAST workgroup of the finishing pass that had a run to finish (round 5:
+                               # until round 4 only the last-dispatched 256 workgroups raised the end stamp, which missed the ones that
+                               # finish the 13 constant ids' 16384-entry runs -- first in the grid, last to end: ~29 us of this)
+                               "finishing_pass_ms": round(all_st - a_st, 5)},
+            "timing": f"in-graph kernel stamps over {len(st)} steps behind the timed region" + (" + the dispatch overhead by rocprofv3's clock" if clock_off else "")}
 
 
 def main():
@@ -437,7 +442,23 @@ def _measure(args, world, rank, dev):
     fold = bool(eng._fold_wide and world == 1)
     apply_bytes = by["apply_deep"] + (U * 24 + args.batch * 4 if fold else 0)
     lookup_bytes = by["lookup"] + (U * 4 + n_apply * 4 if fold else 0)
-    apply_ms = sum(kmain) / len(kmain)
+    apply_ms_stamps = sum(kmain) / len(kmain)
+    # The profiler's clock.  rocprofv3 times a dispatch from the command processor's begin to its end signal; the kernels' own
+    # stamps (first workgroup in -> last wave out) leave out the few microseconds in front of the first workgroup and behind the
+    # last wave.  That difference is a property of the launch, measured where BOTH clocks saw the same launches -- this command
+    # under `rocprofv3 --kernel-trace --stats` (tools/clock_offsets.py: rocprof's average duration - the stamps' average, per
+    # kernel, committed as profiles/rNN_clock_offsets.json) -- and added here, so that `roofline.frac` is what the profiler's
+    # clock would read on THIS box; the stamps stay as secondary fields.
+    clock_off, clock_src = {"apply_main_us": 0.0, "lookup_us": 0.0}, None
+    if eng._step_graph is not None:
+        for rnd in ("r05", "r04"):
+            cp = os.path.join(ROOT, "profiles", f"{rnd}_clock_offsets.json")
+            if os.path.exists(cp):
+                c_ = json.load(open(cp))
+                clock_off = {k: float(c_[k]) for k in clock_off}
+                clock_src = f"profiles/{rnd}_clock_offsets.json"
+                break
+    apply_ms = apply_ms_stamps + clock_off["apply_main_us"] * 1e-3
     achieved = apply_bytes / (apply_ms * 1e-3) / 1e9
     peak = 8000.0
     # HBM bytes per launch of the dominant kernel come from the committed PMC passes (profiles/: rocprofv3 --pmc FETCH_SIZE /
@@ -447,7 +468,7 @@ def _measure(args, world, rank, dev):
     default_cfg = (args.vocab == 200_000_000 and args.emb_dim == 80 and args.batch == 16384 and args.fields == 26
                    and args.dist == "uniform" and not args.split_state and world == 1 and args.mlp_dtype in ("bf16", "fp16")
                    and not args.shard_protocol)
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if default_cfg and os.path.exists(pmc_path):
             traffic = json.load(open(pmc_path)).get("apply_main_adam", {}).get("total_bytes")
@@ -505,6 +526,9 @@ def _measure(args, world, rank, dev):
                      "row_gradient_dtype": dt_name if io16 else "f32", "wide_folded": fold,
                      "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": apply_bytes, "avg_ms": round(apply_ms, 5),
+                     "clock": ("rocprofv3's: the kernel's own stamps + the dispatch overhead measured under rocprofv3 (" + clock_src + ")") if clock_src
+                              else "the kernel's own stamps / HIP events (no committed clock offsets)",
+                     "avg_ms_stamps": round(apply_ms_stamps, 5), "frac_stamps": round(apply_bytes / (apply_ms_stamps * 1e-3) / 1e9 / peak, 4),
                      "avg_ms_hip_events_eager": round(sum(ev_ms) / len(ev_ms), 5) if ev_ms else None,
                      "measured_copy_gbps": copy_gbps,
                      "timing": apply_timing.format(n=len(kmain))},
@@ -514,17 +538,21 @@ def _measure(args, world, rank, dev):
     }
     lookup_timing = "torch events around the gather in eager extra steps after the timed region"
     apply_all_ms = None
+    lookup_ms_stamps = apply_all_stamps = None
     if fold and embed_stamps:
-        # in-graph truth: both kernels stamp the device wall clock themselves in every timed step
-        lookup_ms = sum(a for a, _ in embed_stamps) / len(embed_stamps)
-        apply_all_ms = sum(b for _, b in embed_stamps) / len(embed_stamps)
+        # in-graph truth: both kernels stamp the device wall clock themselves in every timed step (+ the dispatch overhead, above)
+        lookup_ms_stamps = sum(a for a, _ in embed_stamps) / len(embed_stamps)
+        apply_all_stamps = sum(b for _, b in embed_stamps) / len(embed_stamps)
+        lookup_ms = lookup_ms_stamps + clock_off["lookup_us"] * 1e-3
+        apply_all_ms = apply_all_stamps + clock_off["apply_main_us"] * 1e-3
         lookup_timing = (f"device wall-clock stamps written by the lookup kernel itself inside the timed steps' graph (first workgroup begin -> last "
                          f"wave end of the last-dispatched workgroups), averaged over {len(embed_stamps)} timed steps")
     if world == 1 and lookup_ms:
         out["roofline_lookup"] = {"bound": "hbm", "kernel": "k_gather_rows (EmbeddingLookup, mask fused%s)" % (" + the row's wide word" if fold else ""),
                                   "achieved": round(lookup_bytes / (lookup_ms * 1e-3) / 1e9, 1),
                                   "peak": peak, "unit": "GB/s", "frac": round(lookup_bytes / (lookup_ms * 1e-3) / 1e9 / peak, 4),
-                                  "algorithmic_bytes": lookup_bytes, "avg_ms": round(lookup_ms, 5), "timing": lookup_timing}
+                                  "algorithmic_bytes": lookup_bytes, "avg_ms": round(lookup_ms, 5), "timing": lookup_timing,
+                                  "avg_ms_stamps": round(lookup_ms_stamps, 5) if lookup_ms_stamps else None}
         tot_b = tot_ms = None
         if fold:
             # both tables' lookup and apply are these kernels (the per-sample sum of the wide products is in the head kernel); the
@@ -540,12 +568,16 @@ def _measure(args, world, rank, dev):
                                               "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / peak, 4), "algorithmic_bytes": tot_b,
                                               "sum_ms": round(tot_ms, 5), "lookup_ms": round(lookup_ms, 5),
                                               "apply_ms_incl_finishing_kernel": round(apply_all_ms, 5) if apply_all_ms is not None else None,
-                                              "timing": "in-graph kernel stamps" if apply_all_ms is not None else "events in eager extra steps; k_apply_long not counted"}
+                                              "timing": ("in-graph kernel stamps + the dispatch overhead of both kernels by rocprofv3's clock (" + str(clock_src) + ")")
+                                                        if apply_all_ms is not None else "events in eager extra steps; k_apply_long not counted",
+                                              "frac_stamps": round(tot_b / ((lookup_ms_stamps + apply_all_stamps) * 1e-3) / 1e9 / peak, 4)
+                                                             if apply_all_stamps is not None else None,
+                                              "finishing_pass_ms": round(apply_all_stamps - apply_ms_stamps, 5) if apply_all_stamps is not None else None}
     if default_cfg and "roofline_embedding_path" in out:
         # The same quantities from rocprofv3's clock: average kernel durations of the committed `rocprofv3 --kernel-trace --stats`
         # run of this command (profiles/rNN_bench_kernel_summary.txt; NOT measured in this run).  The apply's finishing pass has no
         # kernel of its own since round 4 (it is the first workgroups of the dense Adam launch, k_finish_dense_adam).
-        for rnd in ("r04",):
+        for rnd in ("r05", "r04"):
             sp = os.path.join(ROOT, "profiles", f"{rnd}_bench_kernel_summary.txt")
             if os.path.exists(sp):
                 avg = {}
@@ -561,7 +593,7 @@ def _measure(args, world, rank, dev):
                     t_us = avg["k_apply_main<"] + ga + avg.get("k_apply_long<", 0.0)
                     # the finishing pass has no rocprof duration of its own: its length by this run's stamps (end of the finishing
                     # work - end of k_apply_main) is added for the figure that counts everything
-                    fin_us = max(0.0, (apply_all_ms - apply_ms) * 1e3) if (apply_all_ms is not None and "k_apply_long<" not in avg) else 0.0
+                    fin_us = max(0.0, (apply_all_stamps - apply_ms_stamps) * 1e3) if (apply_all_stamps is not None and "k_apply_long<" not in avg) else 0.0
                     out["roofline_embedding_path"]["rocprof"] = {
                         "source": f"profiles/{rnd}_bench_kernel_summary.txt (separate rocprofv3 --kernel-trace --stats run of this command)",
                         "apply_main_us": avg["k_apply_main<"], "lookup_us": ga, "apply_long_us": avg.get("k_apply_long<"),
@@ -583,7 +615,7 @@ def _measure(args, world, rank, dev):
         # (process_data.py:138-147) -- on a second engine that trains on the SAME tables: the duplicate-heavy case of the same
         # kernels (U / N ~ 0.2), a secondary line, not `value`
         try:
-            out["roofline_zipf39"] = zipf39_line(args, eng, dev, peak)
+            out["roofline_zipf39"] = zipf39_line(args, eng, dev, peak, clock_off if clock_src else None)
         except Exception as e:       # noqa: BLE001  (a secondary measurement must not take the line down)
             out["roofline_zipf39"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     if world > 1 or args.shard_protocol:

@@ -206,3 +206,45 @@ def check_data_parallel_fixture(make_engine, dev):
     assert row_rel(eng.deep.cpu().numpy(), z["rank0/final/embedding_table"]) <= 1e-5
     assert np.allclose(eng.wide.cpu().numpy(), z["rank0/final/wide_embeddinglookup.embedding_table"], rtol=1e-4, atol=1e-8)
     assert json.loads(str(z["ckpts"])) == ["widedeep_train-1_2.ckpt"]            # rank 0 alone checkpoints (train_and_eval_distribute.py:108-110)
+
+
+# ---- fixtures at CONFIGURATION size (tests/golden/make_ref_fixtures_cfgsize.py): inputs and initial parameters are too large to
+# ---- commit, so both sides derive them from these functions; the fixture holds what the REFERENCE's code computed from them -------
+def cfgsize_param(name, shape, sigma=0.01):
+    """Initial value of the parameter `name`: the oracle's counter-based N(0, sigma^2) stream keyed by a CRC of the name."""
+    import zlib
+    from oracle import oracle as O
+    shape = tuple(int(x) for x in shape)
+    rows = shape[0]
+    cols = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+    return O.fill_normal(zlib.crc32(name.encode()) & 0x7FFFFFFF, rows, cols, sigma).reshape(shape)
+
+
+def cfgsize_batches(seed, S, B, F, V):
+    """Criteo-like batches: with 39 fields the first 13 are the constant ids 0..12 with fractional weights
+    (datasets/criteo_1tb/process_data.py:138-147), the rest Zipf(1.05) ids with weight 1 (:149-162); labels Bernoulli(0.3)."""
+    rng = np.random.default_rng(seed)
+    nd = 13 if F == 39 else 0
+    ids = (np.minimum(rng.zipf(1.05, size=(S, B, F)), V - nd - 1) + nd - 1 + 1).astype(np.int32)
+    wts = np.ones((S, B, F), np.float32)
+    if nd:
+        ids[:, :, :nd] = np.arange(nd, dtype=np.int32)
+        wts[:, :, :nd] = rng.random((S, B, nd)).astype(np.float32)
+    label = (rng.random((S, B, 1)) < 0.3).astype(np.float32)
+    return ids, wts, label
+
+
+def cfgsize_summary(a, n=32):
+    """What a fixture keeps of a large tensor: sum, sum of squares (float64) and n elements at fixed places."""
+    a = np.asarray(a, np.float32).reshape(-1)
+    idx = (np.arange(n, dtype=np.int64) * 2654435761 + 12345) % a.size
+    return np.concatenate([[a.astype(np.float64).sum(), (a.astype(np.float64) ** 2).sum()], a[idx].astype(np.float64)])
+
+
+def cfgsize_rows(ids, V, n=1024):
+    """Row numbers a fixture keeps of a table: n of the rows the batches touched (the hottest included) and n / 4 they did not."""
+    touched = np.unique(ids)
+    rng = np.random.default_rng(99)
+    t = np.unique(np.concatenate([touched[:16], rng.choice(touched, size=min(n, touched.size), replace=False)]))
+    free = np.setdiff1d(rng.integers(0, V, size=n), touched)[: n // 4]
+    return t.astype(np.int64), free.astype(np.int64)

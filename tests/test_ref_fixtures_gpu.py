@@ -365,3 +365,79 @@ def test_a_loss_the_engine_does_not_compute_is_not_lowered(ms_hip):
     step.opt_wide.lr_power = -0.4
     ms_hip.Model(step)._run_step(step, batch)
     assert step.__dict__["_lowered"] is False and "lr_power" in step._lowering_refused
+
+
+# ---- the reference's own model code at CONFIGURATION size (tests/golden/make_ref_fixtures_cfgsize.py) ---------------------------------
+def _cfgsize_init(comp):
+    return {"init/" + k: RF.cfgsize_param(k, tuple(comp["shapes"][k]), comp["sigma"][k]) for k in comp["shapes"]}
+
+
+def _check_summary(name, got, ref, rtol_sum, rtol_el, lr_steps):
+    """sum / sum of squares / 32 elements of a dense parameter against what the reference's run left (Adam: an element whose gradient is
+    ~0 may step +-lr either way, so elements are held to a few steps of lr on top of the relative bar)."""
+    g = RF.cfgsize_summary(got)
+    assert abs(g[1] - ref[1]) <= rtol_sum * abs(ref[1]) + 1e-12, (name, "sum of squares", g[1], ref[1])
+    assert np.all(np.abs(g[2:] - ref[2:]) <= rtol_el * np.abs(ref[2:]) + lr_steps), (name, np.abs(g[2:] - ref[2:]).max())
+
+
+@pytest.mark.timeout(600)
+def test_deep_cross_engine_at_configuration_size_matches_the_reference_code(dev):
+    """BASELINE configs[2] -- batch 16384, 39 x 30, 1170-1024-1024, 6 cross layers, fp32 -- run by the REFERENCE's DeepCrossModel /
+    NetWithLossClass / TrainStepWrap (ref_dcn_cfg2.npz) against the product engine's large-shape dispatch (three-part GEMMs, batch
+    slabs, the row-looking-up Adam over the table, the whole step as one graph from the third step on): losses, sampled table rows
+    (touched and untouched), every dense parameter's sum of squares and 32 of its elements, evaluation logits."""
+    from mindrec_amd.deep_cross import DeepCrossConfig, DeepCrossEngine
+    z, cfg, comp = RF.load("ref_dcn_cfg2")
+    eng = DeepCrossEngine(DeepCrossConfig(vocab_size=cfg["vocab_size"], emb_dim=cfg["emb_dim"], field_size=cfg["field_size"],
+                                          batch_size=cfg["batch_size"], deep_layer_dim=list(cfg["deep_layer_dim"]),
+                                          cross_layer_num=cfg["cross_layer_num"], learning_rate=comp["lr"], eps=comp["eps"],
+                                          loss_scale=comp["loss_scale"]), dev)
+    assert eng._native
+    RF.dcn_load_init(eng, _cfgsize_init(comp))
+    ids, wts, label = RF.cfgsize_batches(comp["batch_seed"], comp["steps"], cfg["batch_size"], cfg["field_size"], cfg["vocab_size"])
+    losses = np.array([float(eng.train_step(*(torch.from_numpy(a[s]).to(dev) for a in (ids, wts, label)))) for s in range(comp["steps"])])
+    assert np.allclose(losses, z["loss"], rtol=1e-5, atol=0), (losses, z["loss"])
+    st = RF.dcn_state(eng)
+    table = st.pop("deep_embeddinglookup.embedding_table")
+    assert np.array_equal(table[z["rows_free"]], z["table_free"]) or np.allclose(table[z["rows_free"]], z["table_free"], rtol=2e-4, atol=1e-7)
+    lr_steps = 2.5 * comp["lr"] * comp["steps"]
+    assert np.all(np.abs(table[z["rows_touched"]] - z["table_touched"]) <= 2e-4 * np.abs(z["table_touched"]) + lr_steps)
+    assert np.mean(np.abs(table[z["rows_touched"]] - z["table_touched"]) <= 2e-4 * np.abs(z["table_touched"]) + 0.02 * comp["lr"]) > 0.99
+    for k, v in st.items():
+        _check_summary(k, v, z["sum/" + k], 1e-5, 2e-4, lr_steps)
+    logit, _ = eng.predict(*(torch.from_numpy(a[-1]).to(dev) for a in (ids, wts)))
+    assert np.allclose(logit.cpu().numpy().reshape(-1)[:256], z["eval_logits"], rtol=1e-3, atol=2e-4)
+
+
+@pytest.mark.timeout(600)
+def test_wide_deep_engine_at_the_benchmarked_shape_matches_the_reference_code(dev):
+    """The benchmarked step's shape -- batch 16384, 39 fields, dim 80, the 1024-512-256-128 net in the reference's fp16, LazyAdam + FTRL
+    on row gradients -- run by the REFERENCE's WideDeepModel / NetWithLossClass / TrainStepWrap (ref_wd_cfg1.npz; vocabulary 200 000)
+    against the product engine with everything on: fused rows, the folded wide branch, the fused tail launch, graphs.  The fp16 net is
+    held within the reference's own double rounding (its DenseLayer rounds the MatMul output and the bias sum separately, :121-126)."""
+    from mindrec_amd.wide_deep import WideDeepEngine
+    z, cfg, comp = RF.load("ref_wd_cfg1")
+    eng = WideDeepEngine(RF.wd_config(cfg, comp), dev)
+    assert eng._mfma and eng._fold_wide
+    init = _cfgsize_init(comp)
+    RF.wd_load_init(eng, init)
+    ids, wts, label = RF.cfgsize_batches(comp["batch_seed"], comp["steps"], cfg["batch_size"], cfg["field_size"], cfg["vocab_size"])
+    losses = np.array([float(eng.train_step(*(torch.from_numpy(a[s]).to(dev) for a in (ids, wts, label)))) for s in range(comp["steps"])])
+    assert np.allclose(losses, z["loss_w"], rtol=5e-4, atol=0), (losses, z["loss_w"])
+    deep, wide = eng.deep.cpu().numpy(), eng.wide.cpu().numpy()
+    t, f = z["rows_touched"], z["rows_free"]
+    assert np.array_equal(deep[f], z["deep_free"]) and np.array_equal(wide[f], z["wide_free"])       # LazyAdam / sparse FTRL: untouched rows do not move
+    d0, w0 = init["init/embedding_table"], init["init/wide_embeddinglookup.embedding_table"]
+    step = np.abs(z["deep_touched"] - d0[t]).max()
+    assert np.abs(deep[t] - z["deep_touched"]).max() <= 0.15 * step                                    # the updates agree to 15 % of the largest update ...
+    assert RF.row_rel(deep[t], z["deep_touched"]) <= 2e-4                                              # ... and the rows to 2e-4 of their own scale
+    wstep = np.abs(z["wide_touched"] - w0[t]).max()
+    assert np.abs(wide[t] - z["wide_touched"]).max() <= 0.15 * wstep
+    for k, v in RF.wd_dense_state(eng).items():
+        ref = z["sum/" + k]
+        g = RF.cfgsize_summary(v)
+        i0 = RF.cfgsize_summary(init["init/" + k])
+        upd = np.abs(ref[2:] - i0[2:]).max()
+        assert np.abs(g[2:] - ref[2:]).max() <= 0.15 * upd + 1e-7, (k, np.abs(g[2:] - ref[2:]).max(), upd)
+    logit, _ = eng.predict(*(torch.from_numpy(a[-1]).to(dev) for a in (ids, wts)))
+    assert np.allclose(logit.cpu().numpy().reshape(-1)[:256], z["eval_logits"], rtol=2e-2, atol=2e-3)

@@ -11,15 +11,20 @@ O=$R/gpurun_out/final
 mkdir -p $O
 if [ "$PART" = 1 ]; then
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/bench_line.json 2> $O/bench.err
-echo "bench done"; cut -c1-200 $O/bench_line.json
-python3 $R/bench.py --mlp-dtype bf16 --no-cpu-baseline --no-zipf39 > $O/bench_line_bf16.json 2>> $O/bench.err
-python3 $R/bench.py --dropout --no-cpu-baseline --no-zipf39 > $O/bench_line_dropout.json 2>> $O/bench.err
+RND=${RND:-r05}
+# the profiler's clock first: kernel statistics of the benchmarked command, and what rocprofv3 adds to the kernels' own stamps
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-zipf39 > $O/bench_line_under_rocprof.json 2> $O/prof.err
 cp $(find $O/prof -name "*kernel_stats.csv") $O/bench_kernel_stats.csv
 python3 $R/tools/prof_summary.py $O/bench_kernel_stats.csv > $O/bench_kernel_summary.txt
 python3 $R/tools/step_timeline.py $O/prof > $O/step_timeline_under_rocprof.txt 2>&1
+python3 $R/tools/clock_offsets.py $O/bench_line_under_rocprof.json $O/bench_kernel_summary.txt $O/clock_offsets.json
+cp $O/clock_offsets.json $R/profiles/${RND}_clock_offsets.json            # (the lines below are printed with THIS run's offsets and summary)
+cp $O/bench_kernel_summary.txt $R/profiles/${RND}_bench_kernel_summary.txt
 echo "prof done"
+python3 $R/bench.py > $O/bench_line.json 2> $O/bench.err
+echo "bench done"; cut -c1-200 $O/bench_line.json
+python3 $R/bench.py --mlp-dtype bf16 --no-cpu-baseline --no-zipf39 > $O/bench_line_bf16.json 2>> $O/bench.err
+python3 $R/bench.py --dropout --no-cpu-baseline --no-zipf39 > $O/bench_line_dropout.json 2>> $O/bench.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 6 --warmup 2 --repeats 1 --prime-steps 0 --no-cpu-baseline --no-zipf39 > $O/pmc_bench_line.json 2> $O/pmc1.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 6 --warmup 2 --repeats 1 --prime-steps 0 --no-cpu-baseline --no-zipf39 > /dev/null 2> $O/pmc2.err
 python3 $R/tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json $O/pmc_bench_line.json > $O/pmc_traffic.txt
