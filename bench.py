@@ -58,6 +58,9 @@ def parse():
                     "of the optimizers, the dense net only, or nothing (kernel by kernel)")
     ap.add_argument("--shard-protocol", action="store_true", help="one GPU: run the row-shard protocol (routing kernels + RCCL collectives "
                     "that talk to themselves) -- what a rank of an N-GPU job does besides moving bytes over xGMI")
+    ap.add_argument("--shard-uniques", type=float, default=0.0, help="row shards: exchange the batch's UNIQUE ids (one fp32 row / one summed "
+                    "gradient row per unique id) with room for this many unique ids per position (Criteo-like ids: 0.3); 0: one 16-bit "
+                    "row per position")
     ap.add_argument("--capacity-factor", type=float, default=None, help="row shards: request slots per owner = ceil(factor * ids / ranks); "
                     "default 1.05 for uniform ids (an owner's share of 425 984 uniform ids is within 0.6 %% of the mean at 12 sigma for 8 ranks), "
                     "1.25 otherwise (the engine's default); a run that drops a position is refused")
@@ -336,7 +339,8 @@ def _measure(args, world, rank, dev):
     cfg = WideDeepConfig(vocab_size=args.vocab, emb_dim=args.emb_dim, field_size=args.fields, batch_size=args.batch,
                          mlp_dtype=args.mlp_dtype, fused_state=not args.split_state, graphs=args.graphs,
                          dynamic_embedding=args.dynamic_embedding, hash_capacity=args.hash_capacity,
-                         host_cache_rows=args.host_cache_rows, shard_capacity_factor=args.capacity_factor, dropout_flag=args.dropout)
+                         host_cache_rows=args.host_cache_rows, shard_capacity_factor=args.capacity_factor, dropout_flag=args.dropout,
+                         shard_unique_factor=args.shard_uniques)
     eng = WideDeepEngine(cfg, dev, rank=rank, world=world, shard_protocol=args.shard_protocol)
     _ENGINES.append(eng)
     batches = [synthetic_batch(cfg, dev, args.dist, seed=1000 + i, rank=rank) for i in range(args.n_batches)]
@@ -620,16 +624,30 @@ def _measure(args, world, rank, dev):
             out["roofline_zipf39"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     if world > 1 or args.shard_protocol:
         # what a first multi-GPU run needs in order to be diagnosable from its one line
-        ns = eng.k.shard_capacity(args.batch * args.fields, world, args.capacity_factor) * world
-        W = eng.k.shard_msg_words(args.emb_dim, eng._act)[1]
+        uq = float(args.shard_uniques)
+        N_ = args.batch * args.fields
+        ns = eng.k.shard_capacity(max(int(N_ * uq), 1) if uq > 0 else N_, world, args.capacity_factor) * world
+        W = eng.k.shard_msg_words(args.emb_dim, torch.float32 if uq > 0 else eng._act)[1]
         off = (world - 1) / world                  # a rank's own chunk never moves
         id_b = 8 if batches[0][0].dtype == torch.int32 else 16
+
+        def model(nw, uqf, act):                   # bytes a rank puts on xGMI per step and direction at nw ranks (its own chunk stays)
+            slots = eng.k.shard_capacity(max(int(N_ * uqf), 1) if uqf > 0 else N_, nw, args.capacity_factor) * nw
+            Wm = eng.k.shard_msg_words(args.emb_dim, torch.float32 if uqf > 0 else act)[1]
+            o_ = (nw - 1) / nw
+            return {"slots_per_rank": slots, "request": int(slots * id_b * o_), "answer": int(slots * Wm * 4 * o_), "gradient": int(slots * Wm * 4 * o_)}
         out["rccl"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
                        "own_chunk_bypass": bool(eng._bypass),          # did _exchange_selftest keep the per-peer-list exchange?
                        "whole_step_graph": eng._step_graph is not None,
                        "slots_per_rank": ns, "capacity_factor": args.capacity_factor,
                        "a2a_bytes_per_rank_per_step": {"request": int(ns * id_b * off), "answer": int(ns * W * 4 * off),
                                                        "gradient": int(ns * W * 4 * off)},
+                       "exchange": "unique ids (fp32 rows / summed gradient rows)" if uq > 0 else "positions (16-bit rows)", "unique_factor": uq,
+                       # the byte model of an 8-rank node, whatever this run's world size (at world 1 nothing moves): today's
+                       # per-position exchange against the unique-level one at this run's unique ids per position
+                       "a2a_bytes_model_n8": {"positions": model(8, 0.0, eng._act),
+                                              "uniques": model(8, max(uq, min(1.0, round(U / max(n_apply, 1) * 1.0, 4))) if world == 1 else uq, eng._act),
+                                              "unique_ids_per_position_measured": round(U / max(n_apply, 1), 4) if world == 1 and uq == 0 else None},
                        "allreduce_bytes_per_step": int(eng.dense_grad_full.numel() * 4),
                        "kernels_ms_keys": ["route", "a2a_rows", "unroute", "a2a_grads", "allreduce_dense"]}
         # dropped positions: the count every rank holds is the SUM over all ranks (it rides the dense all-reduce), so all ranks

@@ -177,6 +177,10 @@ int mrec_sparse_apply_window(int32_t D, int aligned16);
 int mrec_segment_sum_f32(const int32_t* sorted_pos, const int32_t* sorted_seg, const int32_t* seg_offsets,
                          int64_t n, const float* g, int64_t ldg, const float* row_scale, float grad_scale,
                          int32_t D, float* out, void* ws, size_t ws_bytes, void* stream);
+/* The same over 16-bit row gradients (g_kind 1: bf16, 2: IEEE half; ldg in 16-bit elements), widened exactly, summed in fp32. */
+int mrec_segment_sum_g16(const int32_t* sorted_pos, const int32_t* sorted_seg, const int32_t* seg_offsets,
+                         int64_t n, const void* g, int32_t g_kind, int64_t ldg, const float* row_scale, float grad_scale,
+                         int32_t D, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* nn.LazyAdam on a RowTensor gradient (wide_and_deep.py:420-422).  b1_pow/b2_pow are
  * beta^t AFTER this step's multiply.  Rows outside [0,V) are skipped. */
@@ -789,6 +793,16 @@ int mrec_shard_route_slots_i32(const int32_t* ids, const float* wts, int64_t n, 
 int mrec_shard_route_slots_i64(const int64_t* ids, const float* wts, int64_t n, int32_t n_shards, int64_t cap, int hashed,
                                int32_t chunk_rot, void* req, int32_t* slot_of_pos, int32_t* pos_of_slot, int64_t* overflow_dev, void* ws,
                                size_t ws_bytes, void* stream);
+/* mrec_shard_route_slots_* over a list whose LENGTH lives on the device (*n_valid_dev <= n; entries past it are nobody's: no slot,
+ * slot_of_pos = -1, no overflow): a step's UNIQUE ids straight out of mrec_dedup_* (uniq, n_uniq_dev) -- the reference dedups in
+ * front of the sharded lookup too (Unique().shard(((1,),)), models/wide_deep/src/wide_and_deep.py:212; embedding.py:189-195).
+ * An owner then answers one row per unique id and receives one summed gradient row per unique id (mindrec_amd/wide_deep_shard.py). */
+int mrec_shard_route_slots_nv_i32(const int32_t* ids, const float* wts, int64_t n, const int64_t* n_valid_dev, int32_t n_shards,
+                                  int64_t cap, int hashed, int32_t chunk_rot, void* req, int32_t* slot_of_pos, int32_t* pos_of_slot,
+                                  int64_t* overflow_dev, void* ws, size_t ws_bytes, void* stream);
+int mrec_shard_route_slots_nv_i64(const int64_t* ids, const float* wts, int64_t n, const int64_t* n_valid_dev, int32_t n_shards,
+                                  int64_t cap, int hashed, int32_t chunk_rot, void* req, int32_t* slot_of_pos, int32_t* pos_of_slot,
+                                  int64_t* overflow_dev, void* ws, size_t ws_bytes, void* stream);
 int mrec_shard_unpack_req(const void* req, int32_t id_bytes, int64_t n_slots, void* ids_out, float* wts_out, void* stream);
 int mrec_shard_unroute_slots(const float* back, int64_t W, const int32_t* slot_of_pos, int64_t n, int32_t Dw, float* emb_out,
                              float* wprod_out, void* stream);

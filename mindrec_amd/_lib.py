@@ -58,6 +58,8 @@ _SIGS = {
     "mrec_shard_route_slots_workspace_bytes": [_i64, _i32, _szp],
     "mrec_shard_route_slots_i32": [_vp, _vp, _i64, _i32, _i64, _int, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_shard_route_slots_i64": [_vp, _vp, _i64, _i32, _i64, _int, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_shard_route_slots_nv_i32": [_vp, _vp, _i64, _vp, _i32, _i64, _int, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mrec_shard_route_slots_nv_i64": [_vp, _vp, _i64, _vp, _i32, _i64, _int, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mrec_shard_unpack_req": [_vp, _i32, _i64, _vp, _vp, _vp],
     "mrec_shard_unroute_slots": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_shard_route_grads": [_vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp, _i64, _vp],
@@ -70,6 +72,7 @@ _SIGS = {
     "mrec_sparse_apply_workspace_bytes": [_i64, _i32, _szp],
     "mrec_sparse_apply_window": [_i32, _int],
     "mrec_segment_sum_f32": [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _f32, _i32, _vp, _vp, _sz, _vp],
+    "mrec_segment_sum_g16": [_vp, _vp, _vp, _i64, _vp, _i32, _i64, _vp, _f32, _i32, _vp, _vp, _sz, _vp],
     "mrec_sparse_lazy_adam_f32_i32": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
                                       _f32, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp, _sz, _vp],
     "mrec_sparse_lazy_adam_f32_i64": [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,

@@ -1022,6 +1022,22 @@ MREC_API int mrec_segment_sum_f32(const int32_t* sorted_pos, const int32_t* sort
                                          ldg, row_scale, grad_scale, ws, ws_bytes, stream);
 }
 
+/* ... over 16-bit row gradients (g_kind 1: bf16, 2: IEEE half), widened exactly and summed in fp32: what a rank of a row-sharded
+ * step sends an owner when it exchanges UNIQUE ids -- one fp32 sum per unique id instead of one 16-bit row per position. */
+MREC_API int mrec_segment_sum_g16(const int32_t* sorted_pos, const int32_t* sorted_seg, const int32_t* seg_offsets,
+                                  int64_t n, const void* g, int32_t g_kind, int64_t ldg, const float* row_scale, float grad_scale,
+                                  int32_t D, float* out, void* ws, size_t ws_bytes, void* stream) {
+    UpdStore u;
+    u.s[0] = out;
+    if (g_kind == 1)
+        return apply_impl<int32_t, UpdStore, bf16_t>(u, n, D, D, (const int32_t*)nullptr, sorted_pos, sorted_seg, seg_offsets, n, (const bf16_t*)g,
+                                                     ldg, row_scale, grad_scale, ws, ws_bytes, stream);
+    if (g_kind == 2)
+        return apply_impl<int32_t, UpdStore, f16_t>(u, n, D, D, (const int32_t*)nullptr, sorted_pos, sorted_seg, seg_offsets, n, (const f16_t*)g,
+                                                    ldg, row_scale, grad_scale, ws, ws_bytes, stream);
+    return MREC_EINVAL;
+}
+
 MREC_API int mrec_sparse_lazy_adam_f32_i32(float* p, float* m, float* v, int64_t V, int64_t ld, int32_t D,
                                            const int32_t* uniq, const int32_t* sorted_pos, const int32_t* sorted_seg,
                                            const int32_t* seg_offsets, int64_t n, const float* g, int64_t ldg,

@@ -25,11 +25,12 @@ __device__ __forceinline__ int owner_of(K id, int S, bool hash) {
 
 template <class K>
 __global__ __launch_bounds__(256) void k_owner(const K* __restrict__ ids, int64_t n, int S, int* __restrict__ owner, bool hash,
-                                               int rot = 0) {
+                                               int rot = 0, const int64_t* __restrict__ nv = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     int c = owner_of(ids[i], S, hash) - rot;      // the message chunk of the id's owner (rot = 0: chunk = owner)
     if (c < 0) c += S;
+    if (nv && i >= *nv) c = S;                    // not an entry (the list's length lives on the device): nobody's, sorted behind every owner's
     owner[i] = c;
 }
 
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void k_route_slots(const K* __restrict__ ids, 
                                                      int64_t cap, const int* __restrict__ perm, const int* __restrict__ dbase,
                                                      ReqEntry<K>* __restrict__ req, int* __restrict__ slot_of_pos,
                                                      int* __restrict__ pos_of_slot, unsigned long long* __restrict__ overflow,
-                                                     bool hash, int rot) {
+                                                     bool hash, int rot, const int64_t* __restrict__ nv = nullptr) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t < n) {
         const int pos = perm[t];
@@ -188,7 +189,9 @@ __global__ __launch_bounds__(256) void k_route_slots(const K* __restrict__ ids, 
         int c = o - rot;                                   // the owner's chunk of the message
         if (c < 0) c += S;
         const int64_t j = t - dbase[c];
-        if (j < cap) {
+        if (nv && pos >= *nv) {
+            slot_of_pos[pos] = -1;                         // past the list's device-side length: no entry, no slot, no overflow
+        } else if (j < cap) {
             const int64_t s = (int64_t)c * cap + j;
             ReqEntry<K> e{};
             e.id = hash ? id : (id - (K)o) / (K)S;
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(256) void k_route_slots(const K* __restrict__ ids, 
     if (t < (int64_t)S * cap) {
         const int o = (int)(t / cap);
         const int64_t j = t - (int64_t)o * cap;
-        const int64_t cnt = (int64_t)((o + 1 < S) ? dbase[o + 1] : (int)n) - dbase[o];
+        const int64_t cnt = (int64_t)((o + 1 < S || nv) ? dbase[o + 1] : (int)n) - dbase[o];      // (nv: bucket S -- nobody's -- starts at dbase[S])
         if (j >= cnt) {
             ReqEntry<K> e{};
             e.id = (K)-1;
@@ -308,9 +311,9 @@ __global__ __launch_bounds__(256) void k_route_grads(const float* __restrict__ g
 
 template <class K>
 int route_slots_impl(const K* ids, const float* wts, int64_t n, int32_t S, int64_t cap, int hashed, int32_t rot, void* req, int32_t* slot_of_pos,
-                     int32_t* pos_of_slot, int64_t* overflow_dev, void* ws, size_t ws_bytes, void* stream) {
+                     int32_t* pos_of_slot, int64_t* overflow_dev, void* ws, size_t ws_bytes, void* stream, const int64_t* nv = nullptr) {
     hipStream_t st = (hipStream_t)stream;
-    if (n <= 0 || S <= 0 || S > RNB || cap <= 0 || !ids || !req || !slot_of_pos || !pos_of_slot || !overflow_dev || !ws) return MREC_EINVAL;
+    if (n <= 0 || S <= 0 || S + (nv ? 1 : 0) > RNB || cap <= 0 || !ids || !req || !slot_of_pos || !pos_of_slot || !overflow_dev || !ws) return MREC_EINVAL;
     if (rot < 0 || rot >= S) return MREC_EINVAL;
     if (n > (int64_t(1) << 30) || (int64_t)S * cap > (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
     if (((uintptr_t)req) & (sizeof(ReqEntry<K>) - 1)) return MREC_EINVAL;
@@ -325,12 +328,12 @@ int route_slots_impl(const K* ids, const float* wts, int64_t n, int32_t S, int64
     int* perm = a.take<int>(n);
     if (!a.ok) return MREC_EWORKSPACE;
     int nbits = 1;
-    while ((1 << nbits) < S) ++nbits;
-    k_owner<K><<<(unsigned)mrec_cdiv(n, 256), 256, 0, st>>>(ids, n, S, owner, hashed != 0, rot);
+    while ((1 << nbits) < S + (nv ? 1 : 0)) ++nbits;
+    k_owner<K><<<(unsigned)mrec_cdiv(n, 256), 256, 0, st>>>(ids, n, S, owner, hashed != 0, rot, nv);
     radix_pass(owner, nullptr, (int)n, 0, nbits, hist, hscan, totals, dbase, okeys, perm, st);
     const int64_t m = n > (int64_t)S * cap ? n : (int64_t)S * cap;
     k_route_slots<K><<<(unsigned)mrec_cdiv(m, 256), 256, 0, st>>>(ids, wts, n, S, cap, perm, dbase, (ReqEntry<K>*)req, slot_of_pos,
-                                                                 pos_of_slot, (unsigned long long*)overflow_dev, hashed != 0, rot);
+                                                                 pos_of_slot, (unsigned long long*)overflow_dev, hashed != 0, rot, nv);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
@@ -462,6 +465,22 @@ MREC_API int mrec_shard_route_slots_i64(const int64_t* ids, const float* wts, in
                                         int32_t chunk_rot, void* req, int32_t* slot_of_pos, int32_t* pos_of_slot, int64_t* overflow_dev,
                                         void* ws, size_t ws_bytes, void* stream) {
     return route_slots_impl<int64_t>(ids, wts, n, n_shards, cap, hashed, chunk_rot, req, slot_of_pos, pos_of_slot, overflow_dev, ws, ws_bytes, stream);
+}
+/* ... of a list whose length lives on the device (a step's UNIQUE ids: mrec_dedup_* writes n_uniq_dev): entries at and past
+ * *n_valid_dev are nobody's -- no slot (slot_of_pos = -1), no overflow. */
+MREC_API int mrec_shard_route_slots_nv_i32(const int32_t* ids, const float* wts, int64_t n, const int64_t* n_valid_dev, int32_t n_shards,
+                                           int64_t cap, int hashed, int32_t chunk_rot, void* req, int32_t* slot_of_pos, int32_t* pos_of_slot,
+                                           int64_t* overflow_dev, void* ws, size_t ws_bytes, void* stream) {
+    if (!n_valid_dev) return MREC_EINVAL;
+    return route_slots_impl<int32_t>(ids, wts, n, n_shards, cap, hashed, chunk_rot, req, slot_of_pos, pos_of_slot, overflow_dev, ws, ws_bytes, stream,
+                                     n_valid_dev);
+}
+MREC_API int mrec_shard_route_slots_nv_i64(const int64_t* ids, const float* wts, int64_t n, const int64_t* n_valid_dev, int32_t n_shards,
+                                           int64_t cap, int hashed, int32_t chunk_rot, void* req, int32_t* slot_of_pos, int32_t* pos_of_slot,
+                                           int64_t* overflow_dev, void* ws, size_t ws_bytes, void* stream) {
+    if (!n_valid_dev) return MREC_EINVAL;
+    return route_slots_impl<int64_t>(ids, wts, n, n_shards, cap, hashed, chunk_rot, req, slot_of_pos, pos_of_slot, overflow_dev, ws, ws_bytes, stream,
+                                     n_valid_dev);
 }
 MREC_API int mrec_shard_unpack_req(const void* req, int32_t id_bytes, int64_t n_slots, void* ids_out, float* wts_out, void* stream) {
     if (n_slots < 0 || (id_bytes != 4 && id_bytes != 8)) return MREC_EINVAL;

@@ -324,12 +324,16 @@ def segment_sum(plan, g, row_scale=None, grad_scale=1.0):
     are the per-unique-id sums (rows >= U are unspecified)."""
     _need_cuda(g, row_scale)
     D = g.shape[-1]
-    g2, ldg = _grads(plan, g, D)
+    g2, ldg = _grads(plan, g, D, allow_bf16=True)
     rs = _row_scale(plan, row_scale)
     out = torch.empty((max(plan.n, 1), D), dtype=torch.float32, device=g.device)
     ws = _apply_ws(plan, D, g.device)
-    _lib.call("mrec_segment_sum_f32", _ptr(plan.sorted_pos), _ptr(plan.sorted_seg), _ptr(plan.seg_offsets), plan.n,
-              _ptr(g2), ldg, _ptr(rs), grad_scale, D, _ptr(out), _ptr(ws), ws.numel(), _stream())
+    if g2.dtype == torch.float32:
+        _lib.call("mrec_segment_sum_f32", _ptr(plan.sorted_pos), _ptr(plan.sorted_seg), _ptr(plan.seg_offsets), plan.n,
+                  _ptr(g2), ldg, _ptr(rs), grad_scale, D, _ptr(out), _ptr(ws), ws.numel(), _stream())
+    else:       # 16-bit row gradients (what the mixed-precision MLP backward produces): widened exactly, summed in fp32
+        _lib.call("mrec_segment_sum_g16", _ptr(plan.sorted_pos), _ptr(plan.sorted_seg), _ptr(plan.seg_offsets), plan.n,
+                  _ptr(g2), 1 if g2.dtype == torch.bfloat16 else 2, ldg, _ptr(rs), grad_scale, D, _ptr(out), _ptr(ws), ws.numel(), _stream())
     return out
 
 
@@ -872,7 +876,7 @@ def shard_capacity(n, n_shards, factor=1.25):
     return int(min(n, -(-c // 64) * 64))
 
 
-def shard_route_slots(ids, wts, n_shards, cap, hashed=False, overflow=None, rot=0, out=None):
+def shard_route_slots(ids, wts, n_shards, cap, hashed=False, overflow=None, rot=0, out=None, n_valid_dev=None):
     """Request message of a step (all owners, `cap` slots each): returns (req, slot_of_pos int32 [n], pos_of_slot int32
     [n_shards * cap]); req is int32 [n_shards * cap, 2] ({id, weight bits}) for int32 ids, int64-addressable
     [n_shards * cap, 2] ({key, weight bits | 0}) for int64.  overflow: int64 [1] device counter (sticky).  rot: owner o's slots
@@ -898,6 +902,12 @@ def shard_route_slots(ids, wts, n_shards, cap, hashed=False, overflow=None, rot=
             raise TypeError("wts must be float32 with one value per id")
     nb = _lib.query_bytes("mrec_shard_route_slots_workspace_bytes", n, n_shards)
     ws = workspace("route_slots", nb, dev)
+    if n_valid_dev is not None:
+        # the list's length lives on the device (a step's unique ids: Dedup.n_uniq_dev): entries past it get no slot
+        _need_cuda(n_valid_dev)
+        _lib.call(f"mrec_shard_route_slots_nv_{sfx}", _ptr(flat), _ptr(w), n, _ptr(n_valid_dev), int(n_shards), int(cap), int(bool(hashed)),
+                  int(rot), _ptr(req), _ptr(slot_of_pos), _ptr(pos_of_slot), _ptr(overflow), _ptr(ws), ws.numel(), _stream())
+        return req, slot_of_pos, pos_of_slot
     _lib.call(f"mrec_shard_route_slots_{sfx}", _ptr(flat), _ptr(w), n, int(n_shards), int(cap), int(bool(hashed)), int(rot), _ptr(req),
               _ptr(slot_of_pos), _ptr(pos_of_slot), _ptr(overflow), _ptr(ws), ws.numel(), _stream())
     return req, slot_of_pos, pos_of_slot

@@ -79,6 +79,10 @@ class WideDeepConfig:
                                      # reference's vocab_cache_size, wide_and_deep.py:215-265)
     shard_capacity_factor: float = 1.25   # row shards: request slots a rank reserves per owner = ceil(factor * ids / ranks) -- every
                                           # message of a sharded step has a static shape (mindrec_amd/wide_deep_shard.py)
+    shard_unique_factor: float = 0.0      # > 0: row shards exchange the batch's UNIQUE ids (one fp32 row / one summed gradient row per
+                                          # unique id) instead of one 16-bit row per position; the value is the unique ids a batch may
+                                          # hold per position (capacity = shard_capacity_factor * this * ids / ranks).  Criteo-like ids:
+                                          # 0.2-0.3 unique per position (mindrec_amd/wide_deep_shard.py)
     graphs: str = "step"           # what replays as HIP graphs: "step" the whole step (sinks of steps: train_steps), "front" everything in
                                    # front of the optimizers, "mlp" the dense net only, "none" kernel by kernel
     fused_tail: bool = True        # the last two hidden layers, the output head and their input-gradient bprops as one launch

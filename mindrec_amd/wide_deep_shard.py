@@ -22,6 +22,15 @@ host-known shape: no bucket sizes cross the host, and with a capturable communic
 included -- is ONE HIP graph per rank.  A position that finds its bucket full is dropped and counted in a sticky device
 counter (`shard_overflow()`, checked by the caller once per sink: such a step is not a valid step).
 
+UNIQUE-level exchange (`WideDeepConfig.shard_unique_factor` > 0; round 5).  The reference dedups in front of the sharded lookup
+(Unique().shard(((1,),)), wide_and_deep.py:212; embedding.py:189-195), and Criteo-like batches hold 0.2-0.3 unique ids per position:
+the requester routes its batch's UNIQUE ids (mrec_shard_route_slots_nv_*: the list's length lives on the device), the owner answers
+one fp32 row per unique id ([row | wide weight], no mask), the requester fans the answers out to its positions with the one-GPU
+fused lookup kernel over the returned message as its table (fp32 row x the position's weight, rounded once: bit-identical to one
+GPU); backward the requester sums its positions' row gradients per unique id (mrec_segment_sum_g16, positions in ascending order)
+and ships one fp32 sum per unique id, which the owner's one apply kernel reads in place.  Slots per owner: ceil(capacity_factor *
+unique_factor * N / n) -- 336-byte fp32 rows against 176-byte 16-bit ones, so it pays below ~0.5 unique ids per position.
+
 A rank's OWN chunk of a message never moves: the requester numbers the chunks of what it sends so that its own comes last
 (owner o -> chunk (o - rank - 1) mod n: `chunk_rot` of mrec_shard_route_slots), an owner lays out what it receives so that its
 own comes first (sender s -> chunk (s - rank) mod n), and the send buffer X[0 : n] and the receive buffer X[n - 1 : 2n - 1] of one
@@ -202,8 +211,82 @@ class ShardStepMixin:
             self.comm.all_to_all(recv_req, req)
         return {"recv_req": recv_req, "slot_of_pos": slot_of_pos, "pos_of_slot": pos_of_slot, "ns": self.world * cap}
 
+    def _uniques_on(self):
+        """Unique-level exchange: dense-storage fused rows under the 16-bit net (the benchmarked configuration)."""
+        on = float(getattr(self.cfg, "shard_unique_factor", 0.0)) > 0.0
+        if on and not (self._shard_fold and self._mfma and self.index is None and self.hb is None):
+            raise ValueError("shard_unique_factor needs row shards of dense tables in the fused-row layout under the 16-bit net")
+        return on
+
+    def _shard_lookup_uniques(self, ids, wts, want_plan=True):
+        """The lookup half with UNIQUE ids on the wire (module docstring).  Same return as _shard_lookup."""
+        cfg, k = self.cfg, self.k
+        B, Fd = ids.shape
+        D, n = cfg.emb_dim, ids.numel()
+        ev = self._tick("route")
+        d = k.unique(ids)                                      # critical path: the request is made of the batch's unique ids
+        capu = k.shard_capacity(max(int(n * float(cfg.shard_unique_factor)), 1), self.world, cfg.shard_capacity_factor)
+        ns = self.world * capu
+        if self._bypass:
+            req, recv_req = self._xbuf(ns, 2, ids.dtype)
+            _, slot_of_u, u_of_slot = k.shard_route_slots(d.uniq_buf, None, self.world, capu, overflow=self._overflow,
+                                                          rot=(self.rank + 1) % self.world, out=req, n_valid_dev=d.n_uniq_dev)
+            self._exchange(recv_req, req, to_owner=True)
+        else:
+            req, slot_of_u, u_of_slot = k.shard_route_slots(d.uniq_buf, None, self.world, capu, overflow=self._overflow,
+                                                            n_valid_dev=d.n_uniq_dev)
+            recv_req = torch.empty_like(req)
+            self.comm.all_to_all(recv_req, req)
+        self._tock(ev)
+        ev = self._tick("gather_deep")
+        W = k.shard_msg_words(D, torch.float32)[1]
+        back = ans_out = None
+        if self._bypass:
+            back, ans_out = self._xbuf(ns, W, torch.float32)
+        # the owner answers UNMASKED fp32 rows + the row's wide weight (weight 1 travelled in the request entries)
+        if recv_req.dtype == torch.int32:
+            ans = k.gather_rows_req(self.deep, recv_req, 2, recv_req.view(torch.float32).view(-1)[1:], 2, ns, D, torch.float32, out=ans_out)
+        else:
+            ans = k.gather_rows_req(self.deep, recv_req, 2, recv_req.view(torch.float32).view(-1)[2:], 4, ns, D, torch.float32, out=ans_out)
+        fork_ev = None
+        if self._side is not None and want_plan:
+            fork_ev = torch.cuda.Event()
+            fork_ev.record(torch.cuda.current_stream())
+        self._tock(ev)
+        ev = self._tick("a2a_rows")
+        if self._bypass:
+            self._exchange(back, ans, to_owner=False)
+        else:
+            back = torch.empty_like(ans)
+            self.comm.all_to_all(back, ans)
+        self._tock(ev)
+        ev = self._tick("unroute")
+        # fan-out: position p reads message row slot_of_u[inv[p]] -- the one-GPU fused lookup over the message as its table
+        slot_of_pos = k.compose_i32(slot_of_u, d.inv)
+        emb, wprod = k.gather_rows_wide(back[:, :D], slot_of_pos.view(B, Fd), wts, D, out=self._emb_out(n, D, self._amp), out_dtype=self._amp)
+        self._tock(ev)
+        plan_r = plan_o = rows = recv_wts = None
+        if want_plan:
+            with (torch.cuda.stream(self._side) if fork_ev is not None else _null()):
+                if fork_ev is not None:
+                    self._side.wait_event(fork_ev)
+                plan_r = k.group_by_inverse(d)                  # the requester's inverted index: its backward sums per unique id
+                rows, recv_wts = k.shard_unpack_req(recv_req)
+                plan_o = k.sparse_plan(rows, skip_negative=True)     # the owner's: one entry per (rank, unique id) received
+            if fork_ev is not None:
+                main = torch.cuda.current_stream()
+                for t in (rows, recv_wts, recv_req, plan_o.uniq_buf, plan_o.inv, plan_o.n_uniq_dev, plan_o.sorted_pos, plan_o.sorted_seg,
+                          plan_o.seg_offsets, plan_r.sorted_pos, plan_r.sorted_seg, plan_r.seg_offsets, d.uniq_buf, d.inv):
+                    self._rs(t, main)
+                    self._rs(t, self._side)
+        route = {"pos_of_slot": u_of_slot, "recv_wts": recv_wts, "plan": plan_o, "plan_r": plan_r, "ns": ns, "keep": (recv_req, rows, d),
+                 "uniques": True}
+        return emb.view(B, Fd * D), wprod.view(B, Fd, 2), route
+
     def _shard_lookup(self, ids, wts, want_plan=True):
         """Requests out, answers back.  Returns (emb [B, F * D] act dtype, wprod [B, F, 2] fp32, route state)."""
+        if self._uniques_on():
+            return self._shard_lookup_uniques(ids, wts, want_plan)
         cfg, k = self.cfg, self.k
         B, Fd = ids.shape
         D, n, act = cfg.emb_dim, ids.numel(), self._act
@@ -307,12 +390,24 @@ class ShardStepMixin:
             state = self._step_state
             state.advance(cfg.adam_lr, float(self.beta1), float(self.beta2))
         ev = self._tick("a2a_grads")
+        uniques = bool(route.get("uniques"))
+        if uniques:
+            # one fp32 SUM per unique id: this rank's positions summed in ascending order (the Mul bprops of the masks as row_scale),
+            # the wide branch's per-position gradient dlogit[sample] * weight likewise
+            act = torch.float32
+            if self._side is not None:
+                torch.cuda.current_stream().wait_stream(self._side)       # the requester's inverted index (queued under the MLP)
+            sums = k.segment_sum(route["plan_r"], g_emb.reshape(n, D), wts)
+            gw_u = k.segment_sum(route["plan_r"], g_wide.view(B, 1).expand(B, Fd).reshape(n, 1), wts).reshape(-1)
+            g_rows, g_dl, g_F = sums, gw_u, 1
+        else:
+            g_rows, g_dl, g_F = g_emb.reshape(n, D), g_wide.reshape(B).contiguous(), Fd
         if self._bypass:
             gmsg, recv_g = self._xbuf(route["ns"], k.shard_msg_words(D, act)[1], torch.float32)
-            k.shard_route_grads(g_emb.reshape(n, D), g_wide.reshape(B).contiguous(), Fd, route["pos_of_slot"], out=gmsg)
+            k.shard_route_grads(g_rows, g_dl, g_F, route["pos_of_slot"], out=gmsg)
             self._exchange(recv_g, gmsg, to_owner=True)
         else:
-            gmsg = k.shard_route_grads(g_emb.reshape(n, D), g_wide.reshape(B).contiguous(), Fd, route["pos_of_slot"])
+            gmsg = k.shard_route_grads(g_rows, g_dl, g_F, route["pos_of_slot"])
             recv_g = torch.empty_like(gmsg)
             self.comm.all_to_all(recv_g, gmsg)
         self._tock(ev)

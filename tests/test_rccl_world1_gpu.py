@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, port, out_dir, mlp_dtype):
+def _worker(rank, port, out_dir, mlp_dtype, uniq=0.0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -34,7 +34,7 @@ def _worker(rank, port, out_dir, mlp_dtype):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     cfg = WideDeepConfig(vocab_size=30_011, emb_dim=80, field_size=26, batch_size=512, deep_layer_dim=[64, 32],
-                         mlp_dtype=mlp_dtype)
+                         mlp_dtype=mlp_dtype, shard_unique_factor=uniq)
     eng = WideDeepEngine(cfg, dev, rank=0, world=1, shard_protocol=True)
     assert eng._sharded and eng.comm.__class__.__name__ == "_DirectComm"
     losses = []
@@ -57,10 +57,10 @@ def _worker(rank, port, out_dir, mlp_dtype):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mlp_dtype", ["bf16", "fp16", "fp32"])
-def test_sharded_engine_over_rccl_world1_matches_one_gpu_engine(dev, tmp_path, mlp_dtype):
+@pytest.mark.parametrize("mlp_dtype,uniq", [("bf16", 0.0), ("fp16", 0.0), ("fp32", 0.0), ("fp16", 1.0)])      # (uniq: UNIQUE ids on the wire)
+def test_sharded_engine_over_rccl_world1_matches_one_gpu_engine(dev, tmp_path, mlp_dtype, uniq):
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
-    mp.spawn(_worker, args=(_free_port(), str(tmp_path), mlp_dtype), nprocs=1, join=True)
+    mp.spawn(_worker, args=(_free_port(), str(tmp_path), mlp_dtype, uniq), nprocs=1, join=True)
     r = np.load(tmp_path / "rccl.npz")
     cfg = WideDeepConfig(vocab_size=30_011, emb_dim=80, field_size=26, batch_size=512, deep_layer_dim=[64, 32], mlp_dtype=mlp_dtype)
     eng = WideDeepEngine(cfg, dev)

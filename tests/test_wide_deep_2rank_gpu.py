@@ -18,18 +18,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 MLP_DTYPE = "fp32"
 CAP_FACTOR = 1.25
+UNIQ = 0.0
 
 
 def _cfg(B, fields=39, mlp_dtype=None):
     from mindrec_amd.wide_deep import WideDeepConfig
     return WideDeepConfig(vocab_size=30_011, emb_dim=80, field_size=fields, batch_size=B, deep_layer_dim=[64, 32],
-                          mlp_dtype=mlp_dtype or MLP_DTYPE, shard_capacity_factor=CAP_FACTOR)
+                          mlp_dtype=mlp_dtype or MLP_DTYPE, shard_capacity_factor=CAP_FACTOR, shard_unique_factor=UNIQ)
 
 
-def _worker(rank, world, port, steps, out_dir, mlp_dtype="fp32", cap_factor=1.25, broken_lists=False):
-    global MLP_DTYPE, CAP_FACTOR
+def _worker(rank, world, port, steps, out_dir, mlp_dtype="fp32", cap_factor=1.25, broken_lists=False, uniq=0.0):
+    global MLP_DTYPE, CAP_FACTOR, UNIQ
     MLP_DTYPE = mlp_dtype
     CAP_FACTOR = cap_factor
+    UNIQ = uniq
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -64,20 +66,23 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mlp_dtype,world,cap_factor,broken_lists", [("fp32", 2, 1.25, False), ("bf16", 2, 1.25, False), ("fp16", 2, 1.25, False),
-                                                                      ("bf16", 4, 1.25, False), ("fp16", 4, 2.0, False), ("bf16", 5, 1.5, False),
-                                                                      ("fp16", 3, 1.5, True)])
-def test_ranks_on_one_gpu_match_single_process(dev, tmp_path, mlp_dtype, world, cap_factor, broken_lists):
+@pytest.mark.parametrize("mlp_dtype,world,cap_factor,broken_lists,uniq", [("fp32", 2, 1.25, False, 0.0), ("bf16", 2, 1.25, False, 0.0), ("fp16", 2, 1.25, False, 0.0),
+                                                                           ("bf16", 4, 1.25, False, 0.0), ("fp16", 4, 2.0, False, 0.0), ("bf16", 5, 1.5, False, 0.0),
+                                                                           ("fp16", 3, 1.5, True, 0.0),
+                                                                           # UNIQUE ids on the wire (one fp32 row / one summed gradient row per unique id)
+                                                                           ("fp16", 2, 1.25, False, 1.0), ("bf16", 4, 1.5, False, 0.75), ("fp16", 3, 1.5, True, 1.0)])
+def test_ranks_on_one_gpu_match_single_process(dev, tmp_path, mlp_dtype, world, cap_factor, broken_lists, uniq):
     """The fixed-capacity protocol (mindrec_amd/wide_deep_shard.py) with the real HIP kernels.  fp32: fp32 rows on the wire,
     torch MLP.  bf16 / fp16: the production path -- weights travel with the ids, 16-bit rows and 16-bit row-gradients on the
     wire, hand-written MLP step, one apply kernel for both tables reading the received gradient message in place.  (Criteo-like
     ids: the 13 constant dense-field ids 0..12 load the owners unevenly -- the slack the capacity factor is for.)"""
-    global MLP_DTYPE
+    global MLP_DTYPE, UNIQ
     from mindrec_amd.wide_deep import WideDeepEngine, synthetic_batch
     MLP_DTYPE = mlp_dtype
+    UNIQ = 0.0         # (the single-process engine below has nothing to exchange)
     steps = 4          # the MLP graphs are captured on step 3 and replayed on step 4
     # (broken_lists: the communicator refuses the per-peer-list all-to-all -- every rank falls back to the plain one)
-    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), mlp_dtype, cap_factor, broken_lists), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), mlp_dtype, cap_factor, broken_lists, uniq), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
     eng = WideDeepEngine(_cfg(128 * world), dev)
     losses = []
