@@ -646,8 +646,8 @@ def _measure(args, world, rank, dev):
                        # the byte model of an 8-rank node, whatever this run's world size (at world 1 nothing moves): today's
                        # per-position exchange against the unique-level one at this run's unique ids per position
                        "a2a_bytes_model_n8": {"positions": model(8, 0.0, eng._act),
-                                              "uniques": model(8, max(uq, min(1.0, round(U / max(n_apply, 1) * 1.0, 4))) if world == 1 else uq, eng._act),
-                                              "unique_ids_per_position_measured": round(U / max(n_apply, 1), 4) if world == 1 and uq == 0 else None},
+                                              "uniques": model(8, uq if uq > 0 else min(1.0, round(U / max(n_apply, 1), 4)), eng._act),
+                                              "unique_ids_per_position": uq if uq > 0 else round(U / max(n_apply, 1), 4)},
                        "allreduce_bytes_per_step": int(eng.dense_grad_full.numel() * 4),
                        "kernels_ms_keys": ["route", "a2a_rows", "unroute", "a2a_grads", "allreduce_dense"]}
         # dropped positions: the count every rank holds is the SUM over all ranks (it rides the dense all-reduce), so all ranks
