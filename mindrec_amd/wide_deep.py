@@ -35,7 +35,7 @@ import torch.distributed as dist
 from . import ops
 from .wide_deep_ckpt import load_checkpoint, merge_shards, save_checkpoint  # noqa: F401  (re-exported)
 from .wide_deep_mlp import DenseNetMixin, _WideProd
-from .wide_deep_shard import ShardCapacityError, ShardStepMixin  # noqa: F401  (re-exported)
+from .wide_deep_shard import ShardCapacityError, ShardStepMixin, grow_shard_capacity  # noqa: F401  (re-exported)
 
 
 @dataclass

@@ -45,6 +45,22 @@ class ShardCapacityError(RuntimeError):
     """A step's ids did not fit the fixed-capacity request message: raise WideDeepConfig.shard_capacity_factor."""
 
 
+def grow_shard_capacity(eng, mult=2.0):
+    """After a ShardCapacityError: the request messages get `mult` times the slots (the capacity factor, and the unique-ids-per-
+    position bound up to 1) and the captured steps -- whose message shapes are part of them -- are dropped; the next step
+    captures anew.  Every rank calls it (the error is raised on every rank alike).  The steps since the last check ran with
+    zero rows for the dropped positions: the caller decides whether to restore a checkpoint or to go on."""
+    cfg = eng.cfg
+    uq = float(getattr(cfg, "shard_unique_factor", 0.0))
+    if uq > 0.0 and uq < 1.0:
+        cfg.shard_unique_factor = min(1.0, uq * mult)
+    else:
+        cfg.shard_capacity_factor = float(cfg.shard_capacity_factor) * mult
+    eng.release_graphs()
+    eng._guard.factor = cfg.shard_capacity_factor
+    return cfg.shard_capacity_factor, float(getattr(cfg, "shard_unique_factor", 0.0))
+
+
 class OverflowGuard:
     """Makes a dropped position impossible to miss: the library itself raises, on EVERY rank, at most one call late.
 

@@ -122,7 +122,13 @@ def _overflow_worker(rank, world, port, out_dir):
         eng.train_step(ids, wts, label)        # the library itself raises at the next call, on EVERY rank
     except ShardCapacityError:
         raised = True
-    np.savez(os.path.join(out_dir, f"ovf{rank}.npz"), local=local, raised=raised)
+    # every rank grows the messages together and goes on: the same batch now fits (rank 0's 2 x 24 x 39 positions all go to owner 0)
+    from mindrec_amd.wide_deep_shard import grow_shard_capacity
+    grown = grow_shard_capacity(eng, 2.0)[0]
+    before = eng.shard_overflow()
+    eng.train_step(ids, wts, label)
+    eng.check_shard_overflow()                 # (raises if the grown capacity dropped anything: it does not)
+    np.savez(os.path.join(out_dir, f"ovf{rank}.npz"), local=local, raised=raised, grown=grown, more=eng.shard_overflow() - before)
     dist.destroy_process_group()
 
 
@@ -135,6 +141,7 @@ def test_dropped_positions_raise_on_every_rank(tmp_path):
     r = [np.load(tmp_path / f"ovf{k}.npz") for k in range(2)]
     assert int(r[0]["local"]) > 0 and int(r[1]["local"]) == 0          # only rank 0 dropped something ...
     assert bool(r[0]["raised"]) and bool(r[1]["raised"])               # ... and both ranks raised
+    assert float(r[0]["grown"]) == 2.0 and int(r[0]["more"]) == 0 and int(r[1]["more"]) == 0      # grow_shard_capacity: the batch fits, training goes on
 
 
 def test_engine_refuses_cpu_without_kernels():
