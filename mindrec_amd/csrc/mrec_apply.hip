@@ -680,6 +680,14 @@ __device__ __forceinline__ void apply_long_body(Upd upd, int64_t V, int64_t ld, 
     }
 
     // ---- pass B: the long runs among this block's windows, one after the other, the whole block on each
+    // (Round 5, built, parity-green, measured and not kept: HOT runs -- Criteo's 13 constant dense-field ids, 2048 partials each --
+    // finished COOPERATIVELY: k_apply_main listed their owner windows (a word whose high half carried the step number, so nothing
+    // needed clearing), every workgroup of this pass summed chunks of 128 partials round-robin over the list, chunk sums travelled
+    // write-through (sc1 stores; with agent-scope release fences instead the pass took 80 us: each fence writes back what the
+    // dense Adam beside it has dirtied in the XCD's L2), the workgroup whose ticket was a run's last added the chunk sums in
+    // chunk order and updated the row.  Zipf ids x 39 fields, same box, two A/B pairs: this pass 35.0-36.9 us against 29.6-30.8
+    // as it is, k_apply_main 97.6-98.4 against 98.2-98.4, the step 0.7366 against 0.7321-0.7458 ms -- the hot runs are not what
+    // the pass waits for; the thousands of runs of 9-1000 entries are, one lane-group or one workgroup each.)
     {
         for (int o = 0; o < cnt; ++o) {
             const int sw = list[o];
