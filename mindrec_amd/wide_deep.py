@@ -540,6 +540,11 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
             if self._fold_wide:
                 wide_done = True             # the wide table's FTRL rides the deep table's apply (train_step)
                 if fork_ev is not None and plan_early is None:
+                    # (Round 5, each an A/B pair on one box against forking behind the lookup: behind the forward GEMMs ("fwd") and behind the
+                    # output head ("head") the lookup runs alone, 46.3 -> 40.6 us, and the step gets 3-6 us LONGER; the NEXT step's plan
+                    # issued behind this step's sparse apply inside a sink's graph -- beside the finishing pass, the dense Adam and the
+                    # staging copies -- 0.6263-0.6298 -> 0.6281-0.6313 ms with the lookup at 50.8 us: the plan's kernels cost the chain
+                    # ~30 us wherever they run beside it.)
                     # MREC_PLAN_FORK=head: the plan's branch starts behind the output head, beside the BACKWARD launches (multi-round
                     # grids: a CU the plan's kernels slow down simply takes fewer workgroups) instead of beside the lookup and the
                     # one-round layer-0 forward, whose slowest CU sets its time
