@@ -1,7 +1,10 @@
 """`mindspore.train.serialization`: save_checkpoint / load_checkpoint / load_param_into_net
 (models/wide_deep/eval.py:86-107; examples/online_learning/online_train.py:27).  MindSpore's `.ckpt` is a protobuf
-stream; this one is a numpy `.npz` stream under the same file name: one array per Parameter; a MapParameter is three
-arrays (`<name>::keys`, `<name>::values`, `<name>::status`) plus one per optimizer slot (`<name>::slot::<slot>`)."""
+stream; THIS ONE IS A NUMPY `.npz` STREAM under the same file name (a checkpoint written by MindSpore itself cannot be read, nor
+the other way round): one array per Parameter under MindSpore's parameter names, optimizer slots as `moment1.<name>` /
+`moment2.<name>` / `accum.<name>` / `linear.<name>`, the optimizers' step scalars under their cell path
+(`optimizer_d.global_step`); a MapParameter is three arrays (`<name>::keys`, `<name>::values`, `<name>::status`) plus one per
+optimizer slot (`<name>::slot::<slot>`)."""
 import os
 
 import numpy as np
@@ -12,7 +15,15 @@ from ..common.tensor import Tensor
 from ..experimental import MapParameter
 
 
-def _items(save_obj):
+_SLOT_PREFIXES = ("moment1.", "moment2.", "accum.", "linear.")
+
+
+def _items(save_obj, legacy=False):
+    """(checkpoint name, parameter).  Optimizer slots go under MindSpore's own names -- `moment1.<parameter name>`, `accum.<...>`:
+    a script that filters a checkpoint by `filter_prefix='moment1'` keeps meaning what it meant -- ; the step scalars every optimizer
+    holds under the same name (`global_step`, `beta1_power`, ...) under the optimizer cell's path, which is what tells two
+    optimizers' apart (TrainStepWrap has two, wide_and_deep.py:415-445).  legacy=True: the names of files written before round 5
+    (slots under the cell path too), which load_param_into_net still accepts."""
     from ..nn.cell import Cell
     if isinstance(save_obj, Cell):
         seen = set()
@@ -21,10 +32,11 @@ def _items(save_obj):
                 if id(p) not in seen:
                     seen.add(id(p))
                     yield p.name, p
-            for p in c.get_parameters(expand=False):          # state a cell keeps outside its attributes (optimizers): under its path
+            for p in c.get_parameters(expand=False):          # state a cell keeps outside its attributes (optimizers)
                 if id(p) not in seen:
                     seen.add(id(p))
-                    yield (cname + "." if cname else "") + p.name, p
+                    under_path = (cname + "." if cname else "") + p.name
+                    yield (under_path if legacy or not str(p.name).startswith(_SLOT_PREFIXES) else p.name), p
         return
     if isinstance(save_obj, dict):
         yield from save_obj.items()
@@ -118,7 +130,10 @@ def load_param_into_net(net, parameter_dict, strict_load=False):
     if not isinstance(parameter_dict, dict):
         raise TypeError(f"For 'load_param_into_net', the argument 'parameter_dict' should be a dict, but got {type(parameter_dict)}.")
     missing = []
+    old_names = {id(q): n for n, q in _items(net, legacy=True)}
     for name, p in _items(net):
+        if name not in parameter_dict and old_names.get(id(p)) in parameter_dict:
+            name = old_names[id(p)]                            # a file written before round 5
         if isinstance(p, MapParameter):
             if name + "::keys" not in parameter_dict:
                 missing.append(name)

@@ -239,3 +239,35 @@ def test_reference_data_parallel_run_equals_one_engine_on_the_concatenated_batch
     equal to the same single-process step): losses = the mean of the ranks' losses, parameters equal to summation order."""
     from _oracle_engine import OracleWideDeepEngine
     RF.check_data_parallel_fixture(lambda c: OracleWideDeepEngine(c, "cpu"), "cpu")
+
+
+def test_checkpoint_names_are_mindspore_names(ms_cpu, tmp_path):
+    """optimizer slots are saved under MindSpore's names (`moment1.<parameter>`, `accum.<parameter>`; the step scalars of
+    the two optimizers under their cell path) -- `filter_prefix='moment1'` means what it means there -- and a file with the older
+    cell-path names still loads."""
+    import _ms_models
+    from mindspore.train.serialization import load_checkpoint, load_param_into_net, save_checkpoint
+    z, cfg, comp = RF.load("ref_wd_sparse")
+    step, net = _ms_models.wide_deep_from_fixture(z, cfg, comp)
+    batch = tuple(ms_cpu.Tensor(z[k][0]) for k in ("ids", "wts", "label"))
+    step(*batch)
+    path = save_checkpoint(step, str(tmp_path / "a.ckpt"))
+    names = list(np.load(path).files)
+    m1 = step.opt_deep._slot(net.layer0.weight, "moment1", 0.0).name          # `moment1.<the parameter's name when the optimizer was built>`
+    w_name = m1[len("moment1."):]
+    assert m1.startswith("moment1.") and m1 in names and f"moment2.{w_name}" in names and any(n.startswith("accum.") for n in names)
+    assert "opt_deep.global_step" in names and "opt_wide.global_step" in names and "opt_deep.beta1_power" in names
+    kept = load_checkpoint(path, filter_prefix="moment1")
+    assert not any(k.startswith("moment1") for k in kept) and f"moment2.{w_name}" in kept
+    # a second, fresh model takes everything back -- from this file and from one with the pre-round-5 names
+    ref_m = np.load(path)[f"moment1.{w_name}"]
+    old = {(("opt_deep." + k) if k.startswith(("moment1.", "moment2.")) else ("opt_wide." + k) if k.startswith(("accum.", "linear.")) else k): v
+           for k, v in np.load(path).items()}
+    np.savez(open(tmp_path / "old.ckpt", "wb"), **old)
+    for f in ("a.ckpt", "old.ckpt"):
+        step2, net2 = _ms_models.wide_deep_from_fixture(z, cfg, comp)
+        step2(*batch)                                                         # (creates the optimizer slots)
+        missing = load_param_into_net(step2, load_checkpoint(str(tmp_path / f)))
+        assert not missing, (f, missing)
+        assert np.array_equal(step2.opt_deep._slot(net2.layer0.weight, "moment1", 0.0).asnumpy(), ref_m)
+        assert step2.opt_deep.global_step == 1
