@@ -613,6 +613,18 @@ int mrec_map_lookup(mrec_map_t* h, const void* keys, int32_t key_bytes, int64_t 
                     int32_t* rows_admitted_out, void* ws, size_t ws_bytes, void* stream);
 /* out[i, :] = default value of keys[i] wherever rows[i] < 0 (insert_default_value=False: a missing key reads as its
  * default without entering the table); only D / sigma / fill / seed of `table` are used. */
+/* MapTensorGet with insertion AND its output for new keys (mindspore_rec/ops/embedding.py:193; README.md:160-205): as
+ * mrec_map_lookup, and the kernel that generates the default rows of new keys also writes them to out[p, :] for the position p of
+ * the key's first occurrence (`out_table`: which of `tables` is the one being read; out rows 16-byte aligned, ldo % 4 == 0).
+ * rows_gather[i] = the row a gather behind this call reads for position i, -1 where `out` holds the row already -- follow with
+ * mrec_gather_rows_f32_skip_i32(table, V, ld, D, rows_gather, n, out, stream).  A lookup of all-new keys moves the new rows
+ * once (generator -> table and output) instead of three times (generator -> table -> gather -> output). */
+int mrec_map_lookup_out(mrec_map_t* h, const void* keys, int32_t key_bytes, int64_t n, const int64_t* n_dev, uint32_t flags,
+                        int64_t step, int32_t permit, const mrec_map_table_t* tables, int32_t n_tables, int32_t* rows_out,
+                        int32_t* rows_admitted_out, float* out, int64_t ldo, int32_t out_table, int32_t* rows_gather, void* ws,
+                        size_t ws_bytes, void* stream);
+int mrec_gather_rows_f32_skip_i32(const float* table, int64_t V, int64_t ld, int32_t D, const int32_t* ids, int64_t n, float* out,
+                                  void* stream);
 int mrec_map_fill_missing(const void* keys, int32_t key_bytes, const int32_t* rows, int64_t n, float* out, int64_t ldo,
                           const mrec_map_table_t* table, void* stream);
 /* Eviction on the device: every live key whose last training lookup is more than `threshold` steps before `step` leaves

@@ -150,6 +150,8 @@ _SIGS = {
     "mrec_map_tracking_dev": [_vp, _vp, _vp, _vp],
     "mrec_map_lookup_workspace_bytes": [_i64, _szp],
     "mrec_map_lookup": [_vp, _vp, _i32, _i64, _vp, C.c_uint32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp],
+    "mrec_map_lookup_out": [_vp, _vp, _i32, _i64, _vp, C.c_uint32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _sz, _vp],
+    "mrec_gather_rows_f32_skip_i32": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp],
     "mrec_map_fill_missing": [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp],
     "mrec_map_evict": [_vp, _i64, _i64, _vp, _vp, _sz, _vp],
     "mrec_map_export_dirty": [_vp, _vp, _vp, _vp, _vp, _int, _vp, _sz, _vp],

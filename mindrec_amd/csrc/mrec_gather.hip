@@ -731,7 +731,7 @@ int gather_bf16_impl(const float* table, int64_t V, int64_t ld, int32_t D, const
 
 template <class K>
 int gather_impl(const float* table, int64_t V, int64_t ld, int32_t D, const K* ids, int64_t n,
-                const float* row_scale, float* out, void* stream) {
+                const float* row_scale, float* out, void* stream, bool skip_invalid = false) {
     hipStream_t st = (hipStream_t)stream;
     if (n < 0 || D <= 0 || V < 0 || ld < D) return MREC_EINVAL;
     if (n == 0) return MREC_OK;
@@ -742,7 +742,9 @@ int gather_impl(const float* table, int64_t V, int64_t ld, int32_t D, const K* i
         RowGeom gm{D / 4, 64 / (D / 4)};
         const int64_t rows_per_block = (int64_t)4 * gm.G * GB;
         k_gather_rows<4, K><<<(unsigned)mrec_cdiv(n, rows_per_block), 256, 0, st>>>(table, V, ld, ids, n, row_scale,
-                                                                                  out, D, gm);
+                                                                                  out, D, gm, nullptr, 0, 2, GatherDrop{}, 1, 1, skip_invalid);
+    } else if (skip_invalid) {
+        return MREC_EUNSUPPORTED;
     } else if (D <= 64) {
         RowGeom gm{D, 64 / D};
         const int64_t rows_per_block = (int64_t)4 * gm.G * GB;
@@ -859,6 +861,12 @@ MREC_API int mrec_gather_rows_f32_i32(const float* table, int64_t V, int64_t ld,
 MREC_API int mrec_gather_rows_f32_i64(const float* table, int64_t V, int64_t ld, int32_t D, const int64_t* ids,
                                       int64_t n, const float* row_scale, float* out, void* stream) {
     return gather_impl<int64_t>(table, V, ld, D, ids, n, row_scale, out, stream);
+}
+/* ... leaving the rows of ids outside [0, V) ALONE instead of writing zeros (MapTensorGet over new keys: mrec_map_lookup_out has
+ * written their default rows into `out` already; 16-byte aligned rows, D % 4 == 0, D <= 256). */
+MREC_API int mrec_gather_rows_f32_skip_i32(const float* table, int64_t V, int64_t ld, int32_t D, const int32_t* ids,
+                                           int64_t n, float* out, void* stream) {
+    return gather_impl<int32_t>(table, V, ld, D, ids, n, nullptr, out, stream, true);
 }
 
 MREC_API int mrec_gather_rows_bf16_i32(const float* table, int64_t V, int64_t ld, int32_t D, const int32_t* ids,

@@ -263,6 +263,13 @@ struct LookupWs {
     int64_t* newkey;   // [n]
     int64_t* words;    // [0] = new keys of this call
     uint32_t smask;
+    // mrec_map_lookup_out: the lookup's OUTPUT rows of the first occurrences of new keys are written by the kernel that generates
+    // their default rows (one pass less over them than table -> gather -> output)
+    int* newpos;       // [n]   position of the first occurrence, in rank order
+    float* out;        // [n, ldo] (nullable)
+    int64_t ldo;
+    int out_tab;       // which table's rows `out` holds
+    int* rows_gather;  // [n]   row per position for the gather BEHIND this call: -1 where `out` is written here
 };
 
 __device__ __forceinline__ int map_lookback(unsigned* status, int tile) {
@@ -312,11 +319,12 @@ __global__ __launch_bounds__(HB) void k_map_probe(MapDev m, const K* __restrict_
                                                   int* __restrict__ rows_out, LookupWs w) {
     const int64_t i = (int64_t)blockIdx.x * HB + threadIdx.x;
     if (i >= n_max) return;
-    if (i >= eff_n(n_max, n_dev)) { rows_out[i] = -1; return; }
+    if (i >= eff_n(n_max, n_dev)) { rows_out[i] = -1; if (w.rows_gather) w.rows_gather[i] = -1; return; }
     const int64_t key = (int64_t)keys[i];
     if ((flags & F_SKIP_PAD) && key == -1) {      // a padding slot of a request message: nobody's key
         rows_out[i] = -1;
         w.sidx[i] = -1;
+        if (w.rows_gather) w.rows_gather[i] = -1;
         return;
     }
     const uint32_t hsh = mrec_hash_key(key);
@@ -329,6 +337,7 @@ __global__ __launch_bounds__(HB) void k_map_probe(MapDev m, const K* __restrict_
         s = (s + 1) & m.mask;
     }
     rows_out[i] = row;
+    if (w.rows_gather) w.rows_gather[i] = row;       // (a miss stays -1 where the finishing kernel writes the output row itself)
     if (row >= 0) {
         if (flags & F_TRAIN) {
             // one hit per key and step, however many positions carry the key: the position that moves last_step counts
@@ -420,6 +429,7 @@ __global__ __launch_bounds__(HB) void k_map_place(MapDev m, const K* __restrict_
         rows_out[i] = row;
         w.newrow[r] = row;
         w.newkey[r] = key;
+        if (w.newpos) w.newpos[r] = (int)i;
         if (!(flags & F_UNIQUE)) {
             w.srank[w.sidx[i]] = row;
             w.slots[w.sidx[i]] = kEmptyPos;        // the scratch table leaves the call as it entered it
@@ -466,6 +476,7 @@ __global__ __launch_bounds__(HB) void k_map_finish(MapDev m, MapTabs tabs, int64
                 if (row < 0) continue;
                 const int64_t key = w.newkey[r];
                 float* dst = tb.rows + (int64_t)row * tb.ld;
+                float* dst2 = (w.out && t == w.out_tab) ? w.out + (int64_t)w.newpos[r] * w.ldo : nullptr;       // the lookup's output row of the key's first position
                 if (vec) {
                     for (int c = sub * 4; c < tb.D; c += lpr * 4) {
                         float4 v;
@@ -477,9 +488,14 @@ __global__ __launch_bounds__(HB) void k_map_finish(MapDev m, MapTabs tabs, int64
                             v = make_float4(tb.fill, tb.fill, tb.fill, tb.fill);
                         }
                         *(float4*)(dst + c) = v;
+                        if (dst2) *(float4*)(dst2 + c) = v;
                     }
                 } else {
-                    for (int c = 0; c < tb.D; ++c) dst[c] = tb.sigma >= 0.0f ? tb.sigma * mrec_det_normal(tb.seed, key, c) : tb.fill;
+                    for (int c = 0; c < tb.D; ++c) {
+                        const float x = tb.sigma >= 0.0f ? tb.sigma * mrec_det_normal(tb.seed, key, c) : tb.fill;
+                        dst[c] = x;
+                        if (dst2) dst2[c] = x;
+                    }
                 }
             }
         }
@@ -492,6 +508,7 @@ __global__ __launch_bounds__(HB) void k_map_finish(MapDev m, MapTabs tabs, int64
         if (fix && i < eff && row < 0 && !((flags & F_SKIP_PAD) && w.sidx[i] < 0)) {
             row = w.srank[w.sidx[i]];
             rows_out[i] = row;
+            if (w.rows_gather) w.rows_gather[i] = row;      // a LATER position of a new key: the gather behind this call reads the new row
         }
         if (rows_adm) rows_adm[i] = (row >= 0 && m.hits[row] >= permit) ? row : -1;
     }
@@ -829,7 +846,7 @@ MREC_API int mrec_map_lookup_workspace_bytes(int64_t n, size_t* out) {
     if (n >= (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
     const size_t nn = (size_t)(n ? n : 1);
     const uint64_t cap = lookup_cap(n);
-    *out = mrec_align_up(cap * 4, 256) * 2 + mrec_align_up(nn * 4, 256) * 2 + mrec_align_up(nn * 8, 256) +
+    *out = mrec_align_up(cap * 4, 256) * 2 + mrec_align_up(nn * 4, 256) * 3 + mrec_align_up(nn * 8, 256) +
            mrec_align_up((size_t)mrec_cdiv(nn, HT) * 4, 256) + 256;
     return MREC_OK;
 }
@@ -837,7 +854,8 @@ MREC_API int mrec_map_lookup_workspace_bytes(int64_t n, size_t* out) {
 template <class K>
 static int map_lookup_impl(mrec_map* h, const K* keys, int64_t n, const int64_t* n_dev, uint32_t flags, int64_t step,
                            int32_t permit, const mrec_map_table_t* tables, int32_t n_tables, int32_t* rows_out,
-                           int32_t* rows_adm, void* ws, size_t ws_bytes, hipStream_t st) {
+                           int32_t* rows_adm, void* ws, size_t ws_bytes, hipStream_t st, float* out = nullptr, int64_t ldo = 0,
+                           int32_t out_table = 0, int32_t* rows_gather = nullptr) {
     MapTabs tabs;
     tabs.n = n_tables;
     for (int t = 0; t < n_tables; ++t) {
@@ -856,6 +874,8 @@ static int map_lookup_impl(mrec_map* h, const K* keys, int64_t n, const int64_t*
     w.status = (unsigned*)a.take<int>(ntiles);
     w.words = a.take<int64_t>(2);
     w.smask = (uint32_t)(cap - 1);
+    w.newpos = a.take<int>(n);
+    w.out = out; w.ldo = ldo; w.out_tab = out_table; w.rows_gather = rows_gather;
     if (!a.ok) return MREC_EWORKSPACE;
     const bool inserting = (flags & F_INSERT) != 0;
     if (inserting && !(flags & F_PRIMED)) {
@@ -888,6 +908,28 @@ MREC_API int mrec_map_lookup(mrec_map_t* h, const void* keys, int32_t key_bytes,
                                         rows_admitted_out, ws, ws_bytes, (hipStream_t)stream);
     return map_lookup_impl<int64_t>(h, (const int64_t*)keys, n, n_dev, flags, step, permit, tables, n_tables, rows_out,
                                     rows_admitted_out, ws, ws_bytes, (hipStream_t)stream);
+}
+
+/* MapTensorGet with insertion, the lookup's OUTPUT included for new keys: as mrec_map_lookup, and the kernel that generates the
+ * default rows also writes them to out[position of the key's first occurrence, :] (table `out_table` of `tables`);
+ * rows_gather[i] = the row the gather behind this call must read for position i, -1 where `out` is already written (run
+ * mrec_gather_rows_f32_skip_i32(table, ..., rows_gather, n, out) next: one pass over the new rows less than lookup + gather). */
+MREC_API int mrec_map_lookup_out(mrec_map_t* h, const void* keys, int32_t key_bytes, int64_t n, const int64_t* n_dev, uint32_t flags,
+                                 int64_t step, int32_t permit, const mrec_map_table_t* tables, int32_t n_tables,
+                                 int32_t* rows_out, int32_t* rows_admitted_out, float* out, int64_t ldo, int32_t out_table,
+                                 int32_t* rows_gather, void* ws, size_t ws_bytes, void* stream) {
+    if (!h || n < 0 || (key_bytes != 4 && key_bytes != 8) || n_tables <= 0 || n_tables > 8 || !tables || step < 0 || step > 0x7fffffff ||
+        out_table < 0 || out_table >= n_tables)
+        return MREC_EINVAL;
+    if (n == 0) return MREC_OK;
+    if (!keys || !rows_out || !ws || !out || !rows_gather || ldo < tables[out_table].D) return MREC_EINVAL;
+    if (n >= (int64_t(1) << 30)) return MREC_EUNSUPPORTED;
+    if ((ldo % 4) || (((uintptr_t)out) & 15)) return MREC_EUNSUPPORTED;
+    if (key_bytes == 4)
+        return map_lookup_impl<int32_t>(h, (const int32_t*)keys, n, n_dev, flags, step, permit, tables, n_tables, rows_out,
+                                        rows_admitted_out, ws, ws_bytes, (hipStream_t)stream, out, ldo, out_table, rows_gather);
+    return map_lookup_impl<int64_t>(h, (const int64_t*)keys, n, n_dev, flags, step, permit, tables, n_tables, rows_out,
+                                    rows_admitted_out, ws, ws_bytes, (hipStream_t)stream, out, ldo, out_table, rows_gather);
 }
 
 MREC_API int mrec_map_fill_missing(const void* keys, int32_t key_bytes, const int32_t* rows, int64_t n, float* out, int64_t ldo,

@@ -139,6 +139,18 @@ class MapParameter:
     def get(self, key_tensor, insert_default_value=True):
         """MapTensorGet: 4 launches (the lookup chain + the row gather), 3 without insertion (probe, gather, defaults)."""
         keys = self._keys(key_tensor)
+        D = self.value_shape[0]
+        if insert_default_value and D % 4 == 0 and D <= 256:
+            # one pass over the rows of NEW keys less: the kernel that generates their default rows writes them to the table AND to
+            # the output; the gather behind it moves the rows of the keys that were there (and of later positions of new keys)
+            out = torch.empty((keys.numel(), D), dtype=torch.float32, device=self.device)
+            train = self._track
+            if train:
+                self.step += 1
+            _, rows_g = self.index.lookup(keys, insert=True, train=train, step=self.step, permit=self.permit_filter_value,
+                                          tables=self._tables(), out=out, out_table=0)
+            ops.gather_rows_skip_(self.values, rows_g, out)
+            return out
         _, _, rows_pos = self.lookup_rows(keys, insert=insert_default_value)
         out = ops.gather_rows(self.values, rows_pos)
         if not insert_default_value:

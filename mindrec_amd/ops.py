@@ -228,6 +228,18 @@ def gather_rows_wide(table, ids, row_scale, wide_col, out=None, out_dtype=torch.
     return out.view(tuple(ids.shape) + (D,)), wprod.view(tuple(ids.shape) + (2,))
 
 
+def gather_rows_skip_(table, rows, out):
+    """out[i, :] = table[rows[i], :] where rows[i] is a row of the table; rows of ids outside it (-1) are LEFT ALONE (the lookup in
+    front has written them: KeyIndex.lookup(out=...))."""
+    _need_cuda(table, rows, out)
+    V, D, ld = _table(table)
+    flat = rows.reshape(-1).contiguous()
+    if flat.dtype != torch.int32 or out.dtype != torch.float32 or out.numel() != flat.numel() * D or not out.is_contiguous():
+        raise TypeError("gather_rows_skip_: int32 rows, contiguous float32 [n, D] out")
+    _lib.call("mrec_gather_rows_f32_skip_i32", _ptr(table), V, ld, D, _ptr(flat), flat.numel(), _ptr(out), _stream())
+    return out
+
+
 def gather_rows_pinned(host_table, ids):
     """Rows of a PINNED HOST table straight into HBM: the same gather kernel reads host memory over PCIe (pinned
     allocations are device-addressable; ~45 GB/s measured).  ids < 0 give zero rows without touching the host."""
@@ -591,7 +603,7 @@ class KeyIndex:
         return arr
 
     def lookup(self, keys, insert=True, unique=False, train=False, step=0, permit=1, tables=(), n_dev=None, want_admitted=False,
-               skip_pad=False):
+               skip_pad=False, out=None, out_table=0):
         """Rows of `keys` (int32 / int64, any shape, duplicates allowed) in 3 launches (1 when not inserting): probe, rank and
         place the missing keys in order of first appearance, default rows of `tables` = [(tensor [C, D], sigma or None, fill,
         seed)] + admission.  Returns rows int32 [n] (and the admitted rows when want_admitted).  skip_pad: key -1 is a padding
@@ -607,10 +619,22 @@ class KeyIndex:
         primed = _MAP_PRIMED.pop(key, False)
         flags = (1 if insert else 0) | (2 if unique else 0) | (4 if train else 0) | (8 if primed else 0) | (16 if skip_pad else 0)
         tabs = self._tables(tables)
-        _lib.call("mrec_map_lookup", self._h, _ptr(flat), flat.element_size(), n, _ptr(n_dev), flags, int(step), int(permit),
-                  C.cast(tabs, C.c_void_p), len(tables), _ptr(rows), _ptr(adm), _ptr(ws), ws.numel(), _stream())
+        if out is not None:
+            # the lookup's output rows of NEW keys are written by the kernel that generates their default rows; returns
+            # (rows, rows for the gather behind this call: -1 where `out` is written already)
+            if not insert or not tables or out.dtype != torch.float32 or out.dim() != 2 or out.shape[0] != n or out.stride(1) != 1:
+                raise TypeError("lookup(out=...): an inserting lookup with tables and a float32 [n, D] output")
+            rows_g = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)[:n]
+            _lib.call("mrec_map_lookup_out", self._h, _ptr(flat), flat.element_size(), n, _ptr(n_dev), flags, int(step), int(permit),
+                      C.cast(tabs, C.c_void_p), len(tables), _ptr(rows), _ptr(adm), _ptr(out), out.stride(0), int(out_table), _ptr(rows_g),
+                      _ptr(ws), ws.numel(), _stream())
+        else:
+            _lib.call("mrec_map_lookup", self._h, _ptr(flat), flat.element_size(), n, _ptr(n_dev), flags, int(step), int(permit),
+                      C.cast(tabs, C.c_void_p), len(tables), _ptr(rows), _ptr(adm), _ptr(ws), ws.numel(), _stream())
         if primed or (insert and not torch.cuda.is_current_stream_capturing()):
             _MAP_PRIMED[key] = True        # (a probe-only call leaves the workspace untouched; a captured call has not run)
+        if out is not None:
+            return (rows, adm, rows_g) if want_admitted else (rows, rows_g)
         return (rows, adm) if want_admitted else rows
 
     def fill_missing(self, keys, rows, out, sigma, fill, seed):
