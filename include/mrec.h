@@ -261,13 +261,16 @@ typedef struct mrec_step_state {
     float reserved0;
     int64_t step;
     uint64_t reserved1;
-    /* [step % MREC_STAMP_RING] = {begin of the first workgroup, end of the last wave} of the main sparse-apply kernel that
-     * ran with this state, in ticks of the device wall clock (mrec_wall_clock_khz) */
+    /* [step % MREC_STAMP_RING][0] = begin of the first workgroup of the main sparse-apply kernel that ran with this state, in ticks of
+     * the device wall clock (mrec_wall_clock_khz); its end: stamps_end below */
     uint64_t stamps[MREC_STAMP_RING][2];
     /* [step % MREC_STAMP_RING] = {begin, end of the step's fused lookup kernel (mrec_gather_rows_wide_ex with step_state: it runs
      * BEFORE the step's mrec_step_advance and stamps the slot of step + 1), end of the finishing kernel of the sparse apply
      * (k_apply_long), 0}: what bench.py reads the in-graph times of EmbeddingLookup + sparse apply from */
     uint64_t stamps_aux[MREC_STAMP_RING][4];
+    /* [step % MREC_STAMP_RING][workgroup % 64] = end of that workgroup's last wave in the main sparse-apply kernel: the kernel's end is
+     * the maximum over the 64 slots (stamps[.][1] is no longer written: one atomicMax per workgroup on it cost the step 4 us) */
+    uint64_t stamps_end[MREC_STAMP_RING][64];
 } mrec_step_state_t;
 int mrec_step_state_init(void* state, float beta1_power, float beta2_power, int64_t step, void* stream);
 /* powers *= betas, step += 1, lr_t recomputed, the stamp slot of the new step reset */

@@ -566,7 +566,10 @@ __global__ __launch_bounds__(256, WIDE ? MREC_WPS4 : 1) void k_apply_main(Upd up
     // Stamps: workgroup 0 (dispatched first) stores the begin; the last wave of every workgroup raises the end -- ONE global
     // atomic per workgroup (an atomic per wave on the one address serialised at ~6 ns each and made the kernel 140 us longer).
     __shared__ int waves_done;
-    unsigned long long* stamp = ss ? ss->stamps[(unsigned)ss->step % kStampRing] : nullptr;
+    unsigned long long* stamp = ((MREC_STAMPS & 1) && ss) ? ss->stamps[(unsigned)ss->step % kStampRing] : nullptr;
+    // (the end: only the LAST-dispatched 1024 workgroups -- the last round of residency at 4 per CU -- read the clock; every
+    // workgroup doing it lengthened each of the four rounds by its realtime read: 4-6 us per step, profiles/r05_stamps_ab.txt)
+    if (stamp && blockIdx.x != 0 && (int)blockIdx.x + 1024 < (int)gridDim.x) stamp = nullptr;
     if (stamp) {
         if (threadIdx.x == 0) {
             waves_done = 0;
@@ -576,8 +579,8 @@ __global__ __launch_bounds__(256, WIDE ? MREC_WPS4 : 1) void k_apply_main(Upd up
     }
     apply_main_body<VEC, K, Upd, GT, WIDE>(upd, V, ld, uniq, spos, sseg, n, g, ldg, rscale, gscale, gm, carry_head, carry_tail, owners,
                                            seg_offsets, wa);
-    if (stamp && (threadIdx.x & 63) == 0 && atomicAdd(&waves_done, 1) == 3)
-        atomicMax(&stamp[1], (unsigned long long)wall_clock64());
+    if (stamp && (int)blockIdx.x + 1024 >= (int)gridDim.x && (threadIdx.x & 63) == 0 && atomicAdd(&waves_done, 1) == 3)
+        ss->ends[(unsigned)ss->step % kStampRing][blockIdx.x & 63u] = (unsigned long long)wall_clock64();
 }
 
 
@@ -752,7 +755,7 @@ __device__ __forceinline__ void apply_long_body(Upd upd, int64_t V, int64_t ld, 
     // end stamp (measurement): the workgroups that had a run to finish raise it -- one atomic each.  A step whose batch left no
     // partial sums behind (uniform ids since round 5: straddling pairs are summed by k_apply_main) has no finishing work and
     // no finishing stamp: its apply ends with k_apply_main's own end stamp.
-    if (ss && threadIdx.x == 0 && cnt_a + cnt > 0)
+    if ((MREC_STAMPS & 4) && ss && threadIdx.x == 0 && cnt_a + cnt > 0)
         atomicMax((unsigned long long*)&ss->aux[(unsigned)ss->step % kStampRing][2], (unsigned long long)wall_clock64());
 }
 
@@ -950,11 +953,15 @@ __global__ void k_step_init(StepState* s, float b1p, float b2p, long long step) 
     if (i < kStampRing) {
         s->stamps[i][0] = ~0ull; s->stamps[i][1] = 0ull;
         s->aux[i][0] = ~0ull; s->aux[i][1] = 0ull; s->aux[i][2] = 0ull; s->aux[i][3] = 0ull;
+        for (int j = 0; j < 64; ++j) s->ends[i][j] = 0ull;
     }
 }
 __global__ void k_step_advance(StepState* s, float lr, float b1, float b2) {
     const float b1p = s->b1p * b1, b2p = s->b2p * b2;
     const long long step = s->step + 1;
+    __syncthreads();                                                 // (64 threads: every one has read the old step)
+    s->ends[(unsigned)step % kStampRing][threadIdx.x & 63u] = 0ull;  // this step's k_apply_main end slots
+    if (threadIdx.x != 0) return;
     s->b1p = b1p; s->b2p = b2p; s->step = step;
     s->lr_t = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);      // same fp32 operations as the host-side entries
     s->stamps[(unsigned)step % kStampRing][0] = ~0ull;
@@ -973,7 +980,7 @@ MREC_API int mrec_step_state_init(void* state, float beta1_power, float beta2_po
 }
 MREC_API int mrec_step_advance(void* state, float lr, float beta1, float beta2, void* stream) {
     if (!state) return MREC_EINVAL;
-    k_step_advance<<<1, 1, 0, (hipStream_t)stream>>>((StepState*)state, lr, beta1, beta2);
+    k_step_advance<<<1, 64, 0, (hipStream_t)stream>>>((StepState*)state, lr, beta1, beta2);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }

@@ -1019,7 +1019,7 @@ class StepState:
     state the optimizer's own graph advances (nn.Adam: beta1_power *= beta1) -- so that a captured step has constant arguments."""
     RING = 256
     _DT = np.dtype([("beta1_power", "<f4"), ("beta2_power", "<f4"), ("lr_t", "<f4"), ("r0", "<f4"), ("step", "<i8"), ("r1", "<u8"),
-                    ("stamps", "<u8", (256, 2)), ("stamps_aux", "<u8", (256, 4))])
+                    ("stamps", "<u8", (256, 2)), ("stamps_aux", "<u8", (256, 4)), ("stamps_end", "<u8", (256, 64))])
 
     def __init__(self, device, beta1_power=1.0, beta2_power=1.0, step=0):
         self.buf = torch.empty(self._DT.itemsize, dtype=torch.uint8, device=device)
@@ -1041,10 +1041,11 @@ class StepState:
 
     def apply_ms(self, steps):
         """Durations (ms) of the main sparse-apply kernel in the given step numbers, from the kernel's own stamps."""
-        st = self.read()["stamps"]
+        r = self.read()
+        st, en = r["stamps"], r["stamps_end"]
         out = []
         for k in steps:
-            a, b = int(st[k % self.RING][0]), int(st[k % self.RING][1])
+            a, b = int(st[k % self.RING][0]), int(en[k % self.RING].max())
             if b > a and a != 0xFFFFFFFFFFFFFFFF:
                 out.append((b - a) / self.clock_khz)
         return out
@@ -1053,10 +1054,10 @@ class StepState:
         """Per step: (fused lookup kernel ms, sparse apply incl. its finishing kernel ms: begin of k_apply_main -> end of
         k_apply_long) from the kernels' own stamps -- the in-graph times of EmbeddingLookup + sparse apply."""
         r = self.read()
-        st, aux = r["stamps"], r["stamps_aux"]
+        st, aux, en = r["stamps"], r["stamps_aux"], r["stamps_end"]
         out = []
         for k in steps:
-            a0, a1, l0, l1, e2 = (int(st[k % self.RING][0]), int(st[k % self.RING][1]), int(aux[k % self.RING][0]), int(aux[k % self.RING][1]),
+            a0, a1, l0, l1, e2 = (int(st[k % self.RING][0]), int(en[k % self.RING].max()), int(aux[k % self.RING][0]), int(aux[k % self.RING][1]),
                                   int(aux[k % self.RING][2]))
             if a1 > a0 and a0 != 0xFFFFFFFFFFFFFFFF and l1 > l0 and l0 != 0xFFFFFFFFFFFFFFFF and (e2 >= a1 or e2 == 0):
                 # (e2 == 0: no workgroup of the finishing pass had a run to finish in this step -- the apply ended with k_apply_main)
