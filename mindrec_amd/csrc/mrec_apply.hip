@@ -690,7 +690,11 @@ __device__ __forceinline__ void apply_long_body(Upd upd, int64_t V, int64_t ld, 
     // dense Adam beside it has dirtied in the XCD's L2), the workgroup whose ticket was a run's last added the chunk sums in
     // chunk order and updated the row.  Zipf ids x 39 fields, same box, two A/B pairs: this pass 35.0-36.9 us against 29.6-30.8
     // as it is, k_apply_main 97.6-98.4 against 98.2-98.4, the step 0.7366 against 0.7321-0.7458 ms -- the hot runs are not what
-    // the pass waits for; the thousands of runs of 9-1000 entries are, one lane-group or one workgroup each.)
+    // the pass waits for; the thousands of runs of 9-1000 entries are, one lane-group or one workgroup each.
+    // Nor is it their placement or the length of a run's chain: 12 or 24 windows per workgroup instead of 48 (the flagged windows
+    // of Zipf ids sit at the head of the list), and a per-window record {row, partials} written by k_apply_main that takes three
+    // dependent round trips off every run here, both left the pass at 42-47 us.  As a launch of its own the same pass took 13 us
+    // (round 3): inside this launch every round trip waits in the memory system behind the dense Adam's 4.7 TB/s of streaming.)
     {
         for (int o = 0; o < cnt; ++o) {
             const int sw = list[o];
