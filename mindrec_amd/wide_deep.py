@@ -25,6 +25,7 @@ data-parallel with one flat all-reduce(mean) (gradients_mean=True,
 train_and_eval_distribute.py:135-138).
 """
 import contextlib
+import os
 from dataclasses import dataclass, field
 from typing import List
 
@@ -343,6 +344,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         # (default priority: a high-priority side stream was measured at 1.52 ms/step instead of 0.88)
         self._side = torch.cuda.Stream(device=self.device) if self._gpu else None
         import os
+        self._fuse_finish = True      # the apply's finishing pass inside the dense Adam launch (see _choose_finish)
         self._plan_fork = os.environ.get("MREC_PLAN_FORK", "lookup")       # where the captured step forks its plan branch: "lookup" | "head"
         self.deep_apply_timer = None  # optional ops.KernelTimer armed right before the deep table's sparse apply
         self._dyn = False             # step scalars (Adam powers / step size) in device memory: set per step
@@ -640,8 +642,17 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         self.last_plan = g["plan"]
         return g["loss"]
 
+    def _choose_finish(self):
+        """Where the sparse apply's finishing pass runs: inside the dense net's Adam launch (default), or -- MREC_FUSE_FINISH=0 -- as a
+        launch of its own in front of it.  Measured on one box (round 5): uniform ids have nothing to finish (an empty pass is free
+        inside the Adam launch, ~4 us as a launch); Zipf ids x 39 fields: the pass takes 43 us inside the Adam launch (its dependent
+        round trips queue behind 4.7 TB/s of streaming) and 31 us alone, but the step 0.715 ms fused against 0.732-0.737 separate --
+        fused, the pass hides under the Adam pass it runs beside."""
+        self._fuse_finish = os.environ.get("MREC_FUSE_FINISH", "1") != "0"
+
     def _capture_step(self, ids, wts, label):
         try:
+            self._choose_finish()
             g = {"ids": ids, "wts": wts, "label": label}
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
@@ -792,6 +803,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
 
     def _capture_sink(self, key, inputs):
         try:
+            self._choose_finish()
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             losses = []
@@ -914,7 +926,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
                                                    lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
                                                    beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
                                                    grad_scale=inv_sens, ftrl_lr=cfg.ftrl_lr, l1=cfg.ftrl_l1, l2=cfg.ftrl_l2,
-                                                   step_state=state, defer=True)
+                                                   step_state=state, defer=self._fuse_finish)
         else:
             self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, lr=cfg.adam_lr,
                                      beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
