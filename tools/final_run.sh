@@ -36,6 +36,10 @@ cd $R
 # what a rank of an N-GPU job does besides moving bytes over xGMI: the row-shard protocol over RCCL with itself, and its kernels alone
 python bench.py --no-cpu-baseline --shard-protocol 2>/dev/null | grep "^{\"metric\"" | tail -1 > $O/bench_line_shard_protocol.json
 cut -c1-220 $O/bench_line_shard_protocol.json
+# ... on Criteo-like ids x 39 fields: one 16-bit row per position against one fp32 row per UNIQUE id on the wire (the line's rccl block carries
+# the byte model of an 8-rank node for both)
+python bench.py --no-cpu-baseline --shard-protocol --dist zipf --fields 39 2>/dev/null | grep "^{\"metric\"" | tail -1 > $O/bench_line_shard_protocol_zipf39.json
+python bench.py --no-cpu-baseline --shard-protocol --dist zipf --fields 39 --shard-uniques 0.3 2>/dev/null | grep "^{\"metric\"" | tail -1 > $O/bench_line_shard_protocol_zipf39_uniques.json
 python bench.py --no-cpu-baseline --dist zipf --fields 39 > $O/bench_line_zipf39.json 2>/dev/null
 # id-distribution sweep: uniform / Zipf(1.05), 26 / 39 fields
 for d in uniform zipf; do for f in 26 39; do
@@ -61,4 +65,12 @@ timeout -k 10 300 python tools/cache_bench.py > $O/cache_bench.txt 2>/dev/null
 tail -5 $O/cache_bench.txt
 python bench.py --no-cpu-baseline --no-zipf39 --mlp-dtype fp32 2>/dev/null | tail -1 > $O/bench_line_fp32net.json      # the fp32-net option (exact-fp32 MFMA DenseLayers)
 bash tools/probes/run_cross_trace.sh gpurun_out/final/cross_trace
+python tools/config5_bench.py fp16 2>/dev/null | tail -1 > $O/config5_line.json
+fi
+if [ "$PART" = 4 ]; then
+cd $R
+# SQ counters of the 16-bit DenseLayer kernels inside the benchmarked step; L2 / atomic / wait counters of MapParameter.get over new keys
+bash tools/probes/run_gemm16_pmc.sh > /dev/null 2>&1; cp gpurun_out/gemm16_pmc/gemm16_pmc.txt $O/gemm16_pmc.txt
+bash tools/probes/run_map_pmc.sh > /dev/null 2>&1; cp gpurun_out/map_pmc/map_pmc.txt $O/map_pmc.txt
+tail -30 $O/map_pmc.txt
 fi
