@@ -455,6 +455,13 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     if (head_pair) posw[0] = posw[1];                     // (skipped: its gradient row is not this window's -- request a line it fetches anyway)
     const int e_end2 = e_end + (tail_pair ? 1 : 0);       // the entries this window walks
     asm volatile("" : "+v"(last_end));      // landed with the row numbers (needed here: see vtouch)
+    // (CHUNKS, round 5, built, parity-green at chunk widths 2 / 3 / 8 and measured: a lane-group walks W consecutive windows and
+    // keeps a run's sum in its registers from one window into the next, so runs leave partial sums only where they cross a
+    // chunk of W x 8 entries.  Zipf ids x 39 fields, one box: the finishing pass 44 -> 23-24 us at every W >= 2 (its floor inside
+    // the dense Adam's launch), but this kernel 97 -> 104 us already at W = 1 -- the loop-carried sum and the chunk's state cost
+    // 5-8 spilled registers at the 128 budget -- and 113 / 116 / 125 / 135 us at W = 2 / 3 / 4 / 6: neighbouring lane-groups no
+    // longer share index lines and a slot's W windows are no longer balanced by the dispatcher.  Uniform ids 176.5 -> 179.5 (W = 1)
+    // -> 182-201 us.  The step did not move (0.717-0.726 ms at every W): the finishing pass already hides behind the dense Adam.)
     // (A two-round-trip path for windows that own no run end -- all eight gradient rows at once, no row numbers; half of the
     // windows on Zipf ids x 39 fields -- was built and measured: 94.6-95.5 us against 95.6-96.1, not kept.)
     Vf<VEC> acc;
