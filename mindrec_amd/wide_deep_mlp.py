@@ -301,7 +301,11 @@ class DenseNetMixin:
         gradient is left as per-tile-row partial sums) and the weight gradient (fp32 batch slabs) are workgroups of the
         same kernel -- both read dh, and for the narrow layers neither fills the chip alone.  Slabs and partial sums are
         added up inside the dense Adam.  (Weight gradients on a parallel stream / graph branch instead were measured:
-        the graph runtime queues chain kernels behind side-branch work, 0.87 -> 0.95 ms/step.)"""
+        the graph runtime queues chain kernels behind side-branch work, 0.87 -> 0.95 ms/step.  Round 5, layer 0 only: its input
+        gradient alone on the chain and its weight gradient -- which feeds nothing but the dense Adam -- on a branch beside the
+        SPARSE APPLY, an HBM-bound launch that leaves the matrix cores idle: the apply stretched by the whole GEMM, 177 -> 241 us
+        on uniform ids and 96 -> 203 us on Zipf ids x 39 fields, the step 0.632 -> 0.655 ms; forked in front of the input gradient
+        0.749 ms.  A GEMM workgroup holds its CU's registers and LDS for its whole K loop: the apply's waves do not fit beside it.)"""
         n = len(self.dims) - 1
         hs, dh = ctx["hs"], ctx["dh"]
         B = hs[0].shape[0]
