@@ -14,6 +14,13 @@
 // k-steps in lockstep, sweep a contiguous window.  (Read from the row-major matrices -- 16 rows x 64 B per instruction, the same
 // column offset in every wave -- the stream ran at 26 GB/s per CU, a third of what the XCD's L2 delivers: 10 us per 256-KB pass.)
 // Accumulators hold C transposed as in mrec_gemm.h: a lane owns 4 consecutive output columns of one row.
+//
+// (Round 5, built, parity-green and measured, not kept: the tail THREE layers deep -- the 1024 -> 512 layer's forward as a phase in
+// front and its input gradient as a phase behind, its 1-MB weight copies streamed through a two-chunk register ring, its three
+// weight gradients riding the first layer's backward launch.  The launch took 90 us against 34 + the 26-us forward GEMM it
+// replaces, the backward launch that absorbed the weight gradients 194 us against 129 + 63, the step 0.626 -> 0.657 ms.  Every
+// workgroup pulls the whole weight matrix through its XCD's L2 for 64 rows of reuse: 32 CUs x 2 MB = 64 MB per XCD for the two
+// phases, 56 us at the ~1.1 TB/s an XCD's L2 delivered to this access pattern -- the 256 x 256 GEMM tiles move a third of that.)
 #include "mrec_common.h"
 #include "mrec_dropout.h"
 #include "mrec_mlp.h"
