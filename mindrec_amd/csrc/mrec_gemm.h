@@ -222,8 +222,10 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
         const bool last_ = ktail && (kt0 + tt_ == Ttot - 1);                                                      \
         const uint32_t v0_ = !live_ ? kOob : last_ ? (isP_ ? voffPt[h_][0] : voffQt[h_][0]) : (isP_ ? voffP[h_][0] : voffQ[h_][0]); \
         const uint32_t v1_ = !live_ ? kOob : last_ ? (isP_ ? voffPt[h_][1] : voffQt[h_][1]) : (isP_ ? voffP[h_][1] : voffQ[h_][1]); \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(isP_ ? rP : rQ, (MGEMM_LDS void*)dst_, 16, v0_, soff_, 0, 0);    \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(isP_ ? rP : rQ, (MGEMM_LDS void*)(dst_ + 1024), 16, v1_, soff_, 0, 0); \
+        if (!((VAR & 8) && tt_ >= 2)) {                                                                           \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(isP_ ? rP : rQ, (MGEMM_LDS void*)dst_, 16, v0_, (VAR & 32) ? 0u : soff_, 0, 0);    \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(isP_ ? rP : rQ, (MGEMM_LDS void*)(dst_ + 1024), 16, v1_, (VAR & 32) ? 0u : soff_, 0, 0); \
+        }                                                                                                         \
     } while (0)
 
     // ---- per-lane LDS read offsets
@@ -253,6 +255,11 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
     // (Skipping the MFMAs of the wave quadrants that lie outside the output in the tiles that hang over its edge -- 2080 =
     // 8 x 256 + 32: the ninth column tile of layer 0's input gradient -- was measured: the launch takes as long; such a
     // workgroup's K-tile takes what its staging and barriers take.)
+    // Harness-only variants (tools/probes/dense_gemm_test.hip; no product kernel sets these bits): VAR & 8 stages the first two
+    // K-tiles only, VAR & 16 reads the fragments of the first K-tile only, VAR & 32 stages every K-tile from the first one's
+    // addresses (served by the caches), VAR & 64 adds up where a phase's cycles go (s_memtime per segment; sums to colsum_ws).
+    bool rd_done = false;
+    uint32_t tseg[8][4] = {}, tlast = 0;          // [phase + 4 * buffer][segment: issue + waits, first barrier, MFMAs, second barrier]
     u32x4_t fP[4][2], fQ0[2][2], fQ1[2][2];       // fragments [rep][ks]
     f32x4_t acc[MR][4];
 #pragma unroll
@@ -270,6 +277,7 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
 
 #define MG_READ_P(BUF, H)                                                                              \
     do {                                                                                               \
+        if ((VAR & 16) && rd_done) break;                                                              \
         _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) { \
             if (!PT) fP[mi_][ks_] = ld128(slot_off(BUF, (H) ? 3 : 0) + (mi_ * 2 + ks_) * 1024 + rdP0); \
             else fP[mi_][ks_] = ldtr(slot_off(BUF, (H) ? 3 : 0) + (4 * ks_ + (mi_ >> 1)) * 1024 + ((mi_ & 1) ? rdP1 : rdP0)); \
@@ -277,6 +285,7 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
     } while (0)
 #define MG_READ_Q(BUF, H, F)                                                                           \
     do {                                                                                               \
+        if ((VAR & 16) && rd_done) break;                                                              \
         _Pragma("unroll") for (int nj_ = 0; nj_ < 2; ++nj_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) { \
             if (!QT) F[nj_][ks_] = ld128(slot_off(BUF, (H) ? 2 : 1) + (nj_ * 2 + ks_) * 1024 + rdQ0);  \
             else F[nj_][ks_] = ldtr(slot_off(BUF, (H) ? 2 : 1) + (2 * ks_) * 1024 + (nj_ ? rdQ1 : rdQ0)); \
@@ -296,7 +305,9 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
     } while (0)
 #define MG_SYNC_PRE()                                     \
     do {                                                  \
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
+        if constexpr ((VAR & 4096) != 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
+        if constexpr ((VAR & 2048) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         __builtin_amdgcn_sched_barrier(0);                \
         __builtin_amdgcn_s_barrier();                     \
         __builtin_amdgcn_sched_barrier(0);                \
@@ -307,30 +318,71 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
         __builtin_amdgcn_s_barrier();      \
         __builtin_amdgcn_sched_barrier(0); \
     } while (0)
+#define MG_T(PH, SG)                                                              \
+    do {                                                                              \
+        if constexpr ((VAR & 64) != 0) {                                              \
+            __builtin_amdgcn_sched_barrier(0);                                        \
+            const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();             \
+            tseg[PH][SG] += now_ - tlast;                                             \
+            tlast = now_;                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                        \
+        }                                                                             \
+    } while (0)
+#define MG_PHASE_SYNC_MFMA(PH, MH, NH, F, half_)     \
+    do {                                             \
+        if constexpr ((VAR & 64) != 0) {             \
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
+            MG_T(PH, 0);                             \
+            __builtin_amdgcn_s_barrier();            \
+            MG_T(PH, 1);                             \
+            MG_MFMA(MH, NH, F, half_);               \
+            MG_T(PH, 2);                             \
+            __builtin_amdgcn_s_barrier();            \
+            MG_T(PH, 3);                             \
+        } else {                                     \
+            MG_SYNC_PRE();                           \
+            MG_MFMA(MH, NH, F, half_);               \
+            MG_SYNC_POST();                          \
+        }                                            \
+    } while (0)
+    // (VAR & 128, harness only, WRONG results: the same 24 fragment reads dealt out 6 / 6 / 6 / 6 over the four phases instead of
+    // 12 / 4 / 8 / 0 -- what balancing the load segments would be worth, before building it)
+#define MG_RD1P(BUF, H, mi_, ks_) fP[mi_][ks_] = ld128(slot_off(BUF, (H) ? 3 : 0) + ((mi_) * 2 + (ks_)) * 1024 + rdP0)
+#define MG_KTILE_BAL(BUF, t)                         \
+    do {                                             \
+        const bool half_ = false;                    \
+        MG_READ_Q(BUF, 0, fQ0);                      \
+        MG_RD1P(BUF, 0, 0, 0); MG_RD1P(BUF, 0, 0, 1); \
+        MG_STAGE(2, (BUF) ^ 1, (t) + 1);             \
+        MG_PHASE_SYNC_MFMA(0 + 4 * (BUF), 0, 0, fQ0, half_); \
+        MG_READ_Q(BUF, 1, fQ1);                      \
+        MG_RD1P(BUF, 0, 1, 0); MG_RD1P(BUF, 0, 1, 1); \
+        MG_STAGE(3, (BUF) ^ 1, (t) + 1);             \
+        MG_PHASE_SYNC_MFMA(1 + 4 * (BUF), 0, 1, fQ1, half_); \
+        MG_RD1P(BUF, 1, 0, 0); MG_RD1P(BUF, 1, 0, 1); MG_RD1P(BUF, 1, 1, 0); MG_RD1P(BUF, 1, 1, 1); MG_RD1P(BUF, 1, 2, 0); MG_RD1P(BUF, 1, 2, 1); \
+        MG_STAGE(0, BUF, (t) + 2);                   \
+        MG_PHASE_SYNC_MFMA(2 + 4 * (BUF), 1, 1, fQ1, half_); \
+        MG_RD1P(BUF, 1, 3, 0); MG_RD1P(BUF, 1, 3, 1); MG_RD1P(BUF, 0, 2, 0); MG_RD1P(BUF, 0, 2, 1); MG_RD1P(BUF, 0, 3, 0); MG_RD1P(BUF, 0, 3, 1); \
+        MG_STAGE(1, BUF, (t) + 2);                   \
+        MG_PHASE_SYNC_MFMA(3 + 4 * (BUF), 1, 0, fQ0, half_); \
+    } while (0)
     // the four phases of K-tile t living in LDS buffer BUF
 #define MG_KTILE(BUF, t)                             \
     do {                                             \
-        const bool half_ = ktail && krem <= 32 && (kt0 + (t)) == Ttot - 1;    \
+        const bool half_ = !(VAR & 1024) && ktail && krem <= 32 && (kt0 + (t)) == Ttot - 1;    \
         MG_READ_Q(BUF, 0, fQ0);                      \
         MG_READ_P(BUF, 0);                           \
         MG_STAGE(2, (BUF) ^ 1, (t) + 1);             \
-        MG_SYNC_PRE();                               \
-        MG_MFMA(0, 0, fQ0, half_);                   \
-        MG_SYNC_POST();                              \
+        MG_PHASE_SYNC_MFMA(0 + 4 * (BUF), 0, 0, fQ0, half_); \
         MG_READ_Q(BUF, 1, fQ1);                      \
         MG_STAGE(3, (BUF) ^ 1, (t) + 1);             \
-        MG_SYNC_PRE();                               \
-        MG_MFMA(0, 1, fQ1, half_);                   \
-        MG_SYNC_POST();                              \
+        MG_PHASE_SYNC_MFMA(1 + 4 * (BUF), 0, 1, fQ1, half_); \
         MG_READ_P(BUF, 1);                           \
         MG_STAGE(0, BUF, (t) + 2);                   \
-        MG_SYNC_PRE();                               \
-        MG_MFMA(1, 1, fQ1, half_);                   \
-        MG_SYNC_POST();                              \
+        MG_PHASE_SYNC_MFMA(2 + 4 * (BUF), 1, 1, fQ1, half_); \
         MG_STAGE(1, BUF, (t) + 2);                   \
-        MG_SYNC_PRE();                               \
-        MG_MFMA(1, 0, fQ0, half_);                   \
-        MG_SYNC_POST();                              \
+        MG_PHASE_SYNC_MFMA(3 + 4 * (BUF), 1, 0, fQ0, half_); \
+        if (VAR & 16) rd_done = true;                \
     } while (0)
 
     if constexpr (MR == 8) {
@@ -344,9 +396,50 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
         MG_SYNC_PRE();
         if (!(VAR & 1) && wr == 1) __builtin_amdgcn_s_barrier();       // stagger: wave row 1 runs one barrier behind wave row 0
 
+        uint64_t tc0 = 0, tr0 = 0;
+        if constexpr ((VAR & 64) != 0) {
+            tc0 = __builtin_amdgcn_s_memtime();
+            tr0 = __builtin_amdgcn_s_memrealtime();
+            tlast = (uint32_t)tc0;
+        }
+        if constexpr ((VAR & 128) != 0 && !PT && !QT) {
+            MG_READ_P(0, 0);
+            for (int t = 0; t < T; t += 2) {
+                MG_KTILE_BAL(0, t);
+                if (t + 1 < T) MG_KTILE_BAL(1, t + 1);
+            }
+        } else if constexpr ((VAR & 256) != 0) {
+            for (int t = 0; t < T; t += 4) {
+                MG_KTILE(0, t);
+                if (t + 1 < T) MG_KTILE(1, t + 1);
+                if (t + 2 < T) MG_KTILE(0, t + 2);
+                if (t + 3 < T) MG_KTILE(1, t + 3);
+            }
+        } else if constexpr ((VAR & 512) != 0) {
+            for (int t = 0; t < T; t += 8) {
+                MG_KTILE(0, t);
+                if (t + 1 < T) MG_KTILE(1, t + 1);
+                if (t + 2 < T) MG_KTILE(0, t + 2);
+                if (t + 3 < T) MG_KTILE(1, t + 3);
+                if (t + 4 < T) MG_KTILE(0, t + 4);
+                if (t + 5 < T) MG_KTILE(1, t + 5);
+                if (t + 6 < T) MG_KTILE(0, t + 6);
+                if (t + 7 < T) MG_KTILE(1, t + 7);
+            }
+        } else
         for (int t = 0; t < T; t += 2) {
             MG_KTILE(0, t);
             if (t + 1 < T) MG_KTILE(1, t + 1);
+        }
+        if constexpr ((VAR & 64) != 0) {
+            if (l == 0 && a.colsum_ws != nullptr) {          // [workgroup][wave][phase][segment] cycle sums
+#pragma unroll
+                for (int ph = 0; ph < 8; ++ph)
+#pragma unroll
+                    for (int sg = 0; sg < 4; ++sg) a.colsum_ws[((int64_t)bid * 8 + w) * 36 + ph * 4 + sg] = (float)tseg[ph][sg];
+                a.colsum_ws[((int64_t)bid * 8 + w) * 36 + 32] = (float)(__builtin_amdgcn_s_memtime() - tc0);         // shader cycles
+                a.colsum_ws[((int64_t)bid * 8 + w) * 36 + 33] = (float)(__builtin_amdgcn_s_memrealtime() - tr0);     // 100 MHz ticks
+            }
         }
     } else {
         // ---- 128 x 256 tile: a K-tile is three 16-KB pieces (P, Q cols 0-31, Q cols 32-63 of every wave column) in one of
@@ -675,6 +768,10 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
 #undef MG_SYNC_PRE
 #undef MG_SYNC_POST
 #undef MG_KTILE
+#undef MG_T
+#undef MG_RD1P
+#undef MG_KTILE_BAL
+#undef MG_PHASE_SYNC_MFMA
 }
 
 template <bool PT, bool QT, int EPI, bool F16, int VAR = 0, int MR = 8>

@@ -171,8 +171,75 @@ static void test_wgrad(int M, int Kin, int N, int S) {
     CK(hipFree(dX)); CK(hipFree(ddY)); CK(hipFree(dC));
 }
 
+
+// Main-loop ablations of the forward kernel as the product launches it (both operands K-contiguous, fp16; timing only: the
+// ablated variants compute garbage).  VAR bits: mrec_gemm.h.  VAR & 64: prints where a phase's cycles go.
+template <int VAR>
+static void time_fwd_kc(int M, int N, int K, const char* what) {
+    std::vector<uint16_t> hX((size_t)M * K), hW((size_t)N * K);
+    for (auto& x : hX) x = h_f2bf(frand());         // (bit patterns only matter for the clock the chip holds: full-range random)
+    for (auto& x : hW) x = h_f2bf(frand());
+    uint16_t *dX, *dW, *dC; float *db, *dws;
+    CK(hipMalloc(&dX, hX.size() * 2)); CK(hipMalloc(&dW, hW.size() * 2)); CK(hipMalloc(&dC, (size_t)M * N * 2)); CK(hipMalloc(&db, N * 4));
+    CK(hipMemcpy(dX, hX.data(), hX.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(db, 0, N * 4));
+    Args a{};
+    a.P = dX; a.Q = dW; a.C = dC; a.bias = db; a.ldp = K; a.ldq = K; a.ldc = N; a.Pext = M; a.Qext = N; a.K = K;
+    a.nTp = (M + 255) / 256; a.nTq = (N + 255) / 256; a.relu = 1; a.kt_per_slab = (K + 63) / 64;
+    const int grid = a.nTp * a.nTq;
+    CK(hipMalloc(&dws, (size_t)grid * 8 * 36 * 4));
+    CK(hipMemset(dws, 0, (size_t)grid * 8 * 36 * 4));
+    if (VAR & 64) a.colsum_ws = dws;
+    auto run = [&] { k_gemm256<false, false, EPI_FWD, true, VAR, 8><<<grid, kThreads>>>(a); };
+    run();
+    CK(hipDeviceSynchronize());
+    Timer tm;
+    double best = 1e30, sum = 0;
+    for (int r = 0; r < 5; ++r) { const double us = tm.us(run, 20); best = us < best ? us : best; sum += us; }
+    printf("var %3d %-34s M=%d N=%d K=%d grid %d: mean %7.1f us  best %7.1f us  %6.3f PF/s\n", VAR, what, M, N, K, grid, sum / 5, best,
+           2.0 * M * N * K / best / 1e9);
+    if (VAR & 64) {
+        std::vector<float> h((size_t)grid * 8 * 36);
+        CK(hipMemcpy(h.data(), dws, h.size() * 4, hipMemcpyDeviceToHost));
+        const int T = (K + 63) / 64;
+        for (int half = 0; half < 2; ++half) {
+            double acc[32] = {};
+            double cyc = 0, rt = 0;
+            for (int b = 0; b < grid; ++b)
+                for (int w = half * 4; w < half * 4 + 4; ++w) { cyc += h[((size_t)b * 8 + w) * 36 + 32]; rt += h[((size_t)b * 8 + w) * 36 + 33]; }
+            for (int b = 0; b < grid; ++b)
+                for (int w = half * 4; w < half * 4 + 4; ++w)
+                    for (int i = 0; i < 32; ++i) acc[i] += h[((size_t)b * 8 + w) * 36 + i];
+            printf("    waves %d-%d, cycles per phase (issue+waits | barrier 1 | MFMAs | barrier 2):", half * 4, half * 4 + 3);
+            double tot = 0;
+            for (int ph = 0; ph < 8; ++ph) {
+                if (ph == 4) printf("\n            odd K-tiles:");
+                printf("  [");
+                for (int sg = 0; sg < 4; ++sg) { const double v = acc[ph * 4 + sg] / (grid * 4.0) / (T / 2); tot += v; printf(" %5.0f", v); }
+                printf(" ]");
+            }
+            printf("  two K-tiles %6.0f  clock %.2f GHz\n", tot, cyc / rt * 0.1);
+        }
+    }
+    CK(hipFree(dX)); CK(hipFree(dW)); CK(hipFree(dC)); CK(hipFree(db)); CK(hipFree(dws));
+}
+static void ablations(int B) {
+    for (int rep = 0; rep < 3; ++rep) {
+        const int K = rep == 0 ? 2080 : rep == 1 ? 1024 : 8320;
+        time_fwd_kc<0>(B, 1024, K, "as shipped");
+        time_fwd_kc<128>(B, 1024, K, "reads dealt 6/6/6/6 (wrong results)");
+        time_fwd_kc<128 + 2048>(B, 1024, K, "... + lgkmcnt(0) before barrier 1");
+        time_fwd_kc<128 + 4096>(B, 1024, K, "... + vmcnt(6)");
+        time_fwd_kc<128 + 2048 + 4096>(B, 1024, K, "... + both");
+        time_fwd_kc<2048>(B, 1024, K, "as shipped + lgkmcnt(0) before barrier 1");
+        time_fwd_kc<4096>(B, 1024, K, "as shipped + vmcnt(6) (wrong results)");
+        time_fwd_kc<0>(B, 1024, K, "as shipped (again)");
+    }
+}
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 16384;
+    if (argc > 2 && !strcmp(argv[2], "ablate")) { ablations(B); return 0; }
     if (argc > 2 && !strcmp(argv[2], "prof")) {        // one long dispatch for counter passes (clock, LDS conflicts)
         test_fwd(B, 1024, 33280);
         test_dgrad<8>(B, 1024, 33280, false);
