@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--dropout", action="store_true", help="dropout_flag: True as in benchmarks/wide_deep/default_config.yaml:15 (Dropout(0.5) on every "
                     "DenseLayer input; models/wide_deep/default_config.yaml:27, the configuration of configs[1], has it off)")
     ap.add_argument("--sink-size", type=int, default=5, help="training steps per host call (the reference's dataset_sink_mode / sink_size: "
-                    "train_and_eval.py:98-101, train_and_eval_distribute.py:115-116); with the whole-step graph a sink is ONE graph launch")
+                    "train_and_eval.py:98-101, train_and_eval_distribute.py:115-116); with the whole-step graph a sink is ONE graph launch "
+                    "(sinks of 1 / 2 / 3 / 5 / 6 / 10 / 15 / 30 steps measured on one box, round 5: 0.636 / 0.636 / 0.631 / 0.631-0.636 / 0.633 / "
+                    "0.639 / 0.642 / 0.640 ms per step -- the host enqueues the next sink while this one runs; longer graphs are no faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of each cpu_baseline leg")
     ap.add_argument("--n-batches", type=int, default=4, help="distinct resident batches cycled through")
@@ -66,6 +68,11 @@ def parse():
                     "1.25 otherwise (the engine's default); a run that drops a position is refused")
     ap.add_argument("--comm-timeout", type=int, default=180, help="seconds after which a rendezvous or a collective that a peer never joined "
                     "raises instead of hanging")
+    ap.add_argument("--stamps", default="roofline", choices=["roofline", "always", "never"],
+                    help="the kernels' own wall-clock stamps (they cost the step ~6 us, profiles/r05_stamps_ab.txt): 'roofline' (default) = off in "
+                    "the timed blocks `value` comes from, on in --stamp-blocks extra blocks of the same steps right behind them, which the "
+                    "roofline figures come from; 'always' = on throughout (what the runs under rocprofv3 that calibrate the clock offsets use)")
+    ap.add_argument("--stamp-blocks", type=int, default=2)
     ap.add_argument("--no-zipf39", action="store_true", help="skip the secondary Criteo-like measurement (Zipf ids, 39 fields) behind the timed region")
     args = ap.parse_args()
     if args.capacity_factor is None:
@@ -376,6 +383,10 @@ def _measure(args, world, rank, dev):
     # 45 % slower than its fourth (min / max of the blocks: 0.633 / 0.932 ms).  A fixed count, the same on every rank.
     run_steps(args.prime_steps)
     barrier()
+    ss_ = getattr(eng, "_step_state", None)
+    stamps_split = bool(args.stamps == "roofline" and ss_ is not None and eng._step_graph is not None)
+    if ss_ is not None and (stamps_split or args.stamps == "never"):
+        ss_.set_stamps(False)
     run_steps(args.warmup)
     barrier()
     block_s, kmain = [], []
@@ -396,16 +407,33 @@ def _measure(args, world, rank, dev):
     embed_stamps = []
     apply_timing = ("HIP events around k_apply_main on its launch stream (mrec_profile_next_apply), "
                     "averaged over the {n} timed steps")
-    if eng._step_graph is not None:
+    n_stamped_blocks = len(block_s)
+    stamped_ms_per_step = None
+    if stamps_split:
+        # the same steps again, stamped: the blocks the roofline figures are read from (not `value`)
+        ss_.set_stamps(True)
+        run_steps(args.steps)                      # (untimed: the first stamped sink)
+        n_stamped_blocks = max(1, args.stamp_blocks)
+        sb = []
+        for r in range(n_stamped_blocks):
+            barrier()
+            t0 = time.perf_counter()
+            run_steps(args.steps)
+            barrier()
+            sb.append(time.perf_counter() - t0)
+        stamped_ms_per_step = round(median(sb) / args.steps * 1e3, 4)
+    if eng._step_graph is not None and args.stamps != "never":
         # The whole step is one HIP graph: events recorded inside a captured graph cannot be timed on this stack (hipError 400,
         # tools/probes/graph_event_probe.py), so the kernel stamps the device wall clock itself -- first workgroup in, last wave
         # out -- into a ring in the device-side step state, read here after the timed region.
         last = eng.step_count
-        n_timed = min(len(block_s) * args.steps, ops.StepState.RING - 1)
+        n_timed = min(n_stamped_blocks * args.steps, ops.StepState.RING - 1)
         kmain = eng._step_state.apply_ms(range(last - n_timed + 1, last + 1))
         embed_stamps = eng._step_state.embed_ms(range(last - n_timed + 1, last + 1))      # (lookup, apply incl. k_apply_long) per step
         apply_timing = ("device wall-clock stamps written by k_apply_main itself (first workgroup begin -> last wave end; the step "
-                        "is one HIP graph, whose event nodes cannot be timed), averaged over the last {n} timed steps")
+                        "is one HIP graph, whose event nodes cannot be timed), averaged over the last {n} timed steps"
+                        + (f" -- of {n_stamped_blocks} extra blocks of the same steps run right behind the blocks `value` comes from, with the "
+                           f"stamps switched on ({stamped_ms_per_step} ms per step there); `value`'s blocks run without them" if stamps_split else ""))
     dt = median(block_s)
     graphs_used = {"step": eng._step_graph is not None, "front": eng._front_graph is not None, "mlp": eng._mlp_graph is not None,
                    "sink_size": S if (any(k[0] == S and v for k, v in eng._sink_graphs.items()) and args.steps >= S) else 1}
@@ -446,6 +474,9 @@ def _measure(args, world, rank, dev):
     fold = bool(eng._fold_wide and world == 1)
     apply_bytes = by["apply_deep"] + (U * 24 + args.batch * 4 if fold else 0)
     lookup_bytes = by["lookup"] + (U * 4 + n_apply * 4 if fold else 0)
+    if not kmain:                 # (--stamps never on a whole-step graph: only the eager cross-check is left)
+        kmain = ev_ms or [float("nan")]
+        apply_timing = "HIP events around k_apply_main in {n} eager extra steps (--stamps never)"
     apply_ms_stamps = sum(kmain) / len(kmain)
     # The profiler's clock.  rocprofv3 times a dispatch from the command processor's begin to its end signal; the kernels' own
     # stamps (first workgroup in -> last wave out) leave out the few microseconds in front of the first workgroup and behind the
@@ -522,6 +553,8 @@ def _measure(args, world, rank, dev):
                                f"({'hand-written MFMA kernels' if eng._mfma else (f'hand-written fp32 DenseLayers, MatMuls: {cfg.fp32_matmul}' if getattr(eng, '_f32net', False) else 'torch GEMMs')}; looked-up rows and row gradients in {dt_name})"
                                f"{f', {S} steps per host call (sink_size)' if graphs_used.get('sink_size', 1) > 1 else ''}"
                                f"{', Dropout(0.5) on every DenseLayer input' if args.dropout else ''}",
+                   "kernel_stamps": ("off in the timed blocks; on in %d extra blocks of the same steps behind them (%s ms per step), which the roofline "
+                                     "figures are read from" % (n_stamped_blocks, stamped_ms_per_step)) if stamps_split else args.stamps,
                    "global_batch": args.batch * world, "id_dist": args.dist, "hip_graphs": graphs_used, "unique_frac": round(U / max(n_apply, 1), 4),
                    "parallelism": ("1 GPU" + (", row-shard protocol over RCCL with itself" if args.shard_protocol else "")) if world == 1 else f"tables row-sharded x{world} (RCCL all-to-all), MLP dp{world}"},
         "roofline": {"bound": "hbm",

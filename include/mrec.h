@@ -260,7 +260,8 @@ typedef struct mrec_step_state {
     float lr_t;                       /* lr * sqrt(1 - beta2_power) / (1 - beta1_power), fp32 operations in this order */
     float reserved0;
     int64_t step;
-    uint64_t reserved1;
+    uint64_t stamps_off;              /* nonzero: the kernels leave no stamps (mrec_step_state_init sets 0; the host may store to this word
+                                       * between steps: it is read by the kernels of the steps that follow) */
     /* [step % MREC_STAMP_RING][0] = begin of the first workgroup of the main sparse-apply kernel that ran with this state, in ticks of
      * the device wall clock (mrec_wall_clock_khz); its end: stamps_end below */
     uint64_t stamps[MREC_STAMP_RING][2];

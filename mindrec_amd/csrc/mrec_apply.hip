@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256, WIDE ? MREC_WPS4 : 1) void k_apply_main(Upd up
     // Stamps: workgroup 0 (dispatched first) stores the begin; the last wave of every workgroup raises the end -- ONE global
     // atomic per workgroup (an atomic per wave on the one address serialised at ~6 ns each and made the kernel 140 us longer).
     __shared__ int waves_done;
-    unsigned long long* stamp = ((MREC_STAMPS & 1) && ss) ? ss->stamps[(unsigned)ss->step % kStampRing] : nullptr;
+    unsigned long long* stamp = ((MREC_STAMPS & 1) && ss && !ss->stamps_off) ? ss->stamps[(unsigned)ss->step % kStampRing] : nullptr;
     // (the end: only the LAST-dispatched 1024 workgroups -- the last round of residency at 4 per CU -- read the clock; every
     // workgroup doing it lengthened each of the four rounds by its realtime read: 4-6 us per step, profiles/r05_stamps_ab.txt)
     if (stamp && blockIdx.x != 0 && (int)blockIdx.x + 1024 < (int)gridDim.x) stamp = nullptr;
@@ -766,7 +766,7 @@ __device__ __forceinline__ void apply_long_body(Upd upd, int64_t V, int64_t ld, 
     // end stamp (measurement): the workgroups that had a run to finish raise it -- one atomic each.  A step whose batch left no
     // partial sums behind (uniform ids since round 5: straddling pairs are summed by k_apply_main) has no finishing work and
     // no finishing stamp: its apply ends with k_apply_main's own end stamp.
-    if ((MREC_STAMPS & 4) && ss && threadIdx.x == 0 && cnt_a + cnt > 0)
+    if ((MREC_STAMPS & 4) && ss && !ss->stamps_off && threadIdx.x == 0 && cnt_a + cnt > 0)
         atomicMax((unsigned long long*)&ss->aux[(unsigned)ss->step % kStampRing][2], (unsigned long long)wall_clock64());
 }
 
@@ -960,7 +960,7 @@ int ftrl_impl(float* var, float* accum, float* linear, int64_t V, int64_t ld, in
 namespace {
 __global__ void k_step_init(StepState* s, float b1p, float b2p, long long step) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) { s->b1p = b1p; s->b2p = b2p; s->lr_t = 0.f; s->pad0 = 0.f; s->step = step; s->pad1 = 0; }
+    if (i == 0) { s->b1p = b1p; s->b2p = b2p; s->lr_t = 0.f; s->pad0 = 0.f; s->step = step; s->stamps_off = 0; }
     if (i < kStampRing) {
         s->stamps[i][0] = ~0ull; s->stamps[i][1] = 0ull;
         s->aux[i][0] = ~0ull; s->aux[i][1] = 0ull; s->aux[i][2] = 0ull; s->aux[i][3] = 0ull;

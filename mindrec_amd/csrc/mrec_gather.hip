@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
     // Stamps (measurement only; ss == nullptr: none): workgroup 0 stores the begin, the last wave of each of the LAST-dispatched
     // 512 workgroups raises the end -- this lookup belongs to step ss->step + 1 (the step's advance runs behind it).
     __shared__ int waves_done;
-    unsigned long long* stamp = ((MREC_STAMPS & 2) && ss) ? ss->aux[(unsigned)(ss->step + 1) % kStampRing] : nullptr;
+    unsigned long long* stamp = ((MREC_STAMPS & 2) && ss && !ss->stamps_off) ? ss->aux[(unsigned)(ss->step + 1) % kStampRing] : nullptr;
     if (stamp) {
         if (threadIdx.x == 0) {
             waves_done = 0;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_gather_rows_w16(const float* __restrict
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
     __shared__ int waves_done;
-    unsigned long long* stamp = ((MREC_STAMPS & 2) && ss) ? ss->aux[(unsigned)(ss->step + 1) % kStampRing] : nullptr;      // (as k_gather_rows)
+    unsigned long long* stamp = ((MREC_STAMPS & 2) && ss && !ss->stamps_off) ? ss->aux[(unsigned)(ss->step + 1) % kStampRing] : nullptr;      // (as k_gather_rows)
     if (stamp) {
         if (threadIdx.x == 0) {
             waves_done = 0;

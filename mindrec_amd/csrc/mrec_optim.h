@@ -30,7 +30,8 @@ constexpr int kStampRing = 256;
 struct StepState {
     float b1p, b2p, lr_t, pad0;
     long long step;
-    unsigned long long pad1;
+    unsigned long long stamps_off;              // nonzero: no kernel stamps in the steps that run with this state (a training run: 0 costs
+                                                // the step ~6 us; bench.py turns them on for the blocks its roofline figures come from)
     unsigned long long stamps[kStampRing][2];   // [step % ring] = {first workgroup start, last wave end} of k_apply_main, wall clock ticks
     // [step % ring] = {begin, end of the step's fused lookup kernel (k_gather_rows with the wide lane), end of k_apply_long, 0}
     unsigned long long aux[kStampRing][4];

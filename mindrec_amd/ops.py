@@ -1035,6 +1035,11 @@ class StepState:
     def advance(self, lr, beta1, beta2):
         _lib.call("mrec_step_advance", _ptr(self.buf), float(lr), float(beta1), float(beta2), _stream())
 
+    def set_stamps(self, on):
+        """Kernel stamps on (the state's initial setting) or off for the steps enqueued after this call (a store to the state's
+        `stamps_off` word on the current stream; captured graphs read the word when they run)."""
+        self.buf[24:32].view(torch.int64).fill_(0 if on else 1)
+
     def read(self):
         """Host copy (synchronises): a numpy record with beta1_power, beta2_power, lr_t, step, stamps[256, 2]."""
         return self.buf.cpu().numpy().view(self._DT)[0]

@@ -13,7 +13,7 @@ if [ "$PART" = 1 ]; then
 cd /tmp && export TMPDIR=/tmp
 RND=${RND:-r05}
 # the profiler's clock first: kernel statistics of the benchmarked command, and what rocprofv3 adds to the kernels' own stamps
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-zipf39 > $O/bench_line_under_rocprof.json 2> $O/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-zipf39 --stamps always > $O/bench_line_under_rocprof.json 2> $O/prof.err
 cp $(find $O/prof -name "*kernel_stats.csv") $O/bench_kernel_stats.csv
 python3 $R/tools/prof_summary.py $O/bench_kernel_stats.csv > $O/bench_kernel_summary.txt
 python3 $R/tools/step_timeline.py $O/prof > $O/step_timeline_under_rocprof.txt 2>&1

@@ -226,15 +226,11 @@ static void time_fwd_kc(int M, int N, int K, const char* what) {
 }
 static void ablations(int B) {
     for (int rep = 0; rep < 3; ++rep) {
-        const int K = rep == 0 ? 2080 : rep == 1 ? 1024 : 8320;
+        const int K = rep == 0 ? 2080 : rep == 1 ? 1024 : 128;
         time_fwd_kc<0>(B, 1024, K, "as shipped");
-        time_fwd_kc<128>(B, 1024, K, "reads dealt 6/6/6/6 (wrong results)");
-        time_fwd_kc<128 + 2048>(B, 1024, K, "... + lgkmcnt(0) before barrier 1");
-        time_fwd_kc<128 + 4096>(B, 1024, K, "... + vmcnt(6)");
-        time_fwd_kc<128 + 2048 + 4096>(B, 1024, K, "... + both");
-        time_fwd_kc<2048>(B, 1024, K, "as shipped + lgkmcnt(0) before barrier 1");
-        time_fwd_kc<4096>(B, 1024, K, "as shipped + vmcnt(6) (wrong results)");
+        time_fwd_kc<8192>(B, 1024, K, "no output stores");
         time_fwd_kc<0>(B, 1024, K, "as shipped (again)");
+        time_fwd_kc<8192>(B, 1024, K, "no output stores (again)");
     }
 }
 int main(int argc, char** argv) {
