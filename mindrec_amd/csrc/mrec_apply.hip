@@ -350,6 +350,73 @@ __device__ __forceinline__ int64_t seg_row(const K* uniq, int seg) {
     return uniq ? (int64_t)uniq[seg] : (int64_t)seg;
 }
 
+// ---- constant columns ------------------------------------------------------------------------------------------------------
+// Criteo's 13 dense features are fields whose id is the SAME in every sample (datasets/criteo_1tb/process_data.py:138-147: one id per
+// dense field, the feature's value is the weight): a run of B entries in the sorted index, 2048 window partials and a block's worth
+// of finishing work each -- a third of the positions of a 39-field batch.  For such a column the sum over the batch needs no index
+// at all: row b of the gradient matrix holds the column's 160 bytes at a fixed offset, neighbouring constant columns next to it.
+// k_const_cols (below) finds the columns whose id is one and the same in all B samples and occurs in no other column; the windows
+// of k_apply_main skip their entries (position -> field -> a bit of the mask), the first `cblocks` workgroups of the SAME launch sum
+// the columns sample by sample (a lane-group walks ONE column over a chunk of `rr` consecutive samples, eight in flight; products and
+// order of operations as in the windows), and the finishing launch adds a column's chunk sums in chunk order and updates its one
+// row.  Fixed order: bitwise reproducible.  (First form, measured on Zipf ids x 39 fields: a lane-group = 16 samples x all columns,
+// 32 dependent round trips -- as long as the whole launch -- and 1024 partial rows per column for the finishing pass: k_apply_main
+// 121 -> 124 us, the finishing pass 44 -> 66 us.)
+constexpr int kConstMax = 16;        // constant columns handled (the first 16 in field order)
+constexpr int kConstLG = 256;        // chunks of consecutive samples the partial-sum pass cuts the batch into, at most
+struct ConstCols { const unsigned long long* mask; const void* ids0; float* part; int B, rr, nlg; unsigned cblocks; int id_bytes; };
+
+// bit f: field f is a constant column (at most kConstMax bits; written by k_const_cols' last workgroup: one scalar load here)
+__device__ __forceinline__ unsigned long long const_mask(const unsigned long long* __restrict__ mask) { return *mask; }
+
+template <class GT>
+__device__ __forceinline__ void const_part_body(const ConstCols& cc, unsigned long long cmask, const GT* __restrict__ g, int64_t ldg,
+                                                const float* __restrict__ rscale, float gscale, const WideArgs& wa, ApplyGeom gm) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
+    if (grp >= gm.G) return;
+    // a lane-group = (chunk of rr consecutive samples, constant column j): neighbouring lane-groups take neighbouring columns of the
+    // same samples (one contiguous stretch of a gradient row where the constant columns are adjacent fields), eight samples in flight
+    const int nc = __popcll(cmask);
+    const int lg = ((int)blockIdx.x * 4 + wave) * gm.G + grp;
+    if (lg >= cc.nlg * nc) return;
+    const int chunk = lg / nc, j = lg - chunk * nc;
+    int f = 0;
+    {
+        unsigned long long m = cmask;
+        for (int q = 0; q < j; ++q) m &= m - 1ull;
+        f = (int)__ffsll((long long)m) - 1;
+    }
+    const bool wl = sub == gm.lpr - 1;
+    const int ccol = sub * 4;
+    const int b0 = chunk * cc.rr, b1 = (b0 + cc.rr < cc.B) ? b0 + cc.rr : cc.B;
+    Vf<4> acc;
+    vzero(acc);
+    for (int bb = b0; bb < b1; bb += 8) {
+        GBits<4, GT> gb[8];
+        float rs[8], gwv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int b = bb + q < b1 ? bb + q : b1 - 1;                  // (past the chunk: its last sample again, dropped)
+            const int64_t pos = (int64_t)b * wa.F + f;
+            gload<true>(gb[q], g + pos * ldg + (wl ? 0 : ccol));
+            rs[q] = rscale ? rscale[pos] : 1.0f;
+            gwv[q] = wa.gw[(unsigned)b * wa.gws];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (bb + q >= b1) continue;
+            Vf<4> x;
+            gwiden(x, gb[q]);
+            if (wl) { vzero(x); vset_x(x, gwv[q]); }
+            if (rscale) vmul(x, rs[q]);
+            vmul(x, gscale);
+            if (bb + q == b0) acc = x; else vadd(acc, x);
+        }
+    }
+    vstore<false>(cc.part + ((int64_t)chunk * kConstMax + j) * gm.D + ccol, acc);
+}
+
 // (WIDE: MREC_WPS4 waves per SIMD asked of the register allocator)
 template <int VEC, class K, class Upd, class GT, bool WIDE = false>
 __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
@@ -358,7 +425,7 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
                                                     const float* __restrict__ rscale, float gscale, ApplyGeom gm,
                                                     float* __restrict__ carry_head, float* __restrict__ carry_tail,
                                                     int* __restrict__ owners, const int* __restrict__ seg_offsets,
-                                                    const WideArgs& wa) {
+                                                    const WideArgs& wa, const unsigned long long cmask = 0ull, const unsigned bid0 = 0u) {
     constexpr int AW = ACfg<VEC>::AW, AB = ACfg<VEC>::AB, GP = ACfg<VEC>::GP;
     constexpr bool NT = ACfg<VEC>::NT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -372,12 +439,12 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     // A wave walks several windows (the grid is capped at MREC_APPLY_MAXB workgroups, the waves in flight at any moment cover a
     // contiguous stretch of the list): a new wave pays a chain of scalar round trips -- kernel arguments in pieces, the step
     // state, the device-side length -- before its first index word, as long as the window's own chain.
-    const int64_t sw_stride = (int64_t)gridDim.x * 4 * gm.G;
+    const int64_t sw_stride = (int64_t)(gridDim.x - bid0) * 4 * gm.G;      // (bid0: workgroups in front of this pass in the launch)
     // Straddling pairs are summed in place (below) only where duplicates are rare.  The same decision in every wave of every
     // window: the number of groups is the last entry's group number + 1.
     const int n_groups = n > 0 ? sseg[n - 1] + 1 : 0;
     const bool pairs_on = MREC_PAIRS && (int64_t)(n - n_groups) * MREC_PAIRS_DUP_DIV <= (int64_t)n;
-    for (int64_t sw = ((int64_t)blockIdx.x * 4 + wave) * gm.G + grp; sw * AW < n; sw += sw_stride) {
+    for (int64_t sw = ((int64_t)(blockIdx.x - bid0) * 4 + wave) * gm.G + grp; sw * AW < n; sw += sw_stride) {
     const int s = (int)(sw * AW);
     const int e_end = (s + AW < n) ? s + AW : n;
 
@@ -412,9 +479,28 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     const int seg_after = sseg[s + AW + 1 < nlast ? s + AW + 1 : nlast];
 #pragma unroll
     for (int q = AW + 1; q < AW + GP; ++q) { posw[q] = 0; segw[q] = -2; }
+    // entries of CONSTANT columns (cmask, above) are not this pass's: their runs -- B entries each -- are summed row by row by the
+    // launch's first workgroups.  Such a run is longer than a window, so its entries are a window's head, its tail or all of it:
+    // they become entries past the end (group -2), which every test below already treats as nobody's.
+    unsigned hotm = 0u;
+    if (WIDE && cmask) {
+#pragma unroll
+        for (int q = 0; q < AW; ++q) {
+            const unsigned pos = (unsigned)posw[q];
+            const unsigned fld = pos - (wa.F == 1 ? pos : __umulhi(pos, wa.magic)) * (unsigned)wa.F;
+            hotm |= ((unsigned)(cmask >> fld) & 1u) << q;
+        }
+        unsigned inw = 0u;
+#pragma unroll
+        for (int q = 0; q < AW; ++q) inw |= (s + q < e_end ? 1u : 0u) << q;
+        if ((inw & ~hotm) == 0u) {                       // the whole window lies inside constant columns' runs: nothing to do, nothing carried
+            if (sub == 0) owners[sw] = 0;
+            continue;
+        }
+    }
 #pragma unroll
     for (int q = 0; q < AW; ++q) {
-        const bool valid = s + q < e_end;
+        const bool valid = s + q < e_end && !((hotm >> q) & 1u);
         posw[q] = valid ? posw[q] : 0;
         segw[q] = valid ? segw[q] : -2;
     }
@@ -439,11 +525,11 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     // requested with the row numbers, not behind the window's stores: a load there waits for them -- vmcnt counts in order)
     int last_seg = segw[0];
 #pragma unroll
-    for (int q = 1; q < AW; ++q) last_seg = (s + q < e_end) ? segw[q] : last_seg;
+    for (int q = 1; q < AW; ++q) last_seg = (s + q < e_end) ? segw[q] : last_seg;      // (-2 where the window ends inside a constant column's run)
     int last_end = seg_offsets[(last_seg < 0 ? 0 : last_seg) + 1];
 #pragma unroll
     for (int q = 0; q < AW; ++q) {
-        const bool valid = s + q < e_end;
+        const bool valid = s + q < e_end && !((hotm >> q) & 1u);
         const bool is_end = valid && segw[q + 1] != segw[q];
         const bool open = head_open && segw[q] == first_seg;
         endm |= is_end ? (1u << q) : 0u;
@@ -515,7 +601,7 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
 #pragma unroll
             for (int k = 0; k < AB; ++k) {
                 const int q = j0 + k;
-                if (s + q >= e_end2) continue;
+                if (s + q >= e_end2 || ((hotm >> q) & 1u)) continue;
                 Vf<VEC> x = xs[k];
                 const bool is_start = q == 0 || segw[q] != segw[q - 1];
                 if (is_start) acc = x; else vadd(acc, x);
@@ -565,27 +651,36 @@ __global__ __launch_bounds__(256, WIDE ? MREC_WPS4 : 1) void k_apply_main(Upd up
                                                     const float* __restrict__ rscale, float gscale, ApplyGeom gm,
                                                     float* __restrict__ carry_head, float* __restrict__ carry_tail,
                                                     int* __restrict__ owners, const int* __restrict__ seg_offsets,
-                                                    WideArgs wa, StepState* ss, const int64_t* __restrict__ nv = nullptr) {
+                                                    WideArgs wa, StepState* ss, const int64_t* __restrict__ nv = nullptr,
+                                                    const ConstCols cc = ConstCols{}) {
     // (Fetching all kernel arguments in one scalar round trip at the top -- left alone the compiler fetches them in pieces,
     // each in front of its first use -- was measured: uniform ids 172 -> 174 us, Zipf x 39 fields 96 -> 101; not kept.)
     resolve_step(upd, ss);
     if (nv) { const int64_t x = *nv; if (x < n) n = x < 0 ? 0 : (int)x; }      // entries of the index proper: known on the device only
+    unsigned long long cmask = 0ull;
+    if constexpr (WIDE && VEC == 4) {
+        if (cc.mask) cmask = const_mask(cc.mask);
+        if (blockIdx.x < cc.cblocks) {                 // the constant columns' partial sums: dispatched first, a chain of `rr` round trips
+            if (cmask) const_part_body<GT>(cc, cmask, g, ldg, rscale, gscale, wa, gm);
+            return;
+        }
+    }
     // Stamps: workgroup 0 (dispatched first) stores the begin; the last wave of every workgroup raises the end -- ONE global
     // atomic per workgroup (an atomic per wave on the one address serialised at ~6 ns each and made the kernel 140 us longer).
     __shared__ int waves_done;
     unsigned long long* stamp = ((MREC_STAMPS & 1) && ss && !ss->stamps_off) ? ss->stamps[(unsigned)ss->step % kStampRing] : nullptr;
     // (the end: only the LAST-dispatched 1024 workgroups -- the last round of residency at 4 per CU -- read the clock; every
     // workgroup doing it lengthened each of the four rounds by its realtime read: 4-6 us per step, profiles/r05_stamps_ab.txt)
-    if (stamp && blockIdx.x != 0 && (int)blockIdx.x + 1024 < (int)gridDim.x) stamp = nullptr;
+    if (stamp && blockIdx.x != cc.cblocks && (int)blockIdx.x + 1024 < (int)gridDim.x) stamp = nullptr;
     if (stamp) {
         if (threadIdx.x == 0) {
             waves_done = 0;
-            if (blockIdx.x == 0) stamp[0] = (unsigned long long)wall_clock64();
+            if (blockIdx.x == cc.cblocks) stamp[0] = (unsigned long long)wall_clock64();
         }
         __syncthreads();
     }
     apply_main_body<VEC, K, Upd, GT, WIDE>(upd, V, ld, uniq, spos, sseg, n, g, ldg, rscale, gscale, gm, carry_head, carry_tail, owners,
-                                           seg_offsets, wa);
+                                           seg_offsets, wa, cmask, cc.cblocks);
     if (stamp && (int)blockIdx.x + 1024 >= (int)gridDim.x && (threadIdx.x & 63) == 0 && atomicAdd(&waves_done, 1) == 3)
         ss->ends[(unsigned)ss->step % kStampRing][blockIdx.x & 63u] = (unsigned long long)wall_clock64();
 }
@@ -788,10 +883,84 @@ __global__ __launch_bounds__(256) void k_apply_long(Upd upd, int64_t V, int64_t 
 // dependent round trips with almost nothing to move (uniform ids: ~450 runs; 9-10 us as a launch of its own behind
 // k_apply_main, 13 us on Zipf ids x 39 fields), which hides entirely inside the 32-us HBM-bound Adam pass beside it.  (As a graph
 // side branch instead the cross-branch join costs more than the overlap returns)
+// The constant columns' rows: workgroup j of this pass adds the lane-groups' partial sums of column j in lane-group order (twelve
+// lane-groups take a twelfth each, eight rows in flight, then their sums in order) and updates the column's one row.
+template <class K>
+__device__ __forceinline__ void const_finish_body(UpdAdam upd, int64_t V, int64_t ld, ApplyGeom gm, const WideArgs& wa, const ConstCols& cc,
+                                                  const StepState* ss, int j) {
+    resolve_step(upd, ss);
+    const unsigned long long cmask = const_mask(cc.mask);
+    __shared__ float cred[1024];          // 4 G lane-groups x 4 lpr floats, G * lpr <= 64
+    int f = -1;
+    {
+        unsigned long long m = cmask;
+        for (int q = 0; q <= j && m; ++q) { if (q == j) f = (int)__ffsll((long long)m) - 1; m &= m - 1ull; }
+    }
+    if (f < 0) return;                                   // fewer constant columns than j + 1 (uniform over the workgroup)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
+    const bool active = grp < gm.G;
+    const bool wl = sub == gm.lpr - 1;
+    const int col = sub * 4, tcol = wl ? wa.wcol : col;
+    const int NG = 4 * gm.G, gi = wave * gm.G + grp;
+    const int per = (cc.nlg + NG - 1) / NG;
+    Vf<4> acc;
+    vzero(acc);
+    if (active) {
+        const int l0 = gi * per, l1 = (l0 + per < cc.nlg) ? l0 + per : cc.nlg;
+        for (int t0 = l0; t0 < l1; t0 += 8) {
+            Vf<4> x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int t = t0 + q < l1 ? t0 + q : l1 - 1;
+                vload<false>(x[q], cc.part + ((int64_t)t * kConstMax + j) * gm.D + col);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (t0 + q < l1) { if (t0 + q == l0) acc = x[q]; else vadd(acc, x[q]); }
+        }
+        vstore<false>(cred + gi * gm.D + col, acc);
+    }
+    __syncthreads();
+    if (active && gi == 0) {
+        for (int q = 1; q < NG; ++q) {
+            if (q * per >= cc.nlg) break;
+            Vf<4> x;
+            vload<false>(x, cred + q * gm.D + col);
+            vadd(acc, x);
+        }
+        const int64_t row = (int64_t)((const K*)cc.ids0)[f];
+        if (row >= 0 && row < V) {
+            const int64_t roff = row * ld + tcol;
+            Vf<4> st[3];
+            if (wl) {
+                vload<false>(st[0], upd.s[0] + roff);
+                wide_apply(st[0], acc, wa.h);
+                vstore<false>(upd.s[0] + roff, st[0]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) vload<false>(st[i], upd.s[i] + roff);
+                upd_apply<UpdAdam>(upd, st, acc);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) vstore<false>(upd.s[i] + roff, st[i]);
+            }
+        }
+    }
+    if ((MREC_STAMPS & 4) && ss && !ss->stamps_off && threadIdx.x == 0)
+        atomicMax((unsigned long long*)&ss->aux[(unsigned)ss->step % kStampRing][2], (unsigned long long)wall_clock64());
+}
+
+template <class K>
+__global__ __launch_bounds__(256) void k_apply_const_finish(UpdAdam upd, int64_t V, int64_t ld, ApplyGeom gm, WideArgs wa, ConstCols cc,
+                                                            const StepState* ss) {
+    const_finish_body<K>(upd, V, ld, gm, wa, cc, ss, (int)blockIdx.x);
+}
+
 struct ApplyFinish {
     UpdAdam upd; int64_t V, ld; const void* uniq; int key_bytes; const int* sseg; const int* seg_offsets; int n; ApplyGeom gm;
     const float* carry_head; const float* carry_tail; const int* owners; int nsw; WideArgs wa; const StepState* ss;
     const int64_t* nv; unsigned lblocks; unsigned magic;
+    ConstCols cc; unsigned cfin;            // cfin: workgroups of the constant columns' finishing pass (kConstMax, or 0: no such pass)
 };
 static_assert(sizeof(ApplyFinish) <= sizeof(mrec_apply_finish_t), "mrec_apply_finish_t too small");
 constexpr unsigned kFinishMagic = 0x4D524543u;
@@ -803,21 +972,28 @@ __global__ __launch_bounds__(256) void k_finish_dense_adam(ApplyFinish f, DenseA
                                              f.carry_tail, f.owners, f.nsw, f.wa, f.ss, f.nv, (int)blockIdx.x, (int)f.lblocks);
         return;
     }
+    if (blockIdx.x < f.lblocks + f.cfin) {
+        const_finish_body<K>(f.upd, f.V, f.ld, f.gm, f.wa, f.cc, f.ss, (int)(blockIdx.x - f.lblocks));
+        return;
+    }
+    const unsigned front = f.lblocks + f.cfin;
     dense_adam4_slabs_body<SHK>(a.p, a.m, a.v, a.g, a.n4, a.h, a.shadow, sg, a.ss, a.f1,
-                                (int64_t)(blockIdx.x - f.lblocks) * 256 + threadIdx.x, (int64_t)(gridDim.x - f.lblocks) * 256);
+                                (int64_t)(blockIdx.x - front) * 256 + threadIdx.x, (int64_t)(gridDim.x - front) * 256);
 }
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 thread_local hipEvent_t t_prof_start = nullptr, t_prof_stop = nullptr;
 thread_local ApplyFinish* t_defer = nullptr;        // set by mrec_sparse_lazy_adam_wide_defer: the finishing pass is handed back, not launched
+thread_local ConstCols t_const = ConstCols{};       // set by mrec_sparse_apply_next_const_cols: the next wide apply takes constant columns out of its windows
 
-struct ApplyWs { float* carry_head; float* carry_tail; int* owners; int* n_owners; float* dummy; };
+struct ApplyWs { float* carry_head; float* carry_tail; int* owners; int* n_owners; float* dummy; float* cpart; };
 
 size_t apply_ws_bytes(int64_t n, int32_t D) {
     const size_t nsw = (size_t)mrec_cdiv(n ? n : 1, AW_MIN);
     const int Dc = D > 256 ? 256 : D;
-    return mrec_align_up(nsw * Dc * 4, 256) * 2 + mrec_align_up(nsw * 4, 256) + 256 + 2048 * 64;
+    return mrec_align_up(nsw * Dc * 4, 256) * 2 + mrec_align_up(nsw * 4, 256) + 256 + 2048 * 64 +
+           mrec_align_up((size_t)kConstLG * kConstMax * Dc * 4, 256);
 }
 
 // One launch pair over columns [c0, c0+Dc) of every array.
@@ -845,9 +1021,22 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
     t_prof_start = t_prof_stop = nullptr;
     if (ev0) MREC_HIP_CHECK(hipEventRecord(ev0, st));
     if (nv && !(vec == 4 && wide)) return MREC_EUNSUPPORTED;
+    // constant columns (armed for this call by mrec_sparse_apply_next_const_cols): the batch is B = n / F samples of F fields, ids of
+    // the table's key width, LazyAdam on the fused rows -- anything else runs every column through the windows
+    ConstCols cc = t_const;
+    t_const = ConstCols{};
+    if (!(vec == 4 && wide && std::is_same<Upd, UpdAdam>::value && !nv && cc.mask && cc.ids0 && wa.F >= 1 && wa.F <= 64 &&
+          n % wa.F == 0 && cc.B == (int)(n / wa.F) && cc.B > 0 && wa.gws == 1 && cc.id_bytes == (int)sizeof(K)))
+        cc = ConstCols{};
+    if (cc.mask) {
+        cc.part = w.cpart;
+        cc.rr = (int)mrec_cdiv((int64_t)cc.B, (int64_t)kConstLG);
+        cc.nlg = (int)mrec_cdiv((int64_t)cc.B, (int64_t)cc.rr);                                      // chunks
+        cc.cblocks = (unsigned)mrec_cdiv((int64_t)cc.nlg * kConstMax, (int64_t)4 * gm.G);      // (room for kConstMax columns: how many there are is known on the device)
+    }
     if (vec == 4 && wide) {
-        k_apply_main<4, K, Upd, GT, true><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
-                                                             w.carry_head, w.carry_tail, w.owners, seg_offsets, wa, ss, nv);
+        k_apply_main<4, K, Upd, GT, true><<<blocks + cc.cblocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
+                                                             w.carry_head, w.carry_tail, w.owners, seg_offsets, wa, ss, nv, cc);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         if (t_defer) {
             if constexpr (std::is_same<Upd, UpdAdam>::value) {
@@ -855,12 +1044,16 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
                 f->upd = upd; f->V = V; f->ld = ld; f->uniq = uniq; f->key_bytes = (int)sizeof(K); f->sseg = sseg; f->seg_offsets = seg_offsets;
                 f->n = (int)n; f->gm = gm; f->carry_head = w.carry_head; f->carry_tail = w.carry_tail; f->owners = w.owners; f->nsw = (int)nsw;
                 f->wa = wa; f->ss = ss; f->nv = nv; f->lblocks = lblocks; f->magic = kFinishMagic;
+                f->cc = cc; f->cfin = cc.mask ? (unsigned)kConstMax : 0u;
             } else {
                 return MREC_EUNSUPPORTED;
             }
         } else {
             k_apply_long<4, K, Upd, true><<<lblocks, 256, 0, st>>>(upd, V, ld, uniq, sseg, seg_offsets, (int)n, gm,
                                                                   w.carry_head, w.carry_tail, w.owners, (int)nsw, wa, ss, nv);
+            if constexpr (std::is_same<Upd, UpdAdam>::value) {
+                if (cc.mask) k_apply_const_finish<K><<<kConstMax, 256, 0, st>>>(upd, V, ld, gm, wa, cc, ss);
+            }
         }
     } else if (vec == 4) {
         k_apply_main<4, K, Upd, GT><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
@@ -907,6 +1100,7 @@ int apply_impl(Upd upd, int64_t V, int64_t ld, int32_t D, const K* uniq, const i
     w.owners = a.take<int>(nsw);
     w.n_owners = a.take<int>(1);
     w.dummy = a.take<float>(2048 * 16);
+    w.cpart = a.take<float>((size_t)kConstLG * kConstMax * Dc_max);
     if (!a.ok) return MREC_EWORKSPACE;
     bool aligned = (ld % 4 == 0) && (ldg % 4 == 0) && ((((uintptr_t)g) & (4 * sizeof(GT) - 1)) == 0);
     for (int i = 0; i < Upd::NS; ++i) aligned = aligned && al16(upd.s[i]);
@@ -981,7 +1175,91 @@ __global__ void k_step_advance(StepState* s, float lr, float b1, float b2) {
     s->aux[(unsigned)(step + 1) % kStampRing][0] = ~0ull;            // the NEXT step's lookup (it runs before that step's advance)
     s->aux[(unsigned)(step + 1) % kStampRing][1] = 0ull;
 }
+// Which fields of a [B, F] batch are constant columns: field f qualifies iff every sample holds sample 0's id there, that id lies in
+// [0, V) and occurs in no other field.  Candidates = the fields where samples 0 and 1 agree (every workgroup works them out itself: 2 F
+// loads); a batch without one -- ids drawn per sample -- costs those loads and nothing else: workgroup 0 stores an empty mask.  With
+// candidates, every thread compares its ids with the candidates' (LDS), a workgroup ORs the candidates it saw fail into ONE device
+// word (a returning agent-scope atomic, waited for), THEN takes a ticket (so the ticket's last holder sees every workgroup's word: both
+// are atomics at the memory side, no fence -- a release fence here writes back whatever the kernels beside this one have dirtied in
+// L2, 17 us per step when it was tried), and that last workgroup turns the survivors into the mask the apply's kernels read with one
+// scalar load and clears word and ticket for the next batch: no memset node, no second launch.
+struct ConstState { unsigned long long badmask; unsigned ticket, pad; unsigned long long mask; unsigned long long pad2; };
+static_assert(sizeof(ConstState) == MREC_CONST_COLS_STATE_BYTES, "mrec.h: MREC_CONST_COLS_STATE_BYTES");
+template <class K>
+__global__ __launch_bounds__(256) void k_const_cols(const K* __restrict__ ids, int64_t n, int F, int64_t V, ConstState* __restrict__ st) {
+    __shared__ long long c[64];
+    __shared__ int clist[64];
+    __shared__ unsigned lbad[2];
+    __shared__ unsigned long long candm;
+    __shared__ int is_last;
+    const int t = (int)threadIdx.x;
+    if (t < 64) {
+        bool ok = false;
+        if (t < F) {
+            const long long v0 = (long long)ids[t], v1 = n >= 2 * (int64_t)F ? (long long)ids[F + t] : v0;
+            c[t] = v0;
+            ok = v0 == v1 && v0 >= 0 && v0 < V;
+        }
+        const unsigned long long m = __ballot(ok);           // (threads 0-63 are wave 0)
+        if (t == 0) { candm = m; lbad[0] = lbad[1] = 0u; }
+        if (ok) clist[__popcll(m & ((1ull << t) - 1ull))] = t;
+    }
+    __syncthreads();
+    const unsigned long long m = candm;
+    if (m == 0ull) {
+        if (blockIdx.x == 0 && t == 0) st->mask = 0ull;
+        return;
+    }
+    const int nc = __popcll(m);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + t; e < n; e += stride) {
+        const long long id = (long long)ids[e];
+        const int f = (int)(e % F);
+        if (((m >> f) & 1ull) && id != c[f] && !((lbad[f >> 5] >> (f & 31)) & 1u)) atomicOr(&lbad[f >> 5], 1u << (f & 31));
+        for (int q = 0; q < nc; ++q) {
+            const int f2 = clist[q];
+            if (f2 != f && id == c[f2] && !((lbad[f2 >> 5] >> (f2 & 31)) & 1u)) atomicOr(&lbad[f2 >> 5], 1u << (f2 & 31));
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        const unsigned long long mine = (unsigned long long)lbad[0] | ((unsigned long long)lbad[1] << 32);
+        if (mine) {
+            unsigned long long old = atomicOr(&st->badmask, mine);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(old) : : "memory");        // performed before the ticket is taken
+        }
+        is_last = atomicAdd(&st->ticket, 1u) == gridDim.x - 1u;
+    }
+    __syncthreads();
+    if (is_last && t == 0) {
+        const unsigned long long b = atomicOr(&st->badmask, 0ull);
+        unsigned long long mm = m & ~b, keep = 0ull;
+        for (int j = 0; j < kConstMax && mm; ++j) { const unsigned long long low = mm & (~mm + 1ull); keep |= low; mm ^= low; }
+        st->mask = keep;
+        atomicExch(&st->badmask, 0ull);
+        atomicExch(&st->ticket, 0u);
+    }
+}
 }  // namespace
+
+MREC_API int mrec_const_cols_detect(const void* ids, int32_t id_bytes, int64_t B, int32_t F, int64_t V, void* state, void* stream) {
+    if (!ids || !state || (id_bytes != 4 && id_bytes != 8) || B <= 0 || F <= 0 || V <= 0) return MREC_EINVAL;
+    if (F > 64) return MREC_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = B * F;
+    unsigned blocks = (unsigned)mrec_cdiv(n, (int64_t)256 * 8);
+    if (blocks > 256u) blocks = 256u;
+    if (id_bytes == 4) k_const_cols<int32_t><<<blocks, 256, 0, st>>>((const int32_t*)ids, n, F, V, (ConstState*)state);
+    else k_const_cols<int64_t><<<blocks, 256, 0, st>>>((const int64_t*)ids, n, F, V, (ConstState*)state);
+    MREC_LAUNCH_CHECK();
+    return MREC_OK;
+}
+MREC_API int mrec_sparse_apply_next_const_cols(const void* state, const void* ids, int32_t id_bytes, int64_t B) {
+    if ((state == nullptr) != (ids == nullptr) || B < 0 || B > (int64_t(1) << 30) || (ids && id_bytes != 4 && id_bytes != 8)) return MREC_EINVAL;
+    t_const = ConstCols{};
+    if (state) { t_const.mask = &((const ConstState*)state)->mask; t_const.ids0 = ids; t_const.B = (int)B; t_const.id_bytes = id_bytes; }
+    return MREC_OK;
+}
 
 MREC_API int mrec_step_state_init(void* state, float beta1_power, float beta2_power, int64_t step, void* stream) {
     if (!state || step < 0) return MREC_EINVAL;
@@ -1170,7 +1448,7 @@ MREC_API int mrec_sparse_lazy_adam_wide_defer(float* p, float* m, float* v, int6
                                               row_scale, lr, b1, b2, eps, b1_pow, b2_pow, grad_scale, nesterov, gw, gw_stride, F, wide_col,
                                               ftrl_lr, l1, l2, lr_power, ws, ws_bytes, step_state, n_valid_dev, stream);
     t_defer = nullptr;
-    if (rc == MREC_OK && f->magic != kFinishMagic) { f->lblocks = 0; f->magic = kFinishMagic; }      // (n == 0: nothing to finish)
+    if (rc == MREC_OK && f->magic != kFinishMagic) { f->lblocks = 0; f->cfin = 0; f->magic = kFinishMagic; }      // (n == 0: nothing to finish)
     return rc;
 }
 
@@ -1214,7 +1492,7 @@ MREC_API int mrec_dense_adam_slabs_finish_f32(float* p, float* m, float* v, cons
     }
     int64_t ab = mrec_cdiv(a.n4, 256);
     if (ab > 256 * 16) ab = 256 * 16;
-    const unsigned grid = fp->lblocks + (unsigned)ab;
+    const unsigned grid = fp->lblocks + fp->cfin + (unsigned)ab;
     if (grid == 0) return MREC_OK;
     hipStream_t st = (hipStream_t)stream;
 #define MREC_FIN(KT)                                                                                      \

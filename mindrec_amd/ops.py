@@ -369,16 +369,48 @@ def sparse_lazy_adam_(p, m, v, plan, g, row_scale=None, lr=3.5e-4, beta1=0.9, be
 
 
 class ApplyFinish(C.Structure):      # mrec_apply_finish_t
-    _fields_ = [("opaque", C.c_ubyte * 384)]
+    _fields_ = [("opaque", C.c_ubyte * 448)]
+
+
+CONST_COLS_STATE_BYTES = 32        # MREC_CONST_COLS_STATE_BYTES
+
+
+def const_cols_state(device):
+    """The device-side state of const_cols_detect (zeroed once, then owned by the library's calls)."""
+    return torch.zeros(CONST_COLS_STATE_BYTES // 4, dtype=torch.int32, device=device)
+
+
+def const_cols_detect(ids, V, state=None):
+    """Which fields of the [B, F] batch `ids` are constant columns (mrec_const_cols_detect, include/mrec.h): every sample holds
+    sample 0's id in the field, that id is a row of a V-row table and occurs in no other field -- what the reference's Criteo pipeline
+    gives the 13 dense features (process_data.py:138-147).  Returns the state tensor (const_cols_state) that holds the
+    mask (const_cols_mask reads it); hand it to sparse_lazy_adam_wide_(..., const_cols=(state, ids)).  None: more than 64 fields."""
+    _need_cuda(ids)
+    if ids.dim() != 2 or ids.dtype not in (torch.int32, torch.int64) or not ids.is_contiguous():
+        raise TypeError("ids must be a contiguous [B, F] int32 / int64 tensor")
+    B, F = ids.shape
+    if F > 64 or B == 0:
+        return None
+    if state is None:
+        state = const_cols_state(ids.device)
+    _lib.call("mrec_const_cols_detect", _ptr(ids), ids.element_size(), B, F, int(V), _ptr(state), _stream())
+    return state
+
+
+def const_cols_mask(state):
+    """The constant columns of the last const_cols_detect over this state, as a Python int (bit f = field f); synchronises."""
+    w = state[4:6].cpu().numpy().view(np.uint64)
+    return int(w[0])
 
 
 def sparse_lazy_adam_wide_(p, m, v, plan, g, row_scale, gw, F, wide_col, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8,
                            beta1_power=0.9, beta2_power=0.999, grad_scale=1.0, use_nesterov=False, ftrl_lr=5e-2, l1=1e-8, l2=1e-8,
-                           lr_power=-0.5, step_state=None, defer=False):
+                           lr_power=-0.5, step_state=None, defer=False, const_cols=None):
     """LazyAdam on the deep columns and FTRL on the wide record of the same fused rows in ONE pass (wide_and_deep.py:420-430):
     gw [n / F] is the wide branch's gradient per sample (the head's dlogit); position i contributes gw[i // F] * row_scale[i].
     step_state (StepState): the Adam step size comes from device memory (beta powers ignored) and the main kernel stamps its
-    begin / end there."""
+    begin / end there.  const_cols = (const_cols_detect(ids, V), ids): the batch's constant columns are summed sample by sample
+    by the same launch instead of through the index (a different, fixed order of additions for those rows)."""
     _need_cuda(p, m, v, g, row_scale, gw)
     V, D, ld = _table(p)
     for t in (m, v):
@@ -402,12 +434,21 @@ def sparse_lazy_adam_wide_(p, m, v, plan, g, row_scale, gw, F, wide_col, lr=3.5e
             beta1, beta2, eps, beta1_power, beta2_power, grad_scale, int(use_nesterov), _ptr(gw), int(gws), int(F), int(wide_col),
             ftrl_lr, l1, l2, lr_power, _ptr(ws), ws.numel(), _ptr(step_state.buf) if step_state is not None else None,
             _ptr(getattr(plan, "n_valid_dev", None)))
+    keep_cc = None
+    if const_cols is not None and const_cols[0] is not None:
+        bad, ids = const_cols
+        _need_cuda(bad, ids)
+        if (ids.dim() != 2 or ids.shape[1] != F or ids.numel() != plan.n or not ids.is_contiguous()
+                or ids.element_size() != plan.uniq_buf.element_size() or bad.dtype != torch.int32 or bad.numel() * 4 != CONST_COLS_STATE_BYTES):
+            raise TypeError("const_cols: (the state of const_cols_detect, the contiguous [n / F, F] id batch of the plan, ids of the table's key width)")
+        _lib.call("mrec_sparse_apply_next_const_cols", _ptr(bad), _ptr(ids), ids.element_size(), ids.shape[0])
+        keep_cc = (bad, ids)
     if defer:
         # the finishing pass (runs of duplicates that cross windows of the sorted index) is handed back: dense_adam_slabs_(...,
         # finish=...) runs it as the first workgroups of the dense net's Adam launch.  The record points into `ws`, the plan and
         # the tables: run the finish before any of them is reused.
         fin = ApplyFinish()
-        fin.keep = (ws, plan, p, g2, rs, gw)
+        fin.keep = (ws, plan, p, g2, rs, gw, keep_cc)
         _lib.call("mrec_sparse_lazy_adam_wide_defer", *args, C.cast(C.pointer(fin), C.c_void_p), _stream())
         return fin
     _lib.call("mrec_sparse_lazy_adam_wide", *args, _stream())

@@ -95,6 +95,11 @@ class WideDeepConfig:
                                     # parent (Cell.update_parameters_name uses the attribute path [EXT]; pinned by tests/golden/
                                     # ref_wd_*.npz, which the reference's own TrainStepWrap produced over compat/mindspore).  "adam":
                                     # the literal reading of the constructor name "Wide_b" (rounds 2-3)
+    const_columns: bool = True     # fields whose id is the same in every sample of a batch (the reference's Criteo pipeline gives each
+                                   # of the 13 dense features ONE id, process_data.py:138-147) are summed sample by sample by the folded
+                                   # one-GPU apply instead of through the inverted index (WideDeepEngine._plan; include/mrec.h,
+                                   # mrec_const_cols_detect): same products, another fixed order of additions for those rows -- False
+                                   # where two engines must agree bit for bit across code paths (hash tables, row shards)
 
 
 _GRAPH_LEVEL = {"none": 0, "mlp": 1, "front": 2, "step": 3}
@@ -345,6 +350,8 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         self._side = torch.cuda.Stream(device=self.device) if self._gpu else None
         import os
         self._fuse_finish = True      # the apply's finishing pass inside the dense Adam launch (see _choose_finish)
+        self._const_cols = bool(getattr(cfg, "const_columns", True)) and os.environ.get("MREC_CONST_COLS", "1") != "0"      # (see _plan)
+        self._col_bad, self._cc = None, None
         self._plan_fork = os.environ.get("MREC_PLAN_FORK", "lookup")       # where the captured step forks its plan branch: "lookup" | "head"
         self.deep_apply_timer = None  # optional ops.KernelTimer armed right before the deep table's sparse apply
         self._dyn = False             # step scalars (Adam powers / step size) in device memory: set per step
@@ -468,6 +475,21 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         if not torch.cuda.is_current_stream_capturing():
             t.record_stream(stream)
 
+    def _plan(self, ids):
+        """The step's inverted index (Unique + positions per unique id) and, beside it on the same stream, which fields of the batch
+        are CONSTANT COLUMNS (mrec_const_cols_detect: the reference's Criteo pipeline gives each of the 13 dense features one id,
+        process_data.py:138-147) -- the folded one-GPU apply sums those columns sample by sample instead of through the index."""
+        plan = self.k.sparse_plan(ids)
+        self._cc = None
+        if (self._const_cols and self._fold_wide and self.cfg.sparse and not self._sharded and not self.cfg.dynamic_embedding and self.hb is None
+                and ids.dim() == 2 and ids.shape[1] <= 64 and hasattr(self.k, "const_cols_detect")):
+            if self._col_bad is None:
+                self._col_bad = self.k.const_cols_state(self.device)
+            bad = self.k.const_cols_detect(ids, self.cfg.vocab_size, state=self._col_bad)
+            if bad is not None:
+                self._cc = (bad, ids)
+        return plan
+
     def _front(self, ids, wts, label, capturing=False):
         """Everything of a step in front of the sparse applies: lookups, the step's Unique + inverted index (side
         stream), the MLP forward/backward with the wide branch's work hooked in.  Returns
@@ -498,7 +520,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
             else:
                 self._side.wait_stream(main)
                 with torch.cuda.stream(self._side):
-                    plan_early = self.k.sparse_plan(ids)
+                    plan_early = self._plan(ids)
                 for t in (plan_early.uniq_buf, plan_early.inv, plan_early.n_uniq_dev, plan_early.sorted_pos,
                           plan_early.sorted_seg, plan_early.seg_offsets):
                     self._rs(t, main)
@@ -513,7 +535,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
             if self._plan_fork == "lookup":
                 self._side.wait_event(fork_ev)
                 with torch.cuda.stream(self._side):
-                    plan_early = self.k.sparse_plan(ids)
+                    plan_early = self._plan(ids)
         if self._side is not None and plan_early is None:
             # Side stream, in this order: (1) the wide branch, which the main stream joins only right before the
             # output head -- it runs while the hidden-layer GEMMs do; (2) the step's Unique + inverted index, which
@@ -529,7 +551,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
                         torch.cuda.current_stream().wait_event(ev_wide)
                         self._rs(wide_t, torch.cuda.current_stream())
                         return wide_t
-                plan_early = self.k.sparse_plan(ids)
+                plan_early = self._plan(ids)
             for t in (plan_early.uniq_buf, plan_early.inv, plan_early.n_uniq_dev, plan_early.sorted_pos,
                       plan_early.sorted_seg, plan_early.seg_offsets):
                 self._rs(t, main)
@@ -555,7 +577,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
                     def after_head(_gw):
                         self._side.wait_event(torch.cuda.current_stream().record_event())
                         with torch.cuda.stream(self._side):
-                            box["plan"] = self.k.sparse_plan(ids)
+                            box["plan"] = self._plan(ids)
             elif plan_early is not None and self._side is not None and cfg.sparse:
                 def after_head(gw_b):
                     # wide FTRL beside the backward GEMMs: needs only the plan (already on the side stream, in order)
@@ -907,7 +929,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         else:
             gb = g_wide.sum().view(1)
         ev = self._tick("plan")
-        plan = plan_early if plan_early is not None else self.k.sparse_plan(ids)
+        plan = plan_early if plan_early is not None else self._plan(ids)
         self._tock(ev)
         # (The dense Adam on the side branch beside the sparse applies was measured: the step gains ~1 % on one box and nothing
         # on the next, and the apply kernel -- two HBM-bound kernels sharing the memory system -- stretches from 0.185 to 0.20 ms.)
@@ -926,7 +948,7 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
                                                    lr=cfg.adam_lr, beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,
                                                    beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
                                                    grad_scale=inv_sens, ftrl_lr=cfg.ftrl_lr, l1=cfg.ftrl_l1, l2=cfg.ftrl_l2,
-                                                   step_state=state, defer=self._fuse_finish)
+                                                   step_state=state, defer=self._fuse_finish, const_cols=getattr(self, "_cc", None))
         else:
             self.k.sparse_lazy_adam_(self.deep, self.deep_m, self.deep_v, plan, g_emb.view(B * Fd, D), wts, lr=cfg.adam_lr,
                                      beta1=float(self.beta1), beta2=float(self.beta2), eps=cfg.adam_eps,

@@ -231,6 +231,17 @@ def test_graph_replay_is_bit_identical_to_eager(dev, level):
     if level == "step":
         ms = a._step_state.apply_ms(range(4, 10))
         assert len(ms) == 6 and all(0.0 < x < 50.0 for x in ms), ms
+        # the stamps' runtime switch (mrec_step_state_t.stamps_off): the captured graph reads it when it runs; same results, no stamps
+        a._step_state.set_stamps(False)
+        for s in range(9, 12):
+            ids, wts, label = synthetic_batch(a.cfg, dev, "zipf", seed=70 + s)
+            assert float(a.train_step(ids, wts, label)) == float(b.train_step(ids, wts, label)), s
+        assert torch.equal(a.deep, b.deep) and torch.equal(a.dense_flat.detach(), b.dense_flat.detach())
+        assert a._step_state.apply_ms(range(10, 13)) == []
+        a._step_state.set_stamps(True)
+        ids, wts, label = synthetic_batch(a.cfg, dev, "zipf", seed=90)
+        a.train_step(ids, wts, label)
+        assert len(a._step_state.apply_ms(range(13, 14))) == 1
 
 
 def test_step_graph_survives_checkpoint_restore(dev, tmp_path):
@@ -263,7 +274,8 @@ def test_dynamic_embedding_engine_equals_dense_table_engine(dev, graph):
     from mindrec_amd import ops
     from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
     kw = dict(vocab_size=50000, emb_dim=16, field_size=39, batch_size=1024, deep_layer_dim=[128, 64, 32],
-              mlp_dtype="bf16", graphs="step" if graph else "none")
+              mlp_dtype="bf16", graphs="step" if graph else "none",
+              const_columns=False)      # (two code paths compared bit for bit: the dense-table engine's constant-column sums are another order)
     a = WideDeepEngine(WideDeepConfig(**kw), dev)
     b = WideDeepEngine(WideDeepConfig(dynamic_embedding=True, hash_capacity=1 << 16, **kw), dev)
     seen = []
