@@ -482,27 +482,35 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     // entries of CONSTANT columns (cmask, above) are not this pass's: their runs -- B entries each -- are summed row by row by the
     // launch's first workgroups.  Such a run is longer than a window, so its entries are a window's head, its tail or all of it:
     // they become entries past the end (group -2), which every test below already treats as nobody's.
-    unsigned hotm = 0u;
-    if (WIDE && cmask) {
+    // (the mask of such entries is used up right here -- the kernel sits at its register budget: a value kept across the window's body
+    // cost ten spilled registers and 45 us -- and afterwards an entry that is nobody's is told by its group number, -2)
+    // (only where it fits the 128 registers: 32-bit keys under LazyAdam.  64-bit row numbers leave no room -- those variants spilled 35
+    // registers with the path compiled in -- so they, and the FTRL / store updaters that never use it, are compiled without it and the
+    // host does not arm it for them)
+    constexpr bool CONSTC = WIDE && sizeof(K) == 4 && std::is_same<Upd, UpdAdam>::value;
+    if (CONSTC && cmask) {
+        bool any = false;
 #pragma unroll
         for (int q = 0; q < AW; ++q) {
             const unsigned pos = (unsigned)posw[q];
             const unsigned fld = pos - (wa.F == 1 ? pos : __umulhi(pos, wa.magic)) * (unsigned)wa.F;
-            hotm |= ((unsigned)(cmask >> fld) & 1u) << q;
+            const bool hot = (unsigned)(cmask >> fld) & 1u;
+            const bool valid = s + q < e_end && !hot;
+            any = any || valid;
+            posw[q] = valid ? posw[q] : 0;
+            segw[q] = valid ? segw[q] : -2;
         }
-        unsigned inw = 0u;
-#pragma unroll
-        for (int q = 0; q < AW; ++q) inw |= (s + q < e_end ? 1u : 0u) << q;
-        if ((inw & ~hotm) == 0u) {                       // the whole window lies inside constant columns' runs: nothing to do, nothing carried
+        if (!any) {                                      // the whole window lies inside constant columns' runs: nothing to do, nothing carried
             if (sub == 0) owners[sw] = 0;
             continue;
         }
-    }
+    } else {
 #pragma unroll
-    for (int q = 0; q < AW; ++q) {
-        const bool valid = s + q < e_end && !((hotm >> q) & 1u);
-        posw[q] = valid ? posw[q] : 0;
-        segw[q] = valid ? segw[q] : -2;
+        for (int q = 0; q < AW; ++q) {
+            const bool valid = s + q < e_end;
+            posw[q] = valid ? posw[q] : 0;
+            segw[q] = valid ? segw[q] : -2;
+        }
     }
     if (!(s + AW < n)) segw[AW] = -2;
     const int first_seg = segw[0];
@@ -529,7 +537,7 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     int last_end = seg_offsets[(last_seg < 0 ? 0 : last_seg) + 1];
 #pragma unroll
     for (int q = 0; q < AW; ++q) {
-        const bool valid = s + q < e_end && !((hotm >> q) & 1u);
+        const bool valid = CONSTC ? segw[q] != -2 : s + q < e_end;     // (entries of constant columns are nobody's either)
         const bool is_end = valid && segw[q + 1] != segw[q];
         const bool open = head_open && segw[q] == first_seg;
         endm |= is_end ? (1u << q) : 0u;
@@ -601,7 +609,7 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
 #pragma unroll
             for (int k = 0; k < AB; ++k) {
                 const int q = j0 + k;
-                if (s + q >= e_end2 || ((hotm >> q) & 1u)) continue;
+                if (s + q >= e_end2 || (CONSTC && segw[q] == -2)) continue;
                 Vf<VEC> x = xs[k];
                 const bool is_start = q == 0 || segw[q] != segw[q - 1];
                 if (is_start) acc = x; else vadd(acc, x);
@@ -658,7 +666,7 @@ __global__ __launch_bounds__(256, WIDE ? MREC_WPS4 : 1) void k_apply_main(Upd up
     resolve_step(upd, ss);
     if (nv) { const int64_t x = *nv; if (x < n) n = x < 0 ? 0 : (int)x; }      // entries of the index proper: known on the device only
     unsigned long long cmask = 0ull;
-    if constexpr (WIDE && VEC == 4) {
+    if constexpr (WIDE && VEC == 4 && sizeof(K) == 4 && std::is_same<Upd, UpdAdam>::value) {
         if (cc.mask) cmask = const_mask(cc.mask);
         if (blockIdx.x < cc.cblocks) {                 // the constant columns' partial sums: dispatched first, a chain of `rr` round trips
             if (cmask) const_part_body<GT>(cc, cmask, g, ldg, rscale, gscale, wa, gm);
@@ -1025,7 +1033,7 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
     // the table's key width, LazyAdam on the fused rows -- anything else runs every column through the windows
     ConstCols cc = t_const;
     t_const = ConstCols{};
-    if (!(vec == 4 && wide && std::is_same<Upd, UpdAdam>::value && !nv && cc.mask && cc.ids0 && wa.F >= 1 && wa.F <= 64 &&
+    if (!(vec == 4 && wide && std::is_same<Upd, UpdAdam>::value && sizeof(K) == 4 && !nv && cc.mask && cc.ids0 && wa.F >= 1 && wa.F <= 64 &&
           n % wa.F == 0 && cc.B == (int)(n / wa.F) && cc.B > 0 && wa.gws == 1 && cc.id_bytes == (int)sizeof(K)))
         cc = ConstCols{};
     if (cc.mask) {
@@ -1035,6 +1043,9 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
         cc.cblocks = (unsigned)mrec_cdiv((int64_t)cc.nlg * kConstMax, (int64_t)4 * gm.G);      // (room for kConstMax columns: how many there are is known on the device)
     }
     if (vec == 4 && wide) {
+      if constexpr (!std::is_same<Upd, UpdAdam>::value) {
+        return MREC_EUNSUPPORTED;                  // (the wide lane rides LazyAdam only: no such instantiation of the other updaters)
+      } else {
         k_apply_main<4, K, Upd, GT, true><<<blocks + cc.cblocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
                                                              w.carry_head, w.carry_tail, w.owners, seg_offsets, wa, ss, nv, cc);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
@@ -1055,6 +1066,7 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
                 if (cc.mask) k_apply_const_finish<K><<<kConstMax, 256, 0, st>>>(upd, V, ld, gm, wa, cc, ss);
             }
         }
+      }
     } else if (vec == 4) {
         k_apply_main<4, K, Upd, GT><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
                                                        w.carry_head, w.carry_tail, w.owners, seg_offsets, wa, ss);

@@ -1,6 +1,9 @@
+# Constant columns off / on / off / on per id distribution (the engine reads MREC_CONST_COLS), ONE box: bash tools/probes/ab_const_cols.sh
+# (both arms run the SAME library: compare a line of the 26-field case with the committed round's profile too -- a change that slows the
+# kernel in both arms does not show here)
 for cfg in "--dist uniform --fields 26" "--dist zipf --fields 39" "--dist uniform --fields 39" "--dist zipf --fields 26"; do
 for cc in 0 1 0 1; do
 MREC_CONST_COLS=$cc python bench.py --no-cpu-baseline --no-zipf39 --repeats 3 --stamps always $cfg 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); e=d.get('roofline_embedding_path',{})
-print('cc=$cc $cfg :', 'step', d['ms_per_step'], 'apply_main', d['roofline']['avg_ms_stamps'], 'lookup', e.get('lookup_ms'), 'apply_all', e.get('apply_ms_incl_finishing_kernel'), 'finishing', e.get('finishing_pass_ms'), 'path', e.get('frac'), 'U/N', d['config']['unique_frac'])"
+print('cc=$cc $cfg :', 'step', d['ms_per_step'], 'apply_main', d['roofline']['avg_ms_stamps'], 'lookup', e.get('lookup_ms'), 'apply_all', e.get('apply_ms_incl_finishing_kernel'), 'finishing', e.get('finishing_pass_ms'), 'path', e.get('frac'), 'U/N', d['config']['unique_frac'], 'copy GB/s', d['roofline'].get('measured_copy_gbps'))"
 done; done
