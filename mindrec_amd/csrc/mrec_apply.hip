@@ -361,7 +361,8 @@ __device__ __forceinline__ int64_t seg_row(const K* uniq, int seg) {
 // order of operations as in the windows), and the finishing launch adds a column's chunk sums in chunk order and updates its one
 // row.  Fixed order: bitwise reproducible.  (First form, measured on Zipf ids x 39 fields: a lane-group = 16 samples x all columns,
 // 32 dependent round trips -- as long as the whole launch -- and 1024 partial rows per column for the finishing pass: k_apply_main
-// 121 -> 124 us, the finishing pass 44 -> 66 us.)
+// no faster, the finishing pass 44 -> 66 us.  As built: k_apply_main 91.9 -> 84.5 us, finishing pass 42.9 -> 27.4 us,
+// profiles/r05_const_cols_ab.txt.)
 constexpr int kConstMax = 16;        // constant columns handled (the first 16 in field order)
 constexpr int kConstLG = 256;        // chunks of consecutive samples the partial-sum pass cuts the batch into, at most
 struct ConstCols { const unsigned long long* mask; const void* ids0; float* part; int B, rr, nlg; unsigned cblocks; int id_bytes; };
