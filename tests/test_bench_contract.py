@@ -1,4 +1,4 @@
-"""The committed bench line of the current round (profiles/r04_bench_line.json, produced by `python bench.py` on the GPU box) carries every
+"""The committed bench line of the current round (profiles/r05_bench_line.json, produced by `python bench.py` on the GPU box) carries every
 field of the driver's contract: metric/value/unit/n_gpus/steps/warmup/ms_per_step/higher_is_better/scaling/vs_baseline/
 dtype/data/config.workload plus the roofline and cpu_baseline objects."""
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    line = open(os.path.join(ROOT, "profiles", "r04_bench_line.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, "profiles", "r05_bench_line.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     assert "configs[1]" in d["config"]["workload"] and d["dtype"] == "f16" and d["metric"] == "samples/sec Wide&Deep Criteo batch16384"
     e = d["roofline_embedding_path"]
