@@ -361,21 +361,23 @@ int mrec_sparse_lazy_adam_wide_defer(float* p, float* m, float* v, int64_t V, in
                                      float grad_scale, int nesterov, const float* gw, int64_t gw_stride, int32_t F, int32_t wide_col,
                                      float ftrl_lr, float l1, float l2, float lr_power, void* ws, size_t ws_bytes, void* step_state,
                                      const int64_t* n_valid_dev, mrec_apply_finish_t* finish_out, void* stream);
-/* Constant columns.  The reference's Criteo pipeline gives each of the 13 dense features ONE id (datasets/criteo_1tb/process_data.py:
- * 138-147: the feature's value travels as the weight), so a 39-field batch holds 13 fields whose id is the same in every sample: a third
- * of the positions, in 13 runs of B entries of the inverted index.  mrec_const_cols_detect finds the fields of ids[B, F] (F <= 64) that
- * are such a column -- all B samples hold sample 0's id in field f, that id lies in [0, V) and occurs in no other field -- and leaves
- * them as a bit mask (the first 16 of them) in `state`: MREC_CONST_COLS_STATE_BYTES of device memory, ZEROED ONCE by the caller and
- * owned by these calls from then on (a word of failed candidates and a ticket that the launch's last workgroup clears again: one launch, no memset; a batch
- * whose samples 0 and 1 agree in no field costs 2 F loads per workgroup).  mrec_sparse_apply_next_const_cols arms the NEXT
- * mrec_sparse_lazy_adam_wide(_defer) call of this host thread (ids: the same [B, F] batch the plan was built from, of the table's key
- * width): the windows of that call skip the constant columns' entries, the first workgroups of the same launch add those columns up
- * sample by sample (the gradient matrix holds a column at a fixed offset of every row -- no index, neighbouring constant columns
- * adjacent), and the finishing pass (own launch, or the workgroups handed back in mrec_apply_finish_t) updates their rows: same
- * products, a fixed order of additions (another one than the windows': the sums agree to rounding).  (nullptr, nullptr, 0, 0) disarms.
+/* Hot columns.  The reference's Criteo pipeline gives each of the 13 dense features ONE id (datasets/criteo_1tb/process_data.py:138-147:
+ * the feature's value travels as the weight), so a 39-field batch holds 13 fields whose id is the same in every sample: a third of the
+ * positions, in 13 runs of B entries of the inverted index.  mrec_const_cols_detect finds the fields of ids[B, F] (F <= 64) in which ONE
+ * id -- the most frequent of the field's first 16 samples, in at least a quarter of them -- fills at least min_count of the B samples,
+ * lies in [0, V) and occurs in no other field (min_count = B: constant columns; smaller: also a field's dominant id), and leaves them
+ * as a bit mask and their ids in `state`: MREC_CONST_COLS_STATE_BYTES of device memory, ZEROED ONCE by the caller and owned by these
+ * calls from then on (counters, a word of failed candidates and a ticket that the launch's last workgroup clears again: one launch, no
+ * memset; a batch without a candidate costs 16 F loads per workgroup).  mrec_sparse_apply_next_const_cols arms the NEXT
+ * mrec_sparse_lazy_adam_wide(_defer) call of this host thread (ids: the same [B, F] batch the plan was built from, 32-bit, B <= 65536;
+ * otherwise the call runs as if not armed): it launches the HOT variant of the apply kernel, whose windows skip the entries that hold a
+ * field's hot id, whose first workgroups add those entries' gradient rows up sample by sample (no index: a field sits at a fixed offset
+ * of every gradient row, neighbouring hot fields adjacent), and whose finishing pass (own launch, or the workgroups handed back in
+ * mrec_apply_finish_t) updates the hot rows: same products, a fixed order of additions (another one than the windows': the sums agree to
+ * rounding).  Not armed, the call launches the plain kernel: not an instruction of this path.  (nullptr, nullptr, 0, 0) disarms.
  * Replaces the optimizer-side Unique + UnsortedSegmentSum + LazyAdam / FTRL of those rows (wide_and_deep.py:420-430, 490-492). */
-#define MREC_CONST_COLS_STATE_BYTES 32
-int mrec_const_cols_detect(const void* ids, int32_t id_bytes, int64_t B, int32_t F, int64_t V, void* state, void* stream);
+#define MREC_CONST_COLS_STATE_BYTES 800
+int mrec_const_cols_detect(const void* ids, int32_t id_bytes, int64_t B, int32_t F, int64_t V, int64_t min_count, void* state, void* stream);
 int mrec_sparse_apply_next_const_cols(const void* state, const void* ids, int32_t id_bytes, int64_t B);
 int mrec_dense_adam_slabs_finish_f32(float* p, float* m, float* v, const float* g, void* shadow16, int shadow_kind, int64_t n,
                                      int32_t nseg, const float* const* slabs, const int64_t* starts, const int64_t* lens,

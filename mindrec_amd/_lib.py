@@ -70,7 +70,7 @@ _SIGS = {
     "mrec_wide_sum_f32_i32": [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_wide_sum_f32_i64": [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "mrec_sparse_apply_workspace_bytes": [_i64, _i32, _szp],
-    "mrec_const_cols_detect": [_vp, _i32, _i64, _i32, _i64, _vp, _vp],
+    "mrec_const_cols_detect": [_vp, _i32, _i64, _i32, _i64, _i64, _vp, _vp],
     "mrec_sparse_apply_next_const_cols": [_vp, _vp, _i32, _i64],
     "mrec_sparse_apply_window": [_i32, _int],
     "mrec_segment_sum_f32": [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _f32, _i32, _vp, _vp, _sz, _vp],

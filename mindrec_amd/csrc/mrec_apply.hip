@@ -363,42 +363,60 @@ __device__ __forceinline__ int64_t seg_row(const K* uniq, int seg) {
 // 32 dependent round trips -- as long as the whole launch -- and 1024 partial rows per column for the finishing pass: k_apply_main
 // no faster, the finishing pass 44 -> 66 us.  As built: k_apply_main 91.9 -> 84.5 us, finishing pass 42.9 -> 27.4 us,
 // profiles/r05_const_cols_ab.txt.)
-constexpr int kConstMax = 16;        // constant columns handled (the first 16 in field order)
-constexpr int kConstLG = 256;        // chunks of consecutive samples the partial-sum pass cuts the batch into, at most
-struct ConstCols { const unsigned long long* mask; const void* ids0; float* part; int B, rr, nlg; unsigned cblocks; int id_bytes; };
+constexpr int kConstMax = 64;        // hot columns handled: every field can be one (F <= 64)
+constexpr int kConstLG = 1024;       // chunks of 64 consecutive samples the partial-sum pass cuts the batch into, at most (B <= 65536)
+struct ConstCols { const unsigned long long* mask; const long long* hid; const void* ids0; float* part; int B, rr, nlg; unsigned cblocks; int id_bytes; };
 
 // bit f: field f is a constant column (at most kConstMax bits; written by k_const_cols' last workgroup: one scalar load here)
 __device__ __forceinline__ unsigned long long const_mask(const unsigned long long* __restrict__ mask) { return *mask; }
 
-template <class GT>
+template <class K, class GT>
 __device__ __forceinline__ void const_part_body(const ConstCols& cc, unsigned long long cmask, const GT* __restrict__ g, int64_t ldg,
                                                 const float* __restrict__ rscale, float gscale, const WideArgs& wa, ApplyGeom gm) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / gm.lpr, sub = lane - grp * gm.lpr;
-    if (grp >= gm.G) return;
-    // a lane-group = (chunk of rr consecutive samples, constant column j): neighbouring lane-groups take neighbouring columns of the
-    // same samples (one contiguous stretch of a gradient row where the constant columns are adjacent fields), eight samples in flight
+    // a lane-group = (chunk of rr <= 64 consecutive samples, hot column j): neighbouring lane-groups take neighbouring columns of the
+    // same samples (one contiguous stretch of a gradient row where the hot columns are adjacent fields).  First which of the chunk's
+    // samples hold the column's hot id (every lane looks at a few, a ballot collects them: all of them in a constant column), then
+    // those samples' gradient rows, eight in flight, in sample order.
     const int nc = __popcll(cmask);
     const int lg = ((int)blockIdx.x * 4 + wave) * gm.G + grp;
-    if (lg >= cc.nlg * nc) return;
-    const int chunk = lg / nc, j = lg - chunk * nc;
+    const bool live = grp < gm.G && lg < cc.nlg * nc;
+    const int chunk = live ? lg / nc : 0, j = live ? lg - chunk * nc : 0;
     int f = 0;
     {
         unsigned long long m = cmask;
         for (int q = 0; q < j; ++q) m &= m - 1ull;
         f = (int)__ffsll((long long)m) - 1;
     }
+    const long long hid = cc.hid[f];
+    const int b0 = chunk * cc.rr, b1 = (b0 + cc.rr < cc.B) ? b0 + cc.rr : cc.B;
+    unsigned long long mm = 0ull;                        // bit i: sample b0 + i holds the hot id
+    for (int r = 0; r * gm.lpr < cc.rr; ++r) {
+        const int i = r * gm.lpr + sub;
+        const bool pred = live && i < cc.rr && b0 + i < b1 && (long long)((const K*)cc.ids0)[(int64_t)(b0 + i) * wa.F + f] == hid;
+        const unsigned long long bal = __ballot(pred);    // (every lane of the wave arrives here: no early return above)
+        mm |= ((bal >> (grp * gm.lpr)) & ((1ull << gm.lpr) - 1ull)) << (r * gm.lpr);
+    }
+    if (!live) return;
     const bool wl = sub == gm.lpr - 1;
     const int ccol = sub * 4;
-    const int b0 = chunk * cc.rr, b1 = (b0 + cc.rr < cc.B) ? b0 + cc.rr : cc.B;
     Vf<4> acc;
     vzero(acc);
-    for (int bb = b0; bb < b1; bb += 8) {
+    bool first = true;
+    while (mm) {
+        int bq[8];
+        unsigned long long m2 = mm;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            bq[q] = m2 ? b0 + (int)__ffsll((long long)m2) - 1 : -1;
+            m2 &= m2 - 1ull;
+        }
         GBits<4, GT> gb[8];
         float rs[8], gwv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int b = bb + q < b1 ? bb + q : b1 - 1;                  // (past the chunk: its last sample again, dropped)
+            const int b = bq[q] >= 0 ? bq[q] : b0;                        // (fewer than eight left: the chunk's first sample again, dropped)
             const int64_t pos = (int64_t)b * wa.F + f;
             gload<true>(gb[q], g + pos * ldg + (wl ? 0 : ccol));
             rs[q] = rscale ? rscale[pos] : 1.0f;
@@ -406,27 +424,29 @@ __device__ __forceinline__ void const_part_body(const ConstCols& cc, unsigned lo
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            if (bb + q >= b1) continue;
+            if (bq[q] < 0) continue;
             Vf<4> x;
             gwiden(x, gb[q]);
             if (wl) { vzero(x); vset_x(x, gwv[q]); }
             if (rscale) vmul(x, rs[q]);
             vmul(x, gscale);
-            if (bb + q == b0) acc = x; else vadd(acc, x);
+            if (first) { acc = x; first = false; } else vadd(acc, x);
         }
+        mm = m2;
     }
     vstore<false>(cc.part + ((int64_t)chunk * kConstMax + j) * gm.D + ccol, acc);
 }
 
 // (WIDE: MREC_WPS4 waves per SIMD asked of the register allocator)
-template <int VEC, class K, class Upd, class GT, bool WIDE = false>
+template <int VEC, class K, class Upd, class GT, bool WIDE = false, bool HOT = false>
 __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
                                                     const int* __restrict__ spos, const int* __restrict__ sseg,
                                                     int n, const GT* __restrict__ g, int64_t ldg,
                                                     const float* __restrict__ rscale, float gscale, ApplyGeom gm,
                                                     float* __restrict__ carry_head, float* __restrict__ carry_tail,
                                                     int* __restrict__ owners, const int* __restrict__ seg_offsets,
-                                                    const WideArgs& wa, const unsigned long long cmask = 0ull, const unsigned bid0 = 0u) {
+                                                    const WideArgs& wa, const unsigned long long cmask = 0ull, const unsigned bid0 = 0u,
+                                                    const int* s_hid = nullptr) {
     constexpr int AW = ACfg<VEC>::AW, AB = ACfg<VEC>::AB, GP = ACfg<VEC>::GP;
     constexpr bool NT = ACfg<VEC>::NT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -480,37 +500,48 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     const int seg_after = sseg[s + AW + 1 < nlast ? s + AW + 1 : nlast];
 #pragma unroll
     for (int q = AW + 1; q < AW + GP; ++q) { posw[q] = 0; segw[q] = -2; }
-    // entries of CONSTANT columns (cmask, above) are not this pass's: their runs -- B entries each -- are summed row by row by the
-    // launch's first workgroups.  Such a run is longer than a window, so its entries are a window's head, its tail or all of it:
-    // they become entries past the end (group -2), which every test below already treats as nobody's.
-    // (the mask of such entries is used up right here -- the kernel sits at its register budget: a value kept across the window's body
-    // cost ten spilled registers and 45 us -- and afterwards an entry that is nobody's is told by its group number, -2)
-    // (only where it fits the 128 registers: 32-bit keys under LazyAdam.  64-bit row numbers leave no room -- those variants spilled 35
-    // registers with the path compiled in -- so they, and the FTRL / store updaters that never use it, are compiled without it and the
-    // host does not arm it for them)
-    constexpr bool CONSTC = WIDE && sizeof(K) == 4 && std::is_same<Upd, UpdAdam>::value;
-    if (CONSTC && cmask) {
-        bool any = false;
+    // HOT (the kernel variant a stream with hot columns is captured with; the plain one is the round's earlier code, instruction for
+    // instruction): entries whose id is a field's hot id -- cmask: which fields have one, s_hid: that id, the launch's first
+    // workgroups sum them sample by sample -- are not this pass's.  Such a run is far longer than a window, so its entries are a
+    // window's head, its tail or all of it: they become entries past the end (group -2), which every test below already treats as
+    // nobody's.  The test needs the entry's id = its group's row number, which the window requests anyway: here they are requested
+    // right behind the index words, with the end of the window's last run, and the window's logic follows them.
+    // (The mask of such entries is used up right here -- the kernel sits at its register budget: kept across the window's body it cost
+    // ten spilled registers and 45 us.  Only 32-bit keys under LazyAdam have the registers: no HOT variant of the others exists.)
+    constexpr bool CONSTC = HOT;
+    static_assert(!HOT || (WIDE && sizeof(K) == 4 && std::is_same<Upd, UpdAdam>::value), "HOT: the wide-folded LazyAdam apply over 32-bit keys");
+    typedef typename std::conditional<sizeof(K) == 4, int, int64_t>::type RowT;
+    RowT rowv[AW + GP];                                   // table row of the run that ends at entry q (-1: none / out of range)
+    int last_end = 0;
 #pragma unroll
-        for (int q = 0; q < AW; ++q) {
-            const unsigned pos = (unsigned)posw[q];
-            const unsigned fld = pos - (wa.F == 1 ? pos : __umulhi(pos, wa.magic)) * (unsigned)wa.F;
-            const bool hot = (unsigned)(cmask >> fld) & 1u;
-            const bool valid = s + q < e_end && !hot;
-            any = any || valid;
-            posw[q] = valid ? posw[q] : 0;
-            segw[q] = valid ? segw[q] : -2;
-        }
-        if (!any) {                                      // the whole window lies inside constant columns' runs: nothing to do, nothing carried
-            if (sub == 0) owners[sw] = 0;
-            continue;
-        }
-    } else {
+    for (int q = 0; q < AW; ++q) {
+        const bool valid = s + q < e_end;
+        posw[q] = valid ? posw[q] : 0;
+        segw[q] = valid ? segw[q] : -2;
+    }
+    if constexpr (HOT) {
+        int last_seg0 = segw[0];
 #pragma unroll
-        for (int q = 0; q < AW; ++q) {
-            const bool valid = s + q < e_end;
-            posw[q] = valid ? posw[q] : 0;
-            segw[q] = valid ? segw[q] : -2;
+        for (int q = 1; q < AW; ++q) last_seg0 = (s + q < e_end) ? segw[q] : last_seg0;
+#pragma unroll
+        for (int q = 0; q < AW; ++q) rowv[q] = (RowT)seg_row<K>(uniq, segw[q] < 0 ? 0 : segw[q]);
+        last_end = seg_offsets[(last_seg0 < 0 ? 0 : last_seg0) + 1];
+        if (cmask) {
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < AW; ++q) {
+                const unsigned pos = (unsigned)posw[q];
+                const unsigned fld = pos - (wa.F == 1 ? pos : __umulhi(pos, wa.magic)) * (unsigned)wa.F;
+                const bool hot = ((unsigned)(cmask >> fld) & 1u) && (int)rowv[q] == s_hid[fld];
+                const bool valid = segw[q] != -2 && !hot;
+                any = any || valid;
+                posw[q] = valid ? posw[q] : 0;
+                segw[q] = valid ? segw[q] : -2;
+            }
+            if (!any) {                                  // the whole window lies inside hot runs: nothing to do, nothing carried
+                if (sub == 0) owners[sw] = 0;
+                continue;
+            }
         }
     }
     if (!(s + AW < n)) segw[AW] = -2;
@@ -522,11 +553,11 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     const bool tail_pair = pairs_on && s + AW < n && segw[AW] == segw[AW - 1] && segw[AW - 2] != segw[AW - 1] &&
                            (s + AW + 1 >= n || seg_after != segw[AW]);
     unsigned endm = 0u, openm = 0u;                       // bit q: entry q ends its run / belongs to the run open at the head
-    // (held at the width of the ids: 32-bit ids name 32-bit rows -- registers, in the kernel that sits at its register budget)
-    typedef typename std::conditional<sizeof(K) == 4, int, int64_t>::type RowT;
-    RowT rowv[AW + GP];                                   // table row of the run that ends at entry q (-1: none / out of range)
+    // (row numbers held at the width of the ids: 32-bit ids name 32-bit rows -- registers, in the kernel that sits at its register budget)
+    if constexpr (!HOT) {
 #pragma unroll
-    for (int q = 0; q < AW; ++q) rowv[q] = (RowT)seg_row<K>(uniq, segw[q] < 0 ? 0 : segw[q]);
+        for (int q = 0; q < AW; ++q) rowv[q] = (RowT)seg_row<K>(uniq, segw[q] < 0 ? 0 : segw[q]);
+    }
     rowv[AW] = tail_pair ? rowv[AW - 1] : (RowT)-1;
 #pragma unroll
     for (int q = AW + 1; q < AW + GP; ++q) rowv[q] = (RowT)-1;
@@ -534,8 +565,8 @@ __device__ __forceinline__ void apply_main_body(const Upd& upd, int64_t V, int64
     // requested with the row numbers, not behind the window's stores: a load there waits for them -- vmcnt counts in order)
     int last_seg = segw[0];
 #pragma unroll
-    for (int q = 1; q < AW; ++q) last_seg = (s + q < e_end) ? segw[q] : last_seg;      // (-2 where the window ends inside a constant column's run)
-    int last_end = seg_offsets[(last_seg < 0 ? 0 : last_seg) + 1];
+    for (int q = 1; q < AW; ++q) last_seg = (s + q < e_end) ? segw[q] : last_seg;      // (HOT: -2 where the window ends inside a hot run)
+    if constexpr (!HOT) last_end = seg_offsets[(last_seg < 0 ? 0 : last_seg) + 1];
 #pragma unroll
     for (int q = 0; q < AW; ++q) {
         const bool valid = CONSTC ? segw[q] != -2 : s + q < e_end;     // (entries of constant columns are nobody's either)
@@ -653,7 +684,7 @@ template <class Upd>
 __device__ __forceinline__ void resolve_step(Upd&, const StepState*) {}
 __device__ __forceinline__ void resolve_step(UpdAdam& u, const StepState* ss) { if (ss) u.h.lr_t = ss->lr_t; }
 
-template <int VEC, class K, class Upd, class GT, bool WIDE = false>
+template <int VEC, class K, class Upd, class GT, bool WIDE = false, bool HOT = false>
 __global__ __launch_bounds__(256, WIDE ? MREC_WPS4 : 1) void k_apply_main(Upd upd, int64_t V, int64_t ld, const K* __restrict__ uniq,
                                                     const int* __restrict__ spos, const int* __restrict__ sseg,
                                                     int n, const GT* __restrict__ g, int64_t ldg,
@@ -667,10 +698,15 @@ __global__ __launch_bounds__(256, WIDE ? MREC_WPS4 : 1) void k_apply_main(Upd up
     resolve_step(upd, ss);
     if (nv) { const int64_t x = *nv; if (x < n) n = x < 0 ? 0 : (int)x; }      // entries of the index proper: known on the device only
     unsigned long long cmask = 0ull;
-    if constexpr (WIDE && VEC == 4 && sizeof(K) == 4 && std::is_same<Upd, UpdAdam>::value) {
-        if (cc.mask) cmask = const_mask(cc.mask);
-        if (blockIdx.x < cc.cblocks) {                 // the constant columns' partial sums: dispatched first, a chain of `rr` round trips
-            if (cmask) const_part_body<GT>(cc, cmask, g, ldg, rscale, gscale, wa, gm);
+    __shared__ int s_hid[HOT ? 64 : 1];
+    if constexpr (HOT) {
+        cmask = const_mask(cc.mask);
+        if (cmask) {                                   // (uniform over the launch)
+            if (threadIdx.x < 64) s_hid[threadIdx.x] = (int)cc.hid[threadIdx.x];
+            __syncthreads();
+        }
+        if (blockIdx.x < cc.cblocks) {                 // the hot columns' chunk sums: dispatched first, a chain of ~10 round trips
+            if (cmask) const_part_body<K, GT>(cc, cmask, g, ldg, rscale, gscale, wa, gm);
             return;
         }
     }
@@ -688,8 +724,8 @@ __global__ __launch_bounds__(256, WIDE ? MREC_WPS4 : 1) void k_apply_main(Upd up
         }
         __syncthreads();
     }
-    apply_main_body<VEC, K, Upd, GT, WIDE>(upd, V, ld, uniq, spos, sseg, n, g, ldg, rscale, gscale, gm, carry_head, carry_tail, owners,
-                                           seg_offsets, wa, cmask, cc.cblocks);
+    apply_main_body<VEC, K, Upd, GT, WIDE, HOT>(upd, V, ld, uniq, spos, sseg, n, g, ldg, rscale, gscale, gm, carry_head, carry_tail, owners,
+                                                seg_offsets, wa, cmask, HOT ? cc.cblocks : 0u, s_hid);
     if (stamp && (int)blockIdx.x + 1024 >= (int)gridDim.x && (threadIdx.x & 63) == 0 && atomicAdd(&waves_done, 1) == 3)
         ss->ends[(unsigned)ss->step % kStampRing][blockIdx.x & 63u] = (unsigned long long)wall_clock64();
 }
@@ -938,7 +974,7 @@ __device__ __forceinline__ void const_finish_body(UpdAdam upd, int64_t V, int64_
             vload<false>(x, cred + q * gm.D + col);
             vadd(acc, x);
         }
-        const int64_t row = (int64_t)((const K*)cc.ids0)[f];
+        const int64_t row = (int64_t)cc.hid[f];
         if (row >= 0 && row < V) {
             const int64_t roff = row * ld + tcol;
             Vf<4> st[3];
@@ -1001,8 +1037,9 @@ struct ApplyWs { float* carry_head; float* carry_tail; int* owners; int* n_owner
 size_t apply_ws_bytes(int64_t n, int32_t D) {
     const size_t nsw = (size_t)mrec_cdiv(n ? n : 1, AW_MIN);
     const int Dc = D > 256 ? 256 : D;
+    const size_t nch = (size_t)mrec_cdiv(n ? n : 1, 64) < (size_t)kConstLG ? (size_t)mrec_cdiv(n ? n : 1, 64) : (size_t)kConstLG;
     return mrec_align_up(nsw * Dc * 4, 256) * 2 + mrec_align_up(nsw * 4, 256) + 256 + 2048 * 64 +
-           mrec_align_up((size_t)kConstLG * kConstMax * Dc * 4, 256);
+           mrec_align_up(nch * kConstMax * Dc * 4, 256);
 }
 
 // One launch pair over columns [c0, c0+Dc) of every array.
@@ -1035,11 +1072,11 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
     ConstCols cc = t_const;
     t_const = ConstCols{};
     if (!(vec == 4 && wide && std::is_same<Upd, UpdAdam>::value && sizeof(K) == 4 && !nv && cc.mask && cc.ids0 && wa.F >= 1 && wa.F <= 64 &&
-          n % wa.F == 0 && cc.B == (int)(n / wa.F) && cc.B > 0 && wa.gws == 1 && cc.id_bytes == (int)sizeof(K)))
+          n % wa.F == 0 && cc.B == (int)(n / wa.F) && cc.B > 0 && cc.B <= 64 * kConstLG && wa.gws == 1 && cc.id_bytes == (int)sizeof(K)))
         cc = ConstCols{};
     if (cc.mask) {
         cc.part = w.cpart;
-        cc.rr = (int)mrec_cdiv((int64_t)cc.B, (int64_t)kConstLG);
+        cc.rr = 64;                                                                                  // (a chunk's samples are a 64-bit mask)
         cc.nlg = (int)mrec_cdiv((int64_t)cc.B, (int64_t)cc.rr);                                      // chunks
         cc.cblocks = (unsigned)mrec_cdiv((int64_t)cc.nlg * kConstMax, (int64_t)4 * gm.G);      // (room for kConstMax columns: how many there are is known on the device)
     }
@@ -1047,7 +1084,13 @@ int apply_cols(Upd upd, int64_t V, int64_t ld, const K* uniq, const int* spos, c
       if constexpr (!std::is_same<Upd, UpdAdam>::value) {
         return MREC_EUNSUPPORTED;                  // (the wide lane rides LazyAdam only: no such instantiation of the other updaters)
       } else {
-        k_apply_main<4, K, Upd, GT, true><<<blocks + cc.cblocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
+        if constexpr (sizeof(K) == 4) {
+            if (cc.mask)
+                k_apply_main<4, K, Upd, GT, true, true><<<blocks + cc.cblocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale,
+                                                             gscale, gm, w.carry_head, w.carry_tail, w.owners, seg_offsets, wa, ss, nv, cc);
+        }
+        if (!cc.mask)
+            k_apply_main<4, K, Upd, GT, true><<<blocks, 256, 0, st>>>(upd, V, ld, uniq, spos, sseg, (int)n, g, ldg, rscale, gscale, gm,
                                                              w.carry_head, w.carry_tail, w.owners, seg_offsets, wa, ss, nv, cc);
         if (ev1) MREC_HIP_CHECK(hipEventRecord(ev1, st));
         if (t_defer) {
@@ -1113,7 +1156,8 @@ int apply_impl(Upd upd, int64_t V, int64_t ld, int32_t D, const K* uniq, const i
     w.owners = a.take<int>(nsw);
     w.n_owners = a.take<int>(1);
     w.dummy = a.take<float>(2048 * 16);
-    w.cpart = a.take<float>((size_t)kConstLG * kConstMax * Dc_max);
+    const size_t nch = (size_t)mrec_cdiv(n, 64) < (size_t)kConstLG ? (size_t)mrec_cdiv(n, 64) : (size_t)kConstLG;
+    w.cpart = a.take<float>(nch * kConstMax * Dc_max);
     if (!a.ok) return MREC_EWORKSPACE;
     bool aligned = (ld % 4 == 0) && (ldg % 4 == 0) && ((((uintptr_t)g) & (4 * sizeof(GT) - 1)) == 0);
     for (int i = 0; i < Upd::NS; ++i) aligned = aligned && al16(upd.s[i]);
@@ -1188,31 +1232,44 @@ __global__ void k_step_advance(StepState* s, float lr, float b1, float b2) {
     s->aux[(unsigned)(step + 1) % kStampRing][0] = ~0ull;            // the NEXT step's lookup (it runs before that step's advance)
     s->aux[(unsigned)(step + 1) % kStampRing][1] = 0ull;
 }
-// Which fields of a [B, F] batch are constant columns: field f qualifies iff every sample holds sample 0's id there, that id lies in
-// [0, V) and occurs in no other field.  Candidates = the fields where samples 0 and 1 agree (every workgroup works them out itself: 2 F
-// loads); a batch without one -- ids drawn per sample -- costs those loads and nothing else: workgroup 0 stores an empty mask.  With
-// candidates, every thread compares its ids with the candidates' (LDS), a workgroup ORs the candidates it saw fail into ONE device
-// word (a returning agent-scope atomic, waited for), THEN takes a ticket (so the ticket's last holder sees every workgroup's word: both
-// are atomics at the memory side, no fence -- a release fence here writes back whatever the kernels beside this one have dirtied in
-// L2, 17 us per step when it was tried), and that last workgroup turns the survivors into the mask the apply's kernels read with one
-// scalar load and clears word and ticket for the next batch: no memset node, no second launch.
-struct ConstState { unsigned long long badmask; unsigned ticket, pad; unsigned long long mask; unsigned long long pad2; };
+// Which fields of a [B, F] batch are HOT COLUMNS: field f qualifies iff ONE id -- its candidate: the most frequent id among the field's
+// first 16 samples, in at least a quarter of them -- fills at least `min_count` of its B samples, lies in [0, V) and occurs in no other
+// field.  min_count = B: constant columns (the 13 one-id dense fields of a Criteo batch); smaller: also a field's dominant id (the
+// bucket that rare categories fall into).  Every workgroup works the candidates out itself (16 F loads); a batch without one costs
+// those loads and nothing else: workgroup 0 stores an empty mask.  With candidates, every thread compares its ids with the candidates'
+// (LDS): matches are counted (LDS, then one device atomic per workgroup and candidate), a candidate seen in another field is
+// reported in ONE device word; both by returning agent-scope atomics that are waited for, THEN the workgroup takes a ticket (so
+// the ticket's last holder sees every workgroup's counts: atomics at the memory side, no fence -- a release fence here writes back
+// whatever the kernels beside this one have dirtied in L2, 17 us per step when it was tried), and that last workgroup turns the
+// survivors into the mask and the ids the apply's kernels read, and clears counters, word and ticket for the next batch: no memset
+// node, no second launch.
+struct ConstState { unsigned long long badmask; unsigned ticket, pad; unsigned long long mask; unsigned long long pad2; long long hid[64]; unsigned cnt[64]; };
 static_assert(sizeof(ConstState) == MREC_CONST_COLS_STATE_BYTES, "mrec.h: MREC_CONST_COLS_STATE_BYTES");
 template <class K>
-__global__ __launch_bounds__(256) void k_const_cols(const K* __restrict__ ids, int64_t n, int F, int64_t V, ConstState* __restrict__ st) {
+__global__ __launch_bounds__(256) void k_const_cols(const K* __restrict__ ids, int64_t n, int F, int64_t V, unsigned min_count, ConstState* __restrict__ st) {
     __shared__ long long c[64];
     __shared__ int clist[64];
-    __shared__ unsigned lbad[2];
+    __shared__ unsigned lbad[2], lcnt[64];
     __shared__ unsigned long long candm;
     __shared__ int is_last;
     const int t = (int)threadIdx.x;
+    const int64_t B = n / F;
     if (t < 64) {
         bool ok = false;
+        long long best = 0;
         if (t < F) {
-            const long long v0 = (long long)ids[t], v1 = n >= 2 * (int64_t)F ? (long long)ids[F + t] : v0;
-            c[t] = v0;
-            ok = v0 == v1 && v0 >= 0 && v0 < V;
+            const int S = B < 16 ? (int)B : 16;
+            int bc = 0;
+            for (int i = 0; i < S; ++i) {                     // the most frequent of the first S samples (the earliest on a tie)
+                const long long vi = (long long)ids[(int64_t)i * F + t];
+                int ci = 0;
+                for (int j = 0; j < S; ++j) ci += (long long)ids[(int64_t)j * F + t] == vi ? 1 : 0;
+                if (ci > bc) { bc = ci; best = vi; }
+            }
+            ok = 4 * bc >= S && best >= 0 && best < V;
+            c[t] = best;
         }
+        lcnt[t] = 0u;
         const unsigned long long m = __ballot(ok);           // (threads 0-63 are wave 0)
         if (t == 0) { candm = m; lbad[0] = lbad[1] = 0u; }
         if (ok) clist[__popcll(m & ((1ull << t) - 1ull))] = t;
@@ -1228,49 +1285,63 @@ __global__ __launch_bounds__(256) void k_const_cols(const K* __restrict__ ids, i
     for (int64_t e = (int64_t)blockIdx.x * 256 + t; e < n; e += stride) {
         const long long id = (long long)ids[e];
         const int f = (int)(e % F);
-        if (((m >> f) & 1ull) && id != c[f] && !((lbad[f >> 5] >> (f & 31)) & 1u)) atomicOr(&lbad[f >> 5], 1u << (f & 31));
+        if (((m >> f) & 1ull) && id == c[f]) atomicAdd(&lcnt[f], 1u);
         for (int q = 0; q < nc; ++q) {
             const int f2 = clist[q];
             if (f2 != f && id == c[f2] && !((lbad[f2 >> 5] >> (f2 & 31)) & 1u)) atomicOr(&lbad[f2 >> 5], 1u << (f2 & 31));
         }
     }
     __syncthreads();
-    if (t == 0) {
-        const unsigned long long mine = (unsigned long long)lbad[0] | ((unsigned long long)lbad[1] << 32);
-        if (mine) {
-            unsigned long long old = atomicOr(&st->badmask, mine);
+    if (t < 64) {
+        if (lcnt[t]) {
+            unsigned old = atomicAdd(&st->cnt[t], lcnt[t]);
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(old) : : "memory");        // performed before the ticket is taken
         }
-        is_last = atomicAdd(&st->ticket, 1u) == gridDim.x - 1u;
+        if (t == 0) {
+            const unsigned long long mine = (unsigned long long)lbad[0] | ((unsigned long long)lbad[1] << 32);
+            if (mine) {
+                unsigned long long old = atomicOr(&st->badmask, mine);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(old) : : "memory");
+            }
+        }
     }
     __syncthreads();
-    if (is_last && t == 0) {
+    if (t == 0) is_last = atomicAdd(&st->ticket, 1u) == gridDim.x - 1u;
+    __syncthreads();
+    if (is_last && t < 64) {
         const unsigned long long b = atomicOr(&st->badmask, 0ull);
-        unsigned long long mm = m & ~b, keep = 0ull;
-        for (int j = 0; j < kConstMax && mm; ++j) { const unsigned long long low = mm & (~mm + 1ull); keep |= low; mm ^= low; }
-        st->mask = keep;
-        atomicExch(&st->badmask, 0ull);
-        atomicExch(&st->ticket, 0u);
+        const unsigned cn = atomicAdd(&st->cnt[t], 0u);
+        const bool hot = ((m >> t) & 1ull) && !((b >> t) & 1ull) && cn >= min_count;
+        const unsigned long long keep = __ballot(hot);
+        st->hid[t] = hot ? c[t] : -1ll;
+        atomicExch(&st->cnt[t], 0u);
+        if (t == 0) {
+            st->mask = keep;
+            atomicExch(&st->badmask, 0ull);
+            atomicExch(&st->ticket, 0u);
+        }
     }
 }
 }  // namespace
 
-MREC_API int mrec_const_cols_detect(const void* ids, int32_t id_bytes, int64_t B, int32_t F, int64_t V, void* state, void* stream) {
-    if (!ids || !state || (id_bytes != 4 && id_bytes != 8) || B <= 0 || F <= 0 || V <= 0) return MREC_EINVAL;
+MREC_API int mrec_const_cols_detect(const void* ids, int32_t id_bytes, int64_t B, int32_t F, int64_t V, int64_t min_count, void* state,
+                                    void* stream) {
+    if (!ids || !state || (id_bytes != 4 && id_bytes != 8) || B <= 0 || F <= 0 || V <= 0 || min_count < 1) return MREC_EINVAL;
     if (F > 64) return MREC_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = B * F;
+    if (min_count > B) min_count = B + 1;              // (nothing qualifies)
     unsigned blocks = (unsigned)mrec_cdiv(n, (int64_t)256 * 8);
     if (blocks > 256u) blocks = 256u;
-    if (id_bytes == 4) k_const_cols<int32_t><<<blocks, 256, 0, st>>>((const int32_t*)ids, n, F, V, (ConstState*)state);
-    else k_const_cols<int64_t><<<blocks, 256, 0, st>>>((const int64_t*)ids, n, F, V, (ConstState*)state);
+    if (id_bytes == 4) k_const_cols<int32_t><<<blocks, 256, 0, st>>>((const int32_t*)ids, n, F, V, (unsigned)min_count, (ConstState*)state);
+    else k_const_cols<int64_t><<<blocks, 256, 0, st>>>((const int64_t*)ids, n, F, V, (unsigned)min_count, (ConstState*)state);
     MREC_LAUNCH_CHECK();
     return MREC_OK;
 }
 MREC_API int mrec_sparse_apply_next_const_cols(const void* state, const void* ids, int32_t id_bytes, int64_t B) {
     if ((state == nullptr) != (ids == nullptr) || B < 0 || B > (int64_t(1) << 30) || (ids && id_bytes != 4 && id_bytes != 8)) return MREC_EINVAL;
     t_const = ConstCols{};
-    if (state) { t_const.mask = &((const ConstState*)state)->mask; t_const.ids0 = ids; t_const.B = (int)B; t_const.id_bytes = id_bytes; }
+    if (state) { t_const.mask = &((const ConstState*)state)->mask; t_const.hid = ((const ConstState*)state)->hid; t_const.ids0 = ids; t_const.B = (int)B; t_const.id_bytes = id_bytes; }
     return MREC_OK;
 }
 

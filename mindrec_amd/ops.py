@@ -372,7 +372,7 @@ class ApplyFinish(C.Structure):      # mrec_apply_finish_t
     _fields_ = [("opaque", C.c_ubyte * 448)]
 
 
-CONST_COLS_STATE_BYTES = 32        # MREC_CONST_COLS_STATE_BYTES
+CONST_COLS_STATE_BYTES = 800       # MREC_CONST_COLS_STATE_BYTES
 
 
 def const_cols_state(device):
@@ -380,11 +380,13 @@ def const_cols_state(device):
     return torch.zeros(CONST_COLS_STATE_BYTES // 4, dtype=torch.int32, device=device)
 
 
-def const_cols_detect(ids, V, state=None):
-    """Which fields of the [B, F] batch `ids` are constant columns (mrec_const_cols_detect, include/mrec.h): every sample holds
-    sample 0's id in the field, that id is a row of a V-row table and occurs in no other field -- what the reference's Criteo pipeline
-    gives the 13 dense features (process_data.py:138-147).  Returns the state tensor (const_cols_state) that holds the
-    mask (const_cols_mask reads it); hand it to sparse_lazy_adam_wide_(..., const_cols=(state, ids)).  None: more than 64 fields."""
+def const_cols_detect(ids, V, state=None, min_count=None):
+    """Which fields of the [B, F] batch `ids` are hot columns (mrec_const_cols_detect, include/mrec.h): ONE id -- the most frequent of
+    the field's first 16 samples -- fills at least `min_count` of the field's B samples, is a row of a V-row table and occurs in no
+    other field.  min_count = B (the default): constant columns, what the reference's Criteo pipeline gives the 13 dense features
+    (process_data.py:138-147); smaller: also a field's dominant id (the bucket its rare categories fall into).  Returns the state
+    tensor (const_cols_state) that holds the mask and the ids (const_cols_mask / const_cols_ids read them); hand it to
+    sparse_lazy_adam_wide_(..., const_cols=(state, ids)).  None: more than 64 fields."""
     _need_cuda(ids)
     if ids.dim() != 2 or ids.dtype not in (torch.int32, torch.int64) or not ids.is_contiguous():
         raise TypeError("ids must be a contiguous [B, F] int32 / int64 tensor")
@@ -393,7 +395,8 @@ def const_cols_detect(ids, V, state=None):
         return None
     if state is None:
         state = const_cols_state(ids.device)
-    _lib.call("mrec_const_cols_detect", _ptr(ids), ids.element_size(), B, F, int(V), _ptr(state), _stream())
+    _lib.call("mrec_const_cols_detect", _ptr(ids), ids.element_size(), B, F, int(V), int(B if min_count is None else max(1, min_count)),
+              _ptr(state), _stream())
     return state
 
 
@@ -401,6 +404,14 @@ def const_cols_mask(state):
     """The constant columns of the last const_cols_detect over this state, as a Python int (bit f = field f); synchronises."""
     w = state[4:6].cpu().numpy().view(np.uint64)
     return int(w[0])
+
+
+def const_cols_ids(state):
+    """{field: hot id} of the last const_cols_detect over this state; synchronises."""
+    a = state.cpu().numpy()
+    m = int(a[4:6].view(np.uint64)[0])
+    hid = a[8:8 + 128].view(np.int64)
+    return {f: int(hid[f]) for f in range(64) if (m >> f) & 1}
 
 
 def sparse_lazy_adam_wide_(p, m, v, plan, g, row_scale, gw, F, wide_col, lr=3.5e-4, beta1=0.9, beta2=0.999, eps=1e-8,

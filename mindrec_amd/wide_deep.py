@@ -352,6 +352,12 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         self._fuse_finish = True      # the apply's finishing pass inside the dense Adam launch (see _choose_finish)
         self._const_cols = bool(getattr(cfg, "const_columns", True)) and os.environ.get("MREC_CONST_COLS", "1") != "0"      # (see _plan)
         self._col_bad, self._cc = None, None
+        self._hot_seen = False          # the stream's first batches held hot columns (looked at in the eager steps, see _plan)
+        # a field's DOMINANT id (not in every sample, but in at least max(MREC_HOT_MIN, B / 8) of them) can take the same path; 0 (the
+        # default): constant columns only -- measured on the bench's Zipf ids, whose 26 categorical fields each fold their rare ids into
+        # one id (~40 % of the field): k_apply_main 87 -> 90 us, finishing pass 27.9 -> 24.9 us, path 36.0 -> 35.9 %: nothing
+        # (profiles/r05_const_cols_ab.txt); the pass is at its floor inside the dense Adam's launch
+        self._hot_min = int(os.environ.get("MREC_HOT_MIN", "0"))
         self._plan_fork = os.environ.get("MREC_PLAN_FORK", "lookup")       # where the captured step forks its plan branch: "lookup" | "head"
         self.deep_apply_timer = None  # optional ops.KernelTimer armed right before the deep table's sparse apply
         self._dyn = False             # step scalars (Adam powers / step size) in device memory: set per step
@@ -477,17 +483,27 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
 
     def _plan(self, ids):
         """The step's inverted index (Unique + positions per unique id) and, beside it on the same stream, which fields of the batch
-        are CONSTANT COLUMNS (mrec_const_cols_detect: the reference's Criteo pipeline gives each of the 13 dense features one id,
-        process_data.py:138-147) -- the folded one-GPU apply sums those columns sample by sample instead of through the index."""
+        are HOT COLUMNS (mrec_const_cols_detect): one id fills the field -- the reference's Criteo pipeline gives each of the 13 dense
+        features one id, process_data.py:138-147 -- or most of it (the id a field's rare categories are folded into).  The folded
+        one-GPU apply sums those ids' gradient rows sample by sample instead of through the index.  Whether a batch stream HAS such
+        columns is looked at in the engine's first, eager steps (one host read of the mask each); a stream without them is captured
+        without the detection launch and with the plain apply kernel."""
         plan = self.k.sparse_plan(ids)
         self._cc = None
         if (self._const_cols and self._fold_wide and self.cfg.sparse and not self._sharded and not self.cfg.dynamic_embedding and self.hb is None
-                and ids.dim() == 2 and ids.shape[1] <= 64 and hasattr(self.k, "const_cols_detect")):
-            if self._col_bad is None:
-                self._col_bad = self.k.const_cols_state(self.device)
-            bad = self.k.const_cols_detect(ids, self.cfg.vocab_size, state=self._col_bad)
-            if bad is not None:
-                self._cc = (bad, ids)
+                and ids.dim() == 2 and ids.shape[1] <= 64 and ids.dtype == torch.int32 and hasattr(self.k, "const_cols_detect")):
+            probing = self.step_count <= 2 and not (self._gpu and torch.cuda.is_current_stream_capturing())
+            if probing or self._hot_seen:
+                if self._col_bad is None:
+                    self._col_bad = self.k.const_cols_state(self.device)
+                B = ids.shape[0]
+                st = self.k.const_cols_detect(ids, self.cfg.vocab_size, state=self._col_bad,
+                                              min_count=B if self._hot_min <= 0 else max(self._hot_min, -(-B // 8)))
+                if st is not None:
+                    if probing and not self._hot_seen:
+                        self._hot_seen = self.k.const_cols_mask(st) != 0
+                    if self._hot_seen:
+                        self._cc = (st, ids)
         return plan
 
     def _front(self, ids, wts, label, capturing=False):

@@ -17,17 +17,25 @@ def _ids(rng, B, F, V, nconst, dtype):
     return ids
 
 
-def _detect_ref(ids, V):
+def _detect_ref(ids, V, min_count):
+    """{field: hot id}: the most frequent id of the field's first 16 samples (the earliest on a tie), in at least a quarter of them, a row
+    of the table, in at least min_count of the field's samples and in no other field."""
     B, F = ids.shape
-    bad = np.zeros(64, np.int32)
-    c = ids[0]
+    S = min(16, B)
+    out = {}
     for f in range(F):
-        if not (0 <= c[f] < V) or (ids[:, f] != c[f]).any():
-            bad[f] = 1
-        other = np.delete(ids, f, axis=1)
-        if (other == c[f]).any():
-            bad[f] = 1
-    return bad
+        col = ids[:S, f]
+        best, bc = None, 0
+        for i in range(S):
+            ci = int((col == col[i]).sum())
+            if ci > bc:
+                best, bc = int(col[i]), ci
+        if 4 * bc < S or not (0 <= best < V):
+            continue
+        if int((ids[:, f] == best).sum()) < min_count or (np.delete(ids, f, axis=1) == best).any():
+            continue
+        out[f] = best
+    return out
 
 
 @pytest.mark.parametrize("idt", [np.int32, np.int64])
@@ -40,33 +48,38 @@ def test_detection_matches_the_restatement(dev, idt):
     ids[17, 30] = ids[0, 5]                   # column 5's id also occurs in field 30
     ids[:, 9] = V + 2                         # column 9: one id, but not a row of the table
     ids[:, 38] = 11                           # a constant column that is not among the first fields ... and the id of column 4
+    ids[rng.random(B) < 0.6, 20] = 3210       # field 20: a dominant id in ~60 % of the samples
     state = ops.const_cols_state(dev)
-    ref = _detect_ref(ids, V)
+    tid = torch.from_numpy(ids).to(dev)
     for _ in range(3):                        # (the state is reused batch after batch: the launch's last workgroup clears it)
-        got = ops.const_cols_mask(ops.const_cols_detect(torch.from_numpy(ids).to(dev), V, state))
-        assert [f for f in range(F) if (got >> f) & 1] == [f for f in range(F) if ref[f] == 0] == [0, 1, 2, 6, 7, 8, 10, 11, 12]
-        assert (state[:4] == 0).all()
-    # no constant column at all (same state); samples 0 and 1 agree by chance in a field that is not constant; more than 64 fields
+        got = ops.const_cols_ids(ops.const_cols_detect(tid, V, state))                     # constant columns only
+        assert got == _detect_ref(ids, V, B) and sorted(got) == [0, 1, 2, 6, 7, 8, 10, 11, 12]
+        assert (state[:4] == 0).all() and (state[136:] == 0).all()
+        got = ops.const_cols_ids(ops.const_cols_detect(tid, V, state, min_count=B // 8))   # ... and dominant ids
+        assert got == _detect_ref(ids, V, B // 8) and sorted(got) == [0, 1, 2, 3, 6, 7, 8, 10, 11, 12, 20] and got[20] == 3210
+    # no hot column at all (same state); samples agree by chance in a field that is not constant; more than 64 fields
     ids2 = rng.integers(0, V, size=(64, 26)).astype(idt)
     assert ops.const_cols_mask(ops.const_cols_detect(torch.from_numpy(ids2).to(dev), V, state)) == 0
-    ids2[1, 4] = ids2[0, 4]
+    ids2[1:5, 4] = ids2[0, 4]
     ids2[:, 20] = 123
-    assert ops.const_cols_mask(ops.const_cols_detect(torch.from_numpy(ids2).to(dev), V, state)) == (0 if (ids2 == 123).sum() > 64 else 1 << 20)
-    # more constant columns than the path takes: the first 16 in field order
+    assert ops.const_cols_ids(ops.const_cols_detect(torch.from_numpy(ids2).to(dev), V, state)) == _detect_ref(ids2, V, 64)
     ids3 = _ids(rng, 50, 39, V, 20, idt)
-    assert ops.const_cols_mask(ops.const_cols_detect(torch.from_numpy(ids3).to(dev), V, state)) == (1 << 16) - 1
+    assert ops.const_cols_mask(ops.const_cols_detect(torch.from_numpy(ids3).to(dev), V, state)) == (1 << 20) - 1
     assert ops.const_cols_detect(torch.zeros((4, 65), dtype=torch.int32, device=dev), V) is None
 
 
 @pytest.mark.parametrize("defer", [False, True])
-@pytest.mark.parametrize("idt,gdt,B,nconst", [(torch.int32, torch.float16, 1024, 13), (torch.int64, torch.bfloat16, 515, 13),
-                                             (torch.int32, torch.float16, 2000, 18), (torch.int32, torch.float32, 96, 1)])
-def test_apply_with_constant_columns(dev, oracle, defer, idt, gdt, B, nconst):
+@pytest.mark.parametrize("idt,gdt,B,nconst,dom", [(torch.int32, torch.float16, 1024, 13, 0), (torch.int64, torch.bfloat16, 515, 13, 0),
+                                                 (torch.int32, torch.float16, 2000, 18, 3), (torch.int32, torch.float32, 96, 1, 0),
+                                                 (torch.int32, torch.bfloat16, 777, 0, 5)])
+def test_apply_with_constant_columns(dev, oracle, defer, idt, gdt, B, nconst, dom):
     from mindrec_amd import ops
     rng = np.random.default_rng(B + nconst)
     V, D, F = 5000, 80, 39
     ld = 256
     ids = _ids(rng, B, F, V, nconst, np.int64)
+    for d in range(dom):                                              # `dom` more fields with a dominant id (40-90 % of the samples, ids 30 ..)
+        ids[rng.random(B) < 0.4 + 0.1 * d, 20 + d] = 30 + d
     wts = rng.random((B, F)).astype(np.float32)
     g = (rng.standard_normal((B * F, D)) * 1.024).astype(np.float32)
     dname = {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: None}[gdt]
@@ -84,7 +97,7 @@ def test_apply_with_constant_columns(dev, oracle, defer, idt, gdt, B, nconst):
     def run(cc):
         st = torch.from_numpy(st0.copy()).to(dev)
         plan = ops.sparse_plan(tid)
-        const = (ops.const_cols_detect(tid, V), tid) if cc else None
+        const = (ops.const_cols_detect(tid, V, min_count=B // 8 if dom else None), tid) if cc else None
         fin = ops.sparse_lazy_adam_wide_(st[:, :D], st[:, D + 4:2 * D + 4], st[:, 2 * D + 4:3 * D + 4], plan, tg, twt, tgw, F, D, defer=defer,
                                          const_cols=const, **kw)
         if defer:
@@ -94,7 +107,7 @@ def test_apply_with_constant_columns(dev, oracle, defer, idt, gdt, B, nconst):
         return st.cpu().numpy()
 
     a, b = run(True), run(False)
-    crows = np.arange(min(nconst, 16)) + 7                           # (the first 16 constant columns take the new path)
+    crows = np.concatenate([np.arange(nconst) + 7, np.arange(dom) + 30]).astype(np.int64)       # the rows that take the new path
     other = np.ones(V, bool)
     other[crows] = False
     assert np.array_equal(a[other], b[other]), "rows outside the constant columns must not change"
