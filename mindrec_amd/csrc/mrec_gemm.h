@@ -34,6 +34,10 @@
 #include <stdint.h>
 #include "mrec_dropout.h"
 
+#ifndef MREC_GEMM_READS_8484
+#define MREC_GEMM_READS_8484 0       // 1: the 8 / 4 / 8 / 4 fragment-read schedule of the 256 x 256 body (round 5: built, bit-identical, measured, not the default)
+#endif
+
 namespace mgemm {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -261,6 +265,7 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
     bool rd_done = false;
     uint32_t tseg[8][4] = {}, tlast = 0;          // [phase + 4 * buffer][segment: issue + waits, first barrier, MFMAs, second barrier]
     u32x4_t fP[4][2], fQ0[2][2], fQ1[2][2];       // fragments [rep][ks]
+    u32x4_t fPb[4];                               // MR = 8: the second k-step's P fragments of a K-tile's FIRST half (read a phase early)
     f32x4_t acc[MR][4];
 #pragma unroll
     for (int i = 0; i < MR; ++i)
@@ -283,6 +288,23 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
             else fP[mi_][ks_] = ldtr(slot_off(BUF, (H) ? 3 : 0) + (4 * ks_ + (mi_ >> 1)) * 1024 + ((mi_ & 1) ? rdP1 : rdP0)); \
         }                                                                                              \
     } while (0)
+    // the P fragments of ONE k-step of half H (MR = 8 schedule below): ks 0 into fP[.][0], ks 1 of the first half into fPb
+#define MG_READ_P_KS0(BUF)                                                                             \
+    do {                                                                                               \
+        if ((VAR & 16) && rd_done) break;                                                              \
+        _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_) {                                          \
+            if (!PT) fP[mi_][0] = ld128(slot_off(BUF, 0) + (mi_ * 2 + 0) * 1024 + rdP0);               \
+            else fP[mi_][0] = ldtr(slot_off(BUF, 0) + (4 * 0 + (mi_ >> 1)) * 1024 + ((mi_ & 1) ? rdP1 : rdP0)); \
+        }                                                                                              \
+    } while (0)
+#define MG_READ_P_KS1B(BUF)                                                                            \
+    do {                                                                                               \
+        if ((VAR & 16) && rd_done) break;                                                              \
+        _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_) {                                          \
+            if (!PT) fPb[mi_] = ld128(slot_off(BUF, 0) + (mi_ * 2 + 1) * 1024 + rdP0);                 \
+            else fPb[mi_] = ldtr(slot_off(BUF, 0) + (4 * 1 + (mi_ >> 1)) * 1024 + ((mi_ & 1) ? rdP1 : rdP0)); \
+        }                                                                                              \
+    } while (0)
 #define MG_READ_Q(BUF, H, F)                                                                           \
     do {                                                                                               \
         if ((VAR & 16) && rd_done) break;                                                              \
@@ -300,6 +322,18 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
         if (!(HALF)) {                                                                                 \
             _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_) _Pragma("unroll") for (int nj_ = 0; nj_ < 2; ++nj_) \
                 acc[(MH) * 4 + mi_][(NH) * 2 + nj_] = E::mfma(F[nj_][1], fP[mi_][1], acc[(MH) * 4 + mi_][(NH) * 2 + nj_]); \
+        }                                                                                              \
+        if (!(VAR & 2)) __builtin_amdgcn_s_setprio(2);                                                 \
+    } while (0)
+    // ... of the first half (MH = 0) with the second k-step's P fragments in fPb
+#define MG_MFMA0(NH, F, HALF)                                                                          \
+    do {                                                                                               \
+        if (!(VAR & 2)) __builtin_amdgcn_s_setprio(3);                                                 \
+        _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_) _Pragma("unroll") for (int nj_ = 0; nj_ < 2; ++nj_) \
+            acc[mi_][(NH) * 2 + nj_] = E::mfma(F[nj_][0], fP[mi_][0], acc[mi_][(NH) * 2 + nj_]);      \
+        if (!(HALF)) {                                                                                 \
+            _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_) _Pragma("unroll") for (int nj_ = 0; nj_ < 2; ++nj_) \
+                acc[mi_][(NH) * 2 + nj_] = E::mfma(F[nj_][1], fPb[mi_], acc[mi_][(NH) * 2 + nj_]);    \
         }                                                                                              \
         if (!(VAR & 2)) __builtin_amdgcn_s_setprio(2);                                                 \
     } while (0)
@@ -366,8 +400,73 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
         MG_STAGE(1, BUF, (t) + 2);                   \
         MG_PHASE_SYNC_MFMA(3 + 4 * (BUF), 1, 0, fQ0, half_); \
     } while (0)
-    // the four phases of K-tile t living in LDS buffer BUF
-#define MG_KTILE(BUF, t)                             \
+    // (VAR & 16384, harness only, WRONG results: 8 / 4 / 8 / 4 -- what moving the second k-step's P fragments of phase 0 into the
+    // reads of the phase before it would be worth; that form needs no change of the staging order or of the waits)
+#define MG_KTILE_B8(BUF, t)                          \
+    do {                                             \
+        const bool half_ = false;                    \
+        MG_READ_Q(BUF, 0, fQ0);                      \
+        MG_RD1P(BUF, 0, 0, 0); MG_RD1P(BUF, 0, 1, 0); MG_RD1P(BUF, 0, 2, 0); MG_RD1P(BUF, 0, 3, 0); \
+        MG_STAGE(2, (BUF) ^ 1, (t) + 1);             \
+        MG_PHASE_SYNC_MFMA(0, 0, 0, fQ0, half_);     \
+        MG_READ_Q(BUF, 1, fQ1);                      \
+        MG_STAGE(3, (BUF) ^ 1, (t) + 1);             \
+        MG_PHASE_SYNC_MFMA(1, 0, 1, fQ1, half_);     \
+        MG_READ_P(BUF, 1);                           \
+        MG_STAGE(0, BUF, (t) + 2);                   \
+        MG_PHASE_SYNC_MFMA(2, 1, 1, fQ1, half_);     \
+        MG_RD1P(BUF, 0, 0, 1); MG_RD1P(BUF, 0, 1, 1); MG_RD1P(BUF, 0, 2, 1); MG_RD1P(BUF, 0, 3, 1); \
+        MG_STAGE(1, BUF, (t) + 2);                   \
+        MG_PHASE_SYNC_MFMA(3, 1, 0, fQ0, half_);     \
+    } while (0)
+#define MG_PHASE_SYNC_MFMA0(PH, NH, F, half_)        \
+    do {                                             \
+        if constexpr ((VAR & 64) != 0) {             \
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
+            MG_T(PH, 0);                             \
+            __builtin_amdgcn_s_barrier();            \
+            MG_T(PH, 1);                             \
+            MG_MFMA0(NH, F, half_);                  \
+            MG_T(PH, 2);                             \
+            __builtin_amdgcn_s_barrier();            \
+            MG_T(PH, 3);                             \
+        } else {                                     \
+            MG_SYNC_PRE();                           \
+            MG_MFMA0(NH, F, half_);                  \
+            MG_SYNC_POST();                          \
+        }                                            \
+    } while (0)
+    // An 8 / 4 / 8 / 4 read schedule (round 5; built, measured, NOT the default: -DMREC_GEMM_READS_8484=1, or VAR & 65536 in the harness).
+    // The shipped schedule reads 12 / 4 / 8 / 0 fragments in a K-tile's four phases, and the phase with twelve is the long pole of the
+    // ping-pong (profiles/r05_gemm_ablation.txt).  Here the first half's P fragments of the SECOND k-step are read a phase early -- in
+    // phase 3 of the K-tile before, from the other buffer: that piece was staged six phases earlier, the wait that retires it sits in
+    // front of phase 2's first barrier, and the piece is restaged in the next tile's phase 2, behind its last read in phase 0 as
+    // before: no wait, no staging order and no barrier changes -- into four registers of their own (fPb; 216 -> 230-237 VGPRs).
+    // The same MFMAs in the same order: every output bit equal to the shipped schedule's over forward / input gradient / weight
+    // gradient, ragged shapes and K tails, six launches each (`dense_gemm_test compare`).  Alone: layer 0's forward 62.3 -> 61.6 us,
+    // K = 1024 37.1 -> 36.3, K = 8320 212.5 -> 209 (half of what the emulation with misplaced reads promised).  In the step: 0.629-0.633
+    // -> 0.636-0.638 ms, three A/B pairs on one box -- slower; the launches beside the GEMMs find 20 registers less per lane on every
+    // SIMD.  Not kept.
+#define MG_KTILE_8484(BUF, t)                        \
+    do {                                             \
+        const bool half_ = !(VAR & 1024) && ktail && krem <= 32 && (kt0 + (t)) == Ttot - 1;    \
+        MG_READ_Q(BUF, 0, fQ0);                      \
+        MG_READ_P_KS0(BUF);                          \
+        MG_STAGE(2, (BUF) ^ 1, (t) + 1);             \
+        MG_PHASE_SYNC_MFMA0(0 + 4 * (BUF), 0, fQ0, half_); \
+        MG_READ_Q(BUF, 1, fQ1);                      \
+        MG_STAGE(3, (BUF) ^ 1, (t) + 1);             \
+        MG_PHASE_SYNC_MFMA0(1 + 4 * (BUF), 1, fQ1, half_); \
+        MG_READ_P(BUF, 1);                           \
+        MG_STAGE(0, BUF, (t) + 2);                   \
+        MG_PHASE_SYNC_MFMA(2 + 4 * (BUF), 1, 1, fQ1, half_); \
+        MG_READ_P_KS1B((BUF) ^ 1);                   \
+        MG_STAGE(1, BUF, (t) + 2);                   \
+        MG_PHASE_SYNC_MFMA(3 + 4 * (BUF), 1, 0, fQ0, half_); \
+        if (VAR & 16) rd_done = true;                \
+    } while (0)
+    // the four phases of K-tile t living in LDS buffer BUF (the shipped schedule)
+#define MG_KTILE(BUF, t)                         \
     do {                                             \
         const bool half_ = !(VAR & 1024) && ktail && krem <= 32 && (kt0 + (t)) == Ttot - 1;    \
         MG_READ_Q(BUF, 0, fQ0);                      \
@@ -396,7 +495,7 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
         MG_SYNC_PRE();
         if (!(VAR & 1) && wr == 1) __builtin_amdgcn_s_barrier();       // stagger: wave row 1 runs one barrier behind wave row 0
 
-        uint64_t tc0 = 0, tr0 = 0;
+        [[maybe_unused]] uint64_t tc0 = 0, tr0 = 0;
         if constexpr ((VAR & 64) != 0) {
             tc0 = __builtin_amdgcn_s_memtime();
             tr0 = __builtin_amdgcn_s_memrealtime();
@@ -407,6 +506,12 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
             for (int t = 0; t < T; t += 2) {
                 MG_KTILE_BAL(0, t);
                 if (t + 1 < T) MG_KTILE_BAL(1, t + 1);
+            }
+        } else if constexpr ((VAR & 16384) != 0 && !PT && !QT) {
+            MG_READ_P(0, 0);
+            for (int t = 0; t < T; t += 2) {
+                MG_KTILE_B8(0, t);
+                if (t + 1 < T) MG_KTILE_B8(1, t + 1);
             }
         } else if constexpr ((VAR & 256) != 0) {
             for (int t = 0; t < T; t += 4) {
@@ -426,19 +531,16 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
                 if (t + 6 < T) MG_KTILE(0, t + 6);
                 if (t + 7 < T) MG_KTILE(1, t + 7);
             }
-        } else
-        for (int t = 0; t < T; t += 2) {
-            MG_KTILE(0, t);
-            if (t + 1 < T) MG_KTILE(1, t + 1);
-        }
-        if constexpr ((VAR & 64) != 0) {
-            if (l == 0 && a.colsum_ws != nullptr) {          // [workgroup][wave][phase][segment] cycle sums
-#pragma unroll
-                for (int ph = 0; ph < 8; ++ph)
-#pragma unroll
-                    for (int sg = 0; sg < 4; ++sg) a.colsum_ws[((int64_t)bid * 8 + w) * 36 + ph * 4 + sg] = (float)tseg[ph][sg];
-                a.colsum_ws[((int64_t)bid * 8 + w) * 36 + 32] = (float)(__builtin_amdgcn_s_memtime() - tc0);         // shader cycles
-                a.colsum_ws[((int64_t)bid * 8 + w) * 36 + 33] = (float)(__builtin_amdgcn_s_memrealtime() - tr0);     // 100 MHz ticks
+        } else if constexpr ((VAR & 65536) != 0 || MREC_GEMM_READS_8484) {
+            MG_READ_P_KS1B(0);                     // K-tile 0's (landed with the prologue's first two pieces)
+            for (int t = 0; t < T; t += 2) {
+                MG_KTILE_8484(0, t);
+                if (t + 1 < T) MG_KTILE_8484(1, t + 1);
+            }
+        } else {
+            for (int t = 0; t < T; t += 2) {
+                MG_KTILE(0, t);
+                if (t + 1 < T) MG_KTILE(1, t + 1);
             }
         }
     } else {
@@ -772,6 +874,12 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
 #undef MG_T
 #undef MG_RD1P
 #undef MG_KTILE_BAL
+#undef MG_KTILE_8484
+#undef MG_READ_P_KS0
+#undef MG_READ_P_KS1B
+#undef MG_MFMA0
+#undef MG_PHASE_SYNC_MFMA0
+#undef MG_KTILE_B8
 #undef MG_PHASE_SYNC_MFMA
 }
 

@@ -225,17 +225,119 @@ static void time_fwd_kc(int M, int N, int K, const char* what) {
     CK(hipFree(dX)); CK(hipFree(dW)); CK(hipFree(dC)); CK(hipFree(db)); CK(hipFree(dws));
 }
 static void ablations(int B) {
-    for (int rep = 0; rep < 3; ++rep) {
-        const int K = rep == 0 ? 2080 : rep == 1 ? 1024 : 128;
+    for (int rep = 0; rep < 2; ++rep) {
+        const int K = rep == 0 ? 2080 : 8320;
         time_fwd_kc<0>(B, 1024, K, "as shipped");
+        time_fwd_kc<1>(B, 1024, K, "no stagger");
+        time_fwd_kc<2>(B, 1024, K, "no priorities");
+        time_fwd_kc<8>(B, 1024, K, "no staging past K-tile 1");
+        time_fwd_kc<16>(B, 1024, K, "no fragment reads past K-tile 0");
+        time_fwd_kc<24>(B, 1024, K, "neither (MFMAs + barriers)");
+        time_fwd_kc<32>(B, 1024, K, "staging from K-tile 0's addresses");
+        time_fwd_kc<128>(B, 1024, K, "reads dealt 6/6/6/6 (wrong results)");
+        time_fwd_kc<16384>(B, 1024, K, "reads dealt 8/4/8/4 (wrong results)");
+        time_fwd_kc<65536>(B, 1024, K, "reads 8/4/8/4 (correct: bit-identical)");
+        time_fwd_kc<256>(B, 1024, K, "four K-tiles per loop trip");
+        time_fwd_kc<512>(B, 1024, K, "eight K-tiles per loop trip");
         time_fwd_kc<8192>(B, 1024, K, "no output stores");
         time_fwd_kc<0>(B, 1024, K, "as shipped (again)");
-        time_fwd_kc<8192>(B, 1024, K, "no output stores (again)");
+        time_fwd_kc<64>(B, 1024, K, "stamped");
+        time_fwd_kc<72>(B, 1024, K, "stamped, no staging past K-tile 1");
+        time_fwd_kc<80>(B, 1024, K, "stamped, no fragment reads");
+        time_fwd_kc<88>(B, 1024, K, "stamped, neither");
+        time_fwd_kc<96>(B, 1024, K, "stamped, staging from K-tile 0");
     }
+    time_fwd_kc<0>(4096, 4096, 4096, "4096^3");
+    time_fwd_kc<0>(8192, 8192, 8192, "8192^3");
 }
+
+// The round-5 read schedule of the 256 x 256 body against the shipped one (VAR & 65536 selects it): the same MFMAs in the same order, so every
+// output bit must agree -- forward (both operand layouts), input gradient with mask and column sums, weight gradient slabs; ragged
+// shapes and K tails included; several launches each (a race between the early fragment reads and the staging DMA would show as a
+// difference that comes and goes).
+template <bool PT, bool QT, int EPI>
+static int compare_old_new(int M, int N, int K, int S, const char* what) {
+    // forward / dgrad: C[M, N] 16-bit = P[M, K] . Q (QT ? [K, N] : [N, K]);  wgrad (PT && QT): C[S][Kin = N?]...  (sizes as the tests above)
+    const int Pext = PT ? N : M;            // wgrad: P = x [M, Kin] read as [k = m][p = kin]: Pext = Kin (passed as N), Qext = Nout (passed as K)
+    (void)Pext;
+    std::vector<uint16_t> hP, hQ, hH;
+    size_t nC;
+    Args a{};
+    uint16_t *dP, *dQ, *dH = nullptr;
+    float* dws = nullptr;
+    if (!(PT && QT)) {
+        hP.resize((size_t)M * K); hQ.resize((size_t)N * K);
+        for (auto& x : hP) x = h_f2bf(frand());
+        for (auto& x : hQ) x = h_f2bf(frand() * 0.05f);
+        a.ldp = K; a.ldq = QT ? N : K; a.ldc = N; a.Pext = M; a.Qext = N; a.K = K;
+        a.nTp = (M + 255) / 256; a.nTq = (N + 255) / 256; a.kt_per_slab = (K + 63) / 64; a.relu = 1;
+        nC = (size_t)M * N * 2;
+    } else {
+        // dW[Kin = N, Nout = K] = x[M, Kin]^T . dy[M, Nout], reduction over M in S slabs
+        hP.resize((size_t)M * N); hQ.resize((size_t)M * K);
+        for (auto& x : hP) x = h_f2bf(frand());
+        for (auto& x : hQ) x = h_f2bf(frand() * 0.05f);
+        a.ldp = N; a.ldq = K; a.ldc = K; a.Pext = N; a.Qext = K; a.K = M;
+        a.nTp = (N + 255) / 256; a.nTq = (K + 255) / 256;
+        const int Tt = (M + 63) / 64;
+        a.kt_per_slab = (Tt + S - 1) / S; a.slab_stride = (int64_t)N * K;
+        nC = (size_t)S * N * K * 4;
+    }
+    CK(hipMalloc(&dP, hP.size() * 2)); CK(hipMalloc(&dQ, hQ.size() * 2));
+    CK(hipMemcpy(dP, hP.data(), hP.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dQ, hQ.data(), hQ.size() * 2, hipMemcpyHostToDevice));
+    a.P = dP; a.Q = dQ;
+    if (EPI == EPI_DGRAD) {
+        hH.resize((size_t)M * N);
+        for (auto& x : hH) { float v = frand(); x = h_f2bf(v > 0.2f ? v : 0.f); }
+        CK(hipMalloc(&dH, hH.size() * 2));
+        CK(hipMemcpy(dH, hH.data(), hH.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMalloc(&dws, (size_t)a.nTp * N * 4));
+        a.H = dH; a.colsum_ws = dws;
+    }
+    float* db = nullptr;
+    if (EPI == EPI_FWD) { CK(hipMalloc(&db, N * 4)); CK(hipMemset(db, 0, N * 4)); a.bias = db; }
+    void *c0, *c1;
+    CK(hipMalloc(&c0, nC)); CK(hipMalloc(&c1, nC));
+    const int grid = a.nTp * a.nTq * ((PT && QT) ? S : 1);
+    std::vector<unsigned char> h0(nC), h1(nC);
+    int bad = 0;
+    for (int rep = 0; rep < 6; ++rep) {
+        CK(hipMemset(c0, 0xEE, nC)); CK(hipMemset(c1, 0x11, nC));
+        a.C = c0; k_gemm256<PT, QT, EPI, false, 0, 8><<<grid, kThreads>>>(a);
+        a.C = c1; k_gemm256<PT, QT, EPI, false, 65536, 8><<<grid, kThreads>>>(a);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(h0.data(), c0, nC, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(h1.data(), c1, nC, hipMemcpyDeviceToHost));
+        if (memcmp(h0.data(), h1.data(), nC)) ++bad;
+    }
+    printf("shipped vs 8/4/8/4 schedule, %-22s M=%d N=%d K=%d S=%d grid %d: %s\n", what, M, N, K, S, grid, bad ? "DIFFERENT" : "bit-identical (6 launches)");
+    CK(hipFree(dP)); CK(hipFree(dQ)); CK(hipFree(c0)); CK(hipFree(c1));
+    if (dH) CK(hipFree(dH));
+    if (dws) CK(hipFree(dws));
+    if (db) CK(hipFree(db));
+    return bad;
+}
+static int compare_all(int B) {
+    int bad = 0;
+    bad += compare_old_new<false, false, EPI_FWD>(B, 1024, 2080, 1, "forward (W transposed)");
+    bad += compare_old_new<false, true, EPI_FWD>(B, 1024, 2080, 1, "forward (W as stored)");
+    bad += compare_old_new<false, false, EPI_FWD>(700, 264, 3120, 1, "forward, ragged");
+    bad += compare_old_new<false, true, EPI_FWD>(300, 200, 96, 1, "forward, short K");
+    bad += compare_old_new<false, false, EPI_FWD>(512, 256, 72, 1, "forward, K tail 8");
+    bad += compare_old_new<false, false, EPI_FWD>(256, 256, 32, 1, "forward, half tile");
+    bad += compare_old_new<false, false, EPI_DGRAD>(B, 2080, 1024, 1, "input gradient");
+    bad += compare_old_new<false, false, EPI_DGRAD>(300, 200, 128, 1, "input gradient, ragged");
+    bad += compare_old_new<true, true, EPI_F32>(B, 2080, 1024, 7, "weight gradient");
+    bad += compare_old_new<true, true, EPI_F32>(1000, 3120, 264, 3, "weight gradient, ragged");
+    bad += compare_old_new<true, true, EPI_F32>(96, 264, 72, 1, "weight gradient, short");
+    return bad;
+}
+
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 16384;
     if (argc > 2 && !strcmp(argv[2], "ablate")) { ablations(B); return 0; }
+    if (argc > 2 && !strcmp(argv[2], "compare")) { return compare_all(B) ? 1 : 0; }
     if (argc > 2 && !strcmp(argv[2], "prof")) {        // one long dispatch for counter passes (clock, LDS conflicts)
         test_fwd(B, 1024, 33280);
         test_dgrad<8>(B, 1024, 33280, false);
