@@ -384,7 +384,8 @@ def _measure(args, world, rank, dev):
     run_steps(args.prime_steps)
     barrier()
     ss_ = getattr(eng, "_step_state", None)
-    stamps_split = bool(args.stamps == "roofline" and ss_ is not None and eng._step_graph is not None)
+    # (one GPU only: with ranks, a rank whose capture failed would run a different number of steps -- and collectives -- than its peers)
+    stamps_split = bool(args.stamps == "roofline" and ss_ is not None and eng._step_graph is not None and world == 1)
     if ss_ is not None and (stamps_split or args.stamps == "never"):
         ss_.set_stamps(False)
     run_steps(args.warmup)
