@@ -376,7 +376,7 @@ int mrec_sparse_lazy_adam_wide_defer(float* p, float* m, float* v, int64_t V, in
  * mrec_apply_finish_t) updates the hot rows: same products, a fixed order of additions (another one than the windows': the sums agree to
  * rounding).  Not armed, the call launches the plain kernel: not an instruction of this path.  (nullptr, nullptr, 0, 0) disarms.
  * Replaces the optimizer-side Unique + UnsortedSegmentSum + LazyAdam / FTRL of those rows (wide_and_deep.py:420-430, 490-492). */
-#define MREC_CONST_COLS_STATE_BYTES 800
+#define MREC_CONST_COLS_STATE_BYTES 2592
 int mrec_const_cols_detect(const void* ids, int32_t id_bytes, int64_t B, int32_t F, int64_t V, int64_t min_count, void* state, void* stream);
 int mrec_sparse_apply_next_const_cols(const void* state, const void* ids, int32_t id_bytes, int64_t B);
 int mrec_dense_adam_slabs_finish_f32(float* p, float* m, float* v, const float* g, void* shadow16, int shadow_kind, int64_t n,

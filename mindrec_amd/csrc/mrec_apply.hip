@@ -1243,7 +1243,7 @@ __global__ void k_step_advance(StepState* s, float lr, float b1, float b2) {
 // whatever the kernels beside this one have dirtied in L2, 17 us per step when it was tried), and that last workgroup turns the
 // survivors into the mask and the ids the apply's kernels read, and clears counters, word and ticket for the next batch: no memset
 // node, no second launch.
-struct ConstState { unsigned long long badmask; unsigned ticket, pad; unsigned long long mask; unsigned long long pad2; long long hid[64]; unsigned cnt[64]; };
+struct ConstState { unsigned long long badmask; unsigned ticket, pad; unsigned long long mask; unsigned long long pad2; long long hid[64]; unsigned cnt[8][64]; };
 static_assert(sizeof(ConstState) == MREC_CONST_COLS_STATE_BYTES, "mrec.h: MREC_CONST_COLS_STATE_BYTES");
 template <class K>
 __global__ __launch_bounds__(256) void k_const_cols(const K* __restrict__ ids, int64_t n, int F, int64_t V, unsigned min_count, ConstState* __restrict__ st) {
@@ -1289,27 +1289,61 @@ __global__ __launch_bounds__(256) void k_const_cols(const K* __restrict__ ids, i
     // in seven.  (First form: a thread walked the flat id list and counted in LDS -- with the bench's Zipf ids every field has a
     // candidate and 40 % of all ids match theirs: 300 k LDS atomics on 39 words, 130 us beside the backward GEMMs.)
     const int nc = __popcll(m);
-    __shared__ unsigned bloom[8];
-    if (t < 8) bloom[t] = 0u;
+    // the candidates as a 128-slot hash set in LDS (id -> its field): "is this id ANOTHER field's candidate?" is one probe for almost
+    // every id.  (A 256-bit filter in front of a loop over the candidates was the form before: some lane of a wave always hit, the
+    // loop -- two dependent LDS reads per candidate -- ran for every id: 118 of that kernel's 133 us on the bench's Zipf ids.)
+    __shared__ unsigned long long hkey[128];
+    __shared__ int hfld[128];
+    if (t < 128) hkey[t] = ~0ull;
     __syncthreads();
     if (t < nc) {
-        const unsigned h = (unsigned)((unsigned long long)c[clist[t]] * 0x9E3779B97F4A7C15ull >> 56);
-        atomicOr(&bloom[h >> 5], 1u << (h & 31));
+        const int f1 = clist[t];
+        const unsigned long long key = (unsigned long long)c[f1];
+        unsigned slot = (unsigned)(key * 0x9E3779B97F4A7C15ull >> 57);
+        for (int it = 0; it < 128; ++it) {
+            const unsigned long long old = atomicCAS(&hkey[slot], ~0ull, key);
+            if (old == ~0ull) { hfld[slot] = f1; break; }
+            if (old == key) break;                            // (two fields, one candidate: both fail below; one entry is enough)
+            slot = (slot + 1u) & 127u;
+        }
     }
     __syncthreads();
+    // (two fields with the SAME candidate fail each other: settled here once, so that the loop below need not ask about an id that is
+    // its own field's candidate -- with the bench's Zipf ids that is 40 % of all ids)
+    if (t < nc) {
+        const int f1 = clist[t];
+        for (int q = 0; q < nc; ++q)
+            if (q != t && c[clist[q]] == c[f1]) atomicOr(&lbad[f1 >> 5], 1u << (f1 & 31));
+    }
     const int f = t & 63, sub = t >> 6;
     if (f < F) {
         const bool mycand = (m >> f) & 1ull;
         const long long cf = c[f];
         unsigned mine = 0u;
-        for (int64_t b = (int64_t)blockIdx.x * 4 + sub; b < B; b += (int64_t)gridDim.x * 4) {
-            const long long id = (long long)ids[b * F + f];
-            mine += (mycand && id == cf) ? 1u : 0u;
-            const unsigned h = (unsigned)((unsigned long long)id * 0x9E3779B97F4A7C15ull >> 56);
-            if ((bloom[h >> 5] >> (h & 31)) & 1u) {
-                for (int q = 0; q < nc; ++q) {
-                    const int f2 = clist[q];
-                    if (f2 != f && id == c[f2] && !((lbad[f2 >> 5] >> (f2 & 31)) & 1u)) atomicOr(&lbad[f2 >> 5], 1u << (f2 & 31));
+        const int64_t step = (int64_t)gridDim.x * 4;
+        for (int64_t b0 = (int64_t)blockIdx.x * 4 + sub; b0 < B; b0 += 4 * step) {
+            long long idv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                     // four samples in flight
+                const int64_t b = b0 + u * step;
+                idv[u] = (long long)ids[(b < B ? b : b0) * F + f];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (b0 + u * step >= B) continue;
+                const long long id = idv[u];
+                if (mycand && id == cf) { ++mine; continue; }
+                if (id < 0) continue;                         // (nobody's candidate: they are rows of the table)
+                unsigned slot = (unsigned)((unsigned long long)id * 0x9E3779B97F4A7C15ull >> 57);
+                for (int it = 0; it < 128; ++it) {
+                    const unsigned long long k = hkey[slot];
+                    if (k == (unsigned long long)id) {
+                        const int f2 = hfld[slot];
+                        if (f2 != f && !((lbad[f2 >> 5] >> (f2 & 31)) & 1u)) atomicOr(&lbad[f2 >> 5], 1u << (f2 & 31));
+                        break;
+                    }
+                    if (k == ~0ull) break;
+                    slot = (slot + 1u) & 127u;
                 }
             }
         }
@@ -1318,7 +1352,9 @@ __global__ __launch_bounds__(256) void k_const_cols(const K* __restrict__ ids, i
     __syncthreads();
     if (t < 64) {
         if (lcnt[t]) {
-            unsigned old = atomicAdd(&st->cnt[t], lcnt[t]);
+            // (eight copies of the counters, a workgroup adds to copy number % 8: atomics on ONE device word serialise at ~270 ns each,
+            // and 256 workgroups adding to 39 words took 70 us of this kernel's 73)
+            unsigned old = atomicAdd(&st->cnt[blockIdx.x & 7u][t], lcnt[t]);
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(old) : : "memory");        // performed before the ticket is taken
         }
         if (t == 0) {
@@ -1334,11 +1370,12 @@ __global__ __launch_bounds__(256) void k_const_cols(const K* __restrict__ ids, i
     __syncthreads();
     if (is_last && t < 64) {
         const unsigned long long b = atomicOr(&st->badmask, 0ull);
-        const unsigned cn = atomicAdd(&st->cnt[t], 0u);
+        unsigned cn = 0u;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) cn += atomicExch(&st->cnt[r][t], 0u);
         const bool hot = ((m >> t) & 1ull) && !((b >> t) & 1ull) && cn >= min_count;
         const unsigned long long keep = __ballot(hot);
         st->hid[t] = hot ? c[t] : -1ll;
-        atomicExch(&st->cnt[t], 0u);
         if (t == 0) {
             st->mask = keep;
             atomicExch(&st->badmask, 0ull);

@@ -372,7 +372,7 @@ class ApplyFinish(C.Structure):      # mrec_apply_finish_t
     _fields_ = [("opaque", C.c_ubyte * 448)]
 
 
-CONST_COLS_STATE_BYTES = 800       # MREC_CONST_COLS_STATE_BYTES
+CONST_COLS_STATE_BYTES = 2592      # MREC_CONST_COLS_STATE_BYTES
 
 
 def const_cols_state(device):

@@ -54,7 +54,7 @@ def test_detection_matches_the_restatement(dev, idt):
     for _ in range(3):                        # (the state is reused batch after batch: the launch's last workgroup clears it)
         got = ops.const_cols_ids(ops.const_cols_detect(tid, V, state))                     # constant columns only
         assert got == _detect_ref(ids, V, B) and sorted(got) == [0, 1, 2, 6, 7, 8, 10, 11, 12]
-        assert (state[:4] == 0).all() and (state[136:] == 0).all()
+        assert (state[:4] == 0).all() and (state[136:] == 0).all()      # (word, ticket and the eight copies of the counters: cleared)
         got = ops.const_cols_ids(ops.const_cols_detect(tid, V, state, min_count=B // 8))   # ... and dominant ids
         assert got == _detect_ref(ids, V, B // 8) and sorted(got) == [0, 1, 2, 3, 6, 7, 8, 10, 11, 12, 20] and got[20] == 3210
     # no hot column at all (same state); samples agree by chance in a field that is not constant; more than 64 fields
