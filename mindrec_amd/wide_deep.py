@@ -491,7 +491,8 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         plan = self.k.sparse_plan(ids)
         self._cc = None
         if (self._const_cols and self._fold_wide and self.cfg.sparse and not self._sharded and not self.cfg.dynamic_embedding and self.hb is None
-                and ids.dim() == 2 and ids.shape[1] <= 64 and ids.dtype == torch.int32 and hasattr(self.k, "const_cols_detect")):
+                and ids.dim() == 2 and ids.shape[1] <= 64 and ids.dtype == torch.int32 and ids.is_contiguous() and ids.shape[0] <= 65536
+                and hasattr(self.k, "const_cols_detect")):
             probing = self.step_count <= 2 and not (self._gpu and torch.cuda.is_current_stream_capturing())
             if probing or self._hot_seen:
                 if self._col_bad is None:
