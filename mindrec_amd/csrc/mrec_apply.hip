@@ -949,19 +949,33 @@ __device__ __forceinline__ void const_finish_body(UpdAdam upd, int64_t V, int64_
     const int col = sub * 4, tcol = wl ? wa.wcol : col;
     const int NG = 4 * gm.G, gi = wave * gm.G + grp;
     const int per = (cc.nlg + NG - 1) / NG;
+    // (the row's number and its state are requested BEFORE the chunk sums, which do not depend on them: two round trips less in a
+    // pass that is nothing but its chain -- inside the dense Adam's launch a round trip is 3-4 us)
+    const int64_t row = (int64_t)cc.hid[f];
+    const bool rok = row >= 0 && row < V;
+    const int64_t roff = (rok ? row : 0) * ld + tcol;
+    Vf<4> st[3];
+    if (active && gi == 0) {
+        if (wl) {
+            vload<false>(st[0], upd.s[0] + roff);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) vload<false>(st[i], upd.s[i] + roff);
+        }
+    }
     Vf<4> acc;
     vzero(acc);
     if (active) {
         const int l0 = gi * per, l1 = (l0 + per < cc.nlg) ? l0 + per : cc.nlg;
-        for (int t0 = l0; t0 < l1; t0 += 8) {
-            Vf<4> x[8];
+        for (int t0 = l0; t0 < l1; t0 += 11) {
+            Vf<4> x[11];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 11; ++q) {
                 const int t = t0 + q < l1 ? t0 + q : l1 - 1;
                 vload<false>(x[q], cc.part + ((int64_t)t * kConstMax + j) * gm.D + col);
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
+            for (int q = 0; q < 11; ++q)
                 if (t0 + q < l1) { if (t0 + q == l0) acc = x[q]; else vadd(acc, x[q]); }
         }
         vstore<false>(cred + gi * gm.D + col, acc);
@@ -974,17 +988,11 @@ __device__ __forceinline__ void const_finish_body(UpdAdam upd, int64_t V, int64_
             vload<false>(x, cred + q * gm.D + col);
             vadd(acc, x);
         }
-        const int64_t row = (int64_t)cc.hid[f];
-        if (row >= 0 && row < V) {
-            const int64_t roff = row * ld + tcol;
-            Vf<4> st[3];
+        if (rok) {
             if (wl) {
-                vload<false>(st[0], upd.s[0] + roff);
                 wide_apply(st[0], acc, wa.h);
                 vstore<false>(upd.s[0] + roff, st[0]);
             } else {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) vload<false>(st[i], upd.s[i] + roff);
                 upd_apply<UpdAdam>(upd, st, acc);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) vstore<false>(upd.s[i] + roff, st[i]);
