@@ -374,8 +374,14 @@ __global__ __launch_bounds__(HB) void k_map_place(MapDev m, const K* __restrict_
     if (w.words[1] == 0) return;                  // no key of this call was missing
     // the row counters as they stood before this call: read by every tile BEFORE it publishes its count, so the last
     // tile -- whose look-back ends only after all others published -- can commit the new values
-    const int64_t hwm0 = m.counters[C_HWM], nfree0 = m.counters[C_FREE];
+    int64_t hwm0 = m.counters[C_HWM], nfree0 = m.counters[C_FREE];
+    // (the two loads have RETURNED before anything below is issued -- what the ordering above needs; a release fence in their place
+    // also wrote back whatever the workgroup's CU had dirtied in L2: MREC_MAP_FENCE=1 keeps it for A/B builds)
+#if defined(MREC_MAP_FENCE) && MREC_MAP_FENCE
     __threadfence();
+#else
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(hwm0), "+v"(nfree0) : : "memory");
+#endif
     const int64_t eff = eff_n(n_max, n_dev);
     const int64_t base = (int64_t)blockIdx.x * HT + threadIdx.x * HI;
     bool first[HI];
@@ -551,8 +557,12 @@ __global__ __launch_bounds__(HB) void k_map_evict(MapDev m, int step, int64_t th
                                                   int64_t* __restrict__ n_evicted, int64_t S) {
     __shared__ int sm[8];
     __shared__ int s_excl;
-    const int64_t nfree0 = m.counters[C_FREE], nlog0 = m.counters[C_NLOG];
+    int64_t nfree0 = m.counters[C_FREE], nlog0 = m.counters[C_NLOG];
+#if defined(MREC_MAP_FENCE) && MREC_MAP_FENCE
     __threadfence();
+#else
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(nfree0), "+v"(nlog0) : : "memory");      // (as k_map_place: returned before anything below is issued)
+#endif
     const int64_t base = (int64_t)blockIdx.x * HT + threadIdx.x * HI;
     bool dead[HI];
     int c = 0;
