@@ -543,6 +543,16 @@ __device__ __forceinline__ void gemm256_body(const Args& a, const int bid, const
                 if (t + 1 < T) MG_KTILE(1, t + 1);
             }
         }
+        if constexpr ((VAR & 64) != 0) {
+            if (l == 0 && a.colsum_ws != nullptr) {          // [workgroup][wave][phase][segment] cycle sums
+#pragma unroll
+                for (int ph = 0; ph < 8; ++ph)
+#pragma unroll
+                    for (int sg = 0; sg < 4; ++sg) a.colsum_ws[((int64_t)bid * 8 + w) * 36 + ph * 4 + sg] = (float)tseg[ph][sg];
+                a.colsum_ws[((int64_t)bid * 8 + w) * 36 + 32] = (float)(__builtin_amdgcn_s_memtime() - tc0);         // shader cycles
+                a.colsum_ws[((int64_t)bid * 8 + w) * 36 + 33] = (float)(__builtin_amdgcn_s_memrealtime() - tr0);     // 100 MHz ticks
+            }
+        }
     } else {
         // ---- 128 x 256 tile: a K-tile is three 16-KB pieces (P, Q cols 0-31, Q cols 32-63 of every wave column) in one of
         // three LDS buffers, and two phases: phase 0 reads P and Q_n0 and stages P, Q_n0 of K-tile t + 2 (into the buffer
