@@ -937,7 +937,10 @@ class WideDeepEngine(DenseNetMixin, ShardStepMixin):
         state = None
         if self._dyn:
             state = self._step_state
-            state.advance(cfg.adam_lr, float(self.beta1), float(self.beta2))       # one thread: powers *= betas, lr_t
+            # (one thread: powers *= betas, lr_t.  Folded into the fused tail's finishing launch -- the last launch in front of it that
+            # reads nothing of the state -- it saved 1.4 us of a 0.626 ms step, three A/B pairs: the gap in front of this launch is the
+            # join's with the plan's branch and stays; not kept -- DESIGN.md section 9)
+            state.advance(cfg.adam_lr, float(self.beta1), float(self.beta2))
 
         if fused:
             # d loss / d Wide_b = sum of dlogit = the output layer's bias gradient, which the head kernel has
