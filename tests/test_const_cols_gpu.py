@@ -149,3 +149,26 @@ def test_apply_without_constant_columns_is_unchanged(dev):
                                    const_cols=(ops.const_cols_detect(tid, V), tid) if cc else None)
         outs.append(st)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_engine_takes_the_constant_columns_path(dev):
+    """The engine end to end on Criteo-shaped batches (39 fields, the 13 dense fields on one id each): the first, eager steps find the
+    constant columns, the captured step and a sink of steps carry the detection launch and the HOT apply kernel; against the same engine
+    with the path off: the same training run to rounding (the constant ids' sums are taken in another fixed order)."""
+    from mindrec_amd import ops
+    from mindrec_amd.wide_deep import WideDeepConfig, WideDeepEngine, synthetic_batch
+    kw = dict(vocab_size=40000, emb_dim=80, field_size=39, batch_size=2048, deep_layer_dim=[128, 64], mlp_dtype="bf16")
+    a = WideDeepEngine(WideDeepConfig(**kw), dev)
+    b = WideDeepEngine(WideDeepConfig(const_columns=False, **kw), dev)
+    assert a._fold_wide and b._fold_wide
+    batches = [synthetic_batch(a.cfg, dev, "zipf", seed=70 + s) for s in range(10)]
+    la = [float(a.train_step(*x)) for x in batches[:6]] + [float(x) for x in a.train_steps(batches[6:])]
+    lb = [float(b.train_step(*x)) for x in batches[:6]] + [float(x) for x in b.train_steps(batches[6:])]
+    assert a._hot_seen and a._cc is not None and not b._hot_seen and getattr(b, "_cc", None) is None
+    assert ops.const_cols_mask(a._cc[0]) == (1 << 13) - 1 and ops.const_cols_ids(a._cc[0]) == {f: f for f in range(13)}
+    assert a._step_graph is not None and any(v for v in a._sink_graphs.values())          # (graphs replayed: the path is inside them)
+    assert la[0] == lb[0]                                                                  # (the first loss: before any update)
+    assert max(abs(x - y) / abs(y) for x, y in zip(la, lb)) <= 1e-4, (la, lb)
+    for x, y in ((a.deep, b.deep), (a.wide, b.wide), (a.dense_flat.detach(), b.dense_flat.detach())):
+        assert float((x - y).abs().max()) <= 2e-4 * float(y.abs().max())
+    assert not torch.equal(a.deep[:13], torch.zeros_like(a.deep[:13]))
