@@ -172,3 +172,17 @@ def test_engine_takes_the_constant_columns_path(dev):
     for x, y in ((a.deep, b.deep), (a.wide, b.wide), (a.dense_flat.detach(), b.dense_flat.detach())):
         assert float((x - y).abs().max()) <= 2e-4 * float(y.abs().max())
     assert not torch.equal(a.deep[:13], torch.zeros_like(a.deep[:13]))
+    # the stream changes under the captured graphs: a batch without a constant column (empty mask: the HOT kernel's windows do all
+    # the work), one whose field 0 moves to field 5's id (that id then sits in two fields: neither is hot), the old shape again
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for kind in ("none", "moved", "same"):
+        ids, wts, label = (t.clone() for t in batches[2])
+        if kind == "none":
+            ids[:, :13] = torch.randint(13, a.cfg.vocab_size, (ids.shape[0], 13), generator=g, dtype=torch.int32).to(dev)
+        elif kind == "moved":
+            ids[:, 0] = 5
+        xa, xb = float(a.train_step(ids, wts, label)), float(b.train_step(ids, wts, label))
+        want = {"none": 0, "moved": ((1 << 13) - 1) & ~0b100001, "same": (1 << 13) - 1}[kind]
+        assert ops.const_cols_mask(a._cc[0]) == want, kind
+        assert abs(xa - xb) <= 1e-4 * abs(xb), (kind, xa, xb)
+    assert float((a.deep - b.deep).abs().max()) <= 2e-4 * float(b.deep.abs().max())
